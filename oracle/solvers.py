@@ -1,0 +1,478 @@
+"""ADMM drivers and problem classes of the reference, restated (TEST INFRASTRUCTURE).
+
+Follows, line by line where arithmetic order matters:
+  FADMMBase::solve            /root/reference/src/FADMMBase.h:185-265
+  ADMMBase::solve/update_rho  /root/reference/src/ADMMBase.h:85-109,158-216
+  ADMMLassoTall               /root/reference/src/ADMMLassoTall.h:55-231
+  ADMMEnetTall / ADMMEnetWide /root/reference/src/ADMMEnet.h:19-154
+  ADMMLassoWide               /root/reference/src/ADMMLassoWide.h:70-251
+  PADMMBase / PADMMLasso      /root/reference/src/PADMMBase.h:57-237, PADMMLasso.h:17-223
+  ADMMLAD                     /root/reference/src/ADMMLAD.h:62-225
+  ADMMBP                      /root/reference/src/ADMMBP.h:48-197
+Sparse vectors of the reference are kept dense here (they are a storage detail:
+every entry the reference leaves out is an exact zero).  float32 where the
+reference uses `float`, float64 scalars where it uses `double`.
+"""
+import numpy as np
+import scipy.linalg as sla
+
+from .spectra import sym_eigs_largest
+
+F = np.float32
+
+
+def _rho_rule(s):
+    """update_rho(): FADMMBase.h:109-133 == ADMMBase.h:85-109."""
+    if s.resid_primal / s.eps_primal > 10 * s.resid_dual / s.eps_dual:
+        s.rho *= 2
+    elif s.resid_dual / s.eps_dual > 10 * s.resid_primal / s.eps_primal:
+        s.rho /= 2
+    if s.resid_primal < s.eps_primal:
+        s.rho /= 1.2
+    if s.resid_dual < s.eps_dual:
+        s.rho *= 1.2
+
+
+def _soft_d(vec, penalty, T):
+    """soft_threshold with a double penalty compared against T entries
+    (ADMMLassoTall.h:55-69, ADMMLassoWide.h:70-84, PADMMLasso.h:83-97, ADMMLAD.h:79-93)."""
+    v = vec.astype(np.float64)
+    out = np.where(v > penalty, v - penalty, np.where(v < -penalty, v + penalty, 0.0))
+    return out.astype(T)
+
+
+def _enet_f(vec, penalty, alpha):
+    """enet(): ADMMEnet.h:24-40 / :67-83 -- thresh and denom are floats."""
+    thresh = F(F(alpha) * penalty)          # Scalar thresh = alpha * penalty (double product -> float)
+    denom = F(1.0 + penalty * (1.0 - np.float64(F(alpha))))
+    v = vec
+    out = np.where(v > thresh, (v - thresh) / denom, np.where(v < -thresh, (v + thresh) / denom, F(0)))
+    return out.astype(F)
+
+
+def _sqnorm(v, T):
+    return T((v * v).sum(dtype=T))
+
+
+class FADMM:
+    """Goldstein fast ADMM with restart; subclasses define next_x/next_z/residual."""
+
+    update_rho_active = True
+
+    def _init_accel(self):
+        self.adj_a = 1.0
+        self.adj_c = 9999.0
+
+    def solve(self, maxit):
+        T = self.T
+        i = 0
+        for i in range(maxit):
+            old_z = self.aux_z.copy()
+            old_y = self.dual_y.copy()
+            # update_x (:185-194): eps from the *current* iterate, then x
+            self.eps_primal = self.compute_eps_primal()
+            self.eps_dual = self.compute_eps_dual()
+            self.main_x = self.next_x()
+            # update_z (:195-202)
+            self.aux_z = self.next_z()
+            self.resid_dual = self.rho * np.sqrt(np.float64(_sqnorm(self.aux_z - old_z, T)))
+            # update_y (:203-211)
+            r = self.next_residual()
+            self.resid_primal = np.float64(T(np.linalg.norm(r)))
+            self.dual_y = (self.adj_y + T(self.rho) * r).astype(T)
+            if self.resid_primal < self.eps_primal and self.resid_dual < self.eps_dual:
+                return i + 1
+            old_c = self.adj_c
+            self.adj_c = (self.rho * self.resid_primal * self.resid_primal
+                          + self.rho * np.float64(_sqnorm(self.aux_z - self.adj_z, T)))
+            if self.adj_c < 0.999 * old_c:
+                old_a = self.adj_a
+                self.adj_a = 0.5 + 0.5 * np.sqrt(1 + 4.0 * old_a * old_a)
+                ratio = (old_a - 1.0) / self.adj_a
+                self.adj_z = (T(1 + ratio) * self.aux_z - T(ratio) * old_z).astype(T)
+                self.adj_y = (T(1 + ratio) * self.dual_y - T(ratio) * old_y).astype(T)
+            else:
+                self.adj_a = 1.0
+                self.adj_z = old_z
+                self.adj_y = old_y
+                self.adj_c = old_c / 0.999
+            if i > 5 and self.update_rho_active:
+                _rho_rule(self)
+        return maxit + 1          # `return i + 1` after the loop ran out (FADMMBase.h:264)
+
+
+class LassoTall(FADMM):
+    T = F
+    update_rho_active = False    # ADMMLassoTall.h:97  void update_rho() {}
+
+    def __init__(self, X, Y, eps_abs, eps_rel, alpha=None):
+        self.X, self.Y = X, Y
+        self.p = X.shape[1]
+        self.eps_abs, self.eps_rel = eps_abs, eps_rel
+        self.XY = (X.T @ Y).astype(F)                       # :172
+        self.lambda0 = F(np.abs(self.XY).max())             # :173
+        self.alpha = alpha
+        if alpha is not None:
+            self.alpha = F(alpha)
+            self.lambda0 = F(self.lambda0 / (np.float64(self.alpha) + 0.0001))   # ADMMEnet.h:56
+        self.info = {}
+
+    def init(self, lam, rho):
+        p = self.p
+        self.main_x = np.zeros(p, F)
+        self.aux_z = np.zeros(p, F)
+        self.dual_y = np.zeros(p, F)
+        self.adj_z = np.zeros(p, F)
+        self.adj_y = np.zeros(p, F)
+        self.lam = F(lam)
+        self.rho = float(rho)
+        XX = (self.X.T @ self.X).astype(F)                  # cross_prod_lower, :191-192
+        if self.rho <= 0:                                   # :194-202
+            ev = sym_eigs_largest(lambda v: XX @ v, p, 3, 10, 0.1, F, self.info)
+            self.lmax_est = ev
+            self.rho = float(np.float64(ev) ** (1.0 / 3) * np.float64(self.lam) ** (2.0 / 3))
+        XX[np.arange(p), np.arange(p)] += F(self.rho)
+        self.chol = sla.cho_factor(XX, lower=True, check_finite=False)   # :204-205
+        self.eps_primal = self.eps_dual = 0.0
+        self.resid_primal = self.resid_dual = 9999.0
+        self._init_accel()
+
+    def init_warm(self, lam):                               # :219-230 (a, c deliberately kept)
+        self.lam = F(lam)
+        self.eps_primal = self.eps_dual = 0.0
+        self.resid_primal = self.resid_dual = 9999.0
+
+    def compute_eps_primal(self):                           # :141-145
+        r = max(np.float64(F(np.linalg.norm(self.main_x))), np.float64(F(np.linalg.norm(self.aux_z))))
+        return r * self.eps_rel + np.sqrt(float(self.p)) * self.eps_abs
+
+    def compute_eps_dual(self):                             # :146-149
+        return np.float64(F(np.linalg.norm(self.dual_y))) * self.eps_rel + np.sqrt(float(self.p)) * self.eps_abs
+
+    def next_x(self):                                       # :70-80
+        rhs = (self.XY - self.adj_y).astype(F)
+        rhs = (rhs.astype(np.float64) + self.rho * self.adj_z.astype(np.float64)).astype(F)
+        return sla.cho_solve(self.chol, rhs, check_finite=False).astype(F)
+
+    def next_z(self):                                       # :81-85 / ADMMEnet.h:41-45
+        vec = (self.main_x + self.adj_y / F(self.rho)).astype(F)
+        pen = np.float64(self.lam) / self.rho
+        if self.alpha is None:
+            return _soft_d(vec, pen, F)
+        return _enet_f(vec, pen, self.alpha)
+
+    def next_residual(self):                                # :86-95
+        return (self.main_x - self.aux_z).astype(F)
+
+    def get_coef(self):
+        return self.aux_z                                   # Lasso.cpp:108 get_z()
+
+
+class ADMMPlain:
+    """ADMMBase::solve, ADMMBase.h:192-216 (used by the wide solver)."""
+
+    def solve(self, maxit):
+        for i in range(maxit):
+            self.eps_primal = self.compute_eps_primal()
+            self.eps_dual = self.compute_eps_dual()
+            self.main_x = self.next_x()
+            newz = self.next_z()
+            self.resid_dual = self.compute_resid_dual(newz)     # before the swap (:167-175)
+            self.aux_z = newz
+            r = self.next_residual()
+            self.resid_primal = np.float64(F(np.linalg.norm(r)))
+            self.dual_y = (self.dual_y + F(self.rho) * r).astype(F)
+            if self.resid_primal < self.eps_primal and self.resid_dual < self.eps_dual:
+                return i + 1
+            if i > 3:
+                _rho_rule(self)
+        return maxit + 1
+
+
+def is_regular_update(x):
+    """4^k - 1 (ADMMLassoWide.h:121-127)."""
+    if x in (0, 3, 15, 63):
+        return True
+    x += 1
+    if x & (x - 1):
+        return False
+    return bool(x & 0x55555555)
+
+
+class LassoWide(ADMMPlain):
+    def __init__(self, X, Y, eps_abs, eps_rel, alpha=None):
+        self.X, self.Y = X, Y
+        self.n, self.p = X.shape
+        self.eps_abs, self.eps_rel = eps_abs, eps_rel
+        self.lambda0 = F(np.abs((X.T @ Y).astype(F)).max())                 # :197
+        XXt = (X @ X.T).astype(F)                                           # tcross_prod_lower :200-201
+        self.info = {}
+        self.sprad = F(sym_eigs_largest(lambda v: XXt @ v, self.n, 3, 10, 0.1, F, self.info))
+        self.alpha = alpha
+        if alpha is not None:
+            self.alpha = F(alpha)
+            self.lambda0 = F(self.lambda0 / (np.float64(self.alpha) + 0.0001))   # ADMMEnet.h:152
+        self.trace_nnz = []
+
+    def init(self, lam, rho):                                               # :215-237
+        self.main_x = np.zeros(self.p, F)
+        self.cache_Ax = np.zeros(self.n, F)
+        self.aux_z = np.zeros(self.n, F)
+        self.dual_y = np.zeros(self.n, F)
+        self.lam = F(lam)
+        self.rho = float(rho)
+        if self.rho <= 0:
+            self.rho = float((np.float64(self.lam) / np.float64(self.sprad)) ** (1.0 / 3))
+        self.eps_primal = self.eps_dual = 0.0
+        self.resid_primal = self.resid_dual = 9999.0
+        self.iter_counter = 0
+
+    def init_warm(self, lam):                                               # :241-251
+        self.lam = F(lam)
+        self.eps_primal = self.eps_dual = 0.0
+        self.resid_primal = self.resid_dual = 9999.0
+        self.iter_counter = 0
+
+    def compute_eps_primal(self):                                           # :174-178
+        r = max(np.float64(F(np.linalg.norm(self.cache_Ax))), np.float64(F(np.linalg.norm(self.aux_z))))
+        return r * self.eps_rel + np.sqrt(float(self.n)) * self.eps_abs
+
+    def compute_eps_dual(self):                                             # :179-182
+        return (np.float64(F(np.sqrt(self.sprad))) * np.float64(F(np.linalg.norm(self.dual_y))) * self.eps_rel
+                + np.sqrt(float(self.p)) * self.eps_abs)
+
+    def compute_resid_dual(self, new_z):                                    # :183-186
+        return self.rho * np.float64(F(np.sqrt(self.sprad))) * np.float64(F(np.linalg.norm(new_z - self.aux_z)))
+
+    def _prox(self, v, penalty_d):
+        if self.alpha is None:
+            return _soft_d(v, penalty_d, F)
+        return _enet_f(v, penalty_d, self.alpha)
+
+    def _active_set_update(self):                                           # :86-118 / ADMMEnet.h:85-122
+        gamma = self.sprad
+        penalty = F(np.float64(self.lam) / (self.rho * np.float64(gamma)))  # Scalar penalty (float)
+        tmp = ((self.cache_Ax + self.aux_z + self.dual_y / F(self.rho)) / gamma).astype(F)
+        res = self.main_x.copy()
+        idx = np.nonzero(res)[0]
+        if idx.size:
+            val = (res[idx] - (self.X[:, idx].T @ tmp).astype(F)).astype(F)
+            if self.alpha is None:
+                new = np.where(val > penalty, val - penalty, np.where(val < -penalty, val + penalty, F(0)))
+            else:
+                thresh = F(self.alpha * penalty)
+                denom = F(1.0 + np.float64(penalty) * (1.0 - np.float64(self.alpha)))
+                new = np.where(val > thresh, (val - thresh) / denom,
+                               np.where(val < -thresh, (val + thresh) / denom, F(0)))
+            res[idx] = new.astype(F)
+        return res
+
+    def _regular_update(self):                                              # :141-150
+        gamma = self.sprad
+        tmp = (self.cache_Ax + self.aux_z + self.dual_y / F(self.rho)).astype(F)
+        vec = (-(self.X.T @ tmp).astype(F) / gamma).astype(F)
+        vec = (vec + self.main_x).astype(F)
+        return self._prox(vec, np.float64(self.lam) / (self.rho * np.float64(gamma)))
+
+    def next_x(self):
+        if self.alpha is None:                                              # ADMMLassoWide.h:129-155
+            if np.float64(self.lam) > np.float64(self.lambda0) - 1e-5:
+                return np.zeros(self.p, F)
+            if is_regular_update(self.iter_counter):
+                res = self._regular_update()
+            else:
+                res = self._active_set_update()
+        else:                                                               # ADMMEnet.h:124-141
+            if is_regular_update(self.iter_counter) and self.lam < self.lambda0:
+                res = self._regular_update()
+            else:
+                res = self._active_set_update()
+        self.iter_counter += 1
+        self.trace_nnz.append(int(np.count_nonzero(res)))
+        return res
+
+    def next_z(self):                                                       # :156-165
+        idx = np.nonzero(self.main_x)[0]
+        self.cache_Ax = (self.X[:, idx] @ self.main_x[idx]).astype(F) if idx.size else np.zeros(self.n, F)
+        return ((self.Y + self.dual_y + F(self.rho) * self.cache_Ax) / F(-1 - self.rho)).astype(F)
+
+    def next_residual(self):                                                # :166-170
+        return (self.cache_Ax + self.aux_z).astype(F)
+
+    def get_coef(self):
+        return self.main_x                                                  # Lasso.cpp:119 get_x()
+
+
+class PADMMLasso:
+    """Row-block consensus ADMM: PADMMBase_Master/Worker + PADMMLasso_*."""
+
+    def __init__(self, X, Y, K, eps_abs, eps_rel):
+        n, p = X.shape
+        self.K, self.p = K, p
+        self.eps_abs, self.eps_rel = eps_abs, eps_rel
+        self.lambda0 = np.float64(F(np.abs((X.T @ Y).astype(F)).max()))     # PADMMLasso.h:161
+        chunk = n // K                                                      # :163-179
+        self.A, self.b = [], []
+        for i in range(K):
+            lo = i * chunk
+            hi = (i + 1) * chunk if i < K - 1 else n
+            self.A.append(np.ascontiguousarray(X[lo:hi]))
+            self.b.append(Y[lo:hi].copy())
+        self.Ab = [(A.T @ b).astype(F) for A, b in zip(self.A, self.b)]    # worker ctor :42
+
+    def init(self, lam, rho):                                               # :193-212
+        p, K = self.p, self.K
+        self.aux_z = np.zeros(p, F)
+        self.lam = float(lam)
+        self.rho = float(rho)
+        if self.rho <= 0:
+            self.rho = self.lam / K
+        self.x = [np.zeros(p, F) for _ in range(K)]
+        self.y = [np.zeros(p, F) for _ in range(K)]
+        self.chol = []
+        for A in self.A:                                                    # worker init :48-63
+            AA = (A.T @ A if A.shape[0] >= A.shape[1] else A @ A.T).astype(F)
+            m = AA.shape[0]
+            AA[np.arange(m), np.arange(m)] += F(self.rho)
+            self.chol.append(sla.cho_factor(AA, lower=True, check_finite=False))
+        self.sq_r = [0.0] * K
+
+    def init_warm(self, lam):                                               # :215-223
+        self.lam = float(lam)
+
+    def solve(self, maxit):                                                 # PADMMBase.h:222-237
+        K, p = self.K, self.p
+        for it in range(maxit):
+            # update_x (:174-188)
+            xn = sum(np.float64(_sqnorm(x, F)) for x in self.x)
+            eps_primal = (max(np.sqrt(xn), np.float64(F(np.linalg.norm(self.aux_z))) * np.sqrt(K)) * self.eps_rel
+                          + np.sqrt(float(p * K)) * self.eps_abs)
+            yn = sum(np.float64(_sqnorm(y, F)) for y in self.y)
+            eps_dual = np.sqrt(yn) * self.eps_rel + np.sqrt(float(p * K)) * self.eps_abs
+            for k in range(K):                                              # worker next_x PADMMLasso.h:17-31
+                A = self.A[k]
+                rhs = (self.Ab[k] - self.y[k]).astype(F)
+                rhs = (rhs.astype(np.float64) + self.rho * self.aux_z.astype(np.float64)).astype(F)
+                if A.shape[0] >= A.shape[1]:
+                    self.x[k] = sla.cho_solve(self.chol[k], rhs, check_finite=False).astype(F)
+                else:
+                    t = (A @ rhs).astype(F)
+                    s = sla.cho_solve(self.chol[k], t, check_finite=False).astype(F)
+                    self.x[k] = ((rhs - (A.T @ s).astype(F)) / F(self.rho)).astype(F)
+            # update_z (:190-198), master next_z PADMMLasso.h:99-108
+            vec = np.zeros(p, F)
+            for k in range(K):
+                vec = (vec + (self.x[k] + self.y[k] / F(self.rho))).astype(F)
+            vec = (vec / F(K)).astype(F)
+            newz = _soft_d(vec, self.lam / (self.rho * K), F)
+            resid_dual = self.rho * np.sqrt(K * np.float64(_sqnorm(newz - self.aux_z, F)))   # :149-152
+            self.aux_z = newz
+            # update_y (:200-214)
+            coll = 0.0
+            for k in range(K):
+                r = (self.x[k] - self.aux_z).astype(F)
+                coll += np.float64(_sqnorm(r, F))
+                self.y[k] = (self.y[k] + F(self.rho) * r).astype(F)
+            resid_primal = np.sqrt(coll)
+            if resid_primal < eps_primal and resid_dual < eps_dual:
+                return it + 1
+        return maxit + 1
+
+    def get_coef(self):
+        return self.aux_z
+
+
+class LAD(FADMM):
+    T = np.float64
+
+    def __init__(self, X, Y, rho, eps_abs, eps_rel):
+        self.X, self.Y = X, Y
+        self.n, self.p = X.shape
+        self.eps_abs, self.eps_rel = eps_abs, eps_rel
+        self.ynorm = float(np.linalg.norm(Y))
+        XX = X.T @ X                                                        # ADMMLAD.h:186-189
+        self.chol = sla.cho_factor(XX, lower=True, check_finite=False)
+        self.H = None
+        if self.n <= 2000:                                                  # :191-203
+            L = np.tril(self.chol[0])
+            Tm = sla.solve_triangular(L, X.T, lower=True, check_finite=False).T   # T L' = X
+            self.H = Tm @ Tm.T
+        n = self.n
+        self.main_x = np.zeros(n)
+        self.aux_z = np.zeros(n)
+        self.dual_y = np.zeros(n)
+        self.adj_z = np.zeros(n)
+        self.adj_y = np.zeros(n)
+        self.rho = float(rho)
+        self.eps_primal = self.eps_dual = 0.0
+        self.resid_primal = self.resid_dual = 9999.0
+        self._init_accel()
+
+    def compute_eps_primal(self):                                           # :152-157
+        r = max(np.linalg.norm(self.main_x), np.linalg.norm(self.aux_z), self.ynorm)
+        return r * self.eps_rel + np.sqrt(float(self.n)) * self.eps_abs
+
+    def compute_eps_dual(self):                                             # :158-161
+        return np.linalg.norm(self.dual_y) * self.eps_rel + np.sqrt(float(self.n)) * self.eps_abs
+
+    def next_x(self):                                                       # :62-78
+        vec = self.Y - self.adj_y / self.rho + self.adj_z
+        if self.H is not None:
+            return self.H @ vec
+        return self.X @ sla.cho_solve(self.chol, self.X.T @ vec, check_finite=False)
+
+    def next_z(self):                                                       # :94-98
+        vec = self.main_x - self.Y + self.adj_y / self.rho
+        return _soft_d(vec, 1.0 / self.rho, np.float64)
+
+    def next_residual(self):                                                # :99-107
+        return self.main_x - self.Y - self.aux_z
+
+    def get_coef(self):                                                     # get_x :220-225
+        vec = self.Y - self.adj_y / self.rho + self.adj_z
+        return sla.cho_solve(self.chol, self.X.T @ vec, check_finite=False)
+
+
+class BP(FADMM):
+    T = np.float64
+
+    def __init__(self, A, b, rho, eps_abs, eps_rel):
+        self.A = A
+        self.n, self.p = A.shape
+        self.eps_abs, self.eps_rel = eps_abs, eps_rel
+        AAt = A @ A.T                                                       # ADMMBP.h:167-170
+        chol = sla.cho_factor(AAt, lower=True, check_finite=False)
+        self.cache_AAAb = A.T @ sla.cho_solve(chol, b, check_finite=False)
+        L = np.tril(chol[0])
+        self.LinvA = sla.solve_triangular(L, A, lower=True, check_finite=False)   # :173-182
+        p = self.p
+        self.main_x = np.zeros(p)
+        self.aux_z = np.zeros(p)
+        self.dual_y = np.zeros(p)
+        self.adj_z = np.zeros(p)
+        self.adj_y = np.zeros(p)
+        self.rho = float(rho)
+        self.eps_primal = self.eps_dual = 0.0
+        self.resid_primal = self.resid_dual = 9999.0
+        self._init_accel()
+
+    def compute_eps_primal(self):                                           # :138-142
+        r = max(np.linalg.norm(self.main_x), np.linalg.norm(self.aux_z))
+        return r * self.eps_rel + np.sqrt(float(self.p)) * self.eps_abs
+
+    def compute_eps_dual(self):                                             # :143-146
+        return np.linalg.norm(self.dual_y) * self.eps_rel + np.sqrt(float(self.p)) * self.eps_abs
+
+    def next_x(self):                                                       # :48-67
+        vec = -self.adj_y / self.rho + self.adj_z
+        res = vec + self.cache_AAAb
+        return res - self.LinvA.T @ (self.LinvA @ vec)
+
+    def next_z(self):                                                       # :84-88
+        return _soft_d(self.main_x + self.adj_y / self.rho, 1.0 / self.rho, np.float64)
+
+    def next_residual(self):                                                # :89-93
+        return self.main_x - self.aux_z
+
+    def get_coef(self):
+        return self.aux_z                                                   # BP.cpp:40 get_z()
