@@ -1,0 +1,112 @@
+"""ctypes binding of libadmm_hip.so (the C ABI declared in include/admm_hip.h).
+
+The library is built in-tree by `python -m admm_amd.build` (hipcc, gfx950).  There is no CPU
+fallback: if the shared object is missing or no HIP device is usable, calls raise.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libadmm_hip.so")
+
+ADMM_MEM_HOST = 0
+ADMM_MEM_DEVICE = 1
+
+
+class AdmmOpts(ctypes.Structure):
+    _fields_ = [("maxit", ctypes.c_int), ("eps_abs", ctypes.c_double),
+                ("eps_rel", ctypes.c_double), ("rho", ctypes.c_double)]
+
+
+class AdmmStats(ctypes.Structure):
+    _fields_ = [("t_h2d", ctypes.c_double), ("t_standardize", ctypes.c_double), ("t_gram", ctypes.c_double),
+                ("t_eigs", ctypes.c_double), ("t_factor", ctypes.c_double), ("t_loop", ctypes.c_double),
+                ("t_total", ctypes.c_double), ("loop_ms_events", ctypes.c_double),
+                ("xupdate_ms_avg", ctypes.c_double), ("xupdate_samples", ctypes.c_longlong),
+                ("total_iter", ctypes.c_longlong), ("xupdate_launches", ctypes.c_longlong),
+                ("rho", ctypes.c_double), ("eig_est", ctypes.c_double),
+                ("branch", ctypes.c_int), ("reserved", ctypes.c_int)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class AdmmHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libadmm_hip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+_DP = ctypes.c_void_p      # raw pointers: host numpy buffers or device addresses
+_c_double_p = ctypes.POINTER(ctypes.c_double)
+_c_float_p = ctypes.POINTER(ctypes.c_float)
+_c_int_p = ctypes.POINTER(ctypes.c_int)
+
+# every symbol include/admm_hip.h declares
+EXPORTS = ["admm_hip_lasso", "admm_hip_enet", "admm_hip_parlasso", "admm_hip_lad", "admm_hip_bp",
+           "admm_hip_last_error", "admm_hip_version", "admm_hip_device_count", "admm_hip_set_device",
+           "admm_hip_device_synchronize", "admm_hip_lasso_plan_create", "admm_hip_lasso_plan_run",
+           "admm_hip_lasso_plan_destroy"]
+
+
+def load():
+    """Load the shared library (once). Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(
+            f"{LIB_PATH} not found: build it with `python -m admm_amd.build` (hipcc --offload-arch=gfx950). "
+            "admm_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    lasso_args = [_DP, _DP, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                  _DP, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int]
+    tail = [ctypes.POINTER(AdmmOpts), _c_double_p, _c_float_p, _c_int_p, ctypes.POINTER(AdmmStats)]
+    lib.admm_hip_lasso.argtypes = lasso_args + tail
+    lib.admm_hip_enet.argtypes = lasso_args + [ctypes.c_double] + tail
+    lib.admm_hip_parlasso.argtypes = lasso_args + [ctypes.c_int] + tail
+    lib.admm_hip_lad.argtypes = [_DP, _DP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                 ctypes.POINTER(AdmmOpts), _c_double_p, _c_int_p, ctypes.POINTER(AdmmStats)]
+    lib.admm_hip_bp.argtypes = [_DP, _DP, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                ctypes.POINTER(AdmmOpts), _c_double_p, _c_int_p, ctypes.POINTER(AdmmStats)]
+    for name in ("admm_hip_lasso", "admm_hip_enet", "admm_hip_parlasso", "admm_hip_lad", "admm_hip_bp",
+                 "admm_hip_device_count", "admm_hip_set_device", "admm_hip_device_synchronize"):
+        getattr(lib, name).restype = ctypes.c_int
+    lib.admm_hip_set_device.argtypes = [ctypes.c_int]
+    lib.admm_hip_last_error.restype = ctypes.c_char_p
+    lib.admm_hip_version.restype = ctypes.c_char_p
+    lib.admm_hip_lasso_plan_create.argtypes = lasso_args + [ctypes.c_double, ctypes.c_int, ctypes.POINTER(AdmmOpts),
+                                               ctypes.POINTER(ctypes.c_void_p), _c_int_p]
+    lib.admm_hip_lasso_plan_create.restype = ctypes.c_int
+    lib.admm_hip_lasso_plan_run.argtypes = [ctypes.c_void_p, _c_double_p, _c_float_p, _c_int_p, ctypes.POINTER(AdmmStats)]
+    lib.admm_hip_lasso_plan_run.restype = ctypes.c_int
+    lib.admm_hip_lasso_plan_destroy.argtypes = [ctypes.c_void_p]
+    lib.admm_hip_lasso_plan_destroy.restype = ctypes.c_int
+    lib.admm_hip_host_lanczos.argtypes = [_c_float_p, ctypes.c_int, _c_float_p, _c_int_p]
+    lib.admm_hip_host_lanczos.restype = ctypes.c_int
+    _lib = lib
+    return lib
+
+
+def check(code):
+    if code != 0:
+        raise AdmmHipError(code, load().admm_hip_last_error().decode())
+
+
+class DevicePtr:
+    """A raw device address (e.g. torch_tensor.data_ptr()) of column-major float64 data."""
+
+    def __init__(self, ptr):
+        self.ptr = int(ptr)
+
+
+def as_input(a, n=None, p=None):
+    """Return (c_void_p, mem, keepalive) for a host array (copied to column-major float64) or a DevicePtr."""
+    if isinstance(a, DevicePtr):
+        return ctypes.c_void_p(a.ptr), ADMM_MEM_DEVICE, a
+    arr = np.asfortranarray(np.asarray(a, dtype=np.float64))
+    return ctypes.c_void_p(arr.ctypes.data), ADMM_MEM_HOST, arr

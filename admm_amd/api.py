@@ -1,0 +1,322 @@
+"""Host-side mirror of the reference's R interface for the GPU path.
+
+R is not available in this image, so the builder chain of the package is mirrored in Python with
+the same names, argument meaning, defaults and error behaviour:
+
+    admm_lasso(x, y)$penalty(...)$parallel(...)$opts(...)$fit()     R/30_admm_lasso.R
+    admm_enet(x, y)$penalty(..., alpha)$opts(...)$fit()             R/40_admm_enet.R
+    admm_lad(x, y, intercept)$opts(...)$fit()                       R/20_admm_lad.R
+    admm_bp(x, y)$opts(...)$fit()                                   R/10_admm_bp.R
+
+`fit()` forwards to the C ABI of libadmm_hip.so exactly where the R `$fit()` does its
+`.Call("admm_*", ...)` (R/30_admm_lasso.R:136-160 etc.).  All numerics run in the HIP library;
+nothing here computes.  x may be a host array or a `DevicePtr` (column-major float64 in HBM).
+"""
+import ctypes
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _lib
+from ._lib import AdmmOpts, AdmmStats, DevicePtr, as_input, check
+
+
+def _stop(msg):
+    raise ValueError(msg)
+
+
+def _shape(x, n, p):
+    if isinstance(x, DevicePtr):
+        if n is None or p is None:
+            _stop("n and p are required with a DevicePtr")
+        return int(n), int(p)
+    a = np.asarray(x)
+    if a.ndim != 2:
+        _stop("x must be a matrix")
+    return a.shape
+
+
+def _beta_to_csc(beta_dense):
+    """(p+1) x nlambda dense -> CSC holding row 0 always plus the non-zeros (Lasso.cpp:22-30)."""
+    p1, nl = beta_dense.shape
+    indptr = [0]
+    indices, data = [], []
+    for j in range(nl):
+        col = beta_dense[:, j]
+        nz = np.nonzero(col[1:])[0] + 1
+        idx = np.concatenate([[0], nz])
+        indices.append(idx)
+        data.append(col[idx].astype(np.float64))
+        indptr.append(indptr[-1] + idx.size)
+    return sp.csc_matrix((np.concatenate(data), np.concatenate(indices), np.array(indptr)), shape=(p1, nl))
+
+
+class ADMM_Lasso_fit:
+    """Fields lambda, beta (dgCMatrix-like CSC, (p+1) x nlambda), niter (R/30_admm_lasso.R:18-22)."""
+
+    def __init__(self, lam, beta_dense, niter, stats):
+        self.lambda_ = lam
+        self.beta_dense = beta_dense
+        self.beta = _beta_to_csc(beta_dense)
+        self.niter = niter
+        self.stats = stats
+
+    def __repr__(self):
+        return (f"ADMM Lasso fitting result\n\n$lambda\n{self.lambda_}\n\n$beta\n<{self.beta.shape[0]} x "
+                f"{self.beta.shape[1]}> sparse matrix\n\n$niter\n{self.niter}")
+
+
+class ADMM_Lasso:
+    _name = "ADMM Lasso model"
+
+    def __init__(self, x, y, intercept=True, standardize=True, n=None, p=None):
+        n_, p_ = _shape(x, n, p)
+        ylen = n_ if isinstance(y, DevicePtr) else len(y)
+        if n_ != ylen:
+            _stop("nrow(x) should be equal to length(y)")                       # R/30_admm_lasso.R:34-35
+        self.x, self.y, self.n, self.p = x, y, int(n_), int(p_)
+        self.intercept = bool(intercept)
+        self.standardize = bool(standardize)
+        self.lambda_ = np.zeros(0)
+        self.nlambda = 100
+        self.lambda_min_ratio = 0.01 if n_ < p_ else 0.0001
+        self.nthread = 1
+        self.maxit = 10000
+        self.eps_abs = 1e-5
+        self.eps_rel = 1e-5
+        self.rho = -1.0
+
+    def penalty(self, lambda_=None, nlambda=100, lambda_min_ratio=None, **kw):
+        if "lambda" in kw:
+            lambda_ = kw["lambda"]
+        lam = np.sort(np.atleast_1d(np.asarray(lambda_, dtype=np.float64)))[::-1] if lambda_ is not None else np.zeros(0)
+        if np.any(lam <= 0):
+            _stop("lambda must be positive")
+        if nlambda <= 0:
+            _stop("nlambda must be a positive integer")
+        lmr = (0.01 if self.n < self.p else 0.0001) if lambda_min_ratio is None else float(lambda_min_ratio)
+        if lmr >= 1 or lmr <= 0:
+            _stop("lambda_min_ratio must be within (0, 1)")
+        self.lambda_ = lam
+        self.nlambda = int(nlambda)
+        self.lambda_min_ratio = lmr
+        return self
+
+    def parallel(self, nthread=2):
+        nt = int(nthread)
+        if nt < 1:
+            nt = 1
+        if nt >= self.p / 5:
+            _stop("nthread cannot exceed ncol(x)/5")                             # R/30_admm_lasso.R:105-106
+        self.nthread = nt
+        return self
+
+    def opts(self, maxit=10000, eps_abs=1e-5, eps_rel=1e-5, rho=None):
+        if maxit <= 0:
+            _stop("maxit should be positive")
+        if eps_abs < 0 or eps_rel < 0:
+            _stop("eps_abs and eps_rel should be nonnegative")
+        if rho is not None and rho <= 0:
+            _stop("rho should be positive")
+        self.maxit = int(maxit)
+        self.eps_abs = float(eps_abs)
+        self.eps_rel = float(eps_rel)
+        self.rho = -1.0 if rho is None else float(rho)
+        return self
+
+    # -- .Call marshalling
+    def _common(self):
+        lib = _lib.load()
+        xp, xmem, xk = as_input(self.x)
+        yp, ymem, yk = as_input(self.y)
+        if xmem != ymem:
+            _stop("x and y must live in the same memory space")
+        nl = self.lambda_.size if self.lambda_.size else self.nlambda
+        lam_in = np.ascontiguousarray(self.lambda_, dtype=np.float64)
+        o = AdmmOpts(self.maxit, self.eps_abs, self.eps_rel, self.rho)
+        lam_out = np.zeros(nl, dtype=np.float64)
+        beta = np.zeros((self.p + 1, nl), dtype=np.float32, order="F")
+        niter = np.zeros(nl, dtype=np.int32)
+        stats = AdmmStats()
+        head = (xp, yp, self.n, self.p, xmem,
+                ctypes.c_void_p(lam_in.ctypes.data if lam_in.size else 0), int(lam_in.size), self.nlambda,
+                self.lambda_min_ratio, int(self.standardize), int(self.intercept))
+        tail = (ctypes.byref(o), lam_out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                beta.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                niter.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), ctypes.byref(stats))
+        keep = (xk, yk, lam_in)
+        return lib, head, tail, lam_out, beta, niter, stats, keep
+
+    def fit(self):
+        lib, head, tail, lam_out, beta, niter, stats, keep = self._common()
+        if self.nthread <= 1:
+            check(lib.admm_hip_lasso(*head, *tail))                              # .Call("admm_lasso", ...)
+        else:
+            check(lib.admm_hip_parlasso(*head, self.nthread, *tail))             # .Call("admm_parlasso", ...)
+        return ADMM_Lasso_fit(lam_out, beta, niter, stats.as_dict())
+
+
+class ADMM_Enet(ADMM_Lasso):
+    _name = "ADMM Elastic Net model"
+
+    def __init__(self, x, y, intercept=True, standardize=True, n=None, p=None):
+        super().__init__(x, y, intercept, standardize, n, p)
+        self.alpha = 1.0
+
+    def penalty(self, lambda_=None, nlambda=100, lambda_min_ratio=None, alpha=1, **kw):
+        super().penalty(lambda_, nlambda, lambda_min_ratio, **kw)
+        if alpha < 0 or alpha > 1:
+            _stop("alpha must be within [0, 1]")                                 # R/40_admm_enet.R:38-39
+        self.alpha = float(alpha)
+        return self
+
+    def fit(self):
+        lib, head, tail, lam_out, beta, niter, stats, keep = self._common()
+        check(lib.admm_hip_enet(*head, self.alpha, *tail))                       # .Call("admm_enet", ...)
+        return ADMM_Lasso_fit(lam_out, beta, niter, stats.as_dict())
+
+
+class ADMM_BP_fit:
+    def __init__(self, beta, niter, stats):
+        self.beta = beta
+        self.niter = niter
+        self.stats = stats
+
+
+class ADMM_BP:
+    def __init__(self, x, y, n=None, p=None):
+        n_, p_ = _shape(x, n, p)
+        if n_ >= p_:
+            _stop("ncol(x) must be greater than nrow(x)")                        # R/10_admm_bp.R:30-31
+        ylen = n_ if isinstance(y, DevicePtr) else len(y)
+        if n_ != ylen:
+            _stop("nrow(x) should be equal to length(y)")
+        self.x, self.y, self.n, self.p = x, y, int(n_), int(p_)
+        self.nthread = 1
+        self.maxit = 10000
+        self.eps_abs = 1e-4
+        self.eps_rel = 1e-4
+        self.rho = 1.0
+
+    def opts(self, maxit=10000, eps_abs=1e-4, eps_rel=1e-4, rho=1.0):
+        if maxit <= 0:
+            _stop("maxit should be positive")
+        if eps_abs < 0 or eps_rel < 0:
+            _stop("eps_abs and eps_rel should be nonnegative")
+        if rho is not None and rho <= 0:
+            _stop("rho should be positive")
+        self.maxit, self.eps_abs, self.eps_rel = int(maxit), float(eps_abs), float(eps_rel)
+        self.rho = 1.0 if rho is None else float(rho)
+        return self
+
+    def fit(self):
+        lib = _lib.load()
+        xp, xmem, xk = as_input(self.x)
+        yp, ymem, yk = as_input(self.y)
+        o = AdmmOpts(self.maxit, self.eps_abs, self.eps_rel, self.rho)
+        beta = np.zeros(self.p, dtype=np.float64)
+        niter = np.zeros(1, dtype=np.int32)
+        stats = AdmmStats()
+        check(lib.admm_hip_bp(xp, yp, self.n, self.p, xmem, ctypes.byref(o),
+                              beta.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                              niter.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), ctypes.byref(stats)))
+        return ADMM_BP_fit(sp.csc_matrix(beta.reshape(-1, 1)), int(niter[0]), stats.as_dict())   # dgCMatrix p x 1 (BP.cpp:38-43)
+
+
+class ADMM_LAD_fit:
+    def __init__(self, beta, niter, stats):
+        self.beta = beta            # numeric p+1, intercept first (LAD.cpp:40-45)
+        self.niter = niter
+        self.stats = stats
+
+
+class ADMM_LAD(ADMM_BP):
+    def __init__(self, x, y, intercept=True, n=None, p=None):
+        n_, p_ = _shape(x, n, p)
+        if n_ <= p_:
+            _stop("nrow(x) must be greater than ncol(x)")                        # R/20_admm_lad.R:21-22
+        ylen = n_ if isinstance(y, DevicePtr) else len(y)
+        if n_ != ylen:
+            _stop("nrow(x) should be equal to length(y)")
+        self.x, self.y, self.n, self.p = x, y, int(n_), int(p_)
+        self.maxit = 10000
+        self.eps_abs = 1e-4
+        self.eps_rel = 1e-4
+        self.rho = 1.0
+        self.intercept = bool(intercept)
+
+    def fit(self):
+        lib = _lib.load()
+        xp, xmem, xk = as_input(self.x)
+        yp, ymem, yk = as_input(self.y)
+        o = AdmmOpts(self.maxit, self.eps_abs, self.eps_rel, self.rho)
+        beta = np.zeros(self.p + 1, dtype=np.float64)
+        niter = np.zeros(1, dtype=np.int32)
+        stats = AdmmStats()
+        check(lib.admm_hip_lad(xp, yp, self.n, self.p, xmem, int(self.intercept), ctypes.byref(o),
+                               beta.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                               niter.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), ctypes.byref(stats)))
+        return ADMM_LAD_fit(beta, int(niter[0]), stats.as_dict())
+
+
+class LassoPlan:
+    """Prepared problem (admm_hip_lasso_plan_*): setup once, run the lambda path repeatedly.
+
+    Built from a configured ADMM_Lasso / ADMM_Enet object; used by bench.py to time the ADMM
+    loop without the one-time Gram/factorisation."""
+
+    def __init__(self, model):
+        lib = _lib.load()
+        self._lib = lib
+        self.model = model
+        xp, xmem, xk = as_input(model.x)
+        yp, ymem, yk = as_input(model.y)
+        lam_in = np.ascontiguousarray(model.lambda_, dtype=np.float64)
+        o = AdmmOpts(model.maxit, model.eps_abs, model.eps_rel, model.rho)
+        alpha = float(model.alpha) if isinstance(model, ADMM_Enet) else -1.0
+        h = ctypes.c_void_p()
+        nl = ctypes.c_int()
+        check(lib.admm_hip_lasso_plan_create(
+            xp, yp, model.n, model.p, xmem, ctypes.c_void_p(lam_in.ctypes.data if lam_in.size else 0), int(lam_in.size),
+            model.nlambda, model.lambda_min_ratio, int(model.standardize), int(model.intercept), alpha,
+            int(model.nthread), ctypes.byref(o), ctypes.byref(h), ctypes.byref(nl)))
+        self._h = h
+        self.nlambda = nl.value
+
+    def run(self):
+        m = self.model
+        lam_out = np.zeros(self.nlambda, dtype=np.float64)
+        beta = np.zeros((m.p + 1, self.nlambda), dtype=np.float32, order="F")
+        niter = np.zeros(self.nlambda, dtype=np.int32)
+        stats = AdmmStats()
+        check(self._lib.admm_hip_lasso_plan_run(self._h, lam_out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                                beta.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                                                niter.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), ctypes.byref(stats)))
+        return ADMM_Lasso_fit(lam_out, beta, niter, stats.as_dict())
+
+    def close(self):
+        if self._h:
+            check(self._lib.admm_hip_lasso_plan_destroy(self._h))
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def admm_lasso(x, y, intercept=True, standardize=True, **kw):
+    return ADMM_Lasso(x, y, intercept, standardize, **kw)
+
+
+def admm_enet(x, y, intercept=True, standardize=True, **kw):
+    return ADMM_Enet(x, y, intercept, standardize, **kw)
+
+
+def admm_lad(x, y, intercept=True, **kw):
+    return ADMM_LAD(x, y, intercept, **kw)
+
+
+def admm_bp(x, y, **kw):
+    return ADMM_BP(x, y, **kw)

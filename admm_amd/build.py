@@ -1,0 +1,72 @@
+"""Build libadmm_hip.so in-tree with hipcc for gfx950 (no cmake, no JIT cache).
+
+Usage: python -m admm_amd.build [--force]
+Each .hip translation unit is compiled to an object under admm_amd/csrc/_obj (only when stale)
+and linked against rocBLAS / rocSOLVER / RCCL from /opt/rocm into admm_amd/lib/libadmm_hip.so.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libadmm_hip.so")
+ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
+HIPCC = os.path.join(ROCM, "bin", "hipcc")
+ARCH = "gfx950"
+CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
+            "-Wno-unused-result", f"-I{os.path.join(ROCM, 'include')}"]
+LDFLAGS = ["-shared", "-fPIC", f"--offload-arch={ARCH}", f"-L{os.path.join(ROCM, 'lib')}",
+           "-lrocblas", "-lrocsolver", "-lrccl", f"-Wl,-rpath,{os.path.join(ROCM, 'lib')}"]
+
+
+def _sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _newest_header():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hs.append(os.path.join(HERE, "..", "include", "admm_hip.h"))
+    return max(os.path.getmtime(h) for h in hs)
+
+
+def _compile(src, force):
+    obj = os.path.join(OBJ, src[:-4] + ".o")
+    srcp = os.path.join(CSRC, src)
+    if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(srcp)
+            and os.path.getmtime(obj) >= _newest_header()):
+        return obj, False
+    cmd = [HIPCC] + CXXFLAGS + ["-c", srcp, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+    return obj, True
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(LIBDIR, exist_ok=True)
+    srcs = _sources()
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        results = list(ex.map(lambda s: _compile(s, force), srcs))
+    objs = [o for o, _ in results]
+    rebuilt = any(c for _, c in results)
+    if rebuilt or not os.path.exists(LIB):
+        cmd = [HIPCC] + objs + LDFLAGS + ["-o", LIB]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        if verbose:
+            print(f"[admm_amd.build] linked {LIB} ({len(objs)} objects)")
+    elif verbose:
+        print(f"[admm_amd.build] up to date: {LIB}")
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,98 @@
+// Internal helpers shared by the translation units of libadmm_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+#include <cstring>
+#include <cmath>
+#include <string>
+#include <vector>
+#include <stdexcept>
+#include <chrono>
+
+#include "../../include/admm_hip.h"
+
+namespace admm {
+
+// Error carried through the library as an exception and converted to a code at the C boundary.
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+void set_last_error(const std::string& m);
+
+#define ADMM_HIP_CHECK(expr)                                                                       \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            throw ::admm::Error(ADMM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e) +  \
+                                                  " (" __FILE__ ":" + std::to_string(__LINE__) + ")"); \
+    } while (0)
+
+#define ADMM_REQUIRE(cond, msg)                                             \
+    do {                                                                    \
+        if (!(cond)) throw ::admm::Error(ADMM_ERR_INVALID_ARG, (msg));      \
+    } while (0)
+
+inline double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// Owning device allocation.
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    explicit DevBuf(size_t count) { alloc(count); }
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept {
+        if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+        return *this;
+    }
+    ~DevBuf() { release(); }
+    void alloc(size_t count) {
+        release();
+        n = count;
+        if (count) ADMM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)));
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr; n = 0;
+    }
+    void zero(hipStream_t s) { if (n) ADMM_HIP_CHECK(hipMemsetAsync(p, 0, n * sizeof(T), s)); }
+    T* get() const { return p; }
+};
+
+struct Stream {
+    hipStream_t s = nullptr;
+    Stream() { ADMM_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); }
+    ~Stream() { if (s) (void)hipStreamDestroy(s); }
+    Stream(const Stream&) = delete;
+    Stream& operator=(const Stream&) = delete;
+    void sync() const { ADMM_HIP_CHECK(hipStreamSynchronize(s)); }
+};
+
+struct Event {
+    hipEvent_t e = nullptr;
+    Event() { ADMM_HIP_CHECK(hipEventCreate(&e)); }
+    ~Event() { if (e) (void)hipEventDestroy(e); }
+    Event(const Event&) = delete;
+    Event& operator=(const Event&) = delete;
+};
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+inline size_t round_up_sz(size_t v, size_t m) { return (v + m - 1) / m * m; }
+
+struct DeviceInfo {
+    int num_cu = 256;
+    size_t lds_per_block = 64 * 1024;
+};
+const DeviceInfo& device_info();   // queries the current device once per device id
+void require_device();             // throws ADMM_ERR_NO_DEVICE when no usable HIP device
+
+}  // namespace admm

@@ -1,0 +1,258 @@
+// extern "C" boundary of libadmm_hip.so (see include/admm_hip.h).
+#include "solvers.h"
+
+namespace admm {
+const std::string& last_error_ref();
+
+std::vector<double> make_lambda_grid(const LassoProblem& pb, double lambda0, int n, double scaleY) {
+    if (!pb.lambda_in.empty()) return pb.lambda_in;
+    // Lasso.cpp:78-89: lmax = lambda0 / n * scaleY; log-spaced down to lmin_ratio * lmax
+    const int nl = pb.nlambda_auto;
+    const double lmax = lambda0 / n * scaleY;
+    const double lmin = pb.lmin_ratio * lmax;
+    std::vector<double> lam(nl);
+    const double lo = std::log(lmax), hi = std::log(lmin);
+    for (int i = 0; i < nl; ++i) {
+        const double t = nl > 1 ? lo + (hi - lo) * ((double)i / (double)(nl - 1)) : lo;
+        lam[i] = std::exp(i == nl - 1 && nl > 1 ? hi : t);
+    }
+    return lam;
+}
+
+static int env_int(const char* name, int dflt) {
+    const char* v = std::getenv(name);
+    return v ? std::atoi(v) : dflt;
+}
+
+template <typename F>
+static int guarded(F&& f) {
+    try {
+        f();
+        return ADMM_OK;
+    } catch (const Error& e) {
+        set_last_error(e.what());
+        return e.code;
+    } catch (const std::bad_alloc&) {
+        set_last_error("host allocation failed");
+        return ADMM_ERR_INTERNAL;
+    } catch (const std::exception& e) {
+        set_last_error(e.what());
+        return ADMM_ERR_INTERNAL;
+    }
+}
+
+static void check_common(const double* x, const double* y, int n, int p, int mem, const admm_opts* opts) {
+    ADMM_REQUIRE(x != nullptr && y != nullptr, "x and y must not be NULL");
+    ADMM_REQUIRE(n > 0 && p > 0, "n and p must be positive");
+    ADMM_REQUIRE(mem == ADMM_MEM_HOST || mem == ADMM_MEM_DEVICE, "mem must be ADMM_MEM_HOST or ADMM_MEM_DEVICE");
+    ADMM_REQUIRE(opts != nullptr, "opts must not be NULL");
+    ADMM_REQUIRE(opts->maxit > 0, "maxit should be positive");                                  // R/30_admm_lasso.R:119-120
+    ADMM_REQUIRE(opts->eps_abs >= 0 && opts->eps_rel >= 0, "eps_abs and eps_rel should be nonnegative");
+}
+
+struct PlanHandle {
+    Stream st;
+    std::unique_ptr<LassoPlan> plan;
+    int p = 0, nlam = 0;
+    double t_create = 0;
+};
+
+static PlanHandle* create_plan(const double* x, const double* y, int n, int p, int mem,
+                               const double* lambda_in, int nlambda_in, int nlambda_auto, double lmin_ratio,
+                               int standardize, int intercept, bool enet, double alpha, int nworkers,
+                               const admm_opts* opts) {
+    check_common(x, y, n, p, mem, opts);
+    ADMM_REQUIRE(nlambda_in >= 0, "nlambda_in must be >= 0");
+    ADMM_REQUIRE(nlambda_in > 0 ? lambda_in != nullptr : nlambda_auto > 0, "need a lambda grid or nlambda_auto > 0");
+    if (nlambda_in == 0) ADMM_REQUIRE(lmin_ratio > 0 && lmin_ratio < 1, "lambda_min_ratio must be within (0, 1)");
+    for (int i = 0; i < nlambda_in; ++i) ADMM_REQUIRE(lambda_in[i] > 0, "lambda must be positive");
+    if (nworkers > 0) ADMM_REQUIRE(nworkers <= n, "more row blocks than rows");
+    require_device();
+    const double t0 = now_s();
+    std::unique_ptr<PlanHandle> h(new PlanHandle());
+    LassoProblem pb;
+    pb.opts = *opts;
+    pb.lambda_in.assign(lambda_in, lambda_in + nlambda_in);
+    pb.nlambda_auto = nlambda_auto;
+    pb.lmin_ratio = lmin_ratio;
+    pb.enet = enet;
+    pb.alpha = alpha;
+    pb.nworkers = nworkers;
+    pb.batch_iters = env_int("ADMM_HIP_BATCH_ITERS", 0);
+    pb.profile_stride = env_int("ADMM_HIP_PROFILE_STRIDE", 0);
+    DeviceData<float> d;
+    upload_standardize<float>(d, x, y, n, p, mem, standardize != 0, intercept != 0, h->st.s);
+    if (nworkers > 0) h->plan = make_par_plan(std::move(d), pb, h->st.s);
+    else if (n > p) h->plan = make_tall_plan(std::move(d), pb, h->st.s);      // Lasso.cpp:73
+    else h->plan = make_wide_plan(std::move(d), pb, h->st.s);
+    h->p = p;
+    h->nlam = nlambda_in > 0 ? nlambda_in : nlambda_auto;
+    h->t_create = now_s() - t0;
+    return h.release();
+}
+
+static void run_plan(PlanHandle* h, double* lambda_out, float* beta_out, int* niter_out, admm_stats* stats, double t_extra) {
+    ADMM_REQUIRE(h != nullptr && h->plan, "plan is NULL");
+    ADMM_REQUIRE(lambda_out && beta_out && niter_out, "output pointers must not be NULL");
+    const double t0 = now_s();
+    LassoResult res;
+    h->plan->run(res);
+    const int nl = (int)res.lambda.size();
+    for (int i = 0; i < nl; ++i) { lambda_out[i] = res.lambda[i]; niter_out[i] = res.niter[i]; }
+    std::memcpy(beta_out, res.beta.data(), sizeof(float) * (size_t)(h->p + 1) * nl);
+    res.stats.t_total = now_s() - t0 + t_extra;
+    if (stats) *stats = res.stats;
+}
+
+static int lasso_family(const double* x, const double* y, int n, int p, int mem,
+                        const double* lambda_in, int nlambda_in, int nlambda_auto, double lmin_ratio,
+                        int standardize, int intercept, bool enet, double alpha, int nworkers,
+                        const admm_opts* opts, double* lambda_out, float* beta_out, int* niter_out, admm_stats* stats) {
+    return guarded([&] {
+        ADMM_REQUIRE(lambda_out && beta_out && niter_out, "output pointers must not be NULL");
+        std::unique_ptr<PlanHandle> h(create_plan(x, y, n, p, mem, lambda_in, nlambda_in, nlambda_auto, lmin_ratio,
+                                                  standardize, intercept, enet, alpha, nworkers, opts));
+        run_plan(h.get(), lambda_out, beta_out, niter_out, stats, h->t_create);
+    });
+}
+
+}  // namespace admm
+
+using namespace admm;
+
+extern "C" {
+
+int admm_hip_lasso(const double* x, const double* y, int n, int p, int mem,
+                   const double* lambda_in, int nlambda_in, int nlambda_auto, double lmin_ratio,
+                   int standardize, int intercept, const admm_opts* opts,
+                   double* lambda_out, float* beta_out, int* niter_out, admm_stats* stats) {
+    return lasso_family(x, y, n, p, mem, lambda_in, nlambda_in, nlambda_auto, lmin_ratio, standardize, intercept,
+                        false, 1.0, 0, opts, lambda_out, beta_out, niter_out, stats);
+}
+
+int admm_hip_enet(const double* x, const double* y, int n, int p, int mem,
+                  const double* lambda_in, int nlambda_in, int nlambda_auto, double lmin_ratio,
+                  int standardize, int intercept, double alpha, const admm_opts* opts,
+                  double* lambda_out, float* beta_out, int* niter_out, admm_stats* stats) {
+    if (!(alpha >= 0.0 && alpha <= 1.0)) {                       // R/40_admm_enet.R:38-39
+        set_last_error("alpha must be within [0, 1]");
+        return ADMM_ERR_INVALID_ARG;
+    }
+    return lasso_family(x, y, n, p, mem, lambda_in, nlambda_in, nlambda_auto, lmin_ratio, standardize, intercept,
+                        true, alpha, 0, opts, lambda_out, beta_out, niter_out, stats);
+}
+
+int admm_hip_parlasso(const double* x, const double* y, int n, int p, int mem,
+                      const double* lambda_in, int nlambda_in, int nlambda_auto, double lmin_ratio,
+                      int standardize, int intercept, int nthread, const admm_opts* opts,
+                      double* lambda_out, float* beta_out, int* niter_out, admm_stats* stats) {
+    if (nthread < 1) {
+        set_last_error("nthread must be >= 1");
+        return ADMM_ERR_INVALID_ARG;
+    }
+    return lasso_family(x, y, n, p, mem, lambda_in, nlambda_in, nlambda_auto, lmin_ratio, standardize, intercept,
+                        false, 1.0, nthread, opts, lambda_out, beta_out, niter_out, stats);
+}
+
+int admm_hip_lad(const double* x, const double* y, int n, int p, int mem, int intercept,
+                 const admm_opts* opts, double* beta_out, int* niter_out, admm_stats* stats) {
+    return guarded([&] {
+        check_common(x, y, n, p, mem, opts);
+        ADMM_REQUIRE(beta_out && niter_out, "output pointers must not be NULL");
+        ADMM_REQUIRE(n > p, "nrow(x) must be greater than ncol(x)");            // R/20_admm_lad.R:21-22
+        ADMM_REQUIRE(opts->rho > 0, "rho should be positive");
+        require_device();
+        const double t0 = now_s();
+        Stream st;
+        DeviceData<double> d;
+        upload_standardize<double>(d, x, y, n, p, mem, true, intercept != 0, st.s);    // LAD.cpp:34: standardize always TRUE
+        DenseResult res;
+        res.stats.t_h2d = d.t_h2d;
+        res.stats.t_standardize = d.t_std;
+        solve_lad(d, *opts, res, st.s);
+        for (int i = 0; i <= p; ++i) beta_out[i] = res.beta[i];
+        niter_out[0] = res.niter;
+        res.stats.t_total = now_s() - t0;
+        if (stats) *stats = res.stats;
+    });
+}
+
+int admm_hip_bp(const double* x, const double* y, int n, int p, int mem,
+                const admm_opts* opts, double* beta_out, int* niter_out, admm_stats* stats) {
+    return guarded([&] {
+        check_common(x, y, n, p, mem, opts);
+        ADMM_REQUIRE(beta_out && niter_out, "output pointers must not be NULL");
+        ADMM_REQUIRE(p > n, "ncol(x) must be greater than nrow(x)");            // R/10_admm_bp.R:30-31
+        ADMM_REQUIRE(opts->rho > 0, "rho should be positive");
+        require_device();
+        const double t0 = now_s();
+        Stream st;
+        DeviceData<double> d;
+        upload_standardize<double>(d, x, y, n, p, mem, false, false, st.s);     // BP.cpp:24-27: no standardisation
+        DenseResult res;
+        res.stats.t_h2d = d.t_h2d;
+        res.stats.t_standardize = d.t_std;
+        solve_bp(d, *opts, res, st.s);
+        for (int i = 0; i < p; ++i) beta_out[i] = res.beta[i];
+        niter_out[0] = res.niter;
+        res.stats.t_total = now_s() - t0;
+        if (stats) *stats = res.stats;
+    });
+}
+
+int admm_hip_lasso_plan_create(const double* x, const double* y, int n, int p, int mem,
+                               const double* lambda_in, int nlambda_in, int nlambda_auto, double lmin_ratio,
+                               int standardize, int intercept, double alpha, int nthread, const admm_opts* opts,
+                               admm_hip_plan** plan_out, int* nlambda_out) {
+    return guarded([&] {
+        ADMM_REQUIRE(plan_out != nullptr, "plan_out must not be NULL");
+        const bool enet = alpha >= 0.0;
+        if (enet) ADMM_REQUIRE(alpha <= 1.0, "alpha must be within [0, 1]");
+        PlanHandle* h = create_plan(x, y, n, p, mem, lambda_in, nlambda_in, nlambda_auto, lmin_ratio, standardize, intercept,
+                                    enet, enet ? alpha : 1.0, nthread > 1 ? nthread : 0, opts);
+        *plan_out = reinterpret_cast<admm_hip_plan*>(h);
+        if (nlambda_out) *nlambda_out = h->nlam;
+    });
+}
+
+int admm_hip_lasso_plan_run(admm_hip_plan* plan, double* lambda_out, float* beta_out, int* niter_out, admm_stats* stats) {
+    return guarded([&] { run_plan(reinterpret_cast<PlanHandle*>(plan), lambda_out, beta_out, niter_out, stats, 0.0); });
+}
+
+int admm_hip_lasso_plan_destroy(admm_hip_plan* plan) {
+    return guarded([&] { delete reinterpret_cast<PlanHandle*>(plan); });
+}
+
+const char* admm_hip_last_error(void) { return last_error_ref().c_str(); }
+const char* admm_hip_version(void) { return "admm_hip 0.1 (gfx950)"; }
+
+int admm_hip_device_count(void) {
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess) return 0;
+    return cnt;
+}
+int admm_hip_set_device(int device) {
+    return guarded([&] { ADMM_HIP_CHECK(hipSetDevice(device)); });
+}
+int admm_hip_device_synchronize(void) {
+    return guarded([&] { ADMM_HIP_CHECK(hipDeviceSynchronize()); });
+}
+
+// Host-only helper used by the CPU test-suite: runs the Lanczos host logic (lanczos.hip) against a
+// dense symmetric matrix held in host memory.  Not part of any solver path.
+int admm_hip_host_lanczos(const float* A, int n, float* eig_out, int* nmatop_out) {
+    return guarded([&] {
+        ADMM_REQUIRE(A && eig_out && n >= 3, "bad arguments");
+        auto op = [&](const float* v, float* w) {
+            for (int i = 0; i < n; ++i) w[i] = 0.f;
+            for (int j = 0; j < n; ++j) {
+                const float vj = v[j];
+                const float* col = A + (size_t)j * n;
+                for (int i = 0; i < n; ++i) w[i] += col[i] * vj;
+            }
+        };
+        *eig_out = lanczos_largest_f32(op, n, nmatop_out);
+    });
+}
+
+}  // extern "C"

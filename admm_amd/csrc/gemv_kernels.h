@@ -1,0 +1,183 @@
+// Bandwidth-bound dense matrix-vector kernels for gfx950 (CDNA4), shared by every solver.
+//
+// gemv_t: out_r[s][j] = sum_{i in row segment s} A[i + j*lda] * v_r[i]   (r < NRHS)
+//   A is column-major; the summation index runs along the contiguous dimension, so one wave
+//   streams a column with 16-byte-per-lane loads (1 KiB per wave instruction) and the only
+//   partial results are nseg values per output.  The right-hand vectors' segment lives in LDS
+//   and is shared by the 4 waves of the workgroup; a wave owns C columns at a time, so each
+//   LDS read feeds C*NRHS FMAs and C independent 16-B global loads are in flight per lane per
+//   pass.  HBM roofline: lda*k*sizeof(T) bytes read once.
+//
+// Used for: the tall x-update (A = cached (X'X+rho I)^-1, NRHS = 2: base and acceleration
+// direction, see lasso_tall.hip), X'y, Lanczos SYMVs, the wide solver's X't, PADMM / LAD / BP
+// products (on the stored transpose where the reference multiplies by the matrix itself).
+#pragma once
+#include "admm_internal.h"
+#include "device_utils.h"
+
+namespace admm {
+
+constexpr int kGemvThreads = 256;          // 4 waves per workgroup
+constexpr int kGemvWaves = kGemvThreads / kWave;
+
+template <typename T>
+struct GemvTArgs {
+    const T* A;
+    long long lda;
+    int m;              // rows (length of the dot products)
+    int k;              // columns (number of outputs)
+    const T* v[2];
+    T* out[2];          // out[r][s * out_stride + j]
+    long long out_stride;
+    int seg_len;        // rows per segment (multiple of 32 elements: 128-B aligned starts)
+    int seg_alloc;      // LDS stride per right-hand segment: seg_len rounded up to a wave pass
+    int nseg;
+    int groups_per_wg;  // column groups (of C columns) per workgroup
+    const int* skip;    // optional device flag: non-zero -> kernel is a no-op
+};
+
+template <typename T, int NRHS, int C>
+__global__ void __launch_bounds__(kGemvThreads)
+gemv_t_kernel(GemvTArgs<T> a) {
+    using VT = Vec16<T>;
+    using V = typename VT::type;
+    constexpr int VN = VT::N;
+    constexpr int PASS = kWave * VN;        // rows covered by one wave pass
+
+    if (a.skip != nullptr && *a.skip != 0) return;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* rhs = reinterpret_cast<T*>(smem_raw);     // [NRHS][seg_alloc]
+
+    const int s = blockIdx.x % a.nseg;
+    const int cb = blockIdx.x / a.nseg;
+    const int r0 = s * a.seg_len;
+    const int len = min(a.seg_len, a.m - r0);
+    const int lpad = (len + PASS - 1) / PASS * PASS;
+
+    // Stage the right-hand segment(s), zero padded so that padded rows contribute nothing.
+#pragma unroll
+    for (int r = 0; r < NRHS; ++r) {
+        const T* src = a.v[r] + r0;
+        T* dst = rhs + (size_t)r * a.seg_alloc;
+        for (int i = threadIdx.x; i < lpad; i += kGemvThreads) dst[i] = (i < len) ? src[i] : T(0);
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int ngroups = (a.k + C - 1) / C;
+    const int g_end = min((cb + 1) * a.groups_per_wg, ngroups);
+    const int len_v = (len + VN - 1) / VN * VN;          // rows touched by vector loads
+    const int nfull = len_v / PASS;                      // unmasked passes
+
+    for (int g = cb * a.groups_per_wg + wid; g < g_end; g += kGemvWaves) {
+        const int col0 = g * C;
+        const T* colp[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const int col = min(col0 + c, a.k - 1);      // clamp: the duplicate is never written
+            colp[c] = a.A + (size_t)col * a.lda + r0;
+        }
+        T acc[C][NRHS];
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+            for (int r = 0; r < NRHS; ++r) acc[c][r] = T(0);
+
+        int row = lane * VN;
+#pragma unroll 2
+        for (int it = 0; it < nfull; ++it, row += PASS) {
+            V av[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) av[c] = *reinterpret_cast<const V*>(colp[c] + row);
+            V rv[NRHS];
+#pragma unroll
+            for (int r = 0; r < NRHS; ++r) rv[r] = *reinterpret_cast<const V*>(rhs + (size_t)r * a.seg_alloc + row);
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+#pragma unroll
+                for (int r = 0; r < NRHS; ++r) acc[c][r] = VT::dot(av[c], rv[r], acc[c][r]);
+        }
+        if (row < len_v) {   // masked tail pass
+            V rv[NRHS];
+#pragma unroll
+            for (int r = 0; r < NRHS; ++r) rv[r] = *reinterpret_cast<const V*>(rhs + (size_t)r * a.seg_alloc + row);
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                V av = *reinterpret_cast<const V*>(colp[c] + row);
+#pragma unroll
+                for (int r = 0; r < NRHS; ++r) acc[c][r] = VT::dot(av, rv[r], acc[c][r]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+            for (int r = 0; r < NRHS; ++r) acc[c][r] = wave_sum(acc[c][r]);
+        if (lane == 0) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                if (col0 + c < a.k) {
+#pragma unroll
+                    for (int r = 0; r < NRHS; ++r) a.out[r][(size_t)s * a.out_stride + col0 + c] = acc[c][r];
+                }
+            }
+        }
+    }
+}
+
+// Launch geometry for gemv_t: picks the row segmentation and the column blocking so that the
+// grid is about `wg_per_cu` workgroups per CU, each with whole multiples of 4 column groups.
+struct GemvTPlan {
+    int seg_len = 0, seg_alloc = 0, nseg = 0, groups_per_wg = 0, num_cb = 0, grid = 0;
+    size_t lds_bytes = 0;
+};
+
+template <typename T>
+inline GemvTPlan plan_gemv_t(int m, int k, int nrhs, int C, int max_seg_rows = 0, int wg_per_cu = 4) {
+    constexpr int VN = 16 / (int)sizeof(T);
+    const int PASS = kWave * VN;
+    GemvTPlan pl;
+    // LDS budget: at most 160 KiB / wg_per_cu per workgroup for the staged right-hand segments.
+    size_t budget = (size_t)(160 * 1024) / (size_t)wg_per_cu - 512;
+    int max_rows = (int)(budget / ((size_t)nrhs * sizeof(T)));
+    max_rows = max_rows / PASS * PASS;
+    if (max_seg_rows > 0) max_rows = std::min(max_rows, std::max(PASS, max_seg_rows / PASS * PASS));
+    pl.nseg = (m + max_rows - 1) / max_rows;
+    pl.seg_len = round_up((m + pl.nseg - 1) / pl.nseg, 32);      // balanced, 128-B aligned starts
+    pl.nseg = (m + pl.seg_len - 1) / pl.seg_len;
+    pl.seg_alloc = round_up(pl.seg_len, PASS);
+    const int ngroups = (k + C - 1) / C;
+    const int target_wg = device_info().num_cu * wg_per_cu;
+    int cb = std::max(1, target_wg / pl.nseg);
+    int gpw = (ngroups + cb - 1) / cb;
+    gpw = std::max(kGemvWaves, round_up(gpw, kGemvWaves));
+    pl.groups_per_wg = gpw;
+    pl.num_cb = (ngroups + gpw - 1) / gpw;
+    pl.grid = pl.num_cb * pl.nseg;
+    pl.lds_bytes = (size_t)nrhs * pl.seg_alloc * sizeof(T);
+    return pl;
+}
+
+template <typename T, int NRHS, int C>
+inline void launch_gemv_t(const GemvTPlan& pl, const T* A, long long lda, int m, int k,
+                          const T* v0, const T* v1, T* out0, T* out1, long long out_stride,
+                          const int* skip, hipStream_t st) {
+    GemvTArgs<T> a;
+    a.A = A; a.lda = lda; a.m = m; a.k = k;
+    a.v[0] = v0; a.v[1] = v1; a.out[0] = out0; a.out[1] = out1;
+    a.out_stride = out_stride; a.seg_len = pl.seg_len; a.seg_alloc = pl.seg_alloc; a.nseg = pl.nseg;
+    a.groups_per_wg = pl.groups_per_wg; a.skip = skip;
+    hipLaunchKernelGGL((gemv_t_kernel<T, NRHS, C>), dim3(pl.grid), dim3(kGemvThreads), pl.lds_bytes, st, a);
+}
+
+// Sum the nseg partial rows of a gemv_t result: y[j] = sum_s part[s*stride + j].
+template <typename T>
+__global__ void reduce_partials_kernel(const T* part, long long stride, int nseg, int k, T* y) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= k) return;
+    T s = 0;
+    for (int i = 0; i < nseg; ++i) s += part[(size_t)i * stride + j];
+    y[j] = s;
+}
+
+}  // namespace admm

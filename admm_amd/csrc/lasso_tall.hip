@@ -1,0 +1,374 @@
+// Tall (n > p) Lasso / Elastic-net lambda path, device resident.
+//
+// Replaces, for n > p:  ADMMLassoTall / ADMMEnetTall driven by FADMMBase::solve
+//   /root/reference/src/FADMMBase.h:185-265, ADMMLassoTall.h:55-231, ADMMEnet.h:19-58,
+//   and the lambda loop of Lasso.cpp:97-124.
+//
+// Design (MI355X-first, not a translation):
+//  * rho is fixed along the whole path (ADMMLassoTall.h:97, init only at i == 0), so the
+//    Cholesky solve of (X'X + rho I) is replaced by ONE cached symmetric inverse Minv (p x p
+//    fp32, 4p^2 bytes) and the x-update becomes a bandwidth-bound dense mat-vec.
+//  * Goldstein acceleration/restart makes the right-hand side depend on a scalar decided from
+//    global norms.  Both branches are affine in one scalar tau:
+//        adj_z = z + tau (z - z_old), adj_y = y + tau (y - y_old)   (tau = (a-1)/a'  or  -1 on restart)
+//        rhs   = X'y - adj_y + rho adj_z = u + tau w,
+//        u = X'y - y + rho z,   w = -(y - y_old) + rho (z - z_old).
+//    The x-update kernel therefore streams Minv ONCE against the pair (u, w) and produces
+//    a = Minv u, b = Minv w; the next kernel forms x = a + tau b after it has evaluated the
+//    decision from the previous iteration's norm partials.  No host round trip, no grid
+//    barrier, no atomics: two launches per ADMM iteration.
+//  * Convergence test, acceleration scalars, the lambda schedule (init_warm), niter[] and the
+//    beta snapshot all live on the device; the host only enqueues iteration batches and polls
+//    a `done` word asynchronously.
+//  * After a converged lambda the reference re-solves with an unchanged right-hand side
+//    (adj_z/adj_y are not updated on the exit iteration, FADMMBase.h:237-238), so the first
+//    x of the next lambda equals the last x: `mode == 0` reuses it instead of a mat-vec.
+#include "prep.h"
+#include "gemv_kernels.h"
+#include "solvers.h"
+
+namespace admm {
+
+struct TallCtl {
+    double rho, lam, eps_primal, eps_dual, adj_a, adj_c, tau;
+    int mode;       // 1: x = a + tau*b and adj from (cur, old);  0: keep stored x / adj (first iteration after convergence)
+    int restart;    // with mode 1: adj = old exactly
+    int iter;       // index i of the iteration this block describes
+    int lam_idx;
+    int done;
+    int first;
+    int total;
+    int pad;
+};
+
+struct TallParams {
+    int p, nwg, nseg, maxit, nlam, enet;
+    long long part_stride;
+    double eps_abs, eps_rel, alpha, sqrt_p;
+    const double* lambdas;      // device, nlam values already rounded to float
+    const float* XY;
+    const float* a_part; const float* b_part;
+    float* x; float* z0; float* z1; float* y0; float* y1; float* adj_z; float* adj_y; float* u; float* w;
+    TallCtl* ctl;               // [2]
+    double* P;                  // [2][nwg][8]
+    float* beta;                // [nlam][p] snapshots of z (standardised scale)
+    int* niter;                 // [nlam]
+};
+
+constexpr int kTailThreads = 256;
+
+__global__ void __launch_bounds__(kTailThreads)
+tall_tail_kernel(TallParams q, int par) {
+    __shared__ double sums[8];
+    __shared__ double scratch[6 * (kTailThreads / 64)];
+    const TallCtl in = q.ctl[par];
+    TallCtl* outp = &q.ctl[par ^ 1];
+    if (in.done) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) *outp = in;       // keep `done` sticky in both slots
+        return;
+    }
+    // ---- decision from the previous iteration's norm partials (every workgroup, identically)
+    if (threadIdx.x < 6) {
+        const double* Pin = q.P + (size_t)par * q.nwg * 8;
+        double s = 0.0;
+        for (int w = 0; w < q.nwg; ++w) s += Pin[(size_t)w * 8 + threadIdx.x];
+        sums[threadIdx.x] = s;
+    }
+    __syncthreads();
+    const double r2 = sums[0], dz2 = sums[1], daz2 = sums[2], x2 = sums[3], z2 = sums[4], y2 = sums[5];
+    TallCtl out = in;
+    out.first = 0;
+    int lam_finished = -1, niter_val = 0;
+    if (!in.first) {
+        const double rp = sqrt(r2);                    // resid_primal            FADMMBase.h:208
+        const double rd = in.rho * sqrt(dz2);          // resid_dual              ADMMLassoTall.h:150-153
+        if (rp < in.eps_primal && rd < in.eps_dual) {  // converged()             FADMMBase.h:213-217
+            lam_finished = in.lam_idx; niter_val = in.iter + 1;
+            out.mode = 0;
+        } else {
+            const double old_c = in.adj_c;
+            const double c = in.rho * rp * rp + in.rho * daz2;     // compute_resid_combined  ADMMLassoTall.h:154-161
+            if (c < 0.999 * old_c) {                   // FADMMBase.h:243-249
+                const double old_a = in.adj_a;
+                const double a = 0.5 + 0.5 * sqrt(1.0 + 4.0 * old_a * old_a);
+                out.adj_a = a; out.adj_c = c; out.tau = (old_a - 1.0) / a; out.restart = 0;
+            } else {                                   // restart                 FADMMBase.h:250-256
+                out.adj_a = 1.0; out.adj_c = old_c / 0.999; out.tau = -1.0; out.restart = 1;
+            }
+            out.mode = 1;
+            out.iter = in.iter + 1;
+            if (in.iter + 1 >= q.maxit) {              // loop ran out: `return i + 1` with i == maxit
+                lam_finished = in.lam_idx; niter_val = q.maxit + 1;
+            }
+        }
+        if (lam_finished >= 0) {                       // next lambda: init_warm keeps x,z,y,adj,a,c,rho (ADMMLassoTall.h:219-230)
+            out.lam_idx = in.lam_idx + 1;
+            out.iter = 0;
+            if (out.lam_idx >= q.nlam) out.done = 1;
+            else out.lam = q.lambdas[out.lam_idx];
+        }
+    } else {
+        out.mode = 1; out.tau = 0.0; out.restart = 0;  // cold start: adj = 0, x = Minv X'y
+    }
+    // eps for the iteration about to run, from the CURRENT iterate (FADMMBase.h:187-188, ADMMLassoTall.h:141-149)
+    out.eps_primal = fmax(sqrt(x2), sqrt(z2)) * q.eps_rel + q.sqrt_p * q.eps_abs;
+    out.eps_dual = sqrt(y2) * q.eps_rel + q.sqrt_p * q.eps_abs;
+    out.total = in.total + 1;
+
+    const int cur = in.total & 1;                      // buffer holding the current z / y
+    const float* zc_ = cur ? q.z1 : q.z0; const float* yc_ = cur ? q.y1 : q.y0;
+    float* zo_ = cur ? q.z0 : q.z1;       float* yo_ = cur ? q.y0 : q.y1;
+    const int i = blockIdx.x * kTailThreads + threadIdx.x;
+
+    if (lam_finished >= 0 && i < q.p) q.beta[(size_t)lam_finished * q.p + i] = zc_[i];   // get_z() snapshot (Lasso.cpp:108)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (lam_finished >= 0) q.niter[lam_finished] = niter_val;
+        *outp = out;
+    }
+    if (out.done) return;
+
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    if (i < q.p) {
+        const float zc = zc_[i], yc = yc_[i];
+        float adjz, adjy, x;
+        if (out.mode) {
+            float a = 0.f, b = 0.f;
+            for (int s = 0; s < q.nseg; ++s) { a += q.a_part[(size_t)s * q.part_stride + i]; b += q.b_part[(size_t)s * q.part_stride + i]; }
+            const float zo = zo_[i], yo = yo_[i];
+            if (out.restart) { adjz = zo; adjy = yo; x = a - b; }
+            else {
+                const float t = (float)out.tau, t1 = (float)(1.0 + out.tau);
+                adjz = t1 * zc - t * zo;               // (1 + ratio) * aux_z - ratio * old_z   FADMMBase.h:247-248
+                adjy = t1 * yc - t * yo;
+                x = a + t * b;
+            }
+        } else { adjz = q.adj_z[i]; adjy = q.adj_y[i]; x = q.x[i]; }
+        const float rho_f = (float)out.rho;
+        const float vec = x + adjy / rho_f;            // next_z: main_x + adj_y / rho            ADMMLassoTall.h:83
+        const double pen = out.lam / out.rho;
+        float zn;
+        if (!q.enet) {                                 // soft_threshold, double compare          ADMMLassoTall.h:55-69
+            const double v = (double)vec;
+            zn = v > pen ? (float)(v - pen) : (v < -pen ? (float)(v + pen) : 0.f);
+        } else {                                       // enet()                                  ADMMEnet.h:24-40
+            const float thresh = (float)(q.alpha * pen);
+            const float denom = (float)(1.0 + pen * (1.0 - q.alpha));
+            zn = vec > thresh ? (vec - thresh) / denom : (vec < -thresh ? (vec + thresh) / denom : 0.f);
+        }
+        const float r = x - zn;                        // next_residual                            ADMMLassoTall.h:86-95
+        const float yn = adjy + rho_f * r;             // dual_y = adj_y + rho * newr              FADMMBase.h:210
+        const float dz = zn - zc, daz = zn - adjz;
+        acc[0] = (double)r * r; acc[1] = (double)dz * dz; acc[2] = (double)daz * daz;
+        acc[3] = (double)x * x; acc[4] = (double)zn * zn; acc[5] = (double)yn * yn;
+        q.x[i] = x; zo_[i] = zn; yo_[i] = yn; q.adj_z[i] = adjz; q.adj_y[i] = adjy;
+        q.u[i] = (float)((double)(q.XY[i] - yn) + out.rho * (double)zn);
+        q.w[i] = (float)((double)(yc - yn) + out.rho * (double)dz);
+    }
+    block_sum<double, 6>(acc, scratch);
+    if (threadIdx.x == 0) {
+        double* Pout = q.P + ((size_t)(par ^ 1) * q.nwg + blockIdx.x) * 8;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) Pout[k] = acc[k];
+    }
+}
+
+__global__ void tall_init_kernel(TallParams q, double rho, double lam0) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < q.p) {
+        q.x[i] = 0.f; q.z0[i] = 0.f; q.z1[i] = 0.f; q.y0[i] = 0.f; q.y1[i] = 0.f;
+        q.adj_z[i] = 0.f; q.adj_y[i] = 0.f; q.u[i] = q.XY[i]; q.w[i] = 0.f;
+    }
+    if (i < 2 * q.nwg * 8) q.P[i] = 0.0;
+    if (i == 0) {
+        TallCtl c;
+        c.rho = rho; c.lam = lam0; c.eps_primal = 0.0; c.eps_dual = 0.0;
+        c.adj_a = 1.0; c.adj_c = 9999.0; c.tau = 0.0;
+        c.mode = 1; c.restart = 0; c.iter = 0; c.lam_idx = 0; c.done = 0; c.first = 1; c.total = 0; c.pad = 0;
+        q.ctl[0] = c; q.ctl[1] = c;
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+struct TallPlan final : LassoPlan {
+    DeviceData<float> d;
+    LassoProblem pb;
+    hipStream_t st;
+    admm_stats setup_stats{};
+    int p = 0, nlam = 0, nwg = 0;
+    long long ldp = 0;
+    double rho = 0;
+    std::vector<double> lam_user, lam_int;
+    GemvTPlan pl;
+    DevBuf<float> XY, M, a_part, b_part, x, z0, z1, y0, y1, adj_z, adj_y, u, w, beta;
+    DevBuf<int> niter;
+    DevBuf<double> P, dlam;
+    DevBuf<TallCtl> ctl;
+    TallParams q{};
+    TallCtl* hctl = nullptr;
+
+    ~TallPlan() override { if (hctl) (void)hipHostFree(hctl); }
+
+    TallPlan(DeviceData<float>&& data, const LassoProblem& prob, hipStream_t stream) : d(std::move(data)), pb(prob), st(stream) {
+        const int n = d.n;
+        p = d.p;
+        admm_stats& S = setup_stats;
+        S.branch = 0;
+        S.t_h2d = d.t_h2d; S.t_standardize = d.t_std;
+        ldp = round_up(p, 32);
+
+        // X'y and lambda_0 (ADMMLassoTall.h:172-173; ADMMEnet.h:56 divides by alpha + 1e-4)
+        XY.alloc(ldp); XY.zero(st);
+        gemv_t_simple<float>(d.X.get(), d.ldx, n, p, d.Y.get(), XY.get(), st);
+        float lambda0 = device_absmax<float>(XY.get(), p, st);
+        if (pb.enet) lambda0 = (float)(lambda0 / ((double)(float)pb.alpha + 0.0001));
+
+        // lambda grid (Lasso.cpp:78-89) and internal lambdas (Lasso.cpp:99), stored as float like `Scalar lambda`
+        lam_user = make_lambda_grid(pb, lambda0, n, (double)d.scaleY);
+        nlam = (int)lam_user.size();
+        lam_int.resize(nlam);
+        for (int i = 0; i < nlam; ++i) lam_int[i] = (double)(float)(lam_user[i] * n / (double)d.scaleY);
+
+        // Gram (cross_prod_lower, ADMMLassoTall.h:191-192) -- both triangles
+        double t0 = now_s();
+        M.alloc((size_t)ldp * p); M.zero(st);
+        gram_full<float>(d.X.get(), d.ldx, n, p, true, M.get(), ldp, st);
+        ADMM_HIP_CHECK(hipStreamSynchronize(st));
+        S.t_gram = now_s() - t0;
+
+        // rho (ADMMLassoTall.h:194-202)
+        rho = pb.opts.rho;
+        t0 = now_s();
+        if (rho <= 0) {
+            SymMatVec<float> op(M.get(), ldp, p, st);
+            int nmatop = 0;
+            const float ev = lanczos_largest_f32([&](const float* v, float* w_) { op(v, w_); }, p, &nmatop);
+            S.eig_est = ev;
+            rho = std::pow((double)ev, 1.0 / 3) * std::pow(lam_int[0], 2.0 / 3);
+        }
+        S.rho = rho;
+        S.t_eigs = now_s() - t0;
+
+        // (X'X + rho I)^-1, cached for the whole path (rho never changes: ADMMLassoTall.h:97)
+        t0 = now_s();
+        add_diag<float>(M.get(), ldp, p, (float)rho, st);
+        spd_inverse_full<float>(M.get(), ldp, p, st);
+        ADMM_HIP_CHECK(hipStreamSynchronize(st));
+        S.t_factor = now_s() - t0;
+        // X itself is no longer needed by the loop (only X'y and Minv are): release 4np bytes.
+        d.X.release();
+
+        // ---- loop state
+        pl = plan_gemv_t<float>(p, p, 2, 4);
+        nwg = (p + kTailThreads - 1) / kTailThreads;
+        a_part.alloc((size_t)pl.nseg * ldp); b_part.alloc((size_t)pl.nseg * ldp);
+        x.alloc(ldp); z0.alloc(ldp); z1.alloc(ldp); y0.alloc(ldp); y1.alloc(ldp);
+        adj_z.alloc(ldp); adj_y.alloc(ldp); u.alloc(ldp); w.alloc(ldp);
+        beta.alloc((size_t)nlam * p); niter.alloc(nlam);
+        P.alloc((size_t)2 * nwg * 8); dlam.alloc(nlam); ctl.alloc(2);
+        a_part.zero(st); b_part.zero(st); u.zero(st); w.zero(st);
+        ADMM_HIP_CHECK(hipMemcpyAsync(dlam.get(), lam_int.data(), nlam * sizeof(double), hipMemcpyHostToDevice, st));
+
+        q.p = p; q.nwg = nwg; q.nseg = pl.nseg; q.maxit = pb.opts.maxit; q.nlam = nlam; q.enet = pb.enet ? 1 : 0;
+        q.part_stride = ldp;
+        q.eps_abs = pb.opts.eps_abs; q.eps_rel = pb.opts.eps_rel; q.alpha = (double)(float)pb.alpha; q.sqrt_p = std::sqrt((double)p);
+        q.lambdas = dlam.get(); q.XY = XY.get(); q.a_part = a_part.get(); q.b_part = b_part.get();
+        q.x = x.get(); q.z0 = z0.get(); q.z1 = z1.get(); q.y0 = y0.get(); q.y1 = y1.get();
+        q.adj_z = adj_z.get(); q.adj_y = adj_y.get(); q.u = u.get(); q.w = w.get();
+        q.ctl = ctl.get(); q.P = P.get(); q.beta = beta.get(); q.niter = niter.get();
+
+        // Pinned mirror of the control block for asynchronous polling.
+        ADMM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&hctl), 2 * sizeof(TallCtl), hipHostMallocDefault));
+        ADMM_HIP_CHECK(hipStreamSynchronize(st));
+    }
+
+    // One warm-started lambda path from a cold start (init at the first lambda, init_warm after).
+    void run(LassoResult& res) override {
+        admm_stats S = setup_stats;
+        res.lambda = lam_user;
+        beta.zero(st); niter.zero(st);
+        const int init_n = std::max(p, 2 * nwg * 8);
+        hipLaunchKernelGGL(tall_init_kernel, dim3((init_n + 255) / 256), dim3(256), 0, st, q, rho, lam_int[0]);
+        hctl[0].done = hctl[1].done = 0;
+
+        const int batch = pb.batch_iters > 0 ? (pb.batch_iters + 1) / 2 * 2 : 32;    // even
+        const int stride = pb.profile_stride;                          // sample every stride-th x-update with events
+        std::vector<hipEvent_t> evs;
+        struct EvFree { std::vector<hipEvent_t>* v; ~EvFree() { for (auto e : *v) (void)hipEventDestroy(e); } } ef{&evs};
+        Event ev_loop0, ev_loop1, ev_poll[2];
+
+        ADMM_HIP_CHECK(hipStreamSynchronize(st));
+        const double tl0 = now_s();
+        ADMM_HIP_CHECK(hipEventRecord(ev_loop0.e, st));
+        long long g = 0, launches = 0;
+        const long long max_total = (long long)nlam * ((long long)pb.opts.maxit + 2) + 4 + 2 * batch;
+        auto enqueue_batch = [&](int slot) {
+            for (int k = 0; k < batch; ++k, ++g) {
+                const int par = (int)(g & 1);
+                const bool sample = stride > 0 && (g % stride) == 0 && evs.size() < 8192;
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                if (sample) {
+                    ADMM_HIP_CHECK(hipEventCreate(&e0)); ADMM_HIP_CHECK(hipEventCreate(&e1));
+                    evs.push_back(e0); evs.push_back(e1);
+                    ADMM_HIP_CHECK(hipEventRecord(e0, st));
+                }
+                launch_gemv_t<float, 2, 4>(pl, M.get(), ldp, p, p, u.get(), w.get(), a_part.get(), b_part.get(), ldp,
+                                           &ctl.get()[par].done, st);
+                if (sample) ADMM_HIP_CHECK(hipEventRecord(e1, st));
+                hipLaunchKernelGGL(tall_tail_kernel, dim3(nwg), dim3(kTailThreads), 0, st, q, par);
+                ++launches;
+            }
+            // after an even number of iterations the freshest control block is slot g&1 == 0
+            ADMM_HIP_CHECK(hipMemcpyAsync(&hctl[slot], &ctl.get()[(int)(g & 1)], sizeof(TallCtl), hipMemcpyDeviceToHost, st));
+            ADMM_HIP_CHECK(hipEventRecord(ev_poll[slot].e, st));
+        };
+        int slot = 0;
+        enqueue_batch(slot);
+        bool done = false;
+        while (!done) {
+            enqueue_batch(slot ^ 1);                       // keep one batch in flight while polling the previous one
+            ADMM_HIP_CHECK(hipEventSynchronize(ev_poll[slot].e));
+            done = hctl[slot].done != 0;
+            slot ^= 1;
+            if (!done && g > max_total) throw Error(ADMM_ERR_INTERNAL, "tall path: iteration bound exceeded without completion");
+        }
+        ADMM_HIP_CHECK(hipEventRecord(ev_loop1.e, st));
+        ADMM_HIP_CHECK(hipStreamSynchronize(st));
+        S.t_loop = now_s() - tl0;
+        float ms = 0.f;
+        ADMM_HIP_CHECK(hipEventElapsedTime(&ms, ev_loop0.e, ev_loop1.e));
+        S.loop_ms_events = ms;
+        S.xupdate_launches = launches;
+        if (!evs.empty()) {
+            double tot = 0;
+            for (size_t k = 0; k + 1 < evs.size(); k += 2) {
+                float m1 = 0.f;
+                ADMM_HIP_CHECK(hipEventElapsedTime(&m1, evs[k], evs[k + 1]));
+                tot += m1;
+            }
+            S.xupdate_samples = (long long)(evs.size() / 2);
+            S.xupdate_ms_avg = tot / (double)(evs.size() / 2);
+        }
+
+        // ---- results: niter, beta on the original scale (DataStd::recover, Lasso.cpp:108-111)
+        res.niter.assign(nlam, 0);
+        ADMM_HIP_CHECK(hipMemcpy(res.niter.data(), niter.get(), nlam * sizeof(int), hipMemcpyDeviceToHost));
+        std::vector<float> hb((size_t)nlam * p);
+        ADMM_HIP_CHECK(hipMemcpy(hb.data(), beta.get(), hb.size() * sizeof(float), hipMemcpyDeviceToHost));
+        res.beta.assign((size_t)(p + 1) * nlam, 0.f);
+        long long tot_it = 0;
+        for (int l = 0; l < nlam; ++l) {
+            float b0 = 0.f;
+            recover_coef<float>(d, hb.data() + (size_t)l * p, &b0, res.beta.data() + (size_t)l * (p + 1) + 1);
+            res.beta[(size_t)l * (p + 1)] = b0;
+            tot_it += res.niter[l];
+        }
+        S.total_iter = tot_it;
+        res.stats = S;
+    }
+};
+
+std::unique_ptr<LassoPlan> make_tall_plan(DeviceData<float>&& d, const LassoProblem& pb, hipStream_t st) {
+    return std::unique_ptr<LassoPlan>(new TallPlan(std::move(d), pb, st));
+}
+
+}  // namespace admm

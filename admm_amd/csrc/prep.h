@@ -1,0 +1,81 @@
+// One-time device-side preparation shared by the solvers: upload/convert/standardise
+// (the DataStd step of the reference), Gram matrices, Cholesky + cached inverse, Lanczos.
+#pragma once
+#include "admm_internal.h"
+#include <functional>
+
+namespace admm {
+
+// Device copy of the (standardised) problem data in solver precision T.
+template <typename T>
+struct DeviceData {
+    int n = 0, p = 0;
+    long long ldx = 0;          // leading dimension of X (>= n, multiple of 32 elements)
+    DevBuf<T> X;                // n x p column-major, padding rows zero
+    DevBuf<T> Y;                // n (allocated ldx, zero padded)
+    int flag = 0;               // DataStd flag = standardize + 2*intercept (DataStd.h:21-29)
+    std::vector<T> meanX, scaleX;   // host copies for recover()
+    T meanY = 0, scaleY = 1;
+    double t_h2d = 0, t_std = 0;
+};
+
+// Convert the caller's double column-major x (n x p, ld n) and y to T on the device and apply
+// DataStd::standardize (DataStd.h:89-155) there.  mem: ADMM_MEM_HOST / ADMM_MEM_DEVICE.
+template <typename T>
+void upload_standardize(DeviceData<T>& d, const double* x, const double* y, int n, int p, int mem,
+                        bool standardize, bool intercept, hipStream_t st);
+
+// DataStd::recover (DataStd.h:157-207) on a host coefficient vector (length p) in precision T.
+template <typename T>
+void recover_coef(const DeviceData<T>& d, const T* coef, T* beta0, T* out);
+
+// C (k x k, ldc) = A' A for A (m x k, lda) [trans=true] or A A' for A (k x m) [trans=false], both
+// triangles filled.  First cut: rocBLAS SYRK + symmetrise kernel.
+template <typename T>
+void gram_full(const T* A, long long lda, int rows, int cols, bool atA, T* C, long long ldc, hipStream_t st);
+
+template <typename T>
+void add_diag(T* A, long long lda, int n, T v, hipStream_t st);
+template <typename T>
+void symmetrize_from_lower(T* A, long long lda, int n, hipStream_t st);
+
+// In place: A (SPD, lower triangle valid) -> full symmetric inverse. Throws ADMM_ERR_NOT_SPD.
+template <typename T>
+void spd_inverse_full(T* A, long long lda, int n, hipStream_t st);
+// In place Cholesky (lower). Throws ADMM_ERR_NOT_SPD.
+template <typename T>
+void cholesky_lower(T* A, long long lda, int n, hipStream_t st);
+// B <- L^-1 B (left, lower, no-trans), B is n x m.
+template <typename T>
+void trsm_left_lower(const T* L, long long ldl, int n, T* B, long long ldb, int m, hipStream_t st);
+// B <- B L^-T (right, lower, trans), B is m x n.
+template <typename T>
+void trsm_right_lower_t(const T* L, long long ldl, int n, T* B, long long ldb, int m, hipStream_t st);
+// out (cols x rows, ldo) = in' for in (rows x cols, ldi)
+template <typename T>
+void transpose(const T* in, long long ldi, int rows, int cols, T* out, long long ldo, hipStream_t st);
+
+// y = A v for a full symmetric device matrix (column-major, lda), host vectors; used by Lanczos.
+template <typename T>
+struct SymMatVec {
+    const T* A; long long lda; int n; hipStream_t st;
+    DevBuf<T> dv, dw, part;
+    SymMatVec(const T* A_, long long lda_, int n_, hipStream_t st_);
+    void operator()(const T* v_host, T* w_host);
+};
+
+// The reference's Spectra call: SymEigsSolver<T, LARGEST_ALGE>(op, 1, 3); init(); compute(10, 0.1)
+// (ADMMLassoTall.h:196-201, ADMMLassoWide.h:202-207).  Returns the Ritz value; throws
+// ADMM_ERR_EIGS if it never passes the loose convergence test.
+float lanczos_largest_f32(const std::function<void(const float*, float*)>& op, int n, int* nmatop);
+
+// max_j |v_j| of a device vector.
+template <typename T>
+T device_absmax(const T* v, int n, hipStream_t st);
+
+// y = A' v (A m x k column-major, v length m) -> host-free device result; convenience wrapper
+// over gemv_t with an internal partial buffer.
+template <typename T>
+void gemv_t_simple(const T* A, long long lda, int m, int k, const T* v, T* y, hipStream_t st);
+
+}  // namespace admm

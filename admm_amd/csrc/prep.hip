@@ -1,0 +1,427 @@
+// One-time preparation kernels and library wrappers (see prep.h).
+#include "prep.h"
+#include "gemv_kernels.h"
+
+#include <rocblas/rocblas.h>
+#include <rocsolver/rocsolver.h>
+#include <mutex>
+
+namespace admm {
+
+// ------------------------------------------------------------------ process-wide bits
+static thread_local std::string g_last_error;
+void set_last_error(const std::string& m) { g_last_error = m; }
+const std::string& last_error_ref() { return g_last_error; }
+
+void require_device() {
+    int cnt = 0;
+    hipError_t e = hipGetDeviceCount(&cnt);
+    if (e != hipSuccess || cnt <= 0)
+        throw Error(ADMM_ERR_NO_DEVICE, "no usable HIP device (libadmm_hip has no CPU fallback)");
+}
+
+const DeviceInfo& device_info() {
+    static std::mutex mu;
+    static std::vector<DeviceInfo> cache;
+    static std::vector<char> have;
+    int dev = 0;
+    ADMM_HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    if ((int)cache.size() <= dev) { cache.resize(dev + 1); have.resize(dev + 1, 0); }
+    if (!have[dev]) {
+        hipDeviceProp_t prop;
+        ADMM_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+        cache[dev].num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        cache[dev].lds_per_block = prop.sharedMemPerBlock;
+        have[dev] = 1;
+    }
+    return cache[dev];
+}
+
+struct BlasHandle {
+    rocblas_handle h = nullptr;
+    BlasHandle() {
+        if (rocblas_create_handle(&h) != rocblas_status_success) throw Error(ADMM_ERR_BLAS, "rocblas_create_handle failed");
+    }
+    ~BlasHandle() { if (h) rocblas_destroy_handle(h); }
+};
+static rocblas_handle blas(hipStream_t st) {
+    static thread_local BlasHandle bh;
+    if (rocblas_set_stream(bh.h, st) != rocblas_status_success) throw Error(ADMM_ERR_BLAS, "rocblas_set_stream failed");
+    return bh.h;
+}
+#define ADMM_BLAS_CHECK(expr)                                                                   \
+    do {                                                                                        \
+        rocblas_status _s = (expr);                                                             \
+        if (_s != rocblas_status_success)                                                       \
+            throw ::admm::Error(ADMM_ERR_BLAS, std::string(#expr) + " failed with rocblas_status " + std::to_string((int)_s)); \
+    } while (0)
+
+// ------------------------------------------------------------------ standardise (DataStd.h:89-155)
+// One workgroup per column; the column is converted to T first (Lasso.cpp:49 copies double->float
+// before standardising), statistics accumulate in double.
+template <typename T>
+__global__ void __launch_bounds__(256)
+standardize_cols_kernel(const double* __restrict__ x, long long ldin, int n, int flag,
+                        T* __restrict__ X, long long ldx, T* __restrict__ meanX, T* __restrict__ scaleX) {
+    __shared__ double scratch[4];
+    const int j = blockIdx.x;
+    const double* src = x + (size_t)j * ldin;
+    T* dst = X + (size_t)j * ldx;
+    T mean = T(0), inv = T(1);
+    if (flag != 0) {
+        double s[1] = {0.0};
+        for (int i = threadIdx.x; i < n; i += 256) s[0] += (double)(T)src[i];
+        block_sum<double, 1>(s, scratch);
+        mean = (T)(s[0] / (double)n);
+    }
+    if (flag & 1) {
+        double ss[1] = {0.0};
+        for (int i = threadIdx.x; i < n; i += 256) {
+            T c = (T)src[i] - mean;
+            ss[0] += (double)c * (double)c;
+        }
+        block_sum<double, 1>(ss, scratch);
+        const T n_invsqrt = (T)(1.0 / sqrt((double)(T)n));
+        const T scale = (T)((T)sqrt(ss[0]) * n_invsqrt);       // ||x - mean|| / sqrt(n): population sd
+        inv = (T)(1.0 / (double)scale);
+        if (threadIdx.x == 0) scaleX[j] = scale;
+    }
+    const bool center = (flag & 2) != 0;
+    if (threadIdx.x == 0 && center) meanX[j] = mean;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        T v = (T)src[i];
+        if (center) v = v - mean;
+        if (flag & 1) v = v * inv;
+        dst[i] = v;
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(1024)
+standardize_y_kernel(const double* __restrict__ y, int n, int flag, T* __restrict__ Y, T* __restrict__ stats /*mean, scale*/) {
+    __shared__ double scratch[16];
+    T mean = T(0), scale = T(1);
+    if (flag != 0) {
+        double s[1] = {0.0};
+        for (int i = threadIdx.x; i < n; i += 1024) s[0] += (double)(T)y[i];
+        block_sum<double, 1>(s, scratch);
+        mean = (T)(s[0] / (double)n);
+        double ss[1] = {0.0};
+        for (int i = threadIdx.x; i < n; i += 1024) {
+            T c = (T)y[i] - mean;
+            ss[0] += (double)c * (double)c;
+        }
+        block_sum<double, 1>(ss, scratch);
+        const T n_invsqrt = (T)(1.0 / sqrt((double)(T)n));
+        scale = (T)((T)sqrt(ss[0]) * n_invsqrt);
+    }
+    const bool center = (flag & 2) != 0;      // flag 1 scales by sd without centring (DataStd.h:96-99)
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        T v = (T)y[i];
+        if (center) v = v - mean;
+        if (flag != 0) v = v / scale;
+        Y[i] = v;
+    }
+    if (threadIdx.x == 0) { stats[0] = center ? mean : T(0); stats[1] = scale; }
+}
+
+template <typename T>
+void upload_standardize(DeviceData<T>& d, const double* x, const double* y, int n, int p, int mem,
+                        bool standardize, bool intercept, hipStream_t st) {
+    d.n = n; d.p = p;
+    d.flag = int(standardize) + 2 * int(intercept);
+    d.ldx = round_up(n, 32);
+    d.X.alloc((size_t)d.ldx * p);
+    d.Y.alloc((size_t)d.ldx);
+    d.X.zero(st);
+    d.Y.zero(st);
+    DevBuf<T> dmean(p), dscale(p), ystats(2);
+    dmean.zero(st); dscale.zero(st);
+    double t0 = now_s();
+    if (mem == ADMM_MEM_DEVICE) {
+        hipLaunchKernelGGL((standardize_cols_kernel<T>), dim3(p), dim3(256), 0, st, x, (long long)n, n, d.flag,
+                           d.X.get(), d.ldx, dmean.get(), dscale.get());
+        hipLaunchKernelGGL((standardize_y_kernel<T>), dim3(1), dim3(1024), 0, st, y, n, d.flag, d.Y.get(), ystats.get());
+        ADMM_HIP_CHECK(hipStreamSynchronize(st));
+        d.t_h2d = 0;
+        d.t_std = now_s() - t0;
+    } else {
+        // Host input (what R hands over): stream column chunks through two device staging buffers.
+        const size_t chunk_bytes = (size_t)256 << 20;
+        int cols_per_chunk = (int)std::max<size_t>(1, chunk_bytes / ((size_t)n * sizeof(double)));
+        cols_per_chunk = std::min(cols_per_chunk, p);
+        DevBuf<double> stage[2];
+        stage[0].alloc((size_t)cols_per_chunk * n);
+        stage[1].alloc((size_t)cols_per_chunk * n);
+        Event ev[2];
+        bool used[2] = {false, false};
+        double th = 0;
+        int b = 0;
+        for (int c0 = 0; c0 < p; c0 += cols_per_chunk, b ^= 1) {
+            const int nc = std::min(cols_per_chunk, p - c0);
+            if (used[b]) ADMM_HIP_CHECK(hipEventSynchronize(ev[b].e));
+            double t1 = now_s();
+            ADMM_HIP_CHECK(hipMemcpy(stage[b].get(), x + (size_t)c0 * n, (size_t)nc * n * sizeof(double), hipMemcpyHostToDevice));
+            th += now_s() - t1;
+            hipLaunchKernelGGL((standardize_cols_kernel<T>), dim3(nc), dim3(256), 0, st, stage[b].get(), (long long)n, n, d.flag,
+                               d.X.get() + (size_t)c0 * d.ldx, d.ldx, dmean.get() + c0, dscale.get() + c0);
+            ADMM_HIP_CHECK(hipEventRecord(ev[b].e, st));
+            used[b] = true;
+        }
+        DevBuf<double> ystage(n);
+        double t1 = now_s();
+        ADMM_HIP_CHECK(hipMemcpy(ystage.get(), y, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+        th += now_s() - t1;
+        hipLaunchKernelGGL((standardize_y_kernel<T>), dim3(1), dim3(1024), 0, st, ystage.get(), n, d.flag, d.Y.get(), ystats.get());
+        ADMM_HIP_CHECK(hipStreamSynchronize(st));
+        d.t_h2d = th;
+        d.t_std = now_s() - t0 - th;
+    }
+    d.meanX.assign(p, T(0));
+    d.scaleX.assign(p, T(1));
+    if (d.flag & 2) ADMM_HIP_CHECK(hipMemcpy(d.meanX.data(), dmean.get(), (size_t)p * sizeof(T), hipMemcpyDeviceToHost));
+    if (d.flag & 1) ADMM_HIP_CHECK(hipMemcpy(d.scaleX.data(), dscale.get(), (size_t)p * sizeof(T), hipMemcpyDeviceToHost));
+    T ys[2];
+    ADMM_HIP_CHECK(hipMemcpy(ys, ystats.get(), 2 * sizeof(T), hipMemcpyDeviceToHost));
+    d.meanY = ys[0];
+    d.scaleY = ys[1];
+}
+template void upload_standardize<float>(DeviceData<float>&, const double*, const double*, int, int, int, bool, bool, hipStream_t);
+template void upload_standardize<double>(DeviceData<double>&, const double*, const double*, int, int, int, bool, bool, hipStream_t);
+
+template <typename T>
+void recover_coef(const DeviceData<T>& d, const T* coef, T* beta0, T* out) {
+    const int p = d.p;
+    T b0 = T(0);
+    switch (d.flag) {
+        case 0:
+            for (int j = 0; j < p; ++j) out[j] = coef[j];
+            break;
+        case 1:
+            for (int j = 0; j < p; ++j) out[j] = (coef[j] / d.scaleX[j]) * d.scaleY;
+            break;
+        case 2: {
+            T acc = T(0);
+            for (int j = 0; j < p; ++j) { out[j] = coef[j] * d.scaleY; acc += out[j] * d.meanX[j]; }
+            b0 = d.meanY - acc;
+            break;
+        }
+        default: {
+            T acc = T(0);
+            for (int j = 0; j < p; ++j) { out[j] = (coef[j] / d.scaleX[j]) * d.scaleY; acc += out[j] * d.meanX[j]; }
+            b0 = d.meanY - acc;
+        }
+    }
+    *beta0 = b0;
+}
+template void recover_coef<float>(const DeviceData<float>&, const float*, float*, float*);
+template void recover_coef<double>(const DeviceData<double>&, const double*, double*, double*);
+
+// ------------------------------------------------------------------ small dense helpers
+template <typename T>
+__global__ void add_diag_kernel(T* A, long long lda, int n, T v) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) A[(size_t)i * lda + i] += v;
+}
+template <typename T>
+void add_diag(T* A, long long lda, int n, T v, hipStream_t st) {
+    hipLaunchKernelGGL((add_diag_kernel<T>), dim3((n + 255) / 256), dim3(256), 0, st, A, lda, n, v);
+}
+template void add_diag<float>(float*, long long, int, float, hipStream_t);
+template void add_diag<double>(double*, long long, int, double, hipStream_t);
+
+// upper(i<j) <- lower: A[i + j*lda] = A[j + i*lda]; 32x32 tiles through LDS so both sides coalesce.
+template <typename T>
+__global__ void __launch_bounds__(256)
+symmetrize_kernel(T* A, long long lda, int n) {
+    __shared__ T tile[32][33];
+    const int bi = blockIdx.y, bj = blockIdx.x;      // tile (bi,bj) of the LOWER part: bi >= bj
+    if (bi < bj) return;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    // read lower tile rows bi*32.., cols bj*32..
+    for (int c = ty; c < 32; c += 8) {
+        int r = bi * 32 + tx, cc = bj * 32 + c;
+        tile[c][tx] = (r < n && cc < n) ? A[(size_t)cc * lda + r] : T(0);
+    }
+    __syncthreads();
+    // write transposed into tile (bj,bi): element (r', c') = lower(c', r')
+    for (int c = ty; c < 32; c += 8) {
+        int r = bj * 32 + tx, cc = bi * 32 + c;     // target row r (in bj block), col cc (in bi block)
+        if (r < n && cc < n && r < cc) A[(size_t)cc * lda + r] = tile[tx][c];
+    }
+}
+template <typename T>
+void symmetrize_from_lower(T* A, long long lda, int n, hipStream_t st) {
+    int nb = (n + 31) / 32;
+    hipLaunchKernelGGL((symmetrize_kernel<T>), dim3(nb, nb), dim3(256), 0, st, A, lda, n);
+}
+template void symmetrize_from_lower<float>(float*, long long, int, hipStream_t);
+template void symmetrize_from_lower<double>(double*, long long, int, hipStream_t);
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+transpose_kernel(const T* __restrict__ in, long long ldi, int rows, int cols, T* __restrict__ out, long long ldo) {
+    __shared__ T tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    for (int c = ty; c < 32; c += 8) {
+        int r = r0 + tx, cc = c0 + c;
+        tile[c][tx] = (r < rows && cc < cols) ? in[(size_t)cc * ldi + r] : T(0);
+    }
+    __syncthreads();
+    for (int c = ty; c < 32; c += 8) {
+        int orow = c0 + tx, ocol = r0 + c;     // out(orow, ocol) = in(ocol, orow)
+        if (orow < cols && ocol < rows) out[(size_t)ocol * ldo + orow] = tile[tx][c];
+    }
+}
+template <typename T>
+void transpose(const T* in, long long ldi, int rows, int cols, T* out, long long ldo, hipStream_t st) {
+    hipLaunchKernelGGL((transpose_kernel<T>), dim3((rows + 31) / 32, (cols + 31) / 32), dim3(256), 0, st,
+                       in, ldi, rows, cols, out, ldo);
+}
+template void transpose<float>(const float*, long long, int, int, float*, long long, hipStream_t);
+template void transpose<double>(const double*, long long, int, int, double*, long long, hipStream_t);
+
+// ------------------------------------------------------------------ Gram / factorisation (library first cut)
+template <typename T>
+void gram_full(const T* A, long long lda, int rows, int cols, bool atA, T* C, long long ldc, hipStream_t st) {
+    rocblas_handle h = blas(st);
+    const T one = T(1), zero = T(0);
+    const int nC = atA ? cols : rows;
+    const int kk = atA ? rows : cols;
+    const rocblas_operation op = atA ? rocblas_operation_transpose : rocblas_operation_none;
+    if constexpr (std::is_same<T, float>::value) {
+        ADMM_BLAS_CHECK(rocblas_ssyrk(h, rocblas_fill_lower, op, nC, kk, &one, A, (rocblas_int)lda, &zero, C, (rocblas_int)ldc));
+    } else {
+        ADMM_BLAS_CHECK(rocblas_dsyrk(h, rocblas_fill_lower, op, nC, kk, &one, A, (rocblas_int)lda, &zero, C, (rocblas_int)ldc));
+    }
+    symmetrize_from_lower<T>(C, ldc, nC, st);
+}
+template void gram_full<float>(const float*, long long, int, int, bool, float*, long long, hipStream_t);
+template void gram_full<double>(const double*, long long, int, int, bool, double*, long long, hipStream_t);
+
+static void check_info(const DevBuf<rocblas_int>& info, hipStream_t st, const char* what) {
+    rocblas_int h = 0;
+    ADMM_HIP_CHECK(hipMemcpyAsync(&h, info.get(), sizeof(h), hipMemcpyDeviceToHost, st));
+    ADMM_HIP_CHECK(hipStreamSynchronize(st));
+    if (h != 0) throw Error(ADMM_ERR_NOT_SPD, std::string(what) + ": matrix is not positive definite (info=" + std::to_string(h) + ")");
+}
+
+template <typename T>
+void cholesky_lower(T* A, long long lda, int n, hipStream_t st) {
+    rocblas_handle h = blas(st);
+    DevBuf<rocblas_int> info(1);
+    if constexpr (std::is_same<T, float>::value) {
+        ADMM_BLAS_CHECK(rocsolver_spotrf(h, rocblas_fill_lower, n, A, (rocblas_int)lda, info.get()));
+    } else {
+        ADMM_BLAS_CHECK(rocsolver_dpotrf(h, rocblas_fill_lower, n, A, (rocblas_int)lda, info.get()));
+    }
+    check_info(info, st, "Cholesky");
+}
+template void cholesky_lower<float>(float*, long long, int, hipStream_t);
+template void cholesky_lower<double>(double*, long long, int, hipStream_t);
+
+template <typename T>
+void spd_inverse_full(T* A, long long lda, int n, hipStream_t st) {
+    cholesky_lower<T>(A, lda, n, st);
+    rocblas_handle h = blas(st);
+    DevBuf<rocblas_int> info(1);
+    if constexpr (std::is_same<T, float>::value) {
+        ADMM_BLAS_CHECK(rocsolver_spotri(h, rocblas_fill_lower, n, A, (rocblas_int)lda, info.get()));
+    } else {
+        ADMM_BLAS_CHECK(rocsolver_dpotri(h, rocblas_fill_lower, n, A, (rocblas_int)lda, info.get()));
+    }
+    check_info(info, st, "inverse from Cholesky factor");
+    symmetrize_from_lower<T>(A, lda, n, st);
+}
+template void spd_inverse_full<float>(float*, long long, int, hipStream_t);
+template void spd_inverse_full<double>(double*, long long, int, hipStream_t);
+
+template <typename T>
+void trsm_left_lower(const T* L, long long ldl, int n, T* B, long long ldb, int m, hipStream_t st) {
+    rocblas_handle h = blas(st);
+    const T one = T(1);
+    if constexpr (std::is_same<T, float>::value) {
+        ADMM_BLAS_CHECK(rocblas_strsm(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit,
+                                      n, m, &one, L, (rocblas_int)ldl, B, (rocblas_int)ldb));
+    } else {
+        ADMM_BLAS_CHECK(rocblas_dtrsm(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit,
+                                      n, m, &one, L, (rocblas_int)ldl, B, (rocblas_int)ldb));
+    }
+}
+template void trsm_left_lower<float>(const float*, long long, int, float*, long long, int, hipStream_t);
+template void trsm_left_lower<double>(const double*, long long, int, double*, long long, int, hipStream_t);
+
+template <typename T>
+void trsm_right_lower_t(const T* L, long long ldl, int n, T* B, long long ldb, int m, hipStream_t st) {
+    rocblas_handle h = blas(st);
+    const T one = T(1);
+    if constexpr (std::is_same<T, float>::value) {
+        ADMM_BLAS_CHECK(rocblas_strsm(h, rocblas_side_right, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit,
+                                      m, n, &one, L, (rocblas_int)ldl, B, (rocblas_int)ldb));
+    } else {
+        ADMM_BLAS_CHECK(rocblas_dtrsm(h, rocblas_side_right, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit,
+                                      m, n, &one, L, (rocblas_int)ldl, B, (rocblas_int)ldb));
+    }
+}
+template void trsm_right_lower_t<float>(const float*, long long, int, float*, long long, int, hipStream_t);
+template void trsm_right_lower_t<double>(const double*, long long, int, double*, long long, int, hipStream_t);
+
+// ------------------------------------------------------------------ reductions / simple gemv
+template <typename T>
+__global__ void __launch_bounds__(1024)
+absmax_kernel(const T* v, int n, T* out) {
+    __shared__ T sm[16];
+    T m = T(0);
+    for (int i = threadIdx.x; i < n; i += 1024) { T a = fabs(v[i]); m = a > m ? a : m; }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        T r = sm[0];
+        for (int w = 1; w < 16; ++w) r = sm[w] > r ? sm[w] : r;
+        out[0] = r;
+    }
+}
+template <typename T>
+T device_absmax(const T* v, int n, hipStream_t st) {
+    DevBuf<T> out(1);
+    hipLaunchKernelGGL((absmax_kernel<T>), dim3(1), dim3(1024), 0, st, v, n, out.get());
+    T h;
+    ADMM_HIP_CHECK(hipMemcpyAsync(&h, out.get(), sizeof(T), hipMemcpyDeviceToHost, st));
+    ADMM_HIP_CHECK(hipStreamSynchronize(st));
+    return h;
+}
+template float device_absmax<float>(const float*, int, hipStream_t);
+template double device_absmax<double>(const double*, int, hipStream_t);
+
+template <typename T>
+void gemv_t_simple(const T* A, long long lda, int m, int k, const T* v, T* y, hipStream_t st) {
+    GemvTPlan pl = plan_gemv_t<T>(m, k, 1, 4);
+    const long long stride = round_up(k, 32);
+    DevBuf<T> part((size_t)pl.nseg * stride);
+    launch_gemv_t<T, 1, 4>(pl, A, lda, m, k, v, nullptr, part.get(), nullptr, stride, nullptr, st);
+    hipLaunchKernelGGL((reduce_partials_kernel<T>), dim3((k + 255) / 256), dim3(256), 0, st, part.get(), stride, pl.nseg, k, y);
+    ADMM_HIP_CHECK(hipStreamSynchronize(st));   // part is freed on return
+}
+template void gemv_t_simple<float>(const float*, long long, int, int, const float*, float*, hipStream_t);
+template void gemv_t_simple<double>(const double*, long long, int, int, const double*, double*, hipStream_t);
+
+template <typename T>
+SymMatVec<T>::SymMatVec(const T* A_, long long lda_, int n_, hipStream_t st_) : A(A_), lda(lda_), n(n_), st(st_) {
+    dv.alloc(round_up(n, 32));
+    dw.alloc(round_up(n, 32));
+    dv.zero(st);
+}
+template <typename T>
+void SymMatVec<T>::operator()(const T* v_host, T* w_host) {
+    ADMM_HIP_CHECK(hipMemcpyAsync(dv.get(), v_host, (size_t)n * sizeof(T), hipMemcpyHostToDevice, st));
+    gemv_t_simple<T>(A, lda, n, n, dv.get(), dw.get(), st);
+    ADMM_HIP_CHECK(hipMemcpyAsync(w_host, dw.get(), (size_t)n * sizeof(T), hipMemcpyDeviceToHost, st));
+    ADMM_HIP_CHECK(hipStreamSynchronize(st));
+}
+template struct SymMatVec<float>;
+template struct SymMatVec<double>;
+
+}  // namespace admm

@@ -1,0 +1,48 @@
+// Solver entry points behind the C ABI (one per reference problem class).
+#pragma once
+#include "prep.h"
+#include <memory>
+
+namespace admm {
+
+struct LassoProblem {
+    admm_opts opts{};
+    std::vector<double> lambda_in;   // user grid (may be empty -> automatic)
+    int nlambda_auto = 100;
+    double lmin_ratio = 1e-4;
+    bool enet = false;
+    double alpha = 1.0;
+    int nworkers = 0;                // > 0: row-block consensus (admm_parlasso)
+    int batch_iters = 0;             // iterations enqueued per host poll (0 = default)
+    int profile_stride = 0;          // > 0: time every stride-th x-update launch with HIP events
+};
+
+struct LassoResult {
+    std::vector<double> lambda;
+    std::vector<float> beta;         // (p+1) x nlambda column-major, row 0 = intercept
+    std::vector<int> niter;
+    admm_stats stats{};
+};
+
+// Lasso.cpp:78-89
+std::vector<double> make_lambda_grid(const LassoProblem& pb, double lambda0, int n, double scaleY);
+
+// A prepared problem: construction does the one-time work (X'y, Gram, rho, factorisation ...),
+// run() executes one cold-started warm-chained lambda path and may be called repeatedly.
+struct LassoPlan {
+    virtual ~LassoPlan() = default;
+    virtual void run(LassoResult& res) = 0;
+};
+std::unique_ptr<LassoPlan> make_tall_plan(DeviceData<float>&& d, const LassoProblem& pb, hipStream_t st);
+std::unique_ptr<LassoPlan> make_wide_plan(DeviceData<float>&& d, const LassoProblem& pb, hipStream_t st);
+std::unique_ptr<LassoPlan> make_par_plan(DeviceData<float>&& d, const LassoProblem& pb, hipStream_t st);
+
+struct DenseResult {
+    std::vector<double> beta;
+    int niter = 0;
+    admm_stats stats{};
+};
+void solve_lad(const DeviceData<double>& d, const admm_opts& opts, DenseResult& res, hipStream_t st);
+void solve_bp(const DeviceData<double>& d, const admm_opts& opts, DenseResult& res, hipStream_t st);
+
+}  // namespace admm

@@ -1,0 +1,216 @@
+#!/usr/bin/env python
+"""Headline benchmark: ADMM iterations/s of the tall Lasso lambda path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], SURVEY.md section 8d "C2"): admm_lasso tall, n=100000,
+p=10000, fp32 solver arithmetic, automatic 100-lambda grid (lambda_min_ratio 1e-4), warm-started,
+standardize = intercept = TRUE, eps_abs = eps_rel = 1e-5, synthetic Gaussian data generated in
+HBM (X ~ N(0, 2^2), beta* = U(0,1) on the first 1000 coordinates, y = X beta* + N(0,1)).
+
+A "step" is one pass of the hot path: the complete warm-started lambda path (the loop of
+Lasso.cpp:97-124 -> FADMMBase::solve) from a cold start on the resident data.  The one-time
+preparation the reference does before that loop (convert, DataStd, X'y, Gram, Spectra, Cholesky)
+runs once before the timed region and is reported separately as `setup_s`; `sec_to_eps` =
+setup + one path.  value = sum of ADMM iterations of the K timed steps (over all ranks) divided
+by the max-over-ranks wall time of the timed region.
+
+N > 1: the serial tall solver does not shard in the reference ("replicas only");
+each rank runs an independent replica (its own synthetic problem) -> "scaling": "weak", no
+data-path collective.  One process per GPU (torch.distributed / RCCL for the barriers only).
+
+Extra objects on the JSON line: `roofline` for the dominant kernel (the x-update mat-vec,
+4*p^2 algorithmic bytes per launch, durations from HIP events recorded by the library on its own
+stream inside the timed region) and `cpu_baseline` (the NumPy/LAPACK oracle port of the same loop
+timed on the host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12   # B/s, MI355X spec (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=100000)
+    ap.add_argument("--p", type=int, default=10000)
+    ap.add_argument("--m", type=int, default=1000, help="non-zeros in beta*")
+    ap.add_argument("--nlambda", type=int, default=100)
+    ap.add_argument("--seed", type=int, default=123)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline loop (0 disables)")
+    ap.add_argument("--profile-stride", type=int, default=8, help="time every k-th x-update launch with HIP events")
+    return ap.parse_args()
+
+
+def cpu_baseline(p, nlambda, budget_s, seed):
+    """Oracle port (oracle/solvers.py LassoTall, float32, LAPACK Cholesky + 2 triangular solves per
+    iteration like Eigen's LLT::solve) on a bounded sample: same p, n_s = 2p rows of the same
+    synthetic distribution, the first lambdas of the same automatic grid until the budget is spent."""
+    import numpy as np
+    from oracle.datastd import DataStd
+    from oracle.entry import _lambda_grid
+    from oracle.solvers import LassoTall
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([d.get("num_threads", 1) for d in threadpool_info()] or [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    rng = np.random.default_rng(seed)
+    n_s = 2 * p
+    m = max(1, p // 10)
+    X = (rng.standard_normal((n_s, p), dtype=np.float32) * np.float32(2.0))
+    b = np.zeros(p, dtype=np.float32)
+    b[:m] = rng.uniform(size=m).astype(np.float32)
+    Y = (X @ b + rng.standard_normal(n_s, dtype=np.float32)).astype(np.float32)
+    X = np.asfortranarray(X)
+    std = DataStd(n_s, p, True, True, np.float32)
+    std.standardize(X, Y)
+    t0 = time.time()
+    solver = LassoTall(X, Y, 1e-5, 1e-5)
+    lam = _lambda_grid(solver.lambda0, n_s, std.scaleY, nlambda, 1e-4)
+    solver.init(lam[0] * n_s / np.float64(std.scaleY), -1.0)
+    t_setup = time.time() - t0
+    iters, t_loop, nl = 0, 0.0, 0
+    for i in range(nlambda):
+        if i > 0:
+            solver.init_warm(lam[i] * n_s / np.float64(std.scaleY))
+        t1 = time.time()
+        iters += solver.solve(10000)
+        t_loop += time.time() - t1
+        nl += 1
+        if t_loop > budget_s:
+            break
+    return {"value": iters / t_loop, "unit": "iterations/s", "cores": int(cores), "kind": "port",
+            "sample": f"oracle LassoTall (NumPy float32, LAPACK spotrf + 2 strtrs per iteration), p={p}, "
+                      f"n_sample={n_s} rows (per-iteration cost depends on p only), first {nl} of {nlambda} lambdas, "
+                      f"{iters} iterations in {t_loop:.1f} s; CPU setup (Gram+Lanczos+Cholesky) {t_setup:.1f} s"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    import torch                      # before libadmm_hip: one HIP runtime per process
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=dev)
+    os.environ["ADMM_HIP_PROFILE_STRIDE"] = str(a.profile_stride)
+    import numpy as np
+    from admm_amd import admm_lasso, DevicePtr, LassoPlan, load
+    lib = load()
+    rc = lib.admm_hip_set_device(local_rank)
+    assert rc == 0
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    n, p = a.n, a.p
+    # ---- synthetic data, generated in HBM.  xt is p x n row-major == X (n x p) column-major.
+    g = torch.Generator(device=dev)
+    g.manual_seed(a.seed + rank)
+    xt = torch.empty((p, n), dtype=torch.float64, device=dev)
+    chunk = max(1, (1 << 27) // n)
+    for c0 in range(0, p, chunk):
+        c1 = min(p, c0 + chunk)
+        xt[c0:c1] = torch.randn((c1 - c0, n), generator=g, device=dev, dtype=torch.float64) * 2.0
+    beta_true = torch.zeros(p, dtype=torch.float64, device=dev)
+    beta_true[:a.m] = torch.rand(a.m, generator=g, device=dev, dtype=torch.float64)
+    y = beta_true @ xt + torch.randn(n, generator=g, device=dev, dtype=torch.float64)
+    torch.cuda.synchronize()
+
+    # ---- one-time preparation (outside the timed region)
+    t0 = time.time()
+    model = admm_lasso(DevicePtr(xt.data_ptr()), DevicePtr(y.data_ptr()), n=n, p=p).penalty(nlambda=a.nlambda)
+    plan = LassoPlan(model)
+    lib.admm_hip_device_synchronize()
+    setup_s = time.time() - t0
+    del xt
+    torch.cuda.empty_cache()
+
+    fit = None
+    for _ in range(a.warmup):
+        fit = plan.run()
+    barrier()
+    torch.cuda.synchronize()
+    lib.admm_hip_device_synchronize()
+    t0 = time.time()
+    iters = 0
+    xms, xsamp, loop_ms = 0.0, 0, 0.0
+    for _ in range(a.steps):
+        fit = plan.run()
+        iters += int(fit.stats["total_iter"])
+        xms += fit.stats["xupdate_ms_avg"] * fit.stats["xupdate_samples"]
+        xsamp += int(fit.stats["xupdate_samples"])
+        loop_ms += fit.stats["loop_ms_events"]
+    torch.cuda.synchronize()
+    lib.admm_hip_device_synchronize()
+    barrier()
+    elapsed = time.time() - t0
+    if world > 1:
+        t = torch.tensor([elapsed, float(iters)], dtype=torch.float64, device=dev)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed_max, iters_all = float(tmax[0]), float(tsum[1])
+    else:
+        elapsed_max, iters_all = elapsed, float(iters)
+
+    if rank == 0:
+        x_ms = xms / max(1, xsamp)
+        alg_bytes = 4.0 * p * p
+        achieved = alg_bytes / (x_ms * 1e-3) if x_ms > 0 else 0.0
+        out = {
+            "metric": "ADMM iterations/sec, Lasso tall n=%d p=%d (100-lambda warm-started path)" % (n, p),
+            "value": iters_all / elapsed_max,
+            "unit": "iterations/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": elapsed_max / a.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "admm_lasso tall path (BASELINE configs[1])", "n": n, "p": p, "nlambda": a.nlambda,
+                       "standardize": True, "intercept": True, "eps_abs": 1e-5, "eps_rel": 1e-5,
+                       "parallelism": "replicas x%d" % world if world > 1 else "single GPU",
+                       "iters_per_step": iters / a.steps, "step": "one cold-started warm-chained lambda path"},
+            "setup_s": setup_s,
+            "sec_to_eps": setup_s + elapsed / a.steps,
+            "setup_breakdown_s": {k: fit.stats[k] for k in ("t_h2d", "t_standardize", "t_gram", "t_eigs", "t_factor")},
+            "loop_ms_events_per_step": loop_ms / a.steps,
+            "rho": fit.stats["rho"],
+            "nnz_last_lambda": int(np.count_nonzero(fit.beta_dense[1:, -1])),
+            "roofline": {"bound": "hbm", "kernel": "gemv_t_kernel<float,2,4> (x-update, cached inverse x [u w])",
+                         "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": x_ms, "launches_timed": xsamp},
+        }
+        if a.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(p, a.nlambda, a.cpu_seconds, a.seed)
+        print(json.dumps(out), flush=True)
+    plan.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

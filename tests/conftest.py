@@ -8,6 +8,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+try:
+    import torch  # noqa: F401  -- before libadmm_hip so both share ONE HIP runtime (same SONAMEs)
+except Exception:  # pragma: no cover
+    torch = None
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -1,0 +1,94 @@
+"""GPU parity: tall Lasso / Elastic-net through the C ABI vs the CPU oracle (and the README vectors)."""
+import numpy as np
+import pytest
+
+from helpers import relerr, synth_lasso
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4   # north_star: beta within 1e-4 relative (norm-wise)
+
+
+def test_readme_lasso_fixture(readme_lasso_xy):
+    from admm_amd import admm_lasso
+    from oracle import entry, readme
+    x, y = readme_lasso_xy
+    fit = admm_lasso(x, y).penalty(readme.LAMBDA).fit()
+    ref = entry.admm_lasso(x, y, [readme.LAMBDA], 100, 1e-4, True, True, entry.LASSO_OPTS)
+    beta = fit.beta_dense[:, 0]
+    assert relerr(beta, ref["beta"][:, 0]) < TOL
+    assert relerr(beta, readme.LASSO_ADMM) < TOL                 # README.md:66-88 admm column
+    assert np.array_equal(beta != 0, readme.LASSO_ADMM != 0)
+    assert abs(int(fit.niter[0]) - int(ref["niter"][0])) <= 2
+    assert abs(fit.stats["rho"] - 13.678) < 0.01
+
+
+def test_readme_enet_fixture(readme_lasso_xy):
+    from admm_amd import admm_enet
+    from oracle import entry, readme
+    x, y = readme_lasso_xy
+    fit = admm_enet(x, y).penalty(readme.LAMBDA, alpha=0.5).fit()
+    beta = fit.beta_dense[:, 0]
+    assert relerr(beta, readme.ENET_ADMM) < TOL                  # README.md:100-123
+    assert np.array_equal(beta != 0, readme.ENET_ADMM != 0)
+    ref = entry.admm_enet(x, y, [readme.LAMBDA], 100, 1e-4, True, True, 0.5, entry.LASSO_OPTS)
+    assert abs(int(fit.niter[0]) - int(ref["niter"][0])) <= 2
+
+
+@pytest.mark.parametrize("standardize,intercept", [(True, True), (True, False), (False, True), (False, False)])
+def test_tall_path_vs_oracle(standardize, intercept):
+    from admm_amd import admm_lasso
+    from oracle import entry
+    x, y = synth_lasso(2000, 300, 30, seed=7)
+    x += 0.7                                                     # non-zero column means so the flags matter
+    fit = admm_lasso(x, y, intercept=intercept, standardize=standardize).penalty(nlambda=20).fit()
+    ref = entry.admm_lasso(x, y, None, 20, 1e-4, standardize, intercept, entry.LASSO_OPTS)
+    assert np.allclose(fit.lambda_, ref["lambda"], rtol=1e-5)
+    for j in range(20):
+        assert relerr(fit.beta_dense[:, j], ref["beta"][:, j]) < TOL, j
+    assert np.abs(fit.niter.astype(int) - ref["niter"].astype(int)).max() <= 3
+    # first lambda = lambda_max: all coefficients zero
+    assert np.count_nonzero(fit.beta_dense[1:, 0]) == 0
+
+
+def test_tall_enet_path_vs_oracle():
+    from admm_amd import admm_enet
+    from oracle import entry
+    x, y = synth_lasso(1500, 200, 20, seed=11)
+    fit = admm_enet(x, y).penalty(nlambda=15, alpha=0.6).fit()
+    ref = entry.admm_enet(x, y, None, 15, 1e-4, True, True, 0.6, entry.LASSO_OPTS)
+    for j in range(15):
+        assert relerr(fit.beta_dense[:, j], ref["beta"][:, j]) < TOL, j
+    assert np.abs(fit.niter.astype(int) - ref["niter"].astype(int)).max() <= 3
+
+
+def test_tall_ragged_and_maxit():
+    """p not a multiple of anything, user lambda grid, and the maxit exit (niter = maxit + 1)."""
+    from admm_amd import admm_lasso
+    from oracle import entry
+    x, y = synth_lasso(523, 97, 9, seed=3)
+    lam = [0.5, 0.1, 0.02]
+    fit = admm_lasso(x, y).penalty(lam).opts(maxit=5).fit()
+    opts = dict(entry.LASSO_OPTS, maxit=5)
+    ref = entry.admm_lasso(x, y, lam, 100, 1e-4, True, True, opts)
+    assert list(fit.niter) == list(ref["niter"])
+    for j in range(3):
+        assert relerr(fit.beta_dense[:, j], ref["beta"][:, j]) < TOL, j
+    fit = admm_lasso(x, y).penalty(lam).fit()
+    ref = entry.admm_lasso(x, y, lam, 100, 1e-4, True, True, entry.LASSO_OPTS)
+    for j in range(3):
+        assert relerr(fit.beta_dense[:, j], ref["beta"][:, j]) < TOL, j
+
+
+def test_device_resident_input_matches_host_input():
+    """ADMM_MEM_DEVICE path (what bench.py uses) gives the same result as host input."""
+    import torch
+    from admm_amd import admm_lasso, DevicePtr
+    x, y = synth_lasso(1200, 150, 15, seed=5)
+    fit_h = admm_lasso(x, y).penalty(nlambda=8).fit()
+    xd = torch.tensor(np.asfortranarray(x).T.copy(), device="cuda")      # p x n row-major == n x p column-major
+    yd = torch.tensor(y, device="cuda")
+    torch.cuda.synchronize()
+    fit_d = admm_lasso(DevicePtr(xd.data_ptr()), DevicePtr(yd.data_ptr()), n=1200, p=150).penalty(nlambda=8).fit()
+    assert np.array_equal(fit_h.beta_dense, fit_d.beta_dense)
+    assert list(fit_h.niter) == list(fit_d.niter)
