@@ -61,6 +61,7 @@ __global__ void __launch_bounds__(kTailThreads)
 tall_tail_kernel(TallParams q, int par) {
     __shared__ double sums[8];
     __shared__ double scratch[6 * (kTailThreads / 64)];
+    extern __shared__ __attribute__((aligned(16))) double pstage[];     // nwg * 8 doubles
     const TallCtl in = q.ctl[par];
     TallCtl* outp = &q.ctl[par ^ 1];
     if (in.done) {
@@ -68,13 +69,18 @@ tall_tail_kernel(TallParams q, int par) {
         return;
     }
     // ---- decision from the previous iteration's norm partials (every workgroup, identically)
-    if (threadIdx.x < 6) {
+    {   // all threads fetch the partials in parallel (one latency), then 6 threads add them in a fixed order
         const double* Pin = q.P + (size_t)par * q.nwg * 8;
-        double s = 0.0;
-        for (int w = 0; w < q.nwg; ++w) s += Pin[(size_t)w * 8 + threadIdx.x];
-        sums[threadIdx.x] = s;
+        const int np = q.nwg * 8;
+        for (int k = threadIdx.x; k < np; k += kTailThreads) pstage[k] = Pin[k];
+        __syncthreads();
+        if (threadIdx.x < 6) {
+            double s = 0.0;
+            for (int w = 0; w < q.nwg; ++w) s += pstage[w * 8 + threadIdx.x];
+            sums[threadIdx.x] = s;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     const double r2 = sums[0], dz2 = sums[1], daz2 = sums[2], x2 = sums[3], z2 = sums[4], y2 = sums[5];
     TallCtl out = in;
     out.first = 0;
@@ -314,7 +320,7 @@ struct TallPlan final : LassoPlan {
                 launch_gemv_t<float, 2, 4>(pl, M.get(), ldp, p, p, u.get(), w.get(), a_part.get(), b_part.get(), ldp,
                                            &ctl.get()[par].done, st);
                 if (sample) ADMM_HIP_CHECK(hipEventRecord(e1, st));
-                hipLaunchKernelGGL(tall_tail_kernel, dim3(nwg), dim3(kTailThreads), 0, st, q, par);
+                hipLaunchKernelGGL(tall_tail_kernel, dim3(nwg), dim3(kTailThreads), (size_t)nwg * 8 * sizeof(double), st, q, par);
                 ++launches;
             }
             // after an even number of iterations the freshest control block is slot g&1 == 0
