@@ -1,0 +1,349 @@
+// Least-absolute-deviation and basis-pursuit solvers (fp64), device resident.
+//
+// Replaces ADMMLAD / ADMMBP driven by FADMMBase::solve:
+//   /root/reference/src/FADMMBase.h:109-133 (update_rho), :185-265 (solve)
+//   /root/reference/src/ADMMLAD.h:62-107 (next_x/next_z/next_residual), :152-169 (eps/resid), :172-225 (setup, get_x)
+//   /root/reference/src/ADMMBP.h:48-93, :138-153, :157-197
+//
+// Per iteration: `head` (decision of the previous iteration evaluated redundantly by every
+// workgroup from the norm partials -> acceleration/restart scalars, rho adaptation, convergence;
+// then adj_z/adj_y and the vector the projection is applied to), 2-3 streaming mat-vecs
+// (gemv_t on the matrix and on its stored transpose, so every product reads contiguous columns),
+// `tail` (x, soft-threshold z, dual y, six squared norms).  The host enqueues iterations in
+// batches and polls a sticky `done` word; no per-iteration synchronisation.
+#include "prep.h"
+#include "gemv_kernels.h"
+#include "solvers.h"
+#include "loop_driver.h"
+
+namespace admm {
+
+struct DenseCtl {
+    double rho, eps_primal, eps_dual, adj_a, adj_c, tau;
+    int restart, iter, done, first, total, niter, conv, pad;
+};
+
+struct DenseParams {
+    int dim, prob, maxit, nwg_tail;          // prob: 0 = LAD, 1 = BP
+    double eps_abs, eps_rel, sqrt_dim, extra_norm;
+    const double* data_vec;                   // LAD: y (n);  BP: A'(AA')^-1 b (p)
+    double *x, *z0, *z1, *y0, *y1, *adj_z, *adj_y, *vec;
+    const double* gout; int gout_nseg; long long gout_stride;
+    DenseCtl* ctl;                            // [2]
+    double* P;                                // [nwg_tail][8]
+    int* done;
+};
+
+constexpr int kDenseThreads = 256;
+
+__device__ __forceinline__ double soft1(double v, double pen) {
+    return v > pen ? v - pen : (v < -pen ? v + pen : 0.0);
+}
+
+__global__ void __launch_bounds__(kDenseThreads)
+dense_head_kernel(DenseParams q, int par) {
+    __shared__ double sums[8];
+    extern __shared__ __attribute__((aligned(16))) double pstage[];
+    const DenseCtl in = q.ctl[par];
+    DenseCtl* outp = &q.ctl[par ^ 1];
+    if (in.done) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) *outp = in;
+        return;
+    }
+    const int np = q.nwg_tail * 8;
+    for (int k = threadIdx.x; k < np; k += kDenseThreads) pstage[k] = q.P[k];
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        double s = 0.0;
+        for (int w = 0; w < q.nwg_tail; ++w) s += pstage[w * 8 + threadIdx.x];
+        sums[threadIdx.x] = s;
+    }
+    __syncthreads();
+    const double r2 = sums[0], dz2 = sums[1], daz2 = sums[2], x2 = sums[3], z2 = sums[4], y2 = sums[5];
+    DenseCtl out = in;
+    out.first = 0;
+    bool write_adj = true;
+    if (!in.first) {
+        const double rp = sqrt(r2), rd = in.rho * sqrt(dz2);
+        if (rp < in.eps_primal && rd < in.eps_dual) {          // converged(): adj_z/adj_y/rho stay as they are
+            out.done = 1; out.conv = 1; out.niter = in.iter + 1;
+            write_adj = false;
+        } else {
+            const double old_c = in.adj_c;
+            const double c = in.rho * rp * rp + in.rho * daz2;
+            if (c < 0.999 * old_c) {
+                const double old_a = in.adj_a;
+                const double a = 0.5 + 0.5 * sqrt(1.0 + 4.0 * old_a * old_a);
+                out.adj_a = a; out.adj_c = c; out.tau = (old_a - 1.0) / a; out.restart = 0;
+            } else {
+                out.adj_a = 1.0; out.adj_c = old_c / 0.999; out.tau = -1.0; out.restart = 1;
+            }
+            if (in.iter > 5) {                                 // update_rho(), FADMMBase.h:109-133,258-259
+                double rho = in.rho;
+                if (rp / in.eps_primal > 10 * rd / in.eps_dual) rho *= 2;
+                else if (rd / in.eps_dual > 10 * rp / in.eps_primal) rho /= 2;
+                if (rp < in.eps_primal) rho /= 1.2;
+                if (rd < in.eps_dual) rho *= 1.2;
+                out.rho = rho;
+            }
+            out.iter = in.iter + 1;
+            if (in.iter + 1 >= q.maxit) { out.done = 1; out.conv = 0; out.niter = q.maxit + 1; }
+        }
+    } else {
+        out.tau = 0.0; out.restart = 0;
+    }
+    out.eps_primal = fmax(fmax(sqrt(x2), sqrt(z2)), q.extra_norm) * q.eps_rel + q.sqrt_dim * q.eps_abs;
+    out.eps_dual = sqrt(y2) * q.eps_rel + q.sqrt_dim * q.eps_abs;
+    out.total = out.done ? in.total : in.total + 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *outp = out;
+        if (out.done) *q.done = 1;
+    }
+    if (!write_adj) return;
+
+    const int cur = in.total & 1;
+    const double* zc_ = cur ? q.z1 : q.z0; const double* yc_ = cur ? q.y1 : q.y0;
+    const double* zo_ = cur ? q.z0 : q.z1; const double* yo_ = cur ? q.y0 : q.y1;
+    const double t = out.tau, t1 = 1.0 + out.tau, rho = out.rho;
+    for (int i = blockIdx.x * kDenseThreads + threadIdx.x; i < q.dim; i += gridDim.x * kDenseThreads) {
+        double adjz, adjy;
+        if (out.restart) { adjz = zo_[i]; adjy = yo_[i]; }
+        else { adjz = t1 * zc_[i] - t * zo_[i]; adjy = t1 * yc_[i] - t * yo_[i]; }
+        q.adj_z[i] = adjz; q.adj_y[i] = adjy;
+        // LAD: vec = y - adj_y / rho + adj_z (ADMMLAD.h:64-65);  BP: vec = -adj_y / rho + adj_z (ADMMBP.h:50-55)
+        q.vec[i] = (q.prob == 0 ? q.data_vec[i] : 0.0) - adjy / rho + adjz;
+    }
+}
+
+__global__ void __launch_bounds__(kDenseThreads)
+dense_tail_kernel(DenseParams q, int par) {
+    __shared__ double scratch[6 * (kDenseThreads / 64)];
+    const DenseCtl c = q.ctl[par ^ 1];           // written by this iteration's head
+    if (c.done) return;
+    const int cur = (c.total - 1) & 1;           // head already advanced `total`
+    const double* zc_ = cur ? q.z1 : q.z0;
+    double* zn_ = cur ? q.z0 : q.z1; double* yn_ = cur ? q.y0 : q.y1;
+    const double rho = c.rho, pen = 1.0 / rho;
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = blockIdx.x * kDenseThreads + threadIdx.x; i < q.dim; i += gridDim.x * kDenseThreads) {
+        double g = 0.0;
+        for (int s = 0; s < q.gout_nseg; ++s) g += q.gout[(size_t)s * q.gout_stride + i];
+        const double adjy = q.adj_y[i], adjz = q.adj_z[i], zc = zc_[i];
+        double x, zn, r;
+        if (q.prob == 0) {                        // LAD: x = P_X(vec); z = soft(x - y + adj_y/rho, 1/rho); r = x - y - z
+            x = g;
+            const double d = q.data_vec[i];
+            zn = soft1(x - d + adjy / rho, pen);
+            r = x - d - zn;
+        } else {                                  // BP: x = vec + A'(AA')^-1 b - B'(B vec); z = soft(x + adj_y/rho, 1/rho); r = x - z
+            x = q.vec[i] + q.data_vec[i] - g;
+            zn = soft1(x + adjy / rho, pen);
+            r = x - zn;
+        }
+        const double yn = adjy + rho * r;
+        const double dz = zn - zc, daz = zn - adjz;
+        acc[0] += r * r; acc[1] += dz * dz; acc[2] += daz * daz; acc[3] += x * x; acc[4] += zn * zn; acc[5] += yn * yn;
+        q.x[i] = x; zn_[i] = zn; yn_[i] = yn;
+    }
+    block_sum<double, 6>(acc, scratch);
+    if (threadIdx.x == 0) {
+        double* Pout = q.P + (size_t)blockIdx.x * 8;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) Pout[k] = acc[k];
+    }
+}
+
+__global__ void dense_init_kernel(DenseParams q, double rho) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < q.dim) { q.x[i] = 0; q.z0[i] = 0; q.z1[i] = 0; q.y0[i] = 0; q.y1[i] = 0; q.adj_z[i] = 0; q.adj_y[i] = 0; q.vec[i] = 0; }
+    if (i < q.nwg_tail * 8) q.P[i] = 0.0;
+    if (i == 0) {
+        DenseCtl c;
+        c.rho = rho; c.eps_primal = 0; c.eps_dual = 0; c.adj_a = 1.0; c.adj_c = 9999.0; c.tau = 0.0;
+        c.restart = 0; c.iter = 0; c.done = 0; c.first = 1; c.total = 0; c.niter = 0; c.conv = 0; c.pad = 0;
+        q.ctl[0] = c; q.ctl[1] = c;
+        *q.done = 0;
+    }
+}
+
+// vec = y - adj_y / rho + adj_z for LAD's get_x (ADMMLAD.h:220-225)
+__global__ void lad_final_vec_kernel(const double* y, const double* adj_y, const double* adj_z, double rho, int n, double* vec) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) vec[i] = y[i] - adj_y[i] / rho + adj_z[i];
+}
+
+__global__ void __launch_bounds__(1024)
+norm2_kernel(const double* v, int n, double* out) {
+    __shared__ double scratch[16];
+    double s[1] = {0.0};
+    for (int i = threadIdx.x; i < n; i += 1024) s[0] += v[i] * v[i];
+    block_sum<double, 1>(s, scratch);
+    if (threadIdx.x == 0) out[0] = sqrt(s[0]);
+}
+
+namespace {
+
+struct DenseLoop {
+    DevBuf<double> x, z0, z1, y0, y1, adj_z, adj_y, vec, P;
+    DevBuf<DenseCtl> ctl;
+    DevBuf<int> done;
+    DenseParams q{};
+    int nwg_head = 0;
+
+    void init(int dim, int prob, const admm_opts& o, const double* data_vec, double extra_norm, hipStream_t st) {
+        const long long ld = round_up(dim, 32);
+        for (DevBuf<double>* b : {&x, &z0, &z1, &y0, &y1, &adj_z, &adj_y, &vec}) { b->alloc(ld); b->zero(st); }
+        const int nwg_tail = std::max(1, std::min(64, (dim + kDenseThreads - 1) / kDenseThreads));
+        nwg_head = std::max(1, std::min(device_info().num_cu, (dim + kDenseThreads - 1) / kDenseThreads));
+        P.alloc((size_t)nwg_tail * 8); ctl.alloc(2); done.alloc(1);
+        q.dim = dim; q.prob = prob; q.maxit = o.maxit; q.nwg_tail = nwg_tail;
+        q.eps_abs = o.eps_abs; q.eps_rel = o.eps_rel; q.sqrt_dim = std::sqrt((double)dim); q.extra_norm = extra_norm;
+        q.data_vec = data_vec;
+        q.x = x.get(); q.z0 = z0.get(); q.z1 = z1.get(); q.y0 = y0.get(); q.y1 = y1.get();
+        q.adj_z = adj_z.get(); q.adj_y = adj_y.get(); q.vec = vec.get();
+        q.ctl = ctl.get(); q.P = P.get(); q.done = done.get();
+        const int init_n = std::max(dim, nwg_tail * 8);
+        hipLaunchKernelGGL(dense_init_kernel, dim3((init_n + 255) / 256), dim3(256), 0, st, q, o.rho);
+    }
+    void head(long long g, hipStream_t st) {
+        hipLaunchKernelGGL(dense_head_kernel, dim3(nwg_head), dim3(kDenseThreads), (size_t)q.nwg_tail * 8 * sizeof(double), st, q, (int)(g & 1));
+    }
+    void tail(long long g, hipStream_t st) {
+        hipLaunchKernelGGL(dense_tail_kernel, dim3(q.nwg_tail), dim3(kDenseThreads), 0, st, q, (int)(g & 1));
+    }
+    DenseCtl final_ctl(hipStream_t st) {
+        DenseCtl h[2];
+        ADMM_HIP_CHECK(hipMemcpyAsync(h, ctl.get(), sizeof(h), hipMemcpyDeviceToHost, st));
+        ADMM_HIP_CHECK(hipStreamSynchronize(st));
+        return h[0].done ? h[0] : h[1];
+    }
+};
+
+int env_batch(int dflt) {
+    const char* v = std::getenv("ADMM_HIP_BATCH_ITERS");
+    int b = v ? std::atoi(v) : dflt;
+    if (b <= 0) b = dflt;
+    return (b + 1) / 2 * 2;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------- LAD
+void solve_lad(const DeviceData<double>& d, const admm_opts& opts, DenseResult& res, hipStream_t st) {
+    const int n = d.n, p = d.p;
+    admm_stats& S = res.stats;
+    const long long ldp = round_up(p, 32);
+
+    // X'X, its inverse (LLT of X'X in the reference, ADMMLAD.h:186-189), X' stored for the X*s product
+    double t0 = now_s();
+    DevBuf<double> M((size_t)ldp * p); M.zero(st);
+    gram_full<double>(d.X.get(), d.ldx, n, p, true, M.get(), ldp, st);
+    ADMM_HIP_CHECK(hipStreamSynchronize(st));
+    S.t_gram = now_s() - t0;
+    t0 = now_s();
+    spd_inverse_full<double>(M.get(), ldp, p, st);
+    const long long ldxt = round_up(p, 32);
+    DevBuf<double> Xt((size_t)ldxt * n); Xt.zero(st);
+    transpose<double>(d.X.get(), d.ldx, n, p, Xt.get(), ldxt, st);
+    ADMM_HIP_CHECK(hipStreamSynchronize(st));
+    S.t_factor = now_s() - t0;
+
+    DevBuf<double> ynorm_d(1);
+    hipLaunchKernelGGL(norm2_kernel, dim3(1), dim3(1024), 0, st, d.Y.get(), n, ynorm_d.get());
+    double ynorm = 0;
+    ADMM_HIP_CHECK(hipMemcpyAsync(&ynorm, ynorm_d.get(), sizeof(double), hipMemcpyDeviceToHost, st));
+    ADMM_HIP_CHECK(hipStreamSynchronize(st));
+
+    DenseLoop L;
+    L.init(n, 0, opts, d.Y.get(), ynorm, st);
+    GemvT<double> g1, g2, g3;                    // t = X' vec ; s = (X'X)^-1 t ; xs = X s
+    g1.init(d.X.get(), d.ldx, n, p);
+    g2.init(M.get(), ldp, p, p);
+    g3.init(Xt.get(), ldxt, p, n);
+    DevBuf<double> tvec(ldp), svec(ldp);
+    tvec.zero(st); svec.zero(st);
+    L.q.gout = g3.part.get(); L.q.gout_nseg = g3.pl.nseg; L.q.gout_stride = g3.stride;
+
+    const int* skip = L.done.get();
+    LoopTimes lt = run_until_done(st, skip, env_batch(8), (long long)opts.maxit + 2, [&](long long g) {
+        L.head(g, st);
+        g1.run(L.vec.get(), tvec.get(), skip, st);
+        g2.run(tvec.get(), svec.get(), skip, st);
+        g3.run_partials(svec.get(), skip, st);
+        L.tail(g, st);
+    });
+    S.t_loop = lt.wall_s; S.loop_ms_events = lt.events_ms; S.xupdate_launches = lt.launched;
+
+    const DenseCtl fc = L.final_ctl(st);
+    res.niter = fc.niter;
+    S.total_iter = fc.niter; S.rho = fc.rho;
+    // get_x(): beta = (X'X)^-1 X' (y - adj_y/rho + adj_z) with the final adj and rho (ADMMLAD.h:220-225)
+    hipLaunchKernelGGL(lad_final_vec_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d.Y.get(), L.adj_y.get(), L.adj_z.get(), fc.rho, n, L.vec.get());
+    g1.run(L.vec.get(), tvec.get(), nullptr, st);
+    g2.run(tvec.get(), svec.get(), nullptr, st);
+    std::vector<double> coef(p), out(p);
+    ADMM_HIP_CHECK(hipMemcpyAsync(coef.data(), svec.get(), (size_t)p * sizeof(double), hipMemcpyDeviceToHost, st));
+    ADMM_HIP_CHECK(hipStreamSynchronize(st));
+    double b0 = 0;
+    recover_coef<double>(d, coef.data(), &b0, out.data());      // LAD.cpp:41
+    res.beta.assign(p + 1, 0.0);
+    res.beta[0] = b0;
+    for (int j = 0; j < p; ++j) res.beta[j + 1] = out[j];
+}
+
+// ---------------------------------------------------------------------------------------------- BP
+void solve_bp(const DeviceData<double>& d, const admm_opts& opts, DenseResult& res, hipStream_t st) {
+    const int n = d.n, p = d.p;
+    admm_stats& S = res.stats;
+    const long long ldn = round_up(n, 32);
+
+    // AA' = LL' (ADMMBP.h:167-169)
+    double t0 = now_s();
+    DevBuf<double> G((size_t)ldn * n); G.zero(st);
+    gram_full<double>(d.X.get(), d.ldx, n, p, false, G.get(), ldn, st);
+    ADMM_HIP_CHECK(hipStreamSynchronize(st));
+    S.t_gram = now_s() - t0;
+    t0 = now_s();
+    cholesky_lower<double>(G.get(), ldn, n, st);
+    // B = L^-1 A (ADMMBP.h:173-182) and its transpose; w0 = L^-1 b; cache_AAAb = B' w0 = A'(AA')^-1 b (:170)
+    DevBuf<double> B((size_t)d.ldx * p);
+    ADMM_HIP_CHECK(hipMemcpyAsync(B.get(), d.X.get(), (size_t)d.ldx * p * sizeof(double), hipMemcpyDeviceToDevice, st));
+    trsm_left_lower<double>(G.get(), ldn, n, B.get(), d.ldx, p, st);
+    DevBuf<double> w0(d.ldx);
+    ADMM_HIP_CHECK(hipMemcpyAsync(w0.get(), d.Y.get(), (size_t)d.ldx * sizeof(double), hipMemcpyDeviceToDevice, st));
+    trsm_left_lower<double>(G.get(), ldn, n, w0.get(), d.ldx, 1, st);
+    const long long ldbt = round_up(p, 32);
+    DevBuf<double> Bt((size_t)ldbt * n); Bt.zero(st);
+    transpose<double>(B.get(), d.ldx, n, p, Bt.get(), ldbt, st);
+    const long long ldp = round_up(p, 32);
+    DevBuf<double> AAAb(ldp); AAAb.zero(st);
+    GemvT<double> gB, gBt;                       // t = B' w (p outputs) ; w = B vec (n outputs, via the stored transpose)
+    gB.init(B.get(), d.ldx, n, p);
+    gBt.init(Bt.get(), ldbt, p, n);
+    gB.run(w0.get(), AAAb.get(), nullptr, st);
+    ADMM_HIP_CHECK(hipStreamSynchronize(st));
+    S.t_factor = now_s() - t0;
+
+    DenseLoop L;
+    L.init(p, 1, opts, AAAb.get(), 0.0, st);
+    DevBuf<double> wvec(ldn); wvec.zero(st);
+    L.q.gout = gB.part.get(); L.q.gout_nseg = gB.pl.nseg; L.q.gout_stride = gB.stride;
+
+    const int* skip = L.done.get();
+    LoopTimes lt = run_until_done(st, skip, env_batch(8), (long long)opts.maxit + 2, [&](long long g) {
+        L.head(g, st);
+        gBt.run(L.vec.get(), wvec.get(), skip, st);     // workspace = B vec   (mat_vec_prod,  ADMMBP.h:65)
+        gB.run_partials(wvec.get(), skip, st);          // B' workspace        (mat_vec_tprod, ADMMBP.h:66)
+        L.tail(g, st);
+    });
+    S.t_loop = lt.wall_s; S.loop_ms_events = lt.events_ms; S.xupdate_launches = lt.launched;
+
+    const DenseCtl fc = L.final_ctl(st);
+    res.niter = fc.niter;
+    S.total_iter = fc.niter; S.rho = fc.rho;
+    const double* zfin = (fc.total & 1) ? L.z1.get() : L.z0.get();      // get_z() (BP.cpp:40)
+    res.beta.assign(p, 0.0);
+    ADMM_HIP_CHECK(hipMemcpy(res.beta.data(), zfin, (size_t)p * sizeof(double), hipMemcpyDeviceToHost));
+}
+
+}  // namespace admm

@@ -172,12 +172,37 @@ inline void launch_gemv_t(const GemvTPlan& pl, const T* A, long long lda, int m,
 
 // Sum the nseg partial rows of a gemv_t result: y[j] = sum_s part[s*stride + j].
 template <typename T>
-__global__ void reduce_partials_kernel(const T* part, long long stride, int nseg, int k, T* y) {
+__global__ void reduce_partials_kernel(const T* part, long long stride, int nseg, int k, T* y, const int* skip = nullptr) {
+    if (skip != nullptr && *skip != 0) return;
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= k) return;
     T s = 0;
     for (int i = 0; i < nseg; ++i) s += part[(size_t)i * stride + j];
     y[j] = s;
 }
+
+// y = A' v for a fixed column-major matrix with preallocated partial buffers (single right-hand side).
+template <typename T>
+struct GemvT {
+    const T* A = nullptr;
+    long long lda = 0, stride = 0;
+    int m = 0, k = 0;
+    GemvTPlan pl;
+    DevBuf<T> part;
+    void init(const T* A_, long long lda_, int m_, int k_, int wg_per_cu = 4) {
+        A = A_; lda = lda_; m = m_; k = k_;
+        pl = plan_gemv_t<T>(m, k, 1, 4, 0, wg_per_cu);
+        stride = round_up(k, 32);
+        part.alloc((size_t)pl.nseg * stride);
+    }
+    // partials only: part[s * stride + j]
+    void run_partials(const T* v, const int* skip, hipStream_t st) {
+        launch_gemv_t<T, 1, 4>(pl, A, lda, m, k, v, nullptr, part.get(), nullptr, stride, skip, st);
+    }
+    void run(const T* v, T* y, const int* skip, hipStream_t st) {
+        run_partials(v, skip, st);
+        hipLaunchKernelGGL((reduce_partials_kernel<T>), dim3((k + 255) / 256), dim3(256), 0, st, part.get(), stride, pl.nseg, k, y, skip);
+    }
+};
 
 }  // namespace admm

@@ -1,0 +1,55 @@
+// Host side of the device-resident ADMM loops: enqueue iterations in batches without waiting for
+// the device, poll a sticky `done` word through pinned memory, always keeping one batch in flight.
+#pragma once
+#include "admm_internal.h"
+
+namespace admm {
+
+struct LoopTimes {
+    double wall_s = 0;
+    double events_ms = 0;
+    long long launched = 0;
+};
+
+// enqueue(g): enqueue every kernel of iteration g (g = 0, 1, 2, ...) on `st`.
+// d_done: device int that the iteration kernels set to non-zero once the solve is finished; all
+// kernels must be no-ops afterwards.  `batch` iterations are enqueued between two polls.
+template <typename F>
+inline LoopTimes run_until_done(hipStream_t st, const int* d_done, int batch, long long max_iters, F&& enqueue) {
+    int* h_done = nullptr;
+    ADMM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_done), 2 * sizeof(int), hipHostMallocDefault));
+    struct HostFree { void* p; ~HostFree() { (void)hipHostFree(p); } } hf{h_done};
+    h_done[0] = h_done[1] = 0;
+    Event ev0, ev1, poll[2];
+    LoopTimes t;
+    ADMM_HIP_CHECK(hipStreamSynchronize(st));
+    const double t0 = now_s();
+    ADMM_HIP_CHECK(hipEventRecord(ev0.e, st));
+    long long g = 0;
+    auto enqueue_batch = [&](int slot) {
+        for (int k = 0; k < batch; ++k, ++g) enqueue(g);
+        ADMM_HIP_CHECK(hipMemcpyAsync(&h_done[slot], d_done, sizeof(int), hipMemcpyDeviceToHost, st));
+        ADMM_HIP_CHECK(hipEventRecord(poll[slot].e, st));
+    };
+    int slot = 0;
+    enqueue_batch(slot);
+    bool done = false;
+    while (!done) {
+        enqueue_batch(slot ^ 1);
+        ADMM_HIP_CHECK(hipEventSynchronize(poll[slot].e));
+        done = h_done[slot] != 0;
+        slot ^= 1;
+        if (!done && g > max_iters + 2 * batch)
+            throw Error(ADMM_ERR_INTERNAL, "ADMM loop: iteration bound exceeded without completion");
+    }
+    ADMM_HIP_CHECK(hipEventRecord(ev1.e, st));
+    ADMM_HIP_CHECK(hipStreamSynchronize(st));
+    t.wall_s = now_s() - t0;
+    float ms = 0.f;
+    ADMM_HIP_CHECK(hipEventElapsedTime(&ms, ev0.e, ev1.e));
+    t.events_ms = ms;
+    t.launched = g;
+    return t;
+}
+
+}  // namespace admm

@@ -2,6 +2,4 @@
 namespace admm {
 std::unique_ptr<LassoPlan> make_wide_plan(DeviceData<float>&&, const LassoProblem&, hipStream_t) { throw Error(ADMM_ERR_INTERNAL, "wide path not built yet"); }
 std::unique_ptr<LassoPlan> make_par_plan(DeviceData<float>&&, const LassoProblem&, hipStream_t) { throw Error(ADMM_ERR_INTERNAL, "consensus path not built yet"); }
-void solve_lad(const DeviceData<double>&, const admm_opts&, DenseResult&, hipStream_t) { throw Error(ADMM_ERR_INTERNAL, "LAD not built yet"); }
-void solve_bp(const DeviceData<double>&, const admm_opts&, DenseResult&, hipStream_t) { throw Error(ADMM_ERR_INTERNAL, "BP not built yet"); }
 }
