@@ -1,0 +1,351 @@
+// Row-block consensus Lasso (`$parallel()`), device resident.
+//
+// Replaces PADMMLasso_Master / PADMMLasso_Worker driven by PADMMBase_Master::solve:
+//   /root/reference/src/PADMMBase.h:57-78 (worker update_y), :117-145 (eps / resid), :174-237 (solve)
+//   /root/reference/src/PADMMLasso.h:17-31 (worker next_x: Cholesky or Woodbury), :48-68 (init, add_xu_to),
+//   :99-108 (master next_z), :149-152, :163-179 (row partition), :193-223 (init / init_warm)
+//   and the lambda loop of ParLasso.cpp:89-102.
+//
+// Workers are the reference's contiguous row blocks (last block takes the remainder).  Each
+// worker's solve uses a cached inverse: (A'A + rho I)^-1 for a tall block, or the Woodbury form
+// x = (rhs - A'(AA' + rho I)^-1 A rhs) / rho for a wide block, with A and A' both stored so that
+// every product streams contiguous columns (gemv_t).  rho never changes (PADMMBase.h:147-159).
+// Per iteration: head (convergence decision of the previous iteration + lambda schedule + rhs_k),
+// the workers' mat-vecs, pack (x_k and the consensus sum  sum_k x_k + y_k/rho), z (soft-threshold,
+// dual updates, norms).  The consensus sum is the only cross-worker exchange; it is a separate
+// buffer so that a multi-process build can all-reduce it between `pack` and `z`.
+#include "prep.h"
+#include "gemv_kernels.h"
+#include "solvers.h"
+#include "loop_driver.h"
+
+namespace admm {
+
+struct ParCtl {
+    double lam, eps_primal, eps_dual;
+    int iter, lam_idx, done, first, total, pad0, pad1, pad2;
+};
+
+constexpr int kParMaxWorkers = 64;
+constexpr int kParThreads = 256;
+
+struct ParParams {
+    int p, K, maxit, nlam, nwg;
+    long long ldv;                 // stride between the per-worker p-vectors
+    double rho, eps_abs, eps_rel;
+    const double* lambdas;
+    const float* Ab;               // [K][ldv]
+    float* rhs;                    // [K][ldv]
+    float* x;                      // [K][ldv]
+    float* y;                      // [K][ldv]
+    float* z;                      // [ldv]
+    float* wsum;                   // [ldv]  consensus sum (the all-reduce payload)
+    // per worker: result of the last mat-vec of the x-update
+    const float* gout[kParMaxWorkers]; int gnseg[kParMaxWorkers]; long long gstride[kParMaxWorkers];
+    int wide[kParMaxWorkers];      // 1: Woodbury branch, x = (rhs - gout) / rho ; 0: x = gout
+    ParCtl* ctl;                   // [2]
+    double* P;                     // [nwg][8]: sum_k|x_k|^2, sum_k|y_k|^2, sum_k|x_k - z|^2, |z|^2, |z_new - z_old|^2
+    float* beta; int* niter; int* done;
+};
+
+// head(g): decision for iteration g-1 (PADMMBase.h:216-221, 230-231), eps for iteration g (:174-178),
+// then rhs_k = A_k'b_k - y_k + rho z (PADMMLasso.h:19-21).
+__global__ void __launch_bounds__(kParThreads)
+par_head_kernel(ParParams q, int par) {
+    __shared__ double sums[8];
+    extern __shared__ __attribute__((aligned(16))) double pstage[];
+    const ParCtl in = q.ctl[par];
+    ParCtl* outp = &q.ctl[par ^ 1];
+    if (in.done) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) *outp = in;
+        return;
+    }
+    const int np = q.nwg * 8;
+    for (int k = threadIdx.x; k < np; k += kParThreads) pstage[k] = q.P[k];
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        double s = 0.0;
+        for (int w = 0; w < q.nwg; ++w) s += pstage[w * 8 + threadIdx.x];
+        sums[threadIdx.x] = s;
+    }
+    __syncthreads();
+    const double x2 = sums[0], y2 = sums[1], r2 = sums[2], z2 = sums[3], dz2 = sums[4];
+    ParCtl out = in;
+    out.first = 0;
+    int lam_finished = -1, niter_val = 0;
+    if (!in.first) {
+        const double rp = sqrt(r2);                                  // sqrt(sum_k |x_k - z|^2)        PADMMBase.h:213
+        const double rd = q.rho * sqrt((double)q.K * dz2);           // rho sqrt(K |z_new - z|^2)      PADMMLasso.h:149-152
+        if (rp < in.eps_primal && rd < in.eps_dual) { lam_finished = in.lam_idx; niter_val = in.iter + 1; }
+        else {
+            out.iter = in.iter + 1;
+            if (in.iter + 1 >= q.maxit) { lam_finished = in.lam_idx; niter_val = q.maxit + 1; }
+        }
+        if (lam_finished >= 0) {
+            out.lam_idx = in.lam_idx + 1; out.iter = 0;
+            if (out.lam_idx >= q.nlam) out.done = 1;
+            else out.lam = q.lambdas[out.lam_idx];
+        }
+    }
+    const double sK = sqrt((double)q.K), spK = sqrt((double)q.p * (double)q.K);
+    out.eps_primal = fmax(sqrt(x2), sqrt(z2) * sK) * q.eps_rel + spK * q.eps_abs;   // PADMMBase.h:117-128
+    out.eps_dual = sqrt(y2) * q.eps_rel + spK * q.eps_abs;                           // PADMMBase.h:129-139
+    out.total = in.total + 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (lam_finished >= 0) q.niter[lam_finished] = niter_val;
+        *outp = out;
+        if (out.done) *q.done = 1;
+    }
+    for (int i = blockIdx.x * kParThreads + threadIdx.x; i < q.p; i += gridDim.x * kParThreads) {
+        const float z = q.z[i];
+        if (lam_finished >= 0) q.beta[(size_t)lam_finished * q.p + i] = z;           // get_z()  ParLasso.cpp:98
+        if (!out.done) {
+            const double rz = q.rho * (double)z;
+            for (int k = 0; k < q.K; ++k) {
+                const size_t o = (size_t)k * q.ldv + i;
+                const float r0 = q.Ab[o] - q.y[o];
+                q.rhs[o] = (float)((double)r0 + rz);                                  // rhs[idx] += rho * value (double)
+            }
+        }
+    }
+}
+
+// pack: x_k from the mat-vec results, consensus sum w = sum_k (x_k + y_k / rho)   (PADMMLasso.h:65-68,101-105)
+__global__ void __launch_bounds__(kParThreads)
+par_pack_kernel(ParParams q) {
+    if (*q.done) return;
+    const float rho_f = (float)q.rho;
+    for (int i = blockIdx.x * kParThreads + threadIdx.x; i < q.p; i += gridDim.x * kParThreads) {
+        float w = 0.f;
+        for (int k = 0; k < q.K; ++k) {
+            const size_t o = (size_t)k * q.ldv + i;
+            float g = 0.f;
+            for (int s = 0; s < q.gnseg[k]; ++s) g += q.gout[k][(size_t)s * q.gstride[k] + i];
+            const float x = q.wide[k] ? (q.rhs[o] - g) / rho_f : g;                   // PADMMLasso.h:23-30
+            q.x[o] = x;
+            w += x + q.y[o] / rho_f;
+        }
+        q.wsum[i] = w;
+    }
+}
+
+// z: z_new = soft(w / K, lambda / (rho K)); y_k += rho (x_k - z_new); norms   (PADMMLasso.h:99-108, PADMMBase.h:70-78)
+__global__ void __launch_bounds__(kParThreads)
+par_z_kernel(ParParams q, int par) {
+    __shared__ double scratch[5 * (kParThreads / 64)];
+    const ParCtl c = q.ctl[par ^ 1];
+    if (c.done) return;
+    const float rho_f = (float)q.rho;
+    const double pen = c.lam / (q.rho * (double)q.K);
+    double acc[5] = {0, 0, 0, 0, 0};
+    for (int i = blockIdx.x * kParThreads + threadIdx.x; i < q.p; i += gridDim.x * kParThreads) {
+        const float v = q.wsum[i] / (float)q.K;
+        const double vd = (double)v;
+        const float zn = vd > pen ? (float)(vd - pen) : (vd < -pen ? (float)(vd + pen) : 0.f);
+        const float zo = q.z[i];
+        for (int k = 0; k < q.K; ++k) {
+            const size_t o = (size_t)k * q.ldv + i;
+            const float x = q.x[o];
+            const float r = x - zn;
+            const float yn = q.y[o] + rho_f * r;
+            q.y[o] = yn;
+            acc[0] += (double)x * x; acc[1] += (double)yn * yn; acc[2] += (double)r * r;
+        }
+        const float dz = zn - zo;
+        acc[3] += (double)zn * zn; acc[4] += (double)dz * dz;
+        q.z[i] = zn;
+    }
+    block_sum<double, 5>(acc, scratch);
+    if (threadIdx.x == 0) {
+        double* Pout = q.P + (size_t)blockIdx.x * 8;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) Pout[k] = acc[k];
+    }
+}
+
+__global__ void par_init_kernel(ParParams q, double lam0) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < q.p) {
+        q.z[i] = 0.f; q.wsum[i] = 0.f;
+        for (int k = 0; k < q.K; ++k) { const size_t o = (size_t)k * q.ldv + i; q.x[o] = 0.f; q.y[o] = 0.f; q.rhs[o] = 0.f; }
+    }
+    if (i < q.nwg * 8) q.P[i] = 0.0;
+    if (i == 0) {
+        ParCtl c;
+        c.lam = lam0; c.eps_primal = 0; c.eps_dual = 0; c.iter = 0; c.lam_idx = 0; c.done = 0; c.first = 1; c.total = 0;
+        c.pad0 = c.pad1 = c.pad2 = 0;
+        q.ctl[0] = c; q.ctl[1] = c;
+        *q.done = 0;
+    }
+}
+
+__global__ void copy_rows_kernel(const float* X, long long ldx, int row0, int nrows, int p, float* A, long long lda) {
+    const int j = blockIdx.x;
+    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < nrows; i += gridDim.y * blockDim.x)
+        A[(size_t)j * lda + i] = X[(size_t)j * ldx + row0 + i];
+}
+
+struct ParWorker {
+    int rows = 0;
+    bool wide = false;
+    long long lda = 0, ldat = 0, ldm = 0;
+    DevBuf<float> A, At, Minv, tvec, svec;
+    GemvT<float> gA, gAt, gM;       // gA: A' v (p outputs); gAt: A v via the stored transpose (rows outputs); gM: cached inverse
+};
+
+struct ParPlan final : LassoPlan {
+    DeviceData<float> d;
+    LassoProblem pb;
+    hipStream_t st;
+    admm_stats setup_stats{};
+    int p = 0, K = 0, nlam = 0, nwg = 0;
+    long long ldv = 0;
+    double rho = 0;
+    std::vector<double> lam_user, lam_int;
+    std::vector<ParWorker> W;
+    DevBuf<float> Ab, rhs, x, y, z, wsum, beta;
+    DevBuf<int> niter, done;
+    DevBuf<double> P, dlam;
+    DevBuf<ParCtl> ctl;
+    ParParams q{};
+
+    ParPlan(DeviceData<float>&& data, const LassoProblem& prob, hipStream_t stream) : d(std::move(data)), pb(prob), st(stream) {
+        const int n = d.n;
+        p = d.p; K = pb.nworkers;
+        ADMM_REQUIRE(K >= 1 && K <= kParMaxWorkers, "number of row blocks must be within [1, 64]");
+        admm_stats& S = setup_stats;
+        S.branch = 2; S.t_h2d = d.t_h2d; S.t_standardize = d.t_std;
+        ldv = round_up(p, 32);
+
+        // lambda_0 from the full data (PADMMLasso.h:161)
+        DevBuf<float> XY(ldv); XY.zero(st);
+        gemv_t_simple<float>(d.X.get(), d.ldx, n, p, d.Y.get(), XY.get(), st);
+        const float lambda0 = device_absmax<float>(XY.get(), p, st);
+        lam_user = make_lambda_grid(pb, lambda0, n, (double)d.scaleY);
+        nlam = (int)lam_user.size();
+        lam_int.resize(nlam);
+        for (int i = 0; i < nlam; ++i) lam_int[i] = lam_user[i] * n / (double)d.scaleY;   // `double lambda` in the master
+        rho = pb.opts.rho;
+        if (rho <= 0) rho = lam_int[0] / K;                                                // PADMMLasso.h:199-200
+        S.rho = rho;
+
+        // row partition (PADMMLasso.h:163-179) and per-worker factorisations (:48-63)
+        Ab.alloc((size_t)K * ldv); Ab.zero(st);
+        W.resize(K);
+        const int chunk = n / K;
+        double t_gram = 0, t_fac = 0;
+        for (int k = 0; k < K; ++k) {
+            ParWorker& w = W[k];
+            const int lo = k * chunk;
+            w.rows = (k < K - 1) ? chunk : n - lo;
+            w.wide = w.rows < p;                                   // subA.rows() >= subA.cols() -> Cholesky branch
+            w.lda = round_up(w.rows, 32);
+            w.A.alloc((size_t)w.lda * p); w.A.zero(st);
+            hipLaunchKernelGGL(copy_rows_kernel, dim3(p, std::min(64, (w.rows + 255) / 256)), dim3(256), 0, st, d.X.get(), d.ldx, lo, w.rows, p, w.A.get(), w.lda);
+            DevBuf<float> bk(w.lda); bk.zero(st);
+            ADMM_HIP_CHECK(hipMemcpyAsync(bk.get(), d.Y.get() + lo, (size_t)w.rows * sizeof(float), hipMemcpyDeviceToDevice, st));
+            gemv_t_simple<float>(w.A.get(), w.lda, w.rows, p, bk.get(), Ab.get() + (size_t)k * ldv, st);   // A_k' b_k  (:42)
+            double t0 = now_s();
+            if (!w.wide) {
+                w.ldm = round_up(p, 32);
+                w.Minv.alloc((size_t)w.ldm * p); w.Minv.zero(st);
+                gram_full<float>(w.A.get(), w.lda, w.rows, p, true, w.Minv.get(), w.ldm, st);
+                ADMM_HIP_CHECK(hipStreamSynchronize(st));
+                t_gram += now_s() - t0; t0 = now_s();
+                add_diag<float>(w.Minv.get(), w.ldm, p, (float)rho, st);
+                spd_inverse_full<float>(w.Minv.get(), w.ldm, p, st);
+                w.gM.init(w.Minv.get(), w.ldm, p, p);
+                A_release_if_tall(w);
+            } else {
+                w.ldm = round_up(w.rows, 32);
+                w.Minv.alloc((size_t)w.ldm * w.rows); w.Minv.zero(st);
+                gram_full<float>(w.A.get(), w.lda, w.rows, p, false, w.Minv.get(), w.ldm, st);
+                ADMM_HIP_CHECK(hipStreamSynchronize(st));
+                t_gram += now_s() - t0; t0 = now_s();
+                add_diag<float>(w.Minv.get(), w.ldm, w.rows, (float)rho, st);
+                spd_inverse_full<float>(w.Minv.get(), w.ldm, w.rows, st);
+                w.ldat = round_up(p, 32);
+                w.At.alloc((size_t)w.ldat * w.rows); w.At.zero(st);
+                transpose<float>(w.A.get(), w.lda, w.rows, p, w.At.get(), w.ldat, st);
+                w.gAt.init(w.At.get(), w.ldat, p, w.rows);
+                w.gM.init(w.Minv.get(), w.ldm, w.rows, w.rows);
+                w.gA.init(w.A.get(), w.lda, w.rows, p);
+                w.tvec.alloc(w.ldm); w.svec.alloc(w.ldm); w.tvec.zero(st); w.svec.zero(st);
+            }
+            ADMM_HIP_CHECK(hipStreamSynchronize(st));
+            t_fac += now_s() - t0;
+        }
+        S.t_gram = t_gram; S.t_factor = t_fac;
+        d.X.release();
+
+        nwg = std::max(1, std::min(64, (p + kParThreads - 1) / kParThreads));
+        rhs.alloc((size_t)K * ldv); x.alloc((size_t)K * ldv); y.alloc((size_t)K * ldv);
+        z.alloc(ldv); wsum.alloc(ldv);
+        rhs.zero(st); x.zero(st); y.zero(st);
+        beta.alloc((size_t)nlam * p); niter.alloc(nlam); done.alloc(1);
+        P.alloc((size_t)nwg * 8); dlam.alloc(nlam); ctl.alloc(2);
+        ADMM_HIP_CHECK(hipMemcpyAsync(dlam.get(), lam_int.data(), nlam * sizeof(double), hipMemcpyHostToDevice, st));
+        q.p = p; q.K = K; q.maxit = pb.opts.maxit; q.nlam = nlam; q.nwg = nwg; q.ldv = ldv;
+        q.rho = rho; q.eps_abs = pb.opts.eps_abs; q.eps_rel = pb.opts.eps_rel;
+        q.lambdas = dlam.get(); q.Ab = Ab.get(); q.rhs = rhs.get(); q.x = x.get(); q.y = y.get(); q.z = z.get(); q.wsum = wsum.get();
+        for (int k = 0; k < K; ++k) {
+            ParWorker& w = W[k];
+            GemvT<float>& last = w.wide ? w.gA : w.gM;
+            q.gout[k] = last.part.get(); q.gnseg[k] = last.pl.nseg; q.gstride[k] = last.stride; q.wide[k] = w.wide ? 1 : 0;
+        }
+        q.ctl = ctl.get(); q.P = P.get(); q.beta = beta.get(); q.niter = niter.get(); q.done = done.get();
+        ADMM_HIP_CHECK(hipStreamSynchronize(st));
+    }
+
+    static void A_release_if_tall(ParWorker& w) { w.A.release(); }   // a tall block only needs A'b and the inverse
+
+    void run(LassoResult& res) override {
+        admm_stats S = setup_stats;
+        res.lambda = lam_user;
+        beta.zero(st); niter.zero(st);
+        const int init_n = std::max(p, nwg * 8);
+        hipLaunchKernelGGL(par_init_kernel, dim3((init_n + 255) / 256), dim3(256), 0, st, q, lam_int[0]);
+        const int* skip = done.get();
+        const int nwg_e = std::max(1, std::min(device_info().num_cu, (p + kParThreads - 1) / kParThreads));
+        const int batch = pb.batch_iters > 0 ? (pb.batch_iters + 1) / 2 * 2 : 16;
+        LoopTimes lt = run_until_done(st, skip, batch, (long long)nlam * ((long long)pb.opts.maxit + 2) + 4, [&](long long g) {
+            const int par = (int)(g & 1);
+            hipLaunchKernelGGL(par_head_kernel, dim3(nwg_e), dim3(kParThreads), (size_t)nwg * 8 * sizeof(double), st, q, par);
+            for (int k = 0; k < K; ++k) {
+                ParWorker& w = W[k];
+                const float* rk = rhs.get() + (size_t)k * ldv;
+                if (!w.wide) {
+                    w.gM.run_partials(rk, skip, st);                       // x = (A'A + rho I)^-1 rhs
+                } else {
+                    w.gAt.run(rk, w.tvec.get(), skip, st);                 // t = A rhs
+                    w.gM.run(w.tvec.get(), w.svec.get(), skip, st);        // s = (AA' + rho I)^-1 t
+                    w.gA.run_partials(w.svec.get(), skip, st);             // A' s
+                }
+            }
+            hipLaunchKernelGGL(par_pack_kernel, dim3(nwg_e), dim3(kParThreads), 0, st, q);
+            hipLaunchKernelGGL(par_z_kernel, dim3(nwg), dim3(kParThreads), 0, st, q, par);
+        });
+        S.t_loop = lt.wall_s; S.loop_ms_events = lt.events_ms; S.xupdate_launches = lt.launched;
+
+        res.niter.assign(nlam, 0);
+        ADMM_HIP_CHECK(hipMemcpy(res.niter.data(), niter.get(), nlam * sizeof(int), hipMemcpyDeviceToHost));
+        std::vector<float> hb((size_t)nlam * p);
+        ADMM_HIP_CHECK(hipMemcpy(hb.data(), beta.get(), hb.size() * sizeof(float), hipMemcpyDeviceToHost));
+        res.beta.assign((size_t)(p + 1) * nlam, 0.f);
+        long long tot = 0;
+        for (int l = 0; l < nlam; ++l) {
+            float b0 = 0.f;
+            recover_coef<float>(d, hb.data() + (size_t)l * p, &b0, res.beta.data() + (size_t)l * (p + 1) + 1);
+            res.beta[(size_t)l * (p + 1)] = b0;
+            tot += res.niter[l];
+        }
+        S.total_iter = tot;
+        res.stats = S;
+    }
+};
+
+std::unique_ptr<LassoPlan> make_par_plan(DeviceData<float>&& d, const LassoProblem& pb, hipStream_t st) {
+    return std::unique_ptr<LassoPlan>(new ParPlan(std::move(d), pb, st));
+}
+
+}  // namespace admm

@@ -1,5 +1,4 @@
 #include "solvers.h"
 namespace admm {
 std::unique_ptr<LassoPlan> make_wide_plan(DeviceData<float>&&, const LassoProblem&, hipStream_t) { throw Error(ADMM_ERR_INTERNAL, "wide path not built yet"); }
-std::unique_ptr<LassoPlan> make_par_plan(DeviceData<float>&&, const LassoProblem&, hipStream_t) { throw Error(ADMM_ERR_INTERNAL, "consensus path not built yet"); }
 }
