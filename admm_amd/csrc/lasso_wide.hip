@@ -1,0 +1,431 @@
+// Wide (n <= p) Lasso / Elastic-net lambda path: linearised ADMM with active-set iterations.
+//
+// Replaces ADMMLassoWide / ADMMEnetWide driven by ADMMBase::solve:
+//   /root/reference/src/ADMMBase.h:85-109 (update_rho), :158-216 (update_x/z/y, solve)
+//   /root/reference/src/ADMMLassoWide.h:70-84 (soft_threshold), :86-118 (active_set_update),
+//   :121-127 (is_regular_update), :129-155 (next_x), :156-170 (next_z, next_residual),
+//   :174-186 (eps / resid), :189-251 (ctor, init, init_warm)
+//   /root/reference/src/ADMMEnet.h:62-154, and the lambda loop of Lasso.cpp:97-124.
+//
+// Device design:
+//  * "Regular" iterations (counter 0, 3, 15, 63, ... = 4^k - 1) stream all of X once (gemv_t, X't)
+//    and apply the prox to every coordinate; all other iterations touch only the current support.
+//  * No compaction and no index lists: column j belongs to wave (j mod NW).  A wave loads the x
+//    values of its columns, ballots the non-zeros and processes exactly those, so a zero
+//    coordinate stays zero until the next regular iteration (== SparseVector::prune) and a
+//    clustered support is spread over many waves.  Deterministic, no atomics.
+//  * Ax = sum_{j in supp} x_j X_j is a gather mat-vec with the same column->wave map; per-workgroup
+//    partials are summed by the z/y kernel.
+//  * Convergence test, rho adaptation (from iteration 5), the regular/active schedule and the
+//    lambda schedule (init_warm resets the counter, keeps x, z, y, rho) run on the device in the
+//    `head` kernel; the host enqueues batches and polls a sticky done word.
+#include "prep.h"
+#include "gemv_kernels.h"
+#include "solvers.h"
+#include "loop_driver.h"
+
+namespace admm {
+
+enum { W_ZERO = 0, W_REG = 1, W_ACT = 2 };
+
+struct WideCtl {
+    double rho, eps_primal, eps_dual;
+    float lam; int type;
+    int iter, counter, lam_idx, done, first, skip_reg, pad0, pad1;
+};
+
+constexpr int kWideThreads = 256;
+constexpr int kAxWG = 128;                // workgroups of the gather mat-vec (partials per output)
+constexpr int kAxRT = 16;                 // float4 row accumulators per lane -> 4096 rows per row tile
+
+struct WideParams {
+    int n, p, maxit, nlam, enet, nwg_tail;
+    long long ldx;
+    const float* X; const float* Y;
+    float gamma, lambda0, alpha;          // sprad, lambda_0, enet alpha
+    double eps_abs, eps_rel, sqrt_n, sqrt_p, sqrt_gamma;
+    const float* lambdas;                 // device [nlam], internal lambdas as float (Scalar lambda)
+    float* x;                             // p, dense storage of the sparse main_x
+    float* Ax; float* z; float* y; float* t; float* tdiv;     // n
+    const float* gpart; int gnseg; long long gstride;         // X't partials (regular step)
+    float* axpart;                        // [kAxWG][ldn]
+    long long ldn;
+    WideCtl* ctl;                         // [2]
+    double* P;                            // [nwg_tail][8]: |r|^2, |z_new - z|^2, |Ax|^2, |z_new|^2, |y_new|^2
+    float* beta; int* niter; int* done;
+};
+
+__device__ __forceinline__ bool is_regular_update(unsigned int x) {      // 4^k - 1   ADMMLassoWide.h:121-127
+    if (x == 0 || x == 3 || x == 15 || x == 63) return true;
+    x++;
+    if (x & (x - 1)) return false;
+    return (x & 0x55555555u) != 0;
+}
+
+// head(g): decision for iteration g-1, eps + update type for iteration g, t = Ax + z + y / rho.
+__global__ void __launch_bounds__(kWideThreads)
+wide_head_kernel(WideParams q, int par) {
+    __shared__ double sums[8];
+    extern __shared__ __attribute__((aligned(16))) double pstage[];
+    const WideCtl in = q.ctl[par];
+    WideCtl* outp = &q.ctl[par ^ 1];
+    if (in.done) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) *outp = in;
+        return;
+    }
+    const int np = q.nwg_tail * 8;
+    for (int k = threadIdx.x; k < np; k += kWideThreads) pstage[k] = q.P[k];
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        double s = 0.0;
+        for (int w = 0; w < q.nwg_tail; ++w) s += pstage[w * 8 + threadIdx.x];
+        sums[threadIdx.x] = s;
+    }
+    __syncthreads();
+    const double r2 = sums[0], dz2 = sums[1], ax2 = sums[2], z2 = sums[3], y2 = sums[4];
+    WideCtl out = in;
+    out.first = 0;
+    int lam_finished = -1, niter_val = 0;
+    if (!in.first) {
+        const double rp = sqrt(r2);                                   // resid_primal = ||Ax + z||       ADMMBase.h:181
+        const double rd = in.rho * q.sqrt_gamma * sqrt(dz2);          // rho sqrt(sprad) ||z_new - z||   ADMMLassoWide.h:183-186
+        if (rp < in.eps_primal && rd < in.eps_dual) { lam_finished = in.lam_idx; niter_val = in.iter + 1; }
+        else {
+            if (in.iter > 3) {                                        // update_rho()  ADMMBase.h:85-109,209-210
+                double rho = in.rho;
+                if (rp / in.eps_primal > 10 * rd / in.eps_dual) rho *= 2;
+                else if (rd / in.eps_dual > 10 * rp / in.eps_primal) rho /= 2;
+                if (rp < in.eps_primal) rho /= 1.2;
+                if (rd < in.eps_dual) rho *= 1.2;
+                out.rho = rho;
+            }
+            out.iter = in.iter + 1;
+            if (in.iter + 1 >= q.maxit) { lam_finished = in.lam_idx; niter_val = q.maxit + 1; }
+        }
+        if (lam_finished >= 0) {                                      // init_warm: counter = 0, x/z/y/rho kept (:241-251)
+            out.lam_idx = in.lam_idx + 1; out.iter = 0; out.counter = 0;
+            if (out.lam_idx >= q.nlam) out.done = 1;
+            else out.lam = q.lambdas[out.lam_idx];
+        }
+    }
+    // eps for this iteration from the current Ax, z, y (ADMMLassoWide.h:174-182)
+    out.eps_primal = fmax(sqrt(ax2), sqrt(z2)) * q.eps_rel + q.sqrt_n * q.eps_abs;
+    out.eps_dual = q.sqrt_gamma * sqrt(y2) * q.eps_rel + q.sqrt_p * q.eps_abs;
+    // which x-update runs now (ADMMLassoWide.h:129-155 / ADMMEnet.h:124-141)
+    if (!q.enet) {
+        if ((double)out.lam > (double)q.lambda0 - 1e-5) out.type = W_ZERO;        // counter not advanced
+        else { out.type = is_regular_update((unsigned)out.counter) ? W_REG : W_ACT; out.counter++; }
+    } else {
+        out.type = (is_regular_update((unsigned)out.counter) && out.lam < q.lambda0) ? W_REG : W_ACT;
+        out.counter++;
+    }
+    out.skip_reg = (out.done || out.type != W_REG) ? 1 : 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (lam_finished >= 0) q.niter[lam_finished] = niter_val;
+        *outp = out;
+        if (out.done) *q.done = 1;
+    }
+    const int gid = blockIdx.x * kWideThreads + threadIdx.x, gsz = gridDim.x * kWideThreads;
+    if (lam_finished >= 0)
+        for (int j = gid; j < q.p; j += gsz) q.beta[(size_t)lam_finished * q.p + j] = q.x[j];   // get_x()  Lasso.cpp:119
+    if (out.done) return;
+    const float rho_f = (float)out.rho;
+    for (int i = gid; i < q.n; i += gsz) {
+        const float t = q.Ax[i] + q.z[i] + q.y[i] / rho_f;            // cache_Ax + aux_z + dual_y / Scalar(rho)
+        q.t[i] = t;
+        q.tdiv[i] = t / q.gamma;                                       // active-set form divides first (:90)
+    }
+}
+
+__device__ __forceinline__ float prox_f(float val, float thresh, float denom, bool enet) {
+    // active_set_update thresholding in float (ADMMLassoWide.h:108-113, ADMMEnet.h:111-116)
+    if (val > thresh) return enet ? (val - thresh) / denom : val - thresh;
+    if (val < -thresh) return enet ? (val + thresh) / denom : val + thresh;
+    return 0.f;
+}
+
+// x-update.  REG: x = prox(x - X't / gamma) on every coordinate.  ACT: only current non-zeros.  ZERO: x = 0.
+__global__ void __launch_bounds__(kWideThreads)
+wide_xupdate_kernel(WideParams q, int par) {
+    extern __shared__ __attribute__((aligned(16))) float tl[];       // tdiv staged for the active branch
+    const WideCtl c = q.ctl[par ^ 1];
+    if (c.done) return;
+    const int gid = blockIdx.x * kWideThreads + threadIdx.x, gsz = gridDim.x * kWideThreads;
+    if (c.type == W_ZERO) {
+        for (int j = gid; j < q.p; j += gsz) q.x[j] = 0.f;
+        return;
+    }
+    const double pen_d = (double)c.lam / (c.rho * (double)q.gamma);
+    if (c.type == W_REG) {
+        const float thresh = (float)((double)q.alpha * pen_d);
+        const float denom = (float)(1.0 + pen_d * (1.0 - (double)q.alpha));
+        for (int j = gid; j < q.p; j += gsz) {
+            float g = 0.f;
+            for (int s = 0; s < q.gnseg; ++s) g += q.gpart[(size_t)s * q.gstride + j];
+            const float vec = (-g) / q.gamma + q.x[j];                // vec = -X't / gamma; vec += main_x   (:147-149)
+            float xn;
+            if (!q.enet) {                                            // soft_threshold, double compare (:70-84)
+                const double v = (double)vec;
+                xn = v > pen_d ? (float)(v - pen_d) : (v < -pen_d ? (float)(v + pen_d) : 0.f);
+            } else {
+                xn = vec > thresh ? (vec - thresh) / denom : (vec < -thresh ? (vec + thresh) / denom : 0.f);
+            }
+            q.x[j] = xn;
+        }
+        return;
+    }
+    // ---- W_ACT
+    const float penalty = (float)pen_d;                               // `const Scalar penalty` (:89)
+    const float thresh = q.enet ? q.alpha * penalty : penalty;
+    const float denom = q.enet ? (float)(1.0 + (double)penalty * (1.0 - (double)q.alpha)) : 1.f;
+    const int npad = (q.n + 255) / 256 * 256;
+    for (int i = threadIdx.x; i < npad; i += kWideThreads) tl[i] = i < q.n ? q.tdiv[i] : 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int NW = gridDim.x * (kWideThreads / 64);
+    const int w = blockIdx.x * (kWideThreads / 64) + (threadIdx.x >> 6);
+    const int nv = (q.n + 3) / 4 * 4;
+    for (int s0 = 0; (long long)s0 * NW < q.p; s0 += 64) {
+        const long long jl = (long long)(s0 + lane) * NW + w;
+        float xj = (jl < q.p) ? q.x[jl] : 0.f;
+        unsigned long long mask = __ballot(xj != 0.f);
+        while (mask) {
+            const int l = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const long long jj = (long long)(s0 + l) * NW + w;
+            const float xv = __shfl(xj, l, 64);
+            const float* col = q.X + (size_t)jj * q.ldx;
+            float d = 0.f;
+            for (int r = lane * 4; r < nv; r += 256) {
+                const float4 a = *reinterpret_cast<const float4*>(col + r);
+                const float4 b = *reinterpret_cast<const float4*>(tl + r);
+                d = fmaf(a.x, b.x, d); d = fmaf(a.y, b.y, d); d = fmaf(a.z, b.z, d); d = fmaf(a.w, b.w, d);
+            }
+            d = wave_sum(d);
+            const float xn = prox_f(xv - d, thresh, denom, q.enet != 0);
+            if (lane == l) { xj = xn; q.x[jj] = xn; }
+        }
+    }
+}
+
+// Gather mat-vec: axpart[b][i] = sum over the non-zero columns j owned by workgroup b of x_j X[i, j].
+__global__ void __launch_bounds__(kWideThreads)
+wide_ax_kernel(WideParams q) {
+    __shared__ float4 red[kWideThreads];
+    if (*q.done) return;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int NW = gridDim.x * (kWideThreads / 64);
+    const int w = blockIdx.x * (kWideThreads / 64) + wid;
+    for (int r0 = 0; r0 < q.n; r0 += 256 * kAxRT) {
+        float4 acc[kAxRT];
+#pragma unroll
+        for (int k = 0; k < kAxRT; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int rows_here = min(q.n - r0, 256 * kAxRT);
+        const int npass = (rows_here + 255) / 256;
+        for (int s0 = 0; (long long)s0 * NW < q.p; s0 += 64) {
+            const long long jl = (long long)(s0 + lane) * NW + w;
+            const float xj = (jl < q.p) ? q.x[jl] : 0.f;
+            unsigned long long mask = __ballot(xj != 0.f);
+            while (mask) {
+                const int l = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                const long long jj = (long long)(s0 + l) * NW + w;
+                const float xv = __shfl(xj, l, 64);
+                const float* col = q.X + (size_t)jj * q.ldx + r0;
+#pragma unroll
+                for (int k = 0; k < kAxRT; ++k) {
+                    if (k < npass) {
+                        const int r = k * 256 + lane * 4;
+                        if (r < rows_here) {                      // ldx padding rows are zero, vector load is in-bounds
+                            const float4 a = *reinterpret_cast<const float4*>(col + r);
+                            acc[k].x = fmaf(xv, a.x, acc[k].x); acc[k].y = fmaf(xv, a.y, acc[k].y);
+                            acc[k].z = fmaf(xv, a.z, acc[k].z); acc[k].w = fmaf(xv, a.w, acc[k].w);
+                        }
+                    }
+                }
+            }
+        }
+        // combine the 4 waves of the workgroup, then write this workgroup's partial
+#pragma unroll
+        for (int k = 0; k < kAxRT; ++k) {
+            if (k < npass) {
+                __syncthreads();
+                red[threadIdx.x] = acc[k];
+                __syncthreads();
+                if (wid == 0) {
+                    float4 s = red[lane];
+#pragma unroll
+                    for (int ww = 1; ww < kWideThreads / 64; ++ww) {
+                        const float4 o = red[ww * 64 + lane];
+                        s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+                    }
+                    const int r = r0 + k * 256 + lane * 4;
+                    float* dst = q.axpart + (size_t)blockIdx.x * q.ldn + r;
+                    if (r < q.ldn) *reinterpret_cast<float4*>(dst) = s;
+                }
+            }
+        }
+    }
+}
+
+// z/y update: Ax = sum of partials; z_new = -(y_data + y + rho Ax) / (1 + rho); r = Ax + z_new; y += rho r; norms.
+__global__ void __launch_bounds__(kWideThreads)
+wide_tail_kernel(WideParams q, int par) {
+    __shared__ double scratch[5 * (kWideThreads / 64)];
+    const WideCtl c = q.ctl[par ^ 1];
+    if (c.done) return;
+    const float rho_f = (float)c.rho;
+    const float den = (float)(-1.0 - c.rho);                          // Scalar(-1 - rho)   (:164)
+    double acc[5] = {0, 0, 0, 0, 0};
+    for (int i = blockIdx.x * kWideThreads + threadIdx.x; i < q.n; i += gridDim.x * kWideThreads) {
+        float ax = 0.f;
+        for (int b = 0; b < kAxWG; ++b) ax += q.axpart[(size_t)b * q.ldn + i];
+        const float zo = q.z[i], yo = q.y[i];
+        const float zn = (q.Y[i] + yo + rho_f * ax) / den;            // next_z (:156-165)
+        const float dz = zn - zo;
+        const float r = ax + zn;                                       // next_residual (:166-170)
+        const float yn = yo + rho_f * r;                               // dual_y += rho * newr   ADMMBase.h:183
+        q.Ax[i] = ax; q.z[i] = zn; q.y[i] = yn;
+        acc[0] += (double)r * r; acc[1] += (double)dz * dz; acc[2] += (double)ax * ax;
+        acc[3] += (double)zn * zn; acc[4] += (double)yn * yn;
+    }
+    block_sum<double, 5>(acc, scratch);
+    if (threadIdx.x == 0) {
+        double* Pout = q.P + (size_t)blockIdx.x * 8;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) Pout[k] = acc[k];
+    }
+}
+
+__global__ void wide_init_kernel(WideParams q, double rho, float lam0) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < q.p) q.x[i] = 0.f;
+    if (i < q.n) { q.Ax[i] = 0.f; q.z[i] = 0.f; q.y[i] = 0.f; q.t[i] = 0.f; q.tdiv[i] = 0.f; }
+    if (i < q.nwg_tail * 8) q.P[i] = 0.0;
+    if (i == 0) {
+        WideCtl c;
+        c.rho = rho; c.eps_primal = 0; c.eps_dual = 0; c.lam = lam0; c.type = W_REG;
+        c.iter = 0; c.counter = 0; c.lam_idx = 0; c.done = 0; c.first = 1; c.skip_reg = 0; c.pad0 = c.pad1 = 0;
+        q.ctl[0] = c; q.ctl[1] = c;
+        *q.done = 0;
+    }
+}
+
+struct WidePlan final : LassoPlan {
+    DeviceData<float> d;
+    LassoProblem pb;
+    hipStream_t st;
+    admm_stats setup_stats{};
+    int n = 0, p = 0, nlam = 0, nwg_tail = 0;
+    long long ldn = 0;
+    float sprad = 0.f, lambda0 = 0.f;
+    double rho0 = 0;
+    std::vector<double> lam_user;
+    std::vector<float> lam_int;
+    GemvT<float> gX;
+    DevBuf<float> x, Ax, z, y, t, tdiv, axpart, beta, dlam;
+    DevBuf<int> niter, done;
+    DevBuf<double> P;
+    DevBuf<WideCtl> ctl;
+    WideParams q{};
+
+    WidePlan(DeviceData<float>&& data, const LassoProblem& prob, hipStream_t stream) : d(std::move(data)), pb(prob), st(stream) {
+        n = d.n; p = d.p;
+        admm_stats& S = setup_stats;
+        S.branch = 1; S.t_h2d = d.t_h2d; S.t_standardize = d.t_std;
+        const long long ldp = round_up(p, 32);
+        ldn = round_up(n, 256);
+
+        // lambda_0 (ADMMLassoWide.h:197; ADMMEnet.h:152)
+        {
+            DevBuf<float> XY(ldp); XY.zero(st);
+            gemv_t_simple<float>(d.X.get(), d.ldx, n, p, d.Y.get(), XY.get(), st);
+            lambda0 = device_absmax<float>(XY.get(), p, st);
+        }
+        // spectral radius estimate from XX' (ADMMLassoWide.h:200-207)
+        double t0 = now_s();
+        {
+            const long long ldg = round_up(n, 32);
+            DevBuf<float> G((size_t)ldg * n); G.zero(st);
+            gram_full<float>(d.X.get(), d.ldx, n, p, false, G.get(), ldg, st);
+            ADMM_HIP_CHECK(hipStreamSynchronize(st));
+            S.t_gram = now_s() - t0; t0 = now_s();
+            SymMatVec<float> op(G.get(), ldg, n, st);
+            int nmatop = 0;
+            sprad = lanczos_largest_f32([&](const float* v, float* w) { op(v, w); }, n, &nmatop);
+            S.eig_est = sprad; S.t_eigs = now_s() - t0;
+        }
+        if (pb.enet) lambda0 = (float)((double)lambda0 / ((double)(float)pb.alpha + 0.0001));
+
+        lam_user = make_lambda_grid(pb, lambda0, n, (double)d.scaleY);
+        nlam = (int)lam_user.size();
+        lam_int.resize(nlam);
+        for (int i = 0; i < nlam; ++i) lam_int[i] = (float)(lam_user[i] * n / (double)d.scaleY);
+        rho0 = pb.opts.rho;
+        if (rho0 <= 0) rho0 = std::pow((double)lam_int[0] / (double)sprad, 1.0 / 3);       // :227-228
+        S.rho = rho0;
+
+        gX.init(d.X.get(), d.ldx, n, p);
+        nwg_tail = std::max(1, std::min(32, (n + kWideThreads - 1) / kWideThreads));
+        x.alloc(ldp); x.zero(st);
+        for (DevBuf<float>* b : {&Ax, &z, &y, &t, &tdiv}) { b->alloc(ldn); b->zero(st); }
+        axpart.alloc((size_t)kAxWG * ldn); axpart.zero(st);
+        beta.alloc((size_t)nlam * p); niter.alloc(nlam); done.alloc(1); dlam.alloc(nlam);
+        P.alloc((size_t)nwg_tail * 8); ctl.alloc(2);
+        ADMM_HIP_CHECK(hipMemcpyAsync(dlam.get(), lam_int.data(), nlam * sizeof(float), hipMemcpyHostToDevice, st));
+
+        q.n = n; q.p = p; q.maxit = pb.opts.maxit; q.nlam = nlam; q.enet = pb.enet ? 1 : 0; q.nwg_tail = nwg_tail;
+        q.ldx = d.ldx; q.X = d.X.get(); q.Y = d.Y.get();
+        q.gamma = sprad; q.lambda0 = lambda0; q.alpha = (float)pb.alpha;
+        q.eps_abs = pb.opts.eps_abs; q.eps_rel = pb.opts.eps_rel;
+        q.sqrt_n = std::sqrt((double)n); q.sqrt_p = std::sqrt((double)p); q.sqrt_gamma = (double)std::sqrt(sprad);
+        q.lambdas = dlam.get(); q.x = x.get(); q.Ax = Ax.get(); q.z = z.get(); q.y = y.get(); q.t = t.get(); q.tdiv = tdiv.get();
+        q.gpart = gX.part.get(); q.gnseg = gX.pl.nseg; q.gstride = gX.stride;
+        q.axpart = axpart.get(); q.ldn = ldn;
+        q.ctl = ctl.get(); q.P = P.get(); q.beta = beta.get(); q.niter = niter.get(); q.done = done.get();
+        ADMM_HIP_CHECK(hipStreamSynchronize(st));
+    }
+
+    void run(LassoResult& res) override {
+        admm_stats S = setup_stats;
+        res.lambda = lam_user;
+        beta.zero(st); niter.zero(st);
+        const int init_n = std::max(std::max(n, p), nwg_tail * 8);
+        hipLaunchKernelGGL(wide_init_kernel, dim3((init_n + 255) / 256), dim3(256), 0, st, q, rho0, lam_int[0]);
+        const int ncu = device_info().num_cu;
+        const int nwg_head = std::max(1, std::min(ncu, (std::max(n, p) + kWideThreads - 1) / kWideThreads));
+        const int nwg_x = 4 * ncu;                                   // 4096 waves own the columns
+        const size_t lds_x = (size_t)((n + 255) / 256 * 256) * sizeof(float);
+        const int batch = pb.batch_iters > 0 ? (pb.batch_iters + 1) / 2 * 2 : 16;
+        LoopTimes lt = run_until_done(st, done.get(), batch, (long long)nlam * ((long long)pb.opts.maxit + 2) + 4, [&](long long g) {
+            const int par = (int)(g & 1);
+            hipLaunchKernelGGL(wide_head_kernel, dim3(nwg_head), dim3(kWideThreads), (size_t)nwg_tail * 8 * sizeof(double), st, q, par);
+            gX.run_partials(t.get(), &ctl.get()[par ^ 1].skip_reg, st);                   // X't, regular iterations only
+            hipLaunchKernelGGL(wide_xupdate_kernel, dim3(nwg_x), dim3(kWideThreads), lds_x, st, q, par);
+            hipLaunchKernelGGL(wide_ax_kernel, dim3(kAxWG), dim3(kWideThreads), 0, st, q);
+            hipLaunchKernelGGL(wide_tail_kernel, dim3(nwg_tail), dim3(kWideThreads), 0, st, q, par);
+        });
+        S.t_loop = lt.wall_s; S.loop_ms_events = lt.events_ms; S.xupdate_launches = lt.launched;
+
+        res.niter.assign(nlam, 0);
+        ADMM_HIP_CHECK(hipMemcpy(res.niter.data(), niter.get(), nlam * sizeof(int), hipMemcpyDeviceToHost));
+        std::vector<float> hb((size_t)nlam * p);
+        ADMM_HIP_CHECK(hipMemcpy(hb.data(), beta.get(), hb.size() * sizeof(float), hipMemcpyDeviceToHost));
+        res.beta.assign((size_t)(p + 1) * nlam, 0.f);
+        long long tot = 0;
+        for (int l = 0; l < nlam; ++l) {
+            float b0 = 0.f;
+            recover_coef<float>(d, hb.data() + (size_t)l * p, &b0, res.beta.data() + (size_t)l * (p + 1) + 1);
+            res.beta[(size_t)l * (p + 1)] = b0;
+            tot += res.niter[l];
+        }
+        S.total_iter = tot;
+        res.stats = S;
+    }
+};
+
+std::unique_ptr<LassoPlan> make_wide_plan(DeviceData<float>&& d, const LassoProblem& pb, hipStream_t st) {
+    return std::unique_ptr<LassoPlan>(new WidePlan(std::move(d), pb, st));
+}
+
+}  // namespace admm

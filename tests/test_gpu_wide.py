@@ -1,0 +1,57 @@
+"""GPU parity: wide (n <= p) Lasso / Elastic-net (linearised ADMM with active-set iterations) vs the oracle.
+
+The reference holds no known-answer vector for this solver (README.md:285-289 only gives ranges
+against glmnet), so the oracle -- pinned on the five README vectors with which it shares all code
+-- is the reference here ("parity unpinned" in oracle/__init__.py)."""
+import numpy as np
+import pytest
+
+from helpers import assert_path_parity, relerr, synth_lasso
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.mark.parametrize("n,p,m", [(300, 2000, 20), (257, 1031, 10), (500, 500, 15)])
+def test_wide_lasso_path_vs_oracle(n, p, m):
+    from admm_amd import admm_lasso
+    from oracle import entry
+    x, y = synth_lasso(n, p, m, seed=29)
+    fit = admm_lasso(x, y).penalty(nlambda=12).fit()
+    d = {}
+    lmr = 0.01 if n < p else 1e-4                                # R default (R/30_admm_lasso.R:43)
+    ref = entry.admm_lasso(x, y, None, 12, lmr, True, True, entry.LASSO_OPTS, d)
+    assert fit.stats["branch"] == 1
+    assert np.allclose(fit.lambda_, ref["lambda"], rtol=1e-5)
+    assert abs(fit.stats["eig_est"] - float(d["solver"].sprad)) < 1e-4 * float(d["solver"].sprad)
+    loose = assert_path_parity(fit.beta_dense, fit.niter, ref, d, TOL, n_tight_first=4)
+    assert len(loose) <= 4
+    # support agreement on the tight columns
+    for j in range(12):
+        if j not in loose:
+            assert np.array_equal(np.abs(fit.beta_dense[1:, j]) > 1e-5, np.abs(ref["beta"][1:, j]) > 1e-5), j
+
+
+def test_wide_enet_path_vs_oracle():
+    from admm_amd import admm_enet
+    from oracle import entry
+    x, y = synth_lasso(250, 900, 12, seed=31)
+    fit = admm_enet(x, y).penalty(nlambda=10, alpha=0.5).fit()
+    d = {}
+    ref = entry.admm_enet(x, y, None, 10, 0.01, True, True, 0.5, entry.LASSO_OPTS, d)
+    loose = assert_path_parity(fit.beta_dense, fit.niter, ref, d, TOL, alpha=0.5, n_tight_first=4)
+    assert len(loose) <= 3
+
+
+def test_wide_user_lambda_and_maxit():
+    from admm_amd import admm_lasso
+    from oracle import entry
+    x, y = synth_lasso(120, 400, 8, seed=37)
+    lam = [0.8, 0.2, 0.05]
+    for maxit in (7, 10000):
+        fit = admm_lasso(x, y).penalty(lam).opts(maxit=maxit).fit()
+        ref = entry.admm_lasso(x, y, lam, 100, 0.01, True, True, dict(entry.LASSO_OPTS, maxit=maxit))
+        if maxit < 100:
+            assert list(fit.niter) == list(ref["niter"])
+        for j in range(3):
+            assert relerr(fit.beta_dense[:, j], ref["beta"][:, j]) < (TOL if maxit < 100 else 5e-3), j
