@@ -25,6 +25,7 @@
 //    x of the next lambda equals the last x: `mode == 0` reuses it instead of a mat-vec.
 #include "prep.h"
 #include "gemv_kernels.h"
+#include "symv_kernels.h"
 #include "solvers.h"
 
 namespace admm {
@@ -47,7 +48,9 @@ struct TallParams {
     double eps_abs, eps_rel, alpha, sqrt_p;
     const double* lambdas;      // device, nlam values already rounded to float
     const float* XY;
-    const float* a_part; const float* b_part;
+    const float* a_part; const float* b_part;            // gemv_t partials [nseg][part_stride]   (full-matrix x-update)
+    const float* dot0; const float* dot1; const float* axp0; const float* axp1;   // symv partials (lower-triangle x-update)
+    long long ldo; int nrb, ncb;
     float* x; float* z0; float* z1; float* y0; float* y1; float* adj_z; float* adj_y; float* u; float* w;
     TallCtl* ctl;               // [2]
     double* P;                  // [2][nwg][8]
@@ -56,7 +59,9 @@ struct TallParams {
 };
 
 constexpr int kTailThreads = 256;
+constexpr int kTailElems = 64;            // elements per workgroup: 4 lanes cooperate on one element's partial sums
 
+template <bool SYM>
 __global__ void __launch_bounds__(kTailThreads)
 tall_tail_kernel(TallParams q, int par) {
     __shared__ double sums[8];
@@ -68,19 +73,54 @@ tall_tail_kernel(TallParams q, int par) {
         if (blockIdx.x == 0 && threadIdx.x == 0) *outp = in;       // keep `done` sticky in both slots
         return;
     }
-    // ---- decision from the previous iteration's norm partials (every workgroup, identically)
-    {   // all threads fetch the partials in parallel (one latency), then 6 threads add them in a fixed order
-        const double* Pin = q.P + (size_t)par * q.nwg * 8;
-        const int np = q.nwg * 8;
-        for (int k = threadIdx.x; k < np; k += kTailThreads) pstage[k] = Pin[k];
-        __syncthreads();
-        if (threadIdx.x < 6) {
-            double s = 0.0;
-            for (int w = 0; w < q.nwg; ++w) s += pstage[w * 8 + threadIdx.x];
-            sums[threadIdx.x] = s;
+    const int np = q.nwg * 8;
+    for (int k = threadIdx.x; k < np; k += kTailThreads) pstage[k] = q.P[(size_t)par * np + k];
+
+    // ---- x-update results a = Minv u, b = Minv w for this workgroup's elements: independent of the
+    // decision, so the (long-latency) partial loads are issued first.  4 lanes share one element.
+    const int sub = threadIdx.x & 3;
+    const int i = blockIdx.x * kTailElems + (threadIdx.x >> 2);
+    const bool valid = i < q.p;
+    float a = 0.f, b = 0.f;
+    if (valid) {
+        if (SYM) {
+            const int cbi = i / kSyCB, rbi = i / kSyRB;
+            const int rb0 = cbi / 2;
+            const int ndot = q.nrb - rb0;
+            const int nax = min(q.ncb - 1, 2 * rbi + 1) + 1;
+            for (int k = sub; k < ndot; k += 4) {
+                const size_t o = (size_t)(rb0 + k) * q.ldo + i;
+                a += q.dot0[o]; b += q.dot1[o];
+            }
+            for (int k = sub; k < nax; k += 4) {
+                const size_t o = (size_t)k * q.ldo + i;
+                a += q.axp0[o]; b += q.axp1[o];
+            }
+        } else {
+            for (int k = sub; k < q.nseg; k += 4) {
+                const size_t o = (size_t)k * q.part_stride + i;
+                a += q.a_part[o]; b += q.b_part[o];
+            }
         }
-        __syncthreads();
     }
+    a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64);
+    b += __shfl_xor(b, 1, 64); b += __shfl_xor(b, 2, 64);
+    const int cur = in.total & 1;                      // buffer holding the current z / y
+    const float* zc_ = cur ? q.z1 : q.z0; const float* yc_ = cur ? q.y1 : q.y0;
+    float* zo_ = cur ? q.z0 : q.z1;       float* yo_ = cur ? q.y0 : q.y1;
+    float zc = 0.f, yc = 0.f, zo = 0.f, yo = 0.f, adjz_st = 0.f, adjy_st = 0.f, x_st = 0.f, xy = 0.f;
+    if (valid) { zc = zc_[i]; yc = yc_[i]; zo = zo_[i]; yo = yo_[i]; adjz_st = q.adj_z[i]; adjy_st = q.adj_y[i]; x_st = q.x[i]; xy = q.XY[i]; }
+
+    // ---- decision from the previous iteration's norm partials (every workgroup, identically)
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x, which = lane & 7;
+        double sacc = 0.0;
+        if (which < 6) for (int w = lane >> 3; w < q.nwg; w += 8) sacc += pstage[w * 8 + which];
+        sacc += __shfl_xor(sacc, 8, 64); sacc += __shfl_xor(sacc, 16, 64); sacc += __shfl_xor(sacc, 32, 64);
+        if (lane < 6) sums[lane] = sacc;
+    }
+    __syncthreads();
     const double r2 = sums[0], dz2 = sums[1], daz2 = sums[2], x2 = sums[3], z2 = sums[4], y2 = sums[5];
     TallCtl out = in;
     out.first = 0;
@@ -96,8 +136,8 @@ tall_tail_kernel(TallParams q, int par) {
             const double c = in.rho * rp * rp + in.rho * daz2;     // compute_resid_combined  ADMMLassoTall.h:154-161
             if (c < 0.999 * old_c) {                   // FADMMBase.h:243-249
                 const double old_a = in.adj_a;
-                const double a = 0.5 + 0.5 * sqrt(1.0 + 4.0 * old_a * old_a);
-                out.adj_a = a; out.adj_c = c; out.tau = (old_a - 1.0) / a; out.restart = 0;
+                const double aa = 0.5 + 0.5 * sqrt(1.0 + 4.0 * old_a * old_a);
+                out.adj_a = aa; out.adj_c = c; out.tau = (old_a - 1.0) / aa; out.restart = 0;
             } else {                                   // restart                 FADMMBase.h:250-256
                 out.adj_a = 1.0; out.adj_c = old_c / 0.999; out.tau = -1.0; out.restart = 1;
             }
@@ -121,12 +161,8 @@ tall_tail_kernel(TallParams q, int par) {
     out.eps_dual = sqrt(y2) * q.eps_rel + q.sqrt_p * q.eps_abs;
     out.total = in.total + 1;
 
-    const int cur = in.total & 1;                      // buffer holding the current z / y
-    const float* zc_ = cur ? q.z1 : q.z0; const float* yc_ = cur ? q.y1 : q.y0;
-    float* zo_ = cur ? q.z0 : q.z1;       float* yo_ = cur ? q.y0 : q.y1;
-    const int i = blockIdx.x * kTailThreads + threadIdx.x;
-
-    if (lam_finished >= 0 && i < q.p) q.beta[(size_t)lam_finished * q.p + i] = zc_[i];   // get_z() snapshot (Lasso.cpp:108)
+    const bool owner = valid && sub == 0;
+    if (lam_finished >= 0 && owner) q.beta[(size_t)lam_finished * q.p + i] = zc;   // get_z() snapshot (Lasso.cpp:108)
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (lam_finished >= 0) q.niter[lam_finished] = niter_val;
         *outp = out;
@@ -134,13 +170,9 @@ tall_tail_kernel(TallParams q, int par) {
     if (out.done) return;
 
     double acc[6] = {0, 0, 0, 0, 0, 0};
-    if (i < q.p) {
-        const float zc = zc_[i], yc = yc_[i];
+    if (owner) {
         float adjz, adjy, x;
         if (out.mode) {
-            float a = 0.f, b = 0.f;
-            for (int s = 0; s < q.nseg; ++s) { a += q.a_part[(size_t)s * q.part_stride + i]; b += q.b_part[(size_t)s * q.part_stride + i]; }
-            const float zo = zo_[i], yo = yo_[i];
             if (out.restart) { adjz = zo; adjy = yo; x = a - b; }
             else {
                 const float t = (float)out.tau, t1 = (float)(1.0 + out.tau);
@@ -148,7 +180,7 @@ tall_tail_kernel(TallParams q, int par) {
                 adjy = t1 * yc - t * yo;
                 x = a + t * b;
             }
-        } else { adjz = q.adj_z[i]; adjy = q.adj_y[i]; x = q.x[i]; }
+        } else { adjz = adjz_st; adjy = adjy_st; x = x_st; }
         const float rho_f = (float)out.rho;
         const float vec = x + adjy / rho_f;            // next_z: main_x + adj_y / rho            ADMMLassoTall.h:83
         const double pen = out.lam / out.rho;
@@ -167,7 +199,7 @@ tall_tail_kernel(TallParams q, int par) {
         acc[0] = (double)r * r; acc[1] = (double)dz * dz; acc[2] = (double)daz * daz;
         acc[3] = (double)x * x; acc[4] = (double)zn * zn; acc[5] = (double)yn * yn;
         q.x[i] = x; zo_[i] = zn; yo_[i] = yn; q.adj_z[i] = adjz; q.adj_y[i] = adjy;
-        q.u[i] = (float)((double)(q.XY[i] - yn) + out.rho * (double)zn);
+        q.u[i] = (float)((double)(xy - yn) + out.rho * (double)zn);
         q.w[i] = (float)((double)(yc - yn) + out.rho * (double)dz);
     }
     block_sum<double, 6>(acc, scratch);
@@ -205,6 +237,9 @@ struct TallPlan final : LassoPlan {
     double rho = 0;
     std::vector<double> lam_user, lam_int;
     GemvTPlan pl;
+    SymvPlan sy;
+    bool use_sym = false;
+    long long ldv = 0;
     DevBuf<float> XY, M, a_part, b_part, x, z0, z1, y0, y1, adj_z, adj_y, u, w, beta;
     DevBuf<int> niter;
     DevBuf<double> P, dlam;
@@ -264,20 +299,28 @@ struct TallPlan final : LassoPlan {
         d.X.release();
 
         // ---- loop state
+        // x-update variant: lower-triangle symmetric mat-vec (2p^2 bytes) for large p, full-matrix
+        // gemv_t (4p^2 bytes, fewer and larger workgroups) for small p.  ADMM_HIP_XUPDATE=full|sym overrides.
+        use_sym = p >= 2048;
+        if (const char* e = std::getenv("ADMM_HIP_XUPDATE")) use_sym = std::string(e) == "sym";
         pl = plan_gemv_t<float>(p, p, 2, 4);
-        nwg = (p + kTailThreads - 1) / kTailThreads;
-        a_part.alloc((size_t)pl.nseg * ldp); b_part.alloc((size_t)pl.nseg * ldp);
-        x.alloc(ldp); z0.alloc(ldp); z1.alloc(ldp); y0.alloc(ldp); y1.alloc(ldp);
-        adj_z.alloc(ldp); adj_y.alloc(ldp); u.alloc(ldp); w.alloc(ldp);
+        nwg = (p + kTailElems - 1) / kTailElems;
+        ldv = round_up(p, 256);                         // symv reads the right-hand vectors in 256-row blocks
+        if (use_sym) sy.init(p, st);
+        else { a_part.alloc((size_t)pl.nseg * ldp); b_part.alloc((size_t)pl.nseg * ldp); a_part.zero(st); b_part.zero(st); }
+        x.alloc(ldv); z0.alloc(ldv); z1.alloc(ldv); y0.alloc(ldv); y1.alloc(ldv);
+        adj_z.alloc(ldv); adj_y.alloc(ldv); u.alloc(ldv); w.alloc(ldv);
         beta.alloc((size_t)nlam * p); niter.alloc(nlam);
         P.alloc((size_t)2 * nwg * 8); dlam.alloc(nlam); ctl.alloc(2);
-        a_part.zero(st); b_part.zero(st); u.zero(st); w.zero(st);
+        u.zero(st); w.zero(st);
         ADMM_HIP_CHECK(hipMemcpyAsync(dlam.get(), lam_int.data(), nlam * sizeof(double), hipMemcpyHostToDevice, st));
 
         q.p = p; q.nwg = nwg; q.nseg = pl.nseg; q.maxit = pb.opts.maxit; q.nlam = nlam; q.enet = pb.enet ? 1 : 0;
         q.part_stride = ldp;
         q.eps_abs = pb.opts.eps_abs; q.eps_rel = pb.opts.eps_rel; q.alpha = (double)(float)pb.alpha; q.sqrt_p = std::sqrt((double)p);
         q.lambdas = dlam.get(); q.XY = XY.get(); q.a_part = a_part.get(); q.b_part = b_part.get();
+        q.dot0 = sy.dot0.get(); q.dot1 = sy.dot1.get(); q.axp0 = sy.axp0.get(); q.axp1 = sy.axp1.get();
+        q.ldo = sy.ldo; q.nrb = sy.nrb; q.ncb = sy.ncb;
         q.x = x.get(); q.z0 = z0.get(); q.z1 = z1.get(); q.y0 = y0.get(); q.y1 = y1.get();
         q.adj_z = adj_z.get(); q.adj_y = adj_y.get(); q.u = u.get(); q.w = w.get();
         q.ctl = ctl.get(); q.P = P.get(); q.beta = beta.get(); q.niter = niter.get();
@@ -290,6 +333,7 @@ struct TallPlan final : LassoPlan {
     // One warm-started lambda path from a cold start (init at the first lambda, init_warm after).
     void run(LassoResult& res) override {
         admm_stats S = setup_stats;
+        S.xupdate_variant = use_sym ? 1 : 0;
         res.lambda = lam_user;
         beta.zero(st); niter.zero(st);
         const int init_n = std::max(p, 2 * nwg * 8);
@@ -317,10 +361,12 @@ struct TallPlan final : LassoPlan {
                     evs.push_back(e0); evs.push_back(e1);
                     ADMM_HIP_CHECK(hipEventRecord(e0, st));
                 }
-                launch_gemv_t<float, 2, 4>(pl, M.get(), ldp, p, p, u.get(), w.get(), a_part.get(), b_part.get(), ldp,
-                                           &ctl.get()[par].done, st);
+                if (use_sym) sy.launch(M.get(), ldp, u.get(), w.get(), &ctl.get()[par].done, st);
+                else launch_gemv_t<float, 2, 4>(pl, M.get(), ldp, p, p, u.get(), w.get(), a_part.get(), b_part.get(), ldp,
+                                                &ctl.get()[par].done, st);
                 if (sample) ADMM_HIP_CHECK(hipEventRecord(e1, st));
-                hipLaunchKernelGGL(tall_tail_kernel, dim3(nwg), dim3(kTailThreads), (size_t)nwg * 8 * sizeof(double), st, q, par);
+                if (use_sym) hipLaunchKernelGGL(tall_tail_kernel<true>, dim3(nwg), dim3(kTailThreads), (size_t)nwg * 8 * sizeof(double), st, q, par);
+                else hipLaunchKernelGGL(tall_tail_kernel<false>, dim3(nwg), dim3(kTailThreads), (size_t)nwg * 8 * sizeof(double), st, q, par);
                 ++launches;
             }
             // after an even number of iterations the freshest control block is slot g&1 == 0

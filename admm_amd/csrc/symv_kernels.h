@@ -1,0 +1,192 @@
+// Symmetric mat-vec that reads only the lower triangle, for the tall x-update.
+//
+//   y_r = A v_r  (r = 0, 1)  for a symmetric p x p fp32 matrix stored column-major (both triangles
+//   are in memory, only tiles on or below the diagonal are read): 2 p^2 bytes instead of 4 p^2.
+//
+// Tiling: a workgroup owns 256 rows x 128 columns; each of its 4 waves owns the same 256 rows
+// (one float4 per lane) and 32 of the columns.  For every element a_ij (i > j) it loads, a wave
+// does both halves of the symmetric product:
+//     dot  part:  y_j += a_ij v_i   -> per-lane partials of 8 columns at a time, combined across
+//                                      the 64 lanes with a halving butterfly (10 shuffles per 8 columns)
+//     axpy part:  y_i += a_ij v_j   -> 4 per-lane accumulators (v_j is wave-uniform, v_readlane)
+// The diagonal element contributes once (dot part).  Results are written as partials:
+//     dot[rb][j]  (rb = row block of 256)      axp[cb][i]  (cb = column block of 128)
+// and summed by the consumer (`symv_reduce` below, fused into the tall tail kernel):
+//     y_i = sum_{rb >= cb(i)/2} dot[rb][i] + sum_{cb <= 2 rb(i) + 1} axp[cb][i].
+// Deterministic (no atomics).  Partial traffic: (p/256 + p/128) * p * 8 bytes per launch, written
+// once and read once (about 9 % of the triangle at p = 10^4).
+#pragma once
+#include "admm_internal.h"
+#include "device_utils.h"
+
+namespace admm {
+
+constexpr int kSyRB = 256;     // rows per tile
+constexpr int kSyCW = 32;      // columns per wave
+constexpr int kSyCB = 128;     // columns per workgroup tile
+constexpr int kSyThreads = 256;
+
+struct SymvArgs {
+    const float* A; long long lda; int p;
+    const float* v0; const float* v1;      // right-hand vectors, allocated (and zero padded) to a multiple of 256
+    float* dot0; float* dot1;              // [nrb][ldo]
+    float* axp0; float* axp1;              // [ncb][ldo]
+    long long ldo;
+    const int2* tiles;                     // (row block, column block) of every tile touching the lower triangle
+    const int* skip;
+};
+
+// Sum 8 per-lane values over the 64 lanes: afterwards every lane l holds the total of value (l >> 3).
+__device__ __forceinline__ float butterfly8(const float (&v)[8], int lane) {
+    float a4[4], a2[2];
+    {
+        const int b = (lane >> 5) & 1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float keep = b ? v[k + 4] : v[k], send = b ? v[k] : v[k + 4];
+            a4[k] = keep + __shfl_xor(send, 32, 64);
+        }
+    }
+    {
+        const int b = (lane >> 4) & 1;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const float keep = b ? a4[k + 2] : a4[k], send = b ? a4[k] : a4[k + 2];
+            a2[k] = keep + __shfl_xor(send, 16, 64);
+        }
+    }
+    const int b = (lane >> 3) & 1;
+    const float keep = b ? a2[1] : a2[0], send = b ? a2[0] : a2[1];
+    float r = keep + __shfl_xor(send, 8, 64);
+    r += __shfl_xor(r, 4, 64);
+    r += __shfl_xor(r, 2, 64);
+    r += __shfl_xor(r, 1, 64);
+    return r;
+}
+
+__global__ void __launch_bounds__(kSyThreads, 4)
+symv2_lower_kernel(SymvArgs a) {
+    if (a.skip != nullptr && *a.skip != 0) return;
+    __shared__ float4 red[2][kSyThreads];
+    const int2 t = a.tiles[blockIdx.x];
+    const int rb = t.x, cb = t.y;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int row = rb * kSyRB + lane * 4;
+    const int col0 = cb * kSyCB + wid * kSyCW;
+    const int p4 = (a.p + 3) & ~3;
+    const bool active = row < p4;
+    float4 aU = make_float4(0.f, 0.f, 0.f, 0.f), aW = aU;
+
+    if (col0 < a.p) {       // every wave of a listed tile has all its columns <= the block's last row
+        const float4 uI = active ? *reinterpret_cast<const float4*>(a.v0 + row) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 wI = active ? *reinterpret_cast<const float4*>(a.v1 + row) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const int cj = col0 + (lane & 31);
+        const float uj = cj < a.p ? a.v0[cj] : 0.f;
+        const float wj = cj < a.p ? a.v1[cj] : 0.f;
+        const bool diag = col0 + (kSyCW - 1) >= rb * kSyRB;      // this wave's block meets the diagonal
+        const float* base = a.A + (size_t)col0 * a.lda + row;
+#pragma unroll 1
+        for (int q = 0; q < kSyCW / 8; ++q) {
+            float4 av[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int col = col0 + q * 8 + k;
+                av[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (active && col < a.p) av[k] = *reinterpret_cast<const float4*>(base + (size_t)(q * 8 + k) * a.lda);
+            }
+            float dU[8], dW[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int col = col0 + q * 8 + k;
+                float4 v = av[k];
+                float4 ax = v;                                    // axpy part excludes the diagonal
+                if (diag) {
+                    if (row + 0 < col) v.x = 0.f;
+                    if (row + 1 < col) v.y = 0.f;
+                    if (row + 2 < col) v.z = 0.f;
+                    if (row + 3 < col) v.w = 0.f;
+                    ax = v;
+                    if (row + 0 == col) ax.x = 0.f;
+                    if (row + 1 == col) ax.y = 0.f;
+                    if (row + 2 == col) ax.z = 0.f;
+                    if (row + 3 == col) ax.w = 0.f;
+                }
+                dU[k] = fmaf(v.x, uI.x, fmaf(v.y, uI.y, fmaf(v.z, uI.z, v.w * uI.w)));
+                dW[k] = fmaf(v.x, wI.x, fmaf(v.y, wI.y, fmaf(v.z, wI.z, v.w * wI.w)));
+                const float ujc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(uj), q * 8 + k));
+                const float wjc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wj), q * 8 + k));
+                aU.x = fmaf(ax.x, ujc, aU.x); aU.y = fmaf(ax.y, ujc, aU.y); aU.z = fmaf(ax.z, ujc, aU.z); aU.w = fmaf(ax.w, ujc, aU.w);
+                aW.x = fmaf(ax.x, wjc, aW.x); aW.y = fmaf(ax.y, wjc, aW.y); aW.z = fmaf(ax.z, wjc, aW.z); aW.w = fmaf(ax.w, wjc, aW.w);
+            }
+            // dot part of these 8 columns: every lane ends with column (lane >> 3)
+            const float du = butterfly8(dU, lane);
+            const float dw = butterfly8(dW, lane);
+            if ((lane & 7) == 0) {
+                const int col = col0 + q * 8 + (lane >> 3);
+                if (col < a.p) {
+                    a.dot0[(size_t)rb * a.ldo + col] = du;
+                    a.dot1[(size_t)rb * a.ldo + col] = dw;
+                }
+            }
+        }
+    }
+    // axpy part: add the 4 waves (same rows, different columns)
+    red[0][threadIdx.x] = aU;
+    red[1][threadIdx.x] = aW;
+    __syncthreads();
+    if (wid < 2) {
+        float4 s = red[wid][lane];
+#pragma unroll
+        for (int ww = 1; ww < 4; ++ww) {
+            const float4 o = red[wid][ww * 64 + lane];
+            s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+        }
+        float* dst = (wid == 0 ? a.axp0 : a.axp1) + (size_t)cb * a.ldo + row;
+        *reinterpret_cast<float4*>(dst) = s;
+    }
+}
+
+// Number of row / column blocks and the tile list (host).
+struct SymvPlan {
+    int p = 0, nrb = 0, ncb = 0, ntiles = 0;
+    long long ldo = 0;
+    DevBuf<int2> tiles;
+    DevBuf<float> dot0, dot1, axp0, axp1;
+    void init(int p_, hipStream_t st) {
+        p = p_;
+        nrb = (p + kSyRB - 1) / kSyRB;
+        ncb = (p + kSyCB - 1) / kSyCB;
+        ldo = (long long)nrb * kSyRB;
+        std::vector<int2> h;
+        // heavy (long) row strips first so that the tail of the launch is made of small work
+        for (int rb = nrb - 1; rb >= 0; --rb)
+            for (int cb = 0; cb < ncb; ++cb)
+                if (cb * kSyCB <= rb * kSyRB + (kSyRB - 1)) h.push_back(make_int2(rb, cb));
+        ntiles = (int)h.size();
+        tiles.alloc(h.size());
+        ADMM_HIP_CHECK(hipMemcpyAsync(tiles.get(), h.data(), h.size() * sizeof(int2), hipMemcpyHostToDevice, st));
+        dot0.alloc((size_t)nrb * ldo); dot1.alloc((size_t)nrb * ldo);
+        axp0.alloc((size_t)ncb * ldo); axp1.alloc((size_t)ncb * ldo);
+        dot0.zero(st); dot1.zero(st); axp0.zero(st); axp1.zero(st);
+        ADMM_HIP_CHECK(hipStreamSynchronize(st));
+    }
+    void launch(const float* A, long long lda, const float* v0, const float* v1, const int* skip, hipStream_t st) {
+        SymvArgs a;
+        a.A = A; a.lda = lda; a.p = p; a.v0 = v0; a.v1 = v1;
+        a.dot0 = dot0.get(); a.dot1 = dot1.get(); a.axp0 = axp0.get(); a.axp1 = axp1.get();
+        a.ldo = ldo; a.tiles = tiles.get(); a.skip = skip;
+        hipLaunchKernelGGL(symv2_lower_kernel, dim3(ntiles), dim3(kSyThreads), 0, st, a);
+    }
+};
+
+// y_i from the partial arrays (device helper; `part` = 0 / 1 selects the right-hand side).
+__device__ __forceinline__ float symv_reduce(const float* dot, const float* axp, long long ldo, int nrb, int ncb, int i) {
+    const int cbi = i / kSyCB, rbi = i / kSyRB;
+    float s = 0.f;
+    for (int rb = cbi / 2; rb < nrb; ++rb) s += dot[(size_t)rb * ldo + i];
+    const int cmax = min(ncb - 1, 2 * rbi + 1);
+    for (int cb = 0; cb <= cmax; ++cb) s += axp[(size_t)cb * ldo + i];
+    return s;
+}
+
+}  // namespace admm

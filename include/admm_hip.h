@@ -76,7 +76,7 @@ typedef struct admm_stats {
     double rho;            /* rho actually used (first lambda) */
     double eig_est;        /* the loose Lanczos value (lambda_max or spectral-radius estimate) */
     int branch;            /* 0 tall (Cholesky), 1 wide (linearised), 2 consensus */
-    int reserved;
+    int xupdate_variant;   /* tall path: 0 = full-matrix mat-vec (4p^2 B), 1 = lower-triangle symmetric mat-vec (2p^2 B) */
 } admm_stats;
 
 /* lambda_in: user grid of length nlambda_in (sorted decreasing by the R wrapper), or NULL/0
