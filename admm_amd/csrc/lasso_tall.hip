@@ -39,6 +39,8 @@ struct TallCtl {
     int done;
     int first;
     int total;
+    int fin_idx;    // >= 0: the lambda that finished at this decision (snapshot z, record niter)
+    int fin_niter;
     int pad;
 };
 
@@ -59,77 +61,36 @@ struct TallParams {
 };
 
 constexpr int kTailThreads = 256;
-constexpr int kTailElems = 64;            // elements per workgroup: 4 lanes cooperate on one element's partial sums
+constexpr int kTailLanes = 8;             // lanes cooperating on one element's partial sums
+constexpr int kTailElems = kTailThreads / kTailLanes;
 
-template <bool SYM>
-__global__ void __launch_bounds__(kTailThreads)
-tall_tail_kernel(TallParams q, int par) {
-    __shared__ double sums[8];
-    __shared__ double scratch[6 * (kTailThreads / 64)];
-    extern __shared__ __attribute__((aligned(16))) double pstage[];     // nwg * 8 doubles
+// Scalar control of one iteration, run by a single workgroup: reduce the previous iteration's norm
+// partials, evaluate convergence / acceleration / restart / lambda schedule, publish ctl[par ^ 1].
+__device__ void tall_decide(const TallParams& q, int par) {
+    __shared__ double dscratch[6 * (kTailThreads / 64)];
     const TallCtl in = q.ctl[par];
     TallCtl* outp = &q.ctl[par ^ 1];
     if (in.done) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) *outp = in;       // keep `done` sticky in both slots
+        if (threadIdx.x == 0) { TallCtl o = in; o.fin_idx = -1; *outp = o; }   // keep `done` sticky in both slots
         return;
     }
-    const int np = q.nwg * 8;
-    for (int k = threadIdx.x; k < np; k += kTailThreads) pstage[k] = q.P[(size_t)par * np + k];
-
-    // ---- x-update results a = Minv u, b = Minv w for this workgroup's elements: independent of the
-    // decision, so the (long-latency) partial loads are issued first.  4 lanes share one element.
-    const int sub = threadIdx.x & 3;
-    const int i = blockIdx.x * kTailElems + (threadIdx.x >> 2);
-    const bool valid = i < q.p;
-    float a = 0.f, b = 0.f;
-    if (valid) {
-        if (SYM) {
-            const int cbi = i / kSyCB, rbi = i / kSyRB;
-            const int rb0 = cbi / 2;
-            const int ndot = q.nrb - rb0;
-            const int nax = min(q.ncb - 1, 2 * rbi + 1) + 1;
-            for (int k = sub; k < ndot; k += 4) {
-                const size_t o = (size_t)(rb0 + k) * q.ldo + i;
-                a += q.dot0[o]; b += q.dot1[o];
-            }
-            for (int k = sub; k < nax; k += 4) {
-                const size_t o = (size_t)k * q.ldo + i;
-                a += q.axp0[o]; b += q.axp1[o];
-            }
-        } else {
-            for (int k = sub; k < q.nseg; k += 4) {
-                const size_t o = (size_t)k * q.part_stride + i;
-                a += q.a_part[o]; b += q.b_part[o];
-            }
-        }
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    const double* Pin = q.P + (size_t)par * q.nwg * 8;
+    for (int w = threadIdx.x; w < q.nwg; w += kTailThreads) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc[k] += Pin[(size_t)w * 8 + k];
     }
-    a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64);
-    b += __shfl_xor(b, 1, 64); b += __shfl_xor(b, 2, 64);
-    const int cur = in.total & 1;                      // buffer holding the current z / y
-    const float* zc_ = cur ? q.z1 : q.z0; const float* yc_ = cur ? q.y1 : q.y0;
-    float* zo_ = cur ? q.z0 : q.z1;       float* yo_ = cur ? q.y0 : q.y1;
-    float zc = 0.f, yc = 0.f, zo = 0.f, yo = 0.f, adjz_st = 0.f, adjy_st = 0.f, x_st = 0.f, xy = 0.f;
-    if (valid) { zc = zc_[i]; yc = yc_[i]; zo = zo_[i]; yo = yo_[i]; adjz_st = q.adj_z[i]; adjy_st = q.adj_y[i]; x_st = q.x[i]; xy = q.XY[i]; }
-
-    // ---- decision from the previous iteration's norm partials (every workgroup, identically)
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        const int lane = threadIdx.x, which = lane & 7;
-        double sacc = 0.0;
-        if (which < 6) for (int w = lane >> 3; w < q.nwg; w += 8) sacc += pstage[w * 8 + which];
-        sacc += __shfl_xor(sacc, 8, 64); sacc += __shfl_xor(sacc, 16, 64); sacc += __shfl_xor(sacc, 32, 64);
-        if (lane < 6) sums[lane] = sacc;
-    }
-    __syncthreads();
-    const double r2 = sums[0], dz2 = sums[1], daz2 = sums[2], x2 = sums[3], z2 = sums[4], y2 = sums[5];
+    block_sum<double, 6>(acc, dscratch);
+    if (threadIdx.x != 0) return;
+    const double r2 = acc[0], dz2 = acc[1], daz2 = acc[2], x2 = acc[3], z2 = acc[4], y2 = acc[5];
     TallCtl out = in;
     out.first = 0;
-    int lam_finished = -1, niter_val = 0;
+    out.fin_idx = -1; out.fin_niter = 0;
     if (!in.first) {
         const double rp = sqrt(r2);                    // resid_primal            FADMMBase.h:208
         const double rd = in.rho * sqrt(dz2);          // resid_dual              ADMMLassoTall.h:150-153
         if (rp < in.eps_primal && rd < in.eps_dual) {  // converged()             FADMMBase.h:213-217
-            lam_finished = in.lam_idx; niter_val = in.iter + 1;
+            out.fin_idx = in.lam_idx; out.fin_niter = in.iter + 1;
             out.mode = 0;
         } else {
             const double old_c = in.adj_c;
@@ -144,14 +105,15 @@ tall_tail_kernel(TallParams q, int par) {
             out.mode = 1;
             out.iter = in.iter + 1;
             if (in.iter + 1 >= q.maxit) {              // loop ran out: `return i + 1` with i == maxit
-                lam_finished = in.lam_idx; niter_val = q.maxit + 1;
+                out.fin_idx = in.lam_idx; out.fin_niter = q.maxit + 1;
             }
         }
-        if (lam_finished >= 0) {                       // next lambda: init_warm keeps x,z,y,adj,a,c,rho (ADMMLassoTall.h:219-230)
+        if (out.fin_idx >= 0) {                        // next lambda: init_warm keeps x,z,y,adj,a,c,rho (ADMMLassoTall.h:219-230)
             out.lam_idx = in.lam_idx + 1;
             out.iter = 0;
             if (out.lam_idx >= q.nlam) out.done = 1;
             else out.lam = q.lambdas[out.lam_idx];
+            q.niter[out.fin_idx] = out.fin_niter;
         }
     } else {
         out.mode = 1; out.tau = 0.0; out.restart = 0;  // cold start: adj = 0, x = Minv X'y
@@ -160,48 +122,104 @@ tall_tail_kernel(TallParams q, int par) {
     out.eps_primal = fmax(sqrt(x2), sqrt(z2)) * q.eps_rel + q.sqrt_p * q.eps_abs;
     out.eps_dual = sqrt(y2) * q.eps_rel + q.sqrt_p * q.eps_abs;
     out.total = in.total + 1;
+    *outp = out;
+}
 
+struct TallDecideExtra {
+    TallParams q; int par;
+    __device__ void operator()() const { tall_decide(q, par); }
+};
+
+__global__ void __launch_bounds__(kTailThreads)
+tall_decide_kernel(TallParams q, int par) { tall_decide(q, par); }
+
+// Element-wise part of one iteration.  `c` = the control block published by this iteration's decision.
+template <bool SYM>
+__global__ void __launch_bounds__(kTailThreads)
+tall_tail_kernel(TallParams q, int par) {
+    __shared__ double scratch[6 * (kTailThreads / 64)];
+    const TallCtl c = q.ctl[par ^ 1];
+    // Every load below is independent of `c` (the ping-pong parity equals the launch parity because
+    // the decision advances `total` once per launch), so the whole kernel is one memory round trip.
+    const int sub = threadIdx.x & (kTailLanes - 1);
+    const int i = blockIdx.x * kTailElems + threadIdx.x / kTailLanes;
+    const bool valid = i < q.p;
     const bool owner = valid && sub == 0;
-    if (lam_finished >= 0 && owner) q.beta[(size_t)lam_finished * q.p + i] = zc;   // get_z() snapshot (Lasso.cpp:108)
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (lam_finished >= 0) q.niter[lam_finished] = niter_val;
-        *outp = out;
+    const int cur = par;                               // buffer holding the current z / y
+    const float* zc_ = cur ? q.z1 : q.z0; const float* yc_ = cur ? q.y1 : q.y0;
+    float* zo_ = cur ? q.z0 : q.z1;       float* yo_ = cur ? q.y0 : q.y1;
+    float zc = 0.f, yc = 0.f, zo = 0.f, yo = 0.f, adjz_st = 0.f, adjy_st = 0.f, x_st = 0.f, xy = 0.f;
+    if (owner) { zc = zc_[i]; yc = yc_[i]; zo = zo_[i]; yo = yo_[i]; adjz_st = q.adj_z[i]; adjy_st = q.adj_y[i]; x_st = q.x[i]; xy = q.XY[i]; }
+    // ---- x-update results a = Minv u, b = Minv w: kTailLanes lanes share one element and issue all
+    // their partial loads at once, then combine with shuffles.
+    float a = 0.f, b = 0.f;
+    if (valid) {
+        if (SYM) {
+            const int cbi = i / kSyCB, rbi = i / kSyRB;
+            const int rb0 = cbi / 2;
+            const int ndot = q.nrb - rb0;
+            const int nax = min(q.ncb - 1, 2 * rbi + 1) + 1;
+            const int ntot = ndot + nax;
+            for (int k0 = 0; k0 < ntot; k0 += 8 * kTailLanes) {
+                float va[8], vb[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = k0 + j * kTailLanes + sub;
+                    va[j] = 0.f; vb[j] = 0.f;
+                    if (k < ndot) { const size_t o = (size_t)(rb0 + k) * q.ldo + i; va[j] = q.dot0[o]; vb[j] = q.dot1[o]; }
+                    else if (k < ntot) { const size_t o = (size_t)(k - ndot) * q.ldo + i; va[j] = q.axp0[o]; vb[j] = q.axp1[o]; }
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { a += va[j]; b += vb[j]; }
+            }
+        } else {
+            for (int k = sub; k < q.nseg; k += kTailLanes) {
+                const size_t o = (size_t)k * q.part_stride + i;
+                a += q.a_part[o]; b += q.b_part[o];
+            }
+        }
     }
-    if (out.done) return;
+#pragma unroll
+    for (int m = 1; m < kTailLanes; m <<= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }
+    if (c.done && c.fin_idx < 0) return;
 
     double acc[6] = {0, 0, 0, 0, 0, 0};
     if (owner) {
-        float adjz, adjy, x;
-        if (out.mode) {
-            if (out.restart) { adjz = zo; adjy = yo; x = a - b; }
-            else {
-                const float t = (float)out.tau, t1 = (float)(1.0 + out.tau);
-                adjz = t1 * zc - t * zo;               // (1 + ratio) * aux_z - ratio * old_z   FADMMBase.h:247-248
-                adjy = t1 * yc - t * yo;
-                x = a + t * b;
+        if (c.fin_idx >= 0) q.beta[(size_t)c.fin_idx * q.p + i] = zc;     // get_z() snapshot (Lasso.cpp:108)
+        if (!c.done) {
+            float adjz, adjy, x;
+            if (c.mode) {
+                if (c.restart) { adjz = zo; adjy = yo; x = a - b; }
+                else {
+                    const float t = (float)c.tau, t1 = (float)(1.0 + c.tau);
+                    adjz = t1 * zc - t * zo;           // (1 + ratio) * aux_z - ratio * old_z   FADMMBase.h:247-248
+                    adjy = t1 * yc - t * yo;
+                    x = a + t * b;
+                }
+            } else { adjz = adjz_st; adjy = adjy_st; x = x_st; }
+            const float rho_f = (float)c.rho;
+            const float vec = x + adjy / rho_f;        // next_z: main_x + adj_y / rho            ADMMLassoTall.h:83
+            const double pen = c.lam / c.rho;
+            float zn;
+            if (!q.enet) {                             // soft_threshold, double compare          ADMMLassoTall.h:55-69
+                const double v = (double)vec;
+                zn = v > pen ? (float)(v - pen) : (v < -pen ? (float)(v + pen) : 0.f);
+            } else {                                   // enet()                                  ADMMEnet.h:24-40
+                const float thresh = (float)(q.alpha * pen);
+                const float denom = (float)(1.0 + pen * (1.0 - q.alpha));
+                zn = vec > thresh ? (vec - thresh) / denom : (vec < -thresh ? (vec + thresh) / denom : 0.f);
             }
-        } else { adjz = adjz_st; adjy = adjy_st; x = x_st; }
-        const float rho_f = (float)out.rho;
-        const float vec = x + adjy / rho_f;            // next_z: main_x + adj_y / rho            ADMMLassoTall.h:83
-        const double pen = out.lam / out.rho;
-        float zn;
-        if (!q.enet) {                                 // soft_threshold, double compare          ADMMLassoTall.h:55-69
-            const double v = (double)vec;
-            zn = v > pen ? (float)(v - pen) : (v < -pen ? (float)(v + pen) : 0.f);
-        } else {                                       // enet()                                  ADMMEnet.h:24-40
-            const float thresh = (float)(q.alpha * pen);
-            const float denom = (float)(1.0 + pen * (1.0 - q.alpha));
-            zn = vec > thresh ? (vec - thresh) / denom : (vec < -thresh ? (vec + thresh) / denom : 0.f);
+            const float r = x - zn;                    // next_residual                            ADMMLassoTall.h:86-95
+            const float yn = adjy + rho_f * r;         // dual_y = adj_y + rho * newr              FADMMBase.h:210
+            const float dz = zn - zc, daz = zn - adjz;
+            acc[0] = (double)r * r; acc[1] = (double)dz * dz; acc[2] = (double)daz * daz;
+            acc[3] = (double)x * x; acc[4] = (double)zn * zn; acc[5] = (double)yn * yn;
+            q.x[i] = x; zo_[i] = zn; yo_[i] = yn; q.adj_z[i] = adjz; q.adj_y[i] = adjy;
+            q.u[i] = (float)((double)(xy - yn) + c.rho * (double)zn);
+            q.w[i] = (float)((double)(yc - yn) + c.rho * (double)dz);
         }
-        const float r = x - zn;                        // next_residual                            ADMMLassoTall.h:86-95
-        const float yn = adjy + rho_f * r;             // dual_y = adj_y + rho * newr              FADMMBase.h:210
-        const float dz = zn - zc, daz = zn - adjz;
-        acc[0] = (double)r * r; acc[1] = (double)dz * dz; acc[2] = (double)daz * daz;
-        acc[3] = (double)x * x; acc[4] = (double)zn * zn; acc[5] = (double)yn * yn;
-        q.x[i] = x; zo_[i] = zn; yo_[i] = yn; q.adj_z[i] = adjz; q.adj_y[i] = adjy;
-        q.u[i] = (float)((double)(xy - yn) + out.rho * (double)zn);
-        q.w[i] = (float)((double)(yc - yn) + out.rho * (double)dz);
     }
+    if (c.done) return;
     block_sum<double, 6>(acc, scratch);
     if (threadIdx.x == 0) {
         double* Pout = q.P + ((size_t)(par ^ 1) * q.nwg + blockIdx.x) * 8;
@@ -221,7 +239,7 @@ __global__ void tall_init_kernel(TallParams q, double rho, double lam0) {
         TallCtl c;
         c.rho = rho; c.lam = lam0; c.eps_primal = 0.0; c.eps_dual = 0.0;
         c.adj_a = 1.0; c.adj_c = 9999.0; c.tau = 0.0;
-        c.mode = 1; c.restart = 0; c.iter = 0; c.lam_idx = 0; c.done = 0; c.first = 1; c.total = 0; c.pad = 0;
+        c.mode = 1; c.restart = 0; c.iter = 0; c.lam_idx = 0; c.done = 0; c.first = 1; c.total = 0; c.fin_idx = -1; c.fin_niter = 0; c.pad = 0;
         q.ctl[0] = c; q.ctl[1] = c;
     }
 }
@@ -356,17 +374,22 @@ struct TallPlan final : LassoPlan {
                 const int par = (int)(g & 1);
                 const bool sample = stride > 0 && (g % stride) == 0 && evs.size() < 8192;
                 hipEvent_t e0 = nullptr, e1 = nullptr;
+                if (!use_sym) hipLaunchKernelGGL(tall_decide_kernel, dim3(1), dim3(kTailThreads), 0, st, q, par);
                 if (sample) {
                     ADMM_HIP_CHECK(hipEventCreate(&e0)); ADMM_HIP_CHECK(hipEventCreate(&e1));
                     evs.push_back(e0); evs.push_back(e1);
                     ADMM_HIP_CHECK(hipEventRecord(e0, st));
                 }
-                if (use_sym) sy.launch(M.get(), ldp, u.get(), w.get(), &ctl.get()[par].done, st);
-                else launch_gemv_t<float, 2, 4>(pl, M.get(), ldp, p, p, u.get(), w.get(), a_part.get(), b_part.get(), ldp,
-                                                &ctl.get()[par].done, st);
+                if (use_sym) {
+                    // the decision of this iteration rides along as one extra workgroup of the x-update launch
+                    sy.launch(M.get(), ldp, u.get(), w.get(), &ctl.get()[par].done, st, TallDecideExtra{q, par});
+                } else {
+                    launch_gemv_t<float, 2, 4>(pl, M.get(), ldp, p, p, u.get(), w.get(), a_part.get(), b_part.get(), ldp,
+                                               &ctl.get()[par].done, st);
+                }
                 if (sample) ADMM_HIP_CHECK(hipEventRecord(e1, st));
-                if (use_sym) hipLaunchKernelGGL(tall_tail_kernel<true>, dim3(nwg), dim3(kTailThreads), (size_t)nwg * 8 * sizeof(double), st, q, par);
-                else hipLaunchKernelGGL(tall_tail_kernel<false>, dim3(nwg), dim3(kTailThreads), (size_t)nwg * 8 * sizeof(double), st, q, par);
+                if (use_sym) hipLaunchKernelGGL(tall_tail_kernel<true>, dim3(nwg), dim3(kTailThreads), 0, st, q, par);
+                else hipLaunchKernelGGL(tall_tail_kernel<false>, dim3(nwg), dim3(kTailThreads), 0, st, q, par);
                 ++launches;
             }
             // after an even number of iterations the freshest control block is slot g&1 == 0

@@ -64,11 +64,17 @@ __device__ __forceinline__ float butterfly8(const float (&v)[8], int lane) {
     return r;
 }
 
+// `Extra`: a functor run by ONE additional workgroup (block 0) concurrently with the tiles; the tall
+// solver uses it for its scalar iteration control, which then costs no launch and no latency.
+struct SymvNoExtra { __device__ void operator()() const {} };
+
+template <typename Extra>
 __global__ void __launch_bounds__(kSyThreads, 4)
-symv2_lower_kernel(SymvArgs a) {
+symv2_lower_kernel(SymvArgs a, Extra extra) {
+    if (blockIdx.x == 0) { extra(); return; }
     if (a.skip != nullptr && *a.skip != 0) return;
     __shared__ float4 red[2][kSyThreads];
-    const int2 t = a.tiles[blockIdx.x];
+    const int2 t = a.tiles[blockIdx.x - 1];
     const int rb = t.x, cb = t.y;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int row = rb * kSyRB + lane * 4;
@@ -170,12 +176,13 @@ struct SymvPlan {
         dot0.zero(st); dot1.zero(st); axp0.zero(st); axp1.zero(st);
         ADMM_HIP_CHECK(hipStreamSynchronize(st));
     }
-    void launch(const float* A, long long lda, const float* v0, const float* v1, const int* skip, hipStream_t st) {
+    template <typename Extra = SymvNoExtra>
+    void launch(const float* A, long long lda, const float* v0, const float* v1, const int* skip, hipStream_t st, Extra extra = Extra()) {
         SymvArgs a;
         a.A = A; a.lda = lda; a.p = p; a.v0 = v0; a.v1 = v1;
         a.dot0 = dot0.get(); a.dot1 = dot1.get(); a.axp0 = axp0.get(); a.axp1 = axp1.get();
         a.ldo = ldo; a.tiles = tiles.get(); a.skip = skip;
-        hipLaunchKernelGGL(symv2_lower_kernel, dim3(ntiles), dim3(kSyThreads), 0, st, a);
+        hipLaunchKernelGGL((symv2_lower_kernel<Extra>), dim3(ntiles + 1), dim3(kSyThreads), 0, st, a, extra);
     }
 };
 

@@ -44,7 +44,7 @@ int main(int argc, char** argv) {
     (void)hipMemcpy(w.get(), hw.data(), p * 4, hipMemcpyHostToDevice);
     GemvTPlan pl = plan_gemv_t<float>(p, p, 2, 4);
     launch_gemv_t<float, 2, 4>(pl, M.get(), ldp, p, p, u.get(), w.get(), a.get(), b.get(), ldp, nullptr, st);
-    sp.launch(M.get(), ldp, u.get(), w.get(), nullptr, st);
+    sp.launch(M.get(), ldp, u.get(), w.get(), nullptr, st, SymvNoExtra());
     hipLaunchKernelGGL(symv_finish, dim3((p + 255) / 256), dim3(256), 0, st, sp.dot0.get(), sp.axp0.get(), sp.dot1.get(), sp.axp1.get(), sp.ldo, sp.nrb, sp.ncb, p, y0.get(), y1.get());
     (void)hipStreamSynchronize(st);
     std::vector<float> ha((size_t)pl.nseg * ldp), hb((size_t)pl.nseg * ldp), hy0(p), hy1(p);
@@ -60,7 +60,7 @@ int main(int argc, char** argv) {
         n0 = std::max(n0, (double)std::fabs(ra)); n1 = std::max(n1, (double)std::fabs(rb));
     }
     printf("p=%d tiles=%d  max|diff| u: %.3e (max %.3e)  w: %.3e (max %.3e)\n", p, sp.ntiles, e0, n0, e1, n1);
-    double t_sym = time_ms([&] { sp.launch(M.get(), ldp, u.get(), w.get(), nullptr, st); }, st, 50);
+    double t_sym = time_ms([&] { sp.launch(M.get(), ldp, u.get(), w.get(), nullptr, st, SymvNoExtra()); }, st, 50);
     double t_fin = time_ms([&] { hipLaunchKernelGGL(symv_finish, dim3((p + 255) / 256), dim3(256), 0, st, sp.dot0.get(), sp.axp0.get(), sp.dot1.get(), sp.axp1.get(), sp.ldo, sp.nrb, sp.ncb, p, y0.get(), y1.get()); }, st, 50);
     double t_gemv = time_ms([&] { launch_gemv_t<float, 2, 4>(pl, M.get(), ldp, p, p, u.get(), w.get(), a.get(), b.get(), ldp, nullptr, st); }, st, 50);
     printf("symv %.2f us (%.0f GB/s of 4p^2, %.0f GB/s of 2p^2)   finish %.2f us   gemv_t %.2f us\n", t_sym * 1e3, 4.0 * p * p / (t_sym * 1e-3) / 1e9,
