@@ -180,6 +180,15 @@ def main():
         achieved = alg_bytes / (x_ms * 1e-3) if x_ms > 0 else 0.0
         kname = ("symv2_lower_kernel (x-update, lower triangle of the cached inverse x [u w])" if sym
                  else "gemv_t_kernel<float,2,4> (x-update, cached inverse x [u w])")
+        traffic, traffic_src = None, None
+        try:        # PMC counters cannot be collected from inside the run: quote the committed measurement for this exact shape
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            ent = pmc.get("symv2_lower_kernel" if sym else "gemv_t_kernel")
+            if ent and int(ent["p"]) == p:
+                traffic = ent["hbm_read_bytes"] + ent["hbm_write_bytes"]
+                traffic_src = ent["source"]
+        except Exception:
+            pass
         out = {
             "metric": "ADMM iterations/sec, Lasso tall n=%d p=%d (100-lambda warm-started path)" % (n, p),
             "value": iters_all / elapsed_max,
@@ -205,7 +214,7 @@ def main():
             "nnz_last_lambda": int(np.count_nonzero(fit.beta_dense[1:, -1])),
             "roofline": {"bound": "hbm", "kernel": kname,
                          "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK, "traffic": None,
+                         "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": x_ms, "launches_timed": xsamp,
                          "survey_4p2_equivalent_GBps": 4.0 * p * p / (x_ms * 1e-3) / 1e9 if x_ms > 0 else 0.0},
         }
