@@ -1,0 +1,87 @@
+#!/usr/bin/env python
+"""Measure the non-headline BASELINE.json configs (C3 wide, C4 consensus on one GPU, C5 LAD / BP) on
+device-resident synthetic data: iterations, loop seconds, iterations/s and achieved algorithmic GB/s
+(SURVEY.md section 8d byte counts).  Prints one JSON line per config.  Usage: bench_configs.py [c3 c4 c5lad c5bp]"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402  (before libadmm_hip)
+import numpy as np  # noqa: E402
+from admm_amd import DevicePtr, admm_bp, admm_lad, admm_lasso  # noqa: E402
+
+dev = torch.device("cuda", 0)
+g = torch.Generator(device=dev)
+g.manual_seed(123)
+
+
+def gen(n, p, sd, m, dense_beta=False, noise=True):
+    xt = torch.empty((p, n), dtype=torch.float64, device=dev)
+    chunk = max(1, (1 << 27) // n)
+    for c0 in range(0, p, chunk):
+        c1 = min(p, c0 + chunk)
+        xt[c0:c1] = torch.randn((c1 - c0, n), generator=g, device=dev, dtype=torch.float64) * sd
+    b = torch.zeros(p, dtype=torch.float64, device=dev)
+    if dense_beta:
+        b[:] = torch.rand(p, generator=g, device=dev, dtype=torch.float64)
+    else:
+        idx = torch.randperm(p, generator=g, device=dev)[:m] if not noise else torch.arange(m, device=dev)
+        b[idx] = torch.rand(m, generator=g, device=dev, dtype=torch.float64)
+    y = b @ xt
+    if noise:
+        y = y + torch.randn(n, generator=g, device=dev, dtype=torch.float64)
+    torch.cuda.synchronize()
+    return xt, y, b
+
+
+def report(name, fit, bytes_per_iter, extra=None):
+    st = fit.stats
+    it = int(st["total_iter"])
+    out = {"config": name, "iterations": it, "loop_s": st["t_loop"], "iters_per_s": it / st["t_loop"],
+           "alg_GB_per_iter": bytes_per_iter / 1e9, "achieved_GBps": bytes_per_iter * it / st["t_loop"] / 1e9,
+           "frac_of_8TBps": bytes_per_iter * it / st["t_loop"] / 8e12,
+           "setup_s": {k: round(st[k], 4) for k in ("t_standardize", "t_gram", "t_eigs", "t_factor")}, "total_s": st["t_total"]}
+    if extra:
+        out.update(extra)
+    print(json.dumps(out), flush=True)
+
+
+which = sys.argv[1:] or ["c3", "c4", "c5lad", "c5bp"]
+if "c3" in which:       # wide Lasso n=2000 p=200000, 100-lambda path (lambda_min_ratio 0.01)
+    n, p = 2000, 200000
+    xt, y, _ = gen(n, p, 2.0, 100)
+    fit = admm_lasso(DevicePtr(xt.data_ptr()), DevicePtr(y.data_ptr()), n=n, p=p).penalty(nlambda=100).fit()
+    nnz = int(np.count_nonzero(fit.beta_dense[1:, -1]))
+    # bytes: a regular iteration streams X once (4np); every iteration reads the support twice (8 n nS): nS unknown per
+    # iteration, so only the regular-step stream is counted here (lower bound of the traffic)
+    niter = fit.niter.astype(np.int64)
+    reg = sum(int(sum(1 for c in range(k) if (c + 1) & c == 0 and ((c + 1) & 0x55555555))) for k in niter)
+    report("C3 admm_lasso wide n=2000 p=200000 nlambda=100", fit, 4.0 * n * p * reg / max(1, int(niter.sum())),
+           {"regular_iterations": reg, "nnz_last_lambda": nnz, "niter_minmax": [int(niter.min()), int(niter.max())]})
+    del xt
+    torch.cuda.empty_cache()
+if "c4" in which:       # consensus Lasso n=10000 p=100000, 8 row blocks on ONE GPU (Woodbury branch), short path
+    n, p, K = 10000, 100000, 8
+    xt, y, _ = gen(n, p, 2.0, 100)
+    fit = admm_lasso(DevicePtr(xt.data_ptr()), DevicePtr(y.data_ptr()), n=n, p=p).penalty(nlambda=5, lambda_min_ratio=0.1).parallel(K).opts(maxit=300).fit()
+    report("C4 admm_lasso$parallel(8) n=10000 p=100000 (8 virtual workers on 1 GPU), 5 lambdas, maxit 300", fit, 8.0 * n * p + 4.0 * K * (n / K) ** 2,
+           {"niter": [int(v) for v in fit.niter]})
+    del xt
+    torch.cuda.empty_cache()
+if "c5lad" in which:    # LAD n=50000 p=5000 fp64
+    n, p = 50000, 5000
+    xt, y, _ = gen(n, p, 2.0, p, dense_beta=True)
+    fit = admm_lad(DevicePtr(xt.data_ptr()), DevicePtr(y.data_ptr()), intercept=False, n=n, p=p).fit()
+    report("C5 admm_lad n=50000 p=5000 fp64", fit, 16.0 * n * p + 8.0 * p * p)
+    del xt
+    torch.cuda.empty_cache()
+if "c5bp" in which:     # BP n=5000 p=50000 fp64, 500 non-zeros, exact y
+    n, p = 5000, 50000
+    xt, y, b = gen(n, p, 1.0, 500, noise=False)
+    fit = admm_bp(DevicePtr(xt.data_ptr()), DevicePtr(y.data_ptr()), n=n, p=p).fit()
+    beta = np.asarray(fit.beta.todense()).ravel()
+    err = beta - b.cpu().numpy()
+    report("C5 admm_bp n=5000 p=50000 fp64", fit, 16.0 * n * p, {"recovery_error_range": [float(err.min()), float(err.max())]})
