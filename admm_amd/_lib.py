@@ -50,7 +50,8 @@ _c_int_p = ctypes.POINTER(ctypes.c_int)
 EXPORTS = ["admm_hip_lasso", "admm_hip_enet", "admm_hip_parlasso", "admm_hip_lad", "admm_hip_bp",
            "admm_hip_last_error", "admm_hip_version", "admm_hip_device_count", "admm_hip_set_device",
            "admm_hip_device_synchronize", "admm_hip_lasso_plan_create", "admm_hip_lasso_plan_run",
-           "admm_hip_lasso_plan_destroy"]
+           "admm_hip_lasso_plan_destroy", "admm_hip_comm_unique_id", "admm_hip_comm_init", "admm_hip_comm_finalize",
+           "admm_hip_parlasso_dist", "admm_hip_lasso_plan_create_dist"]
 
 
 def load():
@@ -86,6 +87,18 @@ def load():
     lib.admm_hip_lasso_plan_run.restype = ctypes.c_int
     lib.admm_hip_lasso_plan_destroy.argtypes = [ctypes.c_void_p]
     lib.admm_hip_lasso_plan_destroy.restype = ctypes.c_int
+    dist_args = [_DP, _DP, ctypes.c_int, ctypes.c_longlong, ctypes.c_int, ctypes.c_int,
+                 _DP, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(AdmmOpts)]
+    lib.admm_hip_parlasso_dist.argtypes = dist_args + [_c_double_p, _c_float_p, _c_int_p, ctypes.POINTER(AdmmStats)]
+    lib.admm_hip_parlasso_dist.restype = ctypes.c_int
+    lib.admm_hip_lasso_plan_create_dist.argtypes = dist_args + [ctypes.POINTER(ctypes.c_void_p), _c_int_p]
+    lib.admm_hip_lasso_plan_create_dist.restype = ctypes.c_int
+    lib.admm_hip_comm_unique_id.argtypes = [ctypes.c_void_p]
+    lib.admm_hip_comm_unique_id.restype = ctypes.c_int
+    lib.admm_hip_comm_init.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    lib.admm_hip_comm_init.restype = ctypes.c_int
+    lib.admm_hip_comm_finalize.argtypes = []
+    lib.admm_hip_comm_finalize.restype = ctypes.c_int
     lib.admm_hip_host_lanczos.argtypes = [_c_float_p, ctypes.c_int, _c_float_p, _c_int_p]
     lib.admm_hip_host_lanczos.restype = ctypes.c_int
     _lib = lib

@@ -1,8 +1,12 @@
 // extern "C" boundary of libadmm_hip.so (see include/admm_hip.h).
 #include "solvers.h"
+#include "comm.h"
 
 namespace admm {
 const std::string& last_error_ref();
+int comm_unique_id(void* out);
+void comm_init(int nranks, int rank, const void* idbytes);
+void comm_finalize();
 
 std::vector<double> make_lambda_grid(const LassoProblem& pb, double lambda0, int n, double scaleY) {
     if (!pb.lambda_in.empty()) return pb.lambda_in;
@@ -60,13 +64,18 @@ struct PlanHandle {
 static PlanHandle* create_plan(const double* x, const double* y, int n, int p, int mem,
                                const double* lambda_in, int nlambda_in, int nlambda_auto, double lmin_ratio,
                                int standardize, int intercept, bool enet, double alpha, int nworkers,
-                               const admm_opts* opts) {
+                               const admm_opts* opts, long long n_total = 0) {
     check_common(x, y, n, p, mem, opts);
     ADMM_REQUIRE(nlambda_in >= 0, "nlambda_in must be >= 0");
     ADMM_REQUIRE(nlambda_in > 0 ? lambda_in != nullptr : nlambda_auto > 0, "need a lambda grid or nlambda_auto > 0");
     if (nlambda_in == 0) ADMM_REQUIRE(lmin_ratio > 0 && lmin_ratio < 1, "lambda_min_ratio must be within (0, 1)");
     for (int i = 0; i < nlambda_in; ++i) ADMM_REQUIRE(lambda_in[i] > 0, "lambda must be positive");
-    if (nworkers > 0) ADMM_REQUIRE(nworkers <= n, "more row blocks than rows");
+    const bool dist = n_total > 0;
+    if (nworkers > 0 && !dist) ADMM_REQUIRE(nworkers <= n, "more row blocks than rows");
+    if (dist) {
+        ADMM_REQUIRE(nworkers > 0, "the distributed entry point is the consensus solver: nthread must be >= 1");
+        ADMM_REQUIRE(comm_info().active, "no communicator: call admm_hip_comm_init first");
+    }
     require_device();
     const double t0 = now_s();
     std::unique_ptr<PlanHandle> h(new PlanHandle());
@@ -78,10 +87,11 @@ static PlanHandle* create_plan(const double* x, const double* y, int n, int p, i
     pb.enet = enet;
     pb.alpha = alpha;
     pb.nworkers = nworkers;
+    pb.dist = dist;
     pb.batch_iters = env_int("ADMM_HIP_BATCH_ITERS", 0);
     pb.profile_stride = env_int("ADMM_HIP_PROFILE_STRIDE", 0);
     DeviceData<float> d;
-    upload_standardize<float>(d, x, y, n, p, mem, standardize != 0, intercept != 0, h->st.s);
+    upload_standardize<float>(d, x, y, n, p, mem, standardize != 0, intercept != 0, h->st.s, dist ? n_total : 0);
     if (nworkers > 0) h->plan = make_par_plan(std::move(d), pb, h->st.s);
     else if (n > p) h->plan = make_tall_plan(std::move(d), pb, h->st.s);      // Lasso.cpp:73
     else h->plan = make_wide_plan(std::move(d), pb, h->st.s);
@@ -213,6 +223,43 @@ int admm_hip_lasso_plan_create(const double* x, const double* y, int n, int p, i
         *plan_out = reinterpret_cast<admm_hip_plan*>(h);
         if (nlambda_out) *nlambda_out = h->nlam;
     });
+}
+
+int admm_hip_lasso_plan_create_dist(const double* x_local, const double* y_local, int n_local, long long n_total, int p, int mem,
+                                    const double* lambda_in, int nlambda_in, int nlambda_auto, double lmin_ratio,
+                                    int standardize, int intercept, int nthread, const admm_opts* opts,
+                                    admm_hip_plan** plan_out, int* nlambda_out) {
+    return guarded([&] {
+        ADMM_REQUIRE(plan_out != nullptr, "plan_out must not be NULL");
+        ADMM_REQUIRE(n_total >= n_local && n_local > 0, "n_total must be >= n_local > 0");
+        PlanHandle* h = create_plan(x_local, y_local, n_local, p, mem, lambda_in, nlambda_in, nlambda_auto, lmin_ratio,
+                                    standardize, intercept, false, 1.0, nthread, opts, n_total);
+        *plan_out = reinterpret_cast<admm_hip_plan*>(h);
+        if (nlambda_out) *nlambda_out = h->nlam;
+    });
+}
+
+int admm_hip_parlasso_dist(const double* x_local, const double* y_local, int n_local, long long n_total, int p, int mem,
+                           const double* lambda_in, int nlambda_in, int nlambda_auto, double lmin_ratio,
+                           int standardize, int intercept, int nthread, const admm_opts* opts,
+                           double* lambda_out, float* beta_out, int* niter_out, admm_stats* stats) {
+    return guarded([&] {
+        ADMM_REQUIRE(lambda_out && beta_out && niter_out, "output pointers must not be NULL");
+        ADMM_REQUIRE(n_total >= n_local && n_local > 0, "n_total must be >= n_local > 0");
+        std::unique_ptr<PlanHandle> h(create_plan(x_local, y_local, n_local, p, mem, lambda_in, nlambda_in, nlambda_auto, lmin_ratio,
+                                                  standardize, intercept, false, 1.0, nthread, opts, n_total));
+        run_plan(h.get(), lambda_out, beta_out, niter_out, stats, h->t_create);
+    });
+}
+
+int admm_hip_comm_unique_id(void* id_out) {
+    return guarded([&] { ADMM_REQUIRE(id_out != nullptr, "id_out must not be NULL"); comm_unique_id(id_out); });
+}
+int admm_hip_comm_init(int nranks, int rank, const void* id) {
+    return guarded([&] { ADMM_REQUIRE(id != nullptr, "id must not be NULL"); require_device(); comm_init(nranks, rank, id); });
+}
+int admm_hip_comm_finalize(void) {
+    return guarded([&] { comm_finalize(); });
 }
 
 int admm_hip_lasso_plan_run(admm_hip_plan* plan, double* lambda_out, float* beta_out, int* niter_out, admm_stats* stats) {

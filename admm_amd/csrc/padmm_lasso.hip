@@ -18,6 +18,7 @@
 #include "gemv_kernels.h"
 #include "solvers.h"
 #include "loop_driver.h"
+#include "comm.h"
 
 namespace admm {
 
@@ -30,46 +31,85 @@ constexpr int kParMaxWorkers = 64;
 constexpr int kParThreads = 256;
 
 struct ParParams {
-    int p, K, maxit, nlam, nwg;
+    int p, K, Kl, maxit, nlam, nwg;     // K: row blocks of the whole problem; Kl: blocks owned by this process
     long long ldv;                 // stride between the per-worker p-vectors
     double rho, eps_abs, eps_rel;
     const double* lambdas;
-    const float* Ab;               // [K][ldv]
-    float* rhs;                    // [K][ldv]
-    float* x;                      // [K][ldv]
-    float* y;                      // [K][ldv]
+    const float* Ab;               // [Kl][ldv]
+    float* rhs;                    // [Kl][ldv]
+    float* x;                      // [Kl][ldv]
+    float* y;                      // [Kl][ldv]
     float* z;                      // [ldv]
-    float* wsum;                   // [ldv]  consensus sum (the all-reduce payload)
-    // per worker: result of the last mat-vec of the x-update
+    float* wsum;                   // [ldv]  consensus sum (the all-reduce payload, together with nsum[0..2])
+    double* nsum;                  // [8]: sum_k|x_k|^2, sum_k|y_k|^2, sum_k|x_k - z|^2 (summed over ranks), |z|^2, |z_new - z_old|^2
+    // per local worker: result of the last mat-vec of the x-update
     const float* gout[kParMaxWorkers]; int gnseg[kParMaxWorkers]; long long gstride[kParMaxWorkers];
     int wide[kParMaxWorkers];      // 1: Woodbury branch, x = (rhs - gout) / rho ; 0: x = gout
     ParCtl* ctl;                   // [2]
-    double* P;                     // [nwg][8]: sum_k|x_k|^2, sum_k|y_k|^2, sum_k|x_k - z|^2, |z|^2, |z_new - z_old|^2
+    double* P;                     // [nwg][8] per-workgroup partials of the five sums
     float* beta; int* niter; int* done;
 };
 
-// head(g): decision for iteration g-1 (PADMMBase.h:216-221, 230-231), eps for iteration g (:174-178),
-// then rhs_k = A_k'b_k - y_k + rho z (PADMMLasso.h:19-21).
+// head: rhs_k = A_k'b_k - y_k + rho z (PADMMLasso.h:19-21) for the local workers.
 __global__ void __launch_bounds__(kParThreads)
-par_head_kernel(ParParams q, int par) {
-    __shared__ double sums[8];
-    extern __shared__ __attribute__((aligned(16))) double pstage[];
+par_head_kernel(ParParams q) {
+    if (*q.done) return;
+    for (int i = blockIdx.x * kParThreads + threadIdx.x; i < q.p; i += gridDim.x * kParThreads) {
+        const double rz = q.rho * (double)q.z[i];
+        for (int k = 0; k < q.Kl; ++k) {
+            const size_t o = (size_t)k * q.ldv + i;
+            const float r0 = q.Ab[o] - q.y[o];
+            q.rhs[o] = (float)((double)r0 + rz);                                      // rhs[idx] += rho * value (double)
+        }
+    }
+}
+
+// pack: x_k from the mat-vec results, consensus sum w = sum_k (x_k + y_k / rho)   (PADMMLasso.h:65-68,101-105);
+// workgroup 0 also folds the previous iteration's per-workgroup norm partials into nsum[0..4].
+__global__ void __launch_bounds__(kParThreads)
+par_pack_kernel(ParParams q) {
+    __shared__ double scratch[5 * (kParThreads / 64)];
+    if (*q.done) return;
+    if (blockIdx.x == 0) {
+        double acc[5] = {0, 0, 0, 0, 0};
+        for (int w = threadIdx.x; w < q.nwg; w += kParThreads) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) acc[k] += q.P[(size_t)w * 8 + k];
+        }
+        block_sum<double, 5>(acc, scratch);
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) q.nsum[k] = acc[k];
+        }
+    }
+    const float rho_f = (float)q.rho;
+    for (int i = blockIdx.x * kParThreads + threadIdx.x; i < q.p; i += gridDim.x * kParThreads) {
+        float w = 0.f;
+        for (int k = 0; k < q.Kl; ++k) {
+            const size_t o = (size_t)k * q.ldv + i;
+            float g = 0.f;
+            for (int s = 0; s < q.gnseg[k]; ++s) g += q.gout[k][(size_t)s * q.gstride[k] + i];
+            const float x = q.wide[k] ? (q.rhs[o] - g) / rho_f : g;                   // PADMMLasso.h:23-30
+            q.x[o] = x;
+            w += x + q.y[o] / rho_f;
+        }
+        q.wsum[i] = w;
+    }
+}
+
+// z(g): decision for iteration g-1 from nsum (after the all-reduce every rank holds identical numbers and
+// takes identical decisions: PADMMBase.h:216-221,230-231; eps :117-139), lambda schedule, then
+// z_new = soft(w / K, lambda / (rho K)); y_k += rho (x_k - z_new); norms   (PADMMLasso.h:99-108, PADMMBase.h:70-78)
+__global__ void __launch_bounds__(kParThreads)
+par_z_kernel(ParParams q, int par) {
+    __shared__ double scratch[5 * (kParThreads / 64)];
     const ParCtl in = q.ctl[par];
     ParCtl* outp = &q.ctl[par ^ 1];
     if (in.done) {
         if (blockIdx.x == 0 && threadIdx.x == 0) *outp = in;
         return;
     }
-    const int np = q.nwg * 8;
-    for (int k = threadIdx.x; k < np; k += kParThreads) pstage[k] = q.P[k];
-    __syncthreads();
-    if (threadIdx.x < 5) {
-        double s = 0.0;
-        for (int w = 0; w < q.nwg; ++w) s += pstage[w * 8 + threadIdx.x];
-        sums[threadIdx.x] = s;
-    }
-    __syncthreads();
-    const double x2 = sums[0], y2 = sums[1], r2 = sums[2], z2 = sums[3], dz2 = sums[4];
+    const double x2 = q.nsum[0], y2 = q.nsum[1], r2 = q.nsum[2], z2 = q.nsum[3], dz2 = q.nsum[4];
     ParCtl out = in;
     out.first = 0;
     int lam_finished = -1, niter_val = 0;
@@ -96,54 +136,17 @@ par_head_kernel(ParParams q, int par) {
         *outp = out;
         if (out.done) *q.done = 1;
     }
-    for (int i = blockIdx.x * kParThreads + threadIdx.x; i < q.p; i += gridDim.x * kParThreads) {
-        const float z = q.z[i];
-        if (lam_finished >= 0) q.beta[(size_t)lam_finished * q.p + i] = z;           // get_z()  ParLasso.cpp:98
-        if (!out.done) {
-            const double rz = q.rho * (double)z;
-            for (int k = 0; k < q.K; ++k) {
-                const size_t o = (size_t)k * q.ldv + i;
-                const float r0 = q.Ab[o] - q.y[o];
-                q.rhs[o] = (float)((double)r0 + rz);                                  // rhs[idx] += rho * value (double)
-            }
-        }
-    }
-}
-
-// pack: x_k from the mat-vec results, consensus sum w = sum_k (x_k + y_k / rho)   (PADMMLasso.h:65-68,101-105)
-__global__ void __launch_bounds__(kParThreads)
-par_pack_kernel(ParParams q) {
-    if (*q.done) return;
     const float rho_f = (float)q.rho;
-    for (int i = blockIdx.x * kParThreads + threadIdx.x; i < q.p; i += gridDim.x * kParThreads) {
-        float w = 0.f;
-        for (int k = 0; k < q.K; ++k) {
-            const size_t o = (size_t)k * q.ldv + i;
-            float g = 0.f;
-            for (int s = 0; s < q.gnseg[k]; ++s) g += q.gout[k][(size_t)s * q.gstride[k] + i];
-            const float x = q.wide[k] ? (q.rhs[o] - g) / rho_f : g;                   // PADMMLasso.h:23-30
-            q.x[o] = x;
-            w += x + q.y[o] / rho_f;
-        }
-        q.wsum[i] = w;
-    }
-}
-
-// z: z_new = soft(w / K, lambda / (rho K)); y_k += rho (x_k - z_new); norms   (PADMMLasso.h:99-108, PADMMBase.h:70-78)
-__global__ void __launch_bounds__(kParThreads)
-par_z_kernel(ParParams q, int par) {
-    __shared__ double scratch[5 * (kParThreads / 64)];
-    const ParCtl c = q.ctl[par ^ 1];
-    if (c.done) return;
-    const float rho_f = (float)q.rho;
-    const double pen = c.lam / (q.rho * (double)q.K);
+    const double pen = out.lam / (q.rho * (double)q.K);
     double acc[5] = {0, 0, 0, 0, 0};
     for (int i = blockIdx.x * kParThreads + threadIdx.x; i < q.p; i += gridDim.x * kParThreads) {
+        const float zo = q.z[i];
+        if (lam_finished >= 0) q.beta[(size_t)lam_finished * q.p + i] = zo;           // get_z()  ParLasso.cpp:98
+        if (out.done) continue;
         const float v = q.wsum[i] / (float)q.K;
         const double vd = (double)v;
         const float zn = vd > pen ? (float)(vd - pen) : (vd < -pen ? (float)(vd + pen) : 0.f);
-        const float zo = q.z[i];
-        for (int k = 0; k < q.K; ++k) {
+        for (int k = 0; k < q.Kl; ++k) {
             const size_t o = (size_t)k * q.ldv + i;
             const float x = q.x[o];
             const float r = x - zn;
@@ -155,6 +158,7 @@ par_z_kernel(ParParams q, int par) {
         acc[3] += (double)zn * zn; acc[4] += (double)dz * dz;
         q.z[i] = zn;
     }
+    if (out.done) return;
     block_sum<double, 5>(acc, scratch);
     if (threadIdx.x == 0) {
         double* Pout = q.P + (size_t)blockIdx.x * 8;
@@ -167,9 +171,10 @@ __global__ void par_init_kernel(ParParams q, double lam0) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < q.p) {
         q.z[i] = 0.f; q.wsum[i] = 0.f;
-        for (int k = 0; k < q.K; ++k) { const size_t o = (size_t)k * q.ldv + i; q.x[o] = 0.f; q.y[o] = 0.f; q.rhs[o] = 0.f; }
+        for (int k = 0; k < q.Kl; ++k) { const size_t o = (size_t)k * q.ldv + i; q.x[o] = 0.f; q.y[o] = 0.f; q.rhs[o] = 0.f; }
     }
     if (i < q.nwg * 8) q.P[i] = 0.0;
+    if (i < 8) q.nsum[i] = 0.0;
     if (i == 0) {
         ParCtl c;
         c.lam = lam0; c.eps_primal = 0; c.eps_dual = 0; c.iter = 0; c.lam_idx = 0; c.done = 0; c.first = 1; c.total = 0;
@@ -198,8 +203,10 @@ struct ParPlan final : LassoPlan {
     LassoProblem pb;
     hipStream_t st;
     admm_stats setup_stats{};
-    int p = 0, K = 0, nlam = 0, nwg = 0;
+    int p = 0, K = 0, Kl = 0, nlam = 0, nwg = 0;
     long long ldv = 0;
+    CommInfo ci;
+    DevBuf<double> nsum;
     double rho = 0;
     std::vector<double> lam_user, lam_int;
     std::vector<ParWorker> W;
@@ -211,8 +218,18 @@ struct ParPlan final : LassoPlan {
 
     ParPlan(DeviceData<float>&& data, const LassoProblem& prob, hipStream_t stream) : d(std::move(data)), pb(prob), st(stream) {
         const int n = d.n;
+        const long long nt = d.n_total;
         p = d.p; K = pb.nworkers;
-        ADMM_REQUIRE(K >= 1 && K <= kParMaxWorkers, "number of row blocks must be within [1, 64]");
+        ci = pb.dist ? comm_info() : CommInfo();
+        ADMM_REQUIRE(K >= 1, "number of row blocks must be >= 1");
+        ADMM_REQUIRE(K % ci.nranks == 0, "the number of row blocks must be a multiple of the number of ranks");
+        Kl = K / ci.nranks;
+        ADMM_REQUIRE(Kl <= kParMaxWorkers, "at most 64 row blocks per process");
+        // the reference's partition of the GLOBAL rows (PADMMLasso.h:163-179): chunk = n / K, last block takes the remainder
+        const long long chunk = nt / K;
+        ADMM_REQUIRE(chunk >= 1, "more row blocks than rows");
+        const long long expect = (long long)Kl * chunk + (ci.rank == ci.nranks - 1 ? nt - chunk * K : 0);
+        ADMM_REQUIRE(expect == n, "this rank's row count does not match the reference row partition");
         admm_stats& S = setup_stats;
         S.branch = 2; S.t_h2d = d.t_h2d; S.t_standardize = d.t_std;
         ldv = round_up(p, 32);
@@ -220,24 +237,24 @@ struct ParPlan final : LassoPlan {
         // lambda_0 from the full data (PADMMLasso.h:161)
         DevBuf<float> XY(ldv); XY.zero(st);
         gemv_t_simple<float>(d.X.get(), d.ldx, n, p, d.Y.get(), XY.get(), st);
+        if (pb.dist) { allreduce_sum_f32(XY.get(), p, st); ADMM_HIP_CHECK(hipStreamSynchronize(st)); }
         const float lambda0 = device_absmax<float>(XY.get(), p, st);
-        lam_user = make_lambda_grid(pb, lambda0, n, (double)d.scaleY);
+        lam_user = make_lambda_grid(pb, lambda0, (int)nt, (double)d.scaleY);
         nlam = (int)lam_user.size();
         lam_int.resize(nlam);
-        for (int i = 0; i < nlam; ++i) lam_int[i] = lam_user[i] * n / (double)d.scaleY;   // `double lambda` in the master
+        for (int i = 0; i < nlam; ++i) lam_int[i] = lam_user[i] * (double)nt / (double)d.scaleY;   // `double lambda` in the master
         rho = pb.opts.rho;
         if (rho <= 0) rho = lam_int[0] / K;                                                // PADMMLasso.h:199-200
         S.rho = rho;
 
         // row partition (PADMMLasso.h:163-179) and per-worker factorisations (:48-63)
-        Ab.alloc((size_t)K * ldv); Ab.zero(st);
-        W.resize(K);
-        const int chunk = n / K;
+        Ab.alloc((size_t)Kl * ldv); Ab.zero(st);
+        W.resize(Kl);
         double t_gram = 0, t_fac = 0;
-        for (int k = 0; k < K; ++k) {
+        for (int k = 0; k < Kl; ++k) {
             ParWorker& w = W[k];
-            const int lo = k * chunk;
-            w.rows = (k < K - 1) ? chunk : n - lo;
+            const int lo = (int)(k * chunk);
+            w.rows = (k < Kl - 1) ? (int)chunk : n - lo;
             w.wide = w.rows < p;                                   // subA.rows() >= subA.cols() -> Cholesky branch
             w.lda = round_up(w.rows, 32);
             w.A.alloc((size_t)w.lda * p); w.A.zero(st);
@@ -279,16 +296,16 @@ struct ParPlan final : LassoPlan {
         d.X.release();
 
         nwg = std::max(1, std::min(64, (p + kParThreads - 1) / kParThreads));
-        rhs.alloc((size_t)K * ldv); x.alloc((size_t)K * ldv); y.alloc((size_t)K * ldv);
+        rhs.alloc((size_t)Kl * ldv); x.alloc((size_t)Kl * ldv); y.alloc((size_t)Kl * ldv); nsum.alloc(8);
         z.alloc(ldv); wsum.alloc(ldv);
         rhs.zero(st); x.zero(st); y.zero(st);
         beta.alloc((size_t)nlam * p); niter.alloc(nlam); done.alloc(1);
         P.alloc((size_t)nwg * 8); dlam.alloc(nlam); ctl.alloc(2);
         ADMM_HIP_CHECK(hipMemcpyAsync(dlam.get(), lam_int.data(), nlam * sizeof(double), hipMemcpyHostToDevice, st));
-        q.p = p; q.K = K; q.maxit = pb.opts.maxit; q.nlam = nlam; q.nwg = nwg; q.ldv = ldv;
+        q.p = p; q.K = K; q.Kl = Kl; q.nsum = nsum.get(); q.maxit = pb.opts.maxit; q.nlam = nlam; q.nwg = nwg; q.ldv = ldv;
         q.rho = rho; q.eps_abs = pb.opts.eps_abs; q.eps_rel = pb.opts.eps_rel;
         q.lambdas = dlam.get(); q.Ab = Ab.get(); q.rhs = rhs.get(); q.x = x.get(); q.y = y.get(); q.z = z.get(); q.wsum = wsum.get();
-        for (int k = 0; k < K; ++k) {
+        for (int k = 0; k < Kl; ++k) {
             ParWorker& w = W[k];
             GemvT<float>& last = w.wide ? w.gA : w.gM;
             q.gout[k] = last.part.get(); q.gnseg[k] = last.pl.nseg; q.gstride[k] = last.stride; q.wide[k] = w.wide ? 1 : 0;
@@ -310,8 +327,8 @@ struct ParPlan final : LassoPlan {
         const int batch = pb.batch_iters > 0 ? (pb.batch_iters + 1) / 2 * 2 : 16;
         LoopTimes lt = run_until_done(st, skip, batch, (long long)nlam * ((long long)pb.opts.maxit + 2) + 4, [&](long long g) {
             const int par = (int)(g & 1);
-            hipLaunchKernelGGL(par_head_kernel, dim3(nwg_e), dim3(kParThreads), (size_t)nwg * 8 * sizeof(double), st, q, par);
-            for (int k = 0; k < K; ++k) {
+            hipLaunchKernelGGL(par_head_kernel, dim3(nwg_e), dim3(kParThreads), 0, st, q);
+            for (int k = 0; k < Kl; ++k) {
                 ParWorker& w = W[k];
                 const float* rk = rhs.get() + (size_t)k * ldv;
                 if (!w.wide) {
@@ -323,6 +340,9 @@ struct ParPlan final : LassoPlan {
                 }
             }
             hipLaunchKernelGGL(par_pack_kernel, dim3(nwg_e), dim3(kParThreads), 0, st, q);
+            // the only cross-worker exchange: consensus sum (p floats) + the three worker-summed norms, one grouped
+            // RCCL all-reduce over xGMI (no-op in a single process)
+            if (pb.dist) allreduce_sum_f32_f64(wsum.get(), (size_t)p, nsum.get(), 3, st);
             hipLaunchKernelGGL(par_z_kernel, dim3(nwg), dim3(kParThreads), 0, st, q, par);
         });
         S.t_loop = lt.wall_s; S.loop_ms_events = lt.events_ms; S.xupdate_launches = lt.launched;

@@ -10,6 +10,7 @@ namespace admm {
 template <typename T>
 struct DeviceData {
     int n = 0, p = 0;
+    long long n_total = 0;      // rows of the global problem (== n unless the rows are spread over ranks)
     long long ldx = 0;          // leading dimension of X (>= n, multiple of 32 elements)
     DevBuf<T> X;                // n x p column-major, padding rows zero
     DevBuf<T> Y;                // n (allocated ldx, zero padded)
@@ -23,7 +24,7 @@ struct DeviceData {
 // DataStd::standardize (DataStd.h:89-155) there.  mem: ADMM_MEM_HOST / ADMM_MEM_DEVICE.
 template <typename T>
 void upload_standardize(DeviceData<T>& d, const double* x, const double* y, int n, int p, int mem,
-                        bool standardize, bool intercept, hipStream_t st);
+                        bool standardize, bool intercept, hipStream_t st, long long n_total = 0);
 
 // DataStd::recover (DataStd.h:157-207) on a host coefficient vector (length p) in precision T.
 template <typename T>

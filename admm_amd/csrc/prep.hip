@@ -1,6 +1,7 @@
 // One-time preparation kernels and library wrappers (see prep.h).
 #include "prep.h"
 #include "gemv_kernels.h"
+#include "comm.h"
 
 #include <rocblas/rocblas.h>
 #include <rocsolver/rocsolver.h>
@@ -58,94 +59,98 @@ static rocblas_handle blas(hipStream_t st) {
     } while (0)
 
 // ------------------------------------------------------------------ standardise (DataStd.h:89-155)
-// One workgroup per column; the column is converted to T first (Lasso.cpp:49 copies double->float
-// before standardising), statistics accumulate in double.
+// The data are narrowed to T first (Lasso.cpp:49 copies double->float before standardising), then
+// three column passes on the device copy: sums -> means, centred sums of squares -> population sd,
+// apply.  Statistics accumulate in double; in a multi-process run the two statistic vectors are
+// all-reduced so that every rank standardises with the GLOBAL moments (the reference standardises
+// before it splits rows, ParLasso.cpp:68-72).  Index p of the statistic vectors is y.
 template <typename T>
 __global__ void __launch_bounds__(256)
-standardize_cols_kernel(const double* __restrict__ x, long long ldin, int n, int flag,
-                        T* __restrict__ X, long long ldx, T* __restrict__ meanX, T* __restrict__ scaleX) {
-    __shared__ double scratch[4];
+convert_cols_kernel(const double* __restrict__ x, long long ldin, int n, T* __restrict__ X, long long ldx) {
     const int j = blockIdx.x;
     const double* src = x + (size_t)j * ldin;
     T* dst = X + (size_t)j * ldx;
-    T mean = T(0), inv = T(1);
-    if (flag != 0) {
-        double s[1] = {0.0};
-        for (int i = threadIdx.x; i < n; i += 256) s[0] += (double)(T)src[i];
-        block_sum<double, 1>(s, scratch);
-        mean = (T)(s[0] / (double)n);
-    }
-    if (flag & 1) {
-        double ss[1] = {0.0};
-        for (int i = threadIdx.x; i < n; i += 256) {
-            T c = (T)src[i] - mean;
-            ss[0] += (double)c * (double)c;
-        }
-        block_sum<double, 1>(ss, scratch);
-        const T n_invsqrt = (T)(1.0 / sqrt((double)(T)n));
-        const T scale = (T)((T)sqrt(ss[0]) * n_invsqrt);       // ||x - mean|| / sqrt(n): population sd
-        inv = (T)(1.0 / (double)scale);
-        if (threadIdx.x == 0) scaleX[j] = scale;
-    }
-    const bool center = (flag & 2) != 0;
-    if (threadIdx.x == 0 && center) meanX[j] = mean;
+    for (int i = blockIdx.y * 256 + threadIdx.x; i < n; i += gridDim.y * 256) dst[i] = (T)src[i];
+}
+
+template <typename T, int PASS>      // PASS 0: sum ; PASS 1: sum of (v - mean)^2
+__global__ void __launch_bounds__(256)
+colstat_kernel(const T* __restrict__ X, long long ldx, const T* __restrict__ Y, int n, int p,
+               const T* __restrict__ mean, double* __restrict__ out) {
+    __shared__ double scratch[4];
+    const int j = blockIdx.x;
+    const T* col = j < p ? X + (size_t)j * ldx : Y;
+    const T m = PASS == 1 ? mean[j] : T(0);
+    double s[1] = {0.0};
     for (int i = threadIdx.x; i < n; i += 256) {
-        T v = (T)src[i];
-        if (center) v = v - mean;
-        if (flag & 1) v = v * inv;
-        dst[i] = v;
+        if (PASS == 0) s[0] += (double)col[i];
+        else { const T c = col[i] - m; s[0] += (double)c * (double)c; }
+    }
+    block_sum<double, 1>(s, scratch);
+    if (threadIdx.x == 0) out[j] = s[0];
+}
+
+template <typename T>
+__global__ void finish_mean_kernel(const double* sum, double n_total, int count, T* mean) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < count) mean[j] = (T)(sum[j] / n_total);
+}
+template <typename T>
+__global__ void finish_scale_kernel(const double* ss, double n_total, int count, T* scale, T* inv) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < count) {
+        const T n_invsqrt = (T)(1.0 / sqrt((double)(T)n_total));
+        const T sc = (T)((T)sqrt(ss[j]) * n_invsqrt);            // ||v - mean|| / sqrt(n): population sd
+        scale[j] = sc;
+        inv[j] = (T)(1.0 / (double)sc);
     }
 }
 
 template <typename T>
-__global__ void __launch_bounds__(1024)
-standardize_y_kernel(const double* __restrict__ y, int n, int flag, T* __restrict__ Y, T* __restrict__ stats /*mean, scale*/) {
-    __shared__ double scratch[16];
-    T mean = T(0), scale = T(1);
-    if (flag != 0) {
-        double s[1] = {0.0};
-        for (int i = threadIdx.x; i < n; i += 1024) s[0] += (double)(T)y[i];
-        block_sum<double, 1>(s, scratch);
-        mean = (T)(s[0] / (double)n);
-        double ss[1] = {0.0};
-        for (int i = threadIdx.x; i < n; i += 1024) {
-            T c = (T)y[i] - mean;
-            ss[0] += (double)c * (double)c;
+__global__ void __launch_bounds__(256)
+apply_std_kernel(T* __restrict__ X, long long ldx, T* __restrict__ Y, int n, int p, int flag,
+                 const T* __restrict__ mean, const T* __restrict__ scale, const T* __restrict__ inv) {
+    const int j = blockIdx.x;
+    const bool center = (flag & 2) != 0;
+    if (j < p) {
+        T* col = X + (size_t)j * ldx;
+        const T m = center ? mean[j] : T(0);
+        const T iv = (flag & 1) ? inv[j] : T(1);
+        for (int i = blockIdx.y * 256 + threadIdx.x; i < n; i += gridDim.y * 256) {
+            T v = col[i];
+            if (center) v = v - m;
+            if (flag & 1) v = v * iv;                              // X.col(i) *= 1 / scaleX[i]
+            col[i] = v;
         }
-        block_sum<double, 1>(ss, scratch);
-        const T n_invsqrt = (T)(1.0 / sqrt((double)(T)n));
-        scale = (T)((T)sqrt(ss[0]) * n_invsqrt);
+    } else {                                                       // y: flag 1 scales by sd without centring (DataStd.h:96-99)
+        const T m = center ? mean[p] : T(0);
+        const T sc = scale[p];
+        for (int i = blockIdx.y * 256 + threadIdx.x; i < n; i += gridDim.y * 256) {
+            T v = Y[i];
+            if (center) v = v - m;
+            Y[i] = v / sc;                                         // Y.array() /= scaleY
+        }
     }
-    const bool center = (flag & 2) != 0;      // flag 1 scales by sd without centring (DataStd.h:96-99)
-    for (int i = threadIdx.x; i < n; i += 1024) {
-        T v = (T)y[i];
-        if (center) v = v - mean;
-        if (flag != 0) v = v / scale;
-        Y[i] = v;
-    }
-    if (threadIdx.x == 0) { stats[0] = center ? mean : T(0); stats[1] = scale; }
 }
 
 template <typename T>
 void upload_standardize(DeviceData<T>& d, const double* x, const double* y, int n, int p, int mem,
-                        bool standardize, bool intercept, hipStream_t st) {
-    d.n = n; d.p = p;
+                        bool standardize, bool intercept, hipStream_t st, long long n_total) {
+    if (n_total <= 0) n_total = n;
+    d.n = n; d.p = p; d.n_total = n_total;
     d.flag = int(standardize) + 2 * int(intercept);
     d.ldx = round_up(n, 32);
     d.X.alloc((size_t)d.ldx * p);
     d.Y.alloc((size_t)d.ldx);
     d.X.zero(st);
     d.Y.zero(st);
-    DevBuf<T> dmean(p), dscale(p), ystats(2);
-    dmean.zero(st); dscale.zero(st);
+    const int ny = std::max(1, std::min(64, (n + 255) / 256));
     double t0 = now_s();
+    double th = 0;
+    // ---- pass 0: narrow to T on the device
     if (mem == ADMM_MEM_DEVICE) {
-        hipLaunchKernelGGL((standardize_cols_kernel<T>), dim3(p), dim3(256), 0, st, x, (long long)n, n, d.flag,
-                           d.X.get(), d.ldx, dmean.get(), dscale.get());
-        hipLaunchKernelGGL((standardize_y_kernel<T>), dim3(1), dim3(1024), 0, st, y, n, d.flag, d.Y.get(), ystats.get());
-        ADMM_HIP_CHECK(hipStreamSynchronize(st));
-        d.t_h2d = 0;
-        d.t_std = now_s() - t0;
+        hipLaunchKernelGGL((convert_cols_kernel<T>), dim3(p, ny), dim3(256), 0, st, x, (long long)n, n, d.X.get(), d.ldx);
+        hipLaunchKernelGGL((convert_cols_kernel<T>), dim3(1, ny), dim3(256), 0, st, y, (long long)n, n, d.Y.get(), d.ldx);
     } else {
         // Host input (what R hands over): stream column chunks through two device staging buffers.
         const size_t chunk_bytes = (size_t)256 << 20;
@@ -156,7 +161,6 @@ void upload_standardize(DeviceData<T>& d, const double* x, const double* y, int 
         stage[1].alloc((size_t)cols_per_chunk * n);
         Event ev[2];
         bool used[2] = {false, false};
-        double th = 0;
         int b = 0;
         for (int c0 = 0; c0 < p; c0 += cols_per_chunk, b ^= 1) {
             const int nc = std::min(cols_per_chunk, p - c0);
@@ -164,8 +168,8 @@ void upload_standardize(DeviceData<T>& d, const double* x, const double* y, int 
             double t1 = now_s();
             ADMM_HIP_CHECK(hipMemcpy(stage[b].get(), x + (size_t)c0 * n, (size_t)nc * n * sizeof(double), hipMemcpyHostToDevice));
             th += now_s() - t1;
-            hipLaunchKernelGGL((standardize_cols_kernel<T>), dim3(nc), dim3(256), 0, st, stage[b].get(), (long long)n, n, d.flag,
-                               d.X.get() + (size_t)c0 * d.ldx, d.ldx, dmean.get() + c0, dscale.get() + c0);
+            hipLaunchKernelGGL((convert_cols_kernel<T>), dim3(nc, ny), dim3(256), 0, st, stage[b].get(), (long long)n, n,
+                               d.X.get() + (size_t)c0 * d.ldx, d.ldx);
             ADMM_HIP_CHECK(hipEventRecord(ev[b].e, st));
             used[b] = true;
         }
@@ -173,22 +177,38 @@ void upload_standardize(DeviceData<T>& d, const double* x, const double* y, int 
         double t1 = now_s();
         ADMM_HIP_CHECK(hipMemcpy(ystage.get(), y, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
         th += now_s() - t1;
-        hipLaunchKernelGGL((standardize_y_kernel<T>), dim3(1), dim3(1024), 0, st, ystage.get(), n, d.flag, d.Y.get(), ystats.get());
+        hipLaunchKernelGGL((convert_cols_kernel<T>), dim3(1, ny), dim3(256), 0, st, ystage.get(), (long long)n, n, d.Y.get(), d.ldx);
         ADMM_HIP_CHECK(hipStreamSynchronize(st));
-        d.t_h2d = th;
-        d.t_std = now_s() - t0 - th;
     }
     d.meanX.assign(p, T(0));
     d.scaleX.assign(p, T(1));
-    if (d.flag & 2) ADMM_HIP_CHECK(hipMemcpy(d.meanX.data(), dmean.get(), (size_t)p * sizeof(T), hipMemcpyDeviceToHost));
-    if (d.flag & 1) ADMM_HIP_CHECK(hipMemcpy(d.scaleX.data(), dscale.get(), (size_t)p * sizeof(T), hipMemcpyDeviceToHost));
-    T ys[2];
-    ADMM_HIP_CHECK(hipMemcpy(ys, ystats.get(), 2 * sizeof(T), hipMemcpyDeviceToHost));
-    d.meanY = ys[0];
-    d.scaleY = ys[1];
+    d.meanY = T(0); d.scaleY = T(1);
+    if (d.flag != 0) {
+        const int cnt = p + 1;
+        DevBuf<double> stat(cnt);
+        DevBuf<T> mean(cnt), scale(cnt), inv(cnt);
+        hipLaunchKernelGGL((colstat_kernel<T, 0>), dim3(cnt), dim3(256), 0, st, d.X.get(), d.ldx, d.Y.get(), n, p, mean.get(), stat.get());
+        allreduce_sum_f64(stat.get(), cnt, st);
+        hipLaunchKernelGGL((finish_mean_kernel<T>), dim3((cnt + 255) / 256), dim3(256), 0, st, stat.get(), (double)n_total, cnt, mean.get());
+        hipLaunchKernelGGL((colstat_kernel<T, 1>), dim3(cnt), dim3(256), 0, st, d.X.get(), d.ldx, d.Y.get(), n, p, mean.get(), stat.get());
+        allreduce_sum_f64(stat.get(), cnt, st);
+        hipLaunchKernelGGL((finish_scale_kernel<T>), dim3((cnt + 255) / 256), dim3(256), 0, st, stat.get(), (double)n_total, cnt, scale.get(), inv.get());
+        hipLaunchKernelGGL((apply_std_kernel<T>), dim3(cnt, ny), dim3(256), 0, st, d.X.get(), d.ldx, d.Y.get(), n, p, d.flag,
+                           mean.get(), scale.get(), inv.get());
+        std::vector<T> hm(cnt), hs(cnt);
+        ADMM_HIP_CHECK(hipMemcpyAsync(hm.data(), mean.get(), cnt * sizeof(T), hipMemcpyDeviceToHost, st));
+        ADMM_HIP_CHECK(hipMemcpyAsync(hs.data(), scale.get(), cnt * sizeof(T), hipMemcpyDeviceToHost, st));
+        ADMM_HIP_CHECK(hipStreamSynchronize(st));
+        if (d.flag & 2) { for (int j = 0; j < p; ++j) d.meanX[j] = hm[j]; d.meanY = hm[p]; }
+        if (d.flag & 1) for (int j = 0; j < p; ++j) d.scaleX[j] = hs[j];
+        d.scaleY = hs[p];
+    }
+    ADMM_HIP_CHECK(hipStreamSynchronize(st));
+    d.t_h2d = th;
+    d.t_std = now_s() - t0 - th;
 }
-template void upload_standardize<float>(DeviceData<float>&, const double*, const double*, int, int, int, bool, bool, hipStream_t);
-template void upload_standardize<double>(DeviceData<double>&, const double*, const double*, int, int, int, bool, bool, hipStream_t);
+template void upload_standardize<float>(DeviceData<float>&, const double*, const double*, int, int, int, bool, bool, hipStream_t, long long);
+template void upload_standardize<double>(DeviceData<double>&, const double*, const double*, int, int, int, bool, bool, hipStream_t, long long);
 
 template <typename T>
 void recover_coef(const DeviceData<T>& d, const T* coef, T* beta0, T* out) {

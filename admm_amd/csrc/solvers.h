@@ -13,6 +13,7 @@ struct LassoProblem {
     bool enet = false;
     double alpha = 1.0;
     int nworkers = 0;                // > 0: row-block consensus (admm_parlasso)
+    bool dist = false;               // consensus blocks spread over the ranks of the attached communicator
     int batch_iters = 0;             // iterations enqueued per host poll (0 = default)
     int profile_stride = 0;          // > 0: time every stride-th x-update launch with HIP events
 };

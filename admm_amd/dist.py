@@ -1,0 +1,128 @@
+"""One-process-per-GPU consensus Lasso: communicator bootstrap and the distributed entry points.
+
+The RCCL communicator lives inside libadmm_hip.so; this module only moves the 128-byte unique id
+between ranks (over torch.distributed, any backend) and marshals arguments.  Each rank passes its
+contiguous ROW SLICE of the global problem in the reference's partition (PADMMLasso.h:163-179);
+`row_partition` computes that slice.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import AdmmOpts, AdmmStats, as_input, check
+from .api import ADMM_Lasso_fit
+
+UNIQUE_ID_BYTES = 128
+
+
+def row_partition(n_total, nblocks, nranks, rank):
+    """Rows [lo, hi) owned by `rank` when `nblocks` reference row blocks (chunk = n_total // nblocks, the
+    last block takes the remainder) are dealt out contiguously, nblocks // nranks per rank."""
+    if nblocks % nranks:
+        raise ValueError("the number of row blocks must be a multiple of the number of ranks")
+    chunk = n_total // nblocks
+    per = nblocks // nranks
+    lo = rank * per * chunk
+    hi = (rank + 1) * per * chunk if rank < nranks - 1 else n_total
+    return lo, hi
+
+
+def init_comm(nranks=1, rank=0, broadcast=None):
+    """Attach the process-wide RCCL communicator.  `broadcast(buf: np.ndarray[uint8]) -> np.ndarray` must return
+    rank 0's buffer on every rank (not needed for nranks == 1)."""
+    lib = _lib.load()
+    buf = np.zeros(UNIQUE_ID_BYTES, dtype=np.uint8)
+    if rank == 0:
+        check(lib.admm_hip_comm_unique_id(buf.ctypes.data))
+    if nranks > 1:
+        if broadcast is None:
+            raise ValueError("a broadcast function is required for nranks > 1")
+        buf = np.ascontiguousarray(broadcast(buf), dtype=np.uint8)
+    check(lib.admm_hip_comm_init(int(nranks), int(rank), buf.ctypes.data))
+
+
+def init_comm_from_torch(device=None):
+    """Bootstrap over an initialised torch.distributed process group (gloo or nccl)."""
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(), dist.get_world_size()
+
+    def bcast(buf):
+        t = torch.from_numpy(buf.copy())
+        if dist.get_backend() == "nccl":
+            t = t.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+        dist.broadcast(t, src=0)
+        return t.cpu().numpy()
+
+    init_comm(world, rank, bcast if world > 1 else None)
+
+
+def finalize_comm():
+    check(_lib.load().admm_hip_comm_finalize())
+
+
+def _marshal(x_local, y_local, n_local, n_total, p, lam, nlambda, lambda_min_ratio, standardize, intercept, nthread, opts):
+    xp, xmem, xk = as_input(x_local)
+    yp, ymem, yk = as_input(y_local)
+    lam_in = np.ascontiguousarray(np.sort(np.atleast_1d(np.asarray(lam, dtype=np.float64)))[::-1]) if lam is not None else np.zeros(0)
+    o = AdmmOpts(int(opts.get("maxit", 10000)), float(opts.get("eps_abs", 1e-5)), float(opts.get("eps_rel", 1e-5)),
+                 float(opts.get("rho", -1.0) if opts.get("rho") is not None else -1.0))
+    head = (xp, yp, int(n_local), int(n_total), int(p), xmem,
+            ctypes.c_void_p(lam_in.ctypes.data if lam_in.size else 0), int(lam_in.size), int(nlambda), float(lambda_min_ratio),
+            int(bool(standardize)), int(bool(intercept)), int(nthread), ctypes.byref(o))
+    return head, (xk, yk, lam_in, o), (lam_in.size if lam_in.size else int(nlambda))
+
+
+def parlasso_dist(x_local, y_local, n_total, p, nthread, lam=None, nlambda=100, lambda_min_ratio=None,
+                  standardize=True, intercept=True, n_local=None, **opts):
+    """Distributed `admm_lasso(x, y)$penalty(...)$parallel(nthread)$fit()`: every rank calls this with its row slice."""
+    lib = _lib.load()
+    if n_local is None:
+        n_local = np.asarray(x_local).shape[0]
+    if lambda_min_ratio is None:
+        lambda_min_ratio = 0.01 if n_total < p else 1e-4
+    head, keep, nl = _marshal(x_local, y_local, n_local, n_total, p, lam, nlambda, lambda_min_ratio, standardize, intercept, nthread, opts)
+    lam_out = np.zeros(nl)
+    beta = np.zeros((p + 1, nl), dtype=np.float32, order="F")
+    niter = np.zeros(nl, dtype=np.int32)
+    stats = AdmmStats()
+    check(lib.admm_hip_parlasso_dist(*head, lam_out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                     beta.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                                     niter.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), ctypes.byref(stats)))
+    return ADMM_Lasso_fit(lam_out, beta, niter, stats.as_dict())
+
+
+class DistLassoPlan:
+    """Prepared distributed consensus problem (setup once, run the lambda path repeatedly)."""
+
+    def __init__(self, x_local, y_local, n_total, p, nthread, lam=None, nlambda=100, lambda_min_ratio=None,
+                 standardize=True, intercept=True, n_local=None, **opts):
+        lib = _lib.load()
+        self._lib = lib
+        self.p = p
+        if n_local is None:
+            n_local = np.asarray(x_local).shape[0]
+        if lambda_min_ratio is None:
+            lambda_min_ratio = 0.01 if n_total < p else 1e-4
+        head, keep, nl = _marshal(x_local, y_local, n_local, n_total, p, lam, nlambda, lambda_min_ratio, standardize, intercept, nthread, opts)
+        h = ctypes.c_void_p()
+        nlo = ctypes.c_int()
+        check(lib.admm_hip_lasso_plan_create_dist(*head, ctypes.byref(h), ctypes.byref(nlo)))
+        self._h = h
+        self.nlambda = nlo.value
+
+    def run(self):
+        lam_out = np.zeros(self.nlambda)
+        beta = np.zeros((self.p + 1, self.nlambda), dtype=np.float32, order="F")
+        niter = np.zeros(self.nlambda, dtype=np.int32)
+        stats = AdmmStats()
+        check(self._lib.admm_hip_lasso_plan_run(self._h, lam_out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                                beta.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                                                niter.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), ctypes.byref(stats)))
+        return ADMM_Lasso_fit(lam_out, beta, niter, stats.as_dict())
+
+    def close(self):
+        if self._h:
+            check(self._lib.admm_hip_lasso_plan_destroy(self._h))
+            self._h = None

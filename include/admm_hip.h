@@ -130,6 +130,29 @@ int admm_hip_lasso_plan_create(const double* x, const double* y, int n, int p, i
 int admm_hip_lasso_plan_run(admm_hip_plan* plan, double* lambda_out, float* beta_out, int* niter_out, admm_stats* stats);
 int admm_hip_lasso_plan_destroy(admm_hip_plan* plan);
 
+/* ---- one process per GPU: consensus Lasso with its row blocks spread over ranks (RCCL over xGMI).
+ * Bootstrap: rank 0 calls admm_hip_comm_unique_id and ships the ADMM_HIP_UNIQUE_ID_BYTES bytes to the
+ * other ranks over any channel (bench.py uses torch.distributed); every rank then calls
+ * admm_hip_comm_init on its own device.  In the *_dist entry points x/y are this rank's contiguous
+ * ROW SLICE of the global n_total x p problem, in the reference's partition (PADMMLasso.h:163-179:
+ * nthread blocks of n_total / nthread rows, the last block takes the remainder; rank r owns blocks
+ * [r * nthread / nranks, (r+1) * nthread / nranks)).  Standardisation uses the global column moments
+ * (the reference standardises before it splits, ParLasso.cpp:68-72); per ADMM iteration the ranks
+ * exchange ONE grouped all-reduce: the consensus sum (p floats) and three squared norms.  Every rank
+ * returns the full result. */
+#define ADMM_HIP_UNIQUE_ID_BYTES 128
+int admm_hip_comm_unique_id(void* id_out);
+int admm_hip_comm_init(int nranks, int rank, const void* id);
+int admm_hip_comm_finalize(void);
+int admm_hip_parlasso_dist(const double* x_local, const double* y_local, int n_local, long long n_total, int p, int mem,
+                           const double* lambda_in, int nlambda_in, int nlambda_auto, double lmin_ratio,
+                           int standardize, int intercept, int nthread, const admm_opts* opts,
+                           double* lambda_out, float* beta_out, int* niter_out, admm_stats* stats);
+int admm_hip_lasso_plan_create_dist(const double* x_local, const double* y_local, int n_local, long long n_total, int p, int mem,
+                                    const double* lambda_in, int nlambda_in, int nlambda_auto, double lmin_ratio,
+                                    int standardize, int intercept, int nthread, const admm_opts* opts,
+                                    admm_hip_plan** plan_out, int* nlambda_out);
+
 const char* admm_hip_last_error(void);
 const char* admm_hip_version(void);
 int admm_hip_device_count(void);

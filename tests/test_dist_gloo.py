@@ -1,0 +1,171 @@
+"""world_size-2 (gloo, CPU) check of the multi-process consensus protocol.
+
+No GPU here, so the HIP kernels cannot run; what this covers is everything around them that only
+exists when N > 1: the reference row partition dealt out over ranks (`admm_amd.dist.row_partition`),
+standardisation from all-reduced global column moments, lambda_0 from an all-reduced X'y, and the
+per-iteration exchange used by padmm_lasso.hip -- ONE all-reduce of [consensus sum (p floats), three
+worker-summed squared norms] between `pack` and `z`, with the convergence decision of iteration g-1
+taken after the all-reduce of iteration g.  Each rank runs a NumPy model of its device-side steps
+(built from the oracle's pieces); the result must equal the serial oracle of
+PADMMLasso_Master::solve (oracle/solvers.py) in coefficients and (to +-2) iteration counts.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import scipy.linalg as sla
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import relerr, synth_lasso
+
+F = np.float32
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _allreduce(a):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.numpy()
+
+
+def _rank_main(rank, world, port, x, y, K, lam_user, maxit, out_path):
+    from admm_amd.dist import row_partition
+    from oracle.solvers import _soft_d, _sqnorm
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n, p = x.shape
+    lo, hi = row_partition(n, K, world, rank)
+    Xl = np.array(x[lo:hi], dtype=F, order="F")
+    yl = np.array(y[lo:hi], dtype=F)
+    # --- global standardisation (flag 3) from all-reduced moments (prep.hip: colstat passes + all-reduce)
+    s = _allreduce(np.concatenate([Xl.sum(axis=0, dtype=np.float64), [yl.sum(dtype=np.float64)]]))
+    mean = (s / n).astype(F)
+    Xl -= mean[None, :p]
+    yl -= mean[p]
+    ss = _allreduce(np.concatenate([(Xl.astype(np.float64) ** 2).sum(axis=0), [(yl.astype(np.float64) ** 2).sum()]]))
+    n_invsqrt = F(1.0 / np.sqrt(F(n)))
+    scale = (np.sqrt(ss).astype(F) * n_invsqrt).astype(F)
+    Xl *= (F(1.0) / scale[:p])[None, :]
+    yl /= scale[p]
+    scaleY, meanY = scale[p], mean[p]
+    # --- lambda_0 is not needed for a user lambda; internal lambda (ParLasso.cpp:91) and rho (PADMMLasso.h:199-200)
+    lam_int = [lu * n / np.float64(scaleY) for lu in lam_user]
+    rho = lam_int[0] / K
+    # --- local workers (reference row blocks owned by this rank)
+    Kl = K // world
+    chunk = n // K
+    A, Ab, chol = [], [], []
+    for k in range(Kl):
+        a0 = k * chunk
+        a1 = (k + 1) * chunk if (k < Kl - 1 or rank < world - 1) else Xl.shape[0]
+        Ak = np.ascontiguousarray(Xl[a0:a1])
+        A.append(Ak)
+        Ab.append((Ak.T @ yl[a0:a1]).astype(F))
+        AA = (Ak.T @ Ak if Ak.shape[0] >= p else Ak @ Ak.T).astype(F)
+        AA[np.arange(AA.shape[0]), np.arange(AA.shape[0])] += F(rho)
+        chol.append(sla.cho_factor(AA, lower=True, check_finite=False))
+    xs = [np.zeros(p, F) for _ in range(Kl)]
+    ys = [np.zeros(p, F) for _ in range(Kl)]
+    z = np.zeros(p, F)
+    nsum = np.zeros(5)                 # local: sum_k|x_k|^2, sum_k|y_k|^2, sum_k|x_k - z|^2 ; global: |z|^2, |dz|^2
+    first, it, li, lam = True, 0, 0, lam_int[0]
+    eps_p = eps_d = 0.0
+    betas, niters = [], []
+    eps_abs = eps_rel = 1e-5
+    for g in range(100000):
+        # head + x-update + pack
+        wsum = np.zeros(p, F)
+        for k in range(Kl):
+            rhs = (Ab[k] - ys[k]).astype(F)
+            rhs = (rhs.astype(np.float64) + rho * z.astype(np.float64)).astype(F)
+            if A[k].shape[0] >= p:
+                xs[k] = sla.cho_solve(chol[k], rhs, check_finite=False).astype(F)
+            else:
+                t = (A[k] @ rhs).astype(F)
+                sv = sla.cho_solve(chol[k], t, check_finite=False).astype(F)
+                xs[k] = ((rhs - (A[k].T @ sv).astype(F)) / F(rho)).astype(F)
+            wsum = (wsum + (xs[k] + ys[k] / F(rho))).astype(F)
+        # the exchange: p floats + 3 doubles, one all-reduce per iteration
+        payload = _allreduce(np.concatenate([wsum.astype(np.float64), nsum[:3]]))
+        wsum_g = payload[:p].astype(F)
+        x2, y2, r2 = payload[p:]
+        z2, dz2 = nsum[3], nsum[4]
+        # z: decision for iteration g-1, identical on every rank
+        fin = False
+        if not first:
+            rp, rd = np.sqrt(r2), rho * np.sqrt(K * dz2)
+            if rp < eps_p and rd < eps_d:
+                fin, nit = True, it + 1
+            else:
+                it += 1
+                if it >= maxit:
+                    fin, nit = True, maxit + 1
+            if fin:
+                betas.append(z.copy())
+                niters.append(nit)
+                li += 1
+                it = 0
+                if li >= len(lam_int):
+                    break
+                lam = lam_int[li]
+        first = False
+        eps_p = max(np.sqrt(x2), np.sqrt(z2) * np.sqrt(K)) * eps_rel + np.sqrt(float(p * K)) * eps_abs
+        eps_d = np.sqrt(y2) * eps_rel + np.sqrt(float(p * K)) * eps_abs
+        zn = _soft_d((wsum_g / F(K)).astype(F), lam / (rho * K), F)
+        acc = np.zeros(5)
+        for k in range(Kl):
+            r = (xs[k] - zn).astype(F)
+            ys[k] = (ys[k] + F(rho) * r).astype(F)
+            acc[0] += np.float64(_sqnorm(xs[k], F)); acc[1] += np.float64(_sqnorm(ys[k], F)); acc[2] += np.float64(_sqnorm(r, F))
+        acc[3] = np.float64(_sqnorm(zn, F)); acc[4] = np.float64(_sqnorm(zn - z, F))
+        z, nsum = zn, acc
+    # recover (DataStd flag 3) with the GLOBAL moments
+    out = []
+    for b in betas:
+        coef = (b / scale[:p] * scaleY).astype(F)
+        b0 = F(meanY - F((coef * mean[:p]).sum(dtype=F)))
+        out.append(np.concatenate([[b0], coef]))
+    if rank == 0:
+        np.savez(out_path, beta=np.array(out).T, niter=np.array(niters))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,p,K", [(400, 30, 2), (403, 40, 4), (120, 200, 2)])
+def test_two_rank_consensus_protocol_matches_serial_oracle(tmp_path, n, p, K):
+    from oracle import entry
+    x, y = synth_lasso(n, p, max(3, p // 8), seed=53)
+    lam = [0.5, 0.15]
+    maxit = 4000
+    out_path = str(tmp_path / "dist.npz")
+    mp.spawn(_rank_main, args=(2, _free_port(), x, y, K, lam, maxit, out_path), nprocs=2, join=True)
+    got = np.load(out_path)
+    ref = entry.admm_parlasso(x, y, lam, 100, 1e-4, True, True, K, dict(entry.LASSO_OPTS, maxit=maxit))
+    # the global moments are all-reduced in double while the serial oracle averages in float32: trajectories
+    # agree to rounding, so the counts may differ by an iteration out of several hundred
+    assert np.abs(got["niter"].astype(int) - ref["niter"].astype(int)).max() <= 2
+    for j in range(len(lam)):
+        assert relerr(got["beta"][:, j], ref["beta"][:, j]) < 5e-5, j
+
+
+def test_row_partition_covers_all_rows():
+    from admm_amd.dist import row_partition
+    for n, K, W in [(403, 4, 2), (1000, 8, 8), (17, 2, 1), (1201, 6, 3)]:
+        cover = []
+        for r in range(W):
+            lo, hi = row_partition(n, K, W, r)
+            cover.extend(range(lo, hi))
+        assert cover == list(range(n))
+    with pytest.raises(ValueError):
+        row_partition(100, 3, 2, 0)

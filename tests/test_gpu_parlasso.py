@@ -33,3 +33,26 @@ def test_parlasso_path_vs_oracle(n, p, K):
     for j in range(6):
         assert relerr(fit.beta_dense[:, j], ref["beta"][:, j]) < 2 * TOL, j
     assert np.abs(fit.niter.astype(int) - ref["niter"].astype(int)).max() <= np.maximum(5, 0.05 * ref["niter"].max())
+
+
+def test_dist_entry_point_single_rank_matches_single_process():
+    """The multi-process consensus path (RCCL communicator, global-moment standardisation, grouped
+    all-reduce between `pack` and `z`) with ONE rank owning all row blocks must reproduce the
+    single-process solver bit for bit.  (Real multi-rank runs need several GPUs; the protocol itself
+    is covered by the world_size-2 gloo test in tests/test_dist_gloo.py.)"""
+    from admm_amd import admm_lasso, dist
+    x, y = synth_lasso(1201, 150, 12, seed=41)
+    dist.init_comm(1, 0)
+    try:
+        for K in (1, 3):
+            fit_d = dist.parlasso_dist(x, y, 1201, 150, K, nlambda=5, lambda_min_ratio=0.01, maxit=2000)
+            fit_s = admm_lasso(x, y).penalty(nlambda=5, lambda_min_ratio=0.01).opts(maxit=2000)
+            fit_s.nthread = K
+            lib_fit = fit_s.fit() if K > 1 else None
+            if lib_fit is not None:
+                assert np.array_equal(fit_d.beta_dense, lib_fit.beta_dense)
+                assert list(fit_d.niter) == list(lib_fit.niter)
+            else:
+                assert np.isfinite(fit_d.beta_dense).all() and fit_d.niter.min() >= 1
+    finally:
+        dist.finalize_comm()
