@@ -18,6 +18,10 @@ by the max-over-ranks wall time of the timed region.
 N > 1: the serial tall solver does not shard in the reference ("replicas only", SURVEY.md 8e);
 each rank runs an independent replica (its own synthetic problem) -> "scaling": "weak", no
 data-path collective.  One process per GPU (torch.distributed / RCCL for the barriers only).
+The path that DOES have an exchange step -- the row-block consensus solver -- is measured beside
+it in a side run (`consensus` object: BASELINE configs[3] shape, K = N row blocks, rows sharded
+over the N GPUs, one grouped RCCL all-reduce per iteration), executed in child processes with a
+time limit so that it can never invalidate the primary line.
 
 Extra objects on the JSON line: `roofline` for the dominant kernel (the x-update mat-vec,
 4*p^2 algorithmic bytes per launch, durations from HIP events recorded by the library on its own
@@ -48,6 +52,9 @@ def parse():
     ap.add_argument("--seed", type=int, default=123)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline loop (0 disables)")
     ap.add_argument("--profile-stride", type=int, default=8, help="time every k-th x-update launch with HIP events")
+    ap.add_argument("--consensus-seconds", type=float, default=240.0,
+                    help="time limit of the side measurement of the consensus solver (0 disables it)")
+    ap.add_argument("--consensus-child", default="", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -95,8 +102,100 @@ def cpu_baseline(p, nlambda, budget_s, seed):
                       f"{iters} iterations in {t_loop:.1f} s; CPU setup (Gram+Lanczos+Cholesky) {t_setup:.1f} s"}
 
 
+def consensus_child(a):
+    """Side measurement (own process, own process group): BASELINE configs[3]-shaped consensus Lasso
+    `admm_lasso(x, y)$parallel(K)`, n=10000, p=100000, K = number of ranks, one row block per GPU, rows
+    sharded over ranks, one grouped RCCL all-reduce (p floats + 3 doubles) per ADMM iteration."""
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="gloo")      # control plane only; the data path is the library's own RCCL communicator
+    from admm_amd import DevicePtr, load
+    from admm_amd import dist as adist
+    lib = load()
+    assert lib.admm_hip_set_device(local_rank) == 0
+    if world > 1:
+        adist.init_comm_from_torch(dev)
+    else:
+        adist.init_comm(1, 0)
+    n, p, K = 10000, 100000, world
+    lo, hi = adist.row_partition(n, K, world, rank)
+    nl = hi - lo
+    gb = torch.Generator(device="cpu"); gb.manual_seed(a.seed)
+    beta_true = torch.zeros(p, dtype=torch.float64)
+    beta_true[:100] = torch.rand(100, generator=gb, dtype=torch.float64)
+    beta_true = beta_true.to(dev)
+    g = torch.Generator(device=dev); g.manual_seed(a.seed + 1000 + rank)
+    xt = torch.randn((p, nl), generator=g, device=dev, dtype=torch.float64) * 2.0      # p x nl row-major == nl x p column-major
+    y = beta_true @ xt + torch.randn(nl, generator=g, device=dev, dtype=torch.float64)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    plan = adist.DistLassoPlan(DevicePtr(xt.data_ptr()), DevicePtr(y.data_ptr()), n, p, K, nlambda=4, lambda_min_ratio=0.1,
+                               n_local=nl, maxit=150)
+    setup_s = time.time() - t0
+    del xt
+    plan.run()                                           # warm-up (RCCL lazy initialisation)
+    if world > 1:
+        dist.barrier()
+    fit = plan.run()
+    loop_s, iters = fit.stats["t_loop"], int(fit.stats["total_iter"])
+    if world > 1:
+        t = torch.tensor([loop_s], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        loop_s = float(t[0])
+    if rank == 0:
+        rows = n // K
+        bytes_per_gpu = 8.0 * rows * p + 4.0 * rows * rows      # A and A' streamed once each + the cached (AA'+rho I)^-1
+        res = {"workload": "admm_lasso$parallel(K) n=10000 p=100000, K = n_gpus row blocks (one per GPU), 4 lambdas x maxit 150",
+               "n_gpus": world, "K": K, "iterations": iters, "loop_s": loop_s, "iters_per_s": iters / loop_s,
+               "ms_per_iter": loop_s / iters * 1e3, "setup_s": setup_s,
+               "alg_bytes_per_gpu_per_iter": bytes_per_gpu, "achieved_GBps_per_gpu": bytes_per_gpu * iters / loop_s / 1e9,
+               "allreduce_payload_bytes": 4 * p + 24, "niter": [int(v) for v in fit.niter]}
+        with open(a.consensus_child, "w") as f:
+            json.dump(res, f)
+    plan.close()
+    adist.finalize_comm()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_consensus_side_measurement(a, rank, world):
+    """Run consensus_child in a separate process per rank (own rendezvous port) so that a failure or a hang of
+    the multi-process RCCL path can never take the primary measurement down.  Returns a dict (rank 0) or None."""
+    import subprocess
+    import tempfile
+    out_path = os.path.join(tempfile.gettempdir(), "admm_consensus_%s.json" % os.environ.get("MASTER_PORT", "0"))
+    if rank == 0 and os.path.exists(out_path):
+        os.remove(out_path)
+    env = dict(os.environ)
+    if world > 1:
+        env["MASTER_ADDR"] = "127.0.0.1"
+        env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 17)
+    cmd = [sys.executable, os.path.abspath(__file__), "--consensus-child", out_path, "--seed", str(a.seed)]
+    try:
+        r = subprocess.run(cmd, env=env, timeout=a.consensus_seconds, capture_output=True, text=True)
+        if rank != 0:
+            return None
+        if r.returncode != 0 or not os.path.exists(out_path):
+            return {"error": "consensus child failed (rc=%d): %s" % (r.returncode, (r.stderr or "")[-400:])}
+        return json.load(open(out_path))
+    except subprocess.TimeoutExpired:
+        return {"error": "consensus child exceeded %.0f s" % a.consensus_seconds} if rank == 0 else None
+    except Exception as e:                                  # noqa: BLE001
+        return {"error": repr(e)} if rank == 0 else None
+
+
 def main():
     a = parse()
+    if a.consensus_child:
+        consensus_child(a)
+        return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -171,6 +270,8 @@ def main():
     else:
         elapsed_max, iters_all = elapsed, float(iters)
 
+    consensus = run_consensus_side_measurement(a, rank, world) if a.consensus_seconds > 0 else None
+    barrier()
     if rank == 0:
         x_ms = xms / max(1, xsamp)
         sym = int(fit.stats["xupdate_variant"]) == 1
@@ -218,6 +319,8 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": x_ms, "launches_timed": xsamp,
                          "survey_4p2_equivalent_GBps": 4.0 * p * p / (x_ms * 1e-3) / 1e9 if x_ms > 0 else 0.0},
         }
+        if consensus is not None:
+            out["consensus"] = consensus
         if a.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(p, a.nlambda, a.cpu_seconds, a.seed)
         print(json.dumps(out), flush=True)
