@@ -304,8 +304,21 @@ template void transpose<float>(const float*, long long, int, int, float*, long l
 template void transpose<double>(const double*, long long, int, int, double*, long long, hipStream_t);
 
 // ------------------------------------------------------------------ Gram / factorisation (library first cut)
+void gram_xtx_mfma_f32(const float* X, long long ldx, int n, int p, float* C, long long ldc, hipStream_t st);   // syrk_mfma.hip
+
 template <typename T>
 void gram_full(const T* A, long long lda, int rows, int cols, bool atA, T* C, long long ldc, hipStream_t st) {
+    if constexpr (std::is_same<T, float>::value) {
+        // hand-written MFMA kernel for the large tall Gram (enough 128x128 tiles to fill the chip);
+        // ADMM_HIP_GRAM=rocblas forces the library path
+        const char* e = std::getenv("ADMM_HIP_GRAM");
+        const bool force_lib = e && std::string(e) == "rocblas";
+        const long long nb = (cols + 127) / 128;
+        if (atA && !force_lib && nb * (nb + 1) / 2 >= 128) {
+            gram_xtx_mfma_f32(A, lda, rows, cols, C, ldc, st);
+            return;
+        }
+    }
     rocblas_handle h = blas(st);
     const T one = T(1), zero = T(0);
     const int nC = atA ? cols : rows;
