@@ -36,14 +36,19 @@ struct GemvTArgs {
     const int* skip;    // optional device flag: non-zero -> kernel is a no-op
 };
 
-template <typename T, int NRHS, int C>
+// `Extra`: a functor run by ONE additional workgroup (the last block) concurrently with the streaming
+// workgroups; the tall solver uses it for its scalar iteration control (no launch, no latency).
+struct GemvNoExtra { static constexpr bool kHas = false; __device__ void operator()() const {} };
+
+template <typename T, int NRHS, int C, typename Extra = GemvNoExtra>
 __global__ void __launch_bounds__(kGemvThreads)
-gemv_t_kernel(GemvTArgs<T> a) {
+gemv_t_kernel(GemvTArgs<T> a, Extra extra) {
     using VT = Vec16<T>;
     using V = typename VT::type;
     constexpr int VN = VT::N;
     constexpr int PASS = kWave * VN;        // rows covered by one wave pass
 
+    if (Extra::kHas && blockIdx.x == gridDim.x - 1) { extra(); return; }
     if (a.skip != nullptr && *a.skip != 0) return;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -158,16 +163,16 @@ inline GemvTPlan plan_gemv_t(int m, int k, int nrhs, int C, int max_seg_rows = 0
     return pl;
 }
 
-template <typename T, int NRHS, int C>
+template <typename T, int NRHS, int C, typename Extra = GemvNoExtra>
 inline void launch_gemv_t(const GemvTPlan& pl, const T* A, long long lda, int m, int k,
                           const T* v0, const T* v1, T* out0, T* out1, long long out_stride,
-                          const int* skip, hipStream_t st) {
+                          const int* skip, hipStream_t st, Extra extra = Extra()) {
     GemvTArgs<T> a;
     a.A = A; a.lda = lda; a.m = m; a.k = k;
     a.v[0] = v0; a.v[1] = v1; a.out[0] = out0; a.out[1] = out1;
     a.out_stride = out_stride; a.seg_len = pl.seg_len; a.seg_alloc = pl.seg_alloc; a.nseg = pl.nseg;
     a.groups_per_wg = pl.groups_per_wg; a.skip = skip;
-    hipLaunchKernelGGL((gemv_t_kernel<T, NRHS, C>), dim3(pl.grid), dim3(kGemvThreads), pl.lds_bytes, st, a);
+    hipLaunchKernelGGL((gemv_t_kernel<T, NRHS, C, Extra>), dim3(pl.grid + (Extra::kHas ? 1 : 0)), dim3(kGemvThreads), pl.lds_bytes, st, a, extra);
 }
 
 // Sum the nseg partial rows of a gemv_t result: y[j] = sum_s part[s*stride + j].

@@ -126,6 +126,7 @@ __device__ void tall_decide(const TallParams& q, int par) {
 }
 
 struct TallDecideExtra {
+    static constexpr bool kHas = true;
     TallParams q; int par;
     __device__ void operator()() const { tall_decide(q, par); }
 };
@@ -374,7 +375,6 @@ struct TallPlan final : LassoPlan {
                 const int par = (int)(g & 1);
                 const bool sample = stride > 0 && (g % stride) == 0 && evs.size() < 8192;
                 hipEvent_t e0 = nullptr, e1 = nullptr;
-                if (!use_sym) hipLaunchKernelGGL(tall_decide_kernel, dim3(1), dim3(kTailThreads), 0, st, q, par);
                 if (sample) {
                     ADMM_HIP_CHECK(hipEventCreate(&e0)); ADMM_HIP_CHECK(hipEventCreate(&e1));
                     evs.push_back(e0); evs.push_back(e1);
@@ -384,8 +384,8 @@ struct TallPlan final : LassoPlan {
                     // the decision of this iteration rides along as one extra workgroup of the x-update launch
                     sy.launch(M.get(), ldp, u.get(), w.get(), &ctl.get()[par].done, st, TallDecideExtra{q, par});
                 } else {
-                    launch_gemv_t<float, 2, 4>(pl, M.get(), ldp, p, p, u.get(), w.get(), a_part.get(), b_part.get(), ldp,
-                                               &ctl.get()[par].done, st);
+                    launch_gemv_t<float, 2, 4, TallDecideExtra>(pl, M.get(), ldp, p, p, u.get(), w.get(), a_part.get(), b_part.get(), ldp,
+                                                                &ctl.get()[par].done, st, TallDecideExtra{q, par});
                 }
                 if (sample) ADMM_HIP_CHECK(hipEventRecord(e1, st));
                 if (use_sym) hipLaunchKernelGGL(tall_tail_kernel<true>, dim3(nwg), dim3(kTailThreads), 0, st, q, par);

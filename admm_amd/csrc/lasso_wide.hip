@@ -8,8 +8,8 @@
 //   /root/reference/src/ADMMEnet.h:62-154, and the lambda loop of Lasso.cpp:97-124.
 //
 // Device design:
-//  * "Regular" iterations (counter 0, 3, 15, 63, ... = 4^k - 1) stream all of X once (gemv_t, X't)
-//    and apply the prox to every coordinate; all other iterations touch only the current support.
+//  * "Regular" iterations (counter 0, 3, 15, 63, ... = 4^k - 1) stream all of X once and apply the
+//    prox to every coordinate; all other iterations touch only the current support.
 //  * No compaction and no index lists: column j belongs to wave (j mod NW).  A wave loads the x
 //    values of its columns, ballots the non-zeros and processes exactly those, so a zero
 //    coordinate stays zero until the next regular iteration (== SparseVector::prune) and a
@@ -17,8 +17,9 @@
 //  * Ax = sum_{j in supp} x_j X_j is a gather mat-vec with the same column->wave map; per-workgroup
 //    partials are summed by the z/y kernel.
 //  * Convergence test, rho adaptation (from iteration 5), the regular/active schedule and the
-//    lambda schedule (init_warm resets the counter, keeps x, z, y, rho) run on the device in the
-//    `head` kernel; the host enqueues batches and polls a sticky done word.
+//    lambda schedule (init_warm resets the counter, keeps x, z, y, rho) run on the device, evaluated
+//    identically by every workgroup of the x-update launch; three launches per iteration
+//    (x-update, gather mat-vec, z/y + norms); the host enqueues batches and polls a sticky done word.
 #include "prep.h"
 #include "gemv_kernels.h"
 #include "solvers.h"
@@ -62,24 +63,45 @@ __device__ __forceinline__ bool is_regular_update(unsigned int x) {      // 4^k 
     return (x & 0x55555555u) != 0;
 }
 
-// head(g): decision for iteration g-1, eps + update type for iteration g, t = Ax + z + y / rho.
+__device__ __forceinline__ float prox_f(float val, float thresh, float denom, bool enet) {
+    // active_set_update thresholding in float (ADMMLassoWide.h:108-113, ADMMEnet.h:111-116)
+    if (val > thresh) return enet ? (val - thresh) / denom : val - thresh;
+    if (val < -thresh) return enet ? (val + thresh) / denom : val + thresh;
+    return 0.f;
+}
+
+// x(g): every workgroup evaluates (identically) the decision for iteration g-1 -- convergence, rho
+// adaptation, lambda schedule, which x-update runs now -- then builds t = Ax + z + y / rho in LDS and
+// updates the columns its waves own.  A regular step visits every column (x = prox(x - X_j't / gamma)),
+// an active-set step only the current non-zeros; both stream X_j once with 16-byte loads.
 __global__ void __launch_bounds__(kWideThreads)
-wide_head_kernel(WideParams q, int par) {
+wide_x_kernel(WideParams q, int par) {
     __shared__ double sums[8];
-    extern __shared__ __attribute__((aligned(16))) double pstage[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const WideCtl in = q.ctl[par];
     WideCtl* outp = &q.ctl[par ^ 1];
     if (in.done) {
         if (blockIdx.x == 0 && threadIdx.x == 0) *outp = in;
         return;
     }
+    const int npad = (q.n + 255) / 256 * 256;
+    float* tl = reinterpret_cast<float*>(smem_raw);            // t        [npad]
+    float* tdl = tl + npad;                                    // t/gamma  [npad]
+    double* pstage = reinterpret_cast<double*>(tdl + npad);    // [nwg_tail * 8]
     const int np = q.nwg_tail * 8;
     for (int k = threadIdx.x; k < np; k += kWideThreads) pstage[k] = q.P[k];
+    // operands of t = Ax + z + y / rho do not depend on the decision: fetch them in the same round trip
+    for (int i = threadIdx.x; i < npad; i += kWideThreads) {
+        tl[i] = i < q.n ? q.Ax[i] + q.z[i] : 0.f;
+        tdl[i] = i < q.n ? q.y[i] : 0.f;
+    }
     __syncthreads();
-    if (threadIdx.x < 5) {
-        double s = 0.0;
-        for (int w = 0; w < q.nwg_tail; ++w) s += pstage[w * 8 + threadIdx.x];
-        sums[threadIdx.x] = s;
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x, which = lane & 7;
+        double sacc = 0.0;
+        if (which < 5) for (int w = lane >> 3; w < q.nwg_tail; w += 8) sacc += pstage[w * 8 + which];
+        sacc += __shfl_xor(sacc, 8, 64); sacc += __shfl_xor(sacc, 16, 64); sacc += __shfl_xor(sacc, 32, 64);
+        if (lane < 5) sums[lane] = sacc;
     }
     __syncthreads();
     const double r2 = sums[0], dz2 = sums[1], ax2 = sums[2], z2 = sums[3], y2 = sums[4];
@@ -119,68 +141,38 @@ wide_head_kernel(WideParams q, int par) {
         out.type = (is_regular_update((unsigned)out.counter) && out.lam < q.lambda0) ? W_REG : W_ACT;
         out.counter++;
     }
-    out.skip_reg = (out.done || out.type != W_REG) ? 1 : 0;
+    out.skip_reg = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (lam_finished >= 0) q.niter[lam_finished] = niter_val;
         *outp = out;
         if (out.done) *q.done = 1;
     }
+    const bool snap = lam_finished >= 0;                               // get_x() snapshot of the OLD x (Lasso.cpp:119)
+    float* bsnap = snap ? q.beta + (size_t)lam_finished * q.p : nullptr;
     const int gid = blockIdx.x * kWideThreads + threadIdx.x, gsz = gridDim.x * kWideThreads;
-    if (lam_finished >= 0)
-        for (int j = gid; j < q.p; j += gsz) q.beta[(size_t)lam_finished * q.p + j] = q.x[j];   // get_x()  Lasso.cpp:119
-    if (out.done) return;
-    const float rho_f = (float)out.rho;
-    for (int i = gid; i < q.n; i += gsz) {
-        const float t = q.Ax[i] + q.z[i] + q.y[i] / rho_f;            // cache_Ax + aux_z + dual_y / Scalar(rho)
-        q.t[i] = t;
-        q.tdiv[i] = t / q.gamma;                                       // active-set form divides first (:90)
-    }
-}
-
-__device__ __forceinline__ float prox_f(float val, float thresh, float denom, bool enet) {
-    // active_set_update thresholding in float (ADMMLassoWide.h:108-113, ADMMEnet.h:111-116)
-    if (val > thresh) return enet ? (val - thresh) / denom : val - thresh;
-    if (val < -thresh) return enet ? (val + thresh) / denom : val + thresh;
-    return 0.f;
-}
-
-// x-update.  REG: x = prox(x - X't / gamma) on every coordinate.  ACT: only current non-zeros.  ZERO: x = 0.
-__global__ void __launch_bounds__(kWideThreads)
-wide_xupdate_kernel(WideParams q, int par) {
-    extern __shared__ __attribute__((aligned(16))) float tl[];       // tdiv staged for the active branch
-    const WideCtl c = q.ctl[par ^ 1];
-    if (c.done) return;
-    const int gid = blockIdx.x * kWideThreads + threadIdx.x, gsz = gridDim.x * kWideThreads;
-    if (c.type == W_ZERO) {
-        for (int j = gid; j < q.p; j += gsz) q.x[j] = 0.f;
-        return;
-    }
-    const double pen_d = (double)c.lam / (c.rho * (double)q.gamma);
-    if (c.type == W_REG) {
-        const float thresh = (float)((double)q.alpha * pen_d);
-        const float denom = (float)(1.0 + pen_d * (1.0 - (double)q.alpha));
+    if (out.done || out.type == W_ZERO) {
         for (int j = gid; j < q.p; j += gsz) {
-            float g = 0.f;
-            for (int s = 0; s < q.gnseg; ++s) g += q.gpart[(size_t)s * q.gstride + j];
-            const float vec = (-g) / q.gamma + q.x[j];                // vec = -X't / gamma; vec += main_x   (:147-149)
-            float xn;
-            if (!q.enet) {                                            // soft_threshold, double compare (:70-84)
-                const double v = (double)vec;
-                xn = v > pen_d ? (float)(v - pen_d) : (v < -pen_d ? (float)(v + pen_d) : 0.f);
-            } else {
-                xn = vec > thresh ? (vec - thresh) / denom : (vec < -thresh ? (vec + thresh) / denom : 0.f);
-            }
-            q.x[j] = xn;
+            if (snap) bsnap[j] = q.x[j];
+            if (!out.done) q.x[j] = 0.f;
         }
         return;
     }
-    // ---- W_ACT
-    const float penalty = (float)pen_d;                               // `const Scalar penalty` (:89)
-    const float thresh = q.enet ? q.alpha * penalty : penalty;
-    const float denom = q.enet ? (float)(1.0 + (double)penalty * (1.0 - (double)q.alpha)) : 1.f;
-    const int npad = (q.n + 255) / 256 * 256;
-    for (int i = threadIdx.x; i < npad; i += kWideThreads) tl[i] = i < q.n ? q.tdiv[i] : 0.f;
+    // t = cache_Ax + aux_z + dual_y / Scalar(rho); the active-set form divides by gamma first (:90, :141)
+    const float rho_f = (float)out.rho;
+    for (int i = threadIdx.x; i < npad; i += kWideThreads) {       // same thread wrote these slots above
+        const float t = tl[i] + tdl[i] / rho_f;
+        tl[i] = t;
+        tdl[i] = t / q.gamma;
+    }
     __syncthreads();
+    const bool reg = out.type == W_REG;
+    const double pen_d = (double)out.lam / (out.rho * (double)q.gamma);
+    const float penalty = (float)pen_d;                               // `const Scalar penalty` (:89)
+    const float thresh_a = q.enet ? q.alpha * penalty : penalty;
+    const float denom_a = q.enet ? (float)(1.0 + (double)penalty * (1.0 - (double)q.alpha)) : 1.f;
+    const float thresh_r = (float)((double)q.alpha * pen_d);
+    const float denom_r = (float)(1.0 + pen_d * (1.0 - (double)q.alpha));
+    const float* tv = reg ? tl : tdl;
     const int lane = threadIdx.x & 63;
     const int NW = gridDim.x * (kWideThreads / 64);
     const int w = blockIdx.x * (kWideThreads / 64) + (threadIdx.x >> 6);
@@ -188,21 +180,42 @@ wide_xupdate_kernel(WideParams q, int par) {
     for (int s0 = 0; (long long)s0 * NW < q.p; s0 += 64) {
         const long long jl = (long long)(s0 + lane) * NW + w;
         float xj = (jl < q.p) ? q.x[jl] : 0.f;
-        unsigned long long mask = __ballot(xj != 0.f);
+        if (snap && jl < q.p) bsnap[jl] = xj;
+        unsigned long long mask = reg ? __ballot(jl < q.p) : __ballot(xj != 0.f);
         while (mask) {
             const int l = __ffsll((long long)mask) - 1;
             mask &= mask - 1;
             const long long jj = (long long)(s0 + l) * NW + w;
             const float xv = __shfl(xj, l, 64);
             const float* col = q.X + (size_t)jj * q.ldx;
-            float d = 0.f;
-            for (int r = lane * 4; r < nv; r += 256) {
-                const float4 a = *reinterpret_cast<const float4*>(col + r);
-                const float4 b = *reinterpret_cast<const float4*>(tl + r);
-                d = fmaf(a.x, b.x, d); d = fmaf(a.y, b.y, d); d = fmaf(a.z, b.z, d); d = fmaf(a.w, b.w, d);
+            float d0 = 0.f, d1 = 0.f;
+            int r = lane * 4;
+            for (; r + 256 < nv; r += 512) {
+                const float4 a0 = *reinterpret_cast<const float4*>(col + r);
+                const float4 a1 = *reinterpret_cast<const float4*>(col + r + 256);
+                const float4 b0 = *reinterpret_cast<const float4*>(tv + r);
+                const float4 b1 = *reinterpret_cast<const float4*>(tv + r + 256);
+                d0 = fmaf(a0.x, b0.x, d0); d0 = fmaf(a0.y, b0.y, d0); d0 = fmaf(a0.z, b0.z, d0); d0 = fmaf(a0.w, b0.w, d0);
+                d1 = fmaf(a1.x, b1.x, d1); d1 = fmaf(a1.y, b1.y, d1); d1 = fmaf(a1.z, b1.z, d1); d1 = fmaf(a1.w, b1.w, d1);
             }
-            d = wave_sum(d);
-            const float xn = prox_f(xv - d, thresh, denom, q.enet != 0);
+            if (r < nv) {
+                const float4 a0 = *reinterpret_cast<const float4*>(col + r);
+                const float4 b0 = *reinterpret_cast<const float4*>(tv + r);
+                d0 = fmaf(a0.x, b0.x, d0); d0 = fmaf(a0.y, b0.y, d0); d0 = fmaf(a0.z, b0.z, d0); d0 = fmaf(a0.w, b0.w, d0);
+            }
+            const float d = wave_sum(d0 + d1);
+            float xn;
+            if (reg) {
+                const float vec = (-d) / q.gamma + xv;                // vec = -X't / gamma; vec += main_x   (:147-149)
+                if (!q.enet) {                                        // soft_threshold, double compare (:70-84)
+                    const double v = (double)vec;
+                    xn = v > pen_d ? (float)(v - pen_d) : (v < -pen_d ? (float)(v + pen_d) : 0.f);
+                } else {
+                    xn = vec > thresh_r ? (vec - thresh_r) / denom_r : (vec < -thresh_r ? (vec + thresh_r) / denom_r : 0.f);
+                }
+            } else {
+                xn = prox_f(xv - d, thresh_a, denom_a, q.enet != 0);
+            }
             if (lane == l) { xj = xn; q.x[jj] = xn; }
         }
     }
@@ -222,24 +235,33 @@ wide_ax_kernel(WideParams q) {
         for (int k = 0; k < kAxRT; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         const int rows_here = min(q.n - r0, 256 * kAxRT);
         const int npass = (rows_here + 255) / 256;
-        for (int s0 = 0; (long long)s0 * NW < q.p; s0 += 64) {
-            const long long jl = (long long)(s0 + lane) * NW + w;
-            const float xj = (jl < q.p) ? q.x[jl] : 0.f;
-            unsigned long long mask = __ballot(xj != 0.f);
-            while (mask) {
-                const int l = __ffsll((long long)mask) - 1;
-                mask &= mask - 1;
-                const long long jj = (long long)(s0 + l) * NW + w;
-                const float xv = __shfl(xj, l, 64);
-                const float* col = q.X + (size_t)jj * q.ldx + r0;
+        for (int sc = 0; (long long)sc * NW < q.p; sc += 64 * 8) {
+            float xs[8];
 #pragma unroll
-                for (int k = 0; k < kAxRT; ++k) {
-                    if (k < npass) {
-                        const int r = k * 256 + lane * 4;
-                        if (r < rows_here) {                      // ldx padding rows are zero, vector load is in-bounds
-                            const float4 a = *reinterpret_cast<const float4*>(col + r);
-                            acc[k].x = fmaf(xv, a.x, acc[k].x); acc[k].y = fmaf(xv, a.y, acc[k].y);
-                            acc[k].z = fmaf(xv, a.z, acc[k].z); acc[k].w = fmaf(xv, a.w, acc[k].w);
+            for (int u = 0; u < 8; ++u) {                          // the wave's next 512 columns: 8 independent loads per lane
+                const long long jl = (long long)(sc + u * 64 + lane) * NW + w;
+                xs[u] = (jl < q.p) ? q.x[jl] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int s0 = sc + u * 64;
+                const float xj = xs[u];
+                unsigned long long mask = __ballot(xj != 0.f);
+                while (mask) {
+                    const int l = __ffsll((long long)mask) - 1;
+                    mask &= mask - 1;
+                    const long long jj = (long long)(s0 + l) * NW + w;
+                    const float xv = __shfl(xj, l, 64);
+                    const float* col = q.X + (size_t)jj * q.ldx + r0;
+#pragma unroll
+                    for (int k = 0; k < kAxRT; ++k) {
+                        if (k < npass) {
+                            const int r = k * 256 + lane * 4;
+                            if (r < rows_here) {                      // ldx padding rows are zero, vector load is in-bounds
+                                const float4 a = *reinterpret_cast<const float4*>(col + r);
+                                acc[k].x = fmaf(xv, a.x, acc[k].x); acc[k].y = fmaf(xv, a.y, acc[k].y);
+                                acc[k].z = fmaf(xv, a.z, acc[k].z); acc[k].w = fmaf(xv, a.w, acc[k].w);
+                            }
                         }
                     }
                 }
@@ -269,25 +291,40 @@ wide_ax_kernel(WideParams q) {
 }
 
 // z/y update: Ax = sum of partials; z_new = -(y_data + y + rho Ax) / (1 + rho); r = Ax + z_new; y += rho r; norms.
+// 8 lanes share one element and issue their 16 partial loads at once (one memory round trip).
+constexpr int kWtLanes = 8;
+constexpr int kWtElems = kWideThreads / kWtLanes;
+static_assert(kAxWG == 16 * kWtLanes, "tail reduction assumes 16 partials per lane");
+
 __global__ void __launch_bounds__(kWideThreads)
 wide_tail_kernel(WideParams q, int par) {
     __shared__ double scratch[5 * (kWideThreads / 64)];
     const WideCtl c = q.ctl[par ^ 1];
+    const int sub = threadIdx.x & (kWtLanes - 1);
+    const int i = blockIdx.x * kWtElems + threadIdx.x / kWtLanes;
+    const bool valid = i < q.n;
+    float v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = valid ? q.axpart[(size_t)(k * kWtLanes + sub) * q.ldn + i] : 0.f;
+    float zo = 0.f, yo = 0.f, yd = 0.f;
+    if (valid) { zo = q.z[i]; yo = q.y[i]; yd = q.Y[i]; }
+    float ax = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) ax += v[k];
+#pragma unroll
+    for (int m = 1; m < kWtLanes; m <<= 1) ax += __shfl_xor(ax, m, 64);
     if (c.done) return;
-    const float rho_f = (float)c.rho;
-    const float den = (float)(-1.0 - c.rho);                          // Scalar(-1 - rho)   (:164)
     double acc[5] = {0, 0, 0, 0, 0};
-    for (int i = blockIdx.x * kWideThreads + threadIdx.x; i < q.n; i += gridDim.x * kWideThreads) {
-        float ax = 0.f;
-        for (int b = 0; b < kAxWG; ++b) ax += q.axpart[(size_t)b * q.ldn + i];
-        const float zo = q.z[i], yo = q.y[i];
-        const float zn = (q.Y[i] + yo + rho_f * ax) / den;            // next_z (:156-165)
+    if (valid && sub == 0) {
+        const float rho_f = (float)c.rho;
+        const float den = (float)(-1.0 - c.rho);                      // Scalar(-1 - rho)   (:164)
+        const float zn = (yd + yo + rho_f * ax) / den;                // next_z (:156-165)
         const float dz = zn - zo;
         const float r = ax + zn;                                       // next_residual (:166-170)
         const float yn = yo + rho_f * r;                               // dual_y += rho * newr   ADMMBase.h:183
         q.Ax[i] = ax; q.z[i] = zn; q.y[i] = yn;
-        acc[0] += (double)r * r; acc[1] += (double)dz * dz; acc[2] += (double)ax * ax;
-        acc[3] += (double)zn * zn; acc[4] += (double)yn * yn;
+        acc[0] = (double)r * r; acc[1] = (double)dz * dz; acc[2] = (double)ax * ax;
+        acc[3] = (double)zn * zn; acc[4] = (double)yn * yn;
     }
     block_sum<double, 5>(acc, scratch);
     if (threadIdx.x == 0) {
@@ -322,7 +359,6 @@ struct WidePlan final : LassoPlan {
     double rho0 = 0;
     std::vector<double> lam_user;
     std::vector<float> lam_int;
-    GemvT<float> gX;
     DevBuf<float> x, Ax, z, y, t, tdiv, axpart, beta, dlam;
     DevBuf<int> niter, done;
     DevBuf<double> P;
@@ -365,8 +401,7 @@ struct WidePlan final : LassoPlan {
         if (rho0 <= 0) rho0 = std::pow((double)lam_int[0] / (double)sprad, 1.0 / 3);       // :227-228
         S.rho = rho0;
 
-        gX.init(d.X.get(), d.ldx, n, p);
-        nwg_tail = std::max(1, std::min(32, (n + kWideThreads - 1) / kWideThreads));
+        nwg_tail = (n + kWtElems - 1) / kWtElems;                    // 32 elements per workgroup (8 lanes each)
         x.alloc(ldp); x.zero(st);
         for (DevBuf<float>* b : {&Ax, &z, &y, &t, &tdiv}) { b->alloc(ldn); b->zero(st); }
         axpart.alloc((size_t)kAxWG * ldn); axpart.zero(st);
@@ -380,7 +415,7 @@ struct WidePlan final : LassoPlan {
         q.eps_abs = pb.opts.eps_abs; q.eps_rel = pb.opts.eps_rel;
         q.sqrt_n = std::sqrt((double)n); q.sqrt_p = std::sqrt((double)p); q.sqrt_gamma = (double)std::sqrt(sprad);
         q.lambdas = dlam.get(); q.x = x.get(); q.Ax = Ax.get(); q.z = z.get(); q.y = y.get(); q.t = t.get(); q.tdiv = tdiv.get();
-        q.gpart = gX.part.get(); q.gnseg = gX.pl.nseg; q.gstride = gX.stride;
+        q.gpart = nullptr; q.gnseg = 0; q.gstride = 0;
         q.axpart = axpart.get(); q.ldn = ldn;
         q.ctl = ctl.get(); q.P = P.get(); q.beta = beta.get(); q.niter = niter.get(); q.done = done.get();
         ADMM_HIP_CHECK(hipStreamSynchronize(st));
@@ -393,15 +428,14 @@ struct WidePlan final : LassoPlan {
         const int init_n = std::max(std::max(n, p), nwg_tail * 8);
         hipLaunchKernelGGL(wide_init_kernel, dim3((init_n + 255) / 256), dim3(256), 0, st, q, rho0, lam_int[0]);
         const int ncu = device_info().num_cu;
-        const int nwg_head = std::max(1, std::min(ncu, (std::max(n, p) + kWideThreads - 1) / kWideThreads));
-        const int nwg_x = 4 * ncu;                                   // 4096 waves own the columns
-        const size_t lds_x = (size_t)((n + 255) / 256 * 256) * sizeof(float);
+        int wgx = 4;                                                 // workgroups per CU of the x-update launch
+        if (const char* e = std::getenv("ADMM_HIP_WIDE_WGX")) wgx = std::max(1, std::atoi(e));
+        const int nwg_x = wgx * ncu;
+        const size_t lds_x = (size_t)((n + 255) / 256 * 256) * 2 * sizeof(float) + (size_t)nwg_tail * 8 * sizeof(double);
         const int batch = pb.batch_iters > 0 ? (pb.batch_iters + 1) / 2 * 2 : 16;
         LoopTimes lt = run_until_done(st, done.get(), batch, (long long)nlam * ((long long)pb.opts.maxit + 2) + 4, [&](long long g) {
             const int par = (int)(g & 1);
-            hipLaunchKernelGGL(wide_head_kernel, dim3(nwg_head), dim3(kWideThreads), (size_t)nwg_tail * 8 * sizeof(double), st, q, par);
-            gX.run_partials(t.get(), &ctl.get()[par ^ 1].skip_reg, st);                   // X't, regular iterations only
-            hipLaunchKernelGGL(wide_xupdate_kernel, dim3(nwg_x), dim3(kWideThreads), lds_x, st, q, par);
+            hipLaunchKernelGGL(wide_x_kernel, dim3(nwg_x), dim3(kWideThreads), lds_x, st, q, par);
             hipLaunchKernelGGL(wide_ax_kernel, dim3(kAxWG), dim3(kWideThreads), 0, st, q);
             hipLaunchKernelGGL(wide_tail_kernel, dim3(nwg_tail), dim3(kWideThreads), 0, st, q, par);
         });
