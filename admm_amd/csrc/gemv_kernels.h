@@ -14,6 +14,7 @@
 #pragma once
 #include "admm_internal.h"
 #include "device_utils.h"
+#include <hip/hip_ext.h>
 
 namespace admm {
 
@@ -166,13 +167,15 @@ inline GemvTPlan plan_gemv_t(int m, int k, int nrhs, int C, int max_seg_rows = 0
 template <typename T, int NRHS, int C, typename Extra = GemvNoExtra>
 inline void launch_gemv_t(const GemvTPlan& pl, const T* A, long long lda, int m, int k,
                           const T* v0, const T* v1, T* out0, T* out1, long long out_stride,
-                          const int* skip, hipStream_t st, Extra extra = Extra()) {
+                          const int* skip, hipStream_t st, Extra extra = Extra(),
+                          hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
     GemvTArgs<T> a;
     a.A = A; a.lda = lda; a.m = m; a.k = k;
     a.v[0] = v0; a.v[1] = v1; a.out[0] = out0; a.out[1] = out1;
     a.out_stride = out_stride; a.seg_len = pl.seg_len; a.seg_alloc = pl.seg_alloc; a.nseg = pl.nseg;
     a.groups_per_wg = pl.groups_per_wg; a.skip = skip;
-    hipLaunchKernelGGL((gemv_t_kernel<T, NRHS, C, Extra>), dim3(pl.grid + (Extra::kHas ? 1 : 0)), dim3(kGemvThreads), pl.lds_bytes, st, a, extra);
+    hipExtLaunchKernelGGL((gemv_t_kernel<T, NRHS, C, Extra>), dim3(pl.grid + (Extra::kHas ? 1 : 0)), dim3(kGemvThreads),
+                          (std::uint32_t)pl.lds_bytes, st, ev_start, ev_stop, 0, a, extra);
 }
 
 // Sum the nseg partial rows of a gemv_t result: y[j] = sum_s part[s*stride + j].

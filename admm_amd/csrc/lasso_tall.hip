@@ -378,16 +378,15 @@ struct TallPlan final : LassoPlan {
                 if (sample) {
                     ADMM_HIP_CHECK(hipEventCreate(&e0)); ADMM_HIP_CHECK(hipEventCreate(&e1));
                     evs.push_back(e0); evs.push_back(e1);
-                    ADMM_HIP_CHECK(hipEventRecord(e0, st));
                 }
+                // sampled launches carry start/stop events that time exactly the x-update kernel on this stream
                 if (use_sym) {
                     // the decision of this iteration rides along as one extra workgroup of the x-update launch
-                    sy.launch(M.get(), ldp, u.get(), w.get(), &ctl.get()[par].done, st, TallDecideExtra{q, par});
+                    sy.launch(M.get(), ldp, u.get(), w.get(), &ctl.get()[par].done, st, TallDecideExtra{q, par}, e0, e1);
                 } else {
                     launch_gemv_t<float, 2, 4, TallDecideExtra>(pl, M.get(), ldp, p, p, u.get(), w.get(), a_part.get(), b_part.get(), ldp,
-                                                                &ctl.get()[par].done, st, TallDecideExtra{q, par});
+                                                                &ctl.get()[par].done, st, TallDecideExtra{q, par}, e0, e1);
                 }
-                if (sample) ADMM_HIP_CHECK(hipEventRecord(e1, st));
                 if (use_sym) hipLaunchKernelGGL(tall_tail_kernel<true>, dim3(nwg), dim3(kTailThreads), 0, st, q, par);
                 else hipLaunchKernelGGL(tall_tail_kernel<false>, dim3(nwg), dim3(kTailThreads), 0, st, q, par);
                 ++launches;

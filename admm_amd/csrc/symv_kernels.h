@@ -18,6 +18,7 @@
 #pragma once
 #include "admm_internal.h"
 #include "device_utils.h"
+#include <hip/hip_ext.h>
 
 namespace admm {
 
@@ -177,12 +178,14 @@ struct SymvPlan {
         ADMM_HIP_CHECK(hipStreamSynchronize(st));
     }
     template <typename Extra = SymvNoExtra>
-    void launch(const float* A, long long lda, const float* v0, const float* v1, const int* skip, hipStream_t st, Extra extra = Extra()) {
+    void launch(const float* A, long long lda, const float* v0, const float* v1, const int* skip, hipStream_t st, Extra extra = Extra(),
+                hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
         SymvArgs a;
         a.A = A; a.lda = lda; a.p = p; a.v0 = v0; a.v1 = v1;
         a.dot0 = dot0.get(); a.dot1 = dot1.get(); a.axp0 = axp0.get(); a.axp1 = axp1.get();
         a.ldo = ldo; a.tiles = tiles.get(); a.skip = skip;
-        hipLaunchKernelGGL((symv2_lower_kernel<Extra>), dim3(ntiles + 1), dim3(kSyThreads), 0, st, a, extra);
+        // start/stop events (when given) time exactly this kernel on its stream (hipExtLaunchKernel)
+        hipExtLaunchKernelGGL((symv2_lower_kernel<Extra>), dim3(ntiles + 1), dim3(kSyThreads), 0, st, ev_start, ev_stop, 0, a, extra);
     }
 };
 
