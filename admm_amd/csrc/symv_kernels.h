@@ -70,7 +70,7 @@ __device__ __forceinline__ float butterfly8(const float (&v)[8], int lane) {
 struct SymvNoExtra { __device__ void operator()() const {} };
 
 template <typename Extra>
-__global__ void __launch_bounds__(kSyThreads, 4)
+__global__ void __launch_bounds__(kSyThreads, 4)      // 4 waves/SIMD: 2 or 4 measure the same, 8 spills; non-temporal loads are 8 % slower (the 2p^2 bytes stay in the Infinity Cache)
 symv2_lower_kernel(SymvArgs a, Extra extra) {
     if (blockIdx.x == 0) { extra(); return; }
     if (a.skip != nullptr && *a.skip != 0) return;
