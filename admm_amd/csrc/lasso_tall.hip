@@ -274,7 +274,7 @@ struct TallPlan final : LassoPlan {
         admm_stats& S = setup_stats;
         S.branch = 0;
         S.t_h2d = d.t_h2d; S.t_standardize = d.t_std;
-        ldp = round_up(p, 32);
+        ldp = round_up(p, 128);                         // whole 128-row blocks for the matrix-core setup kernels
 
         // X'y and lambda_0 (ADMMLassoTall.h:172-173; ADMMEnet.h:56 divides by alpha + 1e-4)
         XY.alloc(ldp); XY.zero(st);
@@ -290,7 +290,7 @@ struct TallPlan final : LassoPlan {
 
         // Gram (cross_prod_lower, ADMMLassoTall.h:191-192) -- both triangles
         double t0 = now_s();
-        M.alloc((size_t)ldp * p); M.zero(st);
+        M.alloc((size_t)ldp * ldp); M.zero(st);
         gram_full<float>(d.X.get(), d.ldx, n, p, true, M.get(), ldp, st);
         ADMM_HIP_CHECK(hipStreamSynchronize(st));
         S.t_gram = now_s() - t0;
@@ -311,7 +311,11 @@ struct TallPlan final : LassoPlan {
         // (X'X + rho I)^-1, cached for the whole path (rho never changes: ADMMLassoTall.h:97)
         t0 = now_s();
         add_diag<float>(M.get(), ldp, p, (float)rho, st);
-        spd_inverse_full<float>(M.get(), ldp, p, st);
+        {
+            const char* e = std::getenv("ADMM_HIP_FACTOR");
+            if ((e && std::string(e) == "rocsolver") || p < 256) spd_inverse_full<float>(M.get(), ldp, p, st);
+            else spd_inverse_mfma_f32(M.get(), ldp, p, st);
+        }
         ADMM_HIP_CHECK(hipStreamSynchronize(st));
         S.t_factor = now_s() - t0;
         // X itself is no longer needed by the loop (only X'y and Minv are): release 4np bytes.

@@ -43,6 +43,9 @@ void symmetrize_from_lower(T* A, long long lda, int n, hipStream_t st);
 // In place: A (SPD, lower triangle valid) -> full symmetric inverse. Throws ADMM_ERR_NOT_SPD.
 template <typename T>
 void spd_inverse_full(T* A, long long lda, int n, hipStream_t st);
+// fp32, hand-written matrix-core path (syrk_mfma.hip).  Contract: lda >= round_up(n, 128) and the buffer holds
+// round_up(n, 128) columns, padding zero.  ADMM_HIP_FACTOR=rocsolver forces the library path.
+void spd_inverse_mfma_f32(float* A, long long lda, int n, hipStream_t st);
 // In place Cholesky (lower). Throws ADMM_ERR_NOT_SPD.
 template <typename T>
 void cholesky_lower(T* A, long long lda, int n, hipStream_t st);

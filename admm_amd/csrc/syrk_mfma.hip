@@ -1,19 +1,27 @@
-// One-time Gram matrix C = X'X (fp32) on the matrix cores: the only GEMM-shaped work of the path.
+// fp32 matrix-core kernels for the one-time setup of the tall path: the Gram matrix X'X and the
+// cached inverse (X'X + rho I)^-1.  These are the only GEMM-shaped pieces of the whole path.
 //
-// Replaces Linalg::cross_prod_lower (BlasWrapper.h:73-112; under the default NO_FLOAT_BLAS a
-// single-threaded Eigen `triangularView<Lower>() = X'X`), called from ADMMLassoTall.h:191-192.
+// Replaces (reference, all single-threaded Eigen under the default NO_FLOAT_BLAS):
+//   Linalg::cross_prod_lower        BlasWrapper.h:73-112   (called from ADMMLassoTall.h:191-192)
+//   Eigen::LLT::compute / solve     ADMMLassoTall.h:204-205, :79  (here: factor once, cache the inverse)
 //
-// Structure (CDNA4): X (n x p column-major) is first transposed to Z = X' (p x n, leading dimension
-// padded to 128) so that for a fixed summation index k the operands of both factors are contiguous:
-// C[i, j] = sum_k Z[i, k] Z[j, k].  One workgroup (4 waves, 2 x 2) owns a 128 x 128 tile of the
-// LOWER triangle; each wave accumulates 64 x 64 = 2 x 2 MFMA tiles with v_mfma_f32_32x32x2_f32
-// (exact fp32, 64 FLOP/clk/SIMD = the 157 TF/s fp32 peak; there is no xf32/TF32 on gfx950).
-// K tiles of 16 are staged global -> registers -> LDS ([k][i] rows of 128 floats, so the MFMA
-// fragment reads `lds[(kk + lane/32) * 128 + i0 + lane%32]` are bank-conflict free) and double
-// buffered.  Off-diagonal tiles are written twice (tile and transposed tile) so that the result
-// has both triangles, which the symmetric mat-vec and Lanczos expect.  Tile order is remapped so
-// that each XCD (block id % 8) walks a contiguous range of the row-major triangle and re-uses its
-// row panel from its own L2.  n * p * (p + 128) flop, compute bound.
+// One kernel does all the flops: gemm_nt_mfma_kernel computes C = alpha * A B' + beta * C on
+// 128 x 128 tiles where BOTH operands are stored with the output index contiguous (A[i, k] at
+// i + k lda, B[j, k] at j + k ldb), so for a fixed summation index k the operands of both factors
+// are contiguous 512-byte rows.  A workgroup = 4 waves (2 x 2), each wave 64 x 64 = 2 x 2 MFMA
+// tiles of v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD = the 157 TF/s fp32 peak; there
+// is no xf32/TF32 on gfx950).  K tiles of 16 go global -> registers -> LDS ([k][i] rows of 128
+// floats, so the fragment reads lds[(kk + lane/32) * 128 + i0 + lane%32] are bank-conflict free),
+// double buffered.  Tile ids are remapped so that each XCD (block id % 8) walks a contiguous range
+// of tiles and re-uses its operand panels from its own L2.
+//
+//   Gram:      Z = X' (one transpose pass), C = Z Z', lower tiles + mirrored store (both triangles).
+//   Cholesky:  right-looking on 128-blocks: potf2_inv (one workgroup, in LDS: L_kk and L_kk^-1),
+//              panel L_ik = A_ik L_kk^-T (in place), trailing A_ij -= L_ik L_jk' (lower tiles).
+//   Inverse:   U = L^-T built row block by row block with two NT products per block, then
+//              (X'X + rho I)^-1 = U U' (lower tiles + mirror; products start at k = tile row since
+//              U is upper triangular).
+// No rocBLAS / rocSOLVER on this path (their handle creation alone costs 0.1-0.2 s per process).
 #include "prep.h"
 
 namespace admm {
@@ -24,25 +32,45 @@ constexpr int SK_BM = 128;      // tile rows / cols
 constexpr int SK_BK = 16;       // K tile
 constexpr int SK_THREADS = 256;
 
+struct GemmNT {
+    const float* A; long long lda;
+    const float* B; long long ldb;
+    float* C; long long ldc;
+    int M, N, K;                 // K multiple of SK_BK; operand rows readable up to the next multiple of 128
+    float alpha, beta;
+    int nbi, nbj, ntiles;
+    int mirror;                  // LOWER mode: also store the transposed tile (both triangles)
+    int kstart_row;              // start the K loop at the tile's first row (A, B upper triangular)
+};
+
+__device__ __forceinline__ void tri_decode(int t, int& bi, int& bj) {   // t -> (bi, bj), bi >= bj, row-major triangle
+    int b = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+    while ((long long)(b + 1) * (b + 2) / 2 <= t) ++b;
+    while ((long long)b * (b + 1) / 2 > t) --b;
+    bi = b; bj = t - b * (b + 1) / 2;
+}
+
+template <int LOWER>
 __global__ void __launch_bounds__(SK_THREADS, 2)
-syrk_lower_mfma_kernel(const float* __restrict__ Z, long long ldz, int p, int nk /* padded n, multiple of SK_BK */,
-                       float* __restrict__ C, long long ldc, const int2* __restrict__ tiles, int ntiles) {
+gemm_nt_mfma_kernel(GemmNT g) {
     __shared__ __attribute__((aligned(16))) float lds[2][2][SK_BK][SK_BM];      // [buffer][A/B][k][i]
     // XCD-aware remap: block b runs on XCD b % 8; give every XCD a contiguous range of tiles
-    const int per = (ntiles + 7) / 8;
+    const int per = (g.ntiles + 7) / 8;
     const int t_idx = (blockIdx.x % 8) * per + blockIdx.x / 8;
-    if (t_idx >= ntiles) return;
-    const int2 t = tiles[t_idx];
-    const int I0 = t.x * SK_BM, J0 = t.y * SK_BM;
+    if (t_idx >= g.ntiles) return;
+    int bi, bj;
+    if (LOWER) tri_decode(t_idx, bi, bj);
+    else { bi = t_idx % g.nbi; bj = t_idx / g.nbi; }
+    const int I0 = bi * SK_BM, J0 = bj * SK_BM;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wi = (wid >> 1) * 64, wj = (wid & 1) * 64;      // wave's 64 x 64 sub-tile
 
     // staging map: a K tile of one operand is 16 rows x 128 floats = 512 float4; 2 per thread
     const int s_row0 = tid >> 5;              // 0..7   (k row), second load: +8
     const int s_col = (tid & 31) * 4;         // 0..124 (i)
-    const float* gA = Z + (size_t)s_row0 * ldz + I0 + s_col;
-    const float* gB = Z + (size_t)s_row0 * ldz + J0 + s_col;
-    const size_t k8 = (size_t)8 * ldz;
+    const float* gA = g.A + (size_t)s_row0 * g.lda + I0 + s_col;
+    const float* gB = g.B + (size_t)s_row0 * g.ldb + J0 + s_col;
+    const size_t a8 = (size_t)8 * g.lda, b8 = (size_t)8 * g.ldb;
 
     floatx16 acc[2][2];
 #pragma unroll
@@ -54,11 +82,10 @@ syrk_lower_mfma_kernel(const float* __restrict__ Z, long long ldz, int p, int nk
 
     float4 ra0, ra1, rb0, rb1;
     auto gload = [&](int k0) {
-        const size_t off = (size_t)k0 * ldz;
-        ra0 = *reinterpret_cast<const float4*>(gA + off);
-        ra1 = *reinterpret_cast<const float4*>(gA + off + k8);
-        rb0 = *reinterpret_cast<const float4*>(gB + off);
-        rb1 = *reinterpret_cast<const float4*>(gB + off + k8);
+        ra0 = *reinterpret_cast<const float4*>(gA + (size_t)k0 * g.lda);
+        ra1 = *reinterpret_cast<const float4*>(gA + (size_t)k0 * g.lda + a8);
+        rb0 = *reinterpret_cast<const float4*>(gB + (size_t)k0 * g.ldb);
+        rb1 = *reinterpret_cast<const float4*>(gB + (size_t)k0 * g.ldb + b8);
     };
     auto lstore = [&](int buf) {
         *reinterpret_cast<float4*>(&lds[buf][0][s_row0][s_col]) = ra0;
@@ -67,28 +94,31 @@ syrk_lower_mfma_kernel(const float* __restrict__ Z, long long ldz, int p, int nk
         *reinterpret_cast<float4*>(&lds[buf][1][s_row0 + 8][s_col]) = rb1;
     };
 
-    gload(0);
-    lstore(0);
-    __syncthreads();
-    const int ntile_k = nk / SK_BK;
+    const int kbeg = g.kstart_row ? (max(I0, J0) / SK_BK) * SK_BK : 0;
+    const int ntile_k = (g.K - kbeg) / SK_BK;
     const int fk = lane >> 5, fi = lane & 31;
-    for (int kt = 0; kt < ntile_k; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < ntile_k) gload((kt + 1) * SK_BK);          // next tile in flight while this one computes
+    if (ntile_k > 0) {
+        gload(kbeg);
+        lstore(0);
+        __syncthreads();
+        for (int kt = 0; kt < ntile_k; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < ntile_k) gload(kbeg + (kt + 1) * SK_BK);      // next tile in flight while this one computes
 #pragma unroll
-        for (int kk = 0; kk < SK_BK; kk += 2) {
-            const float a0 = lds[buf][0][kk + fk][wi + fi];
-            const float a1 = lds[buf][0][kk + fk][wi + 32 + fi];
-            const float b0 = lds[buf][1][kk + fk][wj + fi];
-            const float b1 = lds[buf][1][kk + fk][wj + 32 + fi];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-        }
-        if (kt + 1 < ntile_k) {
-            lstore(buf ^ 1);
-            __syncthreads();
+            for (int kk = 0; kk < SK_BK; kk += 2) {
+                const float a0 = lds[buf][0][kk + fk][wi + fi];
+                const float a1 = lds[buf][0][kk + fk][wi + 32 + fi];
+                const float b0 = lds[buf][1][kk + fk][wj + fi];
+                const float b1 = lds[buf][1][kk + fk][wj + 32 + fi];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+            if (kt + 1 < ntile_k) {
+                lstore(buf ^ 1);
+                __syncthreads();
+            }
         }
     }
 
@@ -102,32 +132,164 @@ syrk_lower_mfma_kernel(const float* __restrict__ Z, long long ldz, int p, int nk
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = I0 + wi + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row < p && col < p) {
-                    const float v = acc[a][b][r];
-                    C[(size_t)col * ldc + row] = v;
-                    if (offdiag) C[(size_t)row * ldc + col] = v;     // mirrored tile: both triangles
+                if (row < g.M && col < g.N) {
+                    float v = g.alpha * acc[a][b][r];
+                    float* dst = g.C + (size_t)col * g.ldc + row;
+                    if (g.beta != 0.f) v += g.beta * *dst;
+                    *dst = v;
+                    if (LOWER && g.mirror && offdiag) g.C[(size_t)row * g.ldc + col] = v;     // mirrored tile: both triangles
                 }
             }
         }
 }
 
-// out (cols x rows, ldo, zero padded) = in' for in (rows x cols, ldi); declared in prep.h
+static void launch_gemm_nt(bool lower, const float* A, long long lda, const float* B, long long ldb, float* C, long long ldc,
+                           int M, int N, int K, float alpha, float beta, bool mirror, bool kstart_row, hipStream_t st) {
+    if (M <= 0 || N <= 0) return;
+    GemmNT g;
+    g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+    g.alpha = alpha; g.beta = beta; g.mirror = mirror ? 1 : 0; g.kstart_row = kstart_row ? 1 : 0;
+    g.nbi = (M + SK_BM - 1) / SK_BM; g.nbj = (N + SK_BM - 1) / SK_BM;
+    g.ntiles = lower ? g.nbi * (g.nbi + 1) / 2 : g.nbi * g.nbj;
+    const int grid = (g.ntiles + 7) / 8 * 8;
+    if (lower) hipLaunchKernelGGL(gemm_nt_mfma_kernel<1>, dim3(grid), dim3(SK_THREADS), 0, st, g);
+    else hipLaunchKernelGGL(gemm_nt_mfma_kernel<0>, dim3(grid), dim3(SK_THREADS), 0, st, g);
+}
+
+// ---------------------------------------------------------------------------------------------- Gram
 void gram_xtx_mfma_f32(const float* X, long long ldx, int n, int p, float* C, long long ldc, hipStream_t st) {
     const long long ldz = round_up(p, SK_BM);
     const int nk = round_up(n, SK_BK);
     DevBuf<float> Z((size_t)ldz * nk);
     Z.zero(st);
     transpose<float>(X, ldx, n, p, Z.get(), ldz, st);
+    launch_gemm_nt(true, Z.get(), ldz, Z.get(), ldz, C, ldc, p, p, nk, 1.f, 0.f, true, false, st);
+    ADMM_HIP_CHECK(hipStreamSynchronize(st));      // Z is freed on return
+}
+
+// ---------------------------------------------------------------------------------------------- Cholesky of a diagonal block
+// One workgroup: Cholesky of the nbk x nbk diagonal block (nbk <= 128) in LDS, written back in place
+// (lower), plus the inverse of the factor into Dinv (128 x 128, zeros above the diagonal; rows/cols
+// beyond nbk form an identity so that products with padded panels stay exact).
+constexpr int PF_LD = 129;
+
+__global__ void __launch_bounds__(256)
+potf2_inv_kernel(float* __restrict__ A, long long lda, int nbk, float* __restrict__ Dinv, int* __restrict__ info, int base) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* L = sm;                     // [c * PF_LD + r]
+    float* W = sm + 128 * PF_LD;
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < 128 * 128; idx += 256) {
+        const int r = idx & 127, c = idx >> 7;
+        float v = (r == c) ? 1.f : 0.f;
+        if (r < nbk && c < nbk) v = A[(size_t)c * lda + r];
+        L[c * PF_LD + r] = v;
+    }
+    for (int j = 0; j < 128; ++j) {
+        __syncthreads();
+        float d = L[j * PF_LD + j];
+        if (!(d > 0.f) || !isfinite(d)) {
+            if (tid == 0) atomicCAS(info, 0, base + j + 1);
+            d = 1.f;
+        }
+        const float s = sqrtf(d), inv = 1.f / s;
+        __syncthreads();
+        for (int r = j + 1 + tid; r < 128; r += 256) L[j * PF_LD + r] *= inv;
+        if (tid == 0) L[j * PF_LD + j] = s;
+        __syncthreads();
+        const int m = 127 - j;
+        for (int idx = tid; idx < m * m; idx += 256) {
+            const int rr = idx % m, cc = idx / m;
+            if (rr >= cc) {
+                const int r = j + 1 + rr, c = j + 1 + cc;
+                L[c * PF_LD + r] -= L[j * PF_LD + r] * L[j * PF_LD + c];
+            }
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 128 * 128; idx += 256) {
+        const int r = idx & 127, c = idx >> 7;
+        if (r < nbk && c < nbk && r >= c) A[(size_t)c * lda + r] = L[c * PF_LD + r];
+    }
+    // W = L^-1 (lower), one thread per column: forward substitution
+    if (tid < 128) {
+        const int c = tid;
+        float* w = W + c * PF_LD;
+        for (int r = 0; r < c; ++r) w[r] = 0.f;
+        w[c] = 1.f / L[c * PF_LD + c];
+        for (int r = c + 1; r < 128; ++r) {
+            float s = 0.f;
+            for (int k = c; k < r; ++k) s = fmaf(L[k * PF_LD + r], w[k], s);
+            w[r] = -s / L[r * PF_LD + r];
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 128 * 128; idx += 256) {
+        const int r = idx & 127, c = idx >> 7;
+        Dinv[(size_t)c * 128 + r] = W[c * PF_LD + r];
+    }
+}
+
+// U_ii = (L_ii^-1)' for block i (upper triangular), masked to the valid size
+__global__ void __launch_bounds__(256)
+put_diag_transposed_kernel(const float* __restrict__ Dinv, float* __restrict__ U, long long ldu, int nbk) {
+    for (int idx = threadIdx.x; idx < 128 * 128; idx += 256) {
+        const int r = idx & 127, c = idx >> 7;
+        if (r < nbk && c < nbk) U[(size_t)c * ldu + r] = Dinv[(size_t)r * 128 + c];
+    }
+}
+
+// In place: A (p x p, SPD, lower triangle valid, leading dimension lda >= round_up(p, 128), allocation of
+// round_up(p, 128) columns with zero padding) -> full symmetric inverse.  Throws ADMM_ERR_NOT_SPD.
+void spd_inverse_mfma_f32(float* A, long long lda, int p, hipStream_t st) {
     const int nb = (p + SK_BM - 1) / SK_BM;
-    std::vector<int2> h;
-    for (int bi = 0; bi < nb; ++bi)
-        for (int bj = 0; bj <= bi; ++bj) h.push_back(make_int2(bi, bj));
-    DevBuf<int2> tiles(h.size());
-    ADMM_HIP_CHECK(hipMemcpyAsync(tiles.get(), h.data(), h.size() * sizeof(int2), hipMemcpyHostToDevice, st));
-    const int ntiles = (int)h.size();
-    const int grid = (ntiles + 7) / 8 * 8;
-    hipLaunchKernelGGL(syrk_lower_mfma_kernel, dim3(grid), dim3(SK_THREADS), 0, st, Z.get(), ldz, p, nk, C, ldc, tiles.get(), ntiles);
-    ADMM_HIP_CHECK(hipStreamSynchronize(st));      // Z and the tile list are freed on return
+    const int pp = nb * SK_BM;
+    ADMM_REQUIRE(lda >= pp, "spd_inverse_mfma_f32: leading dimension must cover whole 128-row blocks");
+    DevBuf<float> Dinv((size_t)nb * 128 * 128), U((size_t)lda * pp), T2((size_t)lda * 128);
+    DevBuf<int> info(1);
+    info.zero(st); U.zero(st); T2.zero(st);
+    const size_t lds_pf = (size_t)2 * 128 * PF_LD * sizeof(float);
+    ADMM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(potf2_inv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pf));
+    // ---- right-looking blocked Cholesky
+    for (int k = 0; k < nb; ++k) {
+        const int r0 = k * SK_BM;
+        const int nbk = std::min(SK_BM, p - r0);
+        float* Akk = A + (size_t)r0 * lda + r0;
+        float* Dk = Dinv.get() + (size_t)k * 128 * 128;
+        hipLaunchKernelGGL(potf2_inv_kernel, dim3(1), dim3(256), lds_pf, st, Akk, lda, nbk, Dk, info.get(), r0);
+        const int M = p - (r0 + SK_BM);
+        if (M > 0) {
+            float* Apan = A + (size_t)r0 * lda + r0 + SK_BM;                   // rows below the diagonal block, its 128 columns
+            // L_ik = A_ik L_kk^-T : C[i, j] = sum_t A_ik[i, t] Linv[j, t]; in place (a tile only reads its own rows)
+            launch_gemm_nt(false, Apan, lda, Dk, 128, Apan, lda, M, nbk, 128, 1.f, 0.f, false, false, st);
+            // A_ij -= L_ik L_jk' on the lower tiles of the trailing matrix
+            float* Atr = A + (size_t)(r0 + SK_BM) * lda + r0 + SK_BM;
+            launch_gemm_nt(true, Apan, lda, Apan, lda, Atr, lda, M, M, 128, -1.f, 1.f, false, false, st);
+        }
+    }
+    {
+        int h = 0;
+        ADMM_HIP_CHECK(hipMemcpyAsync(&h, info.get(), sizeof(int), hipMemcpyDeviceToHost, st));
+        ADMM_HIP_CHECK(hipStreamSynchronize(st));
+        if (h != 0) throw Error(ADMM_ERR_NOT_SPD, "Cholesky: matrix is not positive definite (pivot " + std::to_string(h) + ")");
+    }
+    // ---- U = L^-T, row block by row block of W = L^-1 (stored transposed)
+    for (int i = 0; i < nb; ++i) {
+        const int r0 = i * SK_BM;
+        const int nbk = std::min(SK_BM, p - r0);
+        const float* Di = Dinv.get() + (size_t)i * 128 * 128;
+        hipLaunchKernelGGL(put_diag_transposed_kernel, dim3(1), dim3(256), 0, st, Di, U.get() + (size_t)r0 * lda + r0, lda, nbk);
+        if (i > 0) {
+            const int K = r0;
+            // T2'[j, r] = sum_k U[j, k] L[r0 + r, k]   (U upper triangular: start at k = tile row)
+            launch_gemm_nt(false, U.get(), lda, A + r0, lda, T2.get(), lda, K, nbk, K, 1.f, 0.f, false, true, st);
+            // U[j, r0 + r] = - sum_k T2'[j, k] Linv_ii[r, k]
+            launch_gemm_nt(false, T2.get(), lda, Di, 128, U.get() + (size_t)r0 * lda, lda, K, nbk, 128, -1.f, 0.f, false, false, st);
+        }
+    }
+    // ---- A^-1 = L^-T L^-1 = U U'  (both triangles)
+    launch_gemm_nt(true, U.get(), lda, U.get(), lda, A, lda, p, p, pp, 1.f, 0.f, true, true, st);
+    ADMM_HIP_CHECK(hipStreamSynchronize(st));
 }
 
 }  // namespace admm

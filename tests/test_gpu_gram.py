@@ -25,3 +25,32 @@ def test_mfma_gram_matches_library_gram_end_to_end():
     assert np.abs(fit.niter.astype(int) - ref.niter.astype(int)).max() <= 2
     for j in range(2):
         assert relerr(fit.beta_dense[:, j], ref.beta_dense[:, j]) < 1e-4
+
+
+@pytest.mark.parametrize("n,p", [(3000, 700), (2500, 1024), (1500, 257)])
+def test_mfma_cholesky_inverse_matches_rocsolver_end_to_end(n, p):
+    """Hand-written blocked Cholesky + inverse (ragged last 128-block, exact multiple, one-past) vs rocSOLVER potrf/potri."""
+    from admm_amd import admm_lasso
+    x, y = synth_lasso(n, p, 25, seed=67)
+    lam = [0.4, 0.1, 0.02]
+    os.environ["ADMM_HIP_FACTOR"] = "rocsolver"
+    try:
+        ref = admm_lasso(x, y).penalty(lam).fit()
+    finally:
+        del os.environ["ADMM_HIP_FACTOR"]
+    fit = admm_lasso(x, y).penalty(lam).fit()
+    assert np.abs(fit.niter.astype(int) - ref.niter.astype(int)).max() <= 2
+    for j in range(3):
+        assert relerr(fit.beta_dense[:, j], ref.beta_dense[:, j]) < 1e-4
+
+
+def test_not_spd_is_reported():
+    """A rank-deficient Gram with rho forced tiny must surface ADMM_ERR_NOT_SPD (the reference never checks LLT::info())."""
+    from admm_amd import AdmmHipError, admm_lasso
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((600, 300))
+    x[:, 100:200] = x[:, 0:100]                       # exactly collinear columns -> singular X'X
+    y = rng.standard_normal(600)
+    with pytest.raises(AdmmHipError) as ei:
+        admm_lasso(x, y, standardize=False, intercept=False).penalty(0.1).opts(rho=1e-12).fit()
+    assert ei.value.code == 5
