@@ -173,60 +173,78 @@ void gram_xtx_mfma_f32(const float* X, long long ldx, int n, int p, float* C, lo
 // beyond nbk form an identity so that products with padded panels stay exact).
 constexpr int PF_LD = 129;
 
-__global__ void __launch_bounds__(256)
+constexpr int PF_THREADS = 1024;      // 16 waves: the 128 sequential steps are LDS-latency bound, 4 waves per SIMD hide it
+constexpr int PF_PARTS = PF_THREADS / 128;
+
+__global__ void __launch_bounds__(PF_THREADS)
 potf2_inv_kernel(float* __restrict__ A, long long lda, int nbk, float* __restrict__ Dinv, int* __restrict__ info, int base) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* L = sm;                     // [c * PF_LD + r]
-    float* W = sm + 128 * PF_LD;
+    float* L = sm;                     // [c * PF_LD + r], lower triangle
+    float* W = sm + 128 * PF_LD;       // [c * PF_LD + r], becomes L^-1
     const int tid = threadIdx.x;
-    for (int idx = tid; idx < 128 * 128; idx += 256) {
-        const int r = idx & 127, c = idx >> 7;
-        float v = (r == c) ? 1.f : 0.f;
-        if (r < nbk && c < nbk) v = A[(size_t)c * lda + r];
-        L[c * PF_LD + r] = v;
+    const int r = tid & 127, part = tid >> 7;        // thread owns row r and the columns c = part (mod PF_PARTS)
+    for (int idx = tid; idx < 128 * 128; idx += PF_THREADS) {
+        const int rr = idx & 127, c = idx >> 7;
+        float v = (rr == c) ? 1.f : 0.f;
+        if (rr < nbk && c < nbk) v = A[(size_t)c * lda + rr];
+        L[c * PF_LD + rr] = v;
+        W[c * PF_LD + rr] = (rr == c) ? 1.f : 0.f;
     }
+    // Right-looking Cholesky fused with the forward elimination of [L | I], ONE barrier per step: the scalings
+    // by 1/l_jj are deferred (column j of L and row j of W stay unscaled in LDS and are never written again;
+    // the update factors carry 1/d = 1/l_jj^2), final L goes straight to global memory, W rows are scaled on output.
+    float* invs = W + 128 * PF_LD;     // [128] 1 / l_jj
     for (int j = 0; j < 128; ++j) {
         __syncthreads();
         float d = L[j * PF_LD + j];
+        const float lr = L[j * PF_LD + min(r, 127)];
         if (!(d > 0.f) || !isfinite(d)) {
             if (tid == 0) atomicCAS(info, 0, base + j + 1);
             d = 1.f;
         }
-        const float s = sqrtf(d), inv = 1.f / s;
-        __syncthreads();
-        for (int r = j + 1 + tid; r < 128; r += 256) L[j * PF_LD + r] *= inv;
-        if (tid == 0) L[j * PF_LD + j] = s;
-        __syncthreads();
-        const int m = 127 - j;
-        for (int idx = tid; idx < m * m; idx += 256) {
-            const int rr = idx % m, cc = idx / m;
-            if (rr >= cc) {
-                const int r = j + 1 + rr, c = j + 1 + cc;
-                L[c * PF_LD + r] -= L[j * PF_LD + r] * L[j * PF_LD + c];
+        const float inv2 = 1.f / d;
+        const float inv = 1.f / sqrtf(d);
+        if (tid == 0) invs[j] = inv;
+        if (part == 0 && r >= j && r < nbk && j < nbk) A[(size_t)j * lda + r] = (r == j) ? d * inv : lr * inv;   // final column j
+        if (r > j) {
+            const float f = lr * inv2;
+            // batches of 8 columns: all LDS reads of a batch (clamped, unconditional) are issued before its writes
+            int c0 = j + 1;
+            c0 += (part - c0) & (PF_PARTS - 1);
+            for (int cb = c0; cb <= r; cb += 8 * PF_PARTS) {
+                float a[8], b[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = min(cb + PF_PARTS * u, 127);
+                    a[u] = L[c * PF_LD + r];
+                    b[u] = L[j * PF_LD + c];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = cb + PF_PARTS * u;
+                    if (c <= r) L[c * PF_LD + r] = a[u] - f * b[u];
+                }
+            }
+            for (int cb = part; cb <= j; cb += 8 * PF_PARTS) {
+                float a[8], b[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = min(cb + PF_PARTS * u, 127);
+                    a[u] = W[c * PF_LD + r];
+                    b[u] = W[c * PF_LD + j];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = cb + PF_PARTS * u;
+                    if (c <= j) W[c * PF_LD + r] = a[u] - f * b[u];
+                }
             }
         }
     }
     __syncthreads();
-    for (int idx = tid; idx < 128 * 128; idx += 256) {
-        const int r = idx & 127, c = idx >> 7;
-        if (r < nbk && c < nbk && r >= c) A[(size_t)c * lda + r] = L[c * PF_LD + r];
-    }
-    // W = L^-1 (lower), one thread per column: forward substitution
-    if (tid < 128) {
-        const int c = tid;
-        float* w = W + c * PF_LD;
-        for (int r = 0; r < c; ++r) w[r] = 0.f;
-        w[c] = 1.f / L[c * PF_LD + c];
-        for (int r = c + 1; r < 128; ++r) {
-            float s = 0.f;
-            for (int k = c; k < r; ++k) s = fmaf(L[k * PF_LD + r], w[k], s);
-            w[r] = -s / L[r * PF_LD + r];
-        }
-    }
-    __syncthreads();
-    for (int idx = tid; idx < 128 * 128; idx += 256) {
-        const int r = idx & 127, c = idx >> 7;
-        Dinv[(size_t)c * 128 + r] = W[c * PF_LD + r];
+    for (int idx = tid; idx < 128 * 128; idx += PF_THREADS) {
+        const int rr = idx & 127, c = idx >> 7;
+        Dinv[(size_t)c * 128 + rr] = (rr >= c) ? W[c * PF_LD + rr] * invs[rr] : 0.f;
     }
 }
 
@@ -248,7 +266,7 @@ void spd_inverse_mfma_f32(float* A, long long lda, int p, hipStream_t st) {
     DevBuf<float> Dinv((size_t)nb * 128 * 128), U((size_t)lda * pp), T2((size_t)lda * 128);
     DevBuf<int> info(1);
     info.zero(st); U.zero(st); T2.zero(st);
-    const size_t lds_pf = (size_t)2 * 128 * PF_LD * sizeof(float);
+    const size_t lds_pf = ((size_t)2 * 128 * PF_LD + 128) * sizeof(float);
     ADMM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(potf2_inv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pf));
     // ---- right-looking blocked Cholesky
     for (int k = 0; k < nb; ++k) {
@@ -256,7 +274,7 @@ void spd_inverse_mfma_f32(float* A, long long lda, int p, hipStream_t st) {
         const int nbk = std::min(SK_BM, p - r0);
         float* Akk = A + (size_t)r0 * lda + r0;
         float* Dk = Dinv.get() + (size_t)k * 128 * 128;
-        hipLaunchKernelGGL(potf2_inv_kernel, dim3(1), dim3(256), lds_pf, st, Akk, lda, nbk, Dk, info.get(), r0);
+        hipLaunchKernelGGL(potf2_inv_kernel, dim3(1), dim3(PF_THREADS), lds_pf, st, Akk, lda, nbk, Dk, info.get(), r0);
         const int M = p - (r0 + SK_BM);
         if (M > 0) {
             float* Apan = A + (size_t)r0 * lda + r0 + SK_BM;                   // rows below the diagonal block, its 128 columns
