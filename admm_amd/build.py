@@ -17,7 +17,7 @@ LIB = os.path.join(LIBDIR, "libadmm_hip.so")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIPCC = os.path.join(ROCM, "bin", "hipcc")
 ARCH = "gfx950"
-CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
+CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
             "-Wno-unused-result", f"-I{os.path.join(ROCM, 'include')}"]
 LDFLAGS = ["-shared", "-fPIC", f"--offload-arch={ARCH}", f"-L{os.path.join(ROCM, 'lib')}",
            "-lrocblas", "-lrocsolver", "-lrccl", f"-Wl,-rpath,{os.path.join(ROCM, 'lib')}"]

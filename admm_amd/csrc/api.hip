@@ -287,7 +287,7 @@ int admm_hip_device_synchronize(void) {
 
 // Host-only helper used by the CPU test-suite: runs the Lanczos host logic (lanczos.hip) against a
 // dense symmetric matrix held in host memory.  Not part of any solver path.
-int admm_hip_host_lanczos(const float* A, int n, float* eig_out, int* nmatop_out) {
+ADMM_HIP_API int admm_hip_host_lanczos(const float* A, int n, float* eig_out, int* nmatop_out) {
     return guarded([&] {
         ADMM_REQUIRE(A && eig_out && n >= 3, "bad arguments");
         auto op = [&](const float* v, float* w) {

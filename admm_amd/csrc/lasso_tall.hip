@@ -14,9 +14,12 @@
 //        rhs   = X'y - adj_y + rho adj_z = u + tau w,
 //        u = X'y - y + rho z,   w = -(y - y_old) + rho (z - z_old).
 //    The x-update kernel therefore streams Minv ONCE against the pair (u, w) and produces
-//    a = Minv u, b = Minv w; the next kernel forms x = a + tau b after it has evaluated the
-//    decision from the previous iteration's norm partials.  No host round trip, no grid
-//    barrier, no atomics: two launches per ADMM iteration.
+//    a = Minv u, b = Minv w; the tail kernel forms x = a + tau b.  The scalar decision itself
+//    (norm reduction, convergence, acceleration/restart, lambda schedule) runs as ONE EXTRA
+//    WORKGROUP of the x-update launch, concurrently with the streaming workgroups.  No host round
+//    trip, no grid barrier, no atomics: two launches per ADMM iteration.
+//  * Minv is symmetric: for p >= 2048 the x-update reads only its lower triangle (symv_kernels.h,
+//    2p^2 bytes); small problems use the full-matrix gemv_t (fewer, larger workgroups).
 //  * Convergence test, acceleration scalars, the lambda schedule (init_warm), niter[] and the
 //    beta snapshot all live on the device; the host only enqueues iteration batches and polls
 //    a `done` word asynchronously.
@@ -130,9 +133,6 @@ struct TallDecideExtra {
     TallParams q; int par;
     __device__ void operator()() const { tall_decide(q, par); }
 };
-
-__global__ void __launch_bounds__(kTailThreads)
-tall_decide_kernel(TallParams q, int par) { tall_decide(q, par); }
 
 // Element-wise part of one iteration.  `c` = the control block published by this iteration's decision.
 template <bool SYM>

@@ -32,7 +32,7 @@ enum { W_ZERO = 0, W_REG = 1, W_ACT = 2 };
 struct WideCtl {
     double rho, eps_primal, eps_dual;
     float lam; int type;
-    int iter, counter, lam_idx, done, first, skip_reg, pad0, pad1;
+    int iter, counter, lam_idx, done, first, pad0, pad1, pad2;
 };
 
 constexpr int kWideThreads = 256;
@@ -47,8 +47,7 @@ struct WideParams {
     double eps_abs, eps_rel, sqrt_n, sqrt_p, sqrt_gamma;
     const float* lambdas;                 // device [nlam], internal lambdas as float (Scalar lambda)
     float* x;                             // p, dense storage of the sparse main_x
-    float* Ax; float* z; float* y; float* t; float* tdiv;     // n
-    const float* gpart; int gnseg; long long gstride;         // X't partials (regular step)
+    float* Ax; float* z; float* y;        // n
     float* axpart;                        // [kAxWG][ldn]
     long long ldn;
     WideCtl* ctl;                         // [2]
@@ -141,7 +140,6 @@ wide_x_kernel(WideParams q, int par) {
         out.type = (is_regular_update((unsigned)out.counter) && out.lam < q.lambda0) ? W_REG : W_ACT;
         out.counter++;
     }
-    out.skip_reg = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (lam_finished >= 0) q.niter[lam_finished] = niter_val;
         *outp = out;
@@ -337,12 +335,12 @@ wide_tail_kernel(WideParams q, int par) {
 __global__ void wide_init_kernel(WideParams q, double rho, float lam0) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < q.p) q.x[i] = 0.f;
-    if (i < q.n) { q.Ax[i] = 0.f; q.z[i] = 0.f; q.y[i] = 0.f; q.t[i] = 0.f; q.tdiv[i] = 0.f; }
+    if (i < q.n) { q.Ax[i] = 0.f; q.z[i] = 0.f; q.y[i] = 0.f; }
     if (i < q.nwg_tail * 8) q.P[i] = 0.0;
     if (i == 0) {
         WideCtl c;
         c.rho = rho; c.eps_primal = 0; c.eps_dual = 0; c.lam = lam0; c.type = W_REG;
-        c.iter = 0; c.counter = 0; c.lam_idx = 0; c.done = 0; c.first = 1; c.skip_reg = 0; c.pad0 = c.pad1 = 0;
+        c.iter = 0; c.counter = 0; c.lam_idx = 0; c.done = 0; c.first = 1; c.pad0 = c.pad1 = c.pad2 = 0;
         q.ctl[0] = c; q.ctl[1] = c;
         *q.done = 0;
     }
@@ -359,7 +357,7 @@ struct WidePlan final : LassoPlan {
     double rho0 = 0;
     std::vector<double> lam_user;
     std::vector<float> lam_int;
-    DevBuf<float> x, Ax, z, y, t, tdiv, axpart, beta, dlam;
+    DevBuf<float> x, Ax, z, y, axpart, beta, dlam;
     DevBuf<int> niter, done;
     DevBuf<double> P;
     DevBuf<WideCtl> ctl;
@@ -403,7 +401,7 @@ struct WidePlan final : LassoPlan {
 
         nwg_tail = (n + kWtElems - 1) / kWtElems;                    // 32 elements per workgroup (8 lanes each)
         x.alloc(ldp); x.zero(st);
-        for (DevBuf<float>* b : {&Ax, &z, &y, &t, &tdiv}) { b->alloc(ldn); b->zero(st); }
+        for (DevBuf<float>* b : {&Ax, &z, &y}) { b->alloc(ldn); b->zero(st); }
         axpart.alloc((size_t)kAxWG * ldn); axpart.zero(st);
         beta.alloc((size_t)nlam * p); niter.alloc(nlam); done.alloc(1); dlam.alloc(nlam);
         P.alloc((size_t)nwg_tail * 8); ctl.alloc(2);
@@ -414,8 +412,7 @@ struct WidePlan final : LassoPlan {
         q.gamma = sprad; q.lambda0 = lambda0; q.alpha = (float)pb.alpha;
         q.eps_abs = pb.opts.eps_abs; q.eps_rel = pb.opts.eps_rel;
         q.sqrt_n = std::sqrt((double)n); q.sqrt_p = std::sqrt((double)p); q.sqrt_gamma = (double)std::sqrt(sprad);
-        q.lambdas = dlam.get(); q.x = x.get(); q.Ax = Ax.get(); q.z = z.get(); q.y = y.get(); q.t = t.get(); q.tdiv = tdiv.get();
-        q.gpart = nullptr; q.gnseg = 0; q.gstride = 0;
+        q.lambdas = dlam.get(); q.x = x.get(); q.Ax = Ax.get(); q.z = z.get(); q.y = y.get();
         q.axpart = axpart.get(); q.ldn = ldn;
         q.ctl = ctl.get(); q.P = P.get(); q.beta = beta.get(); q.niter = niter.get(); q.done = done.get();
         ADMM_HIP_CHECK(hipStreamSynchronize(st));

@@ -23,9 +23,10 @@ it in a side run (`consensus` object: BASELINE configs[3] shape, K = N row block
 over the N GPUs, one grouped RCCL all-reduce per iteration), executed in child processes with a
 time limit so that it can never invalidate the primary line.
 
-Extra objects on the JSON line: `roofline` for the dominant kernel (the x-update mat-vec,
-4*p^2 algorithmic bytes per launch, durations from HIP events recorded by the library on its own
-stream inside the timed region) and `cpu_baseline` (the NumPy/LAPACK oracle port of the same loop
+Extra objects on the JSON line: `roofline` for the dominant kernel (the x-update mat-vec: 2*p^2
+algorithmic bytes per launch for the symmetric lower-triangle kernel, 4*p^2 for the full-matrix
+one; durations from kernel-exact HIP start/stop events recorded by the library on its own stream
+inside the timed region) and `cpu_baseline` (the NumPy/LAPACK oracle port of the same loop
 timed on the host cores on a bounded sample).
 """
 import argparse

@@ -36,6 +36,13 @@
 extern "C" {
 #endif
 
+/* the library is built with -fvisibility=hidden; only the functions below are exported */
+#if defined(__GNUC__)
+#define ADMM_HIP_API __attribute__((visibility("default")))
+#else
+#define ADMM_HIP_API
+#endif
+
 #define ADMM_OK 0
 #define ADMM_ERR_INVALID_ARG 1
 #define ADMM_ERR_NO_DEVICE 2
@@ -89,30 +96,30 @@ typedef struct admm_stats {
  *                             structural zeros are exactly the zeros here, Lasso.cpp:22-30)
  *   niter_out[nl]             ADMM iterations per lambda
  */
-int admm_hip_lasso(const double* x, const double* y, int n, int p, int mem,
+ADMM_HIP_API int admm_hip_lasso(const double* x, const double* y, int n, int p, int mem,
                    const double* lambda_in, int nlambda_in, int nlambda_auto, double lmin_ratio,
                    int standardize, int intercept, const admm_opts* opts,
                    double* lambda_out, float* beta_out, int* niter_out, admm_stats* stats);
 
 /* As admm_hip_lasso with the elastic-net mixing weight alpha (Enet.cpp:63, ADMMEnet.h:24-57). */
-int admm_hip_enet(const double* x, const double* y, int n, int p, int mem,
+ADMM_HIP_API int admm_hip_enet(const double* x, const double* y, int n, int p, int mem,
                   const double* lambda_in, int nlambda_in, int nlambda_auto, double lmin_ratio,
                   int standardize, int intercept, double alpha, const admm_opts* opts,
                   double* lambda_out, float* beta_out, int* niter_out, admm_stats* stats);
 
 /* Row-block consensus ADMM with `nthread` blocks (ParLasso.cpp:71-72: nthread only sets the
  * number of blocks K).  All K blocks run on the current device. */
-int admm_hip_parlasso(const double* x, const double* y, int n, int p, int mem,
+ADMM_HIP_API int admm_hip_parlasso(const double* x, const double* y, int n, int p, int mem,
                       const double* lambda_in, int nlambda_in, int nlambda_auto, double lmin_ratio,
                       int standardize, int intercept, int nthread, const admm_opts* opts,
                       double* lambda_out, float* beta_out, int* niter_out, admm_stats* stats);
 
 /* beta_out[p+1] (row 0 = intercept), niter_out[1]. Requires n > p (R/20_admm_lad.R:21-22). */
-int admm_hip_lad(const double* x, const double* y, int n, int p, int mem, int intercept,
+ADMM_HIP_API int admm_hip_lad(const double* x, const double* y, int n, int p, int mem, int intercept,
                  const admm_opts* opts, double* beta_out, int* niter_out, admm_stats* stats);
 
 /* beta_out[p], niter_out[1]. Requires p > n (R/10_admm_bp.R:30-31). */
-int admm_hip_bp(const double* x, const double* y, int n, int p, int mem,
+ADMM_HIP_API int admm_hip_bp(const double* x, const double* y, int n, int p, int mem,
                 const admm_opts* opts, double* beta_out, int* niter_out, admm_stats* stats);
 
 /* Prepared-problem variant of the Lasso family (the "persistent context" anticipated for a
@@ -123,12 +130,12 @@ int admm_hip_bp(const double* x, const double* y, int n, int p, int mem,
  * 0 <= alpha <= 1 the elastic net; nthread > 1 selects the consensus solver.
  * bench.py times run() only (ADMM iterations/s excludes the one-time setup). */
 typedef struct admm_hip_plan admm_hip_plan;
-int admm_hip_lasso_plan_create(const double* x, const double* y, int n, int p, int mem,
+ADMM_HIP_API int admm_hip_lasso_plan_create(const double* x, const double* y, int n, int p, int mem,
                                const double* lambda_in, int nlambda_in, int nlambda_auto, double lmin_ratio,
                                int standardize, int intercept, double alpha, int nthread, const admm_opts* opts,
                                admm_hip_plan** plan_out, int* nlambda_out);
-int admm_hip_lasso_plan_run(admm_hip_plan* plan, double* lambda_out, float* beta_out, int* niter_out, admm_stats* stats);
-int admm_hip_lasso_plan_destroy(admm_hip_plan* plan);
+ADMM_HIP_API int admm_hip_lasso_plan_run(admm_hip_plan* plan, double* lambda_out, float* beta_out, int* niter_out, admm_stats* stats);
+ADMM_HIP_API int admm_hip_lasso_plan_destroy(admm_hip_plan* plan);
 
 /* ---- one process per GPU: consensus Lasso with its row blocks spread over ranks (RCCL over xGMI).
  * Bootstrap: rank 0 calls admm_hip_comm_unique_id and ships the ADMM_HIP_UNIQUE_ID_BYTES bytes to the
@@ -141,24 +148,24 @@ int admm_hip_lasso_plan_destroy(admm_hip_plan* plan);
  * exchange ONE grouped all-reduce: the consensus sum (p floats) and three squared norms.  Every rank
  * returns the full result. */
 #define ADMM_HIP_UNIQUE_ID_BYTES 128
-int admm_hip_comm_unique_id(void* id_out);
-int admm_hip_comm_init(int nranks, int rank, const void* id);
-int admm_hip_comm_finalize(void);
-int admm_hip_parlasso_dist(const double* x_local, const double* y_local, int n_local, long long n_total, int p, int mem,
+ADMM_HIP_API int admm_hip_comm_unique_id(void* id_out);
+ADMM_HIP_API int admm_hip_comm_init(int nranks, int rank, const void* id);
+ADMM_HIP_API int admm_hip_comm_finalize(void);
+ADMM_HIP_API int admm_hip_parlasso_dist(const double* x_local, const double* y_local, int n_local, long long n_total, int p, int mem,
                            const double* lambda_in, int nlambda_in, int nlambda_auto, double lmin_ratio,
                            int standardize, int intercept, int nthread, const admm_opts* opts,
                            double* lambda_out, float* beta_out, int* niter_out, admm_stats* stats);
-int admm_hip_lasso_plan_create_dist(const double* x_local, const double* y_local, int n_local, long long n_total, int p, int mem,
+ADMM_HIP_API int admm_hip_lasso_plan_create_dist(const double* x_local, const double* y_local, int n_local, long long n_total, int p, int mem,
                                     const double* lambda_in, int nlambda_in, int nlambda_auto, double lmin_ratio,
                                     int standardize, int intercept, int nthread, const admm_opts* opts,
                                     admm_hip_plan** plan_out, int* nlambda_out);
 
-const char* admm_hip_last_error(void);
-const char* admm_hip_version(void);
-int admm_hip_device_count(void);
-int admm_hip_set_device(int device);
+ADMM_HIP_API const char* admm_hip_last_error(void);
+ADMM_HIP_API const char* admm_hip_version(void);
+ADMM_HIP_API int admm_hip_device_count(void);
+ADMM_HIP_API int admm_hip_set_device(int device);
 /* hipDeviceSynchronize on the current device (bench.py brackets its timed region with it). */
-int admm_hip_device_synchronize(void);
+ADMM_HIP_API int admm_hip_device_synchronize(void);
 
 #ifdef __cplusplus
 }
