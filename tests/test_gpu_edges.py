@@ -1,0 +1,81 @@
+"""GPU: edge cases through the C ABI vs the oracle -- minimal sizes, boundaries between solver branches,
+single-lambda grids, the n == p switch (Lasso.cpp:73 sends n == p to the wide solver)."""
+import numpy as np
+import pytest
+
+from helpers import relerr, synth_lasso
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def test_minimal_tall_needs_three_columns_for_the_lanczos_estimate():
+    """p = 3 is the smallest Gram the reference's ncv = 3 Lanczos accepts; p = 2 needs a user rho."""
+    from admm_amd import AdmmHipError, admm_lasso
+    from oracle import entry
+    rng = np.random.default_rng(1)
+    x, y = rng.standard_normal((12, 3)), rng.standard_normal(12)
+    fit = admm_lasso(x, y).penalty(0.05).fit()
+    ref = entry.admm_lasso(x, y, [0.05], 100, 1e-4, True, True, entry.LASSO_OPTS)
+    assert relerr(fit.beta_dense[:, 0], ref["beta"][:, 0]) < TOL
+    x2 = x[:, :2]
+    with pytest.raises(AdmmHipError) as ei:
+        admm_lasso(x2, y).penalty(0.05).fit()
+    assert ei.value.code == 6                                    # ADMM_ERR_EIGS (the reference throws std::invalid_argument)
+    fit = admm_lasso(x2, y).penalty(0.05).opts(rho=2.0).fit()
+    ref = entry.admm_lasso(x2, y, [0.05], 100, 1e-4, True, True, dict(entry.LASSO_OPTS, rho=2.0))
+    assert relerr(fit.beta_dense[:, 0], ref["beta"][:, 0]) < TOL
+
+
+def test_square_problem_takes_the_wide_solver():
+    from admm_amd import admm_lasso
+    from oracle import entry
+    x, y = synth_lasso(64, 64, 5, seed=9)
+    fit = admm_lasso(x, y).penalty([0.3, 0.1]).fit()
+    assert fit.stats["branch"] == 1
+    ref = entry.admm_lasso(x, y, [0.3, 0.1], 100, 1e-4, True, True, entry.LASSO_OPTS)
+    for j in range(2):
+        assert relerr(fit.beta_dense[:, j], ref["beta"][:, j]) < 5e-3   # wide solver: loose stopping rule (README +-2e-3)
+    assert np.abs(fit.niter.astype(int) - ref["niter"].astype(int)).max() <= max(3, int(0.05 * ref["niter"].max()))
+
+
+def test_single_auto_lambda_and_tiny_wide():
+    from admm_amd import admm_enet, admm_lasso
+    from oracle import entry
+    x, y = synth_lasso(7, 40, 3, seed=13)
+    fit = admm_lasso(x, y).penalty(nlambda=1).fit()              # one automatic lambda = lambda_max: null model
+    assert fit.beta_dense.shape == (41, 1) and np.count_nonzero(fit.beta_dense[1:, 0]) == 0
+    fit = admm_enet(x, y).penalty([0.2], alpha=0.3).fit()
+    ref = entry.admm_enet(x, y, [0.2], 100, 0.01, True, True, 0.3, entry.LASSO_OPTS)
+    assert relerr(fit.beta_dense[:, 0], ref["beta"][:, 0]) < 5e-3
+
+
+def test_parallel_block_limits_and_single_block():
+    from admm_amd import admm_lasso
+    from oracle import entry
+    x, y = synth_lasso(300, 26, 4, seed=17)
+    for K in (1, 5):                                             # 5 < 26 / 5: the largest nthread $parallel() accepts here
+        m = admm_lasso(x, y).penalty([0.2]).opts(maxit=3000)
+        m.nthread = K
+        lib = __import__("admm_amd")._lib.load()
+        fit = m.fit() if K > 1 else None
+        ref = entry.admm_parlasso(x, y, [0.2], 100, 1e-4, True, True, K, dict(entry.LASSO_OPTS, maxit=3000))
+        if fit is not None:
+            assert relerr(fit.beta_dense[:, 0], ref["beta"][:, 0]) < 2 * TOL
+            assert abs(int(fit.niter[0]) - int(ref["niter"][0])) <= max(3, int(0.03 * ref["niter"][0]))
+
+
+def test_lad_and_bp_minimal_shapes():
+    from admm_amd import admm_bp, admm_lad
+    from oracle import entry
+    rng = np.random.default_rng(23)
+    x = rng.standard_normal((9, 8))
+    y = rng.standard_normal(9)
+    fit = admm_lad(x, y).fit()                                   # n = p + 1
+    ref = entry.admm_lad(x, y, True, entry.LAD_OPTS)
+    assert relerr(fit.beta, ref["beta"]) < 1e-3
+    a = rng.standard_normal((1, 6))
+    b = a @ np.array([0.0, 2.0, 0, 0, 0, 0])
+    fit = admm_bp(a, b).fit()                                    # a single equation
+    ref = entry.admm_bp(a, b, entry.BP_OPTS)
+    assert relerr(np.asarray(fit.beta.todense()).ravel(), ref["beta"]) < 1e-3
