@@ -14,6 +14,7 @@
 #pragma once
 #include "admm_internal.h"
 #include "device_utils.h"
+#include "gemv_plan.h"
 #include <hip/hip_ext.h>
 
 namespace admm {
@@ -130,13 +131,6 @@ gemv_t_kernel(GemvTArgs<T> a, Extra extra) {
         }
     }
 }
-
-// Launch geometry for gemv_t: picks the row segmentation and the column blocking so that the
-// grid is about `wg_per_cu` workgroups per CU, each with whole multiples of 4 column groups.
-struct GemvTPlan {
-    int seg_len = 0, seg_alloc = 0, nseg = 0, groups_per_wg = 0, num_cb = 0, grid = 0;
-    size_t lds_bytes = 0;
-};
 
 template <typename T>
 inline GemvTPlan plan_gemv_t(int m, int k, int nrhs, int C, int max_seg_rows = 0, int wg_per_cu = 4) {

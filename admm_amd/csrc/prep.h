@@ -2,6 +2,7 @@
 // (the DataStd step of the reference), Gram matrices, Cholesky + cached inverse, Lanczos.
 #pragma once
 #include "admm_internal.h"
+#include "gemv_plan.h"
 #include <functional>
 
 namespace admm {
@@ -64,6 +65,7 @@ template <typename T>
 struct SymMatVec {
     const T* A; long long lda; int n; hipStream_t st;
     DevBuf<T> dv, dw, part;
+    GemvTPlan pl; long long stride = 0;
     SymMatVec(const T* A_, long long lda_, int n_, hipStream_t st_);
     void operator()(const T* v_host, T* w_host);
 };

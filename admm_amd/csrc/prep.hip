@@ -136,6 +136,7 @@ apply_std_kernel(T* __restrict__ X, long long ldx, T* __restrict__ Y, int n, int
 template <typename T>
 void upload_standardize(DeviceData<T>& d, const double* x, const double* y, int n, int p, int mem,
                         bool standardize, bool intercept, hipStream_t st, long long n_total) {
+    const bool dist = n_total > 0;          // only the multi-process entry points pass n_total: all ranks are in this call
     if (n_total <= 0) n_total = n;
     d.n = n; d.p = p; d.n_total = n_total;
     d.flag = int(standardize) + 2 * int(intercept);
@@ -188,10 +189,10 @@ void upload_standardize(DeviceData<T>& d, const double* x, const double* y, int 
         DevBuf<double> stat(cnt);
         DevBuf<T> mean(cnt), scale(cnt), inv(cnt);
         hipLaunchKernelGGL((colstat_kernel<T, 0>), dim3(cnt), dim3(256), 0, st, d.X.get(), d.ldx, d.Y.get(), n, p, mean.get(), stat.get());
-        allreduce_sum_f64(stat.get(), cnt, st);
+        if (dist) allreduce_sum_f64(stat.get(), cnt, st);
         hipLaunchKernelGGL((finish_mean_kernel<T>), dim3((cnt + 255) / 256), dim3(256), 0, st, stat.get(), (double)n_total, cnt, mean.get());
         hipLaunchKernelGGL((colstat_kernel<T, 1>), dim3(cnt), dim3(256), 0, st, d.X.get(), d.ldx, d.Y.get(), n, p, mean.get(), stat.get());
-        allreduce_sum_f64(stat.get(), cnt, st);
+        if (dist) allreduce_sum_f64(stat.get(), cnt, st);
         hipLaunchKernelGGL((finish_scale_kernel<T>), dim3((cnt + 255) / 256), dim3(256), 0, st, stat.get(), (double)n_total, cnt, scale.get(), inv.get());
         hipLaunchKernelGGL((apply_std_kernel<T>), dim3(cnt, ny), dim3(256), 0, st, d.X.get(), d.ldx, d.Y.get(), n, p, d.flag,
                            mean.get(), scale.get(), inv.get());
@@ -446,11 +447,15 @@ SymMatVec<T>::SymMatVec(const T* A_, long long lda_, int n_, hipStream_t st_) : 
     dv.alloc(round_up(n, 32));
     dw.alloc(round_up(n, 32));
     dv.zero(st);
+    pl = plan_gemv_t<T>(n, n, 1, 4);
+    stride = round_up(n, 32);
+    part.alloc((size_t)pl.nseg * stride);               // allocated once: no hipMalloc per mat-vec
 }
 template <typename T>
 void SymMatVec<T>::operator()(const T* v_host, T* w_host) {
     ADMM_HIP_CHECK(hipMemcpyAsync(dv.get(), v_host, (size_t)n * sizeof(T), hipMemcpyHostToDevice, st));
-    gemv_t_simple<T>(A, lda, n, n, dv.get(), dw.get(), st);
+    launch_gemv_t<T, 1, 4>(pl, A, lda, n, n, dv.get(), nullptr, part.get(), nullptr, stride, nullptr, st);
+    hipLaunchKernelGGL((reduce_partials_kernel<T>), dim3((n + 255) / 256), dim3(256), 0, st, part.get(), stride, pl.nseg, n, dw.get(), (const int*)nullptr);
     ADMM_HIP_CHECK(hipMemcpyAsync(w_host, dw.get(), (size_t)n * sizeof(T), hipMemcpyDeviceToHost, st));
     ADMM_HIP_CHECK(hipStreamSynchronize(st));
 }

@@ -18,7 +18,8 @@
 //   Gram:      Z = X' (one transpose pass), C = Z Z', lower tiles + mirrored store (both triangles).
 //   Cholesky:  right-looking on 128-blocks: potf2_inv (one workgroup, in LDS: L_kk and L_kk^-1),
 //              panel L_ik = A_ik L_kk^-T (in place), trailing A_ij -= L_ik L_jk' (lower tiles).
-//   Inverse:   U = L^-T built row block by row block with two NT products per block, then
+//   Inverse:   the same block loop eliminates [L | I] right-looking (W_k <- L_kk^-1 W_k, W_i -= L_ik W_k),
+//              stored transposed (U = L^-T) so that both updates are NT products over many tiles; then
 //              (X'X + rho I)^-1 = U U' (lower tiles + mirror; products start at k = tile row since
 //              U is upper triangular).
 // No rocBLAS / rocSOLVER on this path (their handle creation alone costs 0.1-0.2 s per process).
@@ -248,13 +249,9 @@ potf2_inv_kernel(float* __restrict__ A, long long lda, int nbk, float* __restric
     }
 }
 
-// U_ii = (L_ii^-1)' for block i (upper triangular), masked to the valid size
-__global__ void __launch_bounds__(256)
-put_diag_transposed_kernel(const float* __restrict__ Dinv, float* __restrict__ U, long long ldu, int nbk) {
-    for (int idx = threadIdx.x; idx < 128 * 128; idx += 256) {
-        const int r = idx & 127, c = idx >> 7;
-        if (r < nbk && c < nbk) U[(size_t)c * ldu + r] = Dinv[(size_t)r * 128 + c];
-    }
+__global__ void set_identity_kernel(float* U, long long ldu, int p) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < p) U[(size_t)i * ldu + i] = 1.f;
 }
 
 // In place: A (p x p, SPD, lower triangle valid, leading dimension lda >= round_up(p, 128), allocation of
@@ -263,26 +260,34 @@ void spd_inverse_mfma_f32(float* A, long long lda, int p, hipStream_t st) {
     const int nb = (p + SK_BM - 1) / SK_BM;
     const int pp = nb * SK_BM;
     ADMM_REQUIRE(lda >= pp, "spd_inverse_mfma_f32: leading dimension must cover whole 128-row blocks");
-    DevBuf<float> Dinv((size_t)nb * 128 * 128), U((size_t)lda * pp), T2((size_t)lda * 128);
+    DevBuf<float> Dinv((size_t)nb * 128 * 128), U((size_t)lda * pp);
     DevBuf<int> info(1);
-    info.zero(st); U.zero(st); T2.zero(st);
+    info.zero(st); U.zero(st);
     const size_t lds_pf = ((size_t)2 * 128 * PF_LD + 128) * sizeof(float);
     ADMM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(potf2_inv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pf));
-    // ---- right-looking blocked Cholesky
+    // ---- right-looking blocked Cholesky, fused with the right-looking block elimination of [L | I]:
+    // at block step k   W_k <- L_kk^-1 W_k ;  W_i -= L_ik W_k (i > k),   stored transposed (U = W' = L^-T) so that
+    // every update is an NT product with K = 128 over many tiles (no serial triangular-inverse sweep).
+    hipLaunchKernelGGL(set_identity_kernel, dim3((p + 255) / 256), dim3(256), 0, st, U.get(), lda, p);
     for (int k = 0; k < nb; ++k) {
         const int r0 = k * SK_BM;
         const int nbk = std::min(SK_BM, p - r0);
         float* Akk = A + (size_t)r0 * lda + r0;
         float* Dk = Dinv.get() + (size_t)k * 128 * 128;
         hipLaunchKernelGGL(potf2_inv_kernel, dim3(1), dim3(PF_THREADS), lds_pf, st, Akk, lda, nbk, Dk, info.get(), r0);
+        float* Ukb = U.get() + (size_t)r0 * lda;                               // column block k of U, rows 0 .. r0 + nbk
+        // U[:, k] <- U[:, k] L_kk^-T   (in place: a tile only reads its own rows)
+        launch_gemm_nt(false, Ukb, lda, Dk, 128, Ukb, lda, r0 + nbk, nbk, 128, 1.f, 0.f, false, false, st);
         const int M = p - (r0 + SK_BM);
         if (M > 0) {
             float* Apan = A + (size_t)r0 * lda + r0 + SK_BM;                   // rows below the diagonal block, its 128 columns
-            // L_ik = A_ik L_kk^-T : C[i, j] = sum_t A_ik[i, t] Linv[j, t]; in place (a tile only reads its own rows)
+            // L_ik = A_ik L_kk^-T : C[i, j] = sum_t A_ik[i, t] Linv[j, t]; in place
             launch_gemm_nt(false, Apan, lda, Dk, 128, Apan, lda, M, nbk, 128, 1.f, 0.f, false, false, st);
             // A_ij -= L_ik L_jk' on the lower tiles of the trailing matrix
             float* Atr = A + (size_t)(r0 + SK_BM) * lda + r0 + SK_BM;
             launch_gemm_nt(true, Apan, lda, Apan, lda, Atr, lda, M, M, 128, -1.f, 1.f, false, false, st);
+            // U[:, i] -= U[:, k] L_ik'  for all row blocks i > k at once
+            launch_gemm_nt(false, Ukb, lda, Apan, lda, U.get() + (size_t)(r0 + SK_BM) * lda, lda, r0 + SK_BM, M, 128, -1.f, 1.f, false, false, st);
         }
     }
     {
@@ -290,20 +295,6 @@ void spd_inverse_mfma_f32(float* A, long long lda, int p, hipStream_t st) {
         ADMM_HIP_CHECK(hipMemcpyAsync(&h, info.get(), sizeof(int), hipMemcpyDeviceToHost, st));
         ADMM_HIP_CHECK(hipStreamSynchronize(st));
         if (h != 0) throw Error(ADMM_ERR_NOT_SPD, "Cholesky: matrix is not positive definite (pivot " + std::to_string(h) + ")");
-    }
-    // ---- U = L^-T, row block by row block of W = L^-1 (stored transposed)
-    for (int i = 0; i < nb; ++i) {
-        const int r0 = i * SK_BM;
-        const int nbk = std::min(SK_BM, p - r0);
-        const float* Di = Dinv.get() + (size_t)i * 128 * 128;
-        hipLaunchKernelGGL(put_diag_transposed_kernel, dim3(1), dim3(256), 0, st, Di, U.get() + (size_t)r0 * lda + r0, lda, nbk);
-        if (i > 0) {
-            const int K = r0;
-            // T2'[j, r] = sum_k U[j, k] L[r0 + r, k]   (U upper triangular: start at k = tile row)
-            launch_gemm_nt(false, U.get(), lda, A + r0, lda, T2.get(), lda, K, nbk, K, 1.f, 0.f, false, true, st);
-            // U[j, r0 + r] = - sum_k T2'[j, k] Linv_ii[r, k]
-            launch_gemm_nt(false, T2.get(), lda, Di, 128, U.get() + (size_t)r0 * lda, lda, K, nbk, 128, -1.f, 0.f, false, false, st);
-        }
     }
     // ---- A^-1 = L^-T L^-1 = U U'  (both triangles)
     launch_gemm_nt(true, U.get(), lda, U.get(), lda, A, lda, p, p, pp, 1.f, 0.f, true, true, st);
