@@ -57,9 +57,16 @@ class ADMM_Lasso_fit:
     def __init__(self, lam, beta_dense, niter, stats):
         self.lambda_ = lam
         self.beta_dense = beta_dense
-        self.beta = _beta_to_csc(beta_dense)
+        self._beta = None
         self.niter = niter
         self.stats = stats
+
+    @property
+    def beta(self):
+        """dgCMatrix-like CSC, built on first use."""
+        if self._beta is None:
+            self._beta = _beta_to_csc(self.beta_dense)
+        return self._beta
 
     def __repr__(self):
         return (f"ADMM Lasso fitting result\n\n$lambda\n{self.lambda_}\n\n$beta\n<{self.beta.shape[0]} x "
