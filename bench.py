@@ -97,10 +97,23 @@ def cpu_baseline(p, nlambda, budget_s, seed):
         nl += 1
         if t_loop > budget_s:
             break
-    return {"value": iters / t_loop, "unit": "iterations/s", "cores": int(cores), "kind": "port",
+    # the reference itself runs this loop on ONE core (EIGEN_DONT_PARALLELIZE, Lasso.cpp:1): time a few more
+    # iterations with the BLAS pool limited to 1 thread
+    one_core = None
+    try:
+        from threadpoolctl import threadpool_limits
+        with threadpool_limits(limits=1):
+            solver.init_warm(lam[min(nl, nlambda - 1)] * n_s / np.float64(std.scaleY))
+            t1 = time.time()
+            it1 = solver.solve(60)
+            one_core = min(it1, 60) / (time.time() - t1)
+    except Exception:
+        pass
+    return {"value": iters / t_loop, "unit": "iterations/s", "cores": int(cores), "kind": "port", "value_1core": one_core,
             "sample": f"oracle LassoTall (NumPy float32, LAPACK spotrf + 2 strtrs per iteration), p={p}, "
                       f"n_sample={n_s} rows (per-iteration cost depends on p only), first {nl} of {nlambda} lambdas, "
-                      f"{iters} iterations in {t_loop:.1f} s; CPU setup (Gram+Lanczos+Cholesky) {t_setup:.1f} s"}
+                      f"{iters} iterations in {t_loop:.1f} s; CPU setup (Gram+Lanczos+Cholesky) {t_setup:.1f} s; "
+                      f"value_1core = same loop with the BLAS pool limited to one thread (<= 60 iterations)"}
 
 
 def consensus_child(a):
@@ -178,6 +191,9 @@ def run_consensus_side_measurement(a, rank, world):
     if world > 1:
         env["MASTER_ADDR"] = "127.0.0.1"
         env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 17)
+        # the children build their OWN rendezvous store on that port: do not let env:// look for torchrun's agent store there
+        for k in [k for k in env if k.startswith("TORCHELASTIC_")]:
+            env.pop(k)
     cmd = [sys.executable, os.path.abspath(__file__), "--consensus-child", out_path, "--seed", str(a.seed)]
     try:
         r = subprocess.run(cmd, env=env, timeout=a.consensus_seconds, capture_output=True, text=True)
