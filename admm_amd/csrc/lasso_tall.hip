@@ -134,6 +134,55 @@ struct TallDecideExtra {
     __device__ void operator()() const { tall_decide(q, par); }
 };
 
+// State of one coordinate and its update: everything after x = a + tau b in one iteration
+// (next_z, residual, dual update, norms, right-hand sides of the next x-update).
+struct TallElem { float zc, yc, zo, yo, adjz, adjy, x, xy; };
+
+__device__ __forceinline__ TallElem tall_load_elem(const TallParams& q, int par, int i) {
+    const float* zc_ = par ? q.z1 : q.z0; const float* yc_ = par ? q.y1 : q.y0;
+    const float* zo_ = par ? q.z0 : q.z1; const float* yo_ = par ? q.y0 : q.y1;
+    TallElem e;
+    e.zc = zc_[i]; e.yc = yc_[i]; e.zo = zo_[i]; e.yo = yo_[i]; e.adjz = q.adj_z[i]; e.adjy = q.adj_y[i]; e.x = q.x[i]; e.xy = q.XY[i];
+    return e;
+}
+
+__device__ __forceinline__ void tall_update_elem(const TallParams& q, const TallCtl& c, int par, int i, const TallElem& e, float a, float b, double (&acc)[6]) {
+    float* zo_ = par ? q.z0 : q.z1; float* yo_ = par ? q.y0 : q.y1;
+    const float zc = e.zc, yc = e.yc, zo = e.zo, yo = e.yo;
+    if (c.fin_idx >= 0) q.beta[(size_t)c.fin_idx * q.p + i] = zc;     // get_z() snapshot (Lasso.cpp:108)
+    if (c.done) return;
+    float adjz, adjy, x;
+    if (c.mode) {
+        if (c.restart) { adjz = zo; adjy = yo; x = a - b; }
+        else {
+            const float t = (float)c.tau, t1 = (float)(1.0 + c.tau);
+            adjz = t1 * zc - t * zo;           // (1 + ratio) * aux_z - ratio * old_z   FADMMBase.h:247-248
+            adjy = t1 * yc - t * yo;
+            x = a + t * b;
+        }
+    } else { adjz = e.adjz; adjy = e.adjy; x = e.x; }
+    const float rho_f = (float)c.rho;
+    const float vec = x + adjy / rho_f;        // next_z: main_x + adj_y / rho            ADMMLassoTall.h:83
+    const double pen = c.lam / c.rho;
+    float zn;
+    if (!q.enet) {                             // soft_threshold, double compare          ADMMLassoTall.h:55-69
+        const double v = (double)vec;
+        zn = v > pen ? (float)(v - pen) : (v < -pen ? (float)(v + pen) : 0.f);
+    } else {                                   // enet()                                  ADMMEnet.h:24-40
+        const float thresh = (float)(q.alpha * pen);
+        const float denom = (float)(1.0 + pen * (1.0 - q.alpha));
+        zn = vec > thresh ? (vec - thresh) / denom : (vec < -thresh ? (vec + thresh) / denom : 0.f);
+    }
+    const float r = x - zn;                    // next_residual                            ADMMLassoTall.h:86-95
+    const float yn = adjy + rho_f * r;         // dual_y = adj_y + rho * newr              FADMMBase.h:210
+    const float dz = zn - zc, daz = zn - adjz;
+    acc[0] = (double)r * r; acc[1] = (double)dz * dz; acc[2] = (double)daz * daz;
+    acc[3] = (double)x * x; acc[4] = (double)zn * zn; acc[5] = (double)yn * yn;
+    q.x[i] = x; zo_[i] = zn; yo_[i] = yn; q.adj_z[i] = adjz; q.adj_y[i] = adjy;
+    q.u[i] = (float)((double)(e.xy - yn) + c.rho * (double)zn);
+    q.w[i] = (float)((double)(yc - yn) + c.rho * (double)dz);
+}
+
 // Element-wise part of one iteration.  `c` = the control block published by this iteration's decision.
 template <bool SYM>
 __global__ void __launch_bounds__(kTailThreads)
@@ -146,11 +195,8 @@ tall_tail_kernel(TallParams q, int par) {
     const int i = blockIdx.x * kTailElems + threadIdx.x / kTailLanes;
     const bool valid = i < q.p;
     const bool owner = valid && sub == 0;
-    const int cur = par;                               // buffer holding the current z / y
-    const float* zc_ = cur ? q.z1 : q.z0; const float* yc_ = cur ? q.y1 : q.y0;
-    float* zo_ = cur ? q.z0 : q.z1;       float* yo_ = cur ? q.y0 : q.y1;
-    float zc = 0.f, yc = 0.f, zo = 0.f, yo = 0.f, adjz_st = 0.f, adjy_st = 0.f, x_st = 0.f, xy = 0.f;
-    if (owner) { zc = zc_[i]; yc = yc_[i]; zo = zo_[i]; yo = yo_[i]; adjz_st = q.adj_z[i]; adjy_st = q.adj_y[i]; x_st = q.x[i]; xy = q.XY[i]; }
+    TallElem e = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (owner) e = tall_load_elem(q, par, i);
     // ---- x-update results a = Minv u, b = Minv w: kTailLanes lanes share one element and issue all
     // their partial loads at once, then combine with shuffles.
     float a = 0.f, b = 0.f;
@@ -185,41 +231,7 @@ tall_tail_kernel(TallParams q, int par) {
     if (c.done && c.fin_idx < 0) return;
 
     double acc[6] = {0, 0, 0, 0, 0, 0};
-    if (owner) {
-        if (c.fin_idx >= 0) q.beta[(size_t)c.fin_idx * q.p + i] = zc;     // get_z() snapshot (Lasso.cpp:108)
-        if (!c.done) {
-            float adjz, adjy, x;
-            if (c.mode) {
-                if (c.restart) { adjz = zo; adjy = yo; x = a - b; }
-                else {
-                    const float t = (float)c.tau, t1 = (float)(1.0 + c.tau);
-                    adjz = t1 * zc - t * zo;           // (1 + ratio) * aux_z - ratio * old_z   FADMMBase.h:247-248
-                    adjy = t1 * yc - t * yo;
-                    x = a + t * b;
-                }
-            } else { adjz = adjz_st; adjy = adjy_st; x = x_st; }
-            const float rho_f = (float)c.rho;
-            const float vec = x + adjy / rho_f;        // next_z: main_x + adj_y / rho            ADMMLassoTall.h:83
-            const double pen = c.lam / c.rho;
-            float zn;
-            if (!q.enet) {                             // soft_threshold, double compare          ADMMLassoTall.h:55-69
-                const double v = (double)vec;
-                zn = v > pen ? (float)(v - pen) : (v < -pen ? (float)(v + pen) : 0.f);
-            } else {                                   // enet()                                  ADMMEnet.h:24-40
-                const float thresh = (float)(q.alpha * pen);
-                const float denom = (float)(1.0 + pen * (1.0 - q.alpha));
-                zn = vec > thresh ? (vec - thresh) / denom : (vec < -thresh ? (vec + thresh) / denom : 0.f);
-            }
-            const float r = x - zn;                    // next_residual                            ADMMLassoTall.h:86-95
-            const float yn = adjy + rho_f * r;         // dual_y = adj_y + rho * newr              FADMMBase.h:210
-            const float dz = zn - zc, daz = zn - adjz;
-            acc[0] = (double)r * r; acc[1] = (double)dz * dz; acc[2] = (double)daz * daz;
-            acc[3] = (double)x * x; acc[4] = (double)zn * zn; acc[5] = (double)yn * yn;
-            q.x[i] = x; zo_[i] = zn; yo_[i] = yn; q.adj_z[i] = adjz; q.adj_y[i] = adjy;
-            q.u[i] = (float)((double)(xy - yn) + c.rho * (double)zn);
-            q.w[i] = (float)((double)(yc - yn) + c.rho * (double)dz);
-        }
-    }
+    if (owner) tall_update_elem(q, c, par, i, e, a, b, acc);
     if (c.done) return;
     block_sum<double, 6>(acc, scratch);
     if (threadIdx.x == 0) {
@@ -265,8 +277,15 @@ struct TallPlan final : LassoPlan {
     DevBuf<TallCtl> ctl;
     TallParams q{};
     TallCtl* hctl = nullptr;
+    float* hbeta = nullptr;                             // pinned landing buffer of the beta snapshots (nlam x p)
 
-    ~TallPlan() override { if (hctl) (void)hipHostFree(hctl); }
+    std::vector<hipEvent_t> ev_pool;                    // start/stop events of sampled x-update launches, reused by every run()
+
+    ~TallPlan() override {
+        if (hctl) (void)hipHostFree(hctl);
+        if (hbeta) (void)hipHostFree(hbeta);
+        for (auto e : ev_pool) (void)hipEventDestroy(e);
+    }
 
     TallPlan(DeviceData<float>&& data, const LassoProblem& prob, hipStream_t stream) : d(std::move(data)), pb(prob), st(stream) {
         const int n = d.n;
@@ -350,6 +369,7 @@ struct TallPlan final : LassoPlan {
 
         // Pinned mirror of the control block for asynchronous polling.
         ADMM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&hctl), 2 * sizeof(TallCtl), hipHostMallocDefault));
+        ADMM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&hbeta), (size_t)nlam * p * sizeof(float), hipHostMallocDefault));
         ADMM_HIP_CHECK(hipStreamSynchronize(st));
     }
 
@@ -365,8 +385,7 @@ struct TallPlan final : LassoPlan {
 
         const int batch = pb.batch_iters > 0 ? (pb.batch_iters + 1) / 2 * 2 : 32;    // even
         const int stride = pb.profile_stride;                          // sample every stride-th x-update with events
-        std::vector<hipEvent_t> evs;
-        struct EvFree { std::vector<hipEvent_t>* v; ~EvFree() { for (auto e : *v) (void)hipEventDestroy(e); } } ef{&evs};
+        size_t nev = 0;                                                // events of ev_pool used by this run
         Event ev_loop0, ev_loop1, ev_poll[2];
 
         ADMM_HIP_CHECK(hipStreamSynchronize(st));
@@ -377,22 +396,27 @@ struct TallPlan final : LassoPlan {
         auto enqueue_batch = [&](int slot) {
             for (int k = 0; k < batch; ++k, ++g) {
                 const int par = (int)(g & 1);
-                const bool sample = stride > 0 && (g % stride) == 0 && evs.size() < 8192;
+                const bool sample = stride > 0 && (g % stride) == 0 && nev < 8192;
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (sample) {
-                    ADMM_HIP_CHECK(hipEventCreate(&e0)); ADMM_HIP_CHECK(hipEventCreate(&e1));
-                    evs.push_back(e0); evs.push_back(e1);
+                    while (ev_pool.size() < nev + 2) {
+                        hipEvent_t e; ADMM_HIP_CHECK(hipEventCreate(&e));
+                        ev_pool.push_back(e);
+                    }
+                    e0 = ev_pool[nev]; e1 = ev_pool[nev + 1];
+                    nev += 2;
                 }
                 // sampled launches carry start/stop events that time exactly the x-update kernel on this stream
+                // the decision of this iteration rides along as one extra workgroup of the x-update launch
+                const TallDecideExtra dec{q, par};
                 if (use_sym) {
-                    // the decision of this iteration rides along as one extra workgroup of the x-update launch
-                    sy.launch(M.get(), ldp, u.get(), w.get(), &ctl.get()[par].done, st, TallDecideExtra{q, par}, e0, e1);
+                    sy.launch(M.get(), ldp, u.get(), w.get(), &ctl.get()[par].done, st, dec, e0, e1);
+                    hipLaunchKernelGGL(tall_tail_kernel<true>, dim3(nwg), dim3(kTailThreads), 0, st, q, par);
                 } else {
                     launch_gemv_t<float, 2, 4, TallDecideExtra>(pl, M.get(), ldp, p, p, u.get(), w.get(), a_part.get(), b_part.get(), ldp,
-                                                                &ctl.get()[par].done, st, TallDecideExtra{q, par}, e0, e1);
+                                                                &ctl.get()[par].done, st, dec, e0, e1);
+                    hipLaunchKernelGGL(tall_tail_kernel<false>, dim3(nwg), dim3(kTailThreads), 0, st, q, par);
                 }
-                if (use_sym) hipLaunchKernelGGL(tall_tail_kernel<true>, dim3(nwg), dim3(kTailThreads), 0, st, q, par);
-                else hipLaunchKernelGGL(tall_tail_kernel<false>, dim3(nwg), dim3(kTailThreads), 0, st, q, par);
                 ++launches;
             }
             // after an even number of iterations the freshest control block is slot g&1 == 0
@@ -416,27 +440,27 @@ struct TallPlan final : LassoPlan {
         ADMM_HIP_CHECK(hipEventElapsedTime(&ms, ev_loop0.e, ev_loop1.e));
         S.loop_ms_events = ms;
         S.xupdate_launches = launches;
-        if (!evs.empty()) {
+        if (nev > 0) {
             double tot = 0;
-            for (size_t k = 0; k + 1 < evs.size(); k += 2) {
+            for (size_t k = 0; k + 1 < nev; k += 2) {
                 float m1 = 0.f;
-                ADMM_HIP_CHECK(hipEventElapsedTime(&m1, evs[k], evs[k + 1]));
+                ADMM_HIP_CHECK(hipEventElapsedTime(&m1, ev_pool[k], ev_pool[k + 1]));
                 tot += m1;
             }
-            S.xupdate_samples = (long long)(evs.size() / 2);
-            S.xupdate_ms_avg = tot / (double)(evs.size() / 2);
+            S.xupdate_samples = (long long)(nev / 2);
+            S.xupdate_ms_avg = tot / (double)(nev / 2);
         }
 
         // ---- results: niter, beta on the original scale (DataStd::recover, Lasso.cpp:108-111)
         res.niter.assign(nlam, 0);
         ADMM_HIP_CHECK(hipMemcpy(res.niter.data(), niter.get(), nlam * sizeof(int), hipMemcpyDeviceToHost));
-        std::vector<float> hb((size_t)nlam * p);
-        ADMM_HIP_CHECK(hipMemcpy(hb.data(), beta.get(), hb.size() * sizeof(float), hipMemcpyDeviceToHost));
+        ADMM_HIP_CHECK(hipMemcpyAsync(hbeta, beta.get(), (size_t)nlam * p * sizeof(float), hipMemcpyDeviceToHost, st));
+        ADMM_HIP_CHECK(hipStreamSynchronize(st));
         res.beta.assign((size_t)(p + 1) * nlam, 0.f);
         long long tot_it = 0;
         for (int l = 0; l < nlam; ++l) {
             float b0 = 0.f;
-            recover_coef<float>(d, hb.data() + (size_t)l * p, &b0, res.beta.data() + (size_t)l * (p + 1) + 1);
+            recover_coef<float>(d, hbeta + (size_t)l * p, &b0, res.beta.data() + (size_t)l * (p + 1) + 1);
             res.beta[(size_t)l * (p + 1)] = b0;
             tot_it += res.niter[l];
         }

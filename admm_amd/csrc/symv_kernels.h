@@ -15,6 +15,14 @@
 //     y_i = sum_{rb >= cb(i)/2} dot[rb][i] + sum_{cb <= 2 rb(i) + 1} axp[cb][i].
 // Deterministic (no atomics).  Partial traffic: (p/256 + p/128) * p * 8 bytes per launch, written
 // once and read once (about 9 % of the triangle at p = 10^4).
+//
+// Measured and rejected (scripts/symv_tune.hip, scripts/symv_check.hip, in-situ A/B of the tall loop):
+//  * packing the triangle tile by tile (each 128 KB tile contiguous): +-2..6 % depending on p, -1 % in the
+//    loop at p = 10^4;
+//  * fusing the consumer into this launch ("last tile of a block finalises it", arrival counters): correct,
+//    but cross-XCD visibility needs either agent-scope fences (whole-L2 write-back per wave: 5x slower) or
+//    uncached partial arrays plus an acknowledged-store wait and an atomic round trip per tile (1.65x slower
+//    than two launches).
 #pragma once
 #include "admm_internal.h"
 #include "device_utils.h"
@@ -75,6 +83,7 @@ symv2_lower_kernel(SymvArgs a, Extra extra) {
     if (blockIdx.x == 0) { extra(); return; }
     if (a.skip != nullptr && *a.skip != 0) return;
     __shared__ float4 red[2][kSyThreads];
+    __shared__ float sdot[2][kSyCB];
     const int2 t = a.tiles[blockIdx.x - 1];
     const int rb = t.x, cb = t.y;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -129,15 +138,15 @@ symv2_lower_kernel(SymvArgs a, Extra extra) {
             const float du = butterfly8(dU, lane);
             const float dw = butterfly8(dW, lane);
             if ((lane & 7) == 0) {
-                const int col = col0 + q * 8 + (lane >> 3);
-                if (col < a.p) {
-                    a.dot0[(size_t)rb * a.ldo + col] = du;
-                    a.dot1[(size_t)rb * a.ldo + col] = dw;
-                }
+                sdot[0][wid * kSyCW + q * 8 + (lane >> 3)] = du;
+                sdot[1][wid * kSyCW + q * 8 + (lane >> 3)] = dw;
             }
         }
+    } else if (lane < kSyCW) {
+        sdot[0][wid * kSyCW + lane] = 0.f;
+        sdot[1][wid * kSyCW + lane] = 0.f;
     }
-    // axpy part: add the 4 waves (same rows, different columns)
+    // axpy part: add the 4 waves (same rows, different columns); dot part: one 512-byte row per array
     red[0][threadIdx.x] = aU;
     red[1][threadIdx.x] = aW;
     __syncthreads();
@@ -150,6 +159,9 @@ symv2_lower_kernel(SymvArgs a, Extra extra) {
         }
         float* dst = (wid == 0 ? a.axp0 : a.axp1) + (size_t)cb * a.ldo + row;
         *reinterpret_cast<float4*>(dst) = s;
+    } else {
+        float* dst = (wid == 2 ? a.dot0 : a.dot1) + (size_t)rb * a.ldo + cb * kSyCB + lane * 2;      // < ncb * 128 <= ldo
+        *reinterpret_cast<float2*>(dst) = make_float2(sdot[wid - 2][lane * 2], sdot[wid - 2][lane * 2 + 1]);
     }
 }
 

@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--nlambda", type=int, default=100)
     ap.add_argument("--seed", type=int, default=123)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline loop (0 disables)")
-    ap.add_argument("--profile-stride", type=int, default=8, help="time every k-th x-update launch with HIP events")
+    ap.add_argument("--profile-stride", type=int, default=32, help="time every k-th x-update launch with HIP events")
     ap.add_argument("--consensus-seconds", type=float, default=240.0,
                     help="time limit of the side measurement of the consensus solver (0 disables it)")
     ap.add_argument("--consensus-child", default="", help=argparse.SUPPRESS)
