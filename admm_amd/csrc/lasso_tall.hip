@@ -8,16 +8,21 @@
 //  * rho is fixed along the whole path (ADMMLassoTall.h:97, init only at i == 0), so the
 //    Cholesky solve of (X'X + rho I) is replaced by ONE cached symmetric inverse Minv (p x p
 //    fp32, 4p^2 bytes) and the x-update becomes a bandwidth-bound dense mat-vec.
-//  * Goldstein acceleration/restart makes the right-hand side depend on a scalar decided from
-//    global norms.  Both branches are affine in one scalar tau:
-//        adj_z = z + tau (z - z_old), adj_y = y + tau (y - y_old)   (tau = (a-1)/a'  or  -1 on restart)
-//        rhs   = X'y - adj_y + rho adj_z = u + tau w,
-//        u = X'y - y + rho z,   w = -(y - y_old) + rho (z - z_old).
-//    The x-update kernel therefore streams Minv ONCE against the pair (u, w) and produces
-//    a = Minv u, b = Minv w; the tail kernel forms x = a + tau b.  The scalar decision itself
-//    (norm reduction, convergence, acceleration/restart, lambda schedule) runs as ONE EXTRA
-//    WORKGROUP of the x-update launch, concurrently with the streaming workgroups.  No host round
-//    trip, no grid barrier, no atomics: two launches per ADMM iteration.
+//  * Goldstein acceleration/restart makes the right-hand side depend on a decision taken from
+//    global norms (FADMMBase.h:243-256), but only between TWO vectors that are both known one
+//    iteration earlier: the momentum ratio (a-1)/a' follows from the previous a alone, so
+//        u = fl(fl(X'y - adj_y) + rho adj_z)  with adj = (1+ratio) new - ratio old     ("accelerate")
+//        w = fl(fl(X'y - y_old) + rho z_old)                                          ("restart": adj = old)
+//    are formed by the tail of the previous iteration exactly as ADMMLassoTall.h:70-80 rounds them.
+//    The x-update kernel streams Minv ONCE against the pair (u, w), a = Minv u, b = Minv w, and the
+//    tail picks x = a or x = b.  The scalar decision itself (norm reduction, convergence,
+//    acceleration/restart, lambda schedule) runs as ONE EXTRA WORKGROUP of the x-update launch,
+//    concurrently with the streaming workgroups.  No host round trip, no grid barrier, no atomics:
+//    two launches per ADMM iteration.
+//    (An earlier version used x = Minv u' + tau Minv w' with u' = X'y - y + rho z: equal in exact
+//    arithmetic, but it bypasses the float rounding of the right-hand side, and with it the dead
+//    band that lets the reference's stopping rule fire when rho * ulp(z) exceeds eps_dual -- tiny
+//    lambda, unstandardised data.  scripts/fuzz_parity.py found paths running to maxit.)
 //  * Minv is symmetric: for p >= 2048 the x-update reads only its lower triangle (symv_kernels.h,
 //    2p^2 bytes); small problems use the full-matrix gemv_t (fewer, larger workgroups).
 //  * Convergence test, acceleration scalars, the lambda schedule (init_warm), niter[] and the
@@ -35,7 +40,8 @@ namespace admm {
 
 struct TallCtl {
     double rho, lam, eps_primal, eps_dual, adj_a, adj_c, tau;
-    int mode;       // 1: x = a + tau*b and adj from (cur, old);  0: keep stored x / adj (first iteration after convergence)
+    double a_next, tau_next;   // a' and ratio (a - 1) / a' the NEXT decision uses if it accelerates (computed once, here)
+    int mode;       // 1: x = a (accelerate) or b (restart), adj from (cur, old);  0: keep stored x / adj (first iteration after convergence)
     int restart;    // with mode 1: adj = old exactly
     int iter;       // index i of the iteration this block describes
     int lam_idx;
@@ -99,9 +105,7 @@ __device__ void tall_decide(const TallParams& q, int par) {
             const double old_c = in.adj_c;
             const double c = in.rho * rp * rp + in.rho * daz2;     // compute_resid_combined  ADMMLassoTall.h:154-161
             if (c < 0.999 * old_c) {                   // FADMMBase.h:243-249
-                const double old_a = in.adj_a;
-                const double aa = 0.5 + 0.5 * sqrt(1.0 + 4.0 * old_a * old_a);
-                out.adj_a = aa; out.adj_c = c; out.tau = (old_a - 1.0) / aa; out.restart = 0;
+                out.adj_a = in.a_next; out.adj_c = c; out.tau = in.tau_next; out.restart = 0;
             } else {                                   // restart                 FADMMBase.h:250-256
                 out.adj_a = 1.0; out.adj_c = old_c / 0.999; out.tau = -1.0; out.restart = 1;
             }
@@ -124,6 +128,8 @@ __device__ void tall_decide(const TallParams& q, int par) {
     // eps for the iteration about to run, from the CURRENT iterate (FADMMBase.h:187-188, ADMMLassoTall.h:141-149)
     out.eps_primal = fmax(sqrt(x2), sqrt(z2)) * q.eps_rel + q.sqrt_p * q.eps_abs;
     out.eps_dual = sqrt(y2) * q.eps_rel + q.sqrt_p * q.eps_abs;
+    out.a_next = 0.5 + 0.5 * sqrt(1.0 + 4.0 * out.adj_a * out.adj_a);
+    out.tau_next = (out.adj_a - 1.0) / out.a_next;
     out.total = in.total + 1;
     *outp = out;
 }
@@ -134,7 +140,13 @@ struct TallDecideExtra {
     __device__ void operator()() const { tall_decide(q, par); }
 };
 
-// State of one coordinate and its update: everything after x = a + tau b in one iteration
+// (1 + ratio) * cur - ratio * old without contraction, like the reference build (FADMMBase.h:247-248): the
+// same value is formed twice, as the candidate right-hand side and as adj of the next iteration.
+__device__ __forceinline__ float tall_extrapolate(float t1, float t, float cur, float old) {
+    return __fsub_rn(__fmul_rn(t1, cur), __fmul_rn(t, old));
+}
+
+// State of one coordinate and its update: everything after the x-update in one iteration
 // (next_z, residual, dual update, norms, right-hand sides of the next x-update).
 struct TallElem { float zc, yc, zo, yo, adjz, adjy, x, xy; };
 
@@ -153,12 +165,12 @@ __device__ __forceinline__ void tall_update_elem(const TallParams& q, const Tall
     if (c.done) return;
     float adjz, adjy, x;
     if (c.mode) {
-        if (c.restart) { adjz = zo; adjy = yo; x = a - b; }
+        if (c.restart) { adjz = zo; adjy = yo; x = b; }
         else {
             const float t = (float)c.tau, t1 = (float)(1.0 + c.tau);
-            adjz = t1 * zc - t * zo;           // (1 + ratio) * aux_z - ratio * old_z   FADMMBase.h:247-248
-            adjy = t1 * yc - t * yo;
-            x = a + t * b;
+            adjz = tall_extrapolate(t1, t, zc, zo);       // (1 + ratio) * aux_z - ratio * old_z   FADMMBase.h:247-248
+            adjy = tall_extrapolate(t1, t, yc, yo);
+            x = a;
         }
     } else { adjz = e.adjz; adjy = e.adjy; x = e.x; }
     const float rho_f = (float)c.rho;
@@ -179,8 +191,11 @@ __device__ __forceinline__ void tall_update_elem(const TallParams& q, const Tall
     acc[0] = (double)r * r; acc[1] = (double)dz * dz; acc[2] = (double)daz * daz;
     acc[3] = (double)x * x; acc[4] = (double)zn * zn; acc[5] = (double)yn * yn;
     q.x[i] = x; zo_[i] = zn; yo_[i] = yn; q.adj_z[i] = adjz; q.adj_y[i] = adjy;
-    q.u[i] = (float)((double)(e.xy - yn) + c.rho * (double)zn);
-    q.w[i] = (float)((double)(yc - yn) + c.rho * (double)dz);
+    // both possible right-hand sides of the next x-update, rounded as ADMMLassoTall.h:70-80 does
+    const float tn = (float)c.tau_next, tn1 = (float)(1.0 + c.tau_next);
+    const float adjz_a = tall_extrapolate(tn1, tn, zn, zc), adjy_a = tall_extrapolate(tn1, tn, yn, yc);
+    q.u[i] = (float)((double)(e.xy - adjy_a) + c.rho * (double)adjz_a);
+    q.w[i] = (float)((double)(e.xy - yc) + c.rho * (double)zc);
 }
 
 // Element-wise part of one iteration.  `c` = the control block published by this iteration's decision.
@@ -252,6 +267,7 @@ __global__ void tall_init_kernel(TallParams q, double rho, double lam0) {
         TallCtl c;
         c.rho = rho; c.lam = lam0; c.eps_primal = 0.0; c.eps_dual = 0.0;
         c.adj_a = 1.0; c.adj_c = 9999.0; c.tau = 0.0;
+        c.a_next = 0.5 + 0.5 * sqrt(5.0); c.tau_next = 0.0;
         c.mode = 1; c.restart = 0; c.iter = 0; c.lam_idx = 0; c.done = 0; c.first = 1; c.total = 0; c.fin_idx = -1; c.fin_niter = 0; c.pad = 0;
         q.ctl[0] = c; q.ctl[1] = c;
     }
@@ -373,8 +389,20 @@ struct TallPlan final : LassoPlan {
         ADMM_HIP_CHECK(hipStreamSynchronize(st));
     }
 
+    void debug_dump(const char* tag, const float* dptr, size_t n) {
+        std::vector<float> h(n);
+        ADMM_HIP_CHECK(hipMemcpy(h.data(), dptr, n * sizeof(float), hipMemcpyDeviceToHost));
+        size_t bad = 0; double mx = 0;
+        for (size_t k = 0; k < n; ++k) { const float v = h[k]; if (!(v == v) || std::fabs(v) > 1e30f) { if (bad < 4) fprintf(stderr, "[dbg]   %s[%zu] = %g\n", tag, k, (double)v); ++bad; } else mx = std::max(mx, (double)std::fabs(v)); }
+        fprintf(stderr, "[dbg] %-8s n=%zu nonfinite=%zu max|.|=%g\n", tag, n, bad, mx);
+    }
+
     // One warm-started lambda path from a cold start (init at the first lambda, init_warm after).
     void run(LassoResult& res) override {
+        if (std::getenv("ADMM_HIP_DEBUG_DUMP")) {
+            if (M.get()) debug_dump("M", M.get(), (size_t)ldp * ldp);
+            debug_dump("XY", XY.get(), ldp);
+        }
         admm_stats S = setup_stats;
         S.xupdate_variant = use_sym ? 1 : 0;
         res.lambda = lam_user;
@@ -449,6 +477,16 @@ struct TallPlan final : LassoPlan {
             }
             S.xupdate_samples = (long long)(nev / 2);
             S.xupdate_ms_avg = tot / (double)(nev / 2);
+        }
+
+        if (std::getenv("ADMM_HIP_DEBUG_DUMP")) {
+            debug_dump("x", x.get(), ldv); debug_dump("u", u.get(), ldv); debug_dump("w", w.get(), ldv);
+            debug_dump("z0", z0.get(), ldv); debug_dump("y0", y0.get(), ldv);
+            if (!use_sym) { debug_dump("a_part", a_part.get(), (size_t)pl.nseg * ldp); debug_dump("b_part", b_part.get(), (size_t)pl.nseg * ldp); }
+            std::vector<double> hp((size_t)2 * nwg * 8);
+            ADMM_HIP_CHECK(hipMemcpy(hp.data(), P.get(), hp.size() * sizeof(double), hipMemcpyDeviceToHost));
+            for (size_t k = 0; k < hp.size() && k < 16; ++k) fprintf(stderr, "[dbg] P[%zu]=%g\n", k, hp[k]);
+            fprintf(stderr, "[dbg] nseg=%d nwg=%d ldp=%lld ldv=%lld\n", pl.nseg, nwg, ldp, ldv);
         }
 
         // ---- results: niter, beta on the original scale (DataStd::recover, Lasso.cpp:108-111)

@@ -357,17 +357,48 @@ template void cholesky_lower<float>(float*, long long, int, hipStream_t);
 template void cholesky_lower<double>(double*, long long, int, hipStream_t);
 
 template <typename T>
+__global__ void set_diag_one_kernel(T* X, long long ldx, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) X[(size_t)i * ldx + i] = T(1);
+}
+
+// A(i, j) = A(j, i) = X(i, j) for i >= j
+template <typename T>
+__global__ void __launch_bounds__(256) mirror_lower_kernel(const T* __restrict__ X, long long ldx, T* __restrict__ A, long long lda, int n) {
+    const int j = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n && i >= j) {
+        const T v = X[(size_t)j * ldx + i];
+        A[(size_t)j * lda + i] = v;
+        A[(size_t)i * lda + j] = v;
+    }
+}
+
+// Symmetric inverse of an SPD matrix: potrf, then X = L^-T (L^-1 I) by two triangular solves.
+// (rocSOLVER's potri is not used: on this ROCm its small-size path returned a NaN in the last diagonal
+//  element when the handle's workspace had been used by an fp64 call before -- scripts/fuzz_parity.py.)
+template <typename T>
 void spd_inverse_full(T* A, long long lda, int n, hipStream_t st) {
     cholesky_lower<T>(A, lda, n, st);
     rocblas_handle h = blas(st);
-    DevBuf<rocblas_int> info(1);
+    DevBuf<T> X((size_t)n * n);
+    X.zero(st);
+    hipLaunchKernelGGL((set_diag_one_kernel<T>), dim3((n + 255) / 256), dim3(256), 0, st, X.get(), (long long)n, n);
+    const T one = T(1);
     if constexpr (std::is_same<T, float>::value) {
-        ADMM_BLAS_CHECK(rocsolver_spotri(h, rocblas_fill_lower, n, A, (rocblas_int)lda, info.get()));
+        ADMM_BLAS_CHECK(rocblas_strsm(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit,
+                                      n, n, &one, A, (rocblas_int)lda, X.get(), n));
+        ADMM_BLAS_CHECK(rocblas_strsm(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit,
+                                      n, n, &one, A, (rocblas_int)lda, X.get(), n));
     } else {
-        ADMM_BLAS_CHECK(rocsolver_dpotri(h, rocblas_fill_lower, n, A, (rocblas_int)lda, info.get()));
+        ADMM_BLAS_CHECK(rocblas_dtrsm(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit,
+                                      n, n, &one, A, (rocblas_int)lda, X.get(), n));
+        ADMM_BLAS_CHECK(rocblas_dtrsm(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit,
+                                      n, n, &one, A, (rocblas_int)lda, X.get(), n));
     }
-    check_info(info, st, "inverse from Cholesky factor");
-    symmetrize_from_lower<T>(A, lda, n, st);
+    hipLaunchKernelGGL((mirror_lower_kernel<T>), dim3((n + 255) / 256, n), dim3(256), 0, st, X.get(), (long long)n, A, lda, n);
+    ADMM_HIP_CHECK(hipGetLastError());
+    ADMM_HIP_CHECK(hipStreamSynchronize(st));        // X is released on return
 }
 template void spd_inverse_full<float>(float*, long long, int, hipStream_t);
 template void spd_inverse_full<double>(double*, long long, int, hipStream_t);
