@@ -33,3 +33,36 @@ def cases(ncases, seed):
             cs["ulam"] = rng.uniform(0.02, 0.9, size=cs["nl"]) if cs["user_lam"] else None
             cs["K"] = int(rng.integers(1, max(2, min(6, (p - 1) // 5)))) if kind == "par" else 0
         yield cs
+
+
+def medium_cases(ncases, seed):
+    """Lasso-family problems large enough for the matrix-core setup (p >= 256) and the lower-triangle x-update
+    (p >= 2048), with random solver options.  Still seconds per case for the oracle."""
+    rng = np.random.default_rng(seed)
+    for c in range(ncases):
+        kind = rng.choice(["tall", "enet_tall", "wide", "par"])
+        icpt, stdz = bool(rng.integers(2)), bool(rng.integers(2))
+        scale = float(rng.choice([0.1, 1.0, 2.0, 20.0]))
+        if kind in ("tall", "enet_tall"):
+            p = int(rng.choice([257, 300, 640, 1100, 2048, 2300]))
+            n = p + int(rng.integers(1, 2 * p))
+        elif kind == "wide":
+            n = int(rng.integers(100, 600)); p = n + int(rng.integers(0, 3000))
+        else:
+            p = int(rng.integers(200, 900)); n = int(rng.integers(300, 3000))
+        m = int(rng.integers(1, 40))
+        x = rng.standard_normal((n, p)) * scale
+        if rng.random() < 0.3:
+            x += rng.standard_normal(p) * 3 * scale
+        b = np.zeros(p); b[:m] = rng.uniform(size=m)
+        y = x @ b + rng.standard_normal(n) * scale
+        cs = dict(c=c, kind=kind, icpt=icpt, stdz=stdz, scale=scale, n=n, p=p, x=x, y=y)
+        cs["user_lam"] = rng.random() < 0.3
+        cs["nl"] = int(rng.integers(2, 12))
+        cs["alpha"] = float(rng.choice([0.2, 0.7, 1.0])) if kind == "enet_tall" else None
+        cs["ulam"] = rng.uniform(0.02, 0.9, size=cs["nl"]) if cs["user_lam"] else None
+        cs["K"] = int(rng.integers(2, 9)) if kind == "par" else 0
+        cs["maxit"] = int(rng.choice([7, 300, 10000])) if kind != "par" else int(rng.choice([7, 300]))
+        cs["eps"] = float(rng.choice([1e-5, 1e-3]))
+        cs["rho"] = float(rng.choice([-1.0, -1.0, 5.0, 200.0]))
+        yield cs
