@@ -39,6 +39,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12   # B/s, MI355X spec (MI355X_MICROARCH.md)
+# test hook: take every multi-rank branch (process groups, all-reduces, consensus children) with WORLD_SIZE=1
+FORCE_DIST = os.environ.get("ADMM_BENCH_FORCE_DIST") == "1"
 
 
 def parse():
@@ -123,17 +125,18 @@ def consensus_child(a):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    multi = world > 1 or FORCE_DIST
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if multi:
         dist.init_process_group(backend="gloo")      # control plane only; the data path is the library's own RCCL communicator
     from admm_amd import DevicePtr, load
     from admm_amd import dist as adist
     lib = load()
     assert lib.admm_hip_set_device(local_rank) == 0
-    if world > 1:
+    if multi:
         adist.init_comm_from_torch(dev)
     else:
         adist.init_comm(1, 0)
@@ -154,11 +157,11 @@ def consensus_child(a):
     setup_s = time.time() - t0
     del xt
     plan.run()                                           # warm-up (RCCL lazy initialisation)
-    if world > 1:
+    if multi:
         dist.barrier()
     fit = plan.run()
     loop_s, iters = fit.stats["t_loop"], int(fit.stats["total_iter"])
-    if world > 1:
+    if multi:
         t = torch.tensor([loop_s], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         loop_s = float(t[0])
@@ -174,7 +177,7 @@ def consensus_child(a):
             json.dump(res, f)
     plan.close()
     adist.finalize_comm()
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 
@@ -188,7 +191,8 @@ def run_consensus_side_measurement(a, rank, world):
     if rank == 0 and os.path.exists(out_path):
         os.remove(out_path)
     env = dict(os.environ)
-    if world > 1:
+    multi = world > 1 or FORCE_DIST
+    if multi:
         env["MASTER_ADDR"] = "127.0.0.1"
         env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 17)
         # the children build their OWN rendezvous store on that port: do not let env:// look for torchrun's agent store there
@@ -218,11 +222,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    multi = world > 1 or FORCE_DIST
     import torch                      # before libadmm_hip: one HIP runtime per process
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if multi:
         dist.init_process_group(backend="nccl", device_id=dev)
     os.environ["ADMM_HIP_PROFILE_STRIDE"] = str(a.profile_stride)
     import numpy as np
@@ -232,7 +237,7 @@ def main():
     assert rc == 0
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
 
     n, p = a.n, a.p
@@ -277,7 +282,7 @@ def main():
     lib.admm_hip_device_synchronize()
     barrier()
     elapsed = time.time() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed, float(iters)], dtype=torch.float64, device=dev)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -338,11 +343,11 @@ def main():
         }
         if consensus is not None:
             out["consensus"] = consensus
-        if a.cpu_seconds > 0:
+        if a.cpu_seconds > 0 and world == 1:                # the CPU leg is timed on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(p, a.nlambda, a.cpu_seconds, a.seed)
         print(json.dumps(out), flush=True)
     plan.close()
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 
