@@ -1,0 +1,170 @@
+// fp64 matrix-core Gram for the one-time setup of the LAD / BP solvers (X'X, AA').
+//
+// Replaces (reference):  Linalg::cross_prod_lower / tcross_prod_lower  BlasWrapper.h:73-152
+//   (called from ADMMLAD.h:186-190 and ADMMBP.h:167-170), single-threaded Eigen there.
+//
+// C = Z Z' on 128 x 128 lower tiles (+ mirrored store), Z stored with the OUTPUT index contiguous (Z[i, k] at
+// i + k ldz), so for a fixed summation index k both factors are contiguous 1 KiB rows.  A workgroup = 4 waves
+// (2 x 2), each wave 64 x 64 = 4 x 4 tiles of v_mfma_f64_16x16x4_f64 (32 FLOP/clk/SIMD: the 78.6 TF/s fp64
+// matrix peak).  K tiles of 8 go global -> registers -> LDS, double buffered; rows are padded by 8 doubles so
+// that the fragment reads (16 consecutive doubles from each of 4 k-rows) touch every bank exactly twice.
+// fp64 matrix work is so compute dense (one 64-cycle MFMA per 16-byte LDS read) that nothing else matters.
+#include "prep.h"
+
+namespace admm {
+
+typedef double doublex4 __attribute__((ext_vector_type(4)));
+
+constexpr int DK_BM = 128;
+constexpr int DK_BK = 8;
+constexpr int DK_LD = DK_BM + 8;
+constexpr int DK_THREADS = 256;
+
+struct GemmNTd {
+    const double* A; long long lda;      // operands readable for rows < round_up(M, 128), columns < K (K multiple of 8)
+    double* C; long long ldc;
+    int M, K;
+    int nb, ntiles;
+};
+
+__device__ __forceinline__ void tri_decode_d(int t, int& bi, int& bj) {
+    int b = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+    while ((long long)(b + 1) * (b + 2) / 2 <= t) ++b;
+    while ((long long)b * (b + 1) / 2 > t) --b;
+    bi = b; bj = t - b * (b + 1) / 2;
+}
+
+// C = A A' (lower tiles, mirrored so that both triangles are stored)
+__global__ void __launch_bounds__(DK_THREADS, 2)
+syrk_lower_mfma_f64_kernel(GemmNTd g) {
+    __shared__ __attribute__((aligned(16))) double lds[2][2][DK_BK][DK_LD];      // [buffer][row panel / column panel][k][i]
+    const int per = (g.ntiles + 7) / 8;                                           // XCD b % 8 walks a contiguous range of tiles
+    const int t_idx = (blockIdx.x % 8) * per + blockIdx.x / 8;
+    if (t_idx >= g.ntiles) return;
+    int bi, bj;
+    tri_decode_d(t_idx, bi, bj);
+    const int I0 = bi * DK_BM, J0 = bj * DK_BM;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wi = (wid >> 1) * 64, wj = (wid & 1) * 64;
+
+    // staging: a K tile of one panel is 8 rows x 128 doubles = 512 double2; 2 per thread
+    const int s_row0 = tid >> 6;              // 0..3, second load +4
+    const int s_col = (tid & 63) * 2;
+    const double* gA = g.A + (size_t)s_row0 * g.lda + I0 + s_col;
+    const double* gB = g.A + (size_t)s_row0 * g.lda + J0 + s_col;
+    const size_t r4 = (size_t)4 * g.lda;
+
+    doublex4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[a][b][r] = 0.0;
+
+    double2 ra0, ra1, rb0, rb1;
+    auto gload = [&](int k0) {
+        ra0 = *reinterpret_cast<const double2*>(gA + (size_t)k0 * g.lda);
+        ra1 = *reinterpret_cast<const double2*>(gA + (size_t)k0 * g.lda + r4);
+        rb0 = *reinterpret_cast<const double2*>(gB + (size_t)k0 * g.lda);
+        rb1 = *reinterpret_cast<const double2*>(gB + (size_t)k0 * g.lda + r4);
+    };
+    auto lstore = [&](int buf) {
+        *reinterpret_cast<double2*>(&lds[buf][0][s_row0][s_col]) = ra0;
+        *reinterpret_cast<double2*>(&lds[buf][0][s_row0 + 4][s_col]) = ra1;
+        *reinterpret_cast<double2*>(&lds[buf][1][s_row0][s_col]) = rb0;
+        *reinterpret_cast<double2*>(&lds[buf][1][s_row0 + 4][s_col]) = rb1;
+    };
+
+    const int ntile_k = g.K / DK_BK;
+    const int fk = lane >> 4, fi = lane & 15;            // A / B fragment: one f64 per lane, [i = lane & 15][k = lane >> 4]
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < ntile_k; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < ntile_k) gload((kt + 1) * DK_BK);
+#pragma unroll
+        for (int kk = 0; kk < DK_BK; kk += 4) {
+            double af[4], bf[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                af[m] = lds[buf][0][kk + fk][wi + 16 * m + fi];
+                bf[m] = lds[buf][1][kk + fk][wj + 16 * m + fi];
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
+        if (kt + 1 < ntile_k) {
+            lstore(buf ^ 1);
+            __syncthreads();
+        }
+    }
+
+    // epilogue: C/D layout of the f64 16x16 MFMA: col = lane & 15, row = (lane >> 4) + 4 * r
+    const bool offdiag = I0 != J0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int col = J0 + wj + 16 * b + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = I0 + wi + 16 * a + (lane >> 4) + 4 * r;
+                if (row < g.M && col < g.M) {
+                    const double v = acc[a][b][r];
+                    g.C[(size_t)col * g.ldc + row] = v;
+                    if (offdiag) g.C[(size_t)row * g.ldc + col] = v;
+                }
+            }
+        }
+}
+
+template <bool TRANSPOSE>
+__global__ void __launch_bounds__(256)
+pad_copy_f64_kernel(const double* __restrict__ in, long long ldi, int rows, int cols, double* __restrict__ out, long long ldo) {
+    // out (ldo x K, zero padded) = in (rows x cols) or its transpose; 32 x 32 tiles through LDS
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    if (TRANSPOSE) {
+        for (int c = ty; c < 32; c += 8) {
+            const int r = r0 + tx, cc = c0 + c;
+            tile[c][tx] = (r < rows && cc < cols) ? in[(size_t)cc * ldi + r] : 0.0;
+        }
+        __syncthreads();
+        for (int c = ty; c < 32; c += 8) {
+            const int orow = c0 + tx, ocol = r0 + c;          // out(orow, ocol) = in(ocol, orow)
+            if (orow < cols && ocol < rows) out[(size_t)ocol * ldo + orow] = tile[tx][c];
+        }
+    } else {
+        for (int c = ty; c < 32; c += 8) {
+            const int r = r0 + tx, cc = c0 + c;
+            if (r < rows && cc < cols) out[(size_t)cc * ldo + r] = in[(size_t)cc * ldi + r];
+        }
+    }
+}
+
+// C (both triangles) = A'A (atA, C is cols x cols) or A A' (C is rows x rows), A rows x cols column-major.
+void gram_mfma_f64(const double* A, long long lda, int rows, int cols, bool atA, double* C, long long ldc, hipStream_t st) {
+    const int M = atA ? cols : rows;          // order of C
+    const int Kd = atA ? rows : cols;         // summation length
+    const long long ldz = round_up(M, DK_BM);
+    const int K = (int)round_up(Kd, DK_BK);
+    DevBuf<double> Z((size_t)ldz * K);        // padded operand with the output index contiguous
+    Z.zero(st);
+    if (atA) hipLaunchKernelGGL((pad_copy_f64_kernel<true>), dim3((rows + 31) / 32, (cols + 31) / 32), dim3(256), 0, st, A, lda, rows, cols, Z.get(), ldz);
+    else hipLaunchKernelGGL((pad_copy_f64_kernel<false>), dim3((rows + 31) / 32, (cols + 31) / 32), dim3(256), 0, st, A, lda, rows, cols, Z.get(), ldz);
+    GemmNTd g;
+    g.A = Z.get(); g.lda = ldz; g.C = C; g.ldc = ldc; g.M = M; g.K = K;
+    g.nb = (M + DK_BM - 1) / DK_BM; g.ntiles = g.nb * (g.nb + 1) / 2;
+    const int grid = (g.ntiles + 7) / 8 * 8;
+    hipLaunchKernelGGL(syrk_lower_mfma_f64_kernel, dim3(grid), dim3(DK_THREADS), 0, st, g);
+    ADMM_HIP_CHECK(hipGetLastError());
+    ADMM_HIP_CHECK(hipStreamSynchronize(st));     // Z is freed on return
+}
+
+}  // namespace admm

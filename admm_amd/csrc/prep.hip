@@ -306,6 +306,7 @@ template void transpose<double>(const double*, long long, int, int, double*, lon
 
 // ------------------------------------------------------------------ Gram / factorisation (library first cut)
 void gram_xtx_mfma_f32(const float* X, long long ldx, int n, int p, float* C, long long ldc, hipStream_t st);   // syrk_mfma.hip
+void gram_mfma_f64(const double* A, long long lda, int rows, int cols, bool atA, double* C, long long ldc, hipStream_t st);   // gemm_f64_mfma.hip
 
 template <typename T>
 void gram_full(const T* A, long long lda, int rows, int cols, bool atA, T* C, long long ldc, hipStream_t st) {
@@ -317,6 +318,16 @@ void gram_full(const T* A, long long lda, int rows, int cols, bool atA, T* C, lo
         const long long nb = (cols + 127) / 128;
         if (atA && !force_lib && nb * (nb + 1) / 2 >= 128) {
             gram_xtx_mfma_f32(A, lda, rows, cols, C, ldc, st);
+            return;
+        }
+    }
+    if constexpr (std::is_same<T, double>::value) {
+        // LAD / BP setup: hand-written fp64 matrix-core kernel once there are enough 128x128 tiles
+        const char* e = std::getenv("ADMM_HIP_GRAM");
+        const bool force_lib = e && std::string(e) == "rocblas";
+        const long long nb = ((atA ? cols : rows) + 127) / 128;
+        if (!force_lib && nb * (nb + 1) / 2 >= 128) {
+            gram_mfma_f64(A, lda, rows, cols, atA, C, ldc, st);
             return;
         }
     }

@@ -54,3 +54,25 @@ def test_not_spd_is_reported():
     with pytest.raises(AdmmHipError) as ei:
         admm_lasso(x, y, standardize=False, intercept=False).penalty(0.1).opts(rho=1e-12).fit()
     assert ei.value.code == 5
+
+
+def test_fp64_mfma_gram_matches_library_gram_in_lad_and_bp():
+    """Order 2100 (ragged last tile, 153 lower tiles): LAD's X'X and BP's AA' go through the fp64 matrix-core
+    kernel by default; a fixed number of iterations must reproduce the rocBLAS-Gram run to fp64 rounding."""
+    from admm_amd import admm_bp, admm_lad
+    rng = np.random.default_rng(71)
+    x = rng.standard_normal((4300, 2100)); y = x[:, :5] @ np.arange(1.0, 6.0) + rng.standard_normal(4300)
+    a = rng.standard_normal((2100, 4803)); b0 = np.zeros(4803); b0[:40] = rng.standard_normal(40); b = a @ b0
+    out = {}
+    for mode in ("rocblas", None):
+        if mode:
+            os.environ["ADMM_HIP_GRAM"] = mode
+        try:
+            out[mode] = (admm_lad(x, y).opts(maxit=25).fit(), admm_bp(a, b).opts(maxit=25).fit())
+        finally:
+            os.environ.pop("ADMM_HIP_GRAM", None)
+    lad_ref, bp_ref = out["rocblas"]
+    lad, bp = out[None]
+    assert lad.niter == lad_ref.niter == 26 and bp.niter == bp_ref.niter == 26
+    assert relerr(lad.beta, lad_ref.beta) < 1e-9
+    assert relerr(bp.beta.toarray().ravel(), bp_ref.beta.toarray().ravel()) < 1e-9
