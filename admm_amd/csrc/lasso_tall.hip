@@ -346,11 +346,7 @@ struct TallPlan final : LassoPlan {
         // (X'X + rho I)^-1, cached for the whole path (rho never changes: ADMMLassoTall.h:97)
         t0 = now_s();
         add_diag<float>(M.get(), ldp, p, (float)rho, st);
-        {
-            const char* e = std::getenv("ADMM_HIP_FACTOR");
-            if ((e && std::string(e) == "rocsolver") || p < 256) spd_inverse_full<float>(M.get(), ldp, p, st);
-            else spd_inverse_mfma_f32(M.get(), ldp, p, st);
-        }
+        spd_inverse_f32(M.get(), ldp, p, st);
         ADMM_HIP_CHECK(hipStreamSynchronize(st));
         S.t_factor = now_s() - t0;
         // X itself is no longer needed by the loop (only X'y and Minv are): release 4np bytes.

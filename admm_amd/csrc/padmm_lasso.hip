@@ -264,23 +264,23 @@ struct ParPlan final : LassoPlan {
             gemv_t_simple<float>(w.A.get(), w.lda, w.rows, p, bk.get(), Ab.get() + (size_t)k * ldv, st);   // A_k' b_k  (:42)
             double t0 = now_s();
             if (!w.wide) {
-                w.ldm = round_up(p, 32);
-                w.Minv.alloc((size_t)w.ldm * p); w.Minv.zero(st);
+                w.ldm = round_up(p, 128);                      // whole 128-blocks for the matrix-core inverse
+                w.Minv.alloc((size_t)w.ldm * w.ldm); w.Minv.zero(st);
                 gram_full<float>(w.A.get(), w.lda, w.rows, p, true, w.Minv.get(), w.ldm, st);
                 ADMM_HIP_CHECK(hipStreamSynchronize(st));
                 t_gram += now_s() - t0; t0 = now_s();
                 add_diag<float>(w.Minv.get(), w.ldm, p, (float)rho, st);
-                spd_inverse_full<float>(w.Minv.get(), w.ldm, p, st);
+                spd_inverse_f32(w.Minv.get(), w.ldm, p, st);
                 w.gM.init(w.Minv.get(), w.ldm, p, p);
                 A_release_if_tall(w);
             } else {
-                w.ldm = round_up(w.rows, 32);
-                w.Minv.alloc((size_t)w.ldm * w.rows); w.Minv.zero(st);
+                w.ldm = round_up(w.rows, 128);
+                w.Minv.alloc((size_t)w.ldm * w.ldm); w.Minv.zero(st);
                 gram_full<float>(w.A.get(), w.lda, w.rows, p, false, w.Minv.get(), w.ldm, st);
                 ADMM_HIP_CHECK(hipStreamSynchronize(st));
                 t_gram += now_s() - t0; t0 = now_s();
                 add_diag<float>(w.Minv.get(), w.ldm, w.rows, (float)rho, st);
-                spd_inverse_full<float>(w.Minv.get(), w.ldm, w.rows, st);
+                spd_inverse_f32(w.Minv.get(), w.ldm, w.rows, st);
                 w.ldat = round_up(p, 32);
                 w.At.alloc((size_t)w.ldat * w.rows); w.At.zero(st);
                 transpose<float>(w.A.get(), w.lda, w.rows, p, w.At.get(), w.ldat, st);

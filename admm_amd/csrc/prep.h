@@ -47,6 +47,9 @@ void spd_inverse_full(T* A, long long lda, int n, hipStream_t st);
 // fp32, hand-written matrix-core path (syrk_mfma.hip).  Contract: lda >= round_up(n, 128) and the buffer holds
 // round_up(n, 128) columns, padding zero.  ADMM_HIP_FACTOR=rocsolver forces the library path.
 void spd_inverse_mfma_f32(float* A, long long lda, int n, hipStream_t st);
+// fp32 SPD inverse of a matrix stored in whole 128-blocks (lda >= round_up(n, 128), that many zero-padded columns
+// allocated): hand-written matrix-core kernels for n >= 256, potrf + two trsm below (ADMM_HIP_FACTOR=rocsolver forces the latter).
+void spd_inverse_f32(float* A, long long lda, int n, hipStream_t st);
 // In place Cholesky (lower). Throws ADMM_ERR_NOT_SPD.
 template <typename T>
 void cholesky_lower(T* A, long long lda, int n, hipStream_t st);

@@ -305,19 +305,19 @@ template void transpose<float>(const float*, long long, int, int, float*, long l
 template void transpose<double>(const double*, long long, int, int, double*, long long, hipStream_t);
 
 // ------------------------------------------------------------------ Gram / factorisation (library first cut)
-void gram_xtx_mfma_f32(const float* X, long long ldx, int n, int p, float* C, long long ldc, hipStream_t st);   // syrk_mfma.hip
+void gram_mfma_f32(const float* A, long long lda, int rows, int cols, bool atA, float* C, long long ldc, hipStream_t st);   // syrk_mfma.hip
 void gram_mfma_f64(const double* A, long long lda, int rows, int cols, bool atA, double* C, long long ldc, hipStream_t st);   // gemm_f64_mfma.hip
 
 template <typename T>
 void gram_full(const T* A, long long lda, int rows, int cols, bool atA, T* C, long long ldc, hipStream_t st) {
     if constexpr (std::is_same<T, float>::value) {
-        // hand-written MFMA kernel for the large tall Gram (enough 128x128 tiles to fill the chip);
-        // ADMM_HIP_GRAM=rocblas forces the library path
+        // hand-written matrix-core kernel (split-K when the triangle has few tiles) once the product is big enough to
+        // pay for the padded operand copy; ADMM_HIP_GRAM=rocblas forces the library path
         const char* e = std::getenv("ADMM_HIP_GRAM");
         const bool force_lib = e && std::string(e) == "rocblas";
-        const long long nb = (cols + 127) / 128;
-        if (atA && !force_lib && nb * (nb + 1) / 2 >= 128) {
-            gram_xtx_mfma_f32(A, lda, rows, cols, C, ldc, st);
+        const double order = atA ? cols : rows, len = atA ? rows : cols;
+        if (!force_lib && order >= 128 && order * order * len >= 2e9) {
+            gram_mfma_f32(A, lda, rows, cols, atA, C, ldc, st);
             return;
         }
     }
@@ -412,6 +412,12 @@ void spd_inverse_full(T* A, long long lda, int n, hipStream_t st) {
     ADMM_HIP_CHECK(hipStreamSynchronize(st));        // X is released on return
 }
 template void spd_inverse_full<float>(float*, long long, int, hipStream_t);
+
+void spd_inverse_f32(float* A, long long lda, int n, hipStream_t st) {
+    const char* e = std::getenv("ADMM_HIP_FACTOR");
+    if ((e && std::string(e) == "rocsolver") || n < 256 || lda < round_up(n, 128)) spd_inverse_full<float>(A, lda, n, st);
+    else spd_inverse_mfma_f32(A, lda, n, st);
+}
 template void spd_inverse_full<double>(double*, long long, int, hipStream_t);
 
 template <typename T>

@@ -42,6 +42,8 @@ struct GemmNT {
     int nbi, nbj, ntiles;
     int mirror;                  // LOWER mode: also store the transposed tile (both triangles)
     int kstart_row;              // start the K loop at the tile's first row (A, B upper triangular)
+    int ksplit;                  // > 1: split s of the K range writes its own partial C + s * cstride (alpha = 1, beta = 0)
+    long long cstride;
 };
 
 __device__ __forceinline__ void tri_decode(int t, int& bi, int& bj) {   // t -> (bi, bj), bi >= bj, row-major triangle
@@ -56,9 +58,11 @@ __global__ void __launch_bounds__(SK_THREADS, 2)
 gemm_nt_mfma_kernel(GemmNT g) {
     __shared__ __attribute__((aligned(16))) float lds[2][2][SK_BK][SK_BM];      // [buffer][A/B][k][i]
     // XCD-aware remap: block b runs on XCD b % 8; give every XCD a contiguous range of tiles
-    const int per = (g.ntiles + 7) / 8;
-    const int t_idx = (blockIdx.x % 8) * per + blockIdx.x / 8;
-    if (t_idx >= g.ntiles) return;
+    const int nwork = g.ntiles * g.ksplit;
+    const int per = (nwork + 7) / 8;
+    const int w_idx = (blockIdx.x % 8) * per + blockIdx.x / 8;
+    if (w_idx >= nwork) return;
+    const int t_idx = w_idx % g.ntiles, split = w_idx / g.ntiles;
     int bi, bj;
     if (LOWER) tri_decode(t_idx, bi, bj);
     else { bi = t_idx % g.nbi; bj = t_idx / g.nbi; }
@@ -95,8 +99,9 @@ gemm_nt_mfma_kernel(GemmNT g) {
         *reinterpret_cast<float4*>(&lds[buf][1][s_row0 + 8][s_col]) = rb1;
     };
 
-    const int kbeg = g.kstart_row ? (max(I0, J0) / SK_BK) * SK_BK : 0;
-    const int ntile_k = (g.K - kbeg) / SK_BK;
+    const int kchunk = g.K / g.ksplit;                                  // multiple of SK_BK (launcher)
+    const int kbeg = g.kstart_row ? (max(I0, J0) / SK_BK) * SK_BK : split * kchunk;
+    const int ntile_k = ((g.ksplit > 1 ? kbeg + kchunk : g.K) - kbeg) / SK_BK;
     const int fk = lane >> 5, fi = lane & 31;
     if (ntile_k > 0) {
         gload(kbeg);
@@ -135,37 +140,81 @@ gemm_nt_mfma_kernel(GemmNT g) {
                 const int row = I0 + wi + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (row < g.M && col < g.N) {
                     float v = g.alpha * acc[a][b][r];
-                    float* dst = g.C + (size_t)col * g.ldc + row;
+                    float* Cs = g.C + (size_t)split * g.cstride;
+                    float* dst = Cs + (size_t)col * g.ldc + row;
                     if (g.beta != 0.f) v += g.beta * *dst;
                     *dst = v;
-                    if (LOWER && g.mirror && offdiag) g.C[(size_t)row * g.ldc + col] = v;     // mirrored tile: both triangles
+                    if (LOWER && g.mirror && offdiag) Cs[(size_t)row * g.ldc + col] = v;     // mirrored tile: both triangles
                 }
             }
         }
 }
 
 static void launch_gemm_nt(bool lower, const float* A, long long lda, const float* B, long long ldb, float* C, long long ldc,
-                           int M, int N, int K, float alpha, float beta, bool mirror, bool kstart_row, hipStream_t st) {
+                           int M, int N, int K, float alpha, float beta, bool mirror, bool kstart_row, hipStream_t st,
+                           int ksplit = 1, long long cstride = 0) {
     if (M <= 0 || N <= 0) return;
     GemmNT g;
+    g.ksplit = ksplit; g.cstride = cstride;
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
     g.alpha = alpha; g.beta = beta; g.mirror = mirror ? 1 : 0; g.kstart_row = kstart_row ? 1 : 0;
     g.nbi = (M + SK_BM - 1) / SK_BM; g.nbj = (N + SK_BM - 1) / SK_BM;
     g.ntiles = lower ? g.nbi * (g.nbi + 1) / 2 : g.nbi * g.nbj;
-    const int grid = (g.ntiles + 7) / 8 * 8;
+    const int grid = (g.ntiles * ksplit + 7) / 8 * 8;
     if (lower) hipLaunchKernelGGL(gemm_nt_mfma_kernel<1>, dim3(grid), dim3(SK_THREADS), 0, st, g);
     else hipLaunchKernelGGL(gemm_nt_mfma_kernel<0>, dim3(grid), dim3(SK_THREADS), 0, st, g);
 }
 
 // ---------------------------------------------------------------------------------------------- Gram
-void gram_xtx_mfma_f32(const float* X, long long ldx, int n, int p, float* C, long long ldc, hipStream_t st) {
-    const long long ldz = round_up(p, SK_BM);
-    const int nk = round_up(n, SK_BK);
+// out(i, j) = sum_s part[s](i, j) for i >= j, mirrored (both triangles)
+__global__ void __launch_bounds__(256) sum_splits_mirror_kernel(const float* __restrict__ part, long long ldp, long long stride, int nsplit,
+                                                                float* __restrict__ C, long long ldc, int m) {
+    const int j = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < m && i >= j) {
+        float v = 0.f;
+        for (int s = 0; s < nsplit; ++s) v += part[(size_t)s * stride + (size_t)j * ldp + i];
+        C[(size_t)j * ldc + i] = v;
+        C[(size_t)i * ldc + j] = v;
+    }
+}
+
+__global__ void __launch_bounds__(256) pad_copy_f32_kernel(const float* __restrict__ in, long long ldi, int rows, int cols,
+                                                           float* __restrict__ out, long long ldo) {
+    const int c = blockIdx.y;
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r < rows) out[(size_t)c * ldo + r] = in[(size_t)c * ldi + r];
+}
+
+// C (both triangles) = A'A (atA; C is cols x cols) or A A' (C is rows x rows) for A rows x cols column-major.
+// The operand is copied once into a zero-padded buffer with the OUTPUT index contiguous (A' for atA, A itself
+// otherwise).  When the lower triangle has too few 128 x 128 tiles to fill 256 CUs (wide solver: order n = 2000,
+// K = p = 2 * 10^5; consensus blocks; small tall problems) the summation range is split over several workgroups
+// per tile and the partial tiles are summed in a fixed order (deterministic, no atomics).
+void gram_mfma_f32(const float* A, long long lda, int rows, int cols, bool atA, float* C, long long ldc, hipStream_t st) {
+    const int M = atA ? cols : rows;
+    const int Kd = atA ? rows : cols;
+    const long long ldz = round_up(M, SK_BM);
+    const int nb = (int)(ldz / SK_BM);
+    const int ntiles = nb * (nb + 1) / 2;
+    int ksplit = 1;
+    if (ntiles < 512) ksplit = std::min(std::min(16, (1024 + ntiles - 1) / ntiles), std::max(1, Kd / 2048));
+    const int nk = (int)round_up(Kd, (long long)SK_BK * ksplit);
     DevBuf<float> Z((size_t)ldz * nk);
     Z.zero(st);
-    transpose<float>(X, ldx, n, p, Z.get(), ldz, st);
-    launch_gemm_nt(true, Z.get(), ldz, Z.get(), ldz, C, ldc, p, p, nk, 1.f, 0.f, true, false, st);
-    ADMM_HIP_CHECK(hipStreamSynchronize(st));      // Z is freed on return
+    if (atA) transpose<float>(A, lda, rows, cols, Z.get(), ldz, st);
+    else hipLaunchKernelGGL(pad_copy_f32_kernel, dim3((rows + 255) / 256, cols), dim3(256), 0, st, A, lda, rows, cols, Z.get(), ldz);
+    if (ksplit == 1) {
+        launch_gemm_nt(true, Z.get(), ldz, Z.get(), ldz, C, ldc, M, M, nk, 1.f, 0.f, true, false, st);
+        ADMM_HIP_CHECK(hipStreamSynchronize(st));      // Z is freed on return
+        return;
+    }
+    const long long stride = ldz * ldz;
+    DevBuf<float> part((size_t)stride * ksplit);
+    launch_gemm_nt(true, Z.get(), ldz, Z.get(), ldz, part.get(), ldz, M, M, nk, 1.f, 0.f, false, false, st, ksplit, stride);
+    hipLaunchKernelGGL(sum_splits_mirror_kernel, dim3((M + 255) / 256, M), dim3(256), 0, st, part.get(), ldz, stride, ksplit, C, ldc, M);
+    ADMM_HIP_CHECK(hipGetLastError());
+    ADMM_HIP_CHECK(hipStreamSynchronize(st));
 }
 
 // ---------------------------------------------------------------------------------------------- Cholesky of a diagonal block
