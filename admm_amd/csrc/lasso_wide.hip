@@ -18,8 +18,13 @@
 //    partials are summed by the z/y kernel.
 //  * Convergence test, rho adaptation (from iteration 5), the regular/active schedule and the
 //    lambda schedule (init_warm resets the counter, keeps x, z, y, rho) run on the device, evaluated
-//    identically by every workgroup of the x-update launch; three launches per iteration
-//    (x-update, gather mat-vec, z/y + norms); the host enqueues batches and polls a sticky done word.
+//    identically by every workgroup of the x-update launch; the host enqueues batches and polls a
+//    sticky done word.
+//  * n <= 4096 (a column fits the registers of one wave): the x-update keeps the column it has just
+//    dotted with t and adds x_j X_j to its own partial of Ax right away -- TWO launches per iteration
+//    (x-update + gather, z/y + norms), X_j read once.  On active-set iterations only the first 128
+//    workgroups take part, so the z/y kernel sums 128 partials (all of them on regular iterations).
+//    Larger n: three launches (x-update, gather mat-vec over row tiles of 4096, z/y + norms).
 #include "prep.h"
 #include "gemv_kernels.h"
 #include "solvers.h"
@@ -37,10 +42,12 @@ struct WideCtl {
 
 constexpr int kWideThreads = 256;
 constexpr int kAxWG = 128;                // workgroups of the gather mat-vec (partials per output)
+constexpr int kActWG = 256;               // fused mode: workgroups taking part in an active-set iteration
 constexpr int kAxRT = 16;                 // float4 row accumulators per lane -> 4096 rows per row tile
 
 struct WideParams {
     int n, p, maxit, nlam, enet, nwg_tail;
+    int fused, nwg_x;                     // fused: the x-update launch also writes the Ax partials (n <= 4096)
     long long ldx;
     const float* X; const float* Y;
     float gamma, lambda0, alpha;          // sprad, lambda_0, enet alpha
@@ -73,9 +80,11 @@ __device__ __forceinline__ float prox_f(float val, float thresh, float denom, bo
 // adaptation, lambda schedule, which x-update runs now -- then builds t = Ax + z + y / rho in LDS and
 // updates the columns its waves own.  A regular step visits every column (x = prox(x - X_j't / gamma)),
 // an active-set step only the current non-zeros; both stream X_j once with 16-byte loads.
+template <int RT>     // RT > 0: fused gather, a column is RT float4 per lane (n <= RT * 256); RT == 0: x-update only
 __global__ void __launch_bounds__(kWideThreads)
 wide_x_kernel(WideParams q, int par) {
     __shared__ double sums[8];
+    __shared__ float4 red[RT > 0 ? kWideThreads : 1];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const WideCtl in = q.ctl[par];
     WideCtl* outp = &q.ctl[par ^ 1];
@@ -172,13 +181,32 @@ wide_x_kernel(WideParams q, int par) {
     const float denom_r = (float)(1.0 + pen_d * (1.0 - (double)q.alpha));
     const float* tv = reg ? tl : tdl;
     const int lane = threadIdx.x & 63;
-    const int NW = gridDim.x * (kWideThreads / 64);
+    // fused: an active-set iteration is done by the first kActWG workgroups only (few columns, few partials)
+    int nblk = gridDim.x;
+    if (RT > 0 && !reg) {
+        nblk = min((int)gridDim.x, kActWG);
+        if ((int)blockIdx.x >= nblk) return;
+    }
+    const int NW = nblk * (kWideThreads / 64);
     const int w = blockIdx.x * (kWideThreads / 64) + (threadIdx.x >> 6);
     const int nv = (q.n + 3) / 4 * 4;
-    for (int s0 = 0; (long long)s0 * NW < q.p; s0 += 64) {
+    float4 acc[RT > 0 ? RT : 1];
+#pragma unroll
+    for (int k = 0; k < (RT > 0 ? RT : 1); ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int sc = 0; (long long)sc * NW < q.p; sc += 64 * 8) {
+      float xs[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {                                  // the wave's next 512 columns: 8 independent loads per lane
+          const long long jl = (long long)(sc + u * 64 + lane) * NW + w;
+          xs[u] = (jl < q.p) ? q.x[jl] : 0.f;
+          if (snap && jl < q.p) bsnap[jl] = xs[u];
+      }
+#pragma unroll 1
+      for (int u = 0; u < 8; ++u) {
+        const int s0 = sc + u * 64;
+        if ((long long)s0 * NW >= q.p) break;
         const long long jl = (long long)(s0 + lane) * NW + w;
-        float xj = (jl < q.p) ? q.x[jl] : 0.f;
-        if (snap && jl < q.p) bsnap[jl] = xj;
+        float xj = u == 0 ? xs[0] : (u == 1 ? xs[1] : (u == 2 ? xs[2] : (u == 3 ? xs[3] : (u == 4 ? xs[4] : (u == 5 ? xs[5] : (u == 6 ? xs[6] : xs[7]))))));
         unsigned long long mask = reg ? __ballot(jl < q.p) : __ballot(xj != 0.f);
         while (mask) {
             const int l = __ffsll((long long)mask) - 1;
@@ -187,8 +215,26 @@ wide_x_kernel(WideParams q, int par) {
             const float xv = __shfl(xj, l, 64);
             const float* col = q.X + (size_t)jj * q.ldx;
             float d0 = 0.f, d1 = 0.f;
+            float4 cv[RT > 0 ? RT : 1];
+            if (RT > 0) {
+                // the whole column in registers: all loads in flight at once, reused by the gather below
+#pragma unroll
+                for (int k = 0; k < RT; ++k) {
+                    const int r = k * 256 + lane * 4;
+                    cv[k] = r < nv ? *reinterpret_cast<const float4*>(col + r) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int k = 0; k < RT; ++k) {
+                    const int r = k * 256 + lane * 4;
+                    if (r < nv) {
+                        const float4 b = *reinterpret_cast<const float4*>(tv + r);
+                        float& dd = (k & 1) ? d1 : d0;
+                        dd = fmaf(cv[k].x, b.x, dd); dd = fmaf(cv[k].y, b.y, dd); dd = fmaf(cv[k].z, b.z, dd); dd = fmaf(cv[k].w, b.w, dd);
+                    }
+                }
+            }
             int r = lane * 4;
-            for (; r + 256 < nv; r += 512) {
+            for (; RT == 0 && r + 256 < nv; r += 512) {
                 const float4 a0 = *reinterpret_cast<const float4*>(col + r);
                 const float4 a1 = *reinterpret_cast<const float4*>(col + r + 256);
                 const float4 b0 = *reinterpret_cast<const float4*>(tv + r);
@@ -196,7 +242,7 @@ wide_x_kernel(WideParams q, int par) {
                 d0 = fmaf(a0.x, b0.x, d0); d0 = fmaf(a0.y, b0.y, d0); d0 = fmaf(a0.z, b0.z, d0); d0 = fmaf(a0.w, b0.w, d0);
                 d1 = fmaf(a1.x, b1.x, d1); d1 = fmaf(a1.y, b1.y, d1); d1 = fmaf(a1.z, b1.z, d1); d1 = fmaf(a1.w, b1.w, d1);
             }
-            if (r < nv) {
+            if (RT == 0 && r < nv) {
                 const float4 a0 = *reinterpret_cast<const float4*>(col + r);
                 const float4 b0 = *reinterpret_cast<const float4*>(tv + r);
                 d0 = fmaf(a0.x, b0.x, d0); d0 = fmaf(a0.y, b0.y, d0); d0 = fmaf(a0.z, b0.z, d0); d0 = fmaf(a0.w, b0.w, d0);
@@ -215,6 +261,34 @@ wide_x_kernel(WideParams q, int par) {
                 xn = prox_f(xv - d, thresh_a, denom_a, q.enet != 0);
             }
             if (lane == l) { xj = xn; q.x[jj] = xn; }
+            if (RT > 0 && xn != 0.f) {                                 // gather: Ax partial += x_j X_j
+#pragma unroll
+                for (int k = 0; k < RT; ++k) {
+                    acc[k].x = fmaf(xn, cv[k].x, acc[k].x); acc[k].y = fmaf(xn, cv[k].y, acc[k].y);
+                    acc[k].z = fmaf(xn, cv[k].z, acc[k].z); acc[k].w = fmaf(xn, cv[k].w, acc[k].w);
+                }
+            }
+        }
+      }
+    }
+    if (RT > 0) {
+        // combine the 4 waves of the workgroup, then write this workgroup's partial row
+        const int wid = threadIdx.x >> 6;
+#pragma unroll
+        for (int k = 0; k < RT; ++k) {
+            __syncthreads();
+            red[threadIdx.x] = acc[k];
+            __syncthreads();
+            if (wid == 0) {
+                float4 sacc = red[lane];
+#pragma unroll
+                for (int ww = 1; ww < kWideThreads / 64; ++ww) {
+                    const float4 o = red[ww * 64 + lane];
+                    sacc.x += o.x; sacc.y += o.y; sacc.z += o.z; sacc.w += o.w;
+                }
+                const int rr = k * 256 + lane * 4;
+                if (rr < q.ldn) *reinterpret_cast<float4*>(q.axpart + (size_t)blockIdx.x * q.ldn + rr) = sacc;
+            }
         }
     }
 }
@@ -292,7 +366,7 @@ wide_ax_kernel(WideParams q) {
 // 8 lanes share one element and issue their 16 partial loads at once (one memory round trip).
 constexpr int kWtLanes = 8;
 constexpr int kWtElems = kWideThreads / kWtLanes;
-static_assert(kAxWG == 16 * kWtLanes, "tail reduction assumes 16 partials per lane");
+static_assert(kAxWG == 16 * kWtLanes && kActWG == 2 * kAxWG, "tail reduction assumes 16 (+16 when fused) partials per lane");
 
 __global__ void __launch_bounds__(kWideThreads)
 wide_tail_kernel(WideParams q, int par) {
@@ -301,16 +375,32 @@ wide_tail_kernel(WideParams q, int par) {
     const int sub = threadIdx.x & (kWtLanes - 1);
     const int i = blockIdx.x * kWtElems + threadIdx.x / kWtLanes;
     const bool valid = i < q.n;
-    float v[16];
+    float v[16], v2[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) v[k] = valid ? q.axpart[(size_t)(k * kWtLanes + sub) * q.ldn + i] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v2[k] = (valid && q.fused) ? q.axpart[(size_t)(kAxWG + k * kWtLanes + sub) * q.ldn + i] : 0.f;   // rows 128..255
     float zo = 0.f, yo = 0.f, yd = 0.f;
     if (valid) { zo = q.z[i]; yo = q.y[i]; yd = q.Y[i]; }
     float ax = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) ax += v[k];
 #pragma unroll
+    for (int k = 0; k < 16; ++k) ax += v2[k];
+    if (q.fused && c.type == W_REG) {                                  // a regular step: every x-update workgroup wrote a partial
+        for (int b0 = kActWG; b0 < q.nwg_x; b0 += 16 * kWtLanes) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int b = b0 + k * kWtLanes + sub;
+                v[k] = (valid && b < q.nwg_x) ? q.axpart[(size_t)b * q.ldn + i] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) ax += v[k];
+        }
+    }
+#pragma unroll
     for (int m = 1; m < kWtLanes; m <<= 1) ax += __shfl_xor(ax, m, 64);
+    if (q.fused && c.type == W_ZERO) ax = 0.f;                         // x = 0: nobody wrote partials
     if (c.done) return;
     double acc[5] = {0, 0, 0, 0, 0};
     if (valid && sub == 0) {
@@ -351,7 +441,7 @@ struct WidePlan final : LassoPlan {
     LassoProblem pb;
     hipStream_t st;
     admm_stats setup_stats{};
-    int n = 0, p = 0, nlam = 0, nwg_tail = 0;
+    int n = 0, p = 0, nlam = 0, nwg_tail = 0, nwg_x = 0, fuse_rt = 0;
     long long ldn = 0;
     float sprad = 0.f, lambda0 = 0.f;
     double rho0 = 0;
@@ -402,7 +492,13 @@ struct WidePlan final : LassoPlan {
         nwg_tail = (n + kWtElems - 1) / kWtElems;                    // 32 elements per workgroup (8 lanes each)
         x.alloc(ldp); x.zero(st);
         for (DevBuf<float>* b : {&Ax, &z, &y}) { b->alloc(ldn); b->zero(st); }
-        axpart.alloc((size_t)kAxWG * ldn); axpart.zero(st);
+        int wgx = 4;                                                 // workgroups per CU of the x-update launch
+        if (const char* e = std::getenv("ADMM_HIP_WIDE_WGX")) wgx = std::max(1, std::atoi(e));
+        nwg_x = std::max(wgx * device_info().num_cu, kActWG);
+        // ADMM_HIP_WIDE_FUSE=0: always three launches per iteration
+        fuse_rt = n <= 1024 ? 4 : (n <= 2048 ? 8 : (n <= 4096 ? 16 : 0));
+        if (const char* e = std::getenv("ADMM_HIP_WIDE_FUSE")) if (std::string(e) == "0") fuse_rt = 0;
+        axpart.alloc((size_t)(fuse_rt ? nwg_x : kAxWG) * ldn); axpart.zero(st);
         beta.alloc((size_t)nlam * p); niter.alloc(nlam); done.alloc(1); dlam.alloc(nlam);
         P.alloc((size_t)nwg_tail * 8); ctl.alloc(2);
         ADMM_HIP_CHECK(hipMemcpyAsync(dlam.get(), lam_int.data(), nlam * sizeof(float), hipMemcpyHostToDevice, st));
@@ -413,7 +509,7 @@ struct WidePlan final : LassoPlan {
         q.eps_abs = pb.opts.eps_abs; q.eps_rel = pb.opts.eps_rel;
         q.sqrt_n = std::sqrt((double)n); q.sqrt_p = std::sqrt((double)p); q.sqrt_gamma = (double)std::sqrt(sprad);
         q.lambdas = dlam.get(); q.x = x.get(); q.Ax = Ax.get(); q.z = z.get(); q.y = y.get();
-        q.axpart = axpart.get(); q.ldn = ldn;
+        q.axpart = axpart.get(); q.ldn = ldn; q.fused = fuse_rt ? 1 : 0; q.nwg_x = nwg_x;
         q.ctl = ctl.get(); q.P = P.get(); q.beta = beta.get(); q.niter = niter.get(); q.done = done.get();
         ADMM_HIP_CHECK(hipStreamSynchronize(st));
     }
@@ -424,16 +520,18 @@ struct WidePlan final : LassoPlan {
         beta.zero(st); niter.zero(st);
         const int init_n = std::max(std::max(n, p), nwg_tail * 8);
         hipLaunchKernelGGL(wide_init_kernel, dim3((init_n + 255) / 256), dim3(256), 0, st, q, rho0, lam_int[0]);
-        const int ncu = device_info().num_cu;
-        int wgx = 4;                                                 // workgroups per CU of the x-update launch
-        if (const char* e = std::getenv("ADMM_HIP_WIDE_WGX")) wgx = std::max(1, std::atoi(e));
-        const int nwg_x = wgx * ncu;
         const size_t lds_x = (size_t)((n + 255) / 256 * 256) * 2 * sizeof(float) + (size_t)nwg_tail * 8 * sizeof(double);
         const int batch = pb.batch_iters > 0 ? (pb.batch_iters + 1) / 2 * 2 : 16;
         LoopTimes lt = run_until_done(st, done.get(), batch, (long long)nlam * ((long long)pb.opts.maxit + 2) + 4, [&](long long g) {
             const int par = (int)(g & 1);
-            hipLaunchKernelGGL(wide_x_kernel, dim3(nwg_x), dim3(kWideThreads), lds_x, st, q, par);
-            hipLaunchKernelGGL(wide_ax_kernel, dim3(kAxWG), dim3(kWideThreads), 0, st, q);
+            switch (fuse_rt) {
+                case 4: hipLaunchKernelGGL(wide_x_kernel<4>, dim3(nwg_x), dim3(kWideThreads), lds_x, st, q, par); break;
+                case 8: hipLaunchKernelGGL(wide_x_kernel<8>, dim3(nwg_x), dim3(kWideThreads), lds_x, st, q, par); break;
+                case 16: hipLaunchKernelGGL(wide_x_kernel<16>, dim3(nwg_x), dim3(kWideThreads), lds_x, st, q, par); break;
+                default:
+                    hipLaunchKernelGGL(wide_x_kernel<0>, dim3(nwg_x), dim3(kWideThreads), lds_x, st, q, par);
+                    hipLaunchKernelGGL(wide_ax_kernel, dim3(kAxWG), dim3(kWideThreads), 0, st, q);
+            }
             hipLaunchKernelGGL(wide_tail_kernel, dim3(nwg_tail), dim3(kWideThreads), 0, st, q, par);
         });
         S.t_loop = lt.wall_s; S.loop_ms_events = lt.events_ms; S.xupdate_launches = lt.launched;
