@@ -83,8 +83,6 @@ __device__ __forceinline__ float prox_f(float val, float thresh, float denom, bo
 template <int RT>     // RT > 0: fused gather, a column is RT float4 per lane (n <= RT * 256); RT == 0: x-update only
 __global__ void __launch_bounds__(kWideThreads)
 wide_x_kernel(WideParams q, int par) {
-    __shared__ double sums[8];
-    __shared__ float4 red[RT > 0 ? kWideThreads : 1];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const WideCtl in = q.ctl[par];
     WideCtl* outp = &q.ctl[par ^ 1];
@@ -95,23 +93,36 @@ wide_x_kernel(WideParams q, int par) {
     const int npad = (q.n + 255) / 256 * 256;
     float* tl = reinterpret_cast<float*>(smem_raw);            // t        [npad]
     float* tdl = tl + npad;                                    // t/gamma  [npad]
-    double* pstage = reinterpret_cast<double*>(tdl + npad);    // [nwg_tail * 8]
-    const int np = q.nwg_tail * 8;
-    for (int k = threadIdx.x; k < np; k += kWideThreads) pstage[k] = q.P[k];
-    // operands of t = Ax + z + y / rho do not depend on the decision: fetch them in the same round trip
-    for (int i = threadIdx.x; i < npad; i += kWideThreads) {
-        tl[i] = i < q.n ? q.Ax[i] + q.z[i] : 0.f;
-        tdl[i] = i < q.n ? q.y[i] : 0.f;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int w = blockIdx.x * (kWideThreads / 64) + wid;
+    // Workgroups that take part in every kind of step (all of them when not fused) fetch what does not depend on
+    // the decision in the same round trip as the decision's inputs: the operands of t = Ax + z + y / rho and, fused,
+    // this wave's first 512 slot values of an active-set step (most iterations are active-set steps).
+    const bool always = RT == 0 || (int)blockIdx.x < kActWG;
+    float xs0[8];
+    if (RT > 0 && always) {
+        const int NWa = min((int)gridDim.x, kActWG) * (kWideThreads / 64);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long long jl = (long long)(u * 64 + lane) * NWa + w;
+            xs0[u] = (jl < q.p) ? q.x[jl] : 0.f;
+        }
     }
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        const int lane = threadIdx.x, which = lane & 7;
-        double sacc = 0.0;
-        if (which < 5) for (int w = lane >> 3; w < q.nwg_tail; w += 8) sacc += pstage[w * 8 + which];
-        sacc += __shfl_xor(sacc, 8, 64); sacc += __shfl_xor(sacc, 16, 64); sacc += __shfl_xor(sacc, 32, 64);
-        if (lane < 5) sums[lane] = sacc;
+    auto stage_t = [&]() {
+        for (int i = threadIdx.x; i < npad; i += kWideThreads) {
+            tl[i] = i < q.n ? q.Ax[i] + q.z[i] : 0.f;
+            tdl[i] = i < q.n ? q.y[i] : 0.f;
+        }
+    };
+    if (always) stage_t();
+    // norm partials of the previous iteration: every wave reduces them itself (fixed order), no LDS, no barrier
+    double sums[5] = {0, 0, 0, 0, 0};
+    for (int row = lane; row < q.nwg_tail; row += 64) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) sums[k] += q.P[(size_t)row * 8 + k];
     }
-    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 5; ++k) sums[k] = wave_sum(sums[k]);
     const double r2 = sums[0], dz2 = sums[1], ax2 = sums[2], z2 = sums[3], y2 = sums[4];
     WideCtl out = in;
     out.first = 0;
@@ -164,6 +175,11 @@ wide_x_kernel(WideParams q, int par) {
         }
         return;
     }
+    const bool reg = out.type == W_REG;
+    // fused: an active-set iteration is done by the first kActWG workgroups only (few columns, few partials);
+    // the others leave here, before any barrier or LDS traffic
+    if (RT > 0 && !reg && !always) return;
+    if (!always) stage_t();                                            // regular step of a workgroup beyond kActWG
     // t = cache_Ax + aux_z + dual_y / Scalar(rho); the active-set form divides by gamma first (:90, :141)
     const float rho_f = (float)out.rho;
     for (int i = threadIdx.x; i < npad; i += kWideThreads) {       // same thread wrote these slots above
@@ -172,7 +188,6 @@ wide_x_kernel(WideParams q, int par) {
         tdl[i] = t / q.gamma;
     }
     __syncthreads();
-    const bool reg = out.type == W_REG;
     const double pen_d = (double)out.lam / (out.rho * (double)q.gamma);
     const float penalty = (float)pen_d;                               // `const Scalar penalty` (:89)
     const float thresh_a = q.enet ? q.alpha * penalty : penalty;
@@ -180,61 +195,37 @@ wide_x_kernel(WideParams q, int par) {
     const float thresh_r = (float)((double)q.alpha * pen_d);
     const float denom_r = (float)(1.0 + pen_d * (1.0 - (double)q.alpha));
     const float* tv = reg ? tl : tdl;
-    const int lane = threadIdx.x & 63;
-    // fused: an active-set iteration is done by the first kActWG workgroups only (few columns, few partials)
-    int nblk = gridDim.x;
-    if (RT > 0 && !reg) {
-        nblk = min((int)gridDim.x, kActWG);
-        if ((int)blockIdx.x >= nblk) return;
-    }
+    const int nblk = (RT > 0 && !reg) ? min((int)gridDim.x, kActWG) : (int)gridDim.x;
     const int NW = nblk * (kWideThreads / 64);
-    const int w = blockIdx.x * (kWideThreads / 64) + (threadIdx.x >> 6);
     const int nv = (q.n + 3) / 4 * 4;
     float4 acc[RT > 0 ? RT : 1];
 #pragma unroll
     for (int k = 0; k < (RT > 0 ? RT : 1); ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int sc = 0; (long long)sc * NW < q.p; sc += 64 * 8) {
-      float xs[8];
+
+    // One column: d = X_j't (or X_j't/gamma), the prox, and (fused) acc += x_j X_j.  Returns the new x_j (wave uniform).
+    auto column = [&](long long jj, float xv) -> float {
+        const float* col = q.X + (size_t)jj * q.ldx;
+        float d0 = 0.f, d1 = 0.f;
+        float4 cv[RT > 0 ? RT : 1];
+        if (RT > 0) {
+            // the whole column in registers: all loads in flight at once, reused by the gather below
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {                                  // the wave's next 512 columns: 8 independent loads per lane
-          const long long jl = (long long)(sc + u * 64 + lane) * NW + w;
-          xs[u] = (jl < q.p) ? q.x[jl] : 0.f;
-          if (snap && jl < q.p) bsnap[jl] = xs[u];
-      }
-#pragma unroll 1
-      for (int u = 0; u < 8; ++u) {
-        const int s0 = sc + u * 64;
-        if ((long long)s0 * NW >= q.p) break;
-        const long long jl = (long long)(s0 + lane) * NW + w;
-        float xj = u == 0 ? xs[0] : (u == 1 ? xs[1] : (u == 2 ? xs[2] : (u == 3 ? xs[3] : (u == 4 ? xs[4] : (u == 5 ? xs[5] : (u == 6 ? xs[6] : xs[7]))))));
-        unsigned long long mask = reg ? __ballot(jl < q.p) : __ballot(xj != 0.f);
-        while (mask) {
-            const int l = __ffsll((long long)mask) - 1;
-            mask &= mask - 1;
-            const long long jj = (long long)(s0 + l) * NW + w;
-            const float xv = __shfl(xj, l, 64);
-            const float* col = q.X + (size_t)jj * q.ldx;
-            float d0 = 0.f, d1 = 0.f;
-            float4 cv[RT > 0 ? RT : 1];
-            if (RT > 0) {
-                // the whole column in registers: all loads in flight at once, reused by the gather below
+            for (int k = 0; k < RT; ++k) {
+                const int r = k * 256 + lane * 4;
+                cv[k] = r < nv ? *reinterpret_cast<const float4*>(col + r) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
 #pragma unroll
-                for (int k = 0; k < RT; ++k) {
-                    const int r = k * 256 + lane * 4;
-                    cv[k] = r < nv ? *reinterpret_cast<const float4*>(col + r) : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-#pragma unroll
-                for (int k = 0; k < RT; ++k) {
-                    const int r = k * 256 + lane * 4;
-                    if (r < nv) {
-                        const float4 b = *reinterpret_cast<const float4*>(tv + r);
-                        float& dd = (k & 1) ? d1 : d0;
-                        dd = fmaf(cv[k].x, b.x, dd); dd = fmaf(cv[k].y, b.y, dd); dd = fmaf(cv[k].z, b.z, dd); dd = fmaf(cv[k].w, b.w, dd);
-                    }
+            for (int k = 0; k < RT; ++k) {
+                const int r = k * 256 + lane * 4;
+                if (r < nv) {
+                    const float4 b = *reinterpret_cast<const float4*>(tv + r);
+                    float& dd = (k & 1) ? d1 : d0;
+                    dd = fmaf(cv[k].x, b.x, dd); dd = fmaf(cv[k].y, b.y, dd); dd = fmaf(cv[k].z, b.z, dd); dd = fmaf(cv[k].w, b.w, dd);
                 }
             }
+        } else {
             int r = lane * 4;
-            for (; RT == 0 && r + 256 < nv; r += 512) {
+            for (; r + 256 < nv; r += 512) {
                 const float4 a0 = *reinterpret_cast<const float4*>(col + r);
                 const float4 a1 = *reinterpret_cast<const float4*>(col + r + 256);
                 const float4 b0 = *reinterpret_cast<const float4*>(tv + r);
@@ -242,53 +233,79 @@ wide_x_kernel(WideParams q, int par) {
                 d0 = fmaf(a0.x, b0.x, d0); d0 = fmaf(a0.y, b0.y, d0); d0 = fmaf(a0.z, b0.z, d0); d0 = fmaf(a0.w, b0.w, d0);
                 d1 = fmaf(a1.x, b1.x, d1); d1 = fmaf(a1.y, b1.y, d1); d1 = fmaf(a1.z, b1.z, d1); d1 = fmaf(a1.w, b1.w, d1);
             }
-            if (RT == 0 && r < nv) {
+            if (r < nv) {
                 const float4 a0 = *reinterpret_cast<const float4*>(col + r);
                 const float4 b0 = *reinterpret_cast<const float4*>(tv + r);
                 d0 = fmaf(a0.x, b0.x, d0); d0 = fmaf(a0.y, b0.y, d0); d0 = fmaf(a0.z, b0.z, d0); d0 = fmaf(a0.w, b0.w, d0);
             }
-            const float d = wave_sum(d0 + d1);
-            float xn;
-            if (reg) {
-                const float vec = (-d) / q.gamma + xv;                // vec = -X't / gamma; vec += main_x   (:147-149)
-                if (!q.enet) {                                        // soft_threshold, double compare (:70-84)
-                    const double v = (double)vec;
-                    xn = v > pen_d ? (float)(v - pen_d) : (v < -pen_d ? (float)(v + pen_d) : 0.f);
-                } else {
-                    xn = vec > thresh_r ? (vec - thresh_r) / denom_r : (vec < -thresh_r ? (vec + thresh_r) / denom_r : 0.f);
-                }
+        }
+        const float d = wave_sum(d0 + d1);
+        float xn;
+        if (reg) {
+            const float vec = (-d) / q.gamma + xv;                    // vec = -X't / gamma; vec += main_x   (:147-149)
+            if (!q.enet) {                                            // soft_threshold, double compare (:70-84)
+                const double v = (double)vec;
+                xn = v > pen_d ? (float)(v - pen_d) : (v < -pen_d ? (float)(v + pen_d) : 0.f);
             } else {
-                xn = prox_f(xv - d, thresh_a, denom_a, q.enet != 0);
+                xn = vec > thresh_r ? (vec - thresh_r) / denom_r : (vec < -thresh_r ? (vec + thresh_r) / denom_r : 0.f);
             }
-            if (lane == l) { xj = xn; q.x[jj] = xn; }
-            if (RT > 0 && xn != 0.f) {                                 // gather: Ax partial += x_j X_j
+        } else {
+            xn = prox_f(xv - d, thresh_a, denom_a, q.enet != 0);
+        }
+        if (RT > 0 && xn != 0.f) {                                     // gather: Ax partial += x_j X_j
 #pragma unroll
-                for (int k = 0; k < RT; ++k) {
-                    acc[k].x = fmaf(xn, cv[k].x, acc[k].x); acc[k].y = fmaf(xn, cv[k].y, acc[k].y);
-                    acc[k].z = fmaf(xn, cv[k].z, acc[k].z); acc[k].w = fmaf(xn, cv[k].w, acc[k].w);
-                }
+            for (int k = 0; k < RT; ++k) {
+                acc[k].x = fmaf(xn, cv[k].x, acc[k].x); acc[k].y = fmaf(xn, cv[k].y, acc[k].y);
+                acc[k].z = fmaf(xn, cv[k].z, acc[k].z); acc[k].w = fmaf(xn, cv[k].w, acc[k].w);
             }
         }
-      }
+        return xn;
+    };
+
+    for (int sc = 0; (long long)sc * NW < q.p; sc += 64 * 8) {
+        float xs[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {                                  // the wave's next 512 columns: 8 independent loads per lane
+            const long long jl = (long long)(sc + u * 64 + lane) * NW + w;
+            if (RT > 0 && !reg && sc == 0) xs[u] = xs0[u];             // fetched before the decision
+            else xs[u] = (jl < q.p) ? q.x[jl] : 0.f;
+            if (snap && jl < q.p) bsnap[jl] = xs[u];
+        }
+#pragma unroll 1
+        for (int u = 0; u < 8; ++u) {
+            const int s0 = sc + u * 64;
+            if ((long long)s0 * NW >= q.p) break;
+            const long long jl = (long long)(s0 + lane) * NW + w;
+            const float xj = u == 0 ? xs[0] : (u == 1 ? xs[1] : (u == 2 ? xs[2] : (u == 3 ? xs[3] : (u == 4 ? xs[4] : (u == 5 ? xs[5] : (u == 6 ? xs[6] : xs[7]))))));
+            unsigned long long mask = reg ? __ballot(jl < q.p) : __ballot(xj != 0.f);
+            while (mask) {
+                const int l = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                const long long jj = (long long)(s0 + l) * NW + w;
+                const float xn = column(jj, __shfl(xj, l, 64));
+                if (lane == l) q.x[jj] = xn;
+            }
+        }
     }
     if (RT > 0) {
-        // combine the 4 waves of the workgroup, then write this workgroup's partial row
-        const int wid = threadIdx.x >> 6;
+        // combine the 4 waves of the workgroup through the (now free) t buffers, 4 row slices per round, then write
+        // this workgroup's partial row
+        float4* red = reinterpret_cast<float4*>(smem_raw);             // >= 4 * kWideThreads float4 (launch)
 #pragma unroll
-        for (int k = 0; k < RT; ++k) {
+        for (int k0 = 0; k0 < RT; k0 += 4) {
             __syncthreads();
-            red[threadIdx.x] = acc[k];
-            __syncthreads();
-            if (wid == 0) {
-                float4 sacc = red[lane];
 #pragma unroll
-                for (int ww = 1; ww < kWideThreads / 64; ++ww) {
-                    const float4 o = red[ww * 64 + lane];
-                    sacc.x += o.x; sacc.y += o.y; sacc.z += o.z; sacc.w += o.w;
-                }
-                const int rr = k * 256 + lane * 4;
-                if (rr < q.ldn) *reinterpret_cast<float4*>(q.axpart + (size_t)blockIdx.x * q.ldn + rr) = sacc;
+            for (int k = 0; k < 4; ++k) red[k * kWideThreads + threadIdx.x] = acc[k0 + k];
+            __syncthreads();
+            const int k = threadIdx.x >> 6, ln = threadIdx.x & 63;     // 4 slices x 64 lanes = one output per thread
+            float4 sacc = red[k * kWideThreads + ln];
+#pragma unroll
+            for (int ww = 1; ww < kWideThreads / 64; ++ww) {
+                const float4 v = red[k * kWideThreads + ww * 64 + ln];
+                sacc.x += v.x; sacc.y += v.y; sacc.z += v.z; sacc.w += v.w;
             }
+            const int rr = (k0 + k) * 256 + ln * 4;
+            if (rr < q.ldn) *reinterpret_cast<float4*>(q.axpart + (size_t)blockIdx.x * q.ldn + rr) = sacc;
         }
     }
 }
@@ -442,6 +459,7 @@ struct WidePlan final : LassoPlan {
     hipStream_t st;
     admm_stats setup_stats{};
     int n = 0, p = 0, nlam = 0, nwg_tail = 0, nwg_x = 0, fuse_rt = 0;
+    size_t lds_x = 0;
     long long ldn = 0;
     float sprad = 0.f, lambda0 = 0.f;
     double rho0 = 0;
@@ -492,12 +510,24 @@ struct WidePlan final : LassoPlan {
         nwg_tail = (n + kWtElems - 1) / kWtElems;                    // 32 elements per workgroup (8 lanes each)
         x.alloc(ldp); x.zero(st);
         for (DevBuf<float>* b : {&Ax, &z, &y}) { b->alloc(ldn); b->zero(st); }
-        int wgx = 4;                                                 // workgroups per CU of the x-update launch
-        if (const char* e = std::getenv("ADMM_HIP_WIDE_WGX")) wgx = std::max(1, std::atoi(e));
-        nwg_x = std::max(wgx * device_info().num_cu, kActWG);
         // ADMM_HIP_WIDE_FUSE=0: always three launches per iteration
         fuse_rt = n <= 1024 ? 4 : (n <= 2048 ? 8 : (n <= 4096 ? 16 : 0));
         if (const char* e = std::getenv("ADMM_HIP_WIDE_FUSE")) if (std::string(e) == "0") fuse_rt = 0;
+        lds_x = std::max((size_t)((n + 255) / 256 * 256) * 2 * sizeof(float), (size_t)4 * kWideThreads * sizeof(float4));
+        // grid of the x-update launch: exactly ONE resident round of workgroups (a regular step streams all of X; a
+        // partial second round runs at a fraction of the occupancy: 342 us instead of 280 us at C3 with 4 per CU
+        // when 3 fit).  ADMM_HIP_WIDE_WGX overrides the workgroups per CU.
+        int wgx = 0;
+        {
+            const void* fn = fuse_rt == 4 ? reinterpret_cast<const void*>(wide_x_kernel<4>)
+                           : fuse_rt == 8 ? reinterpret_cast<const void*>(wide_x_kernel<8>)
+                           : fuse_rt == 16 ? reinterpret_cast<const void*>(wide_x_kernel<16>)
+                                           : reinterpret_cast<const void*>(wide_x_kernel<0>);
+            ADMM_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&wgx, fn, kWideThreads, lds_x));
+            wgx = std::max(1, std::min(wgx, 4));
+        }
+        if (const char* e = std::getenv("ADMM_HIP_WIDE_WGX")) wgx = std::max(1, std::atoi(e));
+        nwg_x = std::max(wgx * device_info().num_cu, kActWG);
         axpart.alloc((size_t)(fuse_rt ? nwg_x : kAxWG) * ldn); axpart.zero(st);
         beta.alloc((size_t)nlam * p); niter.alloc(nlam); done.alloc(1); dlam.alloc(nlam);
         P.alloc((size_t)nwg_tail * 8); ctl.alloc(2);
@@ -520,7 +550,6 @@ struct WidePlan final : LassoPlan {
         beta.zero(st); niter.zero(st);
         const int init_n = std::max(std::max(n, p), nwg_tail * 8);
         hipLaunchKernelGGL(wide_init_kernel, dim3((init_n + 255) / 256), dim3(256), 0, st, q, rho0, lam_int[0]);
-        const size_t lds_x = (size_t)((n + 255) / 256 * 256) * 2 * sizeof(float) + (size_t)nwg_tail * 8 * sizeof(double);
         const int batch = pb.batch_iters > 0 ? (pb.batch_iters + 1) / 2 * 2 : 16;
         LoopTimes lt = run_until_done(st, done.get(), batch, (long long)nlam * ((long long)pb.opts.maxit + 2) + 4, [&](long long g) {
             const int par = (int)(g & 1);
