@@ -91,7 +91,12 @@ static PlanHandle* create_plan(const double* x, const double* y, int n, int p, i
     pb.batch_iters = env_int("ADMM_HIP_BATCH_ITERS", 0);
     pb.profile_stride = env_int("ADMM_HIP_PROFILE_STRIDE", 0);
     DeviceData<float> d;
-    upload_standardize<float>(d, x, y, n, p, mem, standardize != 0, intercept != 0, h->st.s, dist ? n_total : 0);
+    // Host input of a large tall problem: standardisation and X'X run under the PCIe transfer (bit-identical result).
+    const char* eg = std::getenv("ADMM_HIP_GRAM");
+    const bool pipelined = mem == ADMM_MEM_HOST && !dist && nworkers <= 0 && n > p && p >= 4096 &&
+                           !(eg && (std::string(eg) == "rocblas" || std::string(eg) == "oneshot"));
+    if (pipelined) upload_standardize_gram_f32(d, x, y, n, p, standardize != 0, intercept != 0, h->st.s);
+    else upload_standardize<float>(d, x, y, n, p, mem, standardize != 0, intercept != 0, h->st.s, dist ? n_total : 0);
     if (nworkers > 0) h->plan = make_par_plan(std::move(d), pb, h->st.s);
     else if (n > p) h->plan = make_tall_plan(std::move(d), pb, h->st.s);      // Lasso.cpp:73
     else h->plan = make_wide_plan(std::move(d), pb, h->st.s);

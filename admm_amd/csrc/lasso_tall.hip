@@ -325,10 +325,15 @@ struct TallPlan final : LassoPlan {
 
         // Gram (cross_prod_lower, ADMMLassoTall.h:191-192) -- both triangles
         double t0 = now_s();
-        M.alloc((size_t)ldp * ldp); M.zero(st);
-        gram_full<float>(d.X.get(), d.ldx, n, p, true, M.get(), ldp, st);
-        ADMM_HIP_CHECK(hipStreamSynchronize(st));
-        S.t_gram = now_s() - t0;
+        if (d.gram.get() && d.ldgram == ldp) {            // computed under the host-to-device transfer (upload_standardize_gram_f32)
+            M = std::move(d.gram);
+            S.t_gram = d.t_gram_tail;
+        } else {
+            M.alloc((size_t)ldp * ldp); M.zero(st);
+            gram_full<float>(d.X.get(), d.ldx, n, p, true, M.get(), ldp, st);
+            ADMM_HIP_CHECK(hipStreamSynchronize(st));
+            S.t_gram = now_s() - t0;
+        }
 
         // rho (ADMMLassoTall.h:194-202)
         rho = pb.opts.rho;

@@ -19,6 +19,11 @@ struct DeviceData {
     std::vector<T> meanX, scaleX;   // host copies for recover()
     T meanY = 0, scaleY = 1;
     double t_h2d = 0, t_std = 0;
+    // Filled by upload_standardize_gram_f32 only: X'X of the standardised data (both triangles), leading dimension and
+    // allocated columns round_up(p, 128), zero padded; the seconds of Gram work left after the last byte arrived.
+    DevBuf<T> gram;
+    long long ldgram = 0;
+    double t_gram_tail = 0;
 };
 
 // Convert the caller's double column-major x (n x p, ld n) and y to T on the device and apply
@@ -26,6 +31,13 @@ struct DeviceData {
 template <typename T>
 void upload_standardize(DeviceData<T>& d, const double* x, const double* y, int n, int p, int mem,
                         bool standardize, bool intercept, hipStream_t st, long long n_total = 0);
+
+// Host-input variant for the tall fp32 path: the same conversion and standardisation, column chunk by column chunk,
+// with the Gram block row of every chunk (it only needs the chunks that have already arrived) enqueued behind it, so
+// that standardisation and X'X run under the PCIe transfer instead of after it.  Results are bit-identical to
+// upload_standardize + the one-shot matrix-core Gram.
+void upload_standardize_gram_f32(DeviceData<float>& d, const double* x, const double* y, int n, int p,
+                                 bool standardize, bool intercept, hipStream_t st);
 
 // DataStd::recover (DataStd.h:157-207) on a host coefficient vector (length p) in precision T.
 template <typename T>

@@ -211,6 +211,110 @@ void upload_standardize(DeviceData<T>& d, const double* x, const double* y, int 
 template void upload_standardize<float>(DeviceData<float>&, const double*, const double*, int, int, int, bool, bool, hipStream_t, long long);
 template void upload_standardize<double>(DeviceData<double>&, const double*, const double*, int, int, int, bool, bool, hipStream_t, long long);
 
+void gram_rows_mfma_f32(const float* Z, long long ldz, int r0, int nr, int K, float* C, long long ldc, hipStream_t st);   // syrk_mfma.hip
+
+void upload_standardize_gram_f32(DeviceData<float>& d, const double* x, const double* y, int n, int p,
+                                 bool standardize, bool intercept, hipStream_t st) {
+    using T = float;
+    d.n = n; d.p = p; d.n_total = n;
+    d.flag = int(standardize) + 2 * int(intercept);
+    d.ldx = round_up(n, 32);
+    d.X.alloc((size_t)d.ldx * p);
+    d.Y.alloc((size_t)d.ldx);
+    d.X.zero(st);
+    d.Y.zero(st);
+    const long long ldz = round_up(p, 128);
+    const int nk = (int)round_up(n, 16);
+    DevBuf<float> Z((size_t)ldz * nk);            // X' (output index contiguous), the operand of the matrix-core Gram
+    Z.zero(st);
+    d.ldgram = ldz;
+    d.gram.alloc((size_t)ldz * ldz);
+    d.gram.zero(st);
+    const int ny = std::max(1, std::min(64, (n + 255) / 256));
+    const int cnt = p + 1;
+    DevBuf<double> stat(cnt);
+    DevBuf<T> mean(cnt), scale(cnt), inv(cnt);
+    const double t0 = now_s();
+    double th = 0;
+    auto standardise_cols = [&](int c0, int nc, bool is_y, hipStream_t st) {       // columns [c0, c0 + nc) of X, or y (statistic index p)
+        if (d.flag == 0) return;
+        T* Xc = d.X.get() + (size_t)c0 * d.ldx;
+        const int idx = is_y ? p : c0, np_ = is_y ? 0 : nc, nb = is_y ? 1 : nc;
+        hipLaunchKernelGGL((colstat_kernel<T, 0>), dim3(nb), dim3(256), 0, st, Xc, d.ldx, d.Y.get(), n, np_, mean.get() + idx, stat.get() + idx);
+        hipLaunchKernelGGL((finish_mean_kernel<T>), dim3((nb + 255) / 256), dim3(256), 0, st, stat.get() + idx, (double)n, nb, mean.get() + idx);
+        hipLaunchKernelGGL((colstat_kernel<T, 1>), dim3(nb), dim3(256), 0, st, Xc, d.ldx, d.Y.get(), n, np_, mean.get() + idx, stat.get() + idx);
+        hipLaunchKernelGGL((finish_scale_kernel<T>), dim3((nb + 255) / 256), dim3(256), 0, st, stat.get() + idx, (double)n, nb, scale.get() + idx, inv.get() + idx);
+        hipLaunchKernelGGL((apply_std_kernel<T>), dim3(nb, ny), dim3(256), 0, st, Xc, d.ldx, d.Y.get(), n, np_, d.flag,
+                           mean.get() + idx, scale.get() + idx, inv.get() + idx);
+    };
+    // y first
+    {
+        DevBuf<double> ystage(n);
+        double t1 = now_s();
+        ADMM_HIP_CHECK(hipMemcpy(ystage.get(), y, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+        th += now_s() - t1;
+        hipLaunchKernelGGL((convert_cols_kernel<T>), dim3(1, ny), dim3(256), 0, st, ystage.get(), (long long)n, n, d.Y.get(), d.ldx);
+        standardise_cols(0, 0, true, st);
+        ADMM_HIP_CHECK(hipStreamSynchronize(st));
+    }
+    // x: chunks of whole 128-column blocks (about 400 MB) through two staging buffers.  Chunks alternate between two
+    // streams so that the block rows of consecutive chunks (each too few tiles to fill the chip) overlap when the GPU
+    // lags behind the copies: the work that arrives with a chunk grows linearly with its position.
+    int cols_per_chunk = (int)(((size_t)400 << 20) / ((size_t)n * sizeof(double)));
+    cols_per_chunk = std::max(128, cols_per_chunk / 128 * 128);
+    DevBuf<double> stage[2];
+    stage[0].alloc((size_t)cols_per_chunk * n);
+    stage[1].alloc((size_t)cols_per_chunk * n);
+    Stream aux;
+    const hipStream_t sq[2] = {st, aux.s};
+    Event ev[2], evT[2], ev0;
+    bool used[2] = {false, false};
+    ADMM_HIP_CHECK(hipEventRecord(ev0.e, st));                     // zero fills / y above
+    ADMM_HIP_CHECK(hipStreamWaitEvent(aux.s, ev0.e, 0));
+    int b = 0;
+    for (int c0 = 0; c0 < p; c0 += cols_per_chunk, b ^= 1) {
+        const int nc = std::min(cols_per_chunk, p - c0);
+        const hipStream_t s = sq[b];
+        if (used[b]) ADMM_HIP_CHECK(hipEventSynchronize(ev[b].e));
+        double t1 = now_s();
+        ADMM_HIP_CHECK(hipMemcpy(stage[b].get(), x + (size_t)c0 * n, (size_t)nc * n * sizeof(double), hipMemcpyHostToDevice));
+        th += now_s() - t1;
+        hipLaunchKernelGGL((convert_cols_kernel<T>), dim3(nc, ny), dim3(256), 0, s, stage[b].get(), (long long)n, n,
+                           d.X.get() + (size_t)c0 * d.ldx, d.ldx);
+        ADMM_HIP_CHECK(hipEventRecord(ev[b].e, s));               // the staging buffer is free once the conversion has read it
+        used[b] = true;
+        standardise_cols(c0, nc, false, s);
+        transpose<float>(d.X.get() + (size_t)c0 * d.ldx, d.ldx, n, nc, Z.get() + c0, ldz, s);
+        ADMM_HIP_CHECK(hipEventRecord(evT[b].e, s));
+        // rows of Z of every earlier chunk: the even ones are ordered by this stream, the odd ones by the other's event
+        if (c0 > 0) ADMM_HIP_CHECK(hipStreamWaitEvent(s, evT[b ^ 1].e, 0));
+        gram_rows_mfma_f32(Z.get(), ldz, c0, nc, nk, d.gram.get(), ldz, s);
+    }
+    {
+        Event done;
+        ADMM_HIP_CHECK(hipEventRecord(done.e, aux.s));
+        ADMM_HIP_CHECK(hipStreamWaitEvent(st, done.e, 0));
+    }
+    const double t_last = now_s();
+    symmetrize_from_lower<float>(d.gram.get(), ldz, p, st);
+    d.meanX.assign(p, T(0));
+    d.scaleX.assign(p, T(1));
+    d.meanY = T(0); d.scaleY = T(1);
+    if (d.flag != 0) {
+        std::vector<T> hm(cnt), hs(cnt);
+        ADMM_HIP_CHECK(hipMemcpyAsync(hm.data(), mean.get(), cnt * sizeof(T), hipMemcpyDeviceToHost, st));
+        ADMM_HIP_CHECK(hipMemcpyAsync(hs.data(), scale.get(), cnt * sizeof(T), hipMemcpyDeviceToHost, st));
+        ADMM_HIP_CHECK(hipStreamSynchronize(st));
+        if (d.flag & 2) { for (int j = 0; j < p; ++j) d.meanX[j] = hm[j]; d.meanY = hm[p]; }
+        if (d.flag & 1) for (int j = 0; j < p; ++j) d.scaleX[j] = hs[j];
+        d.scaleY = hs[p];
+    }
+    ADMM_HIP_CHECK(hipStreamSynchronize(st));
+    d.t_gram_tail = now_s() - t_last;
+    d.t_h2d = th;
+    d.t_std = t_last - t0 - th;                    // host time between copies (launch overhead; the kernels overlap the copies)
+}
+
 template <typename T>
 void recover_coef(const DeviceData<T>& d, const T* coef, T* beta0, T* out) {
     const int p = d.p;

@@ -217,6 +217,13 @@ void gram_mfma_f32(const float* A, long long lda, int rows, int cols, bool atA, 
     ADMM_HIP_CHECK(hipStreamSynchronize(st));
 }
 
+// Block row of a Gram matrix, for the pipelined host-input setup: C[r0 : r0 + nr, 0 : r0 + nr] = Z[r0 : r0 + nr, :] Z[0 : r0 + nr, :]'
+// (Z with the output index contiguous, K a multiple of 16, r0 a multiple of 4, rows readable up to the next multiple of
+// 128 past r0 + nr).  Same K order per element as the one-shot Gram: bit-identical values.
+void gram_rows_mfma_f32(const float* Z, long long ldz, int r0, int nr, int K, float* C, long long ldc, hipStream_t st) {
+    launch_gemm_nt(false, Z + r0, ldz, Z, ldz, C + r0, ldc, nr, r0 + nr, K, 1.f, 0.f, false, false, st);
+}
+
 // ---------------------------------------------------------------------------------------------- Cholesky of a diagonal block
 // One workgroup: Cholesky of the nbk x nbk diagonal block (nbk <= 128), written back in place (lower), plus
 // the inverse of the factor into Dinv (128 x 128, zeros above the diagonal; rows/cols beyond nbk form an

@@ -76,3 +76,26 @@ def test_fp64_mfma_gram_matches_library_gram_in_lad_and_bp():
     assert lad.niter == lad_ref.niter == 26 and bp.niter == bp_ref.niter == 26
     assert relerr(lad.beta, lad_ref.beta) < 1e-9
     assert relerr(bp.beta.toarray().ravel(), bp_ref.beta.toarray().ravel()) < 1e-9
+
+
+@pytest.mark.parametrize("flags", [(True, True), (True, False), (False, True), (False, False)])
+def test_pipelined_host_input_setup_is_bit_identical(flags):
+    """Host input with p >= 4096: conversion, standardisation and the Gram block rows run chunk by chunk under the
+    host-to-device transfer.  ADMM_HIP_GRAM=oneshot takes the sequential path; both must agree bit for bit
+    (p = 4200: ragged last 128-block and, with the 128-column minimum chunk, 33 chunks)."""
+    from admm_amd import admm_lasso
+    standardize, intercept = flags
+    rng = np.random.default_rng(83)
+    n, p = 4300, 4200
+    x = rng.standard_normal((n, p)) * 1.5 + 0.3
+    y = x[:, :20] @ rng.uniform(size=20) + rng.standard_normal(n)
+    lam = [0.2, 0.05]
+    os.environ["ADMM_HIP_GRAM"] = "oneshot"
+    try:
+        ref = admm_lasso(x, y, intercept, standardize).penalty(lam).opts(maxit=200).fit()
+    finally:
+        del os.environ["ADMM_HIP_GRAM"]
+    fit = admm_lasso(x, y, intercept, standardize).penalty(lam).opts(maxit=200).fit()
+    assert fit.stats["rho"] == ref.stats["rho"]
+    assert np.array_equal(fit.niter, ref.niter)
+    assert np.array_equal(fit.beta_dense, ref.beta_dense)
