@@ -22,7 +22,7 @@
 //    (An earlier version used x = Minv u' + tau Minv w' with u' = X'y - y + rho z: equal in exact
 //    arithmetic, but it bypasses the float rounding of the right-hand side, and with it the dead
 //    band that lets the reference's stopping rule fire when rho * ulp(z) exceeds eps_dual -- tiny
-//    lambda, unstandardised data.  scripts/fuzz_parity.py found paths running to maxit.)
+//    lambda, unstandardised data.  tests/tools/fuzz_parity.py found paths running to maxit.)
 //  * Minv is symmetric: for p >= 2048 the x-update reads only its lower triangle (symv_kernels.h,
 //    2p^2 bytes); small problems use the full-matrix gemv_t (fewer, larger workgroups).
 //  * Convergence test, acceleration scalars, the lambda schedule (init_warm), niter[] and the

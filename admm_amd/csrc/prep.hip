@@ -491,7 +491,7 @@ __global__ void __launch_bounds__(256) mirror_lower_kernel(const T* __restrict__
 
 // Symmetric inverse of an SPD matrix: potrf, then X = L^-T (L^-1 I) by two triangular solves.
 // (rocSOLVER's potri is not used: on this ROCm its small-size path returned a NaN in the last diagonal
-//  element when the handle's workspace had been used by an fp64 call before -- scripts/fuzz_parity.py.)
+//  element when the handle's workspace had been used by an fp64 call before -- tests/tools/fuzz_parity.py.)
 template <typename T>
 void spd_inverse_full(T* A, long long lda, int n, hipStream_t st) {
     cholesky_lower<T>(A, lda, n, st);

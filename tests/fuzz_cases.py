@@ -1,5 +1,5 @@
 """Deterministic stream of small random problems for the five entry points (used by test_gpu_fuzz.py and
-scripts/fuzz_parity.py).  All random draws happen here, so case c of (ncases, seed) is reproducible on its own."""
+tests/tools/fuzz_parity.py).  All random draws happen here, so case c of (ncases, seed) is reproducible on its own."""
 import numpy as np
 
 

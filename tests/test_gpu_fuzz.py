@@ -1,5 +1,5 @@
 """GPU: randomised small problems through all five entry points vs the oracle, plus the two regressions the
-sweep found (scripts/fuzz_parity.py is the verbose version of the same sweep).
+sweep found (tests/tools/fuzz_parity.py is the verbose version of the same sweep).
 
 Acceptance per case: beta within 1e-3 (norm-wise, null columns measured on the scale of the path) OR the
 iteration counts differ by more than 2 -- ADMM's stopping rule and the rho adaptation take discrete decisions,

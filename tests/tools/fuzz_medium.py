@@ -1,7 +1,7 @@
 """Dev tool (GPU box): medium-size randomised parity sweep of the Lasso family (matrix-core setup, symmetric
-x-update, consensus with several blocks, random maxit / eps / rho).   python scripts/fuzz_medium.py [ncases] [seed]"""
+x-update, consensus with several blocks, random maxit / eps / rho).   python tests/tools/fuzz_medium.py [ncases] [seed]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: F401
 import numpy as np

@@ -1,8 +1,8 @@
 """Dev tool (GPU box): randomised parity sweep of the five entry points against the oracle on small problems.
 Prints one line per case; a case is SUSPECT when beta differs by > 1e-3 although the iteration counts agree
-(a count flip explains a larger difference: the stopping rule is loose).   python scripts/fuzz_parity.py [ncases] [seed]"""
+(a count flip explains a larger difference: the stopping rule is loose).   python tests/tools/fuzz_parity.py [ncases] [seed]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: F401  (one HIP runtime per process)
