@@ -228,20 +228,26 @@ int env_batch(int dflt) {
 
 }  // namespace
 
+__global__ void __launch_bounds__(256) copy_cols_f64_kernel(const double* __restrict__ in, long long ldi, int rows, double* __restrict__ out, long long ldo) {
+    const int c = blockIdx.y;
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r < rows) out[(size_t)c * ldo + r] = in[(size_t)c * ldi + r];
+}
+
 // ---------------------------------------------------------------------------------------------- LAD
 void solve_lad(const DeviceData<double>& d, const admm_opts& opts, DenseResult& res, hipStream_t st) {
     const int n = d.n, p = d.p;
     admm_stats& S = res.stats;
-    const long long ldp = round_up(p, 32);
+    const long long ldp = round_up(p, 128);                // whole 128-blocks for the matrix-core inverse
 
     // X'X, its inverse (LLT of X'X in the reference, ADMMLAD.h:186-189), X' stored for the X*s product
     double t0 = now_s();
-    DevBuf<double> M((size_t)ldp * p); M.zero(st);
+    DevBuf<double> M((size_t)ldp * ldp); M.zero(st);
     gram_full<double>(d.X.get(), d.ldx, n, p, true, M.get(), ldp, st);
     ADMM_HIP_CHECK(hipStreamSynchronize(st));
     S.t_gram = now_s() - t0;
     t0 = now_s();
-    spd_inverse_full<double>(M.get(), ldp, p, st);
+    spd_inverse_f64(M.get(), ldp, p, st);
     const long long ldxt = round_up(p, 32);
     DevBuf<double> Xt((size_t)ldxt * n); Xt.zero(st);
     transpose<double>(d.X.get(), d.ldx, n, p, Xt.get(), ldxt, st);
@@ -295,26 +301,47 @@ void solve_lad(const DeviceData<double>& d, const admm_opts& opts, DenseResult& 
 void solve_bp(const DeviceData<double>& d, const admm_opts& opts, DenseResult& res, hipStream_t st) {
     const int n = d.n, p = d.p;
     admm_stats& S = res.stats;
-    const long long ldn = round_up(n, 32);
+    const long long ldn = round_up(n, 128);                // whole 128-blocks for the matrix-core factorisation
 
     // AA' = LL' (ADMMBP.h:167-169)
     double t0 = now_s();
-    DevBuf<double> G((size_t)ldn * n); G.zero(st);
+    DevBuf<double> G((size_t)ldn * ldn); G.zero(st);
     gram_full<double>(d.X.get(), d.ldx, n, p, false, G.get(), ldn, st);
     ADMM_HIP_CHECK(hipStreamSynchronize(st));
     S.t_gram = now_s() - t0;
     t0 = now_s();
-    cholesky_lower<double>(G.get(), ldn, n, st);
     // B = L^-1 A (ADMMBP.h:173-182) and its transpose; w0 = L^-1 b; cache_AAAb = B' w0 = A'(AA')^-1 b (:170)
     DevBuf<double> B((size_t)d.ldx * p);
-    ADMM_HIP_CHECK(hipMemcpyAsync(B.get(), d.X.get(), (size_t)d.ldx * p * sizeof(double), hipMemcpyDeviceToDevice, st));
-    trsm_left_lower<double>(G.get(), ldn, n, B.get(), d.ldx, p, st);
-    DevBuf<double> w0(d.ldx);
-    ADMM_HIP_CHECK(hipMemcpyAsync(w0.get(), d.Y.get(), (size_t)d.ldx * sizeof(double), hipMemcpyDeviceToDevice, st));
-    trsm_left_lower<double>(G.get(), ldn, n, w0.get(), d.ldx, 1, st);
+    DevBuf<double> w0(d.ldx); w0.zero(st);
     const long long ldbt = round_up(p, 32);
     DevBuf<double> Bt((size_t)ldbt * n); Bt.zero(st);
-    transpose<double>(B.get(), d.ldx, n, p, Bt.get(), ldbt, st);
+    const char* efac = std::getenv("ADMM_HIP_FACTOR");
+    if (efac && std::string(efac) == "rocsolver") {
+        cholesky_lower<double>(G.get(), ldn, n, st);
+        ADMM_HIP_CHECK(hipMemcpyAsync(B.get(), d.X.get(), (size_t)d.ldx * p * sizeof(double), hipMemcpyDeviceToDevice, st));
+        trsm_left_lower<double>(G.get(), ldn, n, B.get(), d.ldx, p, st);
+        ADMM_HIP_CHECK(hipMemcpyAsync(w0.get(), d.Y.get(), (size_t)d.ldx * sizeof(double), hipMemcpyDeviceToDevice, st));
+        trsm_left_lower<double>(G.get(), ldn, n, w0.get(), d.ldx, 1, st);
+        transpose<double>(B.get(), d.ldx, n, p, Bt.get(), ldbt, st);
+    } else {
+        // hand-written matrix-core path: blocked Cholesky fused with U = L^-T; then B' = A' U is one NT product
+        // (B'[j, i] = sum_k A'[j, k] W[i, k] with W = U' = L^-1), B its transpose, w0 = U' b
+        DevBuf<double> U = cholesky_linvt_mfma_f64(G.get(), ldn, n, st);
+        const int nk = (int)round_up(n, 8);
+        const long long ldxt = round_up(p, 128);
+        DevBuf<double> Xt((size_t)ldxt * nk), W((size_t)ldn * ldn);
+        Xt.zero(st);
+        transpose<double>(d.X.get(), d.ldx, n, p, Xt.get(), ldxt, st);           // A' (p x n), output index contiguous
+        transpose<double>(U.get(), ldn, (int)ldn, (int)ldn, W.get(), ldn, st);    // W = L^-1, zero padded
+        DevBuf<double> Btp((size_t)ldxt * n);                                     // B' with whole 128-row blocks
+        gemm_nt_f64(Xt.get(), ldxt, W.get(), ldn, Btp.get(), ldxt, p, n, nk, st);
+        hipLaunchKernelGGL(copy_cols_f64_kernel, dim3((p + 255) / 256, n), dim3(256), 0, st, Btp.get(), ldxt, p, Bt.get(), ldbt);
+        transpose<double>(Bt.get(), ldbt, p, n, B.get(), d.ldx, st);
+        GemvT<double> gU;                                                         // w0 = U' b
+        gU.init(U.get(), ldn, n, n);
+        gU.run(d.Y.get(), w0.get(), nullptr, st);
+        ADMM_HIP_CHECK(hipStreamSynchronize(st));                                 // temporaries are released here
+    }
     const long long ldp = round_up(p, 32);
     DevBuf<double> AAAb(ldp); AAAb.zero(st);
     GemvT<double> gB, gBt;                       // t = B' w (p outputs) ; w = B vec (n outputs, via the stored transpose)

@@ -3,13 +3,14 @@
 // Replaces (reference):  Linalg::cross_prod_lower / tcross_prod_lower  BlasWrapper.h:73-152
 //   (called from ADMMLAD.h:186-190 and ADMMBP.h:167-170), single-threaded Eigen there.
 //
-// C = Z Z' on 128 x 128 lower tiles (+ mirrored store), Z stored with the OUTPUT index contiguous (Z[i, k] at
+// Gram: C = Z Z' on 128 x 128 lower tiles (+ mirrored store), Z stored with the OUTPUT index contiguous (Z[i, k] at
 // i + k ldz), so for a fixed summation index k both factors are contiguous 1 KiB rows.  A workgroup = 4 waves
 // (2 x 2), each wave 64 x 64 = 4 x 4 tiles of v_mfma_f64_16x16x4_f64 (32 FLOP/clk/SIMD: the 78.6 TF/s fp64
 // matrix peak).  K tiles of 8 go global -> registers -> LDS, double buffered; rows are padded by 8 doubles so
 // that the fragment reads (16 consecutive doubles from each of 4 k-rows) touch every bank exactly twice.
 // fp64 matrix work is so compute dense (one 64-cycle MFMA per 16-byte LDS read) that nothing else matters.
 #include "prep.h"
+#include "chol_inverse.h"
 
 namespace admm {
 
@@ -21,10 +22,14 @@ constexpr int DK_LD = DK_BM + 8;
 constexpr int DK_THREADS = 256;
 
 struct GemmNTd {
-    const double* A; long long lda;      // operands readable for rows < round_up(M, 128), columns < K (K multiple of 8)
+    const double* A; long long lda;      // operands readable for rows < round_up(M / N, 128), columns < K (K multiple of 8)
+    const double* B; long long ldb;
     double* C; long long ldc;
-    int M, K;
-    int nb, ntiles;
+    int M, N, K;
+    double alpha, beta;
+    int nbi, nbj, ntiles;
+    int mirror;                          // LOWER mode: also store the transposed tile (both triangles)
+    int kstart_row;                      // start the K loop at the tile's first row (A, B upper triangular)
 };
 
 __device__ __forceinline__ void tri_decode_d(int t, int& bi, int& bj) {
@@ -34,15 +39,17 @@ __device__ __forceinline__ void tri_decode_d(int t, int& bi, int& bj) {
     bi = b; bj = t - b * (b + 1) / 2;
 }
 
-// C = A A' (lower tiles, mirrored so that both triangles are stored)
+// C = alpha A B' + beta C on 128 x 128 tiles (LOWER: only tiles on or below the diagonal of a square C)
+template <int LOWER>
 __global__ void __launch_bounds__(DK_THREADS, 2)
-syrk_lower_mfma_f64_kernel(GemmNTd g) {
-    __shared__ __attribute__((aligned(16))) double lds[2][2][DK_BK][DK_LD];      // [buffer][row panel / column panel][k][i]
+gemm_nt_mfma_f64_kernel(GemmNTd g) {
+    __shared__ __attribute__((aligned(16))) double lds[2][2][DK_BK][DK_LD];      // [buffer][A / B][k][i]
     const int per = (g.ntiles + 7) / 8;                                           // XCD b % 8 walks a contiguous range of tiles
     const int t_idx = (blockIdx.x % 8) * per + blockIdx.x / 8;
     if (t_idx >= g.ntiles) return;
     int bi, bj;
-    tri_decode_d(t_idx, bi, bj);
+    if (LOWER) tri_decode_d(t_idx, bi, bj);
+    else { bi = t_idx % g.nbi; bj = t_idx / g.nbi; }
     const int I0 = bi * DK_BM, J0 = bj * DK_BM;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wi = (wid >> 1) * 64, wj = (wid & 1) * 64;
@@ -51,8 +58,8 @@ syrk_lower_mfma_f64_kernel(GemmNTd g) {
     const int s_row0 = tid >> 6;              // 0..3, second load +4
     const int s_col = (tid & 63) * 2;
     const double* gA = g.A + (size_t)s_row0 * g.lda + I0 + s_col;
-    const double* gB = g.A + (size_t)s_row0 * g.lda + J0 + s_col;
-    const size_t r4 = (size_t)4 * g.lda;
+    const double* gB = g.B + (size_t)s_row0 * g.ldb + J0 + s_col;
+    const size_t a4 = (size_t)4 * g.lda, b4 = (size_t)4 * g.ldb;
 
     doublex4 acc[4][4];
 #pragma unroll
@@ -65,9 +72,9 @@ syrk_lower_mfma_f64_kernel(GemmNTd g) {
     double2 ra0, ra1, rb0, rb1;
     auto gload = [&](int k0) {
         ra0 = *reinterpret_cast<const double2*>(gA + (size_t)k0 * g.lda);
-        ra1 = *reinterpret_cast<const double2*>(gA + (size_t)k0 * g.lda + r4);
-        rb0 = *reinterpret_cast<const double2*>(gB + (size_t)k0 * g.lda);
-        rb1 = *reinterpret_cast<const double2*>(gB + (size_t)k0 * g.lda + r4);
+        ra1 = *reinterpret_cast<const double2*>(gA + (size_t)k0 * g.lda + a4);
+        rb0 = *reinterpret_cast<const double2*>(gB + (size_t)k0 * g.ldb);
+        rb1 = *reinterpret_cast<const double2*>(gB + (size_t)k0 * g.ldb + b4);
     };
     auto lstore = [&](int buf) {
         *reinterpret_cast<double2*>(&lds[buf][0][s_row0][s_col]) = ra0;
@@ -76,31 +83,34 @@ syrk_lower_mfma_f64_kernel(GemmNTd g) {
         *reinterpret_cast<double2*>(&lds[buf][1][s_row0 + 4][s_col]) = rb1;
     };
 
-    const int ntile_k = g.K / DK_BK;
+    const int kbeg = g.kstart_row ? (max(I0, J0) / DK_BK) * DK_BK : 0;
+    const int ntile_k = (g.K - kbeg) / DK_BK;
     const int fk = lane >> 4, fi = lane & 15;            // A / B fragment: one f64 per lane, [i = lane & 15][k = lane >> 4]
-    gload(0);
-    lstore(0);
-    __syncthreads();
-    for (int kt = 0; kt < ntile_k; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < ntile_k) gload((kt + 1) * DK_BK);
+    if (ntile_k > 0) {
+        gload(kbeg);
+        lstore(0);
+        __syncthreads();
+        for (int kt = 0; kt < ntile_k; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < ntile_k) gload(kbeg + (kt + 1) * DK_BK);
 #pragma unroll
-        for (int kk = 0; kk < DK_BK; kk += 4) {
-            double af[4], bf[4];
+            for (int kk = 0; kk < DK_BK; kk += 4) {
+                double af[4], bf[4];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                af[m] = lds[buf][0][kk + fk][wi + 16 * m + fi];
-                bf[m] = lds[buf][1][kk + fk][wj + 16 * m + fi];
+                for (int m = 0; m < 4; ++m) {
+                    af[m] = lds[buf][0][kk + fk][wi + 16 * m + fi];
+                    bf[m] = lds[buf][1][kk + fk][wj + 16 * m + fi];
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
             }
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
-        }
-        if (kt + 1 < ntile_k) {
-            lstore(buf ^ 1);
-            __syncthreads();
+            if (kt + 1 < ntile_k) {
+                lstore(buf ^ 1);
+                __syncthreads();
+            }
         }
     }
 
@@ -114,13 +124,28 @@ syrk_lower_mfma_f64_kernel(GemmNTd g) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = I0 + wi + 16 * a + (lane >> 4) + 4 * r;
-                if (row < g.M && col < g.M) {
-                    const double v = acc[a][b][r];
-                    g.C[(size_t)col * g.ldc + row] = v;
-                    if (offdiag) g.C[(size_t)row * g.ldc + col] = v;
+                if (row < g.M && col < g.N) {
+                    double v = g.alpha * acc[a][b][r];
+                    double* dst = g.C + (size_t)col * g.ldc + row;
+                    if (g.beta != 0.0) v += g.beta * *dst;
+                    *dst = v;
+                    if (LOWER && g.mirror && offdiag) g.C[(size_t)row * g.ldc + col] = v;
                 }
             }
         }
+}
+
+static void launch_gemm_nt_f64(bool lower, const double* A, long long lda, const double* B, long long ldb, double* C, long long ldc,
+                               int M, int N, int K, double alpha, double beta, bool mirror, bool kstart_row, hipStream_t st) {
+    if (M <= 0 || N <= 0) return;
+    GemmNTd g;
+    g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+    g.alpha = alpha; g.beta = beta; g.mirror = mirror ? 1 : 0; g.kstart_row = kstart_row ? 1 : 0;
+    g.nbi = (M + DK_BM - 1) / DK_BM; g.nbj = (N + DK_BM - 1) / DK_BM;
+    g.ntiles = lower ? g.nbi * (g.nbi + 1) / 2 : g.nbi * g.nbj;
+    const int grid = (g.ntiles + 7) / 8 * 8;
+    if (lower) hipLaunchKernelGGL(gemm_nt_mfma_f64_kernel<1>, dim3(grid), dim3(DK_THREADS), 0, st, g);
+    else hipLaunchKernelGGL(gemm_nt_mfma_f64_kernel<0>, dim3(grid), dim3(DK_THREADS), 0, st, g);
 }
 
 template <bool TRANSPOSE>
@@ -158,13 +183,26 @@ void gram_mfma_f64(const double* A, long long lda, int rows, int cols, bool atA,
     Z.zero(st);
     if (atA) hipLaunchKernelGGL((pad_copy_f64_kernel<true>), dim3((rows + 31) / 32, (cols + 31) / 32), dim3(256), 0, st, A, lda, rows, cols, Z.get(), ldz);
     else hipLaunchKernelGGL((pad_copy_f64_kernel<false>), dim3((rows + 31) / 32, (cols + 31) / 32), dim3(256), 0, st, A, lda, rows, cols, Z.get(), ldz);
-    GemmNTd g;
-    g.A = Z.get(); g.lda = ldz; g.C = C; g.ldc = ldc; g.M = M; g.K = K;
-    g.nb = (M + DK_BM - 1) / DK_BM; g.ntiles = g.nb * (g.nb + 1) / 2;
-    const int grid = (g.ntiles + 7) / 8 * 8;
-    hipLaunchKernelGGL(syrk_lower_mfma_f64_kernel, dim3(grid), dim3(DK_THREADS), 0, st, g);
+    launch_gemm_nt_f64(true, Z.get(), ldz, Z.get(), ldz, C, ldc, M, M, K, 1.0, 0.0, true, false, st);
     ADMM_HIP_CHECK(hipGetLastError());
     ADMM_HIP_CHECK(hipStreamSynchronize(st));     // Z is freed on return
+}
+
+// ---------------------------------------------------------------------------------------------- Cholesky + inverse (chol_inverse.h)
+// A (lda >= round_up(n, 128), that many zero-padded columns allocated) -> A^-1, both triangles.
+void spd_inverse_mfma_f64(double* A, long long lda, int n, hipStream_t st) {
+    spd_inverse_blocked<double>(A, lda, n, st, launch_gemm_nt_f64);
+}
+
+// A -> Cholesky factor L (lower triangle) in place; returns U = L^-T (lda x round_up(n, 128), upper triangular).
+DevBuf<double> cholesky_linvt_mfma_f64(double* A, long long lda, int n, hipStream_t st) {
+    return cholesky_linvt_blocked<double>(A, lda, n, st, launch_gemm_nt_f64);
+}
+
+// C (M x N, ldc) = A B' for operands with the output index contiguous (rows readable up to the next multiple of 128,
+// K a multiple of 8).
+void gemm_nt_f64(const double* A, long long lda, const double* B, long long ldb, double* C, long long ldc, int M, int N, int K, hipStream_t st) {
+    launch_gemm_nt_f64(false, A, lda, B, ldb, C, ldc, M, N, K, 1.0, 0.0, false, false, st);
 }
 
 }  // namespace admm

@@ -62,6 +62,13 @@ void spd_inverse_mfma_f32(float* A, long long lda, int n, hipStream_t st);
 // fp32 SPD inverse of a matrix stored in whole 128-blocks (lda >= round_up(n, 128), that many zero-padded columns
 // allocated): hand-written matrix-core kernels for n >= 256, potrf + two trsm below (ADMM_HIP_FACTOR=rocsolver forces the latter).
 void spd_inverse_f32(float* A, long long lda, int n, hipStream_t st);
+// fp64 counterparts (gemm_f64_mfma.hip); same storage requirements.
+void spd_inverse_mfma_f64(double* A, long long lda, int n, hipStream_t st);
+void spd_inverse_f64(double* A, long long lda, int n, hipStream_t st);
+// A -> Cholesky factor L in place (lower); returns U = L^-T (lda x round_up(n, 128), upper triangular, zero padded).
+DevBuf<double> cholesky_linvt_mfma_f64(double* A, long long lda, int n, hipStream_t st);
+// C (M x N) = A B' for operands with the output index contiguous (rows readable up to the next multiple of 128, K % 8 == 0).
+void gemm_nt_f64(const double* A, long long lda, const double* B, long long ldb, double* C, long long ldc, int M, int N, int K, hipStream_t st);
 // In place Cholesky (lower). Throws ADMM_ERR_NOT_SPD.
 template <typename T>
 void cholesky_lower(T* A, long long lda, int n, hipStream_t st);

@@ -414,24 +414,15 @@ void gram_mfma_f64(const double* A, long long lda, int rows, int cols, bool atA,
 
 template <typename T>
 void gram_full(const T* A, long long lda, int rows, int cols, bool atA, T* C, long long ldc, hipStream_t st) {
-    if constexpr (std::is_same<T, float>::value) {
-        // hand-written matrix-core kernel (split-K when the triangle has few tiles) once the product is big enough to
-        // pay for the padded operand copy; ADMM_HIP_GRAM=rocblas forces the library path
+    // hand-written matrix-core kernels (fp32: split-K when the triangle has few tiles; fp64) for every size, so that no
+    // BLAS handle is ever created in a default run (rocBLAS handle creation alone costs 0.1-0.2 s per process);
+    // ADMM_HIP_GRAM=rocblas forces the library path (A/B tests)
+    {
         const char* e = std::getenv("ADMM_HIP_GRAM");
         const bool force_lib = e && std::string(e) == "rocblas";
-        const double order = atA ? cols : rows, len = atA ? rows : cols;
-        if (!force_lib && order >= 128 && order * order * len >= 2e9) {
-            gram_mfma_f32(A, lda, rows, cols, atA, C, ldc, st);
-            return;
-        }
-    }
-    if constexpr (std::is_same<T, double>::value) {
-        // LAD / BP setup: hand-written fp64 matrix-core kernel once there are enough 128x128 tiles
-        const char* e = std::getenv("ADMM_HIP_GRAM");
-        const bool force_lib = e && std::string(e) == "rocblas";
-        const long long nb = ((atA ? cols : rows) + 127) / 128;
-        if (!force_lib && nb * (nb + 1) / 2 >= 128) {
-            gram_mfma_f64(A, lda, rows, cols, atA, C, ldc, st);
+        if (!force_lib) {
+            if constexpr (std::is_same<T, float>::value) gram_mfma_f32(A, lda, rows, cols, atA, C, ldc, st);
+            else gram_mfma_f64(A, lda, rows, cols, atA, C, ldc, st);
             return;
         }
     }
@@ -519,8 +510,14 @@ template void spd_inverse_full<float>(float*, long long, int, hipStream_t);
 
 void spd_inverse_f32(float* A, long long lda, int n, hipStream_t st) {
     const char* e = std::getenv("ADMM_HIP_FACTOR");
-    if ((e && std::string(e) == "rocsolver") || n < 256 || lda < round_up(n, 128)) spd_inverse_full<float>(A, lda, n, st);
+    if ((e && std::string(e) == "rocsolver") || lda < round_up(n, 128)) spd_inverse_full<float>(A, lda, n, st);
     else spd_inverse_mfma_f32(A, lda, n, st);
+}
+
+void spd_inverse_f64(double* A, long long lda, int n, hipStream_t st) {
+    const char* e = std::getenv("ADMM_HIP_FACTOR");
+    if ((e && std::string(e) == "rocsolver") || lda < round_up(n, 128)) spd_inverse_full<double>(A, lda, n, st);
+    else spd_inverse_mfma_f64(A, lda, n, st);
 }
 template void spd_inverse_full<double>(double*, long long, int, hipStream_t);
 

@@ -24,6 +24,7 @@
 //              U is upper triangular).
 // No rocBLAS / rocSOLVER on this path (their handle creation alone costs 0.1-0.2 s per process).
 #include "prep.h"
+#include "chol_inverse.h"
 
 namespace admm {
 
@@ -165,6 +166,11 @@ static void launch_gemm_nt(bool lower, const float* A, long long lda, const floa
     else hipLaunchKernelGGL(gemm_nt_mfma_kernel<0>, dim3(grid), dim3(SK_THREADS), 0, st, g);
 }
 
+static void launch_gemm_nt_f32(bool lower, const float* A, long long lda, const float* B, long long ldb, float* C, long long ldc,
+                               int M, int N, int K, float alpha, float beta, bool mirror, bool kstart_row, hipStream_t st) {
+    launch_gemm_nt(lower, A, lda, B, ldb, C, ldc, M, N, K, alpha, beta, mirror, kstart_row, st);
+}
+
 // ---------------------------------------------------------------------------------------------- Gram
 // out(i, j) = sum_s part[s](i, j) for i >= j, mirrored (both triangles)
 __global__ void __launch_bounds__(256) sum_splits_mirror_kernel(const float* __restrict__ part, long long ldp, long long stride, int nsplit,
@@ -224,168 +230,10 @@ void gram_rows_mfma_f32(const float* Z, long long ldz, int r0, int nr, int K, fl
     launch_gemm_nt(false, Z + r0, ldz, Z, ldz, C + r0, ldc, nr, r0 + nr, K, 1.f, 0.f, false, false, st);
 }
 
-// ---------------------------------------------------------------------------------------------- Cholesky of a diagonal block
-// One workgroup: Cholesky of the nbk x nbk diagonal block (nbk <= 128), written back in place (lower), plus
-// the inverse of the factor into Dinv (128 x 128, zeros above the diagonal; rows/cols beyond nbk form an
-// identity so that products with padded panels stay exact).
-//
-// Register tiled: thread (bi, bj) keeps the 4 x 4 sub-blocks L[4bi.., 4bj..] and W[4bi.., 4bj..] (W becomes
-// L^-1 by the forward elimination of [L | I]) in registers for the whole factorisation.  A step j only moves
-// the pivot column of L and the pivot row of W through LDS (double buffered: ONE barrier per step, three
-// 16-byte LDS reads per thread instead of one read-modify-write per matrix element).  The scalings by
-// 1 / l_jj are deferred: pivot column and pivot row stay unscaled, the update factors carry 1 / l_jj^2, and
-// the outputs are scaled once at the end.  (First version: both matrices resident in LDS, 258 us per block,
-// LDS-bandwidth bound; 20 ms of the 50 ms factorisation at p = 10^4.)
-constexpr int PF_BLOCKS = 32 * 33 / 2;         // 4 x 4 sub-blocks on or below the diagonal
-constexpr int PF_THREADS = 576;                // 9 waves >= 528 sub-blocks
-
-__global__ void __launch_bounds__(PF_THREADS)
-potf2_inv_kernel(float* __restrict__ A, long long lda, int nbk, float* __restrict__ Dinv, int* __restrict__ info, int base) {
-    __shared__ __attribute__((aligned(16))) float colbuf[2][128];     // unscaled pivot column of L
-    __shared__ __attribute__((aligned(16))) float rowbuf[2][128];     // unscaled pivot row of W
-    __shared__ float invs[128];                                       // 1 / l_jj
-    const int tid = threadIdx.x;
-    // sub-blocks enumerated column by column (bj = 0: bi = 0..31, bj = 1: bi = 1..31, ...): the lanes of a wave
-    // share bj and own consecutive row blocks
-    int bj = 0, first = 0;
-    while (bj < 31 && tid >= first + (32 - bj)) { first += 32 - bj; ++bj; }
-    const int bi = bj + (tid - first);
-    const bool act = tid < PF_BLOCKS;
-    const int r0 = 4 * bi, c0 = 4 * bj;
-    float l[4][4], w[4][4];            // [column][row]; entries above the diagonal of a diagonal sub-block are don't-cares
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int rr = r0 + r, cc = c0 + c;
-            float v = (rr == cc) ? 1.f : 0.f;
-            if (act && rr < nbk && cc < nbk && rr >= cc) v = A[(size_t)cc * lda + rr];
-            l[c][r] = v;
-            w[c][r] = (rr == cc) ? 1.f : 0.f;
-        }
-    for (int k = tid; k < 128; k += PF_THREADS) { colbuf[1][k] = 0.f; rowbuf[1][k] = 0.f; rowbuf[0][k] = 0.f; }
-    __syncthreads();
-    if (act && bj == 0) {              // publish pivot column 0 / pivot row 0
-#pragma unroll
-        for (int r = 0; r < 4; ++r) colbuf[0][r0 + r] = l[0][r];
-        if (bi == 0) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) rowbuf[0][c] = w[c][0];
-        }
-    }
-    for (int j = 0; j < 128; ++j) {
-        __syncthreads();
-        const int cur = j & 1, nxt = cur ^ 1;
-        float d = colbuf[cur][j];
-        if (!(d > 0.f) || !isfinite(d)) {
-            if (tid == 0) atomicCAS(info, 0, base + j + 1);
-            d = 1.f;
-        }
-        if (tid == 0) invs[j] = 1.f / sqrtf(d);
-        if (act && r0 + 3 > j) {
-            const float inv2 = 1.f / d;
-            const float4 lr4 = *reinterpret_cast<const float4*>(&colbuf[cur][r0]);
-            const float4 lc4 = *reinterpret_cast<const float4*>(&colbuf[cur][c0]);
-            const float4 wj4 = *reinterpret_cast<const float4*>(&rowbuf[cur][c0]);
-            // masks folded into the factors: rows <= j get f = 0; columns <= j take the W update, columns > j the L update
-            float f[4], lc[4], wj[4];
-            f[0] = r0 + 0 > j ? lr4.x * inv2 : 0.f; f[1] = r0 + 1 > j ? lr4.y * inv2 : 0.f;
-            f[2] = r0 + 2 > j ? lr4.z * inv2 : 0.f; f[3] = r0 + 3 > j ? lr4.w * inv2 : 0.f;
-            lc[0] = c0 + 0 > j ? lc4.x : 0.f; lc[1] = c0 + 1 > j ? lc4.y : 0.f;
-            lc[2] = c0 + 2 > j ? lc4.z : 0.f; lc[3] = c0 + 3 > j ? lc4.w : 0.f;
-            wj[0] = c0 + 0 > j ? 0.f : wj4.x; wj[1] = c0 + 1 > j ? 0.f : wj4.y;
-            wj[2] = c0 + 2 > j ? 0.f : wj4.z; wj[3] = c0 + 3 > j ? 0.f : wj4.w;
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    l[c][r] = fmaf(-f[r], lc[c], l[c][r]);      // trailing update of L   (rows, columns > j)
-                    w[c][r] = fmaf(-f[r], wj[c], w[c][r]);      // W_r -= l_rj W_j        (rows > j, columns <= j)
-                }
-        }
-        // publish the next pivot column / row (final as of this step) into the other buffer
-        const int jn = j + 1;
-        if (act && jn < 128) {
-            if (bj == (jn >> 2)) {
-                const int cs = jn & 3;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    colbuf[nxt][r0 + r] = cs == 0 ? l[0][r] : (cs == 1 ? l[1][r] : (cs == 2 ? l[2][r] : l[3][r]));
-            }
-            if (bi == (jn >> 2)) {
-                const int rs = jn & 3;
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    rowbuf[nxt][c0 + c] = rs == 0 ? w[c][0] : (rs == 1 ? w[c][1] : (rs == 2 ? w[c][2] : w[c][3]));
-            }
-        }
-    }
-    __syncthreads();
-    // outputs: L(r, c) = l(r, c) / l_cc (diagonal: d / sqrt(d)), Linv(r, c) = w(r, c) / l_rr; zeros above the diagonal of Dinv
-    if (act) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int cc = c0 + c;
-            const float ic = invs[cc];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int rr = r0 + r;
-                if (rr >= cc && rr < nbk && cc < nbk) A[(size_t)cc * lda + rr] = l[c][r] * ic;
-                Dinv[(size_t)cc * 128 + rr] = (rr >= cc) ? w[c][r] * invs[rr] : 0.f;
-                if (bi != bj) Dinv[(size_t)rr * 128 + cc] = 0.f;           // the mirrored sub-block above the diagonal
-            }
-        }
-    }
-}
-
-__global__ void set_identity_kernel(float* U, long long ldu, int p) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < p) U[(size_t)i * ldu + i] = 1.f;
-}
-
-// In place: A (p x p, SPD, lower triangle valid, leading dimension lda >= round_up(p, 128), allocation of
-// round_up(p, 128) columns with zero padding) -> full symmetric inverse.  Throws ADMM_ERR_NOT_SPD.
+// ---------------------------------------------------------------------------------------------- Cholesky + inverse
+// (diagonal-block kernel and block driver: chol_inverse.h)
 void spd_inverse_mfma_f32(float* A, long long lda, int p, hipStream_t st) {
-    const int nb = (p + SK_BM - 1) / SK_BM;
-    const int pp = nb * SK_BM;
-    ADMM_REQUIRE(lda >= pp, "spd_inverse_mfma_f32: leading dimension must cover whole 128-row blocks");
-    DevBuf<float> Dinv((size_t)nb * 128 * 128), U((size_t)lda * pp);
-    DevBuf<int> info(1);
-    info.zero(st); U.zero(st);
-    // ---- right-looking blocked Cholesky, fused with the right-looking block elimination of [L | I]:
-    // at block step k   W_k <- L_kk^-1 W_k ;  W_i -= L_ik W_k (i > k),   stored transposed (U = W' = L^-T) so that
-    // every update is an NT product with K = 128 over many tiles (no serial triangular-inverse sweep).
-    hipLaunchKernelGGL(set_identity_kernel, dim3((p + 255) / 256), dim3(256), 0, st, U.get(), lda, p);
-    for (int k = 0; k < nb; ++k) {
-        const int r0 = k * SK_BM;
-        const int nbk = std::min(SK_BM, p - r0);
-        float* Akk = A + (size_t)r0 * lda + r0;
-        float* Dk = Dinv.get() + (size_t)k * 128 * 128;
-        hipLaunchKernelGGL(potf2_inv_kernel, dim3(1), dim3(PF_THREADS), 0, st, Akk, lda, nbk, Dk, info.get(), r0);
-        float* Ukb = U.get() + (size_t)r0 * lda;                               // column block k of U, rows 0 .. r0 + nbk
-        // U[:, k] <- U[:, k] L_kk^-T   (in place: a tile only reads its own rows)
-        launch_gemm_nt(false, Ukb, lda, Dk, 128, Ukb, lda, r0 + nbk, nbk, 128, 1.f, 0.f, false, false, st);
-        const int M = p - (r0 + SK_BM);
-        if (M > 0) {
-            float* Apan = A + (size_t)r0 * lda + r0 + SK_BM;                   // rows below the diagonal block, its 128 columns
-            // L_ik = A_ik L_kk^-T : C[i, j] = sum_t A_ik[i, t] Linv[j, t]; in place
-            launch_gemm_nt(false, Apan, lda, Dk, 128, Apan, lda, M, nbk, 128, 1.f, 0.f, false, false, st);
-            // A_ij -= L_ik L_jk' on the lower tiles of the trailing matrix
-            float* Atr = A + (size_t)(r0 + SK_BM) * lda + r0 + SK_BM;
-            launch_gemm_nt(true, Apan, lda, Apan, lda, Atr, lda, M, M, 128, -1.f, 1.f, false, false, st);
-            // U[:, i] -= U[:, k] L_ik'  for all row blocks i > k at once
-            launch_gemm_nt(false, Ukb, lda, Apan, lda, U.get() + (size_t)(r0 + SK_BM) * lda, lda, r0 + SK_BM, M, 128, -1.f, 1.f, false, false, st);
-        }
-    }
-    {
-        int h = 0;
-        ADMM_HIP_CHECK(hipMemcpyAsync(&h, info.get(), sizeof(int), hipMemcpyDeviceToHost, st));
-        ADMM_HIP_CHECK(hipStreamSynchronize(st));
-        if (h != 0) throw Error(ADMM_ERR_NOT_SPD, "Cholesky: matrix is not positive definite (pivot " + std::to_string(h) + ")");
-    }
-    // ---- A^-1 = L^-T L^-1 = U U'  (both triangles)
-    launch_gemm_nt(true, U.get(), lda, U.get(), lda, A, lda, p, p, pp, 1.f, 0.f, true, true, st);
-    ADMM_HIP_CHECK(hipStreamSynchronize(st));
+    spd_inverse_blocked<float>(A, lda, p, st, launch_gemm_nt_f32);
 }
 
 }  // namespace admm
