@@ -20,7 +20,7 @@ ARCH = "gfx950"
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
             "-Wno-unused-result", f"-I{os.path.join(ROCM, 'include')}"]
 LDFLAGS = ["-shared", "-fPIC", f"--offload-arch={ARCH}", f"-L{os.path.join(ROCM, 'lib')}",
-           "-lrocblas", "-lrocsolver", "-lrccl", f"-Wl,-rpath,{os.path.join(ROCM, 'lib')}"]
+           "-lrccl", "-ldl", f"-Wl,-rpath,{os.path.join(ROCM, 'lib')}"]
 
 
 def _sources():

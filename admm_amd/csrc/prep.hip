@@ -5,6 +5,8 @@
 
 #include <rocblas/rocblas.h>
 #include <rocsolver/rocsolver.h>
+#include <dlfcn.h>
+#include <initializer_list>
 #include <mutex>
 
 namespace admm {
@@ -39,16 +41,53 @@ const DeviceInfo& device_info() {
     return cache[dev];
 }
 
+// rocBLAS / rocSOLVER are only used under the A/B knobs (ADMM_HIP_GRAM=rocblas, ADMM_HIP_FACTOR=rocsolver): they are
+// loaded on first use instead of being link-time dependencies (loading librocblas cold costs seconds, creating a
+// handle another 0.1-0.2 s; a default run needs neither).  The headers are used for types only.
+struct BlasApi {
+    void* hb = nullptr; void* hs = nullptr;
+    decltype(&rocblas_create_handle) create_handle = nullptr;
+    decltype(&rocblas_destroy_handle) destroy_handle = nullptr;
+    decltype(&rocblas_set_stream) set_stream = nullptr;
+    decltype(&rocblas_ssyrk) ssyrk = nullptr;
+    decltype(&rocblas_dsyrk) dsyrk = nullptr;
+    decltype(&rocblas_strsm) strsm = nullptr;
+    decltype(&rocblas_dtrsm) dtrsm = nullptr;
+    decltype(&rocsolver_spotrf) spotrf = nullptr;
+    decltype(&rocsolver_dpotrf) dpotrf = nullptr;
+    static void* open_any(std::initializer_list<const char*> names) {
+        for (const char* n : names) if (void* h = dlopen(n, RTLD_NOW | RTLD_GLOBAL)) return h;
+        return nullptr;
+    }
+    template <typename F> void sym(void* h, const char* name, F& f) {
+        f = reinterpret_cast<F>(dlsym(h, name));
+        if (!f) throw Error(ADMM_ERR_BLAS, std::string("symbol not found: ") + name);
+    }
+    BlasApi() {
+        hb = open_any({"librocblas.so", "librocblas.so.5", "librocblas.so.4"});
+        hs = open_any({"librocsolver.so", "librocsolver.so.0"});
+        if (!hb || !hs) throw Error(ADMM_ERR_BLAS, "ADMM_HIP_GRAM=rocblas / ADMM_HIP_FACTOR=rocsolver need librocblas.so and librocsolver.so on the loader path");
+        sym(hb, "rocblas_create_handle", create_handle); sym(hb, "rocblas_destroy_handle", destroy_handle);
+        sym(hb, "rocblas_set_stream", set_stream);
+        sym(hb, "rocblas_ssyrk", ssyrk); sym(hb, "rocblas_dsyrk", dsyrk);
+        sym(hb, "rocblas_strsm", strsm); sym(hb, "rocblas_dtrsm", dtrsm);
+        sym(hs, "rocsolver_spotrf", spotrf); sym(hs, "rocsolver_dpotrf", dpotrf);
+    }
+};
+static BlasApi& blas_api() {
+    static BlasApi api;
+    return api;
+}
 struct BlasHandle {
     rocblas_handle h = nullptr;
     BlasHandle() {
-        if (rocblas_create_handle(&h) != rocblas_status_success) throw Error(ADMM_ERR_BLAS, "rocblas_create_handle failed");
+        if (blas_api().create_handle(&h) != rocblas_status_success) throw Error(ADMM_ERR_BLAS, "rocblas_create_handle failed");
     }
-    ~BlasHandle() { if (h) rocblas_destroy_handle(h); }
+    ~BlasHandle() { if (h) blas_api().destroy_handle(h); }
 };
 static rocblas_handle blas(hipStream_t st) {
     static thread_local BlasHandle bh;
-    if (rocblas_set_stream(bh.h, st) != rocblas_status_success) throw Error(ADMM_ERR_BLAS, "rocblas_set_stream failed");
+    if (blas_api().set_stream(bh.h, st) != rocblas_status_success) throw Error(ADMM_ERR_BLAS, "rocblas_set_stream failed");
     return bh.h;
 }
 #define ADMM_BLAS_CHECK(expr)                                                                   \
@@ -432,9 +471,9 @@ void gram_full(const T* A, long long lda, int rows, int cols, bool atA, T* C, lo
     const int kk = atA ? rows : cols;
     const rocblas_operation op = atA ? rocblas_operation_transpose : rocblas_operation_none;
     if constexpr (std::is_same<T, float>::value) {
-        ADMM_BLAS_CHECK(rocblas_ssyrk(h, rocblas_fill_lower, op, nC, kk, &one, A, (rocblas_int)lda, &zero, C, (rocblas_int)ldc));
+        ADMM_BLAS_CHECK(blas_api().ssyrk(h, rocblas_fill_lower, op, nC, kk, &one, A, (rocblas_int)lda, &zero, C, (rocblas_int)ldc));
     } else {
-        ADMM_BLAS_CHECK(rocblas_dsyrk(h, rocblas_fill_lower, op, nC, kk, &one, A, (rocblas_int)lda, &zero, C, (rocblas_int)ldc));
+        ADMM_BLAS_CHECK(blas_api().dsyrk(h, rocblas_fill_lower, op, nC, kk, &one, A, (rocblas_int)lda, &zero, C, (rocblas_int)ldc));
     }
     symmetrize_from_lower<T>(C, ldc, nC, st);
 }
@@ -453,9 +492,9 @@ void cholesky_lower(T* A, long long lda, int n, hipStream_t st) {
     rocblas_handle h = blas(st);
     DevBuf<rocblas_int> info(1);
     if constexpr (std::is_same<T, float>::value) {
-        ADMM_BLAS_CHECK(rocsolver_spotrf(h, rocblas_fill_lower, n, A, (rocblas_int)lda, info.get()));
+        ADMM_BLAS_CHECK(blas_api().spotrf(h, rocblas_fill_lower, n, A, (rocblas_int)lda, info.get()));
     } else {
-        ADMM_BLAS_CHECK(rocsolver_dpotrf(h, rocblas_fill_lower, n, A, (rocblas_int)lda, info.get()));
+        ADMM_BLAS_CHECK(blas_api().dpotrf(h, rocblas_fill_lower, n, A, (rocblas_int)lda, info.get()));
     }
     check_info(info, st, "Cholesky");
 }
@@ -492,14 +531,14 @@ void spd_inverse_full(T* A, long long lda, int n, hipStream_t st) {
     hipLaunchKernelGGL((set_diag_one_kernel<T>), dim3((n + 255) / 256), dim3(256), 0, st, X.get(), (long long)n, n);
     const T one = T(1);
     if constexpr (std::is_same<T, float>::value) {
-        ADMM_BLAS_CHECK(rocblas_strsm(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit,
+        ADMM_BLAS_CHECK(blas_api().strsm(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit,
                                       n, n, &one, A, (rocblas_int)lda, X.get(), n));
-        ADMM_BLAS_CHECK(rocblas_strsm(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit,
+        ADMM_BLAS_CHECK(blas_api().strsm(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit,
                                       n, n, &one, A, (rocblas_int)lda, X.get(), n));
     } else {
-        ADMM_BLAS_CHECK(rocblas_dtrsm(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit,
+        ADMM_BLAS_CHECK(blas_api().dtrsm(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit,
                                       n, n, &one, A, (rocblas_int)lda, X.get(), n));
-        ADMM_BLAS_CHECK(rocblas_dtrsm(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit,
+        ADMM_BLAS_CHECK(blas_api().dtrsm(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit,
                                       n, n, &one, A, (rocblas_int)lda, X.get(), n));
     }
     hipLaunchKernelGGL((mirror_lower_kernel<T>), dim3((n + 255) / 256, n), dim3(256), 0, st, X.get(), (long long)n, A, lda, n);
@@ -526,10 +565,10 @@ void trsm_left_lower(const T* L, long long ldl, int n, T* B, long long ldb, int 
     rocblas_handle h = blas(st);
     const T one = T(1);
     if constexpr (std::is_same<T, float>::value) {
-        ADMM_BLAS_CHECK(rocblas_strsm(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit,
+        ADMM_BLAS_CHECK(blas_api().strsm(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit,
                                       n, m, &one, L, (rocblas_int)ldl, B, (rocblas_int)ldb));
     } else {
-        ADMM_BLAS_CHECK(rocblas_dtrsm(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit,
+        ADMM_BLAS_CHECK(blas_api().dtrsm(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit,
                                       n, m, &one, L, (rocblas_int)ldl, B, (rocblas_int)ldb));
     }
 }
@@ -541,10 +580,10 @@ void trsm_right_lower_t(const T* L, long long ldl, int n, T* B, long long ldb, i
     rocblas_handle h = blas(st);
     const T one = T(1);
     if constexpr (std::is_same<T, float>::value) {
-        ADMM_BLAS_CHECK(rocblas_strsm(h, rocblas_side_right, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit,
+        ADMM_BLAS_CHECK(blas_api().strsm(h, rocblas_side_right, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit,
                                       m, n, &one, L, (rocblas_int)ldl, B, (rocblas_int)ldb));
     } else {
-        ADMM_BLAS_CHECK(rocblas_dtrsm(h, rocblas_side_right, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit,
+        ADMM_BLAS_CHECK(blas_api().dtrsm(h, rocblas_side_right, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit,
                                       m, n, &one, L, (rocblas_int)ldl, B, (rocblas_int)ldb));
     }
 }
