@@ -222,17 +222,18 @@ tall_tail_kernel(TallParams q, int par) {
             const int ndot = q.nrb - rb0;
             const int nax = min(q.ncb - 1, 2 * rbi + 1) + 1;
             const int ntot = ndot + nax;
-            for (int k0 = 0; k0 < ntot; k0 += 8 * kTailLanes) {
-                float va[8], vb[8];
+            // 16 partials per lane and array in flight: one memory round trip up to 128 partials (p <= 10^4: all elements)
+            for (int k0 = 0; k0 < ntot; k0 += 16 * kTailLanes) {
+                float va[16], vb[16];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
+                for (int j = 0; j < 16; ++j) {
                     const int k = k0 + j * kTailLanes + sub;
                     va[j] = 0.f; vb[j] = 0.f;
                     if (k < ndot) { const size_t o = (size_t)(rb0 + k) * q.ldo + i; va[j] = q.dot0[o]; vb[j] = q.dot1[o]; }
                     else if (k < ntot) { const size_t o = (size_t)(k - ndot) * q.ldo + i; va[j] = q.axp0[o]; vb[j] = q.axp1[o]; }
                 }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { a += va[j]; b += vb[j]; }
+                for (int j = 0; j < 16; ++j) { a += va[j]; b += vb[j]; }
             }
         } else {
             for (int k = sub; k < q.nseg; k += kTailLanes) {
