@@ -131,6 +131,9 @@ __global__ void set_identity_kernel(T* U, long long ldu, int p) {
 // returned).  Right-looking on 128-blocks, fused with the right-looking block elimination of [L | I]:
 //     at block step k   W_k <- L_kk^-1 W_k ;  W_i -= L_ik W_k (i > k),   stored transposed (U = W' = L^-T)
 // so that every update is an NT product with K = 128 over many tiles (no serial triangular-inverse sweep).
+// Measured and rejected: a second stream for the bulk updates with a look-ahead of one block column (the serial
+// diagonal-block kernel of step k + 1 under the bulk updates of step k) -- correct, but the cross-stream event waits
+// cost more than the overlap gains (38 -> 53 ms at p = 10^4, and a second stream costs small calls 80 ms).
 // Throws ADMM_ERR_NOT_SPD.
 template <typename T, typename Gemm>
 DevBuf<T> cholesky_linvt_blocked(T* A, long long lda, int p, hipStream_t st, Gemm gemm) {
