@@ -67,3 +67,21 @@ def test_readme_bp_perf_range():
     e = bt - out["beta"]
     assert abs(e.min() - readme.BP_PERF_RANGE[0]) < 5e-9
     assert abs(e.max() - readme.BP_PERF_RANGE[1]) < 5e-9
+
+
+def test_golden_file_matches_the_regenerated_fixtures_and_pins_the_oracle():
+    """tests/golden/readme_vectors.json (committed data): inputs equal what the R-RNG restatement regenerates,
+    and the oracle reproduces the README's printed Lasso column from the STORED inputs."""
+    import json
+    import os
+    from oracle import entry, readme
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "readme_vectors.json")
+    g = json.load(open(path))
+    x, y = readme.lasso_data()
+    xs = np.array(g["lasso"]["x_colmajor"]).reshape((100, 20), order="F")
+    assert np.array_equal(xs, x) and np.array_equal(np.array(g["lasso"]["y"]), y)
+    xb, yb, _ = readme.bp_data()
+    assert np.array_equal(np.array(g["bp"]["x_colmajor"]).reshape((50, 100), order="F"), xb)
+    ref = entry.admm_lasso(xs, np.array(g["lasso"]["y"]), [g["lambda"]], 100, 1e-4, True, True, entry.LASSO_OPTS)
+    want = np.array(g["lasso"]["admm"])
+    assert np.abs(ref["beta"][:, 0] - want).max() / np.abs(want).max() < 1e-4
