@@ -273,9 +273,9 @@ void solve_lad(const DeviceData<double>& d, const admm_opts& opts, DenseResult& 
     const int* skip = L.done.get();
     LoopTimes lt = run_until_done(st, skip, env_batch(8), (long long)opts.maxit + 2, [&](long long g) {
         L.head(g, st);
-        g1.run(L.vec.get(), tvec.get(), skip, st);
-        g2.run(tvec.get(), svec.get(), skip, st);
-        g3.run_partials(svec.get(), skip, st);
+        g1.run_partials(L.vec.get(), skip, st);          // chained: the next product sums these partial rows while staging
+        g2.run_partials_from(g1, skip, st);
+        g3.run_partials_from(g2, skip, st);
         L.tail(g, st);
     });
     S.t_loop = lt.wall_s; S.loop_ms_events = lt.events_ms; S.xupdate_launches = lt.launched;
@@ -353,14 +353,13 @@ void solve_bp(const DeviceData<double>& d, const admm_opts& opts, DenseResult& r
 
     DenseLoop L;
     L.init(p, 1, opts, AAAb.get(), 0.0, st);
-    DevBuf<double> wvec(ldn); wvec.zero(st);
     L.q.gout = gB.part.get(); L.q.gout_nseg = gB.pl.nseg; L.q.gout_stride = gB.stride;
 
     const int* skip = L.done.get();
     LoopTimes lt = run_until_done(st, skip, env_batch(8), (long long)opts.maxit + 2, [&](long long g) {
         L.head(g, st);
-        gBt.run(L.vec.get(), wvec.get(), skip, st);     // workspace = B vec   (mat_vec_prod,  ADMMBP.h:65)
-        gB.run_partials(wvec.get(), skip, st);          // B' workspace        (mat_vec_tprod, ADMMBP.h:66)
+        gBt.run_partials(L.vec.get(), skip, st);        // workspace = B vec   (mat_vec_prod,  ADMMBP.h:65)
+        gB.run_partials_from(gBt, skip, st);            // B' workspace        (mat_vec_tprod, ADMMBP.h:66)
         L.tail(g, st);
     });
     S.t_loop = lt.wall_s; S.loop_ms_events = lt.events_ms; S.xupdate_launches = lt.launched;

@@ -29,6 +29,8 @@ struct GemvTArgs {
     int m;              // rows (length of the dot products)
     int k;              // columns (number of outputs)
     const T* v[2];
+    int vparts;         // > 1: v[0] is given as `vparts` partial rows (the un-reduced output of another gemv_t),
+    long long vstride;  //      summed in order while the segment is staged -- no separate reduction launch
     T* out[2];          // out[r][s * out_stride + j]
     long long out_stride;
     int seg_len;        // rows per segment (multiple of 32 elements: 128-B aligned starts)
@@ -67,7 +69,23 @@ gemv_t_kernel(GemvTArgs<T> a, Extra extra) {
     for (int r = 0; r < NRHS; ++r) {
         const T* src = a.v[r] + r0;
         T* dst = rhs + (size_t)r * a.seg_alloc;
-        for (int i = threadIdx.x; i < lpad; i += kGemvThreads) dst[i] = (i < len) ? src[i] : T(0);
+        if (r == 0 && a.vparts > 1) {
+            for (int i = threadIdx.x; i < lpad; i += kGemvThreads) {
+                T acc = T(0);
+                if (i < len) {
+                    for (int q0 = 0; q0 < a.vparts; q0 += 8) {      // 8 independent loads in flight, summed in order
+                        T t[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) t[u] = (q0 + u < a.vparts) ? src[(size_t)(q0 + u) * a.vstride + i] : T(0);
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) acc += t[u];
+                    }
+                }
+                dst[i] = acc;
+            }
+        } else {
+            for (int i = threadIdx.x; i < lpad; i += kGemvThreads) dst[i] = (i < len) ? src[i] : T(0);
+        }
     }
     __syncthreads();
 
@@ -162,10 +180,10 @@ template <typename T, int NRHS, int C, typename Extra = GemvNoExtra>
 inline void launch_gemv_t(const GemvTPlan& pl, const T* A, long long lda, int m, int k,
                           const T* v0, const T* v1, T* out0, T* out1, long long out_stride,
                           const int* skip, hipStream_t st, Extra extra = Extra(),
-                          hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
+                          hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, int vparts = 1, long long vstride = 0) {
     GemvTArgs<T> a;
     a.A = A; a.lda = lda; a.m = m; a.k = k;
-    a.v[0] = v0; a.v[1] = v1; a.out[0] = out0; a.out[1] = out1;
+    a.v[0] = v0; a.v[1] = v1; a.vparts = vparts; a.vstride = vstride; a.out[0] = out0; a.out[1] = out1;
     a.out_stride = out_stride; a.seg_len = pl.seg_len; a.seg_alloc = pl.seg_alloc; a.nseg = pl.nseg;
     a.groups_per_wg = pl.groups_per_wg; a.skip = skip;
     hipExtLaunchKernelGGL((gemv_t_kernel<T, NRHS, C, Extra>), dim3(pl.grid + (Extra::kHas ? 1 : 0)), dim3(kGemvThreads),
@@ -201,8 +219,28 @@ struct GemvT {
     void run_partials(const T* v, const int* skip, hipStream_t st) {
         launch_gemv_t<T, 1, 4>(pl, A, lda, m, k, v, nullptr, part.get(), nullptr, stride, skip, st);
     }
+    // the same with the right-hand vector taken from the un-reduced partials of `prev` (prev.k == m): a chain of
+    // products needs no reduction launches in between
+    void run_partials_from(const GemvT<T>& prev, const int* skip, hipStream_t st) {
+        launch_gemv_t<T, 1, 4>(pl, A, lda, m, k, prev.part.get(), nullptr, part.get(), nullptr, stride, skip, st, GemvNoExtra(),
+                               nullptr, nullptr, prev.pl.nseg, prev.stride);
+    }
     void run(const T* v, T* y, const int* skip, hipStream_t st) {
+        if (pl.nseg == 1) {                                      // one segment: the partial row is the result
+            launch_gemv_t<T, 1, 4>(pl, A, lda, m, k, v, nullptr, y, nullptr, stride, skip, st);
+            return;
+        }
         run_partials(v, skip, st);
+        hipLaunchKernelGGL((reduce_partials_kernel<T>), dim3((k + 255) / 256), dim3(256), 0, st, part.get(), stride, pl.nseg, k, y, skip);
+    }
+    // y from the partials of `prev` as right-hand vector
+    void run_from(const GemvT<T>& prev, T* y, const int* skip, hipStream_t st) {
+        if (pl.nseg == 1) {
+            launch_gemv_t<T, 1, 4>(pl, A, lda, m, k, prev.part.get(), nullptr, y, nullptr, stride, skip, st, GemvNoExtra(),
+                                   nullptr, nullptr, prev.pl.nseg, prev.stride);
+            return;
+        }
+        run_partials_from(prev, skip, st);
         hipLaunchKernelGGL((reduce_partials_kernel<T>), dim3((k + 255) / 256), dim3(256), 0, st, part.get(), stride, pl.nseg, k, y, skip);
     }
 };

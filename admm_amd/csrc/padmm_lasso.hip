@@ -334,9 +334,10 @@ struct ParPlan final : LassoPlan {
                 if (!w.wide) {
                     w.gM.run_partials(rk, skip, st);                       // x = (A'A + rho I)^-1 rhs
                 } else {
-                    w.gAt.run(rk, w.tvec.get(), skip, st);                 // t = A rhs
-                    w.gM.run(w.tvec.get(), w.svec.get(), skip, st);        // s = (AA' + rho I)^-1 t
-                    w.gA.run_partials(w.svec.get(), skip, st);             // A' s
+                    // chained without reduction launches: each product sums the previous one's partial rows while staging
+                    w.gAt.run_partials(rk, skip, st);                      // t = A rhs
+                    w.gM.run_partials_from(w.gAt, skip, st);               // s = (AA' + rho I)^-1 t
+                    w.gA.run_partials_from(w.gM, skip, st);                // A' s
                 }
             }
             hipLaunchKernelGGL(par_pack_kernel, dim3(nwg_e), dim3(kParThreads), 0, st, q);
