@@ -8,8 +8,8 @@
 //   LDS read feeds C*NRHS FMAs and C independent 16-B global loads are in flight per lane per
 //   pass.  HBM roofline: lda*k*sizeof(T) bytes read once.
 //
-// Used for: the tall x-update (A = cached (X'X+rho I)^-1, NRHS = 2: base and acceleration
-// direction, see lasso_tall.hip), X'y, Lanczos SYMVs, the wide solver's X't, PADMM / LAD / BP
+// Used for: the tall x-update (A = cached (X'X+rho I)^-1, NRHS = 2: the accelerate and
+// restart candidates of the right-hand side, see lasso_tall.hip), X'y, Lanczos SYMVs, the wide solver's X't, PADMM / LAD / BP
 // products (on the stored transpose where the reference multiplies by the matrix itself).
 #pragma once
 #include "admm_internal.h"
