@@ -57,7 +57,9 @@ def main():
                 else:
                     fit = admm_lasso(x, y, icpt, stdz).penalty(lam, nlambda=nl).fit()
                     ref = entry.admm_lasso(x, y, lam, nl, lmr, stdz, icpt, opts)
-                floor = 1e-3 * np.abs(ref["beta"]).max()          # a (near-)null column is compared on the scale of the path
+                # a (near-)null column is compared on the scale of the path, and a path that is null altogether (one
+                # automatic lambda = lambda_max) on the natural coefficient scale sd(y) / sd(x)
+                floor = 1e-3 * max(float(np.abs(ref["beta"]).max()), float(np.std(y) / max(np.std(x), 1e-300)))
                 e = max(np.abs(fit.beta_dense[:, j].astype(np.float64) - ref["beta"][:, j]).max() / max(float(np.abs(ref["beta"][:, j]).max()), float(floor), 1e-300)
                         for j in range(ref["beta"].shape[1]))
                 dn = int(np.abs(np.asarray(fit.niter, int) - np.asarray(ref["niter"], int)).max())
