@@ -19,6 +19,15 @@ namespace admm {
 // 1 / l_jj are deferred: pivot column and pivot row stay unscaled, the update factors carry 1 / l_jj^2, and
 // the outputs are scaled once at the end.  (First version: both matrices resident in LDS, 258 us per block,
 // LDS-bandwidth bound; 20 ms of the 50 ms factorisation at p = 10^4.)
+__device__ __forceinline__ void lds_load4(const float* p, float (&v)[4]) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+__device__ __forceinline__ void lds_load4(const double* p, double (&v)[4]) {
+    const double2 a = *reinterpret_cast<const double2*>(p), b = *reinterpret_cast<const double2*>(p + 2);
+    v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+}
+
 constexpr int PF_BLOCKS = 32 * 33 / 2;         // 4 x 4 sub-blocks on or below the diagonal
 constexpr int PF_THREADS = 576;                // 9 waves >= 528 sub-blocks
 
@@ -69,13 +78,17 @@ potf2_inv_kernel(T* __restrict__ A, long long lda, int nbk, T* __restrict__ Dinv
         if (act && r0 + 3 > j) {
             const T inv2 = T(1) / d;
             // masks folded into the factors: rows <= j get f = 0; columns <= j take the W update, columns > j the L update
-            // (the four adjacent LDS reads of each group are merged into one 16- / 32-byte read)
+            // unconditional vector reads first (one 16- / 32-byte LDS read per group), masks afterwards
+            T lr[4], lcv[4], wjv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { lr[k] = T(0); lcv[k] = T(0); wjv[k] = T(0); }
+            lds_load4(&colbuf[cur][r0], lr); lds_load4(&colbuf[cur][c0], lcv); lds_load4(&rowbuf[cur][c0], wjv);
             T f[4], lc[4], wj[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                f[k] = r0 + k > j ? colbuf[cur][r0 + k] * inv2 : T(0);
-                lc[k] = c0 + k > j ? colbuf[cur][c0 + k] : T(0);
-                wj[k] = c0 + k > j ? T(0) : rowbuf[cur][c0 + k];
+                f[k] = r0 + k > j ? lr[k] * inv2 : T(0);
+                lc[k] = c0 + k > j ? lcv[k] : T(0);
+                wj[k] = c0 + k > j ? T(0) : wjv[k];
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c)
