@@ -51,7 +51,13 @@ EXPORTS = ["admm_hip_lasso", "admm_hip_enet", "admm_hip_parlasso", "admm_hip_lad
            "admm_hip_last_error", "admm_hip_version", "admm_hip_device_count", "admm_hip_set_device",
            "admm_hip_device_synchronize", "admm_hip_lasso_plan_create", "admm_hip_lasso_plan_run",
            "admm_hip_lasso_plan_destroy", "admm_hip_comm_unique_id", "admm_hip_comm_init", "admm_hip_comm_finalize",
-           "admm_hip_parlasso_dist", "admm_hip_lasso_plan_create_dist"]
+           "admm_hip_parlasso_dist", "admm_hip_lasso_plan_create_dist",
+           "admm_hip_lasso_plan_trace_enable", "admm_hip_lasso_plan_trace_read",
+           "admm_hip_host_lanczos", "admm_hip_test_symv",
+           "admm_hip_comm_peer_prepare", "admm_hip_comm_init_peer", "admm_hip_comm_init_shm", "admm_hip_comm_test_allreduce"]
+
+TRACE_FIELDS = 10
+TRACE_COLD, TRACE_CONVERGED, TRACE_ACCELERATE, TRACE_RESTART = -1, 0, 1, 2
 
 
 def load():
@@ -99,6 +105,20 @@ def load():
     lib.admm_hip_comm_init.restype = ctypes.c_int
     lib.admm_hip_comm_finalize.argtypes = []
     lib.admm_hip_comm_finalize.restype = ctypes.c_int
+    lib.admm_hip_comm_peer_prepare.argtypes = [ctypes.c_int, ctypes.c_void_p]
+    lib.admm_hip_comm_peer_prepare.restype = ctypes.c_int
+    lib.admm_hip_comm_init_peer.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    lib.admm_hip_comm_init_peer.restype = ctypes.c_int
+    lib.admm_hip_comm_init_shm.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_char_p]
+    lib.admm_hip_comm_init_shm.restype = ctypes.c_int
+    lib.admm_hip_comm_test_allreduce.argtypes = [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int]
+    lib.admm_hip_comm_test_allreduce.restype = ctypes.c_int
+    lib.admm_hip_lasso_plan_trace_enable.argtypes = [ctypes.c_void_p, ctypes.c_longlong]
+    lib.admm_hip_lasso_plan_trace_enable.restype = ctypes.c_int
+    lib.admm_hip_lasso_plan_trace_read.argtypes = [ctypes.c_void_p, _c_double_p, ctypes.c_longlong, ctypes.POINTER(ctypes.c_longlong)]
+    lib.admm_hip_lasso_plan_trace_read.restype = ctypes.c_int
+    lib.admm_hip_test_symv.argtypes = [_c_float_p, ctypes.c_int, _c_float_p, _c_float_p, _c_float_p, _c_float_p]
+    lib.admm_hip_test_symv.restype = ctypes.c_int
     lib.admm_hip_host_lanczos.argtypes = [_c_float_p, ctypes.c_int, _c_float_p, _c_int_p]
     lib.admm_hip_host_lanczos.restype = ctypes.c_int
     _lib = lib

@@ -301,6 +301,19 @@ class LassoPlan:
                                                 niter.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), ctypes.byref(stats)))
         return ADMM_Lasso_fit(lam_out, beta, niter, stats.as_dict())
 
+    def enable_trace(self, capacity=1 << 18):
+        """Record one decision record per ADMM iteration of the following run() calls (tall path only)."""
+        check(self._lib.admm_hip_lasso_plan_trace_enable(self._h, int(capacity)))
+        self._trace_cap = int(capacity)
+
+    def read_trace(self):
+        """(nrecords, TRACE_FIELDS) float64 array of the last run(): see include/admm_hip.h."""
+        buf = np.zeros((self._trace_cap, _lib.TRACE_FIELDS), dtype=np.float64)
+        n = ctypes.c_longlong()
+        check(self._lib.admm_hip_lasso_plan_trace_read(self._h, buf.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                                       self._trace_cap, ctypes.byref(n)))
+        return buf[:n.value].copy()
+
     def close(self):
         if self._h:
             check(self._lib.admm_hip_lasso_plan_destroy(self._h))

@@ -109,7 +109,8 @@ inline size_t round_up_sz(size_t v, size_t m) { return (v + m - 1) / m * m; }
 
 struct DeviceInfo {
     int num_cu = 256;
-    size_t lds_per_block = 64 * 1024;
+    size_t lds_per_block = 64 * 1024;    // dynamic LDS a launch may request without opting in
+    size_t lds_optin = 64 * 1024;        // ... after hipFuncSetAttribute(hipFuncAttributeMaxDynamicSharedMemorySize) (160 KB on gfx950)
 };
 const DeviceInfo& device_info();   // queries the current device once per device id
 void require_device();             // throws ADMM_ERR_NO_DEVICE when no usable HIP device

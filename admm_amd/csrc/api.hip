@@ -4,9 +4,13 @@
 
 namespace admm {
 const std::string& last_error_ref();
+void test_symv(const float* A, int p, const float* v0, const float* v1, float* y0, float* y1);
 int comm_unique_id(void* out);
 void comm_init(int nranks, int rank, const void* idbytes);
 void comm_finalize();
+void comm_peer_prepare(int nranks, void* handle_out);
+void comm_init_peer(int nranks, int rank, const void* handles);
+void comm_init_shm(int nranks, int rank, const char* name);
 
 std::vector<double> make_lambda_grid(const LassoProblem& pb, double lambda0, int n, double scaleY) {
     if (!pb.lambda_in.empty()) return pb.lambda_in;
@@ -266,6 +270,40 @@ int admm_hip_comm_init(int nranks, int rank, const void* id) {
 int admm_hip_comm_finalize(void) {
     return guarded([&] { comm_finalize(); });
 }
+int admm_hip_comm_peer_prepare(int nranks, void* handle_out) {
+    return guarded([&] { ADMM_REQUIRE(handle_out != nullptr, "handle_out must not be NULL"); require_device(); comm_peer_prepare(nranks, handle_out); });
+}
+int admm_hip_comm_init_peer(int nranks, int rank, const void* handles) {
+    return guarded([&] { ADMM_REQUIRE(handles != nullptr, "handles must not be NULL"); require_device(); comm_init_peer(nranks, rank, handles); });
+}
+int admm_hip_comm_init_shm(int nranks, int rank, const char* name) {
+    return guarded([&] { require_device(); comm_init_shm(nranks, rank, name); });
+}
+int admm_hip_comm_test_allreduce(float* fbuf, long long nf, double* dbuf, long long nd, int mem) {
+    return guarded([&] {
+        ADMM_REQUIRE(nf >= 0 && nd >= 0 && (nf == 0 || fbuf) && (nd == 0 || dbuf), "bad arguments");
+        ADMM_REQUIRE(comm_info().active, "no communicator");
+        require_device();
+        Stream st;
+        DevBuf<float> df; DevBuf<double> dd;
+        float* pf = fbuf; double* pd = dbuf;
+        if (mem == ADMM_MEM_HOST) {
+            df.alloc((size_t)nf); dd.alloc((size_t)nd);
+            if (nf) ADMM_HIP_CHECK(hipMemcpyAsync(df.get(), fbuf, (size_t)nf * sizeof(float), hipMemcpyHostToDevice, st.s));
+            if (nd) ADMM_HIP_CHECK(hipMemcpyAsync(dd.get(), dbuf, (size_t)nd * sizeof(double), hipMemcpyHostToDevice, st.s));
+            pf = df.get(); pd = dd.get();
+        }
+        if (nf && nd) allreduce_sum_f32_f64(pf, (size_t)nf, pd, (size_t)nd, st.s);
+        else if (nf) allreduce_sum_f32(pf, (size_t)nf, st.s);
+        else if (nd) allreduce_sum_f64(pd, (size_t)nd, st.s);
+        if (mem == ADMM_MEM_HOST) {
+            if (nf) ADMM_HIP_CHECK(hipMemcpyAsync(fbuf, pf, (size_t)nf * sizeof(float), hipMemcpyDeviceToHost, st.s));
+            if (nd) ADMM_HIP_CHECK(hipMemcpyAsync(dbuf, pd, (size_t)nd * sizeof(double), hipMemcpyDeviceToHost, st.s));
+        }
+        st.sync();
+        comm_check();
+    });
+}
 
 int admm_hip_lasso_plan_run(admm_hip_plan* plan, double* lambda_out, float* beta_out, int* niter_out, admm_stats* stats) {
     return guarded([&] { run_plan(reinterpret_cast<PlanHandle*>(plan), lambda_out, beta_out, niter_out, stats, 0.0); });
@@ -273,6 +311,24 @@ int admm_hip_lasso_plan_run(admm_hip_plan* plan, double* lambda_out, float* beta
 
 int admm_hip_lasso_plan_destroy(admm_hip_plan* plan) {
     return guarded([&] { delete reinterpret_cast<PlanHandle*>(plan); });
+}
+
+int admm_hip_lasso_plan_trace_enable(admm_hip_plan* plan, long long capacity_records) {
+    return guarded([&] {
+        PlanHandle* h = reinterpret_cast<PlanHandle*>(plan);
+        ADMM_REQUIRE(h != nullptr && h->plan, "plan is NULL");
+        ADMM_REQUIRE(capacity_records > 0 && capacity_records <= (1ll << 26), "trace capacity must be within [1, 2^26] records");
+        h->plan->enable_trace(capacity_records);
+    });
+}
+
+int admm_hip_lasso_plan_trace_read(admm_hip_plan* plan, double* out, long long cap_records, long long* nrecords_out) {
+    return guarded([&] {
+        PlanHandle* h = reinterpret_cast<PlanHandle*>(plan);
+        ADMM_REQUIRE(h != nullptr && h->plan, "plan is NULL");
+        ADMM_REQUIRE(out != nullptr && nrecords_out != nullptr && cap_records >= 0, "bad trace output arguments");
+        *nrecords_out = h->plan->read_trace(out, cap_records);
+    });
 }
 
 const char* admm_hip_last_error(void) { return last_error_ref().c_str(); }
@@ -292,7 +348,7 @@ int admm_hip_device_synchronize(void) {
 
 // Host-only helper used by the CPU test-suite: runs the Lanczos host logic (lanczos.hip) against a
 // dense symmetric matrix held in host memory.  Not part of any solver path.
-ADMM_HIP_API int admm_hip_host_lanczos(const float* A, int n, float* eig_out, int* nmatop_out) {
+int admm_hip_host_lanczos(const float* A, int n, float* eig_out, int* nmatop_out) {
     return guarded([&] {
         ADMM_REQUIRE(A && eig_out && n >= 3, "bad arguments");
         auto op = [&](const float* v, float* w) {
@@ -304,6 +360,13 @@ ADMM_HIP_API int admm_hip_host_lanczos(const float* A, int n, float* eig_out, in
             }
         };
         *eig_out = lanczos_largest_f32(op, n, nmatop_out);
+    });
+}
+
+int admm_hip_test_symv(const float* A, int p, const float* v0, const float* v1, float* y0, float* y1) {
+    return guarded([&] {
+        ADMM_REQUIRE(A && v0 && v1 && y0 && y1 && p > 0, "bad arguments");
+        test_symv(A, p, v0, v1, y0, y1);
     });
 }
 

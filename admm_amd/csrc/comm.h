@@ -1,16 +1,32 @@
-// Process-wide RCCL communicator (one process per GPU).  Only the consensus solver and the global
-// standardisation use it; every call is a no-op when no communicator is attached.
+// Process-wide exchange layer (one process per GPU).  Only the solvers with a real exchange step use it: the row-block
+// consensus solver (PADMMLasso: one all-reduce of p floats + 3 doubles per ADMM iteration), the row-sharded tall
+// x-update (2p floats per iteration) and the global-moment standardisation / split-K Gram of their setup.
+//
+// Three interchangeable backends behind the same in-place sum all-reduce, all stream-ordered (the host never waits):
+//   RCCL   ncclAllReduce over xGMI -- the default between GPUs and the correctness baseline.
+//   PEER   one-shot all-reduce over peer-mapped device memory (hipIpc): every rank pushes its payload into a slot of
+//          EVERY rank's exchange buffer and raises a flag there; each rank then waits for its K flags and sums the K
+//          slots locally in rank order.  xGMI is point-to-point (7 links per GPU), the payload is <= 0.4 MB, so the
+//          K-1 pushes travel over K-1 different links at once and the whole exchange is one link latency instead of a
+//          ring's 2(K-1) hops.  Identical summation order on every rank => bit-identical results => identical decisions.
+//   SHM    through POSIX shared memory on the host (D2H, a host function in stream order, H2D).  Slow; exists so that
+//          the multi-rank code paths run as separate processes on ONE GPU / without RCCL (tests), bit-identical to PEER.
+// Every call is a no-op when no communicator is attached.
 #pragma once
 #include "admm_internal.h"
 
 namespace admm {
 
-struct CommInfo { int nranks = 1, rank = 0; bool active = false; };
+enum { COMM_NONE = 0, COMM_RCCL = 1, COMM_SHM = 2, COMM_PEER = 3 };
+struct CommInfo { int nranks = 1, rank = 0; bool active = false; int backend = COMM_NONE; };
 CommInfo comm_info();
-// In-place sum all-reduce on device buffers, enqueued on `st`.  No-ops without a communicator.
+// In-place sum all-reduce on device buffers, enqueued on `st` (any length: long messages go in slot-sized chunks).
 void allreduce_sum_f32(float* buf, size_t n, hipStream_t st);
 void allreduce_sum_f64(double* buf, size_t n, hipStream_t st);
-// Two buffers in one grouped RCCL launch (the consensus payload: p floats + the norm doubles).
+// Two buffers in one exchange (the consensus payload: p floats + the norm doubles).
 void allreduce_sum_f32_f64(float* fbuf, size_t nf, double* dbuf, size_t nd, hipStream_t st);
+// Throws ADMM_ERR_COMM if an exchange of the SHM / PEER backends timed out or a peer reported failure (checked by the
+// loop drivers at every poll; the kernels of a failed exchange return immediately instead of spinning).
+void comm_check();
 
 }  // namespace admm

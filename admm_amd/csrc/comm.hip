@@ -1,16 +1,36 @@
-// RCCL glue: communicator bootstrap through a caller-provided unique id (the Python harness
-// broadcasts it with torch.distributed; an R / MPI caller would use its own channel) and the few
-// collectives the consensus path needs.  xGMI is point-to-point and the payload is small (p floats
-// + 3 doubles per iteration), so this is latency-bound: one grouped all-reduce per ADMM iteration.
+// Exchange layer: RCCL, one-shot peer-mapped all-reduce (hipIpc), host shared memory.  See comm.h.
+//
+// Replaces the shared-memory "collectives" of the reference's OpenMP master/worker loop:
+//   sum_i (x_i + y_i / rho)           /root/reference/src/PADMMLasso.h:99-108 (add_xu_to :65-68)
+//   sum_i ||x_i||^2, ||y_i||^2, ||r_i||^2   /root/reference/src/PADMMBase.h:117-138,200-214
+// The reference reads the workers' vectors directly (threads of one process); here each rank is a process on its own GPU.
+//
+// Bootstrap is caller-driven (the library never opens sockets): RCCL needs rank 0's 128-byte unique id on every rank,
+// PEER needs every rank's 64-byte hipIpc handle on every rank, SHM needs a name all ranks agree on.  The Python harness
+// moves those bytes with torch.distributed or a file; an R / MPI caller would use its own channel.
 #include "comm.h"
 #include <rccl/rccl.h>
+#include <atomic>
 #include <mutex>
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 namespace admm {
 namespace {
+
+constexpr int kMaxRanks = 64;
+constexpr size_t kDefaultSlotBytes = 4u << 20;        // payload capacity of one exchange (longer messages are chunked)
+constexpr double kWaitSeconds = 20.0;                 // bound of every wait (host spin and device spin): never hang the GPU
+
 std::mutex g_mu;
-ncclComm_t g_comm = nullptr;
 CommInfo g_info;
+ncclComm_t g_comm = nullptr;
+size_t g_slot = kDefaultSlotBytes;
+uint64_t g_seq = 0;                                   // exchanges enqueued so far (all ranks enqueue the same sequence)
+int* g_err = nullptr;                                 // pinned, device-visible: set by a timed-out wait (host fn or kernel)
 
 #define ADMM_NCCL_CHECK(expr)                                                                     \
     do {                                                                                          \
@@ -18,6 +38,257 @@ CommInfo g_info;
         if (_r != ncclSuccess)                                                                    \
             throw ::admm::Error(ADMM_ERR_COMM, std::string(#expr) + ": " + ncclGetErrorString(_r)); \
     } while (0)
+
+size_t slot_bytes_from_env() {
+    if (const char* e = std::getenv("ADMM_HIP_COMM_SLOT_BYTES")) {
+        const long long v = std::atoll(e);
+        if (v >= 4096) return (size_t)v / 16 * 16;
+    }
+    return kDefaultSlotBytes;
+}
+
+void alloc_err_word() {
+    if (!g_err) {
+        ADMM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&g_err), sizeof(int), hipHostMallocMapped));
+        *g_err = 0;
+    }
+}
+
+// ================================================================================================ SHM backend
+// Segment: header | data[2][nranks][slot].  Exchange s: every rank copies its payload into data[s & 1][rank], publishes
+// posted[rank] = s, waits until every posted[r] >= s, sums the nranks slots in rank order.  Two parities suffice: a rank
+// can only post s + 2 after it completed s + 1, which needs every peer's post of s + 1, which a peer makes only after it
+// has finished reading s.
+struct ShmHeader {
+    std::atomic<uint64_t> posted[kMaxRanks];
+    std::atomic<uint32_t> attached;
+    std::atomic<uint32_t> failed;
+    uint64_t slot;
+    uint32_t nranks;
+};
+struct ShmOp { uint64_t seq; size_t nf, nd; };
+
+struct ShmState {
+    std::string name;
+    int fd = -1;
+    void* map = nullptr; size_t map_bytes = 0;
+    ShmHeader* hdr = nullptr; unsigned char* data = nullptr;
+    unsigned char* stage_in = nullptr; unsigned char* stage_out = nullptr;     // pinned
+    std::vector<ShmOp> ring; size_t ring_pos = 0;
+    bool owner = false;
+} g_shm;
+
+unsigned char* shm_slot(uint64_t seq, int rank) {
+    return g_shm.data + ((size_t)(seq & 1) * g_info.nranks + (size_t)rank) * g_slot;
+}
+
+// Runs on a runtime thread when the stream reaches it: the payload is in stage_in, the result goes to stage_out.
+void shm_host_fn(void* user) {
+    const ShmOp op = *static_cast<ShmOp*>(user);
+    const size_t off_d = round_up_sz(op.nf * sizeof(float), 16);
+    const size_t bytes = off_d + op.nd * sizeof(double);
+    ShmHeader* h = g_shm.hdr;
+    if (h->failed.load(std::memory_order_acquire) || (g_err && *g_err)) { std::memset(g_shm.stage_out, 0, bytes); return; }
+    std::memcpy(shm_slot(op.seq, g_info.rank), g_shm.stage_in, bytes);
+    h->posted[g_info.rank].store(op.seq, std::memory_order_release);
+    const double t0 = now_s();
+    for (int r = 0; r < g_info.nranks; ++r) {
+        int spins = 0;
+        while (h->posted[r].load(std::memory_order_acquire) < op.seq) {
+            if ((++spins & 1023) == 0) {
+                sched_yield();
+                if (h->failed.load(std::memory_order_acquire) || now_s() - t0 > kWaitSeconds) {
+                    h->failed.store(1, std::memory_order_release);
+                    if (g_err) *g_err = 1;
+                    std::memset(g_shm.stage_out, 0, bytes);
+                    return;
+                }
+            }
+        }
+    }
+    float* of = reinterpret_cast<float*>(g_shm.stage_out);
+    double* od = reinterpret_cast<double*>(g_shm.stage_out + off_d);
+    for (int r = 0; r < g_info.nranks; ++r) {             // fixed rank order: every rank computes the identical sum
+        const float* sf = reinterpret_cast<const float*>(shm_slot(op.seq, r));
+        const double* sd = reinterpret_cast<const double*>(shm_slot(op.seq, r) + off_d);
+        if (r == 0) {
+            for (size_t i = 0; i < op.nf; ++i) of[i] = sf[i];
+            for (size_t i = 0; i < op.nd; ++i) od[i] = sd[i];
+        } else {
+            for (size_t i = 0; i < op.nf; ++i) of[i] += sf[i];
+            for (size_t i = 0; i < op.nd; ++i) od[i] += sd[i];
+        }
+    }
+}
+
+void shm_exchange(float* fbuf, size_t nf, double* dbuf, size_t nd, hipStream_t st) {
+    const size_t off_d = round_up_sz(nf * sizeof(float), 16);
+    ADMM_REQUIRE(off_d + nd * sizeof(double) <= g_slot, "exchange payload exceeds the slot size");
+    ShmOp* op = &g_shm.ring[g_shm.ring_pos++ % g_shm.ring.size()];
+    op->seq = ++g_seq; op->nf = nf; op->nd = nd;
+    if (nf) ADMM_HIP_CHECK(hipMemcpyAsync(g_shm.stage_in, fbuf, nf * sizeof(float), hipMemcpyDeviceToHost, st));
+    if (nd) ADMM_HIP_CHECK(hipMemcpyAsync(g_shm.stage_in + off_d, dbuf, nd * sizeof(double), hipMemcpyDeviceToHost, st));
+    ADMM_HIP_CHECK(hipLaunchHostFunc(st, shm_host_fn, op));
+    if (nf) ADMM_HIP_CHECK(hipMemcpyAsync(fbuf, g_shm.stage_out, nf * sizeof(float), hipMemcpyHostToDevice, st));
+    if (nd) ADMM_HIP_CHECK(hipMemcpyAsync(dbuf, g_shm.stage_out + off_d, nd * sizeof(double), hipMemcpyHostToDevice, st));
+}
+
+void shm_close() {
+    if (g_shm.map) munmap(g_shm.map, g_shm.map_bytes);
+    if (g_shm.fd >= 0) close(g_shm.fd);
+    if (g_shm.owner && !g_shm.name.empty()) shm_unlink(g_shm.name.c_str());
+    if (g_shm.stage_in) (void)hipHostFree(g_shm.stage_in);
+    if (g_shm.stage_out) (void)hipHostFree(g_shm.stage_out);
+    g_shm = ShmState();
+}
+
+// ================================================================================================ PEER backend
+// Every rank owns one exchange buffer in ITS device memory, mapped into every peer with hipIpc:
+//     data[2][nranks][slot]  |  flags[2][nranks] (one 64-byte line each)
+// Exchange s on rank `me`:
+//   push   for every rank q (its own buffer included): copy the payload into q.data[s & 1][me], fence, and once all
+//          workgroups of that copy are through, store s into q.flags[s & 1][me] (release, system scope);
+//   wait   one wave: lane r spins (acquire, system scope, bounded) on its own flags[s & 1][r] until it reads s;
+//   sum    out[i] = sum over r = 0 .. nranks-1 of data[s & 1][r][i], in rank order, written back in place.
+// The buffer is allocated uncached (fine-grained), so a peer's stores are never shadowed by a stale L2 line here.
+struct PeerState {
+    unsigned char* local = nullptr;                      // this rank's buffer
+    unsigned char* remote[kMaxRanks] = {};               // every rank's buffer as mapped here (remote[rank] == local)
+    bool opened[kMaxRanks] = {};
+    size_t bytes = 0, flags_off = 0;
+    unsigned int* count = nullptr;                       // [nranks] workgroup arrival counters of the push (device)
+    unsigned char** d_remote = nullptr;                  // device copy of remote[]
+} g_peer;
+
+constexpr int kPushGroups = 4;                           // workgroups per destination rank
+
+struct PeerArgs {
+    unsigned char* const* remote; unsigned char* local;
+    size_t slot, flags_off;
+    int nranks, rank;
+    unsigned long long seq;
+    const float* fsrc; size_t nf; const double* dsrc; size_t nd; size_t off_d;
+    float* fdst; double* ddst;
+    unsigned int* count;
+    int* err;
+    long long timeout_ticks;
+};
+
+__device__ __forceinline__ unsigned long long* peer_flag(unsigned char* buf, size_t flags_off, unsigned long long seq, int nranks, int src) {
+    return reinterpret_cast<unsigned long long*>(buf + flags_off + ((size_t)(seq & 1) * nranks + src) * 64);
+}
+
+__global__ void __launch_bounds__(256) peer_push_kernel(PeerArgs a) {
+    if (*reinterpret_cast<volatile int*>(a.err)) return;
+    const int q = blockIdx.x / kPushGroups, g = blockIdx.x % kPushGroups;
+    unsigned char* dst = a.remote[q] + ((size_t)(a.seq & 1) * a.nranks + a.rank) * a.slot;
+    float* df = reinterpret_cast<float*>(dst);
+    double* dd = reinterpret_cast<double*>(dst + a.off_d);
+    for (size_t i = (size_t)g * 256 + threadIdx.x; i < a.nf; i += (size_t)kPushGroups * 256) df[i] = a.fsrc[i];
+    for (size_t i = (size_t)g * 256 + threadIdx.x; i < a.nd; i += (size_t)kPushGroups * 256) dd[i] = a.dsrc[i];
+    __threadfence_system();                              // this workgroup's stores are visible system-wide ...
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int prev = __hip_atomic_fetch_add(&a.count[q], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == kPushGroups - 1) {                   // ... before the last one raises the flag at the destination
+            __hip_atomic_store(&a.count[q], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(peer_flag(a.remote[q], a.flags_off, a.seq, a.nranks, a.rank), a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(64) peer_wait_kernel(PeerArgs a) {
+    if (*reinterpret_cast<volatile int*>(a.err)) return;
+    const int r = threadIdx.x;
+    if (r < a.nranks) {
+        unsigned long long* f = peer_flag(a.local, a.flags_off, a.seq, a.nranks, r);
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < a.seq) {
+            __builtin_amdgcn_s_sleep(8);
+            if (wall_clock64() - t0 > a.timeout_ticks || *reinterpret_cast<volatile int*>(a.err)) {
+                *reinterpret_cast<volatile int*>(a.err) = 1;
+                break;
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) peer_sum_kernel(PeerArgs a) {
+    if (*reinterpret_cast<volatile int*>(a.err)) return;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const unsigned char* base = a.local + (size_t)(a.seq & 1) * a.nranks * a.slot;
+    if (i < a.nf) {
+        float s = reinterpret_cast<const float*>(base)[i];
+        for (int r = 1; r < a.nranks; ++r) s += reinterpret_cast<const float*>(base + (size_t)r * a.slot)[i];
+        a.fdst[i] = s;
+    } else if (i - a.nf < a.nd) {
+        const size_t k = i - a.nf;
+        double s = reinterpret_cast<const double*>(base + a.off_d)[k];
+        for (int r = 1; r < a.nranks; ++r) s += reinterpret_cast<const double*>(base + (size_t)r * a.slot + a.off_d)[k];
+        a.ddst[k] = s;
+    }
+}
+
+void peer_exchange(float* fbuf, size_t nf, double* dbuf, size_t nd, hipStream_t st) {
+    PeerArgs a;
+    a.off_d = round_up_sz(nf * sizeof(float), 16);
+    ADMM_REQUIRE(a.off_d + nd * sizeof(double) <= g_slot, "exchange payload exceeds the slot size");
+    a.remote = g_peer.d_remote; a.local = g_peer.local; a.slot = g_slot; a.flags_off = g_peer.flags_off;
+    a.nranks = g_info.nranks; a.rank = g_info.rank; a.seq = ++g_seq;
+    a.fsrc = fbuf; a.nf = nf; a.dsrc = dbuf; a.nd = nd; a.fdst = fbuf; a.ddst = dbuf;
+    a.count = g_peer.count; a.err = g_err;
+    a.timeout_ticks = (long long)(kWaitSeconds * 100e6);                // wall_clock64: constant 100 MHz
+    hipLaunchKernelGGL(peer_push_kernel, dim3(g_info.nranks * kPushGroups), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(peer_wait_kernel, dim3(1), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(peer_sum_kernel, dim3((unsigned)((nf + nd + 255) / 256)), dim3(256), 0, st, a);
+}
+
+void peer_close() {
+    for (int r = 0; r < kMaxRanks; ++r)
+        if (g_peer.opened[r] && g_peer.remote[r]) (void)hipIpcCloseMemHandle(g_peer.remote[r]);
+    if (g_peer.local) (void)hipFree(g_peer.local);
+    if (g_peer.count) (void)hipFree(g_peer.count);
+    if (g_peer.d_remote) (void)hipFree(g_peer.d_remote);
+    g_peer = PeerState();
+}
+
+void peer_alloc_local(int nranks) {
+    g_slot = slot_bytes_from_env();
+    g_peer.flags_off = (size_t)2 * nranks * g_slot;
+    g_peer.bytes = g_peer.flags_off + (size_t)2 * nranks * 64;
+    void* ptr = nullptr;
+    // fine-grained (uncached) device memory: stores arriving from a peer must not be shadowed by this device's L2
+    if (hipExtMallocWithFlags(&ptr, g_peer.bytes, hipDeviceMallocUncached) != hipSuccess) {
+        (void)hipGetLastError();
+        ADMM_HIP_CHECK(hipExtMallocWithFlags(&ptr, g_peer.bytes, hipDeviceMallocFinegrained));
+    }
+    g_peer.local = static_cast<unsigned char*>(ptr);
+    ADMM_HIP_CHECK(hipMemset(g_peer.local, 0, g_peer.bytes));
+    ADMM_HIP_CHECK(hipDeviceSynchronize());
+}
+
+// ================================================================================================ dispatch
+void exchange(float* fbuf, size_t nf, double* dbuf, size_t nd, hipStream_t st) {
+    switch (g_info.backend) {
+        case COMM_RCCL:
+            if (nf && nd) ADMM_NCCL_CHECK(ncclGroupStart());
+            if (nf) ADMM_NCCL_CHECK(ncclAllReduce(fbuf, fbuf, nf, ncclFloat, ncclSum, g_comm, st));
+            if (nd) ADMM_NCCL_CHECK(ncclAllReduce(dbuf, dbuf, nd, ncclDouble, ncclSum, g_comm, st));
+            if (nf && nd) ADMM_NCCL_CHECK(ncclGroupEnd());
+            break;
+        case COMM_SHM: shm_exchange(fbuf, nf, dbuf, nd, st); break;
+        case COMM_PEER: peer_exchange(fbuf, nf, dbuf, nd, st); break;
+        default: break;
+    }
+}
+
+void require_free() {
+    if (g_info.active) throw Error(ADMM_ERR_COMM, "communicator already initialised");
+}
+void check_ranks(int nranks, int rank) {
+    ADMM_REQUIRE(nranks >= 1 && nranks <= kMaxRanks && rank >= 0 && rank < nranks, "bad rank / nranks");
+}
+
 }  // namespace
 
 CommInfo comm_info() {
@@ -25,22 +296,33 @@ CommInfo comm_info() {
     return g_info;
 }
 
-void allreduce_sum_f32(float* buf, size_t n, hipStream_t st) {
-    if (!g_comm || n == 0) return;
-    ADMM_NCCL_CHECK(ncclAllReduce(buf, buf, n, ncclFloat, ncclSum, g_comm, st));
-}
-void allreduce_sum_f64(double* buf, size_t n, hipStream_t st) {
-    if (!g_comm || n == 0) return;
-    ADMM_NCCL_CHECK(ncclAllReduce(buf, buf, n, ncclDouble, ncclSum, g_comm, st));
-}
-void allreduce_sum_f32_f64(float* fbuf, size_t nf, double* dbuf, size_t nd, hipStream_t st) {
-    if (!g_comm) return;
-    ADMM_NCCL_CHECK(ncclGroupStart());
-    ADMM_NCCL_CHECK(ncclAllReduce(fbuf, fbuf, nf, ncclFloat, ncclSum, g_comm, st));
-    ADMM_NCCL_CHECK(ncclAllReduce(dbuf, dbuf, nd, ncclDouble, ncclSum, g_comm, st));
-    ADMM_NCCL_CHECK(ncclGroupEnd());
+void comm_check() {
+    if (g_err && *g_err) throw Error(ADMM_ERR_COMM, "exchange failed: a rank did not arrive within the time limit (or a peer reported failure)");
 }
 
+void allreduce_sum_f32(float* buf, size_t n, hipStream_t st) {
+    if (!g_info.active || n == 0) return;
+    if (g_info.backend == COMM_RCCL) { exchange(buf, n, nullptr, 0, st); return; }
+    const size_t per = g_slot / sizeof(float);
+    for (size_t o = 0; o < n; o += per) exchange(buf + o, std::min(per, n - o), nullptr, 0, st);
+}
+void allreduce_sum_f64(double* buf, size_t n, hipStream_t st) {
+    if (!g_info.active || n == 0) return;
+    if (g_info.backend == COMM_RCCL) { exchange(nullptr, 0, buf, n, st); return; }
+    const size_t per = g_slot / sizeof(double);
+    for (size_t o = 0; o < n; o += per) exchange(nullptr, 0, buf + o, std::min(per, n - o), st);
+}
+void allreduce_sum_f32_f64(float* fbuf, size_t nf, double* dbuf, size_t nd, hipStream_t st) {
+    if (!g_info.active) return;
+    if (g_info.backend != COMM_RCCL && round_up_sz(nf * sizeof(float), 16) + nd * sizeof(double) > g_slot) {
+        allreduce_sum_f32(fbuf, nf, st);
+        allreduce_sum_f64(dbuf, nd, st);
+        return;
+    }
+    exchange(fbuf, nf, dbuf, nd, st);
+}
+
+// ---------------------------------------------------------------------------------------------- bootstrap (api.hip)
 int comm_unique_id(void* out) {
     ncclUniqueId id;
     ADMM_NCCL_CHECK(ncclGetUniqueId(&id));
@@ -49,17 +331,107 @@ int comm_unique_id(void* out) {
 }
 void comm_init(int nranks, int rank, const void* idbytes) {
     std::lock_guard<std::mutex> lk(g_mu);
-    if (g_comm) throw Error(ADMM_ERR_COMM, "communicator already initialised");
-    ADMM_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "bad rank / nranks");
+    require_free();
+    check_ranks(nranks, rank);
     ncclUniqueId id;
     std::memcpy(&id, idbytes, sizeof(id));
     ADMM_NCCL_CHECK(ncclCommInitRank(&g_comm, nranks, id, rank));
-    g_info.nranks = nranks; g_info.rank = rank; g_info.active = true;
+    g_info.nranks = nranks; g_info.rank = rank; g_info.active = true; g_info.backend = COMM_RCCL;
+    g_seq = 0;
 }
+
+void comm_init_shm(int nranks, int rank, const char* name) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    require_free();
+    check_ranks(nranks, rank);
+    ADMM_REQUIRE(name != nullptr && name[0] == '/' && std::strlen(name) < 200, "shm name must start with '/'");
+    alloc_err_word();
+    g_slot = slot_bytes_from_env();
+    const size_t hdr_bytes = round_up_sz(sizeof(ShmHeader), 4096);
+    const size_t total = hdr_bytes + (size_t)2 * nranks * g_slot;
+    g_shm.name = name;
+    const double t0 = now_s();
+    if (rank == 0) {
+        shm_unlink(name);                                                   // a stale segment of a crashed run
+        g_shm.fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (g_shm.fd < 0 || ftruncate(g_shm.fd, (off_t)total) != 0) { shm_close(); throw Error(ADMM_ERR_COMM, "cannot create the shared-memory segment"); }
+        g_shm.owner = true;
+    } else {
+        for (;;) {                                                          // wait until rank 0 has created and sized it
+            g_shm.fd = shm_open(name, O_RDWR, 0600);
+            struct stat sb;
+            if (g_shm.fd >= 0 && fstat(g_shm.fd, &sb) == 0 && (size_t)sb.st_size >= total) break;
+            if (g_shm.fd >= 0) { close(g_shm.fd); g_shm.fd = -1; }
+            if (now_s() - t0 > 60.0) throw Error(ADMM_ERR_COMM, "the shared-memory segment did not appear (is rank 0 running?)");
+            usleep(2000);
+        }
+    }
+    g_shm.map = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, g_shm.fd, 0);
+    if (g_shm.map == MAP_FAILED) { g_shm.map = nullptr; shm_close(); throw Error(ADMM_ERR_COMM, "mmap of the shared-memory segment failed"); }
+    g_shm.map_bytes = total;
+    g_shm.hdr = static_cast<ShmHeader*>(g_shm.map);
+    g_shm.data = static_cast<unsigned char*>(g_shm.map) + hdr_bytes;
+    if (rank == 0) { g_shm.hdr->slot = g_slot; g_shm.hdr->nranks = (uint32_t)nranks; }
+    ADMM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&g_shm.stage_in), g_slot, hipHostMallocDefault));
+    ADMM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&g_shm.stage_out), g_slot, hipHostMallocDefault));
+    g_shm.ring.assign(8192, ShmOp());
+    g_shm.hdr->attached.fetch_add(1, std::memory_order_acq_rel);
+    while (g_shm.hdr->attached.load(std::memory_order_acquire) < (uint32_t)nranks) {       // everybody is mapped before anyone posts
+        if (now_s() - t0 > 60.0) { shm_close(); throw Error(ADMM_ERR_COMM, "not every rank attached to the shared-memory segment"); }
+        usleep(1000);
+    }
+    if (g_shm.hdr->slot != g_slot || g_shm.hdr->nranks != (uint32_t)nranks) { shm_close(); throw Error(ADMM_ERR_COMM, "ranks disagree on slot size / rank count"); }
+    g_info.nranks = nranks; g_info.rank = rank; g_info.active = true; g_info.backend = COMM_SHM;
+    g_seq = 0;
+}
+
+// PEER, step 1: allocate this rank's exchange buffer and export it.
+void comm_peer_prepare(int nranks, void* handle_out) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    require_free();
+    ADMM_REQUIRE(nranks >= 1 && nranks <= kMaxRanks, "bad nranks");
+    if (g_peer.local) peer_close();
+    peer_alloc_local(nranks);
+    hipIpcMemHandle_t h;
+    ADMM_HIP_CHECK(hipIpcGetMemHandle(&h, g_peer.local));
+    static_assert(sizeof(hipIpcMemHandle_t) == ADMM_HIP_PEER_HANDLE_BYTES, "hipIpcMemHandle_t size");
+    std::memcpy(handle_out, &h, sizeof(h));
+}
+// PEER, step 2: `handles` = the nranks handles in rank order (gathered by the caller).
+void comm_init_peer(int nranks, int rank, const void* handles) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    require_free();
+    check_ranks(nranks, rank);
+    if (!g_peer.local) throw Error(ADMM_ERR_COMM, "call admm_hip_comm_peer_prepare first");
+    ADMM_REQUIRE(g_peer.flags_off == (size_t)2 * nranks * g_slot, "nranks differs from the prepared buffer");
+    alloc_err_word();
+    for (int r = 0; r < nranks; ++r) {
+        if (r == rank) { g_peer.remote[r] = g_peer.local; continue; }
+        hipIpcMemHandle_t h;
+        std::memcpy(&h, static_cast<const unsigned char*>(handles) + (size_t)r * sizeof(h), sizeof(h));
+        void* ptr = nullptr;
+        ADMM_HIP_CHECK(hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess));
+        g_peer.remote[r] = static_cast<unsigned char*>(ptr);
+        g_peer.opened[r] = true;
+    }
+    ADMM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g_peer.count), nranks * sizeof(unsigned int)));
+    ADMM_HIP_CHECK(hipMemset(g_peer.count, 0, nranks * sizeof(unsigned int)));
+    ADMM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g_peer.d_remote), nranks * sizeof(unsigned char*)));
+    ADMM_HIP_CHECK(hipMemcpy(g_peer.d_remote, g_peer.remote, nranks * sizeof(unsigned char*), hipMemcpyHostToDevice));
+    ADMM_HIP_CHECK(hipDeviceSynchronize());
+    g_info.nranks = nranks; g_info.rank = rank; g_info.active = true; g_info.backend = COMM_PEER;
+    g_seq = 0;
+}
+
 void comm_finalize() {
     std::lock_guard<std::mutex> lk(g_mu);
+    (void)hipDeviceSynchronize();
     if (g_comm) { (void)ncclCommDestroy(g_comm); g_comm = nullptr; }
+    if (g_info.backend == COMM_SHM) shm_close();
+    if (g_peer.local) peer_close();
+    if (g_err) *g_err = 0;
     g_info = CommInfo();
+    g_seq = 0;
 }
 
 }  // namespace admm

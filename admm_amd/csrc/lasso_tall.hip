@@ -67,10 +67,12 @@ struct TallParams {
     double* P;                  // [2][nwg][8]
     float* beta;                // [nlam][p] snapshots of z (standardised scale)
     int* niter;                 // [nlam]
+    double* trace;              // optional [trace_cap][kTraceFields] decision records (admm_hip_lasso_plan_trace_*), or NULL
+    long long trace_cap;
 };
 
 constexpr int kTailThreads = 256;
-constexpr int kTailLanes = 8;             // lanes cooperating on one element's partial sums
+constexpr int kTailLanes = kSySumLanes;   // lanes cooperating on one element's partial sums
 constexpr int kTailElems = kTailThreads / kTailLanes;
 
 // Scalar control of one iteration, run by a single workgroup: reduce the previous iteration's norm
@@ -92,22 +94,28 @@ __device__ void tall_decide(const TallParams& q, int par) {
     block_sum<double, 6>(acc, dscratch);
     if (threadIdx.x != 0) return;
     const double r2 = acc[0], dz2 = acc[1], daz2 = acc[2], x2 = acc[3], z2 = acc[4], y2 = acc[5];
+    double tr_rp = 0, tr_rd = 0, tr_c = 0, tr_code = ADMM_TRACE_COLD;
     TallCtl out = in;
     out.first = 0;
     out.fin_idx = -1; out.fin_niter = 0;
     if (!in.first) {
         const double rp = sqrt(r2);                    // resid_primal            FADMMBase.h:208
         const double rd = in.rho * sqrt(dz2);          // resid_dual              ADMMLassoTall.h:150-153
+        tr_rp = rp; tr_rd = rd;
         if (rp < in.eps_primal && rd < in.eps_dual) {  // converged()             FADMMBase.h:213-217
             out.fin_idx = in.lam_idx; out.fin_niter = in.iter + 1;
             out.mode = 0;
+            tr_code = ADMM_TRACE_CONVERGED;
         } else {
             const double old_c = in.adj_c;
             const double c = in.rho * rp * rp + in.rho * daz2;     // compute_resid_combined  ADMMLassoTall.h:154-161
+            tr_c = c;
             if (c < 0.999 * old_c) {                   // FADMMBase.h:243-249
                 out.adj_a = in.a_next; out.adj_c = c; out.tau = in.tau_next; out.restart = 0;
+                tr_code = ADMM_TRACE_ACCELERATE;
             } else {                                   // restart                 FADMMBase.h:250-256
                 out.adj_a = 1.0; out.adj_c = old_c / 0.999; out.tau = -1.0; out.restart = 1;
+                tr_code = ADMM_TRACE_RESTART;
             }
             out.mode = 1;
             out.iter = in.iter + 1;
@@ -132,6 +140,11 @@ __device__ void tall_decide(const TallParams& q, int par) {
     out.tau_next = (out.adj_a - 1.0) / out.a_next;
     out.total = in.total + 1;
     *outp = out;
+    if (q.trace != nullptr && in.total < q.trace_cap) {      // what FADMMBase.h:135-170 (print_row, commented out there) would print
+        double* t = q.trace + (size_t)in.total * ADMM_TRACE_FIELDS;
+        t[0] = in.lam_idx; t[1] = in.iter; t[2] = in.eps_primal; t[3] = in.eps_dual; t[4] = tr_rp; t[5] = tr_rd;
+        t[6] = tr_c; t[7] = in.adj_c; t[8] = tr_code; t[9] = in.rho;
+    }
 }
 
 struct TallDecideExtra {
@@ -215,35 +228,18 @@ tall_tail_kernel(TallParams q, int par) {
     // ---- x-update results a = Minv u, b = Minv w: kTailLanes lanes share one element and issue all
     // their partial loads at once, then combine with shuffles.
     float a = 0.f, b = 0.f;
-    if (valid) {
-        if (SYM) {
-            const int cbi = i / kSyCB, rbi = i / kSyRB;
-            const int rb0 = cbi / 2;
-            const int ndot = q.nrb - rb0;
-            const int nax = min(q.ncb - 1, 2 * rbi + 1) + 1;
-            const int ntot = ndot + nax;
-            // 16 partials per lane and array in flight: one memory round trip up to 128 partials (p <= 10^4: all elements)
-            for (int k0 = 0; k0 < ntot; k0 += 16 * kTailLanes) {
-                float va[16], vb[16];
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const int k = k0 + j * kTailLanes + sub;
-                    va[j] = 0.f; vb[j] = 0.f;
-                    if (k < ndot) { const size_t o = (size_t)(rb0 + k) * q.ldo + i; va[j] = q.dot0[o]; vb[j] = q.dot1[o]; }
-                    else if (k < ntot) { const size_t o = (size_t)(k - ndot) * q.ldo + i; va[j] = q.axp0[o]; vb[j] = q.axp1[o]; }
-                }
-#pragma unroll
-                for (int j = 0; j < 16; ++j) { a += va[j]; b += vb[j]; }
-            }
-        } else {
+    if (SYM) {
+        symv_sum_partials<kTailLanes>(q.dot0, q.dot1, q.axp0, q.axp1, q.ldo, q.nrb, q.ncb, i, sub, valid, a, b);
+    } else {
+        if (valid) {
             for (int k = sub; k < q.nseg; k += kTailLanes) {
                 const size_t o = (size_t)k * q.part_stride + i;
                 a += q.a_part[o]; b += q.b_part[o];
             }
         }
-    }
 #pragma unroll
-    for (int m = 1; m < kTailLanes; m <<= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }
+        for (int m = 1; m < kTailLanes; m <<= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }
+    }
     if (c.done && c.fin_idx < 0) return;
 
     double acc[6] = {0, 0, 0, 0, 0, 0};
@@ -293,6 +289,8 @@ struct TallPlan final : LassoPlan {
     DevBuf<double> P, dlam;
     DevBuf<TallCtl> ctl;
     TallParams q{};
+    DevBuf<double> trace;
+    long long trace_cap = 0, trace_n = 0;
     TallCtl* hctl = nullptr;
     float* hbeta = nullptr;                             // pinned landing buffer of the beta snapshots (nlam x p)
 
@@ -350,9 +348,20 @@ struct TallPlan final : LassoPlan {
         S.t_eigs = now_s() - t0;
 
         // (X'X + rho I)^-1, cached for the whole path (rho never changes: ADMMLassoTall.h:97)
+        // Default: factorise and invert in float (the reference's LLT is a float factorisation, XX.diagonal() += rho in float).
+        // ADMM_HIP_INVERSE=f64: the same float Gram factorised and inverted in double, rounded to float once -- each entry
+        // of the cached inverse then carries half an ulp instead of cond * ulp (useful when n ~ p); it costs 150 ms more at
+        // p = 10^4 and does not change how often the stopping rule flips against a float Cholesky solve (measured with
+        // tests/tools/flip_floor.py: 45 vs 44 of 185 lambdas, the reference's own solve against the exact one: 39).
         t0 = now_s();
-        add_diag<float>(M.get(), ldp, p, (float)rho, st);
-        spd_inverse_f32(M.get(), ldp, p, st);
+        bool inv64 = false;
+        if (const char* e = std::getenv("ADMM_HIP_INVERSE")) inv64 = std::string(e) == "f64";
+        if (inv64) {
+            spd_inverse_f32_via_f64(M.get(), ldp, p, (double)(float)rho, st);
+        } else {
+            add_diag<float>(M.get(), ldp, p, (float)rho, st);
+            spd_inverse_f32(M.get(), ldp, p, st);
+        }
         ADMM_HIP_CHECK(hipStreamSynchronize(st));
         S.t_factor = now_s() - t0;
         // X itself is no longer needed by the loop (only X'y and Minv are): release 4np bytes.
@@ -389,6 +398,17 @@ struct TallPlan final : LassoPlan {
         ADMM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&hctl), 2 * sizeof(TallCtl), hipHostMallocDefault));
         ADMM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&hbeta), (size_t)nlam * p * sizeof(float), hipHostMallocDefault));
         ADMM_HIP_CHECK(hipStreamSynchronize(st));
+    }
+
+    void enable_trace(long long cap) override {
+        trace.alloc((size_t)cap * ADMM_TRACE_FIELDS);
+        trace_cap = cap; trace_n = 0;
+        q.trace = trace.get(); q.trace_cap = cap;
+    }
+    long long read_trace(double* out, long long cap) override {
+        const long long nrec = std::min(std::min(trace_n, trace_cap), cap);
+        if (nrec > 0) ADMM_HIP_CHECK(hipMemcpy(out, trace.get(), (size_t)nrec * ADMM_TRACE_FIELDS * sizeof(double), hipMemcpyDeviceToHost));
+        return nrec;
     }
 
     void debug_dump(const char* tag, const float* dptr, size_t n) {
@@ -455,6 +475,7 @@ struct TallPlan final : LassoPlan {
         };
         int slot = 0;
         enqueue_batch(slot);
+        ADMM_HIP_CHECK(hipGetLastError());                 // launch failures surface here
         bool done = false;
         while (!done) {
             enqueue_batch(slot ^ 1);                       // keep one batch in flight while polling the previous one
@@ -505,6 +526,7 @@ struct TallPlan final : LassoPlan {
             tot_it += res.niter[l];
         }
         S.total_iter = tot_it;
+        trace_n = hctl[0].done ? std::max(hctl[0].total, hctl[1].total) : 0;      // decisions taken (the sticky no-op decisions after `done` do not write)
         res.stats = S;
     }
 };

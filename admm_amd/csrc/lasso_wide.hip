@@ -56,6 +56,7 @@ struct WideParams {
     float* x;                             // p, dense storage of the sparse main_x
     float* Ax; float* z; float* y;        // n
     float* axpart;                        // [kAxWG][ldn]
+    float* tbuf;                          // [ldn] t (or t / gamma) of the current iteration in global memory (large-n mode only)
     long long ldn;
     WideCtl* ctl;                         // [2]
     double* P;                            // [nwg_tail][8]: |r|^2, |z_new - z|^2, |Ax|^2, |z_new|^2, |y_new|^2
@@ -76,45 +77,10 @@ __device__ __forceinline__ float prox_f(float val, float thresh, float denom, bo
     return 0.f;
 }
 
-// x(g): every workgroup evaluates (identically) the decision for iteration g-1 -- convergence, rho
-// adaptation, lambda schedule, which x-update runs now -- then builds t = Ax + z + y / rho in LDS and
-// updates the columns its waves own.  A regular step visits every column (x = prox(x - X_j't / gamma)),
-// an active-set step only the current non-zeros; both stream X_j once with 16-byte loads.
-template <int RT>     // RT > 0: fused gather, a column is RT float4 per lane (n <= RT * 256); RT == 0: x-update only
-__global__ void __launch_bounds__(kWideThreads)
-wide_x_kernel(WideParams q, int par) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const WideCtl in = q.ctl[par];
-    WideCtl* outp = &q.ctl[par ^ 1];
-    if (in.done) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) *outp = in;
-        return;
-    }
-    const int npad = (q.n + 255) / 256 * 256;
-    float* tl = reinterpret_cast<float*>(smem_raw);            // t        [npad]
-    float* tdl = tl + npad;                                    // t/gamma  [npad]
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int w = blockIdx.x * (kWideThreads / 64) + wid;
-    // Workgroups that take part in every kind of step (all of them when not fused) fetch what does not depend on
-    // the decision in the same round trip as the decision's inputs: the operands of t = Ax + z + y / rho and, fused,
-    // this wave's first 512 slot values of an active-set step (most iterations are active-set steps).
-    const bool always = RT == 0 || (int)blockIdx.x < kActWG;
-    float xs0[8];
-    if (RT > 0 && always) {
-        const int NWa = min((int)gridDim.x, kActWG) * (kWideThreads / 64);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const long long jl = (long long)(u * 64 + lane) * NWa + w;
-            xs0[u] = (jl < q.p) ? q.x[jl] : 0.f;
-        }
-    }
-    auto stage_t = [&]() {
-        for (int i = threadIdx.x; i < npad; i += kWideThreads) {
-            tl[i] = i < q.n ? q.Ax[i] + q.z[i] : 0.f;
-            tdl[i] = i < q.n ? q.y[i] : 0.f;
-        }
-    };
-    if (always) stage_t();
+// The decision for the iteration that just finished and the kind of x-update that runs now: convergence, rho adaptation
+// (ADMMBase.h:85-109), lambda schedule (init_warm), regular / active-set schedule (ADMMLassoWide.h:121-155).  Every wave
+// that calls it reduces the norm partials itself in a fixed order (no LDS, no barrier) and gets the identical result.
+__device__ __forceinline__ WideCtl wide_decide(const WideParams& q, const WideCtl& in, int lane, int& lam_finished, int& niter_val) {
     // norm partials of the previous iteration: every wave reduces them itself (fixed order), no LDS, no barrier
     double sums[5] = {0, 0, 0, 0, 0};
     for (int row = lane; row < q.nwg_tail; row += 64) {
@@ -126,7 +92,7 @@ wide_x_kernel(WideParams q, int par) {
     const double r2 = sums[0], dz2 = sums[1], ax2 = sums[2], z2 = sums[3], y2 = sums[4];
     WideCtl out = in;
     out.first = 0;
-    int lam_finished = -1, niter_val = 0;
+    lam_finished = -1; niter_val = 0;
     if (!in.first) {
         const double rp = sqrt(r2);                                   // resid_primal = ||Ax + z||       ADMMBase.h:181
         const double rd = in.rho * q.sqrt_gamma * sqrt(dz2);          // rho sqrt(sprad) ||z_new - z||   ADMMLassoWide.h:183-186
@@ -160,6 +126,52 @@ wide_x_kernel(WideParams q, int par) {
         out.type = (is_regular_update((unsigned)out.counter) && out.lam < q.lambda0) ? W_REG : W_ACT;
         out.counter++;
     }
+    return out;
+}
+
+// x(g): every workgroup evaluates (identically) the decision for iteration g-1 -- convergence, rho
+// adaptation, lambda schedule, which x-update runs now -- then builds t = Ax + z + y / rho in LDS and
+// updates the columns its waves own.  A regular step visits every column (x = prox(x - X_j't / gamma)),
+// an active-set step only the current non-zeros; both stream X_j once with 16-byte loads.
+// TG (n too large for the LDS): t is not staged here but read from q.tbuf, written by wide_t_kernel just before.
+template <int RT, bool TG = false>     // RT > 0: fused gather, a column is RT float4 per lane (n <= RT * 256); RT == 0: x-update only
+__global__ void __launch_bounds__(kWideThreads)
+wide_x_kernel(WideParams q, int par) {
+    static_assert(!(TG && RT > 0), "the global-t mode is the unfused x-update");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const WideCtl in = q.ctl[par];
+    WideCtl* outp = &q.ctl[par ^ 1];
+    if (in.done) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) *outp = in;
+        return;
+    }
+    const int npad = (q.n + 255) / 256 * 256;
+    float* tl = reinterpret_cast<float*>(smem_raw);            // t        [npad]
+    float* tdl = tl + npad;                                    // t/gamma  [npad]
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int w = blockIdx.x * (kWideThreads / 64) + wid;
+    // Workgroups that take part in every kind of step (all of them when not fused) fetch what does not depend on
+    // the decision in the same round trip as the decision's inputs: the operands of t = Ax + z + y / rho and, fused,
+    // this wave's first 512 slot values of an active-set step (most iterations are active-set steps).
+    const bool always = RT == 0 || (int)blockIdx.x < kActWG;
+    float xs0[8];
+    if (RT > 0 && always) {
+        const int NWa = min((int)gridDim.x, kActWG) * (kWideThreads / 64);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long long jl = (long long)(u * 64 + lane) * NWa + w;
+            xs0[u] = (jl < q.p) ? q.x[jl] : 0.f;
+        }
+    }
+    auto stage_t = [&]() {
+        for (int i = threadIdx.x; i < npad; i += kWideThreads) {
+            tl[i] = i < q.n ? q.Ax[i] + q.z[i] : 0.f;
+            tdl[i] = i < q.n ? q.y[i] : 0.f;
+        }
+    };
+    if (always && !TG) stage_t();
+    int lam_finished = -1, niter_val = 0;
+    const WideCtl out = wide_decide(q, in, lane, lam_finished, niter_val);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (lam_finished >= 0) q.niter[lam_finished] = niter_val;
         *outp = out;
@@ -179,22 +191,24 @@ wide_x_kernel(WideParams q, int par) {
     // fused: an active-set iteration is done by the first kActWG workgroups only (few columns, few partials);
     // the others leave here, before any barrier or LDS traffic
     if (RT > 0 && !reg && !always) return;
-    if (!always) stage_t();                                            // regular step of a workgroup beyond kActWG
-    // t = cache_Ax + aux_z + dual_y / Scalar(rho); the active-set form divides by gamma first (:90, :141)
-    const float rho_f = (float)out.rho;
-    for (int i = threadIdx.x; i < npad; i += kWideThreads) {       // same thread wrote these slots above
-        const float t = tl[i] + tdl[i] / rho_f;
-        tl[i] = t;
-        tdl[i] = t / q.gamma;
+    if (!TG) {
+        if (!always) stage_t();                                        // regular step of a workgroup beyond kActWG
+        // t = cache_Ax + aux_z + dual_y / Scalar(rho); the active-set form divides by gamma first (:90, :141)
+        const float rho_f = (float)out.rho;
+        for (int i = threadIdx.x; i < npad; i += kWideThreads) {   // same thread wrote these slots above
+            const float t = tl[i] + tdl[i] / rho_f;
+            tl[i] = t;
+            tdl[i] = t / q.gamma;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     const double pen_d = (double)out.lam / (out.rho * (double)q.gamma);
     const float penalty = (float)pen_d;                               // `const Scalar penalty` (:89)
     const float thresh_a = q.enet ? q.alpha * penalty : penalty;
     const float denom_a = q.enet ? (float)(1.0 + (double)penalty * (1.0 - (double)q.alpha)) : 1.f;
     const float thresh_r = (float)((double)q.alpha * pen_d);
     const float denom_r = (float)(1.0 + pen_d * (1.0 - (double)q.alpha));
-    const float* tv = reg ? tl : tdl;
+    const float* tv = TG ? q.tbuf : (reg ? tl : tdl);
     const int nblk = (RT > 0 && !reg) ? min((int)gridDim.x, kActWG) : (int)gridDim.x;
     const int NW = nblk * (kWideThreads / 64);
     const int nv = (q.n + 3) / 4 * 4;
@@ -308,6 +322,28 @@ wide_x_kernel(WideParams q, int par) {
             if (rr < q.ldn) *reinterpret_cast<float4*>(q.axpart + (size_t)blockIdx.x * q.ldn + rr) = sacc;
         }
     }
+}
+
+// Large-n mode (2 n floats exceed the LDS of a workgroup): t = Ax + z + y / rho of the iteration about to run (divided by
+// gamma on an active-set step) into global memory, by its own small launch just before the x-update.  Every workgroup
+// evaluates the same decision as the x-update will (same inputs, same code); the control block is published by the
+// x-update alone.
+__global__ void __launch_bounds__(kWideThreads)
+wide_t_kernel(WideParams q, int par) {
+    const WideCtl in = q.ctl[par];
+    if (in.done) return;
+    int lam_finished = -1, niter_val = 0;
+    const WideCtl out = wide_decide(q, in, threadIdx.x & 63, lam_finished, niter_val);
+    if (out.done || out.type == W_ZERO) return;
+    const int i = blockIdx.x * kWideThreads + threadIdx.x;
+    if (i >= q.ldn) return;
+    const float rho_f = (float)out.rho;
+    float t = 0.f;
+    if (i < q.n) {
+        t = (q.Ax[i] + q.z[i]) + q.y[i] / rho_f;
+        if (out.type != W_REG) t = t / q.gamma;
+    }
+    q.tbuf[i] = t;
 }
 
 // Gather mat-vec: axpart[b][i] = sum over the non-zero columns j owned by workgroup b of x_j X[i, j].
@@ -459,13 +495,14 @@ struct WidePlan final : LassoPlan {
     hipStream_t st;
     admm_stats setup_stats{};
     int n = 0, p = 0, nlam = 0, nwg_tail = 0, nwg_x = 0, fuse_rt = 0;
+    bool t_global = false;               // n too large for the LDS: t through global memory (wide_t_kernel)
     size_t lds_x = 0;
     long long ldn = 0;
     float sprad = 0.f, lambda0 = 0.f;
     double rho0 = 0;
     std::vector<double> lam_user;
     std::vector<float> lam_int;
-    DevBuf<float> x, Ax, z, y, axpart, beta, dlam;
+    DevBuf<float> x, Ax, z, y, axpart, tbuf, beta, dlam;
     DevBuf<int> niter, done;
     DevBuf<double> P;
     DevBuf<WideCtl> ctl;
@@ -514,6 +551,19 @@ struct WidePlan final : LassoPlan {
         fuse_rt = n <= 1024 ? 4 : (n <= 2048 ? 8 : (n <= 4096 ? 16 : 0));
         if (const char* e = std::getenv("ADMM_HIP_WIDE_FUSE")) if (std::string(e) == "0") fuse_rt = 0;
         lds_x = std::max((size_t)((n + 255) / 256 * 256) * 2 * sizeof(float), (size_t)4 * kWideThreads * sizeof(float4));
+        // The x-update stages t and t / gamma (2 n floats) in dynamic LDS: up to 64 KB by default, up to the device's
+        // opt-in limit (160 KB on gfx950) after raising the kernel's attribute; beyond that (n > ~20 000) t goes through
+        // global memory instead (one more small launch per iteration).  ADMM_HIP_WIDE_TGLOBAL=1 forces that mode.
+        if (lds_x > device_info().lds_per_block) {
+            if (lds_x <= device_info().lds_optin) {
+                ADMM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wide_x_kernel<0, false>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_x));
+            } else {
+                t_global = true;
+            }
+        }
+        if (const char* e = std::getenv("ADMM_HIP_WIDE_TGLOBAL")) if (std::string(e) == "1") t_global = true;
+        if (t_global) { fuse_rt = 0; lds_x = 0; tbuf.alloc(ldn); tbuf.zero(st); }
         // grid of the x-update launch: exactly ONE resident round of workgroups (a regular step streams all of X; a
         // partial second round runs at a fraction of the occupancy: 342 us instead of 280 us at C3 with 4 per CU
         // when 3 fit).  ADMM_HIP_WIDE_WGX overrides the workgroups per CU.
@@ -522,7 +572,8 @@ struct WidePlan final : LassoPlan {
             const void* fn = fuse_rt == 4 ? reinterpret_cast<const void*>(wide_x_kernel<4>)
                            : fuse_rt == 8 ? reinterpret_cast<const void*>(wide_x_kernel<8>)
                            : fuse_rt == 16 ? reinterpret_cast<const void*>(wide_x_kernel<16>)
-                                           : reinterpret_cast<const void*>(wide_x_kernel<0>);
+                           : t_global ? reinterpret_cast<const void*>(wide_x_kernel<0, true>)
+                                      : reinterpret_cast<const void*>(wide_x_kernel<0, false>);
             ADMM_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&wgx, fn, kWideThreads, lds_x));
             wgx = std::max(1, std::min(wgx, 4));
         }
@@ -539,7 +590,7 @@ struct WidePlan final : LassoPlan {
         q.eps_abs = pb.opts.eps_abs; q.eps_rel = pb.opts.eps_rel;
         q.sqrt_n = std::sqrt((double)n); q.sqrt_p = std::sqrt((double)p); q.sqrt_gamma = (double)std::sqrt(sprad);
         q.lambdas = dlam.get(); q.x = x.get(); q.Ax = Ax.get(); q.z = z.get(); q.y = y.get();
-        q.axpart = axpart.get(); q.ldn = ldn; q.fused = fuse_rt ? 1 : 0; q.nwg_x = nwg_x;
+        q.axpart = axpart.get(); q.tbuf = tbuf.get(); q.ldn = ldn; q.fused = fuse_rt ? 1 : 0; q.nwg_x = nwg_x;
         q.ctl = ctl.get(); q.P = P.get(); q.beta = beta.get(); q.niter = niter.get(); q.done = done.get();
         ADMM_HIP_CHECK(hipStreamSynchronize(st));
     }
@@ -558,7 +609,12 @@ struct WidePlan final : LassoPlan {
                 case 8: hipLaunchKernelGGL(wide_x_kernel<8>, dim3(nwg_x), dim3(kWideThreads), lds_x, st, q, par); break;
                 case 16: hipLaunchKernelGGL(wide_x_kernel<16>, dim3(nwg_x), dim3(kWideThreads), lds_x, st, q, par); break;
                 default:
-                    hipLaunchKernelGGL(wide_x_kernel<0>, dim3(nwg_x), dim3(kWideThreads), lds_x, st, q, par);
+                    if (t_global) {
+                        hipLaunchKernelGGL(wide_t_kernel, dim3((unsigned)((ldn + kWideThreads - 1) / kWideThreads)), dim3(kWideThreads), 0, st, q, par);
+                        hipLaunchKernelGGL((wide_x_kernel<0, true>), dim3(nwg_x), dim3(kWideThreads), 0, st, q, par);
+                    } else {
+                        hipLaunchKernelGGL((wide_x_kernel<0, false>), dim3(nwg_x), dim3(kWideThreads), lds_x, st, q, par);
+                    }
                     hipLaunchKernelGGL(wide_ax_kernel, dim3(kAxWG), dim3(kWideThreads), 0, st, q);
             }
             hipLaunchKernelGGL(wide_tail_kernel, dim3(nwg_tail), dim3(kWideThreads), 0, st, q, par);

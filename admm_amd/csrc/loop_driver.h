@@ -2,6 +2,7 @@
 // the device, poll a sticky `done` word through pinned memory, always keeping one batch in flight.
 #pragma once
 #include "admm_internal.h"
+#include "comm.h"
 
 namespace admm {
 
@@ -33,10 +34,12 @@ inline LoopTimes run_until_done(hipStream_t st, const int* d_done, int batch, lo
     };
     int slot = 0;
     enqueue_batch(slot);
+    ADMM_HIP_CHECK(hipGetLastError());                 // a failed launch (e.g. too much LDS requested) surfaces here, not as a hang
     bool done = false;
     while (!done) {
         enqueue_batch(slot ^ 1);
         ADMM_HIP_CHECK(hipEventSynchronize(poll[slot].e));
+        comm_check();                                  // a timed-out exchange ends the solve with ADMM_ERR_COMM
         done = h_done[slot] != 0;
         slot ^= 1;
         if (!done && g > max_iters + 2 * batch)

@@ -62,6 +62,8 @@ void spd_inverse_mfma_f32(float* A, long long lda, int n, hipStream_t st);
 // fp32 SPD inverse of a matrix stored in whole 128-blocks (lda >= round_up(n, 128), that many zero-padded columns
 // allocated): hand-written matrix-core kernels for n >= 256, potrf + two trsm below (ADMM_HIP_FACTOR=rocsolver forces the latter).
 void spd_inverse_f32(float* A, long long lda, int n, hipStream_t st);
+// (A + diag I)^-1 of a float matrix, factorised and inverted in double and rounded to float once (same storage).
+void spd_inverse_f32_via_f64(float* A, long long lda, int n, double diag, hipStream_t st);
 // fp64 counterparts (gemm_f64_mfma.hip); same storage requirements.
 void spd_inverse_mfma_f64(double* A, long long lda, int n, hipStream_t st);
 void spd_inverse_f64(double* A, long long lda, int n, hipStream_t st);

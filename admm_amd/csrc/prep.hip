@@ -36,6 +36,11 @@ const DeviceInfo& device_info() {
         ADMM_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
         cache[dev].num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         cache[dev].lds_per_block = prop.sharedMemPerBlock;
+        int optin = 0;
+        if (hipDeviceGetAttribute(&optin, hipDeviceAttributeSharedMemPerBlockOptin, dev) == hipSuccess && optin > 0)
+            cache[dev].lds_optin = std::max((size_t)optin, cache[dev].lds_per_block);
+        else
+            cache[dev].lds_optin = cache[dev].lds_per_block;
         have[dev] = 1;
     }
     return cache[dev];
@@ -546,6 +551,38 @@ void spd_inverse_full(T* A, long long lda, int n, hipStream_t st) {
     ADMM_HIP_CHECK(hipStreamSynchronize(st));        // X is released on return
 }
 template void spd_inverse_full<float>(float*, long long, int, hipStream_t);
+
+// dst (double) = src (float) with `diag` added on the diagonal (in float, like the reference); and the way back (one rounding per entry).
+__global__ void __launch_bounds__(256) widen_add_diag_kernel(const float* __restrict__ src, double* __restrict__ dst, long long ld, int n, double diag) {
+    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
+    if (i < ld) {
+        double v = 0.0;
+        if (i < n && j < n) {
+            const float a = src[(size_t)j * ld + i];
+            v = (i == j) ? (double)__fadd_rn(a, (float)diag) : (double)a;      // XX.diagonal().array() += rho is a float addition (ADMMLassoTall.h:204)
+        }
+        dst[(size_t)j * ld + i] = v;
+    }
+}
+__global__ void __launch_bounds__(256) narrow_kernel(const double* __restrict__ src, float* __restrict__ dst, long long ld, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
+    if (i < ld) dst[(size_t)j * ld + i] = (i < n && j < n) ? (float)src[(size_t)j * ld + i] : 0.f;
+}
+
+// A (float, SPD once `diag` is added, both triangles valid, whole 128-blocks as for spd_inverse_f32) -> (A + diag I)^-1:
+// the Cholesky factorisation and the inverse are done in DOUBLE on the fp64 matrix cores and the result is rounded to
+// float ONCE, so that each entry of the cached inverse carries half an ulp of error instead of the accumulated
+// rounding of an fp32 factorisation (lasso_tall.hip: fewer stopping-rule / restart flips against a Cholesky solve).
+void spd_inverse_f32_via_f64(float* A, long long lda, int n, double diag, hipStream_t st) {
+    const int pp = round_up(n, 128);
+    ADMM_REQUIRE(lda >= pp, "spd_inverse_f32_via_f64: leading dimension must cover whole 128-row blocks");
+    DevBuf<double> D((size_t)lda * pp);
+    hipLaunchKernelGGL(widen_add_diag_kernel, dim3((unsigned)((lda + 255) / 256), pp), dim3(256), 0, st, A, D.get(), lda, n, diag);
+    spd_inverse_f64(D.get(), lda, n, st);
+    hipLaunchKernelGGL(narrow_kernel, dim3((unsigned)((lda + 255) / 256), pp), dim3(256), 0, st, D.get(), A, lda, n);
+    ADMM_HIP_CHECK(hipGetLastError());
+    ADMM_HIP_CHECK(hipStreamSynchronize(st));
+}
 
 void spd_inverse_f32(float* A, long long lda, int n, hipStream_t st) {
     const char* e = std::getenv("ADMM_HIP_FACTOR");

@@ -33,6 +33,9 @@ std::vector<double> make_lambda_grid(const LassoProblem& pb, double lambda0, int
 struct LassoPlan {
     virtual ~LassoPlan() = default;
     virtual void run(LassoResult& res) = 0;
+    // per-decision trace of the iteration control (admm_hip_lasso_plan_trace_*); solvers without one refuse
+    virtual void enable_trace(long long) { throw Error(ADMM_ERR_INVALID_ARG, "this solver records no decision trace (tall Lasso / Elastic net only)"); }
+    virtual long long read_trace(double*, long long) { return 0; }
 };
 std::unique_ptr<LassoPlan> make_tall_plan(DeviceData<float>&& d, const LassoProblem& pb, hipStream_t st);
 std::unique_ptr<LassoPlan> make_wide_plan(DeviceData<float>&& d, const LassoProblem& pb, hipStream_t st);

@@ -11,7 +11,7 @@
 //     axpy part:  y_i += a_ij v_j   -> 4 per-lane accumulators (v_j is wave-uniform, v_readlane)
 // The diagonal element contributes once (dot part).  Results are written as partials:
 //     dot[rb][j]  (rb = row block of 256)      axp[cb][i]  (cb = column block of 128)
-// and summed by the consumer (`symv_reduce` below, fused into the tall tail kernel):
+// and summed by the consumer (`symv_sum_partials` below, fused into the tall tail kernel):
 //     y_i = sum_{rb >= cb(i)/2} dot[rb][i] + sum_{cb <= 2 rb(i) + 1} axp[cb][i].
 // Deterministic (no atomics).  Partial traffic: (p/256 + p/128) * p * 8 bytes per launch, written
 // once and read once (about 9 % of the triangle at p = 10^4).
@@ -34,6 +34,7 @@ constexpr int kSyRB = 256;     // rows per tile
 constexpr int kSyCW = 32;      // columns per wave
 constexpr int kSyCB = 128;     // columns per workgroup tile
 constexpr int kSyThreads = 256;
+constexpr int kSySumLanes = 8;  // lanes that share one element when the consumer sums the partials (symv_sum_partials)
 
 struct SymvArgs {
     const float* A; long long lda; int p;
@@ -201,14 +202,37 @@ struct SymvPlan {
     }
 };
 
-// y_i from the partial arrays (device helper; `part` = 0 / 1 selects the right-hand side).
-__device__ __forceinline__ float symv_reduce(const float* dot, const float* axp, long long ldo, int nrb, int ncb, int i) {
-    const int cbi = i / kSyCB, rbi = i / kSyRB;
-    float s = 0.f;
-    for (int rb = cbi / 2; rb < nrb; ++rb) s += dot[(size_t)rb * ldo + i];
-    const int cmax = min(ncb - 1, 2 * rbi + 1);
-    for (int cb = 0; cb <= cmax; ++cb) s += axp[(size_t)cb * ldo + i];
-    return s;
+// y_i of both right-hand sides from the partial arrays.  NL lanes (a power of two <= 64, consecutive lanes of one
+// wave, `sub` = this lane's index among them) share element i: each issues up to 16 partial loads per array at once
+// (one memory round trip up to 16 * NL partials), then the lanes combine with shuffles.  The summation order is
+// fixed, so the result is bit-reproducible; every lane of the group returns the total.  Used by the tall tail
+// kernel (lasso_tall.hip), by the row-sharded x-update (tall_shard.hip) and by the test hook admm_hip_test_symv.
+template <int NL>
+__device__ __forceinline__ void symv_sum_partials(const float* __restrict__ dot0, const float* __restrict__ dot1,
+                                                  const float* __restrict__ axp0, const float* __restrict__ axp1,
+                                                  long long ldo, int nrb, int ncb, int i, int sub, bool valid, float& a, float& b) {
+    a = 0.f; b = 0.f;
+    if (valid) {
+        const int cbi = i / kSyCB, rbi = i / kSyRB;
+        const int rb0 = cbi / 2;
+        const int ndot = nrb - rb0;
+        const int nax = min(ncb - 1, 2 * rbi + 1) + 1;
+        const int ntot = ndot + nax;
+        for (int k0 = 0; k0 < ntot; k0 += 16 * NL) {
+            float va[16], vb[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int k = k0 + j * NL + sub;
+                va[j] = 0.f; vb[j] = 0.f;
+                if (k < ndot) { const size_t o = (size_t)(rb0 + k) * ldo + i; va[j] = dot0[o]; vb[j] = dot1[o]; }
+                else if (k < ntot) { const size_t o = (size_t)(k - ndot) * ldo + i; va[j] = axp0[o]; vb[j] = axp1[o]; }
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { a += va[j]; b += vb[j]; }
+        }
+    }
+#pragma unroll
+    for (int m = 1; m < NL; m <<= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }
 }
 
 }  // namespace admm

@@ -1,0 +1,42 @@
+// Test hooks behind the C ABI (include/admm_hip.h, "test hooks"): single kernels of the solvers run on caller data so
+// that the test-suite can compare them with the oracle / NumPy.  No solver entry point calls anything in this file.
+#include "symv_kernels.h"
+
+namespace admm {
+void require_device();
+
+// The consumer side of the symmetric mat-vec, with the tall tail kernel's geometry and summation order
+// (kSySumLanes lanes per element, 256 threads per workgroup).
+__global__ void __launch_bounds__(256)
+test_symv_finish_kernel(const float* dot0, const float* dot1, const float* axp0, const float* axp1, long long ldo, int nrb, int ncb,
+                        int p, float* y0, float* y1) {
+    const int sub = threadIdx.x & (kSySumLanes - 1);
+    const int i = blockIdx.x * (256 / kSySumLanes) + threadIdx.x / kSySumLanes;
+    float a, b;
+    symv_sum_partials<kSySumLanes>(dot0, dot1, axp0, axp1, ldo, nrb, ncb, i, sub, i < p, a, b);
+    if (i < p && sub == 0) { y0[i] = a; y1[i] = b; }
+}
+
+void test_symv(const float* A, int p, const float* v0, const float* v1, float* y0, float* y1) {
+    require_device();
+    Stream st;
+    const long long lda = round_up(p, 128), ldv = round_up(p, 256);      // the tall plan's storage (lasso_tall.hip)
+    DevBuf<float> dA((size_t)lda * lda), d0(ldv), d1(ldv), o0(ldv), o1(ldv);
+    dA.zero(st.s); d0.zero(st.s); d1.zero(st.s);
+    ADMM_HIP_CHECK(hipMemcpy2DAsync(dA.get(), lda * sizeof(float), A, (size_t)p * sizeof(float), (size_t)p * sizeof(float), p,
+                                    hipMemcpyHostToDevice, st.s));
+    ADMM_HIP_CHECK(hipMemcpyAsync(d0.get(), v0, (size_t)p * sizeof(float), hipMemcpyHostToDevice, st.s));
+    ADMM_HIP_CHECK(hipMemcpyAsync(d1.get(), v1, (size_t)p * sizeof(float), hipMemcpyHostToDevice, st.s));
+    SymvPlan sy;
+    sy.init(p, st.s);
+    sy.launch(dA.get(), lda, d0.get(), d1.get(), nullptr, st.s);
+    const int per = 256 / kSySumLanes;
+    hipLaunchKernelGGL(test_symv_finish_kernel, dim3((p + per - 1) / per), dim3(256), 0, st.s, sy.dot0.get(), sy.dot1.get(),
+                       sy.axp0.get(), sy.axp1.get(), sy.ldo, sy.nrb, sy.ncb, p, o0.get(), o1.get());
+    ADMM_HIP_CHECK(hipGetLastError());
+    ADMM_HIP_CHECK(hipMemcpyAsync(y0, o0.get(), (size_t)p * sizeof(float), hipMemcpyDeviceToHost, st.s));
+    ADMM_HIP_CHECK(hipMemcpyAsync(y1, o1.get(), (size_t)p * sizeof(float), hipMemcpyDeviceToHost, st.s));
+    st.sync();
+}
+
+}  // namespace admm

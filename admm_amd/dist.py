@@ -58,6 +58,58 @@ def init_comm_from_torch(device=None):
     init_comm(world, rank, bcast if world > 1 else None)
 
 
+PEER_HANDLE_BYTES = 64
+
+
+def init_comm_shm(nranks, rank, name):
+    """Attach the host shared-memory backend (all ranks on one host; `name` like "/admm_job42")."""
+    check(_lib.load().admm_hip_comm_init_shm(int(nranks), int(rank), name.encode()))
+
+
+def init_comm_peer(nranks, rank, allgather):
+    """Attach the one-shot peer-mapped all-reduce.  `allgather(buf: np.ndarray[uint8, 64]) -> np.ndarray[uint8, nranks * 64]`
+    must return the buffers of all ranks concatenated in rank order."""
+    lib = _lib.load()
+    mine = np.zeros(PEER_HANDLE_BYTES, dtype=np.uint8)
+    check(lib.admm_hip_comm_peer_prepare(int(nranks), mine.ctypes.data))
+    allh = np.ascontiguousarray(allgather(mine), dtype=np.uint8)
+    if allh.size != nranks * PEER_HANDLE_BYTES:
+        raise ValueError("allgather returned %d bytes, expected %d" % (allh.size, nranks * PEER_HANDLE_BYTES))
+    check(lib.admm_hip_comm_init_peer(int(nranks), int(rank), allh.ctypes.data))
+
+
+def init_comm_backend_from_torch(backend, device=None, name=None):
+    """Bootstrap `backend` in {"rccl", "peer", "shm"} over an initialised torch.distributed process group."""
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(), dist.get_world_size()
+    if backend == "rccl":
+        return init_comm_from_torch(device)
+    if backend == "shm":
+        return init_comm_shm(world, rank, name or "/admm_hip_%s" % dist.get_world_size())
+    if backend != "peer":
+        raise ValueError(backend)
+
+    def allgather(buf):
+        t = torch.from_numpy(buf.copy())
+        on_gpu = dist.get_backend() == "nccl"
+        if on_gpu:
+            t = t.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+        out = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(out, t)
+        return torch.cat(out).cpu().numpy()
+
+    init_comm_peer(world, rank, allgather)
+
+
+def allreduce_host(fbuf=None, dbuf=None):
+    """In-place sum all-reduce of host float32 / float64 arrays through the attached backend (test hook)."""
+    lib = _lib.load()
+    nf = 0 if fbuf is None else fbuf.size
+    nd = 0 if dbuf is None else dbuf.size
+    check(lib.admm_hip_comm_test_allreduce(fbuf.ctypes.data if nf else None, nf, dbuf.ctypes.data if nd else None, nd, 0))
+
+
 def finalize_comm():
     check(_lib.load().admm_hip_comm_finalize())
 

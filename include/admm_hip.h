@@ -137,6 +137,24 @@ ADMM_HIP_API int admm_hip_lasso_plan_create(const double* x, const double* y, in
 ADMM_HIP_API int admm_hip_lasso_plan_run(admm_hip_plan* plan, double* lambda_out, float* beta_out, int* niter_out, admm_stats* stats);
 ADMM_HIP_API int admm_hip_lasso_plan_destroy(admm_hip_plan* plan);
 
+/* Decision trace of a prepared tall Lasso / Elastic-net problem: what the reference's commented-out iteration table
+ * (print_row, FADMMBase.h:135-170) would print, recorded on the device by the iteration control itself, one record
+ * per decision (the cold-start decision first, then one per ADMM iteration, over all lambdas of a run in order).
+ * enable() before run(); read() afterwards returns min(records of the last run, capacity, cap_records) records of
+ * ADMM_TRACE_FIELDS doubles:
+ *   [0] lambda index  [1] iteration i within the lambda  [2] eps_primal  [3] eps_dual  (the thresholds iteration i was tested against)
+ *   [4] resid_primal  [5] resid_dual  [6] c = rho r_p^2 + rho ||z - adj_z||^2 (0 when converged)  [7] c_old (adj_c before)
+ *   [8] outcome ADMM_TRACE_*  [9] rho
+ * The parity tests use it to show that a lambda whose iteration count differs from the oracle's diverged at a
+ * threshold test decided inside rounding noise, instead of excusing count differences wholesale. */
+#define ADMM_TRACE_FIELDS 10
+#define ADMM_TRACE_COLD (-1)        /* first decision of a run: nothing to test yet */
+#define ADMM_TRACE_CONVERGED 0      /* r_p < eps_p and r_d < eps_d  (FADMMBase.h:213-217,237-238) */
+#define ADMM_TRACE_ACCELERATE 1     /* c < 0.999 c_old              (FADMMBase.h:243-249) */
+#define ADMM_TRACE_RESTART 2        /* otherwise                    (FADMMBase.h:250-256) */
+ADMM_HIP_API int admm_hip_lasso_plan_trace_enable(admm_hip_plan* plan, long long capacity_records);
+ADMM_HIP_API int admm_hip_lasso_plan_trace_read(admm_hip_plan* plan, double* out, long long cap_records, long long* nrecords_out);
+
 /* ---- one process per GPU: consensus Lasso with its row blocks spread over ranks (RCCL over xGMI).
  * Bootstrap: rank 0 calls admm_hip_comm_unique_id and ships the ADMM_HIP_UNIQUE_ID_BYTES bytes to the
  * other ranks over any channel (bench.py uses torch.distributed); every rank then calls
@@ -151,6 +169,22 @@ ADMM_HIP_API int admm_hip_lasso_plan_destroy(admm_hip_plan* plan);
 ADMM_HIP_API int admm_hip_comm_unique_id(void* id_out);
 ADMM_HIP_API int admm_hip_comm_init(int nranks, int rank, const void* id);
 ADMM_HIP_API int admm_hip_comm_finalize(void);
+/* Two more exchange backends behind the same entry points (one of the three is attached at a time; comm.h):
+ *  - PEER: one-shot all-reduce over peer-mapped device memory.  Every rank calls admm_hip_comm_peer_prepare on its own
+ *    device (allocates its exchange buffer, returns its ADMM_HIP_PEER_HANDLE_BYTES-byte hipIpc handle), the caller
+ *    gathers the handles of all ranks in rank order over any channel, then every rank calls admm_hip_comm_init_peer.
+ *    The ranks may be processes on different GPUs of one node (xGMI) or -- for tests -- on the same GPU.
+ *  - SHM: through a POSIX shared-memory segment `name` ("/something", the same on every rank of one host).  Slow; lets
+ *    the multi-rank code run as several processes on ONE GPU without RCCL, bit-identical to PEER.
+ * Every wait is bounded (20 s): a missing rank yields ADMM_ERR_COMM from the running solver call, never a hang.
+ * Ranks should synchronise (barrier) before admm_hip_comm_finalize. */
+#define ADMM_HIP_PEER_HANDLE_BYTES 64
+ADMM_HIP_API int admm_hip_comm_peer_prepare(int nranks, void* handle_out);
+ADMM_HIP_API int admm_hip_comm_init_peer(int nranks, int rank, const void* handles_all_ranks);
+ADMM_HIP_API int admm_hip_comm_init_shm(int nranks, int rank, const char* name);
+/* Test hook: in-place sum all-reduce of a device (mem = ADMM_MEM_DEVICE) or host float / double pair through the
+ * attached backend, synchronous.  nf / nd may be 0. */
+ADMM_HIP_API int admm_hip_comm_test_allreduce(float* fbuf, long long nf, double* dbuf, long long nd, int mem);
 ADMM_HIP_API int admm_hip_parlasso_dist(const double* x_local, const double* y_local, int n_local, long long n_total, int p, int mem,
                            const double* lambda_in, int nlambda_in, int nlambda_auto, double lmin_ratio,
                            int standardize, int intercept, int nthread, const admm_opts* opts,
@@ -166,6 +200,19 @@ ADMM_HIP_API int admm_hip_device_count(void);
 ADMM_HIP_API int admm_hip_set_device(int device);
 /* hipDeviceSynchronize on the current device (bench.py brackets its timed region with it). */
 ADMM_HIP_API int admm_hip_device_synchronize(void);
+
+
+/* ---- test hooks: exported so that the test-suite can put single kernels / host routines under the oracle through
+ * the C ABI.  Not used by any solver entry point above. ---- */
+
+/* The host logic of the loose Lanczos call (ADMMLassoTall.h:196-201 -> SymEigsSolver.h) against a dense symmetric
+ * float matrix in HOST memory (n x n, column-major).  Runs without a GPU (CPU test-suite). */
+ADMM_HIP_API int admm_hip_host_lanczos(const float* A, int n, float* eig_out, int* nmatop_out);
+
+/* The tall x-update mat-vec exactly as the solver runs it for p >= 2048: symv2_lower_kernel on the lower triangle of
+ * the symmetric p x p float matrix A (HOST, column-major, leading dimension p) against the two right-hand sides
+ * v0, v1 (HOST, length p), followed by the tail kernel's ordered partial reduction.  y0 = A v0, y1 = A v1 (HOST). */
+ADMM_HIP_API int admm_hip_test_symv(const float* A, int p, const float* v0, const float* v1, float* y0, float* y1);
 
 #ifdef __cplusplus
 }

@@ -46,8 +46,15 @@ def _lasso_family(x, y, lam, nlambda, lmin_ratio, standardize, intercept, opts, 
     nl = lam.size
     beta = np.zeros((p + 1, nl), dtype=F)
     niter = np.zeros(nl, dtype=np.int32)
+    if detail is not None and detail.get("trace") is not None:
+        solver.trace = detail["trace"]
+    if detail is not None and detail.get("follow") is not None:          # tests: follow another execution's decisions
+        solver.follow = iter(detail["follow"])
+        solver.follow_band = float(detail.get("follow_band", 8.0))
+        solver.forced = detail.setdefault("forced", [])
     for i in range(nl):
         ilambda = lam[i] * n / np.float64(std.scaleY)       # Lasso.cpp:99
+        solver.lam_idx = i
         if i == 0:
             solver.init(ilambda, rho)
         else:

@@ -54,10 +54,75 @@ def _sqnorm(v, T):
     return T((v * v).sum(dtype=T))
 
 
+class FollowMismatch(AssertionError):
+    """Follow mode: the followed execution took a decision this run cannot explain as a near-tie."""
+
+
 class FADMM:
     """Goldstein fast ADMM with restart; subclasses define next_x/next_z/residual."""
 
     update_rho_active = True
+    trace = None     # set to a list to collect one record per iteration, in the layout of include/admm_hip.h (ADMM_TRACE_*)
+    lam_idx = 0
+    # Follow mode (tests only): `follow` = iterator over the decision records of ANOTHER execution of this algorithm
+    # (libadmm_hip's trace, cold-start record removed).  Wherever this run's own threshold test disagrees with the
+    # followed one AND the disagreement is a near-tie that rounding decides, the followed outcome is taken and logged in
+    # `forced`; any other disagreement raises FollowMismatch.  The two executions then stay on one trajectory and can be
+    # compared column by column.  "Near-tie" is measured against the rounding noise of the deciding quantity itself, in
+    # units of float ulps of the iterates (`_noise`): a decision may be taken from the followed run only if moving every
+    # entry of x and z by at most `follow_band` ulps could have produced it here.
+    follow = None
+    follow_band = 8.0
+    forced = None
+    ndecisions = 0
+
+    def _trace(self, i, c, c_old, code):
+        if self.trace is not None:
+            self.trace.append((self.lam_idx, i, self.eps_primal, self.eps_dual, self.resid_primal, self.resid_dual,
+                               c, c_old, code, self.rho))
+
+    def _noise(self):
+        """One-ulp noise floors of (resid_primal, resid_dual, c): what the three quantities move by when every entry of
+        main_x and aux_z moves by one float ulp.  aux_z comes out of a soft-threshold, so its entries carry the ulp of
+        the thresholded value |z| + penalty (an entry may sit at 0 in one execution and just beyond in another)."""
+        T = self.T
+        pen = abs(float(getattr(self, "lam", 0.0))) / self.rho if hasattr(self, "lam") else 1.0 / self.rho
+        uz = float(np.linalg.norm(np.spacing((np.abs(self.aux_z) + T(pen)).astype(T)).astype(np.float64)))
+        ux = float(np.linalg.norm(np.spacing(np.abs(self.main_x).astype(T)).astype(np.float64)))
+        n_p = np.hypot(ux, uz)
+        n_d = self.rho * 2.0 * uz                                   # z - old_z: both move
+        daz = float(np.sqrt(np.float64(_sqnorm(self.aux_z - self.adj_z, T))))
+        n_c = 2.0 * self.rho * (self.resid_primal * n_p + daz * 3.0 * uz)     # adj_z = (1+t) z - t z_old: up to 3 ulps of z
+        return n_p, n_d, n_c
+
+    def _decide(self, i, own, c, c_old):
+        """own: this run's outcome (0 converged, 1 accelerate, 2 restart).  Returns the outcome to act on."""
+        self.ndecisions += 1
+        if self.follow is None:
+            return own
+        g = next(self.follow)
+        if int(g[0]) != self.lam_idx or int(g[1]) != i:
+            raise FollowMismatch(f"followed trace is at (lambda {int(g[0])}, iteration {int(g[1])}), this run at ({self.lam_idx}, {i})")
+        theirs = int(g[8])
+        if theirs == own:
+            return own
+        n_p, n_d, n_c = self._noise()
+        tiny = 1e-300
+        if (theirs == 0) != (own == 0):
+            kind = "stop"
+            gp, gd = self.resid_primal - self.eps_primal, self.resid_dual - self.eps_dual      # >= 0 means "not converged"
+            if own != 0:      # they stopped, this run did not: both residuals must come under their thresholds within noise
+                ulps = max(gp / max(n_p, tiny), gd / max(n_d, tiny), 0.0)
+            else:             # this run stopped, they did not: one residual must reach its threshold within noise
+                ulps = min(-gp / max(n_p, tiny), -gd / max(n_d, tiny))
+        else:
+            kind = "restart"
+            ulps = abs(c - 0.999 * c_old) / max(2.0 * n_c, tiny)     # c_old carries the same noise from the previous iteration
+        rec = dict(record=self.ndecisions - 1, lam=self.lam_idx, iter=i, kind=kind, ulps=float(ulps), own=own, theirs=theirs)
+        if ulps > self.follow_band:
+            raise FollowMismatch(f"decision differs beyond rounding noise: {rec}")
+        self.forced.append(rec)
+        return theirs
 
     def _init_accel(self):
         self.adj_a = 1.0
@@ -80,18 +145,23 @@ class FADMM:
             r = self.next_residual()
             self.resid_primal = np.float64(T(np.linalg.norm(r)))
             self.dual_y = (self.adj_y + T(self.rho) * r).astype(T)
-            if self.resid_primal < self.eps_primal and self.resid_dual < self.eps_dual:
-                return i + 1
+            converged = self.resid_primal < self.eps_primal and self.resid_dual < self.eps_dual     # :213-217
             old_c = self.adj_c
-            self.adj_c = (self.rho * self.resid_primal * self.resid_primal
-                          + self.rho * np.float64(_sqnorm(self.aux_z - self.adj_z, T)))
-            if self.adj_c < 0.999 * old_c:
+            c = (self.rho * self.resid_primal * self.resid_primal
+                 + self.rho * np.float64(_sqnorm(self.aux_z - self.adj_z, T)))                       # :100-107, evaluated at :241
+            own = 0 if converged else (1 if c < 0.999 * old_c else 2)
+            self._trace(i, 0.0 if converged else c, old_c, own)
+            code = self._decide(i, own, c, old_c)
+            if code == 0:
+                return i + 1                                                                        # :237-238
+            self.adj_c = c
+            if code == 1:                                                                           # :243-249
                 old_a = self.adj_a
                 self.adj_a = 0.5 + 0.5 * np.sqrt(1 + 4.0 * old_a * old_a)
                 ratio = (old_a - 1.0) / self.adj_a
                 self.adj_z = (T(1 + ratio) * self.aux_z - T(ratio) * old_z).astype(T)
                 self.adj_y = (T(1 + ratio) * self.dual_y - T(ratio) * old_y).astype(T)
-            else:
+            else:                                                                                   # :250-256
                 self.adj_a = 1.0
                 self.adj_z = old_z
                 self.adj_y = old_y

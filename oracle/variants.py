@@ -1,0 +1,68 @@
+"""Rounding variants of the tall x-update for the NumPy oracle -- TEST INFRASTRUCTURE.
+
+The reference's x-update is `solver.solve(rhs)` with a float Eigen LLT (ADMMLassoTall.h:70-80,204-205).  The classes
+below run the SAME algorithm (everything else inherited from oracle.solvers.LassoTall) with mathematically identical
+x-updates that round differently:
+   llt32    float LAPACK Cholesky + two float triangular solves   (= oracle.solvers.LassoTall, the oracle proper)
+   inv32    float inverse formed from the float factor, float mat-vec        (libadmm_hip with ADMM_HIP_INVERSE=f32)
+   inv64r   inverse formed in double, rounded to float once, float mat-vec   (libadmm_hip with ADMM_HIP_INVERSE=f64)
+   exact    double Cholesky solve of the float system, result rounded to float (what the three above approximate)
+They calibrate how far two correct implementations of the reference's arithmetic may drift apart: ADMM's stopping rule
+and the restart rule are threshold tests on float residuals that, at eps = 1e-5, are mostly rounding noise, so the
+iteration counts (and with them the stopping iterate) change when only the rounding of the solve changes.
+Used by tests/test_flip_floor.py, tests/helpers.py and tests/tools/flip_floor.py.
+"""
+import contextlib
+
+import numpy as np
+import scipy.linalg as sla
+
+from . import entry, solvers
+
+F = np.float32
+MODES = ("llt32", "inv32", "inv64r", "exact")
+
+
+class LassoTallVariant(solvers.LassoTall):
+    mode = "llt32"
+
+    def init(self, lam, rho):
+        super().init(lam, rho)
+        if self.mode == "llt32":
+            return
+        p = self.p
+        XX = (self.X.T @ self.X).astype(F)                          # the float system the reference factorises
+        XX[np.arange(p), np.arange(p)] += F(self.rho)
+        A64 = XX.astype(np.float64)
+        if self.mode == "inv32":
+            L = np.tril(self.chol[0])
+            Li = sla.solve_triangular(L, np.eye(p, dtype=F), lower=True, check_finite=False).astype(F)
+            self.Minv = (Li.T @ Li).astype(F)
+        elif self.mode == "inv64r":
+            self.Minv = np.linalg.inv(A64).astype(F)
+        elif self.mode == "exact":
+            self.chol64 = sla.cho_factor(A64, lower=True)
+        else:
+            raise ValueError(self.mode)
+
+    def next_x(self):                                               # ADMMLassoTall.h:70-80
+        if self.mode == "llt32":
+            return super().next_x()
+        rhs = (self.XY - self.adj_y).astype(F)
+        rhs = (rhs.astype(np.float64) + self.rho * self.adj_z.astype(np.float64)).astype(F)
+        if self.mode == "exact":
+            return sla.cho_solve(self.chol64, rhs.astype(np.float64), check_finite=False).astype(F)
+        return (self.Minv @ rhs).astype(F)
+
+
+@contextlib.contextmanager
+def tall_variant(mode):
+    """Within the block oracle.entry's tall solver uses the given x-update rounding."""
+    assert mode in MODES
+    cls = type("LassoTall_" + mode, (LassoTallVariant,), {"mode": mode})
+    orig = entry.LassoTall
+    entry.LassoTall = cls
+    try:
+        yield
+    finally:
+        entry.LassoTall = orig

@@ -6,7 +6,9 @@ using namespace admm;
 
 __global__ void symv_finish(const float* d0, const float* x0, const float* d1, const float* x1, long long ldo, int nrb, int ncb, int p, float* y0, float* y1) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < p) { y0[i] = symv_reduce(d0, x0, ldo, nrb, ncb, i); y1[i] = symv_reduce(d1, x1, ldo, nrb, ncb, i); }
+    float a, b;
+    symv_sum_partials<1>(d0, d1, x0, x1, ldo, nrb, ncb, i, 0, i < p, a, b);
+    if (i < p) { y0[i] = a; y1[i] = b; }
 }
 
 template <typename F>

@@ -1,0 +1,82 @@
+"""One rank of a multi-process run on ONE GPU (spawned by tests/test_gpu_dist2.py): attaches the SHM or PEER exchange
+backend, checks a raw all-reduce, then runs the distributed consensus Lasso on its row slice and stores the result.
+
+    python tests/dist_worker.py <backend shm|peer> <rank> <nranks> <workdir> <case>
+
+No torch here: a plain ctypes caller of libadmm_hip.so, like the R shim would be.  Handles / barriers go through files."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+
+
+def file_allgather(workdir, tag, rank, nranks, payload, timeout=60.0):
+    path = os.path.join(workdir, f"{tag}.{rank}")
+    with open(path + ".tmp", "wb") as f:
+        f.write(payload.tobytes())
+    os.rename(path + ".tmp", path)
+    out, t0 = [], time.time()
+    for r in range(nranks):
+        pr = os.path.join(workdir, f"{tag}.{r}")
+        while not os.path.exists(pr):
+            if time.time() - t0 > timeout:
+                raise TimeoutError(pr)
+            time.sleep(0.005)
+        out.append(np.fromfile(pr, dtype=payload.dtype))
+    return np.concatenate(out)
+
+
+def barrier(workdir, tag, rank, nranks):
+    file_allgather(workdir, "bar_" + tag, rank, nranks, np.zeros(1, np.uint8))
+
+
+def problem(case):
+    """(x, y, K, kwargs) -- the same arrays on every rank (seeded)."""
+    from helpers import synth_lasso
+    if case == "tallblocks":          # both row blocks tall: Cholesky branch (PADMMLasso.h:23-24)
+        x, y = synth_lasso(900, 120, 10, seed=61)
+        return x, y, 2, dict(nlambda=6, maxit=400)
+    if case == "wideblocks":          # 403 rows in 4 blocks over 2 ranks: Woodbury branch (:25-30), remainder block on the last rank
+        x, y = synth_lasso(403, 300, 12, seed=62)
+        return x, y, 4, dict(nlambda=4, maxit=300)
+    raise SystemExit("unknown case " + case)
+
+
+def main():
+    backend, rank, nranks, workdir, case = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+    from admm_amd import _lib, dist as adist
+    lib = _lib.load()
+    assert lib.admm_hip_set_device(0) == 0
+    if backend == "shm":
+        adist.init_comm_shm(nranks, rank, "/admm_hip_test_" + os.path.basename(workdir))
+    else:
+        adist.init_comm_peer(nranks, rank, lambda mine: file_allgather(workdir, "ipc", rank, nranks, mine))
+    # ---- raw exchange: p floats + 3 doubles (the consensus payload), then a long message that needs chunking
+    rng = np.random.default_rng(1000 + rank)
+    f = rng.standard_normal(100003).astype(np.float32)
+    d = rng.standard_normal(3)
+    f0, d0 = f.copy(), d.copy()
+    adist.allreduce_host(f, d)
+    allf = file_allgather(workdir, "f", rank, nranks, f0).reshape(nranks, -1)
+    alld = file_allgather(workdir, "d", rank, nranks, d0).reshape(nranks, -1)
+    ef, ed = allf[0].copy(), alld[0].copy()
+    for r in range(1, nranks):
+        ef += allf[r]; ed += alld[r]
+    assert np.array_equal(f, ef) and np.array_equal(d, ed), "all-reduce differs from the rank-ordered sum"
+    for rep in range(5):                                   # several in a row: both parities of the slots, flag reuse
+        g = np.full(2500000, float(rank + 1 + rep), dtype=np.float32)     # 10 MB > one 4 MB slot
+        adist.allreduce_host(g, None)
+        assert np.all(g == sum(range(1, nranks + 1)) + nranks * rep), (rep, g[:3])
+    # ---- the distributed consensus solver on this rank's row slice
+    x, y, K, kw = problem(case)
+    n, p = x.shape
+    lo, hi = adist.row_partition(n, K, nranks, rank)
+    fit = adist.parlasso_dist(np.asfortranarray(x[lo:hi]), y[lo:hi], n, p, K, n_local=hi - lo, **kw)
+    np.savez(os.path.join(workdir, f"result.{rank}.npz"), beta=fit.beta_dense, niter=fit.niter, lam=fit.lambda_)
+    barrier(workdir, "end", rank, nranks)                  # nobody unmaps while a peer may still push
+    adist.finalize_comm()
+    print("rank", rank, "ok", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -55,3 +55,45 @@ def test_wide_user_lambda_and_maxit():
             assert list(fit.niter) == list(ref["niter"])
         for j in range(3):
             assert relerr(fit.beta_dense[:, j], ref["beta"][:, j]) < (TOL if maxit < 100 else 5e-3), j
+
+
+def _fit_env(x, y, nl, maxit, **env):
+    """Fit with kernel-variant environment knobs (read at plan creation)."""
+    import os
+    from admm_amd import admm_lasso
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return admm_lasso(x, y).penalty(nlambda=nl).opts(maxit=maxit).fit()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_wide_large_n_lds_modes():
+    """The x-update stages 2 n floats of t in LDS.  n = 9000 needs 72 KB (> the 64 KB default: opt-in attribute, up to
+    160 KB on gfx950) and n = 21000 needs 168 KB (> the opt-in limit: t goes through global memory instead).  Round 1
+    launched both sizes with an unchecked LDS request and failed every launch.  The global-t mode is bit-identical to
+    the LDS mode where both exist, and the large sizes reproduce the oracle."""
+    from oracle import entry
+    x, y = synth_lasso(3000, 3600, 15, seed=41)
+    a = _fit_env(x, y, 4, 40, ADMM_HIP_WIDE_FUSE="0")
+    b = _fit_env(x, y, 4, 40, ADMM_HIP_WIDE_TGLOBAL="1")
+    assert np.array_equal(a.beta_dense, b.beta_dense) and list(a.niter) == list(b.niter)
+    x, y = synth_lasso(9000, 9500, 20, seed=43)
+    a = _fit_env(x, y, 3, 25)
+    b = _fit_env(x, y, 3, 25, ADMM_HIP_WIDE_TGLOBAL="1")
+    assert np.array_equal(a.beta_dense, b.beta_dense) and list(a.niter) == list(b.niter)
+    ref = entry.admm_lasso(x, y, None, 3, 0.01, True, True, dict(entry.LASSO_OPTS, maxit=25))
+    assert list(a.niter) == list(ref["niter"])
+    for j in range(3):
+        assert relerr(a.beta_dense[:, j], ref["beta"][:, j]) < TOL, j
+    x, y = synth_lasso(21000, 21500, 20, seed=47)
+    a = _fit_env(x, y, 2, 12)
+    ref = entry.admm_lasso(x, y, None, 2, 0.01, True, True, dict(entry.LASSO_OPTS, maxit=12))
+    assert list(a.niter) == list(ref["niter"])
+    for j in range(2):
+        assert relerr(a.beta_dense[:, j], ref["beta"][:, j]) < TOL, j
