@@ -54,7 +54,8 @@ EXPORTS = ["admm_hip_lasso", "admm_hip_enet", "admm_hip_parlasso", "admm_hip_lad
            "admm_hip_parlasso_dist", "admm_hip_lasso_plan_create_dist",
            "admm_hip_lasso_plan_trace_enable", "admm_hip_lasso_plan_trace_read",
            "admm_hip_host_lanczos", "admm_hip_test_symv",
-           "admm_hip_comm_peer_prepare", "admm_hip_comm_init_peer", "admm_hip_comm_init_shm", "admm_hip_comm_test_allreduce"]
+           "admm_hip_comm_peer_prepare", "admm_hip_comm_init_peer", "admm_hip_comm_init_shm", "admm_hip_comm_test_allreduce",
+           "admm_hip_lasso_dist", "admm_hip_test_gram", "admm_hip_test_spd_inverse"]
 
 TRACE_FIELDS = 10
 TRACE_COLD, TRACE_CONVERGED, TRACE_ACCELERATE, TRACE_RESTART = -1, 0, 1, 2
@@ -99,6 +100,10 @@ def load():
     lib.admm_hip_parlasso_dist.restype = ctypes.c_int
     lib.admm_hip_lasso_plan_create_dist.argtypes = dist_args + [ctypes.POINTER(ctypes.c_void_p), _c_int_p]
     lib.admm_hip_lasso_plan_create_dist.restype = ctypes.c_int
+    lib.admm_hip_lasso_dist.argtypes = [_DP, _DP, ctypes.c_int, ctypes.c_longlong, ctypes.c_int, ctypes.c_int,
+                                        _DP, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                        ctypes.POINTER(AdmmOpts), _c_double_p, _c_float_p, _c_int_p, ctypes.POINTER(AdmmStats)]
+    lib.admm_hip_lasso_dist.restype = ctypes.c_int
     lib.admm_hip_comm_unique_id.argtypes = [ctypes.c_void_p]
     lib.admm_hip_comm_unique_id.restype = ctypes.c_int
     lib.admm_hip_comm_init.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
@@ -119,6 +124,10 @@ def load():
     lib.admm_hip_lasso_plan_trace_read.restype = ctypes.c_int
     lib.admm_hip_test_symv.argtypes = [_c_float_p, ctypes.c_int, _c_float_p, _c_float_p, _c_float_p, _c_float_p]
     lib.admm_hip_test_symv.restype = ctypes.c_int
+    lib.admm_hip_test_gram.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    lib.admm_hip_test_gram.restype = ctypes.c_int
+    lib.admm_hip_test_spd_inverse.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    lib.admm_hip_test_spd_inverse.restype = ctypes.c_int
     lib.admm_hip_host_lanczos.argtypes = [_c_float_p, ctypes.c_int, _c_float_p, _c_int_p]
     lib.admm_hip_host_lanczos.restype = ctypes.c_int
     _lib = lib

@@ -5,6 +5,8 @@
 namespace admm {
 const std::string& last_error_ref();
 void test_symv(const float* A, int p, const float* v0, const float* v1, float* y0, float* y1);
+template <typename T> void test_gram(const T* A, int rows, int cols, bool atA, T* G);
+template <typename T> void test_spd_inverse(const T* A, int n, T* Ainv, bool via64);
 int comm_unique_id(void* out);
 void comm_init(int nranks, int rank, const void* idbytes);
 void comm_finalize();
@@ -77,8 +79,9 @@ static PlanHandle* create_plan(const double* x, const double* y, int n, int p, i
     const bool dist = n_total > 0;
     if (nworkers > 0 && !dist) ADMM_REQUIRE(nworkers <= n, "more row blocks than rows");
     if (dist) {
-        ADMM_REQUIRE(nworkers > 0, "the distributed entry point is the consensus solver: nthread must be >= 1");
+        ADMM_REQUIRE(nworkers >= 0, "nthread must be >= 0");
         ADMM_REQUIRE(comm_info().active, "no communicator: call admm_hip_comm_init first");
+        if (nworkers == 0) ADMM_REQUIRE(n_total > p, "the row-sharded serial solver is the tall one: it needs n_total > p");
     }
     require_device();
     const double t0 = now_s();
@@ -102,7 +105,7 @@ static PlanHandle* create_plan(const double* x, const double* y, int n, int p, i
     if (pipelined) upload_standardize_gram_f32(d, x, y, n, p, standardize != 0, intercept != 0, h->st.s);
     else upload_standardize<float>(d, x, y, n, p, mem, standardize != 0, intercept != 0, h->st.s, dist ? n_total : 0);
     if (nworkers > 0) h->plan = make_par_plan(std::move(d), pb, h->st.s);
-    else if (n > p) h->plan = make_tall_plan(std::move(d), pb, h->st.s);      // Lasso.cpp:73
+    else if ((dist ? n_total : (long long)n) > p) h->plan = make_tall_plan(std::move(d), pb, h->st.s);      // Lasso.cpp:73
     else h->plan = make_wide_plan(std::move(d), pb, h->st.s);
     h->p = p;
     h->nlam = nlambda_in > 0 ? nlambda_in : nlambda_auto;
@@ -248,6 +251,21 @@ int admm_hip_lasso_plan_create_dist(const double* x_local, const double* y_local
     });
 }
 
+int admm_hip_lasso_dist(const double* x_local, const double* y_local, int n_local, long long n_total, int p, int mem,
+                        const double* lambda_in, int nlambda_in, int nlambda_auto, double lmin_ratio,
+                        int standardize, int intercept, double alpha, const admm_opts* opts,
+                        double* lambda_out, float* beta_out, int* niter_out, admm_stats* stats) {
+    return guarded([&] {
+        ADMM_REQUIRE(lambda_out && beta_out && niter_out, "output pointers must not be NULL");
+        ADMM_REQUIRE(n_total >= n_local && n_local > 0, "n_total must be >= n_local > 0");
+        const bool enet = alpha >= 0.0;
+        if (enet) ADMM_REQUIRE(alpha <= 1.0, "alpha must be within [0, 1]");
+        std::unique_ptr<PlanHandle> h(create_plan(x_local, y_local, n_local, p, mem, lambda_in, nlambda_in, nlambda_auto, lmin_ratio,
+                                                  standardize, intercept, enet, enet ? alpha : 1.0, 0, opts, n_total));
+        run_plan(h.get(), lambda_out, beta_out, niter_out, stats, h->t_create);
+    });
+}
+
 int admm_hip_parlasso_dist(const double* x_local, const double* y_local, int n_local, long long n_total, int p, int mem,
                            const double* lambda_in, int nlambda_in, int nlambda_auto, double lmin_ratio,
                            int standardize, int intercept, int nthread, const admm_opts* opts,
@@ -367,6 +385,22 @@ int admm_hip_test_symv(const float* A, int p, const float* v0, const float* v1, 
     return guarded([&] {
         ADMM_REQUIRE(A && v0 && v1 && y0 && y1 && p > 0, "bad arguments");
         test_symv(A, p, v0, v1, y0, y1);
+    });
+}
+
+int admm_hip_test_gram(const void* A, int rows, int cols, int atA, int is_double, void* G) {
+    return guarded([&] {
+        ADMM_REQUIRE(A && G && rows > 0 && cols > 0, "bad arguments");
+        if (is_double) test_gram<double>(static_cast<const double*>(A), rows, cols, atA != 0, static_cast<double*>(G));
+        else test_gram<float>(static_cast<const float*>(A), rows, cols, atA != 0, static_cast<float*>(G));
+    });
+}
+
+int admm_hip_test_spd_inverse(const void* A, int n, int precision, void* Ainv) {
+    return guarded([&] {
+        ADMM_REQUIRE(A && Ainv && n > 0 && precision >= 0 && precision <= 2, "bad arguments");
+        if (precision == 1) test_spd_inverse<double>(static_cast<const double*>(A), n, static_cast<double*>(Ainv), false);
+        else test_spd_inverse<float>(static_cast<const float*>(A), n, static_cast<float*>(Ainv), precision == 2);
     });
 }
 

@@ -28,5 +28,9 @@ void allreduce_sum_f32_f64(float* fbuf, size_t nf, double* dbuf, size_t nd, hipS
 // Throws ADMM_ERR_COMM if an exchange of the SHM / PEER backends timed out or a peer reported failure (checked by the
 // loop drivers at every poll; the kernels of a failed exchange return immediately instead of spinning).
 void comm_check();
+// PEER backend only: start the next exchange for a solver whose own kernels write the slots / wait and read them
+// (peer_device.h): no launches of the exchange layer itself.
+struct PeerExchange;
+PeerExchange comm_peer_begin(size_t payload_bytes);
 
 }  // namespace admm

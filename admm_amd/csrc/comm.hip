@@ -9,6 +9,7 @@
 // PEER needs every rank's 64-byte hipIpc handle on every rank, SHM needs a name all ranks agree on.  The Python harness
 // moves those bytes with torch.distributed or a file; an R / MPI caller would use its own channel.
 #include "comm.h"
+#include "peer_device.h"
 #include <rccl/rccl.h>
 #include <atomic>
 #include <mutex>
@@ -30,7 +31,9 @@ CommInfo g_info;
 ncclComm_t g_comm = nullptr;
 size_t g_slot = kDefaultSlotBytes;
 uint64_t g_seq = 0;                                   // exchanges enqueued so far (all ranks enqueue the same sequence)
-int* g_err = nullptr;                                 // pinned, device-visible: set by a timed-out wait (host fn or kernel)
+int* g_err = nullptr;                                 // pinned host word: set by a timed-out wait of the SHM host function
+int* g_derr = nullptr;                                // device word: set by a timed-out wait of a PEER kernel (a pinned host word
+                                                      // would cost every workgroup a PCIe round trip: 30 us per exchange, measured)
 
 #define ADMM_NCCL_CHECK(expr)                                                                     \
     do {                                                                                          \
@@ -123,7 +126,7 @@ void shm_host_fn(void* user) {
 
 void shm_exchange(float* fbuf, size_t nf, double* dbuf, size_t nd, hipStream_t st) {
     const size_t off_d = round_up_sz(nf * sizeof(float), 16);
-    ADMM_REQUIRE(off_d + nd * sizeof(double) <= g_slot, "exchange payload exceeds the slot size");
+    ADMM_REQUIRE(off_d + round_up_sz(nd * sizeof(double), 16) <= g_slot, "exchange payload exceeds the slot size");
     ShmOp* op = &g_shm.ring[g_shm.ring_pos++ % g_shm.ring.size()];
     op->seq = ++g_seq; op->nf = nf; op->nd = nd;
     if (nf) ADMM_HIP_CHECK(hipMemcpyAsync(g_shm.stage_in, fbuf, nf * sizeof(float), hipMemcpyDeviceToHost, st));
@@ -148,9 +151,9 @@ void shm_close() {
 // Exchange s on rank `me`:
 //   push   for every rank q (its own buffer included): copy the payload into q.data[s & 1][me], fence, and once all
 //          workgroups of that copy are through, store s into q.flags[s & 1][me] (release, system scope);
-//   wait   one wave: lane r spins (acquire, system scope, bounded) on its own flags[s & 1][r] until it reads s;
-//   sum    out[i] = sum over r = 0 .. nranks-1 of data[s & 1][r][i], in rank order, written back in place.
-// The buffer is allocated uncached (fine-grained), so a peer's stores are never shadowed by a stale L2 line here.
+//   sum    every workgroup first waits (lane r spins, acquire, system scope, bounded) until its own flags[s & 1][r] reads s,
+//          then out[i] = sum over r = 0 .. nranks-1 of data[s & 1][r][i], in rank order, written back in place.
+// The buffer is fine-grained device memory (peer_alloc_local), so a peer's stores are never shadowed by a stale L2 line here.
 struct PeerState {
     unsigned char* local = nullptr;                      // this rank's buffer
     unsigned char* remote[kMaxRanks] = {};               // every rank's buffer as mapped here (remote[rank] == local)
@@ -162,85 +165,105 @@ struct PeerState {
 
 constexpr int kPushGroups = 4;                           // workgroups per destination rank
 
-struct PeerArgs {
-    unsigned char* const* remote; unsigned char* local;
-    size_t slot, flags_off;
-    int nranks, rank;
-    unsigned long long seq;
+struct PeerArgs : PeerExchange {
     const float* fsrc; size_t nf; const double* dsrc; size_t nd; size_t off_d;
     float* fdst; double* ddst;
-    unsigned int* count;
-    int* err;
-    long long timeout_ticks;
 };
 
-__device__ __forceinline__ unsigned long long* peer_flag(unsigned char* buf, size_t flags_off, unsigned long long seq, int nranks, int src) {
-    return reinterpret_cast<unsigned long long*>(buf + flags_off + ((size_t)(seq & 1) * nranks + src) * 64);
+// All payload traffic is in 16-byte units per lane, 1 KiB per wave instruction (with an uncached buffer 4-byte accesses
+// ran at ~1 GB/s: 90 us for an 80 KB sum).
+// The payload [nf floats | pad to 16 | nd doubles] is copied as raw 16-byte units; both source buffers are padded
+// allocations of the solvers (>= a multiple of 16 bytes readable), the tail unit of each segment is assembled lane-wise.
+__device__ __forceinline__ uint4 peer_load_unit(const PeerArgs& a, size_t u) {
+    // unit u of the payload: units [0, uf) come from the float source, the rest from the double source
+    const size_t uf = a.off_d / 16;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (u < uf) {
+        const size_t i = u * 4;
+        if (i + 4 <= a.nf) v = *reinterpret_cast<const uint4*>(a.fsrc + i);
+        else {
+            unsigned int t[4] = {0u, 0u, 0u, 0u};
+            for (int k = 0; k < 4; ++k) if (i + k < a.nf) t[k] = __float_as_uint(a.fsrc[i + k]);
+            v = make_uint4(t[0], t[1], t[2], t[3]);
+        }
+    } else {
+        const size_t i = (u - uf) * 2;
+        if (i + 2 <= a.nd) v = *reinterpret_cast<const uint4*>(a.dsrc + i);
+        else if (i < a.nd) { const unsigned long long b = (unsigned long long)__double_as_longlong(a.dsrc[i]); v = make_uint4((unsigned)b, (unsigned)(b >> 32), 0u, 0u); }
+    }
+    return v;
 }
 
 __global__ void __launch_bounds__(256) peer_push_kernel(PeerArgs a) {
     if (*reinterpret_cast<volatile int*>(a.err)) return;
     const int q = blockIdx.x / kPushGroups, g = blockIdx.x % kPushGroups;
-    unsigned char* dst = a.remote[q] + ((size_t)(a.seq & 1) * a.nranks + a.rank) * a.slot;
-    float* df = reinterpret_cast<float*>(dst);
-    double* dd = reinterpret_cast<double*>(dst + a.off_d);
-    for (size_t i = (size_t)g * 256 + threadIdx.x; i < a.nf; i += (size_t)kPushGroups * 256) df[i] = a.fsrc[i];
-    for (size_t i = (size_t)g * 256 + threadIdx.x; i < a.nd; i += (size_t)kPushGroups * 256) dd[i] = a.dsrc[i];
-    __threadfence_system();                              // this workgroup's stores are visible system-wide ...
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(peer_dst_slot(a, q));
+    const size_t units = a.off_d / 16 + (a.nd + 1) / 2;
+    for (size_t u = (size_t)g * 256 + threadIdx.x; u < units; u += (size_t)kPushGroups * 256) {
+        const uint4 v = peer_load_unit(a, u);
+        peer_store_u64(dst + 2 * u, (unsigned long long)v.x | ((unsigned long long)v.y << 32));       // write-through, no fence needed
+        peer_store_u64(dst + 2 * u + 1, (unsigned long long)v.z | ((unsigned long long)v.w << 32));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // this wave's stores are acknowledged ...
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned int prev = __hip_atomic_fetch_add(&a.count[q], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (prev == kPushGroups - 1) {                   // ... before the last one raises the flag at the destination
+        const unsigned int prev = __hip_atomic_fetch_add(&a.count[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == kPushGroups - 1) {                   // ... before the last workgroup raises the flag at the destination
             __hip_atomic_store(&a.count[q], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(peer_flag(a.remote[q], a.flags_off, a.seq, a.nranks, a.rank), a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            peer_store_u64(peer_flag(a.remote[q], a.flags_off, a.seq, a.nranks, a.rank), a.seq);
         }
     }
 }
 
-__global__ void __launch_bounds__(64) peer_wait_kernel(PeerArgs a) {
-    if (*reinterpret_cast<volatile int*>(a.err)) return;
-    const int r = threadIdx.x;
-    if (r < a.nranks) {
-        unsigned long long* f = peer_flag(a.local, a.flags_off, a.seq, a.nranks, r);
-        const long long t0 = wall_clock64();
-        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < a.seq) {
-            __builtin_amdgcn_s_sleep(8);
-            if (wall_clock64() - t0 > a.timeout_ticks || *reinterpret_cast<volatile int*>(a.err)) {
-                *reinterpret_cast<volatile int*>(a.err) = 1;
-                break;
-            }
-        }
-    }
-}
-
+// Wait for the K flags (the first nranks lanes of every workgroup spin, bounded), then sum the K slots in rank order,
+// 16 bytes per lane.
 __global__ void __launch_bounds__(256) peer_sum_kernel(PeerArgs a) {
-    if (*reinterpret_cast<volatile int*>(a.err)) return;
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const unsigned char* base = a.local + (size_t)(a.seq & 1) * a.nranks * a.slot;
-    if (i < a.nf) {
-        float s = reinterpret_cast<const float*>(base)[i];
-        for (int r = 1; r < a.nranks; ++r) s += reinterpret_cast<const float*>(base + (size_t)r * a.slot)[i];
-        a.fdst[i] = s;
-    } else if (i - a.nf < a.nd) {
-        const size_t k = i - a.nf;
-        double s = reinterpret_cast<const double*>(base + a.off_d)[k];
-        for (int r = 1; r < a.nranks; ++r) s += reinterpret_cast<const double*>(base + (size_t)r * a.slot + a.off_d)[k];
-        a.ddst[k] = s;
+    if (!peer_wait(a)) return;
+    const size_t uf = a.off_d / 16, units = uf + (a.nd + 1) / 2;
+    const size_t u = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (u >= units) return;
+    const unsigned char* base = peer_src_slot(a, 0);
+    if (u < uf) {
+        float4 s = reinterpret_cast<const float4*>(base)[u];
+        for (int r = 1; r < a.nranks; ++r) {
+            const float4 v = reinterpret_cast<const float4*>(base + (size_t)r * a.slot)[u];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        const size_t i = u * 4;
+        if (i + 4 <= a.nf) *reinterpret_cast<float4*>(a.fdst + i) = s;
+        else {
+            const float t[4] = {s.x, s.y, s.z, s.w};
+            for (int k = 0; k < 4; ++k) if (i + k < a.nf) a.fdst[i + k] = t[k];
+        }
+    } else {
+        double2 s = reinterpret_cast<const double2*>(base)[u];
+        for (int r = 1; r < a.nranks; ++r) {
+            const double2 v = reinterpret_cast<const double2*>(base + (size_t)r * a.slot)[u];
+            s.x += v.x; s.y += v.y;
+        }
+        const size_t i = (u - uf) * 2;
+        a.ddst[i] = s.x;
+        if (i + 1 < a.nd) a.ddst[i + 1] = s.y;
     }
+}
+
+void peer_fill(PeerExchange& a) {
+    a.remote = g_peer.d_remote; a.local = g_peer.local; a.slot = g_slot; a.flags_off = g_peer.flags_off;
+    a.nranks = g_info.nranks; a.rank = g_info.rank; a.seq = ++g_seq;
+    a.count = g_peer.count; a.err = g_derr;
+    a.timeout_ticks = (long long)(kWaitSeconds * 100e6);                // wall_clock64: constant 100 MHz
 }
 
 void peer_exchange(float* fbuf, size_t nf, double* dbuf, size_t nd, hipStream_t st) {
     PeerArgs a;
+    peer_fill(a);
     a.off_d = round_up_sz(nf * sizeof(float), 16);
-    ADMM_REQUIRE(a.off_d + nd * sizeof(double) <= g_slot, "exchange payload exceeds the slot size");
-    a.remote = g_peer.d_remote; a.local = g_peer.local; a.slot = g_slot; a.flags_off = g_peer.flags_off;
-    a.nranks = g_info.nranks; a.rank = g_info.rank; a.seq = ++g_seq;
+    ADMM_REQUIRE(a.off_d + round_up_sz(nd * sizeof(double), 16) <= g_slot, "exchange payload exceeds the slot size");
+    ADMM_REQUIRE((reinterpret_cast<uintptr_t>(fbuf) & 15) == 0 && (reinterpret_cast<uintptr_t>(dbuf) & 15) == 0, "exchange buffers must be 16-byte aligned");
     a.fsrc = fbuf; a.nf = nf; a.dsrc = dbuf; a.nd = nd; a.fdst = fbuf; a.ddst = dbuf;
-    a.count = g_peer.count; a.err = g_err;
-    a.timeout_ticks = (long long)(kWaitSeconds * 100e6);                // wall_clock64: constant 100 MHz
+    const size_t units = a.off_d / 16 + (nd + 1) / 2;
     hipLaunchKernelGGL(peer_push_kernel, dim3(g_info.nranks * kPushGroups), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(peer_wait_kernel, dim3(1), dim3(64), 0, st, a);
-    hipLaunchKernelGGL(peer_sum_kernel, dim3((unsigned)((nf + nd + 255) / 256)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(peer_sum_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, st, a);
 }
 
 void peer_close() {
@@ -257,10 +280,15 @@ void peer_alloc_local(int nranks) {
     g_peer.flags_off = (size_t)2 * nranks * g_slot;
     g_peer.bytes = g_peer.flags_off + (size_t)2 * nranks * 64;
     void* ptr = nullptr;
-    // fine-grained (uncached) device memory: stores arriving from a peer must not be shadowed by this device's L2
-    if (hipExtMallocWithFlags(&ptr, g_peer.bytes, hipDeviceMallocUncached) != hipSuccess) {
+    // Fine-grained device memory: the HIP memory model makes system-scope release / acquire pairs (the flag protocol
+    // below) order and publish plain accesses to it across agents, so stores arriving from a peer are never shadowed by
+    // a stale line of this device's L2.  ADMM_HIP_PEER_MEM=uncached selects MTYPE UC instead (every access a memory
+    // transaction of its own: measured 3-10x slower for the 80 KB payload; kept as the conservative fallback).
+    const char* pm = std::getenv("ADMM_HIP_PEER_MEM");
+    const bool uncached = pm && std::string(pm) == "uncached";
+    if (hipExtMallocWithFlags(&ptr, g_peer.bytes, uncached ? hipDeviceMallocUncached : hipDeviceMallocFinegrained) != hipSuccess) {
         (void)hipGetLastError();
-        ADMM_HIP_CHECK(hipExtMallocWithFlags(&ptr, g_peer.bytes, hipDeviceMallocFinegrained));
+        ADMM_HIP_CHECK(hipExtMallocWithFlags(&ptr, g_peer.bytes, uncached ? hipDeviceMallocFinegrained : hipDeviceMallocUncached));
     }
     g_peer.local = static_cast<unsigned char*>(ptr);
     ADMM_HIP_CHECK(hipMemset(g_peer.local, 0, g_peer.bytes));
@@ -291,12 +319,25 @@ void check_ranks(int nranks, int rank) {
 
 }  // namespace
 
+// The next exchange of the PEER backend for a solver whose own kernels produce / consume it (peer_device.h).
+PeerExchange comm_peer_begin(size_t payload_bytes) {
+    if (g_info.backend != COMM_PEER) throw Error(ADMM_ERR_COMM, "the PEER exchange is not attached");
+    ADMM_REQUIRE(payload_bytes <= g_slot, "exchange payload exceeds the slot size");
+    PeerExchange e;
+    peer_fill(e);
+    return e;
+}
+
 CommInfo comm_info() {
     std::lock_guard<std::mutex> lk(g_mu);
     return g_info;
 }
 
 void comm_check() {
+    if (g_info.backend == COMM_PEER && g_derr) {          // called at the solvers' polls (after an event sync) only
+        int h = 0;
+        if (hipMemcpy(&h, g_derr, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess && h && g_err) *g_err = 1;
+    }
     if (g_err && *g_err) throw Error(ADMM_ERR_COMM, "exchange failed: a rank did not arrive within the time limit (or a peer reported failure)");
 }
 
@@ -314,7 +355,7 @@ void allreduce_sum_f64(double* buf, size_t n, hipStream_t st) {
 }
 void allreduce_sum_f32_f64(float* fbuf, size_t nf, double* dbuf, size_t nd, hipStream_t st) {
     if (!g_info.active) return;
-    if (g_info.backend != COMM_RCCL && round_up_sz(nf * sizeof(float), 16) + nd * sizeof(double) > g_slot) {
+    if (g_info.backend != COMM_RCCL && round_up_sz(nf * sizeof(float), 16) + round_up_sz(nd * sizeof(double), 16) > g_slot) {
         allreduce_sum_f32(fbuf, nf, st);
         allreduce_sum_f64(dbuf, nd, st);
         return;
@@ -414,8 +455,10 @@ void comm_init_peer(int nranks, int rank, const void* handles) {
         g_peer.remote[r] = static_cast<unsigned char*>(ptr);
         g_peer.opened[r] = true;
     }
-    ADMM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g_peer.count), nranks * sizeof(unsigned int)));
-    ADMM_HIP_CHECK(hipMemset(g_peer.count, 0, nranks * sizeof(unsigned int)));
+    if (!g_derr) ADMM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g_derr), sizeof(int)));
+    ADMM_HIP_CHECK(hipMemset(g_derr, 0, sizeof(int)));
+    ADMM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g_peer.count), (nranks + 1) * sizeof(unsigned int)));
+    ADMM_HIP_CHECK(hipMemset(g_peer.count, 0, (nranks + 1) * sizeof(unsigned int)));
     ADMM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g_peer.d_remote), nranks * sizeof(unsigned char*)));
     ADMM_HIP_CHECK(hipMemcpy(g_peer.d_remote, g_peer.remote, nranks * sizeof(unsigned char*), hipMemcpyHostToDevice));
     ADMM_HIP_CHECK(hipDeviceSynchronize());
@@ -430,6 +473,7 @@ void comm_finalize() {
     if (g_info.backend == COMM_SHM) shm_close();
     if (g_peer.local) peer_close();
     if (g_err) *g_err = 0;
+    if (g_derr) (void)hipMemset(g_derr, 0, sizeof(int));
     g_info = CommInfo();
     g_seq = 0;
 }

@@ -35,6 +35,8 @@
 #include "gemv_kernels.h"
 #include "symv_kernels.h"
 #include "solvers.h"
+#include "comm.h"
+#include "peer_device.h"
 
 namespace admm {
 
@@ -212,9 +214,12 @@ __device__ __forceinline__ void tall_update_elem(const TallParams& q, const Tall
 }
 
 // Element-wise part of one iteration.  `c` = the control block published by this iteration's decision.
-template <bool SYM>
+// MODE 0: x-update results as gemv_t partial rows; 1: as the symmetric mat-vec's partial arrays; 2: row-sharded over the
+// PEER exchange -- wait for the K flags, then sum the K ranks' shares straight out of the exchange slots.
+enum { TAIL_GEMV = 0, TAIL_SYMV = 1, TAIL_PEER = 2 };
+template <int MODE>
 __global__ void __launch_bounds__(kTailThreads)
-tall_tail_kernel(TallParams q, int par) {
+tall_tail_kernel(TallParams q, int par, PeerExchange ex) {
     __shared__ double scratch[6 * (kTailThreads / 64)];
     const TallCtl c = q.ctl[par ^ 1];
     // Every load below is independent of `c` (the ping-pong parity equals the launch parity because
@@ -228,8 +233,19 @@ tall_tail_kernel(TallParams q, int par) {
     // ---- x-update results a = Minv u, b = Minv w: kTailLanes lanes share one element and issue all
     // their partial loads at once, then combine with shuffles.
     float a = 0.f, b = 0.f;
-    if (SYM) {
+    if (MODE == TAIL_SYMV) {
         symv_sum_partials<kTailLanes>(q.dot0, q.dot1, q.axp0, q.axp1, q.ldo, q.nrb, q.ncb, i, sub, valid, a, b);
+    } else if (MODE == TAIL_PEER) {
+        // the producing launch pushed unless the solve was already finished (replicated flag: all ranks agree)
+        const bool ok = q.ctl[par].done ? false : peer_wait_relaxed(ex);
+        if (ok && valid) {
+            for (int r = sub; r < ex.nranks; r += kTailLanes) {          // rank order fixed by the lane pattern: identical on every rank
+                const float2 v = peer_load_f32x2(reinterpret_cast<const float*>(peer_src_slot(ex, r)) + 2 * (size_t)i);    // (a_i, b_i) interleaved
+                a += v.x; b += v.y;
+            }
+        }
+#pragma unroll
+        for (int m = 1; m < kTailLanes; m <<= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }
     } else {
         if (valid) {
             for (int k = sub; k < q.nseg; k += kTailLanes) {
@@ -251,6 +267,35 @@ tall_tail_kernel(TallParams q, int par) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) Pout[k] = acc[k];
     }
+}
+
+// Row-sharded mode: this rank's share of the two products (the partial arrays of its tiles) summed into ab[2][ld], the
+// vectors the ranks then all-reduce.  Same lane geometry and order as the single-GPU tail.
+__global__ void __launch_bounds__(kTailThreads)
+tall_shard_reduce_kernel(TallParams q, float* ab, long long ld, const int* skip) {
+    if (*skip) return;
+    const int sub = threadIdx.x & (kTailLanes - 1);
+    const int i = blockIdx.x * kTailElems + threadIdx.x / kTailLanes;
+    float a, b;
+    symv_sum_partials<kTailLanes>(q.dot0, q.dot1, q.axp0, q.axp1, q.ldo, q.nrb, q.ncb, i, sub, i < q.p, a, b);
+    if (i < q.p && sub == 0) { ab[i] = a; ab[ld + i] = b; }
+}
+
+// The same over the PEER exchange, without launches of the exchange layer: every workgroup writes its elements of
+// (a, b) straight into this rank's slot of EVERY rank's buffer (lane `sub` of an element's group serves rank sub,
+// sub + 8, ...), and the last workgroup to finish raises the flags (peer_device.h).
+__global__ void __launch_bounds__(kTailThreads)
+tall_shard_push_kernel(TallParams q, PeerExchange ex, long long ld, const int* skip) {
+    if (*skip) return;
+    const int sub = threadIdx.x & (kTailLanes - 1);
+    const int i = blockIdx.x * kTailElems + threadIdx.x / kTailLanes;
+    float a, b;
+    symv_sum_partials<kTailLanes>(q.dot0, q.dot1, q.axp0, q.axp1, q.ldo, q.nrb, q.ncb, i, sub, i < q.p, a, b);
+    if (i < q.p) {
+        for (int dst = sub; dst < ex.nranks; dst += kTailLanes)
+            peer_store_f32x2(reinterpret_cast<float*>(peer_dst_slot(ex, dst)) + 2 * (size_t)i, a, b);       // (a_i, b_i) interleaved: one 8-byte store
+    }
+    peer_publish(ex, gridDim.x);
 }
 
 __global__ void tall_init_kernel(TallParams q, double rho, double lam0) {
@@ -283,6 +328,10 @@ struct TallPlan final : LassoPlan {
     GemvTPlan pl;
     SymvPlan sy;
     bool use_sym = false;
+    bool shard = false;                                 // x-update spread over the ranks of the attached communicator
+    bool peer_fused = false;                            // ... with the exchange done by the solver's own kernels (PEER backend)
+    CommInfo ci;
+    DevBuf<float> ab;                                   // [2][ldp] this rank's share of (a, b), all-reduced in place
     long long ldv = 0;
     DevBuf<float> XY, M, a_part, b_part, x, z0, z1, y0, y1, adj_z, adj_y, u, w, beta;
     DevBuf<int> niter;
@@ -311,16 +360,24 @@ struct TallPlan final : LassoPlan {
         ldp = round_up(p, 128);                         // whole 128-row blocks for the matrix-core setup kernels
 
         // X'y and lambda_0 (ADMMLassoTall.h:172-173; ADMMEnet.h:56 divides by alpha + 1e-4)
+        // Row-sharded mode (not in the reference): d holds this rank's ROWS of the globally standardised
+        // data.  X'y and X'X are sums over the row blocks (split-K over the ranks + one all-reduce each); the Lanczos call
+        // and the factorisation are replicated (identical inputs -> identical rho and inverse on every rank); each rank
+        // then streams 1/nranks of the inverse's lower-triangle tiles per iteration.
+        shard = pb.dist;
+        ci = shard ? comm_info() : CommInfo();
+        const long long nt = d.n_total > 0 ? d.n_total : n;
         XY.alloc(ldp); XY.zero(st);
         gemv_t_simple<float>(d.X.get(), d.ldx, n, p, d.Y.get(), XY.get(), st);
+        if (shard) allreduce_sum_f32(XY.get(), (size_t)p, st);
         float lambda0 = device_absmax<float>(XY.get(), p, st);
         if (pb.enet) lambda0 = (float)(lambda0 / ((double)(float)pb.alpha + 0.0001));
 
         // lambda grid (Lasso.cpp:78-89) and internal lambdas (Lasso.cpp:99), stored as float like `Scalar lambda`
-        lam_user = make_lambda_grid(pb, lambda0, n, (double)d.scaleY);
+        lam_user = make_lambda_grid(pb, lambda0, (int)nt, (double)d.scaleY);
         nlam = (int)lam_user.size();
         lam_int.resize(nlam);
-        for (int i = 0; i < nlam; ++i) lam_int[i] = (double)(float)(lam_user[i] * n / (double)d.scaleY);
+        for (int i = 0; i < nlam; ++i) lam_int[i] = (double)(float)(lam_user[i] * (double)nt / (double)d.scaleY);
 
         // Gram (cross_prod_lower, ADMMLassoTall.h:191-192) -- both triangles
         double t0 = now_s();
@@ -330,7 +387,9 @@ struct TallPlan final : LassoPlan {
         } else {
             M.alloc((size_t)ldp * ldp); M.zero(st);
             gram_full<float>(d.X.get(), d.ldx, n, p, true, M.get(), ldp, st);
+            if (shard) allreduce_sum_f32(M.get(), (size_t)ldp * ldp, st);      // split-K over the ranks' row blocks
             ADMM_HIP_CHECK(hipStreamSynchronize(st));
+            comm_check();
             S.t_gram = now_s() - t0;
         }
 
@@ -348,13 +407,15 @@ struct TallPlan final : LassoPlan {
         S.t_eigs = now_s() - t0;
 
         // (X'X + rho I)^-1, cached for the whole path (rho never changes: ADMMLassoTall.h:97)
-        // Default: factorise and invert in float (the reference's LLT is a float factorisation, XX.diagonal() += rho in float).
+        // ADMM_HIP_INVERSE=f32: factorise and invert in float (the reference's LLT is a float factorisation, XX.diagonal() += rho in float).
         // ADMM_HIP_INVERSE=f64: the same float Gram factorised and inverted in double, rounded to float once -- each entry
         // of the cached inverse then carries half an ulp instead of cond * ulp (useful when n ~ p); it costs 150 ms more at
         // p = 10^4 and does not change how often the stopping rule flips against a float Cholesky solve (measured with
         // tests/tools/flip_floor.py: 45 vs 44 of 185 lambdas, the reference's own solve against the exact one: 39).
         t0 = now_s();
-        bool inv64 = false;
+        // Policy: double below p = 4096 (a few ms there, and the float inverse is 30-100x less accurate: 1-3e-6 against
+        // 3e-8 of the largest entry at cond ~ 30, tests/test_gpu_kernels.py), float above.
+        bool inv64 = p < 4096;
         if (const char* e = std::getenv("ADMM_HIP_INVERSE")) inv64 = std::string(e) == "f64";
         if (inv64) {
             spd_inverse_f32_via_f64(M.get(), ldp, p, (double)(float)rho, st);
@@ -372,11 +433,16 @@ struct TallPlan final : LassoPlan {
         // gemv_t (4p^2 bytes, fewer and larger workgroups) for small p.  ADMM_HIP_XUPDATE=full|sym overrides.
         use_sym = p >= 2048;
         if (const char* e = std::getenv("ADMM_HIP_XUPDATE")) use_sym = std::string(e) == "sym";
+        if (shard) use_sym = true;                       // the sharded x-update is the tile list of the symmetric kernel dealt out to the ranks
         pl = plan_gemv_t<float>(p, p, 2, 4);
         nwg = (p + kTailElems - 1) / kTailElems;
         ldv = round_up(p, 256);                         // symv reads the right-hand vectors in 256-row blocks
-        if (use_sym) sy.init(p, st);
-        else { a_part.alloc((size_t)pl.nseg * ldp); b_part.alloc((size_t)pl.nseg * ldp); a_part.zero(st); b_part.zero(st); }
+        if (use_sym) sy.init(p, st, shard ? ci.rank : 0, shard ? ci.nranks : 1);
+        if (shard) { ab.alloc((size_t)2 * ldp); ab.zero(st); }
+        else if (!use_sym) { a_part.alloc((size_t)pl.nseg * ldp); b_part.alloc((size_t)pl.nseg * ldp); a_part.zero(st); b_part.zero(st); }
+        // ADMM_HIP_PEER_FUSED=0: go through the generic all-reduce of the exchange layer also on the PEER backend
+        peer_fused = shard && ci.backend == COMM_PEER;
+        if (const char* e = std::getenv("ADMM_HIP_PEER_FUSED")) { if (std::string(e) == "0") peer_fused = false; }
         x.alloc(ldv); z0.alloc(ldv); z1.alloc(ldv); y0.alloc(ldv); y1.alloc(ldv);
         adj_z.alloc(ldv); adj_y.alloc(ldv); u.alloc(ldv); w.alloc(ldv);
         beta.alloc((size_t)nlam * p); niter.alloc(nlam);
@@ -388,6 +454,7 @@ struct TallPlan final : LassoPlan {
         q.part_stride = ldp;
         q.eps_abs = pb.opts.eps_abs; q.eps_rel = pb.opts.eps_rel; q.alpha = (double)(float)pb.alpha; q.sqrt_p = std::sqrt((double)p);
         q.lambdas = dlam.get(); q.XY = XY.get(); q.a_part = a_part.get(); q.b_part = b_part.get();
+        if (shard) { q.a_part = ab.get(); q.b_part = ab.get() + ldp; q.nseg = 1; }      // the tail reads the all-reduced pair (generic exchange)
         q.dot0 = sy.dot0.get(); q.dot1 = sy.dot1.get(); q.axp0 = sy.axp0.get(); q.axp1 = sy.axp1.get();
         q.ldo = sy.ldo; q.nrb = sy.nrb; q.ncb = sy.ncb;
         q.x = x.get(); q.z0 = z0.get(); q.z1 = z1.get(); q.y0 = y0.get(); q.y1 = y1.get();
@@ -426,7 +493,7 @@ struct TallPlan final : LassoPlan {
             debug_dump("XY", XY.get(), ldp);
         }
         admm_stats S = setup_stats;
-        S.xupdate_variant = use_sym ? 1 : 0;
+        S.xupdate_variant = shard ? 2 : (use_sym ? 1 : 0);
         res.lambda = lam_user;
         beta.zero(st); niter.zero(st);
         const int init_n = std::max(p, 2 * nwg * 8);
@@ -459,13 +526,27 @@ struct TallPlan final : LassoPlan {
                 // sampled launches carry start/stop events that time exactly the x-update kernel on this stream
                 // the decision of this iteration rides along as one extra workgroup of the x-update launch
                 const TallDecideExtra dec{q, par};
-                if (use_sym) {
+                if (shard && peer_fused) {
+                    // this rank's tiles -> its share of (a, b) written into every rank's exchange slot by the reduction
+                    // launch itself -> the (replicated) tail waits for the K flags and sums the K slots: three launches,
+                    // none of them the exchange layer's
                     sy.launch(M.get(), ldp, u.get(), w.get(), &ctl.get()[par].done, st, dec, e0, e1);
-                    hipLaunchKernelGGL(tall_tail_kernel<true>, dim3(nwg), dim3(kTailThreads), 0, st, q, par);
+                    const PeerExchange ex = comm_peer_begin((size_t)2 * ldp * sizeof(float));
+                    hipLaunchKernelGGL(tall_shard_push_kernel, dim3(nwg), dim3(kTailThreads), 0, st, q, ex, ldp, &ctl.get()[par].done);
+                    hipLaunchKernelGGL(tall_tail_kernel<TAIL_PEER>, dim3(nwg), dim3(kTailThreads), 0, st, q, par, ex);
+                } else if (shard) {
+                    // this rank's tiles -> its share of (a, b) -> ONE all-reduce of 2 ldp floats -> the (replicated) tail
+                    sy.launch(M.get(), ldp, u.get(), w.get(), &ctl.get()[par].done, st, dec, e0, e1);
+                    hipLaunchKernelGGL(tall_shard_reduce_kernel, dim3(nwg), dim3(kTailThreads), 0, st, q, ab.get(), ldp, &ctl.get()[par].done);
+                    allreduce_sum_f32(ab.get(), (size_t)2 * ldp, st);
+                    hipLaunchKernelGGL(tall_tail_kernel<TAIL_GEMV>, dim3(nwg), dim3(kTailThreads), 0, st, q, par, PeerExchange{});
+                } else if (use_sym) {
+                    sy.launch(M.get(), ldp, u.get(), w.get(), &ctl.get()[par].done, st, dec, e0, e1);
+                    hipLaunchKernelGGL(tall_tail_kernel<TAIL_SYMV>, dim3(nwg), dim3(kTailThreads), 0, st, q, par, PeerExchange{});
                 } else {
                     launch_gemv_t<float, 2, 4, TallDecideExtra>(pl, M.get(), ldp, p, p, u.get(), w.get(), a_part.get(), b_part.get(), ldp,
                                                                 &ctl.get()[par].done, st, dec, e0, e1);
-                    hipLaunchKernelGGL(tall_tail_kernel<false>, dim3(nwg), dim3(kTailThreads), 0, st, q, par);
+                    hipLaunchKernelGGL(tall_tail_kernel<TAIL_GEMV>, dim3(nwg), dim3(kTailThreads), 0, st, q, par, PeerExchange{});
                 }
                 ++launches;
             }
@@ -480,6 +561,7 @@ struct TallPlan final : LassoPlan {
         while (!done) {
             enqueue_batch(slot ^ 1);                       // keep one batch in flight while polling the previous one
             ADMM_HIP_CHECK(hipEventSynchronize(ev_poll[slot].e));
+            comm_check();
             done = hctl[slot].done != 0;
             slot ^= 1;
             if (!done && g > max_total) throw Error(ADMM_ERR_INTERNAL, "tall path: iteration bound exceeded without completion");

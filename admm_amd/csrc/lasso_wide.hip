@@ -80,7 +80,9 @@ __device__ __forceinline__ float prox_f(float val, float thresh, float denom, bo
 // The decision for the iteration that just finished and the kind of x-update that runs now: convergence, rho adaptation
 // (ADMMBase.h:85-109), lambda schedule (init_warm), regular / active-set schedule (ADMMLassoWide.h:121-155).  Every wave
 // that calls it reduces the norm partials itself in a fixed order (no LDS, no barrier) and gets the identical result.
-__device__ __forceinline__ WideCtl wide_decide(const WideParams& q, const WideCtl& in, int lane, int& lam_finished, int& niter_val) {
+struct WideDecision { WideCtl out; int lam_finished; int niter_val; };
+__device__ __forceinline__ WideDecision wide_decide(const WideParams& q, const WideCtl& in, int lane) {
+    int lam_finished = -1, niter_val = 0;
     // norm partials of the previous iteration: every wave reduces them itself (fixed order), no LDS, no barrier
     double sums[5] = {0, 0, 0, 0, 0};
     for (int row = lane; row < q.nwg_tail; row += 64) {
@@ -92,7 +94,6 @@ __device__ __forceinline__ WideCtl wide_decide(const WideParams& q, const WideCt
     const double r2 = sums[0], dz2 = sums[1], ax2 = sums[2], z2 = sums[3], y2 = sums[4];
     WideCtl out = in;
     out.first = 0;
-    lam_finished = -1; niter_val = 0;
     if (!in.first) {
         const double rp = sqrt(r2);                                   // resid_primal = ||Ax + z||       ADMMBase.h:181
         const double rd = in.rho * q.sqrt_gamma * sqrt(dz2);          // rho sqrt(sprad) ||z_new - z||   ADMMLassoWide.h:183-186
@@ -126,7 +127,9 @@ __device__ __forceinline__ WideCtl wide_decide(const WideParams& q, const WideCt
         out.type = (is_regular_update((unsigned)out.counter) && out.lam < q.lambda0) ? W_REG : W_ACT;
         out.counter++;
     }
-    return out;
+    WideDecision dec;
+    dec.out = out; dec.lam_finished = lam_finished; dec.niter_val = niter_val;
+    return dec;
 }
 
 // x(g): every workgroup evaluates (identically) the decision for iteration g-1 -- convergence, rho
@@ -170,8 +173,9 @@ wide_x_kernel(WideParams q, int par) {
         }
     };
     if (always && !TG) stage_t();
-    int lam_finished = -1, niter_val = 0;
-    const WideCtl out = wide_decide(q, in, lane, lam_finished, niter_val);
+    const WideDecision dec = wide_decide(q, in, lane);
+    const WideCtl out = dec.out;
+    const int lam_finished = dec.lam_finished, niter_val = dec.niter_val;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (lam_finished >= 0) q.niter[lam_finished] = niter_val;
         *outp = out;
@@ -332,8 +336,7 @@ __global__ void __launch_bounds__(kWideThreads)
 wide_t_kernel(WideParams q, int par) {
     const WideCtl in = q.ctl[par];
     if (in.done) return;
-    int lam_finished = -1, niter_val = 0;
-    const WideCtl out = wide_decide(q, in, threadIdx.x & 63, lam_finished, niter_val);
+    const WideCtl out = wide_decide(q, in, threadIdx.x & 63).out;
     if (out.done || out.type == W_ZERO) return;
     const int i = blockIdx.x * kWideThreads + threadIdx.x;
     if (i >= q.ldn) return;

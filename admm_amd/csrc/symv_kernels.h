@@ -172,7 +172,10 @@ struct SymvPlan {
     long long ldo = 0;
     DevBuf<int2> tiles;
     DevBuf<float> dot0, dot1, axp0, axp1;
-    void init(int p_, hipStream_t st) {
+    // part / nparts: this plan launches only the tiles with (index in the full list) % nparts == part -- the row-sharded
+    // tall x-update gives every rank an equal share of the triangle; the partial arrays keep the full shape (slots of
+    // tiles owned by other ranks stay zero) so that the same consumer code sums them.
+    void init(int p_, hipStream_t st, int part = 0, int nparts = 1) {
         p = p_;
         nrb = (p + kSyRB - 1) / kSyRB;
         ncb = (p + kSyCB - 1) / kSyCB;
@@ -182,9 +185,14 @@ struct SymvPlan {
         for (int rb = nrb - 1; rb >= 0; --rb)
             for (int cb = 0; cb < ncb; ++cb)
                 if (cb * kSyCB <= rb * kSyRB + (kSyRB - 1)) h.push_back(make_int2(rb, cb));
+        if (nparts > 1) {
+            std::vector<int2> mine;
+            for (size_t i = (size_t)part; i < h.size(); i += (size_t)nparts) mine.push_back(h[i]);
+            h.swap(mine);
+        }
         ntiles = (int)h.size();
-        tiles.alloc(h.size());
-        ADMM_HIP_CHECK(hipMemcpyAsync(tiles.get(), h.data(), h.size() * sizeof(int2), hipMemcpyHostToDevice, st));
+        tiles.alloc(std::max<size_t>(h.size(), 1));
+        if (!h.empty()) ADMM_HIP_CHECK(hipMemcpyAsync(tiles.get(), h.data(), h.size() * sizeof(int2), hipMemcpyHostToDevice, st));
         dot0.alloc((size_t)nrb * ldo); dot1.alloc((size_t)nrb * ldo);
         axp0.alloc((size_t)ncb * ldo); axp1.alloc((size_t)ncb * ldo);
         dot0.zero(st); dot1.zero(st); axp0.zero(st); axp1.zero(st);

@@ -1,6 +1,7 @@
 // Test hooks behind the C ABI (include/admm_hip.h, "test hooks"): single kernels of the solvers run on caller data so
 // that the test-suite can compare them with the oracle / NumPy.  No solver entry point calls anything in this file.
 #include "symv_kernels.h"
+#include "prep.h"
 
 namespace admm {
 void require_device();
@@ -38,5 +39,46 @@ void test_symv(const float* A, int p, const float* v0, const float* v1, float* y
     ADMM_HIP_CHECK(hipMemcpyAsync(y1, o1.get(), (size_t)p * sizeof(float), hipMemcpyDeviceToHost, st.s));
     st.sync();
 }
+
+// Gram matrix through the solvers' own path (gram_full: matrix-core SYRK kernels, split-K for small orders):
+// G = A'A (atA) or AA' for a host matrix A (rows x cols, column-major, leading dimension rows); G host, order k, ld k.
+template <typename T>
+void test_gram(const T* A, int rows, int cols, bool atA, T* G) {
+    require_device();
+    Stream st;
+    const long long lda = round_up(rows, 32);
+    const int k = atA ? cols : rows;
+    const long long ldc = round_up(k, 128);
+    DevBuf<T> dA((size_t)lda * cols), dG((size_t)ldc * ldc);
+    dA.zero(st.s); dG.zero(st.s);
+    ADMM_HIP_CHECK(hipMemcpy2DAsync(dA.get(), lda * sizeof(T), A, (size_t)rows * sizeof(T), (size_t)rows * sizeof(T), cols, hipMemcpyHostToDevice, st.s));
+    gram_full<T>(dA.get(), lda, rows, cols, atA, dG.get(), ldc, st.s);
+    ADMM_HIP_CHECK(hipMemcpy2DAsync(G, (size_t)k * sizeof(T), dG.get(), ldc * sizeof(T), (size_t)k * sizeof(T), k, hipMemcpyDeviceToHost, st.s));
+    st.sync();
+}
+template void test_gram<float>(const float*, int, int, bool, float*);
+template void test_gram<double>(const double*, int, int, bool, double*);
+
+// Symmetric inverse of an SPD host matrix (order n, ld n) through the solvers' own path: blocked Cholesky + inverse on
+// the matrix cores (chol_inverse.h) for n >= 256.  via64: the float matrix factorised / inverted in double and rounded once.
+template <typename T>
+void test_spd_inverse(const T* A, int n, T* Ainv, bool via64) {
+    require_device();
+    Stream st;
+    const long long lda = round_up(n, 128);
+    DevBuf<T> dA((size_t)lda * lda);
+    dA.zero(st.s);
+    ADMM_HIP_CHECK(hipMemcpy2DAsync(dA.get(), lda * sizeof(T), A, (size_t)n * sizeof(T), (size_t)n * sizeof(T), n, hipMemcpyHostToDevice, st.s));
+    if constexpr (std::is_same<T, float>::value) {
+        if (via64) spd_inverse_f32_via_f64(dA.get(), lda, n, 0.0, st.s);
+        else spd_inverse_f32(dA.get(), lda, n, st.s);
+    } else {
+        spd_inverse_f64(dA.get(), lda, n, st.s);
+    }
+    ADMM_HIP_CHECK(hipMemcpy2DAsync(Ainv, (size_t)n * sizeof(T), dA.get(), lda * sizeof(T), (size_t)n * sizeof(T), n, hipMemcpyDeviceToHost, st.s));
+    st.sync();
+}
+template void test_spd_inverse<float>(const float*, int, float*, bool);
+template void test_spd_inverse<double>(const double*, int, double*, bool);
 
 }  // namespace admm

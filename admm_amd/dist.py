@@ -28,6 +28,17 @@ def row_partition(n_total, nblocks, nranks, rank):
     return lo, hi
 
 
+def symv_tiles(p, part=0, nparts=1, rows_per_tile=256, cols_per_tile=128):
+    """Host mirror of SymvPlan::init (csrc/symv_kernels.h): the (row block, column block) tiles on or below the diagonal
+    of a p x p symmetric matrix, longest row strips first, and the share of them rank `part` of `nparts` streams in the
+    row-sharded tall x-update (tile i of the full list goes to rank i % nparts)."""
+    nrb = (p + rows_per_tile - 1) // rows_per_tile
+    ncb = (p + cols_per_tile - 1) // cols_per_tile
+    tiles = [(rb, cb) for rb in range(nrb - 1, -1, -1) for cb in range(ncb)
+             if cb * cols_per_tile <= rb * rows_per_tile + (rows_per_tile - 1)]
+    return tiles[part::nparts]
+
+
 def init_comm(nranks=1, rank=0, broadcast=None):
     """Attach the process-wide RCCL communicator.  `broadcast(buf: np.ndarray[uint8]) -> np.ndarray` must return
     rank 0's buffer on every rank (not needed for nranks == 1)."""
@@ -145,8 +156,28 @@ def parlasso_dist(x_local, y_local, n_total, p, nthread, lam=None, nlambda=100, 
     return ADMM_Lasso_fit(lam_out, beta, niter, stats.as_dict())
 
 
+def lasso_dist(x_local, y_local, n_total, p, lam=None, nlambda=100, lambda_min_ratio=1e-4, standardize=True, intercept=True,
+               alpha=None, n_local=None, **opts):
+    """Row-sharded serial tall Lasso / elastic net (`admm_lasso(x, y)$fit()` over several GPUs): every rank calls this
+    with a contiguous row slice."""
+    lib = _lib.load()
+    if n_local is None:
+        n_local = np.asarray(x_local).shape[0]
+    head, keep, nl = _marshal(x_local, y_local, n_local, n_total, p, lam, nlambda, lambda_min_ratio, standardize, intercept, 0, opts)
+    head = head[:-2] + (float(-1.0 if alpha is None else alpha), head[-1])        # (..., intercept, alpha, opts) instead of (..., nthread, opts)
+    lam_out = np.zeros(nl)
+    beta = np.zeros((p + 1, nl), dtype=np.float32, order="F")
+    niter = np.zeros(nl, dtype=np.int32)
+    stats = AdmmStats()
+    check(lib.admm_hip_lasso_dist(*head, lam_out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                  beta.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                                  niter.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), ctypes.byref(stats)))
+    return ADMM_Lasso_fit(lam_out, beta, niter, stats.as_dict())
+
+
 class DistLassoPlan:
-    """Prepared distributed consensus problem (setup once, run the lambda path repeatedly)."""
+    """Prepared distributed problem (setup once, run the lambda path repeatedly): the consensus solver for nthread >= 1,
+    the row-sharded serial tall solver for nthread == 0."""
 
     def __init__(self, x_local, y_local, n_total, p, nthread, lam=None, nlambda=100, lambda_min_ratio=None,
                  standardize=True, intercept=True, n_local=None, **opts):
@@ -173,6 +204,17 @@ class DistLassoPlan:
                                                 beta.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
                                                 niter.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), ctypes.byref(stats)))
         return ADMM_Lasso_fit(lam_out, beta, niter, stats.as_dict())
+
+    def enable_trace(self, capacity=1 << 18):
+        check(self._lib.admm_hip_lasso_plan_trace_enable(self._h, int(capacity)))
+        self._trace_cap = int(capacity)
+
+    def read_trace(self):
+        buf = np.zeros((self._trace_cap, _lib.TRACE_FIELDS), dtype=np.float64)
+        n = ctypes.c_longlong()
+        check(self._lib.admm_hip_lasso_plan_trace_read(self._h, buf.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                                       self._trace_cap, ctypes.byref(n)))
+        return buf[:n.value].copy()
 
     def close(self):
         if self._h:

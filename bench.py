@@ -58,7 +58,9 @@ def parse():
     ap.add_argument("--profile-stride", type=int, default=32, help="time every k-th x-update launch with HIP events")
     ap.add_argument("--consensus-seconds", type=float, default=240.0,
                     help="time limit of the side measurement of the consensus solver (0 disables it)")
-    ap.add_argument("--consensus-child", default="", help=argparse.SUPPRESS)
+    ap.add_argument("--shard-seconds", type=float, default=300.0,
+                    help="time limit of each sharded-tall child run at N > 1 (0 disables them: replicas only)")
+    ap.add_argument("--child", default="", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -128,10 +130,9 @@ def cpu_baseline(p, nlambda, budget_s, seed):
                                       f"forming the inverse took {t_inv:.1f} s (not included)"}}
 
 
-def consensus_child(a):
-    """Side measurement (own process, own process group): BASELINE configs[3]-shaped consensus Lasso
-    `admm_lasso(x, y)$parallel(K)`, n=10000, p=100000, K = number of ranks, one row block per GPU, rows
-    sharded over ranks, one grouped RCCL all-reduce (p floats + 3 doubles) per ADMM iteration."""
+def _child_setup(backend):
+    """Common prologue of the side-measurement children: own gloo process group (control plane), the library's
+    communicator over `backend` in {"rccl", "peer"} (data plane)."""
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -141,15 +142,43 @@ def consensus_child(a):
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if multi:
-        dist.init_process_group(backend="gloo")      # control plane only; the data path is the library's own RCCL communicator
-    from admm_amd import DevicePtr, load
+        dist.init_process_group(backend="gloo")
+    from admm_amd import load
     from admm_amd import dist as adist
     lib = load()
     assert lib.admm_hip_set_device(local_rank) == 0
     if multi:
-        adist.init_comm_from_torch(dev)
+        adist.init_comm_backend_from_torch(backend, dev)
+    elif backend == "peer":
+        adist.init_comm_peer(1, 0, lambda mine: mine)
     else:
         adist.init_comm(1, 0)
+    return rank, world, multi, torch, dist, dev, adist
+
+
+def _child_teardown(plan, adist, dist, multi):
+    plan.close()
+    if multi:
+        dist.barrier()                                   # nobody unmaps / destroys while a peer may still push
+    adist.finalize_comm()
+    if multi:
+        dist.destroy_process_group()
+
+
+def _max_over_ranks(v, torch, dist, multi):
+    if not multi:
+        return v
+    t = torch.tensor([v], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t[0])
+
+
+def consensus_child(a, backend, out_path):
+    """Side measurement (own processes, own process group): BASELINE configs[3]-shaped consensus Lasso
+    `admm_lasso(x, y)$parallel(K)`, n=10000, p=100000, K = number of ranks, one row block per GPU, rows
+    sharded over ranks, one exchange (p floats + 3 doubles) per ADMM iteration over `backend`."""
+    rank, world, multi, torch, dist, dev, adist = _child_setup(backend)
+    from admm_amd import DevicePtr
     n, p, K = 10000, 100000, world
     lo, hi = adist.row_partition(n, K, world, rank)
     nl = hi - lo
@@ -170,62 +199,116 @@ def consensus_child(a):
     if multi:
         dist.barrier()
     fit = plan.run()
-    loop_s, iters = fit.stats["t_loop"], int(fit.stats["total_iter"])
-    if multi:
-        t = torch.tensor([loop_s], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        loop_s = float(t[0])
+    iters = int(fit.stats["total_iter"])
+    loop_s = _max_over_ranks(fit.stats["t_loop"], torch, dist, multi)
     if rank == 0:
         rows = n // K
         bytes_per_gpu = 8.0 * rows * p + 4.0 * rows * rows      # A and A' streamed once each + the cached (AA'+rho I)^-1
         res = {"workload": "admm_lasso$parallel(K) n=10000 p=100000, K = n_gpus row blocks (one per GPU), 4 lambdas x maxit 150",
-               "n_gpus": world, "K": K, "iterations": iters, "loop_s": loop_s, "iters_per_s": iters / loop_s,
-               "ms_per_iter": loop_s / iters * 1e3, "setup_s": setup_s,
+               "exchange": backend, "n_gpus": world, "ranks_in_communicator": world, "K": K, "iterations": iters, "loop_s": loop_s,
+               "iters_per_s": iters / loop_s, "ms_per_iter": loop_s / iters * 1e3, "setup_s": setup_s,
                "alg_bytes_per_gpu_per_iter": bytes_per_gpu, "achieved_GBps_per_gpu": bytes_per_gpu * iters / loop_s / 1e9,
                "allreduce_payload_bytes": 4 * p + 24, "niter": [int(v) for v in fit.niter]}
-        with open(a.consensus_child, "w") as f:
+        with open(out_path, "w") as f:
             json.dump(res, f)
-    plan.close()
-    adist.finalize_comm()
+    _child_teardown(plan, adist, dist, multi)
+
+
+def tallshard_child(a, backend, out_path):
+    """The headline workload itself (BASELINE configs[1]: tall Lasso n x p, 100-lambda path) with its x-update spread
+    over the ranks (admm_hip_lasso_plan_create_dist, nthread = 0): rows of the synthetic problem sharded for the setup
+    (split-K Gram + all-reduce), 1/N of the inverse's lower-triangle tiles per rank and ONE all-reduce of 2p floats per
+    ADMM iteration over `backend`.  Total work is fixed as N grows: strong scaling."""
+    rank, world, multi, torch, dist, dev, adist = _child_setup(backend)
+    from admm_amd import DevicePtr
+    n, p = a.n, a.p
+    lo, hi = n * rank // world, n * (rank + 1) // world
+    nl = hi - lo
+    gb = torch.Generator(device="cpu"); gb.manual_seed(a.seed)
+    beta_true = torch.zeros(p, dtype=torch.float64)
+    beta_true[:a.m] = torch.rand(a.m, generator=gb, dtype=torch.float64)
+    beta_true = beta_true.to(dev)
+    g = torch.Generator(device=dev); g.manual_seed(a.seed + 2000 + rank)
+    xt = torch.empty((p, nl), dtype=torch.float64, device=dev)
+    chunk = max(1, (1 << 27) // max(nl, 1))
+    for c0 in range(0, p, chunk):
+        c1 = min(p, c0 + chunk)
+        xt[c0:c1] = torch.randn((c1 - c0, nl), generator=g, device=dev, dtype=torch.float64) * 2.0
+    y = beta_true @ xt + torch.randn(nl, generator=g, device=dev, dtype=torch.float64)
+    torch.cuda.synchronize()
+    os.environ["ADMM_HIP_PROFILE_STRIDE"] = str(a.profile_stride)
+    t0 = time.time()
+    plan = adist.DistLassoPlan(DevicePtr(xt.data_ptr()), DevicePtr(y.data_ptr()), n, p, 0, nlambda=a.nlambda, lambda_min_ratio=1e-4,
+                               n_local=nl)
+    setup_s = time.time() - t0
+    del xt
+    torch.cuda.empty_cache()
+    for _ in range(max(1, a.warmup)):
+        plan.run()
     if multi:
         dist.barrier()
-        dist.destroy_process_group()
+    t0 = time.time()
+    iters, loop_ms, xms, xsamp = 0, 0.0, 0.0, 0
+    for _ in range(a.steps):
+        fit = plan.run()
+        iters += int(fit.stats["total_iter"])
+        loop_ms += fit.stats["loop_ms_events"]
+        xms += fit.stats["xupdate_ms_avg"] * fit.stats["xupdate_samples"]
+        xsamp += int(fit.stats["xupdate_samples"])
+    elapsed = _max_over_ranks(time.time() - t0, torch, dist, multi)
+    setup_s = _max_over_ranks(setup_s, torch, dist, multi)
+    if rank == 0:
+        x_ms = xms / max(1, xsamp)
+        res = {"workload": "admm_lasso tall path (BASELINE configs[1]), x-update sharded over the ranks", "exchange": backend,
+               "n_gpus": world, "ranks_in_communicator": world, "scaling": "strong", "steps": a.steps,
+               "iterations_per_step": iters / a.steps, "elapsed_s": elapsed, "iters_per_s": iters / elapsed,
+               "us_per_iter": elapsed / iters * 1e6, "loop_ms_events_per_step": loop_ms / a.steps, "setup_s": setup_s,
+               "xupdate_share_avg_launch_ms": x_ms, "xupdate_share_alg_bytes": 2.0 * p * p / world,
+               "xupdate_share_GBps": (2.0 * p * p / world) / (x_ms * 1e-3) / 1e9 if x_ms > 0 else None,
+               "allreduce_payload_bytes": 8 * ((p + 127) // 128 * 128), "niter_first": [int(v) for v in fit.niter[:8]]}
+        with open(out_path, "w") as f:
+            json.dump(res, f)
+    _child_teardown(plan, adist, dist, multi)
 
 
-def run_consensus_side_measurement(a, rank, world):
-    """Run consensus_child in a separate process per rank (own rendezvous port) so that a failure or a hang of
-    the multi-process RCCL path can never take the primary measurement down.  Returns a dict (rank 0) or None."""
+def run_side_measurement(a, rank, world, kind, backend, seconds, port_offset):
+    """Run a child measurement (`kind` in {"consensus", "tallshard"}) in a separate process per rank, with its own
+    rendezvous port and a time limit, so that a failure or a hang of a multi-process exchange path can never take the
+    primary measurement down.  Returns a dict (rank 0) or None."""
     import subprocess
     import tempfile
-    out_path = os.path.join(tempfile.gettempdir(), "admm_consensus_%s.json" % os.environ.get("MASTER_PORT", "0"))
+    out_path = os.path.join(tempfile.gettempdir(), "admm_%s_%s_%s.json" % (kind, backend, os.environ.get("MASTER_PORT", "0")))
     if rank == 0 and os.path.exists(out_path):
         os.remove(out_path)
     env = dict(os.environ)
     multi = world > 1 or FORCE_DIST
     if multi:
         env["MASTER_ADDR"] = "127.0.0.1"
-        env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 17)
+        env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + port_offset)
         # the children build their OWN rendezvous store on that port: do not let env:// look for torchrun's agent store there
         for k in [k for k in env if k.startswith("TORCHELASTIC_")]:
             env.pop(k)
-    cmd = [sys.executable, os.path.abspath(__file__), "--consensus-child", out_path, "--seed", str(a.seed)]
+    cmd = [sys.executable, os.path.abspath(__file__), "--child", "%s:%s:%s" % (kind, backend, out_path), "--seed", str(a.seed),
+           "--n", str(a.n), "--p", str(a.p), "--m", str(a.m), "--nlambda", str(a.nlambda), "--steps", str(a.steps),
+           "--warmup", str(a.warmup), "--profile-stride", str(a.profile_stride)]
     try:
-        r = subprocess.run(cmd, env=env, timeout=a.consensus_seconds, capture_output=True, text=True)
+        r = subprocess.run(cmd, env=env, timeout=seconds, capture_output=True, text=True)
         if rank != 0:
             return None
         if r.returncode != 0 or not os.path.exists(out_path):
-            return {"error": "consensus child failed (rc=%d): %s" % (r.returncode, (r.stderr or "")[-400:])}
+            return {"exchange": backend, "error": "%s child failed (rc=%d): %s" % (kind, r.returncode, (r.stderr or "")[-400:])}
         return json.load(open(out_path))
     except subprocess.TimeoutExpired:
-        return {"error": "consensus child exceeded %.0f s" % a.consensus_seconds} if rank == 0 else None
+        return {"exchange": backend, "error": "%s child exceeded %.0f s" % (kind, seconds)} if rank == 0 else None
     except Exception as e:                                  # noqa: BLE001
-        return {"error": repr(e)} if rank == 0 else None
+        return {"exchange": backend, "error": repr(e)} if rank == 0 else None
 
 
 def main():
     a = parse()
-    if a.consensus_child:
-        consensus_child(a)
+    if a.child:
+        kind, backend, out_path = a.child.split(":", 2)
+        (consensus_child if kind == "consensus" else tallshard_child)(a, backend, out_path)
         return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -264,9 +347,16 @@ def main():
     y = beta_true @ xt + torch.randn(n, generator=g, device=dev, dtype=torch.float64)
     torch.cuda.synchronize()
 
-    # ---- one-time preparation (outside the timed region)
-    t0 = time.time()
+    # ---- one-time preparation (outside the timed region), done twice: the first call of a process also pays the lazy
+    # loading of the library's code objects and the first large allocations (what a fresh R session's first $fit() pays),
+    # the second is the steady-state cost.
     model = admm_lasso(DevicePtr(xt.data_ptr()), DevicePtr(y.data_ptr()), n=n, p=p).penalty(nlambda=a.nlambda)
+    t0 = time.time()
+    plan = LassoPlan(model)
+    lib.admm_hip_device_synchronize()
+    setup_s_cold = time.time() - t0
+    plan.close()
+    t0 = time.time()
     plan = LassoPlan(model)
     lib.admm_hip_device_synchronize()
     setup_s = time.time() - t0
@@ -302,8 +392,18 @@ def main():
     else:
         elapsed_max, iters_all = elapsed, float(iters)
 
-    consensus = run_consensus_side_measurement(a, rank, world) if a.consensus_seconds > 0 else None
-    barrier()
+    # ---- side measurements in child processes (own rendezvous, time-limited): the paths with a real exchange step
+    consensus, shard = [], []
+    if a.consensus_seconds > 0:
+        consensus.append(run_side_measurement(a, rank, world, "consensus", "rccl", a.consensus_seconds, 17))
+        barrier()
+        if multi:
+            consensus.append(run_side_measurement(a, rank, world, "consensus", "peer", a.consensus_seconds, 29))
+            barrier()
+    if multi and a.shard_seconds > 0:
+        for k, backend in enumerate(("rccl", "peer")):
+            shard.append(run_side_measurement(a, rank, world, "tallshard", backend, a.shard_seconds, 41 + 12 * k))
+            barrier()
     if rank == 0:
         x_ms = xms / max(1, xsamp)
         sym = int(fit.stats["xupdate_variant"]) == 1
@@ -314,12 +414,18 @@ def main():
         kname = ("symv2_lower_kernel (x-update, lower triangle of the cached inverse x [u w])" if sym
                  else "gemv_t_kernel<float,2,4> (x-update, cached inverse x [u w])")
         traffic, traffic_src = None, None
-        try:        # PMC counters cannot be collected from inside the run: quote the committed measurement for this exact shape
+        try:        # PMC counters cannot be collected from inside the run: quote the committed measurement for this exact shape,
+            # and only while the kernel source it was taken from is unchanged (otherwise null: re-profile)
+            import hashlib
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             ent = pmc.get("symv2_lower_kernel" if sym else "gemv_t_kernel")
-            if ent and int(ent["p"]) == p:
+            src = os.path.join(ROOT, "admm_amd", "csrc", "symv_kernels.h" if sym else "gemv_kernels.h")
+            sha = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]
+            if ent and int(ent["p"]) == p and ent.get("kernel_source_sha16") == sha:
                 traffic = ent["hbm_read_bytes"] + ent["hbm_write_bytes"]
                 traffic_src = ent["source"]
+            elif ent:
+                traffic_src = "stale: %s changed since %s was captured" % (os.path.basename(src), ent["source"])
         except Exception:
             pass
         out = {
@@ -340,7 +446,9 @@ def main():
                        "parallelism": "replicas x%d" % world if world > 1 else "single GPU",
                        "iters_per_step": iters / a.steps, "step": "one cold-started warm-chained lambda path"},
             "setup_s": setup_s,
+            "setup_s_cold": setup_s_cold,
             "sec_to_eps": setup_s + elapsed / a.steps,
+            "sec_to_eps_cold": setup_s_cold + elapsed / a.steps,
             "setup_breakdown_s": {k: fit.stats[k] for k in ("t_h2d", "t_standardize", "t_gram", "t_eigs", "t_factor")},
             "loop_ms_events_per_step": loop_ms / a.steps,
             "rho": fit.stats["rho"],
@@ -351,8 +459,28 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": x_ms, "launches_timed": xsamp,
                          "survey_4p2_equivalent_GBps": 4.0 * p * p / (x_ms * 1e-3) / 1e9 if x_ms > 0 else 0.0},
         }
-        if consensus is not None:
-            out["consensus"] = consensus
+        consensus = [c for c in consensus if c]
+        shard = [c for c in shard if c]
+        if consensus:
+            out["consensus"] = consensus[0] if len(consensus) == 1 else consensus
+        if shard:
+            out["sharded"] = shard
+            ok = [c for c in shard if "error" not in c]
+            if ok:
+                # N > 1: the primary line is the headline workload itself with its x-update spread over the N GPUs (total
+                # work fixed: strong scaling), over the better of the two exchanges; the independent-replica figure
+                # measured above moves to `replicas_weak`.
+                best = max(ok, key=lambda c: c["iters_per_s"])
+                out["replicas_weak"] = {"value": out["value"], "ms_per_step": out["ms_per_step"], "scaling": "weak",
+                                        "note": "N independent replicas of the single-GPU solver (no exchange)"}
+                out["value"] = best["iters_per_s"]
+                out["ms_per_step"] = best["elapsed_s"] / best["steps"] * 1e3
+                out["scaling"] = "strong"
+                out["config"]["parallelism"] = "x-update sharded over %d GPUs, one all-reduce of 2p floats per iteration (%s)" % (world, best["exchange"])
+                out["config"]["iters_per_step"] = best["iterations_per_step"]
+                out["setup_s"] = best["setup_s"]
+                out["sec_to_eps"] = best["setup_s"] + best["elapsed_s"] / best["steps"]
+                out["roofline"]["note"] = "single-GPU replica kernel; the sharded run's share is in `sharded`"
         if a.cpu_seconds > 0 and world == 1:                # the CPU leg is timed on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(p, a.nlambda, a.cpu_seconds, a.seed)
         print(json.dumps(out), flush=True)

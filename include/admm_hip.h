@@ -83,7 +83,8 @@ typedef struct admm_stats {
     double rho;            /* rho actually used (first lambda) */
     double eig_est;        /* the loose Lanczos value (lambda_max or spectral-radius estimate) */
     int branch;            /* 0 tall (Cholesky), 1 wide (linearised), 2 consensus */
-    int xupdate_variant;   /* tall path: 0 = full-matrix mat-vec (4p^2 B), 1 = lower-triangle symmetric mat-vec (2p^2 B) */
+    int xupdate_variant;   /* tall path: 0 = full-matrix mat-vec (4p^2 B), 1 = lower-triangle symmetric mat-vec (2p^2 B),
+                              2 = the same with the tiles dealt out to the ranks + one all-reduce of 2p floats (admm_hip_lasso_dist) */
 } admm_stats;
 
 /* lambda_in: user grid of length nlambda_in (sorted decreasing by the R wrapper), or NULL/0
@@ -164,7 +165,7 @@ ADMM_HIP_API int admm_hip_lasso_plan_trace_read(admm_hip_plan* plan, double* out
  * [r * nthread / nranks, (r+1) * nthread / nranks)).  Standardisation uses the global column moments
  * (the reference standardises before it splits, ParLasso.cpp:68-72); per ADMM iteration the ranks
  * exchange ONE grouped all-reduce: the consensus sum (p floats) and three squared norms.  Every rank
- * returns the full result. */
+ * returns the full result.  nthread >= 1 in these two entry points. */
 #define ADMM_HIP_UNIQUE_ID_BYTES 128
 ADMM_HIP_API int admm_hip_comm_unique_id(void* id_out);
 ADMM_HIP_API int admm_hip_comm_init(int nranks, int rank, const void* id);
@@ -193,6 +194,19 @@ ADMM_HIP_API int admm_hip_lasso_plan_create_dist(const double* x_local, const do
                                     const double* lambda_in, int nlambda_in, int nlambda_auto, double lmin_ratio,
                                     int standardize, int intercept, int nthread, const admm_opts* opts,
                                     admm_hip_plan** plan_out, int* nlambda_out);
+/* The SERIAL tall solver (admm_lasso / admm_enet with n_total > p) spread over the ranks -- not in the reference, whose
+ * serial solvers are single-threaded; it gives the headline configuration a multi-GPU path.
+ * x_local / y_local: any contiguous row slice of the global problem (the slices of all ranks tile the rows; unlike the
+ * consensus solver the algorithm does not depend on the split).  Setup: global-moment standardisation, X'y and the
+ * Gram matrix as split-K sums over the ranks' row blocks (one all-reduce each), Lanczos value / rho / cached inverse
+ * replicated.  Per ADMM iteration every rank streams 1/nranks of the lower-triangle tiles of the inverse and the ranks
+ * exchange ONE all-reduce of 2p floats; the element-wise tail and all decisions run replicated on identical numbers.
+ * The iterates equal the single-GPU ones up to the summation order of that all-reduce.  alpha < 0: Lasso, else
+ * elastic net.  admm_hip_lasso_plan_create_dist with nthread == 0 prepares the same solver for repeated runs. */
+ADMM_HIP_API int admm_hip_lasso_dist(const double* x_local, const double* y_local, int n_local, long long n_total, int p, int mem,
+                        const double* lambda_in, int nlambda_in, int nlambda_auto, double lmin_ratio,
+                        int standardize, int intercept, double alpha, const admm_opts* opts,
+                        double* lambda_out, float* beta_out, int* niter_out, admm_stats* stats);
 
 ADMM_HIP_API const char* admm_hip_last_error(void);
 ADMM_HIP_API const char* admm_hip_version(void);
@@ -213,6 +227,14 @@ ADMM_HIP_API int admm_hip_host_lanczos(const float* A, int n, float* eig_out, in
  * the symmetric p x p float matrix A (HOST, column-major, leading dimension p) against the two right-hand sides
  * v0, v1 (HOST, length p), followed by the tail kernel's ordered partial reduction.  y0 = A v0, y1 = A v1 (HOST). */
 ADMM_HIP_API int admm_hip_test_symv(const float* A, int p, const float* v0, const float* v1, float* y0, float* y1);
+
+/* The one-time matrix-core kernels as the solvers call them (Linalg::cross_prod_lower / tcross_prod_lower,
+ * BlasWrapper.h:73-154; LLT, ADMMLassoTall.h:204-205), on HOST matrices (column-major, tight leading dimensions):
+ * G = A'A (atA != 0, order cols) or AA' (order rows), both triangles, float (is_double == 0) or double;
+ * Ainv = inverse of the SPD matrix A of order n: precision 0 = float, 1 = double, 2 = float matrix inverted in double
+ * and rounded once (ADMM_HIP_INVERSE=f64). */
+ADMM_HIP_API int admm_hip_test_gram(const void* A, int rows, int cols, int atA, int is_double, void* G);
+ADMM_HIP_API int admm_hip_test_spd_inverse(const void* A, int n, int precision, void* Ainv);
 
 #ifdef __cplusplus
 }

@@ -39,6 +39,12 @@ def problem(case):
     if case == "wideblocks":          # 403 rows in 4 blocks over 2 ranks: Woodbury branch (:25-30), remainder block on the last rank
         x, y = synth_lasso(403, 300, 12, seed=62)
         return x, y, 4, dict(nlambda=4, maxit=300)
+    if case == "tallshard300":        # the serial tall solver with its x-update spread over the ranks (small p: one tile row)
+        x, y = synth_lasso(2000, 300, 30, seed=7)
+        return x, y, 0, dict(nlambda=12)
+    if case == "tallshard2300":       # ~90 lower-triangle tiles dealt out to the ranks
+        x, y = synth_lasso(4700, 2300, 40, seed=2300)
+        return x, y, 0, dict(nlambda=6)
     raise SystemExit("unknown case " + case)
 
 
@@ -70,9 +76,20 @@ def main():
     # ---- the distributed consensus solver on this rank's row slice
     x, y, K, kw = problem(case)
     n, p = x.shape
-    lo, hi = adist.row_partition(n, K, nranks, rank)
-    fit = adist.parlasso_dist(np.asfortranarray(x[lo:hi]), y[lo:hi], n, p, K, n_local=hi - lo, **kw)
-    np.savez(os.path.join(workdir, f"result.{rank}.npz"), beta=fit.beta_dense, niter=fit.niter, lam=fit.lambda_)
+    if K > 0:
+        lo, hi = adist.row_partition(n, K, nranks, rank)
+        fit = adist.parlasso_dist(np.asfortranarray(x[lo:hi]), y[lo:hi], n, p, K, n_local=hi - lo, **kw)
+        trace = np.zeros((0, 10))
+    else:
+        cut = [0] + [int(n * (r + 1) / nranks) + (17 if r < nranks - 1 else 0) for r in range(nranks)]     # uneven slices on purpose
+        lo, hi = cut[rank], cut[rank + 1]
+        plan = adist.DistLassoPlan(np.asfortranarray(x[lo:hi]), y[lo:hi], n, p, 0, lambda_min_ratio=1e-4, n_local=hi - lo, **kw)
+        plan.enable_trace(1 << 16)
+        fit = plan.run()
+        trace = plan.read_trace()
+        assert fit.stats["xupdate_variant"] == 2
+        plan.close()
+    np.savez(os.path.join(workdir, f"result.{rank}.npz"), beta=fit.beta_dense, niter=fit.niter, lam=fit.lambda_, trace=trace)
     barrier(workdir, "end", rank, nranks)                  # nobody unmaps while a peer may still push
     adist.finalize_comm()
     print("rank", rank, "ok", flush=True)

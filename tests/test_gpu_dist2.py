@@ -63,3 +63,23 @@ def test_two_process_consensus_matches_single_process(backend, case):
                               dict(entry.LASSO_OPTS, maxit=kw["maxit"]))
     for j in range(kw["nlambda"]):
         assert relerr(res[0]["beta"][:, j], ref["beta"][:, j]) < 2e-3, j
+
+
+@pytest.mark.parametrize("backend,case", [("shm", "tallshard300"), ("peer", "tallshard300"), ("peer", "tallshard2300")])
+def test_two_process_row_sharded_tall_solver(backend, case):
+    """The serial tall solver with its x-update dealt out to two ranks (admm_hip_lasso_plan_create_dist, nthread = 0):
+    split-K Gram / X'y over the ranks' row slices, replicated factorisation, per iteration each rank's share of the
+    lower-triangle tiles + one all-reduce of 2p floats.  Judged like the single-GPU tall path: the oracle follows the
+    decision trace through rounding-level near-ties only, counts identical, every column within 1e-4."""
+    from oracle import entry
+    from helpers import assert_tall_parity
+    sys.path.insert(0, HERE)
+    from dist_worker import problem
+    res = _run_ranks(backend, case, timeout=600)
+    assert np.array_equal(res[0]["beta"], res[1]["beta"]) and np.array_equal(res[0]["niter"], res[1]["niter"])
+    assert np.array_equal(res[0]["trace"], res[1]["trace"])              # replicated decisions from identical numbers
+    x, y, K, kw = problem(case)
+    prob = dict(x=x, y=y, lam=None, nlambda=kw["nlambda"], lmin_ratio=1e-4, standardize=True, intercept=True,
+                opts=entry.LASSO_OPTS, alpha=None)
+    rep = assert_tall_parity(res[0]["beta"], res[0]["niter"], res[0]["trace"], prob, 1e-4, label=f"{case} over {backend}")
+    assert len(rep["loose"]) == 0

@@ -98,3 +98,90 @@ def test_c5_shape_bp_feasible_and_recovers():
     assert feas < 2e-2                                               # z (returned) satisfies A z = b only up to the ADMM tolerance
     assert (beta - b).abs().max().item() < 5e-2                      # sparse truth recovered
     assert fit.niter < 10000
+
+
+def test_c4_full_size_consensus_k8():
+    """BASELINE configs[3]: admm_lasso$parallel(8), n=10000, p=100000 -- 8 row blocks of 1250 x 10^5 (Woodbury branch,
+    PADMMLasso.h:25-30) on ONE GPU.  Size-independent checks: the lambda_max model is null, the stationarity (KKT)
+    residual of the returned z, and agreement with the serial wide solver (ADMMLassoWide) on the same lambdas -- two
+    different algorithms of the reference for the same optimum, each stopped at its own eps = 1e-5."""
+    from admm_amd import DevicePtr, admm_lasso
+    n, p, K = 10000, 100000, 8
+    xt, y, _ = _gen(n, p, 100, 404)
+    par = admm_lasso(DevicePtr(xt.data_ptr()), DevicePtr(y.data_ptr()), n=n, p=p).penalty(nlambda=4, lambda_min_ratio=0.3) \
+        .parallel(K).opts(maxit=2500).fit()
+    assert par.stats["branch"] == 2
+    assert np.count_nonzero(par.beta_dense[1:, 0]) <= 1 and np.abs(par.beta_dense[1:, 0]).max() < 5e-3      # lambda_max: null model
+    assert np.all(np.isfinite(par.beta_dense)) and par.niter.min() >= 1
+    ser = admm_lasso(DevicePtr(xt.data_ptr()), DevicePtr(y.data_ptr()), n=n, p=p).penalty(list(par.lambda_)).fit()
+    assert ser.stats["branch"] == 1
+    scale = np.abs(ser.beta_dense).max()
+    for j in (1, 2, 3):
+        viol, on, ns = _kkt(xt, y, par.beta_dense[:, j], float(par.lambda_[j]))
+        print(f"[C4 K=8] lambda {j}: niter {int(par.niter[j])} nnz {ns} KKT max|g|/lambda {viol:.4f} on-support {on:.4f}; "
+              f"vs serial wide solver {np.abs(par.beta_dense[:, j] - ser.beta_dense[:, j]).max() / scale:.2e}")
+        assert ns > 0 and int(par.niter[j]) <= 2500
+        assert viol < 1.0 + 5e-2, (j, viol)
+        assert on < 0.1, (j, on, ns)
+        assert np.abs(par.beta_dense[:, j] - ser.beta_dense[:, j]).max() / scale < 2e-2, j
+
+
+def test_c4_woodbury_sibling_k8_vs_oracle():
+    """The same configuration scaled to what the oracle runs in seconds: 8 wide row blocks (200 x 4000)."""
+    from admm_amd import admm_lasso
+    from helpers import relerr, synth_lasso
+    from oracle import entry
+    x, y = synth_lasso(1600, 4000, 30, seed=44)
+    fit = admm_lasso(x, y).penalty(nlambda=4, lambda_min_ratio=0.2).parallel(8).opts(maxit=600).fit()
+    ref = entry.admm_parlasso(x, y, None, 4, 0.2, True, True, 8, dict(entry.LASSO_OPTS, maxit=600))
+    assert np.allclose(fit.lambda_, ref["lambda"], rtol=1e-5)
+    assert np.abs(fit.niter.astype(int) - ref["niter"].astype(int)).max() <= max(5, 0.05 * ref["niter"].max()), (fit.niter, ref["niter"])
+    for j in range(4):
+        assert relerr(fit.beta_dense[:, j], ref["beta"][:, j]) < 2e-4, j
+
+
+def _lad_objective(xt, y, beta):
+    import torch
+    bt = torch.tensor(np.asarray(beta[1:], dtype=np.float64), device=xt.device)
+    return (y - float(beta[0]) - bt @ xt).abs().sum().item()
+
+
+def test_c5_full_size_lad():
+    """BASELINE configs[4]: admm_lad n=50000, p=5000 (fp64).  (1) Fixed-maxit comparison with the oracle fixture
+    tests/golden/c5_lad_fixed_maxit.npz (made by tests/golden/make_c5_lad.py from the same seeded data).  (2) The
+    converged fit against the LAD optimum: its objective sum|y - X beta| may exceed the best objective found by
+    iteratively reweighted least squares (float64, on the GPU through torch) by at most the solver's tolerance, and it
+    must beat least squares clearly."""
+    import os
+    import sys
+    import torch
+    from admm_amd import admm_lad
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from make_c5_lad import c5_lad_data
+    from helpers import relerr
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c5_lad_fixed_maxit.npz"))
+    x, y = c5_lad_data(int(fx["seed"]), int(fx["n"]), int(fx["p"]))
+    maxit = int(fx["maxit"])
+    fit = admm_lad(x, y, intercept=False).opts(maxit=maxit).fit()
+    assert fit.niter == int(fx[f"niter_maxit{maxit}"]) == maxit + 1
+    err = relerr(fit.beta, fx[f"beta_maxit{maxit}"])
+    print(f"[C5 LAD] after {maxit} iterations: relative difference to the oracle fixture {err:.2e}")
+    assert err < 1e-8, err                                           # fp64, identical rho decisions
+    full = admm_lad(x, y, intercept=False).fit()
+    assert full.niter < 10000
+    dev = torch.device("cuda", 0)
+    xt = torch.tensor(np.ascontiguousarray(x.T), device=dev)         # p x n
+    yt = torch.tensor(y, device=dev)
+    # IRLS for min sum |r_i| (weights 1 / max(|r_i|, delta)), started at least squares
+    G = xt @ xt.T
+    b = torch.linalg.solve(G, xt @ yt)
+    f_ls = (yt - b @ xt).abs().sum().item()
+    best = f_ls
+    for _ in range(40):
+        w = 1.0 / (yt - b @ xt).abs().clamp_min(1e-6)
+        b = torch.linalg.solve((xt * w) @ xt.T, (xt * w) @ yt)
+        best = min(best, (yt - b @ xt).abs().sum().item())
+    f_admm = _lad_objective(xt, yt, full.beta)
+    print(f"[C5 LAD] converged in {full.niter} iterations: objective {f_admm:.6e}, IRLS optimum {best:.6e} (+{f_admm / best - 1:.2e}), least squares {f_ls:.6e}")
+    assert f_admm <= best * (1 + 1e-3)
+    assert f_admm < f_ls

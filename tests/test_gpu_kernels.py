@@ -1,0 +1,75 @@
+"""One-time matrix-core kernels under NumPy, through the C-ABI test hooks: the Gram products (fp32 / fp64 SYRK on
+v_mfma_f32_32x32x2_f32 / v_mfma_f64_16x16x4_f64, split-K for small orders) and the blocked Cholesky + inverse.
+Replaces Linalg::cross_prod_lower / tcross_prod_lower (/root/reference/src/Linalg/BlasWrapper.h:73-154) and the LLT of
+ADMMLassoTall.h:204-205, PADMMLasso.h:55-60, ADMMLAD.h:187-189, ADMMBP.h:168-169."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _gram(A, atA):
+    from admm_amd import _lib
+    lib = _lib.load()
+    A = np.asfortranarray(A)
+    dbl = A.dtype == np.float64
+    k = A.shape[1] if atA else A.shape[0]
+    G = np.zeros((k, k), dtype=A.dtype, order="F")
+    _lib.check(lib.admm_hip_test_gram(A.ctypes.data, A.shape[0], A.shape[1], int(atA), int(dbl), G.ctypes.data))
+    return G
+
+
+def _inverse(A, precision):
+    from admm_amd import _lib
+    lib = _lib.load()
+    A = np.asfortranarray(A)
+    out = np.zeros_like(A, order="F")
+    _lib.check(lib.admm_hip_test_spd_inverse(A.ctypes.data, A.shape[0], precision, out.ctypes.data))
+    return out
+
+
+@pytest.mark.parametrize("rows,cols,atA", [(3000, 700, True), (1037, 513, True), (5000, 2300, True), (300, 4000, False),
+                                           (129, 129, True), (2000, 64, True)])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_gram_vs_numpy(rows, cols, atA, dtype):
+    rng = np.random.default_rng(rows + cols)
+    A = (rng.standard_normal((rows, cols)) * 2 + 0.3).astype(dtype)
+    G = _gram(A, atA)
+    A64 = A.astype(np.float64)
+    ref = A64.T @ A64 if atA else A64 @ A64.T
+    assert np.array_equal(G, G.T)                                    # both triangles, mirrored exactly
+    tol = 2e-5 if dtype == np.float32 else 1e-13                      # float sums of thousands of products, no compensation
+    assert np.abs(G - ref).max() / np.abs(ref).max() < tol
+
+
+@pytest.mark.parametrize("n", [256, 300, 1100, 2048, 2300])
+@pytest.mark.parametrize("precision", [0, 1, 2])
+def test_spd_inverse_vs_numpy(n, precision):
+    """Residual ||A Ainv - I|| against what LAPACK achieves in the same precision (cond(A) ~ 30)."""
+    rng = np.random.default_rng(n)
+    X = rng.standard_normal((2 * n, n))
+    A64 = X.T @ X + 0.05 * n * np.eye(n)
+    dtype = np.float64 if precision == 1 else np.float32
+    A = A64.astype(dtype)
+    Ainv = _inverse(A, precision)
+    assert np.abs(Ainv - Ainv.T).max() <= 1e-6 * np.abs(Ainv).max()
+    exact = np.linalg.inv(A.astype(np.float64))
+    err = np.abs(Ainv - exact).max() / np.abs(exact).max()
+    lapack = np.linalg.inv(A).astype(np.float64)
+    err_lapack = np.abs(lapack - exact).max() / np.abs(exact).max()
+    bound = {0: max(5 * err_lapack, 2e-5), 1: 1e-12, 2: 1.2e-7}[precision]      # precision 2: one float rounding of the double inverse
+    print(f"[inverse n={n} precision={precision}] max error {err:.2e} (LAPACK in the same precision: {err_lapack:.2e})")
+    assert err < bound, (n, precision, err, err_lapack)
+
+
+def test_inverse_rejects_an_indefinite_matrix():
+    from admm_amd._lib import AdmmHipError
+    rng = np.random.default_rng(1)
+    X = rng.standard_normal((400, 300))
+    A = (X.T @ X).astype(np.float32)
+    A[200, 200] = -5.0
+    with pytest.raises(AdmmHipError) as e:
+        _inverse(A, 0)
+    assert e.value.code == 5                                          # ADMM_ERR_NOT_SPD (the reference never checks LLT::info())
