@@ -166,6 +166,13 @@ class ADMM_Lasso:
 class ADMM_Enet(ADMM_Lasso):
     _name = "ADMM Elastic Net model"
 
+    def parallel(self, nthread=2):
+        """The reference's $parallel() on an elastic-net model only sets a field that ADMM_Enet$fit never reads
+        (R/40_admm_enet.R:50-64 always calls admm_enet): kept as a no-op with the same validation."""
+        super().parallel(nthread)
+        self.nthread = 1
+        return self
+
     def __init__(self, x, y, intercept=True, standardize=True, n=None, p=None):
         super().__init__(x, y, intercept, standardize, n, p)
         self.alpha = 1.0
@@ -220,6 +227,8 @@ class ADMM_BP:
         lib = _lib.load()
         xp, xmem, xk = as_input(self.x)
         yp, ymem, yk = as_input(self.y)
+        if xmem != ymem:
+            _stop("x and y must live in the same memory space")
         o = AdmmOpts(self.maxit, self.eps_abs, self.eps_rel, self.rho)
         beta = np.zeros(self.p, dtype=np.float64)
         niter = np.zeros(1, dtype=np.int32)
@@ -256,6 +265,8 @@ class ADMM_LAD(ADMM_BP):
         lib = _lib.load()
         xp, xmem, xk = as_input(self.x)
         yp, ymem, yk = as_input(self.y)
+        if xmem != ymem:
+            _stop("x and y must live in the same memory space")
         o = AdmmOpts(self.maxit, self.eps_abs, self.eps_rel, self.rho)
         beta = np.zeros(self.p + 1, dtype=np.float64)
         niter = np.zeros(1, dtype=np.int32)

@@ -230,6 +230,8 @@ int admm_hip_lasso_plan_create(const double* x, const double* y, int n, int p, i
         ADMM_REQUIRE(plan_out != nullptr, "plan_out must not be NULL");
         const bool enet = alpha >= 0.0;
         if (enet) ADMM_REQUIRE(alpha <= 1.0, "alpha must be within [0, 1]");
+        // the reference has no parallel elastic net (R/40_admm_enet.R:50-64 always calls admm_enet): refuse instead of silently running a consensus Lasso
+        ADMM_REQUIRE(!(enet && nthread > 1), "the consensus solver has no elastic-net variant: alpha >= 0 cannot be combined with nthread > 1");
         PlanHandle* h = create_plan(x, y, n, p, mem, lambda_in, nlambda_in, nlambda_auto, lmin_ratio, standardize, intercept,
                                     enet, enet ? alpha : 1.0, nthread > 1 ? nthread : 0, opts);
         *plan_out = reinterpret_cast<admm_hip_plan*>(h);

@@ -262,20 +262,53 @@ void solve_lad(const DeviceData<double>& d, const admm_opts& opts, DenseResult& 
 
     DenseLoop L;
     L.init(n, 0, opts, d.Y.get(), ynorm, st);
-    GemvT<double> g1, g2, g3;                    // t = X' vec ; s = (X'X)^-1 t ; xs = X s
+    GemvT<double> g1, g2, g3, gH;                // t = X' vec ; s = (X'X)^-1 t ; xs = X s ;  or xs = H vec
     g1.init(d.X.get(), d.ldx, n, p);
     g2.init(M.get(), ldp, p, p);
-    g3.init(Xt.get(), ldxt, p, n);
     DevBuf<double> tvec(ldp), svec(ldp);
     tvec.zero(st); svec.zero(st);
-    L.q.gout = g3.part.get(); L.q.gout_nseg = g3.pl.nseg; L.q.gout_stride = g3.stride;
+
+    // n <= 2000: the reference caches the hat matrix H = X (X'X)^-1 X' = T T', T = X L^-T, and projects with one
+    // symmetric product (ADMMLAD.h:67-73,191-203).  Same here: T = X U with U = L^-T from the blocked factorisation,
+    // H = T T' on the fp64 matrix cores, then ONE mat-vec per iteration.  ADMM_HIP_LAD_HAT=0 keeps the general form.
+    bool hat = n <= 2000;
+    if (const char* e = std::getenv("ADMM_HIP_LAD_HAT")) hat = hat && std::string(e) != "0";
+    DevBuf<double> H;
+    long long ldh = 0;
+    if (hat) {
+        t0 = now_s();
+        const long long ldn = round_up(n, 128);
+        const int pk = (int)round_up(p, 8);
+        DevBuf<double> G2((size_t)ldp * ldp); G2.zero(st);
+        gram_full<double>(d.X.get(), d.ldx, n, p, true, G2.get(), ldp, st);
+        DevBuf<double> U = cholesky_linvt_mfma_f64(G2.get(), ldp, p, st);          // U = L^-T (p x p, upper)
+        DevBuf<double> W((size_t)ldp * ldp), Xp((size_t)ldn * pk), T((size_t)ldn * ldp);
+        Xp.zero(st); T.zero(st);
+        transpose<double>(U.get(), ldp, (int)ldp, (int)ldp, W.get(), ldp, st);      // W = L^-1: W[j, k] = U[k, j]
+        hipLaunchKernelGGL(copy_cols_f64_kernel, dim3((n + 255) / 256, p), dim3(256), 0, st, d.X.get(), d.ldx, n, Xp.get(), ldn);
+        gemm_nt_f64(Xp.get(), ldn, W.get(), ldp, T.get(), ldn, n, p, pk, st);       // T[i, j] = sum_k X[i, k] U[k, j]
+        ldh = ldn;
+        H.alloc((size_t)ldh * ldh); H.zero(st);
+        gram_full<double>(T.get(), ldn, n, p, false, H.get(), ldh, st);             // H = T T' (tcross_prod_lower)
+        ADMM_HIP_CHECK(hipStreamSynchronize(st));
+        S.t_factor += now_s() - t0;
+        gH.init(H.get(), ldh, n, n);
+        L.q.gout = gH.part.get(); L.q.gout_nseg = gH.pl.nseg; L.q.gout_stride = gH.stride;
+    } else {
+        g3.init(Xt.get(), ldxt, p, n);
+        L.q.gout = g3.part.get(); L.q.gout_nseg = g3.pl.nseg; L.q.gout_stride = g3.stride;
+    }
 
     const int* skip = L.done.get();
     LoopTimes lt = run_until_done(st, skip, env_batch(8), (long long)opts.maxit + 2, [&](long long g) {
         L.head(g, st);
-        g1.run_partials(L.vec.get(), skip, st);          // chained: the next product sums these partial rows while staging
-        g2.run_partials_from(g1, skip, st);
-        g3.run_partials_from(g2, skip, st);
+        if (hat) {
+            gH.run_partials(L.vec.get(), skip, st);          // dsymv(H, vec)
+        } else {
+            g1.run_partials(L.vec.get(), skip, st);          // chained: the next product sums these partial rows while staging
+            g2.run_partials_from(g1, skip, st);
+            g3.run_partials_from(g2, skip, st);
+        }
         L.tail(g, st);
     });
     S.t_loop = lt.wall_s; S.loop_ms_events = lt.events_ms; S.xupdate_launches = lt.launched;

@@ -128,7 +128,8 @@ ADMM_HIP_API int admm_hip_bp(const double* x, const double* y, int n, int p, int
  * before its lambda loop (copy/convert, DataStd, X'y, Gram, Spectra, factorisation:
  * Lasso.cpp:42-76 + ADMM*::init); run = the warm-started lambda loop of Lasso.cpp:97-124 from a
  * cold start, repeatable; destroy frees all device memory.  alpha < 0 selects the Lasso prox,
- * 0 <= alpha <= 1 the elastic net; nthread > 1 selects the consensus solver.
+ * 0 <= alpha <= 1 the elastic net; nthread > 1 selects the consensus solver (Lasso only: alpha >= 0 with nthread > 1 is
+ * ADMM_ERR_INVALID_ARG -- the reference has no parallel elastic net).
  * bench.py times run() only (ADMM iterations/s excludes the one-time setup). */
 typedef struct admm_hip_plan admm_hip_plan;
 ADMM_HIP_API int admm_hip_lasso_plan_create(const double* x, const double* y, int n, int p, int mem,

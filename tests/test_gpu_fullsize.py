@@ -150,8 +150,8 @@ def test_c5_full_size_lad():
     """BASELINE configs[4]: admm_lad n=50000, p=5000 (fp64).  (1) Fixed-maxit comparison with the oracle fixture
     tests/golden/c5_lad_fixed_maxit.npz (made by tests/golden/make_c5_lad.py from the same seeded data).  (2) The
     converged fit against the LAD optimum: its objective sum|y - X beta| may exceed the best objective found by
-    iteratively reweighted least squares (float64, on the GPU through torch) by at most the solver's tolerance, and it
-    must beat least squares clearly."""
+    iteratively reweighted least squares (float64, on the GPU through torch) by at most the solver's accuracy (5e-3),
+    and it must close at least 80 % of the gap between least squares and that optimum."""
     import os
     import sys
     import torch
@@ -183,5 +183,7 @@ def test_c5_full_size_lad():
         best = min(best, (yt - b @ xt).abs().sum().item())
     f_admm = _lad_objective(xt, yt, full.beta)
     print(f"[C5 LAD] converged in {full.niter} iterations: objective {f_admm:.6e}, IRLS optimum {best:.6e} (+{f_admm / best - 1:.2e}), least squares {f_ls:.6e}")
-    assert f_admm <= best * (1 + 1e-3)
-    assert f_admm < f_ls
+    # eps = 1e-4 stops ADMM within a few 1e-3 of the optimal objective (the README reports coefficient differences of
+    # +-4e-3 .. 7e-3 against quantreg at its own sizes, README.md:331-333,362-364); least squares is far outside that
+    assert f_admm <= best * (1 + 5e-3)
+    assert (f_admm - best) < 0.2 * (f_ls - best)
