@@ -55,7 +55,8 @@ EXPORTS = ["admm_hip_lasso", "admm_hip_enet", "admm_hip_parlasso", "admm_hip_lad
            "admm_hip_lasso_plan_trace_enable", "admm_hip_lasso_plan_trace_read",
            "admm_hip_host_lanczos", "admm_hip_test_symv",
            "admm_hip_comm_peer_prepare", "admm_hip_comm_init_peer", "admm_hip_comm_init_shm", "admm_hip_comm_test_allreduce",
-           "admm_hip_lasso_dist", "admm_hip_test_gram", "admm_hip_test_spd_inverse"]
+           "admm_hip_lasso_dist", "admm_hip_test_gram", "admm_hip_test_spd_inverse",
+           "admm_hip_lasso_dist_cols"]
 
 TRACE_FIELDS = 10
 TRACE_COLD, TRACE_CONVERGED, TRACE_ACCELERATE, TRACE_RESTART = -1, 0, 1, 2
@@ -104,6 +105,10 @@ def load():
                                         _DP, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_double,
                                         ctypes.POINTER(AdmmOpts), _c_double_p, _c_float_p, _c_int_p, ctypes.POINTER(AdmmStats)]
     lib.admm_hip_lasso_dist.restype = ctypes.c_int
+    lib.admm_hip_lasso_dist_cols.argtypes = [_DP, _DP, ctypes.c_int, ctypes.c_int, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_int,
+                                             _DP, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                             ctypes.POINTER(AdmmOpts), _c_double_p, _c_float_p, _c_int_p, ctypes.POINTER(AdmmStats)]
+    lib.admm_hip_lasso_dist_cols.restype = ctypes.c_int
     lib.admm_hip_comm_unique_id.argtypes = [ctypes.c_void_p]
     lib.admm_hip_comm_unique_id.restype = ctypes.c_int
     lib.admm_hip_comm_init.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]

@@ -113,6 +113,41 @@ static PlanHandle* create_plan(const double* x, const double* y, int n, int p, i
     return h.release();
 }
 
+// Column-sharded wide solver: this rank holds columns [col_offset, col_offset + p_local) of the n x p_total problem.
+static PlanHandle* create_plan_cols(const double* x_cols, const double* y, int n, int p_local, long long p_total, long long col_offset, int mem,
+                                    const double* lambda_in, int nlambda_in, int nlambda_auto, double lmin_ratio,
+                                    int standardize, int intercept, bool enet, double alpha, const admm_opts* opts) {
+    check_common(x_cols, y, n, p_local, mem, opts);
+    ADMM_REQUIRE(nlambda_in >= 0, "nlambda_in must be >= 0");
+    ADMM_REQUIRE(nlambda_in > 0 ? lambda_in != nullptr : nlambda_auto > 0, "need a lambda grid or nlambda_auto > 0");
+    if (nlambda_in == 0) ADMM_REQUIRE(lmin_ratio > 0 && lmin_ratio < 1, "lambda_min_ratio must be within (0, 1)");
+    for (int i = 0; i < nlambda_in; ++i) ADMM_REQUIRE(lambda_in[i] > 0, "lambda must be positive");
+    ADMM_REQUIRE(p_total >= p_local && col_offset >= 0 && col_offset + p_local <= p_total, "column block outside [0, p_total)");
+    ADMM_REQUIRE(p_total < (1ll << 31) - 1, "p_total too large");
+    ADMM_REQUIRE((long long)n <= p_total, "the column-sharded solver is the wide one: it needs n <= p_total (Lasso.cpp:73)");
+    ADMM_REQUIRE(comm_info().active, "no communicator: call admm_hip_comm_init first");
+    require_device();
+    const double t0 = now_s();
+    std::unique_ptr<PlanHandle> h(new PlanHandle());
+    LassoProblem pb;
+    pb.opts = *opts;
+    pb.lambda_in.assign(lambda_in, lambda_in + nlambda_in);
+    pb.nlambda_auto = nlambda_auto;
+    pb.lmin_ratio = lmin_ratio;
+    pb.enet = enet;
+    pb.alpha = alpha;
+    pb.p_total = p_total;
+    pb.col_offset = col_offset;
+    pb.batch_iters = env_int("ADMM_HIP_BATCH_ITERS", 0);
+    DeviceData<float> d;
+    upload_standardize<float>(d, x_cols, y, n, p_local, mem, standardize != 0, intercept != 0, h->st.s, 0);   // column moments are local, y is replicated
+    h->plan = make_wide_plan(std::move(d), pb, h->st.s);
+    h->p = (int)p_total;
+    h->nlam = nlambda_in > 0 ? nlambda_in : nlambda_auto;
+    h->t_create = now_s() - t0;
+    return h.release();
+}
+
 static void run_plan(PlanHandle* h, double* lambda_out, float* beta_out, int* niter_out, admm_stats* stats, double t_extra) {
     ADMM_REQUIRE(h != nullptr && h->plan, "plan is NULL");
     ADMM_REQUIRE(lambda_out && beta_out && niter_out, "output pointers must not be NULL");
@@ -277,6 +312,20 @@ int admm_hip_parlasso_dist(const double* x_local, const double* y_local, int n_l
         ADMM_REQUIRE(n_total >= n_local && n_local > 0, "n_total must be >= n_local > 0");
         std::unique_ptr<PlanHandle> h(create_plan(x_local, y_local, n_local, p, mem, lambda_in, nlambda_in, nlambda_auto, lmin_ratio,
                                                   standardize, intercept, false, 1.0, nthread, opts, n_total));
+        run_plan(h.get(), lambda_out, beta_out, niter_out, stats, h->t_create);
+    });
+}
+
+int admm_hip_lasso_dist_cols(const double* x_cols, const double* y, int n, int p_local, long long p_total, long long col_offset, int mem,
+                             const double* lambda_in, int nlambda_in, int nlambda_auto, double lmin_ratio,
+                             int standardize, int intercept, double alpha, const admm_opts* opts,
+                             double* lambda_out, float* beta_out, int* niter_out, admm_stats* stats) {
+    return guarded([&] {
+        ADMM_REQUIRE(lambda_out && beta_out && niter_out, "output pointers must not be NULL");
+        const bool enet = alpha >= 0.0;
+        if (enet) ADMM_REQUIRE(alpha <= 1.0, "alpha must be within [0, 1]");
+        std::unique_ptr<PlanHandle> h(create_plan_cols(x_cols, y, n, p_local, p_total, col_offset, mem, lambda_in, nlambda_in, nlambda_auto,
+                                                       lmin_ratio, standardize, intercept, enet, enet ? alpha : 1.0, opts));
         run_plan(h.get(), lambda_out, beta_out, niter_out, stats, h->t_create);
     });
 }

@@ -79,6 +79,20 @@ constexpr int kTailElems = kTailThreads / kTailLanes;
 
 // Scalar control of one iteration, run by a single workgroup: reduce the previous iteration's norm
 // partials, evaluate convergence / acceleration / restart / lambda schedule, publish ctl[par ^ 1].
+// IN_LAUNCH: the norm partials were written (write-through) by other workgroups of the SAME launch (single-launch
+// iteration below): they are read with agent-scope loads that bypass this XCD's L2.
+__device__ __forceinline__ double tall_load_partial(const double* p, bool in_launch) {
+    if (!in_launch) return *p;
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void tall_store_wt(float* p, float v) {       // write-through store (visible to other XCDs without a fence)
+    __hip_atomic_store(reinterpret_cast<unsigned int*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void tall_store_wt(double* p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <bool IN_LAUNCH = false>
 __device__ void tall_decide(const TallParams& q, int par) {
     __shared__ double dscratch[6 * (kTailThreads / 64)];
     const TallCtl in = q.ctl[par];
@@ -91,7 +105,7 @@ __device__ void tall_decide(const TallParams& q, int par) {
     const double* Pin = q.P + (size_t)par * q.nwg * 8;
     for (int w = threadIdx.x; w < q.nwg; w += kTailThreads) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) acc[k] += Pin[(size_t)w * 8 + k];
+        for (int k = 0; k < 6; ++k) acc[k] += tall_load_partial(Pin + (size_t)w * 8 + k, IN_LAUNCH);
     }
     block_sum<double, 6>(acc, dscratch);
     if (threadIdx.x != 0) return;
@@ -152,7 +166,7 @@ __device__ void tall_decide(const TallParams& q, int par) {
 struct TallDecideExtra {
     static constexpr bool kHas = true;
     TallParams q; int par;
-    __device__ void operator()() const { tall_decide(q, par); }
+    __device__ void operator()() const { tall_decide<false>(q, par); }
 };
 
 // (1 + ratio) * cur - ratio * old without contraction, like the reference build (FADMMBase.h:247-248): the
@@ -173,6 +187,7 @@ __device__ __forceinline__ TallElem tall_load_elem(const TallParams& q, int par,
     return e;
 }
 
+template <bool WT = false>      // WT: u, w are consumed by other workgroups of the same launch -> write-through stores
 __device__ __forceinline__ void tall_update_elem(const TallParams& q, const TallCtl& c, int par, int i, const TallElem& e, float a, float b, double (&acc)[6]) {
     float* zo_ = par ? q.z0 : q.z1; float* yo_ = par ? q.y0 : q.y1;
     const float zc = e.zc, yc = e.yc, zo = e.zo, yo = e.yo;
@@ -209,8 +224,10 @@ __device__ __forceinline__ void tall_update_elem(const TallParams& q, const Tall
     // both possible right-hand sides of the next x-update, rounded as ADMMLassoTall.h:70-80 does
     const float tn = (float)c.tau_next, tn1 = (float)(1.0 + c.tau_next);
     const float adjz_a = tall_extrapolate(tn1, tn, zn, zc), adjy_a = tall_extrapolate(tn1, tn, yn, yc);
-    q.u[i] = (float)((double)(e.xy - adjy_a) + c.rho * (double)adjz_a);
-    q.w[i] = (float)((double)(e.xy - yc) + c.rho * (double)zc);
+    const float un = (float)((double)(e.xy - adjy_a) + c.rho * (double)adjz_a);
+    const float wn = (float)((double)(e.xy - yc) + c.rho * (double)zc);
+    if (WT) { tall_store_wt(q.u + i, un); tall_store_wt(q.w + i, wn); }
+    else { q.u[i] = un; q.w[i] = wn; }
 }
 
 // Element-wise part of one iteration.  `c` = the control block published by this iteration's decision.
@@ -267,6 +284,96 @@ tall_tail_kernel(TallParams q, int par, PeerExchange ex) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) Pout[k] = acc[k];
     }
+}
+
+// ---------------------------------------------------------------------------------------------- single-launch iteration
+// ONE launch per ADMM iteration (p >= 2048, single GPU).  Launch g holds
+//   workgroups [0, nwg)      : the element-wise tail of iteration g-1 (it needs the mat-vec partials of launch g-1, which
+//                              crossed a kernel boundary), then -- by whichever of them finishes last -- the decision g;
+//   workgroups [nwg, nwg + T): the T lower-triangle tiles of the mat-vec of iteration g, which need the right-hand
+//                              sides u, w that the tail workgroups of THIS launch produce.
+// The tiles request their first matrix columns at once (those do not depend on u, w), then wait for a generation flag; the
+// tail workgroups publish u, w and their norm partials with write-through (agent-scope relaxed atomic) stores, wait for
+// the acknowledgements (workgroup-scope release = s_waitcnt, no cache write-back), and count themselves in; the last one
+// raises the flag (64 replicas, one cache line each, so that 1600 polling workgroups do not share a line) and evaluates
+// the decision from the partials (bypass loads).  The tiles then read u, w with bypass loads.  No fence writes back or
+// invalidates a cache, nothing spins on a line another agent hammers.  Against two launches per iteration this removes
+// one kernel boundary and hides the tail's latency under the start of the matrix stream.  The arithmetic, its order and
+// therefore every bit of the result are those of the two-launch path (tests/test_gpu_tall.py compares them).
+// The tail workgroups have the lowest block indices, so they are dispatched before any tile: a tile never waits for a
+// workgroup that cannot start.  Every wait is bounded all the same.
+struct TallFused {
+    SymvArgs sy;
+    int* flag;                   // [64][16] generation flags (one per 64-byte line)
+    unsigned int* arrive;        // tail workgroups that finished in this launch
+    int gen;                     // g + 1
+    int ntail;
+};
+
+struct TallFusedWait {
+    const int* flag; int gen;
+    __device__ __forceinline__ void operator()() const {
+        if (threadIdx.x == 0) {
+            const int* f = flag + (blockIdx.x & 63) * 16;
+            const long long t0 = wall_clock64();
+            while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gen) {
+                __builtin_amdgcn_s_sleep(1);
+                if (wall_clock64() - t0 > 200000000ll) break;           // 2 s: never hang (the result is then wrong and the solve fails its checks)
+            }
+        }
+        __syncthreads();
+    }
+};
+
+__global__ void __launch_bounds__(kTailThreads, 4)
+tall_fused_kernel(TallParams q, int par, TallFused f) {
+    __shared__ float4 red[2][kSyThreads];
+    __shared__ float sdot[2][kSyCB];
+    __shared__ double scratch[6 * (kTailThreads / 64)];
+    __shared__ int s_last;
+    if ((int)blockIdx.x >= f.ntail) {                       // ---- a tile of the mat-vec of iteration g
+        if (*f.sy.skip != 0) return;                        // finished in an earlier launch
+        symv2_tile(f.sy, f.sy.tiles[blockIdx.x - f.ntail], TallFusedWait{f.flag, f.gen}, SymvBypassVec(), red, sdot);
+        return;
+    }
+    // ---- tail of iteration g - 1: parity of that iteration's launch pair in the two-launch scheme
+    const int tp = par ^ 1;
+    const TallCtl c = q.ctl[tp ^ 1];                        // == ctl[par]: published by the decision of launch g - 1
+    if (c.done && c.fin_idx < 0) {                          // finished earlier: the tiles of this launch do not wait either
+        if (blockIdx.x == 0 && threadIdx.x == 0) q.ctl[par ^ 1] = c;     // keep `done` sticky in both slots
+        return;
+    }
+    const int sub = threadIdx.x & (kTailLanes - 1);
+    const int i = blockIdx.x * kTailElems + threadIdx.x / kTailLanes;
+    const bool valid = i < q.p;
+    const bool owner = valid && sub == 0;
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    if (!c.first) {                                         // launch 0 has no previous iteration: u, w come from the init kernel
+        TallElem e = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (owner) e = tall_load_elem(q, tp, i);
+        float a, b;
+        symv_sum_partials<kTailLanes>(q.dot0, q.dot1, q.axp0, q.axp1, q.ldo, q.nrb, q.ncb, i, sub, valid, a, b);
+        if (owner) tall_update_elem<true>(q, c, tp, i, e, a, b, acc);
+    }
+    if (!c.done) {
+        block_sum<double, 6>(acc, scratch);
+        if (threadIdx.x == 0) {
+            double* Pout = q.P + ((size_t)(tp ^ 1) * q.nwg + blockIdx.x) * 8;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) tall_store_wt(Pout + k, acc[k]);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's write-through stores are acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int prev = __hip_atomic_fetch_add(f.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = prev == (unsigned int)f.ntail - 1;
+        if (s_last) __hip_atomic_store(f.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x < 64) __hip_atomic_store(f.flag + threadIdx.x * 16, f.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // u, w are complete
+    tall_decide<true>(q, par);                              // decision g from the partials of iteration g - 1 -> ctl[par ^ 1]
 }
 
 // Row-sharded mode: this rank's share of the two products (the partial arrays of its tiles) summed into ab[2][ld], the
@@ -332,6 +439,9 @@ struct TallPlan final : LassoPlan {
     bool peer_fused = false;                            // ... with the exchange done by the solver's own kernels (PEER backend)
     CommInfo ci;
     DevBuf<float> ab;                                   // [2][ldp] this rank's share of (a, b), all-reduced in place
+    bool fused = false;                                 // one launch per iteration (tall_fused_kernel)
+    DevBuf<int> fflag;                                  // [64][16] generation flags of the single-launch iteration
+    DevBuf<unsigned int> farrive;
     long long ldv = 0;
     DevBuf<float> XY, M, a_part, b_part, x, z0, z1, y0, y1, adj_z, adj_y, u, w, beta;
     DevBuf<int> niter;
@@ -443,6 +553,14 @@ struct TallPlan final : LassoPlan {
         // ADMM_HIP_PEER_FUSED=0: go through the generic all-reduce of the exchange layer also on the PEER backend
         peer_fused = shard && ci.backend == COMM_PEER;
         if (const char* e = std::getenv("ADMM_HIP_PEER_FUSED")) { if (std::string(e) == "0") peer_fused = false; }
+        // single-launch iteration (single GPU, symmetric x-update): opt-in with ADMM_HIP_TALL_FUSED=1.  Measured on C2
+        // (scripts/fused_check.py): bit-identical, 46.7 us against 46.4 us per iteration for two launches on the same box
+        // (17.0 vs 17.5 us at p = 2300) -- the kernel boundary it removes (1.8 us) and the tail latency it hides are paid
+        // back by the in-launch dependency chain (write-through acknowledgements, arrival counter, flag, poll, bypass
+        // loads of u, w: ~2 us per hop through the memory side), so the two-launch path stays the default.
+        fused = false;
+        if (const char* e = std::getenv("ADMM_HIP_TALL_FUSED")) fused = use_sym && !shard && std::string(e) == "1";
+        if (fused) { fflag.alloc(64 * 16); farrive.alloc(1); }
         x.alloc(ldv); z0.alloc(ldv); z1.alloc(ldv); y0.alloc(ldv); y1.alloc(ldv);
         adj_z.alloc(ldv); adj_y.alloc(ldv); u.alloc(ldv); w.alloc(ldv);
         beta.alloc((size_t)nlam * p); niter.alloc(nlam);
@@ -493,11 +611,12 @@ struct TallPlan final : LassoPlan {
             debug_dump("XY", XY.get(), ldp);
         }
         admm_stats S = setup_stats;
-        S.xupdate_variant = shard ? 2 : (use_sym ? 1 : 0);
+        S.xupdate_variant = shard ? 2 : (fused ? 3 : (use_sym ? 1 : 0));
         res.lambda = lam_user;
         beta.zero(st); niter.zero(st);
         const int init_n = std::max(p, 2 * nwg * 8);
         hipLaunchKernelGGL(tall_init_kernel, dim3((init_n + 255) / 256), dim3(256), 0, st, q, rho, lam_int[0]);
+        if (fused) { fflag.zero(st); farrive.zero(st); }
         hctl[0].done = hctl[1].done = 0;
 
         const int batch = pb.batch_iters > 0 ? (pb.batch_iters + 1) / 2 * 2 : 32;    // even
@@ -526,7 +645,12 @@ struct TallPlan final : LassoPlan {
                 // sampled launches carry start/stop events that time exactly the x-update kernel on this stream
                 // the decision of this iteration rides along as one extra workgroup of the x-update launch
                 const TallDecideExtra dec{q, par};
-                if (shard && peer_fused) {
+                if (fused) {
+                    TallFused f;
+                    f.sy = sy.args(M.get(), ldp, u.get(), w.get(), &ctl.get()[par].done);
+                    f.flag = fflag.get(); f.arrive = farrive.get(); f.gen = (int)(g + 1); f.ntail = nwg;
+                    hipExtLaunchKernelGGL(tall_fused_kernel, dim3(nwg + sy.ntiles), dim3(kTailThreads), 0, st, e0, e1, 0, q, par, f);
+                } else if (shard && peer_fused) {
                     // this rank's tiles -> its share of (a, b) written into every rank's exchange slot by the reduction
                     // launch itself -> the (replicated) tail waits for the K flags and sums the K slots: three launches,
                     // none of them the exchange layer's

@@ -29,6 +29,7 @@
 #include "gemv_kernels.h"
 #include "solvers.h"
 #include "loop_driver.h"
+#include "comm.h"
 
 namespace admm {
 
@@ -57,6 +58,7 @@ struct WideParams {
     float* Ax; float* z; float* y;        // n
     float* axpart;                        // [kAxWG][ldn]
     float* tbuf;                          // [ldn] t (or t / gamma) of the current iteration in global memory (large-n mode only)
+    const float* ax_given;                // column-sharded mode: Ax already summed over this rank's partials AND over the ranks (else NULL)
     long long ldn;
     WideCtl* ctl;                         // [2]
     double* P;                            // [nwg_tail][8]: |r|^2, |z_new - z|^2, |Ax|^2, |z_new|^2, |y_new|^2
@@ -424,20 +426,13 @@ constexpr int kWtLanes = 8;
 constexpr int kWtElems = kWideThreads / kWtLanes;
 static_assert(kAxWG == 16 * kWtLanes && kActWG == 2 * kAxWG, "tail reduction assumes 16 (+16 when fused) partials per lane");
 
-__global__ void __launch_bounds__(kWideThreads)
-wide_tail_kernel(WideParams q, int par) {
-    __shared__ double scratch[5 * (kWideThreads / 64)];
-    const WideCtl c = q.ctl[par ^ 1];
-    const int sub = threadIdx.x & (kWtLanes - 1);
-    const int i = blockIdx.x * kWtElems + threadIdx.x / kWtLanes;
-    const bool valid = i < q.n;
+// Ax_i = sum of the x-update's per-workgroup partials (8 lanes share one element and issue their 16 partial loads at once).
+__device__ __forceinline__ float wide_sum_axpart(const WideParams& q, const WideCtl& c, int i, int sub, bool valid) {
     float v[16], v2[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) v[k] = valid ? q.axpart[(size_t)(k * kWtLanes + sub) * q.ldn + i] : 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) v2[k] = (valid && q.fused) ? q.axpart[(size_t)(kAxWG + k * kWtLanes + sub) * q.ldn + i] : 0.f;   // rows 128..255
-    float zo = 0.f, yo = 0.f, yd = 0.f;
-    if (valid) { zo = q.z[i]; yo = q.y[i]; yd = q.Y[i]; }
     float ax = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) ax += v[k];
@@ -457,6 +452,31 @@ wide_tail_kernel(WideParams q, int par) {
 #pragma unroll
     for (int m = 1; m < kWtLanes; m <<= 1) ax += __shfl_xor(ax, m, 64);
     if (q.fused && c.type == W_ZERO) ax = 0.f;                         // x = 0: nobody wrote partials
+    return ax;
+}
+
+// Column-sharded mode: this rank's share of Ax (its column block's partials summed) into `out`, which the ranks then
+// all-reduce; the tail reads the global Ax from there (WideParams::ax_given).
+__global__ void __launch_bounds__(kWideThreads)
+wide_ax_local_kernel(WideParams q, int par, float* out) {
+    const WideCtl c = q.ctl[par ^ 1];
+    const int sub = threadIdx.x & (kWtLanes - 1);
+    const int i = blockIdx.x * kWtElems + threadIdx.x / kWtLanes;
+    float ax = wide_sum_axpart(q, c, i, sub, i < q.n);
+    if (!q.fused && c.type == W_ZERO) ax = 0.f;
+    if (i < q.ldn && sub == 0) out[i] = i < q.n ? ax : 0.f;
+}
+
+__global__ void __launch_bounds__(kWideThreads)
+wide_tail_kernel(WideParams q, int par) {
+    __shared__ double scratch[5 * (kWideThreads / 64)];
+    const WideCtl c = q.ctl[par ^ 1];
+    const int sub = threadIdx.x & (kWtLanes - 1);
+    const int i = blockIdx.x * kWtElems + threadIdx.x / kWtLanes;
+    const bool valid = i < q.n;
+    float zo = 0.f, yo = 0.f, yd = 0.f;
+    if (valid) { zo = q.z[i]; yo = q.y[i]; yd = q.Y[i]; }
+    const float ax = q.ax_given != nullptr ? (valid ? q.ax_given[i] : 0.f) : wide_sum_axpart(q, c, i, sub, valid);
     if (c.done) return;
     double acc[5] = {0, 0, 0, 0, 0};
     if (valid && sub == 0) {
@@ -499,6 +519,10 @@ struct WidePlan final : LassoPlan {
     admm_stats setup_stats{};
     int n = 0, p = 0, nlam = 0, nwg_tail = 0, nwg_x = 0, fuse_rt = 0;
     bool t_global = false;               // n too large for the LDS: t through global memory (wide_t_kernel)
+    bool cshard = false;                 // columns spread over the ranks: per iteration one all-reduce of Ax (n floats)
+    CommInfo ci;
+    long long p_total = 0, col_offset = 0;
+    DevBuf<float> axl;                   // [ldn] this rank's share of Ax, all-reduced in place
     size_t lds_x = 0;
     long long ldn = 0;
     float sprad = 0.f, lambda0 = 0.f;
@@ -513,6 +537,15 @@ struct WidePlan final : LassoPlan {
 
     WidePlan(DeviceData<float>&& data, const LassoProblem& prob, hipStream_t stream) : d(std::move(data)), pb(prob), st(stream) {
         n = d.n; p = d.p;
+        // Column-sharded mode (the north_star's "column-block ... all-reduce of X_i beta_i"; not in the compiled reference,
+        // whose only column-block code is the dead TODO/PADMMBP.h:137-156): the SAME linearised ADMM as ADMMLassoWide, with
+        // rank i holding the columns X_i and x_i.  Everything of length p is local (X_i't, the prox, the active set, the
+        // column moments of DataStd); everything of length n is replicated (z, y, t, the decisions); the only exchange
+        // per iteration is the sum over ranks of A x = sum_i X_i x_i (n floats).  Setup: lambda_0 = max over ranks,
+        // X X' = sum_i X_i X_i' (one all-reduce), the Lanczos value replicated.
+        cshard = pb.p_total > 0;
+        ci = cshard ? comm_info() : CommInfo();
+        p_total = cshard ? pb.p_total : p; col_offset = cshard ? pb.col_offset : 0;
         admm_stats& S = setup_stats;
         S.branch = 1; S.t_h2d = d.t_h2d; S.t_standardize = d.t_std;
         const long long ldp = round_up(p, 32);
@@ -523,6 +556,17 @@ struct WidePlan final : LassoPlan {
             DevBuf<float> XY(ldp); XY.zero(st);
             gemv_t_simple<float>(d.X.get(), d.ldx, n, p, d.Y.get(), XY.get(), st);
             lambda0 = device_absmax<float>(XY.get(), p, st);
+            if (cshard) {                                            // max over ranks through the sum all-reduce of a one-hot vector
+                std::vector<float> h(ci.nranks, 0.f);
+                h[ci.rank] = lambda0;
+                DevBuf<float> dm(round_up(ci.nranks, 4)); dm.zero(st);
+                ADMM_HIP_CHECK(hipMemcpyAsync(dm.get(), h.data(), ci.nranks * sizeof(float), hipMemcpyHostToDevice, st));
+                allreduce_sum_f32(dm.get(), (size_t)ci.nranks, st);
+                ADMM_HIP_CHECK(hipMemcpyAsync(h.data(), dm.get(), ci.nranks * sizeof(float), hipMemcpyDeviceToHost, st));
+                ADMM_HIP_CHECK(hipStreamSynchronize(st));
+                comm_check();
+                for (float v : h) lambda0 = std::max(lambda0, v);
+            }
         }
         // spectral radius estimate from XX' (ADMMLassoWide.h:200-207)
         double t0 = now_s();
@@ -530,7 +574,9 @@ struct WidePlan final : LassoPlan {
             const long long ldg = round_up(n, 32);
             DevBuf<float> G((size_t)ldg * n); G.zero(st);
             gram_full<float>(d.X.get(), d.ldx, n, p, false, G.get(), ldg, st);
+            if (cshard) allreduce_sum_f32(G.get(), (size_t)ldg * n, st);       // X X' = sum over the ranks' column blocks
             ADMM_HIP_CHECK(hipStreamSynchronize(st));
+            comm_check();
             S.t_gram = now_s() - t0; t0 = now_s();
             SymMatVec<float> op(G.get(), ldg, n, st);
             int nmatop = 0;
@@ -591,7 +637,9 @@ struct WidePlan final : LassoPlan {
         q.ldx = d.ldx; q.X = d.X.get(); q.Y = d.Y.get();
         q.gamma = sprad; q.lambda0 = lambda0; q.alpha = (float)pb.alpha;
         q.eps_abs = pb.opts.eps_abs; q.eps_rel = pb.opts.eps_rel;
-        q.sqrt_n = std::sqrt((double)n); q.sqrt_p = std::sqrt((double)p); q.sqrt_gamma = (double)std::sqrt(sprad);
+        q.sqrt_n = std::sqrt((double)n); q.sqrt_p = std::sqrt((double)p_total); q.sqrt_gamma = (double)std::sqrt(sprad);
+        if (cshard) { axl.alloc(ldn); axl.zero(st); }
+        q.ax_given = cshard ? axl.get() : nullptr;
         q.lambdas = dlam.get(); q.x = x.get(); q.Ax = Ax.get(); q.z = z.get(); q.y = y.get();
         q.axpart = axpart.get(); q.tbuf = tbuf.get(); q.ldn = ldn; q.fused = fuse_rt ? 1 : 0; q.nwg_x = nwg_x;
         q.ctl = ctl.get(); q.P = P.get(); q.beta = beta.get(); q.niter = niter.get(); q.done = done.get();
@@ -620,6 +668,10 @@ struct WidePlan final : LassoPlan {
                     }
                     hipLaunchKernelGGL(wide_ax_kernel, dim3(kAxWG), dim3(kWideThreads), 0, st, q);
             }
+            if (cshard) {                                              // the only exchange: A x summed over the ranks' column blocks
+                hipLaunchKernelGGL(wide_ax_local_kernel, dim3((unsigned)((ldn + kWtElems - 1) / kWtElems)), dim3(kWideThreads), 0, st, q, par, axl.get());
+                allreduce_sum_f32(axl.get(), (size_t)n, st);
+            }
             hipLaunchKernelGGL(wide_tail_kernel, dim3(nwg_tail), dim3(kWideThreads), 0, st, q, par);
         });
         S.t_loop = lt.wall_s; S.loop_ms_events = lt.events_ms; S.xupdate_launches = lt.launched;
@@ -628,13 +680,32 @@ struct WidePlan final : LassoPlan {
         ADMM_HIP_CHECK(hipMemcpy(res.niter.data(), niter.get(), nlam * sizeof(int), hipMemcpyDeviceToHost));
         std::vector<float> hb((size_t)nlam * p);
         ADMM_HIP_CHECK(hipMemcpy(hb.data(), beta.get(), hb.size() * sizeof(float), hipMemcpyDeviceToHost));
-        res.beta.assign((size_t)(p + 1) * nlam, 0.f);
+        const size_t pt1 = (size_t)p_total + 1;
+        res.beta.assign(pt1 * nlam, 0.f);
+        std::vector<double> icpt(nlam, 0.0);                          // sum_j beta_j meanX_j over this rank's columns
         long long tot = 0;
         for (int l = 0; l < nlam; ++l) {
             float b0 = 0.f;
-            recover_coef<float>(d, hb.data() + (size_t)l * p, &b0, res.beta.data() + (size_t)l * (p + 1) + 1);
-            res.beta[(size_t)l * (p + 1)] = b0;
+            recover_coef<float>(d, hb.data() + (size_t)l * p, &b0, res.beta.data() + (size_t)l * pt1 + 1 + col_offset);
+            res.beta[(size_t)l * pt1] = b0;
+            icpt[l] = (double)d.meanY - (double)b0;
             tot += res.niter[l];
+        }
+        if (cshard) {
+            // every rank returns the full coefficient matrix: blocks summed into a zero-padded copy, the intercept
+            // beta_0 = meanY - sum over ALL columns (DataStd::recover) from the ranks' partial sums
+            const bool has_icpt = (d.flag & 2) != 0;
+            DevBuf<float> db(res.beta.size()); DevBuf<double> di(nlam);
+            for (int l = 0; l < nlam; ++l) res.beta[(size_t)l * pt1] = 0.f;
+            ADMM_HIP_CHECK(hipMemcpyAsync(db.get(), res.beta.data(), res.beta.size() * sizeof(float), hipMemcpyHostToDevice, st));
+            ADMM_HIP_CHECK(hipMemcpyAsync(di.get(), icpt.data(), nlam * sizeof(double), hipMemcpyHostToDevice, st));
+            allreduce_sum_f32(db.get(), res.beta.size(), st);
+            allreduce_sum_f64(di.get(), (size_t)nlam, st);
+            ADMM_HIP_CHECK(hipMemcpyAsync(res.beta.data(), db.get(), res.beta.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+            ADMM_HIP_CHECK(hipMemcpyAsync(icpt.data(), di.get(), nlam * sizeof(double), hipMemcpyDeviceToHost, st));
+            ADMM_HIP_CHECK(hipStreamSynchronize(st));
+            comm_check();
+            for (int l = 0; l < nlam; ++l) res.beta[(size_t)l * pt1] = has_icpt ? (float)((double)d.meanY - icpt[l]) : 0.f;
         }
         S.total_iter = tot;
         res.stats = S;

@@ -13,7 +13,9 @@ struct LassoProblem {
     bool enet = false;
     double alpha = 1.0;
     int nworkers = 0;                // > 0: row-block consensus (admm_parlasso)
-    bool dist = false;               // consensus blocks spread over the ranks of the attached communicator
+    bool dist = false;               // consensus blocks / rows of the tall solver spread over the ranks of the attached communicator
+    long long p_total = 0;           // > 0: COLUMN-sharded wide solver -- this rank holds columns [col_offset, col_offset + p) of p_total
+    long long col_offset = 0;
     int batch_iters = 0;             // iterations enqueued per host poll (0 = default)
     int profile_stride = 0;          // > 0: time every stride-th x-update launch with HIP events
 };

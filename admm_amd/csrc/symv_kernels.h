@@ -74,42 +74,65 @@ __device__ __forceinline__ float butterfly8(const float (&v)[8], int lane) {
     return r;
 }
 
-// `Extra`: a functor run by ONE additional workgroup (block 0) concurrently with the tiles; the tall
-// solver uses it for its scalar iteration control, which then costs no launch and no latency.
-struct SymvNoExtra { __device__ void operator()() const {} };
+// How a tile reads the right-hand vectors.  Plain: ordinary loads (the vectors were written by an earlier launch).
+// Bypass: agent-scope relaxed atomic loads that skip this XCD's L2 -- for vectors written with write-through stores by
+// OTHER workgroups of the SAME launch (the single-launch tall iteration, lasso_tall.hip).
+struct SymvPlainVec {
+    __device__ __forceinline__ float4 load4(const float* p) const { return *reinterpret_cast<const float4*>(p); }
+    __device__ __forceinline__ float load1(const float* p) const { return *p; }
+};
+struct SymvBypassVec {
+    __device__ __forceinline__ float4 load4(const float* p) const {
+        const unsigned long long lo = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long hi = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return make_float4(__uint_as_float((unsigned)lo), __uint_as_float((unsigned)(lo >> 32)), __uint_as_float((unsigned)hi), __uint_as_float((unsigned)(hi >> 32)));
+    }
+    __device__ __forceinline__ float load1(const float* p) const {
+        return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned int*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+};
+struct SymvNoWait { __device__ __forceinline__ void operator()() const {} };
 
-template <typename Extra>
-__global__ void __launch_bounds__(kSyThreads, 4)      // 4 waves/SIMD: 2 or 4 measure the same, 8 spills; non-temporal loads are 8 % slower (the 2p^2 bytes stay in the Infinity Cache)
-symv2_lower_kernel(SymvArgs a, Extra extra) {
-    if (blockIdx.x == 0) { extra(); return; }
-    if (a.skip != nullptr && *a.skip != 0) return;
-    __shared__ float4 red[2][kSyThreads];
-    __shared__ float sdot[2][kSyCB];
-    const int2 t = a.tiles[blockIdx.x - 1];
+// One tile (256 rows x 128 columns, 4 waves) of the symmetric product.  The first 8 matrix columns of every wave are
+// requested BEFORE `wait()` -- they do not depend on the right-hand vectors -- so that a caller whose vectors are still
+// being produced (wait() = poll a flag + barrier) already has its share of the stream in flight.  wait() is called by
+// every thread of the workgroup exactly once.
+template <typename Wait, typename VecLoad>
+__device__ __forceinline__ void symv2_tile(const SymvArgs& a, const int2 t, Wait wait, VecLoad vl,
+                                           float4 (*red)[kSyThreads], float (*sdot)[kSyCB]) {
     const int rb = t.x, cb = t.y;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int row = rb * kSyRB + lane * 4;
     const int col0 = cb * kSyCB + wid * kSyCW;
     const int p4 = (a.p + 3) & ~3;
     const bool active = row < p4;
+    const bool has = col0 < a.p;           // every wave of a listed tile has all its columns <= the block's last row
+    const float* base = a.A + (size_t)col0 * a.lda + row;
+    float4 av[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        av[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (has && active && col0 + k < a.p) av[k] = *reinterpret_cast<const float4*>(base + (size_t)k * a.lda);
+    }
+    wait();
     float4 aU = make_float4(0.f, 0.f, 0.f, 0.f), aW = aU;
 
-    if (col0 < a.p) {       // every wave of a listed tile has all its columns <= the block's last row
-        const float4 uI = active ? *reinterpret_cast<const float4*>(a.v0 + row) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 wI = active ? *reinterpret_cast<const float4*>(a.v1 + row) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (has) {
+        const float4 uI = active ? vl.load4(a.v0 + row) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 wI = active ? vl.load4(a.v1 + row) : make_float4(0.f, 0.f, 0.f, 0.f);
         const int cj = col0 + (lane & 31);
-        const float uj = cj < a.p ? a.v0[cj] : 0.f;
-        const float wj = cj < a.p ? a.v1[cj] : 0.f;
+        const float uj = cj < a.p ? vl.load1(a.v0 + cj) : 0.f;
+        const float wj = cj < a.p ? vl.load1(a.v1 + cj) : 0.f;
         const bool diag = col0 + (kSyCW - 1) >= rb * kSyRB;      // this wave's block meets the diagonal
-        const float* base = a.A + (size_t)col0 * a.lda + row;
 #pragma unroll 1
         for (int q = 0; q < kSyCW / 8; ++q) {
-            float4 av[8];
+            if (q > 0) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int col = col0 + q * 8 + k;
-                av[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (active && col < a.p) av[k] = *reinterpret_cast<const float4*>(base + (size_t)(q * 8 + k) * a.lda);
+                for (int k = 0; k < 8; ++k) {
+                    const int col = col0 + q * 8 + k;
+                    av[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (active && col < a.p) av[k] = *reinterpret_cast<const float4*>(base + (size_t)(q * 8 + k) * a.lda);
+                }
             }
             float dU[8], dW[8];
 #pragma unroll
@@ -166,6 +189,20 @@ symv2_lower_kernel(SymvArgs a, Extra extra) {
     }
 }
 
+// `Extra`: a functor run by ONE additional workgroup (block 0) concurrently with the tiles; the tall
+// solver uses it for its scalar iteration control, which then costs no launch and no latency.
+struct SymvNoExtra { __device__ void operator()() const {} };
+
+template <typename Extra>
+__global__ void __launch_bounds__(kSyThreads, 4)      // 4 waves/SIMD: 2 or 4 measure the same, 8 spills; non-temporal loads are 8 % slower (the 2p^2 bytes stay in the Infinity Cache)
+symv2_lower_kernel(SymvArgs a, Extra extra) {
+    if (blockIdx.x == 0) { extra(); return; }
+    if (a.skip != nullptr && *a.skip != 0) return;
+    __shared__ float4 red[2][kSyThreads];
+    __shared__ float sdot[2][kSyCB];
+    symv2_tile(a, a.tiles[blockIdx.x - 1], SymvNoWait(), SymvPlainVec(), red, sdot);
+}
+
 // Number of row / column blocks and the tile list (host).
 struct SymvPlan {
     int p = 0, nrb = 0, ncb = 0, ntiles = 0;
@@ -198,13 +235,17 @@ struct SymvPlan {
         dot0.zero(st); dot1.zero(st); axp0.zero(st); axp1.zero(st);
         ADMM_HIP_CHECK(hipStreamSynchronize(st));
     }
-    template <typename Extra = SymvNoExtra>
-    void launch(const float* A, long long lda, const float* v0, const float* v1, const int* skip, hipStream_t st, Extra extra = Extra(),
-                hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
+    SymvArgs args(const float* A, long long lda, const float* v0, const float* v1, const int* skip) const {
         SymvArgs a;
         a.A = A; a.lda = lda; a.p = p; a.v0 = v0; a.v1 = v1;
         a.dot0 = dot0.get(); a.dot1 = dot1.get(); a.axp0 = axp0.get(); a.axp1 = axp1.get();
         a.ldo = ldo; a.tiles = tiles.get(); a.skip = skip;
+        return a;
+    }
+    template <typename Extra = SymvNoExtra>
+    void launch(const float* A, long long lda, const float* v0, const float* v1, const int* skip, hipStream_t st, Extra extra = Extra(),
+                hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
+        const SymvArgs a = args(A, lda, v0, v1, skip);
         // start/stop events (when given) time exactly this kernel on its stream (hipExtLaunchKernel)
         hipExtLaunchKernelGGL((symv2_lower_kernel<Extra>), dim3(ntiles + 1), dim3(kSyThreads), 0, st, ev_start, ev_stop, 0, a, extra);
     }

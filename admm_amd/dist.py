@@ -175,6 +175,35 @@ def lasso_dist(x_local, y_local, n_total, p, lam=None, nlambda=100, lambda_min_r
     return ADMM_Lasso_fit(lam_out, beta, niter, stats.as_dict())
 
 
+def col_partition(p_total, nranks, rank):
+    """Columns [lo, hi) of rank `rank` when p_total columns are dealt out in contiguous, nearly equal blocks."""
+    return p_total * rank // nranks, p_total * (rank + 1) // nranks
+
+
+def lasso_dist_cols(x_cols, y, p_total, col_offset, lam=None, nlambda=100, lambda_min_ratio=0.01, standardize=True, intercept=True,
+                    alpha=None, **opts):
+    """Column-sharded serial wide Lasso / elastic net: every rank calls this with its column block (n x p_local) and the full y."""
+    lib = _lib.load()
+    xp, xmem, xk = as_input(x_cols)
+    yp, ymem, yk = as_input(y)
+    n, p_local = np.asarray(x_cols).shape
+    lam_in = np.ascontiguousarray(np.sort(np.atleast_1d(np.asarray(lam, dtype=np.float64)))[::-1]) if lam is not None else np.zeros(0)
+    o = AdmmOpts(int(opts.get("maxit", 10000)), float(opts.get("eps_abs", 1e-5)), float(opts.get("eps_rel", 1e-5)),
+                 float(opts.get("rho", -1.0) if opts.get("rho") is not None else -1.0))
+    nl = lam_in.size if lam_in.size else int(nlambda)
+    lam_out = np.zeros(nl)
+    beta = np.zeros((p_total + 1, nl), dtype=np.float32, order="F")
+    niter = np.zeros(nl, dtype=np.int32)
+    stats = AdmmStats()
+    check(lib.admm_hip_lasso_dist_cols(xp, yp, int(n), int(p_local), int(p_total), int(col_offset), xmem,
+                                       ctypes.c_void_p(lam_in.ctypes.data if lam_in.size else 0), int(lam_in.size), int(nlambda),
+                                       float(lambda_min_ratio), int(bool(standardize)), int(bool(intercept)),
+                                       float(-1.0 if alpha is None else alpha), ctypes.byref(o),
+                                       lam_out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), beta.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                                       niter.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), ctypes.byref(stats)))
+    return ADMM_Lasso_fit(lam_out, beta, niter, stats.as_dict())
+
+
 class DistLassoPlan:
     """Prepared distributed problem (setup once, run the lambda path repeatedly): the consensus solver for nthread >= 1,
     the row-sharded serial tall solver for nthread == 0."""

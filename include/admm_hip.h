@@ -84,7 +84,8 @@ typedef struct admm_stats {
     double eig_est;        /* the loose Lanczos value (lambda_max or spectral-radius estimate) */
     int branch;            /* 0 tall (Cholesky), 1 wide (linearised), 2 consensus */
     int xupdate_variant;   /* tall path: 0 = full-matrix mat-vec (4p^2 B), 1 = lower-triangle symmetric mat-vec (2p^2 B),
-                              2 = the same with the tiles dealt out to the ranks + one all-reduce of 2p floats (admm_hip_lasso_dist) */
+                              2 = the same with the tiles dealt out to the ranks + one all-reduce of 2p floats (admm_hip_lasso_dist),
+                              3 = 1 with the element-wise tail of the previous iteration inside the same launch (one launch per iteration) */
 } admm_stats;
 
 /* lambda_in: user grid of length nlambda_in (sorted decreasing by the R wrapper), or NULL/0
@@ -208,6 +209,21 @@ ADMM_HIP_API int admm_hip_lasso_dist(const double* x_local, const double* y_loca
                         const double* lambda_in, int nlambda_in, int nlambda_auto, double lmin_ratio,
                         int standardize, int intercept, double alpha, const admm_opts* opts,
                         double* lambda_out, float* beta_out, int* niter_out, admm_stats* stats);
+
+/* The serial WIDE solver (admm_lasso / admm_enet with n <= p_total: ADMMLassoWide / ADMMEnetWide, linearised ADMM with
+ * active-set iterations) with its COLUMNS spread over the ranks -- the "column-block consensus ... all-reduce of X_i beta_i"
+ * of the problem statement.  The compiled reference has no such solver (its only column-block code is the dead
+ * src/TODO/PADMMBP.h:137-156); this is the SAME algorithm as ADMMLassoWide.h:86-186 executed in blocks: rank i holds the
+ * columns X_i (x_cols: n x p_local column-major, the global columns [col_offset, col_offset + p_local)) and x_i, and the
+ * full y.  Everything of length p is local (X_i't, the prox, the active set, DataStd's column moments); everything of
+ * length n (z, the dual, t = Ax + z + y/rho, every decision) is replicated; per ADMM iteration the ranks exchange ONE
+ * all-reduce of A x = sum_i X_i x_i (n floats).  Setup: lambda_0 is the max over ranks, X X' = sum_i X_i X_i' one
+ * all-reduce, the Lanczos value replicated.  The iterates equal the single-GPU ones up to the summation order of A x.
+ * Every rank returns the full (p_total + 1) x nl coefficient matrix.  alpha < 0: Lasso, else elastic net. */
+ADMM_HIP_API int admm_hip_lasso_dist_cols(const double* x_cols, const double* y, int n, int p_local, long long p_total, long long col_offset, int mem,
+                             const double* lambda_in, int nlambda_in, int nlambda_auto, double lmin_ratio,
+                             int standardize, int intercept, double alpha, const admm_opts* opts,
+                             double* lambda_out, float* beta_out, int* niter_out, admm_stats* stats);
 
 ADMM_HIP_API const char* admm_hip_last_error(void);
 ADMM_HIP_API const char* admm_hip_version(void);

@@ -45,6 +45,12 @@ def problem(case):
     if case == "tallshard2300":       # ~90 lower-triangle tiles dealt out to the ranks
         x, y = synth_lasso(4700, 2300, 40, seed=2300)
         return x, y, 0, dict(nlambda=6)
+    if case == "widecols":            # the serial wide solver with its columns spread over the ranks (fused x-update, n <= 4096)
+        x, y = synth_lasso(300, 2000, 20, seed=29)
+        return x, y, -1, dict(nlambda=10)
+    if case == "widecols_enet":
+        x, y = synth_lasso(250, 900, 12, seed=31)
+        return x, y, -1, dict(nlambda=8, alpha=0.5)
     raise SystemExit("unknown case " + case)
 
 
@@ -76,7 +82,12 @@ def main():
     # ---- the distributed consensus solver on this rank's row slice
     x, y, K, kw = problem(case)
     n, p = x.shape
-    if K > 0:
+    if K < 0:
+        lo, hi = adist.col_partition(p, nranks, rank)
+        fit = adist.lasso_dist_cols(np.asfortranarray(x[:, lo:hi]), y, p, lo, lambda_min_ratio=0.01, **kw)
+        assert fit.stats["branch"] == 1
+        trace = np.zeros((0, 10))
+    elif K > 0:
         lo, hi = adist.row_partition(n, K, nranks, rank)
         fit = adist.parlasso_dist(np.asfortranarray(x[lo:hi]), y[lo:hi], n, p, K, n_local=hi - lo, **kw)
         trace = np.zeros((0, 10))
