@@ -72,6 +72,33 @@ class ADMM_Lasso_fit:
         return (f"ADMM Lasso fitting result\n\n$lambda\n{self.lambda_}\n\n$beta\n<{self.beta.shape[0]} x "
                 f"{self.beta.shape[1]}> sparse matrix\n\n$niter\n{self.niter}")
 
+    def show(self):
+        """ADMM_Lasso_fit$show (R/30_admm_lasso.R:181-186)."""
+        print(repr(self))
+
+    def path_data(self):
+        """What ADMM_Lasso_fit$plot draws (R/30_admm_lasso.R:189-214): log(lambda) and, per variable that is non-zero for
+        at least one lambda (intercept excluded), its coefficient along the path.  Returns (loglambda [nl], coef [nl, nvar])."""
+        if self.lambda_.size < 2:
+            _stop("need to have at least two lambda values")
+        inc = np.any(self.beta_dense != 0, axis=1)
+        inc[0] = False
+        return np.log(self.lambda_), self.beta_dense[inc].T.astype(np.float64)
+
+    def plot(self, ax=None):
+        """Solution-path plot (the reference uses ggplot2; here matplotlib, same axes and title)."""
+        loglambda, coef = self.path_data()
+        import matplotlib
+        if ax is None:
+            matplotlib.use("Agg", force=False)
+            import matplotlib.pyplot as plt
+            _, ax = plt.subplots()
+        ax.plot(loglambda, coef)
+        ax.set_xlabel("log(lambda)")
+        ax.set_ylabel("Coefficients")
+        ax.set_title("Solution path")
+        return ax
+
 
 class ADMM_Lasso:
     _name = "ADMM Lasso model"
@@ -196,6 +223,12 @@ class ADMM_BP_fit:
         self.niter = niter
         self.stats = stats
 
+    def __repr__(self):                                                      # ADMM_BP_fit$show (R/10_admm_bp.R:125-133)
+        return f"ADMM Basis Pursuit fitting result\n\n$beta\n<{self.beta.shape[0]} x 1> sparse matrix\n\n$niter\n{self.niter}"
+
+    def show(self):
+        print(repr(self))
+
 
 class ADMM_BP:
     def __init__(self, x, y, n=None, p=None):
@@ -212,6 +245,16 @@ class ADMM_BP:
         self.eps_rel = 1e-4
         self.rho = 1.0
 
+    def parallel(self, nthread=2):
+        """ADMM_BP$parallel (R/10_admm_bp.R:65-76) only stores nthread; $fit() with nthread > 1 then calls the C symbol
+        `admm_parbp`, which the reference never builds (it lives in src/TODO/ParBP.cppp) -- the R call fails.  Mirrored:
+        the setter validates like R does, fit() refuses like R's missing symbol."""
+        nt = max(1, int(nthread))
+        if nt >= self.p / 5:
+            _stop("nthread cannot exceed ncol(x)/5")
+        self.nthread = nt
+        return self
+
     def opts(self, maxit=10000, eps_abs=1e-4, eps_rel=1e-4, rho=1.0):
         if maxit <= 0:
             _stop("maxit should be positive")
@@ -224,6 +267,8 @@ class ADMM_BP:
         return self
 
     def fit(self):
+        if getattr(self, "nthread", 1) > 1:
+            _stop('C symbol name "admm_parbp" not in DLL for package "ADMM"')     # R/10_admm_bp.R:111: the reference's own failure
         lib = _lib.load()
         xp, xmem, xk = as_input(self.x)
         yp, ymem, yk = as_input(self.y)
@@ -244,6 +289,12 @@ class ADMM_LAD_fit:
         self.beta = beta            # numeric p+1, intercept first (LAD.cpp:40-45)
         self.niter = niter
         self.stats = stats
+
+    def __repr__(self):
+        return f"ADMM LAD fitting result\n\n$beta\n{self.beta}\n\n$niter\n{self.niter}"
+
+    def show(self):
+        print(repr(self))
 
 
 class ADMM_LAD(ADMM_BP):

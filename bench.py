@@ -271,6 +271,64 @@ def tallshard_child(a, backend, out_path):
     _child_teardown(plan, adist, dist, multi)
 
 
+def widecols_child(a, backend, out_path):
+    """BASELINE configs[2] (admm_lasso wide n=2000, p=200000, ADMMLassoWide) with its COLUMNS spread over the ranks
+    (admm_hip_lasso_dist_cols): local X_i't / prox / active set, one all-reduce of A x (n floats) per iteration over
+    `backend`.  Total work fixed as N grows: strong scaling.  A 20-lambda path (the full 100 at N = 1 takes 0.45 s)."""
+    rank, world, multi, torch, dist, dev, adist = _child_setup(backend)
+    from admm_amd import DevicePtr
+    n, p = 2000, 200000
+    lo, hi = adist.col_partition(p, world, rank)
+    pl = hi - lo
+    gb = torch.Generator(device="cpu"); gb.manual_seed(a.seed)
+    beta_true = torch.zeros(p, dtype=torch.float64)
+    beta_true[:100] = torch.rand(100, generator=gb, dtype=torch.float64)
+    noise = torch.randn(n, generator=gb, dtype=torch.float64)
+    # every rank needs the full y = X beta* + noise: the first 100 columns (all non-zeros of beta*) are generated identically everywhere
+    gh = torch.Generator(device=dev); gh.manual_seed(a.seed + 3000)
+    xhead = torch.randn((100, n), generator=gh, device=dev, dtype=torch.float64) * 2.0
+    y = beta_true[:100].to(dev) @ xhead + noise.to(dev)
+    g = torch.Generator(device=dev); g.manual_seed(a.seed + 3001 + rank)
+    xt = torch.randn((pl, n), generator=g, device=dev, dtype=torch.float64) * 2.0      # pl x n row-major == n x pl column-major
+    if lo < 100:
+        xt[:100 - lo] = xhead[lo:100]
+    torch.cuda.synchronize()
+    from admm_amd._lib import AdmmOpts, AdmmStats, check, load
+    import ctypes
+    import numpy as np
+    lib = load()
+    nl = 20
+    lam_out = np.zeros(nl); beta = np.zeros((p + 1, nl), dtype=np.float32, order="F"); niter = np.zeros(nl, dtype=np.int32)
+    o = AdmmOpts(10000, 1e-5, 1e-5, -1.0)
+
+    def run():
+        stats = AdmmStats()
+        check(lib.admm_hip_lasso_dist_cols(ctypes.c_void_p(xt.data_ptr()), ctypes.c_void_p(y.data_ptr()), n, pl, p, lo, 1, None, 0, nl, 0.01,
+                                           1, 1, -1.0, ctypes.byref(o), lam_out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                           beta.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), niter.ctypes.data_as(ctypes.POINTER(ctypes.c_int)),
+                                           ctypes.byref(stats)))
+        return stats.as_dict()
+
+    run()                                                # warm-up
+    if multi:
+        dist.barrier()
+    st = run()
+    iters = int(st["total_iter"])
+    loop_s = _max_over_ranks(st["t_loop"], torch, dist, multi)
+    if rank == 0:
+        res = {"workload": "admm_lasso wide n=2000 p=200000 (BASELINE configs[2]), columns sharded over the ranks, 20-lambda path",
+               "exchange": backend, "n_gpus": world, "ranks_in_communicator": world, "scaling": "strong", "iterations": iters,
+               "loop_s": loop_s, "iters_per_s": iters / loop_s, "us_per_iter": loop_s / iters * 1e6,
+               "setup_s": st["t_total"] - st["t_loop"], "allreduce_payload_bytes": 4 * n, "niter_first": [int(v) for v in niter[:8]]}
+        with open(out_path, "w") as f:
+            json.dump(res, f)
+    if multi:
+        dist.barrier()
+    adist.finalize_comm()
+    if multi:
+        dist.destroy_process_group()
+
+
 def run_side_measurement(a, rank, world, kind, backend, seconds, port_offset):
     """Run a child measurement (`kind` in {"consensus", "tallshard"}) in a separate process per rank, with its own
     rendezvous port and a time limit, so that a failure or a hang of a multi-process exchange path can never take the
@@ -308,7 +366,7 @@ def main():
     a = parse()
     if a.child:
         kind, backend, out_path = a.child.split(":", 2)
-        (consensus_child if kind == "consensus" else tallshard_child)(a, backend, out_path)
+        {"consensus": consensus_child, "tallshard": tallshard_child, "widecols": widecols_child}[kind](a, backend, out_path)
         return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -400,9 +458,13 @@ def main():
         if multi:
             consensus.append(run_side_measurement(a, rank, world, "consensus", "peer", a.consensus_seconds, 29))
             barrier()
+    widecols = []
     if multi and a.shard_seconds > 0:
         for k, backend in enumerate(("rccl", "peer")):
             shard.append(run_side_measurement(a, rank, world, "tallshard", backend, a.shard_seconds, 41 + 12 * k))
+            barrier()
+        for k, backend in enumerate(("rccl", "peer")):
+            widecols.append(run_side_measurement(a, rank, world, "widecols", backend, a.shard_seconds, 71 + 12 * k))
             barrier()
     if rank == 0:
         x_ms = xms / max(1, xsamp)
@@ -463,6 +525,9 @@ def main():
         shard = [c for c in shard if c]
         if consensus:
             out["consensus"] = consensus[0] if len(consensus) == 1 else consensus
+        widecols = [c for c in widecols if c]
+        if widecols:
+            out["wide_column_sharded"] = widecols
         if shard:
             out["sharded"] = shard
             ok = [c for c in shard if "error" not in c]

@@ -128,3 +128,26 @@ def test_beta_is_returned_as_csc_with_explicit_intercept_row():
     assert m.shape == (5, 2)
     assert list(m.indptr) == [0, 2, 3]               # row 0 stored even when it is zero (Lasso.cpp:22-30)
     assert list(m.indices) == [0, 2, 0]
+
+
+def test_fit_objects_mirror_show_and_plot_data():
+    """R-side conveniences of the fit classes (R/30_admm_lasso.R:181-214, R/10_admm_bp.R:111,125-133), no GPU needed."""
+    import numpy as np
+    from admm_amd.api import ADMM_BP, ADMM_BP_fit, ADMM_LAD_fit, ADMM_Lasso_fit
+    import scipy.sparse as sp
+    beta = np.zeros((4, 3), dtype=np.float32)
+    beta[0] = [0.5, 0.4, 0.3]; beta[2] = [0.0, 0.1, 0.2]
+    fit = ADMM_Lasso_fit(np.array([1.0, 0.5, 0.25]), beta, np.array([3, 4, 5], dtype=np.int32), {})
+    assert "ADMM Lasso fitting result" in repr(fit)
+    ll, coef = fit.path_data()
+    assert np.allclose(ll, np.log([1.0, 0.5, 0.25])) and coef.shape == (3, 1) and np.allclose(coef[:, 0], [0.0, 0.1, 0.2])
+    ax = fit.plot()
+    assert ax.get_title() == "Solution path" and len(ax.lines) == 1
+    one = ADMM_Lasso_fit(np.array([1.0]), beta[:, :1], np.array([3], dtype=np.int32), {})
+    with pytest.raises(ValueError, match="at least two lambda"):
+        one.path_data()
+    assert "Basis Pursuit" in repr(ADMM_BP_fit(sp.csc_matrix(np.zeros((5, 1))), 7, {}))
+    assert "LAD" in repr(ADMM_LAD_fit(np.zeros(3), 9, {}))
+    m = ADMM_BP(np.zeros((3, 40)), np.zeros(3)).parallel(2)
+    with pytest.raises(ValueError, match="admm_parbp"):
+        m.fit()

@@ -267,3 +267,78 @@ def test_two_rank_row_sharded_tall_protocol_matches_serial_oracle(tmp_path):
     prob = dict(x=x, y=y, lam=None, nlambda=10, lmin_ratio=1e-4, standardize=True, intercept=True, opts=entry.LASSO_OPTS, alpha=None)
     rep = assert_tall_parity(r0["beta"], r0["niter"], r0["trace"], prob, 1e-4, label="gloo model of the row-sharded tall solver")
     assert len(rep["loose"]) == 0
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Column-sharded serial wide solver (admm_hip_lasso_dist_cols): world_size-2 NumPy model of what lasso_wide.hip does.
+def _wide_rank_main(rank, world, port, x, y, nl, out_path):
+    from admm_amd.dist import col_partition
+    from oracle.datastd import DataStd
+    from oracle.entry import _lambda_grid
+    from oracle.solvers import LassoWide
+    from oracle.spectra import sym_eigs_largest
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n, p = x.shape
+    lo, hi = col_partition(p, world, rank)
+    Xl = np.array(x[:, lo:hi], dtype=F, order="F")
+    yl = np.array(y, dtype=F)
+    std = DataStd(n, hi - lo, True, True, F)                 # column moments are local, y is replicated
+    std.standardize(Xl, yl)
+
+    class Cols(LassoWide):
+        def __init__(self):
+            self.X, self.Y, self.n, self.p = Xl, yl, n, hi - lo
+            self.eps_abs = self.eps_rel = 1e-5
+            self.alpha, self.info, self.trace_nnz = None, {}, []
+            lam0 = np.zeros(world, F)
+            lam0[rank] = np.abs((Xl.T @ yl).astype(F)).max()
+            self.lambda0 = F(_allreduce(lam0).max())                         # max over ranks through a sum of one-hot vectors
+            XXt = _allreduce((Xl @ Xl.T).astype(F))                          # X X' = sum over the column blocks
+            self.sprad = F(sym_eigs_largest(lambda v: XXt @ v, n, 3, 10, 0.1, F, self.info))
+
+        def compute_eps_dual(self):                                         # sqrt(p) counts ALL columns
+            return (np.float64(F(np.sqrt(self.sprad))) * np.float64(F(np.linalg.norm(self.dual_y))) * self.eps_rel
+                    + np.sqrt(float(p)) * self.eps_abs)
+
+        def next_z(self):                                                   # the one exchange: A x summed over the ranks
+            idx = np.nonzero(self.main_x)[0]
+            part = (self.X[:, idx] @ self.main_x[idx]).astype(F) if idx.size else np.zeros(n, F)
+            self.cache_Ax = _allreduce(part)
+            return ((self.Y + self.dual_y + F(self.rho) * self.cache_Ax) / F(-1 - self.rho)).astype(F)
+
+    sol = Cols()
+    lam = _lambda_grid(sol.lambda0, n, std.scaleY, nl, 0.01)
+    beta = np.zeros((p + 1, nl), F)
+    niters = []
+    for i in range(nl):
+        li = lam[i] * n / np.float64(std.scaleY)
+        sol.init(li, -1.0) if i == 0 else sol.init_warm(li)
+        niters.append(sol.solve(10000))
+        b0, coef = std.recover(sol.get_coef())
+        full = np.zeros(p + 1, np.float64)
+        full[1 + lo:1 + hi] = coef
+        full[0] = np.float64(std.meanY) - np.float64(b0)                    # this block's share of sum_j beta_j meanX_j
+        full = _allreduce(full)
+        full[0] = np.float64(std.meanY) - full[0]
+        beta[:, i] = full.astype(F)
+    np.savez(out_path + f".{rank}.npz", beta=beta, niter=np.array(niters), lam=lam)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_column_sharded_wide_protocol_matches_serial_oracle(tmp_path):
+    from oracle import entry
+    x, y = synth_lasso(120, 500, 10, seed=83)
+    out = str(tmp_path / "wide")
+    mp.spawn(_wide_rank_main, args=(2, _free_port(), x, y, 8, out), nprocs=2, join=True)
+    r0, r1 = np.load(out + ".0.npz"), np.load(out + ".1.npz")
+    assert np.array_equal(r0["beta"], r1["beta"]) and np.array_equal(r0["niter"], r1["niter"])
+    ref = entry.admm_lasso(x, y, None, 8, 0.01, True, True, entry.LASSO_OPTS)
+    assert np.allclose(r0["lam"], ref["lambda"], rtol=1e-6)
+    # identical algorithm; the two-term sum of A x rounds differently from the one-piece product, so late lambdas may
+    # stop an iteration apart
+    assert np.abs(r0["niter"][:4].astype(int) - ref["niter"][:4].astype(int)).max() <= 2, (r0["niter"], ref["niter"])
+    for j in range(8):
+        assert relerr(r0["beta"][:, j], ref["beta"][:, j]) < (1e-4 if j < 4 else 5e-3), j
