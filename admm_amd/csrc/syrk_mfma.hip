@@ -45,6 +45,7 @@ struct GemmNT {
     int kstart_row;              // start the K loop at the tile's first row (A, B upper triangular)
     int ksplit;                  // > 1: split s of the K range writes its own partial C + s * cstride (alpha = 1, beta = 0)
     long long cstride;
+    const int* tilemap;          // optional [ntiles]: work item -> (bi << 16 | bj); NULL = row-major triangle / column-major grid
 };
 
 __device__ __forceinline__ void tri_decode(int t, int& bi, int& bj) {   // t -> (bi, bj), bi >= bj, row-major triangle
@@ -65,7 +66,8 @@ gemm_nt_mfma_kernel(GemmNT g) {
     if (w_idx >= nwork) return;
     const int t_idx = w_idx % g.ntiles, split = w_idx / g.ntiles;
     int bi, bj;
-    if (LOWER) tri_decode(t_idx, bi, bj);
+    if (g.tilemap != nullptr) { const int m = g.tilemap[t_idx]; bi = m >> 16; bj = m & 0xffff; }
+    else if (LOWER) tri_decode(t_idx, bi, bj);
     else { bi = t_idx % g.nbi; bj = t_idx / g.nbi; }
     const int I0 = bi * SK_BM, J0 = bj * SK_BM;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -151,12 +153,49 @@ gemm_nt_mfma_kernel(GemmNT g) {
         }
 }
 
+// Work order of a lower-triangle launch with a deep K (the Gram): the 64 tiles that are resident on one XCD at a time
+// (32 CUs x 2 workgroups) should form a SQUARE of the tile grid, not a row -- they walk K roughly in step, so an 8 x 8
+// square streams 8 + 8 operand panels through that XCD's L2 for 64 tiles (each loaded line feeds 8 tiles), while 64
+// consecutive tiles of one row stream 1 + 64 panels (the B panels feed one tile each).  Block b runs on XCD b % 8 and is
+// the (b / 8)-th work item of that XCD; super-blocks of 8 x 8 tiles (triangular on the diagonal) are dealt out to the
+// XCDs in turn.  Returns a device array of ntiles entries (bi << 16 | bj) indexed like w_idx in the kernel.
+static DevBuf<int> make_square_tilemap(int nb, hipStream_t st) {
+    const int ntiles = nb * (nb + 1) / 2;
+    const int per = (ntiles + 7) / 8;
+    std::vector<std::vector<int>> q(8);
+    const int S = 8;
+    int turn = 0;
+    for (int sbi = 0; sbi * S < nb; ++sbi)
+        for (int sbj = 0; sbj <= sbi; ++sbj) {
+            // give the super-block to the XCD with the shortest list so far (keeps the 8 lists within one super-block of each other)
+            int x = turn;
+            for (int k = 0; k < 8; ++k) if (q[k].size() < q[x].size()) x = k;
+            turn = (turn + 1) & 7;
+            for (int bi = sbi * S; bi < std::min(nb, (sbi + 1) * S); ++bi)
+                for (int bj = sbj * S; bj < std::min(nb, (sbj + 1) * S); ++bj)
+                    if (bj <= bi) q[x].push_back(bi << 16 | bj);
+        }
+    // the kernel gives XCD x the index range [x * per, (x + 1) * per): rebalance so that no list exceeds `per`
+    std::vector<int> flat;
+    for (int x = 0; x < 8; ++x) while ((int)q[x].size() > per) { flat.push_back(q[x].back()); q[x].pop_back(); }
+    for (int x = 0; x < 8; ++x) while ((int)q[x].size() < per && !flat.empty()) { q[x].push_back(flat.back()); flat.pop_back(); }
+    std::vector<int> order;
+    order.reserve(ntiles);
+    // The kernel gives XCD x the work items [x * per, (x + 1) * per) of tilemap: lay the 8 lists out back to back (a
+    // permutation of all tiles; where a list is a little shorter than `per` a few tiles slide to the neighbouring XCD).
+    for (int x = 0; x < 8; ++x) for (int v : q[x]) order.push_back(v);
+    DevBuf<int> d(order.size());
+    ADMM_HIP_CHECK(hipMemcpyAsync(d.get(), order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    ADMM_HIP_CHECK(hipStreamSynchronize(st));
+    return d;
+}
+
 static void launch_gemm_nt(bool lower, const float* A, long long lda, const float* B, long long ldb, float* C, long long ldc,
                            int M, int N, int K, float alpha, float beta, bool mirror, bool kstart_row, hipStream_t st,
-                           int ksplit = 1, long long cstride = 0) {
+                           int ksplit = 1, long long cstride = 0, const int* tilemap = nullptr) {
     if (M <= 0 || N <= 0) return;
     GemmNT g;
-    g.ksplit = ksplit; g.cstride = cstride;
+    g.ksplit = ksplit; g.cstride = cstride; g.tilemap = tilemap;
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
     g.alpha = alpha; g.beta = beta; g.mirror = mirror ? 1 : 0; g.kstart_row = kstart_row ? 1 : 0;
     g.nbi = (M + SK_BM - 1) / SK_BM; g.nbj = (N + SK_BM - 1) / SK_BM;
@@ -211,8 +250,12 @@ void gram_mfma_f32(const float* A, long long lda, int rows, int cols, bool atA, 
     if (atA) transpose<float>(A, lda, rows, cols, Z.get(), ldz, st);
     else hipLaunchKernelGGL(pad_copy_f32_kernel, dim3((rows + 255) / 256, cols), dim3(256), 0, st, A, lda, rows, cols, Z.get(), ldz);
     if (ksplit == 1) {
-        launch_gemm_nt(true, Z.get(), ldz, Z.get(), ldz, C, ldc, M, M, nk, 1.f, 0.f, true, false, st);
-        ADMM_HIP_CHECK(hipStreamSynchronize(st));      // Z is freed on return
+        // ADMM_HIP_GRAM_ORDER=row: the plain row-major triangle order (A/B measurement)
+        const char* eo = std::getenv("ADMM_HIP_GRAM_ORDER");
+        DevBuf<int> tmap;
+        if (!(eo && std::string(eo) == "row")) tmap = make_square_tilemap(nb, st);
+        launch_gemm_nt(true, Z.get(), ldz, Z.get(), ldz, C, ldc, M, M, nk, 1.f, 0.f, true, false, st, 1, 0, tmap.get());
+        ADMM_HIP_CHECK(hipStreamSynchronize(st));      // Z and the tile map are freed on return
         return;
     }
     const long long stride = ldz * ldz;
