@@ -186,8 +186,12 @@ inline void launch_gemv_t(const GemvTPlan& pl, const T* A, long long lda, int m,
     a.v[0] = v0; a.v[1] = v1; a.vparts = vparts; a.vstride = vstride; a.out[0] = out0; a.out[1] = out1;
     a.out_stride = out_stride; a.seg_len = pl.seg_len; a.seg_alloc = pl.seg_alloc; a.nseg = pl.nseg;
     a.groups_per_wg = pl.groups_per_wg; a.skip = skip;
-    hipExtLaunchKernelGGL((gemv_t_kernel<T, NRHS, C, Extra>), dim3(pl.grid + (Extra::kHas ? 1 : 0)), dim3(kGemvThreads),
-                          (std::uint32_t)pl.lds_bytes, st, ev_start, ev_stop, 0, a, extra);
+    if (ev_start == nullptr && ev_stop == nullptr)
+        hipLaunchKernelGGL((gemv_t_kernel<T, NRHS, C, Extra>), dim3(pl.grid + (Extra::kHas ? 1 : 0)), dim3(kGemvThreads),
+                           (std::uint32_t)pl.lds_bytes, st, a, extra);
+    else
+        hipExtLaunchKernelGGL((gemv_t_kernel<T, NRHS, C, Extra>), dim3(pl.grid + (Extra::kHas ? 1 : 0)), dim3(kGemvThreads),
+                              (std::uint32_t)pl.lds_bytes, st, ev_start, ev_stop, 0, a, extra);
 }
 
 // Sum the nseg partial rows of a gemv_t result: y[j] = sum_s part[s*stride + j].

@@ -678,12 +678,46 @@ struct TallPlan final : LassoPlan {
             ADMM_HIP_CHECK(hipMemcpyAsync(&hctl[slot], &ctl.get()[(int)(g & 1)], sizeof(TallCtl), hipMemcpyDeviceToHost, st));
             ADMM_HIP_CHECK(hipEventRecord(ev_poll[slot].e, st));
         };
+        // ADMM_HIP_TALL_GRAPH=1 (A/B knob): capture one batch (an even number of iterations, so the parity pattern repeats)
+        // into a hipGraph and replay it instead of enqueueing 2 x batch launches per poll.  Measured on C2
+        // (scripts/graph_check.py): bit-identical, 46.86 us per iteration against 46.56 us with plain launches on the
+        // same box -- the host already runs a whole batch ahead of the device, so there is no launch latency left to
+        // remove and the graph's kernel nodes dispatch no faster than back-to-back launches.  Plain launches stay.
+        hipGraphExec_t gexec = nullptr;
+        const bool use_graph = std::getenv("ADMM_HIP_TALL_GRAPH") && std::string(std::getenv("ADMM_HIP_TALL_GRAPH")) == "1" && stride <= 0 && !shard && !fused;
+        if (use_graph) {
+            hipGraph_t graph = nullptr;
+            ADMM_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            const long long g_save = g;
+            for (int k = 0; k < batch; ++k, ++g) {
+                const int par = (int)(g & 1);
+                const TallDecideExtra dec{q, par};
+                if (use_sym) {
+                    sy.launch(M.get(), ldp, u.get(), w.get(), &ctl.get()[par].done, st, dec, nullptr, nullptr);
+                    hipLaunchKernelGGL(tall_tail_kernel<TAIL_SYMV>, dim3(nwg), dim3(kTailThreads), 0, st, q, par, PeerExchange{});
+                } else {
+                    launch_gemv_t<float, 2, 4, TallDecideExtra>(pl, M.get(), ldp, p, p, u.get(), w.get(), a_part.get(), b_part.get(), ldp,
+                                                                &ctl.get()[par].done, st, dec, nullptr, nullptr);
+                    hipLaunchKernelGGL(tall_tail_kernel<TAIL_GEMV>, dim3(nwg), dim3(kTailThreads), 0, st, q, par, PeerExchange{});
+                }
+            }
+            g = g_save;
+            ADMM_HIP_CHECK(hipStreamEndCapture(st, &graph));
+            ADMM_HIP_CHECK(hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(graph);
+        }
+        auto enqueue_batch_graph = [&](int slot) {
+            ADMM_HIP_CHECK(hipGraphLaunch(gexec, st));
+            g += batch; launches += batch;
+            ADMM_HIP_CHECK(hipMemcpyAsync(&hctl[slot], &ctl.get()[(int)(g & 1)], sizeof(TallCtl), hipMemcpyDeviceToHost, st));
+            ADMM_HIP_CHECK(hipEventRecord(ev_poll[slot].e, st));
+        };
         int slot = 0;
-        enqueue_batch(slot);
+        if (use_graph) enqueue_batch_graph(slot); else enqueue_batch(slot);
         ADMM_HIP_CHECK(hipGetLastError());                 // launch failures surface here
         bool done = false;
         while (!done) {
-            enqueue_batch(slot ^ 1);                       // keep one batch in flight while polling the previous one
+            if (use_graph) enqueue_batch_graph(slot ^ 1); else enqueue_batch(slot ^ 1);      // keep one batch in flight while polling the previous one
             ADMM_HIP_CHECK(hipEventSynchronize(ev_poll[slot].e));
             comm_check();
             done = hctl[slot].done != 0;
@@ -693,6 +727,7 @@ struct TallPlan final : LassoPlan {
         ADMM_HIP_CHECK(hipEventRecord(ev_loop1.e, st));
         ADMM_HIP_CHECK(hipStreamSynchronize(st));
         S.t_loop = now_s() - tl0;
+        if (gexec) (void)hipGraphExecDestroy(gexec);
         float ms = 0.f;
         ADMM_HIP_CHECK(hipEventElapsedTime(&ms, ev_loop0.e, ev_loop1.e));
         S.loop_ms_events = ms;

@@ -247,7 +247,8 @@ struct SymvPlan {
                 hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
         const SymvArgs a = args(A, lda, v0, v1, skip);
         // start/stop events (when given) time exactly this kernel on its stream (hipExtLaunchKernel)
-        hipExtLaunchKernelGGL((symv2_lower_kernel<Extra>), dim3(ntiles + 1), dim3(kSyThreads), 0, st, ev_start, ev_stop, 0, a, extra);
+        if (ev_start == nullptr && ev_stop == nullptr) hipLaunchKernelGGL((symv2_lower_kernel<Extra>), dim3(ntiles + 1), dim3(kSyThreads), 0, st, a, extra);
+        else hipExtLaunchKernelGGL((symv2_lower_kernel<Extra>), dim3(ntiles + 1), dim3(kSyThreads), 0, st, ev_start, ev_stop, 0, a, extra);
     }
 };
 
