@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libadmm_hip.so")
+LIB_PATH = os.environ.get("ADMM_HIP_LIB") or os.path.join(_HERE, "lib", "libadmm_hip.so")      # ADMM_HIP_LIB: A/B builds (dev)
 
 ADMM_MEM_HOST = 0
 ADMM_MEM_DEVICE = 1

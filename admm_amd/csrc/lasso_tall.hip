@@ -328,7 +328,7 @@ struct TallFusedWait {
 __global__ void __launch_bounds__(kTailThreads, 4)
 tall_fused_kernel(TallParams q, int par, TallFused f) {
     __shared__ float4 red[2][kSyThreads];
-    __shared__ float sdot[2][kSyCB];
+    __shared__ __attribute__((aligned(16))) float sdot[2][kSyCB];
     __shared__ double scratch[6 * (kTailThreads / 64)];
     __shared__ int s_last;
     if ((int)blockIdx.x >= f.ntail) {                       // ---- a tile of the mat-vec of iteration g

@@ -3,18 +3,19 @@
 //   y_r = A v_r  (r = 0, 1)  for a symmetric p x p fp32 matrix stored column-major (both triangles
 //   are in memory, only tiles on or below the diagonal are read): 2 p^2 bytes instead of 4 p^2.
 //
-// Tiling: a workgroup owns 256 rows x 128 columns; each of its 4 waves owns the same 256 rows
-// (one float4 per lane) and 32 of the columns.  For every element a_ij (i > j) it loads, a wave
+// Tiling: a workgroup owns 256 rows x 256 columns; each of its 4 waves owns the same 256 rows
+// (one float4 per lane) and 64 of the columns (round 1: 128-column tiles, 32 per wave -- twice the axpy partial
+// rows for the consumer to sum and to write here; 256 keeps every tile of p = 10^4 resident in ONE round).  For every element a_ij (i > j) it loads, a wave
 // does both halves of the symmetric product:
 //     dot  part:  y_j += a_ij v_i   -> per-lane partials of 8 columns at a time, combined across
 //                                      the 64 lanes with a halving butterfly (10 shuffles per 8 columns)
 //     axpy part:  y_i += a_ij v_j   -> 4 per-lane accumulators (v_j is wave-uniform, v_readlane)
 // The diagonal element contributes once (dot part).  Results are written as partials:
-//     dot[rb][j]  (rb = row block of 256)      axp[cb][i]  (cb = column block of 128)
+//     dot[rb][j]  (rb = row block of 256)      axp[cb][i]  (cb = column block of 256)
 // and summed by the consumer (`symv_sum_partials` below, fused into the tall tail kernel):
-//     y_i = sum_{rb >= cb(i)/2} dot[rb][i] + sum_{cb <= 2 rb(i) + 1} axp[cb][i].
+//     y_i = sum_{rb >= cb(i)} dot[rb][i] + sum_{cb <= rb(i)} axp[cb][i].
 // Deterministic (no atomics).  Partial traffic: (p/256 + p/128) * p * 8 bytes per launch, written
-// once and read once (about 9 % of the triangle at p = 10^4).
+// once and read once (about 6 % of the triangle at p = 10^4).
 //
 // Measured and rejected (scripts/symv_tune.hip, scripts/symv_check.hip, in-situ A/B of the tall loop):
 //  * packing the triangle tile by tile (each 128 KB tile contiguous): +-2..6 % depending on p, -1 % in the
@@ -31,8 +32,8 @@
 namespace admm {
 
 constexpr int kSyRB = 256;     // rows per tile
-constexpr int kSyCW = 32;      // columns per wave
-constexpr int kSyCB = 128;     // columns per workgroup tile
+constexpr int kSyCW = 64;      // columns per wave
+constexpr int kSyCB = 256;     // columns per workgroup tile
 constexpr int kSyThreads = 256;
 constexpr int kSySumLanes = 8;  // lanes that share one element when the consumer sums the partials (symv_sum_partials)
 
@@ -93,7 +94,7 @@ struct SymvBypassVec {
 };
 struct SymvNoWait { __device__ __forceinline__ void operator()() const {} };
 
-// One tile (256 rows x 128 columns, 4 waves) of the symmetric product.  The first 8 matrix columns of every wave are
+// One tile (256 rows x 256 columns, 4 waves) of the symmetric product.  The first 8 matrix columns of every wave are
 // requested BEFORE `wait()` -- they do not depend on the right-hand vectors -- so that a caller whose vectors are still
 // being produced (wait() = poll a flag + barrier) already has its share of the stream in flight.  wait() is called by
 // every thread of the workgroup exactly once.
@@ -120,7 +121,7 @@ __device__ __forceinline__ void symv2_tile(const SymvArgs& a, const int2 t, Wait
     if (has) {
         const float4 uI = active ? vl.load4(a.v0 + row) : make_float4(0.f, 0.f, 0.f, 0.f);
         const float4 wI = active ? vl.load4(a.v1 + row) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const int cj = col0 + (lane & 31);
+        const int cj = col0 + (lane & (kSyCW - 1));
         const float uj = cj < a.p ? vl.load1(a.v0 + cj) : 0.f;
         const float wj = cj < a.p ? vl.load1(a.v1 + cj) : 0.f;
         const bool diag = col0 + (kSyCW - 1) >= rb * kSyRB;      // this wave's block meets the diagonal
@@ -184,8 +185,9 @@ __device__ __forceinline__ void symv2_tile(const SymvArgs& a, const int2 t, Wait
         float* dst = (wid == 0 ? a.axp0 : a.axp1) + (size_t)cb * a.ldo + row;
         *reinterpret_cast<float4*>(dst) = s;
     } else {
-        float* dst = (wid == 2 ? a.dot0 : a.dot1) + (size_t)rb * a.ldo + cb * kSyCB + lane * 2;      // < ncb * 128 <= ldo
-        *reinterpret_cast<float2*>(dst) = make_float2(sdot[wid - 2][lane * 2], sdot[wid - 2][lane * 2 + 1]);
+        static_assert(kSyCB == 4 * 64, "one float4 of the dot row per lane");
+        float* dst = (wid == 2 ? a.dot0 : a.dot1) + (size_t)rb * a.ldo + cb * kSyCB + lane * 4;      // < ncb * kSyCB <= ldo
+        *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(&sdot[wid - 2][lane * 4]);
     }
 }
 
@@ -199,7 +201,7 @@ symv2_lower_kernel(SymvArgs a, Extra extra) {
     if (blockIdx.x == 0) { extra(); return; }
     if (a.skip != nullptr && *a.skip != 0) return;
     __shared__ float4 red[2][kSyThreads];
-    __shared__ float sdot[2][kSyCB];
+    __shared__ __attribute__((aligned(16))) float sdot[2][kSyCB];
     symv2_tile(a, a.tiles[blockIdx.x - 1], SymvNoWait(), SymvPlainVec(), red, sdot);
 }
 
@@ -264,9 +266,9 @@ __device__ __forceinline__ void symv_sum_partials(const float* __restrict__ dot0
     a = 0.f; b = 0.f;
     if (valid) {
         const int cbi = i / kSyCB, rbi = i / kSyRB;
-        const int rb0 = cbi / 2;
+        const int rb0 = (cbi * kSyCB) / kSyRB;                              // first row block whose tiles reach column block cbi
         const int ndot = nrb - rb0;
-        const int nax = min(ncb - 1, 2 * rbi + 1) + 1;
+        const int nax = min(ncb - 1, ((rbi + 1) * kSyRB - 1) / kSyCB) + 1;  // column blocks up to the diagonal of row block rbi
         const int ntot = ndot + nax;
         for (int k0 = 0; k0 < ntot; k0 += 16 * NL) {
             float va[16], vb[16];

@@ -1,3 +1,6 @@
+// NOTE (round 2): written against the round-1 tiling (256 x 128 tiles, 32 columns per wave); the production kernel now uses
+// 256 x 256 tiles (symv_kernels.h), so the tile list this tool gets from SymvPlan no longer matches its kernels.  Kept for the record of
+// the round-1 measurements quoted in symv_kernels.h.
 // Dev tool: timing-only variants of the lower-triangle symv (layout, chunk width, occupancy) over a sweep of p.
 // hipcc -O3 --offload-arch=gfx950 -I admm_amd/csrc -I include scripts/symv_tune.hip -o /tmp/symv_tune
 #include "symv_kernels.h"
