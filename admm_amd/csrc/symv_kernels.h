@@ -5,7 +5,9 @@
 //
 // Tiling: a workgroup owns 256 rows x 256 columns; each of its 4 waves owns the same 256 rows
 // (one float4 per lane) and 64 of the columns (round 1: 128-column tiles, 32 per wave -- twice the axpy partial
-// rows for the consumer to sum and to write here; 256 keeps every tile of p = 10^4 resident in ONE round).  For every element a_ij (i > j) it loads, a wave
+// rows for the consumer to sum and to write here; 256 keeps every tile of p = 10^4 resident in ONE round:
+// 22.3 k against 20.6 k ADMM iterations/s on C2 in a same-box A/B, kernel 36.9 against 39.3 us.  512-column tiles with
+// 128 columns per wave leave too few workgroups: 51 us.)  For every element a_ij (i > j) it loads, a wave
 // does both halves of the symmetric product:
 //     dot  part:  y_j += a_ij v_i   -> per-lane partials of 8 columns at a time, combined across
 //                                      the 64 lanes with a halving butterfly (10 shuffles per 8 columns)
@@ -121,9 +123,13 @@ __device__ __forceinline__ void symv2_tile(const SymvArgs& a, const int2 t, Wait
     if (has) {
         const float4 uI = active ? vl.load4(a.v0 + row) : make_float4(0.f, 0.f, 0.f, 0.f);
         const float4 wI = active ? vl.load4(a.v1 + row) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const int cj = col0 + (lane & (kSyCW - 1));
-        const float uj = cj < a.p ? vl.load1(a.v0 + cj) : 0.f;
-        const float wj = cj < a.p ? vl.load1(a.v1 + cj) : 0.f;
+        float ujv[kSyCW / 64], wjv[kSyCW / 64];               // the wave's kSyCW right-hand entries, 64 per register
+#pragma unroll
+        for (int h = 0; h < kSyCW / 64; ++h) {
+            const int cj = col0 + h * 64 + lane;
+            ujv[h] = cj < a.p ? vl.load1(a.v0 + cj) : 0.f;
+            wjv[h] = cj < a.p ? vl.load1(a.v1 + cj) : 0.f;
+        }
         const bool diag = col0 + (kSyCW - 1) >= rb * kSyRB;      // this wave's block meets the diagonal
 #pragma unroll 1
         for (int q = 0; q < kSyCW / 8; ++q) {
@@ -136,6 +142,9 @@ __device__ __forceinline__ void symv2_tile(const SymvArgs& a, const int2 t, Wait
                 }
             }
             float dU[8], dW[8];
+            float uj = ujv[0], wj = wjv[0];
+#pragma unroll
+            for (int h = 1; h < kSyCW / 64; ++h) if ((q * 8) / 64 == h) { uj = ujv[h]; wj = wjv[h]; }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const int col = col0 + q * 8 + k;
@@ -154,8 +163,8 @@ __device__ __forceinline__ void symv2_tile(const SymvArgs& a, const int2 t, Wait
                 }
                 dU[k] = fmaf(v.x, uI.x, fmaf(v.y, uI.y, fmaf(v.z, uI.z, v.w * uI.w)));
                 dW[k] = fmaf(v.x, wI.x, fmaf(v.y, wI.y, fmaf(v.z, wI.z, v.w * wI.w)));
-                const float ujc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(uj), q * 8 + k));
-                const float wjc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wj), q * 8 + k));
+                const float ujc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(uj), (q * 8 + k) & 63));
+                const float wjc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wj), (q * 8 + k) & 63));
                 aU.x = fmaf(ax.x, ujc, aU.x); aU.y = fmaf(ax.y, ujc, aU.y); aU.z = fmaf(ax.z, ujc, aU.z); aU.w = fmaf(ax.w, ujc, aU.w);
                 aW.x = fmaf(ax.x, wjc, aW.x); aW.y = fmaf(ax.y, wjc, aW.y); aW.z = fmaf(ax.z, wjc, aW.z); aW.w = fmaf(ax.w, wjc, aW.w);
             }
@@ -167,9 +176,8 @@ __device__ __forceinline__ void symv2_tile(const SymvArgs& a, const int2 t, Wait
                 sdot[1][wid * kSyCW + q * 8 + (lane >> 3)] = dw;
             }
         }
-    } else if (lane < kSyCW) {
-        sdot[0][wid * kSyCW + lane] = 0.f;
-        sdot[1][wid * kSyCW + lane] = 0.f;
+    } else {
+        for (int c = lane; c < kSyCW; c += 64) { sdot[0][wid * kSyCW + c] = 0.f; sdot[1][wid * kSyCW + c] = 0.f; }
     }
     // axpy part: add the 4 waves (same rows, different columns); dot part: one 512-byte row per array
     red[0][threadIdx.x] = aU;
@@ -185,9 +193,8 @@ __device__ __forceinline__ void symv2_tile(const SymvArgs& a, const int2 t, Wait
         float* dst = (wid == 0 ? a.axp0 : a.axp1) + (size_t)cb * a.ldo + row;
         *reinterpret_cast<float4*>(dst) = s;
     } else {
-        static_assert(kSyCB == 4 * 64, "one float4 of the dot row per lane");
-        float* dst = (wid == 2 ? a.dot0 : a.dot1) + (size_t)rb * a.ldo + cb * kSyCB + lane * 4;      // < ncb * kSyCB <= ldo
-        *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(&sdot[wid - 2][lane * 4]);
+        float* dst = (wid == 2 ? a.dot0 : a.dot1) + (size_t)rb * a.ldo + cb * kSyCB;                   // < ncb * kSyCB <= ldo
+        for (int c = lane * 4; c < kSyCB; c += 256) *reinterpret_cast<float4*>(dst + c) = *reinterpret_cast<const float4*>(&sdot[wid - 2][c]);
     }
 }
 
