@@ -333,7 +333,7 @@ tall_fused_kernel(TallParams q, int par, TallFused f) {
     __shared__ int s_last;
     if ((int)blockIdx.x >= f.ntail) {                       // ---- a tile of the mat-vec of iteration g
         if (*f.sy.skip != 0) return;                        // finished in an earlier launch
-        symv2_tile(f.sy, f.sy.tiles[blockIdx.x - f.ntail], TallFusedWait{f.flag, f.gen}, SymvBypassVec(), red, sdot);
+        symv2_tile<true>(f.sy, f.sy.tiles[blockIdx.x - f.ntail], TallFusedWait{f.flag, f.gen}, SymvBypassVec(), red, sdot);
         return;
     }
     // ---- tail of iteration g - 1: parity of that iteration's launch pair in the two-launch scheme

@@ -3,21 +3,21 @@
 //   y_r = A v_r  (r = 0, 1)  for a symmetric p x p fp32 matrix stored column-major (both triangles
 //   are in memory, only tiles on or below the diagonal are read): 2 p^2 bytes instead of 4 p^2.
 //
-// Tiling: a workgroup owns 256 rows x 256 columns; each of its 4 waves owns the same 256 rows
-// (one float4 per lane) and 64 of the columns (round 1: 128-column tiles, 32 per wave -- twice the axpy partial
-// rows for the consumer to sum and to write here; 256 keeps every tile of p = 10^4 resident in ONE round:
-// 22.3 k against 20.6 k ADMM iterations/s on C2 in a same-box A/B, kernel 36.9 against 39.3 us.  512-column tiles with
-// 128 columns per wave leave too few workgroups: 51 us.)  For every element a_ij (i > j) it loads, a wave
+// Tiling: a workgroup owns 256 rows x 128 columns; each of its 4 waves owns the same 256 rows
+// (one float4 per lane) and 32 of the columns.  The column widths are parameters (kSyCW a power of two <= 32 or a
+// multiple of 64).  Measured on C2, same box (round 2): 128-column tiles 35.1 us per launch, 23.2 k ADMM iterations/s;
+// 256-column tiles with 64 columns per wave halve the axpy partial rows (tail 6.6 instead of 7.1 us) but the longer
+// per-wave column loop streams worse: 37.7 us, 22.0 k it/s; 512-column tiles leave too few workgroups: 51 us.  For every element a_ij (i > j) it loads, a wave
 // does both halves of the symmetric product:
 //     dot  part:  y_j += a_ij v_i   -> per-lane partials of 8 columns at a time, combined across
 //                                      the 64 lanes with a halving butterfly (10 shuffles per 8 columns)
 //     axpy part:  y_i += a_ij v_j   -> 4 per-lane accumulators (v_j is wave-uniform, v_readlane)
 // The diagonal element contributes once (dot part).  Results are written as partials:
-//     dot[rb][j]  (rb = row block of 256)      axp[cb][i]  (cb = column block of 256)
+//     dot[rb][j]  (rb = row block of 256)      axp[cb][i]  (cb = column block of 128)
 // and summed by the consumer (`symv_sum_partials` below, fused into the tall tail kernel):
-//     y_i = sum_{rb >= cb(i)} dot[rb][i] + sum_{cb <= rb(i)} axp[cb][i].
+//     y_i = sum_{rb >= cb(i)/2} dot[rb][i] + sum_{cb <= 2 rb(i) + 1} axp[cb][i].
 // Deterministic (no atomics).  Partial traffic: (p/256 + p/128) * p * 8 bytes per launch, written
-// once and read once (about 6 % of the triangle at p = 10^4).
+// once and read once (about 9 % of the triangle at p = 10^4).
 //
 // Measured and rejected (scripts/symv_tune.hip, scripts/symv_check.hip, in-situ A/B of the tall loop):
 //  * packing the triangle tile by tile (each 128 KB tile contiguous): +-2..6 % depending on p, -1 % in the
@@ -34,8 +34,8 @@
 namespace admm {
 
 constexpr int kSyRB = 256;     // rows per tile
-constexpr int kSyCW = 64;      // columns per wave
-constexpr int kSyCB = 256;     // columns per workgroup tile
+constexpr int kSyCW = 32;      // columns per wave
+constexpr int kSyCB = 128;     // columns per workgroup tile
 constexpr int kSyThreads = 256;
 constexpr int kSySumLanes = 8;  // lanes that share one element when the consumer sums the partials (symv_sum_partials)
 
@@ -96,11 +96,14 @@ struct SymvBypassVec {
 };
 struct SymvNoWait { __device__ __forceinline__ void operator()() const {} };
 
-// One tile (256 rows x 256 columns, 4 waves) of the symmetric product.  The first 8 matrix columns of every wave are
+// One tile (kSyRB rows x kSyCB columns, 4 waves) of the symmetric product.  The first 8 matrix columns of every wave are
 // requested BEFORE `wait()` -- they do not depend on the right-hand vectors -- so that a caller whose vectors are still
 // being produced (wait() = poll a flag + barrier) already has its share of the stream in flight.  wait() is called by
 // every thread of the workgroup exactly once.
-template <typename Wait, typename VecLoad>
+// PRE = false (the two-launch path): no wait, right-hand entries first, every 8-column chunk loaded at the top of its loop
+// iteration -- the shape that streams best (with the PRE shape the same 128-column kernel ran at 39.3 instead of 35.1 us on
+// C2: a first chunk carried into the loop in registers and a conditional reload defeat the scheduling of the loads).
+template <bool PRE, typename Wait, typename VecLoad>
 __device__ __forceinline__ void symv2_tile(const SymvArgs& a, const int2 t, Wait wait, VecLoad vl,
                                            float4 (*red)[kSyThreads], float (*sdot)[kSyCB]) {
     const int rb = t.x, cb = t.y;
@@ -112,28 +115,30 @@ __device__ __forceinline__ void symv2_tile(const SymvArgs& a, const int2 t, Wait
     const bool has = col0 < a.p;           // every wave of a listed tile has all its columns <= the block's last row
     const float* base = a.A + (size_t)col0 * a.lda + row;
     float4 av[8];
+    if (PRE) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        av[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (has && active && col0 + k < a.p) av[k] = *reinterpret_cast<const float4*>(base + (size_t)k * a.lda);
+        for (int k = 0; k < 8; ++k) {
+            av[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (has && active && col0 + k < a.p) av[k] = *reinterpret_cast<const float4*>(base + (size_t)k * a.lda);
+        }
+        wait();
     }
-    wait();
     float4 aU = make_float4(0.f, 0.f, 0.f, 0.f), aW = aU;
 
     if (has) {
         const float4 uI = active ? vl.load4(a.v0 + row) : make_float4(0.f, 0.f, 0.f, 0.f);
         const float4 wI = active ? vl.load4(a.v1 + row) : make_float4(0.f, 0.f, 0.f, 0.f);
-        float ujv[kSyCW / 64], wjv[kSyCW / 64];               // the wave's kSyCW right-hand entries, 64 per register
+        float ujv[(kSyCW + 63) / 64], wjv[(kSyCW + 63) / 64];               // the wave's kSyCW right-hand entries, 64 per register
 #pragma unroll
-        for (int h = 0; h < kSyCW / 64; ++h) {
-            const int cj = col0 + h * 64 + lane;
+        for (int h = 0; h < (kSyCW + 63) / 64; ++h) {
+            const int cj = col0 + h * 64 + (kSyCW < 64 ? (lane & (kSyCW - 1)) : lane);
             ujv[h] = cj < a.p ? vl.load1(a.v0 + cj) : 0.f;
             wjv[h] = cj < a.p ? vl.load1(a.v1 + cj) : 0.f;
         }
         const bool diag = col0 + (kSyCW - 1) >= rb * kSyRB;      // this wave's block meets the diagonal
 #pragma unroll 1
         for (int q = 0; q < kSyCW / 8; ++q) {
-            if (q > 0) {
+            if (!PRE || q > 0) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const int col = col0 + q * 8 + k;
@@ -144,7 +149,7 @@ __device__ __forceinline__ void symv2_tile(const SymvArgs& a, const int2 t, Wait
             float dU[8], dW[8];
             float uj = ujv[0], wj = wjv[0];
 #pragma unroll
-            for (int h = 1; h < kSyCW / 64; ++h) if ((q * 8) / 64 == h) { uj = ujv[h]; wj = wjv[h]; }
+            for (int h = 1; h < (kSyCW + 63) / 64; ++h) if ((q * 8) / 64 == h) { uj = ujv[h]; wj = wjv[h]; }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const int col = col0 + q * 8 + k;
@@ -209,7 +214,7 @@ symv2_lower_kernel(SymvArgs a, Extra extra) {
     if (a.skip != nullptr && *a.skip != 0) return;
     __shared__ float4 red[2][kSyThreads];
     __shared__ __attribute__((aligned(16))) float sdot[2][kSyCB];
-    symv2_tile(a, a.tiles[blockIdx.x - 1], SymvNoWait(), SymvPlainVec(), red, sdot);
+    symv2_tile<false>(a, a.tiles[blockIdx.x - 1], SymvNoWait(), SymvPlainVec(), red, sdot);
 }
 
 // Number of row / column blocks and the tile list (host).

@@ -2,6 +2,17 @@
 
 A NumPy restatement of the reference's solvers (reference = /root/reference,
 R package ADMM 1.0): every function cites the reference file:line it follows.
+Beside it:
+  c/admm_tall_cpu.c + ctall.py  the tall loop (FADMMBase::solve + ADMMLassoTall / ADMMEnetTall) restated in C
+                                (gcc, built by __graft_entry__.build()): the compiled CPU baseline of bench.py and a
+                                second, independent restatement pinned to the same README vectors;
+  variants.py                   the tall x-update with mathematically identical roundings (float LLT = the reference,
+                                float inverse, inverse rounded from double, exact): how far two correct executions of
+                                the reference's arithmetic drift apart (tests/test_flip_floor.py);
+  solvers.FADMM follow mode     the oracle taking another execution's outcome of a threshold test ONLY where its own
+                                deciding quantity is within 8 float ulps of rounding noise of the threshold
+                                (FollowMismatch otherwise) -- the GPU parity tests' rule (tests/helpers.py);
+  tracecmp.py                   lock-step comparison of two decision traces (dev tools).
 Only `tests/`, `__graft_entry__.smoke()` and the `cpu_baseline` leg of
 `bench.py` may import this package, and only as the checker / reported CPU
 baseline.  Nothing under `admm_amd/` imports it; the product path fails

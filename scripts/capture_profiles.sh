@@ -1,19 +1,25 @@
 #!/bin/bash
-# Capture the judged evidence for the headline bench on the GPU box (run from the repo root through gpurun):
-#   kernel-trace stats of `bench.py`, PMC HBM bytes (separate passes per counter), the bench line itself.
-# Outputs go to gpurun_out/; copy the summaries into profiles/ afterwards.
+# Capture the judged evidence on the GPU box (run from the repo root through gpurun):
+#   headline bench: kernel-trace stats, PMC HBM bytes (separate passes per counter, no trace domains mixed in), the bench line;
+#   the other BASELINE configs (C3 wide, C4 consensus K=8 on one GPU, C5 LAD / BP): bench lines + kernel-trace stats each.
+# Outputs go to gpurun_out/<tag>/; copy the summaries into profiles/ afterwards.
 set -u
-TAG=${1:-r01_final}
+TAG=${1:-r02}
 export TMPDIR=/tmp
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o c2 -- python bench.py --steps 3 --warmup 1 --cpu-seconds 0 --consensus-seconds 0 > $OUT/trace_bench.log 2>&1
-python scripts/rocpd_summary.py $OUT/trace/c2_results.db $OUT/kernel_stats.md 14
-grep '^{"metric"' $OUT/trace_bench.log | tail -1 > $OUT/kernel_stats_benchline.json
+python scripts/rocpd_summary.py $OUT/trace/c2_results.db $OUT/tall_c2_kernel_stats.md 14
+grep '^{"metric"' $OUT/trace_bench.log | tail -1 > $OUT/tall_c2_kernel_stats_benchline.json
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o c2 -- python bench.py --steps 1 --warmup 0 --cpu-seconds 0 --consensus-seconds 0 --nlambda 10 > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o c2 -- python bench.py --steps 1 --warmup 0 --cpu-seconds 0 --consensus-seconds 0 --nlambda 10 > $OUT/pmc_write.log 2>&1
-python scripts/rocpd_pmc.py $OUT/pmc_fetch/c2_results.db $OUT/pmc_write/c2_results.db $OUT/pmc_hbm_bytes.md
+python scripts/rocpd_pmc.py $OUT/pmc_fetch/c2_results.db $OUT/pmc_write/c2_results.db $OUT/tall_c2_pmc_hbm_bytes.md
 python bench.py > $OUT/bench_default.log 2>&1
-grep '^{"metric"' $OUT/bench_default.log | tail -1 > $OUT/bench_default.json
-rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write      # the databases are large; the summaries are what is kept
+grep '^{"metric"' $OUT/bench_default.log | tail -1 > $OUT/bench_c2.json
+python scripts/bench_configs.py c3 c4 c5lad c5bp > $OUT/bench_configs.jsonl 2> $OUT/bench_configs.err
+for c in c3 c4 c5lad c5bp; do
+  rocprofv3 --kernel-trace --stats -d $OUT/trace_$c -o k -- python scripts/bench_configs.py $c > $OUT/trace_$c.log 2>&1
+  python scripts/rocpd_summary.py $OUT/trace_$c/k_results.db $OUT/${c}_kernel_stats.md 12
+done
+rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/trace_c3 $OUT/trace_c4 $OUT/trace_c5lad $OUT/trace_c5bp      # the databases are large; the summaries are what is kept
 ls -la $OUT
