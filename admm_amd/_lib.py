@@ -56,7 +56,7 @@ EXPORTS = ["admm_hip_lasso", "admm_hip_enet", "admm_hip_parlasso", "admm_hip_lad
            "admm_hip_host_lanczos", "admm_hip_test_symv",
            "admm_hip_comm_peer_prepare", "admm_hip_comm_init_peer", "admm_hip_comm_init_shm", "admm_hip_comm_test_allreduce",
            "admm_hip_lasso_dist", "admm_hip_test_gram", "admm_hip_test_spd_inverse",
-           "admm_hip_lasso_dist_cols"]
+           "admm_hip_lasso_dist_cols", "admm_hip_test_gemv_t"]
 
 TRACE_FIELDS = 10
 TRACE_COLD, TRACE_CONVERGED, TRACE_ACCELERATE, TRACE_RESTART = -1, 0, 1, 2
@@ -131,6 +131,8 @@ def load():
     lib.admm_hip_test_symv.restype = ctypes.c_int
     lib.admm_hip_test_gram.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     lib.admm_hip_test_gram.restype = ctypes.c_int
+    lib.admm_hip_test_gemv_t.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    lib.admm_hip_test_gemv_t.restype = ctypes.c_int
     lib.admm_hip_test_spd_inverse.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     lib.admm_hip_test_spd_inverse.restype = ctypes.c_int
     lib.admm_hip_host_lanczos.argtypes = [_c_float_p, ctypes.c_int, _c_float_p, _c_int_p]

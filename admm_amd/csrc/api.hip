@@ -7,6 +7,7 @@ const std::string& last_error_ref();
 void test_symv(const float* A, int p, const float* v0, const float* v1, float* y0, float* y1);
 template <typename T> void test_gram(const T* A, int rows, int cols, bool atA, T* G);
 template <typename T> void test_spd_inverse(const T* A, int n, T* Ainv, bool via64);
+template <typename T> void test_gemv_t(const T* A, int rows, int cols, const T* v, T* y);
 int comm_unique_id(void* out);
 void comm_init(int nranks, int rank, const void* idbytes);
 void comm_finalize();
@@ -444,6 +445,14 @@ int admm_hip_test_gram(const void* A, int rows, int cols, int atA, int is_double
         ADMM_REQUIRE(A && G && rows > 0 && cols > 0, "bad arguments");
         if (is_double) test_gram<double>(static_cast<const double*>(A), rows, cols, atA != 0, static_cast<double*>(G));
         else test_gram<float>(static_cast<const float*>(A), rows, cols, atA != 0, static_cast<float*>(G));
+    });
+}
+
+int admm_hip_test_gemv_t(const void* A, int rows, int cols, int is_double, const void* v, void* y) {
+    return guarded([&] {
+        ADMM_REQUIRE(A && v && y && rows > 0 && cols > 0, "bad arguments");
+        if (is_double) test_gemv_t<double>(static_cast<const double*>(A), rows, cols, static_cast<const double*>(v), static_cast<double*>(y));
+        else test_gemv_t<float>(static_cast<const float*>(A), rows, cols, static_cast<const float*>(v), static_cast<float*>(y));
     });
 }
 

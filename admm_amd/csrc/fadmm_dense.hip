@@ -247,6 +247,14 @@ void solve_lad(const DeviceData<double>& d, const admm_opts& opts, DenseResult& 
     ADMM_HIP_CHECK(hipStreamSynchronize(st));
     S.t_gram = now_s() - t0;
     t0 = now_s();
+    // n <= 2000: the hat-matrix branch below also needs the Cholesky factor of the same Gram matrix: keep a copy
+    bool hat = n <= 2000;
+    if (const char* e = std::getenv("ADMM_HIP_LAD_HAT")) hat = hat && std::string(e) != "0";
+    DevBuf<double> G2;
+    if (hat) {
+        G2.alloc((size_t)ldp * ldp);
+        ADMM_HIP_CHECK(hipMemcpyAsync(G2.get(), M.get(), (size_t)ldp * ldp * sizeof(double), hipMemcpyDeviceToDevice, st));
+    }
     spd_inverse_f64(M.get(), ldp, p, st);
     const long long ldxt = round_up(p, 32);
     DevBuf<double> Xt((size_t)ldxt * n); Xt.zero(st);
@@ -271,16 +279,12 @@ void solve_lad(const DeviceData<double>& d, const admm_opts& opts, DenseResult& 
     // n <= 2000: the reference caches the hat matrix H = X (X'X)^-1 X' = T T', T = X L^-T, and projects with one
     // symmetric product (ADMMLAD.h:67-73,191-203).  Same here: T = X U with U = L^-T from the blocked factorisation,
     // H = T T' on the fp64 matrix cores, then ONE mat-vec per iteration.  ADMM_HIP_LAD_HAT=0 keeps the general form.
-    bool hat = n <= 2000;
-    if (const char* e = std::getenv("ADMM_HIP_LAD_HAT")) hat = hat && std::string(e) != "0";
     DevBuf<double> H;
     long long ldh = 0;
     if (hat) {
         t0 = now_s();
         const long long ldn = round_up(n, 128);
         const int pk = (int)round_up(p, 8);
-        DevBuf<double> G2((size_t)ldp * ldp); G2.zero(st);
-        gram_full<double>(d.X.get(), d.ldx, n, p, true, G2.get(), ldp, st);
         DevBuf<double> U = cholesky_linvt_mfma_f64(G2.get(), ldp, p, st);          // U = L^-T (p x p, upper)
         DevBuf<double> W((size_t)ldp * ldp), Xp((size_t)ldn * pk), T((size_t)ldn * ldp);
         Xp.zero(st); T.zero(st);

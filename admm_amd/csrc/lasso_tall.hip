@@ -325,6 +325,7 @@ struct TallFusedWait {
     }
 };
 
+template <bool PRE>      // PRE: the tiles request their first matrix columns before they wait (symv2_tile)
 __global__ void __launch_bounds__(kTailThreads, 4)
 tall_fused_kernel(TallParams q, int par, TallFused f) {
     __shared__ float4 red[2][kSyThreads];
@@ -333,7 +334,8 @@ tall_fused_kernel(TallParams q, int par, TallFused f) {
     __shared__ int s_last;
     if ((int)blockIdx.x >= f.ntail) {                       // ---- a tile of the mat-vec of iteration g
         if (*f.sy.skip != 0) return;                        // finished in an earlier launch
-        symv2_tile<true>(f.sy, f.sy.tiles[blockIdx.x - f.ntail], TallFusedWait{f.flag, f.gen}, SymvBypassVec(), red, sdot);
+        if (!PRE) TallFusedWait{f.flag, f.gen}();
+        symv2_tile<PRE>(f.sy, f.sy.tiles[blockIdx.x - f.ntail], TallFusedWait{f.flag, f.gen}, SymvBypassVec(), red, sdot);
         return;
     }
     // ---- tail of iteration g - 1: parity of that iteration's launch pair in the two-launch scheme
@@ -439,7 +441,7 @@ struct TallPlan final : LassoPlan {
     bool peer_fused = false;                            // ... with the exchange done by the solver's own kernels (PEER backend)
     CommInfo ci;
     DevBuf<float> ab;                                   // [2][ldp] this rank's share of (a, b), all-reduced in place
-    bool fused = false;                                 // one launch per iteration (tall_fused_kernel)
+    bool fused = false, fused_pre = false;              // one launch per iteration (tall_fused_kernel); tiles prefetch before they wait
     DevBuf<int> fflag;                                  // [64][16] generation flags of the single-launch iteration
     DevBuf<unsigned int> farrive;
     long long ldv = 0;
@@ -559,7 +561,10 @@ struct TallPlan final : LassoPlan {
         // back by the in-launch dependency chain (write-through acknowledgements, arrival counter, flag, poll, bypass
         // loads of u, w: ~2 us per hop through the memory side), so the two-launch path stays the default.
         fused = false;
-        if (const char* e = std::getenv("ADMM_HIP_TALL_FUSED")) fused = use_sym && !shard && std::string(e) == "1";
+        if (const char* e = std::getenv("ADMM_HIP_TALL_FUSED")) {
+            fused = use_sym && !shard && (std::string(e) == "1" || std::string(e) == "2");
+            fused_pre = std::string(e) == "2";
+        }
         if (fused) { fflag.alloc(64 * 16); farrive.alloc(1); }
         x.alloc(ldv); z0.alloc(ldv); z1.alloc(ldv); y0.alloc(ldv); y1.alloc(ldv);
         adj_z.alloc(ldv); adj_y.alloc(ldv); u.alloc(ldv); w.alloc(ldv);
@@ -649,7 +654,8 @@ struct TallPlan final : LassoPlan {
                     TallFused f;
                     f.sy = sy.args(M.get(), ldp, u.get(), w.get(), &ctl.get()[par].done);
                     f.flag = fflag.get(); f.arrive = farrive.get(); f.gen = (int)(g + 1); f.ntail = nwg;
-                    hipExtLaunchKernelGGL(tall_fused_kernel, dim3(nwg + sy.ntiles), dim3(kTailThreads), 0, st, e0, e1, 0, q, par, f);
+                    if (fused_pre) hipExtLaunchKernelGGL(tall_fused_kernel<true>, dim3(nwg + sy.ntiles), dim3(kTailThreads), 0, st, e0, e1, 0, q, par, f);
+                    else hipExtLaunchKernelGGL(tall_fused_kernel<false>, dim3(nwg + sy.ntiles), dim3(kTailThreads), 0, st, e0, e1, 0, q, par, f);
                 } else if (shard && peer_fused) {
                     // this rank's tiles -> its share of (a, b) written into every rank's exchange slot by the reduction
                     // launch itself -> the (replicated) tail waits for the K flags and sums the K slots: three launches,

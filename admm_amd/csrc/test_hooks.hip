@@ -59,6 +59,24 @@ void test_gram(const T* A, int rows, int cols, bool atA, T* G) {
 template void test_gram<float>(const float*, int, int, bool, float*);
 template void test_gram<double>(const double*, int, int, bool, double*);
 
+// y = A' v through the solvers' streaming mat-vec (gemv_t_kernel: contiguous columns, 16 bytes per lane, K-split into row
+// segments + ordered partial sums): A host, rows x cols column-major (ld rows), v length rows, y length cols.
+template <typename T>
+void test_gemv_t(const T* A, int rows, int cols, const T* v, T* y) {
+    require_device();
+    Stream st;
+    const long long lda = round_up(rows, 32), ldy = round_up(cols, 32);
+    DevBuf<T> dA((size_t)lda * cols), dv(lda), dy(ldy);
+    dA.zero(st.s); dv.zero(st.s); dy.zero(st.s);
+    ADMM_HIP_CHECK(hipMemcpy2DAsync(dA.get(), lda * sizeof(T), A, (size_t)rows * sizeof(T), (size_t)rows * sizeof(T), cols, hipMemcpyHostToDevice, st.s));
+    ADMM_HIP_CHECK(hipMemcpyAsync(dv.get(), v, (size_t)rows * sizeof(T), hipMemcpyHostToDevice, st.s));
+    gemv_t_simple<T>(dA.get(), lda, rows, cols, dv.get(), dy.get(), st.s);
+    ADMM_HIP_CHECK(hipMemcpyAsync(y, dy.get(), (size_t)cols * sizeof(T), hipMemcpyDeviceToHost, st.s));
+    st.sync();
+}
+template void test_gemv_t<float>(const float*, int, int, const float*, float*);
+template void test_gemv_t<double>(const double*, int, int, const double*, double*);
+
 // Symmetric inverse of an SPD host matrix (order n, ld n) through the solvers' own path: blocked Cholesky + inverse on
 // the matrix cores (chol_inverse.h) for n >= 256.  via64: the float matrix factorised / inverted in double and rounded once.
 template <typename T>

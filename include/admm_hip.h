@@ -251,6 +251,9 @@ ADMM_HIP_API int admm_hip_test_symv(const float* A, int p, const float* v0, cons
  * Ainv = inverse of the SPD matrix A of order n: precision 0 = float, 1 = double, 2 = float matrix inverted in double
  * and rounded once (ADMM_HIP_INVERSE=f64). */
 ADMM_HIP_API int admm_hip_test_gram(const void* A, int rows, int cols, int atA, int is_double, void* G);
+/* y = A' v with the streaming mat-vec every other product of the solvers uses (X'y, the wide regular step, the consensus /
+ * LAD / BP products, the tall x-update below p = 2048): A HOST rows x cols column-major (leading dimension rows). */
+ADMM_HIP_API int admm_hip_test_gemv_t(const void* A, int rows, int cols, int is_double, const void* v, void* y);
 ADMM_HIP_API int admm_hip_test_spd_inverse(const void* A, int n, int precision, void* Ainv);
 
 #ifdef __cplusplus

@@ -35,7 +35,7 @@ bt = torch.zeros(p, dtype=torch.float64, device=dev); bt[:1000] = torch.rand(100
 y = bt @ xt + torch.randn(n, generator=g, device=dev, dtype=torch.float64)
 torch.cuda.synchronize()
 res = {}
-for val in ("0", "1"):
+for val in ("0", "1", "2"):
     os.environ["ADMM_HIP_TALL_FUSED"] = val
     plan = LassoPlan(admm_lasso(DevicePtr(xt.data_ptr()), DevicePtr(y.data_ptr()), n=n, p=p).penalty(nlambda=100))
     plan.run()
@@ -45,4 +45,4 @@ for val in ("0", "1"):
     res[val] = fit
     print(f"C2 fused={val}: variant {fit.stats['xupdate_variant']} iterations {int(fit.stats['total_iter'])} us/iter {min(ts):.2f} (runs {['%.2f' % t for t in ts]})")
     plan.close()
-print("C2 identical:", np.array_equal(res["0"].beta_dense, res["1"].beta_dense) and list(res["0"].niter) == list(res["1"].niter))
+print("C2 identical:", all(np.array_equal(res["0"].beta_dense, res[v].beta_dense) and list(res["0"].niter) == list(res[v].niter) for v in ("1", "2")))

@@ -73,3 +73,19 @@ def test_inverse_rejects_an_indefinite_matrix():
     with pytest.raises(AdmmHipError) as e:
         _inverse(A, 0)
     assert e.value.code == 5                                          # ADMM_ERR_NOT_SPD (the reference never checks LLT::info())
+
+
+@pytest.mark.parametrize("rows,cols", [(100, 20), (2000, 300), (50000, 700), (1250, 20000), (33, 4097), (100001, 64)])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_gemv_t_vs_numpy(rows, cols, dtype):
+    """The streaming mat-vec (gemv_t_kernel) at tall, wide and ragged shapes: y = A'v against float64."""
+    from admm_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(rows * 7 + cols)
+    A = np.asfortranarray(rng.standard_normal((rows, cols)).astype(dtype))
+    v = rng.standard_normal(rows).astype(dtype)
+    y = np.zeros(cols, dtype=dtype)
+    _lib.check(lib.admm_hip_test_gemv_t(A.ctypes.data, rows, cols, int(dtype == np.float64), v.ctypes.data, y.ctypes.data))
+    ref = A.astype(np.float64).T @ v.astype(np.float64)
+    scale = (np.abs(A.astype(np.float64)).T @ np.abs(v.astype(np.float64))).max()
+    assert np.abs(y - ref).max() / scale < (2e-6 if dtype == np.float32 else 1e-14)
