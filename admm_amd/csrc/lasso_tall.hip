@@ -555,11 +555,12 @@ struct TallPlan final : LassoPlan {
         // ADMM_HIP_PEER_FUSED=0: go through the generic all-reduce of the exchange layer also on the PEER backend
         peer_fused = shard && ci.backend == COMM_PEER;
         if (const char* e = std::getenv("ADMM_HIP_PEER_FUSED")) { if (std::string(e) == "0") peer_fused = false; }
-        // single-launch iteration (single GPU, symmetric x-update): opt-in with ADMM_HIP_TALL_FUSED=1.  Measured on C2
-        // (scripts/fused_check.py): bit-identical, 46.7 us against 46.4 us per iteration for two launches on the same box
-        // (17.0 vs 17.5 us at p = 2300) -- the kernel boundary it removes (1.8 us) and the tail latency it hides are paid
-        // back by the in-launch dependency chain (write-through acknowledgements, arrival counter, flag, poll, bypass
-        // loads of u, w: ~2 us per hop through the memory side), so the two-launch path stays the default.
+        // single-launch iteration (single GPU, symmetric x-update): opt-in with ADMM_HIP_TALL_FUSED=1 (=2: the tiles also
+        // request their first matrix columns before they wait).  Measured on C2 (scripts/fused_check.py, same box, all
+        // bit-identical): two launches 42.1 us per iteration, one launch 44.5 us, with the prefetch 47.1 us -- the kernel
+        // boundary it removes (1.8 us) and the tail latency it hides are paid back by the in-launch dependency chain
+        // (write-through acknowledgements, arrival counter, flag, poll, bypass loads of u, w: ~2 us per hop through the
+        // memory side), and carrying a prefetched chunk into the column loop costs the stream 4 us.  Two launches stay.
         fused = false;
         if (const char* e = std::getenv("ADMM_HIP_TALL_FUSED")) {
             fused = use_sym && !shard && (std::string(e) == "1" || std::string(e) == "2");
