@@ -7,7 +7,10 @@
 // (one float4 per lane) and 32 of the columns.  The column widths are parameters (kSyCW a power of two <= 32 or a
 // multiple of 64).  Measured on C2, same box (round 2): 128-column tiles 35.1 us per launch, 23.2 k ADMM iterations/s;
 // 256-column tiles with 64 columns per wave halve the axpy partial rows (tail 6.6 instead of 7.1 us) but the longer
-// per-wave column loop streams worse: 37.7 us, 22.0 k it/s; 512-column tiles leave too few workgroups: 51 us.  For every element a_ij (i > j) it loads, a wave
+// per-wave column loop streams worse: 37.7 us, 22.0 k it/s; 512-column tiles leave too few workgroups: 51 us.
+// Also measured and rejected (round 2): both right-hand sides as pairs through v_pk_fma_f32 plus separate loop copies for
+// diagonal / interior / ragged tiles (half the FMA instructions, 32 instead of 74 selects per chunk in the hot copy):
+// 36.7 us -- the loop is not VALU-bound, and the scheduling of its 8 loads in flight is what the time depends on.  For every element a_ij (i > j) it loads, a wave
 // does both halves of the symmetric product:
 //     dot  part:  y_j += a_ij v_i   -> per-lane partials of 8 columns at a time, combined across
 //                                      the 64 lanes with a halving butterfly (10 shuffles per 8 columns)
