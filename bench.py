@@ -547,7 +547,10 @@ def main():
                 out["sec_to_eps"] = best["setup_s"] + best["elapsed_s"] / best["steps"]
                 out["roofline"]["note"] = "single-GPU replica kernel; the sharded run's share is in `sharded`"
         if a.cpu_seconds > 0 and world == 1:                # the CPU leg is timed on rank 0 at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(p, a.nlambda, a.cpu_seconds, a.seed)
+            try:
+                out["cpu_baseline"] = cpu_baseline(p, a.nlambda, a.cpu_seconds, a.seed)
+            except Exception as e:                          # noqa: BLE001 -- never lose the GPU line to the CPU leg
+                out["cpu_baseline"] = {"value": None, "unit": "iterations/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(out), flush=True)
     plan.close()
     if multi:
