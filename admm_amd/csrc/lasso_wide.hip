@@ -38,7 +38,7 @@ enum { W_ZERO = 0, W_REG = 1, W_ACT = 2 };
 struct WideCtl {
     double rho, eps_primal, eps_dual;
     float lam; int type;
-    int iter, counter, lam_idx, done, first, pad0, pad1, pad2;
+    int iter, counter, lam_idx, done, first, total, pad1, pad2;      // total: decisions taken so far (index of the trace record)
 };
 
 constexpr int kWideThreads = 256;
@@ -63,6 +63,7 @@ struct WideParams {
     WideCtl* ctl;                         // [2]
     double* P;                            // [nwg_tail][8]: |r|^2, |z_new - z|^2, |Ax|^2, |z_new|^2, |y_new|^2
     float* beta; int* niter; int* done;
+    double* trace; long long trace_cap;   // optional decision records (admm_hip_lasso_plan_trace_*), or NULL
 };
 
 __device__ __forceinline__ bool is_regular_update(unsigned int x) {      // 4^k - 1   ADMMLassoWide.h:121-127
@@ -82,7 +83,7 @@ __device__ __forceinline__ float prox_f(float val, float thresh, float denom, bo
 // The decision for the iteration that just finished and the kind of x-update that runs now: convergence, rho adaptation
 // (ADMMBase.h:85-109), lambda schedule (init_warm), regular / active-set schedule (ADMMLassoWide.h:121-155).  Every wave
 // that calls it reduces the norm partials itself in a fixed order (no LDS, no barrier) and gets the identical result.
-struct WideDecision { WideCtl out; int lam_finished; int niter_val; };
+struct WideDecision { WideCtl out; int lam_finished; int niter_val; double rp, rd; int code; };
 __device__ __forceinline__ WideDecision wide_decide(const WideParams& q, const WideCtl& in, int lane) {
     int lam_finished = -1, niter_val = 0;
     // norm partials of the previous iteration: every wave reduces them itself (fixed order), no LDS, no barrier
@@ -96,9 +97,11 @@ __device__ __forceinline__ WideDecision wide_decide(const WideParams& q, const W
     const double r2 = sums[0], dz2 = sums[1], ax2 = sums[2], z2 = sums[3], y2 = sums[4];
     WideCtl out = in;
     out.first = 0;
+    double tr_rp = 0, tr_rd = 0; int tr_code = ADMM_TRACE_COLD;
     if (!in.first) {
         const double rp = sqrt(r2);                                   // resid_primal = ||Ax + z||       ADMMBase.h:181
         const double rd = in.rho * q.sqrt_gamma * sqrt(dz2);          // rho sqrt(sprad) ||z_new - z||   ADMMLassoWide.h:183-186
+        tr_rp = rp; tr_rd = rd; tr_code = (rp < in.eps_primal && rd < in.eps_dual) ? ADMM_TRACE_CONVERGED : ADMM_TRACE_CONTINUE;
         if (rp < in.eps_primal && rd < in.eps_dual) { lam_finished = in.lam_idx; niter_val = in.iter + 1; }
         else {
             if (in.iter > 3) {                                        // update_rho()  ADMMBase.h:85-109,209-210
@@ -129,8 +132,10 @@ __device__ __forceinline__ WideDecision wide_decide(const WideParams& q, const W
         out.type = (is_regular_update((unsigned)out.counter) && out.lam < q.lambda0) ? W_REG : W_ACT;
         out.counter++;
     }
+    out.total = in.total + 1;
     WideDecision dec;
     dec.out = out; dec.lam_finished = lam_finished; dec.niter_val = niter_val;
+    dec.rp = tr_rp; dec.rd = tr_rd; dec.code = tr_code;
     return dec;
 }
 
@@ -182,6 +187,11 @@ wide_x_kernel(WideParams q, int par) {
         if (lam_finished >= 0) q.niter[lam_finished] = niter_val;
         *outp = out;
         if (out.done) *q.done = 1;
+        if (q.trace != nullptr && in.total < q.trace_cap) {          // what ADMMBase.h:111-146 (print_row, commented out there) would print
+            double* t = q.trace + (size_t)in.total * ADMM_TRACE_FIELDS;
+            t[0] = in.lam_idx; t[1] = in.iter; t[2] = in.eps_primal; t[3] = in.eps_dual; t[4] = dec.rp; t[5] = dec.rd;
+            t[6] = out.rho; t[7] = out.type; t[8] = dec.code; t[9] = in.rho;
+        }
     }
     const bool snap = lam_finished >= 0;                               // get_x() snapshot of the OLD x (Lasso.cpp:119)
     float* bsnap = snap ? q.beta + (size_t)lam_finished * q.p : nullptr;
@@ -503,7 +513,7 @@ __global__ void wide_init_kernel(WideParams q, double rho, float lam0) {
     if (i == 0) {
         WideCtl c;
         c.rho = rho; c.eps_primal = 0; c.eps_dual = 0; c.lam = lam0; c.type = W_REG;
-        c.iter = 0; c.counter = 0; c.lam_idx = 0; c.done = 0; c.first = 1; c.pad0 = c.pad1 = c.pad2 = 0;
+        c.iter = 0; c.counter = 0; c.lam_idx = 0; c.done = 0; c.first = 1; c.total = 0; c.pad1 = c.pad2 = 0;
         q.ctl[0] = c; q.ctl[1] = c;
         *q.done = 0;
     }
@@ -531,6 +541,19 @@ struct WidePlan final : LassoPlan {
     DevBuf<double> P;
     DevBuf<WideCtl> ctl;
     WideParams q{};
+    DevBuf<double> trace;
+    long long trace_cap = 0, trace_n = 0;
+
+    void enable_trace(long long cap) override {
+        trace.alloc((size_t)cap * ADMM_TRACE_FIELDS);
+        trace_cap = cap; trace_n = 0;
+        q.trace = trace.get(); q.trace_cap = cap;
+    }
+    long long read_trace(double* out, long long cap) override {
+        const long long nrec = std::min(std::min(trace_n, trace_cap), cap);
+        if (nrec > 0) ADMM_HIP_CHECK(hipMemcpy(out, trace.get(), (size_t)nrec * ADMM_TRACE_FIELDS * sizeof(double), hipMemcpyDeviceToHost));
+        return nrec;
+    }
 
     WidePlan(DeviceData<float>&& data, const LassoProblem& prob, hipStream_t stream) : d(std::move(data)), pb(prob), st(stream) {
         n = d.n; p = d.p;
@@ -705,6 +728,11 @@ struct WidePlan final : LassoPlan {
             for (int l = 0; l < nlam; ++l) res.beta[(size_t)l * pt1] = has_icpt ? (float)((double)d.meanY - icpt[l]) : 0.f;
         }
         S.total_iter = tot;
+        {   // decisions taken = the cold-start one + one per ADMM iteration
+            WideCtl hc[2];
+            ADMM_HIP_CHECK(hipMemcpy(hc, ctl.get(), sizeof(hc), hipMemcpyDeviceToHost));
+            trace_n = std::max(hc[0].total, hc[1].total);
+        }
         res.stats = S;
     }
 };

@@ -47,6 +47,7 @@ struct ParParams {
     int wide[kParMaxWorkers];      // 1: Woodbury branch, x = (rhs - gout) / rho ; 0: x = gout
     ParCtl* ctl;                   // [2]
     double* P;                     // [nwg][8] per-workgroup partials of the five sums
+    double* trace; long long trace_cap;      // optional decision records (admm_hip_lasso_plan_trace_*), or NULL
     float* beta; int* niter; int* done;
 };
 
@@ -113,9 +114,11 @@ par_z_kernel(ParParams q, int par) {
     ParCtl out = in;
     out.first = 0;
     int lam_finished = -1, niter_val = 0;
+    double tr_rp = 0, tr_rd = 0, tr_code = ADMM_TRACE_COLD;
     if (!in.first) {
         const double rp = sqrt(r2);                                  // sqrt(sum_k |x_k - z|^2)        PADMMBase.h:213
         const double rd = q.rho * sqrt((double)q.K * dz2);           // rho sqrt(K |z_new - z|^2)      PADMMLasso.h:149-152
+        tr_rp = rp; tr_rd = rd; tr_code = (rp < in.eps_primal && rd < in.eps_dual) ? ADMM_TRACE_CONVERGED : ADMM_TRACE_CONTINUE;
         if (rp < in.eps_primal && rd < in.eps_dual) { lam_finished = in.lam_idx; niter_val = in.iter + 1; }
         else {
             out.iter = in.iter + 1;
@@ -135,6 +138,11 @@ par_z_kernel(ParParams q, int par) {
         if (lam_finished >= 0) q.niter[lam_finished] = niter_val;
         *outp = out;
         if (out.done) *q.done = 1;
+        if (q.trace != nullptr && in.total < q.trace_cap) {
+            double* t = q.trace + (size_t)in.total * ADMM_TRACE_FIELDS;
+            t[0] = in.lam_idx; t[1] = in.iter; t[2] = in.eps_primal; t[3] = in.eps_dual; t[4] = tr_rp; t[5] = tr_rd;
+            t[6] = q.rho; t[7] = 0.0; t[8] = tr_code; t[9] = q.rho;
+        }
     }
     const float rho_f = (float)q.rho;
     const double pen = out.lam / (q.rho * (double)q.K);
@@ -215,6 +223,19 @@ struct ParPlan final : LassoPlan {
     DevBuf<double> P, dlam;
     DevBuf<ParCtl> ctl;
     ParParams q{};
+    DevBuf<double> trace;
+    long long trace_cap = 0, trace_n = 0;
+
+    void enable_trace(long long cap) override {
+        trace.alloc((size_t)cap * ADMM_TRACE_FIELDS);
+        trace_cap = cap; trace_n = 0;
+        q.trace = trace.get(); q.trace_cap = cap;
+    }
+    long long read_trace(double* out, long long cap) override {
+        const long long nrec = std::min(std::min(trace_n, trace_cap), cap);
+        if (nrec > 0) ADMM_HIP_CHECK(hipMemcpy(out, trace.get(), (size_t)nrec * ADMM_TRACE_FIELDS * sizeof(double), hipMemcpyDeviceToHost));
+        return nrec;
+    }
 
     ParPlan(DeviceData<float>&& data, const LassoProblem& prob, hipStream_t stream) : d(std::move(data)), pb(prob), st(stream) {
         const int n = d.n;
@@ -361,6 +382,11 @@ struct ParPlan final : LassoPlan {
             tot += res.niter[l];
         }
         S.total_iter = tot;
+        {   // decisions taken = the cold-start one + one per ADMM iteration
+            ParCtl hc[2];
+            ADMM_HIP_CHECK(hipMemcpy(hc, ctl.get(), sizeof(hc), hipMemcpyDeviceToHost));
+            trace_n = std::max(hc[0].total, hc[1].total);
+        }
         res.stats = S;
     }
 };

@@ -36,7 +36,7 @@ struct LassoPlan {
     virtual ~LassoPlan() = default;
     virtual void run(LassoResult& res) = 0;
     // per-decision trace of the iteration control (admm_hip_lasso_plan_trace_*); solvers without one refuse
-    virtual void enable_trace(long long) { throw Error(ADMM_ERR_INVALID_ARG, "this solver records no decision trace (tall Lasso / Elastic net only)"); }
+    virtual void enable_trace(long long) { throw Error(ADMM_ERR_INVALID_ARG, "this solver records no decision trace"); }
     virtual long long read_trace(double*, long long) { return 0; }
 };
 std::unique_ptr<LassoPlan> make_tall_plan(DeviceData<float>&& d, const LassoProblem& pb, hipStream_t st);

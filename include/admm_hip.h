@@ -140,14 +140,16 @@ ADMM_HIP_API int admm_hip_lasso_plan_create(const double* x, const double* y, in
 ADMM_HIP_API int admm_hip_lasso_plan_run(admm_hip_plan* plan, double* lambda_out, float* beta_out, int* niter_out, admm_stats* stats);
 ADMM_HIP_API int admm_hip_lasso_plan_destroy(admm_hip_plan* plan);
 
-/* Decision trace of a prepared tall Lasso / Elastic-net problem: what the reference's commented-out iteration table
- * (print_row, FADMMBase.h:135-170) would print, recorded on the device by the iteration control itself, one record
+/* Decision trace of a prepared Lasso-family problem (tall, wide and consensus solvers): what the reference's commented-out iteration table
+ * (print_row, FADMMBase.h:135-170, ADMMBase.h:111-146) would print, recorded on the device by the iteration control itself, one record
  * per decision (the cold-start decision first, then one per ADMM iteration, over all lambdas of a run in order).
  * enable() before run(); read() afterwards returns min(records of the last run, capacity, cap_records) records of
  * ADMM_TRACE_FIELDS doubles:
  *   [0] lambda index  [1] iteration i within the lambda  [2] eps_primal  [3] eps_dual  (the thresholds iteration i was tested against)
  *   [4] resid_primal  [5] resid_dual  [6] c = rho r_p^2 + rho ||z - adj_z||^2 (0 when converged)  [7] c_old (adj_c before)
  *   [8] outcome ADMM_TRACE_*  [9] rho
+ * Wide solver (ADMMBase::solve, rho adaptation ADMMBase.h:85-109): [6] rho AFTER this decision's adaptation, [7] kind of
+ * the x-update that follows (0 zero, 1 regular, 2 active set), [9] rho before; consensus solver: [6] = [9] = rho, [7] = 0.
  * The parity tests use it to show that a lambda whose iteration count differs from the oracle's diverged at a
  * threshold test decided inside rounding noise, instead of excusing count differences wholesale. */
 #define ADMM_TRACE_FIELDS 10
@@ -155,6 +157,7 @@ ADMM_HIP_API int admm_hip_lasso_plan_destroy(admm_hip_plan* plan);
 #define ADMM_TRACE_CONVERGED 0      /* r_p < eps_p and r_d < eps_d  (FADMMBase.h:213-217,237-238) */
 #define ADMM_TRACE_ACCELERATE 1     /* c < 0.999 c_old              (FADMMBase.h:243-249) */
 #define ADMM_TRACE_RESTART 2        /* otherwise                    (FADMMBase.h:250-256) */
+#define ADMM_TRACE_CONTINUE 1       /* wide / consensus solvers (no acceleration): not converged    (ADMMBase.h:206-207, PADMMBase.h:230-231) */
 ADMM_HIP_API int admm_hip_lasso_plan_trace_enable(admm_hip_plan* plan, long long capacity_records);
 ADMM_HIP_API int admm_hip_lasso_plan_trace_read(admm_hip_plan* plan, double* out, long long cap_records, long long* nrecords_out);
 

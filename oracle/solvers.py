@@ -58,6 +58,36 @@ class FollowMismatch(AssertionError):
     """Follow mode: the followed execution took a decision this run cannot explain as a near-tie."""
 
 
+def _ulp_norm(v, T, extra=0.0):
+    """|| ulp(|v| + extra) ||_2: what a vector's norm-type functionals move by when every entry moves by one ulp."""
+    return float(np.linalg.norm(np.spacing((np.abs(v) + T(extra)).astype(T)).astype(np.float64)))
+
+
+def _stop_ulps(rp, eps_p, n_p, rd, eps_d, n_d, own_converged):
+    """How many ulps of rounding (of the iterates) separate this run's stopping test from the opposite outcome."""
+    tiny = 1e-300
+    gp, gd = rp - eps_p, rd - eps_d                      # >= 0 means "not converged"
+    if not own_converged:                                 # they stopped, this run did not: both residuals must come under
+        return max(gp / max(n_p, tiny), gd / max(n_d, tiny), 0.0)
+    return min(-gp / max(n_p, tiny), -gd / max(n_d, tiny))    # this run stopped, they did not: one residual must reach its threshold
+
+
+def _rho_candidates(rho, rp, eps_p, n_p, rd, eps_d, n_d, band):
+    """Every rho the adaptation rule (FADMMBase.h:109-133 == ADMMBase.h:85-109) can produce when r_p and r_d move by up to
+    `band` ulps of rounding each (the rule is monotone in both, so the corners suffice)."""
+    out = set()
+    for dp in (-1.0, 0.0, 1.0):
+        for dd in (-1.0, 0.0, 1.0):
+            class _S:
+                pass
+            t = _S()
+            t.rho, t.eps_primal, t.eps_dual = rho, eps_p, eps_d
+            t.resid_primal, t.resid_dual = max(rp + dp * band * n_p, 0.0), max(rd + dd * band * n_d, 0.0)
+            _rho_rule(t)
+            out.add(t.rho)
+    return out
+
+
 class FADMM:
     """Goldstein fast ADMM with restart; subclasses define next_x/next_z/residual."""
 
@@ -239,7 +269,22 @@ class LassoTall(FADMM):
 
 
 class ADMMPlain:
-    """ADMMBase::solve, ADMMBase.h:192-216 (used by the wide solver)."""
+    """ADMMBase::solve, ADMMBase.h:192-216 (used by the wide solver).  `trace` / `follow` as in FADMM: records in the
+    layout of include/admm_hip.h (wide flavour: [6] rho after the adaptation, [8] 0 converged / 1 continue, [9] rho before);
+    in follow mode the followed run's stopping outcome and adapted rho are taken only where this run's own residuals are
+    within `follow_band` ulps of rounding of producing them."""
+    trace = None
+    follow = None
+    follow_band = 8.0
+    forced = None
+    ndecisions = 0
+    lam_idx = 0
+
+    def _noise(self):
+        """One-ulp noise floors of r_p = ||Ax + z|| and r_d = rho sqrt(gamma) ||z_new - z|| (ADMMLassoWide.h:166-186)."""
+        uax = _ulp_norm(self.cache_Ax, F)
+        uz = _ulp_norm(self.aux_z, F)
+        return np.hypot(uax, uz), self.rho * np.float64(F(np.sqrt(self.sprad))) * 2.0 * uz
 
     def solve(self, maxit):
         for i in range(maxit):
@@ -252,10 +297,39 @@ class ADMMPlain:
             r = self.next_residual()
             self.resid_primal = np.float64(F(np.linalg.norm(r)))
             self.dual_y = (self.dual_y + F(self.rho) * r).astype(F)
-            if self.resid_primal < self.eps_primal and self.resid_dual < self.eps_dual:
+            converged = self.resid_primal < self.eps_primal and self.resid_dual < self.eps_dual
+            rho_in = self.rho
+            self.ndecisions += 1
+            g = None
+            if self.follow is not None:
+                g = next(self.follow)
+                if int(g[0]) != self.lam_idx or int(g[1]) != i:
+                    raise FollowMismatch(f"followed trace is at (lambda {int(g[0])}, iteration {int(g[1])}), this run at ({self.lam_idx}, {i})")
+                n_p, n_d = self._noise()
+                if (int(g[8]) == 0) != converged:
+                    ulps = _stop_ulps(self.resid_primal, self.eps_primal, n_p, self.resid_dual, self.eps_dual, n_d, converged)
+                    rec = dict(record=self.ndecisions - 1, lam=self.lam_idx, iter=i, kind="stop", ulps=float(ulps))
+                    if ulps > self.follow_band:
+                        raise FollowMismatch(f"decision differs beyond rounding noise: {rec}")
+                    self.forced.append(rec)
+                    converged = int(g[8]) == 0
+            if converged:
+                if self.trace is not None:
+                    self.trace.append((self.lam_idx, i, self.eps_primal, self.eps_dual, self.resid_primal, self.resid_dual, self.rho, 0, 0, rho_in))
                 return i + 1
             if i > 3:
                 _rho_rule(self)
+                # the two executions' rho differ in the last digits from the start (their Lanczos values do): compare the
+                # MULTIPLIER this decision applied (1, 2, 1/2, 1.2, 1/1.2 and their products), not rho itself
+                if g is not None and abs(self.rho / rho_in - g[6] / g[9]) > 1e-9:
+                    cands = _rho_candidates(rho_in, self.resid_primal, self.eps_primal, n_p, self.resid_dual, self.eps_dual, n_d, self.follow_band)
+                    if not any(abs(c / rho_in - g[6] / g[9]) <= 1e-9 for c in cands):
+                        raise FollowMismatch(f"rho adaptation differs beyond rounding noise at (lambda {self.lam_idx}, iteration {i}): "
+                                             f"x{self.rho / rho_in} here, x{g[6] / g[9]} followed, reachable {sorted(c / rho_in for c in cands)}")
+                    self.forced.append(dict(record=self.ndecisions - 1, lam=self.lam_idx, iter=i, kind="rho", ulps=float(self.follow_band)))
+                    self.rho = rho_in * float(g[6] / g[9])
+            if self.trace is not None:
+                self.trace.append((self.lam_idx, i, self.eps_primal, self.eps_dual, self.resid_primal, self.resid_dual, self.rho, 0, 1, rho_in))
         return maxit + 1
 
 
@@ -444,9 +518,35 @@ class PADMMLasso:
                 coll += np.float64(_sqnorm(r, F))
                 self.y[k] = (self.y[k] + F(self.rho) * r).astype(F)
             resid_primal = np.sqrt(coll)
-            if resid_primal < eps_primal and resid_dual < eps_dual:
+            converged = resid_primal < eps_primal and resid_dual < eps_dual
+            self.ndecisions += 1
+            if self.follow is not None:
+                g = next(self.follow)
+                if int(g[0]) != self.lam_idx or int(g[1]) != it:
+                    raise FollowMismatch(f"followed trace is at (lambda {int(g[0])}, iteration {int(g[1])}), this run at ({self.lam_idx}, {it})")
+                if (int(g[8]) == 0) != converged:
+                    pen = abs(float(self.lam)) / (self.rho * K)
+                    uz = _ulp_norm(self.aux_z, F, pen)
+                    n_p = float(np.sqrt(sum(_ulp_norm(x, F) ** 2 for x in self.x) + K * uz ** 2))
+                    n_d = self.rho * np.sqrt(K) * 2.0 * uz
+                    ulps = _stop_ulps(resid_primal, eps_primal, n_p, resid_dual, eps_dual, n_d, converged)
+                    rec = dict(record=self.ndecisions - 1, lam=self.lam_idx, iter=it, kind="stop", ulps=float(ulps))
+                    if ulps > self.follow_band:
+                        raise FollowMismatch(f"decision differs beyond rounding noise: {rec}")
+                    self.forced.append(rec)
+                    converged = int(g[8]) == 0
+            if self.trace is not None:
+                self.trace.append((self.lam_idx, it, eps_primal, eps_dual, resid_primal, resid_dual, self.rho, 0, 0 if converged else 1, self.rho))
+            if converged:
                 return it + 1
         return maxit + 1
+
+    trace = None
+    follow = None
+    follow_band = 8.0
+    forced = None
+    ndecisions = 0
+    lam_idx = 0
 
     def get_coef(self):
         return self.aux_z

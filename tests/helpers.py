@@ -20,60 +20,6 @@ def synth_lasso(n, p, m, seed=123, sd=2.0):
     return x, y
 
 
-def exact_path_optimum(detail, lam_user, alpha=None):
-    """Exact minimiser of the reference's objective on the oracle's standardised data (float64
-    coordinate descent to 1e-13), mapped back with DataStd.recover: the yardstick for lambdas where
-    the ADMM stopping rule is fragile.  Objective: 1/2||y - X b||^2 + lam_int * (alpha |b|_1 +
-    (1-alpha)/2 |b|^2), lam_int = lam_user * n / scaleY (Lasso.cpp:99, ADMMEnet.h:24-40)."""
-    from sklearn.linear_model import ElasticNet, Lasso
-    solver, std = detail["solver"], detail["std"]
-    X = np.asarray(solver.X, dtype=np.float64)
-    Y = np.asarray(solver.Y, dtype=np.float64)
-    n = X.shape[0]
-    out = []
-    for lu in np.atleast_1d(lam_user):
-        li = float(np.float32(lu * n / np.float64(std.scaleY)))
-        if alpha is None:
-            m = Lasso(alpha=li / n, fit_intercept=False, tol=1e-13, max_iter=200000)
-        else:
-            m = ElasticNet(alpha=li / n, l1_ratio=float(alpha), fit_intercept=False, tol=1e-13, max_iter=200000)
-        m.fit(X, Y)
-        b0, coef = std.recover(m.coef_.astype(std.T))
-        out.append(np.concatenate([[b0], coef]).astype(np.float64))
-    return np.array(out).T
-
-
-def assert_path_parity(beta_gpu, niter_gpu, ref, detail, tol=1e-4, alpha=None, n_tight_first=5):
-    """Column-wise parity with the oracle.  A column must match to `tol` (norm-wise relative);
-    the only accepted exception is a lambda where ADMM's loose stopping rule fired at a different
-    iteration (counts differ by more than 2 there or at an earlier lambda of the warm-started
-    path) -- there both are valid outputs of the reference's algorithm under rounding-level
-    perturbation (the CPU oracle itself moves by this much when its Cholesky solve is replaced by
-    an explicit inverse), so the GPU solution is then held to the exact optimum: it may not be
-    further from it than twice the oracle's own worst column on the same path (the reference's
-    accuracy: README.md:238-242,285-289 report 3e-4 .. 2e-3 against glmnet).  The first
-    `n_tight_first` columns must be tight."""
-    nl = beta_gpu.shape[1]
-    ng = np.asarray(niter_gpu, dtype=int)
-    nr = np.asarray(ref["niter"], dtype=int)
-    loose = []
-    for j in range(nl):
-        e = relerr(beta_gpu[:, j], ref["beta"][:, j])
-        if e < tol:
-            continue
-        assert j >= n_tight_first, (j, e)
-        assert np.abs(ng[:j + 1] - nr[:j + 1]).max() > 2, (j, e, ng, nr)
-        loose.append(j)
-    if loose:
-        exact = exact_path_optimum(detail, ref["lambda"], alpha)
-        # the oracle's own worst distance to the optimum along this path = the solver's accuracy here
-        worst_ref = max(relerr(ref["beta"][:, j], exact[:, j]) for j in range(1, nl))
-        for j in loose:
-            eg = relerr(beta_gpu[:, j], exact[:, j])
-            assert eg <= max(2 * worst_ref, tol), (j, eg, worst_ref)
-    return loose
-
-
 # ---------------------------------------------------------------------------------------------------------------
 # Tall path: parity judged on the decision trace, the oracle FOLLOWING the GPU through near-ties.
 #
@@ -107,9 +53,10 @@ def traced_fit(model, capacity=1 << 18):
     return fit, trace
 
 
-def oracle_following(trace, x, y, lam, nlambda, lmin_ratio, standardize, intercept, opts, alpha=None, mode="llt32", band=8.0):
-    """The oracle (x-update rounding `mode`) following the decisions of `trace` (a libadmm_hip trace or another
-    oracle's).  Returns (result dict, forced decisions, number of decisions consumed)."""
+def oracle_following(trace, x, y, lam, nlambda, lmin_ratio, standardize, intercept, opts, alpha=None, mode="llt32", band=8.0, nthread=None):
+    """The oracle (x-update rounding `mode`, tall solver only) following the decisions of `trace` (a libadmm_hip trace or
+    another oracle's); tall, wide (n <= p) or -- with nthread -- consensus solver, as the reference would dispatch.
+    Returns (result dict, forced decisions, number of decisions consumed)."""
     from oracle import entry
     from oracle.variants import tall_variant
     t = np.asarray(trace, dtype=np.float64)
@@ -117,11 +64,35 @@ def oracle_following(trace, x, y, lam, nlambda, lmin_ratio, standardize, interce
         t = t[1:]                                       # libadmm_hip's cold-start record
     d = {"follow": t, "follow_band": band}
     with tall_variant(mode):
-        if alpha is None:
+        if nthread is not None:
+            ref = entry.admm_parlasso(x, y, lam, nlambda, lmin_ratio, standardize, intercept, nthread, opts, d)
+        elif alpha is None:
             ref = entry.admm_lasso(x, y, lam, nlambda, lmin_ratio, standardize, intercept, opts, d)
         else:
             ref = entry.admm_enet(x, y, lam, nlambda, lmin_ratio, standardize, intercept, alpha, opts, d)
     return ref, d["forced"], d["solver"].ndecisions
+
+
+def assert_followed_parity(beta, niter, trace, problem, tol=1e-4, band=8.0, label=""):
+    """Wide / consensus solvers (no rounding variants of the x-update there): the oracle follows the GPU through
+    rounding-level near-ties of the stopping test and of the rho adaptation only; iteration counts identical for every
+    lambda and every beta column within `tol`."""
+    ref, forced, ndec = oracle_following(trace, band=band, **problem)
+    t = np.asarray(trace)
+    nrec = len(t) - (1 if len(t) and t[0, 8] == -1 else 0)
+    assert ndec == nrec, (label, "the oracle consumed a different number of decisions than the GPU took", ndec, nrec)
+    ng, nr = np.asarray(niter, dtype=int), np.asarray(ref["niter"], dtype=int)
+    assert np.array_equal(ng, nr), (label, ng, nr)
+    nl = beta.shape[1]
+    floor = 1e-2 * float(np.abs(ref["beta"]).max())          # as in assert_tall_parity
+    errs = [col_err(beta[:, j], ref["beta"][:, j], floor) for j in range(nl)]
+    nstop = sum(1 for f in forced if f["kind"] == "stop")
+    fm = max([f["ulps"] for f in forced if f["kind"] == "stop"], default=0.0)
+    print(f"[parity {label}] {nrec} decisions, {nstop} stopping near-ties (largest needs {fm:.2f} ulps) and {len(forced) - nstop} rho near-ties "
+          f"taken from the GPU; niter identical; max beta err {max(errs):.2e}")
+    bad = [(j, e) for j, e in enumerate(errs) if e >= tol]
+    assert not bad, (label, bad)
+    return dict(forced=forced, max_err=max(errs), errs=errs, ref=ref)
 
 
 def col_err(a, b, floor):
@@ -139,7 +110,9 @@ def assert_tall_parity(beta, niter, trace, problem, tol=1e-4, factor=5.0, band=8
     ng, nr = np.asarray(niter, dtype=int), np.asarray(ref["niter"], dtype=int)
     assert np.array_equal(ng, nr), (label, ng, nr)                               # R2
     nl = beta.shape[1]
-    floor = 1e-3 * float(np.abs(ref["beta"]).max())          # null / tiny columns are measured on the scale of the path
+    # null / tiny columns (lambda_max: the coordinate attaining max|X'y| sits exactly on the soft-threshold and may
+    # survive with a value of 1e-7 of the path's scale on one side) are measured against 1 % of the path's largest coefficient
+    floor = 1e-2 * float(np.abs(ref["beta"]).max())
     errs = [col_err(beta[:, j], ref["beta"][:, j], floor) for j in range(nl)]
     loose, yard = [], 0.0
     if max(errs) >= tol:                                                         # R3

@@ -1,36 +1,44 @@
 """GPU: randomised small problems through all five entry points vs the oracle, plus the two regressions the
 sweep found (tests/tools/fuzz_parity.py is the verbose version of the same sweep).
 
-Acceptance per case: beta within 1e-3 (norm-wise, null columns measured on the scale of the path) OR the
-iteration counts differ by more than 2 -- ADMM's stopping rule and the rho adaptation take discrete decisions,
-so a rounding-level difference can move a run to another valid outcome of the same algorithm (the oracle
-itself jumps between the same outcomes when its input is perturbed by 1e-15).  Everything must be finite."""
+Lasso family (tall, wide, elastic net, consensus): judged on the decision trace -- the oracle follows the GPU through
+rounding-level near-ties only, iteration counts identical, every column within 1e-4 (tests/helpers.py).  LAD / BP (no
+trace): beta within 1e-3 OR the iteration counts differ by more than 2 (their rho adaptation takes discrete decisions; the
+oracle itself jumps between the same outcomes when its input is perturbed by 1e-15).  Everything must be finite."""
 import numpy as np
 import pytest
 
 from fuzz_cases import cases, medium_cases
-from helpers import assert_tall_parity, relerr, traced_fit
+from helpers import assert_followed_parity, assert_tall_parity, relerr, traced_fit
 
 pytestmark = pytest.mark.gpu
 
 
-def _run_case(cs):
-    from admm_amd import admm_bp, admm_enet, admm_lad, admm_lasso
-    from admm_amd._lib import check
+def _run_dense_case(cs):
+    """LAD / BP (no decision trace there): beta within 1e-3 or the iteration counts differ by more than 2."""
+    from admm_amd import admm_bp, admm_lad
+    from oracle import entry
+    kind, x, y, icpt = (cs[k] for k in ("kind", "x", "y", "icpt"))
+    if kind == "lad":
+        fit = admm_lad(x, y, icpt).fit()
+        ref = entry.admm_lad(x, y, icpt, entry.LAD_OPTS)
+        bg = np.asarray(fit.beta)
+    else:
+        fit = admm_bp(x, y).fit()
+        ref = entry.admm_bp(x, y, entry.BP_OPTS)
+        bg = fit.beta.toarray().ravel()
+    if int(ref["niter"]) > 10000 and int(fit.niter) > 10000:     # neither converged within maxit: nothing to compare
+        return 0.0, 0, bg
+    return relerr(bg, ref["beta"]), abs(int(fit.niter) - int(ref["niter"])), bg
+
+
+def _run_lasso_case(cs):
+    """Lasso family (tall, wide, elastic net, consensus) through the prepared-problem entry points with the decision
+    trace; the oracle follows the GPU through rounding-level near-ties only; counts identical, every column 1e-4 (tall:
+    or within the oracle's own rounding drift where the reference's formula loses the digits).  Returns the report."""
+    from admm_amd import admm_enet, admm_lasso
     from oracle import entry
     kind, x, y, n, p, icpt, stdz = (cs[k] for k in ("kind", "x", "y", "n", "p", "icpt", "stdz"))
-    if kind in ("lad", "bp"):
-        if kind == "lad":
-            fit = admm_lad(x, y, icpt).fit()
-            ref = entry.admm_lad(x, y, icpt, entry.LAD_OPTS)
-            bg = np.asarray(fit.beta)
-        else:
-            fit = admm_bp(x, y).fit()
-            ref = entry.admm_bp(x, y, entry.BP_OPTS)
-            bg = fit.beta.toarray().ravel()
-        if int(ref["niter"]) > 10000 and int(fit.niter) > 10000:     # neither converged within maxit: nothing to compare
-            return 0.0, 0, bg
-        return relerr(bg, ref["beta"]), abs(int(fit.niter) - int(ref["niter"])), bg
     opts = dict(entry.LASSO_OPTS)
     if kind == "par":
         opts["maxit"] = 500
@@ -41,36 +49,39 @@ def _run_case(cs):
         lam = np.sort(ref0["lambda"][0] * cs["ulam"])[::-1]
     nl = cs["nl"]
     if kind.startswith("enet"):
-        m = admm_enet(x, y, icpt, stdz).penalty(lam, nlambda=nl, alpha=cs["alpha"])
-        fit = m.fit()
-        bg, ng = fit.beta_dense, fit.niter
-        ref = entry.admm_enet(x, y, lam, nl, lmr, stdz, icpt, cs["alpha"], opts)
-    elif kind == "par":
-        m = admm_lasso(x, y, icpt, stdz).penalty(lam, nlambda=nl).opts(maxit=opts["maxit"])
-        m.nthread = cs["K"]
-        lib, head, tail, lam_out, bg, ng, stats, keep = m._common()
-        check(lib.admm_hip_parlasso(*head, cs["K"], *tail))
-        ref = entry.admm_parlasso(x, y, lam, nl, lmr, stdz, icpt, cs["K"], opts)
+        m = admm_enet(x, y, icpt, stdz).penalty(lam, nlambda=nl, lambda_min_ratio=lmr, alpha=cs["alpha"])
     else:
-        fit = admm_lasso(x, y, icpt, stdz).penalty(lam, nlambda=nl).fit()
-        bg, ng = fit.beta_dense, fit.niter
-        ref = entry.admm_lasso(x, y, lam, nl, lmr, stdz, icpt, opts)
-    floor = 1e-3 * float(np.abs(ref["beta"]).max())
-    e = max(float(np.abs(bg[:, j].astype(np.float64) - ref["beta"][:, j]).max()) / max(float(np.abs(ref["beta"][:, j]).max()), floor, 1e-300)
-            for j in range(ref["beta"].shape[1]))
-    return e, int(np.abs(np.asarray(ng, int) - np.asarray(ref["niter"], int)).max()), bg
+        m = admm_lasso(x, y, icpt, stdz).penalty(lam, nlambda=nl, lambda_min_ratio=lmr).opts(maxit=opts["maxit"])
+        if kind == "par":
+            m.nthread = cs["K"]
+    fit, trace = traced_fit(m, capacity=max(nl, 1) * (opts["maxit"] + 2) + 8)
+    assert np.all(np.isfinite(fit.beta_dense)), (cs["c"], kind)
+    prob = dict(x=x, y=y, lam=lam, nlambda=nl, lmin_ratio=lmr, standardize=stdz, intercept=icpt, opts=opts, alpha=cs["alpha"])
+    label = f"small {cs['c']} {kind} n={n} p={p} std={int(stdz)} icpt={int(icpt)} scale={cs['scale']:g}"
+    if kind == "par":
+        if cs["K"] <= 1:                 # nthread = 1 is the serial solver in the R wrapper (R/30_admm_lasso.R:136-147)
+            return None
+        prob["nthread"] = cs["K"]
+    if n > p and kind != "par":
+        return assert_tall_parity(fit.beta_dense, fit.niter, trace, prob, 1e-4, label=label)
+    return assert_followed_parity(fit.beta_dense, fit.niter, trace, prob, 1e-4, label=label)
 
 
 def test_random_small_problems_match_the_oracle():
-    bad, nflip = [], 0
+    bad, nflip, nloose = [], 0, 0
     for cs in cases(48, 7):
-        e, dn, bg = _run_case(cs)
-        assert np.all(np.isfinite(bg)), (cs["c"], cs["kind"])
-        nflip += dn > 2
-        if e > 1e-3 and dn <= 2:
-            bad.append((cs["c"], cs["kind"], e, dn))
+        if cs["kind"] in ("lad", "bp"):
+            e, dn, bg = _run_dense_case(cs)
+            assert np.all(np.isfinite(bg)), (cs["c"], cs["kind"])
+            nflip += dn > 2
+            if e > 1e-3 and dn <= 2:
+                bad.append((cs["c"], cs["kind"], e, dn))
+        else:
+            rep = _run_lasso_case(cs)
+            nloose += len(rep.get("loose", [])) if rep else 0
     assert not bad, bad
-    assert nflip <= 8, nflip                                      # count flips stay the exception (6 of 48 when written)
+    assert nflip <= 4, nflip                                      # LAD / BP only (rho adaptation flips)
+    assert nloose <= 6, nloose
 
 
 def _medium_tall(cs):

@@ -22,17 +22,17 @@ def test_readme_paradmm_column(readme_lasso_xy):
 
 @pytest.mark.parametrize("n,p,K", [(1500, 120, 3), (403, 300, 4), (900, 250, 2)])
 def test_parlasso_path_vs_oracle(n, p, K):
-    """Tall blocks (Cholesky branch), wide blocks (Woodbury branch, PADMMLasso.h:26-29), ragged last block."""
+    """Tall blocks (Cholesky branch), wide blocks (Woodbury branch, PADMMLasso.h:26-29), ragged last block -- judged on
+    the decision trace (the oracle follows the GPU through rounding-level near-ties of the stopping test only)."""
     from admm_amd import admm_lasso
+    from helpers import assert_followed_parity, traced_fit
     from oracle import entry
     x, y = synth_lasso(n, p, max(3, p // 10), seed=17)
-    fit = admm_lasso(x, y).penalty(nlambda=6, lambda_min_ratio=0.01).parallel(K).opts(maxit=3000).fit()
+    fit, trace = traced_fit(admm_lasso(x, y).penalty(nlambda=6, lambda_min_ratio=0.01).parallel(K).opts(maxit=3000))
     opts = dict(entry.LASSO_OPTS, maxit=3000)
-    ref = entry.admm_parlasso(x, y, None, 6, 0.01, True, True, K, opts)
-    assert np.allclose(fit.lambda_, ref["lambda"], rtol=1e-5)
-    for j in range(6):
-        assert relerr(fit.beta_dense[:, j], ref["beta"][:, j]) < 2 * TOL, j
-    assert np.abs(fit.niter.astype(int) - ref["niter"].astype(int)).max() <= np.maximum(5, 0.05 * ref["niter"].max())
+    prob = dict(x=x, y=y, lam=None, nlambda=6, lmin_ratio=0.01, standardize=True, intercept=True, opts=opts, alpha=None, nthread=K)
+    rep = assert_followed_parity(fit.beta_dense, fit.niter, trace, prob, 2 * TOL, label=f"consensus n={n} p={p} K={K}")
+    assert np.allclose(fit.lambda_, rep["ref"]["lambda"], rtol=1e-5)
 
 
 def test_dist_entry_point_single_rank_matches_single_process():

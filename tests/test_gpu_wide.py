@@ -6,41 +6,51 @@ against glmnet), so the oracle -- pinned on the five README vectors with which i
 import numpy as np
 import pytest
 
-from helpers import assert_path_parity, relerr, synth_lasso
+from helpers import assert_followed_parity, relerr, synth_lasso, traced_fit
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
+def _problem(x, y, nl, lmr, alpha=None):
+    from oracle import entry
+    return dict(x=x, y=y, lam=None, nlambda=nl, lmin_ratio=lmr, standardize=True, intercept=True, opts=entry.LASSO_OPTS, alpha=alpha)
+
+
 @pytest.mark.parametrize("n,p,m", [(300, 2000, 20), (257, 1031, 10), (500, 500, 15)])
 def test_wide_lasso_path_vs_oracle(n, p, m):
+    """12-lambda path judged on the decision trace: the oracle follows the GPU through rounding-level near-ties of the
+    stopping test and of the rho adaptation only (helpers.assert_followed_parity); counts identical, every column 1e-4."""
+    from admm_amd import admm_lasso
+    x, y = synth_lasso(n, p, m, seed=29)
+    lmr = 0.01 if n < p else 1e-4                                # R default (R/30_admm_lasso.R:43)
+    fit, trace = traced_fit(admm_lasso(x, y).penalty(nlambda=12, lambda_min_ratio=lmr))
+    assert fit.stats["branch"] == 1
+    rep = assert_followed_parity(fit.beta_dense, fit.niter, trace, _problem(x, y, 12, lmr), TOL, label=f"wide n={n} p={p}")
+    ref = rep["ref"]
+    assert np.allclose(fit.lambda_, ref["lambda"], rtol=1e-5)
+    # support agreement
+    for j in range(12):
+        assert np.array_equal(np.abs(fit.beta_dense[1:, j]) > 1e-5, np.abs(ref["beta"][1:, j]) > 1e-5), j
+    fit2 = admm_lasso(x, y).penalty(nlambda=12, lambda_min_ratio=lmr).fit()
+    assert np.array_equal(fit2.beta_dense, fit.beta_dense) and list(fit2.niter) == list(fit.niter)
+
+
+def test_wide_spectral_radius_estimate():
     from admm_amd import admm_lasso
     from oracle import entry
-    x, y = synth_lasso(n, p, m, seed=29)
-    fit = admm_lasso(x, y).penalty(nlambda=12).fit()
+    x, y = synth_lasso(300, 2000, 20, seed=29)
+    fit = admm_lasso(x, y).penalty(nlambda=2, lambda_min_ratio=0.5).fit()
     d = {}
-    lmr = 0.01 if n < p else 1e-4                                # R default (R/30_admm_lasso.R:43)
-    ref = entry.admm_lasso(x, y, None, 12, lmr, True, True, entry.LASSO_OPTS, d)
-    assert fit.stats["branch"] == 1
-    assert np.allclose(fit.lambda_, ref["lambda"], rtol=1e-5)
+    entry.admm_lasso(x, y, None, 2, 0.5, True, True, entry.LASSO_OPTS, d)
     assert abs(fit.stats["eig_est"] - float(d["solver"].sprad)) < 1e-4 * float(d["solver"].sprad)
-    loose = assert_path_parity(fit.beta_dense, fit.niter, ref, d, TOL, n_tight_first=4)
-    assert len(loose) <= 4
-    # support agreement on the tight columns
-    for j in range(12):
-        if j not in loose:
-            assert np.array_equal(np.abs(fit.beta_dense[1:, j]) > 1e-5, np.abs(ref["beta"][1:, j]) > 1e-5), j
 
 
 def test_wide_enet_path_vs_oracle():
     from admm_amd import admm_enet
-    from oracle import entry
     x, y = synth_lasso(250, 900, 12, seed=31)
-    fit = admm_enet(x, y).penalty(nlambda=10, alpha=0.5).fit()
-    d = {}
-    ref = entry.admm_enet(x, y, None, 10, 0.01, True, True, 0.5, entry.LASSO_OPTS, d)
-    loose = assert_path_parity(fit.beta_dense, fit.niter, ref, d, TOL, alpha=0.5, n_tight_first=4)
-    assert len(loose) <= 3
+    fit, trace = traced_fit(admm_enet(x, y).penalty(nlambda=10, lambda_min_ratio=0.01, alpha=0.5))
+    assert_followed_parity(fit.beta_dense, fit.niter, trace, _problem(x, y, 10, 0.01, alpha=0.5), TOL, label="wide enet")
 
 
 def test_wide_user_lambda_and_maxit():
