@@ -217,6 +217,18 @@ class ADMM_Enet(ADMM_Lasso):
         return ADMM_Lasso_fit(lam_out, beta, niter, stats.as_dict())
 
 
+def _trace_buffers(maxit):
+    cap = maxit + 8 if maxit > 0 else 0
+    return np.zeros((max(cap, 1), _lib.TRACE_FIELDS), dtype=np.float64), ctypes.c_longlong(0)
+
+
+def _trace_args(tr, ntr):
+    cap = tr.shape[0] if tr.shape[0] > 1 else 0
+    if cap == 0:
+        return None, 0, None
+    return tr.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), cap, ctypes.byref(ntr)
+
+
 class ADMM_BP_fit:
     def __init__(self, beta, niter, stats):
         self.beta = beta
@@ -266,7 +278,8 @@ class ADMM_BP:
         self.rho = 1.0 if rho is None else float(rho)
         return self
 
-    def fit(self):
+    def fit(self, trace=False):
+        """trace=True also returns the decision trace (fit.trace, layout of include/admm_hip.h ADMM_TRACE_*)."""
         if getattr(self, "nthread", 1) > 1:
             _stop('C symbol name "admm_parbp" not in DLL for package "ADMM"')     # R/10_admm_bp.R:111: the reference's own failure
         lib = _lib.load()
@@ -278,10 +291,13 @@ class ADMM_BP:
         beta = np.zeros(self.p, dtype=np.float64)
         niter = np.zeros(1, dtype=np.int32)
         stats = AdmmStats()
-        check(lib.admm_hip_bp(xp, yp, self.n, self.p, xmem, ctypes.byref(o),
-                              beta.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
-                              niter.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), ctypes.byref(stats)))
-        return ADMM_BP_fit(sp.csc_matrix(beta.reshape(-1, 1)), int(niter[0]), stats.as_dict())   # dgCMatrix p x 1 (BP.cpp:38-43)
+        tr, ntr = _trace_buffers(self.maxit if trace else 0)
+        check(lib.admm_hip_bp_traced(xp, yp, self.n, self.p, xmem, ctypes.byref(o),
+                                     beta.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                     niter.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), ctypes.byref(stats), *_trace_args(tr, ntr)))
+        fit = ADMM_BP_fit(sp.csc_matrix(beta.reshape(-1, 1)), int(niter[0]), stats.as_dict())   # dgCMatrix p x 1 (BP.cpp:38-43)
+        fit.trace = tr[:ntr.value].copy() if trace else None
+        return fit
 
 
 class ADMM_LAD_fit:
@@ -312,7 +328,7 @@ class ADMM_LAD(ADMM_BP):
         self.rho = 1.0
         self.intercept = bool(intercept)
 
-    def fit(self):
+    def fit(self, trace=False):
         lib = _lib.load()
         xp, xmem, xk = as_input(self.x)
         yp, ymem, yk = as_input(self.y)
@@ -322,10 +338,13 @@ class ADMM_LAD(ADMM_BP):
         beta = np.zeros(self.p + 1, dtype=np.float64)
         niter = np.zeros(1, dtype=np.int32)
         stats = AdmmStats()
-        check(lib.admm_hip_lad(xp, yp, self.n, self.p, xmem, int(self.intercept), ctypes.byref(o),
-                               beta.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
-                               niter.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), ctypes.byref(stats)))
-        return ADMM_LAD_fit(beta, int(niter[0]), stats.as_dict())
+        tr, ntr = _trace_buffers(self.maxit if trace else 0)
+        check(lib.admm_hip_lad_traced(xp, yp, self.n, self.p, xmem, int(self.intercept), ctypes.byref(o),
+                                      beta.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                      niter.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), ctypes.byref(stats), *_trace_args(tr, ntr)))
+        fit = ADMM_LAD_fit(beta, int(niter[0]), stats.as_dict())
+        fit.trace = tr[:ntr.value].copy() if trace else None
+        return fit
 
 
 class LassoPlan:

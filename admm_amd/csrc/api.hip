@@ -214,7 +214,13 @@ int admm_hip_parlasso(const double* x, const double* y, int n, int p, int mem,
 
 int admm_hip_lad(const double* x, const double* y, int n, int p, int mem, int intercept,
                  const admm_opts* opts, double* beta_out, int* niter_out, admm_stats* stats) {
+    return admm_hip_lad_traced(x, y, n, p, mem, intercept, opts, beta_out, niter_out, stats, nullptr, 0, nullptr);
+}
+
+int admm_hip_lad_traced(const double* x, const double* y, int n, int p, int mem, int intercept, const admm_opts* opts,
+                        double* beta_out, int* niter_out, admm_stats* stats, double* trace_out, long long trace_cap, long long* ntrace_out) {
     return guarded([&] {
+        ADMM_REQUIRE(trace_cap == 0 || (trace_out != nullptr && ntrace_out != nullptr && trace_cap > 0), "bad trace arguments");
         check_common(x, y, n, p, mem, opts);
         ADMM_REQUIRE(beta_out && niter_out, "output pointers must not be NULL");
         ADMM_REQUIRE(n > p, "nrow(x) must be greater than ncol(x)");            // R/20_admm_lad.R:21-22
@@ -225,11 +231,13 @@ int admm_hip_lad(const double* x, const double* y, int n, int p, int mem, int in
         DeviceData<double> d;
         upload_standardize<double>(d, x, y, n, p, mem, true, intercept != 0, st.s);    // LAD.cpp:34: standardize always TRUE
         DenseResult res;
+        res.trace_cap = trace_cap;
         res.stats.t_h2d = d.t_h2d;
         res.stats.t_standardize = d.t_std;
         solve_lad(d, *opts, res, st.s);
         for (int i = 0; i <= p; ++i) beta_out[i] = res.beta[i];
         niter_out[0] = res.niter;
+        if (trace_cap > 0) { std::memcpy(trace_out, res.trace.data(), res.trace.size() * sizeof(double)); *ntrace_out = (long long)(res.trace.size() / ADMM_TRACE_FIELDS); }
         res.stats.t_total = now_s() - t0;
         if (stats) *stats = res.stats;
     });
@@ -237,7 +245,13 @@ int admm_hip_lad(const double* x, const double* y, int n, int p, int mem, int in
 
 int admm_hip_bp(const double* x, const double* y, int n, int p, int mem,
                 const admm_opts* opts, double* beta_out, int* niter_out, admm_stats* stats) {
+    return admm_hip_bp_traced(x, y, n, p, mem, opts, beta_out, niter_out, stats, nullptr, 0, nullptr);
+}
+
+int admm_hip_bp_traced(const double* x, const double* y, int n, int p, int mem, const admm_opts* opts,
+                       double* beta_out, int* niter_out, admm_stats* stats, double* trace_out, long long trace_cap, long long* ntrace_out) {
     return guarded([&] {
+        ADMM_REQUIRE(trace_cap == 0 || (trace_out != nullptr && ntrace_out != nullptr && trace_cap > 0), "bad trace arguments");
         check_common(x, y, n, p, mem, opts);
         ADMM_REQUIRE(beta_out && niter_out, "output pointers must not be NULL");
         ADMM_REQUIRE(p > n, "ncol(x) must be greater than nrow(x)");            // R/10_admm_bp.R:30-31
@@ -248,11 +262,13 @@ int admm_hip_bp(const double* x, const double* y, int n, int p, int mem,
         DeviceData<double> d;
         upload_standardize<double>(d, x, y, n, p, mem, false, false, st.s);     // BP.cpp:24-27: no standardisation
         DenseResult res;
+        res.trace_cap = trace_cap;
         res.stats.t_h2d = d.t_h2d;
         res.stats.t_standardize = d.t_std;
         solve_bp(d, *opts, res, st.s);
         for (int i = 0; i < p; ++i) beta_out[i] = res.beta[i];
         niter_out[0] = res.niter;
+        if (trace_cap > 0) { std::memcpy(trace_out, res.trace.data(), res.trace.size() * sizeof(double)); *ntrace_out = (long long)(res.trace.size() / ADMM_TRACE_FIELDS); }
         res.stats.t_total = now_s() - t0;
         if (stats) *stats = res.stats;
     });

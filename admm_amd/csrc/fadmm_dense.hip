@@ -32,6 +32,7 @@ struct DenseParams {
     DenseCtl* ctl;                            // [2]
     double* P;                                // [nwg_tail][8]
     int* done;
+    double* trace; long long trace_cap;       // optional decision records (admm_hip_lad_traced / admm_hip_bp_traced), or NULL
 };
 
 constexpr int kDenseThreads = 256;
@@ -63,14 +64,18 @@ dense_head_kernel(DenseParams q, int par) {
     DenseCtl out = in;
     out.first = 0;
     bool write_adj = true;
+    double tr_rp = 0, tr_rd = 0, tr_c = 0, tr_code = ADMM_TRACE_COLD;
     if (!in.first) {
         const double rp = sqrt(r2), rd = in.rho * sqrt(dz2);
+        tr_rp = rp; tr_rd = rd;
         if (rp < in.eps_primal && rd < in.eps_dual) {          // converged(): adj_z/adj_y/rho stay as they are
             out.done = 1; out.conv = 1; out.niter = in.iter + 1;
             write_adj = false;
+            tr_code = ADMM_TRACE_CONVERGED;
         } else {
             const double old_c = in.adj_c;
             const double c = in.rho * rp * rp + in.rho * daz2;
+            tr_c = c; tr_code = c < 0.999 * old_c ? ADMM_TRACE_ACCELERATE : ADMM_TRACE_RESTART;
             if (c < 0.999 * old_c) {
                 const double old_a = in.adj_a;
                 const double a = 0.5 + 0.5 * sqrt(1.0 + 4.0 * old_a * old_a);
@@ -98,6 +103,11 @@ dense_head_kernel(DenseParams q, int par) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         *outp = out;
         if (out.done) *q.done = 1;
+        if (q.trace != nullptr && in.total < q.trace_cap) {      // what FADMMBase.h:135-170 (print_row, commented out there) would print
+            double* t = q.trace + (size_t)in.total * ADMM_TRACE_FIELDS;
+            t[0] = 0.0; t[1] = in.iter; t[2] = in.eps_primal; t[3] = in.eps_dual; t[4] = tr_rp; t[5] = tr_rd;
+            t[6] = tr_c; t[7] = in.adj_c; t[8] = tr_code; t[9] = in.rho; t[10] = out.rho; t[11] = 0.0;
+        }
     }
     if (!write_adj) return;
 
@@ -189,8 +199,9 @@ struct DenseLoop {
     DevBuf<int> done;
     DenseParams q{};
     int nwg_head = 0;
+    DevBuf<double> trace;
 
-    void init(int dim, int prob, const admm_opts& o, const double* data_vec, double extra_norm, hipStream_t st) {
+    void init(int dim, int prob, const admm_opts& o, const double* data_vec, double extra_norm, hipStream_t st, long long trace_cap = 0) {
         const long long ld = round_up(dim, 32);
         for (DevBuf<double>* b : {&x, &z0, &z1, &y0, &y1, &adj_z, &adj_y, &vec}) { b->alloc(ld); b->zero(st); }
         const int nwg_tail = std::max(1, std::min(64, (dim + kDenseThreads - 1) / kDenseThreads));
@@ -202,6 +213,7 @@ struct DenseLoop {
         q.x = x.get(); q.z0 = z0.get(); q.z1 = z1.get(); q.y0 = y0.get(); q.y1 = y1.get();
         q.adj_z = adj_z.get(); q.adj_y = adj_y.get(); q.vec = vec.get();
         q.ctl = ctl.get(); q.P = P.get(); q.done = done.get();
+        if (trace_cap > 0) { trace.alloc((size_t)trace_cap * ADMM_TRACE_FIELDS); q.trace = trace.get(); q.trace_cap = trace_cap; }
         const int init_n = std::max(dim, nwg_tail * 8);
         hipLaunchKernelGGL(dense_init_kernel, dim3((init_n + 255) / 256), dim3(256), 0, st, q, o.rho);
     }
@@ -235,6 +247,14 @@ __global__ void __launch_bounds__(256) copy_cols_f64_kernel(const double* __rest
 }
 
 // ---------------------------------------------------------------------------------------------- LAD
+// copies the decision records of a finished loop into the result
+static void dense_collect_trace(DenseLoop& L, const DenseCtl& fc, DenseResult& res, hipStream_t st) {
+    if (res.trace_cap <= 0) return;
+    const long long nrec = std::min<long long>(fc.total + (fc.done ? 1 : 0), res.trace_cap);      // the finishing decision does not advance `total`
+    res.trace.resize((size_t)nrec * ADMM_TRACE_FIELDS);
+    if (nrec > 0) ADMM_HIP_CHECK(hipMemcpy(res.trace.data(), L.trace.get(), res.trace.size() * sizeof(double), hipMemcpyDeviceToHost));
+}
+
 void solve_lad(const DeviceData<double>& d, const admm_opts& opts, DenseResult& res, hipStream_t st) {
     const int n = d.n, p = d.p;
     admm_stats& S = res.stats;
@@ -269,7 +289,7 @@ void solve_lad(const DeviceData<double>& d, const admm_opts& opts, DenseResult& 
     ADMM_HIP_CHECK(hipStreamSynchronize(st));
 
     DenseLoop L;
-    L.init(n, 0, opts, d.Y.get(), ynorm, st);
+    L.init(n, 0, opts, d.Y.get(), ynorm, st, res.trace_cap);
     GemvT<double> g1, g2, g3, gH;                // t = X' vec ; s = (X'X)^-1 t ; xs = X s ;  or xs = H vec
     g1.init(d.X.get(), d.ldx, n, p);
     g2.init(M.get(), ldp, p, p);
@@ -320,6 +340,7 @@ void solve_lad(const DeviceData<double>& d, const admm_opts& opts, DenseResult& 
     const DenseCtl fc = L.final_ctl(st);
     res.niter = fc.niter;
     S.total_iter = fc.niter; S.rho = fc.rho;
+    dense_collect_trace(L, fc, res, st);
     // get_x(): beta = (X'X)^-1 X' (y - adj_y/rho + adj_z) with the final adj and rho (ADMMLAD.h:220-225)
     hipLaunchKernelGGL(lad_final_vec_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d.Y.get(), L.adj_y.get(), L.adj_z.get(), fc.rho, n, L.vec.get());
     g1.run(L.vec.get(), tvec.get(), nullptr, st);
@@ -389,7 +410,7 @@ void solve_bp(const DeviceData<double>& d, const admm_opts& opts, DenseResult& r
     S.t_factor = now_s() - t0;
 
     DenseLoop L;
-    L.init(p, 1, opts, AAAb.get(), 0.0, st);
+    L.init(p, 1, opts, AAAb.get(), 0.0, st, res.trace_cap);
     L.q.gout = gB.part.get(); L.q.gout_nseg = gB.pl.nseg; L.q.gout_stride = gB.stride;
 
     const int* skip = L.done.get();
@@ -404,6 +425,7 @@ void solve_bp(const DeviceData<double>& d, const admm_opts& opts, DenseResult& r
     const DenseCtl fc = L.final_ctl(st);
     res.niter = fc.niter;
     S.total_iter = fc.niter; S.rho = fc.rho;
+    dense_collect_trace(L, fc, res, st);
     const double* zfin = (fc.total & 1) ? L.z1.get() : L.z0.get();      // get_z() (BP.cpp:40)
     res.beta.assign(p, 0.0);
     ADMM_HIP_CHECK(hipMemcpy(res.beta.data(), zfin, (size_t)p * sizeof(double), hipMemcpyDeviceToHost));

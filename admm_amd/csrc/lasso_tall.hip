@@ -159,7 +159,7 @@ __device__ void tall_decide(const TallParams& q, int par) {
     if (q.trace != nullptr && in.total < q.trace_cap) {      // what FADMMBase.h:135-170 (print_row, commented out there) would print
         double* t = q.trace + (size_t)in.total * ADMM_TRACE_FIELDS;
         t[0] = in.lam_idx; t[1] = in.iter; t[2] = in.eps_primal; t[3] = in.eps_dual; t[4] = tr_rp; t[5] = tr_rd;
-        t[6] = tr_c; t[7] = in.adj_c; t[8] = tr_code; t[9] = in.rho;
+        t[6] = tr_c; t[7] = in.adj_c; t[8] = tr_code; t[9] = in.rho; t[10] = in.rho; t[11] = 0.0;
     }
 }
 

@@ -141,7 +141,7 @@ par_z_kernel(ParParams q, int par) {
         if (q.trace != nullptr && in.total < q.trace_cap) {
             double* t = q.trace + (size_t)in.total * ADMM_TRACE_FIELDS;
             t[0] = in.lam_idx; t[1] = in.iter; t[2] = in.eps_primal; t[3] = in.eps_dual; t[4] = tr_rp; t[5] = tr_rd;
-            t[6] = q.rho; t[7] = 0.0; t[8] = tr_code; t[9] = q.rho;
+            t[6] = q.rho; t[7] = 0.0; t[8] = tr_code; t[9] = q.rho; t[10] = q.rho; t[11] = 0.0;
         }
     }
     const float rho_f = (float)q.rho;

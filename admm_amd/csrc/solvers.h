@@ -47,6 +47,8 @@ struct DenseResult {
     std::vector<double> beta;
     int niter = 0;
     admm_stats stats{};
+    long long trace_cap = 0;         // > 0: record up to this many decisions (admm_hip_lad_traced / admm_hip_bp_traced)
+    std::vector<double> trace;       // [nrec][ADMM_TRACE_FIELDS]
 };
 void solve_lad(const DeviceData<double>& d, const admm_opts& opts, DenseResult& res, hipStream_t st);
 void solve_bp(const DeviceData<double>& d, const admm_opts& opts, DenseResult& res, hipStream_t st);

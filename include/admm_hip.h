@@ -124,6 +124,13 @@ ADMM_HIP_API int admm_hip_lad(const double* x, const double* y, int n, int p, in
 ADMM_HIP_API int admm_hip_bp(const double* x, const double* y, int n, int p, int mem,
                 const admm_opts* opts, double* beta_out, int* niter_out, admm_stats* stats);
 
+/* admm_hip_lad / admm_hip_bp that also return the decision trace (layout below, ADMM_TRACE_*; lambda index 0):
+ * trace_out receives min(decisions taken, trace_cap) records of ADMM_TRACE_FIELDS doubles, *ntrace_out their number. */
+ADMM_HIP_API int admm_hip_lad_traced(const double* x, const double* y, int n, int p, int mem, int intercept, const admm_opts* opts,
+                        double* beta_out, int* niter_out, admm_stats* stats, double* trace_out, long long trace_cap, long long* ntrace_out);
+ADMM_HIP_API int admm_hip_bp_traced(const double* x, const double* y, int n, int p, int mem, const admm_opts* opts,
+                       double* beta_out, int* niter_out, admm_stats* stats, double* trace_out, long long trace_cap, long long* ntrace_out);
+
 /* Prepared-problem variant of the Lasso family (the "persistent context" anticipated for a
  * re-fitting caller; the R shim does not need it).  create = everything the reference does
  * before its lambda loop (copy/convert, DataStd, X'y, Gram, Spectra, factorisation:
@@ -147,12 +154,13 @@ ADMM_HIP_API int admm_hip_lasso_plan_destroy(admm_hip_plan* plan);
  * ADMM_TRACE_FIELDS doubles:
  *   [0] lambda index  [1] iteration i within the lambda  [2] eps_primal  [3] eps_dual  (the thresholds iteration i was tested against)
  *   [4] resid_primal  [5] resid_dual  [6] c = rho r_p^2 + rho ||z - adj_z||^2 (0 when converged)  [7] c_old (adj_c before)
- *   [8] outcome ADMM_TRACE_*  [9] rho
+ *   [8] outcome ADMM_TRACE_*  [9] rho the iteration ran with  [10] rho after this decision (the adaptation of
+ *   FADMMBase.h:109-133 / ADMMBase.h:85-109 where the solver adapts: wide, LAD, BP)  [11] reserved (0)
  * Wide solver (ADMMBase::solve, rho adaptation ADMMBase.h:85-109): [6] rho AFTER this decision's adaptation, [7] kind of
  * the x-update that follows (0 zero, 1 regular, 2 active set), [9] rho before; consensus solver: [6] = [9] = rho, [7] = 0.
  * The parity tests use it to show that a lambda whose iteration count differs from the oracle's diverged at a
  * threshold test decided inside rounding noise, instead of excusing count differences wholesale. */
-#define ADMM_TRACE_FIELDS 10
+#define ADMM_TRACE_FIELDS 12
 #define ADMM_TRACE_COLD (-1)        /* first decision of a run: nothing to test yet */
 #define ADMM_TRACE_CONVERGED 0      /* r_p < eps_p and r_d < eps_d  (FADMMBase.h:213-217,237-238) */
 #define ADMM_TRACE_ACCELERATE 1     /* c < 0.999 c_old              (FADMMBase.h:243-249) */

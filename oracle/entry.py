@@ -25,6 +25,18 @@ def _lambda_grid(lambda0, n, scaleY, nlambda, lmin_ratio):
     return np.exp(np.linspace(np.log(lmax), np.log(lmin), int(nlambda)))
 
 
+def _attach(solver, detail):
+    """Tests: collect the decision trace / follow another execution's decisions (oracle/solvers.py)."""
+    if detail is None:
+        return
+    if detail.get("trace") is not None:
+        solver.trace = detail["trace"]
+    if detail.get("follow") is not None:
+        solver.follow = iter(detail["follow"])
+        solver.follow_band = float(detail.get("follow_band", 8.0))
+        solver.forced = detail.setdefault("forced", [])
+
+
 def _lasso_family(x, y, lam, nlambda, lmin_ratio, standardize, intercept, opts, alpha, nthread, detail=None):
     x = np.asarray(x, dtype=np.float64)
     y = np.asarray(y, dtype=np.float64)
@@ -46,12 +58,7 @@ def _lasso_family(x, y, lam, nlambda, lmin_ratio, standardize, intercept, opts, 
     nl = lam.size
     beta = np.zeros((p + 1, nl), dtype=F)
     niter = np.zeros(nl, dtype=np.int32)
-    if detail is not None and detail.get("trace") is not None:
-        solver.trace = detail["trace"]
-    if detail is not None and detail.get("follow") is not None:          # tests: follow another execution's decisions
-        solver.follow = iter(detail["follow"])
-        solver.follow_band = float(detail.get("follow_band", 8.0))
-        solver.forced = detail.setdefault("forced", [])
+    _attach(solver, detail)
     for i in range(nl):
         ilambda = lam[i] * n / np.float64(std.scaleY)       # Lasso.cpp:99
         solver.lam_idx = i
@@ -87,6 +94,7 @@ def admm_lad(x, y, intercept, opts, detail=None):
     std = DataStd(n, p, True, intercept, np.float64)        # LAD.cpp:34 standardize is always TRUE
     std.standardize(x, y)
     solver = LAD(x, y, float(opts["rho"]), float(opts["eps_abs"]), float(opts["eps_rel"]))
+    _attach(solver, detail)
     niter = solver.solve(int(opts["maxit"]))
     beta0, coef = std.recover(solver.get_coef())
     if detail is not None:
@@ -98,6 +106,7 @@ def admm_bp(x, y, opts, detail=None):
     x = np.asarray(x, dtype=np.float64)
     y = np.asarray(y, dtype=np.float64)
     solver = BP(x, y, float(opts["rho"]), float(opts["eps_abs"]), float(opts["eps_rel"]))
+    _attach(solver, detail)
     niter = solver.solve(int(opts["maxit"]))
     if detail is not None:
         detail.update(solver=solver)

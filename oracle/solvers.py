@@ -105,11 +105,12 @@ class FADMM:
     follow_band = 8.0
     forced = None
     ndecisions = 0
+    _followed = None
 
-    def _trace(self, i, c, c_old, code):
+    def _trace(self, i, c, c_old, code, rho_in):
         if self.trace is not None:
             self.trace.append((self.lam_idx, i, self.eps_primal, self.eps_dual, self.resid_primal, self.resid_dual,
-                               c, c_old, code, self.rho))
+                               c, c_old, code, rho_in, self.rho, 0.0))
 
     def _noise(self):
         """One-ulp noise floors of (resid_primal, resid_dual, c): what the three quantities move by when every entry of
@@ -128,9 +129,11 @@ class FADMM:
     def _decide(self, i, own, c, c_old):
         """own: this run's outcome (0 converged, 1 accelerate, 2 restart).  Returns the outcome to act on."""
         self.ndecisions += 1
+        self._followed = None
         if self.follow is None:
             return own
         g = next(self.follow)
+        self._followed = g
         if int(g[0]) != self.lam_idx or int(g[1]) != i:
             raise FollowMismatch(f"followed trace is at (lambda {int(g[0])}, iteration {int(g[1])}), this run at ({self.lam_idx}, {i})")
         theirs = int(g[8])
@@ -180,9 +183,10 @@ class FADMM:
             c = (self.rho * self.resid_primal * self.resid_primal
                  + self.rho * np.float64(_sqnorm(self.aux_z - self.adj_z, T)))                       # :100-107, evaluated at :241
             own = 0 if converged else (1 if c < 0.999 * old_c else 2)
-            self._trace(i, 0.0 if converged else c, old_c, own)
+            rho_in = self.rho
             code = self._decide(i, own, c, old_c)
             if code == 0:
+                self._trace(i, 0.0, old_c, own, rho_in)
                 return i + 1                                                                        # :237-238
             self.adj_c = c
             if code == 1:                                                                           # :243-249
@@ -198,6 +202,16 @@ class FADMM:
                 self.adj_c = old_c / 0.999
             if i > 5 and self.update_rho_active:
                 _rho_rule(self)
+                g = self._followed
+                if g is not None and abs(self.rho / rho_in - g[10] / g[9]) > 1e-9:        # compare the multiplier applied (ADMMPlain.solve)
+                    n_p, n_d, _ = self._noise()
+                    cands = _rho_candidates(rho_in, self.resid_primal, self.eps_primal, n_p, self.resid_dual, self.eps_dual, n_d, self.follow_band)
+                    if not any(abs(cd / rho_in - g[10] / g[9]) <= 1e-9 for cd in cands):
+                        raise FollowMismatch(f"rho adaptation differs beyond rounding noise at iteration {i}: x{self.rho / rho_in} here, "
+                                             f"x{g[10] / g[9]} followed, reachable {sorted(cd / rho_in for cd in cands)}")
+                    self.forced.append(dict(record=self.ndecisions - 1, lam=self.lam_idx, iter=i, kind="rho", ulps=float(self.follow_band)))
+                    self.rho = rho_in * float(g[10] / g[9])
+            self._trace(i, c, old_c, own, rho_in)
         return maxit + 1          # `return i + 1` after the loop ran out (FADMMBase.h:264)
 
 
@@ -315,7 +329,7 @@ class ADMMPlain:
                     converged = int(g[8]) == 0
             if converged:
                 if self.trace is not None:
-                    self.trace.append((self.lam_idx, i, self.eps_primal, self.eps_dual, self.resid_primal, self.resid_dual, self.rho, 0, 0, rho_in))
+                    self.trace.append((self.lam_idx, i, self.eps_primal, self.eps_dual, self.resid_primal, self.resid_dual, self.rho, 0, 0, rho_in, self.rho, 0.0))
                 return i + 1
             if i > 3:
                 _rho_rule(self)
@@ -329,7 +343,7 @@ class ADMMPlain:
                     self.forced.append(dict(record=self.ndecisions - 1, lam=self.lam_idx, iter=i, kind="rho", ulps=float(self.follow_band)))
                     self.rho = rho_in * float(g[6] / g[9])
             if self.trace is not None:
-                self.trace.append((self.lam_idx, i, self.eps_primal, self.eps_dual, self.resid_primal, self.resid_dual, self.rho, 0, 1, rho_in))
+                self.trace.append((self.lam_idx, i, self.eps_primal, self.eps_dual, self.resid_primal, self.resid_dual, self.rho, 0, 1, rho_in, self.rho, 0.0))
         return maxit + 1
 
 
@@ -536,7 +550,7 @@ class PADMMLasso:
                     self.forced.append(rec)
                     converged = int(g[8]) == 0
             if self.trace is not None:
-                self.trace.append((self.lam_idx, it, eps_primal, eps_dual, resid_primal, resid_dual, self.rho, 0, 0 if converged else 1, self.rho))
+                self.trace.append((self.lam_idx, it, eps_primal, eps_dual, resid_primal, resid_dual, self.rho, 0, 0 if converged else 1, self.rho, self.rho, 0.0))
             if converged:
                 return it + 1
         return maxit + 1

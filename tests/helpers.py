@@ -133,3 +133,21 @@ def assert_tall_parity(beta, niter, trace, problem, tol=1e-4, factor=5.0, band=8
           f"first at lambda {first}); niter identical; max beta err {max(errs):.2e}; columns beyond {tol:g}: {len(loose)} of {nl}"
           + (f" {loose} (oracle rounding variants differ by {yard:.2e})" if loose else ""))
     return dict(forced=forced, max_ulps=fm, first_forced_lambda=first, loose=loose, max_err=max(errs), errs=errs, ref=ref)
+
+
+def assert_dense_followed(kind, fit_beta, fit_niter, trace, x, y, opts, intercept=True, tol=1e-4, band=8.0, label=""):
+    """LAD / BP (FADMMBase::solve with the rho adaptation of FADMMBase.h:109-133, float64): the oracle follows the GPU's
+    decision trace through rounding-level near-ties of the stopping / restart tests and of the rho adaptation only;
+    iteration counts identical, beta within `tol`."""
+    from oracle import entry
+    t = np.asarray(trace, dtype=np.float64)
+    if len(t) and t[0, 8] == -1:
+        t = t[1:]
+    d = {"follow": t, "follow_band": band}
+    ref = entry.admm_lad(x, y, intercept, opts, d) if kind == "lad" else entry.admm_bp(x, y, opts, d)
+    assert d["solver"].ndecisions == len(t), (label, d["solver"].ndecisions, len(t))
+    assert int(fit_niter) == int(ref["niter"]), (label, fit_niter, ref["niter"])
+    err = relerr(fit_beta, ref["beta"])
+    print(f"[parity {label}] {len(t)} decisions, {len(d['forced'])} near-ties taken from the GPU; niter identical ({int(fit_niter)}); beta err {err:.2e}")
+    assert err < tol, (label, err)
+    return dict(forced=d["forced"], err=err, ref=ref)

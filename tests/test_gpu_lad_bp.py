@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from helpers import relerr
+from helpers import assert_dense_followed, relerr
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -12,12 +12,10 @@ def test_readme_lad_fixture(readme_lasso_xy):
     from admm_amd import admm_lad
     from oracle import entry, readme
     x, y = readme_lasso_xy
-    fit = admm_lad(x, y, intercept=False).fit()
-    ref = entry.admm_lad(x, y, False, entry.LAD_OPTS)
+    fit = admm_lad(x, y, intercept=False).fit(trace=True)
     assert fit.beta[0] == 0.0
     assert relerr(fit.beta[1:], readme.LAD_ADMM) < TOL            # README.md:139-161
-    assert relerr(fit.beta, ref["beta"]) < TOL
-    assert abs(fit.niter - ref["niter"]) <= max(3, 0.05 * ref["niter"])
+    assert_dense_followed("lad", fit.beta, fit.niter, fit.trace, x, y, entry.LAD_OPTS, intercept=False, tol=1e-8, label="README LAD (hat-matrix branch)")
 
 
 @pytest.mark.parametrize("intercept", [True, False])
@@ -30,24 +28,20 @@ def test_lad_general_branch_vs_oracle(intercept):
     x = rng.standard_normal((n, p)) * 2 + 0.3
     b = rng.uniform(size=p)
     y = x @ b + rng.standard_t(3, size=n) + 1.5
-    fit = admm_lad(x, y, intercept=intercept).fit()
-    ref = entry.admm_lad(x, y, intercept, entry.LAD_OPTS)
-    assert relerr(fit.beta, ref["beta"]) < TOL
-    assert abs(fit.niter - ref["niter"]) <= max(3, 0.05 * ref["niter"])
+    fit = admm_lad(x, y, intercept=intercept).fit(trace=True)
+    assert_dense_followed("lad", fit.beta, fit.niter, fit.trace, x, y, entry.LAD_OPTS, intercept=intercept, tol=1e-8, label=f"LAD n=3000 icpt={int(intercept)}")
 
 
 def test_readme_bp_fixture():
     from admm_amd import admm_bp
     from oracle import entry, readme
     x, y, bt = readme.bp_data()
-    fit = admm_bp(x, y).fit()
+    fit = admm_bp(x, y).fit(trace=True)
     beta = np.asarray(fit.beta.todense()).ravel()
     e = bt - beta
     assert abs(e.min() - readme.BP_RANGE[0]) < 1e-6                # README.md:180-182
     assert abs(e.max() - readme.BP_RANGE[1]) < 1e-6
-    ref = entry.admm_bp(x, y, entry.BP_OPTS)
-    assert relerr(beta, ref["beta"]) < TOL
-    assert abs(fit.niter - ref["niter"]) <= 2
+    assert_dense_followed("bp", beta, fit.niter, fit.trace, x, y, entry.BP_OPTS, tol=1e-8, label="README BP")
 
 
 def test_bp_perf_fixture_range():
@@ -70,7 +64,6 @@ def test_bp_maxit_and_rho_adaptation():
     bt[rng.choice(p, 12, replace=False)] = rng.uniform(size=12)
     y = A @ bt
     for maxit in (3, 9, 10000):
-        fit = admm_bp(A, y).opts(maxit=maxit).fit()
-        ref = entry.admm_bp(A, y, dict(entry.BP_OPTS, maxit=maxit))
-        assert abs(fit.niter - ref["niter"]) <= (0 if maxit < 100 else 2)
-        assert relerr(np.asarray(fit.beta.todense()).ravel(), ref["beta"]) < TOL
+        fit = admm_bp(A, y).opts(maxit=maxit).fit(trace=True)
+        assert_dense_followed("bp", np.asarray(fit.beta.todense()).ravel(), fit.niter, fit.trace, A, y, dict(entry.BP_OPTS, maxit=maxit),
+                              tol=1e-8, label=f"BP maxit={maxit}")
