@@ -347,6 +347,21 @@ int admm_hip_lasso_dist_cols(const double* x_cols, const double* y, int n, int p
     });
 }
 
+int admm_hip_lasso_plan_create_dist_cols(const double* x_cols, const double* y, int n, int p_local, long long p_total, long long col_offset, int mem,
+                                         const double* lambda_in, int nlambda_in, int nlambda_auto, double lmin_ratio,
+                                         int standardize, int intercept, double alpha, const admm_opts* opts,
+                                         admm_hip_plan** plan_out, int* nlambda_out) {
+    return guarded([&] {
+        ADMM_REQUIRE(plan_out != nullptr, "plan_out must not be NULL");
+        const bool enet = alpha >= 0.0;
+        if (enet) ADMM_REQUIRE(alpha <= 1.0, "alpha must be within [0, 1]");
+        PlanHandle* h = create_plan_cols(x_cols, y, n, p_local, p_total, col_offset, mem, lambda_in, nlambda_in, nlambda_auto,
+                                         lmin_ratio, standardize, intercept, enet, enet ? alpha : 1.0, opts);
+        *plan_out = reinterpret_cast<admm_hip_plan*>(h);
+        if (nlambda_out) *nlambda_out = h->nlam;
+    });
+}
+
 int admm_hip_comm_unique_id(void* id_out) {
     return guarded([&] { ADMM_REQUIRE(id_out != nullptr, "id_out must not be NULL"); comm_unique_id(id_out); });
 }

@@ -204,6 +204,32 @@ def lasso_dist_cols(x_cols, y, p_total, col_offset, lam=None, nlambda=100, lambd
     return ADMM_Lasso_fit(lam_out, beta, niter, stats.as_dict())
 
 
+class DistColsPlan:
+    """Prepared column-sharded wide problem (admm_hip_lasso_plan_create_dist_cols): setup once, run the path repeatedly."""
+
+    def __init__(self, x_cols, y, p_total, col_offset, lam=None, nlambda=100, lambda_min_ratio=0.01, standardize=True, intercept=True,
+                 alpha=None, **opts):
+        lib = _lib.load()
+        self._lib = lib
+        self.p = int(p_total)
+        xp, xmem, xk = as_input(x_cols)
+        yp, ymem, yk = as_input(y)
+        n, p_local = np.asarray(x_cols).shape
+        lam_in = np.ascontiguousarray(np.sort(np.atleast_1d(np.asarray(lam, dtype=np.float64)))[::-1]) if lam is not None else np.zeros(0)
+        o = AdmmOpts(int(opts.get("maxit", 10000)), float(opts.get("eps_abs", 1e-5)), float(opts.get("eps_rel", 1e-5)),
+                     float(opts.get("rho", -1.0) if opts.get("rho") is not None else -1.0))
+        h = ctypes.c_void_p()
+        nlo = ctypes.c_int()
+        check(lib.admm_hip_lasso_plan_create_dist_cols(xp, yp, int(n), int(p_local), int(p_total), int(col_offset), xmem,
+                                                       ctypes.c_void_p(lam_in.ctypes.data if lam_in.size else 0), int(lam_in.size), int(nlambda),
+                                                       float(lambda_min_ratio), int(bool(standardize)), int(bool(intercept)),
+                                                       float(-1.0 if alpha is None else alpha), ctypes.byref(o), ctypes.byref(h), ctypes.byref(nlo)))
+        self._h = h
+        self.nlambda = nlo.value
+
+    run = None            # bound below (shared with DistLassoPlan)
+
+
 class DistLassoPlan:
     """Prepared distributed problem (setup once, run the lambda path repeatedly): the consensus solver for nthread >= 1,
     the row-sharded serial tall solver for nthread == 0."""
@@ -249,3 +275,7 @@ class DistLassoPlan:
         if self._h:
             check(self._lib.admm_hip_lasso_plan_destroy(self._h))
             self._h = None
+
+
+for _name in ("run", "enable_trace", "read_trace", "close"):
+    setattr(DistColsPlan, _name, getattr(DistLassoPlan, _name))

@@ -236,6 +236,12 @@ ADMM_HIP_API int admm_hip_lasso_dist_cols(const double* x_cols, const double* y,
                              int standardize, int intercept, double alpha, const admm_opts* opts,
                              double* lambda_out, float* beta_out, int* niter_out, admm_stats* stats);
 
+/* prepared-problem form of the above (run with admm_hip_lasso_plan_run; beta_out there is (p_total + 1) x nl) */
+ADMM_HIP_API int admm_hip_lasso_plan_create_dist_cols(const double* x_cols, const double* y, int n, int p_local, long long p_total, long long col_offset, int mem,
+                                         const double* lambda_in, int nlambda_in, int nlambda_auto, double lmin_ratio,
+                                         int standardize, int intercept, double alpha, const admm_opts* opts,
+                                         admm_hip_plan** plan_out, int* nlambda_out);
+
 ADMM_HIP_API const char* admm_hip_last_error(void);
 ADMM_HIP_API const char* admm_hip_version(void);
 ADMM_HIP_API int admm_hip_device_count(void);

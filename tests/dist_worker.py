@@ -84,13 +84,23 @@ def main():
     n, p = x.shape
     if K < 0:
         lo, hi = adist.col_partition(p, nranks, rank)
-        fit = adist.lasso_dist_cols(np.asfortranarray(x[:, lo:hi]), y, p, lo, lambda_min_ratio=0.01, **kw)
+        plan = adist.DistColsPlan(np.asfortranarray(x[:, lo:hi]), y, p, lo, lambda_min_ratio=0.01, **kw)
+        plan.enable_trace(1 << 16)
+        fit = plan.run()
+        trace = plan.read_trace()
+        plan.close()
         assert fit.stats["branch"] == 1
-        trace = np.zeros((0, 10))
+        one = adist.lasso_dist_cols(np.asfortranarray(x[:, lo:hi]), y, p, lo, lambda_min_ratio=0.01, **kw)       # the one-shot entry point
+        assert np.array_equal(one.beta_dense, fit.beta_dense) and list(one.niter) == list(fit.niter)
     elif K > 0:
         lo, hi = adist.row_partition(n, K, nranks, rank)
-        fit = adist.parlasso_dist(np.asfortranarray(x[lo:hi]), y[lo:hi], n, p, K, n_local=hi - lo, **kw)
-        trace = np.zeros((0, 10))
+        plan = adist.DistLassoPlan(np.asfortranarray(x[lo:hi]), y[lo:hi], n, p, K, n_local=hi - lo, **kw)
+        plan.enable_trace(1 << 16)
+        fit = plan.run()
+        trace = plan.read_trace()
+        plan.close()
+        one = adist.parlasso_dist(np.asfortranarray(x[lo:hi]), y[lo:hi], n, p, K, n_local=hi - lo, **kw)     # the one-shot entry point
+        assert np.array_equal(one.beta_dense, fit.beta_dense) and list(one.niter) == list(fit.niter)
     else:
         cut = [0] + [int(n * (r + 1) / nranks) + (17 if r < nranks - 1 else 0) for r in range(nranks)]     # uneven slices on purpose
         lo, hi = cut[rank], cut[rank + 1]

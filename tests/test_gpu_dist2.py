@@ -59,10 +59,13 @@ def test_two_process_consensus_matches_single_process(backend, case):
     assert np.abs(res[0]["niter"].astype(int) - niter1.astype(int)).max() <= 2, (res[0]["niter"], niter1)
     for j in range(kw["nlambda"]):
         assert relerr(res[0]["beta"][:, j], beta1[:, j]) < 1e-4, j
-    ref = entry.admm_parlasso(x, y, None, kw["nlambda"], 0.01 if x.shape[0] < x.shape[1] else 1e-4, True, True, K,
-                              dict(entry.LASSO_OPTS, maxit=kw["maxit"]))
-    for j in range(kw["nlambda"]):
-        assert relerr(res[0]["beta"][:, j], ref["beta"][:, j]) < 2e-3, j
+    # against the oracle on the decision trace (identical counts, every column 1e-4): the global moments are summed in a
+    # different order than in one process, so this is a separate execution with its own near-ties
+    from helpers import assert_followed_parity
+    assert np.array_equal(res[0]["trace"], res[1]["trace"])
+    prob = dict(x=x, y=y, lam=None, nlambda=kw["nlambda"], lmin_ratio=0.01 if x.shape[0] < x.shape[1] else 1e-4, standardize=True,
+                intercept=True, opts=dict(entry.LASSO_OPTS, maxit=kw["maxit"]), alpha=None, nthread=K)
+    assert_followed_parity(res[0]["beta"], res[0]["niter"], res[0]["trace"], prob, 2e-4, label=f"2-process consensus {case} over {backend}")
 
 
 @pytest.mark.parametrize("backend,case", [("shm", "tallshard300"), ("peer", "tallshard300"), ("peer", "tallshard2300")])
@@ -106,12 +109,12 @@ def test_two_process_column_sharded_wide_solver(backend, case):
         one = admm_enet(x, y).penalty(nlambda=nl, lambda_min_ratio=0.01, alpha=alpha).fit()
         ref = entry.admm_enet(x, y, None, nl, 0.01, True, True, alpha, entry.LASSO_OPTS)
     assert np.allclose(res[0]["lam"], one.lambda_, rtol=1e-6)
-    # the sum over ranks of A x rounds differently from the single-process sum over workgroups: the rho adaptation and the
-    # stopping rule may flip on late lambdas, so the first half of the path is compared tightly
+    # the sum over ranks of A x rounds differently from the single-process sum over workgroups, so this is a separate
+    # execution with its own near-ties: judged against the oracle on its decision trace (identical counts, every column 1e-4)
+    from helpers import assert_followed_parity
+    assert np.array_equal(res[0]["trace"], res[1]["trace"])
+    prob = dict(x=x, y=y, lam=None, nlambda=nl, lmin_ratio=0.01, standardize=True, intercept=True, opts=entry.LASSO_OPTS, alpha=alpha)
+    assert_followed_parity(res[0]["beta"], res[0]["niter"], res[0]["trace"], prob, 1e-4, label=f"2-process {case} over {backend}")
     h = nl // 2
-    assert np.abs(res[0]["niter"][:h].astype(int) - one.niter[:h].astype(int)).max() <= 2, (res[0]["niter"], one.niter)
     for j in range(h):
         assert relerr(res[0]["beta"][:, j], one.beta_dense[:, j]) < 1e-4, j
-        assert relerr(res[0]["beta"][:, j], ref["beta"][:, j]) < 1e-4, j
-    for j in range(nl):
-        assert relerr(res[0]["beta"][:, j], ref["beta"][:, j]) < 5e-3, j
