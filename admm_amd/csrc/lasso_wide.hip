@@ -41,6 +41,43 @@ struct WideCtl {
     int iter, counter, lam_idx, done, first, total, pad1, pad2;      // total: decisions taken so far (index of the trace record)
 };
 
+static_assert(sizeof(WideCtl) == 64, "WideCtl is loaded as four 16-byte words");
+
+// The control block through the VECTOR memory path, issued together with the other prologue loads.  (A scalar s_load of
+// it shares its wait counter with the kernel-argument loads: the compiler waits for all of them before it can form the
+// first vector address, which puts the control block's miss in front of every other load -- one more dependent round
+// trip per launch.)  The zero offset is produced by inline asm so that the address is not provably wave-uniform.
+struct WideCtlRaw { uint4 w[4]; };
+__device__ __forceinline__ WideCtlRaw wide_ctl_request(const WideCtl* c) {
+    int vz;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
+    const uint4* cp = reinterpret_cast<const uint4*>(c) + vz;
+    WideCtlRaw r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r.w[k] = cp[k];
+    return r;
+}
+__device__ __forceinline__ double uniform_f64(double v) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ WideCtl wide_ctl_uniform(WideCtl c) {          // identical in every lane: tell the compiler
+    c.rho = uniform_f64(c.rho); c.eps_primal = uniform_f64(c.eps_primal); c.eps_dual = uniform_f64(c.eps_dual);
+    c.lam = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(c.lam)));
+    c.type = __builtin_amdgcn_readfirstlane(c.type); c.iter = __builtin_amdgcn_readfirstlane(c.iter);
+    c.counter = __builtin_amdgcn_readfirstlane(c.counter); c.lam_idx = __builtin_amdgcn_readfirstlane(c.lam_idx);
+    c.done = __builtin_amdgcn_readfirstlane(c.done); c.first = __builtin_amdgcn_readfirstlane(c.first);
+    c.total = __builtin_amdgcn_readfirstlane(c.total);
+    return c;
+}
+__device__ __forceinline__ WideCtl wide_ctl_unpack(const WideCtlRaw& r) {
+    WideCtl c;
+    __builtin_memcpy(&c, &r, sizeof(c));
+    return wide_ctl_uniform(c);
+}
+
 constexpr int kWideThreads = 256;
 constexpr int kAxWG = 128;                // workgroups of the gather mat-vec (partials per output)
 constexpr int kActWG = 256;               // fused mode: workgroups taking part in an active-set iteration
@@ -63,6 +100,7 @@ struct WideParams {
     WideCtl* ctl;                         // [2]
     double* P;                            // [nwg_tail][8]: |r|^2, |z_new - z|^2, |Ax|^2, |z_new|^2, |y_new|^2
     float* beta; int* niter; int* done;
+    int* done_host;                       // pinned host word, set together with *done (loop_driver.h: PinnedFlag)
     double* trace; long long trace_cap;   // optional decision records (admm_hip_lasso_plan_trace_*), or NULL
 };
 
@@ -84,14 +122,27 @@ __device__ __forceinline__ float prox_f(float val, float thresh, float denom, bo
 // (ADMMBase.h:85-109), lambda schedule (init_warm), regular / active-set schedule (ADMMLassoWide.h:121-155).  Every wave
 // that calls it reduces the norm partials itself in a fixed order (no LDS, no barrier) and gets the identical result.
 struct WideDecision { WideCtl out; int lam_finished; int niter_val; double rp, rd; int code; };
-__device__ __forceinline__ WideDecision wide_decide(const WideParams& q, const WideCtl& in, int lane) {
-    int lam_finished = -1, niter_val = 0;
-    // norm partials of the previous iteration: every wave reduces them itself (fixed order), no LDS, no barrier
-    double sums[5] = {0, 0, 0, 0, 0};
-    for (int row = lane; row < q.nwg_tail; row += 64) {
+constexpr int kWideNormRows = 128;        // rows of P that every lane requests unconditionally (P is allocated and zeroed to at least this)
+// The lane's share of the norm partials of the previous iteration (rows lane, lane + 64, ...).  Does not depend on the
+// control block: callers request it in the same memory round trip as the control block itself.
+struct WideNormRaw { double a[5], b[5]; };
+__device__ __forceinline__ WideNormRaw wide_norms_request(const WideParams& q, int lane) {
+    WideNormRaw r;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { r.a[k] = q.P[(size_t)lane * 8 + k]; r.b[k] = q.P[(size_t)(lane + 64) * 8 + k]; }
+    return r;
+}
+__device__ __forceinline__ void wide_norms_finish(const WideParams& q, int lane, const WideNormRaw& r, double (&sums)[5]) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) sums[k] = r.a[k] + r.b[k];
+    for (int row = lane + kWideNormRows; row < q.nwg_tail; row += 64) {
 #pragma unroll
         for (int k = 0; k < 5; ++k) sums[k] += q.P[(size_t)row * 8 + k];
     }
+}
+__device__ __forceinline__ WideDecision wide_decide(const WideParams& q, const WideCtl& in, double (&sums)[5]) {
+    int lam_finished = -1, niter_val = 0;
+    // every wave reduces the norm partials itself (fixed order), no LDS, no barrier
 #pragma unroll
     for (int k = 0; k < 5; ++k) sums[k] = wave_sum(sums[k]);
     const double r2 = sums[0], dz2 = sums[1], ax2 = sums[2], z2 = sums[3], y2 = sums[4];
@@ -149,44 +200,61 @@ __global__ void __launch_bounds__(kWideThreads)
 wide_x_kernel(WideParams q, int par) {
     static_assert(!(TG && RT > 0), "the global-t mode is the unfused x-update");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const WideCtl in = q.ctl[par];
-    WideCtl* outp = &q.ctl[par ^ 1];
-    if (in.done) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) *outp = in;
-        return;
-    }
     const int npad = (q.n + 255) / 256 * 256;
     float* tl = reinterpret_cast<float*>(smem_raw);            // t        [npad]
     float* tdl = tl + npad;                                    // t/gamma  [npad]
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int w = blockIdx.x * (kWideThreads / 64) + wid;
-    // Workgroups that take part in every kind of step (all of them when not fused) fetch what does not depend on
-    // the decision in the same round trip as the decision's inputs: the operands of t = Ax + z + y / rho and, fused,
-    // this wave's first 512 slot values of an active-set step (most iterations are active-set steps).
+    // ---- One memory round trip for everything the prologue needs.  The control block, the norm partials of the
+    // decision and -- in workgroups that take part in every kind of step (all of them when not fused) -- the operands of
+    // t = Ax + z + y / rho and this wave's first 512 slot values of an active-set step are all requested BEFORE the
+    // first use of any of them.  (Round 2 found the earlier form -- control block, then slot values, then a staging
+    // loop that waited on each of its 8 passes, then the norm partials -- to be a chain of ~12 dependent round trips:
+    // the active-set launch took 12 us.)  The empty asm with a memory clobber keeps the compiler from sinking the
+    // loads below the branches that follow.
+    const WideCtlRaw in_raw = wide_ctl_request(q.ctl + par);
+    WideCtl* outp = &q.ctl[par ^ 1];
     const bool always = RT == 0 || (int)blockIdx.x < kActWG;
-    float xs0[8];
-    if (RT > 0 && always) {
-        const int NWa = min((int)gridDim.x, kActWG) * (kWideThreads / 64);
+    constexpr int NT = RT > 0 ? RT : 1;
+    float xs0[8], ta[NT], tz[NT], tb[NT];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const long long jl = (long long)(u * 64 + lane) * NWa + w;
-            xs0[u] = (jl < q.p) ? q.x[jl] : 0.f;
-        }
+    for (int u = 0; u < 8; ++u) xs0[u] = 0.f;
+    const int NWa = min((int)gridDim.x, kActWG) * (kWideThreads / 64);
+    if (RT > 0 && always) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)                                    // clamped index (select below): no branch between the loads
+            xs0[u] = q.x[min((long long)(u * 64 + lane) * NWa + w, (long long)q.p - 1)];
     }
-    auto stage_t = [&]() {
-        for (int i = threadIdx.x; i < npad; i += kWideThreads) {
-            tl[i] = i < q.n ? q.Ax[i] + q.z[i] : 0.f;
-            tdl[i] = i < q.n ? q.y[i] : 0.f;
+    auto load_t = [&]() {                                             // Ax, z, y are allocated and zeroed to 4096 entries at least
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            const int i = k * kWideThreads + threadIdx.x;
+            ta[k] = q.Ax[i]; tz[k] = q.z[i]; tb[k] = q.y[i];
         }
     };
-    if (always && !TG) stage_t();
-    const WideDecision dec = wide_decide(q, in, lane);
-    const WideCtl out = dec.out;
-    const int lam_finished = dec.lam_finished, niter_val = dec.niter_val;
+    if (RT > 0 && always) load_t();
+    const WideNormRaw nraw = wide_norms_request(q, lane);
+    __builtin_amdgcn_sched_barrier(0);                                 // every request above is issued before the first use below
+    asm volatile("" ::: "memory");
+    const WideCtl in = wide_ctl_unpack(in_raw);
+    if (RT > 0 && always) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if ((long long)(u * 64 + lane) * NWa + w >= q.p) xs0[u] = 0.f;
+    }
+    double sums[5];
+    wide_norms_finish(q, lane, nraw, sums);
+    if (in.done) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) *outp = in;
+        return;
+    }
+    const WideDecision dec = wide_decide(q, in, sums);
+    const WideCtl out = wide_ctl_uniform(dec.out);
+    const int lam_finished = __builtin_amdgcn_readfirstlane(dec.lam_finished), niter_val = __builtin_amdgcn_readfirstlane(dec.niter_val);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (lam_finished >= 0) q.niter[lam_finished] = niter_val;
         *outp = out;
-        if (out.done) *q.done = 1;
+        if (out.done) { *q.done = 1; *q.done_host = 1; }
         if (q.trace != nullptr && in.total < q.trace_cap) {          // what ADMMBase.h:111-146 (print_row, commented out there) would print
             double* t = q.trace + (size_t)in.total * ADMM_TRACE_FIELDS;
             t[0] = in.lam_idx; t[1] = in.iter; t[2] = in.eps_primal; t[3] = in.eps_dual; t[4] = dec.rp; t[5] = dec.rd;
@@ -208,13 +276,39 @@ wide_x_kernel(WideParams q, int par) {
     // the others leave here, before any barrier or LDS traffic
     if (RT > 0 && !reg && !always) return;
     if (!TG) {
-        if (!always) stage_t();                                        // regular step of a workgroup beyond kActWG
         // t = cache_Ax + aux_z + dual_y / Scalar(rho); the active-set form divides by gamma first (:90, :141)
         const float rho_f = (float)out.rho;
-        for (int i = threadIdx.x; i < npad; i += kWideThreads) {   // same thread wrote these slots above
-            const float t = tl[i] + tdl[i] / rho_f;
-            tl[i] = t;
-            tdl[i] = t / q.gamma;
+        if (RT > 0) {
+            if (!always) load_t();                                     // regular step of a workgroup beyond kActWG
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+                const int i = k * kWideThreads + threadIdx.x;
+                if (i < npad) {
+                    const float t = i < q.n ? (ta[k] + tz[k]) + tb[k] / rho_f : 0.f;
+                    tl[i] = t;
+                    tdl[i] = t / q.gamma;
+                }
+            }
+        } else {
+            // any n that fits the LDS: passes of 4 x 256 elements, the 12 loads of a pass in flight together
+            for (int i0 = threadIdx.x; i0 < npad; i0 += 4 * kWideThreads) {
+                float a4[4], b4[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int i = min(i0 + k * kWideThreads, npad - 1);       // npad <= ldn: in bounds
+                    a4[k] = q.Ax[i] + q.z[i];
+                    b4[k] = q.y[i];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int i = i0 + k * kWideThreads;
+                    if (i < npad) {
+                        const float t = i < q.n ? a4[k] + b4[k] / rho_f : 0.f;
+                        tl[i] = t;
+                        tdl[i] = t / q.gamma;
+                    }
+                }
+            }
         }
         __syncthreads();
     }
@@ -347,8 +441,10 @@ wide_x_kernel(WideParams q, int par) {
 __global__ void __launch_bounds__(kWideThreads)
 wide_t_kernel(WideParams q, int par) {
     const WideCtl in = q.ctl[par];
+    double sums[5];
+    wide_norms_finish(q, threadIdx.x & 63, wide_norms_request(q, threadIdx.x & 63), sums);
     if (in.done) return;
-    const WideCtl out = wide_decide(q, in, threadIdx.x & 63).out;
+    const WideCtl out = wide_decide(q, in, sums).out;
     if (out.done || out.type == W_ZERO) return;
     const int i = blockIdx.x * kWideThreads + threadIdx.x;
     if (i >= q.ldn) return;
@@ -439,12 +535,16 @@ static_assert(kAxWG == 16 * kWtLanes && kActWG == 2 * kAxWG, "tail reduction ass
 // at once, BEFORE anything that depends on the control block (a version that took `c` as a function argument made the
 // compiler wait for the control block first: one more memory round trip, 9.7 instead of 6.2 us per launch, C3 -15 %).
 #define WIDE_SUM_AXPART(ax)                                                                                              \
+    const int ic = min(i, q.n - 1);                      /* clamped: every load below is unconditional and in bounds */  \
+    const float* ap = q.axpart + (size_t)sub * q.ldn + ic;                                                               \
+    const size_t rstep = (size_t)kWtLanes * q.ldn;       /* partial rows k * 8 + sub */                                  \
     float v[16], v2[16];                                                                                                 \
-    _Pragma("unroll") for (int k = 0; k < 16; ++k) v[k] = valid ? q.axpart[(size_t)(k * kWtLanes + sub) * q.ldn + i] : 0.f;   \
-    _Pragma("unroll") for (int k = 0; k < 16; ++k)                                                                        \
-        v2[k] = (valid && q.fused) ? q.axpart[(size_t)(kAxWG + k * kWtLanes + sub) * q.ldn + i] : 0.f;   /* rows 128..255 */ \
-    float zo = 0.f, yo = 0.f, yd = 0.f;                                                                                  \
-    if (valid) { zo = q.z[i]; yo = q.y[i]; yd = q.Y[i]; }                                                                \
+    _Pragma("unroll") for (int k = 0; k < 16; ++k) v[k] = ap[k * rstep];                                                 \
+    _Pragma("unroll") for (int k = 0; k < 16; ++k) v2[k] = 0.f;                                                          \
+    if (q.fused) { _Pragma("unroll") for (int k = 0; k < 16; ++k) v2[k] = ap[(16 + k) * rstep]; }   /* rows 128..255 */  \
+    float zo = q.z[ic], yo = q.y[ic], yd = q.Y[ic];                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                   /* all requests issued before the first use */                  \
+    if (!valid) { zo = 0.f; yo = 0.f; yd = 0.f; }                                                                        \
     float ax = 0.f;                                                                                                      \
     _Pragma("unroll") for (int k = 0; k < 16; ++k) ax += v[k];                                                           \
     _Pragma("unroll") for (int k = 0; k < 16; ++k) ax += v2[k];                                                          \
@@ -452,7 +552,7 @@ static_assert(kAxWG == 16 * kWtLanes && kActWG == 2 * kAxWG, "tail reduction ass
         for (int b0 = kActWG; b0 < q.nwg_x; b0 += 16 * kWtLanes) {                                                       \
             _Pragma("unroll") for (int k = 0; k < 16; ++k) {                                                             \
                 const int b = b0 + k * kWtLanes + sub;                                                                   \
-                v[k] = (valid && b < q.nwg_x) ? q.axpart[(size_t)b * q.ldn + i] : 0.f;                                   \
+                v[k] = (b < q.nwg_x) ? q.axpart[(size_t)b * q.ldn + ic] : 0.f;                                           \
             }                                                                                                            \
             _Pragma("unroll") for (int k = 0; k < 16; ++k) ax += v[k];                                                   \
         }                                                                                                                \
@@ -540,6 +640,7 @@ struct WidePlan final : LassoPlan {
     DevBuf<int> niter, done;
     DevBuf<double> P;
     DevBuf<WideCtl> ctl;
+    PinnedFlag hflag;
     WideParams q{};
     DevBuf<double> trace;
     long long trace_cap = 0, trace_n = 0;
@@ -615,7 +716,7 @@ struct WidePlan final : LassoPlan {
 
         nwg_tail = (n + kWtElems - 1) / kWtElems;                    // 32 elements per workgroup (8 lanes each)
         x.alloc(ldp); x.zero(st);
-        for (DevBuf<float>* b : {&Ax, &z, &y}) { b->alloc(ldn); b->zero(st); }
+        for (DevBuf<float>* b : {&Ax, &z, &y}) { b->alloc(std::max<long long>(ldn, 4096)); b->zero(st); }   // the fused x-update reads up to 16 x 256 entries unconditionally
         // ADMM_HIP_WIDE_FUSE=0: always three launches per iteration
         fuse_rt = n <= 1024 ? 4 : (n <= 2048 ? 8 : (n <= 4096 ? 16 : 0));
         if (const char* e = std::getenv("ADMM_HIP_WIDE_FUSE")) if (std::string(e) == "0") fuse_rt = 0;
@@ -650,7 +751,7 @@ struct WidePlan final : LassoPlan {
         nwg_x = std::max(wgx * device_info().num_cu, kActWG);
         axpart.alloc((size_t)(fuse_rt ? nwg_x : kAxWG) * ldn); axpart.zero(st);
         beta.alloc((size_t)nlam * p); niter.alloc(nlam); done.alloc(1); dlam.alloc(nlam);
-        P.alloc((size_t)nwg_tail * 8); ctl.alloc(2);
+        P.alloc((size_t)std::max(nwg_tail, kWideNormRows) * 8); P.zero(st); ctl.alloc(2);       // rows beyond nwg_tail stay zero (wide_load_norms)
         ADMM_HIP_CHECK(hipMemcpyAsync(dlam.get(), lam_int.data(), nlam * sizeof(float), hipMemcpyHostToDevice, st));
 
         q.n = n; q.p = p; q.maxit = pb.opts.maxit; q.nlam = nlam; q.enet = pb.enet ? 1 : 0; q.nwg_tail = nwg_tail;
@@ -663,6 +764,7 @@ struct WidePlan final : LassoPlan {
         q.lambdas = dlam.get(); q.x = x.get(); q.Ax = Ax.get(); q.z = z.get(); q.y = y.get();
         q.axpart = axpart.get(); q.tbuf = tbuf.get(); q.ldn = ldn; q.fused = fuse_rt ? 1 : 0; q.nwg_x = nwg_x;
         q.ctl = ctl.get(); q.P = P.get(); q.beta = beta.get(); q.niter = niter.get(); q.done = done.get();
+        q.done_host = hflag.p;
         ADMM_HIP_CHECK(hipStreamSynchronize(st));
     }
 
@@ -670,6 +772,7 @@ struct WidePlan final : LassoPlan {
         admm_stats S = setup_stats;
         res.lambda = lam_user;
         beta.zero(st); niter.zero(st);
+        *hflag.p = 0;
         const int init_n = std::max(std::max(n, p), nwg_tail * 8);
         hipLaunchKernelGGL(wide_init_kernel, dim3((init_n + 255) / 256), dim3(256), 0, st, q, rho0, lam_int[0]);
         const int batch = pb.batch_iters > 0 ? (pb.batch_iters + 1) / 2 * 2 : 16;
@@ -693,7 +796,7 @@ struct WidePlan final : LassoPlan {
                 allreduce_sum_f32(axl.get(), (size_t)n, st);
             }
             hipLaunchKernelGGL(wide_tail_kernel, dim3(nwg_tail), dim3(kWideThreads), 0, st, q, par);
-        });
+        }, hflag.p);
         S.t_loop = lt.wall_s; S.loop_ms_events = lt.events_ms; S.xupdate_launches = lt.launched;
 
         res.niter.assign(nlam, 0);
