@@ -19,6 +19,7 @@ HIPCC = os.path.join(ROCM, "bin", "hipcc")
 ARCH = "gfx950"
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
             "-Wno-unused-result", f"-I{os.path.join(ROCM, 'include')}"]
+CXXFLAGS += os.environ.get("ADMM_HIP_EXTRA_CXXFLAGS", "").split()      # dev builds only (e.g. -DADMM_HIP_PROBE)
 LDFLAGS = ["-shared", "-fPIC", f"--offload-arch={ARCH}", f"-L{os.path.join(ROCM, 'lib')}",
            "-lrccl", "-ldl", f"-Wl,-rpath,{os.path.join(ROCM, 'lib')}"]
 

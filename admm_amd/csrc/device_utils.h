@@ -23,6 +23,49 @@ __device__ __forceinline__ T wave_max(T v) {
     return v;
 }
 
+// Halving butterfly for 8 values per lane over the wave.  `_top` performs the xor-32 / 16 / 8 steps: afterwards lane l
+// holds, for value (l >> 3), the sum over the 8 lanes congruent to l mod 8.  `halving_sum8` adds the xor-4 / 2 / 1 steps:
+// lane l holds the wave total of value (l >> 3).  Every addition is one that wave_sum performs for that value, pair by
+// pair and in the same step order, so the totals are bit-identical to eight wave_sum calls (IEEE addition commutes) at a
+// third of the exchanges (7 + 3 instead of 48).
+template <typename T>
+__device__ __forceinline__ T halving_sum8_top(const T (&v)[8], int lane) {
+    T a4[4], a2[2];
+    {
+        const int b = (lane >> 5) & 1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const T keep = b ? v[k + 4] : v[k], send = b ? v[k] : v[k + 4];
+            a4[k] = keep + __shfl_xor(send, 32, kWave);
+        }
+    }
+    {
+        const int b = (lane >> 4) & 1;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const T keep = b ? a4[k + 2] : a4[k], send = b ? a4[k] : a4[k + 2];
+            a2[k] = keep + __shfl_xor(send, 16, kWave);
+        }
+    }
+    const int b = (lane >> 3) & 1;
+    const T keep = b ? a2[1] : a2[0], send = b ? a2[0] : a2[1];
+    return keep + __shfl_xor(send, 8, kWave);
+}
+template <typename T>
+__device__ __forceinline__ T halving_sum8(const T (&v)[8], int lane) {
+    T r = halving_sum8_top(v, lane);
+    r += __shfl_xor(r, 4, kWave);
+    r += __shfl_xor(r, 2, kWave);
+    r += __shfl_xor(r, 1, kWave);
+    return r;
+}
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, src);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), src);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 // Deterministic block-wide sum of NV values per thread; result valid in every thread.
 // scratch: NV * (blockDim/64) elements of LDS.
 template <typename T, int NV>

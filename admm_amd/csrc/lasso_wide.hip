@@ -102,7 +102,24 @@ struct WideParams {
     float* beta; int* niter; int* done;
     int* done_host;                       // pinned host word, set together with *done (loop_driver.h: PinnedFlag)
     double* trace; long long trace_cap;   // optional decision records (admm_hip_lasso_plan_trace_*), or NULL
+#ifdef ADMM_HIP_PROBE
+    long long* probe;                     // dev build only: in-kernel timestamps [4096 iterations][4 observers][8]
+#endif
 };
+
+// Dev build (-DADMM_HIP_PROBE): wall-clock (100 MHz) timestamps of a few workgroups, one record per decision, dumped by
+// WidePlan::run when ADMM_HIP_PROBE_OUT names a file.  Compiled out of the product.
+#ifdef ADMM_HIP_PROBE
+#define WIDE_PROBE_DECL long long pt_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define WIDE_PROBE(k) do { pt_[k] = wall_clock64(); } while (0)
+#define WIDE_PROBE_FLUSH(obs, total) do { if (q.probe && threadIdx.x == 0 && (obs) >= 0) {                                  \
+        long long* d_ = q.probe + ((size_t)((total) & 4095) * 4 + (obs)) * 8;                                                \
+        _Pragma("unroll") for (int k_ = 0; k_ < 8; ++k_) d_[k_] = pt_[k_]; } } while (0)
+#else
+#define WIDE_PROBE_DECL
+#define WIDE_PROBE(k) do {} while (0)
+#define WIDE_PROBE_FLUSH(obs, total) do {} while (0)
+#endif
 
 __device__ __forceinline__ bool is_regular_update(unsigned int x) {      // 4^k - 1   ADMMLassoWide.h:121-127
     if (x == 0 || x == 3 || x == 15 || x == 63) return true;
@@ -140,18 +157,21 @@ __device__ __forceinline__ void wide_norms_finish(const WideParams& q, int lane,
         for (int k = 0; k < 5; ++k) sums[k] += q.P[(size_t)row * 8 + k];
     }
 }
-__device__ __forceinline__ WideDecision wide_decide(const WideParams& q, const WideCtl& in, double (&sums)[5]) {
+__device__ __forceinline__ WideDecision wide_decide(const WideParams& q, const WideCtl& in, const double (&sums)[5], int lane) {
     int lam_finished = -1, niter_val = 0;
-    // every wave reduces the norm partials itself (fixed order), no LDS, no barrier
-#pragma unroll
-    for (int k = 0; k < 5; ++k) sums[k] = wave_sum(sums[k]);
-    const double r2 = sums[0], dz2 = sums[1], ax2 = sums[2], z2 = sums[3], y2 = sums[4];
+    // Every wave reduces the norm partials itself (fixed order, no LDS, no barrier): the five sums through one halving
+    // butterfly (bit-identical to five wave_sum calls), then ONE square-root sequence with lane 8 k working on sum k,
+    // and the five results read back as wave-uniform scalars.
+    const double v8[8] = {sums[0], sums[1], sums[2], sums[3], sums[4], 0.0, 0.0, 0.0};
+    const double root = sqrt(halving_sum8(v8, lane));
+    const double sq_r2 = readlane_f64(root, 0), sq_dz2 = readlane_f64(root, 8), sq_ax2 = readlane_f64(root, 16);
+    const double sq_z2 = readlane_f64(root, 24), sq_y2 = readlane_f64(root, 32);
     WideCtl out = in;
     out.first = 0;
     double tr_rp = 0, tr_rd = 0; int tr_code = ADMM_TRACE_COLD;
     if (!in.first) {
-        const double rp = sqrt(r2);                                   // resid_primal = ||Ax + z||       ADMMBase.h:181
-        const double rd = in.rho * q.sqrt_gamma * sqrt(dz2);          // rho sqrt(sprad) ||z_new - z||   ADMMLassoWide.h:183-186
+        const double rp = sq_r2;                                      // resid_primal = ||Ax + z||       ADMMBase.h:181
+        const double rd = in.rho * q.sqrt_gamma * sq_dz2;             // rho sqrt(sprad) ||z_new - z||   ADMMLassoWide.h:183-186
         tr_rp = rp; tr_rd = rd; tr_code = (rp < in.eps_primal && rd < in.eps_dual) ? ADMM_TRACE_CONVERGED : ADMM_TRACE_CONTINUE;
         if (rp < in.eps_primal && rd < in.eps_dual) { lam_finished = in.lam_idx; niter_val = in.iter + 1; }
         else {
@@ -173,8 +193,8 @@ __device__ __forceinline__ WideDecision wide_decide(const WideParams& q, const W
         }
     }
     // eps for this iteration from the current Ax, z, y (ADMMLassoWide.h:174-182)
-    out.eps_primal = fmax(sqrt(ax2), sqrt(z2)) * q.eps_rel + q.sqrt_n * q.eps_abs;
-    out.eps_dual = q.sqrt_gamma * sqrt(y2) * q.eps_rel + q.sqrt_p * q.eps_abs;
+    out.eps_primal = fmax(sq_ax2, sq_z2) * q.eps_rel + q.sqrt_n * q.eps_abs;
+    out.eps_dual = q.sqrt_gamma * sq_y2 * q.eps_rel + q.sqrt_p * q.eps_abs;
     // which x-update runs now (ADMMLassoWide.h:129-155 / ADMMEnet.h:124-141)
     if (!q.enet) {
         if ((double)out.lam > (double)q.lambda0 - 1e-5) out.type = W_ZERO;        // counter not advanced
@@ -212,6 +232,10 @@ wide_x_kernel(WideParams q, int par) {
     // loop that waited on each of its 8 passes, then the norm partials -- to be a chain of ~12 dependent round trips:
     // the active-set launch took 12 us.)  The empty asm with a memory clobber keeps the compiler from sinking the
     // loads below the branches that follow.
+    WIDE_PROBE_DECL
+    WIDE_PROBE(0);
+    const int pobs = blockIdx.x == 0 ? 0 : ((int)blockIdx.x == kActWG - 1 ? 1 : (blockIdx.x == gridDim.x - 1 ? 2 : -1));
+    (void)pobs;
     const WideCtlRaw in_raw = wide_ctl_request(q.ctl + par);
     WideCtl* outp = &q.ctl[par ^ 1];
     const bool always = RT == 0 || (int)blockIdx.x < kActWG;
@@ -236,20 +260,47 @@ wide_x_kernel(WideParams q, int par) {
     const WideNormRaw nraw = wide_norms_request(q, lane);
     __builtin_amdgcn_sched_barrier(0);                                 // every request above is issued before the first use below
     asm volatile("" ::: "memory");
-    const WideCtl in = wide_ctl_unpack(in_raw);
+    constexpr int NRT = RT > 0 ? RT : 1;
+    const int nv = (q.n + 3) / 4 * 4;
+    // fused mode: col_request puts a whole column in flight (RT 16-byte loads per lane, reused by the gather)
+    auto col_request = [&](long long jj, float4 (&cv)[NRT]) {
+        const float* col = q.X + (size_t)jj * q.ldx;
+#pragma unroll
+        for (int k = 0; k < NRT; ++k) {
+            const int r = k * 256 + lane * 4;
+            cv[k] = r < nv ? *reinterpret_cast<const float4*>(col + r) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    // Speculative request of this wave's first non-zero column: almost every step is an active-set step, and what it reads
+    // first does not depend on the decision -- so the column's round trip overlaps the decision and the staging of t
+    // (a regular / zero / final step simply drops it).
+    constexpr bool kSpec = RT > 0 && RT <= 8;                          // RT = 16: a second column in registers would halve the occupancy
+    float4 cv0[kSpec ? NRT : 1];
+    long long pj = -1;
     if (RT > 0 && always) {
 #pragma unroll
         for (int u = 0; u < 8; ++u)
             if ((long long)(u * 64 + lane) * NWa + w >= q.p) xs0[u] = 0.f;
+        if constexpr (kSpec) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const unsigned long long m = __ballot(xs0[u] != 0.f);
+                if (pj < 0 && m != 0) pj = (long long)(u * 64 + __ffsll((long long)m) - 1) * NWa + w;
+            }
+            if (pj >= 0) col_request(pj, cv0);
+        }
     }
+    const WideCtl in = wide_ctl_unpack(in_raw);
     double sums[5];
     wide_norms_finish(q, lane, nraw, sums);
     if (in.done) {
         if (blockIdx.x == 0 && threadIdx.x == 0) *outp = in;
         return;
     }
-    const WideDecision dec = wide_decide(q, in, sums);
+    WIDE_PROBE(1);
+    const WideDecision dec = wide_decide(q, in, sums, lane);
     const WideCtl out = wide_ctl_uniform(dec.out);
+    WIDE_PROBE(2);
     const int lam_finished = __builtin_amdgcn_readfirstlane(dec.lam_finished), niter_val = __builtin_amdgcn_readfirstlane(dec.niter_val);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (lam_finished >= 0) q.niter[lam_finished] = niter_val;
@@ -274,7 +325,7 @@ wide_x_kernel(WideParams q, int par) {
     const bool reg = out.type == W_REG;
     // fused: an active-set iteration is done by the first kActWG workgroups only (few columns, few partials);
     // the others leave here, before any barrier or LDS traffic
-    if (RT > 0 && !reg && !always) return;
+    if (RT > 0 && !reg && !always) { WIDE_PROBE_FLUSH(pobs, in.total); return; }
     if (!TG) {
         // t = cache_Ax + aux_z + dual_y / Scalar(rho); the active-set form divides by gamma first (:90, :141)
         const float rho_f = (float)out.rho;
@@ -312,6 +363,7 @@ wide_x_kernel(WideParams q, int par) {
         }
         __syncthreads();
     }
+    WIDE_PROBE(3);
     const double pen_d = (double)out.lam / (out.rho * (double)q.gamma);
     const float penalty = (float)pen_d;                               // `const Scalar penalty` (:89)
     const float thresh_a = q.enet ? q.alpha * penalty : penalty;
@@ -321,49 +373,12 @@ wide_x_kernel(WideParams q, int par) {
     const float* tv = TG ? q.tbuf : (reg ? tl : tdl);
     const int nblk = (RT > 0 && !reg) ? min((int)gridDim.x, kActWG) : (int)gridDim.x;
     const int NW = nblk * (kWideThreads / 64);
-    const int nv = (q.n + 3) / 4 * 4;
     float4 acc[RT > 0 ? RT : 1];
 #pragma unroll
     for (int k = 0; k < (RT > 0 ? RT : 1); ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
 
     // One column: d = X_j't (or X_j't/gamma), the prox, and (fused) acc += x_j X_j.  Returns the new x_j (wave uniform).
-    auto column = [&](long long jj, float xv) -> float {
-        const float* col = q.X + (size_t)jj * q.ldx;
-        float d0 = 0.f, d1 = 0.f;
-        float4 cv[RT > 0 ? RT : 1];
-        if (RT > 0) {
-            // the whole column in registers: all loads in flight at once, reused by the gather below
-#pragma unroll
-            for (int k = 0; k < RT; ++k) {
-                const int r = k * 256 + lane * 4;
-                cv[k] = r < nv ? *reinterpret_cast<const float4*>(col + r) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#pragma unroll
-            for (int k = 0; k < RT; ++k) {
-                const int r = k * 256 + lane * 4;
-                if (r < nv) {
-                    const float4 b = *reinterpret_cast<const float4*>(tv + r);
-                    float& dd = (k & 1) ? d1 : d0;
-                    dd = fmaf(cv[k].x, b.x, dd); dd = fmaf(cv[k].y, b.y, dd); dd = fmaf(cv[k].z, b.z, dd); dd = fmaf(cv[k].w, b.w, dd);
-                }
-            }
-        } else {
-            int r = lane * 4;
-            for (; r + 256 < nv; r += 512) {
-                const float4 a0 = *reinterpret_cast<const float4*>(col + r);
-                const float4 a1 = *reinterpret_cast<const float4*>(col + r + 256);
-                const float4 b0 = *reinterpret_cast<const float4*>(tv + r);
-                const float4 b1 = *reinterpret_cast<const float4*>(tv + r + 256);
-                d0 = fmaf(a0.x, b0.x, d0); d0 = fmaf(a0.y, b0.y, d0); d0 = fmaf(a0.z, b0.z, d0); d0 = fmaf(a0.w, b0.w, d0);
-                d1 = fmaf(a1.x, b1.x, d1); d1 = fmaf(a1.y, b1.y, d1); d1 = fmaf(a1.z, b1.z, d1); d1 = fmaf(a1.w, b1.w, d1);
-            }
-            if (r < nv) {
-                const float4 a0 = *reinterpret_cast<const float4*>(col + r);
-                const float4 b0 = *reinterpret_cast<const float4*>(tv + r);
-                d0 = fmaf(a0.x, b0.x, d0); d0 = fmaf(a0.y, b0.y, d0); d0 = fmaf(a0.z, b0.z, d0); d0 = fmaf(a0.w, b0.w, d0);
-            }
-        }
-        const float d = wave_sum(d0 + d1);
+    auto finish = [&](float d, float xv) -> float {
         float xn;
         if (reg) {
             const float vec = (-d) / q.gamma + xv;                    // vec = -X't / gamma; vec += main_x   (:147-149)
@@ -376,14 +391,54 @@ wide_x_kernel(WideParams q, int par) {
         } else {
             xn = prox_f(xv - d, thresh_a, denom_a, q.enet != 0);
         }
-        if (RT > 0 && xn != 0.f) {                                     // gather: Ax partial += x_j X_j
+        return xn;
+    };
+    // fused mode: consume a column that col_request put in flight
+    auto col_finish = [&](float xv, const float4 (&cv)[NRT]) -> float {
+        float d0 = 0.f, d1 = 0.f;
 #pragma unroll
-            for (int k = 0; k < RT; ++k) {
+        for (int k = 0; k < NRT; ++k) {
+            const int r = k * 256 + lane * 4;
+            if (r < nv) {
+                const float4 b = *reinterpret_cast<const float4*>(tv + r);
+                float& dd = (k & 1) ? d1 : d0;
+                dd = fmaf(cv[k].x, b.x, dd); dd = fmaf(cv[k].y, b.y, dd); dd = fmaf(cv[k].z, b.z, dd); dd = fmaf(cv[k].w, b.w, dd);
+            }
+        }
+        const float xn = finish(wave_sum(d0 + d1), xv);
+        if (xn != 0.f) {                                               // gather: Ax partial += x_j X_j
+#pragma unroll
+            for (int k = 0; k < NRT; ++k) {
                 acc[k].x = fmaf(xn, cv[k].x, acc[k].x); acc[k].y = fmaf(xn, cv[k].y, acc[k].y);
                 acc[k].z = fmaf(xn, cv[k].z, acc[k].z); acc[k].w = fmaf(xn, cv[k].w, acc[k].w);
             }
         }
         return xn;
+    };
+    auto column = [&](long long jj, float xv) -> float {
+        if (RT > 0) {
+            if constexpr (kSpec) { if (!reg && jj == pj) return col_finish(xv, cv0); }     // requested before the decision
+            float4 cv[NRT];
+            col_request(jj, cv);
+            return col_finish(xv, cv);
+        }
+        const float* col = q.X + (size_t)jj * q.ldx;
+        float d0 = 0.f, d1 = 0.f;
+        int r = lane * 4;
+        for (; r + 256 < nv; r += 512) {
+            const float4 a0 = *reinterpret_cast<const float4*>(col + r);
+            const float4 a1 = *reinterpret_cast<const float4*>(col + r + 256);
+            const float4 b0 = *reinterpret_cast<const float4*>(tv + r);
+            const float4 b1 = *reinterpret_cast<const float4*>(tv + r + 256);
+            d0 = fmaf(a0.x, b0.x, d0); d0 = fmaf(a0.y, b0.y, d0); d0 = fmaf(a0.z, b0.z, d0); d0 = fmaf(a0.w, b0.w, d0);
+            d1 = fmaf(a1.x, b1.x, d1); d1 = fmaf(a1.y, b1.y, d1); d1 = fmaf(a1.z, b1.z, d1); d1 = fmaf(a1.w, b1.w, d1);
+        }
+        if (r < nv) {
+            const float4 a0 = *reinterpret_cast<const float4*>(col + r);
+            const float4 b0 = *reinterpret_cast<const float4*>(tv + r);
+            d0 = fmaf(a0.x, b0.x, d0); d0 = fmaf(a0.y, b0.y, d0); d0 = fmaf(a0.z, b0.z, d0); d0 = fmaf(a0.w, b0.w, d0);
+        }
+        return finish(wave_sum(d0 + d1), xv);
     };
 
     for (int sc = 0; (long long)sc * NW < q.p; sc += 64 * 8) {
@@ -411,27 +466,34 @@ wide_x_kernel(WideParams q, int par) {
             }
         }
     }
+    WIDE_PROBE(4);
     if (RT > 0) {
-        // combine the 4 waves of the workgroup through the (now free) t buffers, 4 row slices per round, then write
-        // this workgroup's partial row
-        float4* red = reinterpret_cast<float4*>(smem_raw);             // >= 4 * kWideThreads float4 (launch)
+        // combine the 4 waves of the workgroup through the (now free) t buffers, up to 8 row slices per round (one round
+        // for n <= 2048), then write this workgroup's partial row
+        constexpr int RS = RT < 8 ? RT : 8;
+        float4* red = reinterpret_cast<float4*>(smem_raw);             // >= RS * kWideThreads float4 (launch)
 #pragma unroll
-        for (int k0 = 0; k0 < RT; k0 += 4) {
+        for (int k0 = 0; k0 < RT; k0 += RS) {
             __syncthreads();
 #pragma unroll
-            for (int k = 0; k < 4; ++k) red[k * kWideThreads + threadIdx.x] = acc[k0 + k];
+            for (int k = 0; k < RS; ++k) red[k * kWideThreads + threadIdx.x] = acc[k0 + k];
             __syncthreads();
-            const int k = threadIdx.x >> 6, ln = threadIdx.x & 63;     // 4 slices x 64 lanes = one output per thread
-            float4 sacc = red[k * kWideThreads + ln];
 #pragma unroll
-            for (int ww = 1; ww < kWideThreads / 64; ++ww) {
-                const float4 v = red[k * kWideThreads + ww * 64 + ln];
-                sacc.x += v.x; sacc.y += v.y; sacc.z += v.z; sacc.w += v.w;
+            for (int h = 0; h < RS / 4; ++h) {                         // RS slices x 64 lanes outputs, RS / 4 per thread
+                const int k = h * 4 + (threadIdx.x >> 6), ln = threadIdx.x & 63;
+                float4 sacc = red[k * kWideThreads + ln];
+#pragma unroll
+                for (int ww = 1; ww < kWideThreads / 64; ++ww) {
+                    const float4 v = red[k * kWideThreads + ww * 64 + ln];
+                    sacc.x += v.x; sacc.y += v.y; sacc.z += v.z; sacc.w += v.w;
+                }
+                const int rr = (k0 + k) * 256 + ln * 4;
+                if (rr < q.ldn) *reinterpret_cast<float4*>(q.axpart + (size_t)blockIdx.x * q.ldn + rr) = sacc;
             }
-            const int rr = (k0 + k) * 256 + ln * 4;
-            if (rr < q.ldn) *reinterpret_cast<float4*>(q.axpart + (size_t)blockIdx.x * q.ldn + rr) = sacc;
         }
     }
+    WIDE_PROBE(5);
+    WIDE_PROBE_FLUSH(pobs, in.total);
 }
 
 // Large-n mode (2 n floats exceed the LDS of a workgroup): t = Ax + z + y / rho of the iteration about to run (divided by
@@ -444,7 +506,7 @@ wide_t_kernel(WideParams q, int par) {
     double sums[5];
     wide_norms_finish(q, threadIdx.x & 63, wide_norms_request(q, threadIdx.x & 63), sums);
     if (in.done) return;
-    const WideCtl out = wide_decide(q, in, sums).out;
+    const WideCtl out = wide_decide(q, in, sums, threadIdx.x & 63).out;
     if (out.done || out.type == W_ZERO) return;
     const int i = blockIdx.x * kWideThreads + threadIdx.x;
     if (i >= q.ldn) return;
@@ -578,6 +640,8 @@ wide_ax_local_kernel(WideParams q, int par, float* out) {
 __global__ void __launch_bounds__(kWideThreads)
 wide_tail_kernel(WideParams q, int par) {
     __shared__ double scratch[5 * (kWideThreads / 64)];
+    WIDE_PROBE_DECL
+    WIDE_PROBE(0);
     const WideCtl c = q.ctl[par ^ 1];
     const int sub = threadIdx.x & (kWtLanes - 1);
     const int i = blockIdx.x * kWtElems + threadIdx.x / kWtLanes;
@@ -585,6 +649,7 @@ wide_tail_kernel(WideParams q, int par) {
     WIDE_SUM_AXPART(ax)
     if (q.ax_given != nullptr) ax = valid ? q.ax_given[i] : 0.f;      // column-sharded mode: already summed over partials and ranks
     if (c.done) return;
+    WIDE_PROBE(1);
     double acc[5] = {0, 0, 0, 0, 0};
     if (valid && sub == 0) {
         const float rho_f = (float)c.rho;
@@ -597,12 +662,23 @@ wide_tail_kernel(WideParams q, int par) {
         acc[0] = (double)r * r; acc[1] = (double)dz * dz; acc[2] = (double)ax * ax;
         acc[3] = (double)zn * zn; acc[4] = (double)yn * yn;
     }
-    block_sum<double, 5>(acc, scratch);
-    if (threadIdx.x == 0) {
-        double* Pout = q.P + (size_t)blockIdx.x * 8;
-#pragma unroll
-        for (int k = 0; k < 5; ++k) Pout[k] = acc[k];
+    // Block sum of the five norms.  Only the lanes with sub == 0 hold values, so wave_sum's xor-4 / 2 / 1 steps would add
+    // exact zeros: the halving butterfly's top half (xor 32 / 16 / 8) leaves the wave total of value k in lane 8 k,
+    // bit-identical to block_sum<double, 5> at 7 exchanges instead of 30.
+    {
+        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+        const double v8[8] = {acc[0], acc[1], acc[2], acc[3], acc[4], 0.0, 0.0, 0.0};
+        const double tot = halving_sum8_top(v8, lane);
+        if ((lane & 7) == 0 && lane < 40) scratch[(lane >> 3) * (kWideThreads / 64) + wid] = tot;
+        __syncthreads();
+        if (threadIdx.x < 5) {
+            double sum = 0;
+            for (int ww = 0; ww < kWideThreads / 64; ++ww) sum += scratch[threadIdx.x * (kWideThreads / 64) + ww];
+            q.P[(size_t)blockIdx.x * 8 + threadIdx.x] = sum;
+        }
     }
+    WIDE_PROBE(2);
+    WIDE_PROBE_FLUSH(blockIdx.x == 0 ? 3 : -1, c.total - 1);
 }
 
 __global__ void wide_init_kernel(WideParams q, double rho, float lam0) {
@@ -641,6 +717,9 @@ struct WidePlan final : LassoPlan {
     DevBuf<double> P;
     DevBuf<WideCtl> ctl;
     PinnedFlag hflag;
+#ifdef ADMM_HIP_PROBE
+    DevBuf<long long> probe;
+#endif
     WideParams q{};
     DevBuf<double> trace;
     long long trace_cap = 0, trace_n = 0;
@@ -720,7 +799,7 @@ struct WidePlan final : LassoPlan {
         // ADMM_HIP_WIDE_FUSE=0: always three launches per iteration
         fuse_rt = n <= 1024 ? 4 : (n <= 2048 ? 8 : (n <= 4096 ? 16 : 0));
         if (const char* e = std::getenv("ADMM_HIP_WIDE_FUSE")) if (std::string(e) == "0") fuse_rt = 0;
-        lds_x = std::max((size_t)((n + 255) / 256 * 256) * 2 * sizeof(float), (size_t)4 * kWideThreads * sizeof(float4));
+        lds_x = std::max((size_t)((n + 255) / 256 * 256) * 2 * sizeof(float), (size_t)std::min(std::max(fuse_rt, 4), 8) * kWideThreads * sizeof(float4));
         // The x-update stages t and t / gamma (2 n floats) in dynamic LDS: up to 64 KB by default, up to the device's
         // opt-in limit (160 KB on gfx950) after raising the kernel's attribute; beyond that (n > ~20 000) t goes through
         // global memory instead (one more small launch per iteration).  ADMM_HIP_WIDE_TGLOBAL=1 forces that mode.
@@ -765,6 +844,10 @@ struct WidePlan final : LassoPlan {
         q.axpart = axpart.get(); q.tbuf = tbuf.get(); q.ldn = ldn; q.fused = fuse_rt ? 1 : 0; q.nwg_x = nwg_x;
         q.ctl = ctl.get(); q.P = P.get(); q.beta = beta.get(); q.niter = niter.get(); q.done = done.get();
         q.done_host = hflag.p;
+#ifdef ADMM_HIP_PROBE
+        probe.alloc((size_t)4096 * 4 * 8); probe.zero(st);
+        q.probe = probe.get();
+#endif
         ADMM_HIP_CHECK(hipStreamSynchronize(st));
     }
 
@@ -798,6 +881,13 @@ struct WidePlan final : LassoPlan {
             hipLaunchKernelGGL(wide_tail_kernel, dim3(nwg_tail), dim3(kWideThreads), 0, st, q, par);
         }, hflag.p);
         S.t_loop = lt.wall_s; S.loop_ms_events = lt.events_ms; S.xupdate_launches = lt.launched;
+#ifdef ADMM_HIP_PROBE
+        if (const char* f = std::getenv("ADMM_HIP_PROBE_OUT")) {
+            std::vector<long long> hp((size_t)4096 * 4 * 8);
+            ADMM_HIP_CHECK(hipMemcpy(hp.data(), probe.get(), hp.size() * sizeof(long long), hipMemcpyDeviceToHost));
+            if (FILE* fp = std::fopen(f, "wb")) { std::fwrite(hp.data(), sizeof(long long), hp.size(), fp); std::fclose(fp); }
+        }
+#endif
 
         res.niter.assign(nlam, 0);
         ADMM_HIP_CHECK(hipMemcpy(res.niter.data(), niter.get(), nlam * sizeof(int), hipMemcpyDeviceToHost));
