@@ -36,6 +36,7 @@
 #include "symv_kernels.h"
 #include "solvers.h"
 #include "comm.h"
+#include "loop_driver.h"
 #include "peer_device.h"
 
 namespace admm {
@@ -69,6 +70,7 @@ struct TallParams {
     double* P;                  // [2][nwg][8]
     float* beta;                // [nlam][p] snapshots of z (standardised scale)
     int* niter;                 // [nlam]
+    int* done_host;             // pinned host word set when the path has finished (loop_driver.h: PinnedFlag)
     double* trace;              // optional [trace_cap][kTraceFields] decision records (admm_hip_lasso_plan_trace_*), or NULL
     long long trace_cap;
 };
@@ -156,6 +158,7 @@ __device__ void tall_decide(const TallParams& q, int par) {
     out.tau_next = (out.adj_a - 1.0) / out.a_next;
     out.total = in.total + 1;
     *outp = out;
+    if (out.done) *q.done_host = 1;
     if (q.trace != nullptr && in.total < q.trace_cap) {      // what FADMMBase.h:135-170 (print_row, commented out there) would print
         double* t = q.trace + (size_t)in.total * ADMM_TRACE_FIELDS;
         t[0] = in.lam_idx; t[1] = in.iter; t[2] = in.eps_primal; t[3] = in.eps_dual; t[4] = tr_rp; t[5] = tr_rd;
@@ -278,11 +281,21 @@ tall_tail_kernel(TallParams q, int par, PeerExchange ex) {
     double acc[6] = {0, 0, 0, 0, 0, 0};
     if (owner) tall_update_elem(q, c, par, i, e, a, b, acc);
     if (c.done) return;
-    block_sum<double, 6>(acc, scratch);
-    if (threadIdx.x == 0) {
-        double* Pout = q.P + ((size_t)(par ^ 1) * q.nwg + blockIdx.x) * 8;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) Pout[k] = acc[k];
+    // Block sum of the six norms.  Only the owner lanes (sub == 0) hold values, so wave_sum's xor-4 / 2 / 1 steps would add
+    // exact zeros: the top half of the halving butterfly (xor 32 / 16 / 8) leaves the wave total of value k in lane 8 k,
+    // bit-identical to block_sum<double, 6> at 7 exchanges instead of 36.
+    static_assert(kTailLanes == 8, "owner lanes are the multiples of 8");
+    {
+        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+        const double v8[8] = {acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], 0.0, 0.0};
+        const double tot = halving_sum8_top(v8, lane);
+        if ((lane & 7) == 0 && lane < 48) scratch[(lane >> 3) * (kTailThreads / 64) + wid] = tot;
+        __syncthreads();
+        if (threadIdx.x < 6) {
+            double sum = 0;
+            for (int ww = 0; ww < kTailThreads / 64; ++ww) sum += scratch[threadIdx.x * (kTailThreads / 64) + ww];
+            q.P[((size_t)(par ^ 1) * q.nwg + blockIdx.x) * 8 + threadIdx.x] = sum;
+        }
     }
 }
 
@@ -453,6 +466,7 @@ struct TallPlan final : LassoPlan {
     DevBuf<double> trace;
     long long trace_cap = 0, trace_n = 0;
     TallCtl* hctl = nullptr;
+    PinnedFlag hflag;
     float* hbeta = nullptr;                             // pinned landing buffer of the beta snapshots (nlam x p)
 
     std::vector<hipEvent_t> ev_pool;                    // start/stop events of sampled x-update launches, reused by every run()
@@ -584,6 +598,7 @@ struct TallPlan final : LassoPlan {
         q.x = x.get(); q.z0 = z0.get(); q.z1 = z1.get(); q.y0 = y0.get(); q.y1 = y1.get();
         q.adj_z = adj_z.get(); q.adj_y = adj_y.get(); q.u = u.get(); q.w = w.get();
         q.ctl = ctl.get(); q.P = P.get(); q.beta = beta.get(); q.niter = niter.get();
+        q.done_host = hflag.p;
 
         // Pinned mirror of the control block for asynchronous polling.
         ADMM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&hctl), 2 * sizeof(TallCtl), hipHostMallocDefault));
@@ -624,6 +639,7 @@ struct TallPlan final : LassoPlan {
         hipLaunchKernelGGL(tall_init_kernel, dim3((init_n + 255) / 256), dim3(256), 0, st, q, rho, lam_int[0]);
         if (fused) { fflag.zero(st); farrive.zero(st); }
         hctl[0].done = hctl[1].done = 0;
+        *hflag.p = 0;
 
         const int batch = pb.batch_iters > 0 ? (pb.batch_iters + 1) / 2 * 2 : 32;    // even
         const int stride = pb.profile_stride;                          // sample every stride-th x-update with events
@@ -681,8 +697,11 @@ struct TallPlan final : LassoPlan {
                 }
                 ++launches;
             }
-            // after an even number of iterations the freshest control block is slot g&1 == 0
-            ADMM_HIP_CHECK(hipMemcpyAsync(&hctl[slot], &ctl.get()[(int)(g & 1)], sizeof(TallCtl), hipMemcpyDeviceToHost, st));
+            // Single rank: no copy per poll, the deciding workgroup sets the pinned flag itself when the path has finished.
+            // Sharded over ranks: every rank must enqueue the SAME number of exchanges, so the stop decision has to be a
+            // deterministic function of the stream position -- the control block sampled in stream order after each
+            // batch -- not of when a flag store happens to become visible to this host.
+            if (shard) ADMM_HIP_CHECK(hipMemcpyAsync(&hctl[slot], &ctl.get()[(int)(g & 1)], sizeof(TallCtl), hipMemcpyDeviceToHost, st));
             ADMM_HIP_CHECK(hipEventRecord(ev_poll[slot].e, st));
         };
         // ADMM_HIP_TALL_GRAPH=1 (A/B knob): capture one batch (an even number of iterations, so the parity pattern repeats)
@@ -716,7 +735,6 @@ struct TallPlan final : LassoPlan {
         auto enqueue_batch_graph = [&](int slot) {
             ADMM_HIP_CHECK(hipGraphLaunch(gexec, st));
             g += batch; launches += batch;
-            ADMM_HIP_CHECK(hipMemcpyAsync(&hctl[slot], &ctl.get()[(int)(g & 1)], sizeof(TallCtl), hipMemcpyDeviceToHost, st));
             ADMM_HIP_CHECK(hipEventRecord(ev_poll[slot].e, st));
         };
         int slot = 0;
@@ -727,13 +745,14 @@ struct TallPlan final : LassoPlan {
             if (use_graph) enqueue_batch_graph(slot ^ 1); else enqueue_batch(slot ^ 1);      // keep one batch in flight while polling the previous one
             ADMM_HIP_CHECK(hipEventSynchronize(ev_poll[slot].e));
             comm_check();
-            done = hctl[slot].done != 0;
+            done = shard ? hctl[slot].done != 0 : *static_cast<volatile int*>(hflag.p) != 0;
             slot ^= 1;
             if (!done && g > max_total) throw Error(ADMM_ERR_INTERNAL, "tall path: iteration bound exceeded without completion");
         }
         ADMM_HIP_CHECK(hipEventRecord(ev_loop1.e, st));
         ADMM_HIP_CHECK(hipStreamSynchronize(st));
         S.t_loop = now_s() - tl0;
+        ADMM_HIP_CHECK(hipMemcpy(hctl, ctl.get(), 2 * sizeof(TallCtl), hipMemcpyDeviceToHost));      // both slots: decisions taken
         if (gexec) (void)hipGraphExecDestroy(gexec);
         float ms = 0.f;
         ADMM_HIP_CHECK(hipEventElapsedTime(&ms, ev_loop0.e, ev_loop1.e));

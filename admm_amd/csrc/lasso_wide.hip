@@ -879,7 +879,7 @@ struct WidePlan final : LassoPlan {
                 allreduce_sum_f32(axl.get(), (size_t)n, st);
             }
             hipLaunchKernelGGL(wide_tail_kernel, dim3(nwg_tail), dim3(kWideThreads), 0, st, q, par);
-        }, hflag.p);
+        }, cshard ? nullptr : hflag.p);       // column-sharded: every rank must enqueue the same number of exchanges -> stream-ordered sampling of `done`
         S.t_loop = lt.wall_s; S.loop_ms_events = lt.events_ms; S.xupdate_launches = lt.launched;
 #ifdef ADMM_HIP_PROBE
         if (const char* f = std::getenv("ADMM_HIP_PROBE_OUT")) {

@@ -25,7 +25,9 @@ struct PinnedFlag {
 // enqueue(g): enqueue every kernel of iteration g (g = 0, 1, 2, ...) on `st`.
 // d_done: device int that the iteration kernels set to non-zero once the solve is finished; all
 // kernels must be no-ops afterwards.  `batch` iterations are enqueued between two polls.
-// h_flag (optional): a PinnedFlag word the kernels set together with d_done -- then no copy is enqueued per poll (a
+// h_flag (optional, SINGLE-RANK solves only: when a flag store becomes visible to the host is not a function of the stream
+// position, and ranks that exchange data per iteration must all stop after the same number of enqueued iterations):
+// a PinnedFlag word the kernels set together with d_done -- then no copy is enqueued per poll (a
 // 4-byte device-to-host copy is a blit launch plus a system-scope release: ~14 us of stream time per batch, measured on
 // the wide path), and the batch grows from `batch` to 4 x `batch` as the solve gets long.
 template <typename F>

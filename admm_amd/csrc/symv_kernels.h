@@ -278,24 +278,34 @@ template <int NL>
 __device__ __forceinline__ void symv_sum_partials(const float* __restrict__ dot0, const float* __restrict__ dot1,
                                                   const float* __restrict__ axp0, const float* __restrict__ axp1,
                                                   long long ldo, int nrb, int ncb, int i, int sub, bool valid, float& a, float& b) {
+    // Branch-free requests: every slot loads from a clamped (always valid) address and out-of-range slots are replaced by
+    // zero afterwards, so the 32 loads of a pass are issued back to back.  (The round-2 form guarded each load by two range
+    // tests: ~25 instructions of exec-mask bookkeeping per load, ~2 us of issue time in the tall tail kernel before the
+    // last request left.)  Offsets fit 32 bits: (nrb + ncb) * ldo < 2^31 up to p ~ 5e5, far beyond what a p x p matrix allows.
+    const int ic = valid ? i : 0;
+    const int cbi = ic / kSyCB, rbi = ic / kSyRB;
+    const int rb0 = (cbi * kSyCB) / kSyRB;                              // first row block whose tiles reach column block cbi
+    const int ndot = nrb - rb0;
+    const int nax = min(ncb - 1, ((rbi + 1) * kSyRB - 1) / kSyCB) + 1;  // column blocks up to the diagonal of row block rbi
+    const int ntot = valid ? ndot + nax : 0;
+    const unsigned ld = (unsigned)ldo;
     a = 0.f; b = 0.f;
-    if (valid) {
-        const int cbi = i / kSyCB, rbi = i / kSyRB;
-        const int rb0 = (cbi * kSyCB) / kSyRB;                              // first row block whose tiles reach column block cbi
-        const int ndot = nrb - rb0;
-        const int nax = min(ncb - 1, ((rbi + 1) * kSyRB - 1) / kSyCB) + 1;  // column blocks up to the diagonal of row block rbi
-        const int ntot = ndot + nax;
-        for (int k0 = 0; k0 < ntot; k0 += 16 * NL) {
-            float va[16], vb[16];
+    for (int k0 = 0; k0 < ntot; k0 += 16 * NL) {
+        float va[16], vb[16];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int k = k0 + j * NL + sub;
-                va[j] = 0.f; vb[j] = 0.f;
-                if (k < ndot) { const size_t o = (size_t)(rb0 + k) * ldo + i; va[j] = dot0[o]; vb[j] = dot1[o]; }
-                else if (k < ntot) { const size_t o = (size_t)(k - ndot) * ldo + i; va[j] = axp0[o]; vb[j] = axp1[o]; }
-            }
+        for (int j = 0; j < 16; ++j) {
+            const int k = k0 + j * NL + sub;
+            const bool isdot = k < ndot;
+            const int row = isdot ? rb0 + k : min(k, ntot - 1) - ndot;      // clamped into the axpy rows when k >= ntot
+            const unsigned o = (unsigned)row * ld + (unsigned)ic;
+            va[j] = (isdot ? dot0 : axp0)[o];
+            vb[j] = (isdot ? dot1 : axp1)[o];
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < 16; ++j) { a += va[j]; b += vb[j]; }
+        for (int j = 0; j < 16; ++j) {
+            const bool in = k0 + j * NL + sub < ntot;
+            a += in ? va[j] : 0.f; b += in ? vb[j] : 0.f;
         }
     }
 #pragma unroll
