@@ -38,6 +38,7 @@
 #include "comm.h"
 #include "loop_driver.h"
 #include "peer_device.h"
+#include "probe.h"
 
 namespace admm {
 
@@ -71,6 +72,9 @@ struct TallParams {
     float* beta;                // [nlam][p] snapshots of z (standardised scale)
     int* niter;                 // [nlam]
     int* done_host;             // pinned host word set when the path has finished (loop_driver.h: PinnedFlag)
+#ifdef ADMM_HIP_PROBE
+    long long* probe;           // dev build only (probe.h)
+#endif
     double* trace;              // optional [trace_cap][kTraceFields] decision records (admm_hip_lasso_plan_trace_*), or NULL
     long long trace_cap;
 };
@@ -97,12 +101,15 @@ __device__ __forceinline__ void tall_store_wt(double* p, double v) {
 template <bool IN_LAUNCH = false>
 __device__ void tall_decide(const TallParams& q, int par) {
     __shared__ double dscratch[6 * (kTailThreads / 64)];
+    WIDE_PROBE_DECL
+    WIDE_PROBE(0);
     const TallCtl in = q.ctl[par];
     TallCtl* outp = &q.ctl[par ^ 1];
     if (in.done) {
         if (threadIdx.x == 0) { TallCtl o = in; o.fin_idx = -1; *outp = o; }   // keep `done` sticky in both slots
         return;
     }
+    WIDE_PROBE(1);
     double acc[6] = {0, 0, 0, 0, 0, 0};
     const double* Pin = q.P + (size_t)par * q.nwg * 8;
     for (int w = threadIdx.x; w < q.nwg; w += kTailThreads) {
@@ -111,6 +118,7 @@ __device__ void tall_decide(const TallParams& q, int par) {
     }
     block_sum<double, 6>(acc, dscratch);
     if (threadIdx.x != 0) return;
+    WIDE_PROBE(2);
     const double r2 = acc[0], dz2 = acc[1], daz2 = acc[2], x2 = acc[3], z2 = acc[4], y2 = acc[5];
     double tr_rp = 0, tr_rd = 0, tr_c = 0, tr_code = ADMM_TRACE_COLD;
     TallCtl out = in;
@@ -159,6 +167,8 @@ __device__ void tall_decide(const TallParams& q, int par) {
     out.total = in.total + 1;
     *outp = out;
     if (out.done) *q.done_host = 1;
+    WIDE_PROBE(3);
+    WIDE_PROBE_FLUSH(2, in.total);
     if (q.trace != nullptr && in.total < q.trace_cap) {      // what FADMMBase.h:135-170 (print_row, commented out there) would print
         double* t = q.trace + (size_t)in.total * ADMM_TRACE_FIELDS;
         t[0] = in.lam_idx; t[1] = in.iter; t[2] = in.eps_primal; t[3] = in.eps_dual; t[4] = tr_rp; t[5] = tr_rd;
@@ -241,6 +251,8 @@ template <int MODE>
 __global__ void __launch_bounds__(kTailThreads)
 tall_tail_kernel(TallParams q, int par, PeerExchange ex) {
     __shared__ double scratch[6 * (kTailThreads / 64)];
+    WIDE_PROBE_DECL
+    WIDE_PROBE(0);
     const TallCtl c = q.ctl[par ^ 1];
     // Every load below is independent of `c` (the ping-pong parity equals the launch parity because
     // the decision advances `total` once per launch), so the whole kernel is one memory round trip.
@@ -277,10 +289,12 @@ tall_tail_kernel(TallParams q, int par, PeerExchange ex) {
         for (int m = 1; m < kTailLanes; m <<= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }
     }
     if (c.done && c.fin_idx < 0) return;
+    WIDE_PROBE(1);
 
     double acc[6] = {0, 0, 0, 0, 0, 0};
     if (owner) tall_update_elem(q, c, par, i, e, a, b, acc);
     if (c.done) return;
+    WIDE_PROBE(2);
     // Block sum of the six norms.  Only the owner lanes (sub == 0) hold values, so wave_sum's xor-4 / 2 / 1 steps would add
     // exact zeros: the top half of the halving butterfly (xor 32 / 16 / 8) leaves the wave total of value k in lane 8 k,
     // bit-identical to block_sum<double, 6> at 7 exchanges instead of 36.
@@ -297,6 +311,8 @@ tall_tail_kernel(TallParams q, int par, PeerExchange ex) {
             q.P[((size_t)(par ^ 1) * q.nwg + blockIdx.x) * 8 + threadIdx.x] = sum;
         }
     }
+    WIDE_PROBE(3);
+    WIDE_PROBE_FLUSH(blockIdx.x == 0 ? 0 : (blockIdx.x == gridDim.x - 1 ? 1 : -1), c.total - 1);
 }
 
 // ---------------------------------------------------------------------------------------------- single-launch iteration
@@ -467,6 +483,9 @@ struct TallPlan final : LassoPlan {
     long long trace_cap = 0, trace_n = 0;
     TallCtl* hctl = nullptr;
     PinnedFlag hflag;
+#ifdef ADMM_HIP_PROBE
+    DevBuf<long long> probe;
+#endif
     float* hbeta = nullptr;                             // pinned landing buffer of the beta snapshots (nlam x p)
 
     std::vector<hipEvent_t> ev_pool;                    // start/stop events of sampled x-update launches, reused by every run()
@@ -599,6 +618,11 @@ struct TallPlan final : LassoPlan {
         q.adj_z = adj_z.get(); q.adj_y = adj_y.get(); q.u = u.get(); q.w = w.get();
         q.ctl = ctl.get(); q.P = P.get(); q.beta = beta.get(); q.niter = niter.get();
         q.done_host = hflag.p;
+#ifdef ADMM_HIP_PROBE
+        probe.alloc((size_t)4096 * 4 * 8); probe.zero(st);
+        q.probe = probe.get();
+        sy.probe = probe.get();
+#endif
 
         // Pinned mirror of the control block for asynchronous polling.
         ADMM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&hctl), 2 * sizeof(TallCtl), hipHostMallocDefault));
@@ -640,6 +664,9 @@ struct TallPlan final : LassoPlan {
         if (fused) { fflag.zero(st); farrive.zero(st); }
         hctl[0].done = hctl[1].done = 0;
         *hflag.p = 0;
+#ifdef ADMM_HIP_PROBE
+        sy.probe_idx = 0;
+#endif
 
         const int batch = pb.batch_iters > 0 ? (pb.batch_iters + 1) / 2 * 2 : 32;    // even
         const int stride = pb.profile_stride;                          // sample every stride-th x-update with events
@@ -753,6 +780,13 @@ struct TallPlan final : LassoPlan {
         ADMM_HIP_CHECK(hipStreamSynchronize(st));
         S.t_loop = now_s() - tl0;
         ADMM_HIP_CHECK(hipMemcpy(hctl, ctl.get(), 2 * sizeof(TallCtl), hipMemcpyDeviceToHost));      // both slots: decisions taken
+#ifdef ADMM_HIP_PROBE
+        if (const char* f = std::getenv("ADMM_HIP_PROBE_OUT")) {
+            std::vector<long long> hp((size_t)4096 * 4 * 8);
+            ADMM_HIP_CHECK(hipMemcpy(hp.data(), probe.get(), hp.size() * sizeof(long long), hipMemcpyDeviceToHost));
+            if (FILE* fp = std::fopen(f, "wb")) { std::fwrite(hp.data(), sizeof(long long), hp.size(), fp); std::fclose(fp); }
+        }
+#endif
         if (gexec) (void)hipGraphExecDestroy(gexec);
         float ms = 0.f;
         ADMM_HIP_CHECK(hipEventElapsedTime(&ms, ev_loop0.e, ev_loop1.e));

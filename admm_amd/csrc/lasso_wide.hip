@@ -30,6 +30,7 @@
 #include "solvers.h"
 #include "loop_driver.h"
 #include "comm.h"
+#include "probe.h"
 
 namespace admm {
 
@@ -107,19 +108,7 @@ struct WideParams {
 #endif
 };
 
-// Dev build (-DADMM_HIP_PROBE): wall-clock (100 MHz) timestamps of a few workgroups, one record per decision, dumped by
-// WidePlan::run when ADMM_HIP_PROBE_OUT names a file.  Compiled out of the product.
-#ifdef ADMM_HIP_PROBE
-#define WIDE_PROBE_DECL long long pt_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define WIDE_PROBE(k) do { pt_[k] = wall_clock64(); } while (0)
-#define WIDE_PROBE_FLUSH(obs, total) do { if (q.probe && threadIdx.x == 0 && (obs) >= 0) {                                  \
-        long long* d_ = q.probe + ((size_t)((total) & 4095) * 4 + (obs)) * 8;                                                \
-        _Pragma("unroll") for (int k_ = 0; k_ < 8; ++k_) d_[k_] = pt_[k_]; } } while (0)
-#else
-#define WIDE_PROBE_DECL
-#define WIDE_PROBE(k) do {} while (0)
-#define WIDE_PROBE_FLUSH(obs, total) do {} while (0)
-#endif
+
 
 __device__ __forceinline__ bool is_regular_update(unsigned int x) {      // 4^k - 1   ADMMLassoWide.h:121-127
     if (x == 0 || x == 3 || x == 15 || x == 63) return true;

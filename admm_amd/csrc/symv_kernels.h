@@ -25,6 +25,10 @@
 // Measured and rejected (scripts/symv_tune.hip, scripts/symv_check.hip, in-situ A/B of the tall loop):
 //  * packing the triangle tile by tile (each 128 KB tile contiguous): +-2..6 % depending on p, -1 % in the
 //    loop at p = 10^4;
+//  * alternating the tile order between launches so that an XCD reads first what it read last (order of the groups of 8
+//    tiles reversed on odd launches; a tile keeps its XCD): no change at all (24.10 vs 24.10 k it/s) -- nothing of the
+//    matrix survives a kernel boundary in the XCD L2s.  In-kernel timestamps (scripts/tall_probe.py) put the streaming
+//    phase itself at 200 MB / 31 us = 6.45 TB/s, the Infinity Cache ceiling; the rest of the 34.5 us is ramp and drain;
 //  * fusing the consumer into this launch ("last tile of a block finalises it", arrival counters): correct,
 //    but cross-XCD visibility needs either agent-scope fences (whole-L2 write-back per wave: 5x slower) or
 //    uncached partial arrays plus an acknowledged-store wait and an atomic round trip per tile (1.65x slower
@@ -50,6 +54,9 @@ struct SymvArgs {
     long long ldo;
     const int2* tiles;                     // (row block, column block) of every tile touching the lower triangle
     const int* skip;
+#ifdef ADMM_HIP_PROBE
+    long long* probe; int probe_idx;       // dev build only (probe.h): entry / end stamps of the first, middle and last tile
+#endif
 };
 
 // Sum 8 per-lane values over the 64 lanes: afterwards every lane l holds the total of value (l >> 3).
@@ -217,7 +224,20 @@ symv2_lower_kernel(SymvArgs a, Extra extra) {
     if (a.skip != nullptr && *a.skip != 0) return;
     __shared__ float4 red[2][kSyThreads];
     __shared__ __attribute__((aligned(16))) float sdot[2][kSyCB];
+#ifdef ADMM_HIP_PROBE
+    const long long pt0 = wall_clock64();
+#endif
     symv2_tile<false>(a, a.tiles[blockIdx.x - 1], SymvNoWait(), SymvPlainVec(), red, sdot);
+#ifdef ADMM_HIP_PROBE
+    if (a.probe != nullptr && threadIdx.x == 0) {
+        const int nt = (int)gridDim.x - 1, t = (int)blockIdx.x - 1;
+        const int which = t == 0 ? 0 : (t == nt / 2 ? 1 : (t == nt - 1 ? 2 : (t == (3 * nt) / 4 ? 3 : -1)));
+        if (which >= 0) {
+            long long* d = a.probe + ((size_t)(a.probe_idx & 4095) * 4 + 3) * 8 + which * 2;
+            d[0] = pt0; d[1] = wall_clock64();
+        }
+    }
+#endif
 }
 
 // Number of row / column blocks and the tile list (host).
@@ -226,6 +246,9 @@ struct SymvPlan {
     long long ldo = 0;
     DevBuf<int2> tiles;
     DevBuf<float> dot0, dot1, axp0, axp1;
+#ifdef ADMM_HIP_PROBE
+    long long* probe = nullptr; mutable int probe_idx = 0;
+#endif
     // part / nparts: this plan launches only the tiles with (index in the full list) % nparts == part -- the row-sharded
     // tall x-update gives every rank an equal share of the triangle; the partial arrays keep the full shape (slots of
     // tiles owned by other ranks stay zero) so that the same consumer code sums them.
@@ -257,6 +280,9 @@ struct SymvPlan {
         a.A = A; a.lda = lda; a.p = p; a.v0 = v0; a.v1 = v1;
         a.dot0 = dot0.get(); a.dot1 = dot1.get(); a.axp0 = axp0.get(); a.axp1 = axp1.get();
         a.ldo = ldo; a.tiles = tiles.get(); a.skip = skip;
+#ifdef ADMM_HIP_PROBE
+        a.probe = probe; a.probe_idx = probe_idx++;
+#endif
         return a;
     }
     template <typename Extra = SymvNoExtra>
