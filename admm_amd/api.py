@@ -181,6 +181,31 @@ class ADMM_Lasso:
         keep = (xk, yk, lam_in)
         return lib, head, tail, lam_out, beta, niter, stats, keep
 
+    def cv(self, nfolds=10, fold_id=None, keep_fold_beta=False):
+        """K-fold cross-validation of this model's lambda path (admm_hip_lasso_cv; not in the reference package).
+        fold_id: integer array of length n with values in [0, nfolds) (default: i mod nfolds)."""
+        lib, head, tail, lam_out, beta, niter, stats, keep = self._common()
+        nl = lam_out.size
+        fid = None if fold_id is None else np.ascontiguousarray(fold_id, dtype=np.int32)
+        if fid is not None and fid.size != self.n:
+            _stop("fold_id should have length nrow(x)")
+        cvm, cvse = np.zeros(nl), np.zeros(nl)
+        fmse = np.zeros((nfolds, nl))
+        fnit = np.zeros((nfolds, nl), dtype=np.int32)
+        fbeta = np.zeros((nfolds, nl, self.p + 1), dtype=np.float32) if keep_fold_beta else None
+        imin, i1se = ctypes.c_int(0), ctypes.c_int(0)
+        dp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+        ip = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_int))
+        alpha = float(getattr(self, "alpha", -1.0))
+        check(lib.admm_hip_lasso_cv(*head[:5], ip(fid) if fid is not None else None, int(nfolds), *head[5:], alpha, tail[0],
+                                    tail[1], tail[2], tail[3], dp(cvm), dp(cvse), dp(fmse), ip(fnit),
+                                    fbeta.ctypes.data_as(ctypes.POINTER(ctypes.c_float)) if keep_fold_beta else None,
+                                    ctypes.byref(imin), ctypes.byref(i1se), tail[4]))
+        fit = ADMM_Lasso_fit(lam_out, beta, niter, stats.as_dict())
+        if fbeta is not None:
+            fbeta = np.transpose(fbeta, (0, 2, 1))                               # [fold][p + 1][lambda]
+        return ADMM_Lasso_cv(fit, cvm, cvse, fmse, fnit, fbeta, imin.value, i1se.value)
+
     def fit(self):
         lib, head, tail, lam_out, beta, niter, stats, keep = self._common()
         if self.nthread <= 1:
@@ -188,6 +213,22 @@ class ADMM_Lasso:
         else:
             check(lib.admm_hip_parlasso(*head, self.nthread, *tail))             # .Call("admm_parlasso", ...)
         return ADMM_Lasso_fit(lam_out, beta, niter, stats.as_dict())
+
+
+class ADMM_Lasso_cv:
+    """Result of ADMM_Lasso.cv / ADMM_Enet.cv: the full-data fit plus the K-fold table (admm_hip_lasso_cv)."""
+
+    def __init__(self, fit, cvm, cvse, fold_mse, fold_niter, fold_beta, idx_min, idx_1se):
+        self.fit = fit
+        self.lambda_ = fit.lambda_
+        self.cvm, self.cvse = cvm, cvse
+        self.fold_mse, self.fold_niter, self.fold_beta = fold_mse, fold_niter, fold_beta
+        self.idx_min, self.idx_1se = int(idx_min), int(idx_1se)
+        self.lambda_min, self.lambda_1se = float(fit.lambda_[idx_min]), float(fit.lambda_[idx_1se])
+
+    def __repr__(self):
+        return (f"ADMM cross-validation: {self.fold_mse.shape[0]} folds x {self.lambda_.size} lambdas\n"
+                f"lambda.min = {self.lambda_min:.6g} (cvm {self.cvm[self.idx_min]:.6g}), lambda.1se = {self.lambda_1se:.6g}")
 
 
 class ADMM_Enet(ADMM_Lasso):

@@ -14,6 +14,8 @@ void comm_finalize();
 void comm_peer_prepare(int nranks, void* handle_out);
 void comm_init_peer(int nranks, int rank, const void* handles);
 void comm_init_shm(int nranks, int rank, const char* name);
+void cv_gather(const double* x, long long ldx, const double* y, const int* d_idx, int m, int p, double* xo, double* yo, hipStream_t st);
+std::vector<double> cv_score(const double* xt, const double* yt, int m, int p, const float* beta_host, int nlam, hipStream_t st);
 
 std::vector<double> make_lambda_grid(const LassoProblem& pb, double lambda0, int n, double scaleY) {
     if (!pb.lambda_in.empty()) return pb.lambda_in;
@@ -174,6 +176,127 @@ static int lasso_family(const double* x, const double* y, int n, int p, int mem,
     });
 }
 
+// K-fold cross-validation (cv.hip).  The full-data fit fixes the lambda grid; fold f is the ordinary plan on the rows with
+// fold_id != f, scored on the rows with fold_id == f.  With a communicator the folds are dealt out to the ranks (fold f on
+// rank f mod nranks: independent replicas, nothing exchanged on the data path) and the score / iteration tables are
+// summed over the ranks at the end.
+static void lasso_cv(const double* x, const double* y, int n, int p, int mem, const int* fold_id, int nfolds,
+                     const double* lambda_in, int nlambda_in, int nlambda_auto, double lmin_ratio,
+                     int standardize, int intercept, double alpha, const admm_opts* opts,
+                     double* lambda_out, float* beta_out, int* niter_out,
+                     double* cv_mean, double* cv_se, double* fold_mse, int* fold_niter, float* fold_beta,
+                     int* idx_min, int* idx_1se, admm_stats* stats) {
+    check_common(x, y, n, p, mem, opts);
+    ADMM_REQUIRE(nfolds >= 2 && nfolds <= n, "nfolds must be within [2, n]");
+    ADMM_REQUIRE(lambda_out && cv_mean && cv_se, "lambda_out, cv_mean and cv_se must not be NULL");
+    const bool enet = alpha >= 0.0;
+    if (enet) ADMM_REQUIRE(alpha <= 1.0, "alpha must be within [0, 1]");
+    require_device();
+    const double t0 = now_s();
+    std::vector<int> fid(n);
+    for (int i = 0; i < n; ++i) {
+        fid[i] = fold_id ? fold_id[i] : i % nfolds;
+        ADMM_REQUIRE(fid[i] >= 0 && fid[i] < nfolds, "fold_id entries must be within [0, nfolds)");
+    }
+    std::vector<int> cnt(nfolds, 0);
+    for (int i = 0; i < n; ++i) ++cnt[fid[i]];
+    for (int f = 0; f < nfolds; ++f) ADMM_REQUIRE(cnt[f] > 0 && cnt[f] < n, "every fold needs at least one held-out row and one training row");
+
+    Stream st;
+    // one resident copy of the data (doubles, as handed over); folds are gathered from it on the device
+    DevBuf<double> xd_own, yd_own;
+    const double* xd = x; const double* yd = y;
+    if (mem == ADMM_MEM_HOST) {
+        xd_own.alloc((size_t)n * p); yd_own.alloc(n);
+        ADMM_HIP_CHECK(hipMemcpyAsync(xd_own.get(), x, (size_t)n * p * sizeof(double), hipMemcpyHostToDevice, st.s));
+        ADMM_HIP_CHECK(hipMemcpyAsync(yd_own.get(), y, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st.s));
+        ADMM_HIP_CHECK(hipStreamSynchronize(st.s));
+        xd = xd_own.get(); yd = yd_own.get();
+    }
+    // ---- full-data fit: the lambda grid (and, if asked for, the coefficients)
+    int nlam = 0;
+    std::vector<double> lam;
+    {
+        std::unique_ptr<PlanHandle> h(create_plan(xd, yd, n, p, ADMM_MEM_DEVICE, lambda_in, nlambda_in, nlambda_auto, lmin_ratio,
+                                                  standardize, intercept, enet, enet ? alpha : 1.0, 0, opts));
+        LassoResult res;
+        h->plan->run(res);
+        nlam = (int)res.lambda.size();
+        lam = res.lambda;
+        for (int l = 0; l < nlam; ++l) lambda_out[l] = lam[l];
+        if (beta_out) std::memcpy(beta_out, res.beta.data(), sizeof(float) * (size_t)(p + 1) * nlam);
+        if (niter_out) for (int l = 0; l < nlam; ++l) niter_out[l] = res.niter[l];
+        if (stats) *stats = res.stats;
+    }
+    // ---- folds
+    const CommInfo ci = comm_info();
+    const int nranks = ci.active ? ci.nranks : 1, rank = ci.active ? ci.rank : 0;
+    std::vector<double> mse((size_t)nfolds * nlam, 0.0);
+    std::vector<double> nit((size_t)nfolds * nlam, 0.0);         // as doubles: summed over ranks with the scores
+    if (fold_beta) std::memset(fold_beta, 0, sizeof(float) * (size_t)(p + 1) * nlam * nfolds);
+    DevBuf<int> didx(n);
+    for (int f = 0; f < nfolds; ++f) {
+        if (f % nranks != rank) continue;
+        std::vector<int> tr, te;
+        for (int i = 0; i < n; ++i) (fid[i] == f ? te : tr).push_back(i);
+        const int ntr = (int)tr.size(), nte = (int)te.size();
+        std::vector<int> both(tr);
+        both.insert(both.end(), te.begin(), te.end());
+        ADMM_HIP_CHECK(hipMemcpyAsync(didx.get(), both.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, st.s));
+        DevBuf<double> xtr((size_t)ntr * p), ytr(ntr), xte((size_t)nte * p), yte(nte);
+        cv_gather(xd, n, yd, didx.get(), ntr, p, xtr.get(), ytr.get(), st.s);
+        cv_gather(xd, n, yd, didx.get() + ntr, nte, p, xte.get(), yte.get(), st.s);
+        ADMM_HIP_CHECK(hipStreamSynchronize(st.s));
+        LassoResult res;
+        {
+            std::unique_ptr<PlanHandle> h(create_plan(xtr.get(), ytr.get(), ntr, p, ADMM_MEM_DEVICE, lam.data(), nlam, 0, lmin_ratio,
+                                                      standardize, intercept, enet, enet ? alpha : 1.0, 0, opts));
+            h->plan->run(res);
+        }
+        const std::vector<double> sse = cv_score(xte.get(), yte.get(), nte, p, res.beta.data(), nlam, st.s);
+        for (int l = 0; l < nlam; ++l) { mse[(size_t)f * nlam + l] = sse[l] / nte; nit[(size_t)f * nlam + l] = res.niter[l]; }
+        if (fold_beta) std::memcpy(fold_beta + (size_t)f * (p + 1) * nlam, res.beta.data(), sizeof(float) * (size_t)(p + 1) * nlam);
+    }
+    if (nranks > 1) {                                             // folds of the other ranks: one sum all-reduce of the tables
+        DevBuf<double> t((size_t)2 * nfolds * nlam);
+        ADMM_HIP_CHECK(hipMemcpyAsync(t.get(), mse.data(), mse.size() * sizeof(double), hipMemcpyHostToDevice, st.s));
+        ADMM_HIP_CHECK(hipMemcpyAsync(t.get() + mse.size(), nit.data(), nit.size() * sizeof(double), hipMemcpyHostToDevice, st.s));
+        allreduce_sum_f64(t.get(), (size_t)2 * nfolds * nlam, st.s);
+        ADMM_HIP_CHECK(hipMemcpyAsync(mse.data(), t.get(), mse.size() * sizeof(double), hipMemcpyDeviceToHost, st.s));
+        ADMM_HIP_CHECK(hipMemcpyAsync(nit.data(), t.get() + mse.size(), nit.size() * sizeof(double), hipMemcpyDeviceToHost, st.s));
+        ADMM_HIP_CHECK(hipStreamSynchronize(st.s));
+        comm_check();
+        if (fold_beta) {
+            const size_t nfb = (size_t)(p + 1) * nlam * nfolds;
+            DevBuf<float> fb(nfb);
+            ADMM_HIP_CHECK(hipMemcpyAsync(fb.get(), fold_beta, nfb * sizeof(float), hipMemcpyHostToDevice, st.s));
+            allreduce_sum_f32(fb.get(), nfb, st.s);
+            ADMM_HIP_CHECK(hipMemcpyAsync(fold_beta, fb.get(), nfb * sizeof(float), hipMemcpyDeviceToHost, st.s));
+            ADMM_HIP_CHECK(hipStreamSynchronize(st.s));
+            comm_check();
+        }
+    }
+    // ---- summary: mean over folds, standard error sd / sqrt(K) (sample sd over the folds), minimum and one-standard-error rule
+    int imin = 0;
+    for (int l = 0; l < nlam; ++l) {
+        double m = 0;
+        for (int f = 0; f < nfolds; ++f) m += mse[(size_t)f * nlam + l];
+        m /= nfolds;
+        double v = 0;
+        for (int f = 0; f < nfolds; ++f) { const double d = mse[(size_t)f * nlam + l] - m; v += d * d; }
+        cv_mean[l] = m;
+        cv_se[l] = std::sqrt(v / (nfolds - 1) / nfolds);
+        if (cv_mean[l] < cv_mean[imin]) imin = l;
+    }
+    int i1se = imin;
+    for (int l = 0; l < nlam; ++l) if (lam[l] > lam[i1se] && cv_mean[l] <= cv_mean[imin] + cv_se[imin]) i1se = l;   // largest lambda within one standard error
+    if (idx_min) *idx_min = imin;
+    if (idx_1se) *idx_1se = i1se;
+    if (fold_mse) std::memcpy(fold_mse, mse.data(), mse.size() * sizeof(double));
+    if (fold_niter) for (size_t k = 0; k < nit.size(); ++k) fold_niter[k] = (int)std::llround(nit[k]);
+    if (stats) stats->t_total = now_s() - t0;
+}
+
 }  // namespace admm
 
 using namespace admm;
@@ -198,6 +321,18 @@ int admm_hip_enet(const double* x, const double* y, int n, int p, int mem,
     }
     return lasso_family(x, y, n, p, mem, lambda_in, nlambda_in, nlambda_auto, lmin_ratio, standardize, intercept,
                         true, alpha, 0, opts, lambda_out, beta_out, niter_out, stats);
+}
+
+int admm_hip_lasso_cv(const double* x, const double* y, int n, int p, int mem, const int* fold_id, int nfolds,
+                      const double* lambda_in, int nlambda_in, int nlambda_auto, double lmin_ratio,
+                      int standardize, int intercept, double alpha, const admm_opts* opts,
+                      double* lambda_out, float* beta_out, int* niter_out,
+                      double* cv_mean, double* cv_se, double* fold_mse, int* fold_niter, float* fold_beta,
+                      int* idx_min, int* idx_1se, admm_stats* stats) {
+    return guarded([&] {
+        lasso_cv(x, y, n, p, mem, fold_id, nfolds, lambda_in, nlambda_in, nlambda_auto, lmin_ratio, standardize, intercept, alpha, opts,
+                 lambda_out, beta_out, niter_out, cv_mean, cv_se, fold_mse, fold_niter, fold_beta, idx_min, idx_1se, stats);
+    });
 }
 
 int admm_hip_parlasso(const double* x, const double* y, int n, int p, int mem,

@@ -111,6 +111,29 @@ ADMM_HIP_API int admm_hip_enet(const double* x, const double* y, int n, int p, i
 
 /* Row-block consensus ADMM with `nthread` blocks (ParLasso.cpp:71-72: nthread only sets the
  * number of blocks K).  All K blocks run on the current device. */
+/* K-fold cross-validation of the lambda path of admm_hip_lasso (alpha < 0) / admm_hip_enet (alpha in [0, 1]).
+ * SURVEY.md section 8(f) row n4 ("cross-validation folds as independent replicas across GPUs"); the reference package has
+ * no CV driver, so there is no reference interface to cite -- the fold fits are the admm_lasso / admm_enet path
+ * (/root/reference/src/Lasso.cpp:32-135, Enet.cpp:31-34) on row subsets.
+ *   grid      the full data's (lambda_in, or the automatic grid of the full-data fit, Lasso.cpp:78-89), used by every fold;
+ *   fold f    fitted on the rows with fold_id[i] != f by the SAME plan a direct call on that row subset gets (coefficients
+ *             bit-identical to it), scored on the rows with fold_id[i] == f: mean squared prediction error per lambda, on
+ *             the original scale, computed in double on the device.  fold_id NULL: i mod nfolds;
+ *   ranks     with a communicator attached, fold f runs on rank f mod nranks (every rank is handed the full x, y;
+ *             nothing is exchanged on the data path) and the tables are summed over the ranks at the end: all ranks
+ *             return identical outputs.
+ * Outputs: lambda_out[nlam]; beta_out (p+1) x nlam and niter_out[nlam] of the full-data fit (either may be NULL);
+ * cv_mean[nlam]; cv_se[nlam] = sample sd over the folds / sqrt(nfolds); fold_mse[nfolds x nlam] (fold-major),
+ * fold_niter[nfolds x nlam], fold_beta[nfolds x (p+1) x nlam] (each may be NULL); idx_min = argmin cv_mean;
+ * idx_1se = index of the largest lambda with cv_mean <= cv_mean[idx_min] + cv_se[idx_min].  stats: the full-data fit's,
+ * with t_total = the whole call. */
+ADMM_HIP_API int admm_hip_lasso_cv(const double* x, const double* y, int n, int p, int mem, const int* fold_id, int nfolds,
+                      const double* lambda_in, int nlambda_in, int nlambda_auto, double lmin_ratio,
+                      int standardize, int intercept, double alpha, const admm_opts* opts,
+                      double* lambda_out, float* beta_out, int* niter_out,
+                      double* cv_mean, double* cv_se, double* fold_mse, int* fold_niter, float* fold_beta,
+                      int* idx_min, int* idx_1se, admm_stats* stats);
+
 ADMM_HIP_API int admm_hip_parlasso(const double* x, const double* y, int n, int p, int mem,
                       const double* lambda_in, int nlambda_in, int nlambda_auto, double lmin_ratio,
                       int standardize, int intercept, int nthread, const admm_opts* opts,

@@ -51,6 +51,9 @@ def problem(case):
     if case == "widecols_enet":
         x, y = synth_lasso(250, 900, 12, seed=31)
         return x, y, -1, dict(nlambda=8, alpha=0.5)
+    if case == "cv":                  # K-fold cross-validation with the folds dealt out to the ranks (fold f on rank f mod nranks)
+        x, y = synth_lasso(500, 60, 8, seed=77)
+        return x, y, -2, dict(nlambda=8)
     raise SystemExit("unknown case " + case)
 
 
@@ -82,6 +85,15 @@ def main():
     # ---- the distributed consensus solver on this rank's row slice
     x, y, K, kw = problem(case)
     n, p = x.shape
+    if K == -2:
+        import admm_amd
+        cv = admm_amd.admm_lasso(np.asfortranarray(x), y).penalty(nlambda=kw["nlambda"]).cv(nfolds=5, keep_fold_beta=True)
+        np.savez(os.path.join(workdir, f"result.{rank}.npz"), cvm=cv.cvm, cvse=cv.cvse, fold_mse=cv.fold_mse, fold_niter=cv.fold_niter,
+                 fold_beta=cv.fold_beta, idx=np.array([cv.idx_min, cv.idx_1se]), beta=cv.fit.beta_dense, niter=cv.fit.niter, lam=cv.lambda_)
+        barrier(workdir, "end", rank, nranks)
+        adist.finalize_comm()
+        print("rank", rank, "ok", flush=True)
+        return
     if K < 0:
         lo, hi = adist.col_partition(p, nranks, rank)
         plan = adist.DistColsPlan(np.asfortranarray(x[:, lo:hi]), y, p, lo, lambda_min_ratio=0.01, **kw)

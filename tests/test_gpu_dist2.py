@@ -118,3 +118,22 @@ def test_two_process_column_sharded_wide_solver(backend, case):
     h = nl // 2
     for j in range(h):
         assert relerr(res[0]["beta"][:, j], one.beta_dense[:, j]) < 1e-4, j
+
+
+@pytest.mark.parametrize("backend", ["shm", "peer"])
+def test_two_process_cross_validation_folds_as_replicas(backend):
+    """admm_hip_lasso_cv with a communicator: fold f runs on rank f mod 2 (independent replicas, no exchange on the data
+    path), the score tables are summed over the ranks at the end.  Every rank must return exactly what one process
+    computing all five folds returns."""
+    import admm_amd
+    sys.path.insert(0, HERE)
+    from dist_worker import problem
+    res = _run_ranks(backend, "cv")
+    x, y, _, kw = problem("cv")
+    one = admm_amd.admm_lasso(np.asfortranarray(x), y).penalty(nlambda=kw["nlambda"]).cv(nfolds=5, keep_fold_beta=True)
+    for r in res:
+        assert np.array_equal(r["fold_mse"], one.fold_mse) and np.array_equal(r["fold_niter"], one.fold_niter)
+        assert np.array_equal(r["fold_beta"], one.fold_beta)
+        assert np.array_equal(r["cvm"], one.cvm) and np.array_equal(r["cvse"], one.cvse)
+        assert list(r["idx"]) == [one.idx_min, one.idx_1se]
+        assert np.array_equal(r["beta"], one.fit.beta_dense) and np.array_equal(r["lam"], one.lambda_)
