@@ -681,7 +681,7 @@ struct TallPlan final : LassoPlan {
         auto enqueue_batch = [&](int slot) {
             for (int k = 0; k < batch; ++k, ++g) {
                 const int par = (int)(g & 1);
-                const bool sample = stride > 0 && (g % stride) == 0 && nev < 8192;
+                const bool sample = stride > 0 && (g % stride) == stride / 2 && nev < 8192;      // mid-batch: not the launch right behind the poll event
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (sample) {
                     while (ev_pool.size() < nev + 2) {

@@ -56,10 +56,10 @@ def parse():
     ap.add_argument("--seed", type=int, default=123)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline loop (0 disables)")
     ap.add_argument("--profile-stride", type=int, default=32, help="time every k-th x-update launch with HIP events")
-    ap.add_argument("--consensus-seconds", type=float, default=240.0,
+    ap.add_argument("--consensus-seconds", type=float, default=180.0,
                     help="time limit of the side measurement of the consensus solver (0 disables it)")
-    ap.add_argument("--shard-seconds", type=float, default=300.0,
-                    help="time limit of each sharded-tall child run at N > 1 (0 disables them: replicas only)")
+    ap.add_argument("--shard-seconds", type=float, default=200.0,
+                    help="time limit of each sharded child run at N > 1 (0 disables them: replicas only)")
     ap.add_argument("--child", default="", help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -368,6 +368,11 @@ def main():
         kind, backend, out_path = a.child.split(":", 2)
         {"consensus": consensus_child, "tallshard": tallshard_child, "widecols": widecols_child}[kind](a, backend, out_path)
         return
+    # The JSON line must be the only thing on stdout: libraries loaded below (RCCL prints a version banner to stdout when
+    # its first communicator is created, flushed at exit) get stderr as their fd 1; the line goes to the saved descriptor.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -551,7 +556,8 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(p, a.nlambda, a.cpu_seconds, a.seed)
             except Exception as e:                          # noqa: BLE001 -- never lose the GPU line to the CPU leg
                 out["cpu_baseline"] = {"value": None, "unit": "iterations/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     plan.close()
     if multi:
         dist.barrier()
