@@ -87,6 +87,20 @@ __device__ __forceinline__ void block_sum(T (&v)[NV], T* scratch) {
     }
 }
 
+// 16-byte load with the non-temporal hint (global_load_dwordx4 ... nt): for operands that are streamed once per pass and
+// are too large to stay in the 256 MB Infinity Cache anyway.  Measured on one MI355X (round 2, same box): the GEMV streams
+// of C4 / C5 gain 10-13 % (C5 LAD 1278 -> 1430 it/s, BP 1375 -> 1525, C4 589 -> 646); operands that DO fit the cache and are
+// re-read every iteration (the tall path's 200 MB triangle) lose 8 % with it and keep plain loads.
+template <typename V>
+__device__ __forceinline__ V load16_nt(const void* p) {
+    static_assert(sizeof(V) == 16, "16-byte vectors only");
+    typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
+    const u4_t raw = __builtin_nontemporal_load(reinterpret_cast<const u4_t*>(p));
+    V v;
+    __builtin_memcpy(&v, &raw, 16);
+    return v;
+}
+
 // 16-byte vector of T (float4 / double2) for coalesced 1 KiB-per-wave loads.
 template <typename T> struct Vec16;
 template <> struct Vec16<float> {

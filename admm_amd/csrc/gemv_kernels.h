@@ -44,7 +44,8 @@ struct GemvTArgs {
 // workgroups; the tall solver uses it for its scalar iteration control (no launch, no latency).
 struct GemvNoExtra { static constexpr bool kHas = false; __device__ void operator()() const {} };
 
-template <typename T, int NRHS, int C, typename Extra = GemvNoExtra>
+// NT: the matrix is read with non-temporal loads (GemvTPlan::nt: operands larger than kGemvNtBytes, device_utils.h).
+template <typename T, int NRHS, int C, typename Extra = GemvNoExtra, bool NT = false>
 __global__ void __launch_bounds__(kGemvThreads)
 gemv_t_kernel(GemvTArgs<T> a, Extra extra) {
     using VT = Vec16<T>;
@@ -114,7 +115,7 @@ gemv_t_kernel(GemvTArgs<T> a, Extra extra) {
         for (int it = 0; it < nfull; ++it, row += PASS) {
             V av[C];
 #pragma unroll
-            for (int c = 0; c < C; ++c) av[c] = *reinterpret_cast<const V*>(colp[c] + row);
+            for (int c = 0; c < C; ++c) av[c] = NT ? load16_nt<V>(colp[c] + row) : *reinterpret_cast<const V*>(colp[c] + row);
             V rv[NRHS];
 #pragma unroll
             for (int r = 0; r < NRHS; ++r) rv[r] = *reinterpret_cast<const V*>(rhs + (size_t)r * a.seg_alloc + row);
@@ -173,6 +174,7 @@ inline GemvTPlan plan_gemv_t(int m, int k, int nrhs, int C, int max_seg_rows = 0
     pl.num_cb = (ngroups + gpw - 1) / gpw;
     pl.grid = pl.num_cb * pl.nseg;
     pl.lds_bytes = (size_t)nrhs * pl.seg_alloc * sizeof(T);
+    pl.nt = (size_t)m * (size_t)k * sizeof(T) > kGemvNtBytes;
     return pl;
 }
 
@@ -186,12 +188,15 @@ inline void launch_gemv_t(const GemvTPlan& pl, const T* A, long long lda, int m,
     a.v[0] = v0; a.v[1] = v1; a.vparts = vparts; a.vstride = vstride; a.out[0] = out0; a.out[1] = out1;
     a.out_stride = out_stride; a.seg_len = pl.seg_len; a.seg_alloc = pl.seg_alloc; a.nseg = pl.nseg;
     a.groups_per_wg = pl.groups_per_wg; a.skip = skip;
-    if (ev_start == nullptr && ev_stop == nullptr)
-        hipLaunchKernelGGL((gemv_t_kernel<T, NRHS, C, Extra>), dim3(pl.grid + (Extra::kHas ? 1 : 0)), dim3(kGemvThreads),
-                           (std::uint32_t)pl.lds_bytes, st, a, extra);
-    else
-        hipExtLaunchKernelGGL((gemv_t_kernel<T, NRHS, C, Extra>), dim3(pl.grid + (Extra::kHas ? 1 : 0)), dim3(kGemvThreads),
-                              (std::uint32_t)pl.lds_bytes, st, ev_start, ev_stop, 0, a, extra);
+    const dim3 grid(pl.grid + (Extra::kHas ? 1 : 0)), block(kGemvThreads);
+    const std::uint32_t lds = (std::uint32_t)pl.lds_bytes;
+    if (ev_start == nullptr && ev_stop == nullptr) {
+        if (pl.nt) hipLaunchKernelGGL((gemv_t_kernel<T, NRHS, C, Extra, true>), grid, block, lds, st, a, extra);
+        else hipLaunchKernelGGL((gemv_t_kernel<T, NRHS, C, Extra, false>), grid, block, lds, st, a, extra);
+    } else {
+        if (pl.nt) hipExtLaunchKernelGGL((gemv_t_kernel<T, NRHS, C, Extra, true>), grid, block, lds, st, ev_start, ev_stop, 0, a, extra);
+        else hipExtLaunchKernelGGL((gemv_t_kernel<T, NRHS, C, Extra, false>), grid, block, lds, st, ev_start, ev_stop, 0, a, extra);
+    }
 }
 
 // Sum the nseg partial rows of a gemv_t result: y[j] = sum_s part[s*stride + j].

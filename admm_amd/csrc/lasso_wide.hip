@@ -252,12 +252,15 @@ wide_x_kernel(WideParams q, int par) {
     constexpr int NRT = RT > 0 ? RT : 1;
     const int nv = (q.n + 3) / 4 * 4;
     // fused mode: col_request puts a whole column in flight (RT 16-byte loads per lane, reused by the gather)
-    auto col_request = [&](long long jj, float4 (&cv)[NRT]) {
+    // A regular step streams all of X once (non-temporal: it cannot stay cache-resident and should not evict the active
+    // columns, which are re-read every iteration with plain loads).
+    auto col_request = [&](long long jj, float4 (&cv)[NRT], bool nt) {
         const float* col = q.X + (size_t)jj * q.ldx;
 #pragma unroll
         for (int k = 0; k < NRT; ++k) {
             const int r = k * 256 + lane * 4;
-            cv[k] = r < nv ? *reinterpret_cast<const float4*>(col + r) : make_float4(0.f, 0.f, 0.f, 0.f);
+            cv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < nv) cv[k] = nt ? load16_nt<float4>(col + r) : *reinterpret_cast<const float4*>(col + r);
         }
     };
     // Speculative request of this wave's first non-zero column: almost every step is an active-set step, and what it reads
@@ -276,7 +279,7 @@ wide_x_kernel(WideParams q, int par) {
                 const unsigned long long m = __ballot(xs0[u] != 0.f);
                 if (pj < 0 && m != 0) pj = (long long)(u * 64 + __ffsll((long long)m) - 1) * NWa + w;
             }
-            if (pj >= 0) col_request(pj, cv0);
+            if (pj >= 0) col_request(pj, cv0, false);
         }
     }
     const WideCtl in = wide_ctl_unpack(in_raw);
@@ -408,15 +411,15 @@ wide_x_kernel(WideParams q, int par) {
         if (RT > 0) {
             if constexpr (kSpec) { if (!reg && jj == pj) return col_finish(xv, cv0); }     // requested before the decision
             float4 cv[NRT];
-            col_request(jj, cv);
+            col_request(jj, cv, reg);
             return col_finish(xv, cv);
         }
         const float* col = q.X + (size_t)jj * q.ldx;
         float d0 = 0.f, d1 = 0.f;
         int r = lane * 4;
         for (; r + 256 < nv; r += 512) {
-            const float4 a0 = *reinterpret_cast<const float4*>(col + r);
-            const float4 a1 = *reinterpret_cast<const float4*>(col + r + 256);
+            const float4 a0 = reg ? load16_nt<float4>(col + r) : *reinterpret_cast<const float4*>(col + r);
+            const float4 a1 = reg ? load16_nt<float4>(col + r + 256) : *reinterpret_cast<const float4*>(col + r + 256);
             const float4 b0 = *reinterpret_cast<const float4*>(tv + r);
             const float4 b1 = *reinterpret_cast<const float4*>(tv + r + 256);
             d0 = fmaf(a0.x, b0.x, d0); d0 = fmaf(a0.y, b0.y, d0); d0 = fmaf(a0.z, b0.z, d0); d0 = fmaf(a0.w, b0.w, d0);
