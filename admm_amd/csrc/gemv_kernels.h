@@ -115,7 +115,10 @@ gemv_t_kernel(GemvTArgs<T> a, Extra extra) {
         for (int it = 0; it < nfull; ++it, row += PASS) {
             V av[C];
 #pragma unroll
-            for (int c = 0; c < C; ++c) av[c] = NT ? load16_nt<V>(colp[c] + row) : *reinterpret_cast<const V*>(colp[c] + row);
+            for (int c = 0; c < C; ++c) {
+                if constexpr (NT) av[c] = load16_nt<V>(colp[c] + row);       // `if constexpr`: the plain variant's code is exactly what it was
+                else av[c] = *reinterpret_cast<const V*>(colp[c] + row);
+            }
             V rv[NRHS];
 #pragma unroll
             for (int r = 0; r < NRHS; ++r) rv[r] = *reinterpret_cast<const V*>(rhs + (size_t)r * a.seg_alloc + row);

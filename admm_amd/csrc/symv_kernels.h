@@ -113,7 +113,7 @@ struct SymvNoWait { __device__ __forceinline__ void operator()() const {} };
 // PRE = false (the two-launch path): no wait, right-hand entries first, every 8-column chunk loaded at the top of its loop
 // iteration -- the shape that streams best (with the PRE shape the same 128-column kernel ran at 39.3 instead of 35.1 us on
 // C2: a first chunk carried into the loop in registers and a conditional reload defeat the scheduling of the loads).
-template <bool PRE, typename Wait, typename VecLoad>
+template <bool PRE, typename Wait, typename VecLoad, bool NT = false>      // NT: matrix read with non-temporal loads (triangle larger than the Infinity Cache)
 __device__ __forceinline__ void symv2_tile(const SymvArgs& a, const int2 t, Wait wait, VecLoad vl,
                                            float4 (*red)[kSyThreads], float (*sdot)[kSyCB]) {
     const int rb = t.x, cb = t.y;
@@ -153,7 +153,8 @@ __device__ __forceinline__ void symv2_tile(const SymvArgs& a, const int2 t, Wait
                 for (int k = 0; k < 8; ++k) {
                     const int col = col0 + q * 8 + k;
                     av[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (active && col < a.p) av[k] = *reinterpret_cast<const float4*>(base + (size_t)(q * 8 + k) * a.lda);
+                    if constexpr (NT) { if (active && col < a.p) av[k] = load16_nt<float4>(base + (size_t)(q * 8 + k) * a.lda); }
+                    else { if (active && col < a.p) av[k] = *reinterpret_cast<const float4*>(base + (size_t)(q * 8 + k) * a.lda); }
                 }
             }
             float dU[8], dW[8];
@@ -217,7 +218,7 @@ __device__ __forceinline__ void symv2_tile(const SymvArgs& a, const int2 t, Wait
 // solver uses it for its scalar iteration control, which then costs no launch and no latency.
 struct SymvNoExtra { __device__ void operator()() const {} };
 
-template <typename Extra>
+template <typename Extra, bool NT = false>
 __global__ void __launch_bounds__(kSyThreads, 4)      // 4 waves/SIMD: 2 or 4 measure the same, 8 spills; non-temporal loads are 8 % slower (the 2p^2 bytes stay in the Infinity Cache)
 symv2_lower_kernel(SymvArgs a, Extra extra) {
     if (blockIdx.x == 0) { extra(); return; }
@@ -227,7 +228,7 @@ symv2_lower_kernel(SymvArgs a, Extra extra) {
 #ifdef ADMM_HIP_PROBE
     const long long pt0 = wall_clock64();
 #endif
-    symv2_tile<false>(a, a.tiles[blockIdx.x - 1], SymvNoWait(), SymvPlainVec(), red, sdot);
+    symv2_tile<false, SymvNoWait, SymvPlainVec, NT>(a, a.tiles[blockIdx.x - 1], SymvNoWait(), SymvPlainVec(), red, sdot);
 #ifdef ADMM_HIP_PROBE
     if (a.probe != nullptr && threadIdx.x == 0) {
         const int nt = (int)gridDim.x - 1, t = (int)blockIdx.x - 1;
@@ -245,6 +246,7 @@ struct SymvPlan {
     int p = 0, nrb = 0, ncb = 0, ntiles = 0;
     long long ldo = 0;
     DevBuf<int2> tiles;
+    bool nt = false;
     DevBuf<float> dot0, dot1, axp0, axp1;
 #ifdef ADMM_HIP_PROBE
     long long* probe = nullptr; mutable int probe_idx = 0;
@@ -268,6 +270,10 @@ struct SymvPlan {
             h.swap(mine);
         }
         ntiles = (int)h.size();
+        // the whole triangle is re-read every iteration: plain loads while it fits the 256 MB Infinity Cache (p = 10^4: 200 MB,
+        // non-temporal loads measured 8 % slower there), non-temporal beyond (it is evicted between two passes anyway)
+        nt = (size_t)2 * (size_t)p * (size_t)p > ((size_t)240 << 20);
+        if (const char* e = std::getenv("ADMM_HIP_SYMV_NT")) nt = std::string(e) == "1";
         tiles.alloc(std::max<size_t>(h.size(), 1));
         if (!h.empty()) ADMM_HIP_CHECK(hipMemcpyAsync(tiles.get(), h.data(), h.size() * sizeof(int2), hipMemcpyHostToDevice, st));
         dot0.alloc((size_t)nrb * ldo); dot1.alloc((size_t)nrb * ldo);
@@ -290,6 +296,11 @@ struct SymvPlan {
                 hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
         const SymvArgs a = args(A, lda, v0, v1, skip);
         // start/stop events (when given) time exactly this kernel on its stream (hipExtLaunchKernel)
+        if (nt) {
+            if (ev_start == nullptr && ev_stop == nullptr) hipLaunchKernelGGL((symv2_lower_kernel<Extra, true>), dim3(ntiles + 1), dim3(kSyThreads), 0, st, a, extra);
+            else hipExtLaunchKernelGGL((symv2_lower_kernel<Extra, true>), dim3(ntiles + 1), dim3(kSyThreads), 0, st, ev_start, ev_stop, 0, a, extra);
+            return;
+        }
         if (ev_start == nullptr && ev_stop == nullptr) hipLaunchKernelGGL((symv2_lower_kernel<Extra>), dim3(ntiles + 1), dim3(kSyThreads), 0, st, a, extra);
         else hipExtLaunchKernelGGL((symv2_lower_kernel<Extra>), dim3(ntiles + 1), dim3(kSyThreads), 0, st, ev_start, ev_stop, 0, a, extra);
     }
