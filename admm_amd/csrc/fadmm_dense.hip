@@ -317,9 +317,12 @@ void solve_lad(const DeviceData<double>& d, const admm_opts& opts, DenseResult& 
         ADMM_HIP_CHECK(hipStreamSynchronize(st));
         S.t_factor += now_s() - t0;
         gH.init(H.get(), ldh, n, n);
+        gH.set_nt(gemv_stream_nt(gH.bytes()));
         L.q.gout = gH.part.get(); L.q.gout_nseg = gH.pl.nseg; L.q.gout_stride = gH.stride;
     } else {
         g3.init(Xt.get(), ldxt, p, n);
+        const bool nt = gemv_stream_nt(g1.bytes() + g2.bytes() + g3.bytes());        // per iteration: X', the inverse, X
+        g1.set_nt(nt); g2.set_nt(nt); g3.set_nt(nt);
         L.q.gout = g3.part.get(); L.q.gout_nseg = g3.pl.nseg; L.q.gout_stride = g3.stride;
     }
 
@@ -405,6 +408,7 @@ void solve_bp(const DeviceData<double>& d, const admm_opts& opts, DenseResult& r
     GemvT<double> gB, gBt;                       // t = B' w (p outputs) ; w = B vec (n outputs, via the stored transpose)
     gB.init(B.get(), d.ldx, n, p);
     gBt.init(Bt.get(), ldbt, p, n);
+    { const bool nt = gemv_stream_nt(gB.bytes() + gBt.bytes()); gB.set_nt(nt); gBt.set_nt(nt); }
     gB.run(w0.get(), AAAb.get(), nullptr, st);
     ADMM_HIP_CHECK(hipStreamSynchronize(st));
     S.t_factor = now_s() - t0;

@@ -221,6 +221,8 @@ struct GemvT {
     int m = 0, k = 0;
     GemvTPlan pl;
     DevBuf<T> part;
+    size_t bytes() const { return (size_t)m * (size_t)k * sizeof(T); }
+    void set_nt(bool nt) { pl.nt = nt; }                           // streaming policy from the solver's working set (gemv_plan.h)
     void init(const T* A_, long long lda_, int m_, int k_, int wg_per_cu = 4) {
         A = A_; lda = lda_; m = m_; k = k_;
         pl = plan_gemv_t<T>(m, k, 1, 4, 0, wg_per_cu);

@@ -87,6 +87,7 @@ constexpr int kAxRT = 16;                 // float4 row accumulators per lane ->
 struct WideParams {
     int n, p, maxit, nlam, enet, nwg_tail;
     int fused, nwg_x;                     // fused: the x-update launch also writes the Ax partials (n <= 4096)
+    int x_nt;                             // regular steps stream X with non-temporal loads (X larger than the Infinity Cache keeps, gemv_plan.h)
     long long ldx;
     const float* X; const float* Y;
     float gamma, lambda0, alpha;          // sprad, lambda_0, enet alpha
@@ -411,15 +412,16 @@ wide_x_kernel(WideParams q, int par) {
         if (RT > 0) {
             if constexpr (kSpec) { if (!reg && jj == pj) return col_finish(xv, cv0); }     // requested before the decision
             float4 cv[NRT];
-            col_request(jj, cv, reg);
+            col_request(jj, cv, reg && q.x_nt);
             return col_finish(xv, cv);
         }
         const float* col = q.X + (size_t)jj * q.ldx;
         float d0 = 0.f, d1 = 0.f;
         int r = lane * 4;
         for (; r + 256 < nv; r += 512) {
-            const float4 a0 = reg ? load16_nt<float4>(col + r) : *reinterpret_cast<const float4*>(col + r);
-            const float4 a1 = reg ? load16_nt<float4>(col + r + 256) : *reinterpret_cast<const float4*>(col + r + 256);
+            const bool nt = reg && q.x_nt;
+            const float4 a0 = nt ? load16_nt<float4>(col + r) : *reinterpret_cast<const float4*>(col + r);
+            const float4 a1 = nt ? load16_nt<float4>(col + r + 256) : *reinterpret_cast<const float4*>(col + r + 256);
             const float4 b0 = *reinterpret_cast<const float4*>(tv + r);
             const float4 b1 = *reinterpret_cast<const float4*>(tv + r + 256);
             d0 = fmaf(a0.x, b0.x, d0); d0 = fmaf(a0.y, b0.y, d0); d0 = fmaf(a0.z, b0.z, d0); d0 = fmaf(a0.w, b0.w, d0);
@@ -834,6 +836,7 @@ struct WidePlan final : LassoPlan {
         q.ax_given = cshard ? axl.get() : nullptr;
         q.lambdas = dlam.get(); q.x = x.get(); q.Ax = Ax.get(); q.z = z.get(); q.y = y.get();
         q.axpart = axpart.get(); q.tbuf = tbuf.get(); q.ldn = ldn; q.fused = fuse_rt ? 1 : 0; q.nwg_x = nwg_x;
+        q.x_nt = gemv_stream_nt((size_t)d.ldx * (size_t)p * sizeof(float)) ? 1 : 0;
         q.ctl = ctl.get(); q.P = P.get(); q.beta = beta.get(); q.niter = niter.get(); q.done = done.get();
         q.done_host = hflag.p;
 #ifdef ADMM_HIP_PROBE

@@ -315,6 +315,12 @@ struct ParPlan final : LassoPlan {
         }
         S.t_gram = t_gram; S.t_factor = t_fac;
         d.X.release();
+        {   // streaming policy of the products from the working set of ONE iteration on this GPU: all local workers' matrices
+            size_t ws = 0;
+            for (int k = 0; k < Kl; ++k) ws += W[k].wide ? W[k].gAt.bytes() + W[k].gM.bytes() + W[k].gA.bytes() : W[k].gM.bytes();
+            const bool nt = gemv_stream_nt(ws);
+            for (int k = 0; k < Kl; ++k) { W[k].gM.set_nt(nt); if (W[k].wide) { W[k].gAt.set_nt(nt); W[k].gA.set_nt(nt); } }
+        }
 
         nwg = std::max(1, std::min(64, (p + kParThreads - 1) / kParThreads));
         rhs.alloc((size_t)Kl * ldv); x.alloc((size_t)Kl * ldv); y.alloc((size_t)Kl * ldv); nsum.alloc(8);
