@@ -87,6 +87,38 @@ __device__ __forceinline__ void block_sum(T (&v)[NV], T* scratch) {
     }
 }
 
+// A small control block (or flag word) that every workgroup of a launch reads first: through the VECTOR memory path, then
+// made wave-uniform again with v_readfirstlane.  Measured with in-kernel timestamps (round 2): (1) a scalar s_load of it
+// shares its wait counter with the kernel-argument loads, so the compiler waits for it before it can form the first vector
+// address -- one more dependent round trip per launch (wide x-update); (2) in the consensus z kernel (391 workgroups) the
+// scalar load of the 64-byte block took 15-17 us to arrive in every workgroup but the first (1.6 us there), the same request
+// as vector loads 0.8 us everywhere: the kernel went from 22 to 6.6 us.  The zero offset comes from inline asm so that the
+// address is not provably uniform.
+template <typename C>
+__device__ __forceinline__ C load_ctl_vector(const C* p) {
+    static_assert(sizeof(C) % 16 == 0, "control blocks are padded to whole 16-byte words");
+    constexpr int N = (int)(sizeof(C) / 16);
+    int vz;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
+    const uint4* cp = reinterpret_cast<const uint4*>(p) + vz;
+    uint4 w[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) w[k] = cp[k];
+    unsigned u[N * 4];
+    __builtin_memcpy(u, w, sizeof(C));
+#pragma unroll
+    for (int k = 0; k < N * 4; ++k) u[k] = (unsigned)__builtin_amdgcn_readfirstlane((int)u[k]);
+    C c;
+    __builtin_memcpy(&c, u, sizeof(C));
+    return c;
+}
+
+__device__ __forceinline__ int load_flag_vector(const int* p) {
+    int vz;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
+    return __builtin_amdgcn_readfirstlane(p[vz]);
+}
+
 // 16-byte load with the non-temporal hint (global_load_dwordx4 ... nt): for operands that are streamed once per pass and
 // are too large to stay in the 256 MB Infinity Cache anyway.  Measured on one MI355X (round 2, same box): the GEMV streams
 // of C4 / C5 gain 10-13 % (C5 LAD 1278 -> 1430 it/s, BP 1375 -> 1525, C4 589 -> 646); operands that DO fit the cache and are

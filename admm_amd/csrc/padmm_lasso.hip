@@ -19,13 +19,15 @@
 #include "solvers.h"
 #include "loop_driver.h"
 #include "comm.h"
+#include "probe.h"
 
 namespace admm {
 
 struct ParCtl {
     double lam, eps_primal, eps_dual;
-    int iter, lam_idx, done, first, total, pad0, pad1, pad2;
+    int iter, lam_idx, done, first, total, pad0, pad1, pad2, pad3, pad4;      // 64 bytes: whole 16-byte words (load_ctl_vector)
 };
+static_assert(sizeof(ParCtl) == 64, "ParCtl layout");
 
 constexpr int kParMaxWorkers = 64;
 constexpr int kParThreads = 256;
@@ -49,18 +51,33 @@ struct ParParams {
     double* P;                     // [nwg][8] per-workgroup partials of the five sums
     double* trace; long long trace_cap;      // optional decision records (admm_hip_lasso_plan_trace_*), or NULL
     float* beta; int* niter; int* done;
+#ifdef ADMM_HIP_PROBE
+    long long* probe;
+#endif
 };
 
 // head: rhs_k = A_k'b_k - y_k + rho z (PADMMLasso.h:19-21) for the local workers.
 __global__ void __launch_bounds__(kParThreads)
 par_head_kernel(ParParams q) {
-    if (*q.done) return;
+    if (load_flag_vector(q.done)) return;
+    // workers in groups of 8: the 16 loads of a group are requested together (one worker at a time was a chain of dependent
+    // round trips: kernel arguments -> addresses -> values, per worker)
     for (int i = blockIdx.x * kParThreads + threadIdx.x; i < q.p; i += gridDim.x * kParThreads) {
         const double rz = q.rho * (double)q.z[i];
-        for (int k = 0; k < q.Kl; ++k) {
-            const size_t o = (size_t)k * q.ldv + i;
-            const float r0 = q.Ab[o] - q.y[o];
-            q.rhs[o] = (float)((double)r0 + rz);                                      // rhs[idx] += rho * value (double)
+        for (int k0 = 0; k0 < q.Kl; k0 += 8) {
+            float ab[8], yv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const size_t o = (size_t)min(k0 + u, q.Kl - 1) * q.ldv + i;
+                ab[u] = q.Ab[o]; yv[u] = q.y[o];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (k0 + u < q.Kl) {
+                    const float r0 = ab[u] - yv[u];
+                    q.rhs[(size_t)(k0 + u) * q.ldv + i] = (float)((double)r0 + rz);   // rhs[idx] += rho * value (double)
+                }
+            }
         }
     }
 }
@@ -70,7 +87,7 @@ par_head_kernel(ParParams q) {
 __global__ void __launch_bounds__(kParThreads)
 par_pack_kernel(ParParams q) {
     __shared__ double scratch[5 * (kParThreads / 64)];
-    if (*q.done) return;
+    if (load_flag_vector(q.done)) return;
     if (blockIdx.x == 0) {
         double acc[5] = {0, 0, 0, 0, 0};
         for (int w = threadIdx.x; w < q.nwg; w += kParThreads) {
@@ -86,13 +103,26 @@ par_pack_kernel(ParParams q) {
     const float rho_f = (float)q.rho;
     for (int i = blockIdx.x * kParThreads + threadIdx.x; i < q.p; i += gridDim.x * kParThreads) {
         float w = 0.f;
-        for (int k = 0; k < q.Kl; ++k) {
-            const size_t o = (size_t)k * q.ldv + i;
-            float g = 0.f;
-            for (int s = 0; s < q.gnseg[k]; ++s) g += q.gout[k][(size_t)s * q.gstride[k] + i];
-            const float x = q.wide[k] ? (q.rhs[o] - g) / rho_f : g;                   // PADMMLasso.h:23-30
-            q.x[o] = x;
-            w += x + q.y[o] / rho_f;
+        for (int k0 = 0; k0 < q.Kl; k0 += 8) {                                      // 8 workers' operands requested together, consumed in order
+            float g0[8], rh[8], yv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = min(k0 + u, q.Kl - 1);
+                const size_t o = (size_t)k * q.ldv + i;
+                g0[u] = q.gout[k][i]; rh[u] = q.rhs[o]; yv[u] = q.y[o];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + u;
+                if (k < q.Kl) {
+                    float g = 0.f;
+                    g += g0[u];
+                    for (int s = 1; s < q.gnseg[k]; ++s) g += q.gout[k][(size_t)s * q.gstride[k] + i];
+                    const float x = q.wide[k] ? (rh[u] - g) / rho_f : g;            // PADMMLasso.h:23-30
+                    q.x[(size_t)k * q.ldv + i] = x;
+                    w += x + yv[u] / rho_f;
+                }
+            }
         }
         q.wsum[i] = w;
     }
@@ -104,13 +134,20 @@ par_pack_kernel(ParParams q) {
 __global__ void __launch_bounds__(kParThreads)
 par_z_kernel(ParParams q, int par) {
     __shared__ double scratch[5 * (kParThreads / 64)];
-    const ParCtl in = q.ctl[par];
+    WIDE_PROBE_DECL
+    WIDE_PROBE(0);
+    const ParCtl in = load_ctl_vector(q.ctl + par);
     ParCtl* outp = &q.ctl[par ^ 1];
     if (in.done) {
         if (blockIdx.x == 0 && threadIdx.x == 0) *outp = in;
         return;
     }
+    WIDE_PROBE(4);
     const double x2 = q.nsum[0], y2 = q.nsum[1], r2 = q.nsum[2], z2 = q.nsum[3], dz2 = q.nsum[4];
+#ifdef ADMM_HIP_PROBE
+    asm volatile("" :: "v"(x2), "v"(y2), "v"(r2), "v"(z2), "v"(dz2));
+#endif
+    WIDE_PROBE(5);
     ParCtl out = in;
     out.first = 0;
     int lam_finished = -1, niter_val = 0;
@@ -134,6 +171,10 @@ par_z_kernel(ParParams q, int par) {
     out.eps_primal = fmax(sqrt(x2), sqrt(z2) * sK) * q.eps_rel + spK * q.eps_abs;   // PADMMBase.h:117-128
     out.eps_dual = sqrt(y2) * q.eps_rel + spK * q.eps_abs;                           // PADMMBase.h:129-139
     out.total = in.total + 1;
+#ifdef ADMM_HIP_PROBE
+    asm volatile("" :: "v"(out.eps_primal), "v"(out.eps_dual));
+#endif
+    WIDE_PROBE(6);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (lam_finished >= 0) q.niter[lam_finished] = niter_val;
         *outp = out;
@@ -144,6 +185,7 @@ par_z_kernel(ParParams q, int par) {
             t[6] = q.rho; t[7] = 0.0; t[8] = tr_code; t[9] = q.rho; t[10] = q.rho; t[11] = 0.0;
         }
     }
+    WIDE_PROBE(1);
     const float rho_f = (float)q.rho;
     const double pen = out.lam / (q.rho * (double)q.K);
     double acc[5] = {0, 0, 0, 0, 0};
@@ -154,25 +196,38 @@ par_z_kernel(ParParams q, int par) {
         const float v = q.wsum[i] / (float)q.K;
         const double vd = (double)v;
         const float zn = vd > pen ? (float)(vd - pen) : (vd < -pen ? (float)(vd + pen) : 0.f);
-        for (int k = 0; k < q.Kl; ++k) {
-            const size_t o = (size_t)k * q.ldv + i;
-            const float x = q.x[o];
-            const float r = x - zn;
-            const float yn = q.y[o] + rho_f * r;
-            q.y[o] = yn;
-            acc[0] += (double)x * x; acc[1] += (double)yn * yn; acc[2] += (double)r * r;
+        for (int k0 = 0; k0 < q.Kl; k0 += 8) {                                      // 8 workers' operands requested together
+            float xv[8], yv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const size_t o = (size_t)min(k0 + u, q.Kl - 1) * q.ldv + i;
+                xv[u] = q.x[o]; yv[u] = q.y[o];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (k0 + u < q.Kl) {
+                    const float x = xv[u];
+                    const float r = x - zn;
+                    const float yn = yv[u] + rho_f * r;
+                    q.y[(size_t)(k0 + u) * q.ldv + i] = yn;
+                    acc[0] += (double)x * x; acc[1] += (double)yn * yn; acc[2] += (double)r * r;
+                }
+            }
         }
         const float dz = zn - zo;
         acc[3] += (double)zn * zn; acc[4] += (double)dz * dz;
         q.z[i] = zn;
     }
     if (out.done) return;
+    WIDE_PROBE(2);
     block_sum<double, 5>(acc, scratch);
     if (threadIdx.x == 0) {
         double* Pout = q.P + (size_t)blockIdx.x * 8;
 #pragma unroll
         for (int k = 0; k < 5; ++k) Pout[k] = acc[k];
     }
+    WIDE_PROBE(3);
+    WIDE_PROBE_FLUSH(blockIdx.x == 0 ? 0 : (blockIdx.x == gridDim.x - 1 ? 1 : (blockIdx.x == gridDim.x / 2 ? 2 : -1)), in.total);
 }
 
 __global__ void par_init_kernel(ParParams q, double lam0) {
@@ -222,6 +277,9 @@ struct ParPlan final : LassoPlan {
     DevBuf<int> niter, done;
     DevBuf<double> P, dlam;
     DevBuf<ParCtl> ctl;
+#ifdef ADMM_HIP_PROBE
+    DevBuf<long long> probe;
+#endif
     ParParams q{};
     DevBuf<double> trace;
     long long trace_cap = 0, trace_n = 0;
@@ -322,7 +380,7 @@ struct ParPlan final : LassoPlan {
             for (int k = 0; k < Kl; ++k) { W[k].gM.set_nt(nt); if (W[k].wide) { W[k].gAt.set_nt(nt); W[k].gA.set_nt(nt); } }
         }
 
-        nwg = std::max(1, std::min(64, (p + kParThreads - 1) / kParThreads));
+        nwg = std::max(1, std::min(1024, (p + kParThreads - 1) / kParThreads));     // one element per thread up to p = 262144 (was <= 64 workgroups: 31 us for p = 10^5)
         rhs.alloc((size_t)Kl * ldv); x.alloc((size_t)Kl * ldv); y.alloc((size_t)Kl * ldv); nsum.alloc(8);
         z.alloc(ldv); wsum.alloc(ldv);
         rhs.zero(st); x.zero(st); y.zero(st);
@@ -338,6 +396,10 @@ struct ParPlan final : LassoPlan {
             q.gout[k] = last.part.get(); q.gnseg[k] = last.pl.nseg; q.gstride[k] = last.stride; q.wide[k] = w.wide ? 1 : 0;
         }
         q.ctl = ctl.get(); q.P = P.get(); q.beta = beta.get(); q.niter = niter.get(); q.done = done.get();
+#ifdef ADMM_HIP_PROBE
+        probe.alloc((size_t)4096 * 4 * 8); probe.zero(st);
+        q.probe = probe.get();
+#endif
         ADMM_HIP_CHECK(hipStreamSynchronize(st));
     }
 
@@ -350,7 +412,7 @@ struct ParPlan final : LassoPlan {
         const int init_n = std::max(p, nwg * 8);
         hipLaunchKernelGGL(par_init_kernel, dim3((init_n + 255) / 256), dim3(256), 0, st, q, lam_int[0]);
         const int* skip = done.get();
-        const int nwg_e = std::max(1, std::min(device_info().num_cu, (p + kParThreads - 1) / kParThreads));
+        const int nwg_e = std::max(1, std::min(4 * device_info().num_cu, (p + kParThreads - 1) / kParThreads));
         const int batch = pb.batch_iters > 0 ? (pb.batch_iters + 1) / 2 * 2 : 16;
         LoopTimes lt = run_until_done(st, skip, batch, (long long)nlam * ((long long)pb.opts.maxit + 2) + 4, [&](long long g) {
             const int par = (int)(g & 1);
@@ -374,6 +436,13 @@ struct ParPlan final : LassoPlan {
             hipLaunchKernelGGL(par_z_kernel, dim3(nwg), dim3(kParThreads), 0, st, q, par);
         });
         S.t_loop = lt.wall_s; S.loop_ms_events = lt.events_ms; S.xupdate_launches = lt.launched;
+#ifdef ADMM_HIP_PROBE
+        if (const char* f = std::getenv("ADMM_HIP_PROBE_OUT")) {
+            std::vector<long long> hp((size_t)4096 * 4 * 8);
+            ADMM_HIP_CHECK(hipMemcpy(hp.data(), probe.get(), hp.size() * sizeof(long long), hipMemcpyDeviceToHost));
+            if (FILE* fp = std::fopen(f, "wb")) { std::fwrite(hp.data(), sizeof(long long), hp.size(), fp); std::fclose(fp); }
+        }
+#endif
 
         res.niter.assign(nlam, 0);
         ADMM_HIP_CHECK(hipMemcpy(res.niter.data(), niter.get(), nlam * sizeof(int), hipMemcpyDeviceToHost));
