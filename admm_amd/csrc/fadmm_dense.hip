@@ -45,7 +45,7 @@ __global__ void __launch_bounds__(kDenseThreads)
 dense_head_kernel(DenseParams q, int par) {
     __shared__ double sums[8];
     extern __shared__ __attribute__((aligned(16))) double pstage[];
-    const DenseCtl in = q.ctl[par];
+    const DenseCtl in = load_ctl_vector(q.ctl + par);
     DenseCtl* outp = &q.ctl[par ^ 1];
     if (in.done) {
         if (blockIdx.x == 0 && threadIdx.x == 0) *outp = in;
@@ -128,7 +128,7 @@ dense_head_kernel(DenseParams q, int par) {
 __global__ void __launch_bounds__(kDenseThreads)
 dense_tail_kernel(DenseParams q, int par) {
     __shared__ double scratch[6 * (kDenseThreads / 64)];
-    const DenseCtl c = q.ctl[par ^ 1];           // written by this iteration's head
+    const DenseCtl c = load_ctl_vector(q.ctl + (par ^ 1));           // written by this iteration's head
     if (c.done) return;
     const int cur = (c.total - 1) & 1;           // head already advanced `total`
     const double* zc_ = cur ? q.z1 : q.z0;
