@@ -568,7 +568,7 @@ int admm_hip_lasso_plan_trace_read(admm_hip_plan* plan, double* out, long long c
 }
 
 const char* admm_hip_last_error(void) { return last_error_ref().c_str(); }
-const char* admm_hip_version(void) { return "admm_hip 0.1 (gfx950)"; }
+const char* admm_hip_version(void) { return "admm_hip 0.2 (gfx950)"; }
 
 int admm_hip_device_count(void) {
     int cnt = 0;
