@@ -462,3 +462,18 @@ def admm_lad(x, y, intercept=True, **kw):
 
 def admm_bp(x, y, **kw):
     return ADMM_BP(x, y, **kw)
+
+
+class ADMM_Dantzig(ADMM_Lasso):
+    """`admm_dantzig` is exported by the reference (NAMESPACE:13, R/50_admm_dantzig.R) but its `.Call("admm_dantzig", ...)`
+    names a symbol the package never builds: the solver lives in src/TODO/ (Dantzig.cpp, ADMMDantzig.h, written against an
+    older ADMMBase with B_mult / c_norm) and is not compiled, so `$fit()` fails in R.  Mirrored: the builder chain works
+    (it is ADMM_Lasso's), fit() fails like the reference does.  No solver is invented for it."""
+    _name = "ADMM Dantzig Selector model"
+
+    def fit(self):
+        _stop('C symbol name "admm_dantzig" not in DLL for package "ADMM"')     # R/50_admm_dantzig.R:38-46: the reference's own failure
+
+
+def admm_dantzig(x, y, intercept=True, standardize=True, **kw):
+    return ADMM_Dantzig(x, y, intercept, standardize, **kw)
