@@ -71,18 +71,30 @@ gemv_t_kernel(GemvTArgs<T> a, Extra extra) {
         const T* src = a.v[r] + r0;
         T* dst = rhs + (size_t)r * a.seg_alloc;
         if (r == 0 && a.vparts > 1) {
-            for (int i = threadIdx.x; i < lpad; i += kGemvThreads) {
-                T acc = T(0);
-                if (i < len) {
-                    for (int q0 = 0; q0 < a.vparts; q0 += 8) {      // 8 independent loads in flight, summed in order
-                        T t[8];
+            // The right-hand vector arrives as `vparts` partial rows (the un-reduced output of the previous product).  Four
+            // elements per thread at a time, 8 partial rows each: 32 independent loads in flight, every element summed in
+            // row order.  (One element at a time was a chain of two dependent round trips per element -- ~7 of the 9.5 us
+            // of the consensus solver's 1250 x 1250 product.)
+            for (int i0 = threadIdx.x; i0 < lpad; i0 += 4 * kGemvThreads) {
+                T acc[4] = {T(0), T(0), T(0), T(0)};
+                for (int q0 = 0; q0 < a.vparts; q0 += 8) {
+                    T t[4][8];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) t[u] = (q0 + u < a.vparts) ? src[(size_t)(q0 + u) * a.vstride + i] : T(0);
+                    for (int e = 0; e < 4; ++e) {
+                        const int i = min(i0 + e * kGemvThreads, len - 1);         // clamped: never stored beyond lpad, zeroed beyond len
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) acc += t[u];
+                        for (int u = 0; u < 8; ++u) t[e][u] = src[(size_t)min(q0 + u, a.vparts - 1) * a.vstride + i];
                     }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) acc[e] += (q0 + u < a.vparts) ? t[e][u] : T(0);
                 }
-                dst[i] = acc;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = i0 + e * kGemvThreads;
+                    if (i < lpad) dst[i] = (i < len) ? acc[e] : T(0);
+                }
             }
         } else {
             for (int i = threadIdx.x; i < lpad; i += kGemvThreads) dst[i] = (i < len) ? src[i] : T(0);
