@@ -267,6 +267,7 @@ wide_x_kernel(WideParams q, int par) {
     // Speculative request of this wave's first non-zero column: almost every step is an active-set step, and what it reads
     // first does not depend on the decision -- so the column's round trip overlaps the decision and the staging of t
     // (a regular / zero / final step simply drops it).
+    constexpr bool kPair = RT > 0 && RT <= 8;                          // regular steps take the wave's columns two at a time
     constexpr bool kSpec = RT > 0 && RT <= 8;                          // RT = 16: a second column in registers would halve the occupancy
     float4 cv0[kSpec ? NRT : 1];
     long long pj = -1;
@@ -451,6 +452,31 @@ wide_x_kernel(WideParams q, int par) {
             const long long jl = (long long)(s0 + lane) * NW + w;
             const float xj = u == 0 ? xs[0] : (u == 1 ? xs[1] : (u == 2 ? xs[2] : (u == 3 ? xs[3] : (u == 4 ? xs[4] : (u == 5 ? xs[5] : (u == 6 ? xs[6] : xs[7]))))));
             unsigned long long mask = reg ? __ballot(jl < q.p) : __ballot(xj != 0.f);
+            if constexpr (kPair) {
+                // regular step, fused mode: two columns requested before the first is consumed (16 KB in flight per wave;
+                // same order of columns: bit-identical partial sums)
+                while (reg && mask) {
+                    const int l0 = __ffsll((long long)mask) - 1;
+                    mask &= mask - 1;
+                    const long long j0 = (long long)(s0 + l0) * NW + w;
+                    float4 c0[NRT], c1[NRT];
+                    col_request(j0, c0, q.x_nt != 0);
+                    int l1 = -1;
+                    long long j1 = 0;
+                    if (mask) {
+                        l1 = __ffsll((long long)mask) - 1;
+                        mask &= mask - 1;
+                        j1 = (long long)(s0 + l1) * NW + w;
+                        col_request(j1, c1, q.x_nt != 0);
+                    }
+                    const float xn0 = col_finish(__shfl(xj, l0, 64), c0);
+                    if (lane == l0) q.x[j0] = xn0;
+                    if (l1 >= 0) {
+                        const float xn1 = col_finish(__shfl(xj, l1, 64), c1);
+                        if (lane == l1) q.x[j1] = xn1;
+                    }
+                }
+            }
             while (mask) {
                 const int l = __ffsll((long long)mask) - 1;
                 mask &= mask - 1;
