@@ -165,6 +165,17 @@ def _child_teardown(plan, adist, dist, multi):
         dist.destroy_process_group()
 
 
+def _ranks_agree(niter, torch, dist, multi, dev):
+    """Replicated decisions: every rank must report the same iteration counts (a broken exchange shows up here first)."""
+    if not multi:
+        return True
+    t = torch.tensor([int(v) for v in niter], dtype=torch.int64, device=dev)
+    hi, lo = t.clone(), t.clone()
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    return bool(torch.equal(hi, lo))
+
+
 def _max_over_ranks(v, torch, dist, multi):
     if not multi:
         return v
@@ -257,9 +268,11 @@ def tallshard_child(a, backend, out_path):
         xsamp += int(fit.stats["xupdate_samples"])
     elapsed = _max_over_ranks(time.time() - t0, torch, dist, multi)
     setup_s = _max_over_ranks(setup_s, torch, dist, multi)
+    agree = _ranks_agree(fit.niter, torch, dist, multi, dev)
     if rank == 0:
         x_ms = xms / max(1, xsamp)
         res = {"workload": "admm_lasso tall path (BASELINE configs[1]), x-update sharded over the ranks", "exchange": backend,
+               "ranks_agree_on_niter": agree, "all_lambdas_converged": bool(int(max(fit.niter)) <= 10000),
                "n_gpus": world, "ranks_in_communicator": world, "scaling": "strong", "steps": a.steps,
                "iterations_per_step": iters / a.steps, "elapsed_s": elapsed, "iters_per_s": iters / elapsed,
                "us_per_iter": elapsed / iters * 1e6, "loop_ms_events_per_step": loop_ms / a.steps, "setup_s": setup_s,
@@ -315,9 +328,10 @@ def widecols_child(a, backend, out_path):
     st = run()
     iters = int(st["total_iter"])
     loop_s = _max_over_ranks(st["t_loop"], torch, dist, multi)
+    agree = _ranks_agree(niter, torch, dist, multi, dev)
     if rank == 0:
         res = {"workload": "admm_lasso wide n=2000 p=200000 (BASELINE configs[2]), columns sharded over the ranks, 20-lambda path",
-               "exchange": backend, "n_gpus": world, "ranks_in_communicator": world, "scaling": "strong", "iterations": iters,
+               "exchange": backend, "ranks_agree_on_niter": agree, "n_gpus": world, "ranks_in_communicator": world, "scaling": "strong", "iterations": iters,
                "loop_s": loop_s, "iters_per_s": iters / loop_s, "us_per_iter": loop_s / iters * 1e6,
                "setup_s": st["t_total"] - st["t_loop"], "allreduce_payload_bytes": 4 * n, "niter_first": [int(v) for v in niter[:8]]}
         with open(out_path, "w") as f:
@@ -536,6 +550,24 @@ def main():
         if shard:
             out["sharded"] = shard
             ok = [c for c in shard if "error" not in c]
+            # a sharded run only counts if its ranks agreed on every iteration count, every lambda converged, and -- for the
+            # PEER exchange -- its total iteration count is the RCCL run's within 2 % (the two sum in different orders, so a few
+            # stopping decisions may flip; a broken exchange does not stay that close)
+            ref = next((c for c in ok if c["exchange"] == "rccl" and c.get("ranks_agree_on_niter") and c.get("all_lambdas_converged")), None)
+            valid = []
+            for c in ok:
+                why = None
+                if not c.get("ranks_agree_on_niter", True):
+                    why = "ranks disagree on the iteration counts"
+                elif not c.get("all_lambdas_converged", True):
+                    why = "a lambda ran into maxit"
+                elif ref is not None and abs(c["iterations_per_step"] - ref["iterations_per_step"]) > 0.02 * ref["iterations_per_step"]:
+                    why = "iteration count deviates from the RCCL run by more than 2 %"
+                if why:
+                    c["rejected"] = why
+                else:
+                    valid.append(c)
+            ok = valid
             if ok:
                 # N > 1: the primary line is the headline workload itself with its x-update spread over the N GPUs (total
                 # work fixed: strong scaling), over the better of the two exchanges; the independent-replica figure
