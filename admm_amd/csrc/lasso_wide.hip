@@ -31,6 +31,7 @@
 #include "loop_driver.h"
 #include "comm.h"
 #include "probe.h"
+#include "peer_device.h"
 
 namespace admm {
 
@@ -656,9 +657,33 @@ wide_ax_local_kernel(WideParams q, int par, float* out) {
     if (i < q.ldn && sub == 0) out[i] = valid ? ax : 0.f;
 }
 
-// z/y update: Ax = sum of partials; z_new = -(y_data + y + rho Ax) / (1 + rho); r = Ax + z_new; y += rho r; norms.
+// The same over the PEER exchange without launches of the exchange layer: every workgroup writes its elements of this
+// rank's share of A x straight into this rank's slot of EVERY rank's buffer (pairs of elements as one 8-byte write-through
+// store; lane `sub` of an element's group serves ranks sub, sub + 8, ...), and the last workgroup to finish raises the flags
+// (peer_device.h).  Skipped, like the consumer's wait, once the replicated control block says the solve has finished.
 __global__ void __launch_bounds__(kWideThreads)
-wide_tail_kernel(WideParams q, int par) {
+wide_ax_push_kernel(WideParams q, int par, PeerExchange ex) {
+    const WideCtl c = q.ctl[par ^ 1];
+    const int sub = threadIdx.x & (kWtLanes - 1);
+    const int i = blockIdx.x * kWtElems + threadIdx.x / kWtLanes;
+    const bool valid = i < q.n;
+    WIDE_SUM_AXPART(ax)
+    (void)zo; (void)yo; (void)yd;
+    if (c.done) return;                                               // uniform over the launch and over the ranks
+    if (!q.fused && c.type == W_ZERO) ax = 0.f;
+    if (!valid) ax = 0.f;
+    const float ax_next = __shfl_down(ax, kWtLanes, 64);              // the element owned by the next group of 8 lanes
+    if (((threadIdx.x / kWtLanes) & 1) == 0 && i < q.ldn) {           // even elements store the pair (i, i + 1); ldn is even
+        for (int dst = sub; dst < ex.nranks; dst += kWtLanes)
+            peer_store_f32x2(reinterpret_cast<float*>(peer_dst_slot(ex, dst)) + i, ax, ax_next);
+    }
+    peer_publish(ex, gridDim.x);
+}
+
+// z/y update: Ax = sum of partials; z_new = -(y_data + y + rho Ax) / (1 + rho); r = Ax + z_new; y += rho r; norms.
+template <bool PEER = false>      // PEER: A x arrives in the K exchange slots (wide_ax_push_kernel of every rank): wait for the flags, sum in lane order
+__global__ void __launch_bounds__(kWideThreads)
+wide_tail_kernel(WideParams q, int par, PeerExchange ex) {
     __shared__ double scratch[5 * (kWideThreads / 64)];
     WIDE_PROBE_DECL
     WIDE_PROBE(0);
@@ -667,8 +692,21 @@ wide_tail_kernel(WideParams q, int par) {
     const int i = blockIdx.x * kWtElems + threadIdx.x / kWtLanes;
     const bool valid = i < q.n;
     WIDE_SUM_AXPART(ax)
-    if (q.ax_given != nullptr) ax = valid ? q.ax_given[i] : 0.f;      // column-sharded mode: already summed over partials and ranks
+    if (!PEER && q.ax_given != nullptr) ax = valid ? q.ax_given[i] : 0.f;      // column-sharded mode: already summed over partials and ranks
     if (c.done) return;
+    if (PEER) {
+        const bool ok = peer_wait_relaxed(ex);
+        float a = 0.f;
+        if (ok && valid) {
+            for (int r = sub; r < ex.nranks; r += kWtLanes) {           // rank order fixed by the lane pattern: identical on every rank
+                const float2 v = peer_load_f32x2(reinterpret_cast<const float*>(peer_src_slot(ex, r)) + (i & ~1));
+                a += (i & 1) ? v.y : v.x;
+            }
+        }
+#pragma unroll
+        for (int m = 1; m < kWtLanes; m <<= 1) a += __shfl_xor(a, m, 64);
+        ax = a;
+    }
     WIDE_PROBE(1);
     double acc[5] = {0, 0, 0, 0, 0};
     if (valid && sub == 0) {
@@ -723,6 +761,7 @@ struct WidePlan final : LassoPlan {
     int n = 0, p = 0, nlam = 0, nwg_tail = 0, nwg_x = 0, fuse_rt = 0;
     bool t_global = false;               // n too large for the LDS: t through global memory (wide_t_kernel)
     bool cshard = false;                 // columns spread over the ranks: per iteration one all-reduce of Ax (n floats)
+    bool peer_fused = false;             // ... done by the solver's own kernels over the PEER exchange (no launches of the exchange layer)
     CommInfo ci;
     long long p_total = 0, col_offset = 0;
     DevBuf<float> axl;                   // [ldn] this rank's share of Ax, all-reduced in place
@@ -765,6 +804,8 @@ struct WidePlan final : LassoPlan {
         // X X' = sum_i X_i X_i' (one all-reduce), the Lanczos value replicated.
         cshard = pb.p_total > 0;
         ci = cshard ? comm_info() : CommInfo();
+        peer_fused = cshard && ci.backend == COMM_PEER;
+        if (const char* e = std::getenv("ADMM_HIP_PEER_FUSED")) { if (std::string(e) == "0") peer_fused = false; }
         p_total = cshard ? pb.p_total : p; col_offset = cshard ? pb.col_offset : 0;
         admm_stats& S = setup_stats;
         S.branch = 1; S.t_h2d = d.t_h2d; S.t_standardize = d.t_std;
@@ -895,11 +936,17 @@ struct WidePlan final : LassoPlan {
                     }
                     hipLaunchKernelGGL(wide_ax_kernel, dim3(kAxWG), dim3(kWideThreads), 0, st, q);
             }
+            if (cshard && peer_fused) {                                // the only exchange, produced and consumed by the solver's own kernels
+                const PeerExchange ex = comm_peer_begin((size_t)ldn * sizeof(float));
+                hipLaunchKernelGGL(wide_ax_push_kernel, dim3((unsigned)((ldn + kWtElems - 1) / kWtElems)), dim3(kWideThreads), 0, st, q, par, ex);
+                hipLaunchKernelGGL(wide_tail_kernel<true>, dim3(nwg_tail), dim3(kWideThreads), 0, st, q, par, ex);
+                return;
+            }
             if (cshard) {                                              // the only exchange: A x summed over the ranks' column blocks
                 hipLaunchKernelGGL(wide_ax_local_kernel, dim3((unsigned)((ldn + kWtElems - 1) / kWtElems)), dim3(kWideThreads), 0, st, q, par, axl.get());
                 allreduce_sum_f32(axl.get(), (size_t)n, st);
             }
-            hipLaunchKernelGGL(wide_tail_kernel, dim3(nwg_tail), dim3(kWideThreads), 0, st, q, par);
+            hipLaunchKernelGGL(wide_tail_kernel<false>, dim3(nwg_tail), dim3(kWideThreads), 0, st, q, par, PeerExchange{});
         }, cshard ? nullptr : hflag.p);       // column-sharded: every rank must enqueue the same number of exchanges -> stream-ordered sampling of `done`
         S.t_loop = lt.wall_s; S.loop_ms_events = lt.events_ms; S.xupdate_launches = lt.launched;
 #ifdef ADMM_HIP_PROBE
