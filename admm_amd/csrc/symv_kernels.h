@@ -273,7 +273,8 @@ struct SymvPlan {
         // The whole triangle is re-read every iteration.  Plain loads while most of it stays in the 256 MB Infinity Cache
         // between two passes, non-temporal beyond.  Measured crossover (one MI355X, plain vs nt, TB/s on 2p^2 bytes):
         // p = 10000 5.7 vs 5.3 | 11000 5.90 vs 5.24 | 12000 6.08 vs 5.41 | 13000 4.31 vs 5.50 | 16000 4.1-4.4 vs 5.3-5.4.
-        nt = (size_t)2 * (size_t)p * (size_t)p > (size_t)310000000;
+        // (a rank of the row-sharded solver re-reads only its 1 / nparts share)
+        nt = (size_t)2 * (size_t)p * (size_t)p / (size_t)std::max(1, nparts) > (size_t)310000000;
         if (const char* e = std::getenv("ADMM_HIP_SYMV_NT")) nt = std::string(e) == "1";
         tiles.alloc(std::max<size_t>(h.size(), 1));
         if (!h.empty()) ADMM_HIP_CHECK(hipMemcpyAsync(tiles.get(), h.data(), h.size() * sizeof(int2), hipMemcpyHostToDevice, st));
