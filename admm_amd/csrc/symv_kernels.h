@@ -29,6 +29,8 @@
 //    tiles reversed on odd launches; a tile keeps its XCD): no change at all (24.10 vs 24.10 k it/s) -- nothing of the
 //    matrix survives a kernel boundary in the XCD L2s.  In-kernel timestamps (scripts/tall_probe.py) put the streaming
 //    phase itself at 200 MB / 31 us = 6.45 TB/s, the Infinity Cache ceiling; the rest of the 34.5 us is ramp and drain;
+//  * two or three tiles per workgroup (half / a third of the workgroups, same tile code): 38.1 / 38.3 instead of 35.6 us
+//    per launch -- the second round of small work units is what balances the end of the launch;
 //  * fusing the consumer into this launch ("last tile of a block finalises it", arrival counters): correct,
 //    but cross-XCD visibility needs either agent-scope fences (whole-L2 write-back per wave: 5x slower) or
 //    uncached partial arrays plus an acknowledged-store wait and an atomic round trip per tile (1.65x slower
