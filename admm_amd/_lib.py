@@ -57,7 +57,7 @@ EXPORTS = ["admm_hip_lasso", "admm_hip_enet", "admm_hip_parlasso", "admm_hip_lad
            "admm_hip_comm_peer_prepare", "admm_hip_comm_init_peer", "admm_hip_comm_init_shm", "admm_hip_comm_test_allreduce",
            "admm_hip_lasso_dist", "admm_hip_test_gram", "admm_hip_test_spd_inverse",
            "admm_hip_lasso_dist_cols", "admm_hip_test_gemv_t", "admm_hip_lad_traced", "admm_hip_bp_traced",
-           "admm_hip_lasso_plan_create_dist_cols", "admm_hip_lasso_cv"]
+           "admm_hip_lasso_plan_create_dist_cols", "admm_hip_lasso_cv", "admm_hip_lasso_multi"]
 
 TRACE_FIELDS = 12
 TRACE_COLD, TRACE_CONVERGED, TRACE_ACCELERATE, TRACE_RESTART = -1, 0, 1, 2
@@ -86,6 +86,10 @@ def load():
                                        _c_double_p, _c_double_p, _c_double_p, _c_int_p, _c_float_p, _c_int_p, _c_int_p,
                                        ctypes.POINTER(AdmmStats)])
     lib.admm_hip_lasso_cv.restype = ctypes.c_int
+    lib.admm_hip_lasso_multi.argtypes = ([_DP, _DP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                          _DP, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                          ctypes.POINTER(AdmmOpts), _c_double_p, _c_float_p, _c_int_p, ctypes.POINTER(AdmmStats)])
+    lib.admm_hip_lasso_multi.restype = ctypes.c_int
     lib.admm_hip_lad.argtypes = [_DP, _DP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                  ctypes.POINTER(AdmmOpts), _c_double_p, _c_int_p, ctypes.POINTER(AdmmStats)]
     lib.admm_hip_bp.argtypes = [_DP, _DP, ctypes.c_int, ctypes.c_int, ctypes.c_int,

@@ -181,6 +181,36 @@ class ADMM_Lasso:
         keep = (xk, yk, lam_in)
         return lib, head, tail, lam_out, beta, niter, stats, keep
 
+    def fit_responses(self, Y, m=None):
+        """Fit this model for several responses of the same x at once (admm_hip_lasso_multi; not in the reference package):
+        Y is n x m (a host matrix, or a DevicePtr to column-major doubles together with m); returns one ADMM_Lasso_fit per
+        column, each bit-identical to a separate fit() with that column as y."""
+        lib, head, tail, lam_out, beta, niter, stats, keep = self._common()
+        if isinstance(Y, DevicePtr):
+            if m is None:
+                _stop("m (the number of responses) is needed with a device pointer")
+            yp, ymem, yk = as_input(Y)
+            m = int(m)
+        else:
+            Ya = np.asfortranarray(Y, dtype=np.float64)
+            if Ya.ndim != 2 or Ya.shape[0] != self.n:
+                _stop("Y should be a matrix with nrow(x) rows")
+            m = Ya.shape[1]
+            yp, ymem, yk = as_input(Ya)
+        if ymem != head[4]:
+            _stop("x and Y must live in the same memory space")
+        nl = lam_out.size
+        lam_all = np.zeros((m, nl))
+        beta_all = np.zeros((m, nl, self.p + 1), dtype=np.float32)
+        nit_all = np.zeros((m, nl), dtype=np.int32)
+        st_all = (AdmmStats * m)()
+        alpha = float(getattr(self, "alpha", -1.0))
+        check(lib.admm_hip_lasso_multi(head[0], yp, head[2], head[3], m, head[4], *head[5:], alpha, tail[0],
+                                       lam_all.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                       beta_all.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                                       nit_all.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), st_all))
+        return [ADMM_Lasso_fit(lam_all[j].copy(), np.asfortranarray(beta_all[j].T), nit_all[j].copy(), st_all[j].as_dict()) for j in range(m)]
+
     def cv(self, nfolds=10, fold_id=None, keep_fold_beta=False):
         """K-fold cross-validation of this model's lambda path (admm_hip_lasso_cv; not in the reference package).
         fold_id: integer array of length n with values in [0, nfolds) (default: i mod nfolds)."""

@@ -297,6 +297,101 @@ static void lasso_cv(const double* x, const double* y, int n, int p, int mem, co
     if (stats) stats->t_total = now_s() - t0;
 }
 
+// Several responses of one design matrix ("batched / multi-response"): response j is the ordinary
+// fit of (x, Y[:, j]) -- bit-identical to admm_hip_lasso / admm_hip_enet on that pair -- but x is uploaded, converted and
+// standardised once, and for the tall solver X'X is formed once (it does not depend on y; the cached inverse does, through
+// rho, and is rebuilt per response).  With a communicator the responses are dealt out to the ranks (response j on rank
+// j mod nranks, independent replicas) and the outputs are summed over the ranks at the end.
+static void lasso_multi(const double* x, const double* Y, int n, int p, int m, int mem,
+                        const double* lambda_in, int nlambda_in, int nlambda_auto, double lmin_ratio,
+                        int standardize, int intercept, double alpha, const admm_opts* opts,
+                        double* lambda_out, float* beta_out, int* niter_out, admm_stats* stats) {
+    check_common(x, Y, n, p, mem, opts);
+    ADMM_REQUIRE(m >= 1, "the number of responses must be >= 1");
+    ADMM_REQUIRE(lambda_out && beta_out && niter_out, "output pointers must not be NULL");
+    ADMM_REQUIRE(nlambda_in >= 0, "nlambda_in must be >= 0");
+    ADMM_REQUIRE(nlambda_in > 0 ? lambda_in != nullptr : nlambda_auto > 0, "need a lambda grid or nlambda_auto > 0");
+    const bool enet = alpha >= 0.0;
+    if (enet) ADMM_REQUIRE(alpha <= 1.0, "alpha must be within [0, 1]");
+    require_device();
+    const int nlam = nlambda_in > 0 ? nlambda_in : nlambda_auto;
+    const size_t bsz = (size_t)(p + 1) * nlam;
+    Stream st;
+    DevBuf<double> xd_own, yd_own;
+    const double* xd = x; const double* yd = Y;
+    if (mem == ADMM_MEM_HOST) {
+        xd_own.alloc((size_t)n * p); yd_own.alloc((size_t)n * m);
+        ADMM_HIP_CHECK(hipMemcpyAsync(xd_own.get(), x, (size_t)n * p * sizeof(double), hipMemcpyHostToDevice, st.s));
+        ADMM_HIP_CHECK(hipMemcpyAsync(yd_own.get(), Y, (size_t)n * m * sizeof(double), hipMemcpyHostToDevice, st.s));
+        ADMM_HIP_CHECK(hipStreamSynchronize(st.s));
+        xd = xd_own.get(); yd = yd_own.get();
+    }
+    const CommInfo ci = comm_info();
+    const int nranks = ci.active ? ci.nranks : 1, rank = ci.active ? ci.rank : 0;
+    std::vector<double> lam((size_t)m * nlam, 0.0), nit((size_t)m * nlam, 0.0);
+    std::memset(beta_out, 0, sizeof(float) * bsz * m);
+    if (stats) std::memset(stats, 0, sizeof(admm_stats) * (size_t)m);
+
+    LassoProblem pb;
+    pb.opts = *opts;
+    pb.lambda_in.assign(lambda_in, lambda_in + nlambda_in);
+    pb.nlambda_auto = nlambda_auto;
+    pb.lmin_ratio = lmin_ratio;
+    pb.enet = enet;
+    pb.alpha = enet ? alpha : 1.0;
+    pb.batch_iters = env_int("ADMM_HIP_BATCH_ITERS", 0);
+    pb.profile_stride = 0;
+    if (nlambda_in == 0) ADMM_REQUIRE(lmin_ratio > 0 && lmin_ratio < 1, "lambda_min_ratio must be within (0, 1)");
+    for (int i = 0; i < nlambda_in; ++i) ADMM_REQUIRE(lambda_in[i] > 0, "lambda must be positive");
+
+    const bool tall = n > p;                                           // Lasso.cpp:73
+    DeviceData<float> base;
+    DevBuf<float> G;
+    long long ldg = 0;
+    double t_shared = 0;
+    int first = -1;
+    for (int j = 0; j < m; ++j) if (j % nranks == rank) { first = j; break; }
+    if (first >= 0) {
+        const double t0 = now_s();
+        upload_standardize<float>(base, xd, yd + (size_t)first * n, n, p, ADMM_MEM_DEVICE, standardize != 0, intercept != 0, st.s, 0);
+        if (tall) {
+            ldg = round_up(p, 128);
+            G.alloc((size_t)ldg * ldg); G.zero(st.s);
+            gram_full<float>(base.X.get(), base.ldx, n, p, true, G.get(), ldg, st.s);
+            ADMM_HIP_CHECK(hipStreamSynchronize(st.s));
+        }
+        t_shared = now_s() - t0;
+    }
+    for (int j = 0; j < m; ++j) {
+        if (j % nranks != rank) continue;
+        const double t0 = now_s();
+        DeviceData<float> d;
+        clone_with_response_f32(d, base, tall ? G.get() : nullptr, ldg, yd + (size_t)j * n, st.s);
+        std::unique_ptr<LassoPlan> plan = tall ? make_tall_plan(std::move(d), pb, st.s) : make_wide_plan(std::move(d), pb, st.s);
+        LassoResult res;
+        plan->run(res);
+        ADMM_REQUIRE((int)res.lambda.size() == nlam, "internal: unexpected path length");
+        for (int l = 0; l < nlam; ++l) { lam[(size_t)j * nlam + l] = res.lambda[l]; nit[(size_t)j * nlam + l] = res.niter[l]; }
+        std::memcpy(beta_out + (size_t)j * bsz, res.beta.data(), sizeof(float) * bsz);
+        if (stats) { stats[j] = res.stats; stats[j].t_total = now_s() - t0 + (j == first ? t_shared : 0.0); }
+    }
+    if (nranks > 1) {                                                  // the other ranks' responses: sum all-reduces of the outputs
+        DevBuf<double> t((size_t)2 * m * nlam);
+        ADMM_HIP_CHECK(hipMemcpyAsync(t.get(), lam.data(), lam.size() * sizeof(double), hipMemcpyHostToDevice, st.s));
+        ADMM_HIP_CHECK(hipMemcpyAsync(t.get() + lam.size(), nit.data(), nit.size() * sizeof(double), hipMemcpyHostToDevice, st.s));
+        allreduce_sum_f64(t.get(), (size_t)2 * m * nlam, st.s);
+        ADMM_HIP_CHECK(hipMemcpyAsync(lam.data(), t.get(), lam.size() * sizeof(double), hipMemcpyDeviceToHost, st.s));
+        ADMM_HIP_CHECK(hipMemcpyAsync(nit.data(), t.get() + lam.size(), nit.size() * sizeof(double), hipMemcpyDeviceToHost, st.s));
+        DevBuf<float> fb(bsz * m);
+        ADMM_HIP_CHECK(hipMemcpyAsync(fb.get(), beta_out, bsz * m * sizeof(float), hipMemcpyHostToDevice, st.s));
+        allreduce_sum_f32(fb.get(), bsz * m, st.s);
+        ADMM_HIP_CHECK(hipMemcpyAsync(beta_out, fb.get(), bsz * m * sizeof(float), hipMemcpyDeviceToHost, st.s));
+        ADMM_HIP_CHECK(hipStreamSynchronize(st.s));
+        comm_check();
+    }
+    for (size_t k = 0; k < lam.size(); ++k) { lambda_out[k] = lam[k]; niter_out[k] = (int)std::llround(nit[k]); }
+}
+
 }  // namespace admm
 
 using namespace admm;
@@ -332,6 +427,16 @@ int admm_hip_lasso_cv(const double* x, const double* y, int n, int p, int mem, c
     return guarded([&] {
         lasso_cv(x, y, n, p, mem, fold_id, nfolds, lambda_in, nlambda_in, nlambda_auto, lmin_ratio, standardize, intercept, alpha, opts,
                  lambda_out, beta_out, niter_out, cv_mean, cv_se, fold_mse, fold_niter, fold_beta, idx_min, idx_1se, stats);
+    });
+}
+
+int admm_hip_lasso_multi(const double* x, const double* Y, int n, int p, int m, int mem,
+                         const double* lambda_in, int nlambda_in, int nlambda_auto, double lmin_ratio,
+                         int standardize, int intercept, double alpha, const admm_opts* opts,
+                         double* lambda_out, float* beta_out, int* niter_out, admm_stats* stats) {
+    return guarded([&] {
+        lasso_multi(x, Y, n, p, m, mem, lambda_in, nlambda_in, nlambda_auto, lmin_ratio, standardize, intercept, alpha, opts,
+                    lambda_out, beta_out, niter_out, stats);
     });
 }
 

@@ -38,6 +38,9 @@ void upload_standardize(DeviceData<T>& d, const double* x, const double* y, int 
 // upload_standardize + the one-shot matrix-core Gram.
 void upload_standardize_gram_f32(DeviceData<float>& d, const double* x, const double* y, int n, int p,
                                  bool standardize, bool intercept, hipStream_t st);
+// Another response of the same x (admm_hip_lasso_multi): X / statistics / Gram copied from `base`, y standardised alone.
+void clone_with_response_f32(DeviceData<float>& d, const DeviceData<float>& base, const float* gram, long long ldgram,
+                             const double* y_dev, hipStream_t st);
 
 // DataStd::recover (DataStd.h:157-207) on a host coefficient vector (length p) in precision T.
 template <typename T>

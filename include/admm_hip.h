@@ -134,6 +134,20 @@ ADMM_HIP_API int admm_hip_lasso_cv(const double* x, const double* y, int n, int 
                       double* cv_mean, double* cv_se, double* fold_mse, int* fold_niter, float* fold_beta,
                       int* idx_min, int* idx_1se, admm_stats* stats);
 
+/* Several responses of one design matrix: Y is n x m column-major, response j is the ordinary admm_hip_lasso (alpha < 0) /
+ * admm_hip_enet (alpha in [0, 1]) fit of (x, Y[:, j]) -- coefficients, grids and iteration counts bit-identical to that call
+ * -- but x is uploaded, converted and standardised once and, for the tall solver (n > p), X'X is formed once (it does not
+ * depend on y; the cached inverse does, through rho, and is rebuilt per response).  SURVEY.md section 8(f) row n4; the
+ * reference has no multi-response entry (its fits are one .Call each, /root/reference/src/Lasso.cpp:32-135).  With a
+ * communicator attached response j runs on rank j mod nranks (every rank is handed the full x, Y; nothing is exchanged on
+ * the data path) and the outputs are summed over the ranks at the end: all ranks return identical outputs.
+ * Outputs (response-major): lambda_out[m x nlam], beta_out[m x (p+1) x nlam], niter_out[m x nlam], stats[m] (may be NULL;
+ * the one-time shared work is charged to the first response of each rank; entries of responses fitted by other ranks stay zero). */
+ADMM_HIP_API int admm_hip_lasso_multi(const double* x, const double* Y, int n, int p, int m, int mem,
+                         const double* lambda_in, int nlambda_in, int nlambda_auto, double lmin_ratio,
+                         int standardize, int intercept, double alpha, const admm_opts* opts,
+                         double* lambda_out, float* beta_out, int* niter_out, admm_stats* stats);
+
 ADMM_HIP_API int admm_hip_parlasso(const double* x, const double* y, int n, int p, int mem,
                       const double* lambda_in, int nlambda_in, int nlambda_auto, double lmin_ratio,
                       int standardize, int intercept, int nthread, const admm_opts* opts,

@@ -86,3 +86,24 @@ def test_cv_argument_checks():
         admm_amd.admm_lasso(x, y).cv(nfolds=3, fold_id=np.full(50, 7, dtype=np.int32))
     with pytest.raises(RuntimeError):
         admm_amd.admm_lasso(x, y).cv(nfolds=3, fold_id=np.zeros(50, dtype=np.int32))     # folds 1, 2 empty
+
+
+def test_multi_response_equals_separate_fits_tall_and_wide():
+    """admm_hip_lasso_multi: every response is bit-identical to its own admm_lasso / admm_enet call (x standardised once,
+    X'X formed once for the tall solver)."""
+    import admm_amd
+    rng = np.random.default_rng(3)
+    for (n, p, kind) in ((500, 60, "lasso"), (70, 260, "enet")):
+        x, y0 = _data(n, p, 6, 10 + n)
+        Y = np.stack([y0, x @ rng.standard_normal(p) * 0.1 + rng.standard_normal(n), rng.standard_normal(n) * 3 + 1], axis=1)
+        if kind == "lasso":
+            mk = lambda yy: admm_amd.admm_lasso(x, yy).penalty(nlambda=9)
+        else:
+            mk = lambda yy: admm_amd.admm_enet(x, yy).penalty(nlambda=7, alpha=0.4)
+        fits = mk(Y[:, 0]).fit_responses(Y)
+        assert len(fits) == 3
+        for j, f in enumerate(fits):
+            one = mk(np.ascontiguousarray(Y[:, j])).fit()
+            assert np.array_equal(one.lambda_, f.lambda_), (kind, j)
+            assert np.array_equal(one.niter, f.niter), (kind, j, one.niter, f.niter)
+            assert np.array_equal(one.beta_dense, f.beta_dense), (kind, j)
