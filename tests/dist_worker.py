@@ -54,6 +54,9 @@ def problem(case):
     if case == "cv":                  # K-fold cross-validation with the folds dealt out to the ranks (fold f on rank f mod nranks)
         x, y = synth_lasso(500, 60, 8, seed=77)
         return x, y, -2, dict(nlambda=8)
+    if case == "multi":               # three responses of one design matrix dealt out to the ranks (response j on rank j mod nranks)
+        x, y = synth_lasso(400, 50, 8, seed=78)
+        return x, y, -3, dict(nlambda=7)
     raise SystemExit("unknown case " + case)
 
 
@@ -85,6 +88,17 @@ def main():
     # ---- the distributed consensus solver on this rank's row slice
     x, y, K, kw = problem(case)
     n, p = x.shape
+    if K == -3:
+        import admm_amd
+        rng = np.random.default_rng(9)
+        Y = np.stack([y, y[::-1].copy(), rng.standard_normal(n)], axis=1)
+        fits = admm_amd.admm_lasso(np.asfortranarray(x), y).penalty(nlambda=kw["nlambda"]).fit_responses(Y)
+        np.savez(os.path.join(workdir, f"result.{rank}.npz"), beta=np.stack([f.beta_dense for f in fits]),
+                 niter=np.stack([f.niter for f in fits]), lam=np.stack([f.lambda_ for f in fits]))
+        barrier(workdir, "end", rank, nranks)
+        adist.finalize_comm()
+        print("rank", rank, "ok", flush=True)
+        return
     if K == -2:
         import admm_amd
         cv = admm_amd.admm_lasso(np.asfortranarray(x), y).penalty(nlambda=kw["nlambda"]).cv(nfolds=5, keep_fold_beta=True)

@@ -137,3 +137,20 @@ def test_two_process_cross_validation_folds_as_replicas(backend):
         assert np.array_equal(r["cvm"], one.cvm) and np.array_equal(r["cvse"], one.cvse)
         assert list(r["idx"]) == [one.idx_min, one.idx_1se]
         assert np.array_equal(r["beta"], one.fit.beta_dense) and np.array_equal(r["lam"], one.lambda_)
+
+
+def test_two_process_multi_response_as_replicas():
+    """admm_hip_lasso_multi with a communicator: response j runs on rank j mod 2, outputs summed over the ranks at the end;
+    every rank returns what separate single-process fits return."""
+    import admm_amd
+    sys.path.insert(0, HERE)
+    from dist_worker import problem
+    res = _run_ranks("shm", "multi")
+    x, y, _, kw = problem("multi")
+    rng = np.random.default_rng(9)
+    Y = np.stack([y, y[::-1].copy(), rng.standard_normal(x.shape[0])], axis=1)
+    for j in range(3):
+        one = admm_amd.admm_lasso(np.asfortranarray(x), np.ascontiguousarray(Y[:, j])).penalty(nlambda=kw["nlambda"]).fit()
+        for r in res:
+            assert np.array_equal(r["beta"][j], one.beta_dense) and np.array_equal(r["niter"][j], one.niter)
+            assert np.array_equal(r["lam"][j], one.lambda_)
