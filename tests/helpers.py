@@ -84,7 +84,7 @@ def assert_followed_parity(beta, niter, trace, problem, tol=1e-4, band=8.0, labe
     ng, nr = np.asarray(niter, dtype=int), np.asarray(ref["niter"], dtype=int)
     assert np.array_equal(ng, nr), (label, ng, nr)
     nl = beta.shape[1]
-    floor = 1e-2 * float(np.abs(ref["beta"]).max())          # as in assert_tall_parity
+    floor = 1e-2 * max(float(np.abs(ref["beta"]).max()), coef_scale(problem))          # as in assert_tall_parity
     errs = [col_err(beta[:, j], ref["beta"][:, j], floor) for j in range(nl)]
     nstop = sum(1 for f in forced if f["kind"] == "stop")
     fm = max([f["ulps"] for f in forced if f["kind"] == "stop"], default=0.0)
@@ -93,6 +93,22 @@ def assert_followed_parity(beta, niter, trace, problem, tol=1e-4, band=8.0, labe
     bad = [(j, e) for j, e in enumerate(errs) if e >= tol]
     assert not bad, (label, bad)
     return dict(forced=forced, max_err=max(errs), errs=errs, ref=ref)
+
+
+def coef_scale(problem):
+    """Natural size of a coefficient of this problem: the largest univariate least-squares coefficient
+    |x_j'y| / (x_j'x_j) (centred when an intercept is fitted).  The yardstick for columns of a path that are (nearly) null:
+    at lambda_max the coordinate attaining max|X'y| sits exactly on the soft threshold and survives with a value that is
+    the difference of two nearly equal numbers -- its RELATIVE error is meaningless, its error relative to the size
+    coefficients have in this problem is not.  (A path of a single lambda at lambda_max has no other scale at all.)"""
+    x = np.asarray(problem["x"], dtype=np.float64)
+    y = np.asarray(problem["y"], dtype=np.float64)
+    if problem.get("intercept", True):
+        x = x - x.mean(axis=0)
+        y = y - y.mean()
+    den = (x * x).sum(axis=0)
+    den[den == 0] = np.inf
+    return float(np.abs(x.T @ y / den).max())
 
 
 def col_err(a, b, floor):
@@ -112,7 +128,7 @@ def assert_tall_parity(beta, niter, trace, problem, tol=1e-4, factor=5.0, band=8
     nl = beta.shape[1]
     # null / tiny columns (lambda_max: the coordinate attaining max|X'y| sits exactly on the soft-threshold and may
     # survive with a value of 1e-7 of the path's scale on one side) are measured against 1 % of the path's largest coefficient
-    floor = 1e-2 * float(np.abs(ref["beta"]).max())
+    floor = 1e-2 * max(float(np.abs(ref["beta"]).max()), coef_scale(problem))
     errs = [col_err(beta[:, j], ref["beta"][:, j], floor) for j in range(nl)]
     loose, yard = [], 0.0
     if max(errs) >= tol:                                                         # R3

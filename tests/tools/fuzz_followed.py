@@ -12,8 +12,11 @@ import test_gpu_fuzz as T  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 120
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 11
+only = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else None
 bad = 0
 for cs in cases(n, seed):
+    if only is not None and cs["c"] not in only:
+        continue
     try:
         if cs["kind"] in ("lad", "bp"):
             T._run_dense_case(cs)
