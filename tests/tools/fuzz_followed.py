@@ -1,5 +1,5 @@
 """Dev tool (GPU box): the strict trace-based parity rule of tests/test_gpu_fuzz.py on another draw of random small
-problems.   python tests/tools/fuzz_followed.py [ncases] [seed]"""
+problems.   python tests/tools/fuzz_followed.py [ncases] [seed] [case,case,...|medium]"""
 import os
 import sys
 import traceback
@@ -12,8 +12,21 @@ import test_gpu_fuzz as T  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 120
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 11
-only = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else None
+medium = len(sys.argv) > 3 and sys.argv[3] == "medium"
+only = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 and not medium else None
 bad = 0
+if medium:
+    from fuzz_cases import medium_cases
+    for cs in medium_cases(n, seed):
+        if cs["kind"] not in ("tall", "enet_tall"):
+            continue
+        try:
+            T._medium_tall(cs)
+        except Exception as e:                              # noqa: BLE001
+            bad += 1
+            print("FAIL medium case", cs["c"], cs["kind"], "n=%d p=%d" % (cs["n"], cs["p"]), type(e).__name__, str(e)[:300], flush=True)
+    print("medium cases", n, "seed", seed, "failures", bad)
+    sys.exit(0)
 for cs in cases(n, seed):
     if only is not None and cs["c"] not in only:
         continue
