@@ -492,7 +492,14 @@ class PADMMLasso:
             AA = (A.T @ A if A.shape[0] >= A.shape[1] else A @ A.T).astype(F)
             m = AA.shape[0]
             AA[np.arange(m), np.arange(m)] += F(self.rho)
-            self.chol.append(sla.cho_factor(AA, lower=True, check_finite=False))
+            if self.xmode == "llt32":                                       # the reference: float LLT
+                self.chol.append(sla.cho_factor(AA, lower=True, check_finite=False))
+            elif self.xmode == "exact":                                     # rounding variants (oracle/variants.py): same system,
+                self.chol.append(sla.cho_factor(AA.astype(np.float64), lower=True, check_finite=False))
+            else:                                                           # "inv32": float inverse from the float factor
+                L = np.tril(sla.cho_factor(AA, lower=True, check_finite=False)[0])
+                Li = sla.solve_triangular(L, np.eye(m, dtype=F), lower=True, check_finite=False).astype(F)
+                self.chol.append((Li.T @ Li).astype(F))
         self.sq_r = [0.0] * K
 
     def init_warm(self, lam):                                               # :215-223
@@ -512,10 +519,10 @@ class PADMMLasso:
                 rhs = (self.Ab[k] - self.y[k]).astype(F)
                 rhs = (rhs.astype(np.float64) + self.rho * self.aux_z.astype(np.float64)).astype(F)
                 if A.shape[0] >= A.shape[1]:
-                    self.x[k] = sla.cho_solve(self.chol[k], rhs, check_finite=False).astype(F)
+                    self.x[k] = self._solve(k, rhs)
                 else:
                     t = (A @ rhs).astype(F)
-                    s = sla.cho_solve(self.chol[k], t, check_finite=False).astype(F)
+                    s = self._solve(k, t)
                     self.x[k] = ((rhs - (A.T @ s).astype(F)) / F(self.rho)).astype(F)
             # update_z (:190-198), master next_z PADMMLasso.h:99-108
             vec = np.zeros(p, F)
@@ -555,6 +562,15 @@ class PADMMLasso:
                 return it + 1
         return maxit + 1
 
+    def _solve(self, k, v):
+        """(A'A + rho I)^-1 v or (AA' + rho I)^-1 v with the rounding of `xmode`."""
+        if self.xmode == "llt32":
+            return sla.cho_solve(self.chol[k], v, check_finite=False).astype(F)
+        if self.xmode == "exact":
+            return sla.cho_solve(self.chol[k], v.astype(np.float64), check_finite=False).astype(F)
+        return (self.chol[k] @ v).astype(F)
+
+    xmode = "llt32"
     trace = None
     follow = None
     follow_band = 8.0

@@ -57,12 +57,16 @@ class LassoTallVariant(solvers.LassoTall):
 
 @contextlib.contextmanager
 def tall_variant(mode):
-    """Within the block oracle.entry's tall solver uses the given x-update rounding."""
+    """Within the block oracle.entry's tall solver -- and the consensus solver's workers (llt32 / inv32 / exact; inv64r
+    runs as inv32 there) -- use the given x-update rounding."""
     assert mode in MODES
     cls = type("LassoTall_" + mode, (LassoTallVariant,), {"mode": mode})
     orig = entry.LassoTall
+    orig_par = solvers.PADMMLasso.xmode
     entry.LassoTall = cls
+    solvers.PADMMLasso.xmode = {"llt32": "llt32", "exact": "exact"}.get(mode, "inv32")
     try:
         yield
     finally:
         entry.LassoTall = orig
+        solvers.PADMMLasso.xmode = orig_par
