@@ -53,6 +53,27 @@ def traced_fit(model, capacity=1 << 18):
     return fit, trace
 
 
+def assert_trace_self_consistent(trace, accelerated, label=""):
+    """Every recorded decision must be the one the reference's rule gives for the values recorded WITH it (the GPU's own
+    residuals and thresholds): converged iff r_p < eps_p and r_d < eps_d (FADMMBase.h:213-217, ADMMBase.h:196-197,
+    PADMMBase.h:230-231); for the accelerated solvers otherwise accelerate iff c < 0.999 c_old, else restart
+    (FADMMBase.h:243).  Independent of the oracle: it checks the decision logic, not the iterates."""
+    t = np.asarray(trace, dtype=np.float64)
+    if len(t) and t[0, 8] == -1:
+        t = t[1:]
+    if not len(t):
+        return 0
+    conv = (t[:, 4] < t[:, 2]) & (t[:, 5] < t[:, 3])
+    assert np.array_equal(conv, t[:, 8] == 0), (label, "stopping decisions inconsistent with the recorded residuals",
+                                                 np.nonzero(conv != (t[:, 8] == 0))[0][:5])
+    if accelerated:
+        nc = ~conv
+        acc = t[nc, 6] < 0.999 * t[nc, 7]
+        assert np.array_equal(acc, t[nc, 8] == 1), (label, "restart decisions inconsistent with the recorded combined residuals",
+                                                    np.nonzero(acc != (t[nc, 8] == 1))[0][:5])
+    return len(t)
+
+
 def oracle_following(trace, x, y, lam, nlambda, lmin_ratio, standardize, intercept, opts, alpha=None, mode="llt32", band=8.0, nthread=None):
     """The oracle (x-update rounding `mode`, tall solver only) following the decisions of `trace` (a libadmm_hip trace or
     another oracle's); tall, wide (n <= p) or -- with nthread -- consensus solver, as the reference would dispatch.
@@ -101,6 +122,7 @@ def assert_followed_parity(beta, niter, trace, problem, tol=1e-4, band=8.0, labe
     """Wide / consensus solvers (no rounding variants of the x-update there): the oracle follows the GPU through
     rounding-level near-ties of the stopping test and of the rho adaptation only; iteration counts identical for every
     lambda and every beta column within `tol`."""
+    assert_trace_self_consistent(trace, accelerated=False, label=label)
     ref, forced, ndec = oracle_following(trace, band=band, **problem)
     t = np.asarray(trace)
     nrec = len(t) - (1 if len(t) and t[0, 8] == -1 else 0)
@@ -154,6 +176,7 @@ def col_err(a, b, floor):
 
 def assert_tall_parity(beta, niter, trace, problem, tol=1e-4, factor=5.0, band=8.0, label=""):
     """problem: dict(x, y, lam, nlambda, lmin_ratio, standardize, intercept, opts, alpha) -- the oracle's arguments."""
+    assert_trace_self_consistent(trace, accelerated=True, label=label)
     ref, forced, ndec = oracle_following(trace, band=band, **problem)          # R1 (raises FollowMismatch)
     t = np.asarray(trace)
     nrec = len(t) - (1 if len(t) and t[0, 8] == -1 else 0)
@@ -196,6 +219,7 @@ def assert_dense_followed(kind, fit_beta, fit_niter, trace, x, y, opts, intercep
     decision trace through rounding-level near-ties of the stopping / restart tests and of the rho adaptation only;
     iteration counts identical, beta within `tol`."""
     from oracle import entry
+    assert_trace_self_consistent(trace, accelerated=True, label=label)
     t = np.asarray(trace, dtype=np.float64)
     if len(t) and t[0, 8] == -1:
         t = t[1:]
