@@ -246,7 +246,11 @@ __device__ __forceinline__ void tall_update_elem(const TallParams& q, const Tall
 // Element-wise part of one iteration.  `c` = the control block published by this iteration's decision.
 // MODE 0: x-update results as gemv_t partial rows; 1: as the symmetric mat-vec's partial arrays; 2: row-sharded over the
 // PEER exchange -- wait for the K flags, then sum the K ranks' shares straight out of the exchange slots.
-enum { TAIL_GEMV = 0, TAIL_SYMV = 1, TAIL_PEER = 2 };
+enum { TAIL_GEMV = 0, TAIL_SYMV = 1, TAIL_PEER = 2, TAIL_PEER1 = 3 };
+// TAIL_PEER1: producer and consumer of the exchange in ONE launch -- every workgroup sums its elements of this rank's share,
+// writes them into every rank's slot and counts itself in (the last one raises the flags), then waits for the K flags like
+// TAIL_PEER.  A workgroup waits for flags that need ALL workgroups of this launch (on every rank) to have published, so
+// the launch must be resident as a whole; the host only chooses it when the grid is at most half of what the device holds.
 template <int MODE>
 __global__ void __launch_bounds__(kTailThreads)
 tall_tail_kernel(TallParams q, int par, PeerExchange ex) {
@@ -267,9 +271,19 @@ tall_tail_kernel(TallParams q, int par, PeerExchange ex) {
     float a = 0.f, b = 0.f;
     if (MODE == TAIL_SYMV) {
         symv_sum_partials<kTailLanes>(q.dot0, q.dot1, q.axp0, q.axp1, q.ldo, q.nrb, q.ncb, i, sub, valid, a, b);
-    } else if (MODE == TAIL_PEER) {
-        // the producing launch pushed unless the solve was already finished (replicated flag: all ranks agree)
-        const bool ok = q.ctl[par].done ? false : peer_wait_relaxed(ex);
+    } else if (MODE == TAIL_PEER || MODE == TAIL_PEER1) {
+        const bool live = !q.ctl[par].done;                          // finished in an earlier launch: nothing pushed, nothing to wait for (replicated flag: all ranks agree)
+        if (MODE == TAIL_PEER1 && live) {
+            float sa, sb;
+            symv_sum_partials<kTailLanes>(q.dot0, q.dot1, q.axp0, q.axp1, q.ldo, q.nrb, q.ncb, i, sub, valid, sa, sb);
+            if (valid) {
+                for (int dst = sub; dst < ex.nranks; dst += kTailLanes)
+                    peer_store_f32x2(reinterpret_cast<float*>(peer_dst_slot(ex, dst)) + 2 * (size_t)i, sa, sb);
+            }
+            peer_publish(ex, gridDim.x);
+        }
+        // the producing launch (or the block above) pushed unless the solve was already finished
+        const bool ok = live ? peer_wait_relaxed(ex) : false;
         if (ok && valid) {
             for (int r = sub; r < ex.nranks; r += kTailLanes) {          // rank order fixed by the lane pattern: identical on every rank
                 const float2 v = peer_load_f32x2(reinterpret_cast<const float*>(peer_src_slot(ex, r)) + 2 * (size_t)i);    // (a_i, b_i) interleaved
@@ -468,6 +482,7 @@ struct TallPlan final : LassoPlan {
     bool use_sym = false;
     bool shard = false;                                 // x-update spread over the ranks of the attached communicator
     bool peer_fused = false;                            // ... with the exchange done by the solver's own kernels (PEER backend)
+    bool peer_one = false;                              // ... producer and consumer in one launch (tall_tail_kernel<TAIL_PEER1>)
     CommInfo ci;
     DevBuf<float> ab;                                   // [2][ldp] this rank's share of (a, b), all-reduced in place
     bool fused = false, fused_pre = false;              // one launch per iteration (tall_fused_kernel); tiles prefetch before they wait
@@ -588,6 +603,14 @@ struct TallPlan final : LassoPlan {
         // ADMM_HIP_PEER_FUSED=0: go through the generic all-reduce of the exchange layer also on the PEER backend
         peer_fused = shard && ci.backend == COMM_PEER;
         if (const char* e = std::getenv("ADMM_HIP_PEER_FUSED")) { if (std::string(e) == "0") peer_fused = false; }
+        if (peer_fused) {
+            // one launch only when the whole grid is resident with room to spare (its workgroups wait for one another)
+            int occ = 0;
+            ADMM_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(tall_tail_kernel<TAIL_PEER1>), kTailThreads, 0));
+            const int nwg_tail = (p + kTailElems - 1) / kTailElems;
+            peer_one = (long long)nwg_tail * 2 <= (long long)occ * device_info().num_cu;
+            if (const char* e = std::getenv("ADMM_HIP_PEER_FUSED")) { if (std::string(e) == "2") peer_one = false; }
+        }
         // single-launch iteration (single GPU, symmetric x-update): opt-in with ADMM_HIP_TALL_FUSED=1 (=2: the tiles also
         // request their first matrix columns before they wait).  Measured on C2 (scripts/fused_check.py, same box, all
         // bit-identical): two launches 42.1 us per iteration, one launch 44.5 us, with the prefetch 47.1 us -- the kernel
@@ -706,8 +729,12 @@ struct TallPlan final : LassoPlan {
                     // none of them the exchange layer's
                     sy.launch(M.get(), ldp, u.get(), w.get(), &ctl.get()[par].done, st, dec, e0, e1);
                     const PeerExchange ex = comm_peer_begin((size_t)2 * ldp * sizeof(float));
-                    hipLaunchKernelGGL(tall_shard_push_kernel, dim3(nwg), dim3(kTailThreads), 0, st, q, ex, ldp, &ctl.get()[par].done);
-                    hipLaunchKernelGGL(tall_tail_kernel<TAIL_PEER>, dim3(nwg), dim3(kTailThreads), 0, st, q, par, ex);
+                    if (peer_one) {
+                        hipLaunchKernelGGL(tall_tail_kernel<TAIL_PEER1>, dim3(nwg), dim3(kTailThreads), 0, st, q, par, ex);
+                    } else {
+                        hipLaunchKernelGGL(tall_shard_push_kernel, dim3(nwg), dim3(kTailThreads), 0, st, q, ex, ldp, &ctl.get()[par].done);
+                        hipLaunchKernelGGL(tall_tail_kernel<TAIL_PEER>, dim3(nwg), dim3(kTailThreads), 0, st, q, par, ex);
+                    }
                 } else if (shard) {
                     // this rank's tiles -> its share of (a, b) -> ONE all-reduce of 2 ldp floats -> the (replicated) tail
                     sy.launch(M.get(), ldp, u.get(), w.get(), &ctl.get()[par].done, st, dec, e0, e1);
