@@ -681,7 +681,11 @@ wide_ax_push_kernel(WideParams q, int par, PeerExchange ex) {
 }
 
 // z/y update: Ax = sum of partials; z_new = -(y_data + y + rho Ax) / (1 + rho); r = Ax + z_new; y += rho r; norms.
-template <bool PEER = false>      // PEER: A x arrives in the K exchange slots (wide_ax_push_kernel of every rank): wait for the flags, sum in lane order
+// PEER 1: A x arrives in the K exchange slots (wide_ax_push_kernel of every rank): wait for the flags, sum in lane order.
+// PEER 2: producer and consumer in ONE launch -- this launch sums the rank's own partials anyway, so it writes the share into
+// every rank's slot itself, counts itself in, and then waits (its workgroups wait for one another: the host chooses it only
+// when the grid is resident with room to spare, which for n / 32 workgroups it practically always is).
+template <int PEER = 0>
 __global__ void __launch_bounds__(kWideThreads)
 wide_tail_kernel(WideParams q, int par, PeerExchange ex) {
     __shared__ double scratch[5 * (kWideThreads / 64)];
@@ -694,6 +698,16 @@ wide_tail_kernel(WideParams q, int par, PeerExchange ex) {
     WIDE_SUM_AXPART(ax)
     if (!PEER && q.ax_given != nullptr) ax = valid ? q.ax_given[i] : 0.f;      // column-sharded mode: already summed over partials and ranks
     if (c.done) return;
+    if (PEER == 2) {
+        float mine = valid ? ax : 0.f;
+        if (!q.fused && c.type == W_ZERO) mine = 0.f;
+        const float next = __shfl_down(mine, kWtLanes, 64);               // the element owned by the next group of 8 lanes
+        if (((threadIdx.x / kWtLanes) & 1) == 0 && i < q.ldn) {
+            for (int dst = sub; dst < ex.nranks; dst += kWtLanes)
+                peer_store_f32x2(reinterpret_cast<float*>(peer_dst_slot(ex, dst)) + i, mine, next);
+        }
+        peer_publish(ex, gridDim.x);
+    }
     if (PEER) {
         const bool ok = peer_wait_relaxed(ex);
         float a = 0.f;
@@ -762,6 +776,7 @@ struct WidePlan final : LassoPlan {
     bool t_global = false;               // n too large for the LDS: t through global memory (wide_t_kernel)
     bool cshard = false;                 // columns spread over the ranks: per iteration one all-reduce of Ax (n floats)
     bool peer_fused = false;             // ... done by the solver's own kernels over the PEER exchange (no launches of the exchange layer)
+    bool peer_one = false;               // ... producer and consumer in one launch (wide_tail_kernel<2>)
     CommInfo ci;
     long long p_total = 0, col_offset = 0;
     DevBuf<float> axl;                   // [ldn] this rank's share of Ax, all-reduced in place
@@ -855,6 +870,12 @@ struct WidePlan final : LassoPlan {
         S.rho = rho0;
 
         nwg_tail = (n + kWtElems - 1) / kWtElems;                    // 32 elements per workgroup (8 lanes each)
+        if (peer_fused) {
+            int occ = 0;
+            ADMM_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(wide_tail_kernel<2>), kWideThreads, 0));
+            peer_one = (long long)nwg_tail * 2 <= (long long)occ * device_info().num_cu;
+            if (const char* e = std::getenv("ADMM_HIP_PEER_FUSED")) { if (std::string(e) == "2") peer_one = false; }
+        }
         x.alloc(ldp); x.zero(st);
         for (DevBuf<float>* b : {&Ax, &z, &y}) { b->alloc(std::max<long long>(ldn, 4096)); b->zero(st); }   // the fused x-update reads up to 16 x 256 entries unconditionally
         // ADMM_HIP_WIDE_FUSE=0: always three launches per iteration
@@ -938,15 +959,19 @@ struct WidePlan final : LassoPlan {
             }
             if (cshard && peer_fused) {                                // the only exchange, produced and consumed by the solver's own kernels
                 const PeerExchange ex = comm_peer_begin((size_t)ldn * sizeof(float));
+                if (peer_one) {
+                    hipLaunchKernelGGL(wide_tail_kernel<2>, dim3(nwg_tail), dim3(kWideThreads), 0, st, q, par, ex);
+                    return;
+                }
                 hipLaunchKernelGGL(wide_ax_push_kernel, dim3((unsigned)((ldn + kWtElems - 1) / kWtElems)), dim3(kWideThreads), 0, st, q, par, ex);
-                hipLaunchKernelGGL(wide_tail_kernel<true>, dim3(nwg_tail), dim3(kWideThreads), 0, st, q, par, ex);
+                hipLaunchKernelGGL(wide_tail_kernel<1>, dim3(nwg_tail), dim3(kWideThreads), 0, st, q, par, ex);
                 return;
             }
             if (cshard) {                                              // the only exchange: A x summed over the ranks' column blocks
                 hipLaunchKernelGGL(wide_ax_local_kernel, dim3((unsigned)((ldn + kWtElems - 1) / kWtElems)), dim3(kWideThreads), 0, st, q, par, axl.get());
                 allreduce_sum_f32(axl.get(), (size_t)n, st);
             }
-            hipLaunchKernelGGL(wide_tail_kernel<false>, dim3(nwg_tail), dim3(kWideThreads), 0, st, q, par, PeerExchange{});
+            hipLaunchKernelGGL(wide_tail_kernel<0>, dim3(nwg_tail), dim3(kWideThreads), 0, st, q, par, PeerExchange{});
         }, cshard ? nullptr : hflag.p);       // column-sharded: every rank must enqueue the same number of exchanges -> stream-ordered sampling of `done`
         S.t_loop = lt.wall_s; S.loop_ms_events = lt.events_ms; S.xupdate_launches = lt.launched;
 #ifdef ADMM_HIP_PROBE
