@@ -17,11 +17,41 @@ only = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 and not med
 bad = 0
 if medium:
     from fuzz_cases import medium_cases
+    import numpy as np
+    from admm_amd import admm_lasso
+    from oracle import entry
+    from helpers import assert_followed_parity, traced_fit
+
+    def medium_other(cs):                                   # wide / consensus with random maxit / eps / rho
+        x, y, icpt, stdz = cs["x"], cs["y"], cs["icpt"], cs["stdz"]
+        opts = dict(maxit=cs["maxit"], eps_abs=cs["eps"], eps_rel=cs["eps"], rho=cs["rho"])
+        lam = None
+        if cs["user_lam"]:
+            ref0 = entry.admm_lasso(x, y, None, 3, 0.1, stdz, icpt, dict(entry.LASSO_OPTS, maxit=1), {})
+            lam = np.sort(ref0["lambda"][0] * cs["ulam"])[::-1]
+        lmr = 0.01 if cs["n"] < cs["p"] else 1e-4
+        m = admm_lasso(x, y, icpt, stdz).penalty(lam, nlambda=cs["nl"], lambda_min_ratio=lmr)
+        m.opts(cs["maxit"], cs["eps"], cs["eps"], None if cs["rho"] <= 0 else cs["rho"])
+        prob = dict(x=x, y=y, lam=lam, nlambda=cs["nl"], lmin_ratio=lmr, standardize=stdz, intercept=icpt, opts=opts, alpha=None)
+        if cs["kind"] == "par":
+            m.nthread = cs["K"]
+            prob["nthread"] = cs["K"]
+        fit, trace = traced_fit(m, capacity=cs["nl"] * (cs["maxit"] + 2) + 8)
+        label = f"medium {cs['c']} {cs['kind']} n={cs['n']} p={cs['p']} K={cs['K']} maxit={cs['maxit']} eps={cs['eps']:g} rho={cs['rho']:g}"
+        return assert_followed_parity(fit.beta_dense, fit.niter, trace, prob, 1e-4, label=label)
+
     for cs in medium_cases(n, seed):
-        if cs["kind"] not in ("tall", "enet_tall"):
-            continue
         try:
-            T._medium_tall(cs)
+            if cs["kind"] in ("tall", "enet_tall"):
+                if len(sys.argv) > 4 and sys.argv[4] == "other":
+                    continue
+                T._medium_tall(cs)
+            else:
+                if not (len(sys.argv) > 4 and sys.argv[4] == "other"):
+                    continue
+                if cs["kind"] == "wide" and cs["maxit"] > 300:
+                    cs["maxit"] = 300                       # the NumPy oracle's wide loop is slow
+                medium_other(cs)
         except Exception as e:                              # noqa: BLE001
             bad += 1
             print("FAIL medium case", cs["c"], cs["kind"], "n=%d p=%d" % (cs["n"], cs["p"]), type(e).__name__, str(e)[:300], flush=True)
