@@ -20,11 +20,12 @@
 //    lambda schedule (init_warm resets the counter, keeps x, z, y, rho) run on the device, evaluated
 //    identically by every workgroup of the x-update launch; the host enqueues batches and polls a
 //    sticky done word.
-//  * n <= 4096 (a column fits the registers of one wave): the x-update keeps the column it has just
+//  * n <= 8192 (a column fits the registers of one wave: 4 / 8 / 16 / 24 / 32 float4 per lane): the x-update keeps the column it has just
 //    dotted with t and adds x_j X_j to its own partial of Ax right away -- TWO launches per iteration
 //    (x-update + gather, z/y + norms), X_j read once.  On active-set iterations only the first 128
 //    workgroups take part, so the z/y kernel sums 128 partials (all of them on regular iterations).
-//    Larger n: three launches (x-update, gather mat-vec over row tiles of 4096, z/y + norms).
+//    Larger n: three launches (x-update, gather mat-vec over row tiles of 4096, z/y + norms).  (Measured at n = 5000 .. 8000:
+//    the two-launch form takes 32-40 us per iteration, the three-launch form 44-70 us.)
 #include "prep.h"
 #include "gemv_kernels.h"
 #include "solvers.h"
@@ -87,7 +88,7 @@ constexpr int kAxRT = 16;                 // float4 row accumulators per lane ->
 
 struct WideParams {
     int n, p, maxit, nlam, enet, nwg_tail;
-    int fused, nwg_x;                     // fused: the x-update launch also writes the Ax partials (n <= 4096)
+    int fused, nwg_x;                     // fused: the x-update launch also writes the Ax partials (n <= 8192)
     int x_nt;                             // regular steps stream X with non-temporal loads (X larger than the Infinity Cache keeps, gemv_plan.h)
     long long ldx;
     const float* X; const float* Y;
@@ -877,9 +878,9 @@ struct WidePlan final : LassoPlan {
             if (const char* e = std::getenv("ADMM_HIP_PEER_FUSED")) { if (std::string(e) == "2") peer_one = false; }
         }
         x.alloc(ldp); x.zero(st);
-        for (DevBuf<float>* b : {&Ax, &z, &y}) { b->alloc(std::max<long long>(ldn, 4096)); b->zero(st); }   // the fused x-update reads up to 16 x 256 entries unconditionally
+        for (DevBuf<float>* b : {&Ax, &z, &y}) { b->alloc(std::max<long long>(ldn, 8192)); b->zero(st); }   // the fused x-update reads up to 32 x 256 entries unconditionally
         // ADMM_HIP_WIDE_FUSE=0: always three launches per iteration
-        fuse_rt = n <= 1024 ? 4 : (n <= 2048 ? 8 : (n <= 4096 ? 16 : 0));
+        fuse_rt = n <= 1024 ? 4 : (n <= 2048 ? 8 : (n <= 4096 ? 16 : (n <= 6144 ? 24 : (n <= 8192 ? 32 : 0))));
         if (const char* e = std::getenv("ADMM_HIP_WIDE_FUSE")) if (std::string(e) == "0") fuse_rt = 0;
         lds_x = std::max((size_t)((n + 255) / 256 * 256) * 2 * sizeof(float), (size_t)std::min(std::max(fuse_rt, 4), 8) * kWideThreads * sizeof(float4));
         // The x-update stages t and t / gamma (2 n floats) in dynamic LDS: up to 64 KB by default, up to the device's
@@ -903,6 +904,8 @@ struct WidePlan final : LassoPlan {
             const void* fn = fuse_rt == 4 ? reinterpret_cast<const void*>(wide_x_kernel<4>)
                            : fuse_rt == 8 ? reinterpret_cast<const void*>(wide_x_kernel<8>)
                            : fuse_rt == 16 ? reinterpret_cast<const void*>(wide_x_kernel<16>)
+                           : fuse_rt == 24 ? reinterpret_cast<const void*>(wide_x_kernel<24>)
+                           : fuse_rt == 32 ? reinterpret_cast<const void*>(wide_x_kernel<32>)
                            : t_global ? reinterpret_cast<const void*>(wide_x_kernel<0, true>)
                                       : reinterpret_cast<const void*>(wide_x_kernel<0, false>);
             ADMM_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&wgx, fn, kWideThreads, lds_x));
@@ -948,6 +951,8 @@ struct WidePlan final : LassoPlan {
                 case 4: hipLaunchKernelGGL(wide_x_kernel<4>, dim3(nwg_x), dim3(kWideThreads), lds_x, st, q, par); break;
                 case 8: hipLaunchKernelGGL(wide_x_kernel<8>, dim3(nwg_x), dim3(kWideThreads), lds_x, st, q, par); break;
                 case 16: hipLaunchKernelGGL(wide_x_kernel<16>, dim3(nwg_x), dim3(kWideThreads), lds_x, st, q, par); break;
+                case 24: hipLaunchKernelGGL(wide_x_kernel<24>, dim3(nwg_x), dim3(kWideThreads), lds_x, st, q, par); break;
+                case 32: hipLaunchKernelGGL(wide_x_kernel<32>, dim3(nwg_x), dim3(kWideThreads), lds_x, st, q, par); break;
                 default:
                     if (t_global) {
                         hipLaunchKernelGGL(wide_t_kernel, dim3((unsigned)((ldn + kWideThreads - 1) / kWideThreads)), dim3(kWideThreads), 0, st, q, par);

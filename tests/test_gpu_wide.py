@@ -107,3 +107,21 @@ def test_wide_large_n_lds_modes():
     assert list(a.niter) == list(ref["niter"])
     for j in range(2):
         assert relerr(a.beta_dense[:, j], ref["beta"][:, j]) < TOL, j
+
+
+@pytest.mark.parametrize("n,p", [(5000, 5600), (7600, 8000)])
+def test_wide_fused_x_update_up_to_8192_rows(n, p):
+    """n in (4096, 8192]: the column just dotted with t still fits the registers of one wave (24 / 32 float4 per lane), so the
+    x-update also gathers A x (two launches per iteration instead of three).  Same algorithm: iteration counts and
+    coefficients of the three-launch path (different order of the partial sums: equal up to rounding) and of the oracle."""
+    from oracle import entry
+    x, y = synth_lasso(n, p, 20, seed=n)
+    a = _fit_env(x, y, 3, 30)
+    b = _fit_env(x, y, 3, 30, ADMM_HIP_WIDE_FUSE="0")
+    assert a.stats["xupdate_launches"] > 0
+    assert list(a.niter) == list(b.niter)
+    ref = entry.admm_lasso(x, y, None, 3, 0.01, True, True, dict(entry.LASSO_OPTS, maxit=30))
+    assert list(a.niter) == list(ref["niter"])
+    for j in range(3):
+        assert relerr(a.beta_dense[:, j], b.beta_dense[:, j]) < 1e-5, j
+        assert relerr(a.beta_dense[:, j], ref["beta"][:, j]) < TOL, j
