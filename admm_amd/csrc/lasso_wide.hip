@@ -269,8 +269,10 @@ wide_x_kernel(WideParams q, int par) {
     // Speculative request of this wave's first non-zero column: almost every step is an active-set step, and what it reads
     // first does not depend on the decision -- so the column's round trip overlaps the decision and the staging of t
     // (a regular / zero / final step simply drops it).
-    constexpr bool kPair = RT > 0 && RT <= 8;                          // regular steps take the wave's columns two at a time
-    constexpr bool kSpec = RT > 0 && RT <= 8;                          // RT = 16: a second column in registers would halve the occupancy
+    // RT <= 8 runs two waves per SIMD and both fit; RT >= 16 runs one wave per SIMD anyway (512 registers to spend), RT = 32
+    // has no room left for a second column
+    constexpr bool kPair = RT > 0 && RT <= 16;                         // regular steps take the wave's columns two at a time
+    constexpr bool kSpec = RT > 0 && RT <= 24;                         // the first non-zero column is requested before the decision
     float4 cv0[kSpec ? NRT : 1];
     long long pj = -1;
     if (RT > 0 && always) {
