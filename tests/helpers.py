@@ -53,6 +53,29 @@ def traced_fit(model, capacity=1 << 18):
     return fit, trace
 
 
+def assert_rho_self_consistent(trace, first_iter, label=""):
+    """The rho adaptation (FADMMBase.h:109-133 == ADMMBase.h:85-109; from iteration `first_iter` on: i > 3 for ADMMBase,
+    i > 5 for FADMMBase) of every non-final record must be the rule applied to the residuals recorded with it: the recorded
+    multiplier rho_out / rho_in equals the rule's."""
+    from oracle.solvers import _rho_rule
+    t = np.asarray(trace, dtype=np.float64)
+    if len(t) and t[0, 8] == -1:
+        t = t[1:]
+    bad = []
+    for k, r in enumerate(t):
+        if r[8] == 0 or r[9] <= 0:                           # converged: no adaptation; r[9] = rho before, r[10] = rho after
+            continue
+        class _S:
+            pass
+        q = _S()
+        q.rho, q.eps_primal, q.eps_dual, q.resid_primal, q.resid_dual = 1.0, r[2], r[3], r[4], r[5]
+        if int(r[1]) > first_iter - 1:
+            _rho_rule(q)
+        if abs(q.rho - r[10] / r[9]) > 1e-12 * q.rho:
+            bad.append((k, q.rho, r[10] / r[9]))
+    assert not bad, (label, "rho adaptation inconsistent with the recorded residuals", bad[:5])
+
+
 def assert_trace_self_consistent(trace, accelerated, label=""):
     """Every recorded decision must be the one the reference's rule gives for the values recorded WITH it (the GPU's own
     residuals and thresholds): converged iff r_p < eps_p and r_d < eps_d (FADMMBase.h:213-217, ADMMBase.h:196-197,
@@ -123,6 +146,8 @@ def assert_followed_parity(beta, niter, trace, problem, tol=1e-4, band=8.0, labe
     rounding-level near-ties of the stopping test and of the rho adaptation only; iteration counts identical for every
     lambda and every beta column within `tol`."""
     assert_trace_self_consistent(trace, accelerated=False, label=label)
+    if problem.get("nthread") is None:
+        assert_rho_self_consistent(trace, first_iter=4, label=label)               # ADMMBase::solve: update_rho from i > 3
     ref, forced, ndec = oracle_following(trace, band=band, **problem)
     t = np.asarray(trace)
     nrec = len(t) - (1 if len(t) and t[0, 8] == -1 else 0)
@@ -220,6 +245,7 @@ def assert_dense_followed(kind, fit_beta, fit_niter, trace, x, y, opts, intercep
     iteration counts identical, beta within `tol`."""
     from oracle import entry
     assert_trace_self_consistent(trace, accelerated=True, label=label)
+    assert_rho_self_consistent(trace, first_iter=6, label=label)                   # FADMMBase::solve: update_rho from i > 5
     t = np.asarray(trace, dtype=np.float64)
     if len(t) and t[0, 8] == -1:
         t = t[1:]
