@@ -107,3 +107,20 @@ def test_multi_response_equals_separate_fits_tall_and_wide():
             assert np.array_equal(one.lambda_, f.lambda_), (kind, j)
             assert np.array_equal(one.niter, f.niter), (kind, j, one.niter, f.niter)
             assert np.array_equal(one.beta_dense, f.beta_dense), (kind, j)
+
+
+def test_cv_and_multi_edge_cases():
+    """Folds whose training set flips the dispatch (full data tall, folds wide: each fold still equals the direct call on its
+    rows), a single response through the multi-response entry, and leave-one-out on a tiny problem."""
+    import admm_amd
+    x, y = _data(62, 60, 4, 21)                       # n = p + 2: tall as a whole, wide once a fold is held out
+    nfolds = 3
+    cv = admm_amd.admm_lasso(x, y).penalty(nlambda=6).cv(nfolds=nfolds, keep_fold_beta=True)
+    cv._auto = True
+    _check(cv, x, y, np.arange(62) % nfolds, nfolds, admm_amd.admm_lasso)
+    one = admm_amd.admm_lasso(x, y).penalty(nlambda=6).fit_responses(y.reshape(-1, 1))
+    ref = admm_amd.admm_lasso(x, y).penalty(nlambda=6).fit()
+    assert len(one) == 1 and np.array_equal(one[0].beta_dense, ref.beta_dense) and np.array_equal(one[0].niter, ref.niter)
+    xs, ys = _data(12, 3, 2, 22)
+    loo = admm_amd.admm_lasso(xs, ys).penalty(nlambda=4).cv(nfolds=12)
+    assert loo.fold_mse.shape == (12, 4) and np.all(np.isfinite(loo.cvm)) and np.all(loo.cvse >= 0)
