@@ -29,6 +29,9 @@
 //    tiles reversed on odd launches; a tile keeps its XCD): no change at all (24.10 vs 24.10 k it/s) -- nothing of the
 //    matrix survives a kernel boundary in the XCD L2s.  In-kernel timestamps (scripts/tall_probe.py) put the streaming
 //    phase itself at 200 MB / 31 us = 6.45 TB/s, the Infinity Cache ceiling; the rest of the 34.5 us is ramp and drain;
+//  * 5 or 6 workgroups per CU (launch bounds) so that all 1600 tiles of p = 10^4 are resident at once and end together (the
+//    probe shows ~2.6 us between the end of the last tile in the list and the true last end): 96 / 80 registers spill the
+//    column chunk -- 47 / 113 us per launch;
 //  * two or three tiles per workgroup (half / a third of the workgroups, same tile code): 38.1 / 38.3 instead of 35.6 us
 //    per launch -- the second round of small work units is what balances the end of the launch;
 //  * fusing the consumer into this launch ("last tile of a block finalises it", arrival counters): correct,
