@@ -342,3 +342,52 @@ def test_two_rank_column_sharded_wide_protocol_matches_serial_oracle(tmp_path):
     assert np.abs(r0["niter"][:4].astype(int) - ref["niter"][:4].astype(int)).max() <= 2, (r0["niter"], ref["niter"])
     for j in range(8):
         assert relerr(r0["beta"][:, j], ref["beta"][:, j]) < (1e-4 if j < 4 else 5e-3), j
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Replicas with a final exchange (admm_hip_lasso_cv, admm_hip_lasso_multi): world_size-2 model of the dealing rule of
+# api.hip -- unit u (fold / response) runs on rank u mod world, every rank starts from zeroed tables, ONE sum all-reduce at
+# the end -- with the oracle as the fit.  Every rank must end with the tables a single process computes.
+def _replica_rank_main(rank, world, port, x, y, nfolds, lam, out_path):
+    from oracle import entry
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n, p = x.shape
+    nl = len(lam)
+    fid = np.arange(n) % nfolds                                 # fold_id NULL: i mod nfolds
+    mse = np.zeros((nfolds, nl))
+    nit = np.zeros((nfolds, nl))
+    for f in range(nfolds):
+        if f % world != rank:
+            continue
+        tr, te = fid != f, fid == f
+        fit = entry.admm_lasso(x[tr], y[tr], lam, nl, 1e-4, True, True, entry.LASSO_OPTS)
+        b = fit["beta"].astype(np.float64)
+        pred = b[0][None, :] + x[te] @ b[1:]
+        mse[f] = ((y[te][:, None] - pred) ** 2).mean(axis=0)
+        nit[f] = fit["niter"]
+    both = _allreduce(np.concatenate([mse.ravel(), nit.ravel()]))
+    np.savez(out_path + f".{rank}.npz", mse=both[:nfolds * nl].reshape(nfolds, nl), nit=both[nfolds * nl:].reshape(nfolds, nl))
+    dist.destroy_process_group()
+
+
+def test_two_rank_replica_dealing_and_final_exchange(tmp_path):
+    from oracle import entry
+    x, y = synth_lasso(240, 12, 4, seed=71)
+    lam = [0.4, 0.1, 0.02]
+    nfolds = 5
+    out = str(tmp_path / "cv")
+    mp.spawn(_replica_rank_main, args=(2, _free_port(), x, y, nfolds, lam, out), nprocs=2, join=True)
+    fid = np.arange(240) % nfolds
+    ref_mse = np.zeros((nfolds, 3))
+    ref_nit = np.zeros((nfolds, 3))
+    for f in range(nfolds):
+        tr, te = fid != f, fid == f
+        fit = entry.admm_lasso(x[tr], y[tr], lam, 3, 1e-4, True, True, entry.LASSO_OPTS)
+        b = fit["beta"].astype(np.float64)
+        ref_mse[f] = ((y[te][:, None] - (b[0][None, :] + x[te] @ b[1:])) ** 2).mean(axis=0)
+        ref_nit[f] = fit["niter"]
+    for r in range(2):
+        got = np.load(out + f".{r}.npz")
+        assert np.array_equal(got["mse"], ref_mse) and np.array_equal(got["nit"], ref_nit)
