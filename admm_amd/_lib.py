@@ -137,7 +137,7 @@ def load():
     lib.admm_hip_comm_peer_prepare.restype = ctypes.c_int
     lib.admm_hip_comm_init_peer.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     lib.admm_hip_comm_init_peer.restype = ctypes.c_int
-    lib.admm_hip_comm_init_shm.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_char_p]
+    lib.admm_hip_comm_init_shm.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_ulonglong]
     lib.admm_hip_comm_init_shm.restype = ctypes.c_int
     lib.admm_hip_comm_test_allreduce.argtypes = [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int]
     lib.admm_hip_comm_test_allreduce.restype = ctypes.c_int

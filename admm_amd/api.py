@@ -331,11 +331,10 @@ class ADMM_BP:
     def parallel(self, nthread=2):
         """ADMM_BP$parallel (R/10_admm_bp.R:65-76) only stores nthread; $fit() with nthread > 1 then calls the C symbol
         `admm_parbp`, which the reference never builds (it lives in src/TODO/ParBP.cppp) -- the R call fails.  Mirrored:
-        the setter validates like R does, fit() refuses like R's missing symbol."""
-        nt = max(1, int(nthread))
-        if nt >= self.p / 5:
-            _stop("nthread cannot exceed ncol(x)/5")
-        self.nthread = nt
+        the setter clamps to >= 1 and stores, exactly like R (no ncol(x)/5 check here: only ADMM_Lasso$parallel has one,
+        R/30_admm_lasso.R:119-124); fit() refuses like R's missing symbol.  ADMM_LAD inherits this method as in R
+        (`contains = "ADMM_BP"`, R/20_admm_lad.R:4) and, as in R, its fit() ignores nthread."""
+        self.nthread = max(1, int(nthread))
         return self
 
     def opts(self, maxit=10000, eps_abs=1e-4, eps_rel=1e-4, rho=1.0):
@@ -425,6 +424,8 @@ class LassoPlan:
     loop without the one-time Gram/factorisation."""
 
     def __init__(self, model):
+        if isinstance(model, ADMM_Dantzig):
+            _stop(ADMM_Dantzig._missing)
         lib = _lib.load()
         self._lib = lib
         self.model = model
@@ -501,8 +502,18 @@ class ADMM_Dantzig(ADMM_Lasso):
     (it is ADMM_Lasso's), fit() fails like the reference does.  No solver is invented for it."""
     _name = "ADMM Dantzig Selector model"
 
+    _missing = 'C symbol name "admm_dantzig" not in DLL for package "ADMM"'    # R/50_admm_dantzig.R:38-46: the reference's own failure
+
     def fit(self):
-        _stop('C symbol name "admm_dantzig" not in DLL for package "ADMM"')     # R/50_admm_dantzig.R:38-46: the reference's own failure
+        _stop(self._missing)
+
+    # the extensions of this build that ride on ADMM_Lasso (cross-validation, several responses, prepared problems) must
+    # not run a plain Lasso under a Dantzig label
+    def cv(self, *a, **kw):
+        _stop(self._missing)
+
+    def fit_responses(self, *a, **kw):
+        _stop(self._missing)
 
 
 def admm_dantzig(x, y, intercept=True, standardize=True, **kw):

@@ -13,7 +13,7 @@ void comm_init(int nranks, int rank, const void* idbytes);
 void comm_finalize();
 void comm_peer_prepare(int nranks, void* handle_out);
 void comm_init_peer(int nranks, int rank, const void* handles);
-void comm_init_shm(int nranks, int rank, const char* name);
+void comm_init_shm(int nranks, int rank, const char* name, unsigned long long token);
 void cv_gather(const double* x, long long ldx, const double* y, const int* d_idx, int m, int p, double* xo, double* yo, hipStream_t st);
 std::vector<double> cv_score(const double* xt, const double* yt, int m, int p, const float* beta_host, int nlam, hipStream_t st);
 
@@ -617,8 +617,8 @@ int admm_hip_comm_peer_prepare(int nranks, void* handle_out) {
 int admm_hip_comm_init_peer(int nranks, int rank, const void* handles) {
     return guarded([&] { ADMM_REQUIRE(handles != nullptr, "handles must not be NULL"); require_device(); comm_init_peer(nranks, rank, handles); });
 }
-int admm_hip_comm_init_shm(int nranks, int rank, const char* name) {
-    return guarded([&] { require_device(); comm_init_shm(nranks, rank, name); });
+int admm_hip_comm_init_shm(int nranks, int rank, const char* name, unsigned long long token) {
+    return guarded([&] { require_device(); comm_init_shm(nranks, rank, name, token); });
 }
 int admm_hip_comm_test_allreduce(float* fbuf, long long nf, double* dbuf, long long nd, int mem) {
     return guarded([&] {

@@ -25,6 +25,10 @@ void allreduce_sum_f32(float* buf, size_t n, hipStream_t st);
 void allreduce_sum_f64(double* buf, size_t n, hipStream_t st);
 // Two buffers in one exchange (the consensus payload: p floats + the norm doubles).
 void allreduce_sum_f32_f64(float* fbuf, size_t nf, double* dbuf, size_t nd, hipStream_t st);
+// While one of these is alive the exchanges this process enqueues take the short LOCK-STEP bound on their waits
+// (ADMM_HIP_COMM_TIMEOUT_S, 20 s): the per-iteration exchanges of a solve.  Everything else -- setup reductions, the join
+// of the replica modes -- takes the PATIENT bound (ADMM_HIP_COMM_PATIENT_TIMEOUT_S, one hour), like RCCL would wait.
+struct CommLockstep { CommLockstep(); ~CommLockstep(); CommLockstep(const CommLockstep&) = delete; CommLockstep& operator=(const CommLockstep&) = delete; };
 // Throws ADMM_ERR_COMM if an exchange of the SHM / PEER backends timed out or a peer reported failure (checked by the
 // loop drivers at every poll; the kernels of a failed exchange return immediately instead of spinning).
 void comm_check();

@@ -12,6 +12,7 @@
 #include "peer_device.h"
 #include <rccl/rccl.h>
 #include <atomic>
+#include <cerrno>
 #include <mutex>
 #include <fcntl.h>
 #include <sched.h>
@@ -24,7 +25,22 @@ namespace {
 
 constexpr int kMaxRanks = 64;
 constexpr size_t kDefaultSlotBytes = 4u << 20;        // payload capacity of one exchange (longer messages are chunked)
-constexpr double kWaitSeconds = 20.0;                 // bound of every wait (host spin and device spin): never hang the GPU
+// Every wait (host spin and device spin) is bounded: a missing rank yields ADMM_ERR_COMM, never a hung GPU.  Two bounds:
+//   lock-step  the per-iteration exchanges of a solve (all ranks enqueue the same iterations at the same pace): a rank that
+//              is 20 s late is dead.  ADMM_HIP_COMM_TIMEOUT_S.
+//   patient    everything else -- setup reductions (ranks reach them after uploads / Grams of different sizes) and the
+//              one join of the replica modes (cross-validation folds, several responses: 10 folds on 4 ranks is 3/3/2/2 whole
+//              fits of imbalance BY DESIGN): RCCL would wait for ever there, so SHM / PEER wait long.
+//              ADMM_HIP_COMM_PATIENT_TIMEOUT_S (default one hour).
+// An exchange takes the bound in force when it is ENQUEUED (CommLockstep, comm.h).
+double env_seconds(const char* name, double dflt) {
+    if (const char* e = std::getenv(name)) { const double v = std::atof(e); if (v > 0.0) return v; }
+    return dflt;
+}
+double wait_seconds_lockstep() { static const double v = env_seconds("ADMM_HIP_COMM_TIMEOUT_S", 20.0); return v; }
+double wait_seconds_patient() { static const double v = env_seconds("ADMM_HIP_COMM_PATIENT_TIMEOUT_S", 3600.0); return v; }
+std::atomic<int> g_lockstep{0};
+double wait_seconds_now() { return g_lockstep.load(std::memory_order_relaxed) > 0 ? wait_seconds_lockstep() : wait_seconds_patient(); }
 
 std::mutex g_mu;
 CommInfo g_info;
@@ -68,8 +84,10 @@ struct ShmHeader {
     std::atomic<uint32_t> failed;
     uint64_t slot;
     uint32_t nranks;
+    std::atomic<uint64_t> token;       // the job's generation token, stored LAST by rank 0 (release): a segment of the same
+                                       // name left by a crashed run, or the live one of a concurrent job, never carries it
 };
-struct ShmOp { uint64_t seq; size_t nf, nd; };
+struct ShmOp { uint64_t seq; size_t nf, nd; double wait_s; };
 
 struct ShmState {
     std::string name;
@@ -100,7 +118,7 @@ void shm_host_fn(void* user) {
         while (h->posted[r].load(std::memory_order_acquire) < op.seq) {
             if ((++spins & 1023) == 0) {
                 sched_yield();
-                if (h->failed.load(std::memory_order_acquire) || now_s() - t0 > kWaitSeconds) {
+                if (h->failed.load(std::memory_order_acquire) || now_s() - t0 > op.wait_s) {
                     h->failed.store(1, std::memory_order_release);
                     if (g_err) *g_err = 1;
                     std::memset(g_shm.stage_out, 0, bytes);
@@ -128,7 +146,7 @@ void shm_exchange(float* fbuf, size_t nf, double* dbuf, size_t nd, hipStream_t s
     const size_t off_d = round_up_sz(nf * sizeof(float), 16);
     ADMM_REQUIRE(off_d + round_up_sz(nd * sizeof(double), 16) <= g_slot, "exchange payload exceeds the slot size");
     ShmOp* op = &g_shm.ring[g_shm.ring_pos++ % g_shm.ring.size()];
-    op->seq = ++g_seq; op->nf = nf; op->nd = nd;
+    op->seq = ++g_seq; op->nf = nf; op->nd = nd; op->wait_s = wait_seconds_now();
     if (nf) ADMM_HIP_CHECK(hipMemcpyAsync(g_shm.stage_in, fbuf, nf * sizeof(float), hipMemcpyDeviceToHost, st));
     if (nd) ADMM_HIP_CHECK(hipMemcpyAsync(g_shm.stage_in + off_d, dbuf, nd * sizeof(double), hipMemcpyDeviceToHost, st));
     ADMM_HIP_CHECK(hipLaunchHostFunc(st, shm_host_fn, op));
@@ -251,7 +269,7 @@ void peer_fill(PeerExchange& a) {
     a.remote = g_peer.d_remote; a.local = g_peer.local; a.slot = g_slot; a.flags_off = g_peer.flags_off;
     a.nranks = g_info.nranks; a.rank = g_info.rank; a.seq = ++g_seq;
     a.count = g_peer.count; a.err = g_derr;
-    a.timeout_ticks = (long long)(kWaitSeconds * 100e6);                // wall_clock64: constant 100 MHz
+    a.timeout_ticks = (long long)(wait_seconds_now() * 100e6);          // wall_clock64: constant 100 MHz
 }
 
 void peer_exchange(float* fbuf, size_t nf, double* dbuf, size_t nd, hipStream_t st) {
@@ -333,6 +351,9 @@ CommInfo comm_info() {
     return g_info;
 }
 
+CommLockstep::CommLockstep() { g_lockstep.fetch_add(1, std::memory_order_relaxed); }
+CommLockstep::~CommLockstep() { g_lockstep.fetch_sub(1, std::memory_order_relaxed); }
+
 void comm_check() {
     if (g_info.backend == COMM_PEER && g_derr) {          // called at the solvers' polls (after an event sync) only
         int h = 0;
@@ -381,47 +402,70 @@ void comm_init(int nranks, int rank, const void* idbytes) {
     g_seq = 0;
 }
 
-void comm_init_shm(int nranks, int rank, const char* name) {
+// `token`: a job-unique non-zero number every rank received over the caller's channel (like RCCL's unique id).  Rank 0
+// creates the segment afresh (a stale name is unlinked first: whoever still maps the old inode keeps it, nobody of THIS
+// job can mistake it for the new one) and stores the token into the header last; the other ranks map whatever carries the
+// name, and keep re-opening it until the header shows the token.  Without this a rank that raced rank 0's unlink + create
+// attached to the OLD segment, found `attached` and `posted[]` already high, skipped every wait and summed stale slots.
+void comm_init_shm(int nranks, int rank, const char* name, unsigned long long token) {
     std::lock_guard<std::mutex> lk(g_mu);
     require_free();
     check_ranks(nranks, rank);
     ADMM_REQUIRE(name != nullptr && name[0] == '/' && std::strlen(name) < 200, "shm name must start with '/'");
+    ADMM_REQUIRE(token != 0, "the shared-memory token must be non-zero (a job-unique number all ranks agree on)");
     alloc_err_word();
     g_slot = slot_bytes_from_env();
     const size_t hdr_bytes = round_up_sz(sizeof(ShmHeader), 4096);
     const size_t total = hdr_bytes + (size_t)2 * nranks * g_slot;
     g_shm.name = name;
     const double t0 = now_s();
+    const double patience = std::min(wait_seconds_patient(), 60.0);
+    auto map_segment = [&]() {
+        g_shm.map = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, g_shm.fd, 0);
+        if (g_shm.map == MAP_FAILED) { g_shm.map = nullptr; shm_close(); throw Error(ADMM_ERR_COMM, "mmap of the shared-memory segment failed"); }
+        g_shm.map_bytes = total;
+        g_shm.hdr = static_cast<ShmHeader*>(g_shm.map);
+        g_shm.data = static_cast<unsigned char*>(g_shm.map) + hdr_bytes;
+    };
     if (rank == 0) {
-        shm_unlink(name);                                                   // a stale segment of a crashed run
-        g_shm.fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        for (int attempt = 0; ; ++attempt) {
+            g_shm.fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+            if (g_shm.fd >= 0 || errno != EEXIST || attempt == 1) break;
+            shm_unlink(name);                                               // a stale segment of a crashed run
+        }
         if (g_shm.fd < 0 || ftruncate(g_shm.fd, (off_t)total) != 0) { shm_close(); throw Error(ADMM_ERR_COMM, "cannot create the shared-memory segment"); }
         g_shm.owner = true;
+        map_segment();                                                      // fresh pages read zero: posted[], attached, failed
+        g_shm.hdr->slot = g_slot; g_shm.hdr->nranks = (uint32_t)nranks;
+        g_shm.hdr->token.store(token, std::memory_order_release);
     } else {
-        for (;;) {                                                          // wait until rank 0 has created and sized it
+        for (;;) {                                                          // until the segment of THIS job is there
             g_shm.fd = shm_open(name, O_RDWR, 0600);
             struct stat sb;
-            if (g_shm.fd >= 0 && fstat(g_shm.fd, &sb) == 0 && (size_t)sb.st_size >= total) break;
+            if (g_shm.fd >= 0 && fstat(g_shm.fd, &sb) == 0 && (size_t)sb.st_size >= total) {
+                map_segment();
+                if (g_shm.hdr->token.load(std::memory_order_acquire) == token) break;
+                munmap(g_shm.map, g_shm.map_bytes);                         // another generation's segment (or not initialised yet)
+                g_shm.map = nullptr; g_shm.hdr = nullptr; g_shm.data = nullptr; g_shm.map_bytes = 0;
+            }
             if (g_shm.fd >= 0) { close(g_shm.fd); g_shm.fd = -1; }
-            if (now_s() - t0 > 60.0) throw Error(ADMM_ERR_COMM, "the shared-memory segment did not appear (is rank 0 running?)");
+            if (now_s() - t0 > patience) { shm_close(); throw Error(ADMM_ERR_COMM, "the shared-memory segment of this job did not appear (is rank 0 running? do all ranks pass the same token?)"); }
             usleep(2000);
         }
     }
-    g_shm.map = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, g_shm.fd, 0);
-    if (g_shm.map == MAP_FAILED) { g_shm.map = nullptr; shm_close(); throw Error(ADMM_ERR_COMM, "mmap of the shared-memory segment failed"); }
-    g_shm.map_bytes = total;
-    g_shm.hdr = static_cast<ShmHeader*>(g_shm.map);
-    g_shm.data = static_cast<unsigned char*>(g_shm.map) + hdr_bytes;
-    if (rank == 0) { g_shm.hdr->slot = g_slot; g_shm.hdr->nranks = (uint32_t)nranks; }
     ADMM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&g_shm.stage_in), g_slot, hipHostMallocDefault));
     ADMM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&g_shm.stage_out), g_slot, hipHostMallocDefault));
     g_shm.ring.assign(8192, ShmOp());
     g_shm.hdr->attached.fetch_add(1, std::memory_order_acq_rel);
     while (g_shm.hdr->attached.load(std::memory_order_acquire) < (uint32_t)nranks) {       // everybody is mapped before anyone posts
-        if (now_s() - t0 > 60.0) { shm_close(); throw Error(ADMM_ERR_COMM, "not every rank attached to the shared-memory segment"); }
+        if (now_s() - t0 > patience) { shm_close(); throw Error(ADMM_ERR_COMM, "not every rank attached to the shared-memory segment"); }
         usleep(1000);
     }
-    if (g_shm.hdr->slot != g_slot || g_shm.hdr->nranks != (uint32_t)nranks) { shm_close(); throw Error(ADMM_ERR_COMM, "ranks disagree on slot size / rank count"); }
+    if (g_shm.hdr->attached.load(std::memory_order_acquire) > (uint32_t)nranks || g_shm.hdr->slot != g_slot || g_shm.hdr->nranks != (uint32_t)nranks) {
+        shm_close();
+        throw Error(ADMM_ERR_COMM, "ranks disagree on slot size / rank count (or more ranks attached than the job has)");
+    }
+    if (rank == 0) { shm_unlink(name); g_shm.owner = false; }              // everybody holds a mapping: the name is not needed any more and cannot leak
     g_info.nranks = nranks; g_info.rank = rank; g_info.active = true; g_info.backend = COMM_SHM;
     g_seq = 0;
 }

@@ -697,6 +697,7 @@ struct TallPlan final : LassoPlan {
         Event ev_loop0, ev_loop1, ev_poll[2];
 
         ADMM_HIP_CHECK(hipStreamSynchronize(st));
+        const CommLockstep lockstep;                                   // per-iteration exchanges: the short wait bound (comm.h)
         const double tl0 = now_s();
         ADMM_HIP_CHECK(hipEventRecord(ev_loop0.e, st));
         long long g = 0, launches = 0;

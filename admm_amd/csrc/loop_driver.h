@@ -37,6 +37,7 @@ inline LoopTimes run_until_done(hipStream_t st, const int* d_done, int batch, lo
     ADMM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_done), 2 * sizeof(int), hipHostMallocDefault));
     struct HostFree { void* p; ~HostFree() { (void)hipHostFree(p); } } hf{h_done};
     h_done[0] = h_done[1] = 0;
+    const CommLockstep lockstep;                       // exchanges enqueued from here are per-iteration: short wait bound
     const int batch0 = batch;
     int npoll = 0;
     Event ev0, ev1, poll[2];

@@ -72,9 +72,24 @@ def init_comm_from_torch(device=None):
 PEER_HANDLE_BYTES = 64
 
 
-def init_comm_shm(nranks, rank, name):
-    """Attach the host shared-memory backend (all ranks on one host; `name` like "/admm_job42")."""
-    check(_lib.load().admm_hip_comm_init_shm(int(nranks), int(rank), name.encode()))
+def init_comm_shm(nranks, rank, name, token):
+    """Attach the host shared-memory backend (all ranks on one host; `name` like "/admm_job42"; `token`: a non-zero
+    job-unique integer all ranks agree on -- a stale or foreign segment of the same name is never attached to)."""
+    check(_lib.load().admm_hip_comm_init_shm(int(nranks), int(rank), name.encode(), int(token) & 0xFFFFFFFFFFFFFFFF))
+
+
+def job_token_from_torch():
+    """A fresh non-zero 63-bit token drawn by rank 0 and broadcast over the initialised torch.distributed group."""
+    import os
+    import torch
+    import torch.distributed as dist
+    t = torch.zeros(1, dtype=torch.int64)
+    if dist.get_rank() == 0:
+        t[0] = (int.from_bytes(os.urandom(8), "little") >> 1) | 1
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    dist.broadcast(t, src=0)
+    return int(t.item())
 
 
 def init_comm_peer(nranks, rank, allgather):
@@ -97,7 +112,8 @@ def init_comm_backend_from_torch(backend, device=None, name=None):
     if backend == "rccl":
         return init_comm_from_torch(device)
     if backend == "shm":
-        return init_comm_shm(world, rank, name or "/admm_hip_%s" % dist.get_world_size())
+        token = job_token_from_torch()                      # also makes the default name unique per job
+        return init_comm_shm(world, rank, name or "/admm_hip_%d_%x" % (world, token), token)
     if backend != "peer":
         raise ValueError(backend)
 

@@ -225,14 +225,18 @@ ADMM_HIP_API int admm_hip_comm_finalize(void);
  *    device (allocates its exchange buffer, returns its ADMM_HIP_PEER_HANDLE_BYTES-byte hipIpc handle), the caller
  *    gathers the handles of all ranks in rank order over any channel, then every rank calls admm_hip_comm_init_peer.
  *    The ranks may be processes on different GPUs of one node (xGMI) or -- for tests -- on the same GPU.
- *  - SHM: through a POSIX shared-memory segment `name` ("/something", the same on every rank of one host).  Slow; lets
- *    the multi-rank code run as several processes on ONE GPU without RCCL, bit-identical to PEER.
- * Every wait is bounded (20 s): a missing rank yields ADMM_ERR_COMM from the running solver call, never a hang.
+ *  - SHM: through a POSIX shared-memory segment `name` ("/something", the same on every rank of one host) carrying the
+ *    job's `token` (a non-zero number every rank received over the caller's channel, e.g. drawn by rank 0 and broadcast:
+ *    a segment of that name left by a crashed run or owned by a concurrent job is never attached to).  Slow; lets the
+ *    multi-rank code run as several processes on ONE GPU without RCCL, bit-identical to PEER.
+ * Every wait is bounded: the per-iteration exchanges of a solve by ADMM_HIP_COMM_TIMEOUT_S (20 s), setup reductions and
+ * the one join of the replica modes (cross-validation folds, several responses -- ranks are unbalanced there by design) by
+ * ADMM_HIP_COMM_PATIENT_TIMEOUT_S (one hour); a missing rank yields ADMM_ERR_COMM from the running call, never a hang.
  * Ranks should synchronise (barrier) before admm_hip_comm_finalize. */
 #define ADMM_HIP_PEER_HANDLE_BYTES 64
 ADMM_HIP_API int admm_hip_comm_peer_prepare(int nranks, void* handle_out);
 ADMM_HIP_API int admm_hip_comm_init_peer(int nranks, int rank, const void* handles_all_ranks);
-ADMM_HIP_API int admm_hip_comm_init_shm(int nranks, int rank, const char* name);
+ADMM_HIP_API int admm_hip_comm_init_shm(int nranks, int rank, const char* name, unsigned long long token);
 /* Test hook: in-place sum all-reduce of a device (mem = ADMM_MEM_DEVICE) or host float / double pair through the
  * attached backend, synchronous.  nf / nd may be 0. */
 ADMM_HIP_API int admm_hip_comm_test_allreduce(float* fbuf, long long nf, double* dbuf, long long nd, int mem);

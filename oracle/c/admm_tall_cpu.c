@@ -78,11 +78,15 @@ static float norm_f(const float* v, int p) {           /* VectorXf::norm(): floa
  *   alpha    < 0: Lasso prox; in [0, 1]: elastic net
  *   beta_out nlam x p (row-major per lambda): get_z() after each solve (standardised scale)
  *   niter_out[nlam]; *loop_seconds = wall time of the iteration loops only
+ *   trace    NULL, or room for trace_cap records of 8 doubles -- one per decision, what the reference's commented-out
+ *            print_row would show: lambda index, iteration, eps_primal, eps_dual, resid_primal, resid_dual, c (0 on the exit
+ *            iteration), outcome (0 converged, 1 accelerate, 2 restart); *ntrace = records written
  * Returns 0.
  */
-int oracle_tall_path(const float* F, const float* XY, int p, const double* lam, int nlam, double rho,
-                     double eps_abs, double eps_rel, int maxit, double alpha, int mode, int nthreads,
-                     float* beta_out, int* niter_out, double* loop_seconds) {
+int oracle_tall_path_traced(const float* F, const float* XY, int p, const double* lam, int nlam, double rho,
+                            double eps_abs, double eps_rel, int maxit, double alpha, int mode, int nthreads,
+                            float* beta_out, int* niter_out, double* loop_seconds, double* trace, int trace_cap, int* ntrace) {
+    int ntr = 0;
     float* x = calloc((size_t)p, sizeof(float));
     float* z = calloc((size_t)p, sizeof(float));
     float* y = calloc((size_t)p, sizeof(float));
@@ -138,12 +142,15 @@ int oracle_tall_path(const float* F, const float* XY, int p, const double* lam, 
             /* update_y (FADMMBase.h:203-211) */
             for (int k = 0; k < p; ++k) { r[k] = x[k] - z[k]; y[k] = adj_y[k] + rho_f * r[k]; }
             const double resid_primal = (double)norm_f(r, p);
+            double* tr = (trace && ntr < trace_cap) ? trace + 8 * (size_t)ntr++ : NULL;
+            if (tr) { tr[0] = l; tr[1] = i; tr[2] = eps_primal; tr[3] = eps_dual; tr[4] = resid_primal; tr[5] = resid_dual; tr[6] = 0.0; tr[7] = 0.0; }
             if (resid_primal < eps_primal && resid_dual < eps_dual) { it = i + 1; break; }      /* FADMMBase.h:237-238 */
             /* acceleration / restart (FADMMBase.h:240-256, ADMMLassoTall.h:154-161) */
             const double old_c = adj_c;
             float daz2 = 0.f;
             for (int k = 0; k < p; ++k) { const float d = z[k] - adj_z[k]; daz2 += d * d; }
             adj_c = rho * resid_primal * resid_primal + rho * (double)daz2;
+            if (tr) { tr[6] = adj_c; tr[7] = adj_c < 0.999 * old_c ? 1.0 : 2.0; }
             if (adj_c < 0.999 * old_c) {
                 const double old_a = adj_a;
                 adj_a = 0.5 + 0.5 * sqrt(1.0 + 4.0 * old_a * old_a);
@@ -164,8 +171,16 @@ int oracle_tall_path(const float* F, const float* XY, int p, const double* lam, 
         memcpy(beta_out + (size_t)l * p, z, (size_t)p * sizeof(float));     /* get_z(): Lasso.cpp:108 */
     }
     *loop_seconds = now_s() - t0;
+    if (ntrace) *ntrace = ntr;
     free(x); free(z); free(y); free(adj_z); free(adj_y); free(old_z); free(old_y); free(rhs); free(r);
     return 0;
+}
+
+int oracle_tall_path(const float* F, const float* XY, int p, const double* lam, int nlam, double rho,
+                     double eps_abs, double eps_rel, int maxit, double alpha, int mode, int nthreads,
+                     float* beta_out, int* niter_out, double* loop_seconds) {
+    return oracle_tall_path_traced(F, XY, p, lam, nlam, rho, eps_abs, eps_rel, maxit, alpha, mode, nthreads, beta_out, niter_out,
+                                   loop_seconds, NULL, 0, NULL);
 }
 
 int oracle_max_threads(void) {

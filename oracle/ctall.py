@@ -45,6 +45,8 @@ def load():
         lib.oracle_tall_path.argtypes = [fp, fp, ctypes.c_int, dp, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                          ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int, fp, ip, dp]
         lib.oracle_tall_path.restype = ctypes.c_int
+        lib.oracle_tall_path_traced.argtypes = lib.oracle_tall_path.argtypes + [dp, ctypes.c_int, ip]
+        lib.oracle_tall_path_traced.restype = ctypes.c_int
         lib.oracle_max_threads.restype = ctypes.c_int
         _lib = lib
     return _lib
@@ -54,9 +56,10 @@ def max_threads():
     return int(load().oracle_max_threads())
 
 
-def tall_loop(factor, XY, lam_int, rho, eps_abs, eps_rel, maxit, alpha=None, mode=0, nthreads=1):
+def tall_loop(factor, XY, lam_int, rho, eps_abs, eps_rel, maxit, alpha=None, mode=0, nthreads=1, trace=None):
     """The compiled loop on prepared inputs.  factor: Cholesky factor (mode 0) or inverse (mode 1), p x p float32
-    column-major.  Returns (beta [nlam, p] standardised scale, niter [nlam], loop seconds)."""
+    column-major.  Returns (beta [nlam, p] standardised scale, niter [nlam], loop seconds).  trace: a list that receives
+    one row per decision (lambda index, iteration, eps_p, eps_d, r_p, r_d, c, outcome)."""
     lib = load()
     p = XY.shape[0]
     Fm = np.asfortranarray(factor, dtype=F)
@@ -67,15 +70,21 @@ def tall_loop(factor, XY, lam_int, rho, eps_abs, eps_rel, maxit, alpha=None, mod
     niter = np.zeros(nl, dtype=np.int32)
     secs = ctypes.c_double()
     fp, dp, ip = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)
-    rc = lib.oracle_tall_path(Fm.ctypes.data_as(fp), XY.ctypes.data_as(fp), p, lam_int.ctypes.data_as(dp), nl, float(rho),
-                              float(eps_abs), float(eps_rel), int(maxit), -1.0 if alpha is None else float(alpha), int(mode),
-                              int(nthreads), beta.ctypes.data_as(fp), niter.ctypes.data_as(ip), ctypes.byref(secs))
+    cap = nl * int(maxit) if trace is not None else 0
+    tr = np.zeros((max(cap, 1), 8))
+    ntr = ctypes.c_int(0)
+    rc = lib.oracle_tall_path_traced(Fm.ctypes.data_as(fp), XY.ctypes.data_as(fp), p, lam_int.ctypes.data_as(dp), nl, float(rho),
+                                     float(eps_abs), float(eps_rel), int(maxit), -1.0 if alpha is None else float(alpha), int(mode),
+                                     int(nthreads), beta.ctypes.data_as(fp), niter.ctypes.data_as(ip), ctypes.byref(secs),
+                                     tr.ctypes.data_as(dp) if cap else None, cap, ctypes.byref(ntr))
     if rc != 0:
         raise MemoryError("oracle_tall_path failed")
+    if trace is not None:
+        trace.extend(tr[:ntr.value].tolist())
     return beta, niter, secs.value
 
 
-def _family(x, y, lam, nlambda, lmin_ratio, standardize, intercept, opts, alpha, mode, nthreads):
+def _family(x, y, lam, nlambda, lmin_ratio, standardize, intercept, opts, alpha, mode, nthreads, trace=None):
     x = np.asarray(x, dtype=np.float64)
     y = np.asarray(y, dtype=np.float64)
     n, p = x.shape
@@ -96,7 +105,7 @@ def _family(x, y, lam, nlambda, lmin_ratio, standardize, intercept, opts, alpha,
     else:
         Li = sla.solve_triangular(L.astype(np.float64), np.eye(p), lower=True)
         factor = (Li.T @ Li).astype(F)
-    b, niter, secs = tall_loop(factor, s.XY, lam_int, s.rho, opts["eps_abs"], opts["eps_rel"], opts["maxit"], alpha, mode, nthreads)
+    b, niter, secs = tall_loop(factor, s.XY, lam_int, s.rho, opts["eps_abs"], opts["eps_rel"], opts["maxit"], alpha, mode, nthreads, trace)
     beta = np.zeros((p + 1, lam.size), dtype=F)
     for i in range(lam.size):
         b0, coef = std.recover(b[i])
@@ -105,9 +114,9 @@ def _family(x, y, lam, nlambda, lmin_ratio, standardize, intercept, opts, alpha,
     return {"lambda": lam, "beta": beta, "niter": niter, "loop_seconds": secs, "rho": s.rho}
 
 
-def admm_lasso_c(x, y, lam, nlambda, lmin_ratio, standardize, intercept, opts, mode=0, nthreads=1):
-    return _family(x, y, lam, nlambda, lmin_ratio, standardize, intercept, opts, None, mode, nthreads)
+def admm_lasso_c(x, y, lam, nlambda, lmin_ratio, standardize, intercept, opts, mode=0, nthreads=1, trace=None):
+    return _family(x, y, lam, nlambda, lmin_ratio, standardize, intercept, opts, None, mode, nthreads, trace)
 
 
-def admm_enet_c(x, y, lam, nlambda, lmin_ratio, standardize, intercept, alpha, opts, mode=0, nthreads=1):
-    return _family(x, y, lam, nlambda, lmin_ratio, standardize, intercept, opts, alpha, mode, nthreads)
+def admm_enet_c(x, y, lam, nlambda, lmin_ratio, standardize, intercept, alpha, opts, mode=0, nthreads=1, trace=None):
+    return _family(x, y, lam, nlambda, lmin_ratio, standardize, intercept, opts, alpha, mode, nthreads, trace)

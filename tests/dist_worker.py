@@ -66,7 +66,12 @@ def main():
     lib = _lib.load()
     assert lib.admm_hip_set_device(0) == 0
     if backend == "shm":
-        adist.init_comm_shm(nranks, rank, "/admm_hip_test_" + os.path.basename(workdir))
+        # the job token travels over the caller's channel (here: files), drawn by rank 0
+        mine = np.frombuffer(os.urandom(8), dtype=np.uint64) | np.uint64(1)
+        token = int(file_allgather(workdir, "tok", rank, nranks, mine)[0])
+        if rank == 0 and os.environ.get("ADMM_TEST_RANK0_DELAY_S"):      # let the others meet a planted stale segment first
+            time.sleep(float(os.environ["ADMM_TEST_RANK0_DELAY_S"]))
+        adist.init_comm_shm(nranks, rank, os.environ.get("ADMM_TEST_SHM_NAME", "/admm_hip_test_" + os.path.basename(workdir)), token)
     else:
         adist.init_comm_peer(nranks, rank, lambda mine: file_allgather(workdir, "ipc", rank, nranks, mine))
     # ---- raw exchange: p floats + 3 doubles (the consensus payload), then a long message that needs chunking

@@ -42,6 +42,28 @@ def synth_lasso(n, p, m, seed=123, sd=2.0):
 #       drifted from it by that lambda
 #       (e.g. maxit = 7 with rho five orders below the automatic value: z = (x + y/rho) - lambda/rho cancels 5 digits).
 #       The number of such columns is returned; tests bound and print it.
+# R4  (round 3) follow mode is only as strict as the number of decisions it hands over: every traced test therefore ASSERTS
+#     a ceiling on them -- at most NEAR_TIE_RATE of the decisions (never fewer than NEAR_TIE_MIN allowed, so that one
+#     near-tie in a short run is not a failure) and none needing more than NEAR_TIE_ULPS of rounding -- instead of printing
+#     them.  The ceilings are set from the measured distribution of profiles/r03_soak_summary.md (7 000 random cases):
+#     a systematic bias of the GPU's residuals or thresholds that stays inside the 8-ulp band would multiply the rate of
+#     near-ties and push their ulps towards the band, and fails here.
+NEAR_TIE_RATE = 0.01
+NEAR_TIE_MIN = 3
+NEAR_TIE_ULPS = 6.0
+
+
+def assert_near_tie_budget(forced, ndecisions, label="", rate=NEAR_TIE_RATE, at_least=NEAR_TIE_MIN, max_ulps=NEAR_TIE_ULPS):
+    """R4: the decisions the oracle took from the GPU (`forced`, dicts with kind / ulps) are few and small."""
+    if rate is None:
+        return
+    allowed = max(int(at_least), int(np.ceil(rate * ndecisions)))
+    assert len(forced) <= allowed, (label, f"{len(forced)} of {ndecisions} decisions taken from the GPU as near-ties; at most {allowed} allowed",
+                                    [(f["lam"], f["iter"], f["kind"], round(f["ulps"], 2)) for f in forced][:10])
+    big = [(f["lam"], f["iter"], f["kind"], round(f["ulps"], 2)) for f in forced if f["kind"] != "rho" and f["ulps"] > max_ulps]
+    assert not big, (label, f"near-ties needing more than {max_ulps} ulps of rounding", big)
+
+
 def traced_fit(model, capacity=1 << 18):
     """Run a configured ADMM_Lasso / ADMM_Enet model through the prepared-problem entry points with the decision trace."""
     from admm_amd.api import LassoPlan
@@ -141,7 +163,7 @@ def threshold_quantum(ref, n, alpha=None):
     return np.asarray(out)
 
 
-def assert_followed_parity(beta, niter, trace, problem, tol=1e-4, band=8.0, label="", factor=5.0):
+def assert_followed_parity(beta, niter, trace, problem, tol=1e-4, band=8.0, label="", factor=5.0, budget=True):
     """Wide / consensus solvers (no rounding variants of the x-update there): the oracle follows the GPU through
     rounding-level near-ties of the stopping test and of the rho adaptation only; iteration counts identical for every
     lambda and every beta column within `tol`."""
@@ -161,6 +183,8 @@ def assert_followed_parity(beta, niter, trace, problem, tol=1e-4, band=8.0, labe
     fm = max([f["ulps"] for f in forced if f["kind"] == "stop"], default=0.0)
     print(f"[parity {label}] {nrec} decisions, {nstop} stopping near-ties (largest needs {fm:.2f} ulps) and {len(forced) - nstop} rho near-ties "
           f"taken from the GPU; niter identical; max beta err {max(errs):.2e}")
+    if budget:
+        assert_near_tie_budget(forced, nrec, label)
     bad = [(j, e) for j, e in enumerate(errs) if e >= tol]
     if bad and problem.get("nthread") is not None:
         # consensus solver: like R3 of the tall rule -- a column may exceed `tol` only within `factor` x the distance the
@@ -199,7 +223,7 @@ def col_err(a, b, floor):
     return np.abs(a - b).max() / max(np.abs(b).max(), floor, 1e-300)
 
 
-def assert_tall_parity(beta, niter, trace, problem, tol=1e-4, factor=5.0, band=8.0, label=""):
+def assert_tall_parity(beta, niter, trace, problem, tol=1e-4, factor=5.0, band=8.0, label="", budget=True):
     """problem: dict(x, y, lam, nlambda, lmin_ratio, standardize, intercept, opts, alpha) -- the oracle's arguments."""
     assert_trace_self_consistent(trace, accelerated=True, label=label)
     ref, forced, ndec = oracle_following(trace, band=band, **problem)          # R1 (raises FollowMismatch)
@@ -236,10 +260,12 @@ def assert_tall_parity(beta, niter, trace, problem, tol=1e-4, factor=5.0, band=8
     print(f"[parity {label}] {nrec} decisions, {len(forced)} near-ties taken from the GPU (largest needs {fm:.2f} ulps of rounding, "
           f"first at lambda {first}); niter identical; max beta err {max(errs):.2e}; columns beyond {tol:g}: {len(loose)} of {nl}"
           + (f" {loose} (oracle rounding variants differ by {yard:.2e})" if loose else ""))
+    if budget:
+        assert_near_tie_budget(forced, nrec, label)
     return dict(forced=forced, max_ulps=fm, first_forced_lambda=first, loose=loose, max_err=max(errs), errs=errs, ref=ref)
 
 
-def assert_dense_followed(kind, fit_beta, fit_niter, trace, x, y, opts, intercept=True, tol=1e-4, band=8.0, label=""):
+def assert_dense_followed(kind, fit_beta, fit_niter, trace, x, y, opts, intercept=True, tol=1e-4, band=8.0, label="", budget=True):
     """LAD / BP (FADMMBase::solve with the rho adaptation of FADMMBase.h:109-133, float64): the oracle follows the GPU's
     decision trace through rounding-level near-ties of the stopping / restart tests and of the rho adaptation only;
     iteration counts identical, beta within `tol`."""
@@ -256,4 +282,21 @@ def assert_dense_followed(kind, fit_beta, fit_niter, trace, x, y, opts, intercep
     err = relerr(fit_beta, ref["beta"])
     print(f"[parity {label}] {len(t)} decisions, {len(d['forced'])} near-ties taken from the GPU; niter identical ({int(fit_niter)}); beta err {err:.2e}")
     assert err < tol, (label, err)
+    if budget:
+        assert_near_tie_budget(d["forced"], len(t), label)
     return dict(forced=d["forced"], err=err, ref=ref)
+
+
+def traced_parity(model, problem, tol=1e-4, label="", capacity=None, **kw):
+    """Fit a configured ADMM_Lasso / ADMM_Enet model with the decision trace and judge it by the rule above (R1-R4): the tall
+    rule for n > p without $parallel(), the followed rule for the wide and consensus solvers.  `problem` = the oracle's
+    arguments (dict x, y, lam, nlambda, lmin_ratio, standardize, intercept, opts, alpha[, nthread]).  Returns (fit, report)."""
+    nl = len(problem["lam"]) if problem.get("lam") is not None else int(problem["nlambda"])
+    cap = capacity or max(nl, 1) * (int(problem["opts"]["maxit"]) + 2) + 8
+    fit, trace = traced_fit(model, capacity=min(cap, 1 << 22))
+    n, p = np.asarray(problem["x"]).shape
+    if n > p and problem.get("nthread") is None:
+        rep = assert_tall_parity(fit.beta_dense, fit.niter, trace, problem, tol, label=label, **kw)
+    else:
+        rep = assert_followed_parity(fit.beta_dense, fit.niter, trace, problem, tol, label=label, **kw)
+    return fit, rep

@@ -19,9 +19,9 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _run_ranks(backend, case, nranks=2, timeout=300):
+def _run_ranks(backend, case, nranks=2, timeout=300, extra_env=None):
     with tempfile.TemporaryDirectory(prefix="admmdist") as wd:
-        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
         procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), backend, str(r), str(nranks), wd, case],
                                   env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(nranks)]
         outs = []
@@ -56,16 +56,17 @@ def test_two_process_consensus_matches_single_process(backend, case):
     check(lib.admm_hip_parlasso(*head, K, *tail))
     # single process, same K: the only difference is where the column moments / X'y partial sums are added up
     assert np.allclose(res[0]["lam"], lam_out, rtol=1e-6)
-    assert np.abs(res[0]["niter"].astype(int) - niter1.astype(int)).max() <= 2, (res[0]["niter"], niter1)
+    # (two executions with their own roundings: each is held to the oracle by the trace rule -- the single process in
+    # tests/test_gpu_parlasso.py, the two processes below -- so no slack on iteration counts is needed between them)
     for j in range(kw["nlambda"]):
-        assert relerr(res[0]["beta"][:, j], beta1[:, j]) < 1e-4, j
+        assert relerr(res[0]["beta"][:, j], beta1[:, j]) < 2e-4, j
     # against the oracle on the decision trace (identical counts, every column 1e-4): the global moments are summed in a
     # different order than in one process, so this is a separate execution with its own near-ties
     from helpers import assert_followed_parity
     assert np.array_equal(res[0]["trace"], res[1]["trace"])
     prob = dict(x=x, y=y, lam=None, nlambda=kw["nlambda"], lmin_ratio=0.01 if x.shape[0] < x.shape[1] else 1e-4, standardize=True,
                 intercept=True, opts=dict(entry.LASSO_OPTS, maxit=kw["maxit"]), alpha=None, nthread=K)
-    assert_followed_parity(res[0]["beta"], res[0]["niter"], res[0]["trace"], prob, 2e-4, label=f"2-process consensus {case} over {backend}")
+    assert_followed_parity(res[0]["beta"], res[0]["niter"], res[0]["trace"], prob, 1e-4, label=f"2-process consensus {case} over {backend}")
 
 
 @pytest.mark.parametrize("backend,case", [("shm", "tallshard300"), ("peer", "tallshard300"), ("peer", "tallshard2300")])
@@ -154,3 +155,36 @@ def test_two_process_multi_response_as_replicas():
         for r in res:
             assert np.array_equal(r["beta"][j], one.beta_dense) and np.array_equal(r["niter"][j], one.niter)
             assert np.array_equal(r["lam"][j], one.lambda_)
+
+
+def test_shm_bootstrap_ignores_a_stale_segment_of_the_same_name():
+    """A segment of the job's name left behind by a crashed run -- sized right, `attached` already at nranks, every
+    posted[] sequence number far ahead, slots full of garbage -- used to be attached to by any rank that opened the name
+    before rank 0 had replaced it: that rank skipped every wait and summed stale slots (comm.hip, ShmHeader::token).  Now
+    the header must carry the job's token.  The stale segment is planted BEFORE the ranks start, rank 0 is held back a
+    little so that rank 1 certainly sees the stale one first, and the run must still produce the single-process result."""
+    import mmap
+    name = "/admm_hip_stale_%d" % os.getpid()
+    path = "/dev/shm" + name
+    total = 4096 + 2 * 2 * (4 << 20)
+    with open(path, "wb") as f:
+        f.truncate(total)
+    with open(path, "r+b") as f:
+        mm = mmap.mmap(f.fileno(), total)
+        hdr = np.frombuffer(mm, dtype=np.uint64, count=64)
+        hdr[:] = 1 << 40                                       # posted[r]: every exchange "already posted"
+        np.frombuffer(mm, dtype=np.uint32, count=2, offset=512)[:] = (2, 0)      # attached = nranks, failed = 0
+        np.frombuffer(mm, dtype=np.uint64, count=1, offset=520)[:] = 4 << 20     # slot
+        np.frombuffer(mm, dtype=np.uint32, count=1, offset=528)[:] = 2           # nranks
+        np.frombuffer(mm, dtype=np.float32, count=(total - 4096) // 4, offset=4096)[:] = 1e30
+        del hdr
+        mm.flush()
+    try:
+        res = _run_ranks("shm", "tallblocks", extra_env=dict(ADMM_TEST_SHM_NAME=name, ADMM_TEST_RANK0_DELAY_S="1.5"))
+        ref = _run_ranks("shm", "tallblocks")
+        assert np.array_equal(res[0]["beta"], res[1]["beta"])
+        assert np.array_equal(res[0]["beta"], ref[0]["beta"]) and np.array_equal(res[0]["niter"], ref[0]["niter"])
+        assert np.all(np.isfinite(res[0]["beta"]))
+    finally:
+        if os.path.exists(path):
+            os.unlink(path)

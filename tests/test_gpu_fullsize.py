@@ -132,12 +132,13 @@ def test_c4_woodbury_sibling_k8_vs_oracle():
     from helpers import relerr, synth_lasso
     from oracle import entry
     x, y = synth_lasso(1600, 4000, 30, seed=44)
-    fit = admm_lasso(x, y).penalty(nlambda=4, lambda_min_ratio=0.2).parallel(8).opts(maxit=600).fit()
-    ref = entry.admm_parlasso(x, y, None, 4, 0.2, True, True, 8, dict(entry.LASSO_OPTS, maxit=600))
-    assert np.allclose(fit.lambda_, ref["lambda"], rtol=1e-5)
-    assert np.abs(fit.niter.astype(int) - ref["niter"].astype(int)).max() <= max(5, 0.05 * ref["niter"].max()), (fit.niter, ref["niter"])
-    for j in range(4):
-        assert relerr(fit.beta_dense[:, j], ref["beta"][:, j]) < 2e-4, j
+    from helpers import traced_parity
+    prob = dict(x=x, y=y, lam=None, nlambda=4, lmin_ratio=0.2, standardize=True, intercept=True, opts=dict(entry.LASSO_OPTS, maxit=600),
+                alpha=None, nthread=8)
+    # on the decision trace: iteration counts identical, every column within 1e-4
+    fit, rep = traced_parity(admm_lasso(x, y).penalty(nlambda=4, lambda_min_ratio=0.2).parallel(8).opts(maxit=600), prob, 1e-4,
+                             label="C4 sibling K=8 Woodbury")
+    assert np.allclose(fit.lambda_, rep["ref"]["lambda"], rtol=1e-5)
 
 
 def _lad_objective(xt, y, beta):
@@ -187,3 +188,47 @@ def test_c5_full_size_lad():
     # +-4e-3 .. 7e-3 against quantreg at its own sizes, README.md:331-333,362-364); least squares is far outside that
     assert f_admm <= best * (1 + 5e-3)
     assert (f_admm - best) < 0.2 * (f_ls - best)
+
+
+def test_c2_width_short_path_vs_compiled_oracle_fixture():
+    """Solver-level parity at the HEADLINE width p = 10 000 (symmetric lower-triangle x-update, matrix-core Gram and
+    inverse): tests/golden/c2_short_path.npz holds what the compiled C oracle (oracle/c/admm_tall_cpu.c, mode 0 = the
+    reference's arithmetic: float Cholesky factor + two triangular solves, FADMMBase.h:185-265, ADMMLassoTall.h:70-95)
+    returns for the first ten lambdas of the automatic grid on n = 20 000 rows with maxit = 42, together with its decision
+    trace.  The GPU must take the SAME decision at every one of its iterations (stop / accelerate / restart, lambda by
+    lambda), hence identical iteration counts incl. the maxit exits, and every coefficient column must be within 1e-4."""
+    import os
+    import sys
+    from admm_amd import admm_lasso
+    from helpers import assert_trace_self_consistent, col_err, traced_fit
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    from make_c2_short import c2_short_data
+    g = np.load(os.path.join(here, "golden", "c2_short_path.npz"))
+    x, y = c2_short_data(int(g["seed"]), int(g["n"]), int(g["p"]), int(g["m"]))
+    lam, maxit = g["lam"], int(g["maxit"])
+    fit, trace = traced_fit(admm_lasso(x, y).penalty(lam).opts(maxit=maxit), capacity=len(lam) * (maxit + 2) + 8)
+    assert fit.stats["xupdate_variant"] == 1 and fit.stats["branch"] == 0
+    assert abs(fit.stats["rho"] - float(g["rho"])) < 1e-5 * float(g["rho"])            # same Lanczos estimate -> same rho
+    assert_trace_self_consistent(trace, accelerated=True, label="c2 short")
+    t = np.asarray(trace)
+    t = t[1:] if t[0, 8] == -1 else t
+    o = g["trace"]
+    assert len(t) == len(o), (len(t), len(o))
+    assert np.array_equal(t[:, 0], o[:, 0]) and np.array_equal(t[:, 1], o[:, 1])       # same (lambda, iteration) sequence
+    assert np.array_equal(t[:, 8].astype(int), o[:, 7].astype(int)), np.nonzero(t[:, 8] != o[:, 7])[0][:5]   # same decisions
+    # the quantities the decisions were taken on agree to the rounding of the iterates: thresholds, primal residual, and the
+    # dual residual while it is above its threshold (below, rho ||z - z_old|| is single-ulp flips of a few z entries)
+    assert np.allclose(t[:, 2], o[:, 2], rtol=1e-3) and np.allclose(t[:, 3], o[:, 3], rtol=1e-3)
+    assert np.allclose(t[:, 4], o[:, 4], rtol=2e-2), float((np.abs(t[:, 4] - o[:, 4]) / o[:, 4]).max())
+    big = o[:, 5] > o[:, 3]
+    assert big.sum() > 50 and np.allclose(t[big, 5], o[big, 5], rtol=0.1)
+    assert list(map(int, fit.niter)) == list(map(int, g["niter"])), (fit.niter, g["niter"])
+    assert (np.asarray(fit.niter) == maxit + 1).any() and (np.asarray(fit.niter) <= maxit).any()
+    floor = 1e-2 * float(np.abs(g["beta"]).max())
+    errs = [col_err(fit.beta_dense[:, j], g["beta"][:, j], floor) for j in range(len(lam))]
+    print(f"[c2 short] {len(t)} decisions identical to the compiled oracle's; niter {list(map(int, fit.niter))}; max beta err {max(errs):.2e}")
+    assert max(errs) < 1e-4, errs
+    for j in range(len(lam)):                                  # same support up to entries at the float threshold
+        a, b = np.abs(fit.beta_dense[1:, j]) > 1e-5 * floor * 100, np.abs(g["beta"][1:, j]) > 1e-5 * floor * 100
+        assert (a != b).sum() <= 2, (j, int((a != b).sum()))

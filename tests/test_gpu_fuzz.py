@@ -13,28 +13,13 @@ from helpers import assert_dense_followed, assert_followed_parity, assert_tall_p
 pytestmark = pytest.mark.gpu
 
 
-def _run_dense_case(cs):
-    """LAD / BP (float64) on the decision trace: the oracle follows the GPU through rounding-level near-ties only."""
-    from admm_amd import admm_bp, admm_lad
+def _dense_opts(kind):
     from oracle import entry
-    kind, x, y, icpt = (cs[k] for k in ("kind", "x", "y", "icpt"))
-    label = f"small {cs['c']} {kind} n={cs['n']} p={cs['p']} icpt={int(icpt)} scale={cs['scale']:g}"
-    if kind == "lad":
-        fit = admm_lad(x, y, icpt).fit(trace=True)
-        bg = np.asarray(fit.beta)
-        assert np.all(np.isfinite(bg)), label
-        return assert_dense_followed("lad", bg, fit.niter, fit.trace, x, y, entry.LAD_OPTS, intercept=icpt, tol=1e-6, label=label)
-    fit = admm_bp(x, y).fit(trace=True)
-    bg = fit.beta.toarray().ravel()
-    assert np.all(np.isfinite(bg)), label
-    return assert_dense_followed("bp", bg, fit.niter, fit.trace, x, y, entry.BP_OPTS, tol=1e-6, label=label)
+    return entry.LAD_OPTS if kind == "lad" else entry.BP_OPTS
 
 
-def _run_lasso_case(cs):
-    """Lasso family (tall, wide, elastic net, consensus) through the prepared-problem entry points with the decision
-    trace; the oracle follows the GPU through rounding-level near-ties only; counts identical, every column 1e-4 (tall:
-    or within the oracle's own rounding drift where the reference's formula loses the digits).  Returns the report."""
-    from admm_amd import admm_enet, admm_lasso
+def _lasso_problem(cs):
+    """The oracle's arguments for a Lasso-family case of fuzz_cases.cases (everything but the GPU's outputs)."""
     from oracle import entry
     kind, x, y, n, p, icpt, stdz = (cs[k] for k in ("kind", "x", "y", "n", "p", "icpt", "stdz"))
     opts = dict(entry.LASSO_OPTS)
@@ -45,24 +30,70 @@ def _run_lasso_case(cs):
     if cs["user_lam"]:
         ref0 = entry.admm_lasso(x, y, None, 3, 0.1, stdz, icpt, dict(opts, maxit=1), {})
         lam = np.sort(ref0["lambda"][0] * cs["ulam"])[::-1]
-    nl = cs["nl"]
+    prob = dict(x=x, y=y, lam=lam, nlambda=cs["nl"], lmin_ratio=lmr, standardize=stdz, intercept=icpt, opts=opts, alpha=cs["alpha"])
+    if kind == "par" and cs["K"] > 1:
+        prob["nthread"] = cs["K"]
+    return prob
+
+
+def case_label(cs):
+    if cs["kind"] in ("lad", "bp"):
+        return f"small {cs['c']} {cs['kind']} n={cs['n']} p={cs['p']} icpt={int(cs['icpt'])} scale={cs['scale']:g}"
+    return f"small {cs['c']} {cs['kind']} n={cs['n']} p={cs['p']} std={int(cs['stdz'])} icpt={int(cs['icpt'])} scale={cs['scale']:g}"
+
+
+def gpu_capture(cs):
+    """What libadmm_hip returns for a case of fuzz_cases.cases: dict(beta, niter, trace) -- everything the judgement
+    needs from the GPU, so that a capture written by tests/tools/soak_capture.py can be judged again without one."""
+    from admm_amd import admm_bp, admm_enet, admm_lad, admm_lasso
+    kind = cs["kind"]
+    if kind == "lad":
+        fit = admm_lad(cs["x"], cs["y"], cs["icpt"]).fit(trace=True)
+        return dict(beta=np.asarray(fit.beta, dtype=np.float64), niter=np.asarray(fit.niter), trace=np.asarray(fit.trace))
+    if kind == "bp":
+        fit = admm_bp(cs["x"], cs["y"]).fit(trace=True)
+        return dict(beta=fit.beta.toarray().ravel(), niter=np.asarray(fit.niter), trace=np.asarray(fit.trace))
+    prob = _lasso_problem(cs)
     if kind.startswith("enet"):
-        m = admm_enet(x, y, icpt, stdz).penalty(lam, nlambda=nl, lambda_min_ratio=lmr, alpha=cs["alpha"])
+        m = admm_enet(cs["x"], cs["y"], cs["icpt"], cs["stdz"]).penalty(prob["lam"], nlambda=cs["nl"], lambda_min_ratio=prob["lmin_ratio"],
+                                                                        alpha=cs["alpha"])
     else:
-        m = admm_lasso(x, y, icpt, stdz).penalty(lam, nlambda=nl, lambda_min_ratio=lmr).opts(maxit=opts["maxit"])
+        m = admm_lasso(cs["x"], cs["y"], cs["icpt"], cs["stdz"]).penalty(prob["lam"], nlambda=cs["nl"], lambda_min_ratio=prob["lmin_ratio"])
+        m.opts(maxit=prob["opts"]["maxit"])
         if kind == "par":
             m.nthread = cs["K"]
-    fit, trace = traced_fit(m, capacity=max(nl, 1) * (opts["maxit"] + 2) + 8)
-    assert np.all(np.isfinite(fit.beta_dense)), (cs["c"], kind)
-    prob = dict(x=x, y=y, lam=lam, nlambda=nl, lmin_ratio=lmr, standardize=stdz, intercept=icpt, opts=opts, alpha=cs["alpha"])
-    label = f"small {cs['c']} {kind} n={n} p={p} std={int(stdz)} icpt={int(icpt)} scale={cs['scale']:g}"
-    if kind == "par":
-        if cs["K"] <= 1:                 # nthread = 1 is the serial solver in the R wrapper (R/30_admm_lasso.R:136-147)
-            return None
-        prob["nthread"] = cs["K"]
-    if n > p and kind != "par":
-        return assert_tall_parity(fit.beta_dense, fit.niter, trace, prob, 1e-4, label=label)
-    return assert_followed_parity(fit.beta_dense, fit.niter, trace, prob, 1e-4, label=label)
+    fit, trace = traced_fit(m, capacity=max(cs["nl"], 1) * (prob["opts"]["maxit"] + 2) + 8)
+    return dict(beta=np.asarray(fit.beta_dense), niter=np.asarray(fit.niter), trace=np.asarray(trace))
+
+
+def judge_capture(cs, cap, band=8.0, budget=True):
+    """The parity rule of tests/helpers.py applied to a capture (CPU only).  Returns the report (None: not judged).
+    budget=False (the soak tool, which RECORDS the near-ties instead): the ceiling on decisions taken from the GPU (R4) is
+    not asserted."""
+    kind = cs["kind"]
+    label = case_label(cs)
+    assert np.all(np.isfinite(cap["beta"])), label
+    if kind in ("lad", "bp"):
+        return assert_dense_followed(kind, cap["beta"], cap["niter"], cap["trace"], cs["x"], cs["y"], _dense_opts(kind),
+                                     intercept=cs["icpt"], tol=1e-6, band=band, label=label, budget=budget)
+    prob = _lasso_problem(cs)
+    if kind == "par" and cs["K"] <= 1:   # nthread = 1 is the serial solver in the R wrapper (R/30_admm_lasso.R:136-147)
+        return None
+    if cs["n"] > cs["p"] and kind != "par":
+        return assert_tall_parity(cap["beta"], cap["niter"], cap["trace"], prob, 1e-4, band=band, label=label, budget=budget)
+    return assert_followed_parity(cap["beta"], cap["niter"], cap["trace"], prob, 1e-4, band=band, label=label, budget=budget)
+
+
+def _run_dense_case(cs):
+    """LAD / BP (float64) on the decision trace: the oracle follows the GPU through rounding-level near-ties only."""
+    return judge_capture(cs, gpu_capture(cs))
+
+
+def _run_lasso_case(cs):
+    """Lasso family (tall, wide, elastic net, consensus) through the prepared-problem entry points with the decision
+    trace; the oracle follows the GPU through rounding-level near-ties only; counts identical, every column 1e-4 (tall:
+    or within the oracle's own rounding drift where the reference's formula loses the digits).  Returns the report."""
+    return judge_capture(cs, gpu_capture(cs))
 
 
 def test_random_small_problems_match_the_oracle():
@@ -114,7 +145,9 @@ def test_medium_tall_problems_match_the_oracle():
         nloose += len(rep["loose"])
         ncases += 1
     assert ncases >= 4
-    assert nloose <= 2 * ncases, nloose
+    # columns beyond 1e-4 but inside the oracle's own rounding drift (R3): measured 2 (case 3: maxit = 7 with rho five orders
+    # below the automatic value -- columns 4 and 5 of its 6); nothing else may join them
+    assert nloose <= 2, nloose
 
 
 def test_tiny_lambda_on_unstandardised_data_stops_like_the_reference():
@@ -125,10 +158,9 @@ def test_tiny_lambda_on_unstandardised_data_stops_like_the_reference():
     from oracle import entry
     cs = next(c for c in cases(45, 7) if c["c"] == 44)
     assert cs["kind"] == "tall" and cs["scale"] == 50.0 and not cs["stdz"]
-    fit = admm_lasso(cs["x"], cs["y"], cs["icpt"], cs["stdz"]).penalty(None, nlambda=cs["nl"]).fit()
-    ref = entry.admm_lasso(cs["x"], cs["y"], None, cs["nl"], 1e-4, cs["stdz"], cs["icpt"], entry.LASSO_OPTS)
-    assert np.abs(fit.niter.astype(int) - ref["niter"].astype(int)).max() <= 10, (fit.niter, ref["niter"])
-    assert relerr(fit.beta_dense[:, -1], ref["beta"][:, -1]) < 1e-4
+    rep = _run_lasso_case(cs)                  # the trace rule: iteration counts identical to the following oracle's
+    free = entry.admm_lasso(cs["x"], cs["y"], None, cs["nl"], 1e-4, cs["stdz"], cs["icpt"], entry.LASSO_OPTS)      # the oracle on its own
+    assert int(np.asarray(rep["ref"]["niter"]).max()) < 200 and int(free["niter"].max()) < 200, (rep["ref"]["niter"], free["niter"])
 
 
 def test_small_inverse_after_a_double_precision_solve_is_finite():

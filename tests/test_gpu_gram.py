@@ -9,20 +9,35 @@ from helpers import relerr, synth_lasso
 pytestmark = pytest.mark.gpu
 
 
+def _traced_with_env(env, x, y, lam, label):
+    """A tall fit with kernel-variant knobs set (read at plan creation), judged by the trace rule (helpers R1-R4): every
+    variant is its own execution with its own near-ties, so each is held to the oracle -- identical iteration counts,
+    columns within 1e-4 -- instead of to the other variant with a slack on the counts."""
+    from admm_amd import admm_lasso
+    from helpers import traced_parity
+    from oracle import entry
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        prob = dict(x=x, y=y, lam=lam, nlambda=100, lmin_ratio=1e-4, standardize=True, intercept=True, opts=entry.LASSO_OPTS, alpha=None)
+        return traced_parity(admm_lasso(x, y).penalty(lam), prob, 1e-4, label=label)[0]
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def test_mfma_gram_matches_library_gram_end_to_end():
     """p = 2100 -> 17 x 17 tiles / 2 = 153 tiles >= 128: the MFMA path is taken by default (ragged last tile)."""
     from admm_amd import admm_lasso
     x, y = synth_lasso(6000, 2100, 50, seed=61)
     lam = [0.3, 0.05]
-    os.environ["ADMM_HIP_GRAM"] = "rocblas"
-    try:
-        ref = admm_lasso(x, y).penalty(lam).fit()
-    finally:
-        del os.environ["ADMM_HIP_GRAM"]
-    fit = admm_lasso(x, y).penalty(lam).fit()
+    ref = _traced_with_env(dict(ADMM_HIP_GRAM="rocblas"), x, y, lam, "library Gram")
+    fit = _traced_with_env({}, x, y, lam, "matrix-core Gram")
     # same Lanczos estimate (sets rho) to float rounding, same path
     assert abs(fit.stats["eig_est"] - ref.stats["eig_est"]) < 1e-5 * ref.stats["eig_est"]
-    assert np.abs(fit.niter.astype(int) - ref.niter.astype(int)).max() <= 2
     for j in range(2):
         assert relerr(fit.beta_dense[:, j], ref.beta_dense[:, j]) < 1e-4
 
@@ -33,13 +48,8 @@ def test_mfma_cholesky_inverse_matches_rocsolver_end_to_end(n, p):
     from admm_amd import admm_lasso
     x, y = synth_lasso(n, p, 25, seed=67)
     lam = [0.4, 0.1, 0.02]
-    os.environ["ADMM_HIP_FACTOR"] = "rocsolver"
-    try:
-        ref = admm_lasso(x, y).penalty(lam).fit()
-    finally:
-        del os.environ["ADMM_HIP_FACTOR"]
-    fit = admm_lasso(x, y).penalty(lam).fit()
-    assert np.abs(fit.niter.astype(int) - ref.niter.astype(int)).max() <= 2
+    ref = _traced_with_env(dict(ADMM_HIP_FACTOR="rocsolver"), x, y, lam, f"rocSOLVER factor p={p}")
+    fit = _traced_with_env({}, x, y, lam, f"matrix-core factor p={p}")
     for j in range(3):
         assert relerr(fit.beta_dense[:, j], ref.beta_dense[:, j]) < 1e-4
 

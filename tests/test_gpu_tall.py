@@ -2,43 +2,44 @@
 import numpy as np
 import pytest
 
-from helpers import assert_tall_parity, relerr, synth_lasso, traced_fit
+from helpers import assert_tall_parity, relerr, synth_lasso, traced_fit, traced_parity
 
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-4   # north_star: beta within 1e-4 relative (norm-wise)
 
 
+def _problem(x, y, nl, standardize=True, intercept=True, alpha=None, lam=None, opts=None):
+    from oracle import entry
+    return dict(x=x, y=y, lam=lam, nlambda=nl, lmin_ratio=1e-4, standardize=standardize, intercept=intercept,
+                opts=opts or entry.LASSO_OPTS, alpha=alpha)
+
+
 def test_readme_lasso_fixture(readme_lasso_xy):
     from admm_amd import admm_lasso
     from oracle import entry, readme
     x, y = readme_lasso_xy
-    fit = admm_lasso(x, y).penalty(readme.LAMBDA).fit()
-    ref = entry.admm_lasso(x, y, [readme.LAMBDA], 100, 1e-4, True, True, entry.LASSO_OPTS)
+    # on the decision trace: iteration count IDENTICAL to the oracle's (31), beta within 1e-4 of it
+    fit, rep = traced_parity(admm_lasso(x, y).penalty(readme.LAMBDA), _problem(x, y, 100, lam=[readme.LAMBDA]), TOL, label="README lasso")
     beta = fit.beta_dense[:, 0]
-    assert relerr(beta, ref["beta"][:, 0]) < TOL
     assert relerr(beta, readme.LASSO_ADMM) < TOL                 # README.md:66-88 admm column
     assert np.array_equal(beta != 0, readme.LASSO_ADMM != 0)
-    assert abs(int(fit.niter[0]) - int(ref["niter"][0])) <= 2
+    assert int(fit.niter[0]) == 31 and len(rep["forced"]) == 0
     assert abs(fit.stats["rho"] - 13.678) < 0.01
+    plain = admm_lasso(x, y).penalty(readme.LAMBDA).fit()         # the plain entry point is the same execution
+    assert np.array_equal(plain.beta_dense, fit.beta_dense) and list(plain.niter) == list(fit.niter)
 
 
 def test_readme_enet_fixture(readme_lasso_xy):
     from admm_amd import admm_enet
     from oracle import entry, readme
     x, y = readme_lasso_xy
-    fit = admm_enet(x, y).penalty(readme.LAMBDA, alpha=0.5).fit()
+    fit, rep = traced_parity(admm_enet(x, y).penalty(readme.LAMBDA, alpha=0.5), _problem(x, y, 100, alpha=0.5, lam=[readme.LAMBDA]), TOL,
+                             label="README enet")
     beta = fit.beta_dense[:, 0]
     assert relerr(beta, readme.ENET_ADMM) < TOL                  # README.md:100-123
     assert np.array_equal(beta != 0, readme.ENET_ADMM != 0)
-    ref = entry.admm_enet(x, y, [readme.LAMBDA], 100, 1e-4, True, True, 0.5, entry.LASSO_OPTS)
-    assert abs(int(fit.niter[0]) - int(ref["niter"][0])) <= 2
-
-
-def _problem(x, y, nl, standardize=True, intercept=True, alpha=None, lam=None, opts=None):
-    from oracle import entry
-    return dict(x=x, y=y, lam=lam, nlambda=nl, lmin_ratio=1e-4, standardize=standardize, intercept=intercept,
-                opts=opts or entry.LASSO_OPTS, alpha=alpha)
+    assert int(fit.niter[0]) == 22 and len(rep["forced"]) == 0   # 22 iterations
 
 
 @pytest.mark.parametrize("standardize,intercept", [(True, True), (True, False), (False, True), (False, False)])
@@ -53,7 +54,7 @@ def test_tall_path_vs_oracle(standardize, intercept):
     rep = assert_tall_parity(fit.beta_dense, fit.niter, trace, _problem(x, y, 20, standardize, intercept), TOL,
                              label=f"std={int(standardize)} icpt={int(intercept)}")
     assert np.allclose(fit.lambda_, rep["ref"]["lambda"], rtol=1e-5)
-    assert rep["first_forced_lambda"] is None or rep["first_forced_lambda"] >= 5     # no near-tie on the first quarter of the path
+    # (the ceiling on decisions taken from the GPU -- helpers R4 -- is asserted inside assert_tall_parity)
     assert len(rep["loose"]) == 0, rep["loose"]
     # the plain entry point gives the same result as the prepared-problem one the trace came from
     fit2 = admm_lasso(x, y, intercept=intercept, standardize=standardize).penalty(nlambda=20).fit()
@@ -87,16 +88,11 @@ def test_tall_ragged_and_maxit():
     from oracle import entry
     x, y = synth_lasso(523, 97, 9, seed=3)
     lam = [0.5, 0.1, 0.02]
-    fit = admm_lasso(x, y).penalty(lam).opts(maxit=5).fit()
     opts = dict(entry.LASSO_OPTS, maxit=5)
-    ref = entry.admm_lasso(x, y, lam, 100, 1e-4, True, True, opts)
-    assert list(fit.niter) == list(ref["niter"])
-    for j in range(3):
-        assert relerr(fit.beta_dense[:, j], ref["beta"][:, j]) < TOL, j
-    fit = admm_lasso(x, y).penalty(lam).fit()
-    ref = entry.admm_lasso(x, y, lam, 100, 1e-4, True, True, entry.LASSO_OPTS)
-    for j in range(3):
-        assert relerr(fit.beta_dense[:, j], ref["beta"][:, j]) < TOL, j
+    fit, _ = traced_parity(admm_lasso(x, y).penalty(lam).opts(maxit=5), _problem(x, y, 100, lam=lam, opts=opts), TOL, label="ragged maxit 5")
+    assert list(fit.niter) == [6, 6, 6]
+    fit, _ = traced_parity(admm_lasso(x, y).penalty(lam), _problem(x, y, 100, lam=lam), TOL, label="ragged")
+    assert fit.niter.max() < 10000
 
 
 def test_device_resident_input_matches_host_input():

@@ -87,3 +87,58 @@ int main(void) {
     r = subprocess.run([str(exe)], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
     assert r.returncode == 0 and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, (r.stdout, r.stderr[-2000:])
     assert len(r.stdout.split()) == 3
+
+
+def test_c_oracle_decision_trace_matches_numpy_oracle():
+    """The decision trace the compiled loop records (used by the p = 10 000 fixture, tests/golden/make_c2_short.py): same
+    (lambda, iteration) sequence, same outcomes and the same residuals / thresholds as the NumPy oracle's own trace on the
+    first lambdas of a path (before any rounding-level count flip), and consistent with the iteration counts returned."""
+    from oracle import ctall, entry
+    x, y = synth_lasso(600, 80, 8, seed=2)
+    tr = []
+    r = ctall.admm_lasso_c(x, y, None, 6, 1e-4, True, True, entry.LASSO_OPTS, mode=0, nthreads=1, trace=tr)
+    tr = np.asarray(tr)
+    d = {"trace": []}
+    ref = entry.admm_lasso(x, y, None, 6, 1e-4, True, True, entry.LASSO_OPTS, d)
+    rt = np.asarray(d["trace"], dtype=np.float64)
+    assert len(tr) == int(np.sum(r["niter"])) and len(rt) == int(np.sum(ref["niter"]))
+    # the two restatements round their triangular solves differently (own loops vs LAPACK), so somewhere along the path a
+    # near-tie flips an iteration count (tests/test_flip_floor.py): compare the lambdas before the first such flip
+    same = 0
+    while same < 6 and r["niter"][same] == ref["niter"][same]:
+        same += 1
+    assert same >= 3, (r["niter"], ref["niter"])
+    a, b = tr[tr[:, 0] < same], rt[rt[:, 0] < same]
+    assert np.array_equal(a[:, 0], b[:, 0]) and np.array_equal(a[:, 1], b[:, 1])
+    assert np.array_equal(a[:, 7].astype(int), b[:, 8].astype(int))                    # outcome: 0 stop, 1 accelerate, 2 restart
+    assert np.allclose(a[:, 2], b[:, 2], rtol=1e-4) and np.allclose(a[:, 3], b[:, 3], rtol=1e-4)      # eps_p, eps_d
+    assert np.allclose(a[:, 4], b[:, 4], rtol=1e-2)                                    # r_p
+    big = b[:, 5] > b[:, 3]                      # r_d = rho ||z - z_old||: single-ulp flips of a few z entries once it is below eps_d
+    assert big.sum() > 20 and np.allclose(a[big, 5], b[big, 5], rtol=0.1)
+    for l in range(6):                                                                 # one "stop" record ends every converged lambda
+        rows = tr[tr[:, 0] == l]
+        assert len(rows) == r["niter"][l] and rows[-1, 7] == 0 and (rows[:-1, 7] > 0).all()
+
+
+def test_c2_short_fixture_is_self_consistent():
+    """tests/golden/c2_short_path.npz (the compiled oracle at p = 10 000; the GPU test that uses it is
+    tests/test_gpu_fullsize.py::test_c2_width_short_path_vs_compiled_oracle_fixture): every recorded decision is the rule
+    applied to the residuals recorded with it, the counts are the trace's, and both kinds of exit occur."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c2_short_path.npz"))
+    t, niter, maxit = g["trace"], g["niter"], int(g["maxit"])
+    conv = (t[:, 4] < t[:, 2]) & (t[:, 5] < t[:, 3])
+    assert np.array_equal(conv, t[:, 7] == 0)
+    for l in range(len(niter)):
+        rows = t[t[:, 0] == l]
+        assert len(rows) == min(int(niter[l]), maxit)
+        assert (rows[-1, 7] == 0) == (niter[l] <= maxit)
+    c, code = t[:, 6], t[:, 7]
+    c_old = 9999.0
+    for k in range(len(t)):                         # the restart rule on the recorded c (FADMMBase.h:243-256), chained across lambdas
+        if code[k] == 0:
+            continue
+        assert (c[k] < 0.999 * c_old) == (code[k] == 1), k
+        c_old = c[k] if code[k] == 1 else c_old / 0.999
+    assert (niter == maxit + 1).any() and (niter <= maxit).any()
+    assert g["beta"].shape == (int(g["p"]) + 1, len(niter)) and np.isfinite(g["beta"]).all()
