@@ -467,6 +467,21 @@ class LassoPlan:
                                                        self._trace_cap, ctypes.byref(n)))
         return buf[:n.value].copy()
 
+    def enable_state(self, capacity):
+        """Also dump the iterates of every iteration of the following run() calls (tall and consensus solvers; include/admm_hip.h,
+        admm_hip_lasso_plan_state_*): record s = the iterates trace record s judged."""
+        check(self._lib.admm_hip_lasso_plan_state_enable(self._h, int(capacity)))
+        self._state_cap = int(capacity)
+
+    def read_state(self):
+        """(nrecords, record_floats) float32 array of the last run()."""
+        n, rf = ctypes.c_longlong(), ctypes.c_longlong()
+        check(self._lib.admm_hip_lasso_plan_state_read(self._h, None, 0, ctypes.byref(n), ctypes.byref(rf)))
+        buf = np.zeros((self._state_cap, rf.value), dtype=np.float32)
+        check(self._lib.admm_hip_lasso_plan_state_read(self._h, buf.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), self._state_cap,
+                                                       ctypes.byref(n), ctypes.byref(rf)))
+        return buf[:n.value].copy()
+
     def close(self):
         if self._h:
             check(self._lib.admm_hip_lasso_plan_destroy(self._h))

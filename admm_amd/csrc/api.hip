@@ -672,6 +672,24 @@ int admm_hip_lasso_plan_trace_read(admm_hip_plan* plan, double* out, long long c
     });
 }
 
+int admm_hip_lasso_plan_state_enable(admm_hip_plan* plan, long long capacity_records) {
+    return guarded([&] {
+        PlanHandle* h = reinterpret_cast<PlanHandle*>(plan);
+        ADMM_REQUIRE(h != nullptr && h->plan, "plan is NULL");
+        ADMM_REQUIRE(capacity_records > 0 && capacity_records <= (1ll << 22), "state capacity must be within [1, 2^22] records");
+        h->plan->enable_state(capacity_records);
+    });
+}
+
+int admm_hip_lasso_plan_state_read(admm_hip_plan* plan, float* out, long long cap_records, long long* nrecords_out, long long* record_floats_out) {
+    return guarded([&] {
+        PlanHandle* h = reinterpret_cast<PlanHandle*>(plan);
+        ADMM_REQUIRE(h != nullptr && h->plan, "plan is NULL");
+        ADMM_REQUIRE(nrecords_out != nullptr && cap_records >= 0 && (out != nullptr || cap_records == 0), "bad state output arguments");
+        *nrecords_out = h->plan->read_state(out, cap_records, record_floats_out);
+    });
+}
+
 const char* admm_hip_last_error(void) { return last_error_ref().c_str(); }
 const char* admm_hip_version(void) { return "admm_hip 0.2 (gfx950)"; }
 

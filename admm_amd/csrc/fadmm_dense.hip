@@ -116,6 +116,8 @@ dense_head_kernel(DenseParams q, int par) {
     const double* zo_ = cur ? q.z0 : q.z1; const double* yo_ = cur ? q.y0 : q.y1;
     const double t = out.tau, t1 = 1.0 + out.tau, rho = out.rho;
     for (int i = blockIdx.x * kDenseThreads + threadIdx.x; i < q.dim; i += gridDim.x * kDenseThreads) {
+        // no fused multiply-adds in the elementwise arithmetic: the reference is built without them (lasso_tall.hip, tall_update_elem)
+#pragma clang fp contract(off)
         double adjz, adjy;
         if (out.restart) { adjz = zo_[i]; adjy = yo_[i]; }
         else { adjz = t1 * zc_[i] - t * zo_[i]; adjy = t1 * yc_[i] - t * yo_[i]; }
@@ -136,6 +138,7 @@ dense_tail_kernel(DenseParams q, int par) {
     const double rho = c.rho, pen = 1.0 / rho;
     double acc[6] = {0, 0, 0, 0, 0, 0};
     for (int i = blockIdx.x * kDenseThreads + threadIdx.x; i < q.dim; i += gridDim.x * kDenseThreads) {
+#pragma clang fp contract(off)
         double g = 0.0;
         for (int s = 0; s < q.gout_nseg; ++s) g += q.gout[(size_t)s * q.gout_stride + i];
         const double adjy = q.adj_y[i], adjz = q.adj_z[i], zc = zc_[i];

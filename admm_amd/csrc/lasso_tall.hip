@@ -77,6 +77,8 @@ struct TallParams {
 #endif
     double* trace;              // optional [trace_cap][kTraceFields] decision records (admm_hip_lasso_plan_trace_*), or NULL
     long long trace_cap;
+    float* state;               // optional [state_cap][5][p] iterates x, z, y, adj_z, adj_y of every iteration (admm_hip_lasso_plan_state_*), or NULL
+    long long state_cap;
 };
 
 constexpr int kTailThreads = 256;
@@ -172,7 +174,7 @@ __device__ void tall_decide(const TallParams& q, int par) {
     if (q.trace != nullptr && in.total < q.trace_cap) {      // what FADMMBase.h:135-170 (print_row, commented out there) would print
         double* t = q.trace + (size_t)in.total * ADMM_TRACE_FIELDS;
         t[0] = in.lam_idx; t[1] = in.iter; t[2] = in.eps_primal; t[3] = in.eps_dual; t[4] = tr_rp; t[5] = tr_rd;
-        t[6] = tr_c; t[7] = in.adj_c; t[8] = tr_code; t[9] = in.rho; t[10] = in.rho; t[11] = 0.0;
+        t[6] = tr_c; t[7] = in.adj_c; t[8] = tr_code; t[9] = in.rho; t[10] = in.rho; t[11] = in.lam;
     }
 }
 
@@ -185,7 +187,12 @@ struct TallDecideExtra {
 // (1 + ratio) * cur - ratio * old without contraction, like the reference build (FADMMBase.h:247-248): the
 // same value is formed twice, as the candidate right-hand side and as adj of the next iteration.
 __device__ __forceinline__ float tall_extrapolate(float t1, float t, float cur, float old) {
-    return __fsub_rn(__fmul_rn(t1, cur), __fmul_rn(t, old));
+    // plain operators under contract(off): HIP's __fmul_rn / __fsub_rn are inline `x * y` / `x - y` written in a header that is
+    // compiled with contraction allowed, and the two were fused into v_pk_fma_f32 all the same
+#pragma clang fp contract(off)
+    const float a = t1 * cur;
+    const float b = t * old;
+    return a - b;
 }
 
 // State of one coordinate and its update: everything after the x-update in one iteration
@@ -202,6 +209,10 @@ __device__ __forceinline__ TallElem tall_load_elem(const TallParams& q, int par,
 
 template <bool WT = false>      // WT: u, w are consumed by other workgroups of the same launch -> write-through stores
 __device__ __forceinline__ void tall_update_elem(const TallParams& q, const TallCtl& c, int par, int i, const TallElem& e, float a, float b, double (&acc)[6]) {
+    // The reference is built without fused multiply-adds (R's default flags on x86-64: no -march, /root/reference/src/Makevars):
+    // every product below rounds before it is added, as there.  (__fmul_rn / __fadd_rn are plain operators in HIP and were
+    // contracted all the same: found by the stepwise check of oracle/stepcheck.py, round 3.)
+#pragma clang fp contract(off)
     float* zo_ = par ? q.z0 : q.z1; float* yo_ = par ? q.y0 : q.y1;
     const float zc = e.zc, yc = e.yc, zo = e.zo, yo = e.yo;
     if (c.fin_idx >= 0) q.beta[(size_t)c.fin_idx * q.p + i] = zc;     // get_z() snapshot (Lasso.cpp:108)
@@ -234,6 +245,10 @@ __device__ __forceinline__ void tall_update_elem(const TallParams& q, const Tall
     acc[0] = (double)r * r; acc[1] = (double)dz * dz; acc[2] = (double)daz * daz;
     acc[3] = (double)x * x; acc[4] = (double)zn * zn; acc[5] = (double)yn * yn;
     q.x[i] = x; zo_[i] = zn; yo_[i] = yn; q.adj_z[i] = adjz; q.adj_y[i] = adjy;
+    if (q.state != nullptr && c.total < q.state_cap) {     // record c.total = the trace record that will judge this iteration
+        float* s = q.state + (size_t)c.total * 5 * q.p;
+        s[i] = x; s[q.p + i] = zn; s[2 * (size_t)q.p + i] = yn; s[3 * (size_t)q.p + i] = adjz; s[4 * (size_t)q.p + i] = adjy;
+    }
     // both possible right-hand sides of the next x-update, rounded as ADMMLassoTall.h:70-80 does
     const float tn = (float)c.tau_next, tn1 = (float)(1.0 + c.tau_next);
     const float adjz_a = tall_extrapolate(tn1, tn, zn, zc), adjy_a = tall_extrapolate(tn1, tn, yn, yc);
@@ -496,6 +511,8 @@ struct TallPlan final : LassoPlan {
     TallParams q{};
     DevBuf<double> trace;
     long long trace_cap = 0, trace_n = 0;
+    DevBuf<float> state;
+    long long state_cap = 0;
     TallCtl* hctl = nullptr;
     PinnedFlag hflag;
 #ifdef ADMM_HIP_PROBE
@@ -664,6 +681,19 @@ struct TallPlan final : LassoPlan {
         return nrec;
     }
 
+    void enable_state(long long cap) override {
+        state.alloc((size_t)cap * 5 * p);
+        ADMM_HIP_CHECK(hipMemset(state.get(), 0, (size_t)cap * 5 * p * sizeof(float)));
+        state_cap = cap;
+        q.state = state.get(); q.state_cap = cap;
+    }
+    long long read_state(float* out, long long cap, long long* rec_floats) override {
+        if (rec_floats) *rec_floats = 5ll * p;
+        const long long nrec = std::min(std::min(trace_n, state_cap), cap);       // one record per decision, same numbering as the trace
+        if (nrec > 0 && out) ADMM_HIP_CHECK(hipMemcpy(out, state.get(), (size_t)nrec * 5 * p * sizeof(float), hipMemcpyDeviceToHost));
+        return nrec;
+    }
+
     void debug_dump(const char* tag, const float* dptr, size_t n) {
         std::vector<float> h(n);
         ADMM_HIP_CHECK(hipMemcpy(h.data(), dptr, n * sizeof(float), hipMemcpyDeviceToHost));
@@ -684,6 +714,8 @@ struct TallPlan final : LassoPlan {
         beta.zero(st); niter.zero(st);
         const int init_n = std::max(p, 2 * nwg * 8);
         hipLaunchKernelGGL(tall_init_kernel, dim3((init_n + 255) / 256), dim3(256), 0, st, q, rho, lam_int[0]);
+        if (q.state != nullptr)      // record 0 of the iterate dump (the cold start has no iterates): X'y as this solver holds it, in the x slot
+            ADMM_HIP_CHECK(hipMemcpyAsync(q.state, XY.get(), (size_t)p * sizeof(float), hipMemcpyDeviceToDevice, st));
         if (fused) { fflag.zero(st); farrive.zero(st); }
         hctl[0].done = hctl[1].done = 0;
         *hflag.p = 0;

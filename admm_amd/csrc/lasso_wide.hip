@@ -307,7 +307,7 @@ wide_x_kernel(WideParams q, int par) {
         if (q.trace != nullptr && in.total < q.trace_cap) {          // what ADMMBase.h:111-146 (print_row, commented out there) would print
             double* t = q.trace + (size_t)in.total * ADMM_TRACE_FIELDS;
             t[0] = in.lam_idx; t[1] = in.iter; t[2] = in.eps_primal; t[3] = in.eps_dual; t[4] = dec.rp; t[5] = dec.rd;
-            t[6] = out.rho; t[7] = out.type; t[8] = dec.code; t[9] = in.rho; t[10] = out.rho; t[11] = 0.0;
+            t[6] = out.rho; t[7] = out.type; t[8] = dec.code; t[9] = in.rho; t[10] = out.rho; t[11] = in.lam;
         }
     }
     const bool snap = lam_finished >= 0;                               // get_x() snapshot of the OLD x (Lasso.cpp:119)
@@ -727,6 +727,9 @@ wide_tail_kernel(WideParams q, int par, PeerExchange ex) {
     WIDE_PROBE(1);
     double acc[5] = {0, 0, 0, 0, 0};
     if (valid && sub == 0) {
+        // no fused multiply-adds: the reference is built without them (R's default flags, /root/reference/src/Makevars), so
+        // rho * Ax and rho * r round before they are added (lasso_tall.hip, tall_update_elem)
+#pragma clang fp contract(off)
         const float rho_f = (float)c.rho;
         const float den = (float)(-1.0 - c.rho);                      // Scalar(-1 - rho)   (:164)
         const float zn = (yd + yo + rho_f * ax) / den;                // next_z (:156-165)

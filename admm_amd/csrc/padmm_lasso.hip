@@ -50,6 +50,7 @@ struct ParParams {
     ParCtl* ctl;                   // [2]
     double* P;                     // [nwg][8] per-workgroup partials of the five sums
     double* trace; long long trace_cap;      // optional decision records (admm_hip_lasso_plan_trace_*), or NULL
+    float* state; long long state_cap;       // optional [state_cap][(1 + 2 Kl) p]: z, x_0 .. x_{Kl-1}, y_0 .. y_{Kl-1} of every iteration, or NULL
     float* beta; int* niter; int* done;
 #ifdef ADMM_HIP_PROBE
     long long* probe;
@@ -59,6 +60,8 @@ struct ParParams {
 // head: rhs_k = A_k'b_k - y_k + rho z (PADMMLasso.h:19-21) for the local workers.
 __global__ void __launch_bounds__(kParThreads)
 par_head_kernel(ParParams q) {
+    // no fused multiply-adds in the elementwise arithmetic: the reference is built without them (see lasso_tall.hip, tall_update_elem)
+#pragma clang fp contract(off)
     if (load_flag_vector(q.done)) return;
     // workers in groups of 8: the 16 loads of a group are requested together (one worker at a time was a chain of dependent
     // round trips: kernel arguments -> addresses -> values, per worker)
@@ -86,6 +89,8 @@ par_head_kernel(ParParams q) {
 // workgroup 0 also folds the previous iteration's per-workgroup norm partials into nsum[0..4].
 __global__ void __launch_bounds__(kParThreads)
 par_pack_kernel(ParParams q) {
+    // no fused multiply-adds in the elementwise arithmetic: the reference is built without them (see lasso_tall.hip, tall_update_elem)
+#pragma clang fp contract(off)
     __shared__ double scratch[5 * (kParThreads / 64)];
     if (load_flag_vector(q.done)) return;
     if (blockIdx.x == 0) {
@@ -133,6 +138,8 @@ par_pack_kernel(ParParams q) {
 // z_new = soft(w / K, lambda / (rho K)); y_k += rho (x_k - z_new); norms   (PADMMLasso.h:99-108, PADMMBase.h:70-78)
 __global__ void __launch_bounds__(kParThreads)
 par_z_kernel(ParParams q, int par) {
+    // no fused multiply-adds in the elementwise arithmetic: the reference is built without them (see lasso_tall.hip, tall_update_elem)
+#pragma clang fp contract(off)
     __shared__ double scratch[5 * (kParThreads / 64)];
     WIDE_PROBE_DECL
     WIDE_PROBE(0);
@@ -182,7 +189,7 @@ par_z_kernel(ParParams q, int par) {
         if (q.trace != nullptr && in.total < q.trace_cap) {
             double* t = q.trace + (size_t)in.total * ADMM_TRACE_FIELDS;
             t[0] = in.lam_idx; t[1] = in.iter; t[2] = in.eps_primal; t[3] = in.eps_dual; t[4] = tr_rp; t[5] = tr_rd;
-            t[6] = q.rho; t[7] = 0.0; t[8] = tr_code; t[9] = q.rho; t[10] = q.rho; t[11] = 0.0;
+            t[6] = q.rho; t[7] = 0.0; t[8] = tr_code; t[9] = q.rho; t[10] = q.rho; t[11] = in.lam;
         }
     }
     WIDE_PROBE(1);
@@ -210,6 +217,10 @@ par_z_kernel(ParParams q, int par) {
                     const float r = x - zn;
                     const float yn = yv[u] + rho_f * r;
                     q.y[(size_t)(k0 + u) * q.ldv + i] = yn;
+                    if (q.state != nullptr && out.total < q.state_cap) {     // record out.total = the trace record that will judge this iteration
+                        float* s = q.state + (size_t)out.total * (1 + 2 * (size_t)q.Kl) * q.p;
+                        s[(size_t)(1 + k0 + u) * q.p + i] = x; s[(size_t)(1 + q.Kl + k0 + u) * q.p + i] = yn;
+                    }
                     acc[0] += (double)x * x; acc[1] += (double)yn * yn; acc[2] += (double)r * r;
                 }
             }
@@ -217,6 +228,7 @@ par_z_kernel(ParParams q, int par) {
         const float dz = zn - zo;
         acc[3] += (double)zn * zn; acc[4] += (double)dz * dz;
         q.z[i] = zn;
+        if (q.state != nullptr && out.total < q.state_cap) q.state[(size_t)out.total * (1 + 2 * (size_t)q.Kl) * q.p + i] = zn;
     }
     if (out.done) return;
     WIDE_PROBE(2);
@@ -251,6 +263,23 @@ __global__ void copy_rows_kernel(const float* X, long long ldx, int row0, int nr
     const int j = blockIdx.x;
     for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < nrows; i += gridDim.y * blockDim.x)
         A[(size_t)j * lda + i] = X[(size_t)j * ldx + row0 + i];
+}
+
+// (G + rho I)^-1 of a worker's small system, cached for the whole path (rho never changes: PADMMBase.h:147-159).  Same policy
+// as the tall solver (lasso_tall.hip): below order 4096 the float Gram is factorised and inverted in DOUBLE and rounded to
+// float once.  The reference solves with a float Cholesky factor (PADMMLasso.h:23-29); a float-built explicit inverse loses
+// cond(G + rho I) ulps per entry, and the Woodbury form of a wide block then amplifies that by (sigma^2 + rho) / rho when it
+// subtracts A'(...)A rhs from rhs: the stepwise check (oracle/stepcheck.py, round 3) measured x_k errors of up to 15 x the
+// reference's own on ill-conditioned blocks with the float-built inverse.
+static void par_inverse(float* M, long long ldm, int order, double rho, hipStream_t st) {
+    bool inv64 = order < 4096;
+    if (const char* e = std::getenv("ADMM_HIP_INVERSE")) inv64 = std::string(e) == "f64";
+    if (inv64) {
+        spd_inverse_f32_via_f64(M, ldm, order, (double)(float)rho, st);
+    } else {
+        add_diag<float>(M, ldm, order, (float)rho, st);
+        spd_inverse_f32(M, ldm, order, st);
+    }
 }
 
 struct ParWorker {
@@ -292,6 +321,23 @@ struct ParPlan final : LassoPlan {
     long long read_trace(double* out, long long cap) override {
         const long long nrec = std::min(std::min(trace_n, trace_cap), cap);
         if (nrec > 0) ADMM_HIP_CHECK(hipMemcpy(out, trace.get(), (size_t)nrec * ADMM_TRACE_FIELDS * sizeof(double), hipMemcpyDeviceToHost));
+        return nrec;
+    }
+
+    DevBuf<float> state;
+    long long state_cap = 0;
+    void enable_state(long long cap) override {
+        const size_t rec = (size_t)(1 + 2 * Kl) * p;
+        state.alloc((size_t)cap * rec);
+        ADMM_HIP_CHECK(hipMemset(state.get(), 0, (size_t)cap * rec * sizeof(float)));
+        state_cap = cap;
+        q.state = state.get(); q.state_cap = cap;
+    }
+    long long read_state(float* out, long long cap, long long* rec_floats) override {
+        const size_t rec = (size_t)(1 + 2 * Kl) * p;
+        if (rec_floats) *rec_floats = (long long)rec;
+        const long long nrec = std::min(std::min(trace_n, state_cap), cap);
+        if (nrec > 0 && out) ADMM_HIP_CHECK(hipMemcpy(out, state.get(), (size_t)nrec * rec * sizeof(float), hipMemcpyDeviceToHost));
         return nrec;
     }
 
@@ -348,8 +394,7 @@ struct ParPlan final : LassoPlan {
                 gram_full<float>(w.A.get(), w.lda, w.rows, p, true, w.Minv.get(), w.ldm, st);
                 ADMM_HIP_CHECK(hipStreamSynchronize(st));
                 t_gram += now_s() - t0; t0 = now_s();
-                add_diag<float>(w.Minv.get(), w.ldm, p, (float)rho, st);
-                spd_inverse_f32(w.Minv.get(), w.ldm, p, st);
+                par_inverse(w.Minv.get(), w.ldm, p, rho, st);
                 w.gM.init(w.Minv.get(), w.ldm, p, p);
                 A_release_if_tall(w);
             } else {
@@ -358,8 +403,7 @@ struct ParPlan final : LassoPlan {
                 gram_full<float>(w.A.get(), w.lda, w.rows, p, false, w.Minv.get(), w.ldm, st);
                 ADMM_HIP_CHECK(hipStreamSynchronize(st));
                 t_gram += now_s() - t0; t0 = now_s();
-                add_diag<float>(w.Minv.get(), w.ldm, w.rows, (float)rho, st);
-                spd_inverse_f32(w.Minv.get(), w.ldm, w.rows, st);
+                par_inverse(w.Minv.get(), w.ldm, w.rows, rho, st);
                 w.ldat = round_up(p, 32);
                 w.At.alloc((size_t)w.ldat * w.rows); w.At.zero(st);
                 transpose<float>(w.A.get(), w.lda, w.rows, p, w.At.get(), w.ldat, st);
@@ -411,6 +455,9 @@ struct ParPlan final : LassoPlan {
         beta.zero(st); niter.zero(st);
         const int init_n = std::max(p, nwg * 8);
         hipLaunchKernelGGL(par_init_kernel, dim3((init_n + 255) / 256), dim3(256), 0, st, q, lam_int[0]);
+        if (q.state != nullptr)      // record 0 of the iterate dump: A_k'b_k as the workers hold them, in the x_k slots
+            for (int k = 0; k < Kl; ++k)
+                ADMM_HIP_CHECK(hipMemcpyAsync(q.state + (size_t)(1 + k) * p, Ab.get() + (size_t)k * ldv, (size_t)p * sizeof(float), hipMemcpyDeviceToDevice, st));
         const int* skip = done.get();
         const int nwg_e = std::max(1, std::min(4 * device_info().num_cu, (p + kParThreads - 1) / kParThreads));
         const int batch = pb.batch_iters > 0 ? (pb.batch_iters + 1) / 2 * 2 : 16;

@@ -38,6 +38,9 @@ struct LassoPlan {
     // per-decision trace of the iteration control (admm_hip_lasso_plan_trace_*); solvers without one refuse
     virtual void enable_trace(long long) { throw Error(ADMM_ERR_INVALID_ARG, "this solver records no decision trace"); }
     virtual long long read_trace(double*, long long) { return 0; }
+    // per-iteration iterate dump (admm_hip_lasso_plan_state_*): tall and consensus solvers
+    virtual void enable_state(long long) { throw Error(ADMM_ERR_INVALID_ARG, "this solver records no iterate dump"); }
+    virtual long long read_state(float*, long long, long long*) { return 0; }
 };
 std::unique_ptr<LassoPlan> make_tall_plan(DeviceData<float>&& d, const LassoProblem& pb, hipStream_t st);
 std::unique_ptr<LassoPlan> make_wide_plan(DeviceData<float>&& d, const LassoProblem& pb, hipStream_t st);

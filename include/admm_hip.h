@@ -192,7 +192,8 @@ ADMM_HIP_API int admm_hip_lasso_plan_destroy(admm_hip_plan* plan);
  *   [0] lambda index  [1] iteration i within the lambda  [2] eps_primal  [3] eps_dual  (the thresholds iteration i was tested against)
  *   [4] resid_primal  [5] resid_dual  [6] c = rho r_p^2 + rho ||z - adj_z||^2 (0 when converged)  [7] c_old (adj_c before)
  *   [8] outcome ADMM_TRACE_*  [9] rho the iteration ran with  [10] rho after this decision (the adaptation of
- *   FADMMBase.h:109-133 / ADMMBase.h:85-109 where the solver adapts: wide, LAD, BP)  [11] reserved (0)
+ *   FADMMBase.h:109-133 / ADMMBase.h:85-109 where the solver adapts: wide, LAD, BP)  [11] the penalty lambda the iteration
+ *   ran with, in the solver's internal units (lambda n / scaleY, Lasso.cpp:99; 0 for LAD / BP)
  * Wide solver (ADMMBase::solve, rho adaptation ADMMBase.h:85-109): [6] rho AFTER this decision's adaptation, [7] kind of
  * the x-update that follows (0 zero, 1 regular, 2 active set), [9] rho before; consensus solver: [6] = [9] = rho, [7] = 0.
  * The parity tests use it to show that a lambda whose iteration count differs from the oracle's diverged at a
@@ -205,6 +206,18 @@ ADMM_HIP_API int admm_hip_lasso_plan_destroy(admm_hip_plan* plan);
 #define ADMM_TRACE_CONTINUE 1       /* wide / consensus solvers (no acceleration): not converged    (ADMMBase.h:206-207, PADMMBase.h:230-231) */
 ADMM_HIP_API int admm_hip_lasso_plan_trace_enable(admm_hip_plan* plan, long long capacity_records);
 ADMM_HIP_API int admm_hip_lasso_plan_trace_read(admm_hip_plan* plan, double* out, long long cap_records, long long* nrecords_out);
+/* Iterate dump of a prepared problem (tall and consensus solvers; test / diagnosis facility): the vectors every ADMM
+ * iteration leaves behind, in the solver's own (standardised) units, one record per decision with the SAME numbering as
+ * the decision trace -- record s holds the iterates whose residuals trace record s judged (record 0, the cold start, is
+ * zero).  Tall solver (FADMMBase.h:185-211): 5 p floats  x | z | y | adj_z | adj_y  (main_x, aux_z, dual_y and the
+ * extrapolated pair the iteration started from).  Consensus solver (PADMMBase.h:174-214), K row blocks:
+ * (1 + 2 K) p floats  z | x_0 .. x_{K-1} | y_0 .. y_{K-1}.  With it a test can replay the reference's arithmetic for
+ * ONE iteration from the library's own previous iterates (oracle/stepcheck.py): every step of a run is then checked on its
+ * own, however far two executions have drifted apart over hundreds of iterations at the rounding floor.
+ * enable() before run(); read() afterwards (out may be NULL with cap_records = 0 to query the sizes). */
+ADMM_HIP_API int admm_hip_lasso_plan_state_enable(admm_hip_plan* plan, long long capacity_records);
+ADMM_HIP_API int admm_hip_lasso_plan_state_read(admm_hip_plan* plan, float* out, long long cap_records, long long* nrecords_out,
+                                                long long* record_floats_out);
 
 /* ---- one process per GPU: consensus Lasso with its row blocks spread over ranks (RCCL over xGMI).
  * Bootstrap: rank 0 calls admm_hip_comm_unique_id and ships the ADMM_HIP_UNIQUE_ID_BYTES bytes to the

@@ -31,6 +31,8 @@ def _attach(solver, detail):
         return
     if detail.get("trace") is not None:
         solver.trace = detail["trace"]
+    if detail.get("state") is not None:
+        solver.state_log = detail["state"]
     if detail.get("follow") is not None:
         solver.follow = iter(detail["follow"])
         solver.follow_band = float(detail.get("follow_band", 8.0))

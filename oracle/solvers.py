@@ -43,7 +43,8 @@ def _soft_d(vec, penalty, T):
 
 def _enet_f(vec, penalty, alpha):
     """enet(): ADMMEnet.h:24-40 / :67-83 -- thresh and denom are floats."""
-    thresh = F(F(alpha) * penalty)          # Scalar thresh = alpha * penalty (double product -> float)
+    penalty = np.float64(penalty)           # (a Python float would make NumPy 2 form the products in float32)
+    thresh = F(np.float64(F(alpha)) * penalty)          # Scalar thresh = alpha * penalty (double product -> float)
     denom = F(1.0 + penalty * (1.0 - np.float64(F(alpha))))
     v = vec
     out = np.where(v > thresh, (v - thresh) / denom, np.where(v < -thresh, (v + thresh) / denom, F(0)))
@@ -106,6 +107,7 @@ class FADMM:
     forced = None
     ndecisions = 0
     _followed = None
+    state_log = None  # set to a list to collect (x, z, y, adj_z, adj_y) of every iteration, like admm_hip_lasso_plan_state_* (oracle/stepcheck.py)
 
     def _trace(self, i, c, c_old, code, rho_in):
         if self.trace is not None:
@@ -120,11 +122,28 @@ class FADMM:
         pen = abs(float(getattr(self, "lam", 0.0))) / self.rho if hasattr(self, "lam") else 1.0 / self.rho
         uz = float(np.linalg.norm(np.spacing((np.abs(self.aux_z) + T(pen)).astype(T)).astype(np.float64)))
         ux = float(np.linalg.norm(np.spacing(np.abs(self.main_x).astype(T)).astype(np.float64)))
+        # the x-update is a linear solve: its rounding error is cond(M) ulps of x, not one (`_solve_noise`, measured); z is a
+        # soft-threshold of x + y/rho, so it carries the same error on its support
+        ex = self._solve_noise() / self.follow_band if self.follow_band > 0 else 0.0
+        ux, uz = np.hypot(ux, ex), np.hypot(uz, ex)
         n_p = np.hypot(ux, uz)
         n_d = self.rho * 2.0 * uz                                   # z - old_z: both move
         daz = float(np.sqrt(np.float64(_sqnorm(self.aux_z - self.adj_z, T))))
         n_c = 2.0 * self.rho * (self.resid_primal * n_p + daz * 3.0 * uz)     # adj_z = (1+t) z - t z_old: up to 3 ulps of z
+        # c = rho (||r||^2 + ||z - adj_z||^2) is QUADRATIC in the perturbation: where r and z - adj_z vanish exactly (x = z in
+        # float: every |y / rho| and lambda / rho below half an ulp of x) the first-order term is zero and b ulps move c by
+        # rho (n_p^2 + 9 uz^2) b^2
+        self._n_c2 = self.rho * (n_p * n_p + 9.0 * uz * uz)
         return n_p, n_d, n_c
+
+    def _solve_noise(self):
+        """|| x - x_exact ||_2 of the x-update just made: the distance between this run's float solve and the same system
+        solved in double (rounded to float) -- ONE realisation of the rounding error any float implementation of the
+        reference's x-update makes on this right-hand side (another correct implementation makes an error of the same
+        size in another direction).  Counted ONCE, not scaled by the band (`_noise` divides it out): a decision may be taken
+        from the followed run if moving x by its own measured solve error, plus `follow_band` ulps of every entry, reaches
+        it.  0 where the x-update is not a solve whose error is measured (LAD / BP: float64, never needed)."""
+        return 0.0
 
     def _decide(self, i, own, c, c_old):
         """own: this run's outcome (0 converged, 1 accelerate, 2 restart).  Returns the outcome to act on."""
@@ -150,7 +169,11 @@ class FADMM:
                 ulps = min(-gp / max(n_p, tiny), -gd / max(n_d, tiny))
         else:
             kind = "restart"
-            ulps = abs(c - 0.999 * c_old) / max(2.0 * n_c, tiny)     # c_old carries the same noise from the previous iteration
+            gap, a2 = abs(c - 0.999 * c_old), self._n_c2             # c_old carries the same noise from the previous iteration:
+            if a2 * gap > 1e-6 * n_c * n_c:                          # 2 (n_c b + a2 b^2) = gap
+                ulps = (-n_c + np.sqrt(n_c * n_c + 2.0 * a2 * gap)) / (2.0 * a2)
+            else:
+                ulps = gap / max(2.0 * n_c, tiny)
         rec = dict(record=self.ndecisions - 1, lam=self.lam_idx, iter=i, kind=kind, ulps=float(ulps), own=own, theirs=theirs)
         if ulps > self.follow_band:
             raise FollowMismatch(f"decision differs beyond rounding noise: {rec}")
@@ -178,6 +201,8 @@ class FADMM:
             r = self.next_residual()
             self.resid_primal = np.float64(T(np.linalg.norm(r)))
             self.dual_y = (self.adj_y + T(self.rho) * r).astype(T)
+            if self.state_log is not None:
+                self.state_log.append(np.concatenate([self.main_x, self.aux_z, self.dual_y, self.adj_z, self.adj_y]).astype(T))
             converged = self.resid_primal < self.eps_primal and self.resid_dual < self.eps_dual     # :213-217
             old_c = self.adj_c
             c = (self.rho * self.resid_primal * self.resid_primal
@@ -267,6 +292,20 @@ class LassoTall(FADMM):
         rhs = (self.XY - self.adj_y).astype(F)
         rhs = (rhs.astype(np.float64) + self.rho * self.adj_z.astype(np.float64)).astype(F)
         return sla.cho_solve(self.chol, rhs, check_finite=False).astype(F)
+
+    def _solve_noise(self):
+        """FADMM._solve_noise for x = (X'X + rho I)^-1 rhs: the float system (as the reference factorises it) solved in
+        double on the float right-hand side of this iteration, against the x this run computed."""
+        if getattr(self, "_chol64_rho", None) != self.rho:
+            XX = (self.X.T @ self.X).astype(F).astype(np.float64)
+            XX[np.arange(self.p), np.arange(self.p)] += np.float64(F(self.rho))
+            self._chol64 = sla.cho_factor(XX, lower=True, check_finite=False)
+            self._chol64_rho = self.rho
+        rhs = (self.XY - self.adj_y).astype(F)
+        rhs = (rhs.astype(np.float64) + self.rho * self.adj_z.astype(np.float64)).astype(F)
+        # adj_z / adj_y still hold the values this iteration's x-update used (they are replaced after the decision)
+        xe = sla.cho_solve(self._chol64, rhs.astype(np.float64), check_finite=False)
+        return float(np.linalg.norm(self.main_x.astype(np.float64) - xe))
 
     def next_z(self):                                       # :81-85 / ADMMEnet.h:41-45
         vec = (self.main_x + self.adj_y / F(self.rho)).astype(F)
@@ -514,10 +553,12 @@ class PADMMLasso:
                           + np.sqrt(float(p * K)) * self.eps_abs)
             yn = sum(np.float64(_sqnorm(y, F)) for y in self.y)
             eps_dual = np.sqrt(yn) * self.eps_rel + np.sqrt(float(p * K)) * self.eps_abs
+            rhs_used = []
             for k in range(K):                                              # worker next_x PADMMLasso.h:17-31
                 A = self.A[k]
                 rhs = (self.Ab[k] - self.y[k]).astype(F)
                 rhs = (rhs.astype(np.float64) + self.rho * self.aux_z.astype(np.float64)).astype(F)
+                rhs_used.append(rhs)
                 if A.shape[0] >= A.shape[1]:
                     self.x[k] = self._solve(k, rhs)
                 else:
@@ -539,6 +580,8 @@ class PADMMLasso:
                 coll += np.float64(_sqnorm(r, F))
                 self.y[k] = (self.y[k] + F(self.rho) * r).astype(F)
             resid_primal = np.sqrt(coll)
+            if self.state_log is not None:
+                self.state_log.append(np.concatenate([self.aux_z] + list(self.x) + list(self.y)).astype(F))
             converged = resid_primal < eps_primal and resid_dual < eps_dual
             self.ndecisions += 1
             if self.follow is not None:
@@ -548,7 +591,13 @@ class PADMMLasso:
                 if (int(g[8]) == 0) != converged:
                     pen = abs(float(self.lam)) / (self.rho * K)
                     uz = _ulp_norm(self.aux_z, F, pen)
-                    n_p = float(np.sqrt(sum(_ulp_norm(x, F) ** 2 for x in self.x) + K * uz ** 2))
+                    # the workers' x-updates are linear solves (Cholesky, or Woodbury whose last step cancels
+                    # (sigma^2 + rho) / rho digits): their rounding error E = sqrt(sum_k ||x_k - x_k exact||^2), measured on
+                    # this iteration's right-hand sides (`_solve_noise`), counted once (not scaled by the band); z is a
+                    # soft-threshold of the mean of the x_k + y_k / rho and carries at most E / sqrt(K) of it
+                    E = self._solve_noise(rhs_used) / self.follow_band if self.follow_band > 0 else 0.0
+                    uz = float(np.hypot(uz, E / np.sqrt(K)))
+                    n_p = float(np.sqrt(sum(_ulp_norm(x, F) ** 2 for x in self.x) + E * E + K * uz ** 2))
                     n_d = self.rho * np.sqrt(K) * 2.0 * uz
                     ulps = _stop_ulps(resid_primal, eps_primal, n_p, resid_dual, eps_dual, n_d, converged)
                     rec = dict(record=self.ndecisions - 1, lam=self.lam_idx, iter=it, kind="stop", ulps=float(ulps))
@@ -562,6 +611,23 @@ class PADMMLasso:
                 return it + 1
         return maxit + 1
 
+    def _solve_noise(self, rhs_used):
+        """sqrt(sum_k || x_k - x_k exact ||^2): every worker's system (float Gram + float rho, as the reference builds it)
+        solved in double on the float right-hand side it just used, against the x_k this run computed (FADMM._solve_noise)."""
+        if getattr(self, "_m64_rho", None) != self.rho:
+            self._m64 = []
+            for A in self.A:
+                A64 = A.astype(np.float64)
+                M = A64.T @ A64
+                M[np.arange(self.p), np.arange(self.p)] += np.float64(F(self.rho))
+                self._m64.append(sla.cho_factor(M, lower=True, check_finite=False))
+            self._m64_rho = self.rho
+        e2 = 0.0
+        for k in range(self.K):
+            xe = sla.cho_solve(self._m64[k], rhs_used[k].astype(np.float64), check_finite=False)
+            e2 += float(np.sum((self.x[k].astype(np.float64) - xe) ** 2))
+        return float(np.sqrt(e2))
+
     def _solve(self, k, v):
         """(A'A + rho I)^-1 v or (AA' + rho I)^-1 v with the rounding of `xmode`."""
         if self.xmode == "llt32":
@@ -572,6 +638,7 @@ class PADMMLasso:
 
     xmode = "llt32"
     trace = None
+    state_log = None
     follow = None
     follow_band = 8.0
     forced = None

@@ -20,7 +20,9 @@ import scipy.linalg as sla
 from . import entry, solvers
 
 F = np.float32
-MODES = ("llt32", "inv32", "inv64r", "exact")
+MODES = ("llt32", "inv32", "inv64r", "exact", "stats64")
+#  stats64  the oracle proper (llt32) with the column statistics of DataStd accumulated in double and rounded once
+#           (libadmm_hip's prep kernels) instead of in float (the reference, in Eigen's order): oracle/datastd.py
 
 
 class LassoTallVariant(solvers.LassoTall):
@@ -60,13 +62,19 @@ def tall_variant(mode):
     """Within the block oracle.entry's tall solver -- and the consensus solver's workers (llt32 / inv32 / exact; inv64r
     runs as inv32 there) -- use the given x-update rounding."""
     assert mode in MODES
-    cls = type("LassoTall_" + mode, (LassoTallVariant,), {"mode": mode})
+    from .datastd import DataStd
+    xmode = "llt32" if mode == "stats64" else mode
+    cls = type("LassoTall_" + xmode, (LassoTallVariant,), {"mode": xmode})
     orig = entry.LassoTall
     orig_par = solvers.PADMMLasso.xmode
+    orig_acc = DataStd.acc
     entry.LassoTall = cls
-    solvers.PADMMLasso.xmode = {"llt32": "llt32", "exact": "exact"}.get(mode, "inv32")
+    solvers.PADMMLasso.xmode = {"llt32": "llt32", "exact": "exact"}.get(xmode, "inv32")
+    if mode == "stats64":
+        DataStd.acc = np.float64
     try:
         yield
     finally:
         entry.LassoTall = orig
         solvers.PADMMLasso.xmode = orig_par
+        DataStd.acc = orig_acc

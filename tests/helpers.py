@@ -38,41 +38,60 @@ def synth_lasso(n, p, m, seed=123, sd=2.0):
 #   R2  on that common trajectory the iteration counts are identical for every lambda and every beta column is within
 #       `tol` (1e-4, the north_star bar) of the oracle's;
 #   R3  the only columns that may exceed `tol` are those where the reference's own formula loses the digits: they must be
-#       within `factor` (5) x the distance the oracle's two rounding variants, following the same decisions, have
-#       drifted from it by that lambda
+#       within `factor` (5) x the distance the oracle's rounding variants (oracle/variants.py: the x-update as a float
+#       inverse / as an exact solve; the column statistics of DataStd accumulated in double instead of float), following
+#       the same decisions, have drifted from it by that lambda
 #       (e.g. maxit = 7 with rho five orders below the automatic value: z = (x + y/rho) - lambda/rho cancels 5 digits).
 #       The number of such columns is returned; tests bound and print it.
-# R4  (round 3) follow mode is only as strict as the number of decisions it hands over: every traced test therefore ASSERTS
-#     a ceiling on them -- at most NEAR_TIE_RATE of the decisions (never fewer than NEAR_TIE_MIN allowed, so that one
-#     near-tie in a short run is not a failure) and none needing more than NEAR_TIE_ULPS of rounding -- instead of printing
-#     them.  The ceilings are set from the measured distribution of profiles/r03_soak_summary.md (7 000 random cases):
-#     a systematic bias of the GPU's residuals or thresholds that stays inside the 8-ulp band would multiply the rate of
-#     near-ties and push their ulps towards the band, and fails here.
-NEAR_TIE_RATE = 0.01
-NEAR_TIE_MIN = 3
-NEAR_TIE_ULPS = 6.0
+# R4  (round 3) follow mode is only as strict as the decisions it hands over, so every traced test ASSERTS ceilings on them
+#     instead of printing them.  Measured over the 6 864 passing cases of profiles/r03_soak_summary.md (11.1 M decisions):
+#     near-ties are 0.2-1 per 1000 decisions for the wide / consensus / LAD / BP solvers and 9-10 per 1000 for the tall
+#     family, where they cluster in unstandardised problems: there the dual residual rho ||z - z_old|| of a finished lambda
+#     is a handful of single-ulp flips of z, i.e. quantised right at its threshold, and EVERY lambda ends on a decision
+#     inside one rounding (per-case rate: median 0.8 %, 99th percentile 12 %).  What a biased kernel would change is not
+#     their number but their SIZE: the ulps needed are 0.03 at the median, 0.5 at the 90th and 4.5 at the 99th percentile.
+#     Hence three ceilings:  (a) near-ties that need more than NEAR_TIE_SMALL (2) ulps: at most max(2, 0.3 % of the decisions);
+#     (b) none beyond NEAR_TIE_ULPS (7.5; the band itself is 8);  (c) all of them together: at most max(5, 15 %).
+#     A systematic bias of the residuals or thresholds that stays inside the band pushes near-ties out of the "inside one
+#     rounding" class and fails (a); tests/test_gpu_fuzz.py adds an aggregate ceiling over its fixed sweep.
+NEAR_TIE_SMALL = 2.0
+NEAR_TIE_LARGE_RATE = 0.003
+NEAR_TIE_ULPS = 7.5
+NEAR_TIE_TOTAL_RATE = 0.15
 
 
-def assert_near_tie_budget(forced, ndecisions, label="", rate=NEAR_TIE_RATE, at_least=NEAR_TIE_MIN, max_ulps=NEAR_TIE_ULPS):
-    """R4: the decisions the oracle took from the GPU (`forced`, dicts with kind / ulps) are few and small."""
-    if rate is None:
+def near_tie_stats(forced):
+    sized = [f["ulps"] for f in forced if f["kind"] != "rho"]
+    return dict(total=len(forced), large=sum(1 for v in sized if v > NEAR_TIE_SMALL), max_ulps=max(sized, default=0.0))
+
+
+def assert_near_tie_budget(forced, ndecisions, label="", enabled=True):
+    """R4: the decisions the oracle took from the GPU (`forced`, dicts with kind / ulps / lam / iter) are rounding-sized."""
+    if not enabled:
         return
-    allowed = max(int(at_least), int(np.ceil(rate * ndecisions)))
-    assert len(forced) <= allowed, (label, f"{len(forced)} of {ndecisions} decisions taken from the GPU as near-ties; at most {allowed} allowed",
-                                    [(f["lam"], f["iter"], f["kind"], round(f["ulps"], 2)) for f in forced][:10])
-    big = [(f["lam"], f["iter"], f["kind"], round(f["ulps"], 2)) for f in forced if f["kind"] != "rho" and f["ulps"] > max_ulps]
-    assert not big, (label, f"near-ties needing more than {max_ulps} ulps of rounding", big)
+    st = near_tie_stats(forced)
+    show = [(f["lam"], f["iter"], f["kind"], round(f["ulps"], 2)) for f in forced if f["kind"] != "rho" and f["ulps"] > NEAR_TIE_SMALL][:10]
+    allowed_large = max(2, int(np.ceil(NEAR_TIE_LARGE_RATE * ndecisions)))
+    assert st["large"] <= allowed_large, (label, f"{st['large']} of {ndecisions} decisions taken from the GPU needed more than {NEAR_TIE_SMALL} ulps of "
+                                          f"rounding; at most {allowed_large} allowed", show)
+    assert st["max_ulps"] <= NEAR_TIE_ULPS, (label, f"a near-tie needing {st['max_ulps']:.2f} ulps of rounding (ceiling {NEAR_TIE_ULPS})", show)
+    allowed = max(5, int(np.ceil(NEAR_TIE_TOTAL_RATE * ndecisions)))
+    assert st["total"] <= allowed, (label, f"{st['total']} of {ndecisions} decisions taken from the GPU as near-ties; at most {allowed} allowed")
 
 
-def traced_fit(model, capacity=1 << 18):
-    """Run a configured ADMM_Lasso / ADMM_Enet model through the prepared-problem entry points with the decision trace."""
+def traced_fit(model, capacity=1 << 18, state=False):
+    """Run a configured ADMM_Lasso / ADMM_Enet model through the prepared-problem entry points with the decision trace
+    (and, with state=True, the iterate dump of every iteration: returns (fit, trace, state))."""
     from admm_amd.api import LassoPlan
     plan = LassoPlan(model)
     plan.enable_trace(capacity)
+    if state:
+        plan.enable_state(capacity)
     fit = plan.run()
     trace = plan.read_trace()
+    st = plan.read_state() if state else None
     plan.close()
-    return fit, trace
+    return (fit, trace, st) if state else (fit, trace)
 
 
 def assert_rho_self_consistent(trace, first_iter, label=""):
@@ -182,16 +201,15 @@ def assert_followed_parity(beta, niter, trace, problem, tol=1e-4, band=8.0, labe
     nstop = sum(1 for f in forced if f["kind"] == "stop")
     fm = max([f["ulps"] for f in forced if f["kind"] == "stop"], default=0.0)
     print(f"[parity {label}] {nrec} decisions, {nstop} stopping near-ties (largest needs {fm:.2f} ulps) and {len(forced) - nstop} rho near-ties "
-          f"taken from the GPU; niter identical; max beta err {max(errs):.2e}")
-    if budget:
-        assert_near_tie_budget(forced, nrec, label)
+          f"taken from the GPU ({near_tie_stats(forced)['large']} need > {NEAR_TIE_SMALL:g} ulps); niter identical; max beta err {max(errs):.2e}")
+    assert_near_tie_budget(forced, nrec, label, enabled=budget)
     bad = [(j, e) for j, e in enumerate(errs) if e >= tol]
     if bad and problem.get("nthread") is not None:
         # consensus solver: like R3 of the tall rule -- a column may exceed `tol` only within `factor` x the distance the
         # oracle's own rounding variants of the workers' solves (float inverse, exact), following the same decisions,
         # have drifted from it by that lambda (paths that run into maxit accumulate the rounding of hundreds of solves)
         drift = np.zeros(nl)
-        for mode in ("inv32", "exact"):
+        for mode in ("inv32", "exact", "stats64"):
             v, _, _ = oracle_following(trace, band=1e9, mode=mode, **problem)
             drift = np.maximum(drift, [col_err(v["beta"][:, j], ref["beta"][:, j], floor) for j in range(nl)])
         drift = np.maximum.accumulate(drift)
@@ -245,7 +263,7 @@ def assert_tall_parity(beta, niter, trace, problem, tol=1e-4, factor=5.0, band=8
     errs_eff = [0.0 if errs[j] * scales[j] <= 2.0 * quanta[j] else errs[j] for j in range(nl)]
     if max(errs_eff) >= tol:                                                     # R3
         drift = np.zeros(nl)
-        for mode in ("inv32", "exact"):
+        for mode in ("inv32", "exact", "stats64"):
             v, _, _ = oracle_following(trace, band=1e9, mode=mode, **problem)
             drift = np.maximum(drift, [col_err(v["beta"][:, j], ref["beta"][:, j], floor) for j in range(nl)])
         drift = np.maximum.accumulate(drift)        # along a warm-started path the drift of a lambda carries into the next ones
@@ -257,11 +275,10 @@ def assert_tall_parity(beta, niter, trace, problem, tol=1e-4, factor=5.0, band=8
                 loose.append(j)
     fm = max([f["ulps"] for f in forced], default=0.0)
     first = forced[0]["lam"] if forced else None
-    print(f"[parity {label}] {nrec} decisions, {len(forced)} near-ties taken from the GPU (largest needs {fm:.2f} ulps of rounding, "
-          f"first at lambda {first}); niter identical; max beta err {max(errs):.2e}; columns beyond {tol:g}: {len(loose)} of {nl}"
+    print(f"[parity {label}] {nrec} decisions, {len(forced)} near-ties taken from the GPU ({near_tie_stats(forced)['large']} need > {NEAR_TIE_SMALL:g} ulps; "
+          f"largest needs {fm:.2f} ulps of rounding, first at lambda {first}); niter identical; max beta err {max(errs):.2e}; columns beyond {tol:g}: {len(loose)} of {nl}"
           + (f" {loose} (oracle rounding variants differ by {yard:.2e})" if loose else ""))
-    if budget:
-        assert_near_tie_budget(forced, nrec, label)
+    assert_near_tie_budget(forced, nrec, label, enabled=budget)
     return dict(forced=forced, max_ulps=fm, first_forced_lambda=first, loose=loose, max_err=max(errs), errs=errs, ref=ref)
 
 
@@ -280,10 +297,10 @@ def assert_dense_followed(kind, fit_beta, fit_niter, trace, x, y, opts, intercep
     assert d["solver"].ndecisions == len(t), (label, d["solver"].ndecisions, len(t))
     assert int(fit_niter) == int(ref["niter"]), (label, fit_niter, ref["niter"])
     err = relerr(fit_beta, ref["beta"])
-    print(f"[parity {label}] {len(t)} decisions, {len(d['forced'])} near-ties taken from the GPU; niter identical ({int(fit_niter)}); beta err {err:.2e}")
+    print(f"[parity {label}] {len(t)} decisions, {len(d['forced'])} near-ties taken from the GPU ({near_tie_stats(d['forced'])['large']} need > "
+          f"{NEAR_TIE_SMALL:g} ulps); niter identical ({int(fit_niter)}); beta err {err:.2e}")
     assert err < tol, (label, err)
-    if budget:
-        assert_near_tie_budget(d["forced"], len(t), label)
+    assert_near_tie_budget(d["forced"], len(t), label, enabled=budget)
     return dict(forced=d["forced"], err=err, ref=ref)
 
 

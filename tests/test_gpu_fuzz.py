@@ -42,9 +42,11 @@ def case_label(cs):
     return f"small {cs['c']} {cs['kind']} n={cs['n']} p={cs['p']} std={int(cs['stdz'])} icpt={int(cs['icpt'])} scale={cs['scale']:g}"
 
 
-def gpu_capture(cs):
+def gpu_capture(cs, state=False):
     """What libadmm_hip returns for a case of fuzz_cases.cases: dict(beta, niter, trace) -- everything the judgement
-    needs from the GPU, so that a capture written by tests/tools/soak_capture.py can be judged again without one."""
+    needs from the GPU, so that a capture written by tests/tools/soak_capture.py can be judged again without one.
+    state=True (tall / elastic-net-tall / consensus kinds): also the iterate dump of every iteration, for the stepwise
+    check of oracle/stepcheck.py."""
     from admm_amd import admm_bp, admm_enet, admm_lad, admm_lasso
     kind = cs["kind"]
     if kind == "lad":
@@ -62,8 +64,21 @@ def gpu_capture(cs):
         m.opts(maxit=prob["opts"]["maxit"])
         if kind == "par":
             m.nthread = cs["K"]
-    fit, trace = traced_fit(m, capacity=max(cs["nl"], 1) * (prob["opts"]["maxit"] + 2) + 8)
+    cap = max(cs["nl"], 1) * (prob["opts"]["maxit"] + 2) + 8
+    if state and (kind == "par" and cs["K"] > 1 or kind in ("tall", "enet_tall")):
+        fit, trace, st = traced_fit(m, capacity=cap, state=True)
+        return dict(beta=np.asarray(fit.beta_dense), niter=np.asarray(fit.niter), trace=np.asarray(trace), state=st)
+    fit, trace = traced_fit(m, capacity=cap)
     return dict(beta=np.asarray(fit.beta_dense), niter=np.asarray(fit.niter), trace=np.asarray(trace))
+
+
+def stepwise_capture(cs, cap):
+    """oracle/stepcheck.py on a capture that holds the iterate dump: the report (not asserted here)."""
+    from oracle import stepcheck
+    prob = _lasso_problem(cs)
+    if cs["kind"] == "par":
+        return stepcheck.check_consensus(prob, cap["trace"], cap["state"], label=case_label(cs))
+    return stepcheck.check_tall(prob, cap["trace"], cap["state"], label=case_label(cs))
 
 
 def judge_capture(cs, cap, band=8.0, budget=True):

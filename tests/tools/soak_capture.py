@@ -62,6 +62,17 @@ def worker(seed, ncases, out):
                 except Exception as e:                          # noqa: BLE001  (the rule said no)
                     rec.update(ok=False, judged=True, error=type(e).__name__, message=str(e)[:600])
                     np.savez_compressed(os.path.join(out, f"fail_s{seed}_c{cs['c']}.npz"), beta=cap["beta"], niter=cap["niter"], trace=cap["trace"])
+                    if cs["kind"] in ("tall", "enet_tall") or (cs["kind"] == "par" and cs.get("K", 0) > 1):
+                        try:                                    # the stronger, drift-free statement: every iteration on its own (oracle/stepcheck.py)
+                            cap2 = T.gpu_capture(cs, state=True)
+                            sw = T.stepwise_capture(cs, cap2)
+                            rec["stepwise"] = dict(records=sw["records"], x_ratio_max=float(sw["x_ratio_max"]), x_vs_ref_max=float(sw.get("x_vs_ref_max", 0.0)),
+                                                   bit_mismatch=len(sw["bit_mismatch"]), first_mismatch=[list(map(str, m)) for m in sw["bit_mismatch"][:3]],
+                                                   accum_ties=len(sw["accum_ties"]), norm_rel_max=float(sw["norm_rel_max"]))
+                            if sw["bit_mismatch"]:
+                                np.savez_compressed(os.path.join(out, f"state_s{seed}_c{cs['c']}.npz"), **cap2)
+                        except Exception as e3:                 # noqa: BLE001
+                            rec["stepwise"] = dict(error=type(e3).__name__, message=str(e3)[:400])
                     try:                                        # what band WOULD have been needed (and what else fails then)
                         with contextlib.redirect_stdout(buf):
                             rep = T.judge_capture(cs, cap, band=1e9, budget=False)
@@ -113,9 +124,11 @@ def summarise(out, seeds, ncases, wall):
         lines.append("none")
     for r in fails:
         ub = r.get("unbounded")
+        sw = r.get("stepwise")
         lines.append(f"* seed {r['seed']} case {r['case']} `{r['kind']}` n={r['n']} p={r['p']} K={r['K']} icpt={r['icpt']} std={r['stdz']} "
                      f"scale={r['scale']:g}: {r.get('error')}: {r.get('message', '')[:300]}"
-                     + (f" — with an unbounded band: {json.dumps(ub)[:300]}" if ub else ""))
+                     + (f" — with an unbounded band: {json.dumps(ub)[:300]}" if ub else "")
+                     + (f" — **stepwise** (every iteration replayed from the library's own previous iterates): {json.dumps(sw)[:400]}" if sw else ""))
     open(os.path.join(out, "summary.md"), "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
