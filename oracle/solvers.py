@@ -243,12 +243,15 @@ class FADMM:
 class LassoTall(FADMM):
     T = F
     update_rho_active = False    # ADMMLassoTall.h:97  void update_rho() {}
+    xy_acc = None
 
     def __init__(self, X, Y, eps_abs, eps_rel, alpha=None):
         self.X, self.Y = X, Y
         self.p = X.shape[1]
         self.eps_abs, self.eps_rel = eps_abs, eps_rel
-        self.XY = (X.T @ Y).astype(F)                       # :172
+        # :172.  `xy_acc` (class attribute, oracle/variants.py "xy64"): the type X'y ACCUMULATES in -- float in the reference, in
+        # Eigen's order; np.float64 is the rounding variant "any other summation order" (libadmm_hip sums in its own)
+        self.XY = (X.T @ Y).astype(F) if self.xy_acc is None else (X.astype(self.xy_acc).T @ Y.astype(self.xy_acc)).astype(F)
         self.lambda0 = F(np.abs(self.XY).max())             # :173
         self.alpha = alpha
         if alpha is not None:
@@ -515,7 +518,10 @@ class PADMMLasso:
             hi = (i + 1) * chunk if i < K - 1 else n
             self.A.append(np.ascontiguousarray(X[lo:hi]))
             self.b.append(Y[lo:hi].copy())
-        self.Ab = [(A.T @ b).astype(F) for A, b in zip(self.A, self.b)]    # worker ctor :42
+        if self.xy_acc is None:
+            self.Ab = [(A.T @ b).astype(F) for A, b in zip(self.A, self.b)]    # worker ctor :42
+        else:                                                               # rounding variant "xy64" (LassoTall.xy_acc)
+            self.Ab = [(A.astype(self.xy_acc).T @ b.astype(self.xy_acc)).astype(F) for A, b in zip(self.A, self.b)]
 
     def init(self, lam, rho):                                               # :193-212
         p, K = self.p, self.K
@@ -637,6 +643,7 @@ class PADMMLasso:
         return (self.chol[k] @ v).astype(F)
 
     xmode = "llt32"
+    xy_acc = None
     trace = None
     state_log = None
     follow = None

@@ -20,7 +20,10 @@ import scipy.linalg as sla
 from . import entry, solvers
 
 F = np.float32
-MODES = ("llt32", "inv32", "inv64r", "exact", "stats64")
+MODES = ("llt32", "inv32", "inv64r", "exact", "stats64", "xy64")
+#  xy64     the oracle proper with X'y (consensus: every A_k'b_k) accumulated in double and rounded once: stands for "any
+#           other summation order" of that product (the reference's is Eigen's, NumPy's and libadmm_hip's are their own);
+#           an unconverged, ill-conditioned consensus path moved a coefficient column by 3e-4 on it (soak case 505:139)
 #  stats64  the oracle proper (llt32) with the column statistics of DataStd accumulated in double and rounded once
 #           (libadmm_hip's prep kernels) instead of in float (the reference, in Eigen's order): oracle/datastd.py
 
@@ -63,7 +66,7 @@ def tall_variant(mode):
     runs as inv32 there) -- use the given x-update rounding."""
     assert mode in MODES
     from .datastd import DataStd
-    xmode = "llt32" if mode == "stats64" else mode
+    xmode = "llt32" if mode in ("stats64", "xy64") else mode
     cls = type("LassoTall_" + xmode, (LassoTallVariant,), {"mode": xmode})
     orig = entry.LassoTall
     orig_par = solvers.PADMMLasso.xmode
@@ -72,9 +75,14 @@ def tall_variant(mode):
     solvers.PADMMLasso.xmode = {"llt32": "llt32", "exact": "exact"}.get(xmode, "inv32")
     if mode == "stats64":
         DataStd.acc = np.float64
+    if mode == "xy64":
+        solvers.LassoTall.xy_acc = np.float64
+        solvers.PADMMLasso.xy_acc = np.float64
     try:
         yield
     finally:
         entry.LassoTall = orig
         solvers.PADMMLasso.xmode = orig_par
         DataStd.acc = orig_acc
+        solvers.LassoTall.xy_acc = None
+        solvers.PADMMLasso.xy_acc = None

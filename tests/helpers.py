@@ -39,7 +39,7 @@ def synth_lasso(n, p, m, seed=123, sd=2.0):
 #       `tol` (1e-4, the north_star bar) of the oracle's;
 #   R3  the only columns that may exceed `tol` are those where the reference's own formula loses the digits: they must be
 #       within `factor` (5) x the distance the oracle's rounding variants (oracle/variants.py: the x-update as a float
-#       inverse / as an exact solve; the column statistics of DataStd accumulated in double instead of float), following
+#       inverse / as an exact solve; the column statistics of DataStd, or X'y, accumulated in double instead of float), following
 #       the same decisions, have drifted from it by that lambda
 #       (e.g. maxit = 7 with rho five orders below the automatic value: z = (x + y/rho) - lambda/rho cancels 5 digits).
 #       The number of such columns is returned; tests bound and print it.
@@ -50,10 +50,14 @@ def synth_lasso(n, p, m, seed=123, sd=2.0):
 #     is a handful of single-ulp flips of z, i.e. quantised right at its threshold, and EVERY lambda ends on a decision
 #     inside one rounding (per-case rate: median 0.8 %, 99th percentile 12 %).  What a biased kernel would change is not
 #     their number but their SIZE: the ulps needed are 0.03 at the median, 0.5 at the 90th and 4.5 at the 99th percentile.
-#     Hence three ceilings:  (a) near-ties that need more than NEAR_TIE_SMALL (2) ulps: at most max(2, 0.3 % of the decisions);
-#     (b) none beyond NEAR_TIE_ULPS (7.5; the band itself is 8);  (c) all of them together: at most max(5, 15 %).
-#     A systematic bias of the residuals or thresholds that stays inside the band pushes near-ties out of the "inside one
-#     rounding" class and fails (a); tests/test_gpu_fuzz.py adds an aggregate ceiling over its fixed sweep.
+#     Hence three ceilings:  (a) EPISODES of near-ties needing more than NEAR_TIE_SMALL (2) ulps: at most max(2, 0.3 % of
+#     the decisions) -- an episode is a stretch of one lambda in which they recur every iteration or two: a path caught in a
+#     limit cycle of single-ulp flips of z (r_d alternating between two quantised values either side of eps_d) repeats the
+#     SAME near-tie for dozens of iterations, one event, not dozens;  (b) none beyond NEAR_TIE_ULPS (7.5; the band itself is
+#     8);  (c) all of them together: at most max(5, 15 %).
+#     What these ceilings cannot see -- a bias that hides inside one rounding -- the stepwise check can: wherever a test has
+#     the iterate dump (every tall / elastic-net / consensus case of the random sweep, tests/test_gpu_fuzz.py) it also
+#     requires every single iteration to be the reference's, bit for bit (oracle/stepcheck.py).
 NEAR_TIE_SMALL = 2.0
 NEAR_TIE_LARGE_RATE = 0.003
 NEAR_TIE_ULPS = 7.5
@@ -61,8 +65,19 @@ NEAR_TIE_TOTAL_RATE = 0.15
 
 
 def near_tie_stats(forced):
-    sized = [f["ulps"] for f in forced if f["kind"] != "rho"]
-    return dict(total=len(forced), large=sum(1 for v in sized if v > NEAR_TIE_SMALL), max_ulps=max(sized, default=0.0))
+    sized = [f for f in forced if f["kind"] != "rho"]
+    large, last = 0, None                          # episodes: same lambda, at most 2 iterations after the previous near-tie
+    in_large = False
+    for f in sized:
+        key = (f["lam"], f["iter"])
+        new_episode = last is None or f["lam"] != last[0] or f["iter"] - last[1] > 2
+        if new_episode:
+            in_large = False
+        if f["ulps"] > NEAR_TIE_SMALL and not in_large:
+            large += 1
+            in_large = True
+        last = key
+    return dict(total=len(forced), large=large, max_ulps=max((f["ulps"] for f in sized), default=0.0))
 
 
 def assert_near_tie_budget(forced, ndecisions, label="", enabled=True):
@@ -72,8 +87,8 @@ def assert_near_tie_budget(forced, ndecisions, label="", enabled=True):
     st = near_tie_stats(forced)
     show = [(f["lam"], f["iter"], f["kind"], round(f["ulps"], 2)) for f in forced if f["kind"] != "rho" and f["ulps"] > NEAR_TIE_SMALL][:10]
     allowed_large = max(2, int(np.ceil(NEAR_TIE_LARGE_RATE * ndecisions)))
-    assert st["large"] <= allowed_large, (label, f"{st['large']} of {ndecisions} decisions taken from the GPU needed more than {NEAR_TIE_SMALL} ulps of "
-                                          f"rounding; at most {allowed_large} allowed", show)
+    assert st["large"] <= allowed_large, (label, f"{st['large']} episodes (of {ndecisions} decisions) in which the GPU's outcome needed more than "
+                                          f"{NEAR_TIE_SMALL} ulps of rounding; at most {allowed_large} allowed", show)
     assert st["max_ulps"] <= NEAR_TIE_ULPS, (label, f"a near-tie needing {st['max_ulps']:.2f} ulps of rounding (ceiling {NEAR_TIE_ULPS})", show)
     allowed = max(5, int(np.ceil(NEAR_TIE_TOTAL_RATE * ndecisions)))
     assert st["total"] <= allowed, (label, f"{st['total']} of {ndecisions} decisions taken from the GPU as near-ties; at most {allowed} allowed")
@@ -209,7 +224,7 @@ def assert_followed_parity(beta, niter, trace, problem, tol=1e-4, band=8.0, labe
         # oracle's own rounding variants of the workers' solves (float inverse, exact), following the same decisions,
         # have drifted from it by that lambda (paths that run into maxit accumulate the rounding of hundreds of solves)
         drift = np.zeros(nl)
-        for mode in ("inv32", "exact", "stats64"):
+        for mode in ("inv32", "exact", "stats64", "xy64"):
             v, _, _ = oracle_following(trace, band=1e9, mode=mode, **problem)
             drift = np.maximum(drift, [col_err(v["beta"][:, j], ref["beta"][:, j], floor) for j in range(nl)])
         drift = np.maximum.accumulate(drift)
@@ -263,7 +278,7 @@ def assert_tall_parity(beta, niter, trace, problem, tol=1e-4, factor=5.0, band=8
     errs_eff = [0.0 if errs[j] * scales[j] <= 2.0 * quanta[j] else errs[j] for j in range(nl)]
     if max(errs_eff) >= tol:                                                     # R3
         drift = np.zeros(nl)
-        for mode in ("inv32", "exact", "stats64"):
+        for mode in ("inv32", "exact", "stats64", "xy64"):
             v, _, _ = oracle_following(trace, band=1e9, mode=mode, **problem)
             drift = np.maximum(drift, [col_err(v["beta"][:, j], ref["beta"][:, j], floor) for j in range(nl)])
         drift = np.maximum.accumulate(drift)        # along a warm-started path the drift of a lambda carries into the next ones

