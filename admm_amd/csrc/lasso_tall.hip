@@ -65,7 +65,7 @@ struct TallParams {
     const float* XY;
     const float* a_part; const float* b_part;            // gemv_t partials [nseg][part_stride]   (full-matrix x-update)
     const float* dot0; const float* dot1; const float* axp0; const float* axp1;   // symv partials (lower-triangle x-update)
-    long long ldo; int nrb, ncb;
+    long long ldo; int nrb, p32; SymvSched sched;
     float* x; float* z0; float* z1; float* y0; float* y1; float* adj_z; float* adj_y; float* u; float* w;
     TallCtl* ctl;               // [2]
     double* P;                  // [2][nwg][8]
@@ -285,12 +285,12 @@ tall_tail_kernel(TallParams q, int par, PeerExchange ex) {
     // their partial loads at once, then combine with shuffles.
     float a = 0.f, b = 0.f;
     if (MODE == TAIL_SYMV) {
-        symv_sum_partials<kTailLanes>(q.dot0, q.dot1, q.axp0, q.axp1, q.ldo, q.nrb, q.ncb, i, sub, valid, a, b);
+        symv_sum_partials<kTailLanes>(q.dot0, q.dot1, q.axp0, q.axp1, q.ldo, q.nrb, q.sched, q.p32, i, sub, valid, a, b);
     } else if (MODE == TAIL_PEER || MODE == TAIL_PEER1) {
         const bool live = !q.ctl[par].done;                          // finished in an earlier launch: nothing pushed, nothing to wait for (replicated flag: all ranks agree)
         if (MODE == TAIL_PEER1 && live) {
             float sa, sb;
-            symv_sum_partials<kTailLanes>(q.dot0, q.dot1, q.axp0, q.axp1, q.ldo, q.nrb, q.ncb, i, sub, valid, sa, sb);
+            symv_sum_partials<kTailLanes>(q.dot0, q.dot1, q.axp0, q.axp1, q.ldo, q.nrb, q.sched, q.p32, i, sub, valid, sa, sb);
             if (valid) {
                 for (int dst = sub; dst < ex.nranks; dst += kTailLanes)
                     peer_store_f32x2(reinterpret_cast<float*>(peer_dst_slot(ex, dst)) + 2 * (size_t)i, sa, sb);
@@ -387,7 +387,7 @@ template <bool PRE>      // PRE: the tiles request their first matrix columns be
 __global__ void __launch_bounds__(kTailThreads, 4)
 tall_fused_kernel(TallParams q, int par, TallFused f) {
     __shared__ float4 red[2][kSyThreads];
-    __shared__ __attribute__((aligned(16))) float sdot[2][kSyCB];
+    __shared__ __attribute__((aligned(16))) float sdot[2][kSyCBMax];
     __shared__ double scratch[6 * (kTailThreads / 64)];
     __shared__ int s_last;
     if ((int)blockIdx.x >= f.ntail) {                       // ---- a tile of the mat-vec of iteration g
@@ -412,7 +412,7 @@ tall_fused_kernel(TallParams q, int par, TallFused f) {
         TallElem e = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (owner) e = tall_load_elem(q, tp, i);
         float a, b;
-        symv_sum_partials<kTailLanes>(q.dot0, q.dot1, q.axp0, q.axp1, q.ldo, q.nrb, q.ncb, i, sub, valid, a, b);
+        symv_sum_partials<kTailLanes>(q.dot0, q.dot1, q.axp0, q.axp1, q.ldo, q.nrb, q.sched, q.p32, i, sub, valid, a, b);
         if (owner) tall_update_elem<true>(q, c, tp, i, e, a, b, acc);
     }
     if (!c.done) {
@@ -444,7 +444,7 @@ tall_shard_reduce_kernel(TallParams q, float* ab, long long ld, const int* skip)
     const int sub = threadIdx.x & (kTailLanes - 1);
     const int i = blockIdx.x * kTailElems + threadIdx.x / kTailLanes;
     float a, b;
-    symv_sum_partials<kTailLanes>(q.dot0, q.dot1, q.axp0, q.axp1, q.ldo, q.nrb, q.ncb, i, sub, i < q.p, a, b);
+    symv_sum_partials<kTailLanes>(q.dot0, q.dot1, q.axp0, q.axp1, q.ldo, q.nrb, q.sched, q.p32, i, sub, i < q.p, a, b);
     if (i < q.p && sub == 0) { ab[i] = a; ab[ld + i] = b; }
 }
 
@@ -457,7 +457,7 @@ tall_shard_push_kernel(TallParams q, PeerExchange ex, long long ld, const int* s
     const int sub = threadIdx.x & (kTailLanes - 1);
     const int i = blockIdx.x * kTailElems + threadIdx.x / kTailLanes;
     float a, b;
-    symv_sum_partials<kTailLanes>(q.dot0, q.dot1, q.axp0, q.axp1, q.ldo, q.nrb, q.ncb, i, sub, i < q.p, a, b);
+    symv_sum_partials<kTailLanes>(q.dot0, q.dot1, q.axp0, q.axp1, q.ldo, q.nrb, q.sched, q.p32, i, sub, i < q.p, a, b);
     if (i < q.p) {
         for (int dst = sub; dst < ex.nranks; dst += kTailLanes)
             peer_store_f32x2(reinterpret_cast<float*>(peer_dst_slot(ex, dst)) + 2 * (size_t)i, a, b);       // (a_i, b_i) interleaved: one 8-byte store
@@ -653,7 +653,7 @@ struct TallPlan final : LassoPlan {
         q.lambdas = dlam.get(); q.XY = XY.get(); q.a_part = a_part.get(); q.b_part = b_part.get();
         if (shard) { q.a_part = ab.get(); q.b_part = ab.get() + ldp; q.nseg = 1; }      // the tail reads the all-reduced pair (generic exchange)
         q.dot0 = sy.dot0.get(); q.dot1 = sy.dot1.get(); q.axp0 = sy.axp0.get(); q.axp1 = sy.axp1.get();
-        q.ldo = sy.ldo; q.nrb = sy.nrb; q.ncb = sy.ncb;
+        q.ldo = sy.ldo; q.nrb = sy.nrb; q.p32 = sy.p32; q.sched = sy.sched;
         q.x = x.get(); q.z0 = z0.get(); q.z1 = z1.get(); q.y0 = y0.get(); q.y1 = y1.get();
         q.adj_z = adj_z.get(); q.adj_y = adj_y.get(); q.u = u.get(); q.w = w.get();
         q.ctl = ctl.get(); q.P = P.get(); q.beta = beta.get(); q.niter = niter.get();

@@ -46,9 +46,26 @@
 namespace admm {
 
 constexpr int kSyRB = 256;     // rows per tile
-constexpr int kSyCW = 32;      // columns per wave
-constexpr int kSyCB = 128;     // columns per workgroup tile
+constexpr int kSyCB = 128;     // default columns per workgroup tile (round 2's fixed tile)
+constexpr int kSyCBMax = 256;  // widest column segment a workgroup may own (64 columns per wave: one register of right-hand entries)
 constexpr int kSyThreads = 256;
+
+// Round 3: a tile is 256 rows x a column SEGMENT [c0, c0 + width) of its row strip, width a multiple of 32 up to kSyCBMax,
+// each of the 4 waves owning width / 4 consecutive columns.  The strips are cut with one of two widths (SymvSched): the
+// long strips, dispatched first, in wide segments; the short strips, dispatched last, in narrow ones -- the end of the
+// launch is then made of small work units (the integer number of tiles a CU gets no longer leaves some CUs a whole
+// 256 x 128 tile short of the others), and the wide segments leave fewer axpy partial rows for the consumer to sum.
+// width_big = width_small = 128 reproduces round 2's tiling and partial layout exactly.
+struct SymvSched {
+    int width_big = kSyCB, width_small = kSyCB;
+    int rb_split = 0;              // strips rb >= rb_split are cut in width_big, the others in width_small
+    __host__ __device__ int width(int rb) const { return rb >= rb_split ? width_big : width_small; }
+    // segments of strip rb: its columns 0 .. min((rb + 1) * 256, p32) - 1 in pieces of width(rb)   (p32 = p rounded up to 32)
+    __host__ __device__ int nseg(int rb, int p32) const {
+        const int cols = min((rb + 1) * kSyRB, p32), w = width(rb);
+        return (cols + w - 1) / w;
+    }
+};
 constexpr int kSySumLanes = 8;  // lanes that share one element when the consumer sums the partials (symv_sum_partials)
 
 struct SymvArgs {
@@ -57,7 +74,7 @@ struct SymvArgs {
     float* dot0; float* dot1;              // [nrb][ldo]
     float* axp0; float* axp1;              // [ncb][ldo]
     long long ldo;
-    const int2* tiles;                     // (row block, column block) of every tile touching the lower triangle
+    const int4* tiles;                     // (row block, first column, width, segment index within the strip) of every tile
     const int* skip;
 #ifdef ADMM_HIP_PROBE
     long long* probe; int probe_idx;       // dev build only (probe.h): entry / end stamps of the first, middle and last tile
@@ -119,12 +136,13 @@ struct SymvNoWait { __device__ __forceinline__ void operator()() const {} };
 // iteration -- the shape that streams best (with the PRE shape the same 128-column kernel ran at 39.3 instead of 35.1 us on
 // C2: a first chunk carried into the loop in registers and a conditional reload defeat the scheduling of the loads).
 template <bool PRE, typename Wait, typename VecLoad, bool NT = false>      // NT: matrix read with non-temporal loads (triangle larger than the Infinity Cache)
-__device__ __forceinline__ void symv2_tile(const SymvArgs& a, const int2 t, Wait wait, VecLoad vl,
-                                           float4 (*red)[kSyThreads], float (*sdot)[kSyCB]) {
-    const int rb = t.x, cb = t.y;
+__device__ __forceinline__ void symv2_tile(const SymvArgs& a, const int4 t, Wait wait, VecLoad vl,
+                                           float4 (*red)[kSyThreads], float (*sdot)[kSyCBMax]) {
+    const int rb = t.x, seg = t.w;
+    const int cw = t.z >> 2;               // columns per wave: a multiple of 8, at most 64
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int row = rb * kSyRB + lane * 4;
-    const int col0 = cb * kSyCB + wid * kSyCW;
+    const int col0 = t.y + wid * cw;
     const int p4 = (a.p + 3) & ~3;
     const bool active = row < p4;
     const bool has = col0 < a.p;           // every wave of a listed tile has all its columns <= the block's last row
@@ -143,16 +161,13 @@ __device__ __forceinline__ void symv2_tile(const SymvArgs& a, const int2 t, Wait
     if (has) {
         const float4 uI = active ? vl.load4(a.v0 + row) : make_float4(0.f, 0.f, 0.f, 0.f);
         const float4 wI = active ? vl.load4(a.v1 + row) : make_float4(0.f, 0.f, 0.f, 0.f);
-        float ujv[(kSyCW + 63) / 64], wjv[(kSyCW + 63) / 64];               // the wave's kSyCW right-hand entries, 64 per register
-#pragma unroll
-        for (int h = 0; h < (kSyCW + 63) / 64; ++h) {
-            const int cj = col0 + h * 64 + (kSyCW < 64 ? (lane & (kSyCW - 1)) : lane);
-            ujv[h] = cj < a.p ? vl.load1(a.v0 + cj) : 0.f;
-            wjv[h] = cj < a.p ? vl.load1(a.v1 + cj) : 0.f;
-        }
-        const bool diag = col0 + (kSyCW - 1) >= rb * kSyRB;      // this wave's block meets the diagonal
+        const int cj = col0 + lane;                                          // the wave's (<= 64) right-hand entries, one per lane
+        const float uj = (lane < cw && cj < a.p) ? vl.load1(a.v0 + cj) : 0.f;
+        const float wj = (lane < cw && cj < a.p) ? vl.load1(a.v1 + cj) : 0.f;
+        const bool diag = col0 + (cw - 1) >= rb * kSyRB;         // this wave's block meets the diagonal
+        const int nq = cw >> 3;
 #pragma unroll 1
-        for (int q = 0; q < kSyCW / 8; ++q) {
+        for (int q = 0; q < nq; ++q) {
             if (!PRE || q > 0) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
@@ -163,9 +178,6 @@ __device__ __forceinline__ void symv2_tile(const SymvArgs& a, const int2 t, Wait
                 }
             }
             float dU[8], dW[8];
-            float uj = ujv[0], wj = wjv[0];
-#pragma unroll
-            for (int h = 1; h < (kSyCW + 63) / 64; ++h) if ((q * 8) / 64 == h) { uj = ujv[h]; wj = wjv[h]; }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const int col = col0 + q * 8 + k;
@@ -193,12 +205,12 @@ __device__ __forceinline__ void symv2_tile(const SymvArgs& a, const int2 t, Wait
             const float du = butterfly8(dU, lane);
             const float dw = butterfly8(dW, lane);
             if ((lane & 7) == 0) {
-                sdot[0][wid * kSyCW + q * 8 + (lane >> 3)] = du;
-                sdot[1][wid * kSyCW + q * 8 + (lane >> 3)] = dw;
+                sdot[0][wid * cw + q * 8 + (lane >> 3)] = du;
+                sdot[1][wid * cw + q * 8 + (lane >> 3)] = dw;
             }
         }
     } else {
-        for (int c = lane; c < kSyCW; c += 64) { sdot[0][wid * kSyCW + c] = 0.f; sdot[1][wid * kSyCW + c] = 0.f; }
+        for (int c = lane; c < cw; c += 64) { sdot[0][wid * cw + c] = 0.f; sdot[1][wid * cw + c] = 0.f; }
     }
     // axpy part: add the 4 waves (same rows, different columns); dot part: one 512-byte row per array
     red[0][threadIdx.x] = aU;
@@ -211,11 +223,11 @@ __device__ __forceinline__ void symv2_tile(const SymvArgs& a, const int2 t, Wait
             const float4 o = red[wid][ww * 64 + lane];
             s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
         }
-        float* dst = (wid == 0 ? a.axp0 : a.axp1) + (size_t)cb * a.ldo + row;
+        float* dst = (wid == 0 ? a.axp0 : a.axp1) + (size_t)seg * a.ldo + row;
         *reinterpret_cast<float4*>(dst) = s;
     } else {
-        float* dst = (wid == 2 ? a.dot0 : a.dot1) + (size_t)rb * a.ldo + cb * kSyCB;                   // < ncb * kSyCB <= ldo
-        for (int c = lane * 4; c < kSyCB; c += 256) *reinterpret_cast<float4*>(dst + c) = *reinterpret_cast<const float4*>(&sdot[wid - 2][c]);
+        float* dst = (wid == 2 ? a.dot0 : a.dot1) + (size_t)rb * a.ldo + t.y;                          // t.y + width <= (rb + 1) * 256 <= ldo
+        for (int c = lane * 4; c < t.z; c += 256) *reinterpret_cast<float4*>(dst + c) = *reinterpret_cast<const float4*>(&sdot[wid - 2][c]);
     }
 }
 
@@ -229,7 +241,7 @@ symv2_lower_kernel(SymvArgs a, Extra extra) {
     if (blockIdx.x == 0) { extra(); return; }
     if (a.skip != nullptr && *a.skip != 0) return;
     __shared__ float4 red[2][kSyThreads];
-    __shared__ __attribute__((aligned(16))) float sdot[2][kSyCB];
+    __shared__ __attribute__((aligned(16))) float sdot[2][kSyCBMax];
 #ifdef ADMM_HIP_PROBE
     const long long pt0 = wall_clock64();
 #endif
@@ -246,11 +258,13 @@ symv2_lower_kernel(SymvArgs a, Extra extra) {
 #endif
 }
 
-// Number of row / column blocks and the tile list (host).
+// Number of row blocks, the segment schedule and the tile list (host).
 struct SymvPlan {
-    int p = 0, nrb = 0, ncb = 0, ntiles = 0;
+    int p = 0, nrb = 0, ncb = 0, ntiles = 0, p32 = 0;
+    int nax_rows = 0;              // rows of the axpy partial arrays = the largest number of segments of one strip
+    SymvSched sched;
     long long ldo = 0;
-    DevBuf<int2> tiles;
+    DevBuf<int4> tiles;
     bool nt = false;
     DevBuf<float> dot0, dot1, axp0, axp1;
 #ifdef ADMM_HIP_PROBE
@@ -261,16 +275,50 @@ struct SymvPlan {
     // tiles owned by other ranks stay zero) so that the same consumer code sums them.
     void init(int p_, hipStream_t st, int part = 0, int nparts = 1) {
         p = p_;
+        p32 = (p + 31) / 32 * 32;
         nrb = (p + kSyRB - 1) / kSyRB;
         ncb = (p + kSyCB - 1) / kSyCB;
         ldo = (long long)nrb * kSyRB;
-        std::vector<int2> h;
-        // heavy (long) row strips first so that the tail of the launch is made of small work
-        for (int rb = nrb - 1; rb >= 0; --rb)
-            for (int cb = 0; cb < ncb; ++cb)
-                if (cb * kSyCB <= rb * kSyRB + (kSyRB - 1)) h.push_back(make_int2(rb, cb));
+        // Segment schedule (measured on one MI355X with scripts/symv_sched_sweep.py, profiles/r03_symv_sched.md; it/s of the
+        // whole 100-lambda loop against round 2's fixed 256 x 128 tiles):
+        //   * while the triangle is small enough, the narrowest segments that still fit ONE resident round of workgroups
+        //     (4 per CU): more workgroups in flight and no second round -- p = 2048 / 3000: 32 columns, +41 % / +32 %;
+        //     p = 4096: 64 columns, +14 % (32 columns would need a second round there: -17 %);
+        //   * beyond that two classes: wide segments for the long strips, dispatched first, narrow ones (64) for the short
+        //     strips at the end of the launch, so that its end is made of small work units -- p = 6000 / 8000: 128 | 64,
+        //     +8 % / +7 %; p = 10^4: 192 | 64, +5..7 % (38.8-39.6 instead of 41.7 us per iteration); p = 16000: +8 %.
+        // ADMM_HIP_SYMV_SCHED=big,small,split_permille overrides it ("128,128,0" = round 2's tiling).
+        auto count = [&](const SymvSched& sc) { long long t = 0; for (int rb = 0; rb < nrb; ++rb) t += sc.nseg(rb, p32); return t; };
+        int cus = 256;
+        { int dev = 0; hipDeviceProp_t prop; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount; }
+        const long long slots = 4ll * cus * std::max(1, nparts);      // a rank of the row-sharded solver launches 1 / nparts of the tiles
+        auto uniform = [](int w) { SymvSched sc; sc.width_big = sc.width_small = w; sc.rb_split = 0; return sc; };
+        auto two = [&](int wb, int ws) { SymvSched sc; sc.width_big = wb; sc.width_small = ws; sc.rb_split = nrb / 2; return sc; };
+        if (4 * count(uniform(32)) <= 3 * slots) sched = uniform(32);
+        else if (count(uniform(64)) <= slots) sched = uniform(64);
+        else if (10 * count(two(128, 64)) <= 14 * slots) sched = two(128, 64);
+        else sched = two(192, 64);
+        if (const char* e = std::getenv("ADMM_HIP_SYMV_SCHED")) {
+            int wb = 0, ws = 0, pm = 0;
+            if (std::sscanf(e, "%d,%d,%d", &wb, &ws, &pm) == 3 && wb >= 32 && wb <= kSyCBMax && wb % 32 == 0 && ws >= 32 && ws <= kSyCBMax && ws % 32 == 0 &&
+                pm >= 0 && pm <= 1000) {
+                sched.width_big = wb; sched.width_small = ws; sched.rb_split = (int)((long long)pm * nrb / 1000);
+            }
+        }
+        std::vector<int4> h;
+        nax_rows = 1;
+        // long row strips first so that the end of the launch is made of the short strips' (narrow) segments
+        for (int rb = nrb - 1; rb >= 0; --rb) {
+            const int w = sched.width(rb), ns = sched.nseg(rb, p32);
+            nax_rows = std::max(nax_rows, ns);
+            for (int sg = 0; sg < ns; ++sg) {
+                const int c0 = sg * w;
+                const int cols = std::min((rb + 1) * kSyRB, p32);
+                h.push_back(make_int4(rb, c0, std::min(w, cols - c0), sg));
+            }
+        }
         if (nparts > 1) {
-            std::vector<int2> mine;
+            std::vector<int4> mine;
             for (size_t i = (size_t)part; i < h.size(); i += (size_t)nparts) mine.push_back(h[i]);
             h.swap(mine);
         }
@@ -282,9 +330,9 @@ struct SymvPlan {
         nt = (size_t)2 * (size_t)p * (size_t)p / (size_t)std::max(1, nparts) > (size_t)310000000;
         if (const char* e = std::getenv("ADMM_HIP_SYMV_NT")) nt = std::string(e) == "1";
         tiles.alloc(std::max<size_t>(h.size(), 1));
-        if (!h.empty()) ADMM_HIP_CHECK(hipMemcpyAsync(tiles.get(), h.data(), h.size() * sizeof(int2), hipMemcpyHostToDevice, st));
+        if (!h.empty()) ADMM_HIP_CHECK(hipMemcpyAsync(tiles.get(), h.data(), h.size() * sizeof(int4), hipMemcpyHostToDevice, st));
         dot0.alloc((size_t)nrb * ldo); dot1.alloc((size_t)nrb * ldo);
-        axp0.alloc((size_t)ncb * ldo); axp1.alloc((size_t)ncb * ldo);
+        axp0.alloc((size_t)nax_rows * ldo); axp1.alloc((size_t)nax_rows * ldo);
         dot0.zero(st); dot1.zero(st); axp0.zero(st); axp1.zero(st);
         ADMM_HIP_CHECK(hipStreamSynchronize(st));
     }
@@ -321,16 +369,16 @@ struct SymvPlan {
 template <int NL>
 __device__ __forceinline__ void symv_sum_partials(const float* __restrict__ dot0, const float* __restrict__ dot1,
                                                   const float* __restrict__ axp0, const float* __restrict__ axp1,
-                                                  long long ldo, int nrb, int ncb, int i, int sub, bool valid, float& a, float& b) {
+                                                  long long ldo, int nrb, const SymvSched sched, int p32, int i, int sub, bool valid, float& a, float& b) {
     // Branch-free requests: every slot loads from a clamped (always valid) address and out-of-range slots are replaced by
     // zero afterwards, so the 32 loads of a pass are issued back to back.  (The round-2 form guarded each load by two range
     // tests: ~25 instructions of exec-mask bookkeeping per load, ~2 us of issue time in the tall tail kernel before the
     // last request left.)  Offsets fit 32 bits: (nrb + ncb) * ldo < 2^31 up to p ~ 5e5, far beyond what a p x p matrix allows.
     const int ic = valid ? i : 0;
-    const int cbi = ic / kSyCB, rbi = ic / kSyRB;
-    const int rb0 = (cbi * kSyCB) / kSyRB;                              // first row block whose tiles reach column block cbi
+    const int rbi = ic / kSyRB;
+    const int rb0 = rbi;                                                // first row strip whose segments reach column ic
     const int ndot = nrb - rb0;
-    const int nax = min(ncb - 1, ((rbi + 1) * kSyRB - 1) / kSyCB) + 1;  // column blocks up to the diagonal of row block rbi
+    const int nax = sched.nseg(rbi, p32);                               // segments of row strip rbi (up to its diagonal block)
     const int ntot = valid ? ndot + nax : 0;
     const unsigned ld = (unsigned)ldo;
     a = 0.f; b = 0.f;

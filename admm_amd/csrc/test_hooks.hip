@@ -9,12 +9,12 @@ void require_device();
 // The consumer side of the symmetric mat-vec, with the tall tail kernel's geometry and summation order
 // (kSySumLanes lanes per element, 256 threads per workgroup).
 __global__ void __launch_bounds__(256)
-test_symv_finish_kernel(const float* dot0, const float* dot1, const float* axp0, const float* axp1, long long ldo, int nrb, int ncb,
+test_symv_finish_kernel(const float* dot0, const float* dot1, const float* axp0, const float* axp1, long long ldo, int nrb, SymvSched sched, int p32,
                         int p, float* y0, float* y1) {
     const int sub = threadIdx.x & (kSySumLanes - 1);
     const int i = blockIdx.x * (256 / kSySumLanes) + threadIdx.x / kSySumLanes;
     float a, b;
-    symv_sum_partials<kSySumLanes>(dot0, dot1, axp0, axp1, ldo, nrb, ncb, i, sub, i < p, a, b);
+    symv_sum_partials<kSySumLanes>(dot0, dot1, axp0, axp1, ldo, nrb, sched, p32, i, sub, i < p, a, b);
     if (i < p && sub == 0) { y0[i] = a; y1[i] = b; }
 }
 
@@ -33,7 +33,7 @@ void test_symv(const float* A, int p, const float* v0, const float* v1, float* y
     sy.launch(dA.get(), lda, d0.get(), d1.get(), nullptr, st.s);
     const int per = 256 / kSySumLanes;
     hipLaunchKernelGGL(test_symv_finish_kernel, dim3((p + per - 1) / per), dim3(256), 0, st.s, sy.dot0.get(), sy.dot1.get(),
-                       sy.axp0.get(), sy.axp1.get(), sy.ldo, sy.nrb, sy.ncb, p, o0.get(), o1.get());
+                       sy.axp0.get(), sy.axp1.get(), sy.ldo, sy.nrb, sy.sched, sy.p32, p, o0.get(), o1.get());
     ADMM_HIP_CHECK(hipGetLastError());
     ADMM_HIP_CHECK(hipMemcpyAsync(y0, o0.get(), (size_t)p * sizeof(float), hipMemcpyDeviceToHost, st.s));
     ADMM_HIP_CHECK(hipMemcpyAsync(y1, o1.get(), (size_t)p * sizeof(float), hipMemcpyDeviceToHost, st.s));
