@@ -759,6 +759,423 @@ wide_tail_kernel(WideParams q, int par, PeerExchange ex) {
     WIDE_PROBE_FLUSH(blockIdx.x == 0 ? 3 : -1, c.total - 1);
 }
 
+// ------------------------------------------------------------------------------------------ persistent active-set stretch
+// Round 3.  Almost every iteration of a wide path is an ACTIVE-SET step (ADMMLassoWide.h:86-118: only the current
+// non-zeros are updated; 17 191 of 17 613 iterations at BASELINE configs[2]) on a few dozen to a few hundred columns -- two
+// latency-bound launches, 16.6 us per iteration however little there is to do (profiles/r02_probe_timelines.md: prologue round
+// trip, column round trip, two kernel boundaries, the z / y launch's own round trip).  This kernel runs a whole STRETCH of
+// them -- from wherever the two-launch path stands until the next regular step, a finished lambda, or an active set too
+// large for it -- inside ONE launch: kPG workgroups (blocks b with b % 8 == 0 of a 256-block grid: observed to share one XCD
+// and its L2, a speed-up only, never relied upon) keep iterating and hand their results to one another through global
+// memory with write-through stores and cache-bypassing loads, two hand-overs per iteration:
+//   (B) every wave keeps the x values of ITS column slots in registers (column j <-> slot (j / NW) of wave j mod NW, the
+//       same deal as the two-launch kernel), updates the non-zero ones against t / gamma staged in LDS and accumulates
+//       x_j X_j; the workgroup publishes its partial of A x                                      [hand-over A: partials]
+//   (D) workgroup g owns n / kPG rows: it sums the kPG partials of its rows in workgroup order, forms z_new, y_new, r and its
+//       share of the five norms, and publishes A x + z, y and the norm shares                   [hand-over B: everything else]
+//   (E) every workgroup reduces the norm shares, takes the decision of ADMMBase::solve (wide_decide: stop test, rho adaptation,
+//       schedule), and -- if another active-set step follows -- forms t = (A x + z) + y / rho itself.
+// The arithmetic of a step is the two-launch path's (same functions, same roundings); only the ORDER in which the partials
+// of A x and of the norms are added differs (kPG workgroups instead of 256, per-workgroup norm shares), so the two paths
+// agree to summation rounding, not bit for bit, and both are held to the oracle by the same trace rule.  When the stretch
+// ends the kernel leaves x, A x, z, y, the norm partials and the control block exactly as a tail launch would, and the next
+// x-update launch simply continues.  ADMM_HIP_WIDE_PERSIST=0 disables it.
+constexpr int kPG = 32;                   // workgroups of the persistent stretch
+constexpr int kPNU = 32;                  // x slots per lane a wave can own: p <= kPNU * 64 * (4 kPG) = 262144
+struct WidePersist {
+    unsigned long long* flagA; unsigned long long* flagB;      // [kPG][8] monotonic hand-over words, one 64-byte line each
+    unsigned long long* flagX;                                 // [kPG][8] (launch << 32) | (XCD + 1) of every workgroup
+    float* sz; float* yv;                  // [npad] A x + z and y of the iteration just finished (write-through)
+    double* np;                            // [kPG][8] norm shares: |r|^2, |dz|^2, |Ax|^2, |z|^2, |y|^2, non-zeros
+    int* err;                              // device word: non-zero after a timed-out wait
+    unsigned long long seq;                // launch number (host): hand-over words only ever grow
+    int max_cols;                          // leave the stretch when the active set exceeds this many columns
+    unsigned long long* stat;              // [4] iterations done in stretches, stretches, 100 MHz ticks inside them (diagnostics)
+    double* hint;                          // [2][2] per launch parity: {non-zeros when the kernel last ran, launches to sit out}: while the
+                                           // active set is too large for this kernel it only looks again every 64th launch
+};
+
+// 8-byte payload store.  wt = true: write-through (sc1), visible to a cache-bypassing load anywhere on the device.  wt = false
+// (all workgroups of the stretch were FOUND on one XCD at the start of this launch, wide_act_persist_kernel): a plain store, which
+// stays in the XCD's shared L2 where the readers' cache-bypassing loads find it at L2 latency instead of the fabric's.
+__device__ __forceinline__ void wp_store2(float* p, float a, float b, bool wt) {
+    if (wt) __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *reinterpret_cast<float2*>(p) = make_float2(a, b);
+}
+__device__ __forceinline__ void wp_store_f64(double* p, double v, bool wt) {
+    if (wt) __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+__device__ __forceinline__ unsigned wp_xcc_id() {                                    // which XCD this wave runs on (0..7)
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 0xf;
+}
+__device__ __forceinline__ float2 wp_load2(const float* p) {                        // 8-byte load that bypasses this CU's L1
+    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float2(__uint_as_float((unsigned)v), __uint_as_float((unsigned)(v >> 32)));
+}
+// every storing wave drains its stores, then ONE lane raises the workgroup's word
+__device__ __forceinline__ void wp_publish(unsigned long long* flag, unsigned long long val) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// lanes < kPG of wave 0 poll one word each (bounded); everybody leaves together.  Returns false after a time-out.
+__device__ __forceinline__ bool wp_wait(const unsigned long long* flags, unsigned long long val, int* err, int* s_ok) {
+    if (threadIdx.x < 64) {
+        bool ok = true;
+        if (threadIdx.x < kPG) {
+            const unsigned long long* f = flags + (size_t)threadIdx.x * 8;
+            const long long t0 = wall_clock64();
+            while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < val) {
+                __builtin_amdgcn_s_sleep(1);
+                if (wall_clock64() - t0 > 200000000ll) { ok = false; break; }        // 2 s
+            }
+        }
+        ok = __all(ok) != 0;
+        if (threadIdx.x == 0) { *s_ok = ok ? 1 : 0; if (!ok) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    }
+    __syncthreads();
+    return *s_ok != 0;
+}
+// The same wait on words that carry (launch << 32) | (XCD of the workgroup + 1); *s_same = 1 if all kPG workgroups sit on one XCD.
+__device__ __forceinline__ bool wp_wait_xcc(const unsigned long long* flags, unsigned long long seq, int* err, int* s_ok, int* s_same) {
+    if (threadIdx.x < 64) {
+        bool ok = true;
+        unsigned long long v = 0;
+        if (threadIdx.x < kPG) {
+            const unsigned long long* f = flags + (size_t)threadIdx.x * 8;
+            const long long t0 = wall_clock64();
+            while ((v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < ((seq << 32) | 1ull)) {
+                __builtin_amdgcn_s_sleep(1);
+                if (wall_clock64() - t0 > 200000000ll) { ok = false; break; }
+            }
+        }
+        ok = __all(ok) != 0;
+        const unsigned mine = (unsigned)v, first = (unsigned)__shfl(mine, 0, 64);
+        const bool same = __all(threadIdx.x >= kPG || mine == first) != 0;
+        if (threadIdx.x == 0) { *s_ok = ok ? 1 : 0; *s_same = same ? 1 : 0; if (!ok) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    }
+    __syncthreads();
+    return *s_ok != 0;
+}
+
+template <int RT>      // a column is RT float4 per lane (n <= RT * 256)
+__global__ void __launch_bounds__(kWideThreads)
+wide_act_persist_kernel(WideParams q, int cpar, WidePersist ps) {
+    if ((blockIdx.x & 7) != 0) return;
+    const int g = blockIdx.x >> 3;
+    if (g >= kPG) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int npad = (q.n + 255) / 256 * 256;
+    float* tdl = reinterpret_cast<float*>(smem_raw);                       // t / gamma [npad]
+    float4* red = reinterpret_cast<float4*>(smem_raw + (size_t)npad * sizeof(float));      // [RT][256] wave partials of A x
+    __shared__ int s_ok, s_same;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    constexpr int NWp = kPG * (kWideThreads / 64);
+    const int w = g * (kWideThreads / 64) + wid;
+    // ---- the decision the next x-update launch would take: go on only if it is an active-set step
+    WideCtl in = q.ctl[cpar];
+    in = wide_ctl_uniform(in);
+    // (this launch READS hint[seq & 1] and WRITES hint[(seq + 1) & 1]: every workgroup sees the same words)
+    const double* hin = ps.hint + (size_t)(ps.seq & 1) * 2;
+    double* hout = ps.hint + (size_t)((ps.seq + 1) & 1) * 2;
+    const double h_nnz = hin[0], h_wait = hin[1];
+    const bool leader = g == 0 && threadIdx.x == 0;
+    if (in.done || in.first) { if (leader) { hout[0] = h_nnz; hout[1] = h_wait; } return; }
+    if (h_nnz > (double)ps.max_cols && h_wait > 0.0) { if (leader) { hout[0] = h_nnz; hout[1] = h_wait - 1.0; } return; }
+    double sums[5];
+    {
+        const WideNormRaw nraw = wide_norms_request(q, lane);
+        wide_norms_finish(q, lane, nraw, sums);
+    }
+    WideDecision dec = wide_decide(q, in, sums, lane);
+    WideCtl out = wide_ctl_uniform(dec.out);
+    if (out.done || out.type != W_ACT || __builtin_amdgcn_readfirstlane(dec.lam_finished) >= 0) { if (leader) { hout[0] = h_nnz; hout[1] = h_wait; } return; }
+    // ---- where do we run?  Every workgroup announces its XCD (write-through, valid under any placement); the answer is
+    // collected below, after the loads of the prologue have been issued
+    if (threadIdx.x == 0) __hip_atomic_store(ps.flagX + (size_t)g * 8, (ps.seq << 32) | (unsigned long long)(wp_xcc_id() + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // ---- this wave's x slots, its share of the rows, in registers for the whole stretch
+    float xs[kPNU];
+#pragma unroll
+    for (int u = 0; u < kPNU; ++u) {
+        const long long jl = (long long)(u * 64 + lane) * NWp + w;
+        xs[u] = jl < q.p ? q.x[jl] : 0.f;
+    }
+    const int R = npad / kPG;                                   // rows per workgroup, a multiple of 8
+    // reducer mapping: 8 lanes share a PAIR of rows (4 of the kPG partials each); pairs beyond R / 2 idle
+    const int sub = threadIdx.x & 7, pair = threadIdx.x >> 3;
+    const int npairs_pass = kWideThreads / 8;                    // 32 pairs = 64 rows per pass
+    constexpr int MAXP = 4;                                      // R <= 256 rows per workgroup (n <= 8192)
+    float ax_r[MAXP][2], z_r[MAXP][2], y_r[MAXP][2], yd_r[MAXP][2];
+#pragma unroll
+    for (int ps_ = 0; ps_ < MAXP; ++ps_) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int i = g * R + (ps_ * npairs_pass + pair) * 2 + e;
+            const bool own = (ps_ * npairs_pass + pair) * 2 < R && i < q.n;
+            ax_r[ps_][e] = own ? q.Ax[i] : 0.f; z_r[ps_][e] = own ? q.z[i] : 0.f; y_r[ps_][e] = own ? q.y[i] : 0.f; yd_r[ps_][e] = own ? q.Y[i] : 0.f;
+        }
+    }
+    // first t from the vectors the tail launch left (plain loads: written by an earlier launch)
+    {
+        const float rho_f = (float)out.rho;
+        for (int i = threadIdx.x; i < npad; i += kWideThreads) {
+            const float t = i < q.n ? (q.Ax[i] + q.z[i]) + q.y[i] / rho_f : 0.f;
+            tdl[i] = t / q.gamma;
+        }
+    }
+    const int nv = (q.n + 3) / 4 * 4;
+    // the wave's first non-zero column stays in registers for the whole stretch (the active set only shrinks inside it:
+    // a zero never comes back before the next regular step): no column round trip in most iterations
+    int cu0 = -1, cl0 = -1;
+#pragma unroll
+    for (int u = 0; u < kPNU; ++u) {
+        const unsigned long long m = __ballot(xs[u] != 0.f);
+        if (cu0 < 0 && m != 0) { cu0 = u; cl0 = __ffsll((long long)m) - 1; }
+    }
+    float4 cv0[RT];
+#pragma unroll
+    for (int kk = 0; kk < RT; ++kk) cv0[kk] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cu0 >= 0) {
+        const float* col = q.X + (size_t)((long long)(cu0 * 64 + cl0) * NWp + w) * q.ldx;
+#pragma unroll
+        for (int kk = 0; kk < RT; ++kk) {
+            const int r = kk * 256 + lane * 4;
+            if (r < nv) cv0[kk] = *reinterpret_cast<const float4*>(col + r);
+        }
+    }
+    if (!wp_wait_xcc(ps.flagX, ps.seq, ps.err, &s_ok, &s_same)) return;       // (also the barrier after staging t)
+    const bool wt = s_same == 0;                                 // not all on one XCD: payloads must be written through
+    unsigned long long k = 0;                                    // iterations completed in this launch
+    bool failed = false;
+    double nz_last = 0.0;
+    const long long tick0 = wall_clock64();
+    long long ph[6] = {0, 0, 0, 0, 0, 0}, tp = tick0;              // diagnostics: ticks per phase, as seen by workgroup 0
+#define WP_PHASE(i) { const long long tn = wall_clock64(); ph[i] += tn - tp; tp = tn; }
+    for (;;) {
+        // ---- (record the decision being acted on: what the x-update launch writes)
+        if (g == 0 && threadIdx.x == 0 && q.trace != nullptr && in.total < q.trace_cap) {
+            double* t = q.trace + (size_t)in.total * ADMM_TRACE_FIELDS;
+            t[0] = in.lam_idx; t[1] = in.iter; t[2] = in.eps_primal; t[3] = in.eps_dual; t[4] = dec.rp; t[5] = dec.rd;
+            t[6] = out.rho; t[7] = out.type; t[8] = dec.code; t[9] = in.rho; t[10] = out.rho; t[11] = in.lam;
+        }
+        // ---- (B) active-set update of this wave's non-zero columns (ADMMLassoWide.h:86-118 / ADMMEnet.h:85-122)
+        const double pen_d = (double)out.lam / (out.rho * (double)q.gamma);
+        const float penalty = (float)pen_d;
+        const float thresh_a = q.enet ? q.alpha * penalty : penalty;
+        const float denom_a = q.enet ? (float)(1.0 + (double)penalty * (1.0 - (double)q.alpha)) : 1.f;
+        float4 acc[RT];
+#pragma unroll
+        for (int kk = 0; kk < RT; ++kk) acc[kk] = make_float4(0.f, 0.f, 0.f, 0.f);
+        int nnz_w = 0;
+#pragma unroll
+        for (int u = 0; u < kPNU; ++u) {
+            unsigned long long mask = __ballot(xs[u] != 0.f);
+            while (mask) {
+                const int l = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                const long long jj = (long long)(u * 64 + l) * NWp + w;
+                const float xv = __shfl(xs[u], l, 64);
+                const float* col = q.X + (size_t)jj * q.ldx;
+                float4 cv[RT];
+                if (u == cu0 && l == cl0) {
+#pragma unroll
+                    for (int kk = 0; kk < RT; ++kk) cv[kk] = cv0[kk];
+                } else {
+#pragma unroll
+                    for (int kk = 0; kk < RT; ++kk) {
+                        const int r = kk * 256 + lane * 4;
+                        cv[kk] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (r < nv) cv[kk] = *reinterpret_cast<const float4*>(col + r);
+                    }
+                }
+                float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < RT; ++kk) {
+                    const int r = kk * 256 + lane * 4;
+                    if (r < nv) {
+                        const float4 b = *reinterpret_cast<const float4*>(tdl + r);
+                        float& dd = (kk & 1) ? d1 : d0;
+                        dd = fmaf(cv[kk].x, b.x, dd); dd = fmaf(cv[kk].y, b.y, dd); dd = fmaf(cv[kk].z, b.z, dd); dd = fmaf(cv[kk].w, b.w, dd);
+                    }
+                }
+                const float xn = prox_f(xv - wave_sum(d0 + d1), thresh_a, denom_a, q.enet != 0);
+                if (xn != 0.f) {
+                    nnz_w++;
+#pragma unroll
+                    for (int kk = 0; kk < RT; ++kk) {
+                        acc[kk].x = fmaf(xn, cv[kk].x, acc[kk].x); acc[kk].y = fmaf(xn, cv[kk].y, acc[kk].y);
+                        acc[kk].z = fmaf(xn, cv[kk].z, acc[kk].z); acc[kk].w = fmaf(xn, cv[kk].w, acc[kk].w);
+                    }
+                }
+                if (lane == l) xs[u] = xn;
+            }
+        }
+        WP_PHASE(0)
+        // ---- (C) the workgroup's partial of A x: the 4 waves in order, written through
+        __syncthreads();                                         // everybody is done with tdl's neighbour `red` of the last round
+#pragma unroll
+        for (int kk = 0; kk < RT; ++kk) red[kk * kWideThreads + threadIdx.x] = acc[kk];
+        __syncthreads();
+        for (int e = threadIdx.x; e < npad / 2; e += kWideThreads) {          // element pair e: rows 2 e, 2 e + 1
+            const int r0 = 2 * e, kk = r0 / 256, ln = (r0 % 256) / 4, c = r0 & 3;
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < kWideThreads / 64; ++ww) {
+                const float4 v = red[kk * kWideThreads + ww * 64 + ln];
+                const float a = c == 0 ? v.x : v.z, b = c == 0 ? v.y : v.w;
+                s0 = ww == 0 ? a : s0 + a; s1 = ww == 0 ? b : s1 + b;
+            }
+            wp_store2(q.axpart + (size_t)g * q.ldn + r0, s0, s1, wt);
+        }
+        const unsigned long long tag = (ps.seq << 32) | (k + 1);
+        wp_publish(ps.flagA + (size_t)g * 8, tag);
+        WP_PHASE(1)
+        // ---- (D) rows of this workgroup: A x from the kPG partials in workgroup order, z / y update, norm shares
+        if (!wp_wait(ps.flagA, tag, ps.err, &s_ok)) { failed = true; break; }
+        WP_PHASE(2)
+        double nacc[5] = {0, 0, 0, 0, 0};
+        {
+            const float rho_f = (float)out.rho;
+            const float den = (float)(-1.0 - out.rho);
+#pragma unroll
+            for (int ps_ = 0; ps_ < MAXP; ++ps_) {
+                const int pr = ps_ * npairs_pass + pair;
+                if (pr * 2 < R) {
+                    const int i0 = g * R + pr * 2;
+                    float2 v[kPG / 8];
+#pragma unroll
+                    for (int m = 0; m < kPG / 8; ++m) v[m] = wp_load2(q.axpart + (size_t)(m * 8 + sub) * q.ldn + i0);
+                    float a0 = v[0].x, a1 = v[0].y;
+#pragma unroll
+                    for (int m = 1; m < kPG / 8; ++m) { a0 += v[m].x; a1 += v[m].y; }
+#pragma unroll
+                    for (int m = 1; m < 8; m <<= 1) { a0 += __shfl_xor(a0, m, 64); a1 += __shfl_xor(a1, m, 64); }
+                    if (sub == 0) {
+#pragma clang fp contract(off)
+                        const float axn[2] = {a0, a1};
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            if (i0 + e < q.n) {
+                                const float ax = axn[e];
+                                const float zn = (yd_r[ps_][e] + y_r[ps_][e] + rho_f * ax) / den;      // next_z (:156-165)
+                                const float dz = zn - z_r[ps_][e];
+                                const float r = ax + zn;                                               // next_residual (:166-170)
+                                const float yn = y_r[ps_][e] + rho_f * r;                              // ADMMBase.h:183
+                                ax_r[ps_][e] = ax; z_r[ps_][e] = zn; y_r[ps_][e] = yn;
+                                nacc[0] += (double)r * r; nacc[1] += (double)dz * dz; nacc[2] += (double)ax * ax;
+                                nacc[3] += (double)zn * zn; nacc[4] += (double)yn * yn;
+                            }
+                        }
+                        wp_store2(ps.sz + i0, ax_r[ps_][0] + z_r[ps_][0], ax_r[ps_][1] + z_r[ps_][1], wt);
+                        wp_store2(ps.yv + i0, y_r[ps_][0], y_r[ps_][1], wt);
+                    }
+                }
+            }
+        }
+        {   // the workgroup's norm shares and non-zero count: fixed order (lanes, then waves)
+            double* scr = reinterpret_cast<double*>(red);                     // `red` has been consumed (barrier inside wp_wait)
+            double v6[6] = {nacc[0], nacc[1], nacc[2], nacc[3], nacc[4], (double)nnz_w};
+#pragma unroll
+            for (int m = 0; m < 6; ++m) v6[m] = wave_sum(v6[m]);
+            // nnz_w is wave uniform: wave_sum multiplied it by 64
+            if (lane == 0) {
+#pragma unroll
+                for (int m = 0; m < 6; ++m) scr[wid * 8 + m] = v6[m];
+            }
+            __syncthreads();
+            if (threadIdx.x < 6) {
+                double t = 0;
+                for (int ww = 0; ww < kWideThreads / 64; ++ww) t += scr[ww * 8 + threadIdx.x];
+                if (threadIdx.x == 5) t *= 1.0 / 64.0;
+                wp_store_f64(ps.np + (size_t)g * 8 + threadIdx.x, t, wt);
+            }
+        }
+        wp_publish(ps.flagB + (size_t)g * 8, tag);
+        WP_PHASE(3)
+        k++;
+        // ---- (E) the decision on this iteration, by everybody from the same numbers
+        if (!wp_wait(ps.flagB, tag, ps.err, &s_ok)) { failed = true; break; }
+        WP_PHASE(4)
+        in = out;
+        // everything the rest of the iteration needs is requested at once: the norm shares AND the vectors of the next t
+        constexpr int NE = (RT * 256 / 2 + kWideThreads - 1) / kWideThreads;          // element pairs per thread
+        float2 sza[NE], yva[NE];
+#pragma unroll
+        for (int ee = 0; ee < NE; ++ee) {
+            const int e = ee * kWideThreads + threadIdx.x;
+            sza[ee] = make_float2(0.f, 0.f); yva[ee] = make_float2(0.f, 0.f);
+            if (e < npad / 2) { sza[ee] = wp_load2(ps.sz + 2 * e); yva[ee] = wp_load2(ps.yv + 2 * e); }
+        }
+        double nz_total;
+        {
+            double sh[6];
+#pragma unroll
+            for (int m = 0; m < 6; ++m)
+                sh[m] = lane < kPG ? __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(ps.np + (size_t)lane * 8 + m),
+                                                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0.0;
+#pragma unroll
+            for (int m = 0; m < 5; ++m) sums[m] = sh[m];
+            nz_total = wave_sum(sh[5]);
+        }
+        nz_last = nz_total;
+        dec = wide_decide(q, in, sums, lane);
+        out = wide_ctl_uniform(dec.out);
+        const bool go_on = !out.done && out.type == W_ACT && __builtin_amdgcn_readfirstlane(dec.lam_finished) < 0 && nz_total <= (double)ps.max_cols;
+        if (!go_on) { WP_PHASE(5) break; }
+        {   // t of the next active-set step from what the row owners published
+            const float rho_f = (float)out.rho;
+#pragma unroll
+            for (int ee = 0; ee < NE; ++ee) {
+                const int e = ee * kWideThreads + threadIdx.x;
+                if (e < npad / 2) {
+                    const float2 a = sza[ee], b = yva[ee];
+                    const float t0 = 2 * e < q.n ? a.x + b.x / rho_f : 0.f, t1 = 2 * e + 1 < q.n ? a.y + b.y / rho_f : 0.f;
+                    tdl[2 * e] = t0 / q.gamma; tdl[2 * e + 1] = t1 / q.gamma;
+                }
+            }
+        }
+        __syncthreads();
+        WP_PHASE(5)
+    }
+    if (failed) return;
+    if (leader) {
+        hout[0] = nz_last; hout[1] = 64.0;
+        ps.stat[0] += k; ps.stat[1] += 1; ps.stat[2] += (unsigned long long)(wall_clock64() - tick0); ps.stat[3] += wt ? 1 : 0;
+        for (int i = 0; i < 6; ++i) ps.stat[4 + i] += (unsigned long long)ph[i];
+    }
+    // ---- leave everything as a tail launch would have: x, A x, z, y, the norm partials, the control block
+#pragma unroll
+    for (int u = 0; u < kPNU; ++u) {
+        const long long jl = (long long)(u * 64 + lane) * NWp + w;
+        if (jl < q.p) q.x[jl] = xs[u];
+    }
+    if (sub == 0) {
+#pragma unroll
+        for (int ps_ = 0; ps_ < MAXP; ++ps_) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int pr = ps_ * npairs_pass + pair;
+                const int i = g * R + pr * 2 + e;
+                if (pr * 2 < R && i < q.n) { q.Ax[i] = ax_r[ps_][e]; q.z[i] = z_r[ps_][e]; q.y[i] = y_r[ps_][e]; }
+            }
+        }
+    }
+    if (g == 0) {
+        for (int idx = threadIdx.x; idx < q.nwg_tail * 8 || idx < kPG * 8; idx += kWideThreads) {
+            const int row = idx >> 3, m = idx & 7;
+            double v = 0.0;
+            if (row < kPG && m < 5) v = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(ps.np + (size_t)row * 8 + m),
+                                                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            q.P[idx] = v;                                       // P holds max(nwg_tail, kWideNormRows) >= kPG rows
+        }
+        if (threadIdx.x == 0) q.ctl[cpar] = in;                 // the state the breaking decision was taken FROM: the next launch repeats it
+    }
+}
+
 __global__ void wide_init_kernel(WideParams q, double rho, float lam0) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < q.p) q.x[i] = 0.f;
@@ -939,7 +1356,41 @@ struct WidePlan final : LassoPlan {
         probe.alloc((size_t)4096 * 4 * 8); probe.zero(st);
         q.probe = probe.get();
 #endif
+        setup_persist();
         ADMM_HIP_CHECK(hipStreamSynchronize(st));
+    }
+
+    // persistent active-set stretch (wide_act_persist_kernel)
+    bool persist = false;
+    DevBuf<unsigned long long> pflags;
+    DevBuf<float> psz, pyv;
+    DevBuf<double> pnp, phint;
+    DevBuf<int> perr;
+    DevBuf<unsigned long long> pstat;
+    unsigned long long pseq = 0;
+    int pmax_cols = 512;
+    size_t lds_persist = 0;
+
+    void setup_persist() {
+        persist = (fuse_rt == 4 || fuse_rt == 8) && !cshard && (long long)p <= (long long)kPNU * 64 * kPG * (kWideThreads / 64);
+        if (const char* e = std::getenv("ADMM_HIP_WIDE_PERSIST")) if (std::string(e) == "0") persist = false;
+        if (const char* e = std::getenv("ADMM_HIP_WIDE_PERSIST_COLS")) pmax_cols = std::max(1, std::atoi(e));
+        if (!persist) return;
+        const size_t npad = (size_t)(n + 255) / 256 * 256;
+        lds_persist = npad * sizeof(float) + (size_t)fuse_rt * kWideThreads * sizeof(float4);
+        pflags.alloc((size_t)3 * kPG * 8); pflags.zero(st);
+        psz.alloc(npad); pyv.alloc(npad); psz.zero(st); pyv.zero(st);
+        pnp.alloc((size_t)kPG * 8); pnp.zero(st);
+        phint.alloc(4); phint.zero(st);
+        perr.alloc(1); perr.zero(st);
+        pstat.alloc(16); pstat.zero(st);
+    }
+    void launch_persist(int cpar) {
+        WidePersist ps;
+        ps.flagA = pflags.get(); ps.flagB = pflags.get() + (size_t)kPG * 8; ps.flagX = pflags.get() + (size_t)2 * kPG * 8;
+        ps.sz = psz.get(); ps.yv = pyv.get(); ps.np = pnp.get(); ps.err = perr.get(); ps.seq = ++pseq; ps.max_cols = pmax_cols; ps.hint = phint.get(); ps.stat = pstat.get();
+        if (fuse_rt == 4) hipLaunchKernelGGL(wide_act_persist_kernel<4>, dim3(8 * kPG), dim3(kWideThreads), lds_persist, st, q, cpar, ps);
+        else hipLaunchKernelGGL(wide_act_persist_kernel<8>, dim3(8 * kPG), dim3(kWideThreads), lds_persist, st, q, cpar, ps);
     }
 
     void run(LassoResult& res) override {
@@ -947,6 +1398,7 @@ struct WidePlan final : LassoPlan {
         res.lambda = lam_user;
         beta.zero(st); niter.zero(st);
         *hflag.p = 0;
+        if (persist) { phint.zero(st); perr.zero(st); }
         const int init_n = std::max(std::max(n, p), nwg_tail * 8);
         hipLaunchKernelGGL(wide_init_kernel, dim3((init_n + 255) / 256), dim3(256), 0, st, q, rho0, lam_int[0]);
         const int batch = pb.batch_iters > 0 ? (pb.batch_iters + 1) / 2 * 2 : 16;
@@ -982,8 +1434,24 @@ struct WidePlan final : LassoPlan {
                 allreduce_sum_f32(axl.get(), (size_t)n, st);
             }
             hipLaunchKernelGGL(wide_tail_kernel<0>, dim3(nwg_tail), dim3(kWideThreads), 0, st, q, par, PeerExchange{});
+            if (persist) launch_persist(par ^ 1);                      // takes over from the state the next x-update launch would start from
         }, cshard ? nullptr : hflag.p);       // column-sharded: every rank must enqueue the same number of exchanges -> stream-ordered sampling of `done`
         S.t_loop = lt.wall_s; S.loop_ms_events = lt.events_ms; S.xupdate_launches = lt.launched;
+        if (persist) {
+            int herr = 0;
+            ADMM_HIP_CHECK(hipMemcpy(&herr, perr.get(), sizeof(int), hipMemcpyDeviceToHost));
+            if (herr) throw Error(ADMM_ERR_INTERNAL, "wide solver: a hand-over inside the persistent active-set launch timed out");
+            if (std::getenv("ADMM_HIP_WIDE_PERSIST_STATS")) {
+                unsigned long long hs[16] = {0};
+                ADMM_HIP_CHECK(hipMemcpy(hs, pstat.get(), sizeof(hs), hipMemcpyDeviceToHost));
+                const double it = hs[0] ? (double)hs[0] : 1.0;
+                std::fprintf(stderr, "[wide persist] %llu iterations in %llu stretches (%llu of them not on one XCD), %.2f us per iteration inside; %lld host iterations enqueued\n"
+                             "[wide persist] per iteration, workgroup 0: columns %.2f | combine + publish partial %.2f | wait partials %.2f | rows + publish %.2f | wait rows %.2f | decide + t %.2f us\n",
+                             hs[0], hs[1], hs[3], hs[0] ? 0.01 * (double)hs[2] / it : 0.0, (long long)lt.launched,
+                             0.01 * hs[4] / it, 0.01 * hs[5] / it, 0.01 * hs[6] / it, 0.01 * hs[7] / it, 0.01 * hs[8] / it, 0.01 * hs[9] / it);
+                pstat.zero(st);
+            }
+        }
 #ifdef ADMM_HIP_PROBE
         if (const char* f = std::getenv("ADMM_HIP_PROBE_OUT")) {
             std::vector<long long> hp((size_t)4096 * 4 * 8);
