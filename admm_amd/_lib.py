@@ -27,7 +27,8 @@ class AdmmStats(ctypes.Structure):
                 ("xupdate_ms_avg", ctypes.c_double), ("xupdate_samples", ctypes.c_longlong),
                 ("total_iter", ctypes.c_longlong), ("xupdate_launches", ctypes.c_longlong),
                 ("rho", ctypes.c_double), ("eig_est", ctypes.c_double),
-                ("branch", ctypes.c_int), ("xupdate_variant", ctypes.c_int)]
+                ("branch", ctypes.c_int), ("xupdate_variant", ctypes.c_int),
+                ("exchange_variant", ctypes.c_int), ("refine", ctypes.c_int), ("persist_iter", ctypes.c_longlong)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -113,6 +113,11 @@ struct DeviceInfo {
     size_t lds_optin = 64 * 1024;        // ... after hipFuncSetAttribute(hipFuncAttributeMaxDynamicSharedMemorySize) (160 KB on gfx950)
 };
 const DeviceInfo& device_info();   // queries the current device once per device id
+// Workgroups of a kernel the device holds resident at once, given the occupancy query's answer per CU.  Launches whose
+// workgroups WAIT for one another (the single-launch PEER exchange of the sharded solvers) are only chosen when their whole
+// grid fits into half of this.  ADMM_HIP_TEST_RESIDENT_WGS overrides it (test hook: pretends the device holds fewer, so that
+// the condition is violated on purpose and the fallback -- separate producer and consumer launches -- must be taken).
+long long resident_workgroups(int occupancy_per_cu);
 void require_device();             // throws ADMM_ERR_NO_DEVICE when no usable HIP device
 
 }  // namespace admm

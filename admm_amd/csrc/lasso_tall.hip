@@ -625,7 +625,7 @@ struct TallPlan final : LassoPlan {
             int occ = 0;
             ADMM_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(tall_tail_kernel<TAIL_PEER1>), kTailThreads, 0));
             const int nwg_tail = (p + kTailElems - 1) / kTailElems;
-            peer_one = (long long)nwg_tail * 2 <= (long long)occ * device_info().num_cu;
+            peer_one = (long long)nwg_tail * 2 <= resident_workgroups(occ);
             if (const char* e = std::getenv("ADMM_HIP_PEER_FUSED")) { if (std::string(e) == "2") peer_one = false; }
         }
         // single-launch iteration (single GPU, symmetric x-update): opt-in with ADMM_HIP_TALL_FUSED=1 (=2: the tiles also
@@ -710,6 +710,7 @@ struct TallPlan final : LassoPlan {
         }
         admm_stats S = setup_stats;
         S.xupdate_variant = shard ? 2 : (fused ? 3 : (use_sym ? 1 : 0));
+        S.exchange_variant = !shard ? 0 : (!peer_fused ? 1 : (peer_one ? 3 : 2));
         res.lambda = lam_user;
         beta.zero(st); niter.zero(st);
         const int init_n = std::max(p, 2 * nwg * 8);

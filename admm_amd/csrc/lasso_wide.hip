@@ -1296,7 +1296,7 @@ struct WidePlan final : LassoPlan {
         if (peer_fused) {
             int occ = 0;
             ADMM_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(wide_tail_kernel<2>), kWideThreads, 0));
-            peer_one = (long long)nwg_tail * 2 <= (long long)occ * device_info().num_cu;
+            peer_one = (long long)nwg_tail * 2 <= resident_workgroups(occ);
             if (const char* e = std::getenv("ADMM_HIP_PEER_FUSED")) { if (std::string(e) == "2") peer_one = false; }
         }
         x.alloc(ldp); x.zero(st);
@@ -1437,19 +1437,21 @@ struct WidePlan final : LassoPlan {
             if (persist) launch_persist(par ^ 1);                      // takes over from the state the next x-update launch would start from
         }, cshard ? nullptr : hflag.p);       // column-sharded: every rank must enqueue the same number of exchanges -> stream-ordered sampling of `done`
         S.t_loop = lt.wall_s; S.loop_ms_events = lt.events_ms; S.xupdate_launches = lt.launched;
+        S.exchange_variant = !cshard ? 0 : (!peer_fused ? 1 : (peer_one ? 3 : 2));
         if (persist) {
             int herr = 0;
             ADMM_HIP_CHECK(hipMemcpy(&herr, perr.get(), sizeof(int), hipMemcpyDeviceToHost));
             if (herr) throw Error(ADMM_ERR_INTERNAL, "wide solver: a hand-over inside the persistent active-set launch timed out");
+            unsigned long long hs[16] = {0};
+            ADMM_HIP_CHECK(hipMemcpy(hs, pstat.get(), sizeof(hs), hipMemcpyDeviceToHost));
+            S.persist_iter = (long long)hs[0];
+            pstat.zero(st);
             if (std::getenv("ADMM_HIP_WIDE_PERSIST_STATS")) {
-                unsigned long long hs[16] = {0};
-                ADMM_HIP_CHECK(hipMemcpy(hs, pstat.get(), sizeof(hs), hipMemcpyDeviceToHost));
                 const double it = hs[0] ? (double)hs[0] : 1.0;
                 std::fprintf(stderr, "[wide persist] %llu iterations in %llu stretches (%llu of them not on one XCD), %.2f us per iteration inside; %lld host iterations enqueued\n"
                              "[wide persist] per iteration, workgroup 0: columns %.2f | combine + publish partial %.2f | wait partials %.2f | rows + publish %.2f | wait rows %.2f | decide + t %.2f us\n",
                              hs[0], hs[1], hs[3], hs[0] ? 0.01 * (double)hs[2] / it : 0.0, (long long)lt.launched,
                              0.01 * hs[4] / it, 0.01 * hs[5] / it, 0.01 * hs[6] / it, 0.01 * hs[7] / it, 0.01 * hs[8] / it, 0.01 * hs[9] / it);
-                pstat.zero(st);
             }
         }
 #ifdef ADMM_HIP_PROBE

@@ -23,6 +23,11 @@ void require_device() {
         throw Error(ADMM_ERR_NO_DEVICE, "no usable HIP device (libadmm_hip has no CPU fallback)");
 }
 
+long long resident_workgroups(int occupancy_per_cu) {
+    if (const char* e = std::getenv("ADMM_HIP_TEST_RESIDENT_WGS")) { const long long v = std::atoll(e); if (v >= 0) return v; }
+    return (long long)occupancy_per_cu * device_info().num_cu;
+}
+
 const DeviceInfo& device_info() {
     static std::mutex mu;
     static std::vector<DeviceInfo> cache;

@@ -86,6 +86,11 @@ typedef struct admm_stats {
     int xupdate_variant;   /* tall path: 0 = full-matrix mat-vec (4p^2 B), 1 = lower-triangle symmetric mat-vec (2p^2 B),
                               2 = the same with the tiles dealt out to the ranks + one all-reduce of 2p floats (admm_hip_lasso_dist),
                               3 = 1 with the element-wise tail of the previous iteration inside the same launch (one launch per iteration) */
+    int exchange_variant;  /* sharded solvers: how the per-iteration exchange ran -- 0 none, 1 the exchange layer's all-reduce, 2 PEER slots written /
+                              read by the solver's own kernels (producer and consumer launches), 3 the same with producer and consumer in ONE
+                              launch (chosen only when that launch is resident as a whole: its workgroups wait for one another) */
+    int refine;            /* tall path: 1 = every x-update refined once with a double-precision residual (ADMM_HIP_REFINE=1) */
+    long long persist_iter;/* wide path: iterations that ran inside persistent active-set launches (of total_iter) */
 } admm_stats;
 
 /* lambda_in: user grid of length nlambda_in (sorted decreasing by the R wrapper), or NULL/0

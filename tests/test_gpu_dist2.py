@@ -188,3 +188,20 @@ def test_shm_bootstrap_ignores_a_stale_segment_of_the_same_name():
     finally:
         if os.path.exists(path):
             os.unlink(path)
+
+
+@pytest.mark.parametrize("case", ["tallshard2300", "widecols"])
+def test_single_launch_exchange_falls_back_when_its_grid_would_not_be_resident(case):
+    """The PEER exchange of the two sharded solvers normally runs producer and consumer in ONE launch (tall_tail_kernel
+    <TAIL_PEER1>, wide_tail_kernel<2>): every workgroup publishes its share, counts itself in and then WAITS for the flags,
+    which need all workgroups of that launch on every rank -- correct only if the whole grid is resident at once, so the
+    host chooses it only when the grid fits into half of what the device holds (lasso_tall.hip / lasso_wide.hip,
+    resident_workgroups).  Here that condition is VIOLATED on purpose (ADMM_HIP_TEST_RESIDENT_WGS=4: a device that holds four
+    workgroups): the solvers must take the two-launch form (exchange_variant 2, not 3) -- no hang -- and return the very
+    same bits."""
+    one = _run_ranks("peer", case)
+    two = _run_ranks("peer", case, extra_env=dict(ADMM_HIP_TEST_RESIDENT_WGS="4"))
+    assert int(one[0]["exchange_variant"]) == 3 and int(two[0]["exchange_variant"]) == 2, (one[0]["exchange_variant"], two[0]["exchange_variant"])
+    for r in range(2):
+        assert np.array_equal(one[r]["beta"], two[r]["beta"]) and np.array_equal(one[r]["niter"], two[r]["niter"])
+        assert np.array_equal(one[r]["trace"], two[r]["trace"])
