@@ -77,6 +77,8 @@ struct TallParams {
 #endif
     double* trace;              // optional [trace_cap][kTraceFields] decision records (admm_hip_lasso_plan_trace_*), or NULL
     long long trace_cap;
+    const float* refine_ab;     // refined x-update (ADMM_HIP_REFINE=1): the first solve's a | b (leading dimension refine_ld), to which the tail adds
+    long long refine_ld;        // the correction it sums from the partials; NULL otherwise
     float* state;               // optional [state_cap][5][p] iterates x, z, y, adj_z, adj_y of every iteration (admm_hip_lasso_plan_state_*), or NULL
     long long state_cap;
 };
@@ -286,6 +288,10 @@ tall_tail_kernel(TallParams q, int par, PeerExchange ex) {
     float a = 0.f, b = 0.f;
     if (MODE == TAIL_SYMV) {
         symv_sum_partials<kTailLanes>(q.dot0, q.dot1, q.axp0, q.axp1, q.ldo, q.nrb, q.sched, q.p32, i, sub, valid, a, b);
+        if (q.refine_ab != nullptr && valid) {            // x = x1 + Minv (rhs - M x1): the partials hold the correction
+            a = q.refine_ab[i] + a;
+            b = q.refine_ab[q.refine_ld + i] + b;
+        }
     } else if (MODE == TAIL_PEER || MODE == TAIL_PEER1) {
         const bool live = !q.ctl[par].done;                          // finished in an earlier launch: nothing pushed, nothing to wait for (replicated flag: all ranks agree)
         if (MODE == TAIL_PEER1 && live) {
@@ -448,6 +454,18 @@ tall_shard_reduce_kernel(TallParams q, float* ab, long long ld, const int* skip)
     if (i < q.p && sub == 0) { ab[i] = a; ab[ld + i] = b; }
 }
 
+// Refined x-update, residual step: r = rhs - M x1 for both candidates, M x1 from the double partial arrays of
+// symv2_lower_f64acc_kernel, the subtraction in double, the result rounded to float once.
+__global__ void __launch_bounds__(kTailThreads)
+tall_refine_resid_kernel(TallParams q, const double* d0, const double* d1, const double* x0, const double* x1, float* ru, float* rw, const int* skip) {
+    if (*skip) return;
+    const int sub = threadIdx.x & (kTailLanes - 1);
+    const int i = blockIdx.x * kTailElems + threadIdx.x / kTailLanes;
+    double ma, mb;
+    symv_sum_partials<kTailLanes, double>(d0, d1, x0, x1, q.ldo, q.nrb, q.sched, q.p32, i, sub, i < q.p, ma, mb);
+    if (i < q.p && sub == 0) { ru[i] = (float)((double)q.u[i] - ma); rw[i] = (float)((double)q.w[i] - mb); }
+}
+
 // The same over the PEER exchange, without launches of the exchange layer: every workgroup writes its elements of
 // (a, b) straight into this rank's slot of EVERY rank's buffer (lane `sub` of an element's group serves rank sub,
 // sub + 8, ...), and the last workgroup to finish raises the flags (peer_device.h).
@@ -513,6 +531,10 @@ struct TallPlan final : LassoPlan {
     long long trace_cap = 0, trace_n = 0;
     DevBuf<float> state;
     long long state_cap = 0;
+    // mixed-precision refinement of the x-update (ADMM_HIP_REFINE=1)
+    bool refine = false;
+    DevBuf<float> Mg, rab, ruw;                          // the float system X'X + rho I; first solve a | b; residuals r_u | r_w
+    DevBuf<double> dD0, dD1, xD0, xD1;                   // double partial arrays of M x1
     TallCtl* hctl = nullptr;
     PinnedFlag hflag;
 #ifdef ADMM_HIP_PROBE
@@ -589,6 +611,16 @@ struct TallPlan final : LassoPlan {
         // of the cached inverse then carries half an ulp instead of cond * ulp (useful when n ~ p); it costs 150 ms more at
         // p = 10^4 and does not change how often the stopping rule flips against a float Cholesky solve (measured with
         // tests/tools/flip_floor.py: 45 vs 44 of 185 lambdas, the reference's own solve against the exact one: 39).
+        // ADMM_HIP_REFINE=1 (opt-in): every x-update is refined once, x = x1 + Minv (rhs - M x1) with the residual in double
+        // from the float system M = X'X + rho I (the reference's: XX.diagonal() += rho in float, ADMMLassoTall.h:204) -- the
+        // x-update's error against the exact solve of that system drops from cond(M) ulps to about one ulp, i.e. onto what
+        // oracle/variants.py calls the `exact` variant, at three passes over the triangle per iteration instead of one.
+        if (const char* e = std::getenv("ADMM_HIP_REFINE")) refine = std::string(e) == "1" && !shard;
+        if (refine) {
+            Mg.alloc((size_t)ldp * ldp);
+            ADMM_HIP_CHECK(hipMemcpyAsync(Mg.get(), M.get(), (size_t)ldp * ldp * sizeof(float), hipMemcpyDeviceToDevice, st));
+            add_diag<float>(Mg.get(), ldp, p, (float)rho, st);
+        }
         t0 = now_s();
         // Policy: double below p = 4096 (a few ms there, and the float inverse is 30-100x less accurate: 1-3e-6 against
         // 3e-8 of the largest entry at cond ~ 30, tests/test_gpu_kernels.py), float above.
@@ -610,11 +642,19 @@ struct TallPlan final : LassoPlan {
         // gemv_t (4p^2 bytes, fewer and larger workgroups) for small p.  ADMM_HIP_XUPDATE=full|sym overrides.
         use_sym = p >= 2048;
         if (const char* e = std::getenv("ADMM_HIP_XUPDATE")) use_sym = std::string(e) == "sym";
+        if (refine) use_sym = true;                      // the refinement is built on the symmetric kernel's partial layout
         if (shard) use_sym = true;                       // the sharded x-update is the tile list of the symmetric kernel dealt out to the ranks
         pl = plan_gemv_t<float>(p, p, 2, 4);
         nwg = (p + kTailElems - 1) / kTailElems;
         ldv = round_up(p, 256);                         // symv reads the right-hand vectors in 256-row blocks
         if (use_sym) sy.init(p, st, shard ? ci.rank : 0, shard ? ci.nranks : 1);
+        if (refine) {
+            rab.alloc((size_t)2 * ldv); rab.zero(st);
+            ruw.alloc((size_t)2 * ldv); ruw.zero(st);
+            dD0.alloc((size_t)sy.nrb * sy.ldo); dD1.alloc((size_t)sy.nrb * sy.ldo);
+            xD0.alloc((size_t)sy.nax_rows * sy.ldo); xD1.alloc((size_t)sy.nax_rows * sy.ldo);
+            dD0.zero(st); dD1.zero(st); xD0.zero(st); xD1.zero(st);
+        }
         if (shard) { ab.alloc((size_t)2 * ldp); ab.zero(st); }
         else if (!use_sym) { a_part.alloc((size_t)pl.nseg * ldp); b_part.alloc((size_t)pl.nseg * ldp); a_part.zero(st); b_part.zero(st); }
         // ADMM_HIP_PEER_FUSED=0: go through the generic all-reduce of the exchange layer also on the PEER backend
@@ -654,6 +694,7 @@ struct TallPlan final : LassoPlan {
         if (shard) { q.a_part = ab.get(); q.b_part = ab.get() + ldp; q.nseg = 1; }      // the tail reads the all-reduced pair (generic exchange)
         q.dot0 = sy.dot0.get(); q.dot1 = sy.dot1.get(); q.axp0 = sy.axp0.get(); q.axp1 = sy.axp1.get();
         q.ldo = sy.ldo; q.nrb = sy.nrb; q.p32 = sy.p32; q.sched = sy.sched;
+        q.refine_ab = refine ? rab.get() : nullptr; q.refine_ld = ldv;
         q.x = x.get(); q.z0 = z0.get(); q.z1 = z1.get(); q.y0 = y0.get(); q.y1 = y1.get();
         q.adj_z = adj_z.get(); q.adj_y = adj_y.get(); q.u = u.get(); q.w = w.get();
         q.ctl = ctl.get(); q.P = P.get(); q.beta = beta.get(); q.niter = niter.get();
@@ -711,6 +752,7 @@ struct TallPlan final : LassoPlan {
         admm_stats S = setup_stats;
         S.xupdate_variant = shard ? 2 : (fused ? 3 : (use_sym ? 1 : 0));
         S.exchange_variant = !shard ? 0 : (!peer_fused ? 1 : (peer_one ? 3 : 2));
+        S.refine = refine ? 1 : 0;
         res.lambda = lam_user;
         beta.zero(st); niter.zero(st);
         const int init_n = std::max(p, 2 * nwg * 8);
@@ -775,6 +817,19 @@ struct TallPlan final : LassoPlan {
                     hipLaunchKernelGGL(tall_shard_reduce_kernel, dim3(nwg), dim3(kTailThreads), 0, st, q, ab.get(), ldp, &ctl.get()[par].done);
                     allreduce_sum_f32(ab.get(), (size_t)2 * ldp, st);
                     hipLaunchKernelGGL(tall_tail_kernel<TAIL_GEMV>, dim3(nwg), dim3(kTailThreads), 0, st, q, par, PeerExchange{});
+                } else if (use_sym && refine) {
+                    // x1 = Minv rhs (both candidates) -> vectors; r = rhs - M x1 in double; correction Minv r -> partials; the tail adds
+                    const int* skip = &ctl.get()[par].done;
+                    sy.launch(M.get(), ldp, u.get(), w.get(), skip, st, dec, e0, e1);
+                    hipLaunchKernelGGL(tall_shard_reduce_kernel, dim3(nwg), dim3(kTailThreads), 0, st, q, rab.get(), ldv, skip);
+                    SymvArgsD ad;
+                    ad.A = Mg.get(); ad.lda = ldp; ad.p = p; ad.v0 = rab.get(); ad.v1 = rab.get() + ldv;
+                    ad.dot0 = dD0.get(); ad.dot1 = dD1.get(); ad.axp0 = xD0.get(); ad.axp1 = xD1.get(); ad.ldo = sy.ldo; ad.tiles = sy.tiles.get(); ad.skip = skip;
+                    hipLaunchKernelGGL(symv2_lower_f64acc_kernel, dim3(sy.ntiles), dim3(kSyThreads), 0, st, ad);
+                    hipLaunchKernelGGL(tall_refine_resid_kernel, dim3(nwg), dim3(kTailThreads), 0, st, q, dD0.get(), dD1.get(), xD0.get(), xD1.get(),
+                                       ruw.get(), ruw.get() + ldv, skip);
+                    sy.launch(M.get(), ldp, ruw.get(), ruw.get() + ldv, skip, st, SymvNoExtra());
+                    hipLaunchKernelGGL(tall_tail_kernel<TAIL_SYMV>, dim3(nwg), dim3(kTailThreads), 0, st, q, par, PeerExchange{});
                 } else if (use_sym) {
                     sy.launch(M.get(), ldp, u.get(), w.get(), &ctl.get()[par].done, st, dec, e0, e1);
                     hipLaunchKernelGGL(tall_tail_kernel<TAIL_SYMV>, dim3(nwg), dim3(kTailThreads), 0, st, q, par, PeerExchange{});

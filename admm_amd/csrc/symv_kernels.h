@@ -82,13 +82,14 @@ struct SymvArgs {
 };
 
 // Sum 8 per-lane values over the 64 lanes: afterwards every lane l holds the total of value (l >> 3).
-__device__ __forceinline__ float butterfly8(const float (&v)[8], int lane) {
-    float a4[4], a2[2];
+template <typename T>
+__device__ __forceinline__ T butterfly8(const T (&v)[8], int lane) {
+    T a4[4], a2[2];
     {
         const int b = (lane >> 5) & 1;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float keep = b ? v[k + 4] : v[k], send = b ? v[k] : v[k + 4];
+            const T keep = b ? v[k + 4] : v[k], send = b ? v[k] : v[k + 4];
             a4[k] = keep + __shfl_xor(send, 32, 64);
         }
     }
@@ -96,13 +97,13 @@ __device__ __forceinline__ float butterfly8(const float (&v)[8], int lane) {
         const int b = (lane >> 4) & 1;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const float keep = b ? a4[k + 2] : a4[k], send = b ? a4[k] : a4[k + 2];
+            const T keep = b ? a4[k + 2] : a4[k], send = b ? a4[k] : a4[k + 2];
             a2[k] = keep + __shfl_xor(send, 16, 64);
         }
     }
     const int b = (lane >> 3) & 1;
-    const float keep = b ? a2[1] : a2[0], send = b ? a2[0] : a2[1];
-    float r = keep + __shfl_xor(send, 8, 64);
+    const T keep = b ? a2[1] : a2[0], send = b ? a2[0] : a2[1];
+    T r = keep + __shfl_xor(send, 8, 64);
     r += __shfl_xor(r, 4, 64);
     r += __shfl_xor(r, 2, 64);
     r += __shfl_xor(r, 1, 64);
@@ -258,6 +259,87 @@ symv2_lower_kernel(SymvArgs a, Extra extra) {
 #endif
 }
 
+// Mixed-precision refinement of the tall x-update (opt-in, ADMM_HIP_REFINE=1; lasso_tall.hip): the products M x0, M x1 of the
+// float system matrix M = X'X + rho I (lower triangle read, both halves of the symmetric product per loaded element, as
+// above) with the two float vectors x0, x1, every product and every sum in DOUBLE -- the residual of a refinement step has
+// to be formed more accurately than the solve it corrects.  Same tiles, same partial layout, double partial arrays.  Not
+// tuned like the float kernel (a refined iteration streams the triangle three times anyway).
+struct SymvArgsD {
+    const float* A; long long lda; int p;
+    const float* v0; const float* v1;
+    double* dot0; double* dot1; double* axp0; double* axp1;
+    long long ldo;
+    const int4* tiles;
+    const int* skip;
+};
+static __global__ void __launch_bounds__(kSyThreads, 2)
+symv2_lower_f64acc_kernel(SymvArgsD a) {
+    if (a.skip != nullptr && *a.skip != 0) return;
+    __shared__ double4 red[2][kSyThreads];
+    __shared__ __attribute__((aligned(16))) double sdot[2][kSyCBMax];
+    const int4 t = a.tiles[blockIdx.x];
+    const int rb = t.x, seg = t.w, cw = t.z >> 2;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int row = rb * kSyRB + lane * 4;
+    const int col0 = t.y + wid * cw;
+    const int p4 = (a.p + 3) & ~3;
+    const bool active = row < p4, has = col0 < a.p;
+    const float* base = a.A + (size_t)col0 * a.lda + row;
+    double4 aU = make_double4(0, 0, 0, 0), aW = aU;
+    if (has) {
+        const float4 uI = active ? *reinterpret_cast<const float4*>(a.v0 + row) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 wI = active ? *reinterpret_cast<const float4*>(a.v1 + row) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const int cj = col0 + lane;
+        const float uj = (lane < cw && cj < a.p) ? a.v0[cj] : 0.f;
+        const float wj = (lane < cw && cj < a.p) ? a.v1[cj] : 0.f;
+        const bool diag = col0 + (cw - 1) >= rb * kSyRB;
+        for (int q = 0; q < (cw >> 3); ++q) {
+            double dU[8], dW[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int col = col0 + q * 8 + k;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (active && col < a.p) v = *reinterpret_cast<const float4*>(base + (size_t)(q * 8 + k) * a.lda);
+                float4 ax = v;
+                if (diag) {
+                    if (row + 0 < col) v.x = 0.f;
+                    if (row + 1 < col) v.y = 0.f;
+                    if (row + 2 < col) v.z = 0.f;
+                    if (row + 3 < col) v.w = 0.f;
+                    ax = v;
+                    if (row + 0 == col) ax.x = 0.f;
+                    if (row + 1 == col) ax.y = 0.f;
+                    if (row + 2 == col) ax.z = 0.f;
+                    if (row + 3 == col) ax.w = 0.f;
+                }
+                dU[k] = (double)v.x * uI.x + (double)v.y * uI.y + (double)v.z * uI.z + (double)v.w * uI.w;
+                dW[k] = (double)v.x * wI.x + (double)v.y * wI.y + (double)v.z * wI.z + (double)v.w * wI.w;
+                const double ujc = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(uj), (q * 8 + k) & 63));
+                const double wjc = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(wj), (q * 8 + k) & 63));
+                aU.x += ax.x * ujc; aU.y += ax.y * ujc; aU.z += ax.z * ujc; aU.w += ax.w * ujc;
+                aW.x += ax.x * wjc; aW.y += ax.y * wjc; aW.z += ax.z * wjc; aW.w += ax.w * wjc;
+            }
+            const double du = butterfly8(dU, lane), dw = butterfly8(dW, lane);
+            if ((lane & 7) == 0) { sdot[0][wid * cw + q * 8 + (lane >> 3)] = du; sdot[1][wid * cw + q * 8 + (lane >> 3)] = dw; }
+        }
+    } else {
+        for (int c = lane; c < cw; c += 64) { sdot[0][wid * cw + c] = 0.0; sdot[1][wid * cw + c] = 0.0; }
+    }
+    red[0][threadIdx.x] = aU;
+    red[1][threadIdx.x] = aW;
+    __syncthreads();
+    if (wid < 2) {
+        double4 s = red[wid][lane];
+#pragma unroll
+        for (int ww = 1; ww < 4; ++ww) { const double4 o = red[wid][ww * 64 + lane]; s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w; }
+        double* dst = (wid == 0 ? a.axp0 : a.axp1) + (size_t)seg * a.ldo + row;
+        dst[0] = s.x; dst[1] = s.y; dst[2] = s.z; dst[3] = s.w;
+    } else {
+        double* dst = (wid == 2 ? a.dot0 : a.dot1) + (size_t)rb * a.ldo + t.y;
+        for (int c = lane; c < t.z; c += 64) dst[c] = sdot[wid - 2][c];
+    }
+}
+
 // Number of row blocks, the segment schedule and the tile list (host).
 struct SymvPlan {
     int p = 0, nrb = 0, ncb = 0, ntiles = 0, p32 = 0;
@@ -366,10 +448,10 @@ struct SymvPlan {
 // (one memory round trip up to 16 * NL partials), then the lanes combine with shuffles.  The summation order is
 // fixed, so the result is bit-reproducible; every lane of the group returns the total.  Used by the tall tail
 // kernel (lasso_tall.hip), by the row-sharded x-update (tall_shard.hip) and by the test hook admm_hip_test_symv.
-template <int NL>
-__device__ __forceinline__ void symv_sum_partials(const float* __restrict__ dot0, const float* __restrict__ dot1,
-                                                  const float* __restrict__ axp0, const float* __restrict__ axp1,
-                                                  long long ldo, int nrb, const SymvSched sched, int p32, int i, int sub, bool valid, float& a, float& b) {
+template <int NL, typename T = float>
+__device__ __forceinline__ void symv_sum_partials(const T* __restrict__ dot0, const T* __restrict__ dot1,
+                                                  const T* __restrict__ axp0, const T* __restrict__ axp1,
+                                                  long long ldo, int nrb, const SymvSched sched, int p32, int i, int sub, bool valid, T& a, T& b) {
     // Branch-free requests: every slot loads from a clamped (always valid) address and out-of-range slots are replaced by
     // zero afterwards, so the 32 loads of a pass are issued back to back.  (The round-2 form guarded each load by two range
     // tests: ~25 instructions of exec-mask bookkeeping per load, ~2 us of issue time in the tall tail kernel before the
@@ -381,9 +463,9 @@ __device__ __forceinline__ void symv_sum_partials(const float* __restrict__ dot0
     const int nax = sched.nseg(rbi, p32);                               // segments of row strip rbi (up to its diagonal block)
     const int ntot = valid ? ndot + nax : 0;
     const unsigned ld = (unsigned)ldo;
-    a = 0.f; b = 0.f;
+    a = T(0); b = T(0);
     for (int k0 = 0; k0 < ntot; k0 += 16 * NL) {
-        float va[16], vb[16];
+        T va[16], vb[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int k = k0 + j * NL + sub;
@@ -397,7 +479,7 @@ __device__ __forceinline__ void symv_sum_partials(const float* __restrict__ dot0
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const bool in = k0 + j * NL + sub < ntot;
-            a += in ? va[j] : 0.f; b += in ? vb[j] : 0.f;
+            a += in ? va[j] : T(0); b += in ? vb[j] : T(0);
         }
     }
 #pragma unroll

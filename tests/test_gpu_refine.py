@@ -1,0 +1,61 @@
+"""GPU: mixed-precision refinement of the tall x-update (ADMM_HIP_REFINE=1).
+
+x1 = Minv rhs with the cached float inverse, r = rhs - M x1 in DOUBLE from the float system M = X'X + rho I (the system the
+reference factorises, ADMMLassoTall.h:191-205), x = x1 + Minv r: one refinement step per x-update, three passes over the
+lower triangle instead of one (opt-in).  Evidence that it does what it is for, without comparing executions:
+
+  * the stepwise check (oracle/stepcheck.py) measures, at EVERY iteration, the distance between the library's x and the
+    exact solve of the float system on the library's own right-hand side: refined it is a small fraction of the first-order
+    float-solve yardstick (about one rounding of x), unrefined it is of the yardstick's order;
+  * everything else of the iteration stays bit-identical to the reference's arithmetic (same check);
+  * following the same decisions, the refined run is closer to the oracle's `exact` rounding variant (oracle/variants.py:
+    double Cholesky solve of the float system, rounded to float once) than to the reference float solve."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import col_err, oracle_following, synth_lasso, traced_fit
+
+pytestmark = pytest.mark.gpu
+
+
+def _fit(x, y, nl, refine):
+    from admm_amd import admm_lasso
+    old = os.environ.get("ADMM_HIP_REFINE")
+    if refine:
+        os.environ["ADMM_HIP_REFINE"] = "1"
+    try:
+        return traced_fit(admm_lasso(x, y).penalty(nlambda=nl), capacity=1 << 14, state=True)
+    finally:
+        if old is None:
+            os.environ.pop("ADMM_HIP_REFINE", None)
+        else:
+            os.environ["ADMM_HIP_REFINE"] = old
+
+
+def test_refined_xupdate_is_the_exact_solve_to_one_rounding():
+    from oracle import entry, stepcheck
+    x, y = synth_lasso(2700, 2100, 40, seed=2100)            # n = 1.3 p: cond(X'X + rho I) in the hundreds
+    prob = dict(x=x, y=y, lam=None, nlambda=6, lmin_ratio=1e-4, standardize=True, intercept=True, opts=entry.LASSO_OPTS, alpha=None)
+    reps = {}
+    fits = {}
+    for refine in (False, True):
+        fit, trace, state = _fit(x, y, 6, refine)
+        assert int(fit.stats["refine"]) == int(refine) and int(fit.stats["xupdate_variant"]) == 1
+        rep = stepcheck.check_tall(prob, trace, state, label=f"refine={refine}")
+        print(f"[refine={int(refine)}] {rep['records']} iterations, niter {list(map(int, fit.niter))}: x-update error <= {rep['x_ratio_max']:.3f} x yardstick "
+              f"(rms {rep['x_rms_vs_yardstick']:.3f} x; {rep['x_rms_vs_ref']:.3f} x the reference float solve's), bit mismatches {len(rep['bit_mismatch'])}")
+        stepcheck.assert_stepwise(rep, label=f"refine={refine}", x_factor=4.0)
+        reps[refine], fits[refine] = rep, (fit, trace)
+    assert reps[True]["x_rms_vs_yardstick"] < 0.35 * reps[False]["x_rms_vs_yardstick"], (reps[True]["x_rms_vs_yardstick"], reps[False]["x_rms_vs_yardstick"])
+    assert reps[True]["x_ratio_max"] < 0.5
+    # on the refined run's own decisions: closer to the `exact` variant than to the float Cholesky solve
+    fit, trace = fits[True]
+    errs = {}
+    for mode in ("llt32", "exact"):
+        ref, _, _ = oracle_following(trace, band=1e9, mode=mode, **prob)
+        floor = 1e-2 * float(np.abs(ref["beta"]).max())
+        errs[mode] = max(col_err(fit.beta_dense[:, j], ref["beta"][:, j], floor) for j in range(6))
+    print(f"[refine] max column error following the refined run's decisions: vs exact variant {errs['exact']:.2e}, vs float Cholesky {errs['llt32']:.2e}")
+    assert errs["exact"] <= errs["llt32"] and errs["exact"] < 5e-6
