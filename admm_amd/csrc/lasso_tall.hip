@@ -578,6 +578,24 @@ struct TallPlan final : LassoPlan {
         lam_int.resize(nlam);
         for (int i = 0; i < nlam; ++i) lam_int[i] = (double)(float)(lam_user[i] * (double)nt / (double)d.scaleY);
 
+        // Memory wall: this solver keeps (X'X + rho I)^-1, ldp^2 floats, next to X (until the loop starts), the Gram and -- below
+        // p = 4096 or with ADMM_HIP_INVERSE=f64 -- a double copy during the factorisation.  Refuse clearly instead of failing
+        // inside some allocation (ADMM_HIP_TEST_FREE_BYTES: test hook that pretends the device has that much memory left).
+        {
+            size_t free_b = 0, total_b = 0;
+            ADMM_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+            if (const char* e = std::getenv("ADMM_HIP_TEST_FREE_BYTES")) free_b = (size_t)std::atoll(e);
+            const bool have_gram = d.gram.get() && d.ldgram == ldp;
+            const bool inv64_wanted = p < 4096 || (std::getenv("ADMM_HIP_INVERSE") && std::string(std::getenv("ADMM_HIP_INVERSE")) == "f64");
+            const double mat = (double)ldp * (double)ldp * 4.0;
+            const double need = (have_gram ? 0.0 : mat) + (inv64_wanted ? 2.0 * mat : 0.5 * mat) + (std::getenv("ADMM_HIP_REFINE") ? mat : 0.0);
+            if (need > 0.97 * (double)free_b) {
+                char msg[320];
+                std::snprintf(msg, sizeof msg, "tall solver: the cached %d x %d inverse and its workspace need %.1f GB, the device has %.1f GB free; "
+                              "use $parallel() (row blocks, admm_hip_parlasso) or fewer columns", p, p, need / 1e9, (double)free_b / 1e9);
+                throw Error(ADMM_ERR_MEMORY, msg);
+            }
+        }
         // Gram (cross_prod_lower, ADMMLassoTall.h:191-192) -- both triangles
         double t0 = now_s();
         if (d.gram.get() && d.ldgram == ldp) {            // computed under the host-to-device transfer (upload_standardize_gram_f32)

@@ -1267,9 +1267,21 @@ struct WidePlan final : LassoPlan {
                 for (float v : h) lambda0 = std::max(lambda0, v);
             }
         }
-        // spectral radius estimate from XX' (ADMMLassoWide.h:200-207)
+        // spectral radius estimate from XX' (ADMMLassoWide.h:200-207).  Single process: Gram-FREE -- the Lanczos products are
+        // formed as X (X' v) on the stored X (GramFreeWideOp, prep.h), the n x n Gram is never built (nothing else needs it).
+        // ADMM_HIP_WIDE_SPRAD=gram takes the Gram-based product (the column-sharded solver always does: its ranks sum one
+        // n x n matrix once instead of exchanging a p-vector per product).
         double t0 = now_s();
-        {
+        bool gram_free = !cshard;
+        if (const char* e = std::getenv("ADMM_HIP_WIDE_SPRAD")) gram_free = !cshard && std::string(e) != "gram";
+        if (gram_free) {
+            GramFreeWideOp op(d.X.get(), d.ldx, n, p, st);
+            ADMM_HIP_CHECK(hipStreamSynchronize(st));
+            S.t_gram = 0.0;
+            int nmatop = 0;
+            sprad = lanczos_largest_f32([&](const float* v, float* w) { op(v, w); }, n, &nmatop);
+            S.eig_est = sprad; S.t_eigs = now_s() - t0;
+        } else {
             const long long ldg = round_up(n, 32);
             DevBuf<float> G((size_t)ldg * n); G.zero(st);
             gram_full<float>(d.X.get(), d.ldx, n, p, false, G.get(), ldg, st);

@@ -97,6 +97,18 @@ struct SymMatVec {
     void operator()(const T* v_host, T* w_host);
 };
 
+// Gram-free operator of the wide solver's spectral-radius estimate (the idea of the reference's unused
+// ADMMMatOp.h:31-40): w = X (X' v) for X n x p column-major, two passes over X per product instead of one n^2 p Gram up
+// front -- at BASELINE configs[2] (n = 2000, p = 2 * 10^5) the 3-5 products of the ncv = 3 Lanczos run read 16 GB against the
+// 8e11 flop of X X'.  Same value as the Gram-based call to float rounding (the sums associate differently).
+struct GramFreeWideOp {
+    const float* X; long long ldx; int n, p; hipStream_t st;
+    DevBuf<float> dv, ds, dw, part;
+    int cols_per_wg = 512; long long ldpart = 0; int nchunk = 0;
+    GramFreeWideOp(const float* X_, long long ldx_, int n_, int p_, hipStream_t st_);
+    void operator()(const float* v_host, float* w_host);
+};
+
 // The reference's Spectra call: SymEigsSolver<T, LARGEST_ALGE>(op, 1, 3); init(); compute(10, 0.1)
 // (ADMMLassoTall.h:196-201, ADMMLassoWide.h:202-207).  Returns the Ritz value; throws
 // ADMM_ERR_EIGS if it never passes the loose convergence test.

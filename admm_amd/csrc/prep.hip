@@ -736,4 +736,52 @@ void SymMatVec<T>::operator()(const T* v_host, T* w_host) {
 template struct SymMatVec<float>;
 template struct SymMatVec<double>;
 
+// ---- w = X s: every workgroup takes `cols` consecutive columns and a tile of 1024 rows (one float4 per lane and wave),
+// streams its columns once (1 KiB per wave instruction) and writes one partial row; the partial rows are summed in
+// workgroup order afterwards (deterministic, no atomics).
+__global__ void __launch_bounds__(256)
+gemv_n_partial_kernel(const float* __restrict__ X, long long ldx, int n, int p, const float* __restrict__ s, int cols, float* __restrict__ part, long long ldpart) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int row = blockIdx.y * 1024 + wid * 256 + lane * 4;
+    const int j0 = blockIdx.x * cols, j1 = min(p, j0 + cols);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < n) {                                        // ldx is padded to 32 rows and the padding is zero: the float4 stays in bounds
+        const float* col = X + (size_t)j0 * ldx + row;
+        int j = j0;
+        for (; j + 4 <= j1; j += 4) {
+            const float4 a0 = *reinterpret_cast<const float4*>(col), a1 = *reinterpret_cast<const float4*>(col + ldx);
+            const float4 a2 = *reinterpret_cast<const float4*>(col + 2 * ldx), a3 = *reinterpret_cast<const float4*>(col + 3 * ldx);
+            const float s0 = s[j], s1 = s[j + 1], s2 = s[j + 2], s3 = s[j + 3];
+            acc.x = fmaf(s0, a0.x, acc.x); acc.y = fmaf(s0, a0.y, acc.y); acc.z = fmaf(s0, a0.z, acc.z); acc.w = fmaf(s0, a0.w, acc.w);
+            acc.x = fmaf(s1, a1.x, acc.x); acc.y = fmaf(s1, a1.y, acc.y); acc.z = fmaf(s1, a1.z, acc.z); acc.w = fmaf(s1, a1.w, acc.w);
+            acc.x = fmaf(s2, a2.x, acc.x); acc.y = fmaf(s2, a2.y, acc.y); acc.z = fmaf(s2, a2.z, acc.z); acc.w = fmaf(s2, a2.w, acc.w);
+            acc.x = fmaf(s3, a3.x, acc.x); acc.y = fmaf(s3, a3.y, acc.y); acc.z = fmaf(s3, a3.z, acc.z); acc.w = fmaf(s3, a3.w, acc.w);
+            col += 4 * ldx;
+        }
+        for (; j < j1; ++j) {
+            const float4 a0 = *reinterpret_cast<const float4*>(col);
+            const float s0 = s[j];
+            acc.x = fmaf(s0, a0.x, acc.x); acc.y = fmaf(s0, a0.y, acc.y); acc.z = fmaf(s0, a0.z, acc.z); acc.w = fmaf(s0, a0.w, acc.w);
+            col += ldx;
+        }
+        *reinterpret_cast<float4*>(part + (size_t)blockIdx.x * ldpart + row) = acc;
+    }
+}
+
+GramFreeWideOp::GramFreeWideOp(const float* X_, long long ldx_, int n_, int p_, hipStream_t st_) : X(X_), ldx(ldx_), n(n_), p(p_), st(st_) {
+    dv.alloc(round_up(n, 32)); dw.alloc(round_up(n, 32)); ds.alloc(round_up(p, 32));
+    dv.zero(st); ds.zero(st);
+    nchunk = (p + cols_per_wg - 1) / cols_per_wg;
+    ldpart = round_up(n, 1024);
+    part.alloc((size_t)nchunk * ldpart); part.zero(st);
+}
+void GramFreeWideOp::operator()(const float* v_host, float* w_host) {
+    ADMM_HIP_CHECK(hipMemcpyAsync(dv.get(), v_host, (size_t)n * sizeof(float), hipMemcpyHostToDevice, st));
+    gemv_t_simple<float>(X, ldx, n, p, dv.get(), ds.get(), st);                                             // s = X' v
+    hipLaunchKernelGGL(gemv_n_partial_kernel, dim3(nchunk, (n + 1023) / 1024), dim3(256), 0, st, X, ldx, n, p, ds.get(), cols_per_wg, part.get(), ldpart);
+    hipLaunchKernelGGL((reduce_partials_kernel<float>), dim3((n + 255) / 256), dim3(256), 0, st, part.get(), ldpart, nchunk, n, dw.get(), (const int*)nullptr);
+    ADMM_HIP_CHECK(hipMemcpyAsync(w_host, dw.get(), (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st));
+    ADMM_HIP_CHECK(hipStreamSynchronize(st));
+}
+
 }  // namespace admm

@@ -52,6 +52,8 @@ extern "C" {
 #define ADMM_ERR_EIGS 6         /* Lanczos produced no converged Ritz value (the reference then reads evals[0] of an empty vector) */
 #define ADMM_ERR_COMM 7
 #define ADMM_ERR_INTERNAL 8
+#define ADMM_ERR_MEMORY 9       /* the problem does not fit the device: the tall solver caches a p x p inverse (4 p^2 bytes, 160 GB at p = 2e5) --
+                                   use the consensus solver ($parallel(): row blocks, Woodbury form) or the wide solver's shape instead */
 
 #define ADMM_MEM_HOST 0
 #define ADMM_MEM_DEVICE 1
