@@ -115,6 +115,39 @@ def admm_bp(x, y, opts, detail=None):
     return {"beta": solver.get_coef().copy(), "niter": niter}
 
 
+def admm_dantzig(x, y, lam, nlambda, lmin_ratio, standardize, intercept, opts, detail=None):
+    """src/TODO/Dantzig.cpp:32-99 (never built by the reference): DataStd<double>, the automatic grid from lambda_0 = max|X'y|
+    (:63-70), internal lambda = lambda n / scaleY (:79), warm-started loop, recover -> (p+1) x nlambda doubles."""
+    from .solvers import Dantzig
+    x = np.array(x, dtype=np.float64, order="F")
+    y = np.array(y, dtype=np.float64)
+    n, p = x.shape
+    std = DataStd(n, p, standardize, intercept, np.float64)
+    std.standardize(x, y)
+    solver = Dantzig(x, y, float(opts["eps_abs"]), float(opts["eps_rel"]))
+    lam = np.atleast_1d(np.asarray(lam, dtype=np.float64)) if lam is not None else np.zeros(0)
+    if lam.size < 1:
+        lam = _lambda_grid(solver.lambda0, n, std.scaleY, nlambda, lmin_ratio)
+    if detail is not None and detail.get("trace") is not None:
+        solver.trace = detail["trace"]
+    beta = np.zeros((p + 1, lam.size))
+    niter = np.zeros(lam.size, dtype=np.int32)
+    for i in range(lam.size):
+        solver.lam_idx = i
+        il = lam[i] * n / np.float64(std.scaleY)
+        if i == 0:
+            solver.init(il, float(opts["rho"]))
+        else:
+            solver.init_warm(il)
+        niter[i] = solver.solve(int(opts["maxit"]))
+        b0, coef = std.recover(solver.get_coef())
+        beta[0, i] = b0
+        beta[1:, i] = coef
+    if detail is not None:
+        detail.update(solver=solver, std=std)
+    return {"lambda": lam, "beta": beta, "niter": niter}
+
+
 # Defaults of the R builders (R/30_admm_lasso.R:31-50, R/10_admm_bp.R:34-43, R/20_admm_lad.R:25-32)
 LASSO_OPTS = {"maxit": 10000, "eps_abs": 1e-5, "eps_rel": 1e-5, "rho": -1.0}
 BP_OPTS = {"maxit": 10000, "eps_abs": 1e-4, "eps_rel": 1e-4, "rho": 1.0}

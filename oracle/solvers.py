@@ -750,3 +750,86 @@ class BP(FADMM):
 
     def get_coef(self):
         return self.aux_z                                                   # BP.cpp:40 get_z()
+
+
+class Dantzig:
+    """ADMMDantzig -- the Dantzig selector, min ||beta||_1 s.t. ||X'(X beta - y)||_inf <= lambda -- restated from the
+    reference's UNBUILT source /root/reference/src/TODO/ADMMDantzig.h (its R wrapper R/50_admm_dantzig.R:30-46 calls a
+    symbol the package never compiles) against the CURRENT driver ADMMBase::solve (ADMMBase.h:158-216, update_rho :85-109):
+    linearised ADMM on  x = beta, A = X'X, c = X'y, z = -(A x - c) clipped to [-lambda, lambda]:
+        x-update   rhs = (A x + z + y / rho - c) / (-gamma);  x = soft(A rhs + x, 1 / (rho gamma))      (:132-144; the active-set
+                   form is commented out there: every step is a regular one)          gamma = sprad = (lambda_max estimate)^2
+        z-update   A x;  zz = A x + y / rho - c;  z_i = -min(zz_i, lambda) if zz_i > 0 else min(-zz_i, lambda)     (:170-187)
+        residual   r = A x + z - c;  y += rho r                                                             (:188-191)
+        eps_p = max(||A x||, ||z||, ||c||) eps_rel + sqrt(p) eps_abs;  eps_d = sqrt(gamma) ||y|| eps_rel + sqrt(p) eps_abs (:196-204)
+        r_d = rho sqrt(gamma) ||z_new - z||   (:201-204);   rho = 1 / sqrt(gamma) by default (:256-259)
+    float64 throughout (`typedef double Scalar`).  A = X'X explicitly when n > p and p <= 1000 (:222), else X'(X v)."""
+    trace = None
+    lam_idx = 0
+
+    def __init__(self, X, Y, eps_abs, eps_rel):
+        from .spectra import sym_eigs_largest
+        n, p = X.shape
+        self.X, self.p = X, p
+        self.eps_abs, self.eps_rel = eps_abs, eps_rel
+        self.use_XX = n > p and p <= 1000
+        self.XX = X.T @ X if self.use_XX else None
+        self.XY = X.T @ Y
+        self.XY_norm = float(np.linalg.norm(self.XY))
+        self.lambda0 = float(np.abs(self.XY).max())
+        self.info = {}
+        ev = sym_eigs_largest(self.A_mult, p, 3, 10, 0.1, np.float64, self.info)          # srand(0); eigs.init(); compute(10, 0.1)  (:226-233)
+        self.lmax_est = float(ev)
+        self.sprad = float(ev) * float(ev)
+
+    def A_mult(self, v):
+        return self.XX @ v if self.use_XX else self.X.T @ (self.X @ v)
+
+    def init(self, lam, rho):
+        p = self.p
+        self.main_x = np.zeros(p); self.aux_z = np.zeros(p); self.dual_y = np.zeros(p); self.cache_Ax = np.zeros(p)
+        self.lam = float(lam)
+        self.rho = float(rho) if rho > 0 else 1.0 / np.sqrt(self.sprad)
+        self.iter_counter = 0
+
+    def init_warm(self, lam):
+        self.lam = float(lam)
+        self.iter_counter = 0
+
+    def solve(self, maxit):
+        sq = np.sqrt(self.sprad)
+        sqp = np.sqrt(float(self.p))
+        for i in range(maxit):
+            eps_primal = max(np.linalg.norm(self.cache_Ax), np.linalg.norm(self.aux_z), self.XY_norm) * self.eps_rel + sqp * self.eps_abs
+            eps_dual = sq * np.linalg.norm(self.dual_y) * self.eps_rel + sqp * self.eps_abs
+            if self.lam > self.lambda0 - 1e-5:
+                self.main_x = np.zeros(self.p)
+            else:
+                rhs = (self.cache_Ax + self.aux_z + self.dual_y / self.rho - self.XY) / (-self.sprad)
+                vec = self.A_mult(rhs) + self.main_x
+                pen = 1.0 / (self.rho * self.sprad)
+                self.main_x = np.where(vec > pen, vec - pen, np.where(vec < -pen, vec + pen, 0.0))
+                self.iter_counter += 1
+            self.cache_Ax = self.A_mult(self.main_x)
+            zz = self.cache_Ax + self.dual_y / self.rho - self.XY
+            newz = np.where(zz > 0, -np.minimum(zz, self.lam), np.minimum(-zz, self.lam))
+            resid_dual = self.rho * sq * np.linalg.norm(newz - self.aux_z)
+            self.aux_z = newz
+            r = self.cache_Ax + self.aux_z - self.XY
+            resid_primal = float(np.linalg.norm(r))
+            self.dual_y = self.dual_y + self.rho * r
+            self.eps_primal, self.eps_dual, self.resid_primal, self.resid_dual = eps_primal, eps_dual, resid_primal, resid_dual
+            converged = resid_primal < eps_primal and resid_dual < eps_dual
+            rho_in = self.rho
+            if converged:
+                if self.trace is not None:
+                    self.trace.append((self.lam_idx, i, eps_primal, eps_dual, resid_primal, resid_dual, self.rho, 0, 0, rho_in, self.rho, self.lam))
+                return i + 1
+            if i > 3:
+                _rho_rule(self)
+            if self.trace is not None:
+                self.trace.append((self.lam_idx, i, eps_primal, eps_dual, resid_primal, resid_dual, self.rho, 0, 1, rho_in, self.rho, self.lam))
+        return maxit + 1
+
+    def get_coef(self):
+        return self.main_x
