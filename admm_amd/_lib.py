@@ -54,7 +54,7 @@ EXPORTS = ["admm_hip_lasso", "admm_hip_enet", "admm_hip_parlasso", "admm_hip_lad
            "admm_hip_lasso_plan_destroy", "admm_hip_comm_unique_id", "admm_hip_comm_init", "admm_hip_comm_finalize",
            "admm_hip_parlasso_dist", "admm_hip_lasso_plan_create_dist",
            "admm_hip_lasso_plan_trace_enable", "admm_hip_lasso_plan_trace_read",
-           "admm_hip_lasso_plan_state_enable", "admm_hip_lasso_plan_state_read",
+           "admm_hip_lasso_plan_state_enable", "admm_hip_lasso_plan_state_read", "admm_hip_lasso_plan_system_read",
            "admm_hip_host_lanczos", "admm_hip_test_symv",
            "admm_hip_comm_peer_prepare", "admm_hip_comm_init_peer", "admm_hip_comm_init_shm", "admm_hip_comm_test_allreduce",
            "admm_hip_lasso_dist", "admm_hip_test_gram", "admm_hip_test_spd_inverse",
@@ -152,6 +152,8 @@ def load():
     lib.admm_hip_lasso_plan_state_read.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.c_longlong,
                                                    ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong)]
     lib.admm_hip_lasso_plan_state_read.restype = ctypes.c_int
+    lib.admm_hip_lasso_plan_system_read.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.c_longlong]
+    lib.admm_hip_lasso_plan_system_read.restype = ctypes.c_int
     lib.admm_hip_test_symv.argtypes = [_c_float_p, ctypes.c_int, _c_float_p, _c_float_p, _c_float_p, _c_float_p]
     lib.admm_hip_test_symv.restype = ctypes.c_int
     lib.admm_hip_test_gram.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]

@@ -482,6 +482,13 @@ class LassoPlan:
                                                        ctypes.byref(n), ctypes.byref(rf)))
         return buf[:n.value].copy()
 
+    def read_system(self):
+        """(p, p) float32: the system matrix X'X + rho I as this library formed it (tall solver, ADMM_HIP_REFINE=1 only)."""
+        p = self.model.p
+        out = np.zeros((p, p), dtype=np.float32, order="F")
+        check(self._lib.admm_hip_lasso_plan_system_read(self._h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), p))
+        return out
+
     def close(self):
         if self._h:
             check(self._lib.admm_hip_lasso_plan_destroy(self._h))

@@ -690,6 +690,14 @@ int admm_hip_lasso_plan_state_read(admm_hip_plan* plan, float* out, long long ca
     });
 }
 
+int admm_hip_lasso_plan_system_read(admm_hip_plan* plan, float* out, long long ld) {
+    return guarded([&] {
+        PlanHandle* h = reinterpret_cast<PlanHandle*>(plan);
+        ADMM_REQUIRE(h != nullptr && h->plan, "plan is NULL");
+        h->plan->read_system(out, ld);
+    });
+}
+
 const char* admm_hip_last_error(void) { return last_error_ref().c_str(); }
 const char* admm_hip_version(void) { return "admm_hip 0.2 (gfx950)"; }
 

@@ -753,6 +753,12 @@ struct TallPlan final : LassoPlan {
         return nrec;
     }
 
+    void read_system(float* out, long long ld) override {
+        if (!refine) throw Error(ADMM_ERR_INVALID_ARG, "the system matrix is only kept with ADMM_HIP_REFINE=1");
+        ADMM_REQUIRE(out != nullptr && ld >= p, "bad output for the system matrix");
+        ADMM_HIP_CHECK(hipMemcpy2D(out, (size_t)ld * sizeof(float), Mg.get(), (size_t)ldp * sizeof(float), (size_t)p * sizeof(float), (size_t)p, hipMemcpyDeviceToHost));
+    }
+
     void debug_dump(const char* tag, const float* dptr, size_t n) {
         std::vector<float> h(n);
         ADMM_HIP_CHECK(hipMemcpy(h.data(), dptr, n * sizeof(float), hipMemcpyDeviceToHost));

@@ -41,6 +41,9 @@ struct LassoPlan {
     // per-iteration iterate dump (admm_hip_lasso_plan_state_*): tall and consensus solvers
     virtual void enable_state(long long) { throw Error(ADMM_ERR_INVALID_ARG, "this solver records no iterate dump"); }
     virtual long long read_state(float*, long long, long long*) { return 0; }
+    // the float system matrix X'X + rho I the x-update solves, p x p column-major (admm_hip_lasso_plan_system_read): only
+    // the tall solver with ADMM_HIP_REFINE=1 keeps it
+    virtual void read_system(float*, long long) { throw Error(ADMM_ERR_INVALID_ARG, "this plan does not keep its system matrix (tall solver with ADMM_HIP_REFINE=1 only)"); }
 };
 std::unique_ptr<LassoPlan> make_tall_plan(DeviceData<float>&& d, const LassoProblem& pb, hipStream_t st);
 std::unique_ptr<LassoPlan> make_wide_plan(DeviceData<float>&& d, const LassoProblem& pb, hipStream_t st);

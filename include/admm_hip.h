@@ -222,6 +222,9 @@ ADMM_HIP_API int admm_hip_lasso_plan_trace_read(admm_hip_plan* plan, double* out
  * ONE iteration from the library's own previous iterates (oracle/stepcheck.py): every step of a run is then checked on its
  * own, however far two executions have drifted apart over hundreds of iterations at the rounding floor.
  * enable() before run(); read() afterwards (out may be NULL with cap_records = 0 to query the sizes). */
+/* Test hook: the float system matrix X'X + rho I (p x p, column-major, leading dimension ld >= p) the tall solver's x-update solves,
+ * as THIS library formed it (its Gram rounds differently from anybody else's).  Only kept with ADMM_HIP_REFINE=1. */
+ADMM_HIP_API int admm_hip_lasso_plan_system_read(admm_hip_plan* plan, float* out, long long ld);
 ADMM_HIP_API int admm_hip_lasso_plan_state_enable(admm_hip_plan* plan, long long capacity_records);
 ADMM_HIP_API int admm_hip_lasso_plan_state_read(admm_hip_plan* plan, float* out, long long cap_records, long long* nrecords_out,
                                                 long long* record_floats_out);

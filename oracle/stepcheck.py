@@ -44,7 +44,7 @@ def _rule_float_norm(v):
     return np.float64(np.sqrt(np.sum(v.astype(F) * v.astype(F), dtype=F)))
 
 
-def check_tall(problem, trace, state, x_factor=4.0, x_floor_ulps=8.0, label=""):
+def check_tall(problem, trace, state, x_factor=4.0, x_floor_ulps=8.0, label="", system=None):
     """problem: the oracle's arguments (dict x, y, lam, nlambda, lmin_ratio, standardize, intercept, opts, alpha).
     trace: libadmm_hip decision trace INCLUDING the cold-start record; state: (nrec, 5 p) iterate dump of the same run."""
     x = np.asarray(problem["x"], dtype=np.float64)
@@ -67,8 +67,16 @@ def check_tall(problem, trace, state, x_factor=4.0, x_floor_ulps=8.0, label=""):
     rho = float(t[1, 9]) if len(t) > 1 else s.rho
     assert abs(rho - s.rho) <= 1e-5 * s.rho, (label, "rho", rho, s.rho)
     rho_f = F(rho)
-    XX = (datX.T @ datX).astype(F).astype(np.float64)
-    XX[np.arange(p), np.arange(p)] += np.float64(F(rho))
+    # the float system the x-update solves: the Gram in float with rho added on the diagonal IN FLOAT (XX.diagonal().array() += rho,
+    # ADMMLassoTall.h:204).  `system`: that matrix as the LIBRARY formed it (admm_hip_lasso_plan_system_read) -- its Gram
+    # rounds differently from NumPy's, and measured against NumPy's system that difference (cond(M) ulps of x) would be booked
+    # as an error of the solve
+    if system is not None:
+        XX = np.asarray(system, dtype=np.float64)
+    else:
+        XX32 = (datX.T @ datX).astype(F)
+        XX32[np.arange(p), np.arange(p)] += F(rho)
+        XX = XX32.astype(np.float64)
     chol64 = sla.cho_factor(XX, lower=True, check_finite=False)
     chol32 = sla.cho_factor(XX.astype(F), lower=True, check_finite=False)
     S = np.asarray(state, dtype=F).reshape(len(state), 5, p)

@@ -115,7 +115,8 @@ def _run_lasso_case(cs):
     if "state" in cap:
         rep = stepwise_capture(cs, cap)
         per_record = rep.get("x_vs_ref_max", 0.0) if cs["kind"] == "par" else rep["x_ratio_max"]
-        stepcheck.assert_stepwise(dict(rep, x_ratio_max=per_record), label=case_label(cs), x_factor=16.0 if cs["kind"] == "par" else 4.0)
+        stepcheck.assert_stepwise(dict(rep, x_ratio_max=per_record), label=case_label(cs), x_factor=16.0 if cs["kind"] == "par" else 4.0,
+                                 x_rms_factor=5.0 if cs["kind"] == "par" else 2.5)
     return judge_capture(cs, cap)
 
 
