@@ -1165,11 +1165,18 @@ wide_act_persist_kernel(WideParams q, int cpar, WidePersist ps) {
         }
     }
     if (g == 0) {
+        // the norm partials as a tail launch leaves them: rows [0, nwg_tail) hold the sums (here: row 0 holds all of it, added
+        // in workgroup order), every other row is ZERO -- the decision of the next launch adds up max(nwg_tail, 128) rows, and a
+        // later tail launch only overwrites the first nwg_tail of them (a stale share left in row nwg_tail .. kPG - 1 was added
+        // to every later decision: found by the random sweep, case 41 of seed 7, n = 19)
         for (int idx = threadIdx.x; idx < q.nwg_tail * 8 || idx < kPG * 8; idx += kWideThreads) {
             const int row = idx >> 3, m = idx & 7;
             double v = 0.0;
-            if (row < kPG && m < 5) v = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(ps.np + (size_t)row * 8 + m),
-                                                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (row == 0 && m < 5) {
+                for (int r = 0; r < kPG; ++r)
+                    v += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(ps.np + (size_t)r * 8 + m),
+                                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            }
             q.P[idx] = v;                                       // P holds max(nwg_tail, kWideNormRows) >= kPG rows
         }
         if (threadIdx.x == 0) q.ctl[cpar] = in;                 // the state the breaking decision was taken FROM: the next launch repeats it

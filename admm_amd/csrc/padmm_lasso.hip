@@ -19,6 +19,7 @@
 #include "solvers.h"
 #include "loop_driver.h"
 #include "comm.h"
+#include "peer_device.h"
 #include "probe.h"
 
 namespace admm {
@@ -87,8 +88,15 @@ par_head_kernel(ParParams q) {
 
 // pack: x_k from the mat-vec results, consensus sum w = sum_k (x_k + y_k / rho)   (PADMMLasso.h:65-68,101-105);
 // workgroup 0 also folds the previous iteration's per-workgroup norm partials into nsum[0..4].
+// PEER = 1 (multi-process run over the PEER exchange, round 3): this launch is the PRODUCER of the iteration's one exchange --
+// every workgroup writes its elements of the consensus sum straight into this rank's slot of EVERY rank's exchange buffer
+// (pairs of elements as one 8-byte write-through store), workgroup 0 adds the three worker-summed norms behind them, and the
+// last workgroup to finish raises the flags (peer_device.h); par_z_kernel<1> is the consumer.  No launches of the exchange
+// layer, like the sharded tall and wide solvers (replaces the shared-memory reads of PADMMLasso.h:99-108, PADMMBase.h:200-214).
+constexpr size_t par_peer_norm_offset(int p) { return ((size_t)p * sizeof(float) + 15) / 16 * 16; }
+template <int PEER>
 __global__ void __launch_bounds__(kParThreads)
-par_pack_kernel(ParParams q) {
+par_pack_kernel(ParParams q, PeerExchange ex) {
     // no fused multiply-adds in the elementwise arithmetic: the reference is built without them (see lasso_tall.hip, tall_update_elem)
 #pragma clang fp contract(off)
     __shared__ double scratch[5 * (kParThreads / 64)];
@@ -103,11 +111,20 @@ par_pack_kernel(ParParams q) {
         if (threadIdx.x == 0) {
 #pragma unroll
             for (int k = 0; k < 5; ++k) q.nsum[k] = acc[k];
+            if (PEER) {
+                for (int dst = 0; dst < ex.nranks; ++dst) {
+                    unsigned long long* nd = reinterpret_cast<unsigned long long*>(peer_dst_slot(ex, dst) + par_peer_norm_offset(q.p));
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) peer_store_u64(nd + k, (unsigned long long)__double_as_longlong(acc[k]));
+                }
+            }
         }
     }
     const float rho_f = (float)q.rho;
-    for (int i = blockIdx.x * kParThreads + threadIdx.x; i < q.p; i += gridDim.x * kParThreads) {
+    const int pe = PEER ? (q.p + 1) / 2 * 2 : q.p;        // PEER: whole pairs (the partner lane of the last odd element stores a zero)
+    for (int i = blockIdx.x * kParThreads + threadIdx.x; i < pe; i += gridDim.x * kParThreads) {
         float w = 0.f;
+        if (i < q.p) {
         for (int k0 = 0; k0 < q.Kl; k0 += 8) {                                      // 8 workers' operands requested together, consumed in order
             float g0[8], rh[8], yv[8];
 #pragma unroll
@@ -129,15 +146,26 @@ par_pack_kernel(ParParams q) {
                 }
             }
         }
-        q.wsum[i] = w;
+        }
+        if (PEER) {
+            const float wn = __shfl_down(w, 1, 64);        // i is even in even lanes (grid stride and block size are even)
+            if ((i & 1) == 0) {
+                for (int dst = 0; dst < ex.nranks; ++dst)
+                    peer_store_f32x2(reinterpret_cast<float*>(peer_dst_slot(ex, dst)) + i, w, wn);
+            }
+        } else {
+            q.wsum[i] = w;
+        }
     }
+    if (PEER) peer_publish(ex, gridDim.x);
 }
 
 // z(g): decision for iteration g-1 from nsum (after the all-reduce every rank holds identical numbers and
 // takes identical decisions: PADMMBase.h:216-221,230-231; eps :117-139), lambda schedule, then
 // z_new = soft(w / K, lambda / (rho K)); y_k += rho (x_k - z_new); norms   (PADMMLasso.h:99-108, PADMMBase.h:70-78)
+template <int PEER>      // 1: the consensus sum and the worker-summed norms arrive in the K exchange slots (par_pack_kernel<1> of every rank)
 __global__ void __launch_bounds__(kParThreads)
-par_z_kernel(ParParams q, int par) {
+par_z_kernel(ParParams q, int par, PeerExchange ex) {
     // no fused multiply-adds in the elementwise arithmetic: the reference is built without them (see lasso_tall.hip, tall_update_elem)
 #pragma clang fp contract(off)
     __shared__ double scratch[5 * (kParThreads / 64)];
@@ -150,7 +178,18 @@ par_z_kernel(ParParams q, int par) {
         return;
     }
     WIDE_PROBE(4);
-    const double x2 = q.nsum[0], y2 = q.nsum[1], r2 = q.nsum[2], z2 = q.nsum[3], dz2 = q.nsum[4];
+    double x2 = q.nsum[0], y2 = q.nsum[1], r2 = q.nsum[2];
+    const double z2 = q.nsum[3], dz2 = q.nsum[4];
+    if (PEER) {
+        if (!peer_wait_relaxed(ex)) return;                               // a rank did not arrive in time: ADMM_ERR_COMM at the next poll
+        x2 = 0.0; y2 = 0.0; r2 = 0.0;
+        for (int r = 0; r < ex.nranks; ++r) {                             // rank order: identical sums on every rank
+            const unsigned long long* nd = reinterpret_cast<const unsigned long long*>(peer_src_slot(ex, r) + par_peer_norm_offset(q.p));
+            x2 += __longlong_as_double((long long)__hip_atomic_load(nd + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+            y2 += __longlong_as_double((long long)__hip_atomic_load(nd + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+            r2 += __longlong_as_double((long long)__hip_atomic_load(nd + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+        }
+    }
 #ifdef ADMM_HIP_PROBE
     asm volatile("" :: "v"(x2), "v"(y2), "v"(r2), "v"(z2), "v"(dz2));
 #endif
@@ -200,7 +239,17 @@ par_z_kernel(ParParams q, int par) {
         const float zo = q.z[i];
         if (lam_finished >= 0) q.beta[(size_t)lam_finished * q.p + i] = zo;           // get_z()  ParLasso.cpp:98
         if (out.done) continue;
-        const float v = q.wsum[i] / (float)q.K;
+        float wtot;
+        if (PEER) {
+            wtot = 0.f;
+            for (int r = 0; r < ex.nranks; ++r) {
+                const float2 pr = peer_load_f32x2(reinterpret_cast<const float*>(peer_src_slot(ex, r)) + (i & ~1));
+                wtot += (i & 1) ? pr.y : pr.x;
+            }
+        } else {
+            wtot = q.wsum[i];
+        }
+        const float v = wtot / (float)q.K;
         const double vd = (double)v;
         const float zn = vd > pen ? (float)(vd - pen) : (vd < -pen ? (float)(vd + pen) : 0.f);
         for (int k0 = 0; k0 < q.Kl; k0 += 8) {                                      // 8 workers' operands requested together
@@ -324,6 +373,7 @@ struct ParPlan final : LassoPlan {
         return nrec;
     }
 
+    bool peer_fused = false;          // multi-process over the PEER backend: the exchange is done by pack / z themselves
     DevBuf<float> state;
     long long state_cap = 0;
     void enable_state(long long cap) override {
@@ -424,6 +474,8 @@ struct ParPlan final : LassoPlan {
             for (int k = 0; k < Kl; ++k) { W[k].gM.set_nt(nt); if (W[k].wide) { W[k].gAt.set_nt(nt); W[k].gA.set_nt(nt); } }
         }
 
+        peer_fused = pb.dist && ci.active && ci.backend == COMM_PEER;
+        if (const char* e = std::getenv("ADMM_HIP_PEER_FUSED")) { if (std::string(e) == "0") peer_fused = false; }
         nwg = std::max(1, std::min(1024, (p + kParThreads - 1) / kParThreads));     // one element per thread up to p = 262144 (was <= 64 workgroups: 31 us for p = 10^5)
         rhs.alloc((size_t)Kl * ldv); x.alloc((size_t)Kl * ldv); y.alloc((size_t)Kl * ldv); nsum.alloc(8);
         z.alloc(ldv); wsum.alloc(ldv);
@@ -476,13 +528,21 @@ struct ParPlan final : LassoPlan {
                     w.gA.run_partials_from(w.gM, skip, st);                // A' s
                 }
             }
-            hipLaunchKernelGGL(par_pack_kernel, dim3(nwg_e), dim3(kParThreads), 0, st, q);
+            if (peer_fused) {
+                // the only cross-worker exchange, produced by `pack` and consumed by `z` themselves (PEER slots)
+                const PeerExchange ex = comm_peer_begin(par_peer_norm_offset(p) + 3 * sizeof(double));
+                hipLaunchKernelGGL(par_pack_kernel<1>, dim3(nwg_e), dim3(kParThreads), 0, st, q, ex);
+                hipLaunchKernelGGL(par_z_kernel<1>, dim3(nwg), dim3(kParThreads), 0, st, q, par, ex);
+                return;
+            }
+            hipLaunchKernelGGL(par_pack_kernel<0>, dim3(nwg_e), dim3(kParThreads), 0, st, q, PeerExchange{});
             // the only cross-worker exchange: consensus sum (p floats) + the three worker-summed norms, one grouped
             // RCCL all-reduce over xGMI (no-op in a single process)
             if (pb.dist) allreduce_sum_f32_f64(wsum.get(), (size_t)p, nsum.get(), 3, st);
-            hipLaunchKernelGGL(par_z_kernel, dim3(nwg), dim3(kParThreads), 0, st, q, par);
+            hipLaunchKernelGGL(par_z_kernel<0>, dim3(nwg), dim3(kParThreads), 0, st, q, par, PeerExchange{});
         });
         S.t_loop = lt.wall_s; S.loop_ms_events = lt.events_ms; S.xupdate_launches = lt.launched;
+        S.exchange_variant = !pb.dist ? 0 : (peer_fused ? 2 : 1);
 #ifdef ADMM_HIP_PROBE
         if (const char* f = std::getenv("ADMM_HIP_PROBE_OUT")) {
             std::vector<long long> hp((size_t)4096 * 4 * 8);
