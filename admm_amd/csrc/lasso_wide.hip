@@ -841,11 +841,11 @@ __device__ __forceinline__ bool wp_wait(const unsigned long long* flags, unsigne
     return *s_ok != 0;
 }
 // The same wait on words that carry (launch << 32) | (XCD of the workgroup + 1); *s_same = 1 if all kPG workgroups sit on one XCD.
-__device__ __forceinline__ bool wp_wait_xcc(const unsigned long long* flags, unsigned long long seq, int* err, int* s_ok, int* s_same) {
+__device__ __forceinline__ bool wp_wait_xcc(const unsigned long long* flags, unsigned long long seq, int* err, int* s_ok, int* s_same, int npart = kPG) {
     if (threadIdx.x < 64) {
         bool ok = true;
         unsigned long long v = 0;
-        if (threadIdx.x < kPG) {
+        if ((int)threadIdx.x < npart) {
             const unsigned long long* f = flags + (size_t)threadIdx.x * 8;
             const long long t0 = wall_clock64();
             while ((v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < ((seq << 32) | 1ull)) {
@@ -855,7 +855,7 @@ __device__ __forceinline__ bool wp_wait_xcc(const unsigned long long* flags, uns
         }
         ok = __all(ok) != 0;
         const unsigned mine = (unsigned)v, first = (unsigned)__shfl(mine, 0, 64);
-        const bool same = __all(threadIdx.x >= kPG || mine == first) != 0;
+        const bool same = __all((int)threadIdx.x >= npart || mine == first) != 0;
         if (threadIdx.x == 0) { *s_ok = ok ? 1 : 0; *s_same = same ? 1 : 0; if (!ok) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     }
     __syncthreads();
@@ -1183,6 +1183,12 @@ wide_act_persist_kernel(WideParams q, int cpar, WidePersist ps) {
     }
 }
 
+// Measured and rejected (round 3): the same stretch with ONE hand-over per iteration -- 16 workgroups of 512 threads, every
+// workgroup adds up all 16 partials of A x itself (128 KB from the XCD's L2 per iteration) and keeps the whole z / y / A x in
+// registers, so that norms, decision and the next t need no second exchange.  Correct (same tests), but 12.1 us per iteration
+// inside against 10.5 us for the two-hand-over form above on C3: the 8-wave combine and the 16 x 8 KB of partial loads per
+// workgroup cost more than the second hop they remove.
+
 __global__ void wide_init_kernel(WideParams q, double rho, float lam0) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < q.p) q.x[i] = 0.f;
@@ -1389,6 +1395,7 @@ struct WidePlan final : LassoPlan {
     unsigned long long pseq = 0;
     int pmax_cols = 512;
     size_t lds_persist = 0;
+
 
     void setup_persist() {
         persist = (fuse_rt == 4 || fuse_rt == 8) && !cshard && (long long)p <= (long long)kPNU * 64 * kPG * (kWideThreads / 64);
