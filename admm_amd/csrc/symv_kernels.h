@@ -3,9 +3,9 @@
 //   y_r = A v_r  (r = 0, 1)  for a symmetric p x p fp32 matrix stored column-major (both triangles
 //   are in memory, only tiles on or below the diagonal are read): 2 p^2 bytes instead of 4 p^2.
 //
-// Tiling: a workgroup owns 256 rows x 128 columns; each of its 4 waves owns the same 256 rows
-// (one float4 per lane) and 32 of the columns.  The column widths are parameters (kSyCW a power of two <= 32 or a
-// multiple of 64).  Measured on C2, same box (round 2): 128-column tiles 35.1 us per launch, 23.2 k ADMM iterations/s;
+// Tiling: a workgroup owns 256 rows x a column segment of its row strip (round 3: 32 .. 256 columns, SymvSched below;
+// round 2: always 128); each of its 4 waves owns the same 256 rows (one float4 per lane) and a quarter of the columns.
+// Measured on C2, same box (round 2, fixed widths): 128-column tiles 35.1 us per launch, 23.2 k ADMM iterations/s;
 // 256-column tiles with 64 columns per wave halve the axpy partial rows (tail 6.6 instead of 7.1 us) but the longer
 // per-wave column loop streams worse: 37.7 us, 22.0 k it/s; 512-column tiles leave too few workgroups: 51 us.
 // Also measured and rejected (round 2): both right-hand sides as pairs through v_pk_fma_f32 plus separate loop copies for

@@ -4,7 +4,7 @@
 #   the other BASELINE configs (C3 wide, C4 consensus K=8 on one GPU, C5 LAD / BP): bench lines + kernel-trace stats each.
 # Outputs go to gpurun_out/<tag>/; copy the summaries into profiles/ afterwards.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 export TMPDIR=/tmp
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
