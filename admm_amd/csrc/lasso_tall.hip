@@ -742,7 +742,9 @@ struct TallPlan final : LassoPlan {
 
     void enable_state(long long cap) override {
         state.alloc((size_t)cap * 5 * p);
-        ADMM_HIP_CHECK(hipMemset(state.get(), 0, (size_t)cap * 5 * p * sizeof(float)));
+        // on the solver's own (non-blocking) stream: a null-stream memset is not ordered against it and, on a busy device, landed
+        // AFTER run() had copied record 0 into the dump (suspected cause of the one unreadable record 0 of the 40-process soak, case 546:23)
+        ADMM_HIP_CHECK(hipMemsetAsync(state.get(), 0, (size_t)cap * 5 * p * sizeof(float), st));
         state_cap = cap;
         q.state = state.get(); q.state_cap = cap;
     }
