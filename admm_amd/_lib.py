@@ -57,7 +57,7 @@ EXPORTS = ["admm_hip_lasso", "admm_hip_enet", "admm_hip_parlasso", "admm_hip_lad
            "admm_hip_lasso_plan_state_enable", "admm_hip_lasso_plan_state_read", "admm_hip_lasso_plan_system_read",
            "admm_hip_host_lanczos", "admm_hip_test_symv",
            "admm_hip_comm_peer_prepare", "admm_hip_comm_init_peer", "admm_hip_comm_init_shm", "admm_hip_comm_test_allreduce",
-           "admm_hip_lasso_dist", "admm_hip_test_gram", "admm_hip_test_spd_inverse",
+           "admm_hip_lasso_dist", "admm_hip_test_gram", "admm_hip_test_spd_inverse", "admm_hip_test_cv_fold_system",
            "admm_hip_lasso_dist_cols", "admm_hip_test_gemv_t", "admm_hip_lad_traced", "admm_hip_bp_traced",
            "admm_hip_lasso_plan_create_dist_cols", "admm_hip_lasso_cv", "admm_hip_lasso_multi"]
 
@@ -162,6 +162,9 @@ def load():
     lib.admm_hip_test_gemv_t.restype = ctypes.c_int
     lib.admm_hip_test_spd_inverse.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     lib.admm_hip_test_spd_inverse.restype = ctypes.c_int
+    lib.admm_hip_test_cv_fold_system.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                                 ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    lib.admm_hip_test_cv_fold_system.restype = ctypes.c_int
     lib.admm_hip_host_lanczos.argtypes = [_c_float_p, ctypes.c_int, _c_float_p, _c_int_p]
     lib.admm_hip_host_lanczos.restype = ctypes.c_int
     _lib = lib

@@ -70,6 +70,22 @@ struct PlanHandle {
     double t_create = 0;
 };
 
+static LassoProblem make_problem(const double* lambda_in, int nlambda_in, int nlambda_auto, double lmin_ratio, bool enet, double alpha,
+                                 int nworkers, bool dist, const admm_opts* opts) {
+    LassoProblem pb;
+    pb.opts = *opts;
+    pb.lambda_in.assign(lambda_in, lambda_in + nlambda_in);
+    pb.nlambda_auto = nlambda_auto;
+    pb.lmin_ratio = lmin_ratio;
+    pb.enet = enet;
+    pb.alpha = alpha;
+    pb.nworkers = nworkers;
+    pb.dist = dist;
+    pb.batch_iters = env_int("ADMM_HIP_BATCH_ITERS", 0);
+    pb.profile_stride = env_int("ADMM_HIP_PROFILE_STRIDE", 0);
+    return pb;
+}
+
 static PlanHandle* create_plan(const double* x, const double* y, int n, int p, int mem,
                                const double* lambda_in, int nlambda_in, int nlambda_auto, double lmin_ratio,
                                int standardize, int intercept, bool enet, double alpha, int nworkers,
@@ -89,17 +105,7 @@ static PlanHandle* create_plan(const double* x, const double* y, int n, int p, i
     require_device();
     const double t0 = now_s();
     std::unique_ptr<PlanHandle> h(new PlanHandle());
-    LassoProblem pb;
-    pb.opts = *opts;
-    pb.lambda_in.assign(lambda_in, lambda_in + nlambda_in);
-    pb.nlambda_auto = nlambda_auto;
-    pb.lmin_ratio = lmin_ratio;
-    pb.enet = enet;
-    pb.alpha = alpha;
-    pb.nworkers = nworkers;
-    pb.dist = dist;
-    pb.batch_iters = env_int("ADMM_HIP_BATCH_ITERS", 0);
-    pb.profile_stride = env_int("ADMM_HIP_PROFILE_STRIDE", 0);
+    const LassoProblem pb = make_problem(lambda_in, nlambda_in, nlambda_auto, lmin_ratio, enet, alpha, nworkers, dist, opts);
     DeviceData<float> d;
     // Host input of a large tall problem: standardisation and X'X run under the PCIe transfer (bit-identical result).
     const char* eg = std::getenv("ADMM_HIP_GRAM");
@@ -213,12 +219,34 @@ static void lasso_cv(const double* x, const double* y, int n, int p, int mem, co
         ADMM_HIP_CHECK(hipStreamSynchronize(st.s));
         xd = xd_own.get(); yd = yd_own.get();
     }
+    // Folds as down-dates of the full-data Gram (cv.hip): when every fit of the call is the tall solver's and the Gram is
+    // what setup costs (p >= 1024; ADMM_HIP_CV_DOWNDATE=1 / 0 forces it on for any tall call / off).
+    int min_tr = n;
+    for (int f = 0; f < nfolds; ++f) min_tr = std::min(min_tr, n - cnt[f]);
+    bool downdate = min_tr > p && p >= 1024;
+    if (const char* e = std::getenv("ADMM_HIP_CV_DOWNDATE")) downdate = min_tr > p && std::string(e) == "1";
+    CvBase base;
+    if (downdate) {
+        ADMM_REQUIRE(nlambda_in >= 0, "nlambda_in must be >= 0");
+        ADMM_REQUIRE(nlambda_in > 0 ? lambda_in != nullptr : nlambda_auto > 0, "need a lambda grid or nlambda_auto > 0");
+        if (nlambda_in == 0) ADMM_REQUIRE(lmin_ratio > 0 && lmin_ratio < 1, "lambda_min_ratio must be within (0, 1)");
+        for (int i = 0; i < nlambda_in; ++i) ADMM_REQUIRE(lambda_in[i] > 0, "lambda must be positive");
+        cv_downdate_prepare(base, xd, yd, n, p, standardize != 0, intercept != 0, st.s);
+    }
     // ---- full-data fit: the lambda grid (and, if asked for, the coefficients)
     int nlam = 0;
     std::vector<double> lam;
     {
-        std::unique_ptr<PlanHandle> h(create_plan(xd, yd, n, p, ADMM_MEM_DEVICE, lambda_in, nlambda_in, nlambda_auto, lmin_ratio,
-                                                  standardize, intercept, enet, enet ? alpha : 1.0, 0, opts));
+        std::unique_ptr<PlanHandle> h;
+        if (downdate) {
+            h.reset(new PlanHandle());
+            DeviceData<float> d;
+            cv_downdate_full(d, base, h->st.s);
+            h->plan = make_tall_plan(std::move(d), make_problem(lambda_in, nlambda_in, nlambda_auto, lmin_ratio, enet, enet ? alpha : 1.0, 0, false, opts), h->st.s);
+        } else {
+            h.reset(create_plan(xd, yd, n, p, ADMM_MEM_DEVICE, lambda_in, nlambda_in, nlambda_auto, lmin_ratio,
+                                standardize, intercept, enet, enet ? alpha : 1.0, 0, opts));
+        }
         LassoResult res;
         h->plan->run(res);
         nlam = (int)res.lambda.size();
@@ -243,12 +271,19 @@ static void lasso_cv(const double* x, const double* y, int n, int p, int mem, co
         std::vector<int> both(tr);
         both.insert(both.end(), te.begin(), te.end());
         ADMM_HIP_CHECK(hipMemcpyAsync(didx.get(), both.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, st.s));
-        DevBuf<double> xtr((size_t)ntr * p), ytr(ntr), xte((size_t)nte * p), yte(nte);
-        cv_gather(xd, n, yd, didx.get(), ntr, p, xtr.get(), ytr.get(), st.s);
+        DevBuf<double> xtr, ytr, xte((size_t)nte * p), yte(nte);
         cv_gather(xd, n, yd, didx.get() + ntr, nte, p, xte.get(), yte.get(), st.s);
-        ADMM_HIP_CHECK(hipStreamSynchronize(st.s));
         LassoResult res;
-        {
+        if (downdate) {
+            std::unique_ptr<PlanHandle> h(new PlanHandle());
+            DeviceData<float> d;
+            cv_downdate_fold(d, base, yd, didx.get(), ntr, didx.get() + ntr, nte, st.s);
+            h->plan = make_tall_plan(std::move(d), make_problem(lam.data(), nlam, 0, lmin_ratio, enet, enet ? alpha : 1.0, 0, false, opts), h->st.s);
+            h->plan->run(res);
+        } else {
+            xtr.alloc((size_t)ntr * p); ytr.alloc(ntr);
+            cv_gather(xd, n, yd, didx.get(), ntr, p, xtr.get(), ytr.get(), st.s);
+            ADMM_HIP_CHECK(hipStreamSynchronize(st.s));
             std::unique_ptr<PlanHandle> h(create_plan(xtr.get(), ytr.get(), ntr, p, ADMM_MEM_DEVICE, lam.data(), nlam, 0, lmin_ratio,
                                                       standardize, intercept, enet, enet ? alpha : 1.0, 0, opts));
             h->plan->run(res);
@@ -758,6 +793,35 @@ int admm_hip_test_spd_inverse(const void* A, int n, int precision, void* Ainv) {
         ADMM_REQUIRE(A && Ainv && n > 0 && precision >= 0 && precision <= 2, "bad arguments");
         if (precision == 1) test_spd_inverse<double>(static_cast<const double*>(A), n, static_cast<double*>(Ainv), false);
         else test_spd_inverse<float>(static_cast<const float*>(A), n, static_cast<float*>(Ainv), precision == 2);
+    });
+}
+
+int admm_hip_test_cv_fold_system(const double* x, const double* y, int n, int p, const int* fold_id, int nfolds, int fold,
+                                 int standardize, int intercept, float* gram, float* xy, float* mean_x, float* scale_x, float* mean_scale_y) {
+    return guarded([&] {
+        ADMM_REQUIRE(x && y && gram && xy && mean_x && scale_x && mean_scale_y && n > 0 && p > 0, "bad arguments");
+        ADMM_REQUIRE(nfolds >= 2 && fold >= 0 && fold < nfolds, "fold must be within [0, nfolds)");
+        require_device();
+        Stream st;
+        DevBuf<double> xd((size_t)n * p), yd(n);
+        ADMM_HIP_CHECK(hipMemcpyAsync(xd.get(), x, (size_t)n * p * sizeof(double), hipMemcpyHostToDevice, st.s));
+        ADMM_HIP_CHECK(hipMemcpyAsync(yd.get(), y, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st.s));
+        std::vector<int> tr, te;
+        for (int i = 0; i < n; ++i) ((fold_id ? fold_id[i] : i % nfolds) == fold ? te : tr).push_back(i);
+        const int ntr = (int)tr.size(), nte = (int)te.size();
+        ADMM_REQUIRE(ntr > p && nte > 0, "the fold needs held-out rows and more training rows than columns");
+        std::vector<int> both(tr);
+        both.insert(both.end(), te.begin(), te.end());
+        DevBuf<int> didx(n);
+        ADMM_HIP_CHECK(hipMemcpyAsync(didx.get(), both.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, st.s));
+        CvBase base;
+        cv_downdate_prepare(base, xd.get(), yd.get(), n, p, standardize != 0, intercept != 0, st.s);
+        DeviceData<float> d;
+        cv_downdate_fold(d, base, yd.get(), didx.get(), ntr, didx.get() + ntr, nte, st.s);
+        ADMM_HIP_CHECK(hipMemcpy2D(gram, (size_t)p * sizeof(float), d.gram.get(), (size_t)d.ldgram * sizeof(float), (size_t)p * sizeof(float), p, hipMemcpyDeviceToHost));
+        ADMM_HIP_CHECK(hipMemcpy(xy, d.xy.get(), (size_t)p * sizeof(float), hipMemcpyDeviceToHost));
+        for (int j = 0; j < p; ++j) { mean_x[j] = d.meanX[j]; scale_x[j] = d.scaleX[j]; }
+        mean_scale_y[0] = d.meanY; mean_scale_y[1] = d.scaleY;
     });
 }
 

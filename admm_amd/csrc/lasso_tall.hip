@@ -566,9 +566,14 @@ struct TallPlan final : LassoPlan {
         shard = pb.dist;
         ci = shard ? comm_info() : CommInfo();
         const long long nt = d.n_total > 0 ? d.n_total : n;
-        XY.alloc(ldp); XY.zero(st);
-        gemv_t_simple<float>(d.X.get(), d.ldx, n, p, d.Y.get(), XY.get(), st);
-        if (shard) allreduce_sum_f32(XY.get(), (size_t)p, st);
+        if (d.xy.get()) {                                  // Gram-form data (a cross-validation fold formed as a down-date, cv.hip)
+            ADMM_REQUIRE(!shard && d.gram.get() && d.ldgram == ldp, "Gram-form data needs X'X next to X'y");
+            XY = std::move(d.xy);
+        } else {
+            XY.alloc(ldp); XY.zero(st);
+            gemv_t_simple<float>(d.X.get(), d.ldx, n, p, d.Y.get(), XY.get(), st);
+            if (shard) allreduce_sum_f32(XY.get(), (size_t)p, st);
+        }
         float lambda0 = device_absmax<float>(XY.get(), p, st);
         if (pb.enet) lambda0 = (float)(lambda0 / ((double)(float)pb.alpha + 0.0001));
 

@@ -24,6 +24,9 @@ struct DeviceData {
     DevBuf<T> gram;
     long long ldgram = 0;
     double t_gram_tail = 0;
+    // Gram-form data (cross-validation folds formed as down-dates, cv.hip): X'y of the standardised data, round_up(p, 128)
+    // entries, zero padded.  When set the tall solver takes X'y and the Gram from here and X / Y may be empty.
+    DevBuf<T> xy;
 };
 
 // Convert the caller's double column-major x (n x p, ld n) and y to T on the device and apply
@@ -41,6 +44,23 @@ void upload_standardize_gram_f32(DeviceData<float>& d, const double* x, const do
 // Another response of the same x (admm_hip_lasso_multi): X / statistics / Gram copied from `base`, y standardised alone.
 void clone_with_response_f32(DeviceData<float>& d, const DeviceData<float>& base, const float* gram, long long ldgram,
                              const double* y_dev, hipStream_t st);
+
+// Cross-validation folds formed as down-dates of the full-data Gram (cv.hip): what is formed once per call.
+struct CvBase {
+    DeviceData<float> full;         // the full data standardised with ITS statistics: Z (n x p), its response, m, s
+    DevBuf<float> Gall;             // Z'Z, ld = ldp = round_up(p, 128), zero padded
+    long long ldp = 0;
+    std::vector<double> s1, s2;     // column sums of Z and of Z.^2
+    double t_prepare = 0;
+};
+void cv_downdate_prepare(CvBase& b, const double* xd, const double* yd, int n, int p, bool standardize, bool intercept, hipStream_t st);
+void cv_downdate_full(DeviceData<float>& d, const CvBase& b, hipStream_t st);
+void cv_downdate_fold(DeviceData<float>& d, const CvBase& b, const double* yd, const int* d_train, int ntr, const int* d_test, int nte, hipStream_t st);
+
+// y alone (device doubles, n entries): narrowed to float into Yout (ld entries, zero padded) and standardised by the kernels of
+// upload_standardize (flag as there); the statistics come back in *meanY / *scaleY.
+void standardize_response_f32(const double* y_dev, int n, int flag, long long n_total, float* Yout, long long ld,
+                              float* meanY, float* scaleY, hipStream_t st);
 
 // DataStd::recover (DataStd.h:157-207) on a host coefficient vector (length p) in precision T.
 template <typename T>

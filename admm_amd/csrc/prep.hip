@@ -262,6 +262,32 @@ template void upload_standardize<float>(DeviceData<float>&, const double*, const
 // and (if present) the Gram matrix are copied device to device from `base`; y (device doubles) is converted and
 // standardised by the kernels upload_standardize runs on column p with the same flag -- column by column they do not depend
 // on one another, so the result is bit-identical to upload_standardize(x, y).
+void standardize_response_f32(const double* y_dev, int n, int flag, long long n_total, float* Yout, long long ld,
+                              float* meanY, float* scaleY, hipStream_t st) {
+    typedef float T;
+    ADMM_HIP_CHECK(hipMemsetAsync(Yout, 0, (size_t)ld * sizeof(T), st));
+    const int ny = std::max(1, std::min(64, (n + 255) / 256));
+    hipLaunchKernelGGL((convert_cols_kernel<T>), dim3(1, ny), dim3(256), 0, st, y_dev, (long long)n, n, Yout, ld);
+    *meanY = T(0); *scaleY = T(1);
+    if (flag != 0) {
+        DevBuf<double> stat(1);
+        DevBuf<T> mean(1), scale(1), inv(1);
+        // p = 0: the only "column" of these launches is y
+        hipLaunchKernelGGL((colstat_kernel<T, 0>), dim3(1), dim3(256), 0, st, Yout, ld, Yout, n, 0, mean.get(), stat.get());
+        hipLaunchKernelGGL((finish_mean_kernel<T>), dim3(1), dim3(256), 0, st, stat.get(), (double)n_total, 1, mean.get());
+        hipLaunchKernelGGL((colstat_kernel<T, 1>), dim3(1), dim3(256), 0, st, Yout, ld, Yout, n, 0, mean.get(), stat.get());
+        hipLaunchKernelGGL((finish_scale_kernel<T>), dim3(1), dim3(256), 0, st, stat.get(), (double)n_total, 1, scale.get(), inv.get());
+        hipLaunchKernelGGL((apply_std_kernel<T>), dim3(1, ny), dim3(256), 0, st, Yout, ld, Yout, n, 0, flag, mean.get(), scale.get(), inv.get());
+        T hm = 0, hs = 1;
+        ADMM_HIP_CHECK(hipMemcpyAsync(&hm, mean.get(), sizeof(T), hipMemcpyDeviceToHost, st));
+        ADMM_HIP_CHECK(hipMemcpyAsync(&hs, scale.get(), sizeof(T), hipMemcpyDeviceToHost, st));
+        ADMM_HIP_CHECK(hipStreamSynchronize(st));
+        if (flag & 2) *meanY = hm;
+        *scaleY = hs;
+    }
+    ADMM_HIP_CHECK(hipGetLastError());
+}
+
 void clone_with_response_f32(DeviceData<float>& d, const DeviceData<float>& base, const float* gram, long long ldgram,
                              const double* y_dev, hipStream_t st) {
     typedef float T;
@@ -271,27 +297,7 @@ void clone_with_response_f32(DeviceData<float>& d, const DeviceData<float>& base
     d.X.alloc((size_t)d.ldx * p);
     ADMM_HIP_CHECK(hipMemcpyAsync(d.X.get(), base.X.get(), (size_t)d.ldx * p * sizeof(T), hipMemcpyDeviceToDevice, st));
     d.Y.alloc((size_t)d.ldx);
-    d.Y.zero(st);
-    const int ny = std::max(1, std::min(64, (n + 255) / 256));
-    hipLaunchKernelGGL((convert_cols_kernel<T>), dim3(1, ny), dim3(256), 0, st, y_dev, (long long)n, n, d.Y.get(), d.ldx);
-    d.meanY = T(0); d.scaleY = T(1);
-    if (d.flag != 0) {
-        DevBuf<double> stat(1);
-        DevBuf<T> mean(1), scale(1), inv(1);
-        // p = 0: the only "column" of these launches is y
-        hipLaunchKernelGGL((colstat_kernel<T, 0>), dim3(1), dim3(256), 0, st, d.X.get(), d.ldx, d.Y.get(), n, 0, mean.get(), stat.get());
-        hipLaunchKernelGGL((finish_mean_kernel<T>), dim3(1), dim3(256), 0, st, stat.get(), (double)d.n_total, 1, mean.get());
-        hipLaunchKernelGGL((colstat_kernel<T, 1>), dim3(1), dim3(256), 0, st, d.X.get(), d.ldx, d.Y.get(), n, 0, mean.get(), stat.get());
-        hipLaunchKernelGGL((finish_scale_kernel<T>), dim3(1), dim3(256), 0, st, stat.get(), (double)d.n_total, 1, scale.get(), inv.get());
-        hipLaunchKernelGGL((apply_std_kernel<T>), dim3(1, ny), dim3(256), 0, st, d.X.get(), d.ldx, d.Y.get(), n, 0, d.flag,
-                           mean.get(), scale.get(), inv.get());
-        T hm = 0, hs = 1;
-        ADMM_HIP_CHECK(hipMemcpyAsync(&hm, mean.get(), sizeof(T), hipMemcpyDeviceToHost, st));
-        ADMM_HIP_CHECK(hipMemcpyAsync(&hs, scale.get(), sizeof(T), hipMemcpyDeviceToHost, st));
-        ADMM_HIP_CHECK(hipStreamSynchronize(st));
-        if (d.flag & 2) d.meanY = hm;
-        d.scaleY = hs;
-    }
+    standardize_response_f32(y_dev, n, d.flag, d.n_total, d.Y.get(), d.ldx, &d.meanY, &d.scaleY, st);
     if (gram != nullptr) {
         d.gram.alloc((size_t)ldgram * ldgram);
         ADMM_HIP_CHECK(hipMemcpyAsync(d.gram.get(), gram, (size_t)ldgram * ldgram * sizeof(T), hipMemcpyDeviceToDevice, st));

@@ -336,6 +336,13 @@ ADMM_HIP_API int admm_hip_test_gram(const void* A, int rows, int cols, int atA, 
  * LAD / BP products, the tall x-update below p = 2048): A HOST rows x cols column-major (leading dimension rows). */
 ADMM_HIP_API int admm_hip_test_gemv_t(const void* A, int rows, int cols, int is_double, const void* v, void* y);
 ADMM_HIP_API int admm_hip_test_spd_inverse(const void* A, int n, int precision, void* Ainv);
+/* The system admm_hip_lasso_cv hands the tall solver for fold `fold` when it forms the folds as down-dates of the full-data
+ * Gram (cv.hip): x, y HOST column-major doubles, fold_id as in admm_hip_lasso_cv (NULL: i mod nfolds).  Out (HOST): gram p x p
+ * float (X_T'X_T of the training rows standardised by THEIR statistics), xy p floats, mean_x / scale_x p floats, and
+ * mean_scale_y[2]. */
+ADMM_HIP_API int admm_hip_test_cv_fold_system(const double* x, const double* y, int n, int p, const int* fold_id, int nfolds, int fold,
+                                              int standardize, int intercept, float* gram, float* xy, float* mean_x, float* scale_x,
+                                              float* mean_scale_y);
 
 #ifdef __cplusplus
 }
