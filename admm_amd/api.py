@@ -330,10 +330,10 @@ class ADMM_BP:
 
     def parallel(self, nthread=2):
         """ADMM_BP$parallel (R/10_admm_bp.R:65-76) only stores nthread; $fit() with nthread > 1 then calls the C symbol
-        `admm_parbp`, which the reference never builds (it lives in src/TODO/ParBP.cppp) -- the R call fails.  Mirrored:
-        the setter clamps to >= 1 and stores, exactly like R (no ncol(x)/5 check here: only ADMM_Lasso$parallel has one,
-        R/30_admm_lasso.R:119-124); fit() refuses like R's missing symbol.  ADMM_LAD inherits this method as in R
-        (`contains = "ADMM_BP"`, R/20_admm_lad.R:4) and, as in R, its fit() ignores nthread."""
+        `admm_parbp`, which the reference never builds (it lives in src/TODO/ParBP.cppp) -- the R call fails there; here it
+        runs the column-block sharing solver (admm_hip_parbp).  The setter clamps to >= 1 and stores, exactly like R (no
+        ncol(x)/5 check here: only ADMM_Lasso$parallel has one, R/30_admm_lasso.R:119-124).  ADMM_LAD inherits this method
+        as in R (`contains = "ADMM_BP"`, R/20_admm_lad.R:4) and, as in R, its fit() ignores nthread."""
         self.nthread = max(1, int(nthread))
         return self
 
@@ -350,8 +350,6 @@ class ADMM_BP:
 
     def fit(self, trace=False):
         """trace=True also returns the decision trace (fit.trace, layout of include/admm_hip.h ADMM_TRACE_*)."""
-        if getattr(self, "nthread", 1) > 1:
-            _stop('C symbol name "admm_parbp" not in DLL for package "ADMM"')     # R/10_admm_bp.R:111: the reference's own failure
         lib = _lib.load()
         xp, xmem, xk = as_input(self.x)
         yp, ymem, yk = as_input(self.y)
@@ -362,9 +360,16 @@ class ADMM_BP:
         niter = np.zeros(1, dtype=np.int32)
         stats = AdmmStats()
         tr, ntr = _trace_buffers(self.maxit if trace else 0)
-        check(lib.admm_hip_bp_traced(xp, yp, self.n, self.p, xmem, ctypes.byref(o),
-                                     beta.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
-                                     niter.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), ctypes.byref(stats), *_trace_args(tr, ntr)))
+        if getattr(self, "nthread", 1) > 1:
+            # .Call("admm_parbp", x, y, nthread, list(maxit, eps_abs, eps_rel, rho_ratio = rho)), R/10_admm_bp.R:111-116 -- the
+            # symbol the reference never builds; here the column-block sharing solver of admm_amd/csrc/sharing_bp.hip
+            check(lib.admm_hip_parbp_traced(xp, yp, self.n, self.p, xmem, int(self.nthread), ctypes.byref(o),
+                                            beta.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                            niter.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), ctypes.byref(stats), *_trace_args(tr, ntr)))
+        else:
+            check(lib.admm_hip_bp_traced(xp, yp, self.n, self.p, xmem, ctypes.byref(o),
+                                         beta.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                         niter.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), ctypes.byref(stats), *_trace_args(tr, ntr)))
         fit = ADMM_BP_fit(sp.csc_matrix(beta.reshape(-1, 1)), int(niter[0]), stats.as_dict())   # dgCMatrix p x 1 (BP.cpp:38-43)
         fit.trace = tr[:ntr.value].copy() if trace else None
         return fit

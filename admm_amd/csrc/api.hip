@@ -549,6 +549,52 @@ int admm_hip_bp_traced(const double* x, const double* y, int n, int p, int mem, 
     });
 }
 
+// admm_parbp (R/10_admm_bp.R:111-116; TODO/ParBP.cppp:26-71): opts->rho carries rho_ratio.
+static void parbp_common(const double* x_cols, const double* y, int n, int p_local, long long p_total, long long col_offset, int mem, int nthread,
+                         const admm_opts* opts, double* beta_out, int* niter_out, admm_stats* stats,
+                         double* trace_out, long long trace_cap, long long* ntrace_out) {
+    ADMM_REQUIRE(trace_cap == 0 || (trace_out != nullptr && ntrace_out != nullptr && trace_cap > 0), "bad trace arguments");
+    check_common(x_cols, y, n, p_local, mem, opts);
+    ADMM_REQUIRE(beta_out && niter_out, "output pointers must not be NULL");
+    ADMM_REQUIRE(p_total > n, "ncol(x) must be greater than nrow(x)");            // R/10_admm_bp.R:30-31
+    ADMM_REQUIRE(opts->rho > 0, "rho should be positive");
+    ADMM_REQUIRE(nthread >= 1 && nthread <= p_total, "nthread must be within [1, ncol(x)]");
+    require_device();
+    const double t0 = now_s();
+    Stream st;
+    DeviceData<double> d;
+    upload_standardize<double>(d, x_cols, y, n, p_local, mem, false, false, st.s);     // ParBP.cppp:36-37: no standardisation
+    DenseResult res;
+    res.trace_cap = trace_cap;
+    res.stats.t_h2d = d.t_h2d;
+    res.stats.t_standardize = d.t_std;
+    solve_parbp(d, *opts, nthread, p_total, col_offset, res, st.s);
+    for (int i = 0; i < p_local; ++i) beta_out[i] = res.beta[i];
+    niter_out[0] = res.niter;
+    if (trace_cap > 0) { std::memcpy(trace_out, res.trace.data(), res.trace.size() * sizeof(double)); *ntrace_out = (long long)(res.trace.size() / ADMM_TRACE_FIELDS); }
+    res.stats.t_total = now_s() - t0;
+    if (stats) *stats = res.stats;
+}
+
+int admm_hip_parbp(const double* x, const double* y, int n, int p, int mem, int nthread, const admm_opts* opts,
+                   double* beta_out, int* niter_out, admm_stats* stats) {
+    return guarded([&] { parbp_common(x, y, n, p, p, 0, mem, nthread, opts, beta_out, niter_out, stats, nullptr, 0, nullptr); });
+}
+
+int admm_hip_parbp_traced(const double* x, const double* y, int n, int p, int mem, int nthread, const admm_opts* opts,
+                          double* beta_out, int* niter_out, admm_stats* stats, double* trace_out, long long trace_cap, long long* ntrace_out) {
+    return guarded([&] { parbp_common(x, y, n, p, p, 0, mem, nthread, opts, beta_out, niter_out, stats, trace_out, trace_cap, ntrace_out); });
+}
+
+int admm_hip_parbp_dist(const double* x_cols, const double* y, int n, int p_local, long long p_total, long long col_offset, int mem, int nthread,
+                        const admm_opts* opts, double* beta_local_out, int* niter_out, admm_stats* stats) {
+    return guarded([&] {
+        ADMM_REQUIRE(comm_info().active, "no communicator: call admm_hip_comm_init first");
+        ADMM_REQUIRE(p_total >= p_local && col_offset >= 0 && col_offset + p_local <= p_total, "column block outside [0, p_total)");
+        parbp_common(x_cols, y, n, p_local, p_total, col_offset, mem, nthread, opts, beta_local_out, niter_out, stats, nullptr, 0, nullptr);
+    });
+}
+
 int admm_hip_lasso_plan_create(const double* x, const double* y, int n, int p, int mem,
                                const double* lambda_in, int nlambda_in, int nlambda_auto, double lmin_ratio,
                                int standardize, int intercept, double alpha, int nthread, const admm_opts* opts,

@@ -84,7 +84,7 @@ typedef struct admm_stats {
     long long xupdate_launches;
     double rho;            /* rho actually used (first lambda) */
     double eig_est;        /* the loose Lanczos value (lambda_max or spectral-radius estimate) */
-    int branch;            /* 0 tall (Cholesky), 1 wide (linearised), 2 consensus */
+    int branch;            /* 0 tall (Cholesky), 1 wide (linearised), 2 consensus; 6 admm_parbp (column-block sharing) */
     int xupdate_variant;   /* tall path: 0 = full-matrix mat-vec (4p^2 B), 1 = lower-triangle symmetric mat-vec (2p^2 B),
                               2 = the same with the tiles dealt out to the ranks + one all-reduce of 2p floats (admm_hip_lasso_dist),
                               3 = 1 with the element-wise tail of the previous iteration inside the same launch (one launch per iteration) */
@@ -167,6 +167,27 @@ ADMM_HIP_API int admm_hip_lad(const double* x, const double* y, int n, int p, in
 /* beta_out[p], niter_out[1]. Requires p > n (R/10_admm_bp.R:30-31). */
 ADMM_HIP_API int admm_hip_bp(const double* x, const double* y, int n, int p, int mem,
                 const admm_opts* opts, double* beta_out, int* niter_out, admm_stats* stats);
+
+/* Basis pursuit with the COLUMNS of x in `nthread` blocks -- what R's admm_bp(x, y)$parallel(nthread)$fit() asks for:
+ * .Call("admm_parbp", x, y, nthread, list(maxit, eps_abs, eps_rel, rho_ratio = rho)) (R/10_admm_bp.R:111-116), a symbol the
+ * reference never builds (src/TODO/ParBP.cppp:26-71, src/TODO/PADMMBP.h against a base class that no longer exists).  The
+ * feature-split "sharing" ADMM of that source, restated on the current PADMMBase_Master loop (admm_amd/csrc/sharing_bp.hip,
+ * oracle/solvers.py SharingBP).  opts->rho carries rho_ratio (R default 1): rho = 1 / (rho_ratio * mean_i lambda_max(A_i'A_i)).
+ * Partition as PADMMBP.h:150-167: nthread - 1 blocks of p div nthread columns, the last takes the remainder.  n <= 8192.
+ * beta_out[p] dense doubles (the reference returns a one-column dgCMatrix), niter_out[1] (maxit + 1 when not converged, as
+ * PADMMBase_Master::solve returns).  _traced: decision records as for admm_hip_bp_traced ([11] = 1 on a regular iteration,
+ * outcome ADMM_TRACE_CONVERGED / ADMM_TRACE_CONTINUE).
+ * _dist: the blocks spread over the ranks of the attached communicator -- this rank passes columns
+ * [col_offset, col_offset + p_local) of the p_total, whole blocks of the partition above, and gets their coefficients back;
+ * one sum all-reduce of n + O(n / 32) doubles per iteration (the "all-reduce of X_i beta_i" of SURVEY.md section 8f row n2). */
+ADMM_HIP_API int admm_hip_parbp(const double* x, const double* y, int n, int p, int mem, int nthread, const admm_opts* opts,
+                                double* beta_out, int* niter_out, admm_stats* stats);
+ADMM_HIP_API int admm_hip_parbp_traced(const double* x, const double* y, int n, int p, int mem, int nthread, const admm_opts* opts,
+                                       double* beta_out, int* niter_out, admm_stats* stats,
+                                       double* trace_out, long long trace_cap, long long* ntrace_out);
+ADMM_HIP_API int admm_hip_parbp_dist(const double* x_cols, const double* y, int n, int p_local, long long p_total, long long col_offset,
+                                     int mem, int nthread, const admm_opts* opts, double* beta_local_out, int* niter_out,
+                                     admm_stats* stats);
 
 /* admm_hip_lad / admm_hip_bp that also return the decision trace (layout below, ADMM_TRACE_*; lambda index 0):
  * trace_out receives min(decisions taken, trace_cap) records of ADMM_TRACE_FIELDS doubles, *ntrace_out their number. */

@@ -115,6 +115,22 @@ def admm_bp(x, y, opts, detail=None):
     return {"beta": solver.get_coef().copy(), "niter": niter}
 
 
+def admm_parbp(x, y, nthread, opts, detail=None):
+    """src/TODO/ParBP.cppp:26-71 (never built by the reference): opts carries rho_ratio (R passes its `rho` field under that
+    name, R/10_admm_bp.R:115); returns the dense coefficient vector (the reference: a one-column dgCMatrix) and niter."""
+    from .solvers import SharingBP
+    x = np.asarray(x, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64)
+    solver = SharingBP(x, y, int(nthread), float(opts["eps_abs"]), float(opts["eps_rel"]))
+    solver.init(float(opts.get("rho_ratio", opts.get("rho", 1.0))))
+    if detail is not None and detail.get("trace") is not None:
+        solver.trace = detail["trace"]
+    niter = solver.solve(int(opts["maxit"]))
+    if detail is not None:
+        detail.update(solver=solver)
+    return {"beta": solver.get_x(), "niter": niter}
+
+
 def admm_dantzig(x, y, lam, nlambda, lmin_ratio, standardize, intercept, opts, detail=None):
     """src/TODO/Dantzig.cpp:32-99 (never built by the reference): DataStd<double>, the automatic grid from lambda_0 = max|X'y|
     (:63-70), internal lambda = lambda n / scaleY (:79), warm-started loop, recover -> (p+1) x nlambda doubles."""

@@ -833,3 +833,111 @@ class Dantzig:
 
     def get_coef(self):
         return self.main_x
+
+
+class SharingBP:
+    """`admm_parbp` -- basis pursuit  min ||x||_1  s.t.  A x = b  with the COLUMNS of A split into N blocks ("sharing" ADMM,
+    Boyd et al. 2011 section 7.3) -- restated from the reference's UNBUILT source /root/reference/src/TODO/PADMMBP.h (its R
+    wrapper R/10_admm_bp.R:111 calls a symbol the package never compiles; the file is written against a master / worker
+    base class that no longer exists) against the loop shape of the CURRENT PADMMBase_Master (PADMMBase.h:174-237:
+    update_x -> update_z -> update_y -> converged, thresholds recomputed at the top of update_x, rho fixed).
+    TEST INFRASTRUCTURE.
+
+    What PADMMBP.h fixes (kept to the letter):
+      * the partition: N - 1 blocks of p div N columns, the last one takes the remainder                  (:150-167)
+      * rho = 1 / (rho_ratio * mean_i sprad_i), sprad_i = lambda_max(A_i'A_i)                             (:181-186)
+      * z-bar = b / N                                                                                     (:137-140)
+      * the worker's x-update, linearised with gamma = 2 rho + sprad_i:  v = y / rho + r,  r = mean_i(A_i x_i) - z-bar,
+        x_i <- soft(x_i - A_i'v / gamma, 1 / (rho gamma))  on iterations 0, 10, 20, ... of the worker     (:47-61)
+        and on the others only on the current non-zeros of x_i (active set), followed by prune            (:19-44)
+    What it does not contain (the old base class held it) and is therefore OURS, modelled on the current base class with
+    the identity of the consensus constraint replaced by A_i (constraint  A_i x_i - z_i = 0,  sum_i z_i = b, so
+    z_i = A_i x_i - r after the z-update):
+      * y <- y + rho r                                              (Boyd's u <- u + x-bar - z-bar, y = rho u)
+      * resid_primal = sqrt(N) ||r||                                (the N stacked copies of r; PADMMBase.h:209-221)
+      * resid_dual   = rho sqrt(sum_i ||dz_i||^2), dz_i = A_i dx_i - dr                                   (:137-142)
+                       evaluated as  sum_i ||A_i dx_i||^2 - 2 dr'dS + N ||dr||^2,  S = sum_i A_i x_i  (clamped at 0): the column
+                       blocks may live on different ranks and this form needs S and two scalars summed over them, nothing else
+      * eps_primal = eps_rel max(sqrt(sum_i ||A_i x_i||^2), sqrt(sum_i ||z_i||^2)) + sqrt(n N) eps_abs    (:118-127)
+      * eps_dual   = eps_rel sqrt(N) ||y|| + sqrt(n N) eps_abs                                            (:129-136)
+    sprad_i: the reference asks an R function that does not exist (`.spectral_radius_xx`, :64-71); the exact largest
+    eigenvalue here (the library: Lanczos with full re-orthogonalisation run to 1e-13)."""
+
+    def __init__(self, A, b, nblocks, eps_abs, eps_rel):
+        A = np.asarray(A, dtype=np.float64)
+        self.n, self.p = A.shape
+        self.N = int(nblocks)
+        chunk = self.p // self.N
+        self.off = [i * chunk for i in range(self.N)] + [self.p]
+        self.A = [A[:, self.off[i]:self.off[i + 1]] for i in range(self.N)]
+        self.b = np.asarray(b, dtype=np.float64)
+        self.eps_abs, self.eps_rel = float(eps_abs), float(eps_rel)
+        self.sprad = [float(np.linalg.norm(Ai, 2) ** 2) for Ai in self.A]
+        self.trace = None
+
+    def init(self, rho_ratio):
+        self.rho = 1.0 / (float(rho_ratio) * float(np.mean(self.sprad)))
+        self.x = [np.zeros(Ai.shape[1]) for Ai in self.A]
+        self.Ax = [np.zeros(self.n) for _ in self.A]
+        self.y = np.zeros(self.n)
+        self.r = np.zeros(self.n)
+        self.S = np.zeros(self.n)
+        self.counter = 0
+        self.eps_primal = self.eps_dual = 0.0
+        self.resid_primal = self.resid_dual = 9999.0
+
+    def _eps(self):
+        N, n = self.N, self.n
+        sax = sum(float(a @ a) for a in self.Ax)
+        abar = sum(self.Ax) / N
+        sz = sax - 2.0 * N * float(abar @ self.r) + N * float(self.r @ self.r)      # sum_i ||A_i x_i - r||^2
+        self.eps_primal = self.eps_rel * np.sqrt(max(sax, sz, 0.0)) + np.sqrt(float(n * N)) * self.eps_abs
+        self.eps_dual = self.eps_rel * np.sqrt(float(N)) * float(np.linalg.norm(self.y)) + np.sqrt(float(n * N)) * self.eps_abs
+
+    def solve(self, maxit):
+        N = self.N
+        zbar = self.b / N
+        for it in range(int(maxit)):
+            self._eps()
+            v = self.y / self.rho + self.r
+            regular = self.counter % 10 == 0
+            newAx = []
+            for i, Ai in enumerate(self.A):
+                gamma = 2.0 * self.rho + self.sprad[i]
+                pen = 1.0 / (self.rho * gamma)
+                xi = self.x[i]
+                if regular:
+                    vec = xi - (Ai.T @ v) / gamma
+                    xi = np.sign(vec) * np.maximum(np.abs(vec) - pen, 0.0)
+                else:
+                    nz = np.nonzero(xi)[0]
+                    xn = np.zeros_like(xi)
+                    if nz.size:
+                        val = xi[nz] - (Ai[:, nz].T @ v) / gamma
+                        xn[nz] = np.sign(val) * np.maximum(np.abs(val) - pen, 0.0)
+                    xi = xn
+                self.x[i] = xi
+                nz = np.nonzero(xi)[0]
+                newAx.append(Ai[:, nz] @ xi[nz] if nz.size else np.zeros(self.n))
+            self.counter += 1
+            Snew = sum(newAx)
+            rnew = Snew / N - zbar
+            dr = rnew - self.r
+            dS = Snew - self.S
+            q = sum(float((newAx[i] - self.Ax[i]) @ (newAx[i] - self.Ax[i])) for i in range(N))
+            sd = q - 2.0 * float(dr @ dS) + N * float(dr @ dr)
+            self.resid_dual = self.rho * np.sqrt(max(sd, 0.0))
+            self.Ax = newAx
+            self.S = Snew
+            self.r = rnew
+            self.y = self.y + self.rho * rnew
+            self.resid_primal = np.sqrt(N * float(rnew @ rnew))
+            conv = self.resid_primal < self.eps_primal and self.resid_dual < self.eps_dual
+            if self.trace is not None:
+                self.trace.append((it, self.eps_primal, self.eps_dual, self.resid_primal, self.resid_dual, int(regular), int(conv)))
+            if conv:
+                return it + 1
+        return int(maxit) + 1                                       # `return i + 1` after the loop, PADMMBase.h:236
+
+    def get_x(self):
+        return np.concatenate(self.x)

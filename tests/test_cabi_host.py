@@ -148,9 +148,8 @@ def test_fit_objects_mirror_show_and_plot_data():
         one.path_data()
     assert "Basis Pursuit" in repr(ADMM_BP_fit(sp.csc_matrix(np.zeros((5, 1))), 7, {}))
     assert "LAD" in repr(ADMM_LAD_fit(np.zeros(3), 9, {}))
-    m = ADMM_BP(np.zeros((3, 40)), np.zeros(3)).parallel(2)
-    with pytest.raises(ValueError, match="admm_parbp"):
-        m.fit()
+    m = ADMM_BP(np.zeros((3, 40)), np.zeros(3)).parallel(2)            # $parallel only stores nthread (R/10_admm_bp.R:65-76); fit -> admm_hip_parbp
+    assert m.nthread == 2 and ADMM_BP(np.zeros((3, 40)), np.zeros(3)).parallel(0).nthread == 1
     # admm_dantzig is exported by the reference but calls a symbol it never builds (src/TODO/Dantzig.cpp): same failure here
     import admm_amd
     dz = admm_amd.admm_dantzig(np.zeros((30, 4)), np.zeros(30)).penalty(nlambda=5).opts(maxit=10)

@@ -1,0 +1,103 @@
+"""GPU: admm_hip_parbp -- basis pursuit with the columns in blocks (the "sharing" ADMM of the reference's unbuilt
+src/TODO/PADMMBP.h, restated on the current PADMMBase_Master loop) -- against
+oracle/solvers.py SharingBP iteration by iteration (decision trace), against the serial solver, and against the linear
+programme it solves."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _fit(x, y, N, **opts):
+    import admm_amd
+    m = admm_amd.admm_bp(x, y).parallel(N)
+    if opts:
+        m.opts(**opts)
+    return m.fit(trace=True)
+
+
+def _oracle(x, y, N, maxit=10000, eps=1e-4, rho=1.0):
+    from oracle import entry
+    d = {"trace": []}
+    o = entry.admm_parbp(x, y, N, dict(maxit=maxit, eps_abs=eps, eps_rel=eps, rho_ratio=rho), d)
+    return o, np.asarray(d["trace"], dtype=np.float64), d["solver"]
+
+
+def _compare(x, y, N, label, **opts):
+    fit = _fit(x, y, N, **opts)
+    o, tr, sol = _oracle(x, y, N, maxit=opts.get("maxit", 10000), eps=opts.get("eps_abs", 1e-4), rho=opts.get("rho", 1.0))
+    t = fit.trace
+    assert t[0, 8] == -1                                        # the cold-start record
+    t = t[1:]
+    nrec = min(len(t), len(tr))
+    assert abs(fit.stats["rho"] / sol.rho - 1) < 1e-10, (label, fit.stats["rho"], sol.rho)
+    # every iteration: thresholds and residuals as the oracle has them, the same regular / active-set schedule, the same decision
+    rel = lambda a, b: np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+    errs = dict(eps_p=rel(t[:nrec, 2], tr[:nrec, 1]), eps_d=rel(t[:nrec, 3], tr[:nrec, 2]), rp=rel(t[:nrec, 4], tr[:nrec, 3]),
+                rd=np.abs(t[:nrec, 5] - tr[:nrec, 4]).max() / tr[:nrec, 4].max())
+    assert np.array_equal(t[:nrec, 1], tr[:nrec, 0]) and np.array_equal(t[:nrec, 11], tr[:nrec, 5]), label
+    assert np.array_equal(t[:nrec, 8] == 0, tr[:nrec, 6] == 1), label
+    b = fit.beta.toarray().ravel()
+    eb = np.abs(b - o["beta"]).max() / np.abs(o["beta"]).max()
+    print(f"[parbp {label}] N={N}: {fit.niter} iterations (oracle {o['niter']}), rho {fit.stats['rho']:.4g}; trace vs oracle {({k: float(f'{v:.1e}') for k, v in errs.items()})}, "
+          f"beta {eb:.1e}, support {np.count_nonzero(b)} / {np.count_nonzero(o['beta'])}")
+    assert fit.niter == o["niter"], (label, fit.niter, o["niter"])
+    assert len(t) == len(tr)
+    assert max(errs.values()) < 1e-8 and eb < 1e-9, (label, errs, eb)
+    assert np.array_equal(b != 0, o["beta"] != 0)               # the active set itself
+    return fit, o
+
+
+def test_readme_problem_block_counts():
+    from oracle import readme
+    x, y, bt = readme.bp_data()                                  # README.md:217-246: n = 50, p = 100
+    import admm_amd
+    ser = admm_amd.admm_bp(x, y).fit()
+    for N in (2, 3, 4, 7):                                       # 3 and 7: the last block takes the remainder (PADMMBP.h:150-167)
+        fit, o = _compare(x, y, N, "README n=50 p=100")
+        b = fit.beta.toarray().ravel()
+        assert np.abs(b - bt).max() < 2e-3                       # recovers the sparse truth like the serial solver (README range 1e-3)
+        assert np.abs(b - ser.beta.toarray().ravel()).max() < 3e-3
+
+
+def test_readme_perf_problem_and_ragged_rows():
+    from oracle import readme
+    x, y, bt = readme.bp_data(1000, 2000, 100)                   # README.md:369-393
+    fit, o = _compare(x, y, 4, "README n=1000 p=2000")
+    assert np.abs(fit.beta.toarray().ravel() - bt).max() < 5e-3
+    rng = np.random.default_rng(3)
+    n, p = 301, 1203                                             # rows not a multiple of anything, 5 blocks of 240 + 243
+    x = rng.standard_normal((n, p))
+    b0 = np.zeros(p); b0[rng.choice(p, 25, replace=False)] = rng.standard_normal(25) * 3
+    _compare(np.asfortranarray(x), x @ b0, 5, "n=301 p=1203")
+
+
+def test_against_the_linear_programme():
+    """Basis pursuit is an LP: min 1'(u + w) s.t. A (u - w) = b, u, w >= 0.  The sharing solver's ||x||_1 against HiGHS."""
+    from scipy.optimize import linprog
+    rng = np.random.default_rng(11)
+    n, p = 40, 120
+    A = rng.standard_normal((n, p))
+    b = A @ (rng.standard_normal(p) * (rng.uniform(size=p) < 0.08))
+    lp = linprog(np.ones(2 * p), A_eq=np.hstack([A, -A]), b_eq=b, bounds=[(0, None)] * (2 * p), method="highs")
+    assert lp.status == 0
+    fit = _fit(np.asfortranarray(A), b, 3, eps_abs=1e-6, eps_rel=1e-6, maxit=20000)
+    xg = fit.beta.toarray().ravel()
+    print(f"[parbp vs LP] ||x||_1 {np.abs(xg).sum():.6f} (LP {lp.fun:.6f}), ||Ax - b|| {np.linalg.norm(A @ xg - b):.2e}, {fit.niter} iterations")
+    assert fit.niter <= 20000
+    assert np.linalg.norm(A @ xg - b) < 1e-3 * np.linalg.norm(b)
+    assert abs(np.abs(xg).sum() / lp.fun - 1) < 1e-3
+
+
+def test_maxit_exit_and_arguments():
+    import admm_amd
+    from oracle import readme
+    x, y, _ = readme.bp_data()
+    fit = _fit(x, y, 2, maxit=37)
+    assert fit.niter == 38                                       # `return i + 1` after the loop (PADMMBase.h:236)
+    o, tr, _ = _oracle(x, y, 2, maxit=37)
+    assert o["niter"] == 38 and np.abs(fit.beta.toarray().ravel() - o["beta"]).max() < 1e-10
+    with pytest.raises(RuntimeError):
+        admm_amd.admm_bp(x, y).parallel(101).fit()               # more blocks than columns
+    one = _fit(x, y, 1)                                          # nthread = 1 through $parallel is the serial solver, as in R
+    assert one.stats["branch"] != 6
