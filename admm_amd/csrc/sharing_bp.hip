@@ -15,15 +15,16 @@
 //          every column on iterations 0, 10, 20, ...; only the current non-zeros otherwise
 //   y <- y + rho r
 //
-// Per iteration: `step` (the decision of the previous iteration, evaluated identically by every workgroup from the norm
-// partials; then the x-update: a workgroup owns a range of columns of one block -- or of the block's non-zero list --, its
-// 256 threads own the rows: a batch of column dots is reduced over the workgroup, the new x_j is known to every thread, and
-// x_j A_j is added to the workgroup's own partial of A_i x_i in registers, summation order fixed), on regular iterations
-// `list` (the blocks' non-zero lists, ascending, from per-workgroup counts), `tail_a` (block sums of the partials,
-// S = sum_i A_i x_i, sum ||A_i x_i||^2, sum ||A_i dx_i||^2) and `tail_b` (r, y, v, norm partials).  With a communicator
-// attached the column blocks are spread over the ranks and ONE sum all-reduce of n + 2 nT doubles sits between the two
-// tails: S and the two block sums -- the dual residual is evaluated as  sum_i ||A_i dx_i - dr||^2 = sum_i ||A_i dx_i||^2
-// - 2 dr'dS + N ||dr||^2  so that it needs nothing else.  The host enqueues iterations in batches and polls a sticky flag.
+// Launches.  Regular iteration (0, 10, 20, ...): `xreg` (the decision of the previous iteration, evaluated identically by every
+// workgroup from the norm partials; then the x-update of EVERY column as a streaming transposed mat-vec, 6.5 TB/s at the C5
+// shape), `list` (the blocks' non-zero lists, ascending, from per-workgroup counts), `xact<AXONLY>` (the workgroup partials of
+// A_i x_i over the lists), `tail`.  Active-set iteration: `xact` (decision; x-update of the listed non-zeros and the partials
+// of A_i x_i in the same launch), `tail` (block sums of the partials, S = sum_i A_i x_i, the two block norms; r, y, v and the
+// norm partials).  With a communicator attached the column blocks are spread over the ranks and ONE sum all-reduce of
+// n + 2 nT doubles sits between `tail` and `tail_b`: S and the two block sums -- the dual residual is evaluated as
+// sum_i ||A_i dx_i - dr||^2 = sum_i ||A_i dx_i||^2 - 2 dr'dS + N ||dr||^2  so that it needs nothing else.  The host enqueues
+// iterations in batches and polls a sticky flag.  Measured (C5 shape n = 5000, p = 50 000, 8 blocks on one MI355X, 545
+// non-zeros at the end, 5754 iterations): regular iteration 308 + 5 + 11 + 11 us, active-set iteration 20 + 11 us, loop 0.36 s.
 #include "prep.h"
 #include "solvers.h"
 #include "loop_driver.h"
@@ -39,17 +40,23 @@ struct SbpCtl {                                   // 64 bytes: whole 16-byte wor
     int iter, done, niter, conv, total, pad0, pad1, pad2;
 };
 
+struct SbpBlk {                                   // 32 bytes: one vector round trip (load_ctl_vector)
+    int c0, pb;                                   // first local column, columns
+    double gamma, pen;                            // 2 rho + sprad_i, 1 / (rho gamma_i)
+    long long pad;
+};
+
 struct SbpParams {
-    int n, npad, N, NL, maxit, G, nT, pad;
+    int n, npad, N, NL, maxit, G, nT, min_share;
     double eps_abs, eps_rel, rho, sqrt_nN, sqrtN, dN;
     const double* A; long long lda;              // this rank's columns, n x pl column-major, rows padded with zeros to npad
-    const int* wg_block; const int* wg_sub;      // [G]
-    const int* blk_g0; const int* blk_c0;        // [NL + 1]
-    const double* blk_gamma; const double* blk_pen;   // [NL]
+    int Gb, pad1;                                // workgroups per local block (the same for every block: block = g / Gb, no table)
+    const SbpBlk* blk;                           // [NL]
     double* x;                                   // [pl]
     int* list; int* cnt;                         // [pl] block-relative indices of the non-zeros, ascending; [NL]
-    int* wcount; int* pnz;                       // [G]
-    double* P;                                   // [G][npad]
+    int* wcount;                                 // [G]
+    double* xl;                                  // [pl] the values of the listed entries, in list order
+    double* P;                                   // [G][npad] workgroup partials of A_i x_i
     double* Axo;                                 // [NL][npad]
     double* S; double* Qa;                       // exchange buffer: [npad] | [nT][2]
     double* Sold; double* y; double* r; double* v; const double* zbar;   // [npad]
@@ -64,20 +71,25 @@ __device__ __forceinline__ double sbp_soft(double v, double pen) {
     return v > pen ? v - pen : (v < -pen ? v + pen : 0.0);
 }
 
-template <int RPT> struct SbpBatch { static constexpr int value = RPT <= 4 ? 8 : (RPT <= 8 ? 4 : 2); };
+// Entries of a block's work list per workgroup.  Regular iterations: the columns in Gb equal shares.  Active-set iterations: at
+// least `min_share` (4: one round of the four waves) list entries per workgroup, so that a few hundred non-zeros occupy a few
+// dozen workgroups and the tail sums that many partial rows instead of Gb (measured: 1 -> 0.354 s, 4 -> 0.373, 8 -> 0.430, 16 -> 0.573).
+__host__ __device__ __forceinline__ int sbp_share(int total, int Gb, int min_share) {
+    const int per = (total + Gb - 1) / Gb;
+    return per > min_share ? per : min_share;                       // min_share = 0: regular iterations, equal shares of the columns
+}
 
-template <int RPT>
-__global__ void __launch_bounds__(kSbpThreads)
-sbp_step_kernel(SbpParams q, int par) {
-    constexpr int CB = SbpBatch<RPT>::value;
-    __shared__ double red[8 * 4];
+// The decision every iteration starts with, evaluated identically by every workgroup of the iteration's first launch: the
+// residuals of the iteration just finished against the thresholds it ran with (PADMMBase.h:223-231), then the thresholds of the
+// coming one (:118-136).  Returns false when the loop is over (all threads agree).  red: 28 doubles of LDS.
+__device__ __forceinline__ bool sbp_decide(const SbpParams& q, int par, SbpCtl& out, double* red) {
     const SbpCtl in = load_ctl_vector(q.ctl + par);
     SbpCtl* outp = &q.ctl[par ^ 1];
+    out = in;
     if (in.done) {
         if (blockIdx.x == 0 && threadIdx.x == 0) *outp = in;
-        return;
+        return false;
     }
-    // ---- the iteration just finished: residuals against the thresholds it ran with; then the thresholds of this one
     double s[7] = {0, 0, 0, 0, 0, 0, 0};
     for (int w = threadIdx.x; w < q.nT; w += kSbpThreads) {
 #pragma unroll
@@ -86,7 +98,6 @@ sbp_step_kernel(SbpParams q, int par) {
     }
     block_sum<double, 7>(s, red);
     const double drdS = s[0], dr2 = s[1], r2 = s[2], y2 = s[3], abar_r = s[4], sax = s[5], qq = s[6];
-    SbpCtl out = in;
     double code = ADMM_TRACE_COLD;
     if (in.iter > 0) {
         const double sd = qq - 2.0 * drdS + q.dN * dr2;
@@ -113,81 +124,170 @@ sbp_step_kernel(SbpParams q, int par) {
             t[6] = 0.0; t[7] = 0.0; t[8] = code; t[9] = q.rho; t[10] = q.rho; t[11] = in.iter > 0 && ((in.iter - 1) % 10) == 0 ? 1.0 : 0.0;      // the judged iteration was a regular one
         }
     }
-    if (out.done) return;
+    return !out.done;
+}
 
-    // ---- x-update of this workgroup's share of its block
+// Regular iterations (0, 10, 20, ...), first launch: x_j <- soft(x_j - A_j'v / gamma, pen) for EVERY column -- a streaming
+// transposed mat-vec: v staged in LDS, a wave owns two columns at a time and reads them with 16-byte loads, no barrier in the
+// loop.  A_i x_i is NOT formed here (after the threshold nearly every column is zero): the list launch builds the non-zero
+// lists from the per-workgroup counts and the step launch below adds x_j A_j over them (AXONLY).
+template <bool NT>                                                  // NT: the matrix does not stay in the Infinity Cache between two regular iterations
+__global__ void __launch_bounds__(kSbpThreads)
+sbp_xreg_kernel(SbpParams q, int par) {
+    extern __shared__ __attribute__((aligned(16))) double vsh[];    // npad doubles
+    __shared__ double red[8 * 4];
+    __shared__ int wnz[4];
+    SbpCtl c;
+    if (!sbp_decide(q, par, c, red)) return;
+    for (int k = threadIdx.x; k < q.npad; k += kSbpThreads) vsh[k] = q.v[k];
+    __syncthreads();
     const int g = blockIdx.x;
-    const int b = q.wg_block[g], sub = q.wg_sub[g];
-    const int Gb = q.blk_g0[b + 1] - q.blk_g0[b];
-    const int c0 = q.blk_c0[b], pb = q.blk_c0[b + 1] - c0;
-    const double gamma = q.blk_gamma[b], pen = q.blk_pen[b];
-    const bool regular = (in.iter % 10) == 0;
-    const int total = regular ? pb : load_flag_vector(q.cnt + b);
-    const int per = (total + Gb - 1) / Gb;
-    const int lo = sub * per, hi = min(total, lo + per);
-    double v[RPT], axp[RPT];
-#pragma unroll
-    for (int k = 0; k < RPT; ++k) {
-        const int row = threadIdx.x + kSbpThreads * k;
-        v[k] = row < q.npad ? q.v[row] : 0.0;
-        axp[k] = 0.0;
-    }
+    const int Gb = q.Gb, b = g / Gb, sub = g - b * Gb;
+    const SbpBlk bi = load_ctl_vector(q.blk + b);
+    const int c0 = bi.c0, pb = bi.pb;
+    const double gamma = bi.gamma, pen = bi.pen;
+    const int per = sbp_share(pb, Gb, 0);
+    const int lo = sub * per, hi = min(pb, lo + per);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int nk = q.npad / 128;                                    // 16-byte loads: 128 rows per wave instruction
     int nzc = 0;
-    for (int e = lo; e < hi; e += CB) {
-        int col[CB]; double xj[CB], d[CB];
+    for (int e = lo + 2 * wid; e < hi; e += 8) {
+        const bool two = e + 1 < hi;
+        const double2* a0 = reinterpret_cast<const double2*>(q.A + (size_t)(c0 + e) * q.lda) + lane;
+        const double2* a1 = reinterpret_cast<const double2*>(q.A + (size_t)(c0 + e + (two ? 1 : 0)) * q.lda) + lane;
+        const double2* vv = reinterpret_cast<const double2*>(vsh) + lane;
+        double d0 = 0.0, d1 = 0.0;
+        int k = 0;
+        for (; k + 4 <= nk; k += 4) {
+            double2 x0[4], x1[4];
 #pragma unroll
-        for (int c = 0; c < CB; ++c) {
-            col[c] = -1; xj[c] = 0.0; d[c] = 0.0;
-            if (e + c < hi) {
-                const int j = c0 + (regular ? e + c : q.list[c0 + e + c]);
-                const double xv = q.x[j];
-                if (regular || xv != 0.0) { col[c] = j; xj[c] = xv; }      // an entry the active set has already pruned stays zero (PADMMBP.h:43)
+            for (int u = 0; u < 4; ++u) { x0[u] = NT ? load16_nt<double2>(a0 + (size_t)(k + u) * 64) : a0[(size_t)(k + u) * 64]; x1[u] = NT ? load16_nt<double2>(a1 + (size_t)(k + u) * 64) : a1[(size_t)(k + u) * 64]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double2 w = vv[(k + u) * 64];
+                d0 = fma(x0[u].x, w.x, d0); d0 = fma(x0[u].y, w.y, d0);
+                d1 = fma(x1[u].x, w.x, d1); d1 = fma(x1[u].y, w.y, d1);
             }
         }
-#pragma unroll
-        for (int c = 0; c < CB; ++c) {
-            if (col[c] < 0) continue;                                       // uniform
-            const double* a = q.A + (size_t)col[c] * q.lda;
-#pragma unroll
-            for (int k = 0; k < RPT; ++k) {
-                const int row = threadIdx.x + kSbpThreads * k;
-                if (row < q.npad) d[c] = fma(a[row], v[k], d[c]);
-            }
+        for (; k < nk; ++k) {
+            const double2 x0 = NT ? load16_nt<double2>(a0 + (size_t)k * 64) : a0[(size_t)k * 64], x1 = NT ? load16_nt<double2>(a1 + (size_t)k * 64) : a1[(size_t)k * 64], w = vv[k * 64];
+            d0 = fma(x0.x, w.x, d0); d0 = fma(x0.y, w.y, d0);
+            d1 = fma(x1.x, w.x, d1); d1 = fma(x1.y, w.y, d1);
         }
-        block_sum<double, CB>(d, red);
-#pragma unroll
-        for (int c = 0; c < CB; ++c) {
-            if (col[c] < 0) continue;
-            double xn;
-            {
+        d0 = wave_sum(d0); d1 = wave_sum(d1);
+        double xn0, xn1;
+        {
 #pragma clang fp contract(off)
-                const double val = xj[c] - d[c] / gamma;
-                xn = sbp_soft(val, pen);
-            }
-            if (threadIdx.x == 0) q.x[col[c]] = xn;
-            if (xn != 0.0) {
-                ++nzc;
-                const double* a = q.A + (size_t)col[c] * q.lda;
+            xn0 = sbp_soft(q.x[c0 + e] - d0 / gamma, pen);
+            xn1 = two ? sbp_soft(q.x[c0 + e + 1] - d1 / gamma, pen) : 0.0;
+        }
+        if (lane == 0) { q.x[c0 + e] = xn0; if (two) q.x[c0 + e + 1] = xn1; }
+        nzc += (xn0 != 0.0) + (xn1 != 0.0);
+    }
+    if (lane == 0) wnz[wid] = nzc;
+    __syncthreads();
+    if (threadIdx.x == 0) q.wcount[g] = wnz[0] + wnz[1] + wnz[2] + wnz[3];
+}
+
+// Active-set iterations, first launch (AXONLY = false): the decision, then x_j <- soft(x_j - A_j'v / gamma, pen) for the blocks'
+// current non-zeros only (PADMMBP.h:19-44) and their share of A_i x_i.  The block's list is cut into shares of at least
+// `min_share` entries per workgroup; in a round of four entries a wave streams one column (16-byte loads, v
+// staged in LDS, the column requested in chunks of 24 x 16 bytes per lane), the four new values are exchanged through LDS, and then every thread adds  sum_c x_c A_c  for ITS rows (the
+// columns are still in L2; entry order, so the additions have a fixed order) into registers -- the workgroup's partial of
+// A_i x_i, stored to P[g] at the end.  Latency is what this launch costs (a dependent round trip to memory is ~1.5 us):
+// the block record, the list length, the list entries and the first column are requested BEFORE the decision, whose own two
+// round trips (control block, norm partials) they overlap.  Measured on the way here (C5 shape, 545 non-zeros, one MI355X):
+// block-per-column dots with the partial in registers 45 us; wave-per-column + a row-gather launch 13 + 22 us (every 512-byte
+// piece of the gather on another page of the 2 GB matrix); wave-per-column with the waves taking turns on an LDS partial 23 us.
+// Regular iterations, third launch (AXONLY = true): the same over the lists just built, x untouched.
+constexpr int kSbpChunk = 24;                                       // double2 per lane requested together when a wave streams a column
+constexpr int kSbpRowPairs = 16;                                    // double2 per thread: 2 * 256 * 16 = 8192 rows at most
+template <bool AXONLY>
+__global__ void __launch_bounds__(kSbpThreads)
+sbp_xact_kernel(SbpParams q, int par) {
+    extern __shared__ __attribute__((aligned(16))) double vsh[];    // npad doubles: v (not used by AXONLY)
+    __shared__ double red[8 * 4];
+    __shared__ double sx[4];
+    __shared__ int sj[4];
+    const int g = blockIdx.x;
+    const int Gb = q.Gb, b = g / Gb, sub = g - b * Gb;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    // ---- requests that do not depend on the decision
+    const SbpBlk bi = load_ctl_vector(q.blk + b);
+    const int total = load_flag_vector(q.cnt + b);
+    const int c0 = bi.c0;
+    const int per = sbp_share(total, Gb, q.min_share);
+    const int lo = sub * per, hi = min(total, lo + per);
+    int j0 = 0; double x0 = 0.0;
+    if (lo + wid < hi) { j0 = q.list[c0 + lo + wid]; x0 = q.xl[c0 + lo + wid]; }
+    if (!AXONLY && lo < total)
+        for (int k = threadIdx.x; k < q.npad; k += kSbpThreads) vsh[k] = q.v[k];      // made visible by the barriers of the decision
+    __builtin_amdgcn_sched_barrier(0);
+    SbpCtl out;
+    if (AXONLY) {
+        out = load_ctl_vector(q.ctl + par);                         // written by this iteration's xreg launch
+        if (out.done) return;
+    } else {
+        if (!sbp_decide(q, par, out, red)) return;
+    }
+    if (lo >= total) return;                                        // only the first ceil(total / per) workgroups of the block work (the tail knows)
+    const double gamma = bi.gamma, pen = bi.pen;
+    const int nk = q.npad / 128;                                    // double2 per lane and column
+    const int np2 = q.npad / 2;                                     // double2 per column
+    const double2* vv = reinterpret_cast<const double2*>(vsh) + lane;
+    double2 acc[kSbpRowPairs];
 #pragma unroll
-                for (int k = 0; k < RPT; ++k) {
-                    const int row = threadIdx.x + kSbpThreads * k;
-                    if (row < q.npad) axp[k] = fma(xn, a[row], axp[k]);
+    for (int k = 0; k < kSbpRowPairs; ++k) acc[k] = make_double2(0.0, 0.0);
+    for (int e4 = lo; e4 < hi; e4 += 4) {                           // uniform trip count: the barriers below are the workgroup's
+        const int e = e4 + wid;
+        double xn = 0.0;
+        int j = 0;
+        if (e < hi) {
+            j = __builtin_amdgcn_readfirstlane(e4 == lo ? j0 : q.list[c0 + e]);
+            const double xj = readlane_f64(e4 == lo ? x0 : q.xl[c0 + e], 0);
+            if (AXONLY) {
+                xn = xj;
+            } else if (xj != 0.0) {                                 // an entry the active set has already pruned stays zero (PADMMBP.h:43)
+                const double2* a = reinterpret_cast<const double2*>(q.A + (size_t)(c0 + j) * q.lda) + lane;
+                double d0 = 0.0, d1 = 0.0;
+                for (int k0 = 0; k0 < nk; k0 += kSbpChunk) {       // a chunk of the column entirely in flight: one round trip per 3072 rows
+                    double2 x[kSbpChunk];
+#pragma unroll
+                    for (int u = 0; u < kSbpChunk; ++u) x[u] = k0 + u < nk ? a[(size_t)(k0 + u) * 64] : make_double2(0.0, 0.0);
+#pragma unroll
+                    for (int u = 0; u < kSbpChunk; u += 2) {
+                        if (k0 + u < nk) { const double2 w = vv[(k0 + u) * 64]; d0 = fma(x[u].x, w.x, d0); d0 = fma(x[u].y, w.y, d0); }
+                        if (k0 + u + 1 < nk) { const double2 w = vv[(k0 + u + 1) * 64]; d1 = fma(x[u + 1].x, w.x, d1); d1 = fma(x[u + 1].y, w.y, d1); }
+                    }
                 }
+                const double d = wave_sum(d0 + d1);
+                {
+#pragma clang fp contract(off)
+                    xn = sbp_soft(xj - d / gamma, pen);
+                }
+                if (lane == 0) { q.x[c0 + j] = xn; q.xl[c0 + e] = xn; }
             }
         }
-    }
-    if (nzc > 0) {
-        double* P = q.P + (size_t)g * q.npad;
+        __syncthreads();                                            // (the previous round's readers of sx / sj are done)
+        if (lane == 0) { sx[wid] = xn; sj[wid] = j; }
+        __syncthreads();
 #pragma unroll
-        for (int k = 0; k < RPT; ++k) {
-            const int row = threadIdx.x + kSbpThreads * k;
-            if (row < q.npad) P[row] = axp[k];
+        for (int c = 0; c < 4; ++c) {                               // entry order: every thread adds x_c A_c for its rows
+            const double xc = sx[c];
+            if (xc == 0.0) continue;                                // uniform
+            const double2* ac = reinterpret_cast<const double2*>(q.A + (size_t)(c0 + sj[c]) * q.lda) + threadIdx.x;
+            double2 t[kSbpRowPairs];
+#pragma unroll
+            for (int k = 0; k < kSbpRowPairs; ++k) t[k] = k * kSbpThreads + (int)threadIdx.x < np2 ? ac[(size_t)k * kSbpThreads] : make_double2(0.0, 0.0);
+#pragma unroll
+            for (int k = 0; k < kSbpRowPairs; ++k) { acc[k].x = fma(xc, t[k].x, acc[k].x); acc[k].y = fma(xc, t[k].y, acc[k].y); }
         }
     }
-    if (threadIdx.x == 0) {
-        q.pnz[g] = nzc > 0 ? 1 : 0;
-        if (regular) q.wcount[g] = nzc;
-    }
+    double2* P = reinterpret_cast<double2*>(q.P + (size_t)g * q.npad) + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < kSbpRowPairs; ++k)
+        if (k * kSbpThreads + (int)threadIdx.x < np2) P[(size_t)k * kSbpThreads] = acc[k];
+    (void)gamma; (void)pen; (void)vv; (void)nk;
 }
 
 // Regular iterations only: the non-zero lists of the blocks, ascending, from the counts the step left per workgroup.
@@ -198,9 +298,9 @@ sbp_list_kernel(SbpParams q, int par) {
     const SbpCtl c = load_ctl_vector(q.ctl + par);                  // written by this iteration's step
     if (c.done) return;
     const int g = blockIdx.x;
-    const int b = q.wg_block[g], sub = q.wg_sub[g];
-    const int g0 = q.blk_g0[b], Gb = q.blk_g0[b + 1] - g0;
-    const int c0 = q.blk_c0[b], pb = q.blk_c0[b + 1] - c0;
+    const int Gb = q.Gb, b = g / Gb, sub = g - b * Gb, g0 = b * Gb;
+    const SbpBlk bi = load_ctl_vector(q.blk + b);
+    const int c0 = bi.c0, pb = bi.pb;
     const int per = (pb + Gb - 1) / Gb;
     const int lo = sub * per, hi = min(pb, lo + per);
     int off = 0;
@@ -222,34 +322,100 @@ sbp_list_kernel(SbpParams q, int par) {
         __syncthreads();
         int woff = 0;
         for (int w = 0; w < wid; ++w) woff += sh[w];
-        if (nz) q.list[c0 + base + woff + before] = e;
+        if (nz) { q.list[c0 + base + woff + before] = e; q.xl[c0 + base + woff + before] = q.x[c0 + e]; }
         base += sh[0] + sh[1] + sh[2] + sh[3];
     }
     if (sub == Gb - 1 && threadIdx.x == 0) q.cnt[b] = base;
 }
 
-// tail_a: one thread per row.  A_i x_i of every local block from the workgroup partials (ascending), what changed, the sums.
-__global__ void __launch_bounds__(64)
-sbp_tail_a_kernel(SbpParams q, int par) {
-    const SbpCtl c = load_ctl_vector(q.ctl + par);
-    if (c.done) return;
-    const int row = blockIdx.x * 64 + threadIdx.x;                   // < npad (npad is a multiple of 64)
-    double S = 0.0, sax = 0.0, qq = 0.0;
-    for (int b = 0; b < q.NL; ++b) {
-        double a = 0.0;
-        const int g1 = q.blk_g0[b + 1];
-        for (int g = q.blk_g0[b]; g < g1; ++g)
-            if (q.pnz[g]) a += q.P[(size_t)g * q.npad + row];        // uniform
-        double* ao = q.Axo + (size_t)b * q.npad + row;
-        const double d = a - *ao;
-        *ao = a;
-        S += a;
-        sax = fma(a, a, sax);
-        qq = fma(d, d, qq);
+// Every iteration, last launch(es): A_i x_i of every local block = the sum of the workgroup partials the x-update launch left
+// (the first ceil(list length / share) workgroups of the block wrote one) -- 64 rows per workgroup, eight waves; blocks are
+// taken eight at a time, their list lengths requested together and then wave w's partials w, w + 8, ... of ALL eight blocks
+// (ascending within a block): two dependent round trips per eight blocks.  Wave t then adds the eight waves' sums of block t in
+// wave order and books what changed; wave 0 adds the blocks in order: S = sum_i A_i x_i of the local blocks and the two sums.
+// FUSE_B (one process): the r / y / v update and the norm partials of tail_b in the same launch.
+constexpr int kSbpTailWaves = 8;
+constexpr int kSbpTailBlocks = 8;
+template <bool FUSE_B>
+__global__ void __launch_bounds__(64 * kSbpTailWaves)
+sbp_tail_kernel(SbpParams q, int par) {
+    __shared__ double sh[kSbpTailBlocks][kSbpTailWaves][64];        // 32 KB
+    __shared__ double shS[kSbpTailBlocks][3][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int row = blockIdx.x * 64 + lane;                         // < npad (npad is a multiple of 128)
+    const int Gb = q.Gb;
+    int nact0[kSbpTailBlocks];
+#pragma unroll
+    for (int t = 0; t < kSbpTailBlocks; ++t) {                      // requested before the control block arrives
+        const int total = t < q.NL ? load_flag_vector(q.cnt + t) : 0;
+        const int per = sbp_share(total, Gb, q.min_share);
+        nact0[t] = min(Gb, (total + per - 1) / per);
     }
-    q.S[row] = S;
+    const SbpCtl c = load_ctl_vector(q.ctl + par);                  // written by this iteration's first launch
+    if (c.done) return;
+    double S = 0.0, sax = 0.0, qq = 0.0;                            // wave 0 only
+    for (int b0 = 0; b0 < q.NL; b0 += kSbpTailBlocks) {
+        const int nb = min(kSbpTailBlocks, q.NL - b0);
+        double a[kSbpTailBlocks];
+#pragma unroll
+        for (int t = 0; t < kSbpTailBlocks; ++t) {
+            a[t] = 0.0;
+            if (t >= nb) continue;
+            int nact = nact0[t];
+            if (b0 > 0) {
+                const int total = load_flag_vector(q.cnt + b0 + t);
+                const int per = sbp_share(total, Gb, q.min_share);
+                nact = min(Gb, (total + per - 1) / per);
+            }
+            const double* P = q.P + (size_t)(b0 + t) * Gb * q.npad + row;
+            for (int g0 = grp; g0 < nact; g0 += 8 * kSbpTailWaves) {       // predicated, not counted: all eight requests leave together
+                double pv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int g = g0 + u * kSbpTailWaves; pv[u] = g < nact ? P[(size_t)g * q.npad] : 0.0; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a[t] += pv[u];
+            }
+        }
+        __syncthreads();                                            // (the previous chunk's readers are done)
+#pragma unroll
+        for (int t = 0; t < kSbpTailBlocks; ++t) sh[t][grp][lane] = a[t];
+        __syncthreads();
+        if (grp < nb) {                                             // wave t finishes block b0 + t
+            double v = sh[grp][0][lane];
+#pragma unroll
+            for (int w = 1; w < kSbpTailWaves; ++w) v += sh[grp][w][lane];
+            double* ao = q.Axo + (size_t)(b0 + grp) * q.npad + row;
+            const double d = v - *ao;
+            *ao = v;
+            shS[grp][0][lane] = v; shS[grp][1][lane] = v * v; shS[grp][2][lane] = d * d;
+        }
+        __syncthreads();
+        if (grp == 0)
+            for (int t = 0; t < nb; ++t) { S += shS[t][0][lane]; sax += shS[t][1][lane]; qq += shS[t][2][lane]; }
+    }
+    if (grp != 0) return;
     sax = wave_sum(sax); qq = wave_sum(qq);
-    if (threadIdx.x == 0) { q.Qa[blockIdx.x * 2] = sax; q.Qa[blockIdx.x * 2 + 1] = qq; }
+    if (lane == 0) { q.Qa[blockIdx.x * 2] = sax; q.Qa[blockIdx.x * 2 + 1] = qq; }
+    if (!FUSE_B) { q.S[row] = S; return; }
+    double drdS, dr2, r2, y2, abar_r;
+    {
+#pragma clang fp contract(off)
+        const double dS = S - q.Sold[row];
+        q.Sold[row] = S;
+        const double abar = S / q.dN;
+        const double rn = abar - q.zbar[row];
+        const double dr = rn - q.r[row];
+        q.r[row] = rn;
+        const double yn = q.y[row] + q.rho * rn;
+        q.y[row] = yn;
+        q.v[row] = yn / q.rho + rn;
+        drdS = dr * dS; dr2 = dr * dr; r2 = rn * rn; y2 = yn * yn; abar_r = abar * rn;
+    }
+    drdS = wave_sum(drdS); dr2 = wave_sum(dr2); r2 = wave_sum(r2); y2 = wave_sum(y2); abar_r = wave_sum(abar_r);
+    if (lane == 0) {
+        double* Q = q.Q + (size_t)blockIdx.x * 8;
+        Q[0] = drdS; Q[1] = dr2; Q[2] = r2; Q[3] = y2; Q[4] = abar_r;
+    }
 }
 
 // tail_b: r, y, v and the norm partials, from S summed over ALL blocks (all-reduced between the two tails when the blocks
@@ -378,15 +544,16 @@ static double sbp_sprad(const double* Ab, long long lda, int n, int pb, hipStrea
     return theta;                                                   // n steps: exact up to rounding
 }
 
+static int env_int(const char* name, int dflt) {
+    const char* e = std::getenv(name);
+    const int v = e ? std::atoi(e) : 0;
+    return v > 0 ? v : dflt;
+}
+
 static int sbp_batch() {
     const char* e = std::getenv("ADMM_HIP_BATCH_ITERS");
     const int v = e ? std::atoi(e) : 0;
     return v > 0 ? (v + 1) / 2 * 2 : 20;                            // even: the parity pattern of the control block
-}
-
-template <int RPT>
-static void sbp_launch_step(const SbpParams& q, int par, hipStream_t st) {
-    hipLaunchKernelGGL((sbp_step_kernel<RPT>), dim3(q.G), dim3(kSbpThreads), 0, st, q, par);
 }
 
 // d: this rank's columns (n x pl).  nblocks: N (global); blk_first / nloc: the global blocks this rank holds; p_total.
@@ -443,7 +610,7 @@ void solve_parbp(const DeviceData<double>& d, const admm_opts& opts, int nblocks
     S.rho = rho; S.eig_est = avg; S.t_eigs = now_s() - t0;
 
     // ---- layout
-    const int npad = (int)round_up(n, 64);
+    const int npad = (int)round_up(n, 128);                      // 16-byte loads of the regular launch: 128 rows per wave instruction
     ADMM_REQUIRE(d.ldx >= npad || d.ldx >= n, "internal: leading dimension");
     // rows beyond n must read as zero: DeviceData pads to 32 rows, the kernels to 64 -> own copy when the paddings differ
     DevBuf<double> Aown;
@@ -458,30 +625,28 @@ void solve_parbp(const DeviceData<double>& d, const admm_opts& opts, int nblocks
     }
     int ncu = 256;
     { hipDeviceProp_t prop; int dev = 0; ADMM_HIP_CHECK(hipGetDevice(&dev)); ADMM_HIP_CHECK(hipGetDeviceProperties(&prop, dev)); ncu = prop.multiProcessorCount; }
-    const int Gwant = std::max(NL, std::min(2 * ncu, pl));
-    std::vector<int> wg_block, wg_sub, blk_g0(NL + 1, 0);
-    for (int b = 0; b < NL; ++b) {
-        const int pb = c0[b + 1] - c0[b];
-        int Gb = (int)std::max<long long>(1, (long long)Gwant * pb / pl);
-        Gb = std::min(Gb, pb);
-        blk_g0[b + 1] = blk_g0[b] + Gb;
-        for (int k = 0; k < Gb; ++k) { wg_block.push_back(b); wg_sub.push_back(k); }
-    }
-    const int G = blk_g0[NL];
+    // workgroups per block: the same for every local block (block = g / Gb), about two per CU in all, never more than a block has columns
+    int Gb = std::max(1, env_int("ADMM_HIP_SBP_WGS", 2 * ncu) / NL);
+    for (int b = 0; b < NL; ++b) Gb = std::min(Gb, c0[b + 1] - c0[b]);
+    const int G = Gb * NL;
     const int nT = npad / 64;
-    std::vector<double> bg(NL), bp(NL);
-    for (int b = 0; b < NL; ++b) { bg[b] = 2.0 * rho + sprad[b_first + b]; bp[b] = 1.0 / (rho * bg[b]); }
+    std::vector<SbpBlk> hblk(NL);
+    for (int b = 0; b < NL; ++b) {
+        hblk[b].c0 = c0[b]; hblk[b].pb = c0[b + 1] - c0[b];
+        hblk[b].gamma = 2.0 * rho + sprad[b_first + b];
+        hblk[b].pen = 1.0 / (rho * hblk[b].gamma);
+        hblk[b].pad = 0;
+    }
 
-    DevBuf<int> d_wg_block(G), d_wg_sub(G), d_blk_g0(NL + 1), d_blk_c0(NL + 1), d_list(pl), d_cnt(NL), d_wcount(G), d_pnz(G), d_done(1);
-    DevBuf<double> d_bg(NL), d_bp(NL), x(pl), P((size_t)G * npad), Axo((size_t)NL * npad), ex((size_t)npad + 2 * nT), Sold(npad), y(npad), r(npad), v(npad),
+    DevBuf<int> d_list(pl), d_cnt(std::max(NL, 8)), d_wcount(G), d_done(1);
+    DevBuf<SbpBlk> d_blk(NL);
+    DevBuf<double> x(pl), xl(pl), P((size_t)G * npad), Axo((size_t)NL * npad), ex((size_t)npad + 2 * nT), Sold(npad), y(npad), r(npad), v(npad),
         zbar(npad), Q((size_t)nT * 8), trace;
     DevBuf<SbpCtl> ctl(2);
     auto h2d = [&](void* dst, const void* src, size_t bytes) { ADMM_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st)); };
-    h2d(d_wg_block.get(), wg_block.data(), (size_t)G * sizeof(int)); h2d(d_wg_sub.get(), wg_sub.data(), (size_t)G * sizeof(int));
-    h2d(d_blk_g0.get(), blk_g0.data(), (size_t)(NL + 1) * sizeof(int)); h2d(d_blk_c0.get(), c0.data(), (size_t)(NL + 1) * sizeof(int));
-    h2d(d_bg.get(), bg.data(), (size_t)NL * sizeof(double)); h2d(d_bp.get(), bp.data(), (size_t)NL * sizeof(double));
-    x.zero(st); P.zero(st); Axo.zero(st); ex.zero(st); Sold.zero(st); y.zero(st); r.zero(st); v.zero(st); zbar.zero(st); Q.zero(st);
-    d_list.zero(st); d_cnt.zero(st); d_wcount.zero(st); d_pnz.zero(st); d_done.zero(st);
+    h2d(d_blk.get(), hblk.data(), (size_t)NL * sizeof(SbpBlk));
+    x.zero(st); xl.zero(st); Axo.zero(st); ex.zero(st); Sold.zero(st); y.zero(st); r.zero(st); v.zero(st); zbar.zero(st); Q.zero(st);
+    d_list.zero(st); d_cnt.zero(st); d_wcount.zero(st); d_done.zero(st);
     {
         std::vector<double> hz(n), hy(n);
         ADMM_HIP_CHECK(hipMemcpyAsync(hy.data(), d.Y.get(), (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -497,36 +662,38 @@ void solve_parbp(const DeviceData<double>& d, const admm_opts& opts, int nblocks
     PinnedFlag hflag;
 
     SbpParams q{};
+    q.min_share = std::max(1, env_int("ADMM_HIP_SBP_SHARE", 4));
     q.n = n; q.npad = npad; q.N = N; q.NL = NL; q.maxit = opts.maxit; q.G = G; q.nT = nT;
     q.eps_abs = opts.eps_abs; q.eps_rel = opts.eps_rel; q.rho = rho;
     q.sqrt_nN = std::sqrt((double)n * (double)N); q.sqrtN = std::sqrt((double)N); q.dN = (double)N;
     q.A = A; q.lda = lda;
-    q.wg_block = d_wg_block.get(); q.wg_sub = d_wg_sub.get(); q.blk_g0 = d_blk_g0.get(); q.blk_c0 = d_blk_c0.get();
-    q.blk_gamma = d_bg.get(); q.blk_pen = d_bp.get();
-    q.x = x.get(); q.list = d_list.get(); q.cnt = d_cnt.get(); q.wcount = d_wcount.get(); q.pnz = d_pnz.get();
-    q.P = P.get(); q.Axo = Axo.get(); q.S = ex.get(); q.Qa = ex.get() + npad;
+    q.Gb = Gb; q.blk = d_blk.get();
+    q.x = x.get(); q.list = d_list.get(); q.cnt = d_cnt.get(); q.wcount = d_wcount.get();
+    q.xl = xl.get(); q.P = P.get(); q.Axo = Axo.get(); q.S = ex.get(); q.Qa = ex.get() + npad;
     q.Sold = Sold.get(); q.y = y.get(); q.r = r.get(); q.v = v.get(); q.zbar = zbar.get(); q.Q = Q.get();
     q.ctl = ctl.get(); q.done = d_done.get(); q.hflag = dist ? nullptr : hflag.p;
     q.trace = res.trace_cap > 0 ? trace.get() : nullptr; q.trace_cap = res.trace_cap;
 
-    const int rpt = (npad + kSbpThreads - 1) / kSbpThreads;
-    auto step = [&](int par) {
-        if (rpt <= 1) sbp_launch_step<1>(q, par, st);
-        else if (rpt <= 2) sbp_launch_step<2>(q, par, st);
-        else if (rpt <= 4) sbp_launch_step<4>(q, par, st);
-        else if (rpt <= 8) sbp_launch_step<8>(q, par, st);
-        else if (rpt <= 16) sbp_launch_step<16>(q, par, st);
-        else sbp_launch_step<32>(q, par, st);
-    };
+    const bool nt = (double)lda * (double)pl * 8.0 > 220e6;       // as gemv_plan.h: beyond what the 256 MB Infinity Cache keeps
     ADMM_HIP_CHECK(hipStreamSynchronize(st));
     LoopTimes lt = run_until_done(st, d_done.get(), sbp_batch(), (long long)opts.maxit + 2,
         [&](long long g) {
             const int par = (int)(g & 1);
-            step(par);
-            if (g % 10 == 0) hipLaunchKernelGGL(sbp_list_kernel, dim3(G), dim3(kSbpThreads), 0, st, q, par ^ 1);
-            hipLaunchKernelGGL(sbp_tail_a_kernel, dim3(nT), dim3(64), 0, st, q, par ^ 1);
-            if (dist) allreduce_sum_f64(ex.get(), (size_t)npad + 2 * nT, st);
-            hipLaunchKernelGGL(sbp_tail_b_kernel, dim3(nT), dim3(64), 0, st, q, par ^ 1);
+            if (g % 10 == 0) {                                       // regular iteration (the counter IS the enqueue index until `done`)
+                if (nt) hipLaunchKernelGGL((sbp_xreg_kernel<true>), dim3(G), dim3(kSbpThreads), (size_t)npad * sizeof(double), st, q, par);
+                else hipLaunchKernelGGL((sbp_xreg_kernel<false>), dim3(G), dim3(kSbpThreads), (size_t)npad * sizeof(double), st, q, par);
+                hipLaunchKernelGGL(sbp_list_kernel, dim3(G), dim3(kSbpThreads), 0, st, q, par ^ 1);
+                hipLaunchKernelGGL((sbp_xact_kernel<true>), dim3(G), dim3(kSbpThreads), 0, st, q, par ^ 1);
+            } else {
+                hipLaunchKernelGGL((sbp_xact_kernel<false>), dim3(G), dim3(kSbpThreads), (size_t)npad * sizeof(double), st, q, par);
+            }
+            if (dist) {
+                hipLaunchKernelGGL((sbp_tail_kernel<false>), dim3(nT), dim3(64 * kSbpTailWaves), 0, st, q, par ^ 1);
+                allreduce_sum_f64(ex.get(), (size_t)npad + 2 * nT, st);
+                hipLaunchKernelGGL(sbp_tail_b_kernel, dim3(nT), dim3(64), 0, st, q, par ^ 1);
+            } else {
+                hipLaunchKernelGGL((sbp_tail_kernel<true>), dim3(nT), dim3(64 * kSbpTailWaves), 0, st, q, par ^ 1);
+            }
         }, dist ? nullptr : hflag.p);
     SbpCtl hc[2];
     ADMM_HIP_CHECK(hipMemcpy(hc, ctl.get(), sizeof(hc), hipMemcpyDeviceToHost));

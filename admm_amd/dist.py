@@ -220,6 +220,35 @@ def lasso_dist_cols(x_cols, y, p_total, col_offset, lam=None, nlambda=100, lambd
     return ADMM_Lasso_fit(lam_out, beta, niter, stats.as_dict())
 
 
+def parbp_partition(p_total, nthread, nranks, rank):
+    """Columns [lo, hi) of rank `rank` for admm_hip_parbp_dist: whole blocks of PADMMBP's partition (nthread - 1 blocks of
+    p div nthread columns, the last takes the remainder; PADMMBP.h:150-167), nthread / nranks consecutive blocks per rank."""
+    if nthread % nranks:
+        raise ValueError("nthread must be a multiple of the number of ranks")
+    chunk = p_total // nthread
+    per = nthread // nranks
+    lo = rank * per * chunk
+    hi = p_total if rank == nranks - 1 else (rank + 1) * per * chunk
+    return lo, hi
+
+
+def parbp_dist(x_cols, y, p_total, col_offset, nthread, maxit=10000, eps_abs=1e-4, eps_rel=1e-4, rho=1.0):
+    """Column-block sharing basis pursuit (admm_hip_parbp_dist) with the blocks spread over the ranks: every rank calls this with
+    its columns (n x p_local, whole blocks -- parbp_partition) and the full y; returns (this rank's coefficients, niter, stats)."""
+    lib = _lib.load()
+    xp, xmem, xk = as_input(x_cols)
+    yp, ymem, yk = as_input(y)
+    n, p_local = np.asarray(x_cols).shape
+    o = AdmmOpts(int(maxit), float(eps_abs), float(eps_rel), float(rho))
+    beta = np.zeros(p_local)
+    niter = np.zeros(1, dtype=np.int32)
+    stats = AdmmStats()
+    check(lib.admm_hip_parbp_dist(xp, yp, int(n), int(p_local), int(p_total), int(col_offset), xmem, int(nthread), ctypes.byref(o),
+                                  beta.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), niter.ctypes.data_as(ctypes.POINTER(ctypes.c_int)),
+                                  ctypes.byref(stats)))
+    return beta, int(niter[0]), stats.as_dict()
+
+
 class DistColsPlan:
     """Prepared column-sharded wide problem (admm_hip_lasso_plan_create_dist_cols): setup once, run the path repeatedly."""
 

@@ -1,6 +1,6 @@
 // Rcpp shim that a maintainer of yixuan/ADMM adds to src/ in place of Lasso.cpp, Enet.cpp, ParLasso.cpp,
 // LAD.cpp and BP.cpp.  It keeps the five `.Call` symbols the R code looks up by name
-// (R/30_admm_lasso.R:140,149; R/40_admm_enet.R:53; R/20_admm_lad.R:60; R/10_admm_bp.R:104) and forwards the
+// (R/30_admm_lasso.R:140,149; R/40_admm_enet.R:53; R/20_admm_lad.R:60; R/10_admm_bp.R:104,111) and forwards the
 // unpacked arguments to libadmm_hip.so (include/admm_hip.h).  R/ stays untouched.
 //
 // src/Makevars:   PKG_CPPFLAGS = -I/path/to/admm-mi355x/include
@@ -109,6 +109,36 @@ BEGIN_RCPP
 END_RCPP
 }
 
+// Shared by admm_bp and admm_parbp: the p x 1 dgCMatrix of the non-zeros (BP.cpp:38-43, ParBP.cppp:58-61)
+static Rcpp::S4 sparse_column(const std::vector<double>& b) {
+    const int p = (int)b.size();
+    std::vector<int> ii; std::vector<double> xx;
+    for (int i = 0; i < p; ++i) if (b[i] != 0.0) { ii.push_back(i); xx.push_back(b[i]); }
+    Rcpp::S4 m("dgCMatrix");
+    m.slot("i") = IntegerVector(ii.begin(), ii.end());
+    m.slot("p") = IntegerVector::create(0, (int)ii.size());
+    m.slot("x") = NumericVector(xx.begin(), xx.end());
+    m.slot("Dim") = IntegerVector::create(p, 1);
+    return m;
+}
+
+// The symbol R/10_admm_bp.R:111 asks for and the reference never builds (src/TODO/ParBP.cppp:26-71): opts carries rho_ratio.
+RcppExport SEXP admm_parbp(SEXP x_, SEXP y_, SEXP nthread_, SEXP opts_) {
+BEGIN_RCPP
+    NumericMatrix x(x_);
+    NumericVector y(y_);
+    List opts(opts_);
+    admm_opts o;
+    o.maxit = as<int>(opts["maxit"]); o.eps_abs = as<double>(opts["eps_abs"]); o.eps_rel = as<double>(opts["eps_rel"]);
+    o.rho = as<double>(opts["rho_ratio"]);
+    const int p = x.ncol();
+    std::vector<double> b(p);
+    int niter = 0;
+    check(admm_hip_parbp(x.begin(), y.begin(), x.nrow(), p, ADMM_MEM_HOST, as<int>(nthread_), &o, b.data(), &niter, nullptr));
+    return List::create(Named("beta") = sparse_column(b), Named("niter") = niter);
+END_RCPP
+}
+
 RcppExport SEXP admm_bp(SEXP x_, SEXP y_, SEXP opts_) {
 BEGIN_RCPP
     NumericMatrix x(x_);
@@ -118,15 +148,6 @@ BEGIN_RCPP
     std::vector<double> b(p);
     int niter = 0;
     check(admm_hip_bp(x.begin(), y.begin(), x.nrow(), p, ADMM_MEM_HOST, &o, b.data(), &niter, nullptr));
-    std::vector<float> bf(b.begin(), b.end());
-    // BP.cpp:38-43 returns a p x 1 dgCMatrix of the non-zeros
-    std::vector<int> ii; std::vector<double> xx;
-    for (int i = 0; i < p; ++i) if (b[i] != 0.0) { ii.push_back(i); xx.push_back(b[i]); }
-    Rcpp::S4 m("dgCMatrix");
-    m.slot("i") = IntegerVector(ii.begin(), ii.end());
-    m.slot("p") = IntegerVector::create(0, (int)ii.size());
-    m.slot("x") = NumericVector(xx.begin(), xx.end());
-    m.slot("Dim") = IntegerVector::create(p, 1);
-    return List::create(Named("beta") = m, Named("niter") = niter);
+    return List::create(Named("beta") = sparse_column(b), Named("niter") = niter);
 END_RCPP
 }

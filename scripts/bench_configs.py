@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Measure the non-headline BASELINE.json configs (C3 wide, C4 consensus on one GPU, C5 LAD / BP) on
 device-resident synthetic data: iterations, loop seconds, iterations/s and achieved algorithmic GB/s
-(SURVEY.md section 8d byte counts).  Prints one JSON line per config.  Usage: bench_configs.py [c3 c4 c5lad c5bp]"""
+(SURVEY.md section 8d byte counts).  Prints one JSON line per config.  Usage: bench_configs.py [c3 c4 c5lad c5bp c5parbp]"""
 import json
 import os
 import sys
@@ -85,3 +85,16 @@ if "c5bp" in which:     # BP n=5000 p=50000 fp64, 500 non-zeros, exact y
     beta = np.asarray(fit.beta.todense()).ravel()
     err = beta - b.cpu().numpy()
     report("C5 admm_bp n=5000 p=50000 fp64", fit, 16.0 * n * p, {"recovery_error_range": [float(err.min()), float(err.max())]})
+if "c5parbp" in which:  # the same problem by the column-block sharing solver (admm_bp$parallel(8): admm_hip_parbp), 8 blocks on ONE GPU
+    n, p = 5000, 50000
+    xt, y, b = gen(n, p, 1.0, 500, noise=False)
+    for nb in (8,):
+        fit = admm_bp(DevicePtr(xt.data_ptr()), DevicePtr(y.data_ptr()), n=n, p=p).parallel(nb).fit()
+        beta = np.asarray(fit.beta.todense()).ravel()
+        err = beta - b.cpu().numpy()
+        it = int(fit.stats["total_iter"])
+        # algorithmic bytes: a regular iteration (every 10th) reads the whole matrix once, 8np; an active-set iteration the non-zero columns twice
+        reg = (it + 9) // 10
+        report(f"C5 admm_bp$parallel({nb}) n=5000 p=50000 fp64 (sharing ADMM)", fit, 8.0 * n * p * reg / max(it, 1),
+               {"recovery_error_range": [float(err.min()), float(err.max())], "regular_iterations": reg, "nnz": int(np.count_nonzero(beta)),
+                "lanczos_steps": int(fit.stats["xupdate_samples"]), "rho": fit.stats["rho"]})

@@ -57,6 +57,12 @@ def problem(case):
     if case == "multi":               # three responses of one design matrix dealt out to the ranks (response j on rank j mod nranks)
         x, y = synth_lasso(400, 50, 8, seed=78)
         return x, y, -3, dict(nlambda=7)
+    if case == "parbp":               # column-block sharing basis pursuit, 4 blocks over 2 ranks (the last block takes the remainder)
+        rng = np.random.default_rng(81)
+        n, p = 200, 803
+        x = np.asfortranarray(rng.standard_normal((n, p)))
+        b = np.zeros(p); b[rng.choice(p, 18, replace=False)] = rng.standard_normal(18) * 2
+        return x, x @ b, -4, dict(nthread=4)
     raise SystemExit("unknown case " + case)
 
 
@@ -93,6 +99,15 @@ def main():
     # ---- the distributed consensus solver on this rank's row slice
     x, y, K, kw = problem(case)
     n, p = x.shape
+    if K == -4:
+        lo, hi = adist.parbp_partition(p, kw["nthread"], nranks, rank)
+        beta, niter, st = adist.parbp_dist(np.asfortranarray(x[:, lo:hi]), y, p, lo, kw["nthread"])
+        np.savez(os.path.join(workdir, f"result.{rank}.npz"), beta=beta, niter=np.array([niter]), lo=np.array([lo, hi]), rho=np.array([st["rho"]]),
+                 exchange_variant=int(st["exchange_variant"]))
+        barrier(workdir, "end", rank, nranks)
+        adist.finalize_comm()
+        print("rank", rank, "ok", flush=True)
+        return
     if K == -3:
         import admm_amd
         rng = np.random.default_rng(9)

@@ -391,3 +391,97 @@ def test_two_rank_replica_dealing_and_final_exchange(tmp_path):
     for r in range(2):
         got = np.load(out + f".{r}.npz")
         assert np.array_equal(got["mse"], ref_mse) and np.array_equal(got["nit"], ref_nit)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Column-block sharing basis pursuit (admm_hip_parbp_dist, sharing_bp.hip): world_size-2 model of its exchange -- the blocks of
+# PADMMBP's partition dealt out to the ranks (admm_amd.dist.parbp_partition), the spectral radii gathered through a sum of
+# one-hot vectors, and per iteration ONE sum all-reduce of [S = sum_i A_i x_i (n), sum ||A_i x_i||^2, sum ||A_i dx_i||^2]
+# between the block sums and the replicated r / y / decision step.  Every rank runs the oracle's own worker arithmetic on
+# its blocks; the joint result must be the serial oracle's.
+def _parbp_rank_main(rank, world, port, A, b, N, out_path):
+    from admm_amd.dist import parbp_partition
+    from oracle.solvers import SharingBP
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n, p = A.shape
+    lo, hi = parbp_partition(p, N, world, rank)
+    chunk, per = p // N, N // world
+    b_first = rank * per
+    ser = SharingBP(A, b, N, 1e-4, 1e-4)                       # only its partition / block views are used below
+    mine = list(range(b_first, b_first + per))
+    assert ser.off[mine[0]] == lo and ser.off[mine[-1] + 1] == hi
+    sprad = np.zeros(N)
+    for i in mine:
+        sprad[i] = ser.sprad[i]
+    sprad = _allreduce(sprad)
+    rho = 1.0 / float(np.mean(sprad))
+    x = {i: np.zeros(ser.A[i].shape[1]) for i in mine}
+    Ax = {i: np.zeros(n) for i in mine}
+    y, r, S = np.zeros(n), np.zeros(n), np.zeros(n)
+    zbar = b / N
+    sax = abar_r = 0.0
+    niter = 10001
+    for it in range(10000):
+        r2, y2 = float(r @ r), float(y @ y)
+        sz = sax - 2.0 * N * abar_r + N * r2
+        eps_p = 1e-4 * np.sqrt(max(sax, sz, 0.0)) + np.sqrt(float(n * N)) * 1e-4
+        eps_d = 1e-4 * np.sqrt(float(N)) * np.sqrt(y2) + np.sqrt(float(n * N)) * 1e-4
+        v = y / rho + r
+        payload = np.zeros(n + 2)
+        for i in mine:
+            Ai = ser.A[i]
+            gamma = 2.0 * rho + sprad[i]
+            pen = 1.0 / (rho * gamma)
+            xi = x[i]
+            if it % 10 == 0:
+                vec = xi - (Ai.T @ v) / gamma
+                xi = np.sign(vec) * np.maximum(np.abs(vec) - pen, 0.0)
+            else:
+                nz = np.nonzero(xi)[0]
+                xn = np.zeros_like(xi)
+                if nz.size:
+                    val = xi[nz] - (Ai[:, nz].T @ v) / gamma
+                    xn[nz] = np.sign(val) * np.maximum(np.abs(val) - pen, 0.0)
+                xi = xn
+            x[i] = xi
+            nz = np.nonzero(xi)[0]
+            new = Ai[:, nz] @ xi[nz] if nz.size else np.zeros(n)
+            d = new - Ax[i]
+            Ax[i] = new
+            payload[:n] += new
+            payload[n] += float(new @ new)
+            payload[n + 1] += float(d @ d)
+        payload = _allreduce(payload)                           # THE exchange of the iteration
+        Snew, sax, q = payload[:n], float(payload[n]), float(payload[n + 1])
+        rnew = Snew / N - zbar
+        dr, dS = rnew - r, Snew - S
+        sd = q - 2.0 * float(dr @ dS) + N * float(dr @ dr)
+        S, r = Snew, rnew
+        y = y + rho * rnew
+        abar_r = float((Snew / N) @ rnew)
+        if np.sqrt(N * float(rnew @ rnew)) < eps_p and rho * np.sqrt(max(sd, 0.0)) < eps_d:
+            niter = it + 1
+            break
+    np.savez(out_path + f".{rank}.npz", beta=np.concatenate([x[i] for i in mine]), niter=np.array([niter]), lo=np.array([lo, hi]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_column_block_sharing_bp_protocol_matches_serial_oracle(tmp_path):
+    from oracle import entry
+    rng = np.random.default_rng(91)
+    n, p, N = 60, 243, 4                                        # 3 blocks of 60 + one of 63
+    A = rng.standard_normal((n, p))
+    b0 = np.zeros(p)
+    b0[rng.choice(p, 9, replace=False)] = rng.standard_normal(9) * 2
+    b = A @ b0
+    out = str(tmp_path / "parbp")
+    mp.spawn(_parbp_rank_main, args=(2, _free_port(), A, b, N, out), nprocs=2, join=True)
+    r0, r1 = np.load(out + ".0.npz"), np.load(out + ".1.npz")
+    assert list(r0["lo"]) == [0, 120] and list(r1["lo"]) == [120, 243]
+    ref = entry.admm_parbp(A, b, N, dict(entry.BP_OPTS, rho_ratio=1.0))
+    assert r0["niter"][0] == r1["niter"][0] == ref["niter"]      # double arithmetic: the two-piece sum of S moves nothing visible
+    beta = np.concatenate([r0["beta"], r1["beta"]])
+    assert np.abs(beta - ref["beta"]).max() < 1e-12 and np.abs(beta - b0).max() < 5e-3
