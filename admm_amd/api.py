@@ -69,7 +69,7 @@ class ADMM_Lasso_fit:
         return self._beta
 
     def __repr__(self):
-        return (f"ADMM Lasso fitting result\n\n$lambda\n{self.lambda_}\n\n$beta\n<{self.beta.shape[0]} x "
+        return (f"{getattr(self, '_title', 'ADMM Lasso fitting result')}\n\n$lambda\n{self.lambda_}\n\n$beta\n<{self.beta.shape[0]} x "
                 f"{self.beta.shape[1]}> sparse matrix\n\n$niter\n{self.niter}")
 
     def show(self):
@@ -525,17 +525,28 @@ def admm_bp(x, y, **kw):
 class ADMM_Dantzig(ADMM_Lasso):
     """`admm_dantzig` is exported by the reference (NAMESPACE:13, R/50_admm_dantzig.R) but its `.Call("admm_dantzig", ...)`
     names a symbol the package never builds: the solver lives in src/TODO/ (Dantzig.cpp, ADMMDantzig.h, written against an
-    older ADMMBase with B_mult / c_norm) and is not compiled, so `$fit()` fails in R.  Mirrored: the builder chain works
-    (it is ADMM_Lasso's), fit() fails like the reference does.  No solver is invented for it."""
+    older ADMMBase) and is not compiled, so `$fit()` fails in R.  Here fit() runs that algorithm restated on the current
+    ADMMBase::solve (admm_hip_dantzig; admm_amd/csrc/dantzig.hip, oracle/solvers.py Dantzig) -- double precision like its
+    `typedef double Scalar`.  It converges on comfortably tall problems (n >= 5 p) and, as the restated algorithm itself, not for
+    p > n (tests/test_oracle_dantzig.py): niter = maxit + 1 marks such a lambda.  The builder chain is ADMM_Lasso's
+    (R/50_admm_dantzig.R:2 `contains = "ADMM_Lasso"`): $parallel stores nthread as there and, as there, $fit ignores it."""
     _name = "ADMM Dantzig Selector model"
 
-    _missing = 'C symbol name "admm_dantzig" not in DLL for package "ADMM"'    # R/50_admm_dantzig.R:38-46: the reference's own failure
+    _missing = "not available for the Dantzig selector (the reference has no such entry point)"
 
-    def fit(self):
-        _stop(self._missing)
+    def fit(self, trace=False):
+        lib, head, tail, lam_out, _, niter, stats, keep = self._common()
+        beta = np.zeros((self.p + 1, lam_out.size), dtype=np.float64, order="F")
+        tr, ntr = _trace_buffers(self.maxit * lam_out.size + 2 * lam_out.size if trace else 0)
+        check(lib.admm_hip_dantzig_traced(*head, tail[0], tail[1], beta.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), tail[3], tail[4],
+                                          *_trace_args(tr, ntr)))
+        fit = ADMM_Lasso_fit(lam_out, beta, niter, stats.as_dict())
+        fit._title = "ADMM Dantzig Selector fitting result"                     # ADMM_Dantzig_fit$show, R/50_admm_dantzig.R:52-58
+        fit.trace = tr[:ntr.value].copy() if trace else None
+        return fit
 
-    # the extensions of this build that ride on ADMM_Lasso (cross-validation, several responses, prepared problems) must
-    # not run a plain Lasso under a Dantzig label
+    # the extensions of this build that ride on ADMM_Lasso (cross-validation, several responses, prepared problems, row blocks)
+    # must not run a plain Lasso under a Dantzig label
     def cv(self, *a, **kw):
         _stop(self._missing)
 

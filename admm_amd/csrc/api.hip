@@ -549,6 +549,49 @@ int admm_hip_bp_traced(const double* x, const double* y, int n, int p, int mem, 
     });
 }
 
+// admm_dantzig (R/50_admm_dantzig.R:30-46; TODO/Dantzig.cpp:32-99)
+int admm_hip_dantzig_traced(const double* x, const double* y, int n, int p, int mem,
+                            const double* lambda_in, int nlambda_in, int nlambda_auto, double lmin_ratio,
+                            int standardize, int intercept, const admm_opts* opts,
+                            double* lambda_out, double* beta_out, int* niter_out, admm_stats* stats,
+                            double* trace_out, long long trace_cap, long long* ntrace_out) {
+    return guarded([&] {
+        ADMM_REQUIRE(trace_cap == 0 || (trace_out != nullptr && ntrace_out != nullptr && trace_cap > 0), "bad trace arguments");
+        check_common(x, y, n, p, mem, opts);
+        ADMM_REQUIRE(lambda_out && beta_out && niter_out, "output pointers must not be NULL");
+        ADMM_REQUIRE(nlambda_in >= 0, "nlambda_in must be >= 0");
+        ADMM_REQUIRE(nlambda_in > 0 ? lambda_in != nullptr : nlambda_auto > 0, "need a lambda grid or nlambda_auto > 0");
+        if (nlambda_in == 0) ADMM_REQUIRE(lmin_ratio > 0 && lmin_ratio < 1, "lambda_min_ratio must be within (0, 1)");
+        for (int i = 0; i < nlambda_in; ++i) ADMM_REQUIRE(lambda_in[i] > 0, "lambda must be positive");
+        ADMM_REQUIRE(p >= 3, "the spectral-radius estimate needs at least 3 columns");
+        require_device();
+        const double t0 = now_s();
+        Stream st;
+        DeviceData<double> d;
+        upload_standardize<double>(d, x, y, n, p, mem, standardize != 0, intercept != 0, st.s);     // Dantzig.cpp:52-55
+        const LassoProblem pb = make_problem(lambda_in, nlambda_in, nlambda_auto, lmin_ratio, false, 1.0, 0, false, opts);
+        DantzigResult res;
+        res.trace_cap = trace_cap;
+        res.stats.t_h2d = d.t_h2d;
+        res.stats.t_standardize = d.t_std;
+        solve_dantzig(d, pb, res, st.s);
+        const int nl = (int)res.lambda.size();
+        for (int i = 0; i < nl; ++i) { lambda_out[i] = res.lambda[i]; niter_out[i] = res.niter[i]; }
+        std::memcpy(beta_out, res.beta.data(), sizeof(double) * (size_t)(p + 1) * nl);
+        if (trace_cap > 0) { std::memcpy(trace_out, res.trace.data(), res.trace.size() * sizeof(double)); *ntrace_out = (long long)(res.trace.size() / ADMM_TRACE_FIELDS); }
+        res.stats.t_total = now_s() - t0;
+        if (stats) *stats = res.stats;
+    });
+}
+
+int admm_hip_dantzig(const double* x, const double* y, int n, int p, int mem,
+                     const double* lambda_in, int nlambda_in, int nlambda_auto, double lmin_ratio,
+                     int standardize, int intercept, const admm_opts* opts,
+                     double* lambda_out, double* beta_out, int* niter_out, admm_stats* stats) {
+    return admm_hip_dantzig_traced(x, y, n, p, mem, lambda_in, nlambda_in, nlambda_auto, lmin_ratio, standardize, intercept, opts,
+                                   lambda_out, beta_out, niter_out, stats, nullptr, 0, nullptr);
+}
+
 // admm_parbp (R/10_admm_bp.R:111-116; TODO/ParBP.cppp:26-71): opts->rho carries rho_ratio.
 static void parbp_common(const double* x_cols, const double* y, int n, int p_local, long long p_total, long long col_offset, int mem, int nthread,
                          const admm_opts* opts, double* beta_out, int* niter_out, admm_stats* stats,

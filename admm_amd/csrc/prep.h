@@ -133,6 +133,7 @@ struct GramFreeWideOp {
 // (ADMMLassoTall.h:196-201, ADMMLassoWide.h:202-207).  Returns the Ritz value; throws
 // ADMM_ERR_EIGS if it never passes the loose convergence test.
 float lanczos_largest_f32(const std::function<void(const float*, float*)>& op, int n, int* nmatop);
+double lanczos_largest_f64(const std::function<void(const double*, double*)>& op, int n, int* nmatop);
 
 // max_j |v_j| of a device vector.
 template <typename T>

@@ -58,6 +58,15 @@ struct DenseResult {
 };
 void solve_lad(const DeviceData<double>& d, const admm_opts& opts, DenseResult& res, hipStream_t st);
 void solve_bp(const DeviceData<double>& d, const admm_opts& opts, DenseResult& res, hipStream_t st);
+// admm_dantzig (dantzig.hip): the Dantzig selector path in double.  res.beta: (p + 1) x nlambda column-major, row 0 = intercept.
+struct DantzigResult {
+    std::vector<double> lambda, beta;
+    std::vector<int> niter;
+    admm_stats stats{};
+    long long trace_cap = 0;
+    std::vector<double> trace;
+};
+void solve_dantzig(DeviceData<double>& d, const LassoProblem& pb, DantzigResult& res, hipStream_t st);
 // admm_parbp: basis pursuit with the columns in `nblocks` blocks (sharing ADMM, sharing_bp.hip).  d holds this rank's columns
 // [col_offset, col_offset + d.p) of p_total (whole blocks); opts.rho carries rho_ratio.  res.beta: this rank's coefficients.
 void solve_parbp(const DeviceData<double>& d, const admm_opts& opts, int nblocks, long long p_total, long long col_offset,

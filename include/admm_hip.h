@@ -84,7 +84,7 @@ typedef struct admm_stats {
     long long xupdate_launches;
     double rho;            /* rho actually used (first lambda) */
     double eig_est;        /* the loose Lanczos value (lambda_max or spectral-radius estimate) */
-    int branch;            /* 0 tall (Cholesky), 1 wide (linearised), 2 consensus; 6 admm_parbp (column-block sharing) */
+    int branch;            /* 0 tall (Cholesky), 1 wide (linearised), 2 consensus; 6 admm_parbp (column-block sharing); 7 admm_dantzig */
     int xupdate_variant;   /* tall path: 0 = full-matrix mat-vec (4p^2 B), 1 = lower-triangle symmetric mat-vec (2p^2 B),
                               2 = the same with the tiles dealt out to the ranks + one all-reduce of 2p floats (admm_hip_lasso_dist),
                               3 = 1 with the element-wise tail of the previous iteration inside the same launch (one launch per iteration) */
@@ -167,6 +167,24 @@ ADMM_HIP_API int admm_hip_lad(const double* x, const double* y, int n, int p, in
 /* beta_out[p], niter_out[1]. Requires p > n (R/10_admm_bp.R:30-31). */
 ADMM_HIP_API int admm_hip_bp(const double* x, const double* y, int n, int p, int mem,
                 const admm_opts* opts, double* beta_out, int* niter_out, admm_stats* stats);
+
+/* The Dantzig selector path, min ||beta||_1 s.t. ||X'(X beta - y)||_inf <= lambda -- what R's admm_dantzig(x, y)$fit() asks for,
+ * .Call("admm_dantzig", x, y, lambda, nlambda, lambda_min_ratio, standardize, intercept, opts) (R/50_admm_dantzig.R:30-46), a
+ * symbol the reference never builds (src/TODO/Dantzig.cpp:32-99, src/TODO/ADMMDantzig.h against an older ADMMBase).  Restated
+ * on the current ADMMBase::solve (admm_amd/csrc/dantzig.hip, oracle/solvers.py Dantzig).  Arguments as admm_hip_lasso; opts->rho
+ * <= 0: automatic (1 / loose Lanczos value of X'X).  Everything is double: beta_out[(p + 1) * nl] column-major, row 0 = intercept.
+ * niter_out[l] = maxit + 1 when lambda l did not converge.  NOTE (tests/test_oracle_dantzig.py): the iteration converges on
+ * comfortably tall problems (n >= 5 p) and does not for p > n -- the algorithm as the reference holds it.
+ * _traced: decision records, layout ADMM_TRACE_* ([0] lambda index, [11] internal lambda; CONVERGED / CONTINUE). */
+ADMM_HIP_API int admm_hip_dantzig(const double* x, const double* y, int n, int p, int mem,
+                                  const double* lambda_in, int nlambda_in, int nlambda_auto, double lmin_ratio,
+                                  int standardize, int intercept, const admm_opts* opts,
+                                  double* lambda_out, double* beta_out, int* niter_out, admm_stats* stats);
+ADMM_HIP_API int admm_hip_dantzig_traced(const double* x, const double* y, int n, int p, int mem,
+                                         const double* lambda_in, int nlambda_in, int nlambda_auto, double lmin_ratio,
+                                         int standardize, int intercept, const admm_opts* opts,
+                                         double* lambda_out, double* beta_out, int* niter_out, admm_stats* stats,
+                                         double* trace_out, long long trace_cap, long long* ntrace_out);
 
 /* Basis pursuit with the COLUMNS of x in `nthread` blocks -- what R's admm_bp(x, y)$parallel(nthread)$fit() asks for:
  * .Call("admm_parbp", x, y, nthread, list(maxit, eps_abs, eps_rel, rho_ratio = rho)) (R/10_admm_bp.R:111-116), a symbol the

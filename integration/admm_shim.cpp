@@ -1,6 +1,6 @@
 // Rcpp shim that a maintainer of yixuan/ADMM adds to src/ in place of Lasso.cpp, Enet.cpp, ParLasso.cpp,
 // LAD.cpp and BP.cpp.  It keeps the five `.Call` symbols the R code looks up by name
-// (R/30_admm_lasso.R:140,149; R/40_admm_enet.R:53; R/20_admm_lad.R:60; R/10_admm_bp.R:104,111) and forwards the
+// (R/30_admm_lasso.R:140,149; R/40_admm_enet.R:53; R/20_admm_lad.R:60; R/10_admm_bp.R:104,111; R/50_admm_dantzig.R:38) and forwards the
 // unpacked arguments to libadmm_hip.so (include/admm_hip.h).  R/ stays untouched.
 //
 // src/Makevars:   PKG_CPPFLAGS = -I/path/to/admm-mi355x/include
@@ -106,6 +106,25 @@ BEGIN_RCPP
     int niter = 0;
     check(admm_hip_lad(x.begin(), y.begin(), x.nrow(), x.ncol(), ADMM_MEM_HOST, as<bool>(intercept_), &o, beta.begin(), &niter, nullptr));
     return List::create(Named("beta") = beta, Named("niter") = niter);
+END_RCPP
+}
+
+// The symbol R/50_admm_dantzig.R:38 asks for and the reference never builds (src/TODO/Dantzig.cpp:32-99): doubles throughout.
+RcppExport SEXP admm_dantzig(SEXP x_, SEXP y_, SEXP lambda_, SEXP nlambda_, SEXP lmin_ratio_, SEXP standardize_, SEXP intercept_, SEXP opts_) {
+BEGIN_RCPP
+    NumericMatrix x(x_);
+    NumericVector y(y_), lambda(lambda_);
+    const int n = x.nrow(), p = x.ncol();
+    const int nl_in = lambda.size();
+    const int nl = nl_in > 0 ? nl_in : as<int>(nlambda_);
+    admm_opts o = unpack_opts(opts_);
+    NumericVector lambda_out(nl);
+    IntegerVector niter(nl);
+    NumericMatrix beta(p + 1, nl);                                  // Dantzig.cpp:85-93 fills a dense (p + 1) x nlambda block
+    check(admm_hip_dantzig(x.begin(), y.begin(), n, p, ADMM_MEM_HOST, nl_in > 0 ? lambda.begin() : nullptr, nl_in, as<int>(nlambda_),
+                           as<double>(lmin_ratio_), as<bool>(standardize_), as<bool>(intercept_), &o, lambda_out.begin(), beta.begin(),
+                           niter.begin(), nullptr));
+    return List::create(Named("lambda") = lambda_out, Named("beta") = beta, Named("niter") = niter);
 END_RCPP
 }
 
