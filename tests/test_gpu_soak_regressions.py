@@ -58,7 +58,7 @@ SOAK_CASES = [
     (510, 46, "enet_tall", "stopping decision at iteration 1137 needs 11 ulps"),
     (537, 141, "enet_tall", "restart decision at iteration 816 needs 11 ulps (n = p + 1)"),
     (548, 109, "tall", "restart decision at iteration 638 needs 10 ulps"),
-    # final soak of the round (profiles/r03_soak_summary.md: 6871 of 6884 pass), the cases not already listed above
+    # last two soaks of the round (profiles/r03_soak_summary.md: 6872 of 6884 pass), the cases not already listed above
     (502, 112, "tall", "stopping decision late in a 1745-decision path needs > 8 ulps"),
     (525, 53, "tall", "decision late in a 981-decision path needs > 8 ulps (standardised, scale 50)"),
     (532, 53, "enet_tall", "decision in a 7655-decision path needs > 8 ulps"),
