@@ -72,11 +72,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("ADMM_HIP_LIB") or LIB_PATH     # ADMM_HIP_LIB: another build of the SAME library (the host-sanitizer variant)
+    if not os.path.exists(path):
         raise FileNotFoundError(
-            f"{LIB_PATH} not found: build it with `python -m admm_amd.build` (hipcc --offload-arch=gfx950). "
+            f"{path} not found: build it with `python -m admm_amd.build` (hipcc --offload-arch=gfx950). "
             "admm_amd has no CPU fallback.")
-    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    lib = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
     lasso_args = [_DP, _DP, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                   _DP, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int]
     tail = [ctypes.POINTER(AdmmOpts), _c_double_p, _c_float_p, _c_int_p, ctypes.POINTER(AdmmStats)]

@@ -49,6 +49,52 @@ def _compile(src, force):
     return obj, True
 
 
+# ---- host-sanitizer variant (tests/test_sanitizers.py, tests/test_gpu_sanitizers.py): the HOST half of every translation unit
+# under AddressSanitizer + UndefinedBehaviorSanitizer (the device code is compiled as usual: -fno-gpu-sanitize), linked against
+# the shared sanitizer runtime so that a python process can LD_PRELOAD it.  Test infrastructure: never loaded by default.
+OBJ_SAN = os.path.join(CSRC, "_obj_san")
+LIB_SAN = os.path.join(LIBDIR, "libadmm_hip_san.so")
+SANFLAGS = ["-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-gpu-sanitize", "-shared-libsan"]
+
+
+def sanitizer_runtime():
+    """Path of clang's shared ASan runtime (to LD_PRELOAD), or None."""
+    import glob
+    hits = sorted(glob.glob(os.path.join(ROCM, "lib", "llvm", "lib", "clang", "*", "lib", "linux", "libclang_rt.asan-x86_64.so")))
+    return hits[-1] if hits else None
+
+
+def _compile_san(src, force):
+    obj = os.path.join(OBJ_SAN, src[:-4] + ".o")
+    srcp = os.path.join(CSRC, src)
+    if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(srcp)
+            and os.path.getmtime(obj) >= _newest_header()):
+        return obj, False
+    flags = [f for f in CXXFLAGS if f != "-O3"] + SANFLAGS
+    r = subprocess.run([HIPCC] + flags + ["-c", srcp, "-o", obj], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc (sanitizers) failed for {src}:\n{r.stdout}\n{r.stderr}")
+    return obj, True
+
+
+def build_sanitized(force=False, verbose=True):
+    os.makedirs(OBJ_SAN, exist_ok=True)
+    os.makedirs(LIBDIR, exist_ok=True)
+    srcs = _sources()
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        results = list(ex.map(lambda s: _compile_san(s, force), srcs))
+    objs = [o for o, _ in results]
+    if any(c for _, c in results) or not os.path.exists(LIB_SAN):
+        r = subprocess.run([HIPCC] + objs + LDFLAGS + ["-fsanitize=address,undefined", "-shared-libsan", "-o", LIB_SAN], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link (sanitizers) failed:\n{r.stdout}\n{r.stderr}")
+        if verbose:
+            print(f"[admm_amd.build] linked {LIB_SAN} ({len(objs)} objects, host ASan + UBSan)")
+    elif verbose:
+        print(f"[admm_amd.build] up to date: {LIB_SAN}")
+    return LIB_SAN
+
+
 def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
