@@ -49,6 +49,15 @@ def _compile(src, force):
     return obj, True
 
 
+def _lib_is_current(lib):
+    """The linked library is newer than every source and header: nothing to do even where the object files did not travel
+    (the GPU box receives the .so files, not csrc/_obj*)."""
+    if not os.path.exists(lib):
+        return False
+    t = os.path.getmtime(lib)
+    return t >= _newest_header() and all(t >= os.path.getmtime(os.path.join(CSRC, f)) for f in _sources())
+
+
 # ---- host-sanitizer variant (tests/test_sanitizers.py, tests/test_gpu_sanitizers.py): the HOST half of every translation unit
 # under AddressSanitizer + UndefinedBehaviorSanitizer (the device code is compiled as usual: -fno-gpu-sanitize), linked against
 # the shared sanitizer runtime so that a python process can LD_PRELOAD it.  Test infrastructure: never loaded by default.
@@ -78,6 +87,10 @@ def _compile_san(src, force):
 
 
 def build_sanitized(force=False, verbose=True):
+    if not force and _lib_is_current(LIB_SAN) and not os.path.isdir(OBJ_SAN):
+        if verbose:
+            print(f"[admm_amd.build] up to date (no object directory): {LIB_SAN}")
+        return LIB_SAN
     os.makedirs(OBJ_SAN, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
     srcs = _sources()
@@ -96,6 +109,10 @@ def build_sanitized(force=False, verbose=True):
 
 
 def build(force=False, verbose=True):
+    if not force and _lib_is_current(LIB) and not os.path.isdir(OBJ):
+        if verbose:
+            print(f"[admm_amd.build] up to date (no object directory): {LIB}")
+        return LIB
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
     srcs = _sources()
