@@ -100,6 +100,28 @@ def test_c5_shape_bp_feasible_and_recovers():
     assert fit.niter < 10000
 
 
+def test_c5_shape_sharing_bp_agrees_with_the_serial_solver():
+    """The same C5-shaped problem by the column-block sharing solver, 8 blocks on one GPU (admm_bp(...)$parallel(8): admm_hip_parbp):
+    two different algorithms of the reference's source tree for one linear programme -- both feasible to their tolerance,
+    both on the sparse truth, the l1 norms within 1e-3 of each other."""
+    import torch
+    from admm_amd import DevicePtr, admm_bp
+    n, p = 5000, 50000
+    xt, y, b = _gen(n, p, 500, 77, sd=1.0, noise=False)
+    ser = admm_bp(DevicePtr(xt.data_ptr()), DevicePtr(y.data_ptr()), n=n, p=p).fit()
+    par = admm_bp(DevicePtr(xt.data_ptr()), DevicePtr(y.data_ptr()), n=n, p=p).parallel(8).fit()
+    bs = torch.tensor(np.asarray(ser.beta.todense()).ravel(), device=xt.device)
+    bp_ = torch.tensor(np.asarray(par.beta.todense()).ravel(), device=xt.device)
+    feas = ((bp_ @ xt - y).norm() / y.norm()).item()
+    l1s, l1p = bs.abs().sum().item(), bp_.abs().sum().item()
+    print(f"[C5 sharing BP] {par.niter} iterations (serial {ser.niter}), feasibility {feas:.1e}, max error vs truth {(bp_ - b).abs().max().item():.1e} "
+          f"(serial {(bs - b).abs().max().item():.1e}), ||x||_1 {l1p:.4f} vs {l1s:.4f}, rho {par.stats['rho']:.3e}")
+    assert par.niter <= 10000 and par.stats["branch"] == 6
+    assert feas < 2e-3
+    assert (bp_ - b).abs().max().item() < 5e-2
+    assert abs(l1p / l1s - 1) < 1e-3
+
+
 def test_c4_full_size_consensus_k8():
     """BASELINE configs[3]: admm_lasso$parallel(8), n=10000, p=100000 -- 8 row blocks of 1250 x 10^5 (Woodbury branch,
     PADMMLasso.h:25-30) on ONE GPU.  Size-independent checks: the lambda_max model is null, the stationarity (KKT)
