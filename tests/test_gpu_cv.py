@@ -229,3 +229,20 @@ def test_cv_with_downdated_folds_against_direct_calls(monkeypatch):
           f"iteration counts differ by at most {dn}; idx_min {cv.idx_min} / {ref.idx_min}")
     assert worst_b < 1e-4 and worst_o < 1e-7 and dm < 1e-4
     assert cv.idx_min == ref.idx_min
+
+
+def test_cv_downdate_is_automatic_where_the_gram_is_the_setup_cost(monkeypatch):
+    """p >= 1024 and every training set taller than wide: the folds are formed as down-dates without being asked (stats of the
+    full fit say so through t_gram covering the one-time base), and the table agrees with the direct mode to 1e-4."""
+    import admm_amd
+    x, y = _data(3300, 1030, 12, 33)
+    monkeypatch.delenv("ADMM_HIP_CV_DOWNDATE", raising=False)
+    auto = admm_amd.admm_lasso(x, y).penalty(nlambda=6, lambda_min_ratio=0.05).cv(nfolds=3)
+    monkeypatch.setenv("ADMM_HIP_CV_DOWNDATE", "1")
+    forced = admm_amd.admm_lasso(x, y).penalty(nlambda=6, lambda_min_ratio=0.05).cv(nfolds=3)
+    monkeypatch.setenv("ADMM_HIP_CV_DOWNDATE", "0")
+    direct = admm_amd.admm_lasso(x, y).penalty(nlambda=6, lambda_min_ratio=0.05).cv(nfolds=3)
+    assert np.array_equal(auto.fold_mse, forced.fold_mse) and np.array_equal(auto.fold_niter, forced.fold_niter)      # automatic == forced on
+    assert not np.array_equal(auto.fold_mse, direct.fold_mse)                                                           # and it is not the direct mode
+    assert np.abs(auto.fold_mse / direct.fold_mse - 1).max() < 1e-4 and auto.idx_min == direct.idx_min
+    assert np.array_equal(auto.fit.beta_dense, direct.fit.beta_dense)                                                   # the full-data fit is the ordinary fit either way
