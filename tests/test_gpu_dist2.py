@@ -212,8 +212,8 @@ def test_single_launch_exchange_falls_back_when_its_grid_would_not_be_resident(c
         assert np.array_equal(one[r]["trace"], two[r]["trace"])
 
 
-@pytest.mark.parametrize("backend", ["shm", "peer"])
-def test_two_process_column_block_sharing_basis_pursuit(backend):
+@pytest.mark.parametrize("backend,nranks", [("shm", 2), ("peer", 2), ("shm", 4), ("peer", 4)])
+def test_two_process_column_block_sharing_basis_pursuit(backend, nranks):
     """admm_hip_parbp_dist: the column blocks of the sharing solver (admm_amd/csrc/sharing_bp.hip; the reference's unbuilt
     PADMMBP.h) dealt out to two ranks -- local x-updates and block sums, ONE all-reduce of S = sum_i A_i x_i and two block norms per
     iteration, replicated r / y / decisions.  Held to the single-process solver (the same blocks in one process: only the order
@@ -222,17 +222,20 @@ def test_two_process_column_block_sharing_basis_pursuit(backend):
     from oracle import entry
     sys.path.insert(0, HERE)
     from dist_worker import problem
-    res = _run_ranks(backend, "parbp")
+    res = _run_ranks(backend, "parbp", nranks=nranks)
     x, y, _, kw = problem("parbp")
     N = kw["nthread"]
-    assert res[0]["niter"][0] == res[1]["niter"][0] and res[0]["rho"][0] == res[1]["rho"][0]
+    assert all(r["niter"][0] == res[0]["niter"][0] and r["rho"][0] == res[0]["rho"][0] for r in res)
     assert int(res[0]["exchange_variant"]) == 1
-    assert list(res[0]["lo"]) == [0, 400] and list(res[1]["lo"]) == [400, 803]          # two blocks of 200 | 200 + 203
-    beta = np.concatenate([res[0]["beta"], res[1]["beta"]])
+    if nranks == 2:
+        assert list(res[0]["lo"]) == [0, 400] and list(res[1]["lo"]) == [400, 803]      # two blocks of 200 | 200 + 203
+    else:
+        assert [list(r["lo"]) for r in res] == [[0, 200], [200, 400], [400, 600], [600, 803]]     # one block per rank, the last takes the remainder
+    beta = np.concatenate([r["beta"] for r in res])
     one = admm_amd.admm_bp(x, y).parallel(N).fit()
     ref = entry.admm_parbp(x, y, N, dict(entry.BP_OPTS, rho_ratio=1.0))
     b1 = one.beta.toarray().ravel()
-    print(f"[2-process parbp over {backend}] {int(res[0]['niter'][0])} iterations (one process {one.niter}, oracle {ref['niter']}); "
+    print(f"[{nranks}-process parbp over {backend}] {int(res[0]['niter'][0])} iterations (one process {one.niter}, oracle {ref['niter']}); "
           f"beta vs one process {np.abs(beta - b1).max():.1e}, vs oracle {np.abs(beta - ref['beta']).max():.1e}")
     assert int(res[0]["niter"][0]) == one.niter == ref["niter"]
     assert np.abs(beta - b1).max() < 1e-10 and np.abs(beta - ref["beta"]).max() < 1e-10
