@@ -45,22 +45,19 @@ struct GemvTArgs {
 struct GemvNoExtra { static constexpr bool kHas = false; __device__ void operator()() const {} };
 
 // NT: the matrix is read with non-temporal loads (GemvTPlan::nt: operands larger than kGemvNtBytes, device_utils.h).
-template <typename T, int NRHS, int C, typename Extra = GemvNoExtra, bool NT = false>
-__global__ void __launch_bounds__(kGemvThreads)
-gemv_t_kernel(GemvTArgs<T> a, Extra extra) {
+// The work of one workgroup (index bx of the product's own grid): shared by the one-product launch and the batched launch.
+template <typename T, int NRHS, int C, bool NT>
+__device__ __forceinline__ void gemv_t_body(const GemvTArgs<T>& a, int bx) {
     using VT = Vec16<T>;
     using V = typename VT::type;
     constexpr int VN = VT::N;
     constexpr int PASS = kWave * VN;        // rows covered by one wave pass
 
-    if (Extra::kHas && blockIdx.x == gridDim.x - 1) { extra(); return; }
-    if (a.skip != nullptr && *a.skip != 0) return;
-
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* rhs = reinterpret_cast<T*>(smem_raw);     // [NRHS][seg_alloc]
 
-    const int s = blockIdx.x % a.nseg;
-    const int cb = blockIdx.x / a.nseg;
+    const int s = bx % a.nseg;
+    const int cb = bx / a.nseg;
     const int r0 = s * a.seg_len;
     const int len = min(a.seg_len, a.m - r0);
     const int lpad = (len + PASS - 1) / PASS * PASS;
@@ -166,6 +163,29 @@ gemv_t_kernel(GemvTArgs<T> a, Extra extra) {
     }
 }
 
+template <typename T, int NRHS, int C, typename Extra = GemvNoExtra, bool NT = false>
+__global__ void __launch_bounds__(kGemvThreads)
+gemv_t_kernel(GemvTArgs<T> a, Extra extra) {
+    if (Extra::kHas && blockIdx.x == gridDim.x - 1) { extra(); return; }
+    if (a.skip != nullptr && *a.skip != 0) return;
+    gemv_t_body<T, NRHS, C, NT>(a, (int)blockIdx.x);
+}
+
+// Several independent products in ONE launch: blockIdx.y picks the product (its argument block lives in device memory,
+// fixed for the life of the solver), blockIdx.x is the workgroup of that product's own grid (the launch is as wide as the
+// widest).  Same body, same partial order: bit-identical to separate launches -- what goes away is a fill / drain and a
+// kernel boundary per product (the consensus solver with several row blocks on one GPU: 24 launches per iteration -> 3).
+template <typename T, int NRHS, int C, bool NT>
+__global__ void __launch_bounds__(kGemvThreads)
+gemv_t_batch_kernel(const GemvTArgs<T>* __restrict__ batch) {
+    const GemvTArgs<T> a = batch[blockIdx.y];
+    if (a.skip != nullptr && *a.skip != 0) return;
+    const int ngroups = (a.k + C - 1) / C;
+    const int grid = a.nseg * ((ngroups + a.groups_per_wg - 1) / a.groups_per_wg);
+    if ((int)blockIdx.x >= grid) return;
+    gemv_t_body<T, NRHS, C, NT>(a, (int)blockIdx.x);
+}
+
 template <typename T>
 inline GemvTPlan plan_gemv_t(int m, int k, int nrhs, int C, int max_seg_rows = 0, int wg_per_cu = 4) {
     constexpr int VN = 16 / (int)sizeof(T);
@@ -259,6 +279,16 @@ struct GemvT {
         run_partials(v, skip, st);
         hipLaunchKernelGGL((reduce_partials_kernel<T>), dim3((k + 255) / 256), dim3(256), 0, st, part.get(), stride, pl.nseg, k, y, skip);
     }
+    // the argument block of run_partials / run_partials_from, for a batched launch (gemv_t_batch_kernel)
+    GemvTArgs<T> args_partials(const T* v, const int* skip, int vparts = 1, long long vstride = 0) {
+        GemvTArgs<T> a;
+        a.A = A; a.lda = lda; a.m = m; a.k = k;
+        a.v[0] = v; a.v[1] = nullptr; a.vparts = vparts; a.vstride = vstride; a.out[0] = part.get(); a.out[1] = nullptr;
+        a.out_stride = stride; a.seg_len = pl.seg_len; a.seg_alloc = pl.seg_alloc; a.nseg = pl.nseg;
+        a.groups_per_wg = pl.groups_per_wg; a.skip = skip;
+        return a;
+    }
+    GemvTArgs<T> args_partials_from(const GemvT<T>& prev, const int* skip) { return args_partials(prev.part.get(), skip, prev.pl.nseg, prev.stride); }
     // y from the partials of `prev` as right-hand vector
     void run_from(const GemvT<T>& prev, T* y, const int* skip, hipStream_t st) {
         if (pl.nseg == 1) {
@@ -270,5 +300,13 @@ struct GemvT {
         hipLaunchKernelGGL((reduce_partials_kernel<T>), dim3((k + 255) / 256), dim3(256), 0, st, part.get(), stride, pl.nseg, k, y, skip);
     }
 };
+
+// One launch for `count` products whose argument blocks sit in device memory (single right-hand side, C = 4).
+template <typename T>
+inline void launch_gemv_t_batch(const GemvTArgs<T>* d_batch, int count, int grid_x, size_t lds_bytes, bool nt, hipStream_t st) {
+    const dim3 grid(grid_x, count), block(kGemvThreads);
+    if (nt) hipLaunchKernelGGL((gemv_t_batch_kernel<T, 1, 4, true>), grid, block, (std::uint32_t)lds_bytes, st, d_batch);
+    else hipLaunchKernelGGL((gemv_t_batch_kernel<T, 1, 4, false>), grid, block, (std::uint32_t)lds_bytes, st, d_batch);
+}
 
 }  // namespace admm

@@ -373,6 +373,11 @@ struct ParPlan final : LassoPlan {
         return nrec;
     }
 
+    // several row blocks in this process, all of one branch: the workers' products of one kind go out as ONE launch each
+    bool batched = false, bt_wide = false, bt_nt = false;
+    DevBuf<GemvTArgs<float>> bAt, bM, bA;
+    int gridAt = 0, gridM = 0, gridA = 0;
+    size_t ldsAt = 0, ldsM = 0, ldsA = 0;
     bool peer_fused = false;          // multi-process over the PEER backend: the exchange is done by pack / z themselves
     DevBuf<float> state;
     long long state_cap = 0;
@@ -498,6 +503,38 @@ struct ParPlan final : LassoPlan {
         probe.alloc((size_t)4096 * 4 * 8); probe.zero(st);
         q.probe = probe.get();
 #endif
+        // ---- batched launches of the workers' products (ADMM_HIP_PAR_BATCH=0: one launch per worker and product, as before)
+        {
+            const char* e = std::getenv("ADMM_HIP_PAR_BATCH");
+            bool same = Kl > 1 && !(e && std::string(e) == "0");
+            for (int k = 1; k < Kl && same; ++k) same = W[k].wide == W[0].wide && W[k].gM.pl.nt == W[0].gM.pl.nt;
+            if (same) {
+                const int* skip = done.get();
+                std::vector<GemvTArgs<float>> hAt, hM, hA;
+                bt_wide = W[0].wide; bt_nt = W[0].gM.pl.nt;
+                for (int k = 0; k < Kl; ++k) {
+                    ParWorker& w = W[k];
+                    const float* rk = rhs.get() + (size_t)k * ldv;
+                    if (!bt_wide) {
+                        hM.push_back(w.gM.args_partials(rk, skip));
+                    } else {
+                        hAt.push_back(w.gAt.args_partials(rk, skip));
+                        hM.push_back(w.gM.args_partials_from(w.gAt, skip));
+                        hA.push_back(w.gA.args_partials_from(w.gM, skip));
+                        gridAt = std::max(gridAt, w.gAt.pl.grid); ldsAt = std::max(ldsAt, w.gAt.pl.lds_bytes);
+                        gridA = std::max(gridA, w.gA.pl.grid); ldsA = std::max(ldsA, w.gA.pl.lds_bytes);
+                    }
+                    gridM = std::max(gridM, w.gM.pl.grid); ldsM = std::max(ldsM, w.gM.pl.lds_bytes);
+                }
+                auto up = [&](DevBuf<GemvTArgs<float>>& d, const std::vector<GemvTArgs<float>>& h) {
+                    if (h.empty()) return;
+                    d.alloc(h.size());
+                    ADMM_HIP_CHECK(hipMemcpyAsync(d.get(), h.data(), h.size() * sizeof(GemvTArgs<float>), hipMemcpyHostToDevice, st));
+                };
+                up(bAt, hAt); up(bM, hM); up(bA, hA);
+                batched = true;
+            }
+        }
         ADMM_HIP_CHECK(hipStreamSynchronize(st));
     }
 
@@ -518,6 +555,16 @@ struct ParPlan final : LassoPlan {
         LoopTimes lt = run_until_done(st, skip, batch, (long long)nlam * ((long long)pb.opts.maxit + 2) + 4, [&](long long g) {
             const int par = (int)(g & 1);
             hipLaunchKernelGGL(par_head_kernel, dim3(nwg_e), dim3(kParThreads), 0, st, q);
+            if (batched) {
+                // all workers' products of one kind in ONE launch (bit-identical to the per-worker launches below)
+                if (bt_wide) {
+                    launch_gemv_t_batch<float>(bAt.get(), Kl, gridAt, ldsAt, bt_nt, st);      // t_k = A_k rhs_k
+                    launch_gemv_t_batch<float>(bM.get(), Kl, gridM, ldsM, bt_nt, st);         // s_k = (A_k A_k' + rho I)^-1 t_k
+                    launch_gemv_t_batch<float>(bA.get(), Kl, gridA, ldsA, bt_nt, st);         // A_k' s_k
+                } else {
+                    launch_gemv_t_batch<float>(bM.get(), Kl, gridM, ldsM, bt_nt, st);         // x_k = (A_k'A_k + rho I)^-1 rhs_k
+                }
+            } else
             for (int k = 0; k < Kl; ++k) {
                 ParWorker& w = W[k];
                 const float* rk = rhs.get() + (size_t)k * ldv;

@@ -60,3 +60,19 @@ def test_dist_entry_point_single_rank_matches_single_process():
                 assert np.isfinite(fit_d.beta_dense).all() and fit_d.niter.min() >= 1
     finally:
         dist.finalize_comm()
+
+
+def test_batched_worker_products_are_bit_identical_to_per_worker_launches(monkeypatch):
+    """Several row blocks in one process: the workers' products of one kind go out as ONE launch (gemv_t_batch_kernel, the same
+    workgroup body and partial order).  Both consensus branches, a remainder block: coefficients and counts bit for bit."""
+    import admm_amd
+    from helpers import synth_lasso
+    for (n, p, K, nl, maxit) in ((900, 120, 4, 5, 300), (403, 300, 4, 3, 200), (250, 700, 3, 3, 150)):
+        x, y = synth_lasso(n, p, 10, seed=n + p)
+        out = []
+        for flag in ("1", "0"):
+            monkeypatch.setenv("ADMM_HIP_PAR_BATCH", flag)
+            m = admm_amd.admm_lasso(x, y).penalty(nlambda=nl).opts(maxit=maxit)
+            m.nthread = K
+            out.append(m.fit())
+        assert np.array_equal(out[0].beta_dense, out[1].beta_dense) and np.array_equal(out[0].niter, out[1].niter), (n, p, K)
