@@ -1,5 +1,5 @@
 // Rcpp shim that a maintainer of yixuan/ADMM adds to src/ in place of Lasso.cpp, Enet.cpp, ParLasso.cpp,
-// LAD.cpp and BP.cpp.  It keeps the five `.Call` symbols the R code looks up by name
+// LAD.cpp and BP.cpp.  It keeps the five `.Call` symbols the R code looks up by name (and supplies admm_parbp / admm_dantzig)
 // (R/30_admm_lasso.R:140,149; R/40_admm_enet.R:53; R/20_admm_lad.R:60; R/10_admm_bp.R:104,111; R/50_admm_dantzig.R:38) and forwards the
 // unpacked arguments to libadmm_hip.so (include/admm_hip.h).  R/ stays untouched.
 //
