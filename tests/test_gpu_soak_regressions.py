@@ -64,6 +64,24 @@ SOAK_CASES = [
     (532, 53, "enet_tall", "decision in a 7655-decision path needs > 8 ulps"),
     (542, 144, "enet_tall", "decision late in a 1723-decision path needs > 8 ulps (scale 0.01 unstandardised)"),
     (546, 23, "tall", "stopping decision at iteration 1641 needs 8.16 ulps: a limit cycle that repeats one near-tie 84 times"),
+    # out-of-sample soak on fresh seeds 601..648 (profiles/r03_soak_summary_seeds601.md: 6881 of 6897 pass): all 16 failures,
+    # the same kind of case -- a stopping / restart decision 8 .. 54 ulps out, late in a long path at its rounding floor
+    (601, 120, "enet_tall", "stopping decision needs 10.4 ulps (n=31 p=3)"),
+    (603, 87, "enet_tall", "stopping decision needs 8.08 ulps"),
+    (607, 134, "tall", "stopping decision needs 16.6 ulps"),
+    (612, 128, "tall", "stopping decision needs 54 ulps (n=13 p=9, scale 0.01 unstandardised)"),
+    (617, 83, "tall", "restart decision needs 8.04 ulps"),
+    (618, 83, "tall", "stopping decision needs 10.1 ulps"),
+    (620, 130, "par", "stopping decision needs 9.5 ulps (K=5)"),
+    (623, 125, "tall", "restart decision needs 8.7 ulps"),
+    (630, 34, "enet_tall", "stopping decision needs 13.7 ulps"),
+    (630, 111, "enet_tall", "stopping decision needs 8.5 ulps"),
+    (631, 101, "enet_tall", "stopping decision needs 11.4 ulps"),
+    (636, 59, "enet_tall", "stopping decision needs 18.8 ulps"),
+    (637, 134, "enet_tall", "stopping decision needs 10.5 ulps"),
+    (638, 148, "tall", "stopping decision needs 9.1 ulps"),
+    (647, 5, "enet_tall", "stopping decision needs 11.9 ulps"),
+    (648, 114, "tall", "restart decision needs 8.1 ulps"),
 ]
 # per-record ceiling of the x-update's error: x the first-order float-solve yardstick (tall family; measured <= 1.8), x the
 # reference's own float Cholesky / Woodbury solve on the same right-hand side (consensus; measured <= 10.4 -- the maximum
