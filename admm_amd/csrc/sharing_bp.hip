@@ -201,10 +201,13 @@ sbp_xreg_kernel(SbpParams q, int par) {
 // piece of the gather on another page of the 2 GB matrix); wave-per-column with the waves taking turns on an LDS partial 23 us.
 // Regular iterations, third launch (AXONLY = true): the same over the lists just built, x untouched.
 constexpr int kSbpChunk = 24;                                       // double2 per lane requested together when a wave streams a column
-constexpr int kSbpRowPairs = 16;                                    // double2 per thread: 2 * 256 * 16 = 8192 rows at most
-template <bool AXONLY>
+// RP: double2 of the partial per thread -- 16 (up to 8192 rows) or 32 (up to 16384 rows: the column pieces of the axpy half
+// are then requested eight at a time instead of all at once)
+template <bool AXONLY, int RP>
 __global__ void __launch_bounds__(kSbpThreads)
 sbp_xact_kernel(SbpParams q, int par) {
+    constexpr int kSbpRowPairs = RP;
+    constexpr int kSub = RP == 16 ? 16 : 8;
     extern __shared__ __attribute__((aligned(16))) double vsh[];    // npad doubles: v (not used by AXONLY)
     __shared__ double red[8 * 4];
     __shared__ double sx[4];
@@ -276,11 +279,14 @@ sbp_xact_kernel(SbpParams q, int par) {
             const double xc = sx[c];
             if (xc == 0.0) continue;                                // uniform
             const double2* ac = reinterpret_cast<const double2*>(q.A + (size_t)(c0 + sj[c]) * q.lda) + threadIdx.x;
-            double2 t[kSbpRowPairs];
 #pragma unroll
-            for (int k = 0; k < kSbpRowPairs; ++k) t[k] = k * kSbpThreads + (int)threadIdx.x < np2 ? ac[(size_t)k * kSbpThreads] : make_double2(0.0, 0.0);
+            for (int kb = 0; kb < kSbpRowPairs; kb += kSub) {
+                double2 t[kSub];
 #pragma unroll
-            for (int k = 0; k < kSbpRowPairs; ++k) { acc[k].x = fma(xc, t[k].x, acc[k].x); acc[k].y = fma(xc, t[k].y, acc[k].y); }
+                for (int k = 0; k < kSub; ++k) t[k] = (kb + k) * kSbpThreads + (int)threadIdx.x < np2 ? ac[(size_t)(kb + k) * kSbpThreads] : make_double2(0.0, 0.0);
+#pragma unroll
+                for (int k = 0; k < kSub; ++k) { acc[kb + k].x = fma(xc, t[k].x, acc[kb + k].x); acc[kb + k].y = fma(xc, t[k].y, acc[kb + k].y); }
+            }
         }
     }
     double2* P = reinterpret_cast<double2*>(q.P + (size_t)g * q.npad) + threadIdx.x;
@@ -564,7 +570,7 @@ void solve_parbp(const DeviceData<double>& d, const admm_opts& opts, int nblocks
     const CommInfo ci = comm_info();
     const bool dist = p_total != (long long)pl;
     ADMM_REQUIRE(!dist || ci.active, "no communicator: call admm_hip_comm_init first");
-    ADMM_REQUIRE(n <= 8192, "admm_parbp: at most 8192 rows (the x-update keeps a row slice per thread); use admm_bp");
+    ADMM_REQUIRE(n <= 16384, "admm_parbp: at most 16384 rows (v lives in LDS, the x-update keeps a row slice per thread); use admm_bp");
     const long long chunk = p_total / N;
     ADMM_REQUIRE(chunk >= 1, "more column blocks than columns");
     // the global partition (PADMMBP.h:150-167): N - 1 blocks of p div N columns, the last takes the remainder
@@ -674,6 +680,13 @@ void solve_parbp(const DeviceData<double>& d, const admm_opts& opts, int nblocks
     q.ctl = ctl.get(); q.done = d_done.get(); q.hflag = dist ? nullptr : hflag.p;
     q.trace = res.trace_cap > 0 ? trace.get() : nullptr; q.trace_cap = res.trace_cap;
 
+    const bool big = npad > 8192;                                  // more than 64 KB of LDS for v: opt in per kernel
+    if (big) {
+        const int lds = npad * (int)sizeof(double);
+        ADMM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&sbp_xreg_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        ADMM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&sbp_xreg_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        ADMM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&sbp_xact_kernel<false, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    }
     const bool nt = (double)lda * (double)pl * 8.0 > 220e6;       // as gemv_plan.h: beyond what the 256 MB Infinity Cache keeps
     ADMM_HIP_CHECK(hipStreamSynchronize(st));
     LoopTimes lt = run_until_done(st, d_done.get(), sbp_batch(), (long long)opts.maxit + 2,
@@ -683,9 +696,11 @@ void solve_parbp(const DeviceData<double>& d, const admm_opts& opts, int nblocks
                 if (nt) hipLaunchKernelGGL((sbp_xreg_kernel<true>), dim3(G), dim3(kSbpThreads), (size_t)npad * sizeof(double), st, q, par);
                 else hipLaunchKernelGGL((sbp_xreg_kernel<false>), dim3(G), dim3(kSbpThreads), (size_t)npad * sizeof(double), st, q, par);
                 hipLaunchKernelGGL(sbp_list_kernel, dim3(G), dim3(kSbpThreads), 0, st, q, par ^ 1);
-                hipLaunchKernelGGL((sbp_xact_kernel<true>), dim3(G), dim3(kSbpThreads), 0, st, q, par ^ 1);
+                if (big) hipLaunchKernelGGL((sbp_xact_kernel<true, 32>), dim3(G), dim3(kSbpThreads), 0, st, q, par ^ 1);
+                else hipLaunchKernelGGL((sbp_xact_kernel<true, 16>), dim3(G), dim3(kSbpThreads), 0, st, q, par ^ 1);
             } else {
-                hipLaunchKernelGGL((sbp_xact_kernel<false>), dim3(G), dim3(kSbpThreads), (size_t)npad * sizeof(double), st, q, par);
+                if (big) hipLaunchKernelGGL((sbp_xact_kernel<false, 32>), dim3(G), dim3(kSbpThreads), (size_t)npad * sizeof(double), st, q, par);
+                else hipLaunchKernelGGL((sbp_xact_kernel<false, 16>), dim3(G), dim3(kSbpThreads), (size_t)npad * sizeof(double), st, q, par);
             }
             if (dist) {
                 hipLaunchKernelGGL((sbp_tail_kernel<false>), dim3(nT), dim3(64 * kSbpTailWaves), 0, st, q, par ^ 1);

@@ -101,3 +101,16 @@ def test_maxit_exit_and_arguments():
         admm_amd.admm_bp(x, y).parallel(101).fit()               # more blocks than columns
     one = _fit(x, y, 1)                                          # nthread = 1 through $parallel is the serial solver, as in R
     assert one.stats["branch"] != 6
+
+
+def test_more_than_8192_rows_takes_the_large_lds_variant():
+    """n > 8192: v needs more than 64 KB of LDS (opt-in per kernel) and the partial 32 double2 per thread.  Held to the oracle like
+    the small cases (a short run: the comparison is per iteration)."""
+    rng = np.random.default_rng(5)
+    n, p = 8400, 8600
+    x = np.asfortranarray(rng.standard_normal((n, p)))
+    b0 = np.zeros(p); b0[rng.choice(p, 30, replace=False)] = rng.standard_normal(30) * 2
+    _compare(x, x @ b0, 2, "n=8400 p=8600", maxit=25)
+    import admm_amd
+    with pytest.raises(RuntimeError):
+        admm_amd.admm_bp(np.zeros((16390, 16400), order="F"), np.zeros(16390)).parallel(2).fit()      # beyond the row limit: a clear error
