@@ -60,7 +60,8 @@ EXPORTS = ["admm_hip_lasso", "admm_hip_enet", "admm_hip_parlasso", "admm_hip_lad
            "admm_hip_lasso_dist", "admm_hip_test_gram", "admm_hip_test_spd_inverse", "admm_hip_test_cv_fold_system",
            "admm_hip_lasso_dist_cols", "admm_hip_test_gemv_t", "admm_hip_lad_traced", "admm_hip_bp_traced",
            "admm_hip_lasso_plan_create_dist_cols", "admm_hip_lasso_cv", "admm_hip_lasso_multi",
-           "admm_hip_parbp", "admm_hip_parbp_traced", "admm_hip_parbp_dist", "admm_hip_dantzig", "admm_hip_dantzig_traced"]
+           "admm_hip_parbp", "admm_hip_parbp_traced", "admm_hip_parbp_dist", "admm_hip_dantzig", "admm_hip_dantzig_traced",
+           "admm_hip_lad_state", "admm_hip_bp_state", "admm_hip_lasso_plan_data_read"]
 
 TRACE_FIELDS = 12
 TRACE_COLD, TRACE_CONVERGED, TRACE_ACCELERATE, TRACE_RESTART = -1, 0, 1, 2
@@ -102,6 +103,10 @@ def load():
     lib.admm_hip_lad_traced.restype = ctypes.c_int
     lib.admm_hip_bp_traced.argtypes = lib.admm_hip_bp.argtypes + [_c_double_p, ctypes.c_longlong, ctypes.POINTER(ctypes.c_longlong)]
     lib.admm_hip_bp_traced.restype = ctypes.c_int
+    lib.admm_hip_lad_state.argtypes = lib.admm_hip_lad_traced.argtypes + [_c_double_p, ctypes.c_longlong, ctypes.POINTER(ctypes.c_longlong)]
+    lib.admm_hip_lad_state.restype = ctypes.c_int
+    lib.admm_hip_bp_state.argtypes = lib.admm_hip_bp_traced.argtypes + [_c_double_p, ctypes.c_longlong, ctypes.POINTER(ctypes.c_longlong)]
+    lib.admm_hip_bp_state.restype = ctypes.c_int
     lib.admm_hip_dantzig.argtypes = [_DP, _DP, ctypes.c_int, ctypes.c_int, ctypes.c_int, _DP, ctypes.c_int, ctypes.c_int, ctypes.c_double,
                                      ctypes.c_int, ctypes.c_int, ctypes.POINTER(AdmmOpts), _c_double_p, _c_double_p, _c_int_p, ctypes.POINTER(AdmmStats)]
     lib.admm_hip_dantzig.restype = ctypes.c_int
@@ -167,6 +172,8 @@ def load():
     lib.admm_hip_lasso_plan_state_read.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.c_longlong,
                                                    ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong)]
     lib.admm_hip_lasso_plan_state_read.restype = ctypes.c_int
+    lib.admm_hip_lasso_plan_data_read.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.c_longlong, ctypes.POINTER(ctypes.c_float)]
+    lib.admm_hip_lasso_plan_data_read.restype = ctypes.c_int
     lib.admm_hip_lasso_plan_system_read.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.c_longlong]
     lib.admm_hip_lasso_plan_system_read.restype = ctypes.c_int
     lib.admm_hip_test_symv.argtypes = [_c_float_p, ctypes.c_int, _c_float_p, _c_float_p, _c_float_p, _c_float_p]

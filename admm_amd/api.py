@@ -300,6 +300,18 @@ def _trace_args(tr, ntr):
     return tr.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), cap, ctypes.byref(ntr)
 
 
+def _state_buffers(nrec, dim):
+    nrec = int(nrec) if nrec else 0
+    return np.zeros((max(nrec, 1), 5, dim), dtype=np.float64), ctypes.c_longlong(0)
+
+
+def _state_args(sbuf, nst):
+    cap = sbuf.shape[0] if sbuf.shape[0] > 1 else 0
+    if cap == 0:
+        return None, 0, None
+    return sbuf.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), cap, ctypes.byref(nst)
+
+
 class ADMM_BP_fit:
     def __init__(self, beta, niter, stats):
         self.beta = beta
@@ -348,8 +360,10 @@ class ADMM_BP:
         self.rho = 1.0 if rho is None else float(rho)
         return self
 
-    def fit(self, trace=False):
-        """trace=True also returns the decision trace (fit.trace, layout of include/admm_hip.h ADMM_TRACE_*)."""
+    def fit(self, trace=False, state=0):
+        """trace=True also returns the decision trace (fit.trace, layout of include/admm_hip.h ADMM_TRACE_*); state = N > 0 (serial
+        solver only) also the iterate dump of the first N decisions (fit.state: (records, 5, p) -- x | z | y | adj_z | adj_y,
+        admm_hip_bp_state)."""
         lib = _lib.load()
         xp, xmem, xk = as_input(self.x)
         yp, ymem, yk = as_input(self.y)
@@ -367,11 +381,14 @@ class ADMM_BP:
                                             beta.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
                                             niter.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), ctypes.byref(stats), *_trace_args(tr, ntr)))
         else:
-            check(lib.admm_hip_bp_traced(xp, yp, self.n, self.p, xmem, ctypes.byref(o),
-                                         beta.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
-                                         niter.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), ctypes.byref(stats), *_trace_args(tr, ntr)))
+            sbuf, nst = _state_buffers(state if trace else 0, self.p)
+            check(lib.admm_hip_bp_state(xp, yp, self.n, self.p, xmem, ctypes.byref(o),
+                                        beta.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                        niter.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), ctypes.byref(stats), *_trace_args(tr, ntr),
+                                        *_state_args(sbuf, nst)))
         fit = ADMM_BP_fit(sp.csc_matrix(beta.reshape(-1, 1)), int(niter[0]), stats.as_dict())   # dgCMatrix p x 1 (BP.cpp:38-43)
         fit.trace = tr[:ntr.value].copy() if trace else None
+        fit.state = sbuf[:nst.value].copy() if (trace and state and self.nthread <= 1) else None
         return fit
 
 
@@ -403,7 +420,8 @@ class ADMM_LAD(ADMM_BP):
         self.rho = 1.0
         self.intercept = bool(intercept)
 
-    def fit(self, trace=False):
+    def fit(self, trace=False, state=0):
+        """trace / state as ADMM_BP.fit (the iterate dump has dimension n: admm_hip_lad_state)."""
         lib = _lib.load()
         xp, xmem, xk = as_input(self.x)
         yp, ymem, yk = as_input(self.y)
@@ -414,11 +432,14 @@ class ADMM_LAD(ADMM_BP):
         niter = np.zeros(1, dtype=np.int32)
         stats = AdmmStats()
         tr, ntr = _trace_buffers(self.maxit if trace else 0)
-        check(lib.admm_hip_lad_traced(xp, yp, self.n, self.p, xmem, int(self.intercept), ctypes.byref(o),
-                                      beta.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
-                                      niter.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), ctypes.byref(stats), *_trace_args(tr, ntr)))
+        sbuf, nst = _state_buffers(state if trace else 0, self.n)
+        check(lib.admm_hip_lad_state(xp, yp, self.n, self.p, xmem, int(self.intercept), ctypes.byref(o),
+                                     beta.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                     niter.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), ctypes.byref(stats), *_trace_args(tr, ntr),
+                                     *_state_args(sbuf, nst)))
         fit = ADMM_LAD_fit(beta, int(niter[0]), stats.as_dict())
         fit.trace = tr[:ntr.value].copy() if trace else None
+        fit.state = sbuf[:nst.value].copy() if (trace and state) else None
         return fit
 
 
@@ -481,11 +502,21 @@ class LassoPlan:
     def read_state(self):
         """(nrecords, record_floats) float32 array of the last run()."""
         n, rf = ctypes.c_longlong(), ctypes.c_longlong()
-        check(self._lib.admm_hip_lasso_plan_state_read(self._h, None, 0, ctypes.byref(n), ctypes.byref(rf)))
-        buf = np.zeros((self._state_cap, rf.value), dtype=np.float32)
-        check(self._lib.admm_hip_lasso_plan_state_read(self._h, buf.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), self._state_cap,
+        check(self._lib.admm_hip_lasso_plan_state_read(self._h, None, 0, ctypes.byref(n), ctypes.byref(rf)))     # size query
+        nrec = max(int(n.value), 1)
+        buf = np.zeros((nrec, rf.value), dtype=np.float32)
+        check(self._lib.admm_hip_lasso_plan_state_read(self._h, buf.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), nrec,
                                                        ctypes.byref(n), ctypes.byref(rf)))
-        return buf[:n.value].copy()
+        return buf[:n.value]
+
+    def read_data(self):
+        """(X, Y): the standardised float32 data as the wide solver holds them (admm_hip_lasso_plan_data_read)."""
+        m = self.model
+        X = np.zeros((m.n, m.p), dtype=np.float32, order="F")
+        Y = np.zeros(m.n, dtype=np.float32)
+        check(self._lib.admm_hip_lasso_plan_data_read(self._h, X.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), m.n,
+                                                      Y.ctypes.data_as(ctypes.POINTER(ctypes.c_float))))
+        return X, Y
 
     def read_system(self):
         """(p, p) float32: the system matrix X'X + rho I as this library formed it (tall solver, ADMM_HIP_REFINE=1 only)."""

@@ -494,8 +494,22 @@ int admm_hip_lad(const double* x, const double* y, int n, int p, int mem, int in
 
 int admm_hip_lad_traced(const double* x, const double* y, int n, int p, int mem, int intercept, const admm_opts* opts,
                         double* beta_out, int* niter_out, admm_stats* stats, double* trace_out, long long trace_cap, long long* ntrace_out) {
+    return admm_hip_lad_state(x, y, n, p, mem, intercept, opts, beta_out, niter_out, stats, trace_out, trace_cap, ntrace_out, nullptr, 0, nullptr);
+}
+
+// copies the iterate dump of a LAD / BP run into the caller's buffer (admm_hip_lad_state / admm_hip_bp_state)
+static void dense_state_out(const DenseResult& res, double* state_out, long long state_cap, long long* nstate_out) {
+    if (state_cap <= 0) return;
+    std::memcpy(state_out, res.state.data(), res.state.size() * sizeof(double));
+    *nstate_out = res.state_dim > 0 ? (long long)(res.state.size() / (5 * (size_t)res.state_dim)) : 0;
+}
+
+int admm_hip_lad_state(const double* x, const double* y, int n, int p, int mem, int intercept, const admm_opts* opts,
+                       double* beta_out, int* niter_out, admm_stats* stats, double* trace_out, long long trace_cap, long long* ntrace_out,
+                       double* state_out, long long state_cap, long long* nstate_out) {
     return guarded([&] {
         ADMM_REQUIRE(trace_cap == 0 || (trace_out != nullptr && ntrace_out != nullptr && trace_cap > 0), "bad trace arguments");
+        ADMM_REQUIRE(state_cap == 0 || (state_out != nullptr && nstate_out != nullptr && state_cap > 0 && trace_cap > 0), "bad state arguments (the iterate dump needs the trace)");
         check_common(x, y, n, p, mem, opts);
         ADMM_REQUIRE(beta_out && niter_out, "output pointers must not be NULL");
         ADMM_REQUIRE(n > p, "nrow(x) must be greater than ncol(x)");            // R/20_admm_lad.R:21-22
@@ -507,12 +521,14 @@ int admm_hip_lad_traced(const double* x, const double* y, int n, int p, int mem,
         upload_standardize<double>(d, x, y, n, p, mem, true, intercept != 0, st.s);    // LAD.cpp:34: standardize always TRUE
         DenseResult res;
         res.trace_cap = trace_cap;
+        res.state_cap = state_cap;
         res.stats.t_h2d = d.t_h2d;
         res.stats.t_standardize = d.t_std;
         solve_lad(d, *opts, res, st.s);
         for (int i = 0; i <= p; ++i) beta_out[i] = res.beta[i];
         niter_out[0] = res.niter;
         if (trace_cap > 0) { std::memcpy(trace_out, res.trace.data(), res.trace.size() * sizeof(double)); *ntrace_out = (long long)(res.trace.size() / ADMM_TRACE_FIELDS); }
+        dense_state_out(res, state_out, state_cap, nstate_out);
         res.stats.t_total = now_s() - t0;
         if (stats) *stats = res.stats;
     });
@@ -525,8 +541,15 @@ int admm_hip_bp(const double* x, const double* y, int n, int p, int mem,
 
 int admm_hip_bp_traced(const double* x, const double* y, int n, int p, int mem, const admm_opts* opts,
                        double* beta_out, int* niter_out, admm_stats* stats, double* trace_out, long long trace_cap, long long* ntrace_out) {
+    return admm_hip_bp_state(x, y, n, p, mem, opts, beta_out, niter_out, stats, trace_out, trace_cap, ntrace_out, nullptr, 0, nullptr);
+}
+
+int admm_hip_bp_state(const double* x, const double* y, int n, int p, int mem, const admm_opts* opts,
+                      double* beta_out, int* niter_out, admm_stats* stats, double* trace_out, long long trace_cap, long long* ntrace_out,
+                      double* state_out, long long state_cap, long long* nstate_out) {
     return guarded([&] {
         ADMM_REQUIRE(trace_cap == 0 || (trace_out != nullptr && ntrace_out != nullptr && trace_cap > 0), "bad trace arguments");
+        ADMM_REQUIRE(state_cap == 0 || (state_out != nullptr && nstate_out != nullptr && state_cap > 0 && trace_cap > 0), "bad state arguments (the iterate dump needs the trace)");
         check_common(x, y, n, p, mem, opts);
         ADMM_REQUIRE(beta_out && niter_out, "output pointers must not be NULL");
         ADMM_REQUIRE(p > n, "ncol(x) must be greater than nrow(x)");            // R/10_admm_bp.R:30-31
@@ -538,12 +561,14 @@ int admm_hip_bp_traced(const double* x, const double* y, int n, int p, int mem, 
         upload_standardize<double>(d, x, y, n, p, mem, false, false, st.s);     // BP.cpp:24-27: no standardisation
         DenseResult res;
         res.trace_cap = trace_cap;
+        res.state_cap = state_cap;
         res.stats.t_h2d = d.t_h2d;
         res.stats.t_standardize = d.t_std;
         solve_bp(d, *opts, res, st.s);
         for (int i = 0; i < p; ++i) beta_out[i] = res.beta[i];
         niter_out[0] = res.niter;
         if (trace_cap > 0) { std::memcpy(trace_out, res.trace.data(), res.trace.size() * sizeof(double)); *ntrace_out = (long long)(res.trace.size() / ADMM_TRACE_FIELDS); }
+        dense_state_out(res, state_out, state_cap, nstate_out);
         res.stats.t_total = now_s() - t0;
         if (stats) *stats = res.stats;
     });
@@ -811,6 +836,14 @@ int admm_hip_lasso_plan_state_read(admm_hip_plan* plan, float* out, long long ca
         ADMM_REQUIRE(h != nullptr && h->plan, "plan is NULL");
         ADMM_REQUIRE(nrecords_out != nullptr && cap_records >= 0 && (out != nullptr || cap_records == 0), "bad state output arguments");
         *nrecords_out = h->plan->read_state(out, cap_records, record_floats_out);
+    });
+}
+
+int admm_hip_lasso_plan_data_read(admm_hip_plan* plan, float* x_out, long long ld, float* y_out) {
+    return guarded([&] {
+        PlanHandle* h = reinterpret_cast<PlanHandle*>(plan);
+        ADMM_REQUIRE(h != nullptr && h->plan, "plan is NULL");
+        h->plan->read_data(x_out, ld, y_out);
     });
 }
 

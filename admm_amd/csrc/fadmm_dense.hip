@@ -33,6 +33,7 @@ struct DenseParams {
     double* P;                                // [nwg_tail][8]
     int* done;
     double* trace; long long trace_cap;       // optional decision records (admm_hip_lad_traced / admm_hip_bp_traced), or NULL
+    double* state; long long state_cap;       // optional [state_cap][5][dim] iterates x, z, y, adj_z, adj_y of every iteration (admm_hip_lad_state / admm_hip_bp_state), or NULL
 };
 
 constexpr int kDenseThreads = 256;
@@ -157,6 +158,10 @@ dense_tail_kernel(DenseParams q, int par) {
         const double dz = zn - zc, daz = zn - adjz;
         acc[0] += r * r; acc[1] += dz * dz; acc[2] += daz * daz; acc[3] += x * x; acc[4] += zn * zn; acc[5] += yn * yn;
         q.x[i] = x; zn_[i] = zn; yn_[i] = yn;
+        if (q.state != nullptr && c.total < q.state_cap) {     // record c.total = the trace record that will judge this iteration
+            double* s = q.state + (size_t)c.total * 5 * q.dim;
+            s[i] = x; s[(size_t)q.dim + i] = zn; s[2 * (size_t)q.dim + i] = yn; s[3 * (size_t)q.dim + i] = adjz; s[4 * (size_t)q.dim + i] = adjy;
+        }
     }
     block_sum<double, 6>(acc, scratch);
     if (threadIdx.x == 0) {
@@ -202,9 +207,9 @@ struct DenseLoop {
     DevBuf<int> done;
     DenseParams q{};
     int nwg_head = 0;
-    DevBuf<double> trace;
+    DevBuf<double> trace, state;
 
-    void init(int dim, int prob, const admm_opts& o, const double* data_vec, double extra_norm, hipStream_t st, long long trace_cap = 0) {
+    void init(int dim, int prob, const admm_opts& o, const double* data_vec, double extra_norm, hipStream_t st, long long trace_cap = 0, long long state_cap = 0) {
         const long long ld = round_up(dim, 32);
         for (DevBuf<double>* b : {&x, &z0, &z1, &y0, &y1, &adj_z, &adj_y, &vec}) { b->alloc(ld); b->zero(st); }
         const int nwg_tail = std::max(1, std::min(64, (dim + kDenseThreads - 1) / kDenseThreads));
@@ -217,6 +222,12 @@ struct DenseLoop {
         q.adj_z = adj_z.get(); q.adj_y = adj_y.get(); q.vec = vec.get();
         q.ctl = ctl.get(); q.P = P.get(); q.done = done.get();
         if (trace_cap > 0) { trace.alloc((size_t)trace_cap * ADMM_TRACE_FIELDS); q.trace = trace.get(); q.trace_cap = trace_cap; }
+        if (state_cap > 0) {     // iterate dump; record 0 (the cold start has no iterates) carries data_vec as this solver holds it, in the x slot
+            state.alloc((size_t)state_cap * 5 * dim);
+            ADMM_HIP_CHECK(hipMemsetAsync(state.get(), 0, (size_t)state_cap * 5 * dim * sizeof(double), st));
+            ADMM_HIP_CHECK(hipMemcpyAsync(state.get(), data_vec, (size_t)dim * sizeof(double), hipMemcpyDeviceToDevice, st));
+            q.state = state.get(); q.state_cap = state_cap;
+        }
         const int init_n = std::max(dim, nwg_tail * 8);
         hipLaunchKernelGGL(dense_init_kernel, dim3((init_n + 255) / 256), dim3(256), 0, st, q, o.rho);
     }
@@ -256,6 +267,12 @@ static void dense_collect_trace(DenseLoop& L, const DenseCtl& fc, DenseResult& r
     const long long nrec = std::min<long long>(fc.total + (fc.done ? 1 : 0), res.trace_cap);      // the finishing decision does not advance `total`
     res.trace.resize((size_t)nrec * ADMM_TRACE_FIELDS);
     if (nrec > 0) ADMM_HIP_CHECK(hipMemcpy(res.trace.data(), L.trace.get(), res.trace.size() * sizeof(double), hipMemcpyDeviceToHost));
+    if (res.state_cap > 0) {                                   // one record per decision, same numbering as the trace
+        const long long ns = std::min<long long>(fc.total + (fc.done ? 1 : 0), res.state_cap);
+        res.state_dim = L.q.dim;
+        res.state.resize((size_t)ns * 5 * L.q.dim);
+        if (ns > 0) ADMM_HIP_CHECK(hipMemcpy(res.state.data(), L.state.get(), res.state.size() * sizeof(double), hipMemcpyDeviceToHost));
+    }
 }
 
 void solve_lad(const DeviceData<double>& d, const admm_opts& opts, DenseResult& res, hipStream_t st) {
@@ -292,7 +309,7 @@ void solve_lad(const DeviceData<double>& d, const admm_opts& opts, DenseResult& 
     ADMM_HIP_CHECK(hipStreamSynchronize(st));
 
     DenseLoop L;
-    L.init(n, 0, opts, d.Y.get(), ynorm, st, res.trace_cap);
+    L.init(n, 0, opts, d.Y.get(), ynorm, st, res.trace_cap, res.state_cap);
     GemvT<double> g1, g2, g3, gH;                // t = X' vec ; s = (X'X)^-1 t ; xs = X s ;  or xs = H vec
     g1.init(d.X.get(), d.ldx, n, p);
     g2.init(M.get(), ldp, p, p);
@@ -417,7 +434,7 @@ void solve_bp(const DeviceData<double>& d, const admm_opts& opts, DenseResult& r
     S.t_factor = now_s() - t0;
 
     DenseLoop L;
-    L.init(p, 1, opts, AAAb.get(), 0.0, st, res.trace_cap);
+    L.init(p, 1, opts, AAAb.get(), 0.0, st, res.trace_cap, res.state_cap);
     L.q.gout = gB.part.get(); L.q.gout_nseg = gB.pl.nseg; L.q.gout_stride = gB.stride;
 
     const int* skip = L.done.get();

@@ -755,6 +755,7 @@ struct TallPlan final : LassoPlan {
     }
     long long read_state(float* out, long long cap, long long* rec_floats) override {
         if (rec_floats) *rec_floats = 5ll * p;
+        if (!out) return std::min(trace_n, state_cap);                             // size query
         const long long nrec = std::min(std::min(trace_n, state_cap), cap);       // one record per decision, same numbering as the trace
         if (nrec > 0 && out) ADMM_HIP_CHECK(hipMemcpy(out, state.get(), (size_t)nrec * 5 * p * sizeof(float), hipMemcpyDeviceToHost));
         return nrec;

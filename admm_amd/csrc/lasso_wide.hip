@@ -106,6 +106,7 @@ struct WideParams {
     float* beta; int* niter; int* done;
     int* done_host;                       // pinned host word, set together with *done (loop_driver.h: PinnedFlag)
     double* trace; long long trace_cap;   // optional decision records (admm_hip_lasso_plan_trace_*), or NULL
+    float* state; long long state_cap;    // optional [state_cap][p + 3 n] iterates x | Ax | z | y of every iteration (admm_hip_lasso_plan_state_*), or NULL
 #ifdef ADMM_HIP_PROBE
     long long* probe;                     // dev build only: in-kernel timestamps [4096 iterations][4 observers][8]
 #endif
@@ -759,6 +760,21 @@ wide_tail_kernel(WideParams q, int par, PeerExchange ex) {
     WIDE_PROBE_FLUSH(blockIdx.x == 0 ? 3 : -1, c.total - 1);
 }
 
+// Iterate dump (admm_hip_lasso_plan_state_*; test / diagnosis facility, launched only when enabled): the vectors the iteration
+// that just finished leaves behind -- x | A x | z | y -- into the record with the number of the trace record that will judge
+// them (the decision taken by the NEXT x-update launch; `total` of the control block this iteration's x-update published).
+__global__ void __launch_bounds__(kWideThreads)
+wide_state_kernel(WideParams q, int par) {
+    const WideCtl c = q.ctl[par ^ 1];
+    if (c.done || c.total >= q.state_cap) return;
+    float* s = q.state + (size_t)c.total * ((size_t)q.p + 3 * (size_t)q.n);
+    for (long long i = (long long)blockIdx.x * kWideThreads + threadIdx.x; i < q.p; i += (long long)gridDim.x * kWideThreads) s[i] = q.x[i];
+    float* v = s + q.p;
+    for (int i = blockIdx.x * kWideThreads + threadIdx.x; i < q.n; i += gridDim.x * kWideThreads) {
+        v[i] = q.Ax[i]; v[(size_t)q.n + i] = q.z[i]; v[2 * (size_t)q.n + i] = q.y[i];
+    }
+}
+
 // ------------------------------------------------------------------------------------------ persistent active-set stretch
 // Round 3.  Almost every iteration of a wide path is an ACTIVE-SET step (ADMMLassoWide.h:86-118: only the current
 // non-zeros are updated; 17 191 of 17 613 iterations at BASELINE configs[2]) on a few dozen to a few hundred columns -- two
@@ -1094,6 +1110,27 @@ wide_act_persist_kernel(WideParams q, int cpar, WidePersist ps) {
                 wp_store_f64(ps.np + (size_t)g * 8 + threadIdx.x, t, wt);
             }
         }
+        if (q.state != nullptr && out.total < q.state_cap) {         // iterate dump: this iteration's x | A x | z | y (record = the trace record that judges it)
+            float* srec = q.state + (size_t)out.total * ((size_t)q.p + 3 * (size_t)q.n);
+#pragma unroll
+            for (int u = 0; u < kPNU; ++u) {
+                const long long jl = (long long)(u * 64 + lane) * NWp + w;
+                if (jl < q.p) srec[jl] = xs[u];
+            }
+            if (sub == 0) {
+#pragma unroll
+                for (int ps_ = 0; ps_ < MAXP; ++ps_) {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int pr = ps_ * npairs_pass + pair;
+                        const int i = g * R + pr * 2 + e;
+                        if (pr * 2 < R && i < q.n) {
+                            srec[(size_t)q.p + i] = ax_r[ps_][e]; srec[(size_t)q.p + q.n + i] = z_r[ps_][e]; srec[(size_t)q.p + 2 * (size_t)q.n + i] = y_r[ps_][e];
+                        }
+                    }
+                }
+            }
+        }
         wp_publish(ps.flagB + (size_t)g * 8, tag);
         WP_PHASE(3)
         k++;
@@ -1243,6 +1280,32 @@ struct WidePlan final : LassoPlan {
         const long long nrec = std::min(std::min(trace_n, trace_cap), cap);
         if (nrec > 0) ADMM_HIP_CHECK(hipMemcpy(out, trace.get(), (size_t)nrec * ADMM_TRACE_FIELDS * sizeof(double), hipMemcpyDeviceToHost));
         return nrec;
+    }
+
+    // iterate dump (test facility): record s = x | A x | z | y (p + 3 n floats) the decision of trace record s judged
+    DevBuf<float> state;
+    long long state_cap = 0;
+    void enable_state(long long cap) override {
+        if (cshard) throw Error(ADMM_ERR_INVALID_ARG, "the column-sharded wide solver records no iterate dump");
+        const size_t rec = (size_t)p + 3 * (size_t)n;
+        state.alloc((size_t)cap * rec);
+        ADMM_HIP_CHECK(hipMemsetAsync(state.get(), 0, (size_t)cap * rec * sizeof(float), st));
+        state_cap = cap;
+        q.state = state.get(); q.state_cap = cap;
+    }
+    long long read_state(float* out, long long cap, long long* rec_floats) override {
+        const size_t rec = (size_t)p + 3 * (size_t)n;
+        if (rec_floats) *rec_floats = (long long)rec;
+        if (!out) return std::min(trace_n, state_cap);                             // size query
+        const long long nrec = std::min(std::min(trace_n, state_cap), cap);
+        if (nrec > 0) ADMM_HIP_CHECK(hipMemcpy(out, state.get(), (size_t)nrec * rec * sizeof(float), hipMemcpyDeviceToHost));
+        return nrec;
+    }
+    // the standardised data as this solver holds them (test hook admm_hip_lasso_plan_data_read)
+    void read_data(float* x_out, long long ld, float* y_out) override {
+        ADMM_HIP_CHECK(hipStreamSynchronize(st));
+        if (x_out) ADMM_HIP_CHECK(hipMemcpy2D(x_out, (size_t)ld * sizeof(float), d.X.get(), (size_t)d.ldx * sizeof(float), (size_t)n * sizeof(float), (size_t)p, hipMemcpyDeviceToHost));
+        if (y_out) ADMM_HIP_CHECK(hipMemcpy(y_out, d.Y.get(), (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
     }
 
     WidePlan(DeviceData<float>&& data, const LassoProblem& prob, hipStream_t stream) : d(std::move(data)), pb(prob), st(stream) {
@@ -1460,6 +1523,7 @@ struct WidePlan final : LassoPlan {
                 allreduce_sum_f32(axl.get(), (size_t)n, st);
             }
             hipLaunchKernelGGL(wide_tail_kernel<0>, dim3(nwg_tail), dim3(kWideThreads), 0, st, q, par, PeerExchange{});
+            if (q.state != nullptr) hipLaunchKernelGGL(wide_state_kernel, dim3(std::min(1024, (std::max(n, p) + kWideThreads - 1) / kWideThreads)), dim3(kWideThreads), 0, st, q, par);
             if (persist) launch_persist(par ^ 1);                      // takes over from the state the next x-update launch would start from
         }, cshard ? nullptr : hflag.p);       // column-sharded: every rank must enqueue the same number of exchanges -> stream-ordered sampling of `done`
         S.t_loop = lt.wall_s; S.loop_ms_events = lt.events_ms; S.xupdate_launches = lt.launched;

@@ -393,6 +393,7 @@ struct ParPlan final : LassoPlan {
     long long read_state(float* out, long long cap, long long* rec_floats) override {
         const size_t rec = (size_t)(1 + 2 * Kl) * p;
         if (rec_floats) *rec_floats = (long long)rec;
+        if (!out) return std::min(trace_n, state_cap);                             // size query
         const long long nrec = std::min(std::min(trace_n, state_cap), cap);
         if (nrec > 0 && out) ADMM_HIP_CHECK(hipMemcpy(out, state.get(), (size_t)nrec * rec * sizeof(float), hipMemcpyDeviceToHost));
         return nrec;

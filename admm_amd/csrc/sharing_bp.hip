@@ -543,7 +543,12 @@ static double sbp_sprad(const double* Ab, long long lda, int n, int pb, hipStrea
             theta = a;
             if (b <= 1e-300 || n == 1) return theta;
         }
-        if (j + 1 == mmax) break;
+        if (j + 1 == mmax) {
+            // n steps span the whole space (exact up to rounding); fewer without the residual bound met is an UNCONVERGED value:
+            // rho and gamma_i = 2 rho + sprad_i hang on it, and an under-estimate breaks the majorisation of the linearised x-update
+            if (mmax < n) throw Error(ADMM_ERR_EIGS, "admm_parbp: the spectral radius of a column block did not converge in 600 Lanczos steps");
+            break;
+        }
         be.push_back(b);
         for (int i = 0; i < n; ++i) vj[i] = w[i] / b;
     }
@@ -680,12 +685,24 @@ void solve_parbp(const DeviceData<double>& d, const admm_opts& opts, int nblocks
     q.ctl = ctl.get(); q.done = d_done.get(); q.hflag = dist ? nullptr : hflag.p;
     q.trace = res.trace_cap > 0 ? trace.get() : nullptr; q.trace_cap = res.trace_cap;
 
-    const bool big = npad > 8192;                                  // more than 64 KB of LDS for v: opt in per kernel
-    if (big) {
-        const int lds = npad * (int)sizeof(double);
-        ADMM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&sbp_xreg_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        ADMM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&sbp_xreg_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        ADMM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&sbp_xact_kernel<false, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    const bool big = npad > 8192;                                  // the x-update's row slice per thread: 16 rows up to npad = 8192, 32 beyond
+    {
+        // v lives in dynamic LDS (npad doubles) NEXT TO the kernels' static arrays: what must fit the default per-workgroup limit is
+        // their sum -- at npad = 8192 the dynamic part alone is exactly 64 KB and the launch was refused without a trace (the
+        // advisor's finding: hipLaunchKernelGGL does not surface the error and the loop ended "without a decision").  Opt in per
+        // kernel whenever static + dynamic exceeds the default, and fail loudly when even the opt-in limit is too small.
+        const size_t lds = (size_t)npad * sizeof(double);
+        const void* fns[] = {reinterpret_cast<const void*>(&sbp_xreg_kernel<true>), reinterpret_cast<const void*>(&sbp_xreg_kernel<false>),
+                             big ? reinterpret_cast<const void*>(&sbp_xact_kernel<false, 32>) : reinterpret_cast<const void*>(&sbp_xact_kernel<false, 16>)};
+        for (const void* fn : fns) {
+            hipFuncAttributes fa{};
+            ADMM_HIP_CHECK(hipFuncGetAttributes(&fa, fn));
+            const size_t need = lds + fa.sharedSizeBytes;
+            if (need > device_info().lds_per_block) {
+                ADMM_REQUIRE(need <= device_info().lds_optin, "admm_parbp: the rows do not fit the LDS of a workgroup");
+                ADMM_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            }
+        }
     }
     const bool nt = (double)lda * (double)pl * 8.0 > 220e6;       // as gemv_plan.h: beyond what the 256 MB Infinity Cache keeps
     ADMM_HIP_CHECK(hipStreamSynchronize(st));
@@ -710,6 +727,7 @@ void solve_parbp(const DeviceData<double>& d, const admm_opts& opts, int nblocks
                 hipLaunchKernelGGL((sbp_tail_kernel<true>), dim3(nT), dim3(64 * kSbpTailWaves), 0, st, q, par ^ 1);
             }
         }, dist ? nullptr : hflag.p);
+    ADMM_HIP_CHECK(hipGetLastError());                             // a refused launch (LDS request, grid) is an error, not a silent no-op
     SbpCtl hc[2];
     ADMM_HIP_CHECK(hipMemcpy(hc, ctl.get(), sizeof(hc), hipMemcpyDeviceToHost));
     const SbpCtl& fin = hc[0].done ? hc[0] : hc[1];

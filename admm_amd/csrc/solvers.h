@@ -43,6 +43,8 @@ struct LassoPlan {
     virtual long long read_state(float*, long long, long long*) { return 0; }
     // the float system matrix X'X + rho I the x-update solves, p x p column-major (admm_hip_lasso_plan_system_read): only
     // the tall solver with ADMM_HIP_REFINE=1 keeps it
+    // the standardised data (X n x p column-major with leading dimension ld, Y) as the solver holds them (admm_hip_lasso_plan_data_read): wide solver
+    virtual void read_data(float*, long long, float*) { throw Error(ADMM_ERR_INVALID_ARG, "this plan does not keep its standardised data (wide solver only)"); }
     virtual void read_system(float*, long long) { throw Error(ADMM_ERR_INVALID_ARG, "this plan does not keep its system matrix (tall solver with ADMM_HIP_REFINE=1 only)"); }
 };
 std::unique_ptr<LassoPlan> make_tall_plan(DeviceData<float>&& d, const LassoProblem& pb, hipStream_t st);
@@ -55,6 +57,9 @@ struct DenseResult {
     admm_stats stats{};
     long long trace_cap = 0;         // > 0: record up to this many decisions (admm_hip_lad_traced / admm_hip_bp_traced)
     std::vector<double> trace;       // [nrec][ADMM_TRACE_FIELDS]
+    long long state_cap = 0;         // > 0: also dump the iterates of up to this many decisions (admm_hip_lad_state / admm_hip_bp_state)
+    std::vector<double> state;       // [nrec][5][state_dim]  x | z | y | adj_z | adj_y
+    long long state_dim = 0;
 };
 void solve_lad(const DeviceData<double>& d, const admm_opts& opts, DenseResult& res, hipStream_t st);
 void solve_bp(const DeviceData<double>& d, const admm_opts& opts, DenseResult& res, hipStream_t st);

@@ -116,8 +116,6 @@ ADMM_HIP_API int admm_hip_enet(const double* x, const double* y, int n, int p, i
                   int standardize, int intercept, double alpha, const admm_opts* opts,
                   double* lambda_out, float* beta_out, int* niter_out, admm_stats* stats);
 
-/* Row-block consensus ADMM with `nthread` blocks (ParLasso.cpp:71-72: nthread only sets the
- * number of blocks K).  All K blocks run on the current device. */
 /* K-fold cross-validation of the lambda path of admm_hip_lasso (alpha < 0) / admm_hip_enet (alpha in [0, 1]).
  * SURVEY.md section 8(f) row n4 ("cross-validation folds as independent replicas across GPUs"); the reference package has
  * no CV driver, so there is no reference interface to cite -- the fold fits are the admm_lasso / admm_enet path
@@ -155,6 +153,8 @@ ADMM_HIP_API int admm_hip_lasso_multi(const double* x, const double* Y, int n, i
                          int standardize, int intercept, double alpha, const admm_opts* opts,
                          double* lambda_out, float* beta_out, int* niter_out, admm_stats* stats);
 
+/* Row-block consensus ADMM with `nthread` blocks (ParLasso.cpp:33-36,71-72: nthread only sets the
+ * number of blocks K).  All K blocks run on the current device. */
 ADMM_HIP_API int admm_hip_parlasso(const double* x, const double* y, int n, int p, int mem,
                       const double* lambda_in, int nlambda_in, int nlambda_auto, double lmin_ratio,
                       int standardize, int intercept, int nthread, const admm_opts* opts,
@@ -214,6 +214,18 @@ ADMM_HIP_API int admm_hip_lad_traced(const double* x, const double* y, int n, in
 ADMM_HIP_API int admm_hip_bp_traced(const double* x, const double* y, int n, int p, int mem, const admm_opts* opts,
                        double* beta_out, int* niter_out, admm_stats* stats, double* trace_out, long long trace_cap, long long* ntrace_out);
 
+/* admm_hip_lad_traced / admm_hip_bp_traced that also return the ITERATE DUMP (test / diagnosis facility, oracle/stepcheck.py):
+ * state_out receives min(decisions taken, state_cap) records of 5 * dim doubles  x | z | y | adj_z | adj_y  (main_x, aux_z, dual_y
+ * and the extrapolated pair the iteration started from, FADMMBase.h:185-211; dim = n for LAD, ADMMLAD.h:62-107, p for BP,
+ * ADMMBP.h:48-93), record s = the iterates trace record s judged; record 0 (the cold start) carries in its x slot the data
+ * vector as the library holds it (LAD: the standardised y; BP: A'(AA')^-1 b, ADMMBP.h:170).  Needs trace_cap > 0. */
+ADMM_HIP_API int admm_hip_lad_state(const double* x, const double* y, int n, int p, int mem, int intercept, const admm_opts* opts,
+                       double* beta_out, int* niter_out, admm_stats* stats, double* trace_out, long long trace_cap, long long* ntrace_out,
+                       double* state_out, long long state_cap, long long* nstate_out);
+ADMM_HIP_API int admm_hip_bp_state(const double* x, const double* y, int n, int p, int mem, const admm_opts* opts,
+                      double* beta_out, int* niter_out, admm_stats* stats, double* trace_out, long long trace_cap, long long* ntrace_out,
+                      double* state_out, long long state_cap, long long* nstate_out);
+
 /* Prepared-problem variant of the Lasso family (the "persistent context" anticipated for a
  * re-fitting caller; the R shim does not need it).  create = everything the reference does
  * before its lambda loop (copy/convert, DataStd, X'y, Gram, Spectra, factorisation:
@@ -252,18 +264,24 @@ ADMM_HIP_API int admm_hip_lasso_plan_destroy(admm_hip_plan* plan);
 #define ADMM_TRACE_CONTINUE 1       /* wide / consensus solvers (no acceleration): not converged    (ADMMBase.h:206-207, PADMMBase.h:230-231) */
 ADMM_HIP_API int admm_hip_lasso_plan_trace_enable(admm_hip_plan* plan, long long capacity_records);
 ADMM_HIP_API int admm_hip_lasso_plan_trace_read(admm_hip_plan* plan, double* out, long long cap_records, long long* nrecords_out);
-/* Iterate dump of a prepared problem (tall and consensus solvers; test / diagnosis facility): the vectors every ADMM
+/* Iterate dump of a prepared problem (tall, wide and consensus solvers; test / diagnosis facility): the vectors every ADMM
  * iteration leaves behind, in the solver's own (standardised) units, one record per decision with the SAME numbering as
  * the decision trace -- record s holds the iterates whose residuals trace record s judged (record 0, the cold start, is
  * zero).  Tall solver (FADMMBase.h:185-211): 5 p floats  x | z | y | adj_z | adj_y  (main_x, aux_z, dual_y and the
  * extrapolated pair the iteration started from).  Consensus solver (PADMMBase.h:174-214), K row blocks:
- * (1 + 2 K) p floats  z | x_0 .. x_{K-1} | y_0 .. y_{K-1}.  With it a test can replay the reference's arithmetic for
+ * (1 + 2 K) p floats  z | x_0 .. x_{K-1} | y_0 .. y_{K-1}.  Wide solver (ADMMBase.h:158-216, ADMMLassoWide.h:129-170; single process):
+ * p + 3 n floats  x | A x | z | y  (main_x, cache_Ax, aux_z, dual_y), written by the two-launch path and by the persistent
+ * active-set launches alike; record 0 is zero.  With it a test can replay the reference's arithmetic for
  * ONE iteration from the library's own previous iterates (oracle/stepcheck.py): every step of a run is then checked on its
  * own, however far two executions have drifted apart over hundreds of iterations at the rounding floor.
  * enable() before run(); read() afterwards (out may be NULL with cap_records = 0 to query the sizes). */
 /* Test hook: the float system matrix X'X + rho I (p x p, column-major, leading dimension ld >= p) the tall solver's x-update solves,
  * as THIS library formed it (its Gram rounds differently from anybody else's).  Only kept with ADMM_HIP_REFINE=1. */
 ADMM_HIP_API int admm_hip_lasso_plan_system_read(admm_hip_plan* plan, float* out, long long ld);
+/* Test hook: the standardised data as the WIDE solver holds them -- X (n x p floats, column-major, leading dimension ld >= n) and
+ * Y (n floats): DataStd's statistics are accumulated in double here, so the library's X differs from any other
+ * standardisation in the last bit, and a stepwise replay of its mat-vecs needs ITS matrix.  Either output may be NULL. */
+ADMM_HIP_API int admm_hip_lasso_plan_data_read(admm_hip_plan* plan, float* x_out, long long ld, float* y_out);
 ADMM_HIP_API int admm_hip_lasso_plan_state_enable(admm_hip_plan* plan, long long capacity_records);
 ADMM_HIP_API int admm_hip_lasso_plan_state_read(admm_hip_plan* plan, float* out, long long cap_records, long long* nrecords_out,
                                                 long long* record_floats_out);

@@ -33,6 +33,8 @@ def _attach(solver, detail):
         solver.trace = detail["trace"]
     if detail.get("state") is not None:
         solver.state_log = detail["state"]
+    if detail.get("types") is not None:
+        solver.type_log = detail["types"]
     if detail.get("follow") is not None:
         solver.follow = iter(detail["follow"])
         solver.follow_band = float(detail.get("follow_band", 8.0))

@@ -335,6 +335,8 @@ class ADMMPlain:
     forced = None
     ndecisions = 0
     lam_idx = 0
+    state_log = None  # set to a list to collect (x, Ax, z, y) of every iteration, like admm_hip_lasso_plan_state_* of the wide solver (oracle/stepcheck.py)
+    type_log = None   # set to a list to collect the kind of every x-update (0 zero, 1 regular, 2 active set: trace field 7 of libadmm_hip)
 
     def _noise(self):
         """One-ulp noise floors of r_p = ||Ax + z|| and r_d = rho sqrt(gamma) ||z_new - z|| (ADMMLassoWide.h:166-186)."""
@@ -353,6 +355,8 @@ class ADMMPlain:
             r = self.next_residual()
             self.resid_primal = np.float64(F(np.linalg.norm(r)))
             self.dual_y = (self.dual_y + F(self.rho) * r).astype(F)
+            if self.state_log is not None:
+                self.state_log.append(np.concatenate([self.main_x, self.cache_Ax, self.aux_z, self.dual_y]).astype(F))
             converged = self.resid_primal < self.eps_primal and self.resid_dual < self.eps_dual
             rho_in = self.rho
             self.ndecisions += 1
@@ -477,16 +481,15 @@ class LassoWide(ADMMPlain):
     def next_x(self):
         if self.alpha is None:                                              # ADMMLassoWide.h:129-155
             if np.float64(self.lam) > np.float64(self.lambda0) - 1e-5:
+                if self.type_log is not None:
+                    self.type_log.append(0)
                 return np.zeros(self.p, F)
-            if is_regular_update(self.iter_counter):
-                res = self._regular_update()
-            else:
-                res = self._active_set_update()
+            reg = is_regular_update(self.iter_counter)
         else:                                                               # ADMMEnet.h:124-141
-            if is_regular_update(self.iter_counter) and self.lam < self.lambda0:
-                res = self._regular_update()
-            else:
-                res = self._active_set_update()
+            reg = is_regular_update(self.iter_counter) and self.lam < self.lambda0
+        if self.type_log is not None:
+            self.type_log.append(1 if reg else 2)
+        res = self._regular_update() if reg else self._active_set_update()
         self.iter_counter += 1
         self.trace_nnz.append(int(np.count_nonzero(res)))
         return res

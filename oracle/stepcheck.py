@@ -23,6 +23,17 @@ dump of admm_hip_lasso_plan_state_* (record s = the vectors trace record s judge
                      double ones: a decision that differs between the two is counted (it is a tie inside the rounding
                      of one norm, the only way the reference could decide differently on the same iterates).
 
+Round 4: the same for the solvers that were held by the follow rule alone --
+    check_wide    ADMMBase::solve (ADMMBase.h:158-216) with ADMMLassoWide / ADMMEnetWide (ADMMLassoWide.h:70-186, ADMMEnet.h:62-141):
+                  dump x | A x | z | y per decision; the two mat-vecs (X't in the x-update, X x for the cache) are held to the
+                  first-order yardstick of a float dot product, everything else -- the prox's zero pattern on active-set steps,
+                  z, y, the thresholds, residuals, the stopping test, the rho adaptation (ADMMBase.h:85-109) and the regular /
+                  active-set schedule (ADMMLassoWide.h:121-155) -- exactly;
+    check_dense   FADMMBase::solve with ADMMLAD (ADMMLAD.h:62-107,152-169) / ADMMBP (ADMMBP.h:48-93,138-153), float64: dump
+                  x | z | y | adj_z | adj_y; the projection is held against a Householder-QR projection (yardstick: what the
+                  reference's own normal-equation solve misses it by), the elementwise steps bit for bit, decisions incl. the rho
+                  adaptation (FADMMBase.h:109-133) exactly.
+
 Returns a report; `assert_*` raise AssertionError with the first offending record.
 """
 import numpy as np
@@ -30,7 +41,7 @@ import scipy.linalg as sla
 
 from .datastd import DataStd
 from .entry import _lambda_grid
-from .solvers import F, LassoTall, PADMMLasso, _enet_f, _soft_d
+from .solvers import F, LassoTall, PADMMLasso, _enet_f, _rho_rule, _soft_d, is_regular_update
 
 
 def _strip(trace):
@@ -329,4 +340,324 @@ def assert_stepwise(rep, label="", x_factor=4.0, max_accum_tie_rate=0.01, norm_t
     assert rep["norm_rel_max"] < norm_tol, (label, "recorded thresholds / residuals differ from the dumped iterates", rep["norm_rel_max"])
     allowed = max(2, int(np.ceil(max_accum_tie_rate * rep["decisions_checked"])))
     assert len(rep["accum_ties"]) <= allowed, (label, "decisions that float norm accumulation would flip", len(rep["accum_ties"]), rep["accum_ties"][:8])
+    return rep
+
+
+# ---------------------------------------------------------------------------------------------------------------- wide
+def check_wide(problem, trace, state, gamma, X=None, Y=None, label=""):
+    """Wide Lasso / elastic net (n <= p).  problem: the oracle's arguments; trace: libadmm_hip's decision trace INCLUDING the
+    cold-start record; state: (nrec, p + 3 n) iterate dump  x | A x | z | y;  gamma: the library's spectral-radius estimate
+    (admm_stats.eig_est -- a float);  X, Y: the standardised data as the LIBRARY holds them (admm_hip_lasso_plan_data_read; its
+    DataStd statistics accumulate in double, so its X differs from the oracle's in the last bit -- measured against the oracle's
+    X that difference would be booked as an error of the mat-vecs); None: the oracle's own standardisation."""
+    x = np.asarray(problem["x"], dtype=np.float64)
+    y = np.asarray(problem["y"], dtype=np.float64)
+    n, p = x.shape
+    opts = problem["opts"]
+    alpha = problem.get("alpha")
+    datX = np.array(x, dtype=F, order="F")
+    datY = np.array(y, dtype=F)
+    std = DataStd(n, p, problem["standardize"], problem["intercept"], F)
+    std.standardize(datX, datY)
+    if X is not None:
+        X = np.asarray(X, dtype=F)
+        sc = np.abs(datX).max(axis=0) + 1e-30
+        assert (np.abs(X - datX).max(axis=0) <= 64 * np.spacing(sc.astype(F))).all(), (label, "the library's standardised X differs from the oracle's beyond rounding")
+        datX = X
+    if Y is not None:
+        Y = np.asarray(Y, dtype=F)
+        assert np.abs(Y - datY).max() <= 64 * np.spacing(F(np.abs(datY).max())), (label, "the library's standardised y differs from the oracle's beyond rounding")
+        datY = Y
+    X64 = datX.astype(np.float64)
+    Xabs = np.abs(X64)
+    gam_f = F(gamma)
+    gam = np.float64(gam_f)
+    sqrt_gam = np.float64(F(np.sqrt(gam_f)))                    # (double)std::sqrt(sprad) of a float
+    lambda0 = F(np.abs((datX.T @ datY).astype(F)).max())
+    if alpha is not None:
+        lambda0 = F(lambda0 / (np.float64(F(alpha)) + 0.0001))
+    t = _strip(trace)
+    assert t[0, 8] == -1, "the trace must start with the cold-start record"
+    S = np.asarray(state, dtype=F)
+    assert S.shape[1] == p + 3 * n, (label, "record size", S.shape, p, n)
+    nrec = min(len(t), len(S))
+    u = float(np.finfo(F).eps) / 2
+    eps_abs, eps_rel = float(opts["eps_abs"]), float(opts["eps_rel"])
+    sqrt_n, sqrt_p = np.sqrt(float(n)), np.sqrt(float(p))
+    maxit = int(opts["maxit"])
+    rep = dict(records=nrec - 1, bit_mismatch=[], accum_ties=[], decisions_checked=0, norm_rel_max=0.0, xt_ratio_max=0.0, ax_ratio_max=0.0,
+               kinds={0: 0, 1: 0, 2: 0}, rho_changes=0)
+    d64 = lambda v: float(np.sqrt(np.sum(v.astype(np.float64) ** 2)))
+    zero = np.zeros(p + 3 * n, F)
+    counter = 0
+    sx = sa = sb_x = sb_a = 0.0
+
+    def split(rec):
+        return rec[:p], rec[p:p + n], rec[p + n:p + 2 * n], rec[p + 2 * n:]
+
+    for k in range(1, nrec):
+        xg, axg, zg, yg = split(S[k])
+        xp_, axp, zp, yp = split(S[k - 1] if k > 1 else zero)
+        li, it = int(t[k, 0]), int(t[k, 1])
+        rho = float(t[k, 9])
+        rho_f = F(rho)
+        lam = F(t[k, 11])
+        kind = int(t[k - 1, 7])
+        # ---- the schedule (ADMMLassoWide.h:121-155 / ADMMEnet.h:124-141): what kind of x-update this iteration had to be
+        if it == 0:
+            counter = 0                                          # init / init_warm
+        # (the first lambda of an automatic grid IS lambda_0 up to the rounding of lambda_0 / n * scaleY * n / scaleY, and the
+        # library's lambda_0 = max|X'y| comes from ITS summation order: within a few ulps of it the comparison is a coin toss by
+        # construction -- the recorded kind is taken, the counter follows it)
+        tie = abs(np.float64(lam) - np.float64(lambda0)) <= 16 * np.spacing(np.float64(lambda0).astype(F)) + (1e-5 if alpha is None else 0.0)
+        if alpha is None:
+            if (np.float64(lam) > np.float64(lambda0) - 1e-5) if not tie else (kind == 0):
+                want = 0
+            else:
+                want = 1 if is_regular_update(counter) else 2
+                counter += 1
+        else:
+            below = (lam < lambda0) if not tie else (kind == 1)
+            want = 1 if (is_regular_update(counter) and below) else 2
+            counter += 1
+        assert kind == want, (label, f"record {k} (lambda {li}, iteration {it}): x-update kind {kind}, the schedule gives {want}")
+        rep["kinds"][kind] += 1
+        # ---- x-update
+        tvec = ((axp + zp).astype(F) + (yp / rho_f).astype(F)).astype(F)             # cache_Ax + aux_z + dual_y / Scalar(rho)
+        pen_d = np.float64(lam) / (rho * gam)
+        if kind == 0:
+            if np.any(xg != 0):
+                rep["bit_mismatch"].append((k, li, it, "x must be zero above lambda_0", int((xg != 0).sum())))
+        else:
+            if kind == 1:
+                cols = np.arange(p)
+                tt = tvec.astype(np.float64)
+                d = X64.T @ tt
+                vec = -d / gam + xp_.astype(np.float64)
+                if alpha is None:
+                    xe = np.where(vec > pen_d, vec - pen_d, np.where(vec < -pen_d, vec + pen_d, 0.0))
+                else:
+                    th = np.float64(F(np.float64(F(alpha)) * pen_d)); den = np.float64(F(1.0 + pen_d * (1.0 - np.float64(F(alpha)))))
+                    xe = np.where(vec > th, (vec - th) / den, np.where(vec < -th, (vec + th) / den, 0.0))
+                B = u * (Xabs.T @ np.abs(tt) / gam + 2.0 * np.abs(vec) + np.abs(xp_.astype(np.float64)))
+            else:
+                cols = np.nonzero(xp_)[0]
+                off = np.ones(p, bool); off[cols] = False
+                if np.any(xg[off] != 0):                         # active-set step: a zero stays zero (SparseVector: only stored entries are visited)
+                    rep["bit_mismatch"].append((k, li, it, "a zero coordinate became non-zero on an active-set step", int((xg[off] != 0).sum())))
+                tmp = (tvec / gam_f).astype(F).astype(np.float64)                     # tmp = (...) / gamma, a float vector (:90)
+                pen_f = np.float64(F(pen_d))                                          # `const Scalar penalty`
+                d = X64[:, cols].T @ tmp
+                vec = xp_[cols].astype(np.float64) - d
+                if alpha is None:
+                    xe = np.where(vec > pen_f, vec - pen_f, np.where(vec < -pen_f, vec + pen_f, 0.0))
+                else:
+                    th = np.float64(F(F(alpha) * F(pen_d))); den = np.float64(F(1.0 + pen_f * (1.0 - np.float64(F(alpha)))))
+                    xe = np.where(vec > th, (vec - th) / den, np.where(vec < -th, (vec + th) / den, 0.0))
+                B = u * (Xabs[:, cols].T @ np.abs(tmp) + 2.0 * np.abs(vec) + np.abs(xp_[cols].astype(np.float64)))
+            e = float(np.linalg.norm(xg[cols].astype(np.float64) - xe))
+            b = float(np.linalg.norm(B))
+            sx += e * e; sb_x += b * b
+            if e / max(b, 1e-300) > rep["xt_ratio_max"]:
+                rep.update(xt_ratio_max=e / max(b, 1e-300), xt_worst=(k, li, it, kind, e, b))
+        # ---- cache_Ax = X x  (ADMMLassoWide.h:158-161)
+        nz = np.nonzero(xg)[0]
+        xa = xg[nz].astype(np.float64)
+        axe = X64[:, nz] @ xa
+        Ba = u * (Xabs[:, nz] @ np.abs(xa) + np.abs(axe))
+        e, b = float(np.linalg.norm(axg.astype(np.float64) - axe)), float(np.linalg.norm(Ba))
+        sa += e * e; sb_a += b * b
+        if e / max(b, 1e-300) > rep["ax_ratio_max"] and (e > 0):
+            rep.update(ax_ratio_max=e / max(b, 1e-300), ax_worst=(k, li, it, int(nz.size), e, b))
+        if nz.size == 0 and np.any(axg != 0):
+            rep["bit_mismatch"].append((k, li, it, "A x of a zero x", int((axg != 0).sum())))
+        # ---- z, y from the library's own A x: elementwise, bit for bit (ADMMLassoWide.h:156-170, ADMMBase.h:176-184)
+        zn = (((datY + yp).astype(F) + (rho_f * axg).astype(F)).astype(F) / F(-1.0 - rho)).astype(F)
+        if not np.array_equal(zn, zg):
+            rep["bit_mismatch"].append((k, li, it, "z", int((zn != zg).sum())))
+        r = (axg + zg).astype(F)
+        yn = (yp + (rho_f * r).astype(F)).astype(F)
+        if not np.array_equal(yn, yg):
+            rep["bit_mismatch"].append((k, li, it, "y", int((yn != yg).sum())))
+        # ---- thresholds / residuals / decision / rho adaptation
+        eps_p = max(d64(axp), d64(zp)) * eps_rel + sqrt_n * eps_abs
+        eps_d = sqrt_gam * d64(yp) * eps_rel + sqrt_p * eps_abs
+        rp = d64(r)
+        rd = rho * sqrt_gam * d64((zg - zp).astype(F))
+        for got, want_v in ((t[k, 2], eps_p), (t[k, 3], eps_d), (t[k, 4], rp), (t[k, 5], rd)):
+            rep["norm_rel_max"] = max(rep["norm_rel_max"], abs(got - want_v) / max(abs(want_v), 1e-300))
+        code = int(t[k, 8])
+        own = 0 if (rp < eps_p and rd < eps_d) else 1
+        assert own == code, (label, f"record {k} (lambda {li}, iteration {it}): the library decided {code}, the rule on its own iterates gives {own}",
+                             dict(eps_p=eps_p, eps_d=eps_d, rp=rp, rd=rd))
+        rpf = _rule_float_norm(r)
+        rdf = rho * sqrt_gam * _rule_float_norm((zg - zp).astype(F))
+        eps_pf = max(_rule_float_norm(axp), _rule_float_norm(zp)) * eps_rel + sqrt_n * eps_abs
+        eps_df = sqrt_gam * _rule_float_norm(yp) * eps_rel + sqrt_p * eps_abs
+        if (0 if (rpf < eps_pf and rdf < eps_df) else 1) != code:
+            rep["accum_ties"].append((k, li, it, code, 1 - code))
+        class _R:
+            pass
+        q = _R()
+        q.rho, q.eps_primal, q.eps_dual, q.resid_primal, q.resid_dual = rho, eps_p, eps_d, rp, rd
+        if code != 0 and it > 3:
+            _rho_rule(q)                                         # ADMMBase.h:85-109, from i > 3 (:209-210)
+        assert abs(q.rho - t[k, 10]) <= 1e-12 * abs(q.rho), (label, f"record {k}: rho after the decision {t[k, 10]}, the rule gives {q.rho}")
+        if q.rho != rho:
+            rep["rho_changes"] += 1
+        if k + 1 < nrec:                                         # what the next iteration runs with
+            nxt = t[k + 1]
+            fin = code == 0 or it + 1 >= maxit
+            assert (int(nxt[0]), int(nxt[1])) == ((li + 1, 0) if fin else (li, it + 1)), (label, f"record {k + 1}: (lambda, iteration) after record {k}", nxt[:2], fin)
+            assert abs(nxt[9] - q.rho) <= 1e-12 * abs(q.rho), (label, f"record {k + 1} ran with rho {nxt[9]}, the decision before it left {q.rho}")
+        rep["decisions_checked"] += 1
+    rep["xt_rms"] = float(np.sqrt(sx / sb_x)) if sb_x > 0 else 0.0
+    rep["ax_rms"] = float(np.sqrt(sa / sb_a)) if sb_a > 0 else 0.0
+    return rep
+
+
+def assert_stepwise_wide(rep, label="", mv_factor=4.0, mv_rms=1.0, max_accum_tie_rate=0.01, norm_tol=1e-9):
+    """check_wide's report is clean: zero pattern, z, y bit-exact; the two mat-vecs within `mv_factor` x (per record) and
+    `mv_rms` x (over the run) the first-order yardstick of a float dot product (one unit roundoff on every term); recorded
+    thresholds / residuals equal to the recomputed ones; decisions, rho adaptation and schedule the rule's (asserted inside)."""
+    assert not rep["bit_mismatch"], (label, "elementwise steps differ from the reference's arithmetic", rep["bit_mismatch"][:8], len(rep["bit_mismatch"]))
+    assert rep["xt_ratio_max"] <= mv_factor, (label, f"x-update (X't) error is {rep['xt_ratio_max']:.2f} x the float dot-product yardstick at {rep.get('xt_worst')}")
+    assert rep["ax_ratio_max"] <= mv_factor, (label, f"A x error is {rep['ax_ratio_max']:.2f} x the float dot-product yardstick at {rep.get('ax_worst')}")
+    assert rep["xt_rms"] <= mv_rms and rep["ax_rms"] <= mv_rms, (label, "mat-vec error over the run (rms, in yardsticks)", rep["xt_rms"], rep["ax_rms"])
+    assert rep["norm_rel_max"] < norm_tol, (label, "recorded thresholds / residuals differ from the dumped iterates", rep["norm_rel_max"])
+    allowed = max(2, int(np.ceil(max_accum_tie_rate * rep["decisions_checked"])))
+    assert len(rep["accum_ties"]) <= allowed, (label, "decisions that float norm accumulation would flip", len(rep["accum_ties"]), rep["accum_ties"][:8])
+    return rep
+
+
+# ---------------------------------------------------------------------------------------------------------------- LAD / BP
+def check_dense(kind, x, y, opts, trace, state, intercept=True, label=""):
+    """LAD (kind "lad": x n x p, n > p; dim n) / BP ("bp": x = A n x p, p > n; dim p), float64.  trace: libadmm_hip's decision
+    trace INCLUDING the cold-start record; state: (nrec, 5, dim) iterate dump  x | z | y | adj_z | adj_y  (record 0: the data
+    vector as the library holds it in the x slot)."""
+    x = np.array(x, dtype=np.float64, order="F")
+    y = np.array(y, dtype=np.float64)
+    n, p = x.shape
+    t = _strip(trace)
+    assert t[0, 8] == -1, "the trace must start with the cold-start record"
+    S = np.asarray(state, dtype=np.float64)
+    dim = n if kind == "lad" else p
+    S = S.reshape(len(S), 5, dim)
+    nrec = min(len(t), len(S))
+    dvec = S[0, 0].copy()
+    if kind == "lad":
+        std = DataStd(n, p, True, intercept, np.float64)        # LAD.cpp:34
+        std.standardize(x, y)
+        assert np.abs(dvec - y).max() <= 64 * np.spacing(np.abs(y).max()), (label, "the library's standardised y differs from the oracle's beyond rounding")
+        Q, _ = np.linalg.qr(x)                                   # range(X): P = Q Q'
+        chol = sla.cho_factor(x.T @ x, lower=True, check_finite=False)     # the reference's route (ADMMLAD.h:75-76,186-189)
+        extra = float(np.linalg.norm(dvec))
+        proj = lambda v: Q @ (Q.T @ v)
+        ref_x = lambda v: x @ sla.cho_solve(chol, x.T @ v, check_finite=False)
+    else:
+        Q, R = np.linalg.qr(x.T)                                 # A' = Q R: null-space projector I - Q Q', A^+ b = Q R^-T b
+        aaab = Q @ sla.solve_triangular(R, y, trans="T", check_finite=False)
+        assert np.abs(dvec - aaab).max() <= 1e-9 * max(np.abs(aaab).max(), 1e-300), (label, "A'(AA')^-1 b differs from the oracle's", np.abs(dvec - aaab).max())
+        chol = sla.cho_factor(x @ x.T, lower=True, check_finite=False)
+        LinvA = sla.solve_triangular(np.tril(chol[0]), x, lower=True, check_finite=False)
+        extra = 0.0
+        proj = lambda v: v + dvec - Q @ (Q.T @ v)
+        ref_x = lambda v: (v + dvec) - LinvA.T @ (LinvA @ v)     # ADMMBP.h:48-67
+    eps_abs, eps_rel, sqrt_dim = float(opts["eps_abs"]), float(opts["eps_rel"]), np.sqrt(float(dim))
+    maxit = int(opts["maxit"])
+    nrm = lambda v: float(np.sqrt(np.sum(v * v)))
+    zero = np.zeros(dim)
+    rep = dict(records=nrec - 1, bit_mismatch=[], decisions_checked=0, norm_rel_max=0.0, x_vs_ref_max=0.0, x_rel_max=0.0, rho_changes=0)
+    a, c_old = 1.0, 9999.0
+    sg = sr = 0.0
+
+    def vecs(k):
+        return (zero,) * 5 if k <= 0 else tuple(S[k, j] for j in range(5))
+
+    for k in range(1, nrec):
+        xg, zg, yg, ajz, ajy = vecs(k)
+        xp_, zp, yp, _, _ = vecs(k - 1)
+        _, zpp, ypp, _, _ = vecs(k - 2)
+        it = int(t[k, 1])
+        rho = float(t[k, 9])
+        prev_code = int(t[k - 1, 8])
+        assert it == k - 1, (label, "iteration number", k, it)
+        # ---- adj of this iteration from the previous decision (FADMMBase.h:243-256)
+        if k == 1:
+            ez, ey = zero, zero
+        elif prev_code == 1:
+            a_new = 0.5 + 0.5 * np.sqrt(1.0 + 4.0 * a * a)
+            ratio = (a - 1.0) / a_new
+            ez = (1.0 + ratio) * zp - ratio * zpp
+            ey = (1.0 + ratio) * yp - ratio * ypp
+            a = a_new
+        else:
+            assert prev_code == 2, (label, "a converged decision ends a LAD / BP run", k, prev_code)
+            ez, ey, a = zpp, ypp, 1.0
+        if not (np.array_equal(ez, ajz) and np.array_equal(ey, ajy)):
+            rep["bit_mismatch"].append((k, it, "adj", int((ez != ajz).sum() + (ey != ajy).sum())))
+        # ---- x-update: the projection (ADMMLAD.h:62-78 / ADMMBP.h:48-67) against Householder QR
+        vec = (dvec if kind == "lad" else 0.0) - ajy / rho + ajz
+        xe = proj(vec)
+        xr = ref_x(vec)
+        e_gpu, e_ref = nrm(xg - xe), nrm(xr - xe)
+        floor = 64 * np.finfo(np.float64).eps * max(nrm(vec), nrm(xe))
+        sg += e_gpu ** 2; sr += max(e_ref, floor) ** 2
+        rep["x_rel_max"] = max(rep["x_rel_max"], e_gpu / max(nrm(xe), 1e-300))
+        if e_gpu / max(e_ref, floor) > rep["x_vs_ref_max"]:
+            rep.update(x_vs_ref_max=e_gpu / max(e_ref, floor), x_worst=(k, it, e_gpu, e_ref, floor))
+        # ---- z, y from the library's own x: elementwise, bit for bit
+        pen = 1.0 / rho
+        if kind == "lad":
+            v = xg - dvec + ajy / rho                            # ADMMLAD.h:94-98
+            zn = np.where(v > pen, v - pen, np.where(v < -pen, v + pen, 0.0))
+            r = xg - dvec - zg                                   # :99-107
+        else:
+            v = xg + ajy / rho                                   # ADMMBP.h:84-88
+            zn = np.where(v > pen, v - pen, np.where(v < -pen, v + pen, 0.0))
+            r = xg - zg
+        if not np.array_equal(zn, zg):
+            rep["bit_mismatch"].append((k, it, "z", int((zn != zg).sum())))
+        yn = ajy + rho * r
+        if not np.array_equal(yn, yg):
+            rep["bit_mismatch"].append((k, it, "y", int((yn != yg).sum())))
+        # ---- thresholds / residuals / decision / rho adaptation (FADMMBase.h:109-133,213-259)
+        eps_p = max(nrm(xp_), nrm(zp), extra) * eps_rel + sqrt_dim * eps_abs
+        eps_d = nrm(yp) * eps_rel + sqrt_dim * eps_abs
+        rp, rd = nrm(r), rho * nrm(zg - zp)
+        c = rho * rp * rp + rho * float(np.sum((zg - ajz) ** 2))
+        code = int(t[k, 8])
+        for got, want in ((t[k, 2], eps_p), (t[k, 3], eps_d), (t[k, 4], rp), (t[k, 5], rd)) + (((t[k, 6], c),) if code != 0 else ()):
+            rep["norm_rel_max"] = max(rep["norm_rel_max"], abs(got - want) / max(abs(want), 1e-300))
+        own = 0 if (rp < eps_p and rd < eps_d) else (1 if c < 0.999 * c_old else 2)
+        assert own == code, (label, f"record {k} (iteration {it}): the library decided {code}, the rule on its own iterates gives {own}",
+                             dict(eps_p=eps_p, eps_d=eps_d, rp=rp, rd=rd, c=c, c_old=c_old))
+        class _R:
+            pass
+        q = _R()
+        q.rho, q.eps_primal, q.eps_dual, q.resid_primal, q.resid_dual = rho, eps_p, eps_d, rp, rd
+        if code != 0 and it > 5:
+            _rho_rule(q)
+        assert abs(q.rho - t[k, 10]) <= 1e-12 * abs(q.rho), (label, f"record {k}: rho after the decision {t[k, 10]}, the rule gives {q.rho}")
+        if q.rho != rho:
+            rep["rho_changes"] += 1
+        if k + 1 < nrec:
+            assert code != 0 and abs(t[k + 1, 9] - q.rho) <= 1e-12 * abs(q.rho), (label, f"record {k + 1} ran with rho {t[k + 1, 9]}, the decision before it left {q.rho}")
+        rep["decisions_checked"] += 1
+        if code == 1:
+            c_old = c
+        elif code == 2:
+            c_old = c_old / 0.999
+    rep["x_rms_vs_ref"] = float(np.sqrt(sg / sr)) if sr > 0 else 0.0
+    return rep
+
+
+def assert_stepwise_dense(rep, label="", x_factor=8.0, x_rms_factor=3.0, norm_tol=1e-9):
+    """check_dense's report is clean: adj, z, y bit-exact; the projection within `x_factor` x (per record) / `x_rms_factor` x
+    (rms over the run) of what the reference's own normal-equation route misses the QR projection by (floored at 64 ulps of
+    the operand); recorded thresholds / residuals / c equal to the recomputed ones; decisions and rho adaptation the rule's."""
+    assert not rep["bit_mismatch"], (label, "elementwise steps differ from the reference's arithmetic", rep["bit_mismatch"][:8], len(rep["bit_mismatch"]))
+    assert rep["x_vs_ref_max"] <= x_factor, (label, f"projection error is {rep['x_vs_ref_max']:.2f} x the reference route's at {rep.get('x_worst')}")
+    assert rep["x_rms_vs_ref"] <= x_rms_factor, (label, "projection error over the run (rms) against the reference route's", rep["x_rms_vs_ref"])
+    assert rep["norm_rel_max"] < norm_tol, (label, "recorded thresholds / residuals differ from the dumped iterates", rep["norm_rel_max"])
     return rep

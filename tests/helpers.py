@@ -94,19 +94,46 @@ def assert_near_tie_budget(forced, ndecisions, label="", enabled=True):
     assert st["total"] <= allowed, (label, f"{st['total']} of {ndecisions} decisions taken from the GPU as near-ties; at most {allowed} allowed")
 
 
-def traced_fit(model, capacity=1 << 18, state=False):
+def traced_fit(model, capacity=1 << 18, state=False, data=False):
     """Run a configured ADMM_Lasso / ADMM_Enet model through the prepared-problem entry points with the decision trace
-    (and, with state=True, the iterate dump of every iteration: returns (fit, trace, state))."""
+    (and, with state=True or a record count, the iterate dump of every iteration: returns (fit, trace, state); with data=True
+    -- wide solver -- also the standardised (X, Y) as the library holds them: (fit, trace, state, (X, Y)))."""
     from admm_amd.api import LassoPlan
     plan = LassoPlan(model)
     plan.enable_trace(capacity)
     if state:
-        plan.enable_state(capacity)
+        plan.enable_state(capacity if state is True else int(state))
     fit = plan.run()
     trace = plan.read_trace()
     st = plan.read_state() if state else None
+    xy = plan.read_data() if data else None
     plan.close()
+    if data:
+        return fit, trace, st, xy
     return (fit, trace, st) if state else (fit, trace)
+
+
+STEPWISE_MAX_ELEMS = 120_000_000    # the CPU replay holds X and |X| in double: beyond this many entries the stepwise rule is skipped
+WIDE_STATE_BYTES = 1 << 30          # iterate dump of the wide solver: at most this much (records x (p + 3 n) floats)
+
+
+def wide_stepwise(fit, trace, st, xy, problem, label=""):
+    """oracle/stepcheck.py on the wide solver's iterate dump (as many records as were captured): every iteration the library made
+    is the reference's iteration applied to the library's own previous iterates -- zero pattern, z, y bit for bit, the two
+    mat-vecs within the float dot-product yardstick, thresholds / residuals / decisions / rho adaptation / schedule exact."""
+    from oracle import stepcheck
+    rep = stepcheck.check_wide(problem, trace, st, fit.stats["eig_est"], X=xy[0], Y=xy[1], label=label)
+    stepcheck.assert_stepwise_wide(rep, label=label)
+    print(f"[stepwise {label}] {rep['decisions_checked']} iterations replayed (zero / regular / active-set {rep['kinds'][0]} / {rep['kinds'][1]} / {rep['kinds'][2]}; "
+          f"{rep['rho_changes']} rho changes): z, y, zero pattern bit-exact; X't within {rep['xt_ratio_max']:.2f} (rms {rep['xt_rms']:.2f}), "
+          f"A x within {rep['ax_ratio_max']:.2f} (rms {rep['ax_rms']:.2f}) float-dot yardsticks; norms {rep['norm_rel_max']:.1e}; "
+          f"{len(rep['accum_ties'])} float-accumulator ties")
+    return rep
+
+
+def wide_state_records(problem, cap):
+    n, p = np.asarray(problem["x"]).shape
+    return int(max(16, min(cap, WIDE_STATE_BYTES // (4 * (p + 3 * n)))))
 
 
 def assert_rho_self_consistent(trace, first_iter, label=""):
@@ -325,14 +352,37 @@ def assert_dense_followed(kind, fit_beta, fit_niter, trace, x, y, opts, intercep
 
 def traced_parity(model, problem, tol=1e-4, label="", capacity=None, **kw):
     """Fit a configured ADMM_Lasso / ADMM_Enet model with the decision trace and judge it by the rule above (R1-R4): the tall
-    rule for n > p without $parallel(), the followed rule for the wide and consensus solvers.  `problem` = the oracle's
+    rule for n > p without $parallel(), the followed rule for the wide and consensus solvers -- the wide solver ALSO by the
+    stepwise rule on its iterate dump (wide_stepwise).  `problem` = the oracle's
     arguments (dict x, y, lam, nlambda, lmin_ratio, standardize, intercept, opts, alpha[, nthread]).  Returns (fit, report)."""
     nl = len(problem["lam"]) if problem.get("lam") is not None else int(problem["nlambda"])
     cap = capacity or max(nl, 1) * (int(problem["opts"]["maxit"]) + 2) + 8
-    fit, trace = traced_fit(model, capacity=min(cap, 1 << 22))
     n, p = np.asarray(problem["x"]).shape
+    if n <= p and problem.get("nthread") is None and n * p <= STEPWISE_MAX_ELEMS:      # wide solver: also the stepwise rule on its iterate dump
+        fit, trace, st, xy = traced_fit(model, capacity=min(cap, 1 << 22), state=wide_state_records(problem, min(cap, 1 << 22)), data=True)
+        wide_stepwise(fit, trace, st, xy, problem, label)
+    else:
+        fit, trace = traced_fit(model, capacity=min(cap, 1 << 22))
     if n > p and problem.get("nthread") is None:
         rep = assert_tall_parity(fit.beta_dense, fit.niter, trace, problem, tol, label=label, **kw)
     else:
         rep = assert_followed_parity(fit.beta_dense, fit.niter, trace, problem, tol, label=label, **kw)
     return fit, rep
+
+
+DENSE_STATE_BYTES = 1 << 30
+
+
+def dense_state_records(dim, maxit):
+    return int(max(16, min(maxit + 8, DENSE_STATE_BYTES // (8 * 5 * dim))))
+
+
+def dense_stepwise(kind, fit, x, y, opts, intercept=True, label=""):
+    """oracle/stepcheck.py on the LAD / BP iterate dump (fit.trace, fit.state of `.fit(trace=True, state=N)`): adj, z, y bit for
+    bit, the projection against Householder QR, decisions and the rho adaptation exact."""
+    from oracle import stepcheck
+    rep = stepcheck.check_dense(kind, x, y, opts, fit.trace, fit.state, intercept=intercept, label=label)
+    stepcheck.assert_stepwise_dense(rep, label=label)
+    print(f"[stepwise {label}] {rep['decisions_checked']} iterations replayed ({rep['rho_changes']} rho changes): adj / z / y bit-exact; projection within "
+          f"{rep['x_vs_ref_max']:.2f} x the reference route's error (rms {rep['x_rms_vs_ref']:.2f}; relative {rep['x_rel_max']:.1e}); norms {rep['norm_rel_max']:.1e}")
+    return rep

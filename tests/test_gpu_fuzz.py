@@ -8,7 +8,8 @@ import numpy as np
 import pytest
 
 from fuzz_cases import cases, medium_cases
-from helpers import assert_dense_followed, assert_followed_parity, assert_tall_parity, relerr, traced_fit
+from helpers import (assert_dense_followed, assert_followed_parity, assert_tall_parity, dense_state_records, relerr, traced_fit,
+                     wide_state_records)
 
 pytestmark = pytest.mark.gpu
 
@@ -50,11 +51,17 @@ def gpu_capture(cs, state=False):
     from admm_amd import admm_bp, admm_enet, admm_lad, admm_lasso
     kind = cs["kind"]
     if kind == "lad":
-        fit = admm_lad(cs["x"], cs["y"], cs["icpt"]).fit(trace=True)
-        return dict(beta=np.asarray(fit.beta, dtype=np.float64), niter=np.asarray(fit.niter), trace=np.asarray(fit.trace))
+        fit = admm_lad(cs["x"], cs["y"], cs["icpt"]).fit(trace=True, state=dense_state_records(cs["n"], 10000) if state else 0)
+        cap = dict(beta=np.asarray(fit.beta, dtype=np.float64), niter=np.asarray(fit.niter), trace=np.asarray(fit.trace))
+        if state:
+            cap["state"] = fit.state
+        return cap
     if kind == "bp":
-        fit = admm_bp(cs["x"], cs["y"]).fit(trace=True)
-        return dict(beta=fit.beta.toarray().ravel(), niter=np.asarray(fit.niter), trace=np.asarray(fit.trace))
+        fit = admm_bp(cs["x"], cs["y"]).fit(trace=True, state=dense_state_records(cs["p"], 10000) if state else 0)
+        cap = dict(beta=fit.beta.toarray().ravel(), niter=np.asarray(fit.niter), trace=np.asarray(fit.trace))
+        if state:
+            cap["state"] = fit.state
+        return cap
     prob = _lasso_problem(cs)
     if kind.startswith("enet"):
         m = admm_enet(cs["x"], cs["y"], cs["icpt"], cs["stdz"]).penalty(prob["lam"], nlambda=cs["nl"], lambda_min_ratio=prob["lmin_ratio"],
@@ -68,6 +75,10 @@ def gpu_capture(cs, state=False):
     if state and (kind == "par" and cs["K"] > 1 or kind in ("tall", "enet_tall")):
         fit, trace, st = traced_fit(m, capacity=cap, state=True)
         return dict(beta=np.asarray(fit.beta_dense), niter=np.asarray(fit.niter), trace=np.asarray(trace), state=st)
+    if state and cs["n"] <= cs["p"] and not (kind == "par" and cs["K"] > 1):      # wide solver (also what `par` with K = 1 and n <= p dispatches to)
+        fit, trace, st, xy = traced_fit(m, capacity=cap, state=wide_state_records(prob, cap), data=True)
+        return dict(beta=np.asarray(fit.beta_dense), niter=np.asarray(fit.niter), trace=np.asarray(trace), state=st, X=xy[0], Y=xy[1],
+                    gamma=float(fit.stats["eig_est"]))
     fit, trace = traced_fit(m, capacity=cap)
     return dict(beta=np.asarray(fit.beta_dense), niter=np.asarray(fit.niter), trace=np.asarray(trace))
 
@@ -75,7 +86,11 @@ def gpu_capture(cs, state=False):
 def stepwise_capture(cs, cap):
     """oracle/stepcheck.py on a capture that holds the iterate dump: the report (not asserted here)."""
     from oracle import stepcheck
+    if cs["kind"] in ("lad", "bp"):
+        return stepcheck.check_dense(cs["kind"], cs["x"], cs["y"], _dense_opts(cs["kind"]), cap["trace"], cap["state"], intercept=cs["icpt"], label=case_label(cs))
     prob = _lasso_problem(cs)
+    if "gamma" in cap:
+        return stepcheck.check_wide(prob, cap["trace"], cap["state"], float(cap["gamma"]), X=cap["X"], Y=cap["Y"], label=case_label(cs))
     if cs["kind"] == "par":
         return stepcheck.check_consensus(prob, cap["trace"], cap["state"], label=case_label(cs))
     return stepcheck.check_tall(prob, cap["trace"], cap["state"], label=case_label(cs))
@@ -100,8 +115,12 @@ def judge_capture(cs, cap, band=8.0, budget=True):
 
 
 def _run_dense_case(cs):
-    """LAD / BP (float64) on the decision trace: the oracle follows the GPU through rounding-level near-ties only."""
-    return judge_capture(cs, gpu_capture(cs))
+    """LAD / BP (float64) on the decision trace: the oracle follows the GPU through rounding-level near-ties only -- and the
+    stepwise rule on the iterate dump (oracle/stepcheck.py check_dense)."""
+    from oracle import stepcheck
+    cap = gpu_capture(cs, state=True)
+    stepcheck.assert_stepwise_dense(stepwise_capture(cs, cap), label=case_label(cs))
+    return judge_capture(cs, cap)
 
 
 def _run_lasso_case(cs):
@@ -112,7 +131,9 @@ def _run_lasso_case(cs):
     in its elementwise steps (oracle/stepcheck.py).  Returns the follow rule's report."""
     from oracle import stepcheck
     cap = gpu_capture(cs, state=True)
-    if "state" in cap:
+    if "gamma" in cap:                                         # wide solver: zero pattern / z / y bit-exact, mat-vecs within the float-dot yardstick
+        stepcheck.assert_stepwise_wide(stepwise_capture(cs, cap), label=case_label(cs))
+    elif "state" in cap:
         rep = stepwise_capture(cs, cap)
         per_record = rep.get("x_vs_ref_max", 0.0) if cs["kind"] == "par" else rep["x_ratio_max"]
         stepcheck.assert_stepwise(dict(rep, x_ratio_max=per_record), label=case_label(cs), x_factor=16.0 if cs["kind"] == "par" else 4.0,

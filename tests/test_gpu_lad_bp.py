@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from helpers import assert_dense_followed, relerr
+from helpers import assert_dense_followed, dense_state_records, dense_stepwise, relerr
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -12,10 +12,11 @@ def test_readme_lad_fixture(readme_lasso_xy):
     from admm_amd import admm_lad
     from oracle import entry, readme
     x, y = readme_lasso_xy
-    fit = admm_lad(x, y, intercept=False).fit(trace=True)
+    fit = admm_lad(x, y, intercept=False).fit(trace=True, state=dense_state_records(len(y), 10000))
     assert fit.beta[0] == 0.0
     assert relerr(fit.beta[1:], readme.LAD_ADMM) < TOL            # README.md:139-161
     assert_dense_followed("lad", fit.beta, fit.niter, fit.trace, x, y, entry.LAD_OPTS, intercept=False, tol=1e-8, label="README LAD (hat-matrix branch)")
+    dense_stepwise("lad", fit, x, y, entry.LAD_OPTS, intercept=False, label="README LAD (hat-matrix branch)")
 
 
 @pytest.mark.parametrize("intercept", [True, False])
@@ -28,20 +29,22 @@ def test_lad_general_branch_vs_oracle(intercept):
     x = rng.standard_normal((n, p)) * 2 + 0.3
     b = rng.uniform(size=p)
     y = x @ b + rng.standard_t(3, size=n) + 1.5
-    fit = admm_lad(x, y, intercept=intercept).fit(trace=True)
+    fit = admm_lad(x, y, intercept=intercept).fit(trace=True, state=dense_state_records(n, 10000))
     assert_dense_followed("lad", fit.beta, fit.niter, fit.trace, x, y, entry.LAD_OPTS, intercept=intercept, tol=1e-8, label=f"LAD n=3000 icpt={int(intercept)}")
+    dense_stepwise("lad", fit, x, y, entry.LAD_OPTS, intercept=intercept, label=f"LAD n=3000 icpt={int(intercept)}")
 
 
 def test_readme_bp_fixture():
     from admm_amd import admm_bp
     from oracle import entry, readme
     x, y, bt = readme.bp_data()
-    fit = admm_bp(x, y).fit(trace=True)
+    fit = admm_bp(x, y).fit(trace=True, state=dense_state_records(x.shape[1], 10000))
     beta = np.asarray(fit.beta.todense()).ravel()
     e = bt - beta
     assert abs(e.min() - readme.BP_RANGE[0]) < 1e-6                # README.md:180-182
     assert abs(e.max() - readme.BP_RANGE[1]) < 1e-6
     assert_dense_followed("bp", beta, fit.niter, fit.trace, x, y, entry.BP_OPTS, tol=1e-8, label="README BP")
+    dense_stepwise("bp", fit, x, y, entry.BP_OPTS, label="README BP")
 
 
 def test_bp_perf_fixture_range():
@@ -64,6 +67,7 @@ def test_bp_maxit_and_rho_adaptation():
     bt[rng.choice(p, 12, replace=False)] = rng.uniform(size=12)
     y = A @ bt
     for maxit in (3, 9, 10000):
-        fit = admm_bp(A, y).opts(maxit=maxit).fit(trace=True)
+        fit = admm_bp(A, y).opts(maxit=maxit).fit(trace=True, state=dense_state_records(p, maxit))
         assert_dense_followed("bp", np.asarray(fit.beta.todense()).ravel(), fit.niter, fit.trace, A, y, dict(entry.BP_OPTS, maxit=maxit),
                               tol=1e-8, label=f"BP maxit={maxit}")
+        dense_stepwise("bp", fit, A, y, dict(entry.BP_OPTS, maxit=maxit), label=f"BP maxit={maxit}")

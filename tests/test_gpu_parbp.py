@@ -103,6 +103,17 @@ def test_maxit_exit_and_arguments():
     assert one.stats["branch"] != 6
 
 
+def test_exactly_8192_rows_needs_the_lds_opt_in_too():
+    """n in 8065 .. 8192 pads to 8192 rows: v takes exactly 64 KB of dynamic LDS NEXT TO the kernels' static arrays, so static +
+    dynamic exceeds the default per-workgroup limit although the dynamic part alone does not (round-3 advisor finding: those
+    launches were refused without a trace and the solve ended 'without a decision')."""
+    rng = np.random.default_rng(6)
+    for n, p in ((8192, 8300), (8100, 8260)):
+        x = np.asfortranarray(rng.standard_normal((n, p)))
+        b0 = np.zeros(p); b0[rng.choice(p, 30, replace=False)] = rng.standard_normal(30) * 2
+        _compare(x, x @ b0, 2, f"n={n} p={p}", maxit=15)
+
+
 def test_more_than_8192_rows_takes_the_large_lds_variant():
     """n > 8192: v needs more than 64 KB of LDS (opt-in per kernel) and the partial 32 double2 per thread.  Held to the oracle like
     the small cases (a short run: the comparison is per iteration)."""

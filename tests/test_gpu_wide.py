@@ -22,11 +22,12 @@ def test_wide_lasso_path_vs_oracle(n, p, m):
     """12-lambda path judged on the decision trace: the oracle follows the GPU through rounding-level near-ties of the
     stopping test and of the rho adaptation only (helpers.assert_followed_parity); counts identical, every column 1e-4."""
     from admm_amd import admm_lasso
+    from helpers import traced_parity
     x, y = synth_lasso(n, p, m, seed=29)
     lmr = 0.01 if n < p else 1e-4                                # R default (R/30_admm_lasso.R:43)
-    fit, trace = traced_fit(admm_lasso(x, y).penalty(nlambda=12, lambda_min_ratio=lmr))
+    # the follow rule AND the stepwise rule on the iterate dump (helpers.traced_parity -> wide_stepwise)
+    fit, rep = traced_parity(admm_lasso(x, y).penalty(nlambda=12, lambda_min_ratio=lmr), _problem(x, y, 12, lmr), TOL, label=f"wide n={n} p={p}")
     assert fit.stats["branch"] == 1
-    rep = assert_followed_parity(fit.beta_dense, fit.niter, trace, _problem(x, y, 12, lmr), TOL, label=f"wide n={n} p={p}")
     ref = rep["ref"]
     assert np.allclose(fit.lambda_, ref["lambda"], rtol=1e-5)
     # support agreement
@@ -49,8 +50,8 @@ def test_wide_spectral_radius_estimate():
 def test_wide_enet_path_vs_oracle():
     from admm_amd import admm_enet
     x, y = synth_lasso(250, 900, 12, seed=31)
-    fit, trace = traced_fit(admm_enet(x, y).penalty(nlambda=10, lambda_min_ratio=0.01, alpha=0.5))
-    assert_followed_parity(fit.beta_dense, fit.niter, trace, _problem(x, y, 10, 0.01, alpha=0.5), TOL, label="wide enet")
+    from helpers import traced_parity
+    traced_parity(admm_enet(x, y).penalty(nlambda=10, lambda_min_ratio=0.01, alpha=0.5), _problem(x, y, 10, 0.01, alpha=0.5), TOL, label="wide enet")
 
 
 def test_wide_user_lambda_and_maxit():
