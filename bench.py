@@ -60,6 +60,11 @@ def parse():
                     help="time limit of the side measurement of the consensus solver (0 disables it)")
     ap.add_argument("--shard-seconds", type=float, default=200.0,
                     help="time limit of each sharded child run at N > 1 (0 disables them: replicas only)")
+    ap.add_argument("--config-seconds", type=float, default=150.0,
+                    help="time limit of each child run of the other BASELINE configs at N = 1 (C3 wide, C4 consensus, C5 LAD / BP, parbp; 0 disables them)")
+    ap.add_argument("--cpu-config-seconds", type=float, default=6.0,
+                    help="budget of EACH timed CPU leg (1 thread, all threads) of the other configs (0 disables their cpu_baseline)")
+    ap.add_argument("--side-shapes", default="", help=argparse.SUPPRESS)      # test hook: "n,p" of the consensus child and "n,p,nl" of the wide child, ";"-separated (tests/test_gpu_bench_children.py)
     ap.add_argument("--child", default="", help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -75,6 +80,9 @@ def cpu_baseline(p, nlambda, budget_s, seed, n_full=None):
     Setup (Gram, Lanczos, Cholesky, inverse) uses NumPy/LAPACK and is not part of either rate."""
     import numpy as np
     import scipy.linalg as sla
+    # the all-core leg: threads pinned and spread over the cores, pages first-touched by the thread that streams them (oracle/c)
+    os.environ.setdefault("OMP_PROC_BIND", "spread")
+    os.environ.setdefault("OMP_PLACES", "cores")
     from oracle import ctall
     from oracle.datastd import DataStd
     from oracle.entry import _lambda_grid
@@ -134,7 +142,8 @@ def cpu_baseline(p, nlambda, budget_s, seed, n_full=None):
                       f"(Gram + Lanczos + Cholesky) {t_setup:.1f} s not included",
             "best_effort": {"value": vb, "unit": "iterations/s", "cores": int(threads),
                             "sample": f"same loop with the x-update as a cached-inverse symmetric mat-vec spread over {threads} OpenMP "
-                                      f"threads (not the reference's arithmetic), first {kb} lambdas: {itb} iterations in {sb:.2f} s; "
+                                      f"threads (OMP_PROC_BIND=spread, OMP_PLACES=cores, matrix pages first-touched by the thread that "
+                                      f"streams them; not the reference's arithmetic), first {kb} lambdas: {itb} iterations in {sb:.2f} s; "
                                       f"forming the inverse took {t_inv:.1f} s (not included)"}}
 
 
@@ -198,7 +207,10 @@ def consensus_child(a, backend, out_path):
     sharded over ranks, one exchange (p floats + 3 doubles) per ADMM iteration over `backend`."""
     rank, world, multi, torch, dist, dev, adist = _child_setup(backend)
     from admm_amd import DevicePtr
-    n, p, K = 10000, 100000, world
+    n, p = 10000, 100000
+    if a.side_shapes:
+        n, p = (int(v) for v in a.side_shapes.split(";")[0].split(","))
+    K = 8 if 8 % world == 0 else world                   # BASELINE configs[3]: 8 row blocks, spread over the ranks (8 / N per GPU): total work fixed as N grows
     lo, hi = adist.row_partition(n, K, world, rank)
     nl = hi - lo
     gb = torch.Generator(device="cpu"); gb.manual_seed(a.seed)
@@ -222,11 +234,13 @@ def consensus_child(a, backend, out_path):
     fit = plan.run()
     iters = int(fit.stats["total_iter"])
     loop_s = _max_over_ranks(fit.stats["t_loop"], torch, dist, multi)
+    agree = _ranks_agree(fit.niter, torch, dist, multi, dev)
     if rank == 0:
         rows = n // K
-        bytes_per_gpu = 8.0 * rows * p + 4.0 * rows * rows      # A and A' streamed once each + the cached (AA'+rho I)^-1
-        res = {"workload": "admm_lasso$parallel(K) n=10000 p=100000, K = n_gpus row blocks (one per GPU), 3 lambdas down to 0.3 lambda_max, run to convergence (maxit 4000)",
-               "converged": bool(all(int(v) <= 4000 for v in fit.niter)),
+        bytes_per_gpu = (K // world) * (8.0 * rows * p + 4.0 * rows * rows)      # per block: A and A' streamed once each + the cached (AA'+rho I)^-1
+        res = {"workload": "admm_lasso$parallel(8) n=10000 p=100000 (BASELINE configs[3]), 8 row blocks spread over the GPUs, 3 lambdas down to 0.3 lambda_max, run to convergence (maxit 4000)",
+               "scaling": "strong",
+               "converged": bool(all(int(v) <= 4000 for v in fit.niter)), "ranks_agree_on_niter": agree,
                "exchange": backend, "n_gpus": world, "ranks_in_communicator": world, "K": K, "iterations": iters, "loop_s": loop_s,
                "iters_per_s": iters / loop_s, "ms_per_iter": loop_s / iters * 1e3, "setup_s": setup_s,
                "alg_bytes_per_gpu_per_iter": bytes_per_gpu, "achieved_GBps_per_gpu": bytes_per_gpu * iters / loop_s / 1e9,
@@ -301,7 +315,9 @@ def widecols_child(a, backend, out_path):
     `backend`.  Total work fixed as N grows: strong scaling.  A 20-lambda path (the full 100 at N = 1 takes 0.45 s)."""
     rank, world, multi, torch, dist, dev, adist = _child_setup(backend)
     from admm_amd import DevicePtr
-    n, p = 2000, 200000
+    n, p, nl_wide = 2000, 200000, 20
+    if a.side_shapes:
+        n, p, nl_wide = (int(v) for v in a.side_shapes.split(";")[1].split(","))
     lo, hi = adist.col_partition(p, world, rank)
     pl = hi - lo
     gb = torch.Generator(device="cpu"); gb.manual_seed(a.seed)
@@ -321,7 +337,7 @@ def widecols_child(a, backend, out_path):
     import ctypes
     import numpy as np
     lib = load()
-    nl = 20
+    nl = nl_wide
     lam_out = np.zeros(nl); beta = np.zeros((p + 1, nl), dtype=np.float32, order="F"); niter = np.zeros(nl, dtype=np.int32)
     o = AdmmOpts(10000, 1e-5, 1e-5, -1.0)
 
@@ -341,8 +357,8 @@ def widecols_child(a, backend, out_path):
     loop_s = _max_over_ranks(st["t_loop"], torch, dist, multi)
     agree = _ranks_agree(niter, torch, dist, multi, dev)
     if rank == 0:
-        res = {"workload": "admm_lasso wide n=2000 p=200000 (BASELINE configs[2]), columns sharded over the ranks, 20-lambda path",
-               "exchange": backend, "ranks_agree_on_niter": agree, "n_gpus": world, "ranks_in_communicator": world, "scaling": "strong", "iterations": iters,
+        res = {"workload": "admm_lasso wide n=%d p=%d (BASELINE configs[2]), columns sharded over the ranks, %d-lambda path" % (n, p, nl),
+               "exchange": backend, "ranks_agree_on_niter": agree, "all_lambdas_converged": bool(int(niter.max()) <= 10000), "n_gpus": world, "ranks_in_communicator": world, "scaling": "strong", "iterations": iters,
                "loop_s": loop_s, "iters_per_s": iters / loop_s, "us_per_iter": loop_s / iters * 1e6,
                "setup_s": st["t_total"] - st["t_loop"], "allreduce_payload_bytes": 4 * n, "niter_first": [int(v) for v in niter[:8]]}
         with open(out_path, "w") as f:
@@ -352,6 +368,280 @@ def widecols_child(a, backend, out_path):
     adist.finalize_comm()
     if multi:
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The other BASELINE.json configs on ONE GPU (N = 1), each in its own time-limited child process, each with its roofline
+# and -- timed in the parent on the host cores -- its cpu_baseline (the NumPy restatement of the same loop, oracle/solvers.py,
+# on the same shape for a bounded number of iterations, with 1 BLAS thread = the reference's configuration and with all of them).
+CONFIGS = {
+    "c3": dict(workload="admm_lasso wide n=2000 p=200000, 100-lambda path (BASELINE configs[2])", dtype="f32"),
+    "c4": dict(workload="admm_lasso$parallel(8) n=10000 p=100000, 8 row blocks on ONE GPU (BASELINE configs[3] at N = 1), 3 lambdas down to 0.3 lambda_max, run to convergence", dtype="f32"),
+    "c5lad": dict(workload="admm_lad n=50000 p=5000 (BASELINE configs[4])", dtype="f64"),
+    "c5bp": dict(workload="admm_bp n=5000 p=50000 (BASELINE configs[4], transposed as the reference's API requires: p > n)", dtype="f64"),
+    "c5parbp": dict(workload="admm_bp$parallel(8) n=5000 p=50000, column-block sharing ADMM, 8 blocks on ONE GPU", dtype="f64"),
+}
+
+
+def _gen_device(torch, dev, g, n, p, sd, m, dense_beta=False, noise=True):
+    xt = torch.empty((p, n), dtype=torch.float64, device=dev)
+    chunk = max(1, (1 << 27) // n)
+    for c0 in range(0, p, chunk):
+        c1 = min(p, c0 + chunk)
+        xt[c0:c1] = torch.randn((c1 - c0, n), generator=g, device=dev, dtype=torch.float64) * sd
+    b = torch.zeros(p, dtype=torch.float64, device=dev)
+    if dense_beta:
+        b[:] = torch.rand(p, generator=g, device=dev, dtype=torch.float64)
+    else:
+        idx = torch.randperm(p, generator=g, device=dev)[:m] if not noise else torch.arange(m, device=dev)
+        b[idx] = torch.rand(m, generator=g, device=dev, dtype=torch.float64)
+    y = b @ xt
+    if noise:
+        y = y + torch.randn(n, generator=g, device=dev, dtype=torch.float64)
+    torch.cuda.synchronize()
+    return xt, y, b
+
+
+def config_child(a, name, out_path):
+    """One of the other BASELINE configs on cuda:0, inputs resident in HBM, a warm-up fit and a timed one.  The rate is
+    iterations / seconds of the ADMM loop (admm_stats.t_loop: host clock around a device sync; loop_ms_events: HIP events on the
+    solver's stream around the same loop), setup reported beside it; `roofline` from SURVEY.md section 8(d)'s per-iteration
+    algorithmic bytes."""
+    import torch
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    import numpy as np
+    from admm_amd import DevicePtr, admm_bp, admm_lad, admm_lasso, load
+    lib = load()
+    assert lib.admm_hip_set_device(0) == 0
+    g = torch.Generator(device=dev)
+    g.manual_seed(a.seed)
+    extra = {}
+    if name == "c3":
+        n, p = 2000, 200000
+        xt, y, _ = _gen_device(torch, dev, g, n, p, 2.0, 100)
+        model = admm_lasso(DevicePtr(xt.data_ptr()), DevicePtr(y.data_ptr()), n=n, p=p).penalty(nlambda=100)
+        model.fit()
+        fit = model.fit()
+        niter = fit.niter.astype(np.int64)
+        reg = sum(int(sum(1 for c in range(k) if (c + 1) & c == 0 and ((c + 1) & 0x55555555))) for k in niter)
+        tot = int(niter.sum())
+        # a regular iteration streams X once (4 n p); an active-set one reads the current non-zeros' columns once (4 n nS, the
+        # gather re-uses the column just dotted): nS per iteration is not recorded -- only the regular-step stream is counted
+        # (a lower bound of the algorithmic bytes, so `frac` is a lower bound too)
+        bytes_iter = 4.0 * n * p * reg / max(1, tot)
+        extra = {"regular_iterations": reg, "nnz_last_lambda": int(np.count_nonzero(fit.beta_dense[1:, -1])), "persist_iter": int(fit.stats["persist_iter"]),
+                 "kernel": "wide_x_kernel / wide_act_persist_kernel (x-update of ADMMLassoWide)", "bytes_note": "regular-step stream of X only (lower bound)"}
+    elif name == "c4":
+        n, p, K = 10000, 100000, 8
+        xt, y, _ = _gen_device(torch, dev, g, n, p, 2.0, 100)
+        model = admm_lasso(DevicePtr(xt.data_ptr()), DevicePtr(y.data_ptr()), n=n, p=p).penalty(nlambda=3, lambda_min_ratio=0.3).parallel(K).opts(maxit=4000)
+        model.fit()
+        fit = model.fit()
+        bytes_iter = 8.0 * n * p + 4.0 * K * (n / K) ** 2
+        extra = {"K": K, "niter": [int(v) for v in fit.niter], "converged": bool(all(int(v) <= 4000 for v in fit.niter)),
+                 "kernel": "gemv_t_batch_kernel (A_k rhs and A_k' s of the 8 Woodbury workers, PADMMLasso.h:22-30)"}
+    elif name == "c5lad":
+        n, p = 50000, 5000
+        xt, y, _ = _gen_device(torch, dev, g, n, p, 2.0, p, dense_beta=True)
+        model = admm_lad(DevicePtr(xt.data_ptr()), DevicePtr(y.data_ptr()), intercept=False, n=n, p=p)
+        model.fit()
+        fit = model.fit()
+        bytes_iter = 16.0 * n * p + 8.0 * p * p
+        extra = {"kernel": "gemv_t_kernel<double> (X' v, (X'X)^-1 t, X s: ADMMLAD.h:75-76)"}
+    elif name in ("c5bp", "c5parbp"):
+        n, p = 5000, 50000
+        xt, y, b = _gen_device(torch, dev, g, n, p, 1.0, 500, noise=False)
+        model = admm_bp(DevicePtr(xt.data_ptr()), DevicePtr(y.data_ptr()), n=n, p=p)
+        if name == "c5parbp":
+            model = model.parallel(8)
+        model.fit()
+        fit = model.fit()
+        beta = np.asarray(fit.beta.todense()).ravel()
+        err = beta - b.cpu().numpy()
+        extra = {"recovery_error_range": [float(err.min()), float(err.max())]}
+        if name == "c5bp":
+            bytes_iter = 16.0 * n * p
+            extra["kernel"] = "gemv_t_kernel<double> (B v and B' w, B = L^-1 A: ADMMBP.h:60-67)"
+        else:
+            it = int(fit.stats["total_iter"])
+            reg = (it + 9) // 10
+            bytes_iter = 8.0 * n * p * reg / max(it, 1)
+            extra.update({"regular_iterations": reg, "nnz": int(np.count_nonzero(beta)), "kernel": "sbp_xreg_kernel / sbp_xact_kernel",
+                          "bytes_note": "regular-step stream of A only (every 10th iteration; lower bound)"})
+    else:
+        raise SystemExit("unknown config " + name)
+    st = fit.stats
+    it = int(st["total_iter"])
+    loop_s = float(st["t_loop"])
+    ev_s = float(st["loop_ms_events"]) * 1e-3
+    t_iter = (ev_s if ev_s > 0 else loop_s) / max(it, 1)
+    achieved = bytes_iter / t_iter
+    res = dict(CONFIGS[name])
+    res.update({"value": it / loop_s, "unit": "iterations/s", "iterations": it, "loop_s": loop_s, "loop_s_events": ev_s, "n_gpus": 1,
+                "setup_s": float(st["t_total"]) - loop_s, "sec_to_eps": float(st["t_total"]),
+                "roofline": {"bound": "hbm", "kernel": extra.pop("kernel", None), "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                             "frac": achieved / HBM_PEAK, "traffic": None, "algorithmic_bytes_per_iteration": bytes_iter,
+                             "avg_iteration_ms": t_iter * 1e3, "note": extra.pop("bytes_note", "per ITERATION (all launches of one ADMM iteration), HIP events around the loop")}})
+    res.update(extra)
+    with open(out_path, "w") as f:
+        json.dump(res, f)
+
+
+def _blas_threads():
+    try:
+        from threadpoolctl import threadpool_info
+        return max([int(i.get("num_threads", 1)) for i in threadpool_info() if i.get("user_api") == "blas"] or [1])
+    except Exception:                                       # noqa: BLE001
+        return 1
+
+
+def _timed_oracle(make_runner, budget_s):
+    """make_runner() -> step() that runs a further chunk of the oracle's loop and returns the iterations it made (0: finished).
+    Runs chunks until the budget is used; returns (iterations, seconds)."""
+    step = make_runner()
+    it, t0 = 0, time.time()
+    while True:
+        k = step()
+        it += k
+        if k == 0 or time.time() - t0 >= budget_s:
+            break
+    return it, time.time() - t0
+
+
+def cpu_config_baseline(name, budget_s, seed):
+    """cpu_baseline of one of the other configs: the NumPy restatement of the reference's loop (oracle/solvers.py -- the checker
+    of the parity tests, here only TIMED) on the SAME shape, synthetic data of the same distribution, for as many iterations as
+    fit `budget_s`, twice: BLAS limited to ONE thread -- the reference's configuration (`Lasso.cpp:1` EIGEN_DONT_PARALLELIZE,
+    R's single-threaded reference BLAS for the dgemv of LAD / BP; only the consensus workers and the wide solver's active-set
+    loop use OpenMP there) -- and all host threads (`best_effort`).  Setup (Gram, factorisation) is not part of either rate."""
+    import numpy as np
+    import torch
+    from threadpoolctl import threadpool_limits
+    from oracle.solvers import BP, LAD, LassoWide, PADMMLasso
+    F = np.float32
+    tg = torch.Generator(); tg.manual_seed(seed + 77)
+
+    def randn(shape, dtype, sd=1.0):
+        return (torch.randn(shape, generator=tg, dtype=dtype) * sd).numpy()
+
+    t_setup0 = time.time()
+    if name == "c3":
+        n, p = 2000, 200000
+        X = np.asfortranarray(randn((p, n), torch.float32, 2.0).T)
+        b = np.zeros(p, F); b[:100] = np.random.default_rng(seed).uniform(size=100)
+        Y = (X[:, :100] @ b[:100] + randn((n,), torch.float32)).astype(F)
+        X -= X.mean(axis=0, dtype=F)[None, :]
+        X *= (1.0 / np.sqrt((X * X).sum(axis=0, dtype=F) / n)).astype(F)[None, :]
+        Y = ((Y - Y.mean()) / Y.std()).astype(F)
+        # (the constructor's n x n Gram -- 8e11 flop -- only serves the spectral-radius estimate: 30 power iterations of X (X'v) stand in,
+        # setup is not timed)
+        s = LassoWide.__new__(LassoWide)
+        s.X, s.Y, s.n, s.p, s.eps_abs, s.eps_rel, s.alpha, s.info, s.trace_nnz = X, Y, n, p, 1e-5, 1e-5, None, {}, []
+        s.lambda0 = F(np.abs(X.T @ Y).max())
+        v = np.ones(n, F) / np.sqrt(F(n))
+        for _ in range(30):
+            w = X @ (X.T @ v)
+            nv = float(np.linalg.norm(w))
+            v = (w / nv).astype(F)
+        s.sprad = F(0.95 * nv)                               # the reference's loose Lanczos value sits 3-8 % below lambda_max (SURVEY.md section 8a row S)
+        lam = np.float64(s.lambda0) * 0.01 ** (np.arange(100) / 99.0)
+        what = f"ADMMLassoWide loop on n={n} p={p}, the first lambdas of the automatic 100-grid from a cold start"
+
+        def make():
+            state = {"i": 0}
+
+            def step():
+                i = state["i"]
+                if i >= len(lam):
+                    return 0
+                s.lam_idx = i
+                (s.init(lam[i], -1.0) if i == 0 else s.init_warm(lam[i]))
+                state["i"] = i + 1
+                return min(int(s.solve(10000)), 10000)
+            return step
+    elif name == "c4":
+        # bounded sample: 2 of the 8 row blocks (2500 rows): the per-iteration cost is K workers x the same two products, so the
+        # measured rate is scaled by 2 / 8 (said in `sample`)
+        n_full, K_full = 10000, 8
+        n, p, K = 2500, 100000, 2
+        X = randn((n, p), torch.float32, 2.0)
+        b = np.zeros(p, F); b[:100] = np.random.default_rng(seed).uniform(size=100)
+        Y = (X[:, :100] @ b[:100] + randn((n,), torch.float32)).astype(F)
+        X -= X.mean(axis=0, dtype=F)[None, :]
+        X *= (1.0 / np.sqrt((X * X).sum(axis=0, dtype=F) / n)).astype(F)[None, :]
+        Y = ((Y - Y.mean()) / Y.std()).astype(F)
+        s = PADMMLasso(X, Y, K, 1e-5, 1e-5)
+        del X
+        lam0 = float(s.lambda0)
+        scale = float(K) / K_full
+        what = (f"PADMMBase_Master::solve with PADMMLasso workers (Woodbury branch, 1250 x {p} blocks), lambda = 0.55 lambda_max, workers one after the other "
+                f"(the reference runs them under OpenMP); SAMPLE: {K} of the {K_full} row blocks of n={n_full}, the measured rate scaled by {K}/{K_full}")
+
+        def make():
+            s.init(0.55 * lam0, -1.0)
+            return lambda: min(int(s.solve(3)), 3)
+    elif name == "c5lad":
+        n, p = 50000, 5000
+        X = np.asfortranarray(randn((p, n), torch.float64, 2.0).T)
+        Y = X @ np.random.default_rng(seed).uniform(size=p) + randn((n,), torch.float64)
+        X /= np.sqrt((X * X).sum(axis=0) / n - X.mean(axis=0) ** 2)[None, :]
+        Y = Y / Y.std()
+        s = LAD(X, Y, 1.0, 1e-4, 1e-4)
+        what = f"FADMMBase::solve + ADMMLAD (general branch X (X'X)^-1 X') on n={n} p={p}"
+
+        def make():
+            return lambda: min(int(s.solve(3)), 3)
+    elif name == "c5bp":
+        n, p = 5000, 50000
+        A = randn((n, p), torch.float64)
+        bt = np.zeros(p); bt[np.random.default_rng(seed).choice(p, 500, replace=False)] = np.random.default_rng(seed + 1).uniform(size=500)
+        s = BP(A, A @ bt, 1.0, 1e-4, 1e-4)
+        what = f"FADMMBase::solve + ADMMBP (two products with L^-1 A per iteration) on n={n} p={p}"
+
+        def make():
+            return lambda: min(int(s.solve(3)), 3)
+    elif name == "c5parbp":
+        from oracle.solvers import SharingBP
+        n, p, N = 5000, 50000, 8
+        A = randn((n, p), torch.float64)
+        bt = np.zeros(p); bt[np.random.default_rng(seed).choice(p, 500, replace=False)] = np.random.default_rng(seed + 1).uniform(size=500)
+        s = SharingBP.__new__(SharingBP)                     # the constructor's exact spectral norms (8 SVDs) replaced by 40 power iterations: setup only
+        s.n, s.p, s.N = n, p, N
+        chunk = p // N
+        s.off = [i * chunk for i in range(N)] + [p]
+        s.A = [A[:, s.off[i]:s.off[i + 1]] for i in range(N)]
+        s.b = A @ bt
+        s.eps_abs = s.eps_rel = 1e-4
+        s.trace = None
+        s.sprad = []
+        for Ai in s.A:
+            v = np.ones(Ai.shape[1]) / np.sqrt(Ai.shape[1])
+            for _ in range(40):
+                w = Ai.T @ (Ai @ v)
+                nv = float(np.linalg.norm(w))
+                v = w / nv
+            s.sprad.append(1.02 * nv)
+        what = f"the sharing-ADMM loop of TODO/PADMMBP.h restated (oracle/solvers.py SharingBP), {N} column blocks one after the other, on n={n} p={p}"
+
+        def make():
+            s.init(1.0)
+            return lambda: min(int(s.solve(10)), 10)
+    else:
+        return None
+    t_setup = time.time() - t_setup0
+    threads = _blas_threads()
+    scale = scale if name == "c4" else 1.0
+    with threadpool_limits(limits=1, user_api="blas"):
+        it1, s1 = _timed_oracle(make, budget_s)
+    itn, sn = _timed_oracle(make, budget_s)
+    it1, itn = it1 * scale, itn * scale
+    return {"value": it1 / s1 if s1 > 0 else None, "unit": "iterations/s", "cores": 1, "kind": "port",
+            "sample": f"NumPy restatement (oracle/solvers.py) of {what}; BLAS limited to ONE thread: {it1:g} (scaled) iterations in {s1:.1f} s; data generation + setup "
+                      f"(Gram / factorisation, all threads) {t_setup:.1f} s not included",
+            "best_effort": {"value": itn / sn if sn > 0 else None, "unit": "iterations/s", "cores": int(threads),
+                            "sample": f"the same loop with OpenBLAS on {threads} threads inside every product (its memory-bound gemv does not scale on this host: "
+                                      f"NUMA-blind, unpinned -- reported as measured, not a tuned CPU build): {itn:g} (scaled) iterations in {sn:.1f} s"}}
 
 
 def run_side_measurement(a, rank, world, kind, backend, seconds, port_offset):
@@ -373,7 +663,7 @@ def run_side_measurement(a, rank, world, kind, backend, seconds, port_offset):
             env.pop(k)
     cmd = [sys.executable, os.path.abspath(__file__), "--child", "%s:%s:%s" % (kind, backend, out_path), "--seed", str(a.seed),
            "--n", str(a.n), "--p", str(a.p), "--m", str(a.m), "--nlambda", str(a.nlambda), "--steps", str(a.steps),
-           "--warmup", str(a.warmup), "--profile-stride", str(a.profile_stride)]
+           "--warmup", str(a.warmup), "--profile-stride", str(a.profile_stride)] + (["--side-shapes", a.side_shapes] if a.side_shapes else [])
     try:
         r = subprocess.run(cmd, env=env, timeout=seconds, capture_output=True, text=True)
         if rank != 0:
@@ -391,6 +681,9 @@ def main():
     a = parse()
     if a.child:
         kind, backend, out_path = a.child.split(":", 2)
+        if kind == "config":
+            config_child(a, backend, out_path)
+            return
         {"consensus": consensus_child, "tallshard": tallshard_child, "widecols": widecols_child}[kind](a, backend, out_path)
         return
     # The JSON line must be the only thing on stdout: libraries loaded below (RCCL prints a version banner to stdout when
@@ -496,6 +789,11 @@ def main():
         for k, backend in enumerate(("rccl", "peer")):
             widecols.append(run_side_measurement(a, rank, world, "widecols", backend, a.shard_seconds, 71 + 12 * k))
             barrier()
+    cfg_results = {}
+    if world == 1 and not FORCE_DIST and a.config_seconds > 0:
+        # the headline plan's 400 MB inverse stays resident; the children need up to ~20 GB each (fp64 inputs + fp32 / fp64 copies)
+        for k, name in enumerate(CONFIGS):
+            cfg_results[name] = run_side_measurement(a, rank, world, "config", name, a.config_seconds, 101 + k)
     if rank == 0:
         x_ms = xms / max(1, xsamp)
         sym = int(fit.stats["xupdate_variant"]) == 1
@@ -599,6 +897,31 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(p, a.nlambda, a.cpu_seconds, a.seed, n_full=n)
             except Exception as e:                          # noqa: BLE001 -- never lose the GPU line to the CPU leg
                 out["cpu_baseline"] = {"value": None, "unit": "iterations/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+        if cfg_results:
+            # every BASELINE config on one line: the headline first (its roofline / cpu_baseline are the top-level objects), then the
+            # child runs, each with its own roofline and -- timed here on the host cores -- its own cpu_baseline
+            cfgs = [{"workload": out["config"]["workload"], "value": out["value"], "unit": "iterations/s", "dtype": "f32", "n_gpus": 1,
+                     "roofline": {k: out["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")},
+                     "cpu_baseline": {k: out.get("cpu_baseline", {}).get(k) for k in ("value", "unit", "cores", "kind")}, "see": "top level"}]
+            for name, res in cfg_results.items():
+                if not res:
+                    continue
+                if "error" in res:
+                    cfgs.append(dict(CONFIGS[name], error=res["error"]))
+                    continue
+                res.pop("exchange", None)
+                if a.cpu_config_seconds > 0:
+                    try:
+                        res["cpu_baseline"] = cpu_config_baseline(name, a.cpu_config_seconds, a.seed)
+                        v = res["cpu_baseline"] and res["cpu_baseline"].get("value")
+                        if v:
+                            res["gpu_over_cpu_1core"] = res["value"] / v
+                            be = res["cpu_baseline"]["best_effort"].get("value")
+                            res["gpu_over_cpu_all_cores"] = res["value"] / be if be else None
+                    except Exception as e:                  # noqa: BLE001 -- never lose the GPU numbers to a CPU leg
+                        res["cpu_baseline"] = {"value": None, "unit": "iterations/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+                cfgs.append(res)
+            out["configs"] = cfgs
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     plan.close()

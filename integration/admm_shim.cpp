@@ -31,14 +31,15 @@ static void check(int rc) {
     if (rc != ADMM_OK) Rcpp::stop("libadmm_hip: %s", admm_hip_last_error());
 }
 
-// (p+1) x nlambda dense float -> dgCMatrix with row 0 always stored (Lasso.cpp:22-30,131)
-static Rcpp::S4 to_dgCMatrix(const std::vector<float>& beta, int nrow, int ncol) {
+// (p+1) x nlambda dense -> dgCMatrix with row 0 always stored (Lasso.cpp:22-30,131)
+template <typename T>
+static Rcpp::S4 to_dgCMatrix(const std::vector<T>& beta, int nrow, int ncol) {
     std::vector<int> ip(1, 0), ii;
     std::vector<double> xx;
     for (int j = 0; j < ncol; ++j) {
         for (int i = 0; i < nrow; ++i) {
-            const float v = beta[(size_t)j * nrow + i];
-            if (i == 0 || v != 0.f) { ii.push_back(i); xx.push_back(v); }
+            const T v = beta[(size_t)j * nrow + i];
+            if (i == 0 || v != T(0)) { ii.push_back(i); xx.push_back((double)v); }
         }
         ip.push_back((int)ii.size());
     }
@@ -120,11 +121,14 @@ BEGIN_RCPP
     admm_opts o = unpack_opts(opts_);
     NumericVector lambda_out(nl);
     IntegerVector niter(nl);
-    NumericMatrix beta(p + 1, nl);                                  // Dantzig.cpp:85-93 fills a dense (p + 1) x nlambda block
+    // `beta` must be a dgCMatrix: R builds the result with do.call(ADMM_Dantzig_fit, res), and ADMM_Dantzig_fit contains
+    // ADMM_Lasso_fit, whose field is beta = "dgCMatrix" (R/30_admm_lasso.R:18-21) -- a plain matrix would fail at object
+    // construction.  TODO/Dantzig.cpp builds `SpMat beta(p + 1, nlambda)` through write_beta_matrix, row 0 always stored.
+    std::vector<double> beta((size_t)(p + 1) * nl);
     check(admm_hip_dantzig(x.begin(), y.begin(), n, p, ADMM_MEM_HOST, nl_in > 0 ? lambda.begin() : nullptr, nl_in, as<int>(nlambda_),
-                           as<double>(lmin_ratio_), as<bool>(standardize_), as<bool>(intercept_), &o, lambda_out.begin(), beta.begin(),
+                           as<double>(lmin_ratio_), as<bool>(standardize_), as<bool>(intercept_), &o, lambda_out.begin(), beta.data(),
                            niter.begin(), nullptr));
-    return List::create(Named("lambda") = lambda_out, Named("beta") = beta, Named("niter") = niter);
+    return List::create(Named("lambda") = lambda_out, Named("beta") = to_dgCMatrix(beta, p + 1, nl), Named("niter") = niter);
 END_RCPP
 }
 

@@ -98,6 +98,20 @@ int oracle_tall_path_traced(const float* F, const float* XY, int p, const double
     float* r = calloc((size_t)p, sizeof(float));
     if (!x || !z || !y || !adj_z || !adj_y || !old_z || !old_y || !rhs || !r) return 1;
     if (nthreads < 1) nthreads = 1;
+    /* mode 1 on several threads: the mat-vec is memory-bound, so WHERE the matrix lives decides its rate.  The caller's array was
+     * written by one thread (one NUMA node); the threads stream a copy whose pages each of them touched first, with the static
+     * schedule of sym_matvec_omp (column j belongs to the same thread in both loops).  Together with OMP_PROC_BIND=spread /
+     * OMP_PLACES=cores (set by bench.py before this library is loaded) that pins every column block to the memory of the core
+     * that reads it.  Not timed (setup). */
+    float* Fown = NULL;
+    if (mode == 1 && nthreads > 1) {
+        Fown = malloc((size_t)p * (size_t)p * sizeof(float));
+        if (Fown) {
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+            for (int j = 0; j < p; ++j) memcpy(Fown + (size_t)j * p, F + (size_t)j * p, (size_t)p * sizeof(float));
+            F = Fown;
+        }
+    }
     const int enet = alpha >= 0.0;
     const float alpha_f = (float)alpha;
     const float rho_f = (float)rho;
@@ -172,7 +186,7 @@ int oracle_tall_path_traced(const float* F, const float* XY, int p, const double
     }
     *loop_seconds = now_s() - t0;
     if (ntrace) *ntrace = ntr;
-    free(x); free(z); free(y); free(adj_z); free(adj_y); free(old_z); free(old_y); free(rhs); free(r);
+    free(x); free(z); free(y); free(adj_z); free(adj_y); free(old_z); free(old_y); free(rhs); free(r); free(Fown);
     return 0;
 }
 

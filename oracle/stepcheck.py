@@ -343,6 +343,15 @@ def assert_stepwise(rep, label="", x_factor=4.0, max_accum_tie_rate=0.01, norm_t
     return rep
 
 
+def _rounding_tie(own, code, rp, eps_p, rd, eps_d, c, c_old, rel=1e-12):
+    """A decision that differs between the library's record and the rule applied to norms recomputed from its dump is excused
+    ONLY where the deciding comparison is a tie to `rel` (1e-12: a few thousand double ulps, nine orders below anything a wrong
+    iterate would produce): the two sums of squares add up in different orders."""
+    if (own == 0) != (code == 0):
+        return (abs(rp - eps_p) <= rel * abs(eps_p)) or (abs(rd - eps_d) <= rel * abs(eps_d))
+    return abs(c - 0.999 * c_old) <= rel * abs(c_old)
+
+
 # ---------------------------------------------------------------------------------------------------------------- wide
 def check_wide(problem, trace, state, gamma, X=None, Y=None, label=""):
     """Wide Lasso / elastic net (n <= p).  problem: the oracle's arguments; trace: libadmm_hip's decision trace INCLUDING the
@@ -488,8 +497,11 @@ def check_wide(problem, trace, state, gamma, X=None, Y=None, label=""):
             rep["norm_rel_max"] = max(rep["norm_rel_max"], abs(got - want_v) / max(abs(want_v), 1e-300))
         code = int(t[k, 8])
         own = 0 if (rp < eps_p and rd < eps_d) else 1
-        assert own == code, (label, f"record {k} (lambda {li}, iteration {it}): the library decided {code}, the rule on its own iterates gives {own}",
-                             dict(eps_p=eps_p, eps_d=eps_d, rp=rp, rd=rd))
+        if own != code and _rounding_tie(own, code, rp, eps_p, rd, eps_d, 0.0, 1.0):
+            rep.setdefault("rounding_ties", []).append((k, it, code, own))
+        else:
+            assert own == code, (label, f"record {k} (lambda {li}, iteration {it}): the library decided {code}, the rule on its own iterates gives {own}",
+                                 dict(eps_p=eps_p, eps_d=eps_d, rp=rp, rd=rd))
         rpf = _rule_float_norm(r)
         rdf = rho * sqrt_gam * _rule_float_norm((zg - zp).astype(F))
         eps_pf = max(_rule_float_norm(axp), _rule_float_norm(zp)) * eps_rel + sqrt_n * eps_abs
@@ -527,6 +539,7 @@ def assert_stepwise_wide(rep, label="", mv_factor=4.0, mv_rms=1.0, max_accum_tie
     assert rep["norm_rel_max"] < norm_tol, (label, "recorded thresholds / residuals differ from the dumped iterates", rep["norm_rel_max"])
     allowed = max(2, int(np.ceil(max_accum_tie_rate * rep["decisions_checked"])))
     assert len(rep["accum_ties"]) <= allowed, (label, "decisions that float norm accumulation would flip", len(rep["accum_ties"]), rep["accum_ties"][:8])
+    assert len(rep.get("rounding_ties", [])) <= 2, (label, "decisions that are exact ties up to the order of a sum", rep.get("rounding_ties"))
     return rep
 
 
@@ -630,8 +643,15 @@ def check_dense(kind, x, y, opts, trace, state, intercept=True, label=""):
         for got, want in ((t[k, 2], eps_p), (t[k, 3], eps_d), (t[k, 4], rp), (t[k, 5], rd)) + (((t[k, 6], c),) if code != 0 else ()):
             rep["norm_rel_max"] = max(rep["norm_rel_max"], abs(got - want) / max(abs(want), 1e-300))
         own = 0 if (rp < eps_p and rd < eps_d) else (1 if c < 0.999 * c_old else 2)
-        assert own == code, (label, f"record {k} (iteration {it}): the library decided {code}, the rule on its own iterates gives {own}",
-                             dict(eps_p=eps_p, eps_d=eps_d, rp=rp, rd=rd, c=c, c_old=c_old))
+        if own != code and _rounding_tie(own, code, rp, eps_p, rd, eps_d, c, c_old):
+            # the norms recomputed here add up in NumPy's order, the library's in its own: a comparison that is an EXACT tie in exact
+            # arithmetic is decided by that last bit.  LAD has one by construction: while z = 0 the iterate repeats (x = P(2 y - x0) = x0),
+            # so after the restart that follows c_2 = c_1 is tested against 0.999 (c_0 / 0.999) = c_0 (1 +- ulp) (README LAD n = 5000:
+            # record 3, c = 2.984715452011392 on both sides)
+            rep.setdefault("rounding_ties", []).append((k, it, code, own))
+        else:
+            assert own == code, (label, f"record {k} (iteration {it}): the library decided {code}, the rule on its own iterates gives {own}",
+                                 dict(eps_p=eps_p, eps_d=eps_d, rp=rp, rd=rd, c=c, c_old=c_old))
         class _R:
             pass
         q = _R()
@@ -660,4 +680,5 @@ def assert_stepwise_dense(rep, label="", x_factor=8.0, x_rms_factor=3.0, norm_to
     assert rep["x_vs_ref_max"] <= x_factor, (label, f"projection error is {rep['x_vs_ref_max']:.2f} x the reference route's at {rep.get('x_worst')}")
     assert rep["x_rms_vs_ref"] <= x_rms_factor, (label, "projection error over the run (rms) against the reference route's", rep["x_rms_vs_ref"])
     assert rep["norm_rel_max"] < norm_tol, (label, "recorded thresholds / residuals differ from the dumped iterates", rep["norm_rel_max"])
+    assert len(rep.get("rounding_ties", [])) <= 2, (label, "decisions that are exact ties up to the order of a sum", rep.get("rounding_ties"))
     return rep

@@ -281,10 +281,19 @@ def coef_scale(problem):
     return float(np.abs(x.T @ y / den).max())
 
 
-def col_err(a, b, floor):
+def col_err(a, b, floor, icpt_row=True):
+    """SURVEY.md section 8c's per-column metric max|a - b| / max|b| (intercept row included).  `floor` (1 % of the path's scale,
+    callers) replaces the column's own scale ONLY for a column with at most one surviving slope coordinate: at lambda_max the
+    coordinate attaining max|X'y| sits exactly on the soft threshold and survives as the difference of two nearly equal numbers
+    (or not at all on one side) -- its relative error is meaningless, and a column that is all zeros has no scale at all.
+    Every other column is held to ITS OWN largest coefficient (round 3 applied the floor to every column, which accepted a
+    column 1e-3 the size of the path's at 1e-3 relative to itself: 10 x looser than the stated metric)."""
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
-    return np.abs(a - b).max() / max(np.abs(b).max(), floor, 1e-300)
+    nnz = int(np.count_nonzero(b[1:] if icpt_row else b))          # icpt_row=False: the caller passes the slope rows only
+    own = float(np.abs(b).max())
+    scale = max(own, floor) if nnz <= 1 else own
+    return np.abs(a - b).max() / max(scale, 1e-300)
 
 
 def assert_tall_parity(beta, niter, trace, problem, tol=1e-4, factor=5.0, band=8.0, label="", budget=True):
