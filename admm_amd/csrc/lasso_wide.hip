@@ -132,6 +132,7 @@ __device__ __forceinline__ float prox_f(float val, float thresh, float denom, bo
 // (ADMMBase.h:85-109), lambda schedule (init_warm), regular / active-set schedule (ADMMLassoWide.h:121-155).  Every wave
 // that calls it reduces the norm partials itself in a fixed order (no LDS, no barrier) and gets the identical result.
 struct WideDecision { WideCtl out; int lam_finished; int niter_val; double rp, rd; int code; };
+__device__ __forceinline__ double wide_halving_dpp(const double (&v)[8], int lane);      // = halving_sum8_dpp (defined with the 2-D stretch below)
 constexpr int kWideNormRows = 128;        // rows of P that every lane requests unconditionally (P is allocated and zeroed to at least this)
 // The lane's share of the norm partials of the previous iteration (rows lane, lane + 64, ...).  Does not depend on the
 // control block: callers request it in the same memory round trip as the control block itself.
@@ -150,13 +151,17 @@ __device__ __forceinline__ void wide_norms_finish(const WideParams& q, int lane,
         for (int k = 0; k < 5; ++k) sums[k] += q.P[(size_t)row * 8 + k];
     }
 }
+template <bool DPP = false>
 __device__ __forceinline__ WideDecision wide_decide(const WideParams& q, const WideCtl& in, const double (&sums)[5], int lane) {
     int lam_finished = -1, niter_val = 0;
     // Every wave reduces the norm partials itself (fixed order, no LDS, no barrier): the five sums through one halving
     // butterfly (bit-identical to five wave_sum calls), then ONE square-root sequence with lane 8 k working on sum k,
     // and the five results read back as wave-uniform scalars.
     const double v8[8] = {sums[0], sums[1], sums[2], sums[3], sums[4], 0.0, 0.0, 0.0};
-    const double root = sqrt(halving_sum8(v8, lane));
+    double tot8;
+    if constexpr (DPP) tot8 = wide_halving_dpp(v8, lane);      // (wide_rows_persist_kernel: the cross-lane hardware of gfx950 instead of LDS permutes)
+    else tot8 = halving_sum8(v8, lane);
+    const double root = sqrt(tot8);
     const double sq_r2 = readlane_f64(root, 0), sq_dz2 = readlane_f64(root, 8), sq_ax2 = readlane_f64(root, 16);
     const double sq_z2 = readlane_f64(root, 24), sq_y2 = readlane_f64(root, 32);
     WideCtl out = in;
@@ -776,49 +781,17 @@ wide_state_kernel(WideParams q, int par) {
 }
 
 // ------------------------------------------------------------------------------------------ persistent active-set stretch
-// Round 3.  Almost every iteration of a wide path is an ACTIVE-SET step (ADMMLassoWide.h:86-118: only the current
-// non-zeros are updated; 17 191 of 17 613 iterations at BASELINE configs[2]) on a few dozen to a few hundred columns -- two
-// latency-bound launches, 16.6 us per iteration however little there is to do (profiles/r02_probe_timelines.md: prologue round
-// trip, column round trip, two kernel boundaries, the z / y launch's own round trip).  This kernel runs a whole STRETCH of
-// them -- from wherever the two-launch path stands until the next regular step, a finished lambda, or an active set too
-// large for it -- inside ONE launch: kPG workgroups (blocks b with b % 8 == 0 of a 256-block grid: observed to share one XCD
-// and its L2, a speed-up only, never relied upon) keep iterating and hand their results to one another through global
-// memory with write-through stores and cache-bypassing loads, two hand-overs per iteration:
-//   (B) every wave keeps the x values of ITS column slots in registers (column j <-> slot (j / NW) of wave j mod NW, the
-//       same deal as the two-launch kernel), updates the non-zero ones against t / gamma staged in LDS and accumulates
-//       x_j X_j; the workgroup publishes its partial of A x                                      [hand-over A: partials]
-//   (D) workgroup g owns n / kPG rows: it sums the kPG partials of its rows in workgroup order, forms z_new, y_new, r and its
-//       share of the five norms, and publishes A x + z, y and the norm shares                   [hand-over B: everything else]
-//   (E) every workgroup reduces the norm shares, takes the decision of ADMMBase::solve (wide_decide: stop test, rho adaptation,
-//       schedule), and -- if another active-set step follows -- forms t = (A x + z) + y / rho itself.
-// The arithmetic of a step is the two-launch path's (same functions, same roundings); only the ORDER in which the partials
-// of A x and of the norms are added differs (kPG workgroups instead of 256, per-workgroup norm shares), so the two paths
-// agree to summation rounding, not bit for bit, and both are held to the oracle by the same trace rule.  When the stretch
-// ends the kernel leaves x, A x, z, y, the norm partials and the control block exactly as a tail launch would, and the next
-// x-update launch simply continues.  ADMM_HIP_WIDE_PERSIST=0 disables it.
-constexpr int kPG = 32;                   // workgroups of the persistent stretch
-constexpr int kPNU = 32;                  // x slots per lane a wave can own: p <= kPNU * 64 * (4 kPG) = 262144
-struct WidePersist {
-    unsigned long long* flagA; unsigned long long* flagB;      // [kPG][8] monotonic hand-over words, one 64-byte line each
-    unsigned long long* flagX;                                 // [kPG][8] (launch << 32) | (XCD + 1) of every workgroup
-    float* sz; float* yv;                  // [npad] A x + z and y of the iteration just finished (write-through)
-    double* np;                            // [kPG][8] norm shares: |r|^2, |dz|^2, |Ax|^2, |z|^2, |y|^2, non-zeros
-    int* err;                              // device word: non-zero after a timed-out wait
-    unsigned long long seq;                // launch number (host): hand-over words only ever grow
-    int max_cols;                          // leave the stretch when the active set exceeds this many columns
-    unsigned long long* stat;              // [4] iterations done in stretches, stretches, 100 MHz ticks inside them (diagnostics)
-    double* hint;                          // [2][2] per launch parity: {non-zeros when the kernel last ran, launches to sit out}: while the
-                                           // active set is too large for this kernel it only looks again every 64th launch
-};
-
-// 8-byte payload store.  wt = true: write-through (sc1), visible to a cache-bypassing load anywhere on the device.  wt = false
-// (all workgroups of the stretch were FOUND on one XCD at the start of this launch, wide_act_persist_kernel): a plain store, which
-// stays in the XCD's shared L2 where the readers' cache-bypassing loads find it at L2 latency instead of the fabric's.
-__device__ __forceinline__ void wp_store2(float* p, float a, float b, bool wt) {
-    if (wt) __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *reinterpret_cast<float2*>(p) = make_float2(a, b);
-}
+// Almost every iteration of a wide path is an ACTIVE-SET step (ADMMLassoWide.h:86-118: only the current non-zeros are updated;
+// 17 191 of 17 613 iterations at BASELINE configs[2]) on a few dozen to ~1500 columns -- as two latency-bound launches 16.6 us per
+// iteration however little there is to do (profiles/r02_probe_timelines.md).  A persistent kernel runs a whole STRETCH of them --
+// from wherever the two-launch path stands until the next regular step, a finished lambda, or an active set too large for it --
+// inside ONE launch, its workgroups handing their results to one another through global memory (write-through stores or plain
+// stores into a shared L2, cache-bypassing loads, monotonic flag words).  When the stretch ends the kernel leaves x, A x, z, y, the
+// norm partials and the control block exactly as a tail launch would, and the next x-update launch simply continues.
+// Round 3's kernel split the COLUMNS over 32 workgroups (two all-to-all hand-overs per iteration: partials of A x, then z / y /
+// norm shares of the row owners; n <= 2048, <= 512 active columns): 10.3-10.5 us per iteration inside, 84 % of configs[2]'s
+// iterations covered, 53.6-56.5 k it/s.  Measured and rejected there: one hand-over per iteration with 16 fat workgroups that each
+// sum all partials (12.1 us).  It is replaced by the 2-D kernel below (round 4); helpers shared by both designs follow.
 __device__ __forceinline__ void wp_store_f64(double* p, double v, bool wt) {
     if (wt) __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else *p = v;
@@ -828,36 +801,10 @@ __device__ __forceinline__ unsigned wp_xcc_id() {                               
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
     return v & 0xf;
 }
-__device__ __forceinline__ float2 wp_load2(const float* p) {                        // 8-byte load that bypasses this CU's L1
-    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return make_float2(__uint_as_float((unsigned)v), __uint_as_float((unsigned)(v >> 32)));
-}
-// every storing wave drains its stores, then ONE lane raises the workgroup's word
-__device__ __forceinline__ void wp_publish(unsigned long long* flag, unsigned long long val) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(flag, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// lanes < kPG of wave 0 poll one word each (bounded); everybody leaves together.  Returns false after a time-out.
-__device__ __forceinline__ bool wp_wait(const unsigned long long* flags, unsigned long long val, int* err, int* s_ok) {
-    if (threadIdx.x < 64) {
-        bool ok = true;
-        if (threadIdx.x < kPG) {
-            const unsigned long long* f = flags + (size_t)threadIdx.x * 8;
-            const long long t0 = wall_clock64();
-            while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < val) {
-                __builtin_amdgcn_s_sleep(1);
-                if (wall_clock64() - t0 > 200000000ll) { ok = false; break; }        // 2 s
-            }
-        }
-        ok = __all(ok) != 0;
-        if (threadIdx.x == 0) { *s_ok = ok ? 1 : 0; if (!ok) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-    }
-    __syncthreads();
-    return *s_ok != 0;
-}
-// The same wait on words that carry (launch << 32) | (XCD of the workgroup + 1); *s_same = 1 if all kPG workgroups sit on one XCD.
-__device__ __forceinline__ bool wp_wait_xcc(const unsigned long long* flags, unsigned long long seq, int* err, int* s_ok, int* s_same, int npart = kPG) {
+// Wait (bounded) for the `npart` words that carry (launch << 32) | (XCD of the workgroup + 1); *s_same = 1 if all of them sit on
+// one XCD: then payloads may be plain stores, which stay in that XCD's shared L2 where the readers' cache-bypassing loads find
+// them at L2 latency; otherwise they are written through.  Lanes < npart of wave 0 poll one word each; everybody leaves together.
+__device__ __forceinline__ bool wp_wait_xcc(const unsigned long long* flags, unsigned long long seq, int* err, int* s_ok, int* s_same, int npart) {
     if (threadIdx.x < 64) {
         bool ok = true;
         unsigned long long v = 0;
@@ -878,353 +825,587 @@ __device__ __forceinline__ bool wp_wait_xcc(const unsigned long long* flags, uns
     return *s_ok != 0;
 }
 
-template <int RT>      // a column is RT float4 per lane (n <= RT * 256)
-__global__ void __launch_bounds__(kWideThreads)
-wide_act_persist_kernel(WideParams q, int cpar, WidePersist ps) {
+// Round 4.  The stretch above splits the COLUMNS over its workgroups, so every iteration needs two all-to-all hand-overs: the
+// partials of A x (every row needs every workgroup's share) and then the norm shares + z / y of the row owners (every
+// workgroup needs them for the decision and the next t): 10.5 us per iteration, of which ~6 are the two hand-overs, and it
+// re-reads every active column from the L2 in every iteration.
+// This kernel splits the ROWS instead: workgroup g owns RS = 64 M rows of EVERYTHING -- of A x, z, y, t and of every active
+// column of X.  Then
+//   * A x, z, y, the residuals and t of its rows are local (no partials of A x at all);
+//   * what needs all rows is the dot product X_j't of an active column: every workgroup forms the PARTIAL dots of its row slice
+//     for all active columns (nS floats), and every workgroup sums the G partial dots of every column itself, in workgroup
+//     order, and applies the prox -- redundantly and identically (x is replicated, like the decision);
+//   * the only other global quantity, the five norms of the stopping test, travels WITH the partial dots of the NEXT iteration:
+//     a workgroup that has finished its rows of iteration k forms t_{k+1} and the partial dots of iteration k+1 right away,
+//     SPECULATING that the decision on iteration k will be "go on, same rho" (it is in ~95 % of the iterations: rho changes 49
+//     times in 1120 iterations of the n = 300 test path), and publishes both together.  ONE hand-over per iteration.  When the
+//     decision changes rho, t_{k+1} = (A x + z) + y / rho is formed again with the new rho and the partial dots are exchanged
+//     once more (an extra hand-over for that iteration); when it ends the lambda / asks for a regular step / finishes the path,
+//     the speculative dots are dropped and the stretch ends;
+//   * a workgroup's slice of an active column is 64 M floats -- M per lane -- and the active set only shrinks inside a stretch, so
+//     the slices of the first KRES columns of every wave stay in REGISTERS for the whole stretch (8 waves x 96 / M columns:
+//     768 columns at n <= 2048): no matrix traffic at all in the steady state.  (First cut of this kernel: 8 workgroups of 256
+//     rows re-reading their slices from the L2 twice per iteration -- 14.7 us per iteration at BASELINE configs[2], bound by what
+//     EIGHT compute units can pull from the L2.)
+// The arithmetic of an iteration is the reference's (ADMMLassoWide.h:86-118,156-170; same prox, same float formulas, FMA
+// contraction off in the elementwise part); what differs from the two-launch path is only the ORDER of the sums inside the two
+// mat-vecs (dot: M rows per lane, lanes, then row slices in order; A x: a wave's columns in list order, then the waves in
+// order), which the stepwise rule holds to the float dot-product yardstick (oracle/stepcheck.py check_wide) like every other
+// variant.  The active columns (the non-zeros of x when the stretch starts; a zero never comes back before the next regular
+// step) are listed once per stretch by a deterministic two-pass ballot compaction that every workgroup performs identically.
+constexpr int kRCMAX = 2048;              // active columns a stretch can carry
+constexpr int kRG = 32;                   // most workgroups
+constexpr int kRNW = 8;                   // waves per workgroup
+struct WideRows {
+    unsigned long long* flag;             // [kRG][8] hand-over words (launch << 32) | hand-over number, one 64-byte line each
+    unsigned long long* flagX;            // [kRG][8] (launch << 32) | (XCD + 1)
+    float* pd;                            // [2][G][kRCMAX] partial dots, by parity of the hand-over number
+    double* np;                           // [2][G][8] norm shares
+    int* err;
+    unsigned long long seq;               // launch number
+    unsigned long long* stat;             // [16] iterations, stretches, ticks, not-one-XCD launches, redo rounds, phase ticks
+    double* hint;                         // [2][2] as WidePersist::hint
+    int* lst_idx; float* lst_x;           // [G][kRCMAX] the workgroups' lists of non-zeros of their slice of x (column, value)
+    int* lcount;                          // [kRG] their lengths
+    float* pa;                            // [2][G][256] partials of A x (workgroup (r, c): its columns, its rows)
+    int G, R, C;                          // G = R C workgroups: R row groups of 256 rows x C column groups
+    int diag;                             // per-phase timestamps (ADMM_HIP_WIDE_PERSIST_STATS)
+};
+
+// halving_sum8 (device_utils.h) for floats on the cross-lane hardware of gfx950 instead of eight LDS permutes + three: the
+// distance-32 / 16 steps as v_permlane32_swap / v_permlane16_swap (one swap + one add per pair of values), distance 8 as a DPP
+// row rotation, the last three as DPP quad permutes and a half-row mirror.  Lane l ends up with the wave total of value (l >> 3).
+// (Other ORDER of the last three additions than halving_sum8: a fixed one, used by wide_rows_persist_kernel only.)
+template <int CTRL> __device__ __forceinline__ float dpp_mov_f32(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float halving_sum8_dpp(const float (&v)[8], int lane) {
+    float a4[4], a2[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[j]), __float_as_uint(v[j + 4]), false, false);
+        a4[j] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a4[j]), __float_as_uint(a4[j + 2]), false, false);
+        a2[j] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    const int b = (lane >> 3) & 1;
+    const float keep = b ? a2[1] : a2[0], send = b ? a2[0] : a2[1];
+    float r = keep + dpp_mov_f32<0x128>(send);              // row_ror:8
+    r += dpp_mov_f32<0xB1>(r);                              // quad_perm [1, 0, 3, 2]
+    r += dpp_mov_f32<0x4E>(r);                              // quad_perm [2, 3, 0, 1]
+    r += dpp_mov_f32<0x141>(r);                             // row_half_mirror
+    return r;
+}
+
+// The same for eight doubles per lane (the five squared norms of the stopping test): every exchange moves the two 32-bit halves.
+__device__ __forceinline__ double dpp_swap_add_f64(double a, double b, bool s32) {
+    const unsigned long long ua = (unsigned long long)__double_as_longlong(a), ub = (unsigned long long)__double_as_longlong(b);
+    unsigned alo = (unsigned)ua, ahi = (unsigned)(ua >> 32), blo = (unsigned)ub, bhi = (unsigned)(ub >> 32);
+    if (s32) {
+        const auto r0 = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+        const auto r1 = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+        alo = r0[0]; blo = r0[1]; ahi = r1[0]; bhi = r1[1];
+    } else {
+        const auto r0 = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+        const auto r1 = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+        alo = r0[0]; blo = r0[1]; ahi = r1[0]; bhi = r1[1];
+    }
+    return __longlong_as_double((long long)(((unsigned long long)ahi << 32) | alo)) + __longlong_as_double((long long)(((unsigned long long)bhi << 32) | blo));
+}
+template <int CTRL> __device__ __forceinline__ double dpp_mov_f64(double x) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xF, 0xF, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xF, 0xF, false);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double halving_sum8_dpp(const double (&v)[8], int lane) {
+    double a4[4], a2[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a4[j] = dpp_swap_add_f64(v[j], v[j + 4], true);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) a2[j] = dpp_swap_add_f64(a4[j], a4[j + 2], false);
+    const int b = (lane >> 3) & 1;
+    const double keep = b ? a2[1] : a2[0], send = b ? a2[0] : a2[1];
+    double r = keep + dpp_mov_f64<0x128>(send);
+    r += dpp_mov_f64<0xB1>(r);
+    r += dpp_mov_f64<0x4E>(r);
+    r += dpp_mov_f64<0x141>(r);
+    return r;
+}
+
+__device__ __forceinline__ double wide_halving_dpp(const double (&v)[8], int lane) { return halving_sum8_dpp(v, lane); }
+
+__device__ __forceinline__ void wr_store_f32(float* p, float v, bool wt) {
+    if (wt) __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+__device__ __forceinline__ float wr_load_f32(const float* p) {
+    return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// Second cut (measured at BASELINE configs[2], 32 workgroups x 64 rows, everything above in place): 10.9 us per iteration -- the
+// all-to-all of the partial dots is G^2 nS floats per iteration (4 MB at nS = 1000: every workgroup reads every workgroup's
+// partial of every column: ~1 us of L2 requests, twice that beyond 512 columns) and every workgroup does the x-update, the dots
+// and A x for ALL columns.  Third cut, this one: a 2-D split.  The G <= 32 workgroups form R row groups x C column groups
+// (R = ceil(n / 256), C = 32 / R: 8 x 4 at n = 2000); workgroup (r, c) keeps the 256-row slices of the listed columns
+// j = c mod C.  Per iteration
+//   (1) x-update of ITS columns from the R partial dots of its column group (x of a column group is replicated R times, not 32),
+//   (2) its partial of A x over its columns for its rows                      -> hand-over A inside the row group (C x 256 floats),
+//   (3) A x, z, y, norms, the speculative next t of its rows (replicated C times), the partial dots of its columns over its rows
+//                                                                             -> hand-over B inside the column group (R x nS / C
+//       floats) + the norm shares of the row groups (published by column group 0),
+//   (4) the decision, by everybody.
+// Two hand-overs per iteration like the round-3 stretch, but their payloads are 1 KB and ~1 KB instead of 8 KB x 32 and the
+// column slices never leave the registers.
+constexpr int kRRS = 256;                 // rows per row group
+constexpr int kRKRES = 24;                // register-resident columns per wave (float4 each: 96 registers)
+
+__global__ void __launch_bounds__(kRNW * 64)
+wide_rows_persist_kernel(WideParams q, int cpar, WideRows ps) {
     if ((blockIdx.x & 7) != 0) return;
-    const int g = blockIdx.x >> 3;
-    if (g >= kPG) return;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int npad = (q.n + 255) / 256 * 256;
-    float* tdl = reinterpret_cast<float*>(smem_raw);                       // t / gamma [npad]
-    float4* red = reinterpret_cast<float4*>(smem_raw + (size_t)npad * sizeof(float));      // [RT][256] wave partials of A x
-    __shared__ int s_ok, s_same;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    constexpr int NWp = kPG * (kWideThreads / 64);
-    const int w = g * (kWideThreads / 64) + wid;
-    // ---- the decision the next x-update launch would take: go on only if it is an active-set step
-    WideCtl in = q.ctl[cpar];
-    in = wide_ctl_uniform(in);
-    // (this launch READS hint[seq & 1] and WRITES hint[(seq + 1) & 1]: every workgroup sees the same words)
+    const int g = blockIdx.x >> 3, G = ps.G, R = ps.R, C = ps.C;
+    if (g >= G) return;
+    const int r = g / C, c = g % C;                         // row group, column group
+    constexpr int NW = kRNW, T = NW * 64, RS = kRRS, KRES = kRKRES;
+    constexpr int KMAX = kRCMAX / NW;                       // list positions per wave (256)
+    __shared__ float xa[kRCMAX];                            // x of the listed columns (only this column group's entries are kept up to date)
+    __shared__ int cidx[kRCMAX];                            // their column numbers
+    __shared__ __attribute__((aligned(16))) float td[RS];   // t / gamma of this workgroup's rows
+    __shared__ __attribute__((aligned(16))) float comb[NW][RS];     // the waves' partials of A x (this workgroup's rows, its columns)
+    __shared__ int cnt[(262144 / 4 / T + 1) * NW + 64];     // compaction: non-zeros per (pass, wave), then their exclusive prefix
+    __shared__ double nsh[4][8];
+    __shared__ int loff[kRG + 2];
+    __shared__ int s_ok, s_same, s_ns;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    WideCtl in = wide_ctl_uniform(q.ctl[cpar]);
     const double* hin = ps.hint + (size_t)(ps.seq & 1) * 2;
     double* hout = ps.hint + (size_t)((ps.seq + 1) & 1) * 2;
     const double h_nnz = hin[0], h_wait = hin[1];
-    const bool leader = g == 0 && threadIdx.x == 0;
+    const bool leader = g == 0 && tid == 0;
     if (in.done || in.first) { if (leader) { hout[0] = h_nnz; hout[1] = h_wait; } return; }
-    if (h_nnz > (double)ps.max_cols && h_wait > 0.0) { if (leader) { hout[0] = h_nnz; hout[1] = h_wait - 1.0; } return; }
+    if (h_nnz > (double)kRCMAX && h_wait > 0.0) { if (leader) { hout[0] = h_nnz; hout[1] = h_wait - 1.0; } return; }
     double sums[5];
     {
         const WideNormRaw nraw = wide_norms_request(q, lane);
         wide_norms_finish(q, lane, nraw, sums);
     }
-    WideDecision dec = wide_decide(q, in, sums, lane);
+    WideDecision dec = wide_decide<true>(q, in, sums, lane);
     WideCtl out = wide_ctl_uniform(dec.out);
     if (out.done || out.type != W_ACT || __builtin_amdgcn_readfirstlane(dec.lam_finished) >= 0) { if (leader) { hout[0] = h_nnz; hout[1] = h_wait; } return; }
-    // ---- where do we run?  Every workgroup announces its XCD (write-through, valid under any placement); the answer is
-    // collected below, after the loads of the prologue have been issued
-    if (threadIdx.x == 0) __hip_atomic_store(ps.flagX + (size_t)g * 8, (ps.seq << 32) | (unsigned long long)(wp_xcc_id() + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // ---- this wave's x slots, its share of the rows, in registers for the whole stretch
-    float xs[kPNU];
-#pragma unroll
-    for (int u = 0; u < kPNU; ++u) {
-        const long long jl = (long long)(u * 64 + lane) * NWp + w;
-        xs[u] = jl < q.p ? q.x[jl] : 0.f;
-    }
-    const int R = npad / kPG;                                   // rows per workgroup, a multiple of 8
-    // reducer mapping: 8 lanes share a PAIR of rows (4 of the kPG partials each); pairs beyond R / 2 idle
-    const int sub = threadIdx.x & 7, pair = threadIdx.x >> 3;
-    const int npairs_pass = kWideThreads / 8;                    // 32 pairs = 64 rows per pass
-    constexpr int MAXP = 4;                                      // R <= 256 rows per workgroup (n <= 8192)
-    float ax_r[MAXP][2], z_r[MAXP][2], y_r[MAXP][2], yd_r[MAXP][2];
-#pragma unroll
-    for (int ps_ = 0; ps_ < MAXP; ++ps_) {
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int i = g * R + (ps_ * npairs_pass + pair) * 2 + e;
-            const bool own = (ps_ * npairs_pass + pair) * 2 < R && i < q.n;
-            ax_r[ps_][e] = own ? q.Ax[i] : 0.f; z_r[ps_][e] = own ? q.z[i] : 0.f; y_r[ps_][e] = own ? q.y[i] : 0.f; yd_r[ps_][e] = own ? q.Y[i] : 0.f;
-        }
-    }
-    // first t from the vectors the tail launch left (plain loads: written by an earlier launch)
-    {
-        const float rho_f = (float)out.rho;
-        for (int i = threadIdx.x; i < npad; i += kWideThreads) {
-            const float t = i < q.n ? (q.Ax[i] + q.z[i]) + q.y[i] / rho_f : 0.f;
-            tdl[i] = t / q.gamma;
-        }
-    }
-    const int nv = (q.n + 3) / 4 * 4;
-    // the wave's first non-zero column stays in registers for the whole stretch (the active set only shrinks inside it:
-    // a zero never comes back before the next regular step): no column round trip in most iterations
-    int cu0 = -1, cl0 = -1;
-#pragma unroll
-    for (int u = 0; u < kPNU; ++u) {
-        const unsigned long long m = __ballot(xs[u] != 0.f);
-        if (cu0 < 0 && m != 0) { cu0 = u; cl0 = __ffsll((long long)m) - 1; }
-    }
-    float4 cv0[RT];
-#pragma unroll
-    for (int kk = 0; kk < RT; ++kk) cv0[kk] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (cu0 >= 0) {
-        const float* col = q.X + (size_t)((long long)(cu0 * 64 + cl0) * NWp + w) * q.ldx;
-#pragma unroll
-        for (int kk = 0; kk < RT; ++kk) {
-            const int r = kk * 256 + lane * 4;
-            if (r < nv) cv0[kk] = *reinterpret_cast<const float4*>(col + r);
-        }
-    }
-    if (!wp_wait_xcc(ps.flagX, ps.seq, ps.err, &s_ok, &s_same)) return;       // (also the barrier after staging t)
-    const bool wt = s_same == 0;                                 // not all on one XCD: payloads must be written through
-    unsigned long long k = 0;                                    // iterations completed in this launch
-    bool failed = false;
-    double nz_last = 0.0;
     const long long tick0 = wall_clock64();
-    long long ph[6] = {0, 0, 0, 0, 0, 0}, tp = tick0;              // diagnostics: ticks per phase, as seen by workgroup 0
-#define WP_PHASE(i) { const long long tn = wall_clock64(); ph[i] += tn - tp; tp = tn; }
+
+    // ---- the active columns.  Workgroup g lists the non-zeros of ITS slice of x (two-pass ballot compaction: counts per (pass,
+    // wave), exclusive prefix, ordered write), publishes count + list, and after the first hand-over of the launch every
+    // workgroup concatenates the G lists in workgroup order: the same list everywhere, 1 / G of the scan each.  (First cut: every
+    // workgroup scanned all of x -- 60 us per stretch at p = 2 * 10^5, 1.5 us per iteration of a 40-iteration stretch.)
+    unsigned long long hs = 0;                              // hand-overs made in this launch
+    auto publish = [&](unsigned long long h) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(ps.flag + (size_t)g * 8, (ps.seq << 32) | h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // every wave polls the words it needs itself: lane l < G watches workgroup l if `need(l)`
+    auto wait_for = [&](unsigned long long h, int kind) -> bool {      // kind 0: everybody, 1: my row group, 2: my column group + the share publishers (column group 0)
+        bool ok = true;
+        const bool need = lane < G && (kind == 0 || (kind == 1 && lane / C == r) || (kind == 2 && (lane % C == c || lane % C == 0)));
+        if (need) {
+            const unsigned long long* fw = ps.flag + (size_t)lane * 8;
+            const unsigned long long val = (ps.seq << 32) | h;
+            const long long t0 = wall_clock64();
+            while (__hip_atomic_load(fw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < val) {
+                __builtin_amdgcn_s_sleep(1);
+                if (wall_clock64() - t0 > 200000000ll) { ok = false; break; }        // 2 s
+            }
+        }
+        ok = __all(ok) != 0;
+        if (!ok && lane == 0) __hip_atomic_store(ps.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return ok;
+    };
+    const int nq = (q.p + 3) / 4;                           // float4 groups of x (padded with zeros to a multiple of 32)
+    const int per = (nq + G - 1) / G;                       // ... per workgroup
+    const int q0 = g * per, q1 = min(nq, q0 + per);
+    const int npass = (per + T - 1) / T;
+    for (int it0 = 0; it0 < npass; it0 += 4) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e4 = q0 + (it0 + u) * T + tid;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (it0 + u < npass && e4 < q1) v[u] = *reinterpret_cast<const float4*>(q.x + (size_t)e4 * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int cc = __popcll(__ballot(v[u].x != 0.f)) + __popcll(__ballot(v[u].y != 0.f)) + __popcll(__ballot(v[u].z != 0.f)) + __popcll(__ballot(v[u].w != 0.f));
+            if (lane == 0 && it0 + u < npass) cnt[(it0 + u) * NW + wid] = cc;
+        }
+    }
+    __syncthreads();
+    if (wid == 0) {                                         // exclusive prefix over the npass * NW counts (one wave, a run per lane)
+        const int m = npass * NW, pl = (m + 63) / 64;
+        int loc = 0;
+        for (int k = 0; k < pl; ++k) { const int i = lane * pl + k; if (i < m) loc += cnt[i]; }
+        int inc = loc;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+        int run = inc - loc;
+        for (int k = 0; k < pl; ++k) { const int i = lane * pl + k; if (i < m) { const int cc = cnt[i]; cnt[i] = run; run += cc; } }
+        if (lane == 63) s_ns = inc;
+    }
+    __syncthreads();
+    const int nloc = s_ns;
+    {
+        int* li = ps.lst_idx + (size_t)g * kRCMAX;
+        float* lx = ps.lst_x + (size_t)g * kRCMAX;
+        if (nloc <= kRCMAX) {
+            for (int it = 0; it < npass; ++it) {
+                int base = cnt[it * NW + wid];
+                const int next = it * NW + wid + 1 < npass * NW ? cnt[it * NW + wid + 1] : nloc;
+                if (next == base) continue;                 // nothing in this wave's 256 entries (wave uniform): no load
+                const int e4 = q0 + it * T + tid;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e4 < q1) v = *reinterpret_cast<const float4*>(q.x + (size_t)e4 * 4);
+                const unsigned long long lt = (1ull << lane) - 1ull;
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    const unsigned long long m = __ballot(vv[cc] != 0.f);
+                    if (vv[cc] != 0.f) {
+                        const int pos = base + __popcll(m & lt);
+                        __hip_atomic_store(li + pos, e4 * 4 + cc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        wr_store_f32(lx + pos, vv[cc], true);
+                    }
+                    base += __popcll(m);
+                }
+            }
+        }
+        if (tid == 0) __hip_atomic_store(ps.lcount + g, nloc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid == 0) __hip_atomic_store(ps.flagX + (size_t)g * 8, (ps.seq << 32) | (unsigned long long)(wp_xcc_id() + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    hs++;
+    publish(hs);
+    if (!wait_for(hs, 0)) return;
+    if (wid == 0) {                                         // offsets of the G lists
+        const int cc = lane < G ? __hip_atomic_load(ps.lcount + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        int inc = cc;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+        if (lane <= G) loff[lane] = lane < G ? inc - cc : 0;
+        if (lane == G - 1) { loff[G] = inc; s_ns = inc; }
+        const int anybig = __any(cc > kRCMAX);
+        if (lane == 0 && anybig) s_ns = kRCMAX + 1;
+    }
+    __syncthreads();
+    const int nS = s_ns;
+    if (nS > kRCMAX || nS == 0) { if (leader) { hout[0] = (double)nS; hout[1] = 64.0; } return; }
+    for (int j = tid; j < nS; j += T) {
+        int lo = 0, hi = G;                                 // the list j falls into: loff[lo] <= j < loff[lo + 1]
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (loff[mid] <= j) lo = mid; else hi = mid; }
+        const int k = j - loff[lo];
+        cidx[j] = __hip_atomic_load(ps.lst_idx + (size_t)lo * kRCMAX + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        xa[j] = wr_load_f32(ps.lst_x + (size_t)lo * kRCMAX + k);
+    }
+    // this column group's part of the list: positions j = c + C jj, jj < nC; wave w takes jj = w + NW k
+    const int nC = nS > c ? (nS - c + C - 1) / C : 0;
+    auto jpos = [&](int w, int k) -> int { return c + C * (w + NW * k); };      // list position of the wave's k-th column
+    // ---- this workgroup's rows in registers (thread tid < RS owns row RS r + tid; replicated in the C workgroups of the row group)
+    const int row = r * RS + tid;
+    const bool own = tid < RS && row < q.n;
+    float ax_r = own ? q.Ax[row] : 0.f, z_r = own ? q.z[row] : 0.f, y_r = own ? q.y[row] : 0.f;
+    const float yd_r = own ? q.Y[row] : 0.f;
+    const int rl = r * RS + lane * 4;                       // the 4 rows a lane holds of a column slice
+    const bool rlok = rl < q.ldx;                           // padding rows up to ldx are zero; beyond that the next column begins
+    if (tid < RS) {                                         // first t from the vectors the tail launch left
+        const float rho_f = (float)out.rho;
+        const float t = own ? (ax_r + z_r) + y_r / rho_f : 0.f;
+        td[tid] = t / q.gamma;
+    }
+    __syncthreads();                                        // list, xa, td complete
+    // the wave's first KRES columns stay in registers for the whole stretch
+    float4 rc[KRES];
+#pragma unroll
+    for (int k0 = 0; k0 < KRES; k0 += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) rc[k0 + u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (wid + NW * k0 < nC && rlok) {                   // nothing beyond the list (wave uniform)
+            int cc[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) cc[u] = cidx[min(jpos(wid, k0 + u), nS - 1)];        // clamped: every load below is unconditional
+#pragma unroll
+            for (int u = 0; u < 8; ++u) rc[k0 + u] = *reinterpret_cast<const float4*>(q.X + (size_t)cc[u] * q.ldx + rl);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (wid + NW * (k0 + u) >= nC) rc[k0 + u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    if (!wp_wait_xcc(ps.flagX, ps.seq, ps.err, &s_ok, &s_same, G)) return;
+    const bool wt = s_same == 0;
+    unsigned long long k_done = 0, redo = 0;
+    long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp = wall_clock64();          // diagnostics: ticks per phase, as seen by workgroup 0
+#define WR_PHASE(i) if (ps.diag) { const long long tn = wall_clock64(); ph[i] += tn - tp; tp = tn; }
+
+    // x of the wave's resident columns, lane-indexed (lane k holds column k): one LDS round trip for all of them; column k's value
+    // is then a readlane with a compile-time lane -- no LDS latency and no branch per column
+    auto wave_x = [&]() -> float {
+        const int j = jpos(wid, lane);
+        return (lane < KRES && wid + NW * lane < nC) ? xa[j] : 0.f;
+    };
+    auto slice = [&](int j) -> float4 {
+        return rlok ? *reinterpret_cast<const float4*>(q.X + (size_t)cidx[j] * q.ldx + rl) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    // partial dots of this workgroup's rows for its live columns, to pd[h & 1][g][wid * KMAX + k].  Eight columns at a time: the
+    // lanes' products, then ONE halving butterfly for the eight sums (lane 8 u ends up with the total of column u).
+    auto dots = [&](unsigned long long h) {
+        float* dst = ps.pd + ((size_t)(h & 1) * G + g) * kRCMAX + (size_t)wid * KMAX;
+        const float4 tv = *reinterpret_cast<const float4*>(td + lane * 4);
+        auto dot1 = [&](const float4& cv) -> float {
+            float d = cv.x * tv.x;
+            d = fmaf(cv.y, tv.y, d); d = fmaf(cv.z, tv.z, d); d = fmaf(cv.w, tv.w, d);
+            return d;
+        };
+        const float xr = wave_x();
+#pragma unroll
+        for (int k0 = 0; k0 < KRES; k0 += 8) {              // register-resident columns
+            if (wid + NW * k0 < nC) {
+                float v8[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float xv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xr), k0 + u));
+                    v8[u] = xv != 0.f ? dot1(rc[k0 + u]) : 0.f;  // (a select: a dead column's slice stays in its registers)
+                }
+                const float tot = halving_sum8_dpp(v8, lane);
+                if ((lane & 7) == 0) wr_store_f32(dst + k0 + (lane >> 3), tot, wt);
+            }
+        }
+        for (int k0 = KRES; wid + NW * k0 < nC; k0 += 8) {  // the others: eight slices in flight (from the L2)
+            float4 cv[8];
+            float xv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool in_list = wid + NW * (k0 + u) < nC;
+                const int j = jpos(wid, k0 + u);
+                xv[u] = in_list ? xa[j] : 0.f;
+                cv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (xv[u] != 0.f) cv[u] = slice(j);
+            }
+            float v8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v8[u] = xv[u] != 0.f ? dot1(cv[u]) : 0.f;
+            const float tot = halving_sum8_dpp(v8, lane);
+            if ((lane & 7) == 0) wr_store_f32(dst + k0 + (lane >> 3), tot, wt);
+        }
+    };
+    // the R partial dots of listed position j (of this column group) in row-group order: all requests in flight together
+    auto pd_get = [&](int j, unsigned long long h) -> float {      // eight requests in flight (R = 8 at n = 2000: one round)
+        const int jj = j / C;
+        const float* src = ps.pd + ((size_t)(h & 1) * G + c) * kRCMAX + (jj % NW) * KMAX + jj / NW;      // workgroup (0, c), then (1, c), ...
+        float d = 0.f;
+        for (int u0 = 0; u0 < R; u0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = wr_load_f32(src + (size_t)min(u0 + u, R - 1) * C * kRCMAX);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) d = (u0 + u == 0) ? v[0] : (u0 + u < R ? d + v[u] : d);
+        }
+        return d;
+    };
+    dots(hs + 1);                                           // iteration under `out`: rho known, nothing speculative
+    hs++;
+    publish(hs);
+    bool failed = false;
+    const long long tick1 = wall_clock64();
+    tp = tick1;
+    if (!wait_for(hs, 2)) return;
+    // the thread's first column: its partial dots are requested together with the norm shares, BEFORE the decision (one memory
+    // round trip for both), and summed right away
+    const int j0 = c + C * tid;                             // list position of the thread's first column
+    float d0 = 0.f;
+    bool have0 = tid < nC && xa[j0] != 0.f;
+    if (have0) d0 = pd_get(j0, hs);
     for (;;) {
+        WR_PHASE(0)
         // ---- (record the decision being acted on: what the x-update launch writes)
-        if (g == 0 && threadIdx.x == 0 && q.trace != nullptr && in.total < q.trace_cap) {
+        if (leader && q.trace != nullptr && in.total < q.trace_cap) {
             double* t = q.trace + (size_t)in.total * ADMM_TRACE_FIELDS;
             t[0] = in.lam_idx; t[1] = in.iter; t[2] = in.eps_primal; t[3] = in.eps_dual; t[4] = dec.rp; t[5] = dec.rd;
             t[6] = out.rho; t[7] = out.type; t[8] = dec.code; t[9] = in.rho; t[10] = out.rho; t[11] = in.lam;
         }
-        // ---- (B) active-set update of this wave's non-zero columns (ADMMLassoWide.h:86-118 / ADMMEnet.h:85-122)
-        const double pen_d = (double)out.lam / (out.rho * (double)q.gamma);
-        const float penalty = (float)pen_d;
-        const float thresh_a = q.enet ? q.alpha * penalty : penalty;
-        const float denom_a = q.enet ? (float)(1.0 + (double)penalty * (1.0 - (double)q.alpha)) : 1.f;
-        float4 acc[RT];
-#pragma unroll
-        for (int kk = 0; kk < RT; ++kk) acc[kk] = make_float4(0.f, 0.f, 0.f, 0.f);
-        int nnz_w = 0;
-#pragma unroll
-        for (int u = 0; u < kPNU; ++u) {
-            unsigned long long mask = __ballot(xs[u] != 0.f);
-            while (mask) {
-                const int l = __ffsll((long long)mask) - 1;
-                mask &= mask - 1;
-                const long long jj = (long long)(u * 64 + l) * NWp + w;
-                const float xv = __shfl(xs[u], l, 64);
-                const float* col = q.X + (size_t)jj * q.ldx;
-                float4 cv[RT];
-                if (u == cu0 && l == cl0) {
-#pragma unroll
-                    for (int kk = 0; kk < RT; ++kk) cv[kk] = cv0[kk];
-                } else {
-#pragma unroll
-                    for (int kk = 0; kk < RT; ++kk) {
-                        const int r = kk * 256 + lane * 4;
-                        cv[kk] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (r < nv) cv[kk] = *reinterpret_cast<const float4*>(col + r);
-                    }
-                }
-                float d0 = 0.f, d1 = 0.f;
-#pragma unroll
-                for (int kk = 0; kk < RT; ++kk) {
-                    const int r = kk * 256 + lane * 4;
-                    if (r < nv) {
-                        const float4 b = *reinterpret_cast<const float4*>(tdl + r);
-                        float& dd = (kk & 1) ? d1 : d0;
-                        dd = fmaf(cv[kk].x, b.x, dd); dd = fmaf(cv[kk].y, b.y, dd); dd = fmaf(cv[kk].z, b.z, dd); dd = fmaf(cv[kk].w, b.w, dd);
-                    }
-                }
-                const float xn = prox_f(xv - wave_sum(d0 + d1), thresh_a, denom_a, q.enet != 0);
-                if (xn != 0.f) {
-                    nnz_w++;
-#pragma unroll
-                    for (int kk = 0; kk < RT; ++kk) {
-                        acc[kk].x = fmaf(xn, cv[kk].x, acc[kk].x); acc[kk].y = fmaf(xn, cv[kk].y, acc[kk].y);
-                        acc[kk].z = fmaf(xn, cv[kk].z, acc[kk].z); acc[kk].w = fmaf(xn, cv[kk].w, acc[kk].w);
-                    }
-                }
-                if (lane == l) xs[u] = xn;
-            }
-        }
-        WP_PHASE(0)
-        // ---- (C) the workgroup's partial of A x: the 4 waves in order, written through
-        __syncthreads();                                         // everybody is done with tdl's neighbour `red` of the last round
-#pragma unroll
-        for (int kk = 0; kk < RT; ++kk) red[kk * kWideThreads + threadIdx.x] = acc[kk];
-        __syncthreads();
-        for (int e = threadIdx.x; e < npad / 2; e += kWideThreads) {          // element pair e: rows 2 e, 2 e + 1
-            const int r0 = 2 * e, kk = r0 / 256, ln = (r0 % 256) / 4, c = r0 & 3;
-            float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-            for (int ww = 0; ww < kWideThreads / 64; ++ww) {
-                const float4 v = red[kk * kWideThreads + ww * 64 + ln];
-                const float a = c == 0 ? v.x : v.z, b = c == 0 ? v.y : v.w;
-                s0 = ww == 0 ? a : s0 + a; s1 = ww == 0 ? b : s1 + b;
-            }
-            wp_store2(q.axpart + (size_t)g * q.ldn + r0, s0, s1, wt);
-        }
-        const unsigned long long tag = (ps.seq << 32) | (k + 1);
-        wp_publish(ps.flagA + (size_t)g * 8, tag);
-        WP_PHASE(1)
-        // ---- (D) rows of this workgroup: A x from the kPG partials in workgroup order, z / y update, norm shares
-        if (!wp_wait(ps.flagA, tag, ps.err, &s_ok)) { failed = true; break; }
-        WP_PHASE(2)
-        double nacc[5] = {0, 0, 0, 0, 0};
+        // ---- x-update of this column group's columns from the R partial dots (ADMMLassoWide.h:86-118 / ADMMEnet.h:85-122)
         {
-            const float rho_f = (float)out.rho;
-            const float den = (float)(-1.0 - out.rho);
+            const double pen_d = (double)out.lam / (out.rho * (double)q.gamma);
+            const float penalty = (float)pen_d;
+            const float thresh_a = q.enet ? q.alpha * penalty : penalty;
+            const float denom_a = q.enet ? (float)(1.0 + (double)penalty * (1.0 - (double)q.alpha)) : 1.f;
+            if (have0) xa[j0] = prox_f(xa[j0] - d0, thresh_a, denom_a, q.enet != 0);        // requested before the decision
+            for (int jj = tid + T; jj < nC; jj += T) {
+                const int j = c + C * jj;
+                const float xv = xa[j];
+                if (xv != 0.f) xa[j] = prox_f(xv - pd_get(j, hs), thresh_a, denom_a, q.enet != 0);
+            }
+        }
+        __syncthreads();
+        WR_PHASE(1)
+        // ---- partial of A x over this workgroup's columns, its rows: a wave adds up x_j X_j over its columns, the waves in order
+        {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float xr = wave_x();
 #pragma unroll
-            for (int ps_ = 0; ps_ < MAXP; ++ps_) {
-                const int pr = ps_ * npairs_pass + pair;
-                if (pr * 2 < R) {
-                    const int i0 = g * R + pr * 2;
-                    float2 v[kPG / 8];
+            for (int k0 = 0; k0 < KRES; k0 += 8) {          // x_j = 0 (dead, or beyond the list: slice 0) adds an exact zero: no branch per column
+                if (wid + NW * k0 < nC) {
 #pragma unroll
-                    for (int m = 0; m < kPG / 8; ++m) v[m] = wp_load2(q.axpart + (size_t)(m * 8 + sub) * q.ldn + i0);
-                    float a0 = v[0].x, a1 = v[0].y;
-#pragma unroll
-                    for (int m = 1; m < kPG / 8; ++m) { a0 += v[m].x; a1 += v[m].y; }
-#pragma unroll
-                    for (int m = 1; m < 8; m <<= 1) { a0 += __shfl_xor(a0, m, 64); a1 += __shfl_xor(a1, m, 64); }
-                    if (sub == 0) {
-#pragma clang fp contract(off)
-                        const float axn[2] = {a0, a1};
-#pragma unroll
-                        for (int e = 0; e < 2; ++e) {
-                            if (i0 + e < q.n) {
-                                const float ax = axn[e];
-                                const float zn = (yd_r[ps_][e] + y_r[ps_][e] + rho_f * ax) / den;      // next_z (:156-165)
-                                const float dz = zn - z_r[ps_][e];
-                                const float r = ax + zn;                                               // next_residual (:166-170)
-                                const float yn = y_r[ps_][e] + rho_f * r;                              // ADMMBase.h:183
-                                ax_r[ps_][e] = ax; z_r[ps_][e] = zn; y_r[ps_][e] = yn;
-                                nacc[0] += (double)r * r; nacc[1] += (double)dz * dz; nacc[2] += (double)ax * ax;
-                                nacc[3] += (double)zn * zn; nacc[4] += (double)yn * yn;
-                            }
-                        }
-                        wp_store2(ps.sz + i0, ax_r[ps_][0] + z_r[ps_][0], ax_r[ps_][1] + z_r[ps_][1], wt);
-                        wp_store2(ps.yv + i0, y_r[ps_][0], y_r[ps_][1], wt);
+                    for (int u = 0; u < 8; ++u) {
+                        const float xv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xr), k0 + u));
+                        acc.x = fmaf(xv, rc[k0 + u].x, acc.x); acc.y = fmaf(xv, rc[k0 + u].y, acc.y);
+                        acc.z = fmaf(xv, rc[k0 + u].z, acc.z); acc.w = fmaf(xv, rc[k0 + u].w, acc.w);
                     }
                 }
             }
+            for (int k0 = KRES; wid + NW * k0 < nC; k0 += 8) {
+                float4 cv[8];
+                float xv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const bool in_list = wid + NW * (k0 + u) < nC;
+                    const int j = jpos(wid, k0 + u);
+                    xv[u] = in_list ? xa[j] : 0.f;
+                    cv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (xv[u] != 0.f) cv[u] = slice(j);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (xv[u] != 0.f) {
+                        acc.x = fmaf(xv[u], cv[u].x, acc.x); acc.y = fmaf(xv[u], cv[u].y, acc.y);
+                        acc.z = fmaf(xv[u], cv[u].z, acc.z); acc.w = fmaf(xv[u], cv[u].w, acc.w);
+                    }
+                }
+            }
+            *reinterpret_cast<float4*>(&comb[wid][lane * 4]) = acc;
         }
-        {   // the workgroup's norm shares and non-zero count: fixed order (lanes, then waves)
-            double* scr = reinterpret_cast<double*>(red);                     // `red` has been consumed (barrier inside wp_wait)
-            double v6[6] = {nacc[0], nacc[1], nacc[2], nacc[3], nacc[4], (double)nnz_w};
+        __syncthreads();
+        if (tid < RS) {                                     // the workgroup's partial: its waves in order            [hand-over A]
+            float a = comb[0][tid];
 #pragma unroll
-            for (int m = 0; m < 6; ++m) v6[m] = wave_sum(v6[m]);
-            // nnz_w is wave uniform: wave_sum multiplied it by 64
-            if (lane == 0) {
+            for (int w = 1; w < NW; ++w) a += comb[w][tid];
+            wr_store_f32(ps.pa + ((size_t)((hs + 1) & 1) * G + g) * RS + tid, a, wt);
+        }
+        hs++;
+        publish(hs);
+        WR_PHASE(2)
+        if (!wait_for(hs, 1)) { failed = true; break; }
+        WR_PHASE(3)
+        double nacc[5] = {0, 0, 0, 0, 0};
+        if (tid < RS) {
+            const float* src = ps.pa + ((size_t)(hs & 1) * G + (size_t)r * C) * RS + tid;      // workgroups (r, 0), (r, 1), ...
+            float ax = 0.f;
+            for (int u0 = 0; u0 < C; u0 += 8) {             // the C partials in column-group order, eight requests in flight
+                float v[8];
 #pragma unroll
-                for (int m = 0; m < 6; ++m) scr[wid * 8 + m] = v6[m];
+                for (int u = 0; u < 8; ++u) v[u] = wr_load_f32(src + (size_t)min(u0 + u, C - 1) * RS);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) ax = (u0 + u == 0) ? v[0] : (u0 + u < C ? ax + v[u] : ax);
+            }
+            if (own) {
+#pragma clang fp contract(off)
+                const float rho_f = (float)out.rho;
+                const float den = (float)(-1.0 - out.rho);
+                const float zn = (yd_r + y_r + rho_f * ax) / den;                      // next_z (:156-165)
+                const float dz = zn - z_r;
+                const float rr = ax + zn;                                              // next_residual (:166-170)
+                const float yn = y_r + rho_f * rr;                                     // ADMMBase.h:183
+                ax_r = ax; z_r = zn; y_r = yn;
+                nacc[0] = (double)rr * rr; nacc[1] = (double)dz * dz; nacc[2] = (double)ax * ax; nacc[3] = (double)zn * zn; nacc[4] = (double)yn * yn;
+                // t of the NEXT active-set step, speculating that the decision keeps rho
+                const float t = (ax_r + z_r) + y_r / rho_f;
+                td[tid] = t / q.gamma;
+            } else {
+                td[tid] = 0.f;
+            }
+        }
+        if (q.state != nullptr && out.total < q.state_cap) {      // iterate dump: x by row group 0 (zeros elsewhere: the dump is cleared), rows by column group 0
+            float* srec = q.state + (size_t)out.total * ((size_t)q.p + 3 * (size_t)q.n);
+            if (r == 0) for (int jj = tid; jj < nC; jj += T) srec[cidx[c + C * jj]] = xa[c + C * jj];
+            if (own && c == 0) { srec[(size_t)q.p + row] = ax_r; srec[(size_t)q.p + q.n + row] = z_r; srec[(size_t)q.p + 2 * (size_t)q.n + row] = y_r; }
+        }
+        if (wid < 4) {                                      // norm share of the 256 rows: lanes (one halving butterfly for the five sums), then the four waves in order
+            const double v8[8] = {nacc[0], nacc[1], nacc[2], nacc[3], nacc[4], 0.0, 0.0, 0.0};
+            const double tot = halving_sum8_dpp(v8, lane);
+            if ((lane & 7) == 0 && lane < 40) nsh[wid][lane >> 3] = tot;
+        }
+        __syncthreads();                                    // td, nsh complete
+        if (c == 0 && tid < 5) {
+            const double v = ((nsh[0][tid] + nsh[1][tid]) + nsh[2][tid]) + nsh[3][tid];
+            wp_store_f64(ps.np + ((size_t)((hs + 1) & 1) * kRG + r) * 8 + tid, v, wt);
+        }
+        dots(hs + 1);                                       //                                                          [hand-over B]
+        hs++;
+        publish(hs);
+        WR_PHASE(4)
+        k_done++;
+        // ---- the decision on the iteration just finished, by everybody from the same numbers
+        if (!wait_for(hs, 2)) { failed = true; break; }
+        WR_PHASE(5)
+        in = out;
+        {
+            const double* sh = ps.np + (size_t)(hs & 1) * kRG * 8;
+            double shv[5];                                  // the norm shares first, the (speculative) partial dots of the thread's first column behind them
+#pragma unroll
+            for (int m = 0; m < 5; ++m)
+                shv[m] = lane < R ? __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(sh + (size_t)lane * 8 + m),
+                                                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0.0;
+            have0 = tid < nC && xa[j0] != 0.f;
+            if (have0) d0 = pd_get(j0, hs);
+#pragma unroll
+            for (int m = 0; m < 5; ++m) sums[m] = shv[m];
+        }
+        dec = wide_decide<true>(q, in, sums, lane);
+        out = wide_ctl_uniform(dec.out);
+        const bool go_on = !out.done && out.type == W_ACT && __builtin_amdgcn_readfirstlane(dec.lam_finished) < 0;
+        WR_PHASE(6)
+        if (!go_on) break;
+        if (out.rho != in.rho) {                            // the speculation was wrong: t with the new rho, the partial dots once more
+            __syncthreads();                                // (everybody has read td for the speculative dots)
+            if (tid < RS) {
+                const float rho_f = (float)out.rho;
+                const float t = own ? (ax_r + z_r) + y_r / rho_f : 0.f;
+                td[tid] = t / q.gamma;
             }
             __syncthreads();
-            if (threadIdx.x < 6) {
-                double t = 0;
-                for (int ww = 0; ww < kWideThreads / 64; ++ww) t += scr[ww * 8 + threadIdx.x];
-                if (threadIdx.x == 5) t *= 1.0 / 64.0;
-                wp_store_f64(ps.np + (size_t)g * 8 + threadIdx.x, t, wt);
-            }
+            dots(hs + 1);
+            hs++;
+            publish(hs);
+            redo++;
+            if (!wait_for(hs, 2)) { failed = true; break; }
+            if (have0) d0 = pd_get(j0, hs);                 // the dots formed with the new rho replace the speculative ones
+            WR_PHASE(7)
         }
-        if (q.state != nullptr && out.total < q.state_cap) {         // iterate dump: this iteration's x | A x | z | y (record = the trace record that judges it)
-            float* srec = q.state + (size_t)out.total * ((size_t)q.p + 3 * (size_t)q.n);
-#pragma unroll
-            for (int u = 0; u < kPNU; ++u) {
-                const long long jl = (long long)(u * 64 + lane) * NWp + w;
-                if (jl < q.p) srec[jl] = xs[u];
-            }
-            if (sub == 0) {
-#pragma unroll
-                for (int ps_ = 0; ps_ < MAXP; ++ps_) {
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const int pr = ps_ * npairs_pass + pair;
-                        const int i = g * R + pr * 2 + e;
-                        if (pr * 2 < R && i < q.n) {
-                            srec[(size_t)q.p + i] = ax_r[ps_][e]; srec[(size_t)q.p + q.n + i] = z_r[ps_][e]; srec[(size_t)q.p + 2 * (size_t)q.n + i] = y_r[ps_][e];
-                        }
-                    }
-                }
-            }
-        }
-        wp_publish(ps.flagB + (size_t)g * 8, tag);
-        WP_PHASE(3)
-        k++;
-        // ---- (E) the decision on this iteration, by everybody from the same numbers
-        if (!wp_wait(ps.flagB, tag, ps.err, &s_ok)) { failed = true; break; }
-        WP_PHASE(4)
-        in = out;
-        // everything the rest of the iteration needs is requested at once: the norm shares AND the vectors of the next t
-        constexpr int NE = (RT * 256 / 2 + kWideThreads - 1) / kWideThreads;          // element pairs per thread
-        float2 sza[NE], yva[NE];
-#pragma unroll
-        for (int ee = 0; ee < NE; ++ee) {
-            const int e = ee * kWideThreads + threadIdx.x;
-            sza[ee] = make_float2(0.f, 0.f); yva[ee] = make_float2(0.f, 0.f);
-            if (e < npad / 2) { sza[ee] = wp_load2(ps.sz + 2 * e); yva[ee] = wp_load2(ps.yv + 2 * e); }
-        }
-        double nz_total;
-        {
-            double sh[6];
-#pragma unroll
-            for (int m = 0; m < 6; ++m)
-                sh[m] = lane < kPG ? __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(ps.np + (size_t)lane * 8 + m),
-                                                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0.0;
-#pragma unroll
-            for (int m = 0; m < 5; ++m) sums[m] = sh[m];
-            nz_total = wave_sum(sh[5]);
-        }
-        nz_last = nz_total;
-        dec = wide_decide(q, in, sums, lane);
-        out = wide_ctl_uniform(dec.out);
-        const bool go_on = !out.done && out.type == W_ACT && __builtin_amdgcn_readfirstlane(dec.lam_finished) < 0 && nz_total <= (double)ps.max_cols;
-        if (!go_on) { WP_PHASE(5) break; }
-        {   // t of the next active-set step from what the row owners published
-            const float rho_f = (float)out.rho;
-#pragma unroll
-            for (int ee = 0; ee < NE; ++ee) {
-                const int e = ee * kWideThreads + threadIdx.x;
-                if (e < npad / 2) {
-                    const float2 a = sza[ee], b = yva[ee];
-                    const float t0 = 2 * e < q.n ? a.x + b.x / rho_f : 0.f, t1 = 2 * e + 1 < q.n ? a.y + b.y / rho_f : 0.f;
-                    tdl[2 * e] = t0 / q.gamma; tdl[2 * e + 1] = t1 / q.gamma;
-                }
-            }
-        }
-        __syncthreads();
-        WP_PHASE(5)
     }
     if (failed) return;
     if (leader) {
-        hout[0] = nz_last; hout[1] = 64.0;
-        ps.stat[0] += k; ps.stat[1] += 1; ps.stat[2] += (unsigned long long)(wall_clock64() - tick0); ps.stat[3] += wt ? 1 : 0;
-        for (int i = 0; i < 6; ++i) ps.stat[4 + i] += (unsigned long long)ph[i];
+        hout[0] = (double)nS; hout[1] = 64.0;
+        ps.stat[0] += k_done; ps.stat[1] += 1; ps.stat[2] += (unsigned long long)(wall_clock64() - tick0); ps.stat[3] += wt ? 1 : 0; ps.stat[4] += redo;
+        ps.stat[5] += (unsigned long long)(tick1 - tick0);
+        for (int i = 0; i < 8; ++i) ps.stat[6 + i] += (unsigned long long)ph[i];
     }
     // ---- leave everything as a tail launch would have: x, A x, z, y, the norm partials, the control block
-#pragma unroll
-    for (int u = 0; u < kPNU; ++u) {
-        const long long jl = (long long)(u * 64 + lane) * NWp + w;
-        if (jl < q.p) q.x[jl] = xs[u];
-    }
-    if (sub == 0) {
-#pragma unroll
-        for (int ps_ = 0; ps_ < MAXP; ++ps_) {
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int pr = ps_ * npairs_pass + pair;
-                const int i = g * R + pr * 2 + e;
-                if (pr * 2 < R && i < q.n) { q.Ax[i] = ax_r[ps_][e]; q.z[i] = z_r[ps_][e]; q.y[i] = y_r[ps_][e]; }
-            }
-        }
-    }
+    if (r == 0) for (int jj = tid; jj < nC; jj += T) q.x[cidx[c + C * jj]] = xa[c + C * jj];
+    if (own && c == 0) { q.Ax[row] = ax_r; q.z[row] = z_r; q.y[row] = y_r; }
     if (g == 0) {
-        // the norm partials as a tail launch leaves them: rows [0, nwg_tail) hold the sums (here: row 0 holds all of it, added
-        // in workgroup order), every other row is ZERO -- the decision of the next launch adds up max(nwg_tail, 128) rows, and a
-        // later tail launch only overwrites the first nwg_tail of them (a stale share left in row nwg_tail .. kPG - 1 was added
-        // to every later decision: found by the random sweep, case 41 of seed 7, n = 19)
-        for (int idx = threadIdx.x; idx < q.nwg_tail * 8 || idx < kPG * 8; idx += kWideThreads) {
-            const int row = idx >> 3, m = idx & 7;
+        // norm partials: the share of row group r in row r (exactly the lanes' inputs of the decision above, so that the next launch,
+        // which repeats it from P, adds the same numbers in the same order), zero in every other row the next decision adds up
+        const double* sh = ps.np + (size_t)(hs & 1) * kRG * 8;
+        const int rows = q.nwg_tail > kWideNormRows ? q.nwg_tail : kWideNormRows;
+        for (int idx = tid; idx < rows * 8; idx += T) {
+            const int rr = idx >> 3, m = idx & 7;
             double v = 0.0;
-            if (row == 0 && m < 5) {
-                for (int r = 0; r < kPG; ++r)
-                    v += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(ps.np + (size_t)r * 8 + m),
-                                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            }
-            q.P[idx] = v;                                       // P holds max(nwg_tail, kWideNormRows) >= kPG rows
+            if (rr < R && m < 5)
+                v = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(sh + (size_t)rr * 8 + m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            q.P[idx] = v;
         }
-        if (threadIdx.x == 0) q.ctl[cpar] = in;                 // the state the breaking decision was taken FROM: the next launch repeats it
+        if (tid == 0) q.ctl[cpar] = in;                     // the state the breaking decision was taken FROM: the next launch repeats it
     }
 }
-
-// Measured and rejected (round 3): the same stretch with ONE hand-over per iteration -- 16 workgroups of 512 threads, every
-// workgroup adds up all 16 partials of A x itself (128 KB from the XCD's L2 per iteration) and keeps the whole z / y / A x in
-// registers, so that norms, decision and the next t need no second exchange.  Correct (same tests), but 12.1 us per iteration
-// inside against 10.5 us for the two-hand-over form above on C3: the 8-wave combine and the 16 x 8 KB of partial loads per
-// workgroup cost more than the second hop they remove.
 
 __global__ void wide_init_kernel(WideParams q, double rho, float lam0) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1444,42 +1625,43 @@ struct WidePlan final : LassoPlan {
         probe.alloc((size_t)4096 * 4 * 8); probe.zero(st);
         q.probe = probe.get();
 #endif
-        setup_persist();
+        setup_persist_rows();
         ADMM_HIP_CHECK(hipStreamSynchronize(st));
     }
 
-    // persistent active-set stretch (wide_act_persist_kernel)
-    bool persist = false;
-    DevBuf<unsigned long long> pflags;
-    DevBuf<float> psz, pyv;
-    DevBuf<double> pnp, phint;
-    DevBuf<int> perr;
-    DevBuf<unsigned long long> pstat;
-    unsigned long long pseq = 0;
-    int pmax_cols = 512;
-    size_t lds_persist = 0;
-
-
-    void setup_persist() {
-        persist = (fuse_rt == 4 || fuse_rt == 8) && !cshard && (long long)p <= (long long)kPNU * 64 * kPG * (kWideThreads / 64);
-        if (const char* e = std::getenv("ADMM_HIP_WIDE_PERSIST")) if (std::string(e) == "0") persist = false;
-        if (const char* e = std::getenv("ADMM_HIP_WIDE_PERSIST_COLS")) pmax_cols = std::max(1, std::atoi(e));
-        if (!persist) return;
-        const size_t npad = (size_t)(n + 255) / 256 * 256;
-        lds_persist = npad * sizeof(float) + (size_t)fuse_rt * kWideThreads * sizeof(float4);
-        pflags.alloc((size_t)3 * kPG * 8); pflags.zero(st);
-        psz.alloc(npad); pyv.alloc(npad); psz.zero(st); pyv.zero(st);
-        pnp.alloc((size_t)kPG * 8); pnp.zero(st);
-        phint.alloc(4); phint.zero(st);
-        perr.alloc(1); perr.zero(st);
-        pstat.alloc(16); pstat.zero(st);
+    // persistent active-set stretch (wide_rows_persist_kernel)
+    bool persist_rows = false;
+    int rows_G = 0, rows_R = 1, rows_C = 1;
+    DevBuf<unsigned long long> rflags, rstat;
+    DevBuf<float> rpd, rlx, rpa;
+    DevBuf<double> rnp, rhint;
+    DevBuf<int> rerr, rli, rlc;
+    unsigned long long rseq = 0;
+    void setup_persist_rows() {
+        // ADMM_HIP_WIDE_PERSIST=0: two launches per iteration only
+        persist_rows = !cshard && n <= kRRS * kRG && (long long)p <= 262144;
+        if (const char* e = std::getenv("ADMM_HIP_WIDE_PERSIST")) if (std::string(e) == "0") persist_rows = false;
+        if (!persist_rows) return;
+        rows_R = (n + kRRS - 1) / kRRS;                                     // row groups of 256 rows
+        rows_C = std::max(1, kRG / rows_R);                                 // column groups: R C <= 32 workgroups (one XCD)
+        if (const char* e = std::getenv("ADMM_HIP_WIDE_ROWS_C")) { const int c = std::atoi(e); if (c >= 1 && c * rows_R <= kRG) rows_C = c; }
+        rows_G = rows_R * rows_C;
+        rflags.alloc((size_t)2 * kRG * 8); rflags.zero(st);
+        rpd.alloc((size_t)2 * rows_G * kRCMAX); rpd.zero(st);
+        rpa.alloc((size_t)2 * rows_G * kRRS); rpa.zero(st);
+        rnp.alloc((size_t)2 * kRG * 8); rnp.zero(st);
+        rhint.alloc(4); rhint.zero(st);
+        rerr.alloc(1); rerr.zero(st);
+        rstat.alloc(16); rstat.zero(st);
+        rli.alloc((size_t)rows_G * kRCMAX); rlx.alloc((size_t)rows_G * kRCMAX); rlc.alloc(kRG); rlc.zero(st);
     }
-    void launch_persist(int cpar) {
-        WidePersist ps;
-        ps.flagA = pflags.get(); ps.flagB = pflags.get() + (size_t)kPG * 8; ps.flagX = pflags.get() + (size_t)2 * kPG * 8;
-        ps.sz = psz.get(); ps.yv = pyv.get(); ps.np = pnp.get(); ps.err = perr.get(); ps.seq = ++pseq; ps.max_cols = pmax_cols; ps.hint = phint.get(); ps.stat = pstat.get();
-        if (fuse_rt == 4) hipLaunchKernelGGL(wide_act_persist_kernel<4>, dim3(8 * kPG), dim3(kWideThreads), lds_persist, st, q, cpar, ps);
-        else hipLaunchKernelGGL(wide_act_persist_kernel<8>, dim3(8 * kPG), dim3(kWideThreads), lds_persist, st, q, cpar, ps);
+    void launch_persist_rows(int cpar) {
+        WideRows ps;
+        ps.flag = rflags.get(); ps.flagX = rflags.get() + (size_t)kRG * 8;
+        ps.pd = rpd.get(); ps.np = rnp.get(); ps.err = rerr.get(); ps.seq = ++rseq; ps.stat = rstat.get(); ps.hint = rhint.get();
+        ps.G = rows_G; ps.R = rows_R; ps.C = rows_C; ps.pa = rpa.get(); ps.diag = std::getenv("ADMM_HIP_WIDE_PERSIST_STATS") ? 1 : 0;
+        ps.lst_idx = rli.get(); ps.lst_x = rlx.get(); ps.lcount = rlc.get();
+        hipLaunchKernelGGL(wide_rows_persist_kernel, dim3(8 * rows_G), dim3(kRNW * 64), 0, st, q, cpar, ps);
     }
 
     void run(LassoResult& res) override {
@@ -1487,7 +1669,7 @@ struct WidePlan final : LassoPlan {
         res.lambda = lam_user;
         beta.zero(st); niter.zero(st);
         *hflag.p = 0;
-        if (persist) { phint.zero(st); perr.zero(st); }
+        if (persist_rows) { rhint.zero(st); rerr.zero(st); }
         const int init_n = std::max(std::max(n, p), nwg_tail * 8);
         hipLaunchKernelGGL(wide_init_kernel, dim3((init_n + 255) / 256), dim3(256), 0, st, q, rho0, lam_int[0]);
         const int batch = pb.batch_iters > 0 ? (pb.batch_iters + 1) / 2 * 2 : 16;
@@ -1524,24 +1706,28 @@ struct WidePlan final : LassoPlan {
             }
             hipLaunchKernelGGL(wide_tail_kernel<0>, dim3(nwg_tail), dim3(kWideThreads), 0, st, q, par, PeerExchange{});
             if (q.state != nullptr) hipLaunchKernelGGL(wide_state_kernel, dim3(std::min(1024, (std::max(n, p) + kWideThreads - 1) / kWideThreads)), dim3(kWideThreads), 0, st, q, par);
-            if (persist) launch_persist(par ^ 1);                      // takes over from the state the next x-update launch would start from
+            if (persist_rows) launch_persist_rows(par ^ 1);             // takes over from the state the next x-update launch would start from
         }, cshard ? nullptr : hflag.p);       // column-sharded: every rank must enqueue the same number of exchanges -> stream-ordered sampling of `done`
         S.t_loop = lt.wall_s; S.loop_ms_events = lt.events_ms; S.xupdate_launches = lt.launched;
         S.exchange_variant = !cshard ? 0 : (!peer_fused ? 1 : (peer_one ? 3 : 2));
-        if (persist) {
+        if (persist_rows) {
             int herr = 0;
-            ADMM_HIP_CHECK(hipMemcpy(&herr, perr.get(), sizeof(int), hipMemcpyDeviceToHost));
-            if (herr) throw Error(ADMM_ERR_INTERNAL, "wide solver: a hand-over inside the persistent active-set launch timed out");
+            ADMM_HIP_CHECK(hipMemcpy(&herr, rerr.get(), sizeof(int), hipMemcpyDeviceToHost));
+            // A hand-over that timed out (the stretch's workgroups were not co-resident: a busy or shared device): every workgroup of
+            // that launch left WITHOUT touching x / A x / z / y / the control block, the two-launch path carried on from the intact
+            // state and the result is valid.  Not an error: the stretch is switched off for the rest of this plan's life.
+            if (herr) { persist_rows = false; S.exchange_variant = -1; }
             unsigned long long hs[16] = {0};
-            ADMM_HIP_CHECK(hipMemcpy(hs, pstat.get(), sizeof(hs), hipMemcpyDeviceToHost));
+            ADMM_HIP_CHECK(hipMemcpy(hs, rstat.get(), sizeof(hs), hipMemcpyDeviceToHost));
             S.persist_iter = (long long)hs[0];
-            pstat.zero(st);
-            if (std::getenv("ADMM_HIP_WIDE_PERSIST_STATS")) {
+            rstat.zero(st);
+            if (std::getenv("ADMM_HIP_WIDE_PERSIST_STATS"))
+            {
                 const double it = hs[0] ? (double)hs[0] : 1.0;
-                std::fprintf(stderr, "[wide persist] %llu iterations in %llu stretches (%llu of them not on one XCD), %.2f us per iteration inside; %lld host iterations enqueued\n"
-                             "[wide persist] per iteration, workgroup 0: columns %.2f | combine + publish partial %.2f | wait partials %.2f | rows + publish %.2f | wait rows %.2f | decide + t %.2f us\n",
-                             hs[0], hs[1], hs[3], hs[0] ? 0.01 * (double)hs[2] / it : 0.0, (long long)lt.launched,
-                             0.01 * hs[4] / it, 0.01 * hs[5] / it, 0.01 * hs[6] / it, 0.01 * hs[7] / it, 0.01 * hs[8] / it, 0.01 * hs[9] / it);
+                std::fprintf(stderr, "[wide rows persist] %llu iterations in %llu stretches (%llu not on one XCD, %llu extra hand-overs after a rho change), %.2f us per iteration inside; %d row groups x %d column groups\n"
+                             "[wide rows persist] start-up %.2f us per stretch; per iteration, workgroup 0: loop %.2f | x-update %.2f | A x partial + publish %.2f | wait A %.2f | rows + dots + publish %.2f | wait B %.2f | decide %.2f | redo %.2f us\n",
+                             hs[0], hs[1], hs[3], hs[4], 0.01 * (double)hs[2] / it, rows_R, rows_C, hs[1] ? 0.01 * (double)hs[5] / (double)hs[1] : 0.0,
+                             0.01 * hs[6] / it, 0.01 * hs[7] / it, 0.01 * hs[8] / it, 0.01 * hs[9] / it, 0.01 * hs[10] / it, 0.01 * hs[11] / it, 0.01 * hs[12] / it, 0.01 * hs[13] / it);
             }
         }
 #ifdef ADMM_HIP_PROBE

@@ -77,13 +77,27 @@ def _rho_candidates(rho, rp, eps_p, n_p, rd, eps_d, n_d, band):
     """Every rho the adaptation rule (FADMMBase.h:109-133 == ADMMBase.h:85-109) can produce when r_p and r_d move by up to
     `band` ulps of rounding each (the rule is monotone in both, so the corners suffice)."""
     out = set()
-    for dp in (-1.0, 0.0, 1.0):
-        for dd in (-1.0, 0.0, 1.0):
-            class _S:
-                pass
+
+    class _S:
+        pass
+    # the box [rp -+ band n_p] x [rd -+ band n_d] (clamped at 0): its corners, and -- the rule's regions are not nested, a large box
+    # can contain a region none of its corners lies in (e.g. "balanced and r_d < eps_d", x1.2, between "r_p far too large", x2, and
+    # "r_d far too large", x0.5) -- a grid over it that is geometric around both thresholds
+    lo_p, hi_p = max(rp - band * n_p, 0.0), rp + band * n_p
+    lo_d, hi_d = max(rd - band * n_d, 0.0), rd + band * n_d
+    def axis(lo, hi, centre, thr):
+        pts = {lo, hi, min(max(centre, lo), hi)}
+        for f in (0.05, 0.2, 0.5, 0.9, 0.999, 1.001, 1.1, 2.0, 5.0, 20.0):
+            for base in (thr, centre):
+                v = base * f
+                if lo <= v <= hi:
+                    pts.add(v)
+        return sorted(pts)
+    for vp in axis(lo_p, hi_p, rp, eps_p):
+        for vd in axis(lo_d, hi_d, rd, eps_d):
             t = _S()
             t.rho, t.eps_primal, t.eps_dual = rho, eps_p, eps_d
-            t.resid_primal, t.resid_dual = max(rp + dp * band * n_p, 0.0), max(rd + dd * band * n_d, 0.0)
+            t.resid_primal, t.resid_dual = vp, vd
             _rho_rule(t)
             out.add(t.rho)
     return out

@@ -134,17 +134,21 @@ def test_wide_fused_x_update_up_to_8192_rows(n, p):
         assert relerr(a.beta_dense[:, j], b.beta_dense[:, j]) < 1e-4, j
 
 
-@pytest.mark.parametrize("n,p", [(600, 9000), (1500, 4000)])
-def test_persistent_active_set_stretch_matches_the_two_launch_path(n, p):
-    """wide_act_persist_kernel (round 3): a whole stretch of active-set iterations inside ONE launch, kPG workgroups handing
-    their partials of A x and their norm shares to one another through global memory.  Same arithmetic per step as the
-    two-launch path, a different ORDER of the partial sums: each is its own execution, both held to the oracle by the trace
-    rule (counts identical, columns 1e-4), and they agree with each other to summation rounding.  Most iterations must
-    actually have run inside the persistent launches."""
+@pytest.mark.parametrize("n,p,cgroups", [(600, 9000, ""), (1500, 4000, ""), (3000, 5000, ""), (257, 1031, ""), (600, 9000, "1"), (5000, 5600, ""), (1500, 4000, "2")])
+def test_persistent_active_set_stretch(n, p, cgroups):
+    """wide_rows_persist_kernel (round 4): the stretch on a 2-D grid of workgroups -- R row groups of 256 rows x C column groups
+    (R C <= 32): partials of A x exchanged inside a row group, partial dots of the active columns inside a column group together
+    with the row groups' norm shares; the next t formed speculatively (same rho) and formed again after a rho change; the column
+    slices resident in registers.  Its own execution (other order of the sums inside the two mat-vecs): held to the oracle by the
+    trace rule AND by the stepwise rule on its iterate dump (helpers.traced_parity), and within summation rounding of the two-launch
+    path.  n = 600: 3 x 10 workgroups; n = 1500: 6 x 5; n = 3000 / 5000: 12 x 2 / 20 x 1 (beyond the 2048 rows the round-3 stretch
+    stops at); n = 257: a second row group that owns ONE row, 2 x 16; C forced to 1 / 2: no / fewer column groups."""
     x, y = synth_lasso(n, p, 15, seed=n + p)
-    a = _traced_env(x, y, 10, 10000, f"wide persistent n={n}")
-    b = _traced_env(x, y, 10, 10000, f"wide two launches n={n}", ADMM_HIP_WIDE_PERSIST="0")
+    env = {}                                                 # the stretch is the default (ADMM_HIP_WIDE_PERSIST=0 switches it off)
+    if cgroups:
+        env["ADMM_HIP_WIDE_ROWS_C"] = cgroups
+    a = _traced_env(x, y, 10, 10000, f"wide 2-D stretch n={n} C={cgroups or 'auto'}", **env)
+    b = _fit_env(x, y, 10, 10000, ADMM_HIP_WIDE_PERSIST="0")
     assert int(a.stats["persist_iter"]) > 0.5 * int(a.stats["total_iter"]), (a.stats["persist_iter"], a.stats["total_iter"])
-    assert int(b.stats["persist_iter"]) == 0
     for j in range(10):
         assert relerr(a.beta_dense[:, j], b.beta_dense[:, j]) < 1e-4, j
