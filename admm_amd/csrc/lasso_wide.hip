@@ -859,8 +859,9 @@ constexpr int kRNW = 8;                   // waves per workgroup
 struct WideRows {
     unsigned long long* flag;             // [kRG][8] hand-over words (launch << 32) | hand-over number, one 64-byte line each
     unsigned long long* flagX;            // [kRG][8] (launch << 32) | (XCD + 1)
+    unsigned long long* flagS;            // [kRG][8] (launch << 32) | iteration whose norm share row group r has published
     float* pd;                            // [2][G][kRCMAX] partial dots, by parity of the hand-over number
-    double* np;                           // [2][G][8] norm shares
+    double* np;                           // [2][kRG][8] norm shares of the row groups, by parity of the iteration number
     int* err;
     unsigned long long seq;               // launch number
     unsigned long long* stat;             // [16] iterations, stretches, ticks, not-one-XCD launches, redo rounds, phase ticks
@@ -1010,7 +1011,7 @@ wide_rows_persist_kernel(WideParams q, int cpar, WideRows ps) {
     // every wave polls the words it needs itself: lane l < G watches workgroup l if `need(l)`
     auto wait_for = [&](unsigned long long h, int kind) -> bool {      // kind 0: everybody, 1: my row group, 2: my column group + the share publishers (column group 0)
         bool ok = true;
-        const bool need = lane < G && (kind == 0 || (kind == 1 && lane / C == r) || (kind == 2 && (lane % C == c || lane % C == 0)));
+        const bool need = lane < G && (kind == 0 || (kind == 1 && lane / C == r) || (kind == 2 && lane % C == c));
         if (need) {
             const unsigned long long* fw = ps.flag + (size_t)lane * 8;
             const unsigned long long val = (ps.seq << 32) | h;
@@ -1334,36 +1335,51 @@ wide_rows_persist_kernel(WideParams q, int cpar, WideRows ps) {
             if ((lane & 7) == 0 && lane < 40) nsh[wid][lane >> 3] = tot;
         }
         __syncthreads();                                    // td, nsh complete
-        if (c == 0 && tid < 5) {
-            const double v = ((nsh[0][tid] + nsh[1][tid]) + nsh[2][tid]) + nsh[3][tid];
-            wp_store_f64(ps.np + ((size_t)((hs + 1) & 1) * kRG + r) * 8 + tid, v, wt);
+        k_done++;
+        // the norm shares leave AT ONCE, with a word of their own (the iteration number): the other workgroups take the decision
+        // from them while this one is still forming its partial dots and while the dots travel -- the decision's ~2 us of shares
+        // round trip, square roots and double divisions are off the critical path of hand-over B
+        if (c == 0 && wid == 0) {
+            if (lane < 5) {
+                const double v = ((nsh[0][lane] + nsh[1][lane]) + nsh[2][lane]) + nsh[3][lane];
+                wp_store_f64(ps.np + ((size_t)(k_done & 1) * kRG + r) * 8 + lane, v, wt);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(ps.flagS + (size_t)r * 8, (ps.seq << 32) | k_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         dots(hs + 1);                                       //                                                          [hand-over B]
         hs++;
         publish(hs);
         WR_PHASE(4)
-        k_done++;
         // ---- the decision on the iteration just finished, by everybody from the same numbers
-        if (!wait_for(hs, 2)) { failed = true; break; }
+        {
+            bool ok = true;
+            if (lane < R) {
+                const unsigned long long* fw = ps.flagS + (size_t)lane * 8;
+                const unsigned long long val = (ps.seq << 32) | k_done;
+                const long long t0 = wall_clock64();
+                while (__hip_atomic_load(fw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < val) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (wall_clock64() - t0 > 200000000ll) { ok = false; break; }
+                }
+            }
+            ok = __all(ok) != 0;
+            if (!ok) { if (lane == 0) __hip_atomic_store(ps.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); failed = true; break; }
+        }
         WR_PHASE(5)
         in = out;
         {
-            const double* sh = ps.np + (size_t)(hs & 1) * kRG * 8;
-            double shv[5];                                  // the norm shares first, the (speculative) partial dots of the thread's first column behind them
+            const double* sh = ps.np + (size_t)(k_done & 1) * kRG * 8;
 #pragma unroll
             for (int m = 0; m < 5; ++m)
-                shv[m] = lane < R ? __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(sh + (size_t)lane * 8 + m),
-                                                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0.0;
-            have0 = tid < nC && xa[j0] != 0.f;
-            if (have0) d0 = pd_get(j0, hs);
-#pragma unroll
-            for (int m = 0; m < 5; ++m) sums[m] = shv[m];
+                sums[m] = lane < R ? __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(sh + (size_t)lane * 8 + m),
+                                                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0.0;
         }
         dec = wide_decide<true>(q, in, sums, lane);
         out = wide_ctl_uniform(dec.out);
         const bool go_on = !out.done && out.type == W_ACT && __builtin_amdgcn_readfirstlane(dec.lam_finished) < 0;
         WR_PHASE(6)
-        if (!go_on) break;
+        if (!go_on) break;                                  // (the speculative dots in flight are dropped)
         if (out.rho != in.rho) {                            // the speculation was wrong: t with the new rho, the partial dots once more
             __syncthreads();                                // (everybody has read td for the speculative dots)
             if (tid < RS) {
@@ -1376,10 +1392,11 @@ wide_rows_persist_kernel(WideParams q, int cpar, WideRows ps) {
             hs++;
             publish(hs);
             redo++;
-            if (!wait_for(hs, 2)) { failed = true; break; }
-            if (have0) d0 = pd_get(j0, hs);                 // the dots formed with the new rho replace the speculative ones
-            WR_PHASE(7)
         }
+        if (!wait_for(hs, 2)) { failed = true; break; }     // the partial dots of the next iteration (speculative ones, or those formed with the new rho)
+        have0 = tid < nC && xa[j0] != 0.f;
+        if (have0) d0 = pd_get(j0, hs);
+        WR_PHASE(7)
     }
     if (failed) return;
     if (leader) {
@@ -1394,7 +1411,7 @@ wide_rows_persist_kernel(WideParams q, int cpar, WideRows ps) {
     if (g == 0) {
         // norm partials: the share of row group r in row r (exactly the lanes' inputs of the decision above, so that the next launch,
         // which repeats it from P, adds the same numbers in the same order), zero in every other row the next decision adds up
-        const double* sh = ps.np + (size_t)(hs & 1) * kRG * 8;
+        const double* sh = ps.np + (size_t)(k_done & 1) * kRG * 8;
         const int rows = q.nwg_tail > kWideNormRows ? q.nwg_tail : kWideNormRows;
         for (int idx = tid; idx < rows * 8; idx += T) {
             const int rr = idx >> 3, m = idx & 7;
@@ -1646,7 +1663,7 @@ struct WidePlan final : LassoPlan {
         rows_C = std::max(1, kRG / rows_R);                                 // column groups: R C <= 32 workgroups (one XCD)
         if (const char* e = std::getenv("ADMM_HIP_WIDE_ROWS_C")) { const int c = std::atoi(e); if (c >= 1 && c * rows_R <= kRG) rows_C = c; }
         rows_G = rows_R * rows_C;
-        rflags.alloc((size_t)2 * kRG * 8); rflags.zero(st);
+        rflags.alloc((size_t)3 * kRG * 8); rflags.zero(st);
         rpd.alloc((size_t)2 * rows_G * kRCMAX); rpd.zero(st);
         rpa.alloc((size_t)2 * rows_G * kRRS); rpa.zero(st);
         rnp.alloc((size_t)2 * kRG * 8); rnp.zero(st);
@@ -1657,7 +1674,7 @@ struct WidePlan final : LassoPlan {
     }
     void launch_persist_rows(int cpar) {
         WideRows ps;
-        ps.flag = rflags.get(); ps.flagX = rflags.get() + (size_t)kRG * 8;
+        ps.flag = rflags.get(); ps.flagX = rflags.get() + (size_t)kRG * 8; ps.flagS = rflags.get() + (size_t)2 * kRG * 8;
         ps.pd = rpd.get(); ps.np = rnp.get(); ps.err = rerr.get(); ps.seq = ++rseq; ps.stat = rstat.get(); ps.hint = rhint.get();
         ps.G = rows_G; ps.R = rows_R; ps.C = rows_C; ps.pa = rpa.get(); ps.diag = std::getenv("ADMM_HIP_WIDE_PERSIST_STATS") ? 1 : 0;
         ps.lst_idx = rli.get(); ps.lst_x = rlx.get(); ps.lcount = rlc.get();
@@ -1725,7 +1742,7 @@ struct WidePlan final : LassoPlan {
             {
                 const double it = hs[0] ? (double)hs[0] : 1.0;
                 std::fprintf(stderr, "[wide rows persist] %llu iterations in %llu stretches (%llu not on one XCD, %llu extra hand-overs after a rho change), %.2f us per iteration inside; %d row groups x %d column groups\n"
-                             "[wide rows persist] start-up %.2f us per stretch; per iteration, workgroup 0: loop %.2f | x-update %.2f | A x partial + publish %.2f | wait A %.2f | rows + dots + publish %.2f | wait B %.2f | decide %.2f | redo %.2f us\n",
+                             "[wide rows persist] start-up %.2f us per stretch; per iteration, workgroup 0: loop %.2f | x-update %.2f | A x partial + publish %.2f | wait A %.2f | rows + dots + publish %.2f | wait shares %.2f | decide %.2f | wait B + dots of my column %.2f us\n",
                              hs[0], hs[1], hs[3], hs[4], 0.01 * (double)hs[2] / it, rows_R, rows_C, hs[1] ? 0.01 * (double)hs[5] / (double)hs[1] : 0.0,
                              0.01 * hs[6] / it, 0.01 * hs[7] / it, 0.01 * hs[8] / it, 0.01 * hs[9] / it, 0.01 * hs[10] / it, 0.01 * hs[11] / it, 0.01 * hs[12] / it, 0.01 * hs[13] / it);
             }
