@@ -78,6 +78,13 @@ def load():
         raise FileNotFoundError(
             f"{path} not found: build it with `python -m admm_amd.build` (hipcc --offload-arch=gfx950). "
             "admm_amd has no CPU fallback.")
+    if not os.environ.get("ADMM_HIP_LIB"):
+        # the in-tree library must have been linked from the sources beside it (admm_amd/build.py keeps their hash in a side file):
+        # a stale prebuilt .so against a newer ctypes layout is an ABI mismatch, not just stale behaviour
+        from . import build as _build
+        if os.path.isdir(_build.CSRC) and not _build._lib_is_current(path):
+            raise RuntimeError(f"{path} was not built from the sources in {_build.CSRC} (source hash differs or is missing): "
+                               "run `python -m admm_amd.build`")
     lib = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
     lasso_args = [_DP, _DP, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                   _DP, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int]

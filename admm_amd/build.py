@@ -49,13 +49,37 @@ def _compile(src, force):
     return obj, True
 
 
+def source_hash():
+    """sha256 over every .hip / .h under csrc/ and include/admm_hip.h (names + contents, sorted)."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    files.append(os.path.join(HERE, "..", "include", "admm_hip.h"))
+    for p in files:
+        h.update(os.path.basename(p).encode())
+        with open(p, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def _hash_file(lib):
+    return lib + ".srchash"
+
+
 def _lib_is_current(lib):
-    """The linked library is newer than every source and header: nothing to do even where the object files did not travel
-    (the GPU box receives the .so files, not csrc/_obj*)."""
-    if not os.path.exists(lib):
+    """The linked library was built from exactly these sources: its side file holds the hash of the sources it was linked from
+    (round 3 compared modification times, which a checkout / rsync / archive extraction does not preserve: a stale prebuilt
+    library could have been used against newer sources and a newer ctypes struct).  Nothing to do then even where the object
+    files did not travel (the GPU box receives the .so files and their side files, not csrc/_obj*)."""
+    if not os.path.exists(lib) or not os.path.exists(_hash_file(lib)):
         return False
-    t = os.path.getmtime(lib)
-    return t >= _newest_header() and all(t >= os.path.getmtime(os.path.join(CSRC, f)) for f in _sources())
+    with open(_hash_file(lib)) as fh:
+        return fh.read().strip() == source_hash()
+
+
+def _write_hash(lib):
+    with open(_hash_file(lib), "w") as fh:
+        fh.write(source_hash() + "\n")
 
 
 # ---- host-sanitizer variant (tests/test_sanitizers.py, tests/test_gpu_sanitizers.py): the HOST half of every translation unit
@@ -87,9 +111,9 @@ def _compile_san(src, force):
 
 
 def build_sanitized(force=False, verbose=True):
-    if not force and _lib_is_current(LIB_SAN) and not os.path.isdir(OBJ_SAN):
+    if not force and _lib_is_current(LIB_SAN):
         if verbose:
-            print(f"[admm_amd.build] up to date (no object directory): {LIB_SAN}")
+            print(f"[admm_amd.build] up to date (source hash matches): {LIB_SAN}")
         return LIB_SAN
     os.makedirs(OBJ_SAN, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
@@ -105,13 +129,14 @@ def build_sanitized(force=False, verbose=True):
             print(f"[admm_amd.build] linked {LIB_SAN} ({len(objs)} objects, host ASan + UBSan)")
     elif verbose:
         print(f"[admm_amd.build] up to date: {LIB_SAN}")
+    _write_hash(LIB_SAN)
     return LIB_SAN
 
 
 def build(force=False, verbose=True):
-    if not force and _lib_is_current(LIB) and not os.path.isdir(OBJ):
+    if not force and _lib_is_current(LIB):
         if verbose:
-            print(f"[admm_amd.build] up to date (no object directory): {LIB}")
+            print(f"[admm_amd.build] up to date (source hash matches): {LIB}")
         return LIB
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
@@ -129,6 +154,7 @@ def build(force=False, verbose=True):
             print(f"[admm_amd.build] linked {LIB} ({len(objs)} objects)")
     elif verbose:
         print(f"[admm_amd.build] up to date: {LIB}")
+    _write_hash(LIB)
     return LIB
 
 
