@@ -442,369 +442,11 @@ tall_fused_kernel(TallParams q, int par, TallFused f) {
     tall_decide<true>(q, par);                              // decision g from the partials of iteration g - 1 -> ctl[par ^ 1]
 }
 
-// ---------------------------------------------------------------------------------------------- persistent tall loop (round 4)
-// The whole lambda path in ONE launch (opt-in: ADMM_HIP_TALL_PERSIST=1; p >= 4096, single GPU).  Two launches per iteration re-read the
-// 2 p^2-byte triangle of the cached inverse from the Infinity Cache every iteration (33.7 of the 39.5 us of an iteration at p = 10^4
-// are that stream at its ceiling); what a kernel boundary cannot keep is the matrix ON CHIP.  Here 2 workgroups per compute unit stay
-// resident for the whole path; each keeps ONE 256 x 128 tile of the triangle in its registers (a wave's 32 columns x one float4 per
-// lane = 128 registers; 512 workgroups x 128 KB = 64 MB, a third of the triangle at p = 10^4) and streams its other 2-3 tiles.  An
-// iteration is
-//   P1  the tiles of the symmetric mat-vec on (u, w) -- resident tile from the registers, the others from memory -- partials written
-//       through;                                                                                              [grid barrier]
-//   P2  every workgroup takes the decision of the previous iteration itself from the norm partials (redundantly, identically: no
-//       broadcast), then the element-wise tail for ITS elements: sums of the partials (cache-bypassing loads), prox, dual, norms, the
-//       two candidate right-hand sides (written through).                                                     [grid barrier]
-// Same tiles (uniform 128-column segments), same per-tile arithmetic and same order of every sum as the two-launch path with
-// ADMM_HIP_SYMV_SCHED=128,128,0: bit-identical results (tests/test_gpu_tall.py).
-struct TallPersist {
-    SymvArgs sy;                 // matrix, u / w, partial arrays, the tile list (uniform 128-column segments)
-    int ntiles;
-    unsigned int* bar;           // grid-barrier arrival counter (monotonic)
-    int* bflag;                  // [64][16] barrier generation, one replica per 64-byte line (a workgroup polls replica wg % 64: 8 pollers per line)
-    int* dflag;                  // [64][16] number of decisions published
-    TallCtl* ctl_pub;            // [2] the decisions workgroup 0 publishes (written through), by parity
-    int* err;                    // non-zero after a timed-out barrier
-    int nwgp;                    // workgroups of this launch
-    unsigned long long* stat;    // [8] diagnostics: iterations, ticks in P1 / barrier 1 / P2 / barrier 2 (workgroup 0)
-};
-
-// All workgroups of the launch: drain this workgroup's stores, count in; the LAST one to arrive raises the generation in 64
-// replicated flag lines, everybody else polls its own replica (512 pollers on ONE word serialise at the memory side: the first cut
-// of this barrier cost 8-35 us).  Bounded.
-__device__ __forceinline__ bool tall_grid_barrier(const TallPersist& f, unsigned int gen, int* s_ok) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        bool ok = true;
-        unsigned int prev = 0;
-        if (threadIdx.x == 0) prev = __hip_atomic_fetch_add(f.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        prev = (unsigned int)__builtin_amdgcn_readfirstlane((int)prev);
-        if (prev == gen * (unsigned int)f.nwgp - 1u) {          // the last arrival: release everybody
-            __hip_atomic_store(f.bflag + threadIdx.x * 16, (int)gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else if (threadIdx.x == 0) {
-            const int* fw = f.bflag + (blockIdx.x & 63) * 16;
-            const long long t0 = wall_clock64();
-            while (__hip_atomic_load(fw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)gen) {
-                __builtin_amdgcn_s_sleep(1);
-                if (wall_clock64() - t0 > 400000000ll) { ok = false; break; }      // 4 s
-            }
-            if (!ok) __hip_atomic_store(f.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (threadIdx.x == 0) *s_ok = ok ? 1 : 0;
-    }
-    __syncthreads();
-    return *s_ok != 0;
-}
-
-// symv2_tile (symv_kernels.h) for the persistent loop: 128-column tiles only (32 columns per wave), right-hand entries through
-// cache-bypassing loads, partials written through.  RES: the wave's 32 column slices come from its registers `rc` instead of memory.
-// The arithmetic and its order are symv2_tile's.
-template <bool RES>
-__device__ __forceinline__ void tall_persist_tile(const SymvArgs& a, const int4 t, const float4 (&rc)[32], float4 (*red)[kSyThreads], float (*sdot)[kSyCBMax]) {
-    const SymvBypassVec vl;
-    const int rb = t.x, seg = t.w;
-    constexpr int cw = 32;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int row = rb * kSyRB + lane * 4;
-    const int col0 = t.y + wid * cw;
-    const int p4 = (a.p + 3) & ~3;
-    const bool active = row < p4;
-    const bool has = col0 < a.p && wid * cw < t.z;
-    const float* base = a.A + (size_t)col0 * a.lda + row;
-    float4 aU = make_float4(0.f, 0.f, 0.f, 0.f), aW = aU;
-    if (has) {
-        const float4 uI = active ? vl.load4(a.v0 + row) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 wI = active ? vl.load4(a.v1 + row) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const int cj = col0 + lane;
-        const float uj = (lane < cw && cj < a.p) ? vl.load1(a.v0 + cj) : 0.f;
-        const float wj = (lane < cw && cj < a.p) ? vl.load1(a.v1 + cj) : 0.f;
-        const bool diag = col0 + (cw - 1) >= rb * kSyRB;
-        // one chunk of 8 columns; AV(k) names the k-th column slice (a register of `rc`, or of the chunk just loaded)
-#define TALL_PERSIST_COL(q, k, AVK)                                                                                                \
-            {                                                                                                                      \
-                const int col = col0 + (q) * 8 + (k);                                                                              \
-                float4 v = AVK;                                                                                                    \
-                float4 ax = v;                                                                                                     \
-                if (DIAGC) {            /* selects, no branches: same values as symv2_tile's masks */                              \
-                    v.x = (row + 0 < col) ? 0.f : v.x; v.y = (row + 1 < col) ? 0.f : v.y;                                          \
-                    v.z = (row + 2 < col) ? 0.f : v.z; v.w = (row + 3 < col) ? 0.f : v.w;                                          \
-                    ax.x = (row + 0 <= col) ? 0.f : v.x; ax.y = (row + 1 <= col) ? 0.f : v.y;                                      \
-                    ax.z = (row + 2 <= col) ? 0.f : v.z; ax.w = (row + 3 <= col) ? 0.f : v.w;                                      \
-                }                                                                                                                  \
-                dU[k] = fmaf(v.x, uI.x, fmaf(v.y, uI.y, fmaf(v.z, uI.z, v.w * uI.w)));                                             \
-                dW[k] = fmaf(v.x, wI.x, fmaf(v.y, wI.y, fmaf(v.z, wI.z, v.w * wI.w)));                                             \
-                const float ujc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(uj), ((q) * 8 + (k)) & 63));             \
-                const float wjc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wj), ((q) * 8 + (k)) & 63));             \
-                aU.x = fmaf(ax.x, ujc, aU.x); aU.y = fmaf(ax.y, ujc, aU.y); aU.z = fmaf(ax.z, ujc, aU.z); aU.w = fmaf(ax.w, ujc, aU.w); \
-                aW.x = fmaf(ax.x, wjc, aW.x); aW.y = fmaf(ax.y, wjc, aW.y); aW.z = fmaf(ax.z, wjc, aW.z); aW.w = fmaf(ax.w, wjc, aW.w); \
-            }
-#define TALL_PERSIST_CHUNK(q, AV)                                                                                                  \
-        {                                                                                                                          \
-            float dU[8], dW[8];                                                                                                    \
-            TALL_PERSIST_COL(q, 0, AV(0)) TALL_PERSIST_COL(q, 1, AV(1)) TALL_PERSIST_COL(q, 2, AV(2)) TALL_PERSIST_COL(q, 3, AV(3))     \
-            TALL_PERSIST_COL(q, 4, AV(4)) TALL_PERSIST_COL(q, 5, AV(5)) TALL_PERSIST_COL(q, 6, AV(6)) TALL_PERSIST_COL(q, 7, AV(7))     \
-            const float du = butterfly8(dU, lane);                                                                                 \
-            const float dw = butterfly8(dW, lane);                                                                                 \
-            if ((lane & 7) == 0) {                                                                                                 \
-                sdot[0][wid * cw + (q) * 8 + (lane >> 3)] = du;                                                                    \
-                sdot[1][wid * cw + (q) * 8 + (lane >> 3)] = dw;                                                                    \
-            }                                                                                                                      \
-        }
-        if constexpr (RES) {
-            // a tile off the diagonal needs no masks at all: two copies of the pass, chosen once
-#define TALL_RC0(k) rc[0 + k]
-#define TALL_RC1(k) rc[8 + k]
-#define TALL_RC2(k) rc[16 + k]
-#define TALL_RC3(k) rc[24 + k]
-            // (the four chunks are independent: without the scheduling barriers the compiler interleaves all 32 columns and spills
-            // several hundred registers of temporaries next to the 128 resident ones)
-            if (diag) {
-                constexpr bool DIAGC = true;
-                TALL_PERSIST_CHUNK(0, TALL_RC0)
-                __builtin_amdgcn_sched_barrier(0);
-                TALL_PERSIST_CHUNK(1, TALL_RC1)
-                __builtin_amdgcn_sched_barrier(0);
-                TALL_PERSIST_CHUNK(2, TALL_RC2)
-                __builtin_amdgcn_sched_barrier(0);
-                TALL_PERSIST_CHUNK(3, TALL_RC3)
-            } else {
-                constexpr bool DIAGC = false;
-                TALL_PERSIST_CHUNK(0, TALL_RC0)
-                __builtin_amdgcn_sched_barrier(0);
-                TALL_PERSIST_CHUNK(1, TALL_RC1)
-                __builtin_amdgcn_sched_barrier(0);
-                TALL_PERSIST_CHUNK(2, TALL_RC2)
-                __builtin_amdgcn_sched_barrier(0);
-                TALL_PERSIST_CHUNK(3, TALL_RC3)
-            }
-        } else {
-#pragma unroll 1
-            for (int q = 0; q < 4; ++q) {
-                float4 av[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int col = col0 + q * 8 + k;
-                    av[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (active && col < a.p) av[k] = *reinterpret_cast<const float4*>(base + (size_t)(q * 8 + k) * a.lda);
-                }
-#define TALL_AV(k) av[k]
-                const bool DIAGC = diag;
-                TALL_PERSIST_CHUNK(q, TALL_AV)
-            }
-        }
-    } else {
-        for (int c = lane; c < cw; c += 64) { sdot[0][wid * cw + c] = 0.f; sdot[1][wid * cw + c] = 0.f; }
-    }
-    red[0][threadIdx.x] = aU;
-    red[1][threadIdx.x] = aW;
-    __syncthreads();
-    if (wid < 2) {
-        float4 s = red[wid][lane];
-#pragma unroll
-        for (int ww = 1; ww < 4; ++ww) {
-            const float4 o = red[wid][ww * 64 + lane];
-            s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
-        }
-        float* dst = (wid == 0 ? a.axp0 : a.axp1) + (size_t)seg * a.ldo + row;
-        tall_store_wt(dst + 0, s.x); tall_store_wt(dst + 1, s.y); tall_store_wt(dst + 2, s.z); tall_store_wt(dst + 3, s.w);
-    } else {
-        float* dst = (wid == 2 ? a.dot0 : a.dot1) + (size_t)rb * a.ldo + t.y;
-        for (int c = lane; c < t.z; c += 64) tall_store_wt(dst + c, sdot[wid - 2][c]);
-    }
-    __syncthreads();                                        // red / sdot are reused by the next tile
-}
-
-// The decision of tall_decide, taken by EVERY workgroup of the persistent launch for itself (same inputs, same arithmetic: identical
-// results): the previous control block lives in LDS, the norm partials are read with cache-bypassing loads.  Workgroup 0 also does
-// what tall_decide does for the host: niter, the trace record, the control block in global memory, the pinned finished flag.
-__device__ void tall_decide_local(const TallParams& q, int par, const TallCtl& in, TallCtl* s_out, int nwgp, double* dscratch) {
-    if (in.done) { if (threadIdx.x == 0) { TallCtl o = in; o.fin_idx = -1; *s_out = o; } return; }
-    double acc[6] = {0, 0, 0, 0, 0, 0};
-    const double* Pin = q.P + (size_t)par * q.nwg * 8;
-    for (int w = threadIdx.x; w < nwgp; w += kTailThreads) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) acc[k] += tall_load_partial(Pin + (size_t)w * 8 + k, true);
-    }
-    block_sum<double, 6>(acc, dscratch);
-    if (threadIdx.x != 0) return;
-    const double r2 = acc[0], dz2 = acc[1], daz2 = acc[2], x2 = acc[3], z2 = acc[4], y2 = acc[5];
-    double tr_rp = 0, tr_rd = 0, tr_c = 0, tr_code = ADMM_TRACE_COLD;
-    TallCtl out = in;
-    out.first = 0;
-    out.fin_idx = -1; out.fin_niter = 0;
-    const bool wg0 = blockIdx.x == 0;
-    if (!in.first) {
-        const double rp = sqrt(r2);
-        const double rd = in.rho * sqrt(dz2);
-        tr_rp = rp; tr_rd = rd;
-        if (rp < in.eps_primal && rd < in.eps_dual) {
-            out.fin_idx = in.lam_idx; out.fin_niter = in.iter + 1;
-            out.mode = 0;
-            tr_code = ADMM_TRACE_CONVERGED;
-        } else {
-            const double old_c = in.adj_c;
-            const double c = in.rho * rp * rp + in.rho * daz2;
-            tr_c = c;
-            if (c < 0.999 * old_c) {
-                out.adj_a = in.a_next; out.adj_c = c; out.tau = in.tau_next; out.restart = 0;
-                tr_code = ADMM_TRACE_ACCELERATE;
-            } else {
-                out.adj_a = 1.0; out.adj_c = old_c / 0.999; out.tau = -1.0; out.restart = 1;
-                tr_code = ADMM_TRACE_RESTART;
-            }
-            out.mode = 1;
-            out.iter = in.iter + 1;
-            if (in.iter + 1 >= q.maxit) { out.fin_idx = in.lam_idx; out.fin_niter = q.maxit + 1; }
-        }
-        if (out.fin_idx >= 0) {
-            out.lam_idx = in.lam_idx + 1;
-            out.iter = 0;
-            if (out.lam_idx >= q.nlam) out.done = 1;
-            else out.lam = q.lambdas[out.lam_idx];
-            if (wg0) q.niter[out.fin_idx] = out.fin_niter;
-        }
-    } else {
-        out.mode = 1; out.tau = 0.0; out.restart = 0;
-    }
-    out.eps_primal = fmax(sqrt(x2), sqrt(z2)) * q.eps_rel + q.sqrt_p * q.eps_abs;
-    out.eps_dual = sqrt(y2) * q.eps_rel + q.sqrt_p * q.eps_abs;
-    out.a_next = 0.5 + 0.5 * sqrt(1.0 + 4.0 * out.adj_a * out.adj_a);
-    out.tau_next = (out.adj_a - 1.0) / out.a_next;
-    out.total = in.total + 1;
-    *s_out = out;
-    if (wg0) {
-        q.ctl[par ^ 1] = out;
-        if (q.trace != nullptr && in.total < q.trace_cap) {
-            double* t = q.trace + (size_t)in.total * ADMM_TRACE_FIELDS;
-            t[0] = in.lam_idx; t[1] = in.iter; t[2] = in.eps_primal; t[3] = in.eps_dual; t[4] = tr_rp; t[5] = tr_rd;
-            t[6] = tr_c; t[7] = in.adj_c; t[8] = tr_code; t[9] = in.rho; t[10] = in.rho; t[11] = in.lam;
-        }
-    }
-}
-
-__global__ void __launch_bounds__(kTailThreads, 2)
-tall_persist_kernel(TallParams q, TallPersist f) {
-    __shared__ float4 red[2][kSyThreads];
-    __shared__ __attribute__((aligned(16))) float sdot[2][kSyCBMax];
-    __shared__ double scratch[6 * (kTailThreads / 64)];
-    __shared__ TallCtl s_ctl[2];
-    __shared__ int s_ok;
-    const int wg = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    // ---- this workgroup's resident tile (the wg-th of the list) into the registers, once
-    float4 rc[32];
-#pragma unroll
-    for (int k = 0; k < 32; ++k) rc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool has_res = wg < f.ntiles;
-    int4 tres = make_int4(0, 0, 0, 0);
-    if (has_res) {
-        // branch-free: every load goes to a clamped (always valid) address and what lies outside the tile is replaced by zero
-        // afterwards (32 conditional loads made 32 basic blocks whose merges spilled several hundred registers)
-        tres = f.sy.tiles[wg];
-        const int row = tres.x * kSyRB + lane * 4, col0 = tres.y + wid * 32;
-        const int p4 = (f.sy.p + 3) & ~3;
-        const bool rows_ok = row < p4 && wid * 32 < tres.z;
-        const int rowc = min(row, p4 - 4);
-#pragma unroll
-        for (int k = 0; k < 32; ++k) {
-            const int colc = min(col0 + k, f.sy.p - 1);
-            rc[k] = *reinterpret_cast<const float4*>(f.sy.A + (size_t)colc * f.sy.lda + rowc);
-        }
-#pragma unroll
-        for (int k = 0; k < 32; ++k)
-            if (!(rows_ok && col0 + k < f.sy.p)) rc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    if (threadIdx.x == 0) { s_ctl[0] = q.ctl[0]; s_ctl[1] = q.ctl[1]; }      // (written by tall_init_kernel before this launch)
-    __syncthreads();
-    unsigned int nbar = 0;
-    long long tk[4] = {0, 0, 0, 0}, tp = wall_clock64();
-    unsigned long long iters = 0;
-    for (long long g = 0;; ++g) {
-        const int par = (int)(g & 1);
-        // ---- the decision on iteration g - 1 (norm partials of the previous P2: complete since the last barrier) by workgroup 0
-        // alone, BEFORE its tile: the others need it only after P1 -- it is off the critical path, like the decision workgroup that
-        // rides in the two-launch path's mat-vec launch.  (Every workgroup taking it for itself: 512 x 256 threads reading the same
-        // 24 KB through the memory side -- 23 us.)
-        if (wg == 0) {
-            tall_decide_local(q, par, s_ctl[par], &s_ctl[par ^ 1], f.nwgp, scratch);
-            __syncthreads();
-            if (threadIdx.x < 64) {
-                const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&s_ctl[par ^ 1]);
-                unsigned long long* dst = reinterpret_cast<unsigned long long*>(f.ctl_pub + (par ^ 1));
-                if (threadIdx.x < (int)(sizeof(TallCtl) / 8)) __hip_atomic_store(dst + threadIdx.x, src[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(f.dflag + threadIdx.x * 16, (int)(g + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        // ---- P1: the mat-vec of iteration g on (u, w)
-        if (has_res) tall_persist_tile<true>(f.sy, tres, rc, red, sdot);
-        if (wg != 0) for (int t = f.nwgp + wg - 1; t < f.ntiles; t += f.nwgp - 1) tall_persist_tile<false>(f.sy, f.sy.tiles[t], rc, red, sdot);
-        if (wg == 0) { const long long tn = wall_clock64(); tk[0] += tn - tp; tp = tn; }
-        if (!tall_grid_barrier(f, ++nbar, &s_ok)) return;
-        if (wg == 0) { const long long tn = wall_clock64(); tk[1] += tn - tp; tp = tn; }
-        // ---- P2: the element-wise tail of iteration g for this workgroup's elements.  The sums of the partials do not depend on the
-        // decision: they are requested first, the published control block is read behind them.
-        const int sub = threadIdx.x & (kTailLanes - 1);
-        const int i = wg * kTailElems + threadIdx.x / kTailLanes;
-        const bool valid = i < q.p;
-        const bool owner = valid && sub == 0;
-        TallElem e = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (owner) e = tall_load_elem(q, par, i);
-        float a = 0.f, b = 0.f;
-        symv_sum_partials<kTailLanes, float, true>(q.dot0, q.dot1, q.axp0, q.axp1, q.ldo, q.nrb, q.sched, q.p32, i, sub, valid, a, b);
-        if (wg != 0) {
-            if (threadIdx.x < 64) {
-                bool ok = true;
-                if (threadIdx.x == 0) {
-                    const int* fw = f.dflag + (wg & 63) * 16;
-                    const long long t0 = wall_clock64();
-                    while (__hip_atomic_load(fw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)(g + 1)) {
-                        __builtin_amdgcn_s_sleep(1);
-                        if (wall_clock64() - t0 > 400000000ll) { ok = false; break; }
-                    }
-                    if (!ok) __hip_atomic_store(f.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                ok = __builtin_amdgcn_readfirstlane((int)ok) != 0;
-                if (ok && threadIdx.x < (int)(sizeof(TallCtl) / 8)) {
-                    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(f.ctl_pub + (par ^ 1)) + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    reinterpret_cast<unsigned long long*>(&s_ctl[par ^ 1])[threadIdx.x] = v;
-                }
-                if (threadIdx.x == 0) s_ok = ok ? 1 : 0;
-            }
-            __syncthreads();
-            if (!s_ok) return;
-        }
-        const TallCtl c = s_ctl[par ^ 1];
-        if (!(c.done && c.fin_idx < 0)) {
-            double acc[6] = {0, 0, 0, 0, 0, 0};
-            if (owner) tall_update_elem<true>(q, c, par, i, e, a, b, acc);
-            if (!c.done) {
-                const double v8[8] = {acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], 0.0, 0.0};
-                const double tot = halving_sum8_top(v8, lane);
-                __syncthreads();                            // (scratch was read by the decision's block sum)
-                if ((lane & 7) == 0 && lane < 48) scratch[(lane >> 3) * (kTailThreads / 64) + wid] = tot;
-                __syncthreads();
-                if (threadIdx.x < 6) {
-                    double sum = 0;
-                    for (int ww = 0; ww < kTailThreads / 64; ++ww) sum += scratch[threadIdx.x * (kTailThreads / 64) + ww];
-                    tall_store_wt(q.P + ((size_t)(par ^ 1) * q.nwg + wg) * 8 + threadIdx.x, sum);
-                }
-            }
-        }
-        iters++;
-        if (c.done) {
-            if (wg == 0 && threadIdx.x == 0) {
-                q.ctl[par] = c;                             // keep `done` sticky in both slots, as the two-launch path leaves it
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                *q.done_host = 1;
-            }
-            break;
-        }
-        if (wg == 0) { const long long tn = wall_clock64(); tk[2] += tn - tp; tp = tn; }
-        if (!tall_grid_barrier(f, ++nbar, &s_ok)) return;
-        if (wg == 0) { const long long tn = wall_clock64(); tk[3] += tn - tp; tp = tn; }
-    }
-    if (wg == 0 && threadIdx.x == 0) { f.stat[0] = iters; for (int k = 0; k < 4; ++k) f.stat[1 + k] = (unsigned long long)tk[k]; }
-}
+// Round 4 also built the whole path as ONE persistent launch with a third of the inverse's triangle resident in registers (two
+// grid barriers per iteration, decision off the critical path; bit-identical): 66.7 us per iteration against 39.25 at C2 -- the
+// barriers + an in-launch tail cost 16.6 us where the kernel boundaries cost 5.6, residency saves at most 10.8 us of the stream, and
+// the stream itself falls to 2.5 TB/s with half the registers taken.  Measurements and the bound that rules out tuning it into a
+// win: profiles/r04_tall_persist.md; the code: commit 6d31127.
 
 // Row-sharded mode: this rank's share of the two products (the partial arrays of its tiles) summed into ab[2][ld], the
 // vectors the ranks then all-reduce.  Same lane geometry and order as the single-GPU tail.
@@ -883,12 +525,6 @@ struct TallPlan final : LassoPlan {
     CommInfo ci;
     DevBuf<float> ab;                                   // [2][ldp] this rank's share of (a, b), all-reduced in place
     bool fused = false, fused_pre = false;              // one launch per iteration (tall_fused_kernel); tiles prefetch before they wait
-    bool persist = false;                               // the whole path in one launch (tall_persist_kernel, ADMM_HIP_TALL_PERSIST=1)
-    int nwgp = 0;
-    DevBuf<unsigned int> pbar;
-    DevBuf<int> perr, pflags;
-    DevBuf<TallCtl> pctl;
-    DevBuf<unsigned long long> pstat;
     DevBuf<int> fflag;                                  // [64][16] generation flags of the single-launch iteration
     DevBuf<unsigned int> farrive;
     long long ldv = 0;
@@ -1040,18 +676,7 @@ struct TallPlan final : LassoPlan {
         pl = plan_gemv_t<float>(p, p, 2, 4);
         nwg = (p + kTailElems - 1) / kTailElems;
         ldv = round_up(p, 256);                         // symv reads the right-hand vectors in 256-row blocks
-        if (const char* e = std::getenv("ADMM_HIP_TALL_PERSIST")) persist = std::string(e) == "1" && use_sym && !shard && !refine && p >= 2048;
-        if (persist) {
-            int occ = 0;
-            ADMM_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(tall_persist_kernel), kTailThreads, 0));
-            nwgp = 2 * device_info().num_cu;
-            // every workgroup must be resident (they wait for one another) and the tail needs a workgroup per 32 elements
-            if (occ < 2 || (long long)nwgp * kTailElems < p) persist = false;
-        }
-        SymvSched uni;                                                        // uniform 128-column tiles: what tall_persist_tile handles
-        uni.width_big = uni.width_small = kSyCB; uni.rb_split = 0;
-        if (use_sym) sy.init(p, st, shard ? ci.rank : 0, shard ? ci.nranks : 1, persist ? &uni : nullptr);
-        if (persist) { pbar.alloc(1); perr.alloc(1); pstat.alloc(8); pstat.zero(st); pflags.alloc((size_t)2 * 64 * 16); pctl.alloc(2); }
+        if (use_sym) sy.init(p, st, shard ? ci.rank : 0, shard ? ci.nranks : 1);
         if (refine) {
             rab.alloc((size_t)2 * ldv); rab.zero(st);
             ruw.alloc((size_t)2 * ldv); ruw.zero(st);
@@ -1087,7 +712,6 @@ struct TallPlan final : LassoPlan {
         x.alloc(ldv); z0.alloc(ldv); z1.alloc(ldv); y0.alloc(ldv); y1.alloc(ldv);
         adj_z.alloc(ldv); adj_y.alloc(ldv); u.alloc(ldv); w.alloc(ldv);
         beta.alloc((size_t)nlam * p); niter.alloc(nlam);
-        if (persist) nwg = std::max(nwg, nwgp);          // a row of norm partials per workgroup of the persistent launch (rows beyond the elements stay zero)
         P.alloc((size_t)2 * nwg * 8); dlam.alloc(nlam); ctl.alloc(2);
         u.zero(st); w.zero(st);
         ADMM_HIP_CHECK(hipMemcpyAsync(dlam.get(), lam_int.data(), nlam * sizeof(double), hipMemcpyHostToDevice, st));
@@ -1164,7 +788,7 @@ struct TallPlan final : LassoPlan {
             debug_dump("XY", XY.get(), ldp);
         }
         admm_stats S = setup_stats;
-        S.xupdate_variant = shard ? 2 : (persist ? 4 : (fused ? 3 : (use_sym ? 1 : 0)));
+        S.xupdate_variant = shard ? 2 : (fused ? 3 : (use_sym ? 1 : 0));
         S.exchange_variant = !shard ? 0 : (!peer_fused ? 1 : (peer_one ? 3 : 2));
         S.refine = refine ? 1 : 0;
         res.lambda = lam_user;
@@ -1295,30 +919,9 @@ struct TallPlan final : LassoPlan {
             ADMM_HIP_CHECK(hipEventRecord(ev_poll[slot].e, st));
         };
         int slot = 0;
-        if (persist) {
-            // ONE launch for the whole path; the host only waits for it (workgroup 0 sets the pinned flag last)
-            pbar.zero(st); perr.zero(st); pflags.zero(st);
-            TallPersist f;
-            f.sy = sy.args(M.get(), ldp, u.get(), w.get(), nullptr);
-            f.ntiles = sy.ntiles; f.bar = pbar.get(); f.err = perr.get(); f.nwgp = nwgp; f.stat = pstat.get();
-            f.bflag = pflags.get(); f.dflag = pflags.get() + 64 * 16; f.ctl_pub = pctl.get();
-            hipLaunchKernelGGL(tall_persist_kernel, dim3(nwgp), dim3(kTailThreads), 0, st, q, f);
-            ADMM_HIP_CHECK(hipGetLastError());
-            ADMM_HIP_CHECK(hipEventRecord(ev_loop1.e, st));
-            ADMM_HIP_CHECK(hipStreamSynchronize(st));
-            int herr = 0;
-            ADMM_HIP_CHECK(hipMemcpy(&herr, perr.get(), sizeof(int), hipMemcpyDeviceToHost));
-            if (herr) throw Error(ADMM_ERR_INTERNAL, "tall path: a grid barrier of the persistent launch timed out (its workgroups were not co-resident)");
-            unsigned long long hs[8] = {0};
-            ADMM_HIP_CHECK(hipMemcpy(hs, pstat.get(), sizeof(hs), hipMemcpyDeviceToHost));
-            launches = (long long)hs[0];
-            if (std::getenv("ADMM_HIP_TALL_PERSIST_STATS") && hs[0])
-                std::fprintf(stderr, "[tall persist] %llu iterations; per iteration, workgroup 0: mat-vec %.2f | barrier %.2f | decision + tail %.2f | barrier %.2f us; %d workgroups, %d tiles\n",
-                             hs[0], 0.01 * hs[1] / hs[0], 0.01 * hs[2] / hs[0], 0.01 * hs[3] / hs[0], 0.01 * hs[4] / hs[0], nwgp, sy.ntiles);
-        }
-        if (!persist) { if (use_graph) enqueue_batch_graph(slot); else enqueue_batch(slot); }
+        if (use_graph) enqueue_batch_graph(slot); else enqueue_batch(slot);
         ADMM_HIP_CHECK(hipGetLastError());                 // launch failures surface here
-        bool done = persist;
+        bool done = false;
         while (!done) {
             if (use_graph) enqueue_batch_graph(slot ^ 1); else enqueue_batch(slot ^ 1);      // keep one batch in flight while polling the previous one
             ADMM_HIP_CHECK(hipEventSynchronize(ev_poll[slot].e));
@@ -1327,7 +930,7 @@ struct TallPlan final : LassoPlan {
             slot ^= 1;
             if (!done && g > max_total) throw Error(ADMM_ERR_INTERNAL, "tall path: iteration bound exceeded without completion");
         }
-        if (!persist) ADMM_HIP_CHECK(hipEventRecord(ev_loop1.e, st));
+        ADMM_HIP_CHECK(hipEventRecord(ev_loop1.e, st));
         ADMM_HIP_CHECK(hipStreamSynchronize(st));
         S.t_loop = now_s() - tl0;
         ADMM_HIP_CHECK(hipMemcpy(hctl, ctl.get(), 2 * sizeof(TallCtl), hipMemcpyDeviceToHost));      // both slots: decisions taken

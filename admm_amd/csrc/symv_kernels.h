@@ -355,7 +355,7 @@ struct SymvPlan {
     // part / nparts: this plan launches only the tiles with (index in the full list) % nparts == part -- the row-sharded
     // tall x-update gives every rank an equal share of the triangle; the partial arrays keep the full shape (slots of
     // tiles owned by other ranks stay zero) so that the same consumer code sums them.
-    void init(int p_, hipStream_t st, int part = 0, int nparts = 1, const SymvSched* force = nullptr) {
+    void init(int p_, hipStream_t st, int part = 0, int nparts = 1) {
         p = p_;
         p32 = (p + 31) / 32 * 32;
         nrb = (p + kSyRB - 1) / kSyRB;
@@ -387,7 +387,6 @@ struct SymvPlan {
                 sched.width_big = wb; sched.width_small = ws; sched.rb_split = (int)((long long)pm * nrb / 1000);
             }
         }
-        if (force != nullptr) sched = *force;                  // (the persistent tall loop: uniform 128-column segments)
         std::vector<int4> h;
         nax_rows = 1;
         // long row strips first so that the end of the launch is made of the short strips' (narrow) segments
@@ -449,9 +448,7 @@ struct SymvPlan {
 // (one memory round trip up to 16 * NL partials), then the lanes combine with shuffles.  The summation order is
 // fixed, so the result is bit-reproducible; every lane of the group returns the total.  Used by the tall tail
 // kernel (lasso_tall.hip), by the row-sharded x-update (tall_shard.hip) and by the test hook admm_hip_test_symv.
-// BYP: the partials were written (write-through) by other workgroups of the SAME launch (the persistent tall loop): they are
-// read with agent-scope loads that bypass this XCD's L2.
-template <int NL, typename T = float, bool BYP = false>
+template <int NL, typename T = float>
 __device__ __forceinline__ void symv_sum_partials(const T* __restrict__ dot0, const T* __restrict__ dot1,
                                                   const T* __restrict__ axp0, const T* __restrict__ axp1,
                                                   long long ldo, int nrb, const SymvSched sched, int p32, int i, int sub, bool valid, T& a, T& b) {
@@ -475,13 +472,8 @@ __device__ __forceinline__ void symv_sum_partials(const T* __restrict__ dot0, co
             const bool isdot = k < ndot;
             const int row = isdot ? rb0 + k : min(k, ntot - 1) - ndot;      // clamped into the axpy rows when k >= ntot
             const unsigned o = (unsigned)row * ld + (unsigned)ic;
-            if constexpr (BYP && sizeof(T) == 4) {
-                va[j] = __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned int*>((isdot ? dot0 : axp0) + o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                vb[j] = __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned int*>((isdot ? dot1 : axp1) + o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            } else {
-                va[j] = (isdot ? dot0 : axp0)[o];
-                vb[j] = (isdot ? dot1 : axp1)[o];
-            }
+            va[j] = (isdot ? dot0 : axp0)[o];
+            vb[j] = (isdot ? dot1 : axp1)[o];
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
