@@ -28,7 +28,8 @@ class AdmmStats(ctypes.Structure):
                 ("total_iter", ctypes.c_longlong), ("xupdate_launches", ctypes.c_longlong),
                 ("rho", ctypes.c_double), ("eig_est", ctypes.c_double),
                 ("branch", ctypes.c_int), ("xupdate_variant", ctypes.c_int),
-                ("exchange_variant", ctypes.c_int), ("refine", ctypes.c_int), ("persist_iter", ctypes.c_longlong)]
+                ("exchange_variant", ctypes.c_int), ("refine", ctypes.c_int), ("persist_iter", ctypes.c_longlong),
+                ("factor_flops", ctypes.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -185,6 +185,78 @@ DevBuf<T> cholesky_linvt_blocked(T* A, long long lda, int p, hipStream_t st, Gem
     return U;
 }
 
+// ---- the same factorisation with its block columns dealt out to the ranks of a communicator
+// Block column k (128 columns of A's lower triangle and of U) belongs to rank k mod N.  Step k: the owner factorises the diagonal
+// block, finishes its column of U and the panel L_ik, and BROADCASTS both (one message: 128 x (pp + 128) floats); every rank then
+// applies the two rank-128 updates to the block columns IT owns (A_ij -= L_ik L_jk', U[:, i] -= U[:, k] L_ik').  Every tile sees
+// exactly the updates, in exactly the order (k ascending, K = 128 per update), of the single-process driver above, from operands
+// that are bit-identical (the broadcast moves them unchanged): the factor, U and everything built from them are BIT-IDENTICAL to
+// the single-process result.  Per rank: 1 / N of the update flops (2 x p^3 / 3 in all); the diagonal-block kernel and the panel
+// stay serial at the owner (nb x ~0.1 ms), and every rank RECEIVES every panel (p^2 floats in all: what a 1-D column distribution
+// costs; a 2-D block-cyclic one would cut it to p^2 / sqrt(N) at the price of row broadcasts).  After the loop every rank holds
+// all of U (each column was broadcast when it became final).  `flops`: update flops this rank performed (for the scaling table).
+template <typename T>
+__global__ void __launch_bounds__(256) panel_pack_kernel(const T* __restrict__ A, const T* __restrict__ U, long long lda, int r0, int pp, T* __restrict__ stage, int unpack,
+                                                         T* __restrict__ Aw, T* __restrict__ Uw) {
+    const int c = blockIdx.y;                               // column of the block (0 .. 127)
+    const int len = pp + 128;                               // (pp - r0) rows of L (diagonal block included) + (r0 + 128) rows of U
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= len) return;
+    const size_t col = (size_t)(r0 + c) * lda;
+    const int nl = pp - r0;
+    if (!unpack) stage[(size_t)c * len + idx] = idx < nl ? A[col + r0 + idx] : U[col + (idx - nl)];
+    else { const T v = stage[(size_t)c * len + idx]; if (idx < nl) Aw[col + r0 + idx] = v; else Uw[col + (idx - nl)] = v; }
+}
+
+template <typename T, typename Gemm, typename Bcast>
+DevBuf<T> cholesky_linvt_blocked_dist(T* A, long long lda, int p, hipStream_t st, Gemm gemm, int nranks, int rank, Bcast bcast, double* flops) {
+    const int nb = (p + 127) / 128;
+    const int pp = nb * 128;
+    ADMM_REQUIRE(lda >= pp, "blocked Cholesky: leading dimension must cover whole 128-row blocks");
+    DevBuf<T> Dinv((size_t)128 * 128), U((size_t)lda * pp), stage((size_t)128 * (pp + 128));
+    DevBuf<int> info(1);
+    info.zero(st); U.zero(st);
+    hipLaunchKernelGGL((set_identity_kernel<T>), dim3((p + 255) / 256), dim3(256), 0, st, U.get(), lda, p);
+    double fl = 0;
+    for (int k = 0; k < nb; ++k) {
+        const int r0 = k * 128;
+        const int nbk = std::min(128, p - r0);
+        const int owner = k % nranks;
+        T* Ukb = U.get() + (size_t)r0 * lda;
+        const int M = p - (r0 + 128);
+        T* Apan = A + (size_t)r0 * lda + r0 + 128;
+        if (rank == owner) {
+            T* Akk = A + (size_t)r0 * lda + r0;
+            hipLaunchKernelGGL((potf2_inv_kernel<T>), dim3(1), dim3(PF_THREADS), 0, st, Akk, lda, nbk, Dinv.get(), info.get(), r0);
+            gemm(false, Ukb, lda, Dinv.get(), 128, Ukb, lda, r0 + nbk, nbk, 128, T(1), T(0), false, false, st);
+            if (M > 0) gemm(false, Apan, lda, Dinv.get(), 128, Apan, lda, M, nbk, 128, T(1), T(0), false, false, st);
+            fl += 2.0 * 128 * nbk * (double)(r0 + nbk + std::max(M, 0));
+        }
+        if (nranks > 1) {
+            const dim3 grid((unsigned)((pp + 128 + 255) / 256), 128);
+            if (rank == owner) hipLaunchKernelGGL((panel_pack_kernel<T>), grid, dim3(256), 0, st, A, U.get(), lda, r0, pp, stage.get(), 0, A, U.get());
+            bcast(stage.get(), (size_t)128 * (pp + 128), owner, st);
+            if (rank != owner) hipLaunchKernelGGL((panel_pack_kernel<T>), grid, dim3(256), 0, st, A, U.get(), lda, r0, pp, stage.get(), 1, A, U.get());
+        }
+        // the block columns j > k this rank owns: trailing update of A (rows >= j) and of U (rows < r0 + 128)
+        for (int j = k + 1; j < nb; ++j) {
+            if (j % nranks != rank) continue;
+            const int c0 = j * 128;
+            const int nj = std::min(128, p - c0);
+            const T* Lj = Apan + (c0 - (r0 + 128));            // rows of block j (and below) of the panel
+            gemm(false, Lj, lda, Lj, lda, A + (size_t)c0 * lda + c0, lda, p - c0, nj, 128, T(-1), T(1), false, false, st);
+            gemm(false, Ukb, lda, Lj, lda, U.get() + (size_t)c0 * lda, lda, r0 + 128, nj, 128, T(-1), T(1), false, false, st);
+            fl += 2.0 * 128 * nj * (double)((p - c0) + (r0 + 128));
+        }
+    }
+    int h = 0;
+    ADMM_HIP_CHECK(hipMemcpyAsync(&h, info.get(), sizeof(int), hipMemcpyDeviceToHost, st));
+    ADMM_HIP_CHECK(hipStreamSynchronize(st));
+    if (h != 0) throw Error(ADMM_ERR_NOT_SPD, "Cholesky: matrix is not positive definite (pivot " + std::to_string(h) + ")");
+    if (flops) *flops = fl;
+    return U;
+}
+
 // In place: A -> full symmetric inverse  A^-1 = L^-T L^-1 = U U'  (both triangles; products start at k = tile row
 // since U is upper triangular).
 template <typename T, typename Gemm>

@@ -374,6 +374,12 @@ void allreduce_sum_f64(double* buf, size_t n, hipStream_t st) {
     const size_t per = g_slot / sizeof(double);
     for (size_t o = 0; o < n; o += per) exchange(nullptr, 0, buf + o, std::min(per, n - o), st);
 }
+void broadcast_f32(float* buf, size_t n, int root, hipStream_t st) {
+    if (!g_info.active || n == 0 || g_info.nranks == 1) return;
+    if (g_info.backend == COMM_RCCL) { ADMM_NCCL_CHECK(ncclBroadcast(buf, buf, n, ncclFloat, root, g_comm, st)); return; }
+    if (g_info.rank != root) ADMM_HIP_CHECK(hipMemsetAsync(buf, 0, n * sizeof(float), st));
+    allreduce_sum_f32(buf, n, st);
+}
 void allreduce_sum_f32_f64(float* fbuf, size_t nf, double* dbuf, size_t nd, hipStream_t st) {
     if (!g_info.active) return;
     if (g_info.backend != COMM_RCCL && round_up_sz(nf * sizeof(float), 16) + round_up_sz(nd * sizeof(double), 16) > g_slot) {

@@ -524,6 +524,7 @@ struct TallPlan final : LassoPlan {
     bool peer_one = false;                              // ... producer and consumer in one launch (tall_tail_kernel<TAIL_PEER1>)
     CommInfo ci;
     DevBuf<float> ab;                                   // [2][ldp] this rank's share of (a, b), all-reduced in place
+    double dist_flops = 0;                              // distributed factorisation: flops this rank performed (0: replicated)
     bool fused = false, fused_pre = false;              // one launch per iteration (tall_fused_kernel); tiles prefetch before they wait
     DevBuf<int> fflag;                                  // [64][16] generation flags of the single-launch iteration
     DevBuf<unsigned int> farrive;
@@ -655,8 +656,28 @@ struct TallPlan final : LassoPlan {
         // 3e-8 of the largest entry at cond ~ 30, tests/test_gpu_kernels.py), float above.
         bool inv64 = p < 4096;
         if (const char* e = std::getenv("ADMM_HIP_INVERSE")) inv64 = std::string(e) == "f64";
+        // Row-sharded solver: the factorisation's block columns dealt out to the ranks, and of the inverse
+        // only the tiles this rank's share of the x-update reads -- 1 / N of the 2 p^3 / 3 + p^3 / 3 flops per rank, bit-identical to the
+        // replicated factorisation (chol_inverse.h).  ADMM_HIP_DIST_FACTOR=0: every rank factorises the whole matrix (round 3).
+        bool dist_factor = shard && ci.nranks > 1 && !inv64 && (p + 127) / 128 >= 2 * ci.nranks && p >= 256;
+        if (const char* e = std::getenv("ADMM_HIP_DIST_FACTOR")) dist_factor = dist_factor && std::string(e) != "0";
         if (inv64) {
             spd_inverse_f32_via_f64(M.get(), ldp, p, (double)(float)rho, st);
+        } else if (dist_factor) {
+            add_diag<float>(M.get(), ldp, p, (float)rho, st);
+            sy.init(p, st, ci.rank, ci.nranks);               // (the tile list of this rank's share; initialised again below, identically)
+            std::vector<int> need;
+            {
+                const int nb128 = (p + 127) / 128;
+                std::vector<char> mark((size_t)nb128 * nb128, 0);
+                for (const int4& t : sy.htiles)
+                    for (int bi = 2 * t.x; bi <= 2 * t.x + 1 && bi < nb128; ++bi)
+                        for (int bj = t.y / 128; bj <= (t.y + t.z - 1) / 128 && bj < nb128; ++bj)
+                            if (bj <= bi && !mark[(size_t)bi * nb128 + bj]) { mark[(size_t)bi * nb128 + bj] = 1; need.push_back(bi << 16 | bj); }
+            }
+            double fl = 0;
+            spd_inverse_mfma_f32_dist(M.get(), ldp, p, need, &fl, st);
+            dist_flops = fl;
         } else {
             add_diag<float>(M.get(), ldp, p, (float)rho, st);
             spd_inverse_f32(M.get(), ldp, p, st);
@@ -791,6 +812,7 @@ struct TallPlan final : LassoPlan {
         S.xupdate_variant = shard ? 2 : (fused ? 3 : (use_sym ? 1 : 0));
         S.exchange_variant = !shard ? 0 : (!peer_fused ? 1 : (peer_one ? 3 : 2));
         S.refine = refine ? 1 : 0;
+        S.factor_flops = dist_flops;
         res.lambda = lam_user;
         beta.zero(st); niter.zero(st);
         const int init_n = std::max(p, 2 * nwg * 8);

@@ -1156,10 +1156,18 @@ wide_rows_persist_kernel(WideParams q, int cpar, WideRows ps) {
     auto slice = [&](int j) -> float4 {
         return rlok ? *reinterpret_cast<const float4*>(q.X + (size_t)cidx[j] * q.ldx + rl) : make_float4(0.f, 0.f, 0.f, 0.f);
     };
-    // partial dots of this workgroup's rows for its live columns, to pd[h & 1][g][wid * KMAX + k].  Eight columns at a time: the
+    // Exchange buffers are indexed by the parity of the ITERATION they belong to, not of the hand-over number (A and B alternate: every
+    // B would get the same parity -- one buffer -- and a workgroup that ran ahead overwrote dots a slower member of its column group
+    // was still reading: found by the 16-process soak, where waves are context-switched, as an x-update 17 yardsticks off in one of
+    // 1432 wide cases).  Two buffers suffice although a workgroup only waits for its row / column group: the reader of pd(k) -- a
+    // column-group mate -- publishes B(k + 1) after it has read, and the writer of pd(k + 2) has waited for that B(k + 1); the reader
+    // of pa(k) -- a row-group mate -- publishes A(k + 1) after it has read, and the writer of pa(k + 2) has waited for that A(k + 1);
+    // the norm shares of iteration k are read by everybody before they publish A(k + 1), which (r'', 0) waits for before it
+    // publishes B(k + 1), which the share publisher (r, 0) waits for before iteration k + 2.
+    // partial dots of this workgroup's rows for its live columns, to pd[it & 1][g][wid * KMAX + k].  Eight columns at a time: the
     // lanes' products, then ONE halving butterfly for the eight sums (lane 8 u ends up with the total of column u).
-    auto dots = [&](unsigned long long h) {
-        float* dst = ps.pd + ((size_t)(h & 1) * G + g) * kRCMAX + (size_t)wid * KMAX;
+    auto dots = [&](unsigned long long it) {            // `it`: the iteration whose x-update consumes these dots (buffer = its parity)
+        float* dst = ps.pd + ((size_t)(it & 1) * G + g) * kRCMAX + (size_t)wid * KMAX;
         const float4 tv = *reinterpret_cast<const float4*>(td + lane * 4);
         auto dot1 = [&](const float4& cv) -> float {
             float d = cv.x * tv.x;
@@ -1199,9 +1207,9 @@ wide_rows_persist_kernel(WideParams q, int cpar, WideRows ps) {
         }
     };
     // the R partial dots of listed position j (of this column group) in row-group order: all requests in flight together
-    auto pd_get = [&](int j, unsigned long long h) -> float {      // eight requests in flight (R = 8 at n = 2000: one round)
+    auto pd_get = [&](int j, unsigned long long it) -> float {     // eight requests in flight (R = 8 at n = 2000: one round)
         const int jj = j / C;
-        const float* src = ps.pd + ((size_t)(h & 1) * G + c) * kRCMAX + (jj % NW) * KMAX + jj / NW;      // workgroup (0, c), then (1, c), ...
+        const float* src = ps.pd + ((size_t)(it & 1) * G + c) * kRCMAX + (jj % NW) * KMAX + jj / NW;      // workgroup (0, c), then (1, c), ...
         float d = 0.f;
         for (int u0 = 0; u0 < R; u0 += 8) {
             float v[8];
@@ -1212,7 +1220,7 @@ wide_rows_persist_kernel(WideParams q, int cpar, WideRows ps) {
         }
         return d;
     };
-    dots(hs + 1);                                           // iteration under `out`: rho known, nothing speculative
+    dots(0);                                                // iteration 0 of the stretch, under `out`: rho known, nothing speculative
     hs++;
     publish(hs);
     bool failed = false;
@@ -1224,7 +1232,7 @@ wide_rows_persist_kernel(WideParams q, int cpar, WideRows ps) {
     const int j0 = c + C * tid;                             // list position of the thread's first column
     float d0 = 0.f;
     bool have0 = tid < nC && xa[j0] != 0.f;
-    if (have0) d0 = pd_get(j0, hs);
+    if (have0) d0 = pd_get(j0, 0);
     for (;;) {
         WR_PHASE(0)
         // ---- (record the decision being acted on: what the x-update launch writes)
@@ -1243,7 +1251,7 @@ wide_rows_persist_kernel(WideParams q, int cpar, WideRows ps) {
             for (int jj = tid + T; jj < nC; jj += T) {
                 const int j = c + C * jj;
                 const float xv = xa[j];
-                if (xv != 0.f) xa[j] = prox_f(xv - pd_get(j, hs), thresh_a, denom_a, q.enet != 0);
+                if (xv != 0.f) xa[j] = prox_f(xv - pd_get(j, k_done), thresh_a, denom_a, q.enet != 0);
             }
         }
         __syncthreads();
@@ -1289,7 +1297,7 @@ wide_rows_persist_kernel(WideParams q, int cpar, WideRows ps) {
             float a = comb[0][tid];
 #pragma unroll
             for (int w = 1; w < NW; ++w) a += comb[w][tid];
-            wr_store_f32(ps.pa + ((size_t)((hs + 1) & 1) * G + g) * RS + tid, a, wt);
+            wr_store_f32(ps.pa + ((size_t)(k_done & 1) * G + g) * RS + tid, a, wt);
         }
         hs++;
         publish(hs);
@@ -1298,7 +1306,7 @@ wide_rows_persist_kernel(WideParams q, int cpar, WideRows ps) {
         WR_PHASE(3)
         double nacc[5] = {0, 0, 0, 0, 0};
         if (tid < RS) {
-            const float* src = ps.pa + ((size_t)(hs & 1) * G + (size_t)r * C) * RS + tid;      // workgroups (r, 0), (r, 1), ...
+            const float* src = ps.pa + ((size_t)(k_done & 1) * G + (size_t)r * C) * RS + tid;      // workgroups (r, 0), (r, 1), ...
             float ax = 0.f;
             for (int u0 = 0; u0 < C; u0 += 8) {             // the C partials in column-group order, eight requests in flight
                 float v[8];
@@ -1347,7 +1355,7 @@ wide_rows_persist_kernel(WideParams q, int cpar, WideRows ps) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) __hip_atomic_store(ps.flagS + (size_t)r * 8, (ps.seq << 32) | k_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        dots(hs + 1);                                       //                                                          [hand-over B]
+        dots(k_done);                                       // (k_done already counts this iteration: the NEXT one consumes them)  [hand-over B]
         hs++;
         publish(hs);
         WR_PHASE(4)
@@ -1388,14 +1396,14 @@ wide_rows_persist_kernel(WideParams q, int cpar, WideRows ps) {
                 td[tid] = t / q.gamma;
             }
             __syncthreads();
-            dots(hs + 1);
+            dots(k_done);
             hs++;
             publish(hs);
             redo++;
         }
         if (!wait_for(hs, 2)) { failed = true; break; }     // the partial dots of the next iteration (speculative ones, or those formed with the new rho)
         have0 = tid < nC && xa[j0] != 0.f;
-        if (have0) d0 = pd_get(j0, hs);
+        if (have0) d0 = pd_get(j0, k_done);
         WR_PHASE(7)
     }
     if (failed) return;

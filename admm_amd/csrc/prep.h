@@ -85,6 +85,9 @@ void spd_inverse_mfma_f32(float* A, long long lda, int n, hipStream_t st);
 // fp32 SPD inverse of a matrix stored in whole 128-blocks (lda >= round_up(n, 128), that many zero-padded columns
 // allocated): hand-written matrix-core kernels for n >= 256, potrf + two trsm below (ADMM_HIP_FACTOR=rocsolver forces the latter).
 void spd_inverse_f32(float* A, long long lda, int n, hipStream_t st);
+// spd_inverse_mfma_f32 with the factorisation's block columns dealt out to the ranks of the attached communicator; of the inverse
+// only the lower 128 x 128 tiles in `need` (bi << 16 | bj) are formed (syrk_mfma.hip).  *flops: what this rank computed.
+void spd_inverse_mfma_f32_dist(float* A, long long lda, int n, const std::vector<int>& need, double* flops, hipStream_t st);
 // (A + diag I)^-1 of a float matrix, factorised and inverted in double and rounded to float once (same storage).
 void spd_inverse_f32_via_f64(float* A, long long lda, int n, double diag, hipStream_t st);
 // fp64 counterparts (gemm_f64_mfma.hip); same storage requirements.

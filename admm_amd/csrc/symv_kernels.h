@@ -347,12 +347,13 @@ struct SymvPlan {
     SymvSched sched;
     long long ldo = 0;
     DevBuf<int4> tiles;
+    std::vector<int4> htiles;      // host copy of this plan's tile list (the distributed setup derives from it which tiles of the inverse a rank reads)
     bool nt = false;
     DevBuf<float> dot0, dot1, axp0, axp1;
 #ifdef ADMM_HIP_PROBE
     long long* probe = nullptr; mutable int probe_idx = 0;
 #endif
-    // part / nparts: this plan launches only the tiles with (index in the full list) % nparts == part -- the row-sharded
+    // part / nparts: this plan launches only the tiles whose 128-column group (index in the full list) % nparts == part -- the row-sharded
     // tall x-update gives every rank an equal share of the triangle; the partial arrays keep the full shape (slots of
     // tiles owned by other ranks stay zero) so that the same consumer code sums them.
     void init(int p_, hipStream_t st, int part = 0, int nparts = 1) {
@@ -400,11 +401,24 @@ struct SymvPlan {
             }
         }
         if (nparts > 1) {
+            // Dealt out in groups of segments that cover whole 128-column blocks of one strip (segment widths of 32 / 64 / 128: 128
+            // columns; 192: 384), not segment by segment: the distributed factorisation (chol_inverse.h) forms, of the inverse,
+            // only the 128 x 128 tiles a rank reads here -- interleaved 32-column segments made every rank read every tile
+            // (measured: 0.78 p^3 flops per rank of 2 where 0.59 p^3 is the share).
+            auto gcd = [](int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; };
             std::vector<int4> mine;
-            for (size_t i = (size_t)part; i < h.size(); i += (size_t)nparts) mine.push_back(h[i]);
+            int group = -1, last_rb = -1, last_cg = -1;
+            for (const int4& t : h) {
+                const int w = sched.width(t.x);
+                const int gw = w / gcd(w, 128) * 128;
+                const int cg = t.y / gw;
+                if (t.x != last_rb || cg != last_cg) { ++group; last_rb = t.x; last_cg = cg; }
+                if (group % nparts == part) mine.push_back(t);
+            }
             h.swap(mine);
         }
         ntiles = (int)h.size();
+        htiles = h;
         // The whole triangle is re-read every iteration.  Plain loads while most of it stays in the 256 MB Infinity Cache
         // between two passes, non-temporal beyond.  Measured crossover (one MI355X, plain vs nt, TB/s on 2p^2 bytes):
         // p = 10000 5.7 vs 5.3 | 11000 5.90 vs 5.24 | 12000 6.08 vs 5.41 | 13000 4.31 vs 5.50 | 16000 4.1-4.4 vs 5.3-5.4.

@@ -26,6 +26,7 @@
 // No rocBLAS / rocSOLVER on this path (their handle creation alone costs 0.1-0.2 s per process).
 #include "prep.h"
 #include "chol_inverse.h"
+#include "comm.h"
 
 namespace admm {
 
@@ -193,7 +194,7 @@ static DevBuf<int> make_square_tilemap(int nb, hipStream_t st) {
 
 static void launch_gemm_nt(bool lower, const float* A, long long lda, const float* B, long long ldb, float* C, long long ldc,
                            int M, int N, int K, float alpha, float beta, bool mirror, bool kstart_row, hipStream_t st,
-                           int ksplit = 1, long long cstride = 0, const int* tilemap = nullptr) {
+                           int ksplit = 1, long long cstride = 0, const int* tilemap = nullptr, int ntiles_listed = -1) {
     if (M <= 0 || N <= 0) return;
     GemmNT g;
     g.ksplit = ksplit; g.cstride = cstride; g.tilemap = tilemap;
@@ -201,6 +202,8 @@ static void launch_gemm_nt(bool lower, const float* A, long long lda, const floa
     g.alpha = alpha; g.beta = beta; g.mirror = mirror ? 1 : 0; g.kstart_row = kstart_row ? 1 : 0;
     g.nbi = (M + SK_BM - 1) / SK_BM; g.nbj = (N + SK_BM - 1) / SK_BM;
     g.ntiles = lower ? g.nbi * (g.nbi + 1) / 2 : g.nbi * g.nbj;
+    if (tilemap != nullptr && ntiles_listed >= 0) g.ntiles = ntiles_listed;     // only the listed tiles (the distributed inverse: this rank's share)
+    if (g.ntiles <= 0) return;
     const int grid = (g.ntiles * ksplit + 7) / 8 * 8;
     if (lower) hipLaunchKernelGGL(gemm_nt_mfma_kernel<1>, dim3(grid), dim3(SK_THREADS), 0, st, g);
     else hipLaunchKernelGGL(gemm_nt_mfma_kernel<0>, dim3(grid), dim3(SK_THREADS), 0, st, g);
@@ -278,6 +281,25 @@ void gram_rows_mfma_f32(const float* Z, long long ldz, int r0, int nr, int K, fl
 // (diagonal-block kernel and block driver: chol_inverse.h)
 void spd_inverse_mfma_f32(float* A, long long lda, int p, hipStream_t st) {
     spd_inverse_blocked<float>(A, lda, p, st, launch_gemm_nt_f32);
+}
+
+// The same with the block columns of the factorisation dealt out to the ranks of the attached communicator (chol_inverse.h,
+// cholesky_linvt_blocked_dist) and, of the inverse U U', only the lower 128 x 128 tiles listed in `need` (bi << 16 | bj): the tiles
+// this rank's share of the sharded x-update reads.  Everything a rank computes is bit-identical to the single-process result.
+void spd_inverse_mfma_f32_dist(float* A, long long lda, int p, const std::vector<int>& need, double* flops, hipStream_t st) {
+    const CommInfo ci = comm_info();
+    double fl = 0;
+    DevBuf<float> U = cholesky_linvt_blocked_dist<float>(A, lda, p, st, launch_gemm_nt_f32, ci.nranks, ci.rank,
+                                                        [](float* b, size_t n, int root, hipStream_t s) { broadcast_f32(b, n, root, s); }, &fl);
+    comm_check();
+    const int pp = (p + 127) / 128 * 128;
+    DevBuf<int> tmap(std::max<size_t>(need.size(), 1));
+    if (!need.empty()) ADMM_HIP_CHECK(hipMemcpyAsync(tmap.get(), need.data(), need.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    launch_gemm_nt(true, U.get(), lda, U.get(), lda, A, lda, p, p, pp, 1.f, 0.f, false, true, st, 1, 0, tmap.get(), (int)need.size());
+    for (int m : need) { const int bi = m >> 16; fl += 2.0 * 128 * 128 * (double)(pp - bi * 128); }
+    ADMM_HIP_CHECK(hipGetLastError());
+    ADMM_HIP_CHECK(hipStreamSynchronize(st));
+    if (flops) *flops = fl;
 }
 
 }  // namespace admm

@@ -93,6 +93,9 @@ typedef struct admm_stats {
                               launch (chosen only when that launch is resident as a whole: its workgroups wait for one another) */
     int refine;            /* tall path: 1 = every x-update refined once with a double-precision residual (ADMM_HIP_REFINE=1) */
     long long persist_iter;/* wide path: iterations that ran inside persistent active-set launches (of total_iter) */
+    double factor_flops;   /* row-sharded tall solver: flops of the Cholesky + inverse THIS rank performed when the factorisation is
+                              distributed over the ranks (block columns dealt out, panels broadcast); 0 when every
+                              rank factorises the whole matrix */
 } admm_stats;
 
 /* lambda_in: user grid of length nlambda_in (sorted decreasing by the R wrapper), or NULL/0
@@ -332,8 +335,10 @@ ADMM_HIP_API int admm_hip_lasso_plan_create_dist(const double* x_local, const do
  * serial solvers are single-threaded; it gives the headline configuration a multi-GPU path.
  * x_local / y_local: any contiguous row slice of the global problem (the slices of all ranks tile the rows; unlike the
  * consensus solver the algorithm does not depend on the split).  Setup: global-moment standardisation, X'y and the
- * Gram matrix as split-K sums over the ranks' row blocks (one all-reduce each), Lanczos value / rho / cached inverse
- * replicated.  Per ADMM iteration every rank streams 1/nranks of the lower-triangle tiles of the inverse and the ranks
+ * Gram matrix as split-K sums over the ranks' row blocks (one all-reduce each), Lanczos value / rho replicated; the
+ * Cholesky factorisation and the cached inverse DISTRIBUTED for p >= 4096 (block columns dealt out to the ranks, panels
+ * broadcast, every rank forms only the tiles of the inverse its x-update share reads -- bit-identical to the replicated
+ * factorisation; ADMM_HIP_DIST_FACTOR=0 switches back to it), replicated below.  Per ADMM iteration every rank streams 1/nranks of the lower-triangle tiles of the inverse and the ranks
  * exchange ONE all-reduce of 2p floats; the element-wise tail and all decisions run replicated on identical numbers.
  * The iterates equal the single-GPU ones up to the summation order of that all-reduce.  alpha < 0: Lasso, else
  * elastic net.  admm_hip_lasso_plan_create_dist with nthread == 0 prepares the same solver for repeated runs. */

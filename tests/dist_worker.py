@@ -157,7 +157,8 @@ def main():
         assert fit.stats["xupdate_variant"] == 2
         plan.close()
     np.savez(os.path.join(workdir, f"result.{rank}.npz"), beta=fit.beta_dense, niter=fit.niter, lam=fit.lambda_, trace=trace,
-             exchange_variant=int(fit.stats.get("exchange_variant", 0)))
+             exchange_variant=int(fit.stats.get("exchange_variant", 0)), factor_flops=float(fit.stats.get("factor_flops", 0.0)),
+             t_factor=float(fit.stats.get("t_factor", 0.0)))
     barrier(workdir, "end", rank, nranks)                  # nobody unmaps while a peer may still push
     adist.finalize_comm()
     print("rank", rank, "ok", flush=True)

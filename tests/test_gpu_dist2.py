@@ -89,6 +89,30 @@ def test_two_process_row_sharded_tall_solver(backend, case):
     assert len(rep["loose"]) == 0
 
 
+@pytest.mark.parametrize("nranks,backend", [(2, "peer"), (4, "shm")])
+def test_distributed_factorisation_is_bit_identical_to_the_replicated_one(nranks, backend):
+    """SURVEY.md section 8f row n1, the multi-GPU half: in the row-sharded tall solver the blocked Cholesky + inverse runs with its
+    128-column blocks dealt out to the ranks -- the owner factorises the diagonal block and the panel and broadcasts them, every
+    rank updates the block columns it owns, and of the inverse U U' a rank forms only the tiles its share of the x-update reads.
+    Every tile sees the same updates in the same order from bit-identical operands as in one process, so the WHOLE solve must be
+    bit-identical to the run in which every rank factorises the full matrix (ADMM_HIP_DIST_FACTOR=0): coefficients, iteration
+    counts, decision trace.  And the work must have been shared: the flops a rank reports are ~1 / nranks of one process's
+    p^3 (2/3 for the factor + U, 1/3 for U U'); the ranks' shares add up to it.  (ADMM_HIP_INVERSE=f32: below p = 4096 the inverse is
+    otherwise built in double, replicated.)"""
+    env = {"ADMM_HIP_INVERSE": "f32"}
+    a = _run_ranks(backend, "tallshard2300", nranks=nranks, timeout=600, extra_env=env)
+    b = _run_ranks(backend, "tallshard2300", nranks=nranks, timeout=600, extra_env=dict(env, ADMM_HIP_DIST_FACTOR="0"))
+    for r in range(nranks):
+        assert np.array_equal(a[r]["beta"], b[r]["beta"]) and np.array_equal(a[r]["niter"], b[r]["niter"]) and np.array_equal(a[r]["trace"], b[r]["trace"]), r
+        assert float(b[r]["factor_flops"]) == 0.0 and float(a[r]["factor_flops"]) > 0.0
+    p = 2300
+    one = float(p) ** 3                                      # 2 p^3 / 3 (factor + U) + p^3 / 3 (U U'), whole 128-blocks make it a little more
+    shares = [float(a[r]["factor_flops"]) for r in range(nranks)]
+    print(f"[dist factor] {nranks} ranks over {backend}: flops per rank / p^3 = {[round(s / one, 3) for s in shares]}, sum {sum(shares) / one:.3f}")
+    assert max(shares) < 1.6 * one / nranks, shares          # shared out (block granularity and the overlapping tiles of U U' cost a little)
+    assert 0.9 * one < sum(shares) < 1.5 * one, shares
+
+
 @pytest.mark.parametrize("backend,case", [("shm", "widecols"), ("peer", "widecols"), ("peer", "widecols_enet")])
 def test_two_process_column_sharded_wide_solver(backend, case):
     """The serial wide solver (ADMMLassoWide / ADMMEnetWide) with its COLUMNS dealt out to two ranks

@@ -51,11 +51,22 @@ def worker(seed, ncases, out):
                        stdz=int(cs["stdz"]), scale=cs["scale"])
             t0 = time.time()
             try:
-                cap = T.gpu_capture(cs)
+                # round 4: the wide, LAD and BP kinds carry their iterate dump too and are ALWAYS held to the stepwise rule as well
+                always_sw = cs["kind"] in ("lad", "bp") or (cs["n"] <= cs["p"] and not (cs["kind"] == "par" and cs.get("K", 0) > 1))
+                cap = T.gpu_capture(cs, state=always_sw)
                 rec["decisions"] = int(len(cap["trace"]))
                 rec["t_gpu"] = round(time.time() - t0, 3)
                 buf = io.StringIO()
                 try:
+                    if always_sw and "state" in cap:
+                        from oracle import stepcheck
+                        sw = T.stepwise_capture(cs, cap)
+                        if cs["kind"] in ("lad", "bp"):
+                            stepcheck.assert_stepwise_dense(sw, label=T.case_label(cs))
+                            rec["stepwise_ok"] = dict(records=sw["records"], x_vs_ref_max=float(sw["x_vs_ref_max"]), ties=len(sw.get("rounding_ties", [])))
+                        else:
+                            stepcheck.assert_stepwise_wide(sw, label=T.case_label(cs))
+                            rec["stepwise_ok"] = dict(records=sw["records"], xt=float(sw["xt_ratio_max"]), ax=float(sw["ax_ratio_max"]), ties=len(sw.get("rounding_ties", [])))
                     with contextlib.redirect_stdout(buf):
                         rep = T.judge_capture(cs, cap, budget=False)          # the near-ties are RECORDED here, not bounded
                     rec.update(ok=True, judged=rep is not None, **_report_stats(rep))
@@ -119,6 +130,15 @@ def summarise(out, seeds, ncases, wall):
         import numpy as np
         q = np.quantile(allu, [0.5, 0.9, 0.99, 1.0])
         lines += ["", f"Largest near-tie per case (cases with at least one, n = {len(allu)}): median {q[0]:.2f}, 90 % {q[1]:.2f}, 99 % {q[2]:.2f}, max {q[3]:.2f} ulps."]
+    sw_ok = [r for r in recs if r.get("stepwise_ok")]
+    if sw_ok:
+        nrec = sum(r["stepwise_ok"]["records"] for r in sw_ok)
+        wide = [r["stepwise_ok"] for r in sw_ok if "xt" in r["stepwise_ok"]]
+        dense = [r["stepwise_ok"] for r in sw_ok if "x_vs_ref_max" in r["stepwise_ok"]]
+        lines += ["", f"Stepwise rule (oracle/stepcheck.py check_wide / check_dense) on every wide / LAD / BP case: {len(sw_ok)} cases, {nrec} iterations replayed, "
+                      f"all elementwise steps bit-exact; wide mat-vecs at most {max([w['xt'] for w in wide], default=0):.2f} (X't) / {max([w['ax'] for w in wide], default=0):.2f} (A x) "
+                      f"float-dot yardsticks; LAD / BP projection at most {max([d['x_vs_ref_max'] for d in dense], default=0):.2f} x the reference route's error; "
+                      f"{sum(w['ties'] for w in wide) + sum(d['ties'] for d in dense)} decisions that are exact ties up to the order of a sum."]
     lines += ["", "## Failures", ""]
     if not fails:
         lines.append("none")
@@ -140,7 +160,7 @@ def main():
     first, nseeds = int(sys.argv[1]), int(sys.argv[2])
     ncases = int(sys.argv[3]) if len(sys.argv) > 3 else 150
     procs = int(sys.argv[4]) if len(sys.argv) > 4 else 16
-    out = sys.argv[5] if len(sys.argv) > 5 else os.path.join(ROOT, "gpurun_out", "soak_r03")
+    out = sys.argv[5] if len(sys.argv) > 5 else os.path.join(ROOT, "gpurun_out", "soak_r04")
     os.makedirs(out, exist_ok=True)
     seeds = list(range(first, first + nseeds))
     env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
