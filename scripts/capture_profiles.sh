@@ -4,15 +4,15 @@
 #   the other BASELINE configs (C3 wide, C4 consensus K=8 on one GPU, C5 LAD / BP): bench lines + kernel-trace stats each.
 # Outputs go to gpurun_out/<tag>/; copy the summaries into profiles/ afterwards.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 export TMPDIR=/tmp
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o c2 -- python bench.py --steps 3 --warmup 1 --cpu-seconds 0 --consensus-seconds 0 > $OUT/trace_bench.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o c2 -- python bench.py --steps 3 --warmup 1 --cpu-seconds 0 --consensus-seconds 0 --config-seconds 0 > $OUT/trace_bench.log 2>&1
 python scripts/rocpd_summary.py $OUT/trace/c2_results.db $OUT/tall_c2_kernel_stats.md 14
 grep '^{"metric"' $OUT/trace_bench.log | tail -1 > $OUT/tall_c2_kernel_stats_benchline.json
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o c2 -- python bench.py --steps 1 --warmup 0 --cpu-seconds 0 --consensus-seconds 0 --nlambda 10 > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o c2 -- python bench.py --steps 1 --warmup 0 --cpu-seconds 0 --consensus-seconds 0 --nlambda 10 > $OUT/pmc_write.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o c2 -- python bench.py --steps 1 --warmup 0 --cpu-seconds 0 --consensus-seconds 0 --config-seconds 0 --nlambda 10 > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o c2 -- python bench.py --steps 1 --warmup 0 --cpu-seconds 0 --consensus-seconds 0 --config-seconds 0 --nlambda 10 > $OUT/pmc_write.log 2>&1
 python scripts/rocpd_pmc.py $OUT/pmc_fetch/c2_results.db $OUT/pmc_write/c2_results.db $OUT/tall_c2_pmc_hbm_bytes.md
 python bench.py > $OUT/bench_default.log 2>&1
 grep '^{"metric"' $OUT/bench_default.log | tail -1 > $OUT/bench_c2.json

@@ -45,6 +45,9 @@ def problem(case):
     if case == "tallshard2300":       # ~90 lower-triangle tiles dealt out to the ranks
         x, y = synth_lasso(4700, 2300, 40, seed=2300)
         return x, y, 0, dict(nlambda=6)
+    if case == "tallshard6000":       # scripts/dist_factor_table.py: a size at which the factorisation dominates the setup
+        x, y = synth_lasso(6400, 6000, 40, seed=6000)
+        return x, y, 0, dict(nlambda=3)
     if case == "widecols":            # the serial wide solver with its columns spread over the ranks (fused x-update, n <= 4096)
         x, y = synth_lasso(300, 2000, 20, seed=29)
         return x, y, -1, dict(nlambda=10)

@@ -485,3 +485,85 @@ def test_two_rank_column_block_sharing_bp_protocol_matches_serial_oracle(tmp_pat
     assert r0["niter"][0] == r1["niter"][0] == ref["niter"]      # double arithmetic: the two-piece sum of S moves nothing visible
     beta = np.concatenate([r0["beta"], r1["beta"]])
     assert np.abs(beta - ref["beta"]).max() < 1e-12 and np.abs(beta - b0).max() < 5e-3
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Distributed factorisation of the row-sharded tall solver (chol_inverse.h cholesky_linvt_blocked_dist,
+# lasso_tall.hip): world_size-2 model of its protocol -- block column k of the lower triangle and of U = L^-T belongs to rank
+# k mod N; the owner factorises the diagonal block, finishes its column of U and the panel and BROADCASTS them as one message;
+# every rank applies the two rank-B updates to the block columns it owns.  The claim the GPU test
+# (tests/test_gpu_dist2.py::test_distributed_factorisation_is_bit_identical_to_the_replicated_one) rests on is modelled here in
+# float32 NumPy: every tile sees the same updates in the same order from bit-identical operands as in one process, so the ranks'
+# pieces ARE the single-process result, bit for bit, and each rank performs ~1 / N of the update flops.
+def _blocked_factor_model(A, B, nranks, rank, bcast):
+    """Right-looking blocked Cholesky of the lower triangle of A (float32, in place) + U = L^-T, block size B, the block columns
+    dealt out to `nranks`; bcast(buf, root) returns root's buffer on every rank.  Returns (A, U, update flops of this rank)."""
+    p = A.shape[0]
+    nb = (p + B - 1) // B
+    U = np.eye(p, dtype=F)
+    flops = 0
+    for k in range(nb):
+        r0, r1 = k * B, min((k + 1) * B, p)
+        owner = k % nranks
+        if rank == owner:
+            Lkk = np.linalg.cholesky(A[r0:r1, r0:r1].astype(np.float64)).astype(F)      # (the model's diagonal-block kernel)
+            Dinv = sla.solve_triangular(Lkk.astype(np.float64), np.eye(r1 - r0), lower=True).astype(F)
+            A[r0:r1, r0:r1] = Lkk
+            U[:r1, r0:r1] = U[:r1, r0:r1] @ Dinv.T                                       # this block column of U is final
+            if r1 < p:
+                A[r1:, r0:r1] = A[r1:, r0:r1] @ Dinv.T                                   # the panel L_ik
+        msg = np.concatenate([A[r0:, r0:r1].ravel(), U[:r1, r0:r1].ravel()]) if rank == owner else None
+        msg = bcast(msg, owner, (p - r0) * (r1 - r0) + r1 * (r1 - r0))
+        nl = (p - r0) * (r1 - r0)
+        A[r0:, r0:r1] = msg[:nl].reshape(p - r0, r1 - r0)
+        U[:r1, r0:r1] = msg[nl:].reshape(r1, r1 - r0)
+        for j in range(k + 1, nb):
+            if j % nranks != rank:
+                continue
+            c0, c1 = j * B, min((j + 1) * B, p)
+            Lj = A[c0:, r0:r1]
+            A[c0:, c0:c1] -= Lj @ A[c0:c1, r0:r1].T
+            U[:r1, c0:c1] -= U[:r1, r0:r1] @ A[c0:c1, r0:r1].T
+            flops += 2 * (r1 - r0) * (c1 - c0) * ((p - c0) + r1)
+    return A, U, flops
+
+
+def _factor_rank_main(rank, world, port, M, B, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def bcast(buf, root, n):
+        t = torch.from_numpy(np.ascontiguousarray(buf)) if rank == root else torch.empty(n, dtype=torch.float32)
+        dist.broadcast(t, src=root)
+        return t.numpy()
+
+    A, U, flops = _blocked_factor_model(M.copy(), B, world, rank, bcast)
+    np.savez(out_path + f".{rank}.npz", A=A, U=U, flops=np.array([flops]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_distributed_factorisation_protocol_is_bit_identical_to_one_process(tmp_path):
+    rng = np.random.default_rng(123)
+    p, B = 150, 16                                               # 10 block columns, the last one ragged (6 columns)
+    X = rng.standard_normal((220, p)).astype(F)
+    M = (X.T @ X + F(3.0) * np.eye(p, dtype=F)).astype(F)
+    A1, U1, fl1 = _blocked_factor_model(M.copy(), B, 1, 0, lambda buf, root, n: buf)
+    out = str(tmp_path / "factor")
+    mp.spawn(_factor_rank_main, args=(2, _free_port(), M, B, out), nprocs=2, join=True)
+    r = [np.load(out + f".{k}.npz") for k in range(2)]
+    nb = (p + B - 1) // B
+    for k in range(2):
+        # U: every block column was broadcast when it became final -- the whole of it on every rank, bit-identical
+        assert np.array_equal(np.triu(r[k]["U"]), np.triu(U1)), k
+        # L: the panels (broadcast) on every rank; the trailing matrix is only kept up to date in the columns a rank owns
+        assert np.array_equal(np.tril(r[k]["A"]), np.tril(A1)), k
+    # the factor is a factor: L L' = M and U = L^-T, to float accuracy
+    L = np.tril(A1).astype(np.float64)
+    assert np.abs(L @ L.T - M).max() < 1e-3 * np.abs(M).max()
+    assert np.abs(np.triu(U1).astype(np.float64).T @ L - np.eye(p)).max() < 1e-4
+    # the update flops are shared out: the two ranks' add up to one process's, neither does more than 60 % (block columns k mod 2)
+    f0, f1 = int(r[0]["flops"][0]), int(r[1]["flops"][0])
+    assert f0 + f1 == fl1 and max(f0, f1) < 0.6 * fl1, (f0, f1, fl1)
+    assert nb == 10
