@@ -24,8 +24,9 @@ CommInfo comm_info();
 void allreduce_sum_f32(float* buf, size_t n, hipStream_t st);
 void allreduce_sum_f64(double* buf, size_t n, hipStream_t st);
 // Broadcast of a device buffer from `root` to every rank, enqueued on `st` (setup only: the panel broadcasts of the distributed
-// factorisation).  RCCL: ncclBroadcast.  PEER / SHM: the other ranks clear their buffer and the ranks sum -- x + 0 + ... + 0 is x
-// bit for bit (those back-ends exist for latency-bound exchanges and for tests, not for bulk transfers).
+// factorisation).  RCCL: ncclBroadcast.  PEER: the root pushes slot-sized chunks into every rank's exchange buffer, the others
+// only raise their flags (same parity protocol as the all-reduce).  SHM (tests): the other ranks clear their buffer and the ranks
+// sum -- x + 0 + ... + 0 is x bit for bit.
 void broadcast_f32(float* buf, size_t n, int root, hipStream_t st);
 // Two buffers in one exchange (the consensus payload: p floats + the norm doubles).
 void allreduce_sum_f32_f64(float* fbuf, size_t nf, double* dbuf, size_t nd, hipStream_t st);

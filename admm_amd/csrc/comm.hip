@@ -186,6 +186,8 @@ constexpr int kPushGroups = 4;                           // workgroups per desti
 struct PeerArgs : PeerExchange {
     const float* fsrc; size_t nf; const double* dsrc; size_t nd; size_t off_d;
     float* fdst; double* ddst;
+    int bcast_root;                                      // >= 0: a broadcast -- only this rank's payload travels, the others only raise their flags
+    int groups;                                          // workgroups per destination rank of the push
 };
 
 // All payload traffic is in 16-byte units per lane, 1 KiB per wave instruction (with an uncached buffer 4-byte accesses
@@ -214,10 +216,10 @@ __device__ __forceinline__ uint4 peer_load_unit(const PeerArgs& a, size_t u) {
 
 __global__ void __launch_bounds__(256) peer_push_kernel(PeerArgs a) {
     if (*reinterpret_cast<volatile int*>(a.err)) return;
-    const int q = blockIdx.x / kPushGroups, g = blockIdx.x % kPushGroups;
+    const int q = blockIdx.x / a.groups, g = blockIdx.x % a.groups;
     unsigned long long* dst = reinterpret_cast<unsigned long long*>(peer_dst_slot(a, q));
-    const size_t units = a.off_d / 16 + (a.nd + 1) / 2;
-    for (size_t u = (size_t)g * 256 + threadIdx.x; u < units; u += (size_t)kPushGroups * 256) {
+    const size_t units = (a.bcast_root >= 0 && a.rank != a.bcast_root) ? 0 : a.off_d / 16 + (a.nd + 1) / 2;
+    for (size_t u = (size_t)g * 256 + threadIdx.x; u < units; u += (size_t)a.groups * 256) {
         const uint4 v = peer_load_unit(a, u);
         peer_store_u64(dst + 2 * u, (unsigned long long)v.x | ((unsigned long long)v.y << 32));       // write-through, no fence needed
         peer_store_u64(dst + 2 * u + 1, (unsigned long long)v.z | ((unsigned long long)v.w << 32));
@@ -226,7 +228,7 @@ __global__ void __launch_bounds__(256) peer_push_kernel(PeerArgs a) {
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned int prev = __hip_atomic_fetch_add(&a.count[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (prev == kPushGroups - 1) {                   // ... before the last workgroup raises the flag at the destination
+        if (prev == (unsigned)a.groups - 1) {            // ... before the last workgroup raises the flag at the destination
             __hip_atomic_store(&a.count[q], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             peer_store_u64(peer_flag(a.remote[q], a.flags_off, a.seq, a.nranks, a.rank), a.seq);
         }
@@ -240,6 +242,17 @@ __global__ void __launch_bounds__(256) peer_sum_kernel(PeerArgs a) {
     const size_t uf = a.off_d / 16, units = uf + (a.nd + 1) / 2;
     const size_t u = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (u >= units) return;
+    if (a.bcast_root >= 0) {                             // broadcast: the root's slot, copied out (the root keeps its own buffer)
+        if (a.rank == a.bcast_root || u >= uf) return;
+        const float4 s = reinterpret_cast<const float4*>(peer_src_slot(a, a.bcast_root))[u];
+        const size_t i = u * 4;
+        if (i + 4 <= a.nf) *reinterpret_cast<float4*>(a.fdst + i) = s;
+        else {
+            const float t[4] = {s.x, s.y, s.z, s.w};
+            for (int k = 0; k < 4; ++k) if (i + k < a.nf) a.fdst[i + k] = t[k];
+        }
+        return;
+    }
     const unsigned char* base = peer_src_slot(a, 0);
     if (u < uf) {
         float4 s = reinterpret_cast<const float4*>(base)[u];
@@ -272,15 +285,21 @@ void peer_fill(PeerExchange& a) {
     a.timeout_ticks = (long long)(wait_seconds_now() * 100e6);          // wall_clock64: constant 100 MHz
 }
 
-void peer_exchange(float* fbuf, size_t nf, double* dbuf, size_t nd, hipStream_t st) {
+// bcast_root >= 0: the payload of that rank only (floats).  Every rank still takes part in every exchange -- the non-roots raise
+// their flags without payload and the root waits for them in its consuming launch -- so the slot parity protocol holds
+// unchanged: the root cannot overwrite slot set s & 1 with chunk s + 2 before every rank has copied chunk s out (it waits for
+// their flags of s + 1, raised in stream order after that copy).
+void peer_exchange(float* fbuf, size_t nf, double* dbuf, size_t nd, hipStream_t st, int bcast_root = -1) {
     PeerArgs a;
     peer_fill(a);
+    a.bcast_root = bcast_root;
+    a.groups = bcast_root >= 0 ? 32 : kPushGroups;        // bulk payload: more workgroups per destination
     a.off_d = round_up_sz(nf * sizeof(float), 16);
     ADMM_REQUIRE(a.off_d + round_up_sz(nd * sizeof(double), 16) <= g_slot, "exchange payload exceeds the slot size");
     ADMM_REQUIRE((reinterpret_cast<uintptr_t>(fbuf) & 15) == 0 && (reinterpret_cast<uintptr_t>(dbuf) & 15) == 0, "exchange buffers must be 16-byte aligned");
     a.fsrc = fbuf; a.nf = nf; a.dsrc = dbuf; a.nd = nd; a.fdst = fbuf; a.ddst = dbuf;
     const size_t units = a.off_d / 16 + (nd + 1) / 2;
-    hipLaunchKernelGGL(peer_push_kernel, dim3(g_info.nranks * kPushGroups), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(peer_push_kernel, dim3(g_info.nranks * a.groups), dim3(256), 0, st, a);
     hipLaunchKernelGGL(peer_sum_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, st, a);
 }
 
@@ -377,7 +396,12 @@ void allreduce_sum_f64(double* buf, size_t n, hipStream_t st) {
 void broadcast_f32(float* buf, size_t n, int root, hipStream_t st) {
     if (!g_info.active || n == 0 || g_info.nranks == 1) return;
     if (g_info.backend == COMM_RCCL) { ADMM_NCCL_CHECK(ncclBroadcast(buf, buf, n, ncclFloat, root, g_comm, st)); return; }
-    if (g_info.rank != root) ADMM_HIP_CHECK(hipMemsetAsync(buf, 0, n * sizeof(float), st));
+    if (g_info.backend == COMM_PEER) {
+        const size_t per = g_slot / sizeof(float);
+        for (size_t o = 0; o < n; o += per) peer_exchange(buf + o, std::min(per, n - o), nullptr, 0, st, root);
+        return;
+    }
+    if (g_info.rank != root) ADMM_HIP_CHECK(hipMemsetAsync(buf, 0, n * sizeof(float), st));      // SHM (tests): x + 0 + ... + 0 is x bit for bit
     allreduce_sum_f32(buf, n, st);
 }
 void allreduce_sum_f32_f64(float* fbuf, size_t nf, double* dbuf, size_t nd, hipStream_t st) {

@@ -48,6 +48,8 @@ struct GemmNT {
     int ksplit;                  // > 1: split s of the K range writes its own partial C + s * cstride (alpha = 1, beta = 0)
     long long cstride;
     const int* tilemap;          // optional [ntiles]: work item -> (bi << 16 | bj); NULL = row-major triangle / column-major grid
+    const int* qmap;             // optional [nq]: QUARTER items (qi << 16 | qj, in units of 64 rows / columns), run by the blocks past the
+    int nq, grid_full;           //   first grid_full ones (the tail of a deep-K launch, see gram_mfma_f32); LOWER + mirror semantics
 };
 
 __device__ __forceinline__ void tri_decode(int t, int& bi, int& bj) {   // t -> (bi, bj), bi >= bj, row-major triangle
@@ -57,10 +59,91 @@ __device__ __forceinline__ void tri_decode(int t, int& bi, int& bj) {   // t -> 
     bi = b; bj = t - b * (b + 1) / 2;
 }
 
+// A 64 x 64 piece of C (a QUARTER of a tile) by one workgroup: wave w owns the 32 x 32 block (w >> 1, w & 1).  Same K order, same
+// instruction, same accumulation per element as the full tile: the values are bit-identical, only the shape of the work item
+// differs.  Used for the last, partly filled round of a deep-K launch (gram_mfma_f32): a quarter item is a quarter of the flops
+// and the round it runs in is latency-bound (at most one workgroup per CU), so global loads run two K tiles ahead.
+__device__ __forceinline__ void gemm_nt_quarter(const GemmNT& g, float (*lds)[2][SK_BK][SK_BM], int qi, int qj) {
+    const int I0 = qi * 64, J0 = qj * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wi = (wid >> 1) * 32, wj = (wid & 1) * 32;
+    const int s_row = tid >> 4;               // 0..15 (k row)
+    const int s_col = (tid & 15) * 4;         // 0..60 (i)
+    const float* gA = g.A + (size_t)s_row * g.lda + I0 + s_col;
+    const float* gB = g.B + (size_t)s_row * g.ldb + J0 + s_col;
+    floatx16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int kbeg = g.kstart_row ? (max(I0, J0) / SK_BK) * SK_BK : 0;
+    const int ntile_k = (g.K - kbeg) / SK_BK;
+    const int fk = lane >> 5, fi = lane & 31;
+    // tile t travels through register set t & 1 (named variables: arrays indexed through lambdas end up in scratch memory)
+    float4 qa0, qb0, qa1, qb1;
+#define SK_QLOAD(S, t)                                                                                       \
+    {                                                                                                        \
+        qa##S = *reinterpret_cast<const float4*>(gA + (size_t)(kbeg + (t) * SK_BK) * g.lda);                 \
+        qb##S = *reinterpret_cast<const float4*>(gB + (size_t)(kbeg + (t) * SK_BK) * g.ldb);                 \
+    }
+#define SK_QSTORE(S, buf)                                                                                    \
+    {                                                                                                        \
+        *reinterpret_cast<float4*>(&lds[buf][0][s_row][s_col]) = qa##S;                                      \
+        *reinterpret_cast<float4*>(&lds[buf][1][s_row][s_col]) = qb##S;                                      \
+    }
+    auto qcompute = [&](int buf) {                                       // all fragments of the K tile first, then the eight dependent instructions
+        float fa[SK_BK / 2], fb[SK_BK / 2];
+#pragma unroll
+        for (int u = 0; u < SK_BK / 2; ++u) { fa[u] = lds[buf][0][2 * u + fk][wi + fi]; fb[u] = lds[buf][1][2 * u + fk][wj + fi]; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < SK_BK / 2; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u], fb[u], acc, 0, 0, 0);
+    };
+    if (ntile_k > 0) {
+        SK_QLOAD(0, 0)
+        if (ntile_k > 1) SK_QLOAD(1, 1)
+        SK_QSTORE(0, 0)
+        __syncthreads();
+        for (int kt = 0; kt < ntile_k; kt += 2) {
+            if (kt + 2 < ntile_k) SK_QLOAD(0, kt + 2)
+            qcompute(0);
+            if (kt + 1 < ntile_k) {
+                SK_QSTORE(1, 1)
+                __syncthreads();
+                if (kt + 3 < ntile_k) SK_QLOAD(1, kt + 3)
+                qcompute(1);
+                if (kt + 2 < ntile_k) { SK_QSTORE(0, 0) __syncthreads(); }
+            }
+        }
+    }
+#undef SK_QLOAD
+#undef SK_QSTORE
+    const bool offdiag = I0 != J0;
+    const int col = J0 + wj + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = I0 + wi + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < g.M && col < g.N) {
+            float v = g.alpha * acc[r];
+            float* dst = g.C + (size_t)col * g.ldc + row;
+            if (g.beta != 0.f) v += g.beta * *dst;
+            *dst = v;
+            if (g.mirror && offdiag) g.C[(size_t)row * g.ldc + col] = v;
+        }
+    }
+}
+
 template <int LOWER>
 __global__ void __launch_bounds__(SK_THREADS, 2)
 gemm_nt_mfma_kernel(GemmNT g) {
     __shared__ __attribute__((aligned(16))) float lds[2][2][SK_BK][SK_BM];      // [buffer][A/B][k][i]
+    if (LOWER && g.nq > 0 && (int)blockIdx.x >= g.grid_full) {                   // the quarter items of the tail, one XCD range each as below
+        const int b = (int)blockIdx.x - g.grid_full;
+        const int perq = (g.nq + 7) / 8;
+        const int q = (b % 8) * perq + b / 8;
+        if (q >= g.nq) return;
+        const int m = g.qmap[q];
+        gemm_nt_quarter(g, lds, m >> 16, m & 0xffff);
+        return;
+    }
     // XCD-aware remap: block b runs on XCD b % 8; give every XCD a contiguous range of tiles
     const int nwork = g.ntiles * g.ksplit;
     const int per = (nwork + 7) / 8;
@@ -90,48 +173,65 @@ gemm_nt_mfma_kernel(GemmNT g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    float4 ra0, ra1, rb0, rb1;
-    auto gload = [&](int k0) {
-        ra0 = *reinterpret_cast<const float4*>(gA + (size_t)k0 * g.lda);
-        ra1 = *reinterpret_cast<const float4*>(gA + (size_t)k0 * g.lda + a8);
-        rb0 = *reinterpret_cast<const float4*>(gB + (size_t)k0 * g.ldb);
-        rb1 = *reinterpret_cast<const float4*>(gB + (size_t)k0 * g.ldb + b8);
-    };
-    auto lstore = [&](int buf) {
-        *reinterpret_cast<float4*>(&lds[buf][0][s_row0][s_col]) = ra0;
-        *reinterpret_cast<float4*>(&lds[buf][0][s_row0 + 8][s_col]) = ra1;
-        *reinterpret_cast<float4*>(&lds[buf][1][s_row0][s_col]) = rb0;
-        *reinterpret_cast<float4*>(&lds[buf][1][s_row0 + 8][s_col]) = rb1;
-    };
-
+    // Global loads run one K tile ahead of the matrix cores: tile t travels through register set t & 1 and is written to the
+    // other LDS buffer before the barrier.  Round 4 measured the alternatives on the C2 Gram (one round of 1024 tiles, K = 10^5,
+    // 25.1-25.8 ms as is; the matrix pipe alone needs 21.7 ms at the 154.9 TF/s scripts/mfma_peak.hip sustains on the box):
+    // loads two tiles ahead 25.8; global -> LDS directly (global_load_lds_dwordx4, no staging registers, no ds_write pass)
+    // 27.2; the fragment reads of k step kk + 2 ahead of the instructions of step kk (sched_barrier) 25.5-25.9; LDS reads and
+    // matrix instructions alone, no loads / writes / barriers, 23.0; K = 12 500 costs the same per K tile as K = 10^5 (so the
+    // 51-fold over-fetch -- tiles of a square drifting apart in K -- is not what the time goes to).  None of them pays: kept as is.
+    // (named registers and macros: register arrays or structs handed to lambdas by reference end up in scratch memory)
+    float4 s0a0, s0a1, s0b0, s0b1, s1a0, s1a1, s1b0, s1b1;
     const int kchunk = g.K / g.ksplit;                                  // multiple of SK_BK (launcher)
     const int kbeg = g.kstart_row ? (max(I0, J0) / SK_BK) * SK_BK : split * kchunk;
     const int ntile_k = ((g.ksplit > 1 ? kbeg + kchunk : g.K) - kbeg) / SK_BK;
     const int fk = lane >> 5, fi = lane & 31;
-    if (ntile_k > 0) {
-        gload(kbeg);
-        lstore(0);
-        __syncthreads();
-        for (int kt = 0; kt < ntile_k; ++kt) {
-            const int buf = kt & 1;
-            if (kt + 1 < ntile_k) gload(kbeg + (kt + 1) * SK_BK);      // next tile in flight while this one computes
+#define SK_GLOAD(S, t)                                                                   \
+    {                                                                                    \
+        const size_t k0_ = (size_t)(kbeg + (t) * SK_BK);                                 \
+        S##a0 = *reinterpret_cast<const float4*>(gA + k0_ * g.lda);                      \
+        S##a1 = *reinterpret_cast<const float4*>(gA + k0_ * g.lda + a8);                 \
+        S##b0 = *reinterpret_cast<const float4*>(gB + k0_ * g.ldb);                      \
+        S##b1 = *reinterpret_cast<const float4*>(gB + k0_ * g.ldb + b8);                 \
+    }
+#define SK_LSTORE(S, buf)                                                                \
+    {                                                                                    \
+        *reinterpret_cast<float4*>(&lds[buf][0][s_row0][s_col]) = S##a0;                 \
+        *reinterpret_cast<float4*>(&lds[buf][0][s_row0 + 8][s_col]) = S##a1;            \
+        *reinterpret_cast<float4*>(&lds[buf][1][s_row0][s_col]) = S##b0;                 \
+        *reinterpret_cast<float4*>(&lds[buf][1][s_row0 + 8][s_col]) = S##b1;            \
+    }
+    auto compute = [&](int buf) {
 #pragma unroll
-            for (int kk = 0; kk < SK_BK; kk += 2) {
-                const float a0 = lds[buf][0][kk + fk][wi + fi];
-                const float a1 = lds[buf][0][kk + fk][wi + 32 + fi];
-                const float b0 = lds[buf][1][kk + fk][wj + fi];
-                const float b1 = lds[buf][1][kk + fk][wj + 32 + fi];
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-            }
+        for (int kk = 0; kk < SK_BK; kk += 2) {
+            const float a0 = lds[buf][0][kk + fk][wi + fi];
+            const float a1 = lds[buf][0][kk + fk][wi + 32 + fi];
+            const float b0 = lds[buf][1][kk + fk][wj + fi];
+            const float b1 = lds[buf][1][kk + fk][wj + 32 + fi];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    };
+    if (ntile_k > 0) {
+        SK_GLOAD(s0, 0)
+        SK_LSTORE(s0, 0)
+        __syncthreads();
+        for (int kt = 0; kt < ntile_k; kt += 2) {                       // two K tiles per trip: even tiles through s0 / buffer 0, odd ones through s1 / buffer 1
+            if (kt + 1 < ntile_k) SK_GLOAD(s1, kt + 1)                  // next tile in flight while this one computes
+            compute(0);
             if (kt + 1 < ntile_k) {
-                lstore(buf ^ 1);
+                SK_LSTORE(s1, 1)
                 __syncthreads();
+                if (kt + 2 < ntile_k) SK_GLOAD(s0, kt + 2)
+                compute(1);
+                if (kt + 2 < ntile_k) { SK_LSTORE(s0, 0) __syncthreads(); }
             }
         }
     }
+#undef SK_GLOAD
+#undef SK_LSTORE
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     const bool offdiag = I0 != J0;
@@ -161,7 +261,7 @@ gemm_nt_mfma_kernel(GemmNT g) {
 // consecutive tiles of one row stream 1 + 64 panels (the B panels feed one tile each).  Block b runs on XCD b % 8 and is
 // the (b / 8)-th work item of that XCD; super-blocks of 8 x 8 tiles (triangular on the diagonal) are dealt out to the
 // XCDs in turn.  Returns a device array of ntiles entries (bi << 16 | bj) indexed like w_idx in the kernel.
-static DevBuf<int> make_square_tilemap(int nb, hipStream_t st) {
+static std::vector<std::vector<int>> square_tile_lists(int nb) {
     const int ntiles = nb * (nb + 1) / 2;
     const int per = (ntiles + 7) / 8;
     std::vector<std::vector<int>> q(8);
@@ -181,30 +281,73 @@ static DevBuf<int> make_square_tilemap(int nb, hipStream_t st) {
     std::vector<int> flat;
     for (int x = 0; x < 8; ++x) while ((int)q[x].size() > per) { flat.push_back(q[x].back()); q[x].pop_back(); }
     for (int x = 0; x < 8; ++x) while ((int)q[x].size() < per && !flat.empty()) { q[x].push_back(flat.back()); flat.pop_back(); }
-    std::vector<int> order;
-    order.reserve(ntiles);
-    // The kernel gives XCD x the work items [x * per, (x + 1) * per) of tilemap: lay the 8 lists out back to back (a
-    // permutation of all tiles; where a list is a little shorter than `per` a few tiles slide to the neighbouring XCD).
-    for (int x = 0; x < 8; ++x) for (int v : q[x]) order.push_back(v);
-    DevBuf<int> d(order.size());
-    ADMM_HIP_CHECK(hipMemcpyAsync(d.get(), order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    return q;
+}
+
+static DevBuf<int> upload_ints(const std::vector<int>& v, hipStream_t st) {
+    DevBuf<int> d(std::max<size_t>(v.size(), 1));
+    if (!v.empty()) ADMM_HIP_CHECK(hipMemcpyAsync(d.get(), v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice, st));
     ADMM_HIP_CHECK(hipStreamSynchronize(st));
     return d;
 }
 
+static DevBuf<int> make_square_tilemap(int nb, hipStream_t st) {
+    // The kernel gives XCD x the work items [x * per, (x + 1) * per) of tilemap: lay the 8 lists out back to back (a
+    // permutation of all tiles; where a list is a little shorter than `per` a few tiles slide to the neighbouring XCD).
+    std::vector<int> order;
+    for (const auto& l : square_tile_lists(nb)) for (int v : l) order.push_back(v);
+    return upload_ints(order, st);
+}
+
+// Work lists of a deep-K lower-triangle launch (the Gram) that ends without a straggling round.  All tiles cost the same and
+// `slots` workgroups are resident at a time (4 per CU: 128 VGPRs, 32 KB of LDS), so T tiles take ceil(T / slots) rounds: at C2 (p = 10^4:
+// 3160 tiles, 1024 slots) the fourth round runs 88 tiles on 1024 slots -- 3.09 rounds of work in the time of 4 (84 ms where 3.09
+// rounds of 21.3 ms are 66), and 79 of those tiles are the ragged
+// last block row (16 of their 128 rows are real).  Here: whole rounds of full tiles, and the remainder -- the ragged block row when
+// at most 64 of its rows are real, plus the tiles of a last round that would be less than `tail_max` full -- cut into QUARTER items
+// (64 x 64, one workgroup each: same values bit for bit, gemm_nt_quarter), dispatched after the full tiles: one short round in
+// which every CU holds at most a workgroup or two.  `full`: the tile lists of the 8 XCDs back to back; `quarters`: qi << 16 | qj.
+static void gram_work_lists(int M, int slots, double tail_max, std::vector<int>& full, std::vector<int>& quarters) {
+    const int nb = (M + SK_BM - 1) / SK_BM;
+    const int ragged = M - (nb - 1) * SK_BM;                           // real rows of the last block row (1 .. 128)
+    const int nbf = (ragged <= 64 && nb > 1) ? nb - 1 : nb;            // block rows done as full tiles
+    full.clear(); quarters.clear();
+    std::vector<std::vector<int>> q = square_tile_lists(nbf);
+    size_t total = 0;
+    for (const auto& l : q) total += l.size();
+    const size_t rem = total % (size_t)slots;
+    size_t cut = (total > (size_t)slots && (double)rem < tail_max * slots) ? rem : 0;
+    // even the lists out first (lengths differ by at most one afterwards), then take the cut from the back of the longest lists
+    auto longest = [&]() { int x = 0; for (int k = 1; k < 8; ++k) if (q[k].size() > q[x].size()) x = k; return x; };
+    auto shortest = [&]() { int x = 0; for (int k = 1; k < 8; ++k) if (q[k].size() < q[x].size()) x = k; return x; };
+    while (q[longest()].size() > q[shortest()].size() + 1) { const int a = longest(), b = shortest(); q[b].push_back(q[a].back()); q[a].pop_back(); }
+    for (; cut > 0; --cut) {
+        const int x = longest();
+        const int m = q[x].back(); q[x].pop_back();
+        const int bi = m >> 16, bj = m & 0xffff;
+        for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) if (2 * bi + a >= 2 * bj + b) quarters.push_back((2 * bi + a) << 16 | (2 * bj + b));
+    }
+    if (nbf < nb) for (int qj = 0; qj <= 2 * nbf; ++qj) quarters.push_back((2 * nbf) << 16 | qj);
+    // the kernel's XCD ranges are [x * per, (x + 1) * per) with per = ceil(count / 8): lists of equal length map onto them exactly;
+    // where they differ by one, a tile slides to the neighbouring XCD (harmless)
+    for (int x = 0; x < 8; ++x) for (int v : q[x]) full.push_back(v);
+}
+
 static void launch_gemm_nt(bool lower, const float* A, long long lda, const float* B, long long ldb, float* C, long long ldc,
                            int M, int N, int K, float alpha, float beta, bool mirror, bool kstart_row, hipStream_t st,
-                           int ksplit = 1, long long cstride = 0, const int* tilemap = nullptr, int ntiles_listed = -1) {
+                           int ksplit = 1, long long cstride = 0, const int* tilemap = nullptr, int ntiles_listed = -1,
+                           const int* qmap = nullptr, int nq = 0) {
     if (M <= 0 || N <= 0) return;
     GemmNT g;
-    g.ksplit = ksplit; g.cstride = cstride; g.tilemap = tilemap;
+    g.ksplit = ksplit; g.cstride = cstride; g.tilemap = tilemap; g.qmap = qmap; g.nq = lower ? nq : 0; g.grid_full = 0;
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
     g.alpha = alpha; g.beta = beta; g.mirror = mirror ? 1 : 0; g.kstart_row = kstart_row ? 1 : 0;
     g.nbi = (M + SK_BM - 1) / SK_BM; g.nbj = (N + SK_BM - 1) / SK_BM;
     g.ntiles = lower ? g.nbi * (g.nbi + 1) / 2 : g.nbi * g.nbj;
     if (tilemap != nullptr && ntiles_listed >= 0) g.ntiles = ntiles_listed;     // only the listed tiles (the distributed inverse: this rank's share)
-    if (g.ntiles <= 0) return;
-    const int grid = (g.ntiles * ksplit + 7) / 8 * 8;
+    if (g.ntiles <= 0 && g.nq <= 0) return;
+    g.grid_full = (g.ntiles * ksplit + 7) / 8 * 8;
+    const int grid = g.grid_full + (g.nq + 7) / 8 * 8;
     if (lower) hipLaunchKernelGGL(gemm_nt_mfma_kernel<1>, dim3(grid), dim3(SK_THREADS), 0, st, g);
     else hipLaunchKernelGGL(gemm_nt_mfma_kernel<0>, dim3(grid), dim3(SK_THREADS), 0, st, g);
 }
@@ -254,11 +397,27 @@ void gram_mfma_f32(const float* A, long long lda, int rows, int cols, bool atA, 
     if (atA) transpose<float>(A, lda, rows, cols, Z.get(), ldz, st);
     else hipLaunchKernelGGL(pad_copy_f32_kernel, dim3((rows + 255) / 256, cols), dim3(256), 0, st, A, lda, rows, cols, Z.get(), ldz);
     if (ksplit == 1) {
-        // ADMM_HIP_GRAM_ORDER=row: the plain row-major triangle order (A/B measurement)
+        // ADMM_HIP_GRAM_ORDER=row: the plain row-major triangle order; ADMM_HIP_GRAM_TAIL=0: no quarter items (A/B measurements)
         const char* eo = std::getenv("ADMM_HIP_GRAM_ORDER");
-        DevBuf<int> tmap;
-        if (!(eo && std::string(eo) == "row")) tmap = make_square_tilemap(nb, st);
-        launch_gemm_nt(true, Z.get(), ldz, Z.get(), ldz, C, ldc, M, M, nk, 1.f, 0.f, true, false, st, 1, 0, tmap.get());
+        const char* et = std::getenv("ADMM_HIP_GRAM_TAIL");
+        if (eo && std::string(eo) == "row") {
+            launch_gemm_nt(true, Z.get(), ldz, Z.get(), ldz, C, ldc, M, M, nk, 1.f, 0.f, true, false, st);
+        } else if (et && std::string(et) == "0") {
+            DevBuf<int> tmap = make_square_tilemap(nb, st);
+            launch_gemm_nt(true, Z.get(), ldz, Z.get(), ldz, C, ldc, M, M, nk, 1.f, 0.f, true, false, st, 1, 0, tmap.get());
+            ADMM_HIP_CHECK(hipStreamSynchronize(st));
+        } else {
+            std::vector<int> full, quarters;
+            int wg_per_cu = 2;                               // resident workgroups per CU (registers / LDS: 4 as compiled today)
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu, gemm_nt_mfma_kernel<1>, SK_THREADS, 0) != hipSuccess || wg_per_cu < 1) wg_per_cu = 2;
+            gram_work_lists(M, wg_per_cu * device_info().num_cu, et ? std::atof(et) : 0.55, full, quarters);
+            if (std::getenv("ADMM_HIP_GRAM_DEBUG")) std::fprintf(stderr, "[gram] M %d wg/cu %d full %zu quarters %zu\n", M, wg_per_cu, full.size(), quarters.size());
+            DevBuf<int> tmap = upload_ints(full, st), qmap = upload_ints(quarters, st);
+            launch_gemm_nt(true, Z.get(), ldz, Z.get(), ldz, C, ldc, M, M, nk, 1.f, 0.f, true, false, st, 1, 0, tmap.get(), (int)full.size(),
+                           qmap.get(), (int)quarters.size());
+            ADMM_HIP_CHECK(hipStreamSynchronize(st));
+        }
+        ADMM_HIP_CHECK(hipGetLastError());
         ADMM_HIP_CHECK(hipStreamSynchronize(st));      // Z and the tile map are freed on return
         return;
     }

@@ -5,7 +5,7 @@ sys.path.insert(0, ROOT)
 import torch
 from admm_amd import admm_lasso, DevicePtr, LassoPlan
 dev = torch.device("cuda", 0)
-n, p = 100000, 10000
+n, p = int(os.environ.get("GRAM_AB_N", 100000)), int(os.environ.get("GRAM_AB_P", 10000))
 g = torch.Generator(device=dev); g.manual_seed(123)
 xt = torch.empty((p, n), dtype=torch.float64, device=dev)
 for c0 in range(0, p, 1000):

@@ -44,6 +44,28 @@ def test_gram_vs_numpy(rows, cols, atA, dtype):
     assert np.abs(G - ref).max() / np.abs(ref).max() < tol
 
 
+@pytest.mark.parametrize("rows,cols", [(300, 4136), (200, 5700), (200, 5800)])
+def test_gram_tail_of_quarter_tiles_is_bit_identical(rows, cols, monkeypatch):
+    """Deep-K Gram launches end with QUARTER work items instead of a straggling round of full tiles (syrk_mfma.hip,
+    gram_work_lists / gemm_nt_quarter): the ragged last block row when at most 64 of its rows are real (4136 = 32 x 128 + 40;
+    5800 = 45 x 128 + 40) and the tiles of a last round that would be mostly empty (5700: 45 block rows = 1035 tiles on 1024
+    resident workgroups -> 11 tiles as 41 quarters).  A quarter item accumulates every element in the same K order with the same
+    instruction as the full tile, so the matrix must be bit-identical to the launch without them (ADMM_HIP_GRAM_TAIL=0) and to
+    the row-major tile order."""
+    rng = np.random.default_rng(cols)
+    A = (rng.standard_normal((rows, cols)) * 2 + 0.3).astype(np.float32)
+    G = _gram(A, True)
+    monkeypatch.setenv("ADMM_HIP_GRAM_TAIL", "0")
+    G0 = _gram(A, True)
+    monkeypatch.delenv("ADMM_HIP_GRAM_TAIL")
+    monkeypatch.setenv("ADMM_HIP_GRAM_ORDER", "row")
+    G1 = _gram(A, True)
+    assert np.array_equal(G, G0) and np.array_equal(G, G1) and np.array_equal(G, G.T)
+    A64 = A.astype(np.float64)
+    ref = A64.T @ A64
+    assert np.abs(G - ref).max() / np.abs(ref).max() < 2e-5
+
+
 @pytest.mark.parametrize("n", [256, 300, 1100, 2048, 2300])
 @pytest.mark.parametrize("precision", [0, 1, 2])
 def test_spd_inverse_vs_numpy(n, precision):
