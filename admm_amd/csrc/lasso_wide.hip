@@ -463,27 +463,35 @@ wide_x_kernel(WideParams q, int par) {
             const float xj = u == 0 ? xs[0] : (u == 1 ? xs[1] : (u == 2 ? xs[2] : (u == 3 ? xs[3] : (u == 4 ? xs[4] : (u == 5 ? xs[5] : (u == 6 ? xs[6] : xs[7]))))));
             unsigned long long mask = reg ? __ballot(jl < q.p) : __ballot(xj != 0.f);
             if constexpr (kPair) {
-                // regular step, fused mode: two columns requested before the first is consumed (16 KB in flight per wave;
-                // same order of columns: bit-identical partial sums)
-                while (reg && mask) {
-                    const int l0 = __ffsll((long long)mask) - 1;
-                    mask &= mask - 1;
-                    const long long j0 = (long long)(s0 + l0) * NW + w;
+                // regular step, fused mode: two columns in flight per wave AT ALL TIMES -- the column after next is requested into
+                // the registers a column has just left (round 3 requested a pair, consumed the pair, requested the next pair: the
+                // wave's memory pipe ran empty once per pair).  Same order of columns: bit-identical partial sums.
+                if (reg && mask) {
                     float4 c0[NRT], c1[NRT];
+                    auto next_col = [&](int& l, long long& j) {
+                        l = -1; j = 0;
+                        if (mask) { l = __ffsll((long long)mask) - 1; mask &= mask - 1; j = (long long)(s0 + l) * NW + w; }
+                    };
+                    int l0, l1;
+                    long long j0, j1;
+                    next_col(l0, j0);
                     col_request(j0, c0, q.x_nt != 0);
-                    int l1 = -1;
-                    long long j1 = 0;
-                    if (mask) {
-                        l1 = __ffsll((long long)mask) - 1;
-                        mask &= mask - 1;
-                        j1 = (long long)(s0 + l1) * NW + w;
-                        col_request(j1, c1, q.x_nt != 0);
-                    }
-                    const float xn0 = col_finish(__shfl(xj, l0, 64), c0);
-                    if (lane == l0) q.x[j0] = xn0;
-                    if (l1 >= 0) {
+                    next_col(l1, j1);
+                    if (l1 >= 0) col_request(j1, c1, q.x_nt != 0);
+                    for (;;) {
+                        const float xn0 = col_finish(__shfl(xj, l0, 64), c0);
+                        if (lane == l0) q.x[j0] = xn0;
+                        int l2, l3;
+                        long long j2, j3;
+                        next_col(l2, j2);
+                        if (l2 >= 0) col_request(j2, c0, q.x_nt != 0);
+                        if (l1 < 0) break;
                         const float xn1 = col_finish(__shfl(xj, l1, 64), c1);
                         if (lane == l1) q.x[j1] = xn1;
+                        next_col(l3, j3);
+                        if (l3 >= 0) col_request(j3, c1, q.x_nt != 0);
+                        if (l2 < 0) break;
+                        l0 = l2; j0 = j2; l1 = l3; j1 = j3;
                     }
                 }
             }

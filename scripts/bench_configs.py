@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Measure the non-headline BASELINE.json configs (C3 wide, C4 consensus on one GPU, C5 LAD / BP) on
 device-resident synthetic data: iterations, loop seconds, iterations/s and achieved algorithmic GB/s
-(SURVEY.md section 8d byte counts).  Prints one JSON line per config.  Usage: bench_configs.py [c3 c4 c5lad c5bp c5parbp]"""
+(SURVEY.md section 8d byte counts).  Prints one JSON line per config.  Usage: bench_configs.py [c3 c4 c5lad c5bp c5parbp dantzig]"""
 import json
 import os
 import sys
@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402  (before libadmm_hip)
 import numpy as np  # noqa: E402
-from admm_amd import DevicePtr, admm_bp, admm_lad, admm_lasso  # noqa: E402
+from admm_amd import DevicePtr, admm_bp, admm_dantzig, admm_lad, admm_lasso  # noqa: E402
 
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev)
@@ -99,3 +99,11 @@ if "c5parbp" in which:  # the same problem by the column-block sharing solver (a
         report(f"C5 admm_bp$parallel({nb}) n=5000 p=50000 fp64 (sharing ADMM)", fit, 8.0 * n * p * reg / max(it, 1),
                {"recovery_error_range": [float(err.min()), float(err.max())], "regular_iterations": reg, "nnz": int(np.count_nonzero(beta)),
                 "lanczos_steps": int(fit.stats["xupdate_samples"]), "rho": fit.stats["rho"]})
+if "dantzig" in which:  # Dantzig selector (admm_hip_dantzig, the reference's unbuilt TODO/ADMMDantzig.h), operator form: n = 50 000, p = 2000 fp64
+    n, p = 50000, 2000
+    xt, y, _ = gen(n, p, 2.0, 100)
+    fit = admm_dantzig(DevicePtr(xt.data_ptr()), DevicePtr(y.data_ptr()), n=n, p=p).penalty(nlambda=5, lambda_min_ratio=0.05).fit()
+    niter = [int(v) for v in fit.niter]
+    # algorithmic bytes: A = X'X is applied twice per iteration (to rhs and to x), each time as X v then X't on the two stored layouts: 4 x 8 n p
+    report("admm_dantzig n=50000 p=2000 fp64, 5 lambdas down to 0.05 lambda_max (operator form: 4 streaming products per iteration)", fit, 32.0 * n * p,
+           {"niter": niter, "maxit_plus_one_marks_no_convergence": 10001, "nnz_last_lambda": int(np.count_nonzero(fit.beta_dense[1:, -1]))})

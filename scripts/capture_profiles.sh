@@ -15,11 +15,11 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o c2 -- python benc
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o c2 -- python bench.py --steps 1 --warmup 0 --cpu-seconds 0 --consensus-seconds 0 --config-seconds 0 --nlambda 10 > $OUT/pmc_write.log 2>&1
 python scripts/rocpd_pmc.py $OUT/pmc_fetch/c2_results.db $OUT/pmc_write/c2_results.db $OUT/tall_c2_pmc_hbm_bytes.md
 python bench.py > $OUT/bench_default.log 2>&1
-grep '^{"metric"' $OUT/bench_default.log | tail -1 > $OUT/bench_c2.json
-python scripts/bench_configs.py c3 c4 c5lad c5bp c5parbp > $OUT/bench_configs.jsonl 2> $OUT/bench_configs.err
-for c in c3 c4 c5lad c5bp c5parbp; do
+grep '^{"metric"' $OUT/bench_default.log | tail -1 > $OUT/bench_all_configs.json
+python scripts/bench_configs.py c3 c4 c5lad c5bp c5parbp dantzig > $OUT/bench_configs.jsonl 2> $OUT/bench_configs.err
+for c in c3 c4 c5lad c5bp c5parbp dantzig; do
   rocprofv3 --kernel-trace --stats -d $OUT/trace_$c -o k -- python scripts/bench_configs.py $c > $OUT/trace_$c.log 2>&1
   python scripts/rocpd_summary.py $OUT/trace_$c/k_results.db $OUT/${c}_kernel_stats.md 12
 done
-rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/trace_c3 $OUT/trace_c4 $OUT/trace_c5lad $OUT/trace_c5bp $OUT/trace_c5parbp      # the databases are large; the summaries are what is kept
+rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/trace_c3 $OUT/trace_c4 $OUT/trace_c5lad $OUT/trace_c5bp $OUT/trace_c5parbp $OUT/trace_dantzig      # the databases are large; the summaries are what is kept
 ls -la $OUT
