@@ -182,6 +182,7 @@ struct PeerState {
 } g_peer;
 
 constexpr int kPushGroups = 4;                           // workgroups per destination rank
+constexpr int kSumGroups = 128;                          // most workgroups of a consuming launch (they all wait for the flags)
 
 struct PeerArgs : PeerExchange {
     const float* fsrc; size_t nf; const double* dsrc; size_t nd; size_t off_d;
@@ -217,7 +218,8 @@ __device__ __forceinline__ uint4 peer_load_unit(const PeerArgs& a, size_t u) {
 __global__ void __launch_bounds__(256) peer_push_kernel(PeerArgs a) {
     if (*reinterpret_cast<volatile int*>(a.err)) return;
     const int q = blockIdx.x / a.groups, g = blockIdx.x % a.groups;
-    unsigned long long* dst = reinterpret_cast<unsigned long long*>(peer_dst_slot(a, q));
+    // a broadcast uses the whole slot set of this parity as ONE slot (only the root writes: nranks x slot bytes per exchange)
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.bcast_root >= 0 ? a.remote[q] + (size_t)(a.seq & 1) * a.nranks * a.slot : peer_dst_slot(a, q));
     const size_t units = (a.bcast_root >= 0 && a.rank != a.bcast_root) ? 0 : a.off_d / 16 + (a.nd + 1) / 2;
     for (size_t u = (size_t)g * 256 + threadIdx.x; u < units; u += (size_t)a.groups * 256) {
         const uint4 v = peer_load_unit(a, u);
@@ -240,41 +242,45 @@ __global__ void __launch_bounds__(256) peer_push_kernel(PeerArgs a) {
 __global__ void __launch_bounds__(256) peer_sum_kernel(PeerArgs a) {
     if (!peer_wait(a)) return;
     const size_t uf = a.off_d / 16, units = uf + (a.nd + 1) / 2;
-    const size_t u = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (u >= units) return;
-    if (a.bcast_root >= 0) {                             // broadcast: the root's slot, copied out (the root keeps its own buffer)
-        if (a.rank == a.bcast_root || u >= uf) return;
-        const float4 s = reinterpret_cast<const float4*>(peer_src_slot(a, a.bcast_root))[u];
-        const size_t i = u * 4;
-        if (i + 4 <= a.nf) *reinterpret_cast<float4*>(a.fdst + i) = s;
-        else {
-            const float t[4] = {s.x, s.y, s.z, s.w};
-            for (int k = 0; k < 4; ++k) if (i + k < a.nf) a.fdst[i + k] = t[k];
+    // grid-stride: the launch is capped at kSumGroups workgroups (peer_exchange).  Every workgroup of this kernel spins until the
+    // flags are up, and with one workgroup per 4 KB of a 4 MB chunk the waiting waves of three rank processes on ONE GPU (the
+    // test set-up) filled the device -- the fourth rank's push kernel found no slot and the exchange timed out (round 4: 5 of 8
+    // four-rank runs).
+    for (size_t u = (size_t)blockIdx.x * 256 + threadIdx.x; u < units; u += (size_t)gridDim.x * 256) {
+        if (a.bcast_root >= 0) {                         // broadcast: the root's slot, copied out (the root keeps its own buffer)
+            if (a.rank == a.bcast_root || u >= uf) return;
+            const float4 s = reinterpret_cast<const float4*>(a.local + (size_t)(a.seq & 1) * a.nranks * a.slot)[u];
+            const size_t i = u * 4;
+            if (i + 4 <= a.nf) *reinterpret_cast<float4*>(a.fdst + i) = s;
+            else {
+                const float t[4] = {s.x, s.y, s.z, s.w};
+                for (int k = 0; k < 4; ++k) if (i + k < a.nf) a.fdst[i + k] = t[k];
+            }
+            continue;
         }
-        return;
-    }
-    const unsigned char* base = peer_src_slot(a, 0);
-    if (u < uf) {
-        float4 s = reinterpret_cast<const float4*>(base)[u];
-        for (int r = 1; r < a.nranks; ++r) {
-            const float4 v = reinterpret_cast<const float4*>(base + (size_t)r * a.slot)[u];
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        const unsigned char* base = peer_src_slot(a, 0);
+        if (u < uf) {
+            float4 s = reinterpret_cast<const float4*>(base)[u];
+            for (int r = 1; r < a.nranks; ++r) {
+                const float4 v = reinterpret_cast<const float4*>(base + (size_t)r * a.slot)[u];
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+            const size_t i = u * 4;
+            if (i + 4 <= a.nf) *reinterpret_cast<float4*>(a.fdst + i) = s;
+            else {
+                const float t[4] = {s.x, s.y, s.z, s.w};
+                for (int k = 0; k < 4; ++k) if (i + k < a.nf) a.fdst[i + k] = t[k];
+            }
+        } else {
+            double2 s = reinterpret_cast<const double2*>(base)[u];
+            for (int r = 1; r < a.nranks; ++r) {
+                const double2 v = reinterpret_cast<const double2*>(base + (size_t)r * a.slot)[u];
+                s.x += v.x; s.y += v.y;
+            }
+            const size_t i = (u - uf) * 2;
+            a.ddst[i] = s.x;
+            if (i + 1 < a.nd) a.ddst[i + 1] = s.y;
         }
-        const size_t i = u * 4;
-        if (i + 4 <= a.nf) *reinterpret_cast<float4*>(a.fdst + i) = s;
-        else {
-            const float t[4] = {s.x, s.y, s.z, s.w};
-            for (int k = 0; k < 4; ++k) if (i + k < a.nf) a.fdst[i + k] = t[k];
-        }
-    } else {
-        double2 s = reinterpret_cast<const double2*>(base)[u];
-        for (int r = 1; r < a.nranks; ++r) {
-            const double2 v = reinterpret_cast<const double2*>(base + (size_t)r * a.slot)[u];
-            s.x += v.x; s.y += v.y;
-        }
-        const size_t i = (u - uf) * 2;
-        a.ddst[i] = s.x;
-        if (i + 1 < a.nd) a.ddst[i + 1] = s.y;
     }
 }
 
@@ -295,12 +301,12 @@ void peer_exchange(float* fbuf, size_t nf, double* dbuf, size_t nd, hipStream_t 
     a.bcast_root = bcast_root;
     a.groups = bcast_root >= 0 ? 32 : kPushGroups;        // bulk payload: more workgroups per destination
     a.off_d = round_up_sz(nf * sizeof(float), 16);
-    ADMM_REQUIRE(a.off_d + round_up_sz(nd * sizeof(double), 16) <= g_slot, "exchange payload exceeds the slot size");
+    ADMM_REQUIRE(a.off_d + round_up_sz(nd * sizeof(double), 16) <= (bcast_root >= 0 ? g_slot * (size_t)g_info.nranks : g_slot), "exchange payload exceeds the slot size");
     ADMM_REQUIRE((reinterpret_cast<uintptr_t>(fbuf) & 15) == 0 && (reinterpret_cast<uintptr_t>(dbuf) & 15) == 0, "exchange buffers must be 16-byte aligned");
     a.fsrc = fbuf; a.nf = nf; a.dsrc = dbuf; a.nd = nd; a.fdst = fbuf; a.ddst = dbuf;
     const size_t units = a.off_d / 16 + (nd + 1) / 2;
     hipLaunchKernelGGL(peer_push_kernel, dim3(g_info.nranks * a.groups), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(peer_sum_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(peer_sum_kernel, dim3((unsigned)std::min<size_t>((units + 255) / 256, (size_t)kSumGroups)), dim3(256), 0, st, a);
 }
 
 void peer_close() {
@@ -397,7 +403,7 @@ void broadcast_f32(float* buf, size_t n, int root, hipStream_t st) {
     if (!g_info.active || n == 0 || g_info.nranks == 1) return;
     if (g_info.backend == COMM_RCCL) { ADMM_NCCL_CHECK(ncclBroadcast(buf, buf, n, ncclFloat, root, g_comm, st)); return; }
     if (g_info.backend == COMM_PEER) {
-        const size_t per = g_slot / sizeof(float);
+        const size_t per = g_slot * (size_t)g_info.nranks / sizeof(float);
         for (size_t o = 0; o < n; o += per) peer_exchange(buf + o, std::min(per, n - o), nullptr, 0, st, root);
         return;
     }

@@ -89,7 +89,7 @@ def test_two_process_row_sharded_tall_solver(backend, case):
     assert len(rep["loose"]) == 0
 
 
-@pytest.mark.parametrize("nranks,backend", [(2, "peer"), (4, "shm")])
+@pytest.mark.parametrize("nranks,backend", [(2, "peer"), (4, "shm"), (4, "peer")])
 def test_distributed_factorisation_is_bit_identical_to_the_replicated_one(nranks, backend):
     """SURVEY.md section 8f row n1, the multi-GPU half: in the row-sharded tall solver the blocked Cholesky + inverse runs with its
     128-column blocks dealt out to the ranks -- the owner factorises the diagonal block and the panel and broadcasts them, every
