@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     from admm_amd._lib import AdmmOpts, AdmmStats
     assert ctypes.sizeof(AdmmOpts) == 32            # int + pad, 3 doubles
-    assert ctypes.sizeof(AdmmStats) == 8 * 9 + 8 * 3 + 8 * 2 + 16 + 8   # 9 doubles, 3 long long, 2 doubles, 4 ints, 1 long long
+    assert ctypes.sizeof(AdmmStats) == 8 * 9 + 8 * 3 + 8 * 2 + 16 + 8 + 8   # 9 doubles, 3 long long, 2 doubles, 4 ints, 1 long long, factor_flops
 
 
 def test_host_lanczos_matches_oracle_including_restart():
