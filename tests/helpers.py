@@ -42,6 +42,8 @@ def synth_lasso(n, p, m, seed=123, sd=2.0):
 #       inverse / as an exact solve; the column statistics of DataStd, or X'y, accumulated in double instead of float), following
 #       the same decisions, have drifted from it by that lambda
 #       (e.g. maxit = 7 with rho five orders below the automatic value: z = (x + y/rho) - lambda/rho cancels 5 digits).
+#       The intercept row is held to the variants' largest ABSOLUTE drift along the path instead: its rounding noise (an ulp of a
+#       column mean in mean(y) - sum_j mean(x_j) beta_j) is additive, the same in every column whatever the column's own scale.
 #       The number of such columns is returned; tests bound and print it.
 # R4  (round 3) follow mode is only as strict as the decisions it hands over, so every traced test ASSERTS ceilings on them
 #     instead of printing them.  Measured over the passing cases of profiles/r03_soak_summary.md (11.1 M decisions):
@@ -318,15 +320,28 @@ def assert_tall_parity(beta, niter, trace, problem, tol=1e-4, factor=5.0, band=8
     errs_eff = [0.0 if errs[j] * scales[j] <= 2.0 * quanta[j] else errs[j] for j in range(nl)]
     if max(errs_eff) >= tol:                                                     # R3
         drift = np.zeros(nl)
+        drift0 = np.zeros(nl)                       # the intercept row's drift in ABSOLUTE terms
         for mode in ("inv32", "exact", "stats64", "xy64"):
             v, _, _ = oracle_following(trace, band=1e9, mode=mode, **problem)
             drift = np.maximum(drift, [col_err(v["beta"][:, j], ref["beta"][:, j], floor) for j in range(nl)])
+            drift0 = np.maximum(drift0, np.abs(v["beta"][0] - ref["beta"][0]))
         drift = np.maximum.accumulate(drift)        # along a warm-started path the drift of a lambda carries into the next ones
+        drift0 = np.maximum.accumulate(drift0)
         for j in range(nl):
             if errs_eff[j] >= tol:
                 yard = max(yard, float(drift[j]))
-                assert errs[j] <= factor * drift[j], (label, f"lambda {j}: error {errs[j]:.2e} on a common trajectory; the oracle's own "
-                                                             f"rounding variants differ by up to {drift[j]:.2e} by then")
+                ok = errs[j] <= factor * drift[j]
+                if not ok and problem.get("intercept"):
+                    # The recovered intercept mean(y) - sum_j mean(x_j) beta_j cancels on uncentred data, and its rounding noise --
+                    # an ulp of a column mean -- is ADDITIVE: the same absolute amount in every column of the path, whatever the
+                    # column's own scale (soak case 705:134, columns of scale 23.5 / 0.49 / 7.9: the variants' intercepts differ by
+                    # 6e-5, 1e-6, 7e-5; the GPU's by 7e-5, 1.2e-4, 6e-5 -- relative to the small middle column that is 2.3e-4).
+                    # Row 0 is therefore held to the variants' largest ABSOLUTE intercept drift so far, the slope rows to the
+                    # relative yardstick as before.
+                    e_slopes = col_err(beta[1:, j], ref["beta"][1:, j], floor, icpt_row=False)
+                    ok = (e_slopes < tol or e_slopes <= factor * drift[j]) and abs(beta[0, j] - ref["beta"][0, j]) <= factor * drift0[j]
+                assert ok, (label, f"lambda {j}: error {errs[j]:.2e} on a common trajectory; the oracle's own "
+                                   f"rounding variants differ by up to {drift[j]:.2e} by then (intercept: {drift0[j]:.2e} absolute)")
                 loose.append(j)
     fm = max([f["ulps"] for f in forced], default=0.0)
     first = forced[0]["lam"] if forced else None
