@@ -57,7 +57,7 @@ EXPORTS = ["admm_hip_lasso", "admm_hip_enet", "admm_hip_parlasso", "admm_hip_lad
            "admm_hip_lasso_plan_trace_enable", "admm_hip_lasso_plan_trace_read",
            "admm_hip_lasso_plan_state_enable", "admm_hip_lasso_plan_state_read", "admm_hip_lasso_plan_system_read",
            "admm_hip_host_lanczos", "admm_hip_test_symv",
-           "admm_hip_comm_peer_prepare", "admm_hip_comm_init_peer", "admm_hip_comm_init_shm", "admm_hip_comm_test_allreduce",
+           "admm_hip_comm_peer_prepare", "admm_hip_comm_init_peer", "admm_hip_comm_init_shm", "admm_hip_comm_test_allreduce", "admm_hip_comm_test_reduce_scatter",
            "admm_hip_lasso_dist", "admm_hip_test_gram", "admm_hip_test_spd_inverse", "admm_hip_test_cv_fold_system",
            "admm_hip_lasso_dist_cols", "admm_hip_test_gemv_t", "admm_hip_lad_traced", "admm_hip_bp_traced",
            "admm_hip_lasso_plan_create_dist_cols", "admm_hip_lasso_cv", "admm_hip_lasso_multi",
@@ -171,6 +171,8 @@ def load():
     lib.admm_hip_comm_init_shm.restype = ctypes.c_int
     lib.admm_hip_comm_test_allreduce.argtypes = [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int]
     lib.admm_hip_comm_test_allreduce.restype = ctypes.c_int
+    lib.admm_hip_comm_test_reduce_scatter.argtypes = [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p]
+    lib.admm_hip_comm_test_reduce_scatter.restype = ctypes.c_int
     lib.admm_hip_lasso_plan_trace_enable.argtypes = [ctypes.c_void_p, ctypes.c_longlong]
     lib.admm_hip_lasso_plan_trace_enable.restype = ctypes.c_int
     lib.admm_hip_lasso_plan_trace_read.argtypes = [ctypes.c_void_p, _c_double_p, ctypes.c_longlong, ctypes.POINTER(ctypes.c_longlong)]

@@ -795,6 +795,22 @@ int admm_hip_comm_test_allreduce(float* fbuf, long long nf, double* dbuf, long l
     });
 }
 
+int admm_hip_comm_test_reduce_scatter(const float* send, long long count, float* recv) {
+    return guarded([&] {
+        ADMM_REQUIRE(count > 0 && count % 4 == 0 && send && recv, "bad arguments (count must be a positive multiple of 4)");
+        require_device();
+        const CommInfo ci = comm_info();
+        const size_t nr = (size_t)(ci.active ? ci.nranks : 1);
+        Stream st;
+        DevBuf<float> ds(nr * (size_t)count), dr((size_t)count);
+        ADMM_HIP_CHECK(hipMemcpyAsync(ds.get(), send, nr * (size_t)count * sizeof(float), hipMemcpyHostToDevice, st.s));
+        reduce_scatter_sum_f32(ds.get(), dr.get(), (size_t)count, st.s);
+        ADMM_HIP_CHECK(hipMemcpyAsync(recv, dr.get(), (size_t)count * sizeof(float), hipMemcpyDeviceToHost, st.s));
+        st.sync();
+        comm_check();
+    });
+}
+
 int admm_hip_lasso_plan_run(admm_hip_plan* plan, double* lambda_out, float* beta_out, int* niter_out, admm_stats* stats) {
     return guarded([&] { run_plan(reinterpret_cast<PlanHandle*>(plan), lambda_out, beta_out, niter_out, stats, 0.0); });
 }

@@ -28,6 +28,10 @@ void allreduce_sum_f64(double* buf, size_t n, hipStream_t st);
 // only raise their flags (same parity protocol as the all-reduce).  SHM (tests): the other ranks clear their buffer and the ranks
 // sum -- x + 0 + ... + 0 is x bit for bit.
 void broadcast_f32(float* buf, size_t n, int root, hipStream_t st);
+// Sum reduce-scatter: `send` holds nranks chunks of `count` floats (chunk q is what rank q is to receive); `recv` (count floats) gets
+// the sum over the ranks of chunk [this rank].  RCCL: ncclReduceScatter.  PEER: chunk q goes into rank q's slots only.  SHM (tests):
+// all-reduce of a copy + own chunk.  No communicator: a copy.  (Setup only: the split-K Gram of the row-sharded tall solver.)
+void reduce_scatter_sum_f32(const float* send, float* recv, size_t count, hipStream_t st);
 // Two buffers in one exchange (the consensus payload: p floats + the norm doubles).
 void allreduce_sum_f32_f64(float* fbuf, size_t nf, double* dbuf, size_t nd, hipStream_t st);
 // While one of these is alive the exchanges this process enqueues take the short LOCK-STEP bound on their waits

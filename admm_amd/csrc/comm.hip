@@ -189,6 +189,7 @@ struct PeerArgs : PeerExchange {
     float* fdst; double* ddst;
     int bcast_root;                                      // >= 0: a broadcast -- only this rank's payload travels, the others only raise their flags
     int groups;                                          // workgroups per destination rank of the push
+    size_t rs_stride;                                    // > 0: a reduce-scatter -- destination q receives the floats fsrc[q * rs_stride ...]
 };
 
 // All payload traffic is in 16-byte units per lane, 1 KiB per wave instruction (with an uncached buffer 4-byte accesses
@@ -221,8 +222,10 @@ __global__ void __launch_bounds__(256) peer_push_kernel(PeerArgs a) {
     // a broadcast uses the whole slot set of this parity as ONE slot (only the root writes: nranks x slot bytes per exchange)
     unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.bcast_root >= 0 ? a.remote[q] + (size_t)(a.seq & 1) * a.nranks * a.slot : peer_dst_slot(a, q));
     const size_t units = (a.bcast_root >= 0 && a.rank != a.bcast_root) ? 0 : a.off_d / 16 + (a.nd + 1) / 2;
+    PeerArgs src = a;
+    src.fsrc = a.fsrc + (size_t)q * a.rs_stride;         // reduce-scatter: rank q gets its own chunk of the send buffer
     for (size_t u = (size_t)g * 256 + threadIdx.x; u < units; u += (size_t)a.groups * 256) {
-        const uint4 v = peer_load_unit(a, u);
+        const uint4 v = peer_load_unit(src, u);
         peer_store_u64(dst + 2 * u, (unsigned long long)v.x | ((unsigned long long)v.y << 32));       // write-through, no fence needed
         peer_store_u64(dst + 2 * u + 1, (unsigned long long)v.z | ((unsigned long long)v.w << 32));
     }
@@ -295,15 +298,17 @@ void peer_fill(PeerExchange& a) {
 // their flags without payload and the root waits for them in its consuming launch -- so the slot parity protocol holds
 // unchanged: the root cannot overwrite slot set s & 1 with chunk s + 2 before every rank has copied chunk s out (it waits for
 // their flags of s + 1, raised in stream order after that copy).
-void peer_exchange(float* fbuf, size_t nf, double* dbuf, size_t nd, hipStream_t st, int bcast_root = -1) {
+void peer_exchange(float* fbuf, size_t nf, double* dbuf, size_t nd, hipStream_t st, int bcast_root = -1, const float* rs_send = nullptr, size_t rs_stride = 0) {
     PeerArgs a;
     peer_fill(a);
     a.bcast_root = bcast_root;
+    a.rs_stride = rs_stride;
     a.groups = bcast_root >= 0 ? 32 : kPushGroups;        // bulk payload: more workgroups per destination
     a.off_d = round_up_sz(nf * sizeof(float), 16);
     ADMM_REQUIRE(a.off_d + round_up_sz(nd * sizeof(double), 16) <= (bcast_root >= 0 ? g_slot * (size_t)g_info.nranks : g_slot), "exchange payload exceeds the slot size");
     ADMM_REQUIRE((reinterpret_cast<uintptr_t>(fbuf) & 15) == 0 && (reinterpret_cast<uintptr_t>(dbuf) & 15) == 0, "exchange buffers must be 16-byte aligned");
-    a.fsrc = fbuf; a.nf = nf; a.dsrc = dbuf; a.nd = nd; a.fdst = fbuf; a.ddst = dbuf;
+    a.fsrc = rs_send ? rs_send : fbuf; a.nf = nf; a.dsrc = dbuf; a.nd = nd; a.fdst = fbuf; a.ddst = dbuf;
+    ADMM_REQUIRE((reinterpret_cast<uintptr_t>(a.fsrc) & 15) == 0 && (rs_stride % 4) == 0, "reduce-scatter chunks must be 16-byte aligned");
     const size_t units = a.off_d / 16 + (nd + 1) / 2;
     hipLaunchKernelGGL(peer_push_kernel, dim3(g_info.nranks * a.groups), dim3(256), 0, st, a);
     hipLaunchKernelGGL(peer_sum_kernel, dim3((unsigned)std::min<size_t>((units + 255) / 256, (size_t)kSumGroups)), dim3(256), 0, st, a);
@@ -409,6 +414,27 @@ void broadcast_f32(float* buf, size_t n, int root, hipStream_t st) {
     }
     if (g_info.rank != root) ADMM_HIP_CHECK(hipMemsetAsync(buf, 0, n * sizeof(float), st));      // SHM (tests): x + 0 + ... + 0 is x bit for bit
     allreduce_sum_f32(buf, n, st);
+}
+void reduce_scatter_sum_f32(const float* send, float* recv, size_t count, hipStream_t st) {
+    if (count == 0) return;
+    if (!g_info.active || g_info.nranks == 1) {
+        ADMM_HIP_CHECK(hipMemcpyAsync(recv, send, count * sizeof(float), hipMemcpyDeviceToDevice, st));
+        return;
+    }
+    if (g_info.backend == COMM_RCCL) { ADMM_NCCL_CHECK(ncclReduceScatter(send, recv, count, ncclFloat, ncclSum, g_comm, st)); return; }
+    if (g_info.backend == COMM_PEER) {
+        // every rank pushes chunk q of its send buffer into rank q's slot and sums the nranks slots it received, in rank order:
+        // (nranks - 1) / nranks of an all-reduce's traffic, 1 / nranks of its additions
+        const size_t per = g_slot / sizeof(float);
+        for (size_t o = 0; o < count; o += per) peer_exchange(recv + o, std::min(per, count - o), nullptr, 0, st, -1, send + o, count);
+        return;
+    }
+    // SHM (tests): an all-reduce of a copy of the whole send buffer, then this rank's chunk -- the same sums in the same order
+    DevBuf<float> tmp((size_t)g_info.nranks * count);
+    ADMM_HIP_CHECK(hipMemcpyAsync(tmp.get(), send, (size_t)g_info.nranks * count * sizeof(float), hipMemcpyDeviceToDevice, st));
+    allreduce_sum_f32(tmp.get(), (size_t)g_info.nranks * count, st);
+    ADMM_HIP_CHECK(hipMemcpyAsync(recv, tmp.get() + (size_t)g_info.rank * count, count * sizeof(float), hipMemcpyDeviceToDevice, st));
+    ADMM_HIP_CHECK(hipStreamSynchronize(st));             // tmp is freed on return
 }
 void allreduce_sum_f32_f64(float* fbuf, size_t nf, double* dbuf, size_t nd, hipStream_t st) {
     if (!g_info.active) return;

@@ -600,7 +600,8 @@ struct TallPlan final : LassoPlan {
             const bool have_gram = d.gram.get() && d.ldgram == ldp;
             const bool inv64_wanted = p < 4096 || (std::getenv("ADMM_HIP_INVERSE") && std::string(std::getenv("ADMM_HIP_INVERSE")) == "f64");
             const double mat = (double)ldp * (double)ldp * 4.0;
-            const double need = (have_gram ? 0.0 : mat) + (inv64_wanted ? 2.0 * mat : 0.5 * mat) + (std::getenv("ADMM_HIP_REFINE") ? mat : 0.0);
+            const double need = (have_gram ? 0.0 : mat) + (inv64_wanted ? 2.0 * mat : 0.5 * mat) + (std::getenv("ADMM_HIP_REFINE") ? mat : 0.0) +
+                                (shard && ci.nranks > 1 ? mat + mat / ci.nranks : 0.0);      // packed send / receive buffers of the Gram's reduce-scatter
             if (need > 0.97 * (double)free_b) {
                 char msg[320];
                 std::snprintf(msg, sizeof msg, "tall solver: the cached %d x %d inverse and its workspace need %.1f GB, the device has %.1f GB free; "
@@ -610,17 +611,21 @@ struct TallPlan final : LassoPlan {
         }
         // Gram (cross_prod_lower, ADMMLassoTall.h:191-192) -- both triangles
         double t0 = now_s();
-        if (d.gram.get() && d.ldgram == ldp) {            // computed under the host-to-device transfer (upload_standardize_gram_f32)
+        const bool gram_given = d.gram.get() && d.ldgram == ldp;
+        if (gram_given) {                                 // computed under the host-to-device transfer (upload_standardize_gram_f32)
             M = std::move(d.gram);
             S.t_gram = d.t_gram_tail;
         } else {
             M.alloc((size_t)ldp * ldp); M.zero(st);
-            gram_full<float>(d.X.get(), d.ldx, n, p, true, M.get(), ldp, st);
-            if (shard) allreduce_sum_f32(M.get(), (size_t)ldp * ldp, st);      // split-K over the ranks' row blocks
+            gram_full<float>(d.X.get(), d.ldx, n, p, true, M.get(), ldp, st);      // sharded: this rank's term of the split-K sum (reduced below)
             ADMM_HIP_CHECK(hipStreamSynchronize(st));
-            comm_check();
             S.t_gram = now_s() - t0;
         }
+        // Row-sharded solver: decided here because it chooses how the split-K Gram is reduced (below)
+        bool inv64 = p < 4096;
+        if (const char* e = std::getenv("ADMM_HIP_INVERSE")) inv64 = std::string(e) == "f64";
+        bool dist_factor = shard && ci.nranks > 1 && !inv64 && (p + 127) / 128 >= 2 * ci.nranks && p >= 256;
+        if (const char* e = std::getenv("ADMM_HIP_DIST_FACTOR")) dist_factor = dist_factor && std::string(e) != "0";
 
         // rho (ADMMLassoTall.h:194-202)
         rho = pb.opts.rho;
@@ -628,12 +633,57 @@ struct TallPlan final : LassoPlan {
         if (rho <= 0) {
             SymMatVec<float> op(M.get(), ldp, p, st);
             int nmatop = 0;
-            const float ev = lanczos_largest_f32([&](const float* v, float* w_) { op(v, w_); }, p, &nmatop);
+            // Row-sharded: M still holds this rank's term X_r'X_r of the Gram, and the product is (sum_r X_r'X_r) v = sum_r (X_r'X_r v):
+            // the local product, then ONE all-reduce of p floats per Lanczos step (3-5 steps) -- so the whole matrix never has to exist
+            // on any rank (round 3 all-reduced the p x p Gram first).  Identical sums in identical order on every rank: identical rho.
+            DevBuf<float> wsum;
+            if (shard && ci.nranks > 1) wsum.alloc(ldp);
+            const float ev = lanczos_largest_f32([&](const float* v, float* w_) {
+                op(v, w_);
+                if (shard && ci.nranks > 1) {
+                    ADMM_HIP_CHECK(hipMemcpyAsync(wsum.get(), w_, (size_t)p * sizeof(float), hipMemcpyHostToDevice, st));
+                    allreduce_sum_f32(wsum.get(), (size_t)p, st);
+                    ADMM_HIP_CHECK(hipMemcpyAsync(w_, wsum.get(), (size_t)p * sizeof(float), hipMemcpyDeviceToHost, st));
+                    ADMM_HIP_CHECK(hipStreamSynchronize(st));
+                    comm_check();
+                }
+            }, p, &nmatop);
             S.eig_est = ev;
             rho = std::pow((double)ev, 1.0 / 3) * std::pow(lam_int[0], 2.0 / 3);
         }
         S.rho = rho;
         S.t_eigs = now_s() - t0;
+
+        // Row-sharded: the split-K sum of the Gram over the ranks.  With the distributed factorisation a rank
+        // only ever reads the block columns it owns (k mod N == rank: chol_inverse.h), so the sum is a REDUCE-SCATTER: the block columns
+        // are packed owner by owner (a block column is 128 x ldp contiguous floats), every rank receives the sum of its own -- 1 / N of the
+        // matrix -- and unpacks it in place; the other block columns of M are dead from here on (the panels arrive by broadcast).
+        // Replicated factorisation (ADMM_HIP_DIST_FACTOR=0, double-built inverses, few blocks): the all-reduce of round 3.
+        if (shard && ci.nranks > 1 && !gram_given) {            // (a Gram that arrived with the data is a single-process set-up: never sharded)
+            const double tr0 = now_s();
+            if (dist_factor) {
+                const int nb128 = (p + 127) / 128, N = ci.nranks;
+                const int nown = (nb128 + N - 1) / N;                           // slots per rank (the last ones of some ranks stay zero)
+                const size_t blk = (size_t)128 * ldp, cnt = (size_t)nown * blk;
+                DevBuf<float> send((size_t)N * cnt), recv(cnt);
+                send.zero(st);
+                for (int k = 0; k < nb128; ++k) {
+                    const size_t cols = (size_t)std::min(128, (int)ldp - k * 128);
+                    ADMM_HIP_CHECK(hipMemcpyAsync(send.get() + ((size_t)(k % N) * nown + k / N) * blk, M.get() + (size_t)k * blk, cols * ldp * sizeof(float),
+                                                  hipMemcpyDeviceToDevice, st));
+                }
+                reduce_scatter_sum_f32(send.get(), recv.get(), cnt, st);
+                for (int k = ci.rank; k < nb128; k += N) {
+                    const size_t cols = (size_t)std::min(128, (int)ldp - k * 128);
+                    ADMM_HIP_CHECK(hipMemcpyAsync(M.get() + (size_t)k * blk, recv.get() + (size_t)(k / N) * blk, cols * ldp * sizeof(float), hipMemcpyDeviceToDevice, st));
+                }
+            } else {
+                allreduce_sum_f32(M.get(), (size_t)ldp * ldp, st);
+            }
+            ADMM_HIP_CHECK(hipStreamSynchronize(st));
+            comm_check();
+            S.t_gram += now_s() - tr0;
+        }
 
         // (X'X + rho I)^-1, cached for the whole path (rho never changes: ADMMLassoTall.h:97)
         // ADMM_HIP_INVERSE=f32: factorise and invert in float (the reference's LLT is a float factorisation, XX.diagonal() += rho in float).
@@ -654,13 +704,9 @@ struct TallPlan final : LassoPlan {
         t0 = now_s();
         // Policy: double below p = 4096 (a few ms there, and the float inverse is 30-100x less accurate: 1-3e-6 against
         // 3e-8 of the largest entry at cond ~ 30, tests/test_gpu_kernels.py), float above.
-        bool inv64 = p < 4096;
-        if (const char* e = std::getenv("ADMM_HIP_INVERSE")) inv64 = std::string(e) == "f64";
         // Row-sharded solver: the factorisation's block columns dealt out to the ranks, and of the inverse
         // only the tiles this rank's share of the x-update reads -- 1 / N of the 2 p^3 / 3 + p^3 / 3 flops per rank, bit-identical to the
         // replicated factorisation (chol_inverse.h).  ADMM_HIP_DIST_FACTOR=0: every rank factorises the whole matrix (round 3).
-        bool dist_factor = shard && ci.nranks > 1 && !inv64 && (p + 127) / 128 >= 2 * ci.nranks && p >= 256;
-        if (const char* e = std::getenv("ADMM_HIP_DIST_FACTOR")) dist_factor = dist_factor && std::string(e) != "0";
         if (inv64) {
             spd_inverse_f32_via_f64(M.get(), ldp, p, (double)(float)rho, st);
         } else if (dist_factor) {

@@ -129,6 +129,16 @@ def init_comm_backend_from_torch(backend, device=None, name=None):
     init_comm_peer(world, rank, allgather)
 
 
+def reduce_scatter_host(send, count):
+    """Sum reduce-scatter of a host float32 array of nranks * count entries through the attached backend (test hook): returns this
+    rank's chunk summed over the ranks."""
+    lib = _lib.load()
+    send = np.ascontiguousarray(send, dtype=np.float32)
+    recv = np.zeros(int(count), dtype=np.float32)
+    check(lib.admm_hip_comm_test_reduce_scatter(send.ctypes.data, int(count), recv.ctypes.data))
+    return recv
+
+
 def allreduce_host(fbuf=None, dbuf=None):
     """In-place sum all-reduce of host float32 / float64 arrays through the attached backend (test hook)."""
     lib = _lib.load()

@@ -323,6 +323,10 @@ ADMM_HIP_API int admm_hip_comm_init_shm(int nranks, int rank, const char* name, 
 /* Test hook: in-place sum all-reduce of a device (mem = ADMM_MEM_DEVICE) or host float / double pair through the
  * attached backend, synchronous.  nf / nd may be 0. */
 ADMM_HIP_API int admm_hip_comm_test_allreduce(float* fbuf, long long nf, double* dbuf, long long nd, int mem);
+/* Test hook: sum reduce-scatter of host floats through the attached backend -- `send` holds nranks chunks of `count` floats (chunk q
+ * is what rank q receives), `recv` (count floats) gets the sum over the ranks of this rank's chunk.  count: a positive multiple of 4.
+ * Without a communicator: a copy of chunk 0.  (The exchange of the row-sharded tall solver's split-K Gram) */
+ADMM_HIP_API int admm_hip_comm_test_reduce_scatter(const float* send, long long count, float* recv);
 ADMM_HIP_API int admm_hip_parlasso_dist(const double* x_local, const double* y_local, int n_local, long long n_total, int p, int mem,
                            const double* lambda_in, int nlambda_in, int nlambda_auto, double lmin_ratio,
                            int standardize, int intercept, int nthread, const admm_opts* opts,

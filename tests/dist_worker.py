@@ -99,6 +99,15 @@ def main():
         g = np.full(2500000, float(rank + 1 + rep), dtype=np.float32)     # 10 MB > one 4 MB slot
         adist.allreduce_host(g, None)
         assert np.all(g == sum(range(1, nranks + 1)) + nranks * rep), (rep, g[:3])
+    # ---- raw reduce-scatter (the split-K Gram of the row-sharded tall solver): chunk q of every rank's buffer summed at rank q,
+    # in rank order -- two sizes, the second one longer than a slot (chunked)
+    for cnt in (1000, 1500000):
+        snd = [np.random.default_rng(7000 + 10 * r + cnt % 7).standard_normal(nranks * cnt).astype(np.float32) for r in range(nranks)]
+        got = adist.reduce_scatter_host(snd[rank], cnt)
+        want = snd[0][rank * cnt:(rank + 1) * cnt].copy()
+        for r in range(1, nranks):
+            want += snd[r][rank * cnt:(rank + 1) * cnt]
+        assert np.array_equal(got, want), ("reduce-scatter differs from the rank-ordered sum", cnt, float(np.abs(got - want).max()))
     # ---- the distributed consensus solver on this rank's row slice
     x, y, K, kw = problem(case)
     n, p = x.shape

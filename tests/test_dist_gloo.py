@@ -567,3 +567,55 @@ def test_two_rank_distributed_factorisation_protocol_is_bit_identical_to_one_pro
     f0, f1 = int(r[0]["flops"][0]), int(r[1]["flops"][0])
     assert f0 + f1 == fl1 and max(f0, f1) < 0.6 * fl1, (f0, f1, fl1)
     assert nb == 10
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Split-K Gram of the row-sharded tall solver as a REDUCE-SCATTER (lasso_tall.hip): world_size-2 model.
+# Every rank forms the Gram of its row slice; the Lanczos products are sum_r (G_r v) with one all-reduce of p floats each (the
+# whole matrix never exists on a rank); the block columns are packed owner by owner (block k -> rank k mod N, slot k div N, zero
+# padded to equal counts) and reduce-scattered, so a rank receives exactly the block columns the distributed factorisation lets it
+# read.  Checked: the received block columns equal those of the all-reduced Gram bit for bit (two ranks: one addition per entry,
+# the same one), the distributed product equals the product with the summed matrix to float rounding.
+def _gram_rs_rank_main(rank, world, port, X, B, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n, p = X.shape
+    lo, hi = rank * (n // world), (n if rank == world - 1 else (rank + 1) * (n // world))
+    Xl = np.asarray(X[lo:hi], dtype=F)
+    G = (Xl.T @ Xl).astype(F)                                    # this rank's term of the split-K sum
+    v = np.random.default_rng(5).standard_normal(p).astype(F)
+    w = _allreduce((G @ v).astype(F))                            # one Lanczos product: local product, p floats all-reduced
+    nb = (p + B - 1) // B
+    pp = nb * B
+    Gp = np.zeros((pp, pp), dtype=F)
+    Gp[:p, :p] = G
+    nown = (nb + world - 1) // world
+    send = np.zeros((world, nown, B, pp), dtype=F)               # [owner][slot][column of the block][row]
+    for k in range(nb):
+        send[k % world, k // world] = Gp[:, k * B:(k + 1) * B].T
+    recv = torch.empty(nown * B * pp, dtype=torch.float32)
+    dist.reduce_scatter(recv, [torch.from_numpy(np.ascontiguousarray(send[r]).ravel()) for r in range(world)])
+    full = _allreduce(Gp.copy())
+    np.savez(out_path + f".{rank}.npz", recv=recv.numpy().reshape(nown, B, pp), full=full, w=w, nown=np.array([nown]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gram_reduce_scatter_hands_every_rank_its_block_columns(tmp_path):
+    rng = np.random.default_rng(321)
+    n, p, B = 160, 70, 16                                        # 5 block columns (the last one ragged): rank 0 owns 0, 2, 4; rank 1 owns 1, 3
+    X = rng.standard_normal((n, p)).astype(F)
+    out = str(tmp_path / "gramrs")
+    mp.spawn(_gram_rs_rank_main, args=(2, _free_port(), X, B, out), nprocs=2, join=True)
+    r = [np.load(out + f".{k}.npz") for k in range(2)]
+    nb = (p + B - 1) // B
+    assert np.array_equal(r[0]["full"], r[1]["full"])
+    for rank in range(2):
+        for k in range(rank, nb, 2):
+            assert np.array_equal(r[rank]["recv"][k // 2], r[rank]["full"][:, k * B:(k + 1) * B].T), (rank, k)
+    assert np.array_equal(r[0]["recv"][2], r[0]["full"][:, 4 * B:5 * B].T) and not r[1]["recv"][2].any()     # rank 1's third slot is padding
+    G = r[0]["full"][:p, :p].astype(np.float64)
+    v = np.random.default_rng(5).standard_normal(p)
+    assert np.array_equal(r[0]["w"], r[1]["w"])
+    assert np.abs(r[0]["w"] - G @ v.astype(F)).max() < 1e-4 * np.abs(G @ v).max()
