@@ -16,6 +16,8 @@ def run_child(script, timeout=600, expect_report=False):
     rt = B.sanitizer_runtime()
     if rt is None or not os.path.exists(B.LIB_SAN):
         pytest.skip("no sanitizer runtime / libadmm_hip_san.so not built (python -c 'from admm_amd import build; build.build_sanitized()')")
+    if not B._lib_is_current(B.LIB_SAN):           # linked from other sources than those beside it (__graft_entry__.build() keeps it current)
+        B.build_sanitized(verbose=False)
     env = dict(os.environ, LD_PRELOAD=rt, ADMM_HIP_LIB=B.LIB_SAN,
                ASAN_OPTIONS="detect_leaks=0:halt_on_error=1:abort_on_error=0:protect_shadow_gap=0:detect_odr_violation=0",
                UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
