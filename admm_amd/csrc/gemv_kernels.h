@@ -257,7 +257,12 @@ struct GemvT {
     void set_nt(bool nt) { pl.nt = nt; }                           // streaming policy from the solver's working set (gemv_plan.h)
     void init(const T* A_, long long lda_, int m_, int k_, int wg_per_cu = 4) {
         A = A_; lda = lda_; m = m_; k = k_;
-        pl = plan_gemv_t<T>(m, k, 1, 4, 0, wg_per_cu);
+        // fp64 matrices beyond the Infinity Cache (LAD / BP / Dantzig at the C5 shapes): row segments of ~2048 -- 16 KB of LDS per
+        // workgroup instead of 36 KB -- measured with scripts/gemv_sweep64.hip on one MI355X (2 GB, non-temporal loads):
+        // 50000 x 5000: 312 -> 291 us (6.41 -> 6.88 TB/s); 5000 x 50000: 301 -> 297 us; a plain streaming read of the same bytes: 322 us
+        // (with few columns -- Dantzig's 50000 x 2000 -- the extra partial rows cost more than the shorter segments gain: 1770 -> 1700 it/s)
+        const bool big64 = sizeof(T) == 8 && (size_t)m * (size_t)k * sizeof(T) > kGemvNtBytes && m > 4096 && k > 4096;
+        pl = plan_gemv_t<T>(m, k, 1, 4, big64 ? 2048 : 0, wg_per_cu);
         stride = round_up(k, 32);
         part.alloc((size_t)pl.nseg * stride);
     }
