@@ -262,6 +262,8 @@ struct GemvT {
         // 50000 x 5000: 312 -> 291 us (6.41 -> 6.88 TB/s); 5000 x 50000: 301 -> 297 us; a plain streaming read of the same bytes: 322 us
         // (with few columns -- Dantzig's 50000 x 2000 -- the extra partial rows cost more than the shorter segments gain: 1770 -> 1700 it/s)
         const bool big64 = sizeof(T) == 8 && (size_t)m * (size_t)k * sizeof(T) > kGemvNtBytes && m > 4096 && k > 4096;
+        // (fp32, the consensus solver's 500 MB blocks: segments of 4096 rows take a single 100000 x 1250 product from 83.3 to 77.6 us, but the
+        // batched launch of the eight workers' products does not gain: C4 782-790 against 801 it/s -- not applied)
         pl = plan_gemv_t<T>(m, k, 1, 4, big64 ? 2048 : 0, wg_per_cu);
         stride = round_up(k, 32);
         part.alloc((size_t)pl.nseg * stride);

@@ -29,14 +29,15 @@ double time_ms(F&& f, hipStream_t st, int reps) {
     return ms / reps;
 }
 
-template <int C>
-void run_variant(int m, int k, long long lda, const double* A, const double* v, double* out, int wg_per_cu, int max_seg, int nt, hipStream_t st) {
-    GemvTPlan pl = plan_gemv_t<double>(m, k, 1, C, max_seg, wg_per_cu);
+template <int C, typename T = double>
+void run_variant(int m, int k, long long lda, const T* A, const T* v, T* out, int wg_per_cu, int max_seg, int nt, hipStream_t st) {
+    GemvTPlan pl = plan_gemv_t<T>(m, k, 1, C, max_seg, wg_per_cu);
     if (nt >= 0) pl.nt = nt != 0;
     const long long stride = round_up(k, 32);
-    double ms = time_ms([&] { launch_gemv_t<double, 1, C>(pl, A, lda, m, k, v, nullptr, out, nullptr, stride, nullptr, st); }, st, 20);
+    double ms = time_ms([&] { launch_gemv_t<T, 1, C>(pl, A, lda, m, k, v, nullptr, out, nullptr, stride, nullptr, st); }, st, 20);
+    printf(sizeof(T) == 4 ? "f32 " : "f64 ");
     printf("m=%d k=%d C=%d wgpc=%d maxseg=%d nt=%d | nseg=%d seg=%d gpw=%d grid=%d lds=%zu : %.1f us  %.0f GB/s\n", m, k, C, wg_per_cu, max_seg, (int)pl.nt,
-           pl.nseg, pl.seg_len, pl.groups_per_wg, pl.grid, pl.lds_bytes, ms * 1e3, 8.0 * m * k / (ms * 1e-3) / 1e9);
+           pl.nseg, pl.seg_len, pl.groups_per_wg, pl.grid, pl.lds_bytes, ms * 1e3, (double)sizeof(T) * m * k / (ms * 1e-3) / 1e9);
 }
 
 int main() {
@@ -58,6 +59,18 @@ int main() {
         }
         run_variant<4>(m, k, lda, A.get(), v.get(), out.get(), 4, 0, 0, st);
         for (int seg : {1024, 2048, 8192, 16384}) run_variant<4>(m, k, lda, A.get(), v.get(), out.get(), 4, seg, -1, st);
+    }
+    // fp32, the consensus solver's blocks at BASELINE configs[3] (8 x 1250 rows of a 10^4 x 10^5 matrix): one 500 MB block, both layouts
+    const float* Af = reinterpret_cast<const float*>(A.get());
+    const float* vf = reinterpret_cast<const float*>(v.get());
+    float* of = reinterpret_cast<float*>(out.get());
+    for (int shape = 0; shape < 2; ++shape) {
+        const int m = shape == 0 ? 100000 : 1250, k = shape == 0 ? 1250 : 100000;
+        const long long lda = round_up(m, 32);
+        for (int seg : {0, 2048, 4096, 8192}) run_variant<4, float>(m, k, lda, Af, vf, of, 4, seg, 1, st);
+        run_variant<2, float>(m, k, lda, Af, vf, of, 4, 0, 1, st);
+        run_variant<8, float>(m, k, lda, Af, vf, of, 4, 0, 1, st);
+        run_variant<4, float>(m, k, lda, Af, vf, of, 8, 0, 1, st);
     }
     return 0;
 }
