@@ -12,6 +12,7 @@
 // restart candidates of the right-hand side, see lasso_tall.hip), X'y, Lanczos SYMVs, the wide solver's X't, PADMM / LAD / BP
 // products (on the stored transpose where the reference multiplies by the matrix itself).
 #pragma once
+#include <cstdlib>
 #include "admm_internal.h"
 #include "device_utils.h"
 #include "gemv_plan.h"
@@ -264,7 +265,9 @@ struct GemvT {
         const bool big64 = sizeof(T) == 8 && (size_t)m * (size_t)k * sizeof(T) > kGemvNtBytes && m > 4096 && k > 4096;
         // (fp32, the consensus solver's 500 MB blocks: segments of 4096 rows take a single 100000 x 1250 product from 83.3 to 77.6 us, but the
         // batched launch of the eight workers' products does not gain: C4 782-790 against 801 it/s -- not applied)
-        pl = plan_gemv_t<T>(m, k, 1, 4, big64 ? 2048 : 0, wg_per_cu);
+        int seg = big64 ? 2048 : 0;
+        if (const char* e = std::getenv("ADMM_HIP_GEMV_SEG64")) { if (sizeof(T) == 8) seg = std::atoi(e); }      // A/B knob: 0 = the LDS-budget segments
+        pl = plan_gemv_t<T>(m, k, 1, 4, seg, wg_per_cu);
         stride = round_up(k, 32);
         part.alloc((size_t)pl.nseg * stride);
     }

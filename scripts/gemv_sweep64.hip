@@ -60,6 +60,17 @@ int main() {
         run_variant<4>(m, k, lda, A.get(), v.get(), out.get(), 4, 0, 0, st);
         for (int seg : {1024, 2048, 8192, 16384}) run_variant<4>(m, k, lda, A.get(), v.get(), out.get(), 4, seg, -1, st);
     }
+    // the p x p inverse of LAD at C5 (200 MB) -- evicted between two uses by the 4 GB of the two big products: flush with a read first
+    for (int rep = 0; rep < 1; ++rep) {
+        const int m = 5000, k = 5000; const long long lda = 5024;
+        auto flush = [&] { hipLaunchKernelGGL(read_bw_kernel, dim3(4096), dim3(256), 0, st, (const double2*)(A.get() + (size_t)5024 * 5000), (size_t)100000000, o2.get()); };
+        const double fl = time_ms(flush, st, 10);
+        for (int nt : {0, 1}) for (int seg : {0, 1024, 512}) for (int wg : {4, 8}) {
+            GemvTPlan pl = plan_gemv_t<double>(m, k, 1, 4, seg, wg); pl.nt = nt != 0;
+            const double ms = time_ms([&] { flush(); launch_gemv_t<double, 1, 4>(pl, A.get(), lda, m, k, v.get(), nullptr, out.get(), nullptr, 5024, nullptr, st); }, st, 10) - fl;
+            printf("f64 inverse 5000x5000 after a 1.6 GB flush: nt=%d maxseg=%d wgpc=%d nseg=%d grid=%d : %.1f us %.0f GB/s\n", nt, seg, wg, pl.nseg, pl.grid, ms * 1e3, 8.0 * m * k / (ms * 1e-3) / 1e9);
+        }
+    }
     // fp32, the consensus solver's blocks at BASELINE configs[3] (8 x 1250 rows of a 10^4 x 10^5 matrix): one 500 MB block, both layouts
     const float* Af = reinterpret_cast<const float*>(A.get());
     const float* vf = reinterpret_cast<const float*>(v.get());
