@@ -26,6 +26,7 @@
 // iterations in batches and polls a sticky flag.  Measured (C5 shape n = 5000, p = 50 000, 8 blocks on one MI355X, 545
 // non-zeros at the end, 5754 iterations): regular iteration 308 + 5 + 11 + 11 us, active-set iteration 20 + 11 us, loop 0.36 s.
 #include "prep.h"
+#include "gemv_kernels.h"
 #include "solvers.h"
 #include "loop_driver.h"
 #include "comm.h"
@@ -503,37 +504,65 @@ static void tridiag_top(std::vector<double> d, std::vector<double> e, double* th
 // lambda_max(A_b'A_b) = lambda_max(A_b A_b') : Lanczos with full re-orthogonalisation on the n x n matrix A_b A_b' (fp64
 // matrix-core Gram), products on the device, the short recurrences on the host; run until the Ritz pair's residual bound
 // |beta_m s_m| is below 1e-14 of the value (the reference asks an R function that does not exist: PADMMBP.h:64-71).
+// Round 4: the Krylov basis stays on the DEVICE and so does the full re-orthogonalisation (two passes of c = V'w, w -= V c): round 3
+// kept the basis on the host and orthogonalised there in scalar loops -- ~150 steps per block at the C5 shape, 4.7e8 host flops per
+// block, 0.71 s of the solver's 1.09 s.  Per step the host now receives two numbers (alpha_j = v_j'A v_j, ||w||^2).
+__global__ void __launch_bounds__(256) sbp_lz_dots_kernel(const double* __restrict__ V, long long ldv, int n, const double* __restrict__ w, double* __restrict__ c) {
+    __shared__ double red[4];                                       // c[k] = V[:, k]'w, one workgroup per column k (k = gridDim.x - 1: w'w when V == nullptr there)
+    const double* col = V + (size_t)blockIdx.x * ldv;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += col[i] * w[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) c[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void __launch_bounds__(256) sbp_lz_update_kernel(const double* __restrict__ V, long long ldv, int n, int m, const double* __restrict__ c, double* __restrict__ w) {
+    const int i = blockIdx.x * 256 + threadIdx.x;                   // w[i] -= sum_k V[i, k] c[k], k ascending
+    if (i >= n) return;
+    double acc = 0.0;
+    for (int k = 0; k < m; ++k) acc += V[(size_t)k * ldv + i] * c[k];
+    w[i] -= acc;
+}
+__global__ void __launch_bounds__(256) sbp_lz_scale_kernel(const double* __restrict__ w, double inv, int n, double* __restrict__ vnext) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) vnext[i] = w[i] * inv;
+}
+
 static double sbp_sprad(const double* Ab, long long lda, int n, int pb, hipStream_t st, int* nsteps) {
     const long long ldg = round_up(n, 32);
     DevBuf<double> Gm((size_t)ldg * ldg);
     Gm.zero(st);
     gram_full<double>(Ab, lda, n, pb, false, Gm.get(), ldg, st);
-    SymMatVec<double> op(Gm.get(), ldg, n, st);
+    SymMatVec<double> op(Gm.get(), ldg, n, st);                     // (its plan and partial buffer; the products below stay on the device)
     const int mmax = std::min(n, 600);
-    std::vector<std::vector<double>> V;
-    std::vector<double> al, be;
-    std::vector<double> vj(n), w(n);
+    const long long ldv = ldg;
+    DevBuf<double> V((size_t)ldv * (mmax + 1)), w(ldg), c(mmax + 2);
+    V.zero(st); w.zero(st);
+    std::vector<double> al, be, v0(n);
     double nrm = 0;
-    for (int i = 0; i < n; ++i) { vj[i] = 1.0 + 0.5 * std::sin(0.7 * (i + 1)); nrm += vj[i] * vj[i]; }
+    for (int i = 0; i < n; ++i) { v0[i] = 1.0 + 0.5 * std::sin(0.7 * (i + 1)); nrm += v0[i] * v0[i]; }
     nrm = std::sqrt(nrm);
-    for (int i = 0; i < n; ++i) vj[i] /= nrm;
+    for (int i = 0; i < n; ++i) v0[i] /= nrm;
+    ADMM_HIP_CHECK(hipMemcpyAsync(V.get(), v0.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+    const dim3 rows((n + 255) / 256);
     double theta = 0;
     for (int j = 0; j < mmax; ++j) {
-        V.push_back(vj);
-        op(vj.data(), w.data());
-        double a = 0;
-        for (int i = 0; i < n; ++i) a += w[i] * vj[i];
+        const double* vj = V.get() + (size_t)j * ldv;
+        launch_gemv_t<double, 1, 4>(op.pl, Gm.get(), ldg, n, n, vj, nullptr, op.part.get(), nullptr, op.stride, nullptr, st);
+        hipLaunchKernelGGL((reduce_partials_kernel<double>), rows, dim3(256), 0, st, op.part.get(), op.stride, op.pl.nseg, n, w.get(), (const int*)nullptr);
+        // full re-orthogonalisation, twice; the first pass's coefficient of v_j is alpha_j = v_j'A v_j
+        hipLaunchKernelGGL(sbp_lz_dots_kernel, dim3(j + 1), dim3(256), 0, st, V.get(), ldv, n, w.get(), c.get());
+        double hc[2] = {0, 0};
+        ADMM_HIP_CHECK(hipMemcpyAsync(&hc[0], c.get() + j, sizeof(double), hipMemcpyDeviceToHost, st));
+        hipLaunchKernelGGL(sbp_lz_update_kernel, rows, dim3(256), 0, st, V.get(), ldv, n, j + 1, c.get(), w.get());
+        hipLaunchKernelGGL(sbp_lz_dots_kernel, dim3(j + 1), dim3(256), 0, st, V.get(), ldv, n, w.get(), c.get());
+        hipLaunchKernelGGL(sbp_lz_update_kernel, rows, dim3(256), 0, st, V.get(), ldv, n, j + 1, c.get(), w.get());
+        hipLaunchKernelGGL(sbp_lz_dots_kernel, dim3(1), dim3(256), 0, st, w.get(), ldv, n, w.get(), c.get() + mmax + 1);      // ||w||^2
+        ADMM_HIP_CHECK(hipMemcpyAsync(&hc[1], c.get() + mmax + 1, sizeof(double), hipMemcpyDeviceToHost, st));
+        ADMM_HIP_CHECK(hipStreamSynchronize(st));
+        const double a = hc[0], b = std::sqrt(hc[1]);
         al.push_back(a);
-        for (int pass = 0; pass < 2; ++pass)
-            for (size_t k = 0; k < V.size(); ++k) {
-                double dot = 0;
-                const double* vk = V[k].data();
-                for (int i = 0; i < n; ++i) dot += w[i] * vk[i];
-                for (int i = 0; i < n; ++i) w[i] -= dot * vk[i];
-            }
-        double b2 = 0;
-        for (int i = 0; i < n; ++i) b2 += w[i] * w[i];
-        const double b = std::sqrt(b2);
         *nsteps = j + 1;
         if (j + 1 >= 2 && ((j + 1) % 4 == 0 || j + 1 == mmax || b <= 1e-300)) {
             double last = 0;
@@ -550,8 +579,9 @@ static double sbp_sprad(const double* Ab, long long lda, int n, int pb, hipStrea
             break;
         }
         be.push_back(b);
-        for (int i = 0; i < n; ++i) vj[i] = w[i] / b;
+        hipLaunchKernelGGL(sbp_lz_scale_kernel, rows, dim3(256), 0, st, w.get(), 1.0 / b, n, V.get() + (size_t)(j + 1) * ldv);
     }
+    ADMM_HIP_CHECK(hipGetLastError());
     return theta;                                                   // n steps: exact up to rounding
 }
 
