@@ -162,10 +162,11 @@ static void run_plan(PlanHandle* h, double* lambda_out, float* beta_out, int* ni
     ADMM_REQUIRE(lambda_out && beta_out && niter_out, "output pointers must not be NULL");
     const double t0 = now_s();
     LassoResult res;
+    res.beta_dst = beta_out;
     h->plan->run(res);
     const int nl = (int)res.lambda.size();
     for (int i = 0; i < nl; ++i) { lambda_out[i] = res.lambda[i]; niter_out[i] = res.niter[i]; }
-    std::memcpy(beta_out, res.beta.data(), sizeof(float) * (size_t)(h->p + 1) * nl);
+    if (!res.beta_written) std::memcpy(beta_out, res.beta.data(), sizeof(float) * (size_t)(h->p + 1) * nl);
     res.stats.t_total = now_s() - t0 + t_extra;
     if (stats) *stats = res.stats;
 }

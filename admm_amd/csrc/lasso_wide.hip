@@ -1440,6 +1440,41 @@ wide_rows_persist_kernel(WideParams q, int cpar, WideRows ps) {
     }
 }
 
+// Result read-back (round 4): the coefficient snapshots are (p x nlambda) floats of mostly zeros -- 80 MB at BASELINE configs[2], whose
+// dense copy, dense host buffers and dense recovery loop (a division and a dependent float add per entry) cost 60 ms of a 0.32 s fit.
+// The non-zeros of every column are listed in ascending order on the device (count, then ordered ballot compaction), only the lists
+// cross PCIe, and the host scatters the recovered values into the caller's cleared buffer.
+__global__ void __launch_bounds__(256) wide_beta_count_kernel(const float* __restrict__ beta, int p, int* __restrict__ cnt) {
+    __shared__ int sh[4];
+    const float* col = beta + (size_t)blockIdx.x * p;
+    int c = 0;
+    for (int j = threadIdx.x; j < p; j += 256) c += col[j] != 0.f;
+    c = wave_sum(c);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) cnt[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+__global__ void __launch_bounds__(256) wide_beta_compact_kernel(const float* __restrict__ beta, int p, const long long* __restrict__ off,
+                                                                int* __restrict__ idx, float* __restrict__ val) {
+    __shared__ int sh[4];
+    const float* col = beta + (size_t)blockIdx.x * p;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    long long base = off[blockIdx.x];
+    for (int j0 = 0; j0 < p; j0 += 256) {
+        const int j = j0 + threadIdx.x;
+        const float v = j < p ? col[j] : 0.f;
+        const bool nz = v != 0.f;
+        const unsigned long long m = __ballot(nz);
+        __syncthreads();                                            // (the previous round's readers of sh are done)
+        if (lane == 0) sh[wid] = __popcll(m);
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wid; ++w) woff += sh[w];
+        if (nz) { const long long pos = base + woff + __popcll(m & ((1ull << lane) - 1ull)); idx[pos] = j; val[pos] = v; }
+        base += sh[0] + sh[1] + sh[2] + sh[3];
+    }
+}
+
 __global__ void wide_init_kernel(WideParams q, double rho, float lam0) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < q.p) q.x[i] = 0.f;
@@ -1773,18 +1808,51 @@ struct WidePlan final : LassoPlan {
 
         res.niter.assign(nlam, 0);
         ADMM_HIP_CHECK(hipMemcpy(res.niter.data(), niter.get(), nlam * sizeof(int), hipMemcpyDeviceToHost));
-        std::vector<float> hb((size_t)nlam * p);
-        ADMM_HIP_CHECK(hipMemcpy(hb.data(), beta.get(), hb.size() * sizeof(float), hipMemcpyDeviceToHost));
         const size_t pt1 = (size_t)p_total + 1;
-        res.beta.assign(pt1 * nlam, 0.f);
         std::vector<double> icpt(nlam, 0.0);                          // sum_j beta_j meanX_j over this rank's columns
         long long tot = 0;
+        if (!cshard && res.beta_dst != nullptr) {
+            // sparse read-back straight into the caller's buffer (kernels above)
+            DevBuf<int> dcnt(nlam);
+            hipLaunchKernelGGL(wide_beta_count_kernel, dim3(nlam), dim3(256), 0, st, beta.get(), p, dcnt.get());
+            std::vector<int> hcnt(nlam);
+            ADMM_HIP_CHECK(hipMemcpyAsync(hcnt.data(), dcnt.get(), (size_t)nlam * sizeof(int), hipMemcpyDeviceToHost, st));
+            ADMM_HIP_CHECK(hipStreamSynchronize(st));
+            std::vector<long long> hoff(nlam + 1, 0);
+            for (int l = 0; l < nlam; ++l) hoff[l + 1] = hoff[l] + hcnt[l];
+            const size_t tot_nz = (size_t)hoff[nlam];
+            DevBuf<long long> doff(nlam);
+            DevBuf<int> didx(std::max<size_t>(tot_nz, 1));
+            DevBuf<float> dval(std::max<size_t>(tot_nz, 1));
+            std::vector<int> hidx(tot_nz);
+            std::vector<float> hval(tot_nz);
+            ADMM_HIP_CHECK(hipMemcpyAsync(doff.get(), hoff.data(), (size_t)nlam * sizeof(long long), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(wide_beta_compact_kernel, dim3(nlam), dim3(256), 0, st, beta.get(), p, doff.get(), didx.get(), dval.get());
+            if (tot_nz) {
+                ADMM_HIP_CHECK(hipMemcpyAsync(hidx.data(), didx.get(), tot_nz * sizeof(int), hipMemcpyDeviceToHost, st));
+                ADMM_HIP_CHECK(hipMemcpyAsync(hval.data(), dval.get(), tot_nz * sizeof(float), hipMemcpyDeviceToHost, st));
+            }
+            std::memset(res.beta_dst, 0, pt1 * nlam * sizeof(float));     // (under the copies)
+            ADMM_HIP_CHECK(hipStreamSynchronize(st));
+            for (int l = 0; l < nlam; ++l) {
+                float b0 = 0.f;
+                recover_coef_sparse<float>(d, hidx.data() + hoff[l], hval.data() + hoff[l], hcnt[l], &b0, res.beta_dst + (size_t)l * pt1 + 1);
+                res.beta_dst[(size_t)l * pt1] = b0;
+                tot += res.niter[l];
+            }
+            res.beta_written = true;
+            res.beta.clear();
+        } else {
+        std::vector<float> hb((size_t)nlam * p);
+        ADMM_HIP_CHECK(hipMemcpy(hb.data(), beta.get(), hb.size() * sizeof(float), hipMemcpyDeviceToHost));
+        res.beta.assign(pt1 * nlam, 0.f);
         for (int l = 0; l < nlam; ++l) {
             float b0 = 0.f;
             recover_coef<float>(d, hb.data() + (size_t)l * p, &b0, res.beta.data() + (size_t)l * pt1 + 1 + col_offset);
             res.beta[(size_t)l * pt1] = b0;
             icpt[l] = (double)d.meanY - (double)b0;
             tot += res.niter[l];
+        }
         }
         if (cshard) {
             // every rank returns the full coefficient matrix: blocks summed into a zero-padded copy, the intercept

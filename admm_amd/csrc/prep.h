@@ -65,6 +65,10 @@ void standardize_response_f32(const double* y_dev, int n, int flag, long long n_
 // DataStd::recover (DataStd.h:157-207) on a host coefficient vector (length p) in precision T.
 template <typename T>
 void recover_coef(const DeviceData<T>& d, const T* coef, T* beta0, T* out);
+// the same for a column given as its non-zeros (ascending indices): writes only those entries of `out` (the caller cleared it).  Same
+// arithmetic in the same order as recover_coef -- the entries skipped there add exact zeros to the intercept's sum.
+template <typename T>
+void recover_coef_sparse(const DeviceData<T>& d, const int* idx, const T* val, long long cnt, T* beta0, T* out);
 
 // C (k x k, ldc) = A' A for A (m x k, lda) [trans=true] or A A' for A (k x m) [trans=false], both
 // triangles filled.  First cut: rocBLAS SYRK + symmetrise kernel.

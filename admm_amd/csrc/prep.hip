@@ -439,6 +439,24 @@ void recover_coef(const DeviceData<T>& d, const T* coef, T* beta0, T* out) {
     }
     *beta0 = b0;
 }
+template <typename T>
+void recover_coef_sparse(const DeviceData<T>& d, const int* idx, const T* val, long long cnt, T* beta0, T* out) {
+    T b0 = T(0), acc = T(0);
+    for (long long k = 0; k < cnt; ++k) {
+        const int j = idx[k];
+        T o;
+        switch (d.flag) {
+            case 0: o = val[k]; break;
+            case 1: o = (val[k] / d.scaleX[j]) * d.scaleY; break;
+            case 2: o = val[k] * d.scaleY; acc += o * d.meanX[j]; break;
+            default: o = (val[k] / d.scaleX[j]) * d.scaleY; acc += o * d.meanX[j];
+        }
+        out[j] = o;
+    }
+    if (d.flag >= 2) b0 = d.meanY - acc;
+    *beta0 = b0;
+}
+template void recover_coef_sparse<float>(const DeviceData<float>&, const int*, const float*, long long, float*, float*);
 template void recover_coef<float>(const DeviceData<float>&, const float*, float*, float*);
 template void recover_coef<double>(const DeviceData<double>&, const double*, double*, double*);
 

@@ -25,6 +25,10 @@ struct LassoResult {
     std::vector<float> beta;         // (p+1) x nlambda column-major, row 0 = intercept
     std::vector<int> niter;
     admm_stats stats{};
+    // optional: the caller's coefficient buffer ((p+1) x nlambda floats).  A solver that fills it directly sets beta_written and leaves
+    // `beta` empty (the wide solver: its coefficient matrix is 80 MB of mostly zeros at BASELINE configs[2])
+    float* beta_dst = nullptr;
+    bool beta_written = false;
 };
 
 // Lasso.cpp:78-89
