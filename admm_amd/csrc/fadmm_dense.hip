@@ -330,7 +330,7 @@ void solve_lad(const DeviceData<double>& d, const admm_opts& opts, DenseResult& 
         Xp.zero(st); T.zero(st);
         transpose<double>(U.get(), ldp, (int)ldp, (int)ldp, W.get(), ldp, st);      // W = L^-1: W[j, k] = U[k, j]
         hipLaunchKernelGGL(copy_cols_f64_kernel, dim3((n + 255) / 256, p), dim3(256), 0, st, d.X.get(), d.ldx, n, Xp.get(), ldn);
-        gemm_nt_f64(Xp.get(), ldn, W.get(), ldp, T.get(), ldn, n, p, pk, st);       // T[i, j] = sum_k X[i, k] U[k, j]
+        gemm_nt_f64(Xp.get(), ldn, W.get(), ldp, T.get(), ldn, n, p, pk, st, true); // T[i, j] = sum_k X[i, k] U[k, j]   (W = U' = L^-1: lower triangular)
         ldh = ldn;
         H.alloc((size_t)ldh * ldh); H.zero(st);
         gram_full<double>(T.get(), ldn, n, p, false, H.get(), ldh, st);             // H = T T' (tcross_prod_lower)
@@ -415,7 +415,7 @@ void solve_bp(const DeviceData<double>& d, const admm_opts& opts, DenseResult& r
         transpose<double>(d.X.get(), d.ldx, n, p, Xt.get(), ldxt, st);           // A' (p x n), output index contiguous
         transpose<double>(U.get(), ldn, (int)ldn, (int)ldn, W.get(), ldn, st);    // W = L^-1, zero padded
         DevBuf<double> Btp((size_t)ldxt * n);                                     // B' with whole 128-row blocks
-        gemm_nt_f64(Xt.get(), ldxt, W.get(), ldn, Btp.get(), ldxt, p, n, nk, st);
+        gemm_nt_f64(Xt.get(), ldxt, W.get(), ldn, Btp.get(), ldxt, p, n, nk, st, true);      // (W = L^-1: lower triangular, the K loop of column block j ends at its last column)
         hipLaunchKernelGGL(copy_cols_f64_kernel, dim3((p + 255) / 256, n), dim3(256), 0, st, Btp.get(), ldxt, p, Bt.get(), ldbt);
         transpose<double>(Bt.get(), ldbt, p, n, B.get(), d.ldx, st);
         GemvT<double> gU;                                                         // w0 = U' b

@@ -30,6 +30,8 @@ struct GemmNTd {
     int nbi, nbj, ntiles;
     int mirror;                          // LOWER mode: also store the transposed tile (both triangles)
     int kstart_row;                      // start the K loop at the tile's first row (A, B upper triangular)
+    int kend_col;                        // B is LOWER triangular (B[j, k] = 0 for k > j): end the K loop after the tile's last column --
+                                         //   the skipped products are exact zeros, the result is bit-identical, half the flops
 };
 
 __device__ __forceinline__ void tri_decode_d(int t, int& bi, int& bj) {
@@ -45,11 +47,12 @@ __global__ void __launch_bounds__(DK_THREADS, 2)
 gemm_nt_mfma_f64_kernel(GemmNTd g) {
     __shared__ __attribute__((aligned(16))) double lds[2][2][DK_BK][DK_LD];      // [buffer][A / B][k][i]
     const int per = (g.ntiles + 7) / 8;                                           // XCD b % 8 walks a contiguous range of tiles
-    const int t_idx = (blockIdx.x % 8) * per + blockIdx.x / 8;
+    // (kend_col: the tiles' K ranges grow with the column block -- dealt out to the XCDs in turn, longest first, instead of in ranges)
+    const int t_idx = g.kend_col ? (int)blockIdx.x : (blockIdx.x % 8) * per + blockIdx.x / 8;
     if (t_idx >= g.ntiles) return;
     int bi, bj;
     if (LOWER) tri_decode_d(t_idx, bi, bj);
-    else { bi = t_idx % g.nbi; bj = t_idx / g.nbi; }
+    else { bi = t_idx % g.nbi; bj = t_idx / g.nbi; if (g.kend_col) bj = g.nbj - 1 - bj; }
     const int I0 = bi * DK_BM, J0 = bj * DK_BM;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wi = (wid >> 1) * 64, wj = (wid & 1) * 64;
@@ -84,7 +87,8 @@ gemm_nt_mfma_f64_kernel(GemmNTd g) {
     };
 
     const int kbeg = g.kstart_row ? (max(I0, J0) / DK_BK) * DK_BK : 0;
-    const int ntile_k = (g.K - kbeg) / DK_BK;
+    const int kend = g.kend_col ? min(g.K, (J0 + DK_BM + DK_BK - 1) / DK_BK * DK_BK) : g.K;
+    const int ntile_k = (kend - kbeg) / DK_BK;
     const int fk = lane >> 4, fi = lane & 15;            // A / B fragment: one f64 per lane, [i = lane & 15][k = lane >> 4]
     if (ntile_k > 0) {
         gload(kbeg);
@@ -136,9 +140,10 @@ gemm_nt_mfma_f64_kernel(GemmNTd g) {
 }
 
 static void launch_gemm_nt_f64(bool lower, const double* A, long long lda, const double* B, long long ldb, double* C, long long ldc,
-                               int M, int N, int K, double alpha, double beta, bool mirror, bool kstart_row, hipStream_t st) {
+                               int M, int N, int K, double alpha, double beta, bool mirror, bool kstart_row, hipStream_t st, bool kend_col) {
     if (M <= 0 || N <= 0) return;
     GemmNTd g;
+    g.kend_col = kend_col && !lower ? 1 : 0;
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
     g.alpha = alpha; g.beta = beta; g.mirror = mirror ? 1 : 0; g.kstart_row = kstart_row ? 1 : 0;
     g.nbi = (M + DK_BM - 1) / DK_BM; g.nbj = (N + DK_BM - 1) / DK_BM;
@@ -146,6 +151,11 @@ static void launch_gemm_nt_f64(bool lower, const double* A, long long lda, const
     const int grid = (g.ntiles + 7) / 8 * 8;
     if (lower) hipLaunchKernelGGL(gemm_nt_mfma_f64_kernel<1>, dim3(grid), dim3(DK_THREADS), 0, st, g);
     else hipLaunchKernelGGL(gemm_nt_mfma_f64_kernel<0>, dim3(grid), dim3(DK_THREADS), 0, st, g);
+}
+
+static void launch_gemm_nt_f64_plain(bool lower, const double* A, long long lda, const double* B, long long ldb, double* C, long long ldc,
+                                     int M, int N, int K, double alpha, double beta, bool mirror, bool kstart_row, hipStream_t st) {
+    launch_gemm_nt_f64(lower, A, lda, B, ldb, C, ldc, M, N, K, alpha, beta, mirror, kstart_row, st, false);
 }
 
 template <bool TRANSPOSE>
@@ -183,7 +193,7 @@ void gram_mfma_f64(const double* A, long long lda, int rows, int cols, bool atA,
     Z.zero(st);
     if (atA) hipLaunchKernelGGL((pad_copy_f64_kernel<true>), dim3((rows + 31) / 32, (cols + 31) / 32), dim3(256), 0, st, A, lda, rows, cols, Z.get(), ldz);
     else hipLaunchKernelGGL((pad_copy_f64_kernel<false>), dim3((rows + 31) / 32, (cols + 31) / 32), dim3(256), 0, st, A, lda, rows, cols, Z.get(), ldz);
-    launch_gemm_nt_f64(true, Z.get(), ldz, Z.get(), ldz, C, ldc, M, M, K, 1.0, 0.0, true, false, st);
+    launch_gemm_nt_f64(true, Z.get(), ldz, Z.get(), ldz, C, ldc, M, M, K, 1.0, 0.0, true, false, st, false);
     ADMM_HIP_CHECK(hipGetLastError());
     ADMM_HIP_CHECK(hipStreamSynchronize(st));     // Z is freed on return
 }
@@ -191,18 +201,18 @@ void gram_mfma_f64(const double* A, long long lda, int rows, int cols, bool atA,
 // ---------------------------------------------------------------------------------------------- Cholesky + inverse (chol_inverse.h)
 // A (lda >= round_up(n, 128), that many zero-padded columns allocated) -> A^-1, both triangles.
 void spd_inverse_mfma_f64(double* A, long long lda, int n, hipStream_t st) {
-    spd_inverse_blocked<double>(A, lda, n, st, launch_gemm_nt_f64);
+    spd_inverse_blocked<double>(A, lda, n, st, launch_gemm_nt_f64_plain);
 }
 
 // A -> Cholesky factor L (lower triangle) in place; returns U = L^-T (lda x round_up(n, 128), upper triangular).
 DevBuf<double> cholesky_linvt_mfma_f64(double* A, long long lda, int n, hipStream_t st) {
-    return cholesky_linvt_blocked<double>(A, lda, n, st, launch_gemm_nt_f64);
+    return cholesky_linvt_blocked<double>(A, lda, n, st, launch_gemm_nt_f64_plain);
 }
 
 // C (M x N, ldc) = A B' for operands with the output index contiguous (rows readable up to the next multiple of 128,
 // K a multiple of 8).
-void gemm_nt_f64(const double* A, long long lda, const double* B, long long ldb, double* C, long long ldc, int M, int N, int K, hipStream_t st) {
-    launch_gemm_nt_f64(false, A, lda, B, ldb, C, ldc, M, N, K, 1.0, 0.0, false, false, st);
+void gemm_nt_f64(const double* A, long long lda, const double* B, long long ldb, double* C, long long ldc, int M, int N, int K, hipStream_t st, bool b_lower) {
+    launch_gemm_nt_f64(false, A, lda, B, ldb, C, ldc, M, N, K, 1.0, 0.0, false, false, st, b_lower);
 }
 
 }  // namespace admm

@@ -100,7 +100,8 @@ void spd_inverse_f64(double* A, long long lda, int n, hipStream_t st);
 // A -> Cholesky factor L in place (lower); returns U = L^-T (lda x round_up(n, 128), upper triangular, zero padded).
 DevBuf<double> cholesky_linvt_mfma_f64(double* A, long long lda, int n, hipStream_t st);
 // C (M x N) = A B' for operands with the output index contiguous (rows readable up to the next multiple of 128, K % 8 == 0).
-void gemm_nt_f64(const double* A, long long lda, const double* B, long long ldb, double* C, long long ldc, int M, int N, int K, hipStream_t st);
+// b_lower: B is lower triangular (B[j, k] = 0 for k > j, zero padded) -- the K loop of a tile ends at its last column: same bits, half the flops
+void gemm_nt_f64(const double* A, long long lda, const double* B, long long ldb, double* C, long long ldc, int M, int N, int K, hipStream_t st, bool b_lower = false);
 // In place Cholesky (lower). Throws ADMM_ERR_NOT_SPD.
 template <typename T>
 void cholesky_lower(T* A, long long lda, int n, hipStream_t st);
