@@ -253,7 +253,8 @@ struct GemvT {
     long long lda = 0, stride = 0;
     int m = 0, k = 0;
     GemvTPlan pl;
-    DevBuf<T> part;
+    DevBuf<T> part, red;                                          // red: the previous product's partial rows summed (run_partials_from, long chains only)
+    static constexpr int kChainRows = 12;
     size_t bytes() const { return (size_t)m * (size_t)k * sizeof(T); }
     void set_nt(bool nt) { pl.nt = nt; }                           // streaming policy from the solver's working set (gemv_plan.h)
     void init(const T* A_, long long lda_, int m_, int k_, int wg_per_cu = 4) {
@@ -278,6 +279,16 @@ struct GemvT {
     // the same with the right-hand vector taken from the un-reduced partials of `prev` (prev.k == m): a chain of
     // products needs no reduction launches in between
     void run_partials_from(const GemvT<T>& prev, const int* skip, hipStream_t st) {
+        static const int chain_rows = []() { const char* e = std::getenv("ADMM_HIP_GEMV_CHAIN"); return e ? std::atoi(e) : kChainRows; }();      // A/B knob
+        if (prev.pl.nseg > chain_rows) {
+            // many partial rows (the 2048-row segments of a tall fp64 operand leave 25): EVERY workgroup of this product would sum
+            // them all for its right-hand segment -- more L2 traffic than the matrix is HBM traffic.  One small launch sums them once,
+            // in the same row order (bit-identical), and this product stages a single row.
+            if (!red.get()) red.alloc((size_t)round_up(m, 32));
+            hipLaunchKernelGGL((reduce_partials_kernel<T>), dim3((m + 255) / 256), dim3(256), 0, st, prev.part.get(), prev.stride, prev.pl.nseg, m, red.get(), skip);
+            run_partials(red.get(), skip, st);
+            return;
+        }
         launch_gemv_t<T, 1, 4>(pl, A, lda, m, k, prev.part.get(), nullptr, part.get(), nullptr, stride, skip, st, GemvNoExtra(),
                                nullptr, nullptr, prev.pl.nseg, prev.stride);
     }
