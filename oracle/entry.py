@@ -35,6 +35,8 @@ def _attach(solver, detail):
         solver.state_log = detail["state"]
     if detail.get("types") is not None:
         solver.type_log = detail["types"]
+    if detail.get("follow_x") is not None and hasattr(solver, "follow_x"):
+        solver.follow_x = iter(detail["follow_x"])
     if detail.get("follow") is not None:
         solver.follow = iter(detail["follow"])
         solver.follow_band = float(detail.get("follow_band", 8.0))

@@ -432,6 +432,21 @@ class LassoWide(ADMMPlain):
             self.lambda0 = F(self.lambda0 / (np.float64(self.alpha) + 0.0001))   # ADMMEnet.h:152
         self.trace_nnz = []
 
+    mv_acc = None                                                           # rounding variant "mv64" (oracle/variants.py): the mat-vecs accumulated in double
+    # Follow mode for the PROX (tests/helpers.py, with the followed run's iterate dump): the active-set schedule makes the path depend
+    # on whether a coordinate is EXACTLY zero after a step -- a zero stays out until the next regular step -- so a soft-threshold
+    # operand within rounding of its threshold is a fork just like a stopping near-tie (out-of-sample soak 824:130: one of 269
+    # coordinates on the threshold at the first regular step of a lambda, 2 % of the column 20 iterations later).  follow_x: iterator
+    # over the followed run's x after every iteration; where its zero pattern differs from this run's and the coordinate is within
+    # follow_band yardsticks of the float dot product X_j't (plus an ulp of x_j) of the threshold, this run takes the followed value.
+    follow_x = None
+
+    def _mv(self, A, v):
+        """A v rounded to float: float accumulation (the reference's Eigen products) unless the mv64 variant is on."""
+        if self.mv_acc is None:
+            return (A @ v).astype(F)
+        return (A.astype(self.mv_acc) @ v.astype(self.mv_acc)).astype(F)
+
     def init(self, lam, rho):                                               # :215-237
         self.main_x = np.zeros(self.p, F)
         self.cache_Ax = np.zeros(self.n, F)
@@ -474,7 +489,7 @@ class LassoWide(ADMMPlain):
         res = self.main_x.copy()
         idx = np.nonzero(res)[0]
         if idx.size:
-            val = (res[idx] - (self.X[:, idx].T @ tmp).astype(F)).astype(F)
+            val = (res[idx] - self._mv(self.X[:, idx].T, tmp)).astype(F)
             if self.alpha is None:
                 new = np.where(val > penalty, val - penalty, np.where(val < -penalty, val + penalty, F(0)))
             else:
@@ -483,13 +498,20 @@ class LassoWide(ADMMPlain):
                 new = np.where(val > thresh, (val - thresh) / denom,
                                np.where(val < -thresh, (val + thresh) / denom, F(0)))
             res[idx] = new.astype(F)
+            if self.follow_x is not None:
+                self._prox_yard = np.zeros(self.p)
+                self._prox_yard[idx] = np.abs(self.X[:, idx].T.astype(np.float64)) @ np.abs(tmp.astype(np.float64)) + np.abs(val.astype(np.float64))
+        elif self.follow_x is not None:
+            self._prox_yard = np.zeros(self.p)
         return res
 
     def _regular_update(self):                                              # :141-150
         gamma = self.sprad
         tmp = (self.cache_Ax + self.aux_z + self.dual_y / F(self.rho)).astype(F)
-        vec = (-(self.X.T @ tmp).astype(F) / gamma).astype(F)
+        vec = (-self._mv(self.X.T, tmp) / gamma).astype(F)
         vec = (vec + self.main_x).astype(F)
+        if self.follow_x is not None:
+            self._prox_yard = (np.abs(self.X.T.astype(np.float64)) @ np.abs(tmp.astype(np.float64))) / np.float64(gamma) + np.abs(vec.astype(np.float64))
         return self._prox(vec, np.float64(self.lam) / (self.rho * np.float64(gamma)))
 
     def next_x(self):
@@ -497,6 +519,8 @@ class LassoWide(ADMMPlain):
             if np.float64(self.lam) > np.float64(self.lambda0) - 1e-5:
                 if self.type_log is not None:
                     self.type_log.append(0)
+                if self.follow_x is not None:
+                    next(self.follow_x, None)                               # (keeps the followed dump aligned: one record per iteration)
                 return np.zeros(self.p, F)
             reg = is_regular_update(self.iter_counter)
         else:                                                               # ADMMEnet.h:124-141
@@ -504,13 +528,27 @@ class LassoWide(ADMMPlain):
         if self.type_log is not None:
             self.type_log.append(1 if reg else 2)
         res = self._regular_update() if reg else self._active_set_update()
+        if self.follow_x is not None:
+            gx = next(self.follow_x, None)
+            if gx is not None:
+                gx = np.asarray(gx, dtype=F)
+                for jj in np.nonzero((res != 0) != (gx != 0))[0]:
+                    yard = float(np.finfo(F).eps) * float(self._prox_yard[jj])
+                    dist = abs(float(res[jj]) - float(gx[jj]))             # one of the two is zero: the other one's distance from the threshold
+                    units = dist / yard if yard > 0 else np.inf
+                    rec = dict(record=self.ndecisions, lam=self.lam_idx, iter=int(self.iter_counter), kind="prox", ulps=float(units), coord=int(jj))
+                    if units > self.follow_band:
+                        continue                                            # not a near-tie: this run keeps its own value (the coefficient tolerance judges the outcome)
+                    if self.forced is not None:
+                        self.forced.append(rec)
+                    res[jj] = gx[jj]
         self.iter_counter += 1
         self.trace_nnz.append(int(np.count_nonzero(res)))
         return res
 
     def next_z(self):                                                       # :156-165
         idx = np.nonzero(self.main_x)[0]
-        self.cache_Ax = (self.X[:, idx] @ self.main_x[idx]).astype(F) if idx.size else np.zeros(self.n, F)
+        self.cache_Ax = self._mv(self.X[:, idx], self.main_x[idx]) if idx.size else np.zeros(self.n, F)
         return ((self.Y + self.dual_y + F(self.rho) * self.cache_Ax) / F(-1 - self.rho)).astype(F)
 
     def next_residual(self):                                                # :166-170

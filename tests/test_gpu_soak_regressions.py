@@ -92,6 +92,20 @@ SOAK_CASES = [
     (717, 117, "enet_tall", "restart decision at iteration 2646 needs 8.01 ulps (479 restart near-ties on the library's own trajectory)"),
     (722, 143, "tall", "stopping decision at iteration 111 needs 9.0 ulps"),
     (730, 106, "par", "stopping decision at iteration 415 needs 10.2 ulps (K=3, scale 50)"),
+    # out-of-sample soak of round 4, seeds 821..868 (profiles/r04_soak_summary_seeds821.md: 6863 of 6874 pass): the ten decision
+    # near-ties beyond the band -- the same kind once more (the eleventh failure, 853:39 -- n = 29, p = 28, one column at 1.31e-4 where
+    # the oracle's variants have drifted 2.5e-5: 5.2 x instead of the 5 x R3 allows -- fails the coefficient rule on any trajectory
+    # and is reported, not listed)
+    (823, 18, "par", "stopping decision at iteration 373 needs 8.8 ulps (K=3)"),
+    (835, 103, "enet_tall", "stopping decision at iteration 3806 needs 8.02 ulps (scale 0.01 unstandardised)"),
+    (836, 111, "enet_tall", "stopping decision at iteration 709 needs 21 ulps (scale 0.01 unstandardised)"),
+    (842, 132, "tall", "stopping decision at iteration 433 needs 22 ulps (scale 0.01 unstandardised)"),
+    (847, 37, "tall", "stopping decision at iteration 381 needs 16 ulps"),
+    (848, 128, "enet_tall", "stopping decision at iteration 235 needs 8.8 ulps"),
+    (856, 50, "tall", "stopping decision at iteration 169 needs 8.1 ulps (n=22 p=5)"),
+    (858, 11, "par", "stopping decision at iteration 225 needs 11.7 ulps (K=3, scale 0.01)"),
+    (859, 15, "enet_tall", "stopping decision at iteration 1908 needs 8.4 ulps"),
+    (868, 70, "enet_tall", "restart decision at iteration 501 needs 8.5 ulps"),
 ]
 # per-record ceiling of the x-update's error: x the first-order float-solve yardstick (tall family; measured <= 1.8), x the
 # reference's own float Cholesky / Woodbury solve on the same right-hand side (consensus; measured <= 10.4 -- the maximum
@@ -186,3 +200,23 @@ def test_fresh_random_sample_every_iteration_is_the_reference_iteration(seed):
         njudged += 1
     print(f"[fresh sample seed {seed}] {njudged} cases judged, {len(fallback)} needed the library's own trajectory: {fallback}")
     assert len(fallback) <= 2, fallback
+
+
+def test_soak_wide_case_a_coordinate_on_the_soft_threshold_forks_the_active_set_path():
+    """Out-of-sample soak case 824:130 (wide, n=21 p=269, unstandardised, scale 0.01): at the first regular step of the second lambda
+    265 coordinates enter the oracle's active set and 264 the library's -- coordinate 138 sits on the soft threshold (the two x
+    vectors agree to 2e-9 otherwise).  An exact zero stays out of the active set until the next regular step, so the column is 2 %
+    apart 20 iterations later although every iteration of the library is the reference's (stepwise: zero pattern / z / y bit for
+    bit given its own iterates, X't within 0.26 yardsticks) and no recorded decision differs.  With the iterate dump the oracle now
+    follows the zero pattern of the x-update through such near-ties (oracle/solvers.py LassoWide.follow_x: same band, in units of the
+    float dot product's error yardstick), and the case passes with the near-tie counted."""
+    from oracle import stepcheck
+    cs = _case(824, 130)
+    assert cs["kind"] == "wide"
+    cap = T.gpu_capture(cs, state=True)
+    stepcheck.assert_stepwise_wide(T.stepwise_capture(cs, cap), label="soak 824:130")
+    rep = T.judge_capture(cs, cap, budget=False)
+    prox = [f for f in rep["forced"] if f["kind"] == "prox"]
+    print(f"[soak 824:130] soft-threshold near-ties followed: {[(f['lam'], f['iter'], f['coord'], round(f['ulps'], 3)) for f in prox]}; max beta err {rep['max_err']:.2e}")
+    assert 1 <= len(prox) <= 3 and max(f["ulps"] for f in prox) < 2.0
+    assert rep["max_err"] < 1e-4

@@ -73,6 +73,8 @@ def worker(seed, ncases, out):
                 except Exception as e:                          # noqa: BLE001  (the rule said no)
                     rec.update(ok=False, judged=True, error=type(e).__name__, message=str(e)[:600])
                     np.savez_compressed(os.path.join(out, f"fail_s{seed}_c{cs['c']}.npz"), beta=cap["beta"], niter=cap["niter"], trace=cap["trace"])
+                    if "state" in cap and "elementwise steps differ" in str(e):        # a bit mismatch of the stepwise rule: keep the dump that showed it
+                        np.savez_compressed(os.path.join(out, f"state_s{seed}_c{cs['c']}.npz"), **{k: v for k, v in cap.items()})
                     if cs["kind"] in ("tall", "enet_tall") or (cs["kind"] == "par" and cs.get("K", 0) > 1):
                         try:                                    # the stronger, drift-free statement: every iteration on its own (oracle/stepcheck.py)
                             cap2 = T.gpu_capture(cs, state=True)
