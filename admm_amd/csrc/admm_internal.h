@@ -104,6 +104,39 @@ struct Event {
     Event& operator=(const Event&) = delete;
 };
 
+// Device-to-host read-back of results, traces and iterate dumps through a pinned bounce buffer of our own (per thread,
+// never freed -- like the stream pool).  Why not hipMemcpy into the caller's pageable memory: under heavy host
+// oversubscription (16 solver processes + their CPU checkers on one box) the runtime's pageable path was caught returning a
+// few stale 64-byte lines at a fixed offset (~128 KB) of a large copy while the device buffer was intact -- a second read of
+// the same device memory gave the right bytes (profiles/r04_transient_stale_lines.md).  A DMA into pinned memory followed by
+// a host memcpy does not go through that staging path.  Copies below kDirectBytes stay on plain hipMemcpy.
+// `st` must be the stream the producing kernels ran on (or nullptr after a device-wide sync); the call returns with the
+// bytes in dst.
+struct PinnedBounce {
+    static constexpr size_t kChunk = size_t(4) << 20;
+    static constexpr size_t kDirectBytes = size_t(32) << 10;
+    static void* buffer() {
+        static thread_local void* buf = nullptr;
+        if (!buf) ADMM_HIP_CHECK(hipHostMalloc(&buf, kChunk, hipHostMallocDefault));
+        return buf;
+    }
+};
+inline void read_back(void* dst, const void* src, size_t bytes, hipStream_t st) {
+    if (!bytes) return;
+    if (bytes <= PinnedBounce::kDirectBytes) {
+        if (st) ADMM_HIP_CHECK(hipStreamSynchronize(st));
+        ADMM_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+        return;
+    }
+    char* bounce = static_cast<char*>(PinnedBounce::buffer());
+    for (size_t off = 0; off < bytes; off += PinnedBounce::kChunk) {
+        const size_t n = bytes - off < PinnedBounce::kChunk ? bytes - off : PinnedBounce::kChunk;
+        ADMM_HIP_CHECK(hipMemcpyAsync(bounce, static_cast<const char*>(src) + off, n, hipMemcpyDeviceToHost, st));
+        ADMM_HIP_CHECK(hipStreamSynchronize(st));
+        std::memcpy(static_cast<char*>(dst) + off, bounce, n);
+    }
+}
+
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 inline size_t round_up_sz(size_t v, size_t m) { return (v + m - 1) / m * m; }
 

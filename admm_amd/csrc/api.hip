@@ -307,7 +307,7 @@ static void lasso_cv(const double* x, const double* y, int n, int p, int mem, co
             DevBuf<float> fb(nfb);
             ADMM_HIP_CHECK(hipMemcpyAsync(fb.get(), fold_beta, nfb * sizeof(float), hipMemcpyHostToDevice, st.s));
             allreduce_sum_f32(fb.get(), nfb, st.s);
-            ADMM_HIP_CHECK(hipMemcpyAsync(fold_beta, fb.get(), nfb * sizeof(float), hipMemcpyDeviceToHost, st.s));
+            read_back(fold_beta, fb.get(), nfb * sizeof(float), st.s);
             ADMM_HIP_CHECK(hipStreamSynchronize(st.s));
             comm_check();
         }
@@ -421,7 +421,7 @@ static void lasso_multi(const double* x, const double* Y, int n, int p, int m, i
         DevBuf<float> fb(bsz * m);
         ADMM_HIP_CHECK(hipMemcpyAsync(fb.get(), beta_out, bsz * m * sizeof(float), hipMemcpyHostToDevice, st.s));
         allreduce_sum_f32(fb.get(), bsz * m, st.s);
-        ADMM_HIP_CHECK(hipMemcpyAsync(beta_out, fb.get(), bsz * m * sizeof(float), hipMemcpyDeviceToHost, st.s));
+        read_back(beta_out, fb.get(), bsz * m * sizeof(float), st.s);
         ADMM_HIP_CHECK(hipStreamSynchronize(st.s));
         comm_check();
     }

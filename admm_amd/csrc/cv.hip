@@ -223,7 +223,7 @@ void cv_downdate_fold(DeviceData<float>& d, const CvBase& b, const double* yd, c
     w.zero(st);
     hipLaunchKernelGGL(cv_scatter_vec_kernel, dim3((ntr + 255) / 256), dim3(256), 0, st, Yt.get(), d_train, ntr, w.get());
     std::vector<float> hY(ntr);
-    ADMM_HIP_CHECK(hipMemcpyAsync(hY.data(), Yt.get(), (size_t)ntr * sizeof(float), hipMemcpyDeviceToHost, st));
+    read_back(hY.data(), Yt.get(), (size_t)ntr * sizeof(float), st);
     DevBuf<float> raw(ldp);
     raw.zero(st);
     gemv_t_simple<float>(f.X.get(), f.ldx, n, p, w.get(), raw.get(), st);

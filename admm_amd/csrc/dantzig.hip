@@ -266,7 +266,7 @@ void solve_dantzig(DeviceData<double>& d, const LassoProblem& pb, DantzigResult&
     // ---- results: recover every column (Dantzig.cpp:88-93)
     std::vector<double> hb((size_t)nlam * p);
     std::vector<int> hn(nlam);
-    ADMM_HIP_CHECK(hipMemcpy(hb.data(), beta.get(), hb.size() * sizeof(double), hipMemcpyDeviceToHost));
+    read_back(hb.data(), beta.get(), hb.size() * sizeof(double), st);
     ADMM_HIP_CHECK(hipMemcpy(hn.data(), dniter.get(), (size_t)nlam * sizeof(int), hipMemcpyDeviceToHost));
     res.beta.assign((size_t)(p + 1) * nlam, 0.0);
     res.niter = hn;
@@ -282,7 +282,7 @@ void solve_dantzig(DeviceData<double>& d, const LassoProblem& pb, DantzigResult&
         ADMM_HIP_CHECK(hipMemcpy(hc, ctl.get(), sizeof(hc), hipMemcpyDeviceToHost));
         const long long nrec = std::min<long long>(std::max(hc[0].total, hc[1].total), res.trace_cap);
         res.trace.assign((size_t)nrec * ADMM_TRACE_FIELDS, 0.0);
-        if (nrec > 0) ADMM_HIP_CHECK(hipMemcpy(res.trace.data(), trace.get(), res.trace.size() * sizeof(double), hipMemcpyDeviceToHost));
+        if (nrec > 0) read_back(res.trace.data(), trace.get(), res.trace.size() * sizeof(double), st);
     }
     S.total_iter = tot;
     S.t_loop = lt.wall_s;

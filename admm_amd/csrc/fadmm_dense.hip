@@ -14,6 +14,8 @@
 #include "prep.h"
 #include "gemv_kernels.h"
 #include "solvers.h"
+#include <cstring>
+#include <cstdio>
 #include "loop_driver.h"
 
 namespace admm {
@@ -266,12 +268,27 @@ static void dense_collect_trace(DenseLoop& L, const DenseCtl& fc, DenseResult& r
     if (res.trace_cap <= 0) return;
     const long long nrec = std::min<long long>(fc.total + (fc.done ? 1 : 0), res.trace_cap);      // the finishing decision does not advance `total`
     res.trace.resize((size_t)nrec * ADMM_TRACE_FIELDS);
-    if (nrec > 0) ADMM_HIP_CHECK(hipMemcpy(res.trace.data(), L.trace.get(), res.trace.size() * sizeof(double), hipMemcpyDeviceToHost));
+    if (nrec > 0) read_back(res.trace.data(), L.trace.get(), res.trace.size() * sizeof(double), st);
     if (res.state_cap > 0) {                                   // one record per decision, same numbering as the trace
         const long long ns = std::min<long long>(fc.total + (fc.done ? 1 : 0), res.state_cap);
         res.state_dim = L.q.dim;
         res.state.resize((size_t)ns * 5 * L.q.dim);
-        if (ns > 0) ADMM_HIP_CHECK(hipMemcpy(res.state.data(), L.state.get(), res.state.size() * sizeof(double), hipMemcpyDeviceToHost));
+        if (ns > 0) read_back(res.state.data(), L.state.get(), res.state.size() * sizeof(double), st);
+        if (ns > 0 && std::getenv("ADMM_HIP_DEBUG_REREAD")) {
+            // diagnosis of profiles/r04_transient_stale_lines.md: the dump above came through read_back()'s pinned bounce buffer.  Read the
+            // same device memory again through the pinned path and through the runtime's pageable hipMemcpy, and report which differs.
+            std::vector<double> pinned2(res.state.size()), pageable(res.state.size());
+            read_back(pinned2.data(), L.state.get(), pinned2.size() * sizeof(double), st);
+            ADMM_HIP_CHECK(hipMemcpy(pageable.data(), L.state.get(), pageable.size() * sizeof(double), hipMemcpyDeviceToHost));
+            size_t d12 = 0, d13 = 0, first12 = 0, first13 = 0;
+            for (size_t i = 0; i < pinned2.size(); ++i) {
+                if (std::memcmp(&pinned2[i], &res.state[i], 8) != 0) { if (!d12) first12 = i; ++d12; }
+                if (std::memcmp(&pageable[i], &res.state[i], 8) != 0) { if (!d13) first13 = i; ++d13; }
+            }
+            if (d12 || d13)
+                std::fprintf(stderr, "[admm_hip reread] dump of %zu doubles (dim %d): second pinned read differs in %zu entries (first at %zu), pageable hipMemcpy differs in %zu (first at %zu)\n",
+                             pinned2.size(), L.q.dim, d12, first12, d13, first13);
+        }
     }
 }
 
@@ -452,7 +469,7 @@ void solve_bp(const DeviceData<double>& d, const admm_opts& opts, DenseResult& r
     dense_collect_trace(L, fc, res, st);
     const double* zfin = (fc.total & 1) ? L.z1.get() : L.z0.get();      // get_z() (BP.cpp:40)
     res.beta.assign(p, 0.0);
-    ADMM_HIP_CHECK(hipMemcpy(res.beta.data(), zfin, (size_t)p * sizeof(double), hipMemcpyDeviceToHost));
+    read_back(res.beta.data(), zfin, (size_t)p * sizeof(double), st);
 }
 
 }  // namespace admm

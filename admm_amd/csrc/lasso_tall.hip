@@ -814,7 +814,7 @@ struct TallPlan final : LassoPlan {
     }
     long long read_trace(double* out, long long cap) override {
         const long long nrec = std::min(std::min(trace_n, trace_cap), cap);
-        if (nrec > 0) ADMM_HIP_CHECK(hipMemcpy(out, trace.get(), (size_t)nrec * ADMM_TRACE_FIELDS * sizeof(double), hipMemcpyDeviceToHost));
+        if (nrec > 0) read_back(out, trace.get(), (size_t)nrec * ADMM_TRACE_FIELDS * sizeof(double), st);
         return nrec;
     }
 
@@ -830,7 +830,7 @@ struct TallPlan final : LassoPlan {
         if (rec_floats) *rec_floats = 5ll * p;
         if (!out) return std::min(trace_n, state_cap);                             // size query
         const long long nrec = std::min(std::min(trace_n, state_cap), cap);       // one record per decision, same numbering as the trace
-        if (nrec > 0 && out) ADMM_HIP_CHECK(hipMemcpy(out, state.get(), (size_t)nrec * 5 * p * sizeof(float), hipMemcpyDeviceToHost));
+        if (nrec > 0 && out) read_back(out, state.get(), (size_t)nrec * 5 * p * sizeof(float), st);
         return nrec;
     }
 

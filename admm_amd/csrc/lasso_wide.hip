@@ -1527,7 +1527,7 @@ struct WidePlan final : LassoPlan {
     }
     long long read_trace(double* out, long long cap) override {
         const long long nrec = std::min(std::min(trace_n, trace_cap), cap);
-        if (nrec > 0) ADMM_HIP_CHECK(hipMemcpy(out, trace.get(), (size_t)nrec * ADMM_TRACE_FIELDS * sizeof(double), hipMemcpyDeviceToHost));
+        if (nrec > 0) read_back(out, trace.get(), (size_t)nrec * ADMM_TRACE_FIELDS * sizeof(double), st);
         return nrec;
     }
 
@@ -1547,7 +1547,7 @@ struct WidePlan final : LassoPlan {
         if (rec_floats) *rec_floats = (long long)rec;
         if (!out) return std::min(trace_n, state_cap);                             // size query
         const long long nrec = std::min(std::min(trace_n, state_cap), cap);
-        if (nrec > 0) ADMM_HIP_CHECK(hipMemcpy(out, state.get(), (size_t)nrec * rec * sizeof(float), hipMemcpyDeviceToHost));
+        if (nrec > 0) read_back(out, state.get(), (size_t)nrec * rec * sizeof(float), st);
         return nrec;
     }
     // the standardised data as this solver holds them (test hook admm_hip_lasso_plan_data_read)
@@ -1829,10 +1829,10 @@ struct WidePlan final : LassoPlan {
             ADMM_HIP_CHECK(hipMemcpyAsync(doff.get(), hoff.data(), (size_t)nlam * sizeof(long long), hipMemcpyHostToDevice, st));
             hipLaunchKernelGGL(wide_beta_compact_kernel, dim3(nlam), dim3(256), 0, st, beta.get(), p, doff.get(), didx.get(), dval.get());
             if (tot_nz) {
-                ADMM_HIP_CHECK(hipMemcpyAsync(hidx.data(), didx.get(), tot_nz * sizeof(int), hipMemcpyDeviceToHost, st));
-                ADMM_HIP_CHECK(hipMemcpyAsync(hval.data(), dval.get(), tot_nz * sizeof(float), hipMemcpyDeviceToHost, st));
+                read_back(hidx.data(), didx.get(), tot_nz * sizeof(int), st);
+                read_back(hval.data(), dval.get(), tot_nz * sizeof(float), st);
             }
-            std::memset(res.beta_dst, 0, pt1 * nlam * sizeof(float));     // (under the copies)
+            std::memset(res.beta_dst, 0, pt1 * nlam * sizeof(float));
             ADMM_HIP_CHECK(hipStreamSynchronize(st));
             for (int l = 0; l < nlam; ++l) {
                 float b0 = 0.f;
@@ -1844,7 +1844,7 @@ struct WidePlan final : LassoPlan {
             res.beta.clear();
         } else {
         std::vector<float> hb((size_t)nlam * p);
-        ADMM_HIP_CHECK(hipMemcpy(hb.data(), beta.get(), hb.size() * sizeof(float), hipMemcpyDeviceToHost));
+        read_back(hb.data(), beta.get(), hb.size() * sizeof(float), st);
         res.beta.assign(pt1 * nlam, 0.f);
         for (int l = 0; l < nlam; ++l) {
             float b0 = 0.f;
@@ -1864,7 +1864,7 @@ struct WidePlan final : LassoPlan {
             ADMM_HIP_CHECK(hipMemcpyAsync(di.get(), icpt.data(), nlam * sizeof(double), hipMemcpyHostToDevice, st));
             allreduce_sum_f32(db.get(), res.beta.size(), st);
             allreduce_sum_f64(di.get(), (size_t)nlam, st);
-            ADMM_HIP_CHECK(hipMemcpyAsync(res.beta.data(), db.get(), res.beta.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+            read_back(res.beta.data(), db.get(), res.beta.size() * sizeof(float), st);
             ADMM_HIP_CHECK(hipMemcpyAsync(icpt.data(), di.get(), nlam * sizeof(double), hipMemcpyDeviceToHost, st));
             ADMM_HIP_CHECK(hipStreamSynchronize(st));
             comm_check();

@@ -369,7 +369,7 @@ struct ParPlan final : LassoPlan {
     }
     long long read_trace(double* out, long long cap) override {
         const long long nrec = std::min(std::min(trace_n, trace_cap), cap);
-        if (nrec > 0) ADMM_HIP_CHECK(hipMemcpy(out, trace.get(), (size_t)nrec * ADMM_TRACE_FIELDS * sizeof(double), hipMemcpyDeviceToHost));
+        if (nrec > 0) read_back(out, trace.get(), (size_t)nrec * ADMM_TRACE_FIELDS * sizeof(double), st);
         return nrec;
     }
 
@@ -395,7 +395,7 @@ struct ParPlan final : LassoPlan {
         if (rec_floats) *rec_floats = (long long)rec;
         if (!out) return std::min(trace_n, state_cap);                             // size query
         const long long nrec = std::min(std::min(trace_n, state_cap), cap);
-        if (nrec > 0 && out) ADMM_HIP_CHECK(hipMemcpy(out, state.get(), (size_t)nrec * rec * sizeof(float), hipMemcpyDeviceToHost));
+        if (nrec > 0 && out) read_back(out, state.get(), (size_t)nrec * rec * sizeof(float), st);
         return nrec;
     }
 
@@ -604,7 +604,7 @@ struct ParPlan final : LassoPlan {
         res.niter.assign(nlam, 0);
         ADMM_HIP_CHECK(hipMemcpy(res.niter.data(), niter.get(), nlam * sizeof(int), hipMemcpyDeviceToHost));
         std::vector<float> hb((size_t)nlam * p);
-        ADMM_HIP_CHECK(hipMemcpy(hb.data(), beta.get(), hb.size() * sizeof(float), hipMemcpyDeviceToHost));
+        read_back(hb.data(), beta.get(), hb.size() * sizeof(float), st);
         res.beta.assign((size_t)(p + 1) * nlam, 0.f);
         long long tot = 0;
         for (int l = 0; l < nlam; ++l) {

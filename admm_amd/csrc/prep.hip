@@ -754,8 +754,7 @@ void SymMatVec<T>::operator()(const T* v_host, T* w_host) {
     ADMM_HIP_CHECK(hipMemcpyAsync(dv.get(), v_host, (size_t)n * sizeof(T), hipMemcpyHostToDevice, st));
     launch_gemv_t<T, 1, 4>(pl, A, lda, n, n, dv.get(), nullptr, part.get(), nullptr, stride, nullptr, st);
     hipLaunchKernelGGL((reduce_partials_kernel<T>), dim3((n + 255) / 256), dim3(256), 0, st, part.get(), stride, pl.nseg, n, dw.get(), (const int*)nullptr);
-    ADMM_HIP_CHECK(hipMemcpyAsync(w_host, dw.get(), (size_t)n * sizeof(T), hipMemcpyDeviceToHost, st));
-    ADMM_HIP_CHECK(hipStreamSynchronize(st));
+    read_back(w_host, dw.get(), (size_t)n * sizeof(T), st);
 }
 template struct SymMatVec<float>;
 template struct SymMatVec<double>;
@@ -804,8 +803,7 @@ void GramFreeWideOp::operator()(const float* v_host, float* w_host) {
     gemv_t_simple<float>(X, ldx, n, p, dv.get(), ds.get(), st);                                             // s = X' v
     hipLaunchKernelGGL(gemv_n_partial_kernel, dim3(nchunk, (n + 1023) / 1024), dim3(256), 0, st, X, ldx, n, p, ds.get(), cols_per_wg, part.get(), ldpart);
     hipLaunchKernelGGL((reduce_partials_kernel<float>), dim3((n + 255) / 256), dim3(256), 0, st, part.get(), ldpart, nchunk, n, dw.get(), (const int*)nullptr);
-    ADMM_HIP_CHECK(hipMemcpyAsync(w_host, dw.get(), (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st));
-    ADMM_HIP_CHECK(hipStreamSynchronize(st));
+    read_back(w_host, dw.get(), (size_t)n * sizeof(float), st);
 }
 
 }  // namespace admm

@@ -764,11 +764,11 @@ void solve_parbp(const DeviceData<double>& d, const admm_opts& opts, int nblocks
     ADMM_REQUIRE(fin.done, "admm_parbp: the loop ended without a decision");
     res.niter = fin.niter;
     res.beta.assign(pl, 0.0);
-    ADMM_HIP_CHECK(hipMemcpy(res.beta.data(), x.get(), (size_t)pl * sizeof(double), hipMemcpyDeviceToHost));
+    read_back(res.beta.data(), x.get(), (size_t)pl * sizeof(double), st);
     if (res.trace_cap > 0) {
         const long long nrec = std::min<long long>(fin.total, res.trace_cap);
         res.trace.assign((size_t)nrec * ADMM_TRACE_FIELDS, 0.0);
-        if (nrec > 0) ADMM_HIP_CHECK(hipMemcpy(res.trace.data(), trace.get(), res.trace.size() * sizeof(double), hipMemcpyDeviceToHost));
+        if (nrec > 0) read_back(res.trace.data(), trace.get(), res.trace.size() * sizeof(double), st);
     }
     S.total_iter = fin.niter > opts.maxit ? opts.maxit : fin.niter;
     S.t_loop = lt.wall_s;
