@@ -131,7 +131,13 @@ __device__ __forceinline__ void gemm_nt_quarter(const GemmNT& g, float (*lds)[2]
     }
 }
 
-template <int LOWER>
+// EPI = 1: the output tile leaves through LDS so that C is read and written in whole 512-byte column pieces (launcher: every
+// call without the mirrored store).  The matrix cores hand a lane ONE column and rows four at a time, eight rows apart: written
+// from the registers, a wave's load or store touches 32 columns with 16 bytes each -- measured (scripts/gemm_shortk.hip) 10 us
+// per 128 x 128 tile for the stores and 10 more for the loads of beta C, against 4 us for the K = 128 product itself: the
+// rank-128 updates of the blocked factorisation were 5/6 epilogue.  Same arithmetic per element, bit-identical
+// (tests/test_gpu_kernels.py; ADMM_HIP_GEMM_EPI=0 keeps the direct stores for the A/B).
+template <int LOWER, int EPI = 0>
 __global__ void __launch_bounds__(SK_THREADS, 2)
 gemm_nt_mfma_kernel(GemmNT g) {
     __shared__ __attribute__((aligned(16))) float lds[2][2][SK_BK][SK_BM];      // [buffer][A/B][k][i]
@@ -234,6 +240,61 @@ gemm_nt_mfma_kernel(GemmNT g) {
 #undef SK_LSTORE
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    if (EPI) {
+        // Two passes of 64 columns x 128 rows through the 32 KB of the staging buffers: pass b takes the b-th 32-column block of
+        // every wave.  T[c][row], rows contiguous, float4 slot q = row / 4 stored at q ^ (c & 31): the writers (8 lanes of
+        // different columns per LDS cycle) and the readers (32 lanes walking down one column) are both conflict free.
+        float* T = &lds[0][0][0][0];
+        float* Cs = g.C + (size_t)split * g.cstride;
+        const bool vec = (g.ldc & 3) == 0 && (reinterpret_cast<size_t>(Cs) & 15) == 0;
+        const int cw = (wid & 1) * 32 + (lane & 31);
+        __syncthreads();                                                // the last K tile has been read by every wave
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            if (b) __syncthreads();                                     // pass 0 has been read
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const int q = (wi + a * 32 + 8 * rq + 4 * (lane >> 5)) >> 2;
+                    *reinterpret_cast<float4*>(&T[cw * SK_BM + ((q ^ (cw & 31)) << 2)]) =
+                        make_float4(acc[a][b][4 * rq], acc[a][b][4 * rq + 1], acc[a][b][4 * rq + 2], acc[a][b][4 * rq + 3]);
+                }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int idx = i * SK_THREADS + tid;
+                const int c = idx >> 5, q = idx & 31;
+                const float4 t = *reinterpret_cast<const float4*>(&T[c * SK_BM + ((q ^ (c & 31)) << 2)]);
+                const int col = J0 + (c >> 5) * 64 + b * 32 + (c & 31), row = I0 + q * 4;
+                if (col >= g.N || row >= g.M) continue;
+                float* dst = Cs + (size_t)col * g.ldc + row;
+                const float tv[4] = {t.x, t.y, t.z, t.w};
+                if (vec && row + 3 < g.M) {
+                    float o[4];
+                    float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (g.beta != 0.f) c4 = *reinterpret_cast<const float4*>(dst);
+                    const float cv[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = g.alpha * tv[e];
+                        if (g.beta != 0.f) v += g.beta * cv[e];
+                        o[e] = v;
+                    }
+                    *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (row + e < g.M) {
+                            float v = g.alpha * tv[e];
+                            if (g.beta != 0.f) v += g.beta * dst[e];
+                            dst[e] = v;
+                        }
+                }
+            }
+        }
+        return;
+    }
     const bool offdiag = I0 != J0;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -348,8 +409,13 @@ static void launch_gemm_nt(bool lower, const float* A, long long lda, const floa
     if (g.ntiles <= 0 && g.nq <= 0) return;
     g.grid_full = (g.ntiles * ksplit + 7) / 8 * 8;
     const int grid = g.grid_full + (g.nq + 7) / 8 * 8;
-    if (lower) hipLaunchKernelGGL(gemm_nt_mfma_kernel<1>, dim3(grid), dim3(SK_THREADS), 0, st, g);
-    else hipLaunchKernelGGL(gemm_nt_mfma_kernel<0>, dim3(grid), dim3(SK_THREADS), 0, st, g);
+    const char* epi_env = std::getenv("ADMM_HIP_GEMM_EPI");             // read per call: the A/B test flips it inside one process
+    const bool epi_lds = !(epi_env && epi_env[0] == '0');
+    if (epi_lds && !mirror && g.nq == 0) {                              // (the quarter items of the Gram's tail come with the mirrored store)
+        if (lower) hipLaunchKernelGGL((gemm_nt_mfma_kernel<1, 1>), dim3(grid), dim3(SK_THREADS), 0, st, g);
+        else hipLaunchKernelGGL((gemm_nt_mfma_kernel<0, 1>), dim3(grid), dim3(SK_THREADS), 0, st, g);
+    } else if (lower) hipLaunchKernelGGL((gemm_nt_mfma_kernel<1, 0>), dim3(grid), dim3(SK_THREADS), 0, st, g);
+    else hipLaunchKernelGGL((gemm_nt_mfma_kernel<0, 0>), dim3(grid), dim3(SK_THREADS), 0, st, g);
 }
 
 static void launch_gemm_nt_f32(bool lower, const float* A, long long lda, const float* B, long long ldb, float* C, long long ldc,
@@ -409,7 +475,7 @@ void gram_mfma_f32(const float* A, long long lda, int rows, int cols, bool atA, 
         } else {
             std::vector<int> full, quarters;
             int wg_per_cu = 2;                               // resident workgroups per CU (registers / LDS: 4 as compiled today)
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu, gemm_nt_mfma_kernel<1>, SK_THREADS, 0) != hipSuccess || wg_per_cu < 1) wg_per_cu = 2;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu, gemm_nt_mfma_kernel<1, 0>, SK_THREADS, 0) != hipSuccess || wg_per_cu < 1) wg_per_cu = 2;
             gram_work_lists(M, wg_per_cu * device_info().num_cu, et ? std::atof(et) : 0.55, full, quarters);
             if (std::getenv("ADMM_HIP_GRAM_DEBUG")) std::fprintf(stderr, "[gram] M %d wg/cu %d full %zu quarters %zu\n", M, wg_per_cu, full.size(), quarters.size());
             DevBuf<int> tmap = upload_ints(full, st), qmap = upload_ints(quarters, st);

@@ -66,6 +66,23 @@ def test_gram_tail_of_quarter_tiles_is_bit_identical(rows, cols, monkeypatch):
     assert np.abs(G - ref).max() / np.abs(ref).max() < 2e-5
 
 
+@pytest.mark.parametrize("n", [256, 301, 1100, 2300])
+def test_output_tiles_through_lds_are_bit_identical(n, monkeypatch):
+    """The float NT-GEMM hands its output tile over through LDS so that C is read and written in whole column pieces
+    (syrk_mfma.hip, EPI = 1: every launch without the mirrored store -- all rank-128 updates of the blocked factorisation, the
+    split-K partial Grams).  Same arithmetic per element as the direct stores from the matrix-core layout
+    (ADMM_HIP_GEMM_EPI=0): the inverse (beta = 1 updates, orders that are not multiples of 4 or 128 -> the scalar edge path) and
+    a split-K Gram (beta = 0, partial tiles) must not change in a single bit."""
+    rng = np.random.default_rng(n)
+    X = rng.standard_normal((2 * n, n))
+    A = (X.T @ X + 0.05 * n * np.eye(n)).astype(np.float32)
+    W = (rng.standard_normal((n // 2, 3 * n)) * 2 + 0.3).astype(np.float32)      # few tiles, deep K: split-K launch
+    inv1, g1 = _inverse(A, 0), _gram(W.T.copy(), True)
+    monkeypatch.setenv("ADMM_HIP_GEMM_EPI", "0")
+    inv0, g0 = _inverse(A, 0), _gram(W.T.copy(), True)
+    assert np.array_equal(inv1, inv0) and np.array_equal(g1, g0)
+
+
 @pytest.mark.parametrize("n", [256, 300, 1100, 2048, 2300])
 @pytest.mark.parametrize("precision", [0, 1, 2])
 def test_spd_inverse_vs_numpy(n, precision):
