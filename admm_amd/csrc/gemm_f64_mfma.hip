@@ -42,7 +42,10 @@ __device__ __forceinline__ void tri_decode_d(int t, int& bi, int& bj) {
 }
 
 // C = alpha A B' + beta C on 128 x 128 tiles (LOWER: only tiles on or below the diagonal of a square C)
-template <int LOWER>
+// EPI = 1 (every launch without the mirrored store): the output tile leaves through LDS, as in the float kernel
+// (syrk_mfma.hip: C read and written in whole column pieces instead of 32-byte pieces of 16 columns per instruction); same
+// arithmetic per element, bit-identical; ADMM_HIP_GEMM_EPI=0 keeps the direct stores.
+template <int LOWER, int EPI = 0>
 __global__ void __launch_bounds__(DK_THREADS, 2)
 gemm_nt_mfma_f64_kernel(GemmNTd g) {
     __shared__ __attribute__((aligned(16))) double lds[2][2][DK_BK][DK_LD];      // [buffer][A / B][k][i]
@@ -119,6 +122,60 @@ gemm_nt_mfma_f64_kernel(GemmNTd g) {
     }
 
     // epilogue: C/D layout of the f64 16x16 MFMA: col = lane & 15, row = (lane >> 4) + 4 * r
+    if (EPI) {
+        // Four passes of 32 columns x 128 rows through the staging buffers (4096 of their 4352 doubles): pass b takes the b-th
+        // 16-column block of every wave.  T[c][row]; the 4-row group row / 4 is stored at group ^ c, so that the 16 columns a
+        // write instruction touches spread over the banks and a reader walking down a column meets every group once.
+        double* T = &lds[0][0][0][0];
+        const bool vec = (g.ldc & 1) == 0 && (reinterpret_cast<size_t>(g.C) & 15) == 0;
+        const int cw = (wid & 1) * 16 + (lane & 15);
+        __syncthreads();                                                // the last K tile has been read by every wave
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if (b) __syncthreads();                                     // the previous pass has been read
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = wi + 16 * a + 4 * r;                // + (lane >> 4): stays inside the 4-row group
+                    T[cw * DK_BM + ((((row >> 2) ^ cw) & 31) << 2) + (lane >> 4)] = acc[a][b][r];
+                }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int idx = i * DK_THREADS + tid;
+                const int c = idx >> 6, r2 = idx & 63;
+                const int rowl = 2 * r2;
+                const double2 t = *reinterpret_cast<const double2*>(&T[c * DK_BM + ((((rowl >> 2) ^ c) & 31) << 2) + (rowl & 3)]);
+                const int col = J0 + (c >> 4) * 64 + b * 16 + (c & 15), row = I0 + rowl;
+                if (col >= g.N || row >= g.M) continue;
+                double* dst = g.C + (size_t)col * g.ldc + row;
+                const double tv[2] = {t.x, t.y};
+                if (vec && row + 1 < g.M) {
+                    double2 c2 = make_double2(0.0, 0.0);
+                    if (g.beta != 0.0) c2 = *reinterpret_cast<const double2*>(dst);
+                    const double cv[2] = {c2.x, c2.y};
+                    double o[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        double v = g.alpha * tv[e];
+                        if (g.beta != 0.0) v += g.beta * cv[e];
+                        o[e] = v;
+                    }
+                    *reinterpret_cast<double2*>(dst) = make_double2(o[0], o[1]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+                        if (row + e < g.M) {
+                            double v = g.alpha * tv[e];
+                            if (g.beta != 0.0) v += g.beta * dst[e];
+                            dst[e] = v;
+                        }
+                }
+            }
+        }
+        return;
+    }
     const bool offdiag = I0 != J0;
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -149,8 +206,13 @@ static void launch_gemm_nt_f64(bool lower, const double* A, long long lda, const
     g.nbi = (M + DK_BM - 1) / DK_BM; g.nbj = (N + DK_BM - 1) / DK_BM;
     g.ntiles = lower ? g.nbi * (g.nbi + 1) / 2 : g.nbi * g.nbj;
     const int grid = (g.ntiles + 7) / 8 * 8;
-    if (lower) hipLaunchKernelGGL(gemm_nt_mfma_f64_kernel<1>, dim3(grid), dim3(DK_THREADS), 0, st, g);
-    else hipLaunchKernelGGL(gemm_nt_mfma_f64_kernel<0>, dim3(grid), dim3(DK_THREADS), 0, st, g);
+    const char* epi_env = std::getenv("ADMM_HIP_GEMM_EPI");             // read per call: the A/B test flips it inside one process
+    const bool epi_lds = !(epi_env && epi_env[0] == '0');
+    if (epi_lds && !mirror) {
+        if (lower) hipLaunchKernelGGL((gemm_nt_mfma_f64_kernel<1, 1>), dim3(grid), dim3(DK_THREADS), 0, st, g);
+        else hipLaunchKernelGGL((gemm_nt_mfma_f64_kernel<0, 1>), dim3(grid), dim3(DK_THREADS), 0, st, g);
+    } else if (lower) hipLaunchKernelGGL((gemm_nt_mfma_f64_kernel<1, 0>), dim3(grid), dim3(DK_THREADS), 0, st, g);
+    else hipLaunchKernelGGL((gemm_nt_mfma_f64_kernel<0, 0>), dim3(grid), dim3(DK_THREADS), 0, st, g);
 }
 
 static void launch_gemm_nt_f64_plain(bool lower, const double* A, long long lda, const double* B, long long ldb, double* C, long long ldc,

@@ -67,20 +67,23 @@ def test_gram_tail_of_quarter_tiles_is_bit_identical(rows, cols, monkeypatch):
 
 
 @pytest.mark.parametrize("n", [256, 301, 1100, 2300])
-def test_output_tiles_through_lds_are_bit_identical(n, monkeypatch):
-    """The float NT-GEMM hands its output tile over through LDS so that C is read and written in whole column pieces
-    (syrk_mfma.hip, EPI = 1: every launch without the mirrored store -- all rank-128 updates of the blocked factorisation, the
-    split-K partial Grams).  Same arithmetic per element as the direct stores from the matrix-core layout
+@pytest.mark.parametrize("precision", [0, 1])
+def test_output_tiles_through_lds_are_bit_identical(n, precision, monkeypatch):
+    """The NT-GEMMs (float: syrk_mfma.hip, double: gemm_f64_mfma.hip) hand their output tile over through LDS so that C is read
+    and written in whole column pieces (EPI = 1: every launch without the mirrored store -- all rank-128 updates of the blocked
+    factorisation, the split-K partial Grams).  Same arithmetic per element as the direct stores from the matrix-core layout
     (ADMM_HIP_GEMM_EPI=0): the inverse (beta = 1 updates, orders that are not multiples of 4 or 128 -> the scalar edge path) and
     a split-K Gram (beta = 0, partial tiles) must not change in a single bit."""
     rng = np.random.default_rng(n)
+    dtype = np.float64 if precision == 1 else np.float32
     X = rng.standard_normal((2 * n, n))
-    A = (X.T @ X + 0.05 * n * np.eye(n)).astype(np.float32)
-    W = (rng.standard_normal((n // 2, 3 * n)) * 2 + 0.3).astype(np.float32)      # few tiles, deep K: split-K launch
-    inv1, g1 = _inverse(A, 0), _gram(W.T.copy(), True)
+    A = (X.T @ X + 0.05 * n * np.eye(n)).astype(dtype)
+    W = (rng.standard_normal((3 * n, n // 2)) * 2 + 0.3).astype(dtype)           # few tiles, deep K: split-K launch (float)
+    inv1, g1 = _inverse(A, precision), _gram(W, True)
     monkeypatch.setenv("ADMM_HIP_GEMM_EPI", "0")
-    inv0, g0 = _inverse(A, 0), _gram(W.T.copy(), True)
+    inv0, g0 = _inverse(A, precision), _gram(W, True)
     assert np.array_equal(inv1, inv0) and np.array_equal(g1, g0)
+    assert np.abs(inv1 @ A.astype(np.float64) - np.eye(n)).max() < (1e-9 if precision == 1 else 5e-3)
 
 
 @pytest.mark.parametrize("n", [256, 300, 1100, 2048, 2300])
