@@ -51,7 +51,8 @@ gemm_nt_mfma_f64_kernel(GemmNTd g) {
     __shared__ __attribute__((aligned(16))) double lds[2][2][DK_BK][DK_LD];      // [buffer][A / B][k][i]
     const int per = (g.ntiles + 7) / 8;                                           // XCD b % 8 walks a contiguous range of tiles
     // (kend_col: the tiles' K ranges grow with the column block -- dealt out to the XCDs in turn, longest first, instead of in ranges)
-    const int t_idx = g.kend_col ? (int)blockIdx.x : (blockIdx.x % 8) * per + blockIdx.x / 8;
+    // (kstart_row: the inverse U U', K range shrinking with the tile's row -- the same remedy, see syrk_mfma.hip)
+    const int t_idx = g.kend_col || g.kstart_row ? (int)blockIdx.x : (blockIdx.x % 8) * per + blockIdx.x / 8;
     if (t_idx >= g.ntiles) return;
     int bi, bj;
     if (LOWER) tri_decode_d(t_idx, bi, bj);

@@ -153,7 +153,10 @@ gemm_nt_mfma_kernel(GemmNT g) {
     // XCD-aware remap: block b runs on XCD b % 8; give every XCD a contiguous range of tiles
     const int nwork = g.ntiles * g.ksplit;
     const int per = (nwork + 7) / 8;
-    const int w_idx = (blockIdx.x % 8) * per + blockIdx.x / 8;
+    // (kstart_row -- the inverse U U': a tile's K range shrinks with its row, from pp down to 128, and row-major ranges gave the
+    // first XCD ten times the work of the last: 6.5 ms at p = 10^4 where the flops need 2.5.  Tiles in launch order instead:
+    // longest first, consecutive tiles on different XCDs.)
+    const int w_idx = g.kstart_row ? (int)blockIdx.x : (blockIdx.x % 8) * per + blockIdx.x / 8;
     if (w_idx >= nwork) return;
     const int t_idx = w_idx % g.ntiles, split = w_idx / g.ntiles;
     int bi, bj;
