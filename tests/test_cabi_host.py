@@ -159,3 +159,17 @@ def test_fit_objects_mirror_show_and_plot_data():
         dz.cv(3)
     with pytest.raises(ValueError, match="Dantzig"):
         dz.fit_responses(np.zeros((30, 2)))
+
+
+def test_every_environment_knob_the_library_reads_is_in_the_integration_guide():
+    """INTEGRATION.md's knob table is the only place a maintainer learns what ADMM_HIP_* variables do: every name the sources
+    pass to getenv must appear there."""
+    import glob, os, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = set()
+    for f in glob.glob(os.path.join(root, "admm_amd", "csrc", "*")):
+        if f.endswith((".hip", ".h")):
+            names |= set(re.findall(r'getenv\("(ADMM_HIP_[A-Z0-9_]+)"', open(f).read()))
+    guide = open(os.path.join(root, "INTEGRATION.md")).read()
+    missing = sorted(n for n in names if n not in guide)
+    assert len(names) > 20 and not missing, missing
