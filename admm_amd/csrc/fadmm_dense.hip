@@ -13,6 +13,7 @@
 // batches and polls a sticky `done` word; no per-iteration synchronisation.
 #include "prep.h"
 #include "gemv_kernels.h"
+#include "gather_kernels.h"
 #include "solvers.h"
 #include <cstring>
 #include <cstdio>
@@ -36,6 +37,17 @@ struct DenseParams {
     int* done;
     double* trace; long long trace_cap;       // optional decision records (admm_hip_lad_traced / admm_hip_bp_traced), or NULL
     double* state; long long state_cap;       // optional [state_cap][5][dim] iterates x, z, y, adj_z, adj_y of every iteration (admm_hip_lad_state / admm_hip_bp_state), or NULL
+    // BP, one-pass form (round 5; bpn = 0: the two-pass form).  B = L^-1 A has B B' = I, so B x = B vec + B A'(AA')^-1 b - B B' B vec
+    // = L^-1 b =: w0 for EVERY iterate; with y = adj_y + rho (x - z) the n-vector B y follows from B adj_y and B z, B adj_z / B adj_y
+    // from the same accelerate / restart combinations as adj_z / adj_y, and w = B vec = B adj_z - B adj_y / rho needs no pass over B:
+    // only B z (z = prox output, sparse: gather_kernels.h) and the one streaming product B'w remain.
+    // The recurrence is dead-beat, not an integrator: if the held B adj_y is off by e, w is off by -e / rho, then B x is off by
+    // -e / rho as well and the true B y_new = B adj_y + e + rho (w0 - e / rho - B z_new) equals the held one.  What is left per iteration
+    // is (I - B B') B vec, i.e. the rounding of the factorisation, and the rounding of the elementwise updates.
+    int bpn;
+    const double* w0;
+    double *Bz0, *Bz1, *By0, *By1, *Badjy, *w;
+    const double* gpart; int gngroups; long long gpstride;
 };
 
 constexpr int kDenseThreads = 256;
@@ -128,6 +140,41 @@ dense_head_kernel(DenseParams q, int par) {
         // LAD: vec = y - adj_y / rho + adj_z (ADMMLAD.h:64-65);  BP: vec = -adj_y / rho + adj_z (ADMMBP.h:50-55)
         q.vec[i] = (q.prob == 0 ? q.data_vec[i] : 0.0) - adjy / rho + adjz;
     }
+    if (q.bpn > 0) {
+        // the same step for the n-vectors B z, B y, B adj_z, B adj_y (see DenseParams): B z_new = the gather launch's partial rows
+        // summed in group order; B y_new from the adj_y and the rho the tail used (in.rho); then w = B vec for this iteration
+        double* Bzc = cur ? q.Bz1 : q.Bz0; double* Byc = cur ? q.By1 : q.By0;
+        const double* Bzo = cur ? q.Bz0 : q.Bz1; const double* Byo = cur ? q.By0 : q.By1;
+        for (int i = blockIdx.x * kDenseThreads + threadIdx.x; i < q.bpn; i += gridDim.x * kDenseThreads) {
+#pragma clang fp contract(off)
+            double bz = 0.0;
+            for (int c0 = 0; c0 < q.gngroups; c0 += 8) {
+                double tv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) tv[u] = q.gpart[(size_t)min(c0 + u, q.gngroups - 1) * q.gpstride + i];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) bz += c0 + u < q.gngroups ? tv[u] : 0.0;
+            }
+            const double by = in.first ? 0.0 : q.Badjy[i] + in.rho * (q.w0[i] - bz);
+            const double bzo = Bzo[i], byo = Byo[i];
+            Bzc[i] = bz; Byc[i] = by;
+            double badjz, badjy;
+            if (out.restart) { badjz = bzo; badjy = byo; }
+            else { badjz = t1 * bz - t * bzo; badjy = t1 * by - t * byo; }
+            q.Badjy[i] = badjy;
+            q.w[i] = badjz - badjy / rho;
+        }
+    }
+}
+
+// BP one-pass form: B z_new for the z the tail of this iteration just wrote (gather over its non-zeros)
+__global__ void __launch_bounds__(kGatherThreads)
+bp_gather_kernel(DenseParams q, int par, GatherArgs<double> a) {
+    const DenseCtl c = load_ctl_vector(q.ctl + (par ^ 1));
+    if (c.done) return;
+    const int cur = (c.total - 1) & 1;
+    a.v = cur ? q.z0 : q.z1;                     // the tail wrote z_new into the buffer that is not `cur`
+    gather_body<double>(a, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 __global__ void __launch_bounds__(kDenseThreads)
@@ -442,10 +489,16 @@ void solve_bp(const DeviceData<double>& d, const admm_opts& opts, DenseResult& r
     }
     const long long ldp = round_up(p, 32);
     DevBuf<double> AAAb(ldp); AAAb.zero(st);
+    // One-pass form (default; ADMM_HIP_BP_ONEPASS=0 keeps the two streaming products of ADMMBP.h:65-66): only B' w streams per
+    // iteration, B vec comes from n-sized recurrences + a gather over the non-zeros of z (DenseParams), and the second stored
+    // layout of B (its transpose, another 8np bytes) is a setup temporary.
+    bool onepass = true;
+    if (const char* e = std::getenv("ADMM_HIP_BP_ONEPASS")) onepass = std::string(e) != "0";
     GemvT<double> gB, gBt;                       // t = B' w (p outputs) ; w = B vec (n outputs, via the stored transpose)
     gB.init(B.get(), d.ldx, n, p);
-    gBt.init(Bt.get(), ldbt, p, n);
-    { const bool nt = gemv_stream_nt(gB.bytes() + gBt.bytes()); gB.set_nt(nt); gBt.set_nt(nt); }
+    if (!onepass) gBt.init(Bt.get(), ldbt, p, n);
+    else Bt.release();
+    { const bool nt = gemv_stream_nt(gB.bytes() + (onepass ? 0 : gBt.bytes())); gB.set_nt(nt); if (!onepass) gBt.set_nt(nt); }
     gB.run(w0.get(), AAAb.get(), nullptr, st);
     ADMM_HIP_CHECK(hipStreamSynchronize(st));
     S.t_factor = now_s() - t0;
@@ -454,9 +507,30 @@ void solve_bp(const DeviceData<double>& d, const admm_opts& opts, DenseResult& r
     L.init(p, 1, opts, AAAb.get(), 0.0, st, res.trace_cap, res.state_cap);
     L.q.gout = gB.part.get(); L.q.gout_nseg = gB.pl.nseg; L.q.gout_stride = gB.stride;
 
+    DevBuf<double> nvec, gpart;                  // one-pass form: B z (2), B y (2), B adj_y, w ; partial rows of the gather
+    GatherPlan gp;
+    GatherArgs<double> ga{};
+    if (onepass) {
+        const long long ldw = round_up(n, 32);
+        nvec.alloc((size_t)6 * ldw); nvec.zero(st);
+        gp = plan_gather<double>(n, p);
+        gpart.alloc((size_t)gp.ngroups * gp.pstride); gpart.zero(st);
+        ga = gather_args<double>(gp, B.get(), d.ldx, n, p, nullptr, gpart.get(), nullptr);
+        L.q.bpn = n; L.q.w0 = w0.get();
+        L.q.Bz0 = nvec.get(); L.q.Bz1 = nvec.get() + ldw; L.q.By0 = nvec.get() + 2 * ldw; L.q.By1 = nvec.get() + 3 * ldw;
+        L.q.Badjy = nvec.get() + 4 * ldw; L.q.w = nvec.get() + 5 * ldw;
+        L.q.gpart = gpart.get(); L.q.gngroups = gp.ngroups; L.q.gpstride = gp.pstride;
+    }
+
     const int* skip = L.done.get();
     LoopTimes lt = run_until_done(st, skip, env_batch(8), (long long)opts.maxit + 2, [&](long long g) {
         L.head(g, st);
+        if (onepass) {
+            gB.run_partials(L.q.w, skip, st);               // B' w, w = B vec from the recurrences   (mat_vec_tprod, ADMMBP.h:66)
+            L.tail(g, st);
+            hipLaunchKernelGGL(bp_gather_kernel, dim3(gp.tiles, gp.ngroups), dim3(kGatherThreads), 0, st, L.q, (int)(g & 1), ga);      // B z_new
+            return;
+        }
         gBt.run_partials(L.vec.get(), skip, st);        // workspace = B vec   (mat_vec_prod,  ADMMBP.h:65)
         gB.run_partials_from(gBt, skip, st);            // B' workspace        (mat_vec_tprod, ADMMBP.h:66)
         L.tail(g, st);

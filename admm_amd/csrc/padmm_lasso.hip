@@ -16,6 +16,7 @@
 // buffer so that a multi-process build can all-reduce it between `pack` and `z`.
 #include "prep.h"
 #include "gemv_kernels.h"
+#include "gather_kernels.h"
 #include "solvers.h"
 #include "loop_driver.h"
 #include "comm.h"
@@ -32,6 +33,20 @@ static_assert(sizeof(ParCtl) == 64, "ParCtl layout");
 
 constexpr int kParMaxWorkers = 64;
 constexpr int kParThreads = 256;
+
+// One-pass form of a Woodbury worker (round 5).  The reference forms t_k = A_k rhs_k and then A_k's_k with s_k = (A_k A_k' + rho I)^-1 t_k
+// (PADMMLasso.h:23-29): two passes over the block.  With rhs_k = A_k'b_k - y_k + rho z:
+//     t_k = c_k - q_k + rho A_k z,     c_k = A_k (A_k'b_k) (once),   q_k = A_k y_k,   z = the prox output (sparse: gather_kernels.h)
+// and from y_k <- y_k + rho (x_k - z_new), x_k = (rhs_k - A_k's_k) / rho:  A_k x_k = (t_k - A_k A_k's_k) / rho = s_k, hence
+//     q_k <- q_k + rho (s_k - A_k z_new)
+// -- everything rows_k-sized and in double except the ONE stream A_k's_k.  The recurrence is dead-beat: an error e in the held q_k
+// puts -e into t_k, (A_k A_k' + rho I)^-1 carries it into s_k, and the true A_k x_k differs from s_k by exactly -e / rho (plus the
+// residual of the cached inverse), so the true A_k y_k,new and the held q_k,new agree again up to this iteration's own roundings.
+struct ParWb {
+    const float* spart;            // partial rows of s_k = Minv t_k (the worker's gM product), summed in row order like the next product's staging does
+    long long sstride;
+    int snseg, rows;               // rows = 0: a tall block (Cholesky branch), nothing to do
+};
 
 struct ParParams {
     int p, K, Kl, maxit, nlam, nwg;     // K: row blocks of the whole problem; Kl: blocks owned by this process
@@ -53,6 +68,9 @@ struct ParParams {
     double* trace; long long trace_cap;      // optional decision records (admm_hip_lasso_plan_trace_*), or NULL
     float* state; long long state_cap;       // optional [state_cap][(1 + 2 Kl) p]: z, x_0 .. x_{Kl-1}, y_0 .. y_{Kl-1} of every iteration, or NULL
     float* beta; int* niter; int* done;
+    // one-pass Woodbury workers (wb = NULL: the two-pass form): flat [Kl][wb_ld] vectors, gather partial rows [Kl][az_ng][wb_ld]
+    const ParWb* wb; int wb_ld, az_ng;
+    const double* cv; double* qv; float* tvec; const double* azpart;
 #ifdef ADMM_HIP_PROBE
     long long* probe;
 #endif
@@ -84,6 +102,42 @@ par_head_kernel(ParParams q) {
             }
         }
     }
+    if (q.wb != nullptr) {
+        // one-pass Woodbury workers: A_k z from the gather launch's partial rows (group order), q_k = A_k y_k advanced by the dual
+        // update the z kernel just made (its rho is the float one, PADMMBase.h:70-78), t_k = A_k rhs_k for the product with the inverse
+        const double rho_f = (double)(float)q.rho;
+        const int tot = q.Kl * q.wb_ld;
+        for (int gi = blockIdx.x * kParThreads + threadIdx.x; gi < tot; gi += gridDim.x * kParThreads) {
+            const int k = gi / q.wb_ld, i = gi - k * q.wb_ld;
+            const ParWb wb = q.wb[k];
+            if (i >= wb.rows) continue;
+            const double* ap = q.azpart + (size_t)k * q.az_ng * q.wb_ld + i;
+            double az = 0.0;
+            for (int c0 = 0; c0 < q.az_ng; c0 += 8) {
+                double tv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) tv[u] = ap[(size_t)min(c0 + u, q.az_ng - 1) * q.wb_ld];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) az += c0 + u < q.az_ng ? tv[u] : 0.0;
+            }
+            float sv = 0.f;
+            for (int r = 0; r < wb.snseg; ++r) sv += wb.spart[(size_t)r * wb.sstride + i];
+            const double qn = q.qv[gi] + rho_f * ((double)sv - az);
+            q.qv[gi] = qn;
+            q.tvec[gi] = (float)(q.cv[gi] - qn + q.rho * az);
+        }
+    }
+}
+
+// c_k = A_k (A_k'b_k) from the setup gather's partial rows (dense right-hand side), in double
+__global__ void par_wb_c_kernel(ParParams q, double* cv) {
+    const int gi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi >= q.Kl * q.wb_ld) return;
+    const int k = gi / q.wb_ld, i = gi - k * q.wb_ld;
+    double c = 0.0;
+    if (i < q.wb[k].rows)
+        for (int g = 0; g < q.az_ng; ++g) c += q.azpart[((size_t)k * q.az_ng + g) * q.wb_ld + i];
+    cv[gi] = c;
 }
 
 // pack: x_k from the mat-vec results, consensus sum w = sum_k (x_k + y_k / rho)   (PADMMLasso.h:65-68,101-105);
@@ -379,6 +433,14 @@ struct ParPlan final : LassoPlan {
     int gridAt = 0, gridM = 0, gridA = 0;
     size_t ldsAt = 0, ldsM = 0, ldsA = 0;
     bool peer_fused = false;          // multi-process over the PEER backend: the exchange is done by pack / z themselves
+    // one-pass Woodbury workers (ParWb): default; ADMM_HIP_PAR_ONEPASS=0 keeps the reference's two products and the stored transpose
+    bool onepass = false;
+    GatherPlan gp;
+    int wb_ld = 0, gather_tiles = 0;
+    DevBuf<ParWb> wbd;
+    DevBuf<double> cv, qv, azpart;
+    DevBuf<float> tvec;
+    DevBuf<GatherArgs<float>> bG;
     DevBuf<float> state;
     long long state_cap = 0;
     void enable_state(long long cap) override {
@@ -433,6 +495,8 @@ struct ParPlan final : LassoPlan {
         // row partition (PADMMLasso.h:163-179) and per-worker factorisations (:48-63)
         Ab.alloc((size_t)Kl * ldv); Ab.zero(st);
         W.resize(Kl);
+        onepass = true;
+        if (const char* e = std::getenv("ADMM_HIP_PAR_ONEPASS")) onepass = std::string(e) != "0";
         double t_gram = 0, t_fac = 0;
         for (int k = 0; k < Kl; ++k) {
             ParWorker& w = W[k];
@@ -462,10 +526,12 @@ struct ParPlan final : LassoPlan {
                 ADMM_HIP_CHECK(hipStreamSynchronize(st));
                 t_gram += now_s() - t0; t0 = now_s();
                 par_inverse(w.Minv.get(), w.ldm, w.rows, rho, st);
-                w.ldat = round_up(p, 32);
-                w.At.alloc((size_t)w.ldat * w.rows); w.At.zero(st);
-                transpose<float>(w.A.get(), w.lda, w.rows, p, w.At.get(), w.ldat, st);
-                w.gAt.init(w.At.get(), w.ldat, p, w.rows);
+                if (!onepass) {
+                    w.ldat = round_up(p, 32);
+                    w.At.alloc((size_t)w.ldat * w.rows); w.At.zero(st);
+                    transpose<float>(w.A.get(), w.lda, w.rows, p, w.At.get(), w.ldat, st);
+                    w.gAt.init(w.At.get(), w.ldat, p, w.rows);
+                }
                 w.gM.init(w.Minv.get(), w.ldm, w.rows, w.rows);
                 w.gA.init(w.A.get(), w.lda, w.rows, p);
                 w.tvec.alloc(w.ldm); w.svec.alloc(w.ldm); w.tvec.zero(st); w.svec.zero(st);
@@ -477,9 +543,14 @@ struct ParPlan final : LassoPlan {
         d.X.release();
         {   // streaming policy of the products from the working set of ONE iteration on this GPU: all local workers' matrices
             size_t ws = 0;
-            for (int k = 0; k < Kl; ++k) ws += W[k].wide ? W[k].gAt.bytes() + W[k].gM.bytes() + W[k].gA.bytes() : W[k].gM.bytes();
+            for (int k = 0; k < Kl; ++k) ws += W[k].wide ? (onepass ? 0 : W[k].gAt.bytes()) + W[k].gM.bytes() + W[k].gA.bytes() : W[k].gM.bytes();
             const bool nt = gemv_stream_nt(ws);
-            for (int k = 0; k < Kl; ++k) { W[k].gM.set_nt(nt); if (W[k].wide) { W[k].gAt.set_nt(nt); W[k].gA.set_nt(nt); } }
+            for (int k = 0; k < Kl; ++k) { W[k].gM.set_nt(nt); if (W[k].wide) { if (!onepass) W[k].gAt.set_nt(nt); W[k].gA.set_nt(nt); } }
+        }
+        {   // one-pass form only where a Woodbury worker exists
+            bool any_wide = false;
+            for (int k = 0; k < Kl; ++k) any_wide = any_wide || W[k].wide;
+            onepass = onepass && any_wide;
         }
 
         peer_fused = pb.dist && ci.active && ci.backend == COMM_PEER;
@@ -504,6 +575,38 @@ struct ParPlan final : LassoPlan {
         probe.alloc((size_t)4096 * 4 * 8); probe.zero(st);
         q.probe = probe.get();
 #endif
+        if (onepass) {
+            int max_rows = 0, nwide = 0;
+            for (int k = 0; k < Kl; ++k) if (W[k].wide) { max_rows = std::max(max_rows, W[k].rows); ++nwide; }
+            wb_ld = round_up(max_rows, 32);
+            gp = plan_gather<float>(max_rows, p, nwide);
+            gather_tiles = gp.tiles;
+            std::vector<ParWb> hwb(Kl);
+            std::vector<GatherArgs<float>> hG(Kl), hG0(Kl);
+            cv.alloc((size_t)Kl * wb_ld); qv.alloc((size_t)Kl * wb_ld); tvec.alloc((size_t)Kl * wb_ld);
+            azpart.alloc((size_t)Kl * gp.ngroups * wb_ld);
+            cv.zero(st); qv.zero(st); tvec.zero(st); azpart.zero(st);
+            GatherPlan gk = gp; gk.pstride = wb_ld;
+            for (int k = 0; k < Kl; ++k) {
+                ParWorker& w = W[k];
+                hwb[k].spart = w.wide ? w.gM.part.get() : nullptr; hwb[k].sstride = w.gM.stride; hwb[k].snseg = w.gM.pl.nseg;
+                hwb[k].rows = w.wide ? w.rows : 0;
+                double* part = azpart.get() + (size_t)k * gp.ngroups * wb_ld;
+                hG[k] = gather_args<float>(gk, w.A.get(), w.lda, hwb[k].rows, p, z.get(), part, done.get());
+                hG0[k] = gather_args<float>(gk, w.A.get(), w.lda, hwb[k].rows, p, Ab.get() + (size_t)k * ldv, part, nullptr);
+            }
+            wbd.alloc(Kl); bG.alloc(Kl);
+            ADMM_HIP_CHECK(hipMemcpyAsync(wbd.get(), hwb.data(), Kl * sizeof(ParWb), hipMemcpyHostToDevice, st));
+            q.wb = wbd.get(); q.wb_ld = wb_ld; q.az_ng = gp.ngroups;
+            q.cv = cv.get(); q.qv = qv.get(); q.tvec = tvec.get(); q.azpart = azpart.get();
+            // c_k = A_k (A_k'b_k): the same gather with the dense A_k'b_k as right-hand side, once
+            ADMM_HIP_CHECK(hipMemcpyAsync(bG.get(), hG0.data(), Kl * sizeof(GatherArgs<float>), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL((gather_batch_kernel<float>), dim3(gather_tiles, gp.ngroups, Kl), dim3(kGatherThreads), 0, st, bG.get());
+            hipLaunchKernelGGL(par_wb_c_kernel, dim3((Kl * wb_ld + 255) / 256), dim3(256), 0, st, q, cv.get());
+            ADMM_HIP_CHECK(hipStreamSynchronize(st));              // hG0 is a host temporary; the per-iteration blocks replace it
+            ADMM_HIP_CHECK(hipMemcpyAsync(bG.get(), hG.data(), Kl * sizeof(GatherArgs<float>), hipMemcpyHostToDevice, st));
+            ADMM_HIP_CHECK(hipStreamSynchronize(st));
+        }
         // ---- batched launches of the workers' products (ADMM_HIP_PAR_BATCH=0: one launch per worker and product, as before)
         {
             const char* e = std::getenv("ADMM_HIP_PAR_BATCH");
@@ -519,10 +622,14 @@ struct ParPlan final : LassoPlan {
                     if (!bt_wide) {
                         hM.push_back(w.gM.args_partials(rk, skip));
                     } else {
-                        hAt.push_back(w.gAt.args_partials(rk, skip));
-                        hM.push_back(w.gM.args_partials_from(w.gAt, skip));
+                        if (onepass) {
+                            hM.push_back(w.gM.args_partials(tvec.get() + (size_t)k * wb_ld, skip));
+                        } else {
+                            hAt.push_back(w.gAt.args_partials(rk, skip));
+                            hM.push_back(w.gM.args_partials_from(w.gAt, skip));
+                            gridAt = std::max(gridAt, w.gAt.pl.grid); ldsAt = std::max(ldsAt, w.gAt.pl.lds_bytes);
+                        }
                         hA.push_back(w.gA.args_partials_from(w.gM, skip));
-                        gridAt = std::max(gridAt, w.gAt.pl.grid); ldsAt = std::max(ldsAt, w.gAt.pl.lds_bytes);
                         gridA = std::max(gridA, w.gA.pl.grid); ldsA = std::max(ldsA, w.gA.pl.lds_bytes);
                     }
                     gridM = std::max(gridM, w.gM.pl.grid); ldsM = std::max(ldsM, w.gM.pl.lds_bytes);
@@ -547,6 +654,10 @@ struct ParPlan final : LassoPlan {
         beta.zero(st); niter.zero(st);
         const int init_n = std::max(p, nwg * 8);
         hipLaunchKernelGGL(par_init_kernel, dim3((init_n + 255) / 256), dim3(256), 0, st, q, lam_int[0]);
+        if (onepass) {               // y_k = 0, z = 0: q_k = A_k z = 0, and no s_k yet
+            qv.zero(st); azpart.zero(st);
+            for (int k = 0; k < Kl; ++k) if (W[k].wide) W[k].gM.part.zero(st);
+        }
         if (q.state != nullptr)      // record 0 of the iterate dump: A_k'b_k as the workers hold them, in the x_k slots
             for (int k = 0; k < Kl; ++k)
                 ADMM_HIP_CHECK(hipMemcpyAsync(q.state + (size_t)(1 + k) * p, Ab.get() + (size_t)k * ldv, (size_t)p * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -559,7 +670,7 @@ struct ParPlan final : LassoPlan {
             if (batched) {
                 // all workers' products of one kind in ONE launch (bit-identical to the per-worker launches below)
                 if (bt_wide) {
-                    launch_gemv_t_batch<float>(bAt.get(), Kl, gridAt, ldsAt, bt_nt, st);      // t_k = A_k rhs_k
+                    if (!onepass) launch_gemv_t_batch<float>(bAt.get(), Kl, gridAt, ldsAt, bt_nt, st);      // t_k = A_k rhs_k   (one-pass form: formed by the head)
                     launch_gemv_t_batch<float>(bM.get(), Kl, gridM, ldsM, bt_nt, st);         // s_k = (A_k A_k' + rho I)^-1 t_k
                     launch_gemv_t_batch<float>(bA.get(), Kl, gridA, ldsA, bt_nt, st);         // A_k' s_k
                 } else {
@@ -573,8 +684,12 @@ struct ParPlan final : LassoPlan {
                     w.gM.run_partials(rk, skip, st);                       // x = (A'A + rho I)^-1 rhs
                 } else {
                     // chained without reduction launches: each product sums the previous one's partial rows while staging
-                    w.gAt.run_partials(rk, skip, st);                      // t = A rhs
-                    w.gM.run_partials_from(w.gAt, skip, st);               // s = (AA' + rho I)^-1 t
+                    if (onepass) {
+                        w.gM.run_partials(tvec.get() + (size_t)k * wb_ld, skip, st);      // s = (AA' + rho I)^-1 t, t from the head
+                    } else {
+                        w.gAt.run_partials(rk, skip, st);                  // t = A rhs
+                        w.gM.run_partials_from(w.gAt, skip, st);           // s = (AA' + rho I)^-1 t
+                    }
                     w.gA.run_partials_from(w.gM, skip, st);                // A' s
                 }
             }
@@ -583,6 +698,7 @@ struct ParPlan final : LassoPlan {
                 const PeerExchange ex = comm_peer_begin(par_peer_norm_offset(p) + 3 * sizeof(double));
                 hipLaunchKernelGGL(par_pack_kernel<1>, dim3(nwg_e), dim3(kParThreads), 0, st, q, ex);
                 hipLaunchKernelGGL(par_z_kernel<1>, dim3(nwg), dim3(kParThreads), 0, st, q, par, ex);
+                if (onepass) hipLaunchKernelGGL((gather_batch_kernel<float>), dim3(gather_tiles, gp.ngroups, Kl), dim3(kGatherThreads), 0, st, bG.get());
                 return;
             }
             hipLaunchKernelGGL(par_pack_kernel<0>, dim3(nwg_e), dim3(kParThreads), 0, st, q, PeerExchange{});
@@ -590,6 +706,7 @@ struct ParPlan final : LassoPlan {
             // RCCL all-reduce over xGMI (no-op in a single process)
             if (pb.dist) allreduce_sum_f32_f64(wsum.get(), (size_t)p, nsum.get(), 3, st);
             hipLaunchKernelGGL(par_z_kernel<0>, dim3(nwg), dim3(kParThreads), 0, st, q, par, PeerExchange{});
+            if (onepass) hipLaunchKernelGGL((gather_batch_kernel<float>), dim3(gather_tiles, gp.ngroups, Kl), dim3(kGatherThreads), 0, st, bG.get());      // A_k z_new over the non-zeros of z
         });
         S.t_loop = lt.wall_s; S.loop_ms_events = lt.events_ms; S.xupdate_launches = lt.launched;
         S.exchange_variant = !pb.dist ? 0 : (peer_fused ? 2 : 1);
