@@ -288,28 +288,38 @@ class ADMM_Enet(ADMM_Lasso):
         return ADMM_Lasso_fit(lam_out, beta, niter, stats.as_dict())
 
 
+class _Records(np.ndarray):
+    """A record buffer that carries its own capacity (`cap`, 0 = disabled): a one-record request is not mistaken for 'off'
+    (the capacity used to be inferred from shape[0] > 1)."""
+    cap = 0
+
+
+def _records(shape, cap):
+    a = np.zeros(shape, dtype=np.float64).view(_Records)
+    a.cap = int(cap)
+    return a
+
+
 def _trace_buffers(maxit):
     cap = maxit + 8 if maxit > 0 else 0
-    return np.zeros((max(cap, 1), _lib.TRACE_FIELDS), dtype=np.float64), ctypes.c_longlong(0)
+    return _records((max(cap, 1), _lib.TRACE_FIELDS), cap), ctypes.c_longlong(0)
 
 
 def _trace_args(tr, ntr):
-    cap = tr.shape[0] if tr.shape[0] > 1 else 0
-    if cap == 0:
+    if tr.cap == 0:
         return None, 0, None
-    return tr.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), cap, ctypes.byref(ntr)
+    return tr.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), tr.cap, ctypes.byref(ntr)
 
 
 def _state_buffers(nrec, dim):
     nrec = int(nrec) if nrec else 0
-    return np.zeros((max(nrec, 1), 5, dim), dtype=np.float64), ctypes.c_longlong(0)
+    return _records((max(nrec, 1), 5, dim), nrec), ctypes.c_longlong(0)
 
 
 def _state_args(sbuf, nst):
-    cap = sbuf.shape[0] if sbuf.shape[0] > 1 else 0
-    if cap == 0:
+    if sbuf.cap == 0:
         return None, 0, None
-    return sbuf.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), cap, ctypes.byref(nst)
+    return sbuf.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), sbuf.cap, ctypes.byref(nst)
 
 
 class ADMM_BP_fit:

@@ -28,17 +28,42 @@ def _sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
-def _newest_header():
-    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    hs.append(os.path.join(HERE, "..", "include", "admm_hip.h"))
-    return max(os.path.getmtime(h) for h in hs)
+PUBLIC_HEADER = os.path.join(HERE, "..", "include", "admm_hip.h")
+
+
+def _headers():
+    hs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
+    if os.path.exists(PUBLIC_HEADER):
+        hs.append(PUBLIC_HEADER)
+    return hs
+
+
+def _object_key(src, flags):
+    """What an object file was compiled from: the translation unit, EVERY header (any of them may be included) and the flags, by
+    content.  Modification times are not evidence (rsync -t, archive extraction: an object newer than a changed source), ADVICE r4."""
+    import hashlib
+    h = hashlib.sha256()
+    h.update(" ".join(flags).encode())
+    for p in [os.path.join(CSRC, src)] + _headers():
+        h.update(os.path.basename(p).encode())
+        with open(p, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def _object_is_current(obj, key):
+    try:
+        with open(obj + ".key") as fh:
+            return os.path.exists(obj) and fh.read().strip() == key
+    except OSError:
+        return False
 
 
 def _compile(src, force):
     obj = os.path.join(OBJ, src[:-4] + ".o")
     srcp = os.path.join(CSRC, src)
-    if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(srcp)
-            and os.path.getmtime(obj) >= _newest_header()):
+    key = _object_key(src, CXXFLAGS)
+    if not force and _object_is_current(obj, key):
         return obj, False
     cmd = [HIPCC] + CXXFLAGS + ["-c", srcp, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -46,6 +71,8 @@ def _compile(src, force):
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
     if r.stderr.strip():
         sys.stderr.write(r.stderr)
+    with open(obj + ".key", "w") as fh:
+        fh.write(key + "\n")
     return obj, True
 
 
@@ -54,7 +81,8 @@ def source_hash():
     import hashlib
     h = hashlib.sha256()
     files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
-    files.append(os.path.join(HERE, "..", "include", "admm_hip.h"))
+    if os.path.exists(PUBLIC_HEADER):                      # a package shipped without include/: the hash then covers csrc/ only
+        files.append(PUBLIC_HEADER)
     for p in files:
         h.update(os.path.basename(p).encode())
         with open(p, "rb") as fh:
@@ -100,13 +128,15 @@ def sanitizer_runtime():
 def _compile_san(src, force):
     obj = os.path.join(OBJ_SAN, src[:-4] + ".o")
     srcp = os.path.join(CSRC, src)
-    if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(srcp)
-            and os.path.getmtime(obj) >= _newest_header()):
-        return obj, False
     flags = [f for f in CXXFLAGS if f != "-O3"] + SANFLAGS
+    key = _object_key(src, flags)
+    if not force and _object_is_current(obj, key):
+        return obj, False
     r = subprocess.run([HIPCC] + flags + ["-c", srcp, "-o", obj], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc (sanitizers) failed for {src}:\n{r.stdout}\n{r.stderr}")
+    with open(obj + ".key", "w") as fh:
+        fh.write(key + "\n")
     return obj, True
 
 
@@ -154,7 +184,7 @@ def build(force=False, verbose=True):
             print(f"[admm_amd.build] linked {LIB} ({len(objs)} objects)")
     elif verbose:
         print(f"[admm_amd.build] up to date: {LIB}")
-    _write_hash(LIB)
+    _write_hash(LIB)             # every object above was verified against the CONTENT of its sources (or just compiled from them)
     return LIB
 
 

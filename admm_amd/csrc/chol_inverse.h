@@ -5,6 +5,7 @@
 #pragma once
 #include "admm_internal.h"
 #include "device_utils.h"
+#include "comm.h"
 
 namespace admm {
 
@@ -208,6 +209,9 @@ __global__ void __launch_bounds__(256) panel_pack_kernel(const T* __restrict__ A
     else { const T v = stage[(size_t)c * len + idx]; if (idx < nl) Aw[col + r0 + idx] = v; else Uw[col + (idx - nl)] = v; }
 }
 
+// the not-SPD flag of the distributed factorisation as a double, so that the exchange layer's all-reduce can carry it
+static __global__ void info_to_double_kernel(const int* info, double* out) { if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = (double)*info; }
+
 template <typename T, typename Gemm, typename Bcast>
 DevBuf<T> cholesky_linvt_blocked_dist(T* A, long long lda, int p, hipStream_t st, Gemm gemm, int nranks, int rank, Bcast bcast, double* flops) {
     const int nb = (p + 127) / 128;
@@ -250,8 +254,21 @@ DevBuf<T> cholesky_linvt_blocked_dist(T* A, long long lda, int p, hipStream_t st
         }
     }
     int h = 0;
-    ADMM_HIP_CHECK(hipMemcpyAsync(&h, info.get(), sizeof(int), hipMemcpyDeviceToHost, st));
-    ADMM_HIP_CHECK(hipStreamSynchronize(st));
+    if (nranks > 1) {
+        // only the owner of a failing diagonal block sees the flag: summed over the ranks, so that EVERY rank throws the same error
+        // instead of N - 1 of them running on into the solver's exchanges and timing out there
+        DevBuf<double> hd(1);
+        hipLaunchKernelGGL(info_to_double_kernel, dim3(1), dim3(64), 0, st, info.get(), hd.get());
+        allreduce_sum_f64(hd.get(), 1, st);
+        double hs = 0;
+        ADMM_HIP_CHECK(hipMemcpyAsync(&hs, hd.get(), sizeof(double), hipMemcpyDeviceToHost, st));
+        ADMM_HIP_CHECK(hipStreamSynchronize(st));
+        h = hs != 0.0 ? (int)hs : 0;
+        if (hs != 0.0 && h == 0) h = -1;
+    } else {
+        ADMM_HIP_CHECK(hipMemcpyAsync(&h, info.get(), sizeof(int), hipMemcpyDeviceToHost, st));
+        ADMM_HIP_CHECK(hipStreamSynchronize(st));
+    }
     if (h != 0) throw Error(ADMM_ERR_NOT_SPD, "Cholesky: matrix is not positive definite (pivot " + std::to_string(h) + ")");
     if (flops) *flops = fl;
     return U;

@@ -1738,6 +1738,9 @@ struct WidePlan final : LassoPlan {
         beta.zero(st); niter.zero(st);
         *hflag.p = 0;
         if (persist_rows) { rhint.zero(st); rerr.zero(st); }
+        // records written inside a persistent stretch store x for the listed columns only ("zeros elsewhere"): a second run() on the
+        // same plan must not see the previous run's entries
+        if (q.state != nullptr) ADMM_HIP_CHECK(hipMemsetAsync(state.get(), 0, state.n * sizeof(float), st));
         const int init_n = std::max(std::max(n, p), nwg_tail * 8);
         hipLaunchKernelGGL(wide_init_kernel, dim3((init_n + 255) / 256), dim3(256), 0, st, q, rho0, lam_int[0]);
         const int batch = pb.batch_iters > 0 ? (pb.batch_iters + 1) / 2 * 2 : 16;
@@ -1781,10 +1784,18 @@ struct WidePlan final : LassoPlan {
         if (persist_rows) {
             int herr = 0;
             ADMM_HIP_CHECK(hipMemcpy(&herr, rerr.get(), sizeof(int), hipMemcpyDeviceToHost));
-            // A hand-over that timed out (the stretch's workgroups were not co-resident: a busy or shared device): every workgroup of
-            // that launch left WITHOUT touching x / A x / z / y / the control block, the two-launch path carried on from the intact
-            // state and the result is valid.  Not an error: the stretch is switched off for the rest of this plan's life.
-            if (herr) { persist_rows = false; S.exchange_variant = -1; }
+            // A hand-over that timed out (the stretch's workgroups were not co-resident: a busy or shared device).  The waits are per
+            // workgroup, so one workgroup may have left without its write-back while the others completed theirs: the state behind
+            // such a launch cannot be trusted.  The whole path is discarded and run again with the stretch switched off
+            // for the rest of this plan's life; persist_iter = -1 in the stats of that run says so.
+            if (herr) {
+                persist_rows = false;
+                rstat.zero(st);
+                ADMM_HIP_CHECK(hipStreamSynchronize(st));
+                run(res);
+                res.stats.persist_iter = -1;
+                return;
+            }
             unsigned long long hs[16] = {0};
             ADMM_HIP_CHECK(hipMemcpy(hs, rstat.get(), sizeof(hs), hipMemcpyDeviceToHost));
             S.persist_iter = (long long)hs[0];

@@ -237,7 +237,7 @@ def consensus_child(a, backend, out_path):
     agree = _ranks_agree(fit.niter, torch, dist, multi, dev)
     if rank == 0:
         rows = n // K
-        bytes_per_gpu = (K // world) * (8.0 * rows * p + 4.0 * rows * rows)      # per block: A and A' streamed once each + the cached (AA'+rho I)^-1
+        bytes_per_gpu = (K // world) * (4.0 * rows * p + 4.0 * rows * rows)      # per block: A streamed ONCE (A_k's_k; A_k rhs_k by recurrence + gather, round 5) + the cached (AA'+rho I)^-1
         res = {"workload": "admm_lasso$parallel(8) n=10000 p=100000 (BASELINE configs[3]), 8 row blocks spread over the GPUs, 3 lambdas down to 0.3 lambda_max, run to convergence (maxit 4000)",
                "scaling": "strong",
                "converged": bool(all(int(v) <= 4000 for v in fit.niter)), "ranks_agree_on_niter": agree,
@@ -417,6 +417,7 @@ def config_child(a, name, out_path):
     g = torch.Generator(device=dev)
     g.manual_seed(a.seed)
     extra = {}
+    survey_bytes = None
     if name == "c3":
         n, p = 2000, 200000
         xt, y, _ = _gen_device(torch, dev, g, n, p, 2.0, 100)
@@ -431,16 +432,21 @@ def config_child(a, name, out_path):
         # (a lower bound of the algorithmic bytes, so `frac` is a lower bound too)
         bytes_iter = 4.0 * n * p * reg / max(1, tot)
         extra = {"regular_iterations": reg, "nnz_last_lambda": int(np.count_nonzero(fit.beta_dense[1:, -1])), "persist_iter": int(fit.stats["persist_iter"]),
-                 "kernel": "wide_x_kernel / wide_act_persist_kernel (x-update of ADMMLassoWide)", "bytes_note": "regular-step stream of X only (lower bound)"}
+                 "kernel": "wide_x_kernel / wide_rows_persist_kernel (x-update of ADMMLassoWide)", "bytes_note": "regular-step stream of X only (lower bound)"}
     elif name == "c4":
         n, p, K = 10000, 100000, 8
         xt, y, _ = _gen_device(torch, dev, g, n, p, 2.0, 100)
         model = admm_lasso(DevicePtr(xt.data_ptr()), DevicePtr(y.data_ptr()), n=n, p=p).penalty(nlambda=3, lambda_min_ratio=0.3).parallel(K).opts(maxit=4000)
         model.fit()
         fit = model.fit()
-        bytes_iter = 8.0 * n * p + 4.0 * K * (n / K) ** 2
+        # round 5, one-pass Woodbury workers: ONE stream of every A_k per iteration (A_k's_k) + the cached inverses; A_k rhs_k comes
+        # from rows_k-sized recurrences and a gather over the non-zero columns of z (4 n nnz(z) bytes, not recorded per iteration
+        # and not counted: lower bound).  SURVEY section 8(d) prices the reference's two streams: quoted beside it.
+        bytes_iter = 4.0 * n * p + 4.0 * K * (n / K) ** 2
+        survey_bytes = 8.0 * n * p + 4.0 * K * (n / K) ** 2
         extra = {"K": K, "niter": [int(v) for v in fit.niter], "converged": bool(all(int(v) <= 4000 for v in fit.niter)),
-                 "kernel": "gemv_t_batch_kernel (A_k rhs and A_k' s of the 8 Woodbury workers, PADMMLasso.h:22-30)"}
+                 "kernel": "gemv_t_batch_kernel (A_k' s_k of the 8 Woodbury workers, PADMMLasso.h:22-30; A_k rhs_k by recurrence + gather_batch_kernel)",
+                 "bytes_note": "per ITERATION, HIP events around the loop: one stream of A (4np) + the inverses; the gather over supp(z) is not counted (lower bound)"}
     elif name == "c5lad":
         n, p = 50000, 5000
         xt, y, _ = _gen_device(torch, dev, g, n, p, 2.0, p, dense_beta=True)
@@ -461,8 +467,12 @@ def config_child(a, name, out_path):
         err = beta - b.cpu().numpy()
         extra = {"recovery_error_range": [float(err.min()), float(err.max())]}
         if name == "c5bp":
-            bytes_iter = 16.0 * n * p
-            extra["kernel"] = "gemv_t_kernel<double> (B v and B' w, B = L^-1 A: ADMMBP.h:60-67)"
+            # round 5, one-pass form: only B'w streams (8np); B vec from n-sized recurrences + a gather over the non-zeros of z
+            # (8 n nnz(z) bytes, not counted: lower bound).  SURVEY section 8(d) prices the reference's two products (16np).
+            bytes_iter = 8.0 * n * p
+            survey_bytes = 16.0 * n * p
+            extra["kernel"] = "gemv_t_kernel<double> (B' w, B = L^-1 A: ADMMBP.h:60-67; B vec by recurrence + bp_gather_kernel)"
+            extra["bytes_note"] = "per ITERATION, HIP events around the loop: one stream of B (8np); the gather over supp(z) is not counted (lower bound)"
         else:
             it = int(fit.stats["total_iter"])
             reg = (it + 9) // 10
@@ -483,6 +493,9 @@ def config_child(a, name, out_path):
                 "roofline": {"bound": "hbm", "kernel": extra.pop("kernel", None), "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                              "frac": achieved / HBM_PEAK, "traffic": None, "algorithmic_bytes_per_iteration": bytes_iter,
                              "avg_iteration_ms": t_iter * 1e3, "note": extra.pop("bytes_note", "per ITERATION (all launches of one ADMM iteration), HIP events around the loop")}})
+    if survey_bytes is not None:      # what SURVEY section 8(d) counts for the reference's arithmetic on the same iteration (may exceed the peak: bytes never read)
+        res["roofline"]["survey_8d_bytes_per_iteration"] = survey_bytes
+        res["roofline"]["survey_8d_equivalent_GBps"] = survey_bytes / t_iter / 1e9
     res.update(extra)
     with open(out_path, "w") as f:
         json.dump(res, f)

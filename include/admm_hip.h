@@ -92,7 +92,7 @@ typedef struct admm_stats {
                               read by the solver's own kernels (producer and consumer launches), 3 the same with producer and consumer in ONE
                               launch (chosen only when that launch is resident as a whole: its workgroups wait for one another) */
     int refine;            /* tall path: 1 = every x-update refined once with a double-precision residual (ADMM_HIP_REFINE=1) */
-    long long persist_iter;/* wide path: iterations that ran inside persistent active-set launches (of total_iter) */
+    long long persist_iter;/* wide path: iterations that ran inside persistent active-set launches (of total_iter); -1: a hand-over of a stretch timed out and the whole path was run again without stretches */
     double factor_flops;   /* row-sharded tall solver: flops of the Cholesky + inverse THIS rank performed when the factorisation is
                               distributed over the ranks (block columns dealt out, panels broadcast); 0 when every
                               rank factorises the whole matrix */

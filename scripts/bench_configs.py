@@ -68,7 +68,7 @@ if "c4" in which:       # consensus Lasso n=10000 p=100000, 8 row blocks on ONE 
     xt, y, _ = gen(n, p, 2.0, 100)
     # a lambda range on which the consensus iteration converges (like bench.py's child run): the rate is not that of runs cut off at maxit
     fit = admm_lasso(DevicePtr(xt.data_ptr()), DevicePtr(y.data_ptr()), n=n, p=p).penalty(nlambda=3, lambda_min_ratio=0.3).parallel(K).opts(maxit=4000).fit()
-    report("C4 admm_lasso$parallel(8) n=10000 p=100000 (8 virtual workers on 1 GPU), 3 lambdas down to 0.3 lambda_max, run to convergence", fit, 8.0 * n * p + 4.0 * K * (n / K) ** 2,
+    report("C4 admm_lasso$parallel(8) n=10000 p=100000 (8 virtual workers on 1 GPU), 3 lambdas down to 0.3 lambda_max, run to convergence", fit, 4.0 * n * p + 4.0 * K * (n / K) ** 2,
            {"niter": [int(v) for v in fit.niter]})
     del xt
     torch.cuda.empty_cache()
@@ -85,7 +85,7 @@ if "c5bp" in which:     # BP n=5000 p=50000 fp64, 500 non-zeros, exact y
     fit = admm_bp(DevicePtr(xt.data_ptr()), DevicePtr(y.data_ptr()), n=n, p=p).fit()
     beta = np.asarray(fit.beta.todense()).ravel()
     err = beta - b.cpu().numpy()
-    report("C5 admm_bp n=5000 p=50000 fp64", fit, 16.0 * n * p, {"recovery_error_range": [float(err.min()), float(err.max())]})
+    report("C5 admm_bp n=5000 p=50000 fp64", fit, 8.0 * n * p, {"recovery_error_range": [float(err.min()), float(err.max())]})
 if "c5parbp" in which:  # the same problem by the column-block sharing solver (admm_bp$parallel(8): admm_hip_parbp), 8 blocks on ONE GPU
     n, p = 5000, 50000
     xt, y, b = gen(n, p, 1.0, 500, noise=False)
