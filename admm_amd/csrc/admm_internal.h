@@ -137,6 +137,14 @@ inline void read_back(void* dst, const void* src, size_t bytes, hipStream_t st) 
     }
 }
 
+// Host-to-device transfer of the CALLER's data (x, y: pageable memory borrowed from R) through pinned staging of our own, the
+// mirror image of read_back(): worker threads copy a piece into a pinned slot, the calling thread DMAs it from there while the
+// next piece is being copied (prep.hip).  The runtime's pageable path -- a staging copy inside hipMemcpy -- is what returned stale
+// lines in the D2H direction under host oversubscription (profiles/r04_transient_stale_lines.md); a corrupted INPUT line would be
+// silent, so large inputs do not go through it at all.  Returns with the bytes in device memory.
+// ADMM_HIP_H2D=pageable: plain hipMemcpy (A/B).
+void write_device(void* dst, const void* src, size_t bytes);
+
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 inline size_t round_up_sz(size_t v, size_t m) { return (v + m - 1) / m * m; }
 

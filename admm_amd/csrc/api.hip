@@ -215,8 +215,8 @@ static void lasso_cv(const double* x, const double* y, int n, int p, int mem, co
     const double* xd = x; const double* yd = y;
     if (mem == ADMM_MEM_HOST) {
         xd_own.alloc((size_t)n * p); yd_own.alloc(n);
-        ADMM_HIP_CHECK(hipMemcpyAsync(xd_own.get(), x, (size_t)n * p * sizeof(double), hipMemcpyHostToDevice, st.s));
-        ADMM_HIP_CHECK(hipMemcpyAsync(yd_own.get(), y, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st.s));
+        write_device(xd_own.get(), x, (size_t)n * p * sizeof(double));
+        write_device(yd_own.get(), y, (size_t)n * sizeof(double));
         ADMM_HIP_CHECK(hipStreamSynchronize(st.s));
         xd = xd_own.get(); yd = yd_own.get();
     }
@@ -357,8 +357,8 @@ static void lasso_multi(const double* x, const double* Y, int n, int p, int m, i
     const double* xd = x; const double* yd = Y;
     if (mem == ADMM_MEM_HOST) {
         xd_own.alloc((size_t)n * p); yd_own.alloc((size_t)n * m);
-        ADMM_HIP_CHECK(hipMemcpyAsync(xd_own.get(), x, (size_t)n * p * sizeof(double), hipMemcpyHostToDevice, st.s));
-        ADMM_HIP_CHECK(hipMemcpyAsync(yd_own.get(), Y, (size_t)n * m * sizeof(double), hipMemcpyHostToDevice, st.s));
+        write_device(xd_own.get(), x, (size_t)n * p * sizeof(double));
+        write_device(yd_own.get(), Y, (size_t)n * m * sizeof(double));
         ADMM_HIP_CHECK(hipStreamSynchronize(st.s));
         xd = xd_own.get(); yd = yd_own.get();
     }
@@ -943,8 +943,8 @@ int admm_hip_test_cv_fold_system(const double* x, const double* y, int n, int p,
         require_device();
         Stream st;
         DevBuf<double> xd((size_t)n * p), yd(n);
-        ADMM_HIP_CHECK(hipMemcpyAsync(xd.get(), x, (size_t)n * p * sizeof(double), hipMemcpyHostToDevice, st.s));
-        ADMM_HIP_CHECK(hipMemcpyAsync(yd.get(), y, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st.s));
+        write_device(xd.get(), x, (size_t)n * p * sizeof(double));
+        write_device(yd.get(), y, (size_t)n * sizeof(double));
         std::vector<int> tr, te;
         for (int i = 0; i < n; ++i) ((fold_id ? fold_id[i] : i % nfolds) == fold ? te : tr).push_back(i);
         const int ntr = (int)tr.size(), nte = (int)te.size();

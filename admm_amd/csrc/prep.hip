@@ -1,5 +1,7 @@
 // One-time preparation kernels and library wrappers (see prep.h).
 #include "prep.h"
+#include <thread>
+#include <algorithm>
 #include "gemv_kernels.h"
 #include "comm.h"
 
@@ -182,6 +184,78 @@ apply_std_kernel(T* __restrict__ X, long long ldx, T* __restrict__ Y, int n, int
     }
 }
 
+// ---- write_device (admm_internal.h): pinned staging ring + worker threads for the host-side copy
+namespace {
+struct H2DRing {
+    static constexpr int kSlots = 3;
+    static constexpr size_t kSlot = size_t(32) << 20;
+    void* slot[kSlots] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev[kSlots] = {nullptr, nullptr, nullptr};
+    hipStream_t st = nullptr;
+    int dev = -1;
+    bool ok() const { return st != nullptr; }
+    void init() {
+        ADMM_HIP_CHECK(hipGetDevice(&dev));
+        for (int i = 0; i < kSlots; ++i) {
+            ADMM_HIP_CHECK(hipHostMalloc(&slot[i], kSlot, hipHostMallocDefault));
+            ADMM_HIP_CHECK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+        }
+        ADMM_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    }
+};
+// one ring per host thread and device, never freed (like the stream pool and the read-back bounce buffer): the C ABI is
+// re-entrant per thread, and a ring is 96 MB of pinned memory only in threads that pass large host inputs
+H2DRing& h2d_ring() {
+    static thread_local std::vector<H2DRing*> rings;
+    int dev = 0;
+    ADMM_HIP_CHECK(hipGetDevice(&dev));
+    for (H2DRing* r : rings) if (r->dev == dev) return *r;
+    H2DRing* r = new H2DRing();
+    r->init();
+    rings.push_back(r);
+    return *r;
+}
+int h2d_threads() {
+    static const int n = []() {
+        if (const char* e = std::getenv("ADMM_HIP_H2D_THREADS")) { const int v = std::atoi(e); if (v >= 1) return std::min(v, 32); }
+        const unsigned hw = std::thread::hardware_concurrency();
+        return (int)std::max(1u, std::min(8u, hw ? hw / 2 : 4u));
+    }();
+    return n;
+}
+void parallel_memcpy(char* dst, const char* src, size_t bytes, int nthreads) {
+    const size_t per = ((bytes + nthreads - 1) / nthreads + 4095) / 4096 * 4096;
+    if (nthreads <= 1 || bytes < (size_t(4) << 20)) { std::memcpy(dst, src, bytes); return; }
+    std::vector<std::thread> th;
+    for (int t = 1; t < nthreads; ++t) {
+        const size_t off = per * t;
+        if (off >= bytes) break;
+        th.emplace_back([=]() { std::memcpy(dst + off, src + off, std::min(per, bytes - off)); });
+    }
+    std::memcpy(dst, src, std::min(per, bytes));
+    for (std::thread& t : th) t.join();
+}
+}  // namespace
+
+void write_device(void* dst, const void* src, size_t bytes) {
+    if (!bytes) return;
+    static const bool pageable = []() { const char* e = std::getenv("ADMM_HIP_H2D"); return e && std::string(e) == "pageable"; }();
+    if (pageable) { ADMM_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return; }
+    H2DRing& r = h2d_ring();
+    const int nt = h2d_threads();
+    int i = 0;
+    bool used[H2DRing::kSlots] = {false, false, false};
+    for (size_t off = 0; off < bytes; off += H2DRing::kSlot, i = (i + 1) % H2DRing::kSlots) {
+        const size_t n = std::min(H2DRing::kSlot, bytes - off);
+        if (used[i]) ADMM_HIP_CHECK(hipEventSynchronize(r.ev[i]));          // the DMA that read this slot has finished
+        parallel_memcpy(static_cast<char*>(r.slot[i]), static_cast<const char*>(src) + off, n, nt);
+        ADMM_HIP_CHECK(hipMemcpyAsync(static_cast<char*>(dst) + off, r.slot[i], n, hipMemcpyHostToDevice, r.st));
+        ADMM_HIP_CHECK(hipEventRecord(r.ev[i], r.st));
+        used[i] = true;
+    }
+    ADMM_HIP_CHECK(hipStreamSynchronize(r.st));
+}
+
 template <typename T>
 void upload_standardize(DeviceData<T>& d, const double* x, const double* y, int n, int p, int mem,
                         bool standardize, bool intercept, hipStream_t st, long long n_total) {
@@ -216,7 +290,7 @@ void upload_standardize(DeviceData<T>& d, const double* x, const double* y, int 
             const int nc = std::min(cols_per_chunk, p - c0);
             if (used[b]) ADMM_HIP_CHECK(hipEventSynchronize(ev[b].e));
             double t1 = now_s();
-            ADMM_HIP_CHECK(hipMemcpy(stage[b].get(), x + (size_t)c0 * n, (size_t)nc * n * sizeof(double), hipMemcpyHostToDevice));
+            write_device(stage[b].get(), x + (size_t)c0 * n, (size_t)nc * n * sizeof(double));
             th += now_s() - t1;
             hipLaunchKernelGGL((convert_cols_kernel<T>), dim3(nc, ny), dim3(256), 0, st, stage[b].get(), (long long)n, n,
                                d.X.get() + (size_t)c0 * d.ldx, d.ldx);
@@ -225,7 +299,7 @@ void upload_standardize(DeviceData<T>& d, const double* x, const double* y, int 
         }
         DevBuf<double> ystage(n);
         double t1 = now_s();
-        ADMM_HIP_CHECK(hipMemcpy(ystage.get(), y, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+        write_device(ystage.get(), y, (size_t)n * sizeof(double));
         th += now_s() - t1;
         hipLaunchKernelGGL((convert_cols_kernel<T>), dim3(1, ny), dim3(256), 0, st, ystage.get(), (long long)n, n, d.Y.get(), d.ldx);
         ADMM_HIP_CHECK(hipStreamSynchronize(st));
@@ -350,7 +424,7 @@ void upload_standardize_gram_f32(DeviceData<float>& d, const double* x, const do
     {
         DevBuf<double> ystage(n);
         double t1 = now_s();
-        ADMM_HIP_CHECK(hipMemcpy(ystage.get(), y, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+        write_device(ystage.get(), y, (size_t)n * sizeof(double));
         th += now_s() - t1;
         hipLaunchKernelGGL((convert_cols_kernel<T>), dim3(1, ny), dim3(256), 0, st, ystage.get(), (long long)n, n, d.Y.get(), d.ldx);
         standardise_cols(0, 0, true, st);
@@ -376,7 +450,7 @@ void upload_standardize_gram_f32(DeviceData<float>& d, const double* x, const do
         const hipStream_t s = sq[b];
         if (used[b]) ADMM_HIP_CHECK(hipEventSynchronize(ev[b].e));
         double t1 = now_s();
-        ADMM_HIP_CHECK(hipMemcpy(stage[b].get(), x + (size_t)c0 * n, (size_t)nc * n * sizeof(double), hipMemcpyHostToDevice));
+        write_device(stage[b].get(), x + (size_t)c0 * n, (size_t)nc * n * sizeof(double));
         th += now_s() - t1;
         hipLaunchKernelGGL((convert_cols_kernel<T>), dim3(nc, ny), dim3(256), 0, s, stage[b].get(), (long long)n, n,
                            d.X.get() + (size_t)c0 * d.ldx, d.ldx);

@@ -1,0 +1,111 @@
+"""Writes the fixed-maxit ORACLE fixtures at the BASELINE shapes that had none (round 5; C2 and C5-LAD have theirs):
+
+    c3_fixed_maxit.npz     admm_lasso, wide: n = 2000, p = 200 000 (configs[2]); 3 lambdas of the automatic 100-grid x maxit 40
+                           (regular steps at counters 0 / 3 / 15 and the active-set steps between them, ADMMLassoWide.h:121-155)
+    c4_fixed_maxit.npz     admm_lasso$parallel(8): n = 10 000, p = 100 000 (configs[3]), 8 row blocks of 1250 x 10^5 -- the Woodbury
+                           branch of PADMMLasso.h:23-30; automatic 3-lambda grid down to 0.3 lambda_max x maxit 25
+    c5_bp_fixed_maxit.npz  admm_bp: n = 5000, p = 50 000 fp64 (configs[4]), maxit 25
+
+each from oracle/entry.py (the NumPy restatement of the reference, pinned on the README vectors) on data the generators below
+make from a seed (NumPy PCG64 stream, whole-column chunks: the tests regenerate the same arrays).  Data only: the lambdas, the
+coefficients, niter, rho / the loose spectral radius, and the oracle's decision trace (so that a test can tell a different
+decision from a different iterate).
+
+    python tests/golden/make_fullsize.py [c3] [c4] [bp]        (minutes of CPU each; c4 needs ~20 GB of RAM)
+
+Recipes: SURVEY section 8(d) / README.md:195-201, 370-377 (X ~ N(0, 2^2), beta* = U(0,1) on the first 100, unit noise,
+standardize = intercept = TRUE, eps 1e-5; BP: A ~ N(0,1), 500 non-zeros U(0,1) at random positions, y = A beta* exactly, eps 1e-4)."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+C3 = dict(n=2000, p=200000, m=100, seed=3003, maxit=40, pick=(5, 25, 50))
+C4 = dict(n=10000, p=100000, m=100, seed=4004, maxit=25, K=8, nlambda=3, lmin_ratio=0.3)
+BP = dict(n=5000, p=50000, m=500, seed=5005, maxit=25)
+
+
+def lasso_data(seed, n, p, m):
+    rng = np.random.default_rng(seed)
+    x = np.empty((n, p), order="F")
+    step = max(1, (1 << 24) // n)
+    for j0 in range(0, p, step):                      # whole columns per chunk: the stream is the same for any chunking
+        x[:, j0:j0 + step] = rng.standard_normal((n, min(step, p - j0))) * 2.0
+    b = rng.uniform(size=m)
+    y = x[:, :m] @ b + rng.standard_normal(n)
+    return x, y
+
+
+def bp_data(seed, n, p, m):
+    rng = np.random.default_rng(seed)
+    a = np.empty((n, p), order="F")
+    step = max(1, (1 << 24) // n)
+    for j0 in range(0, p, step):
+        a[:, j0:j0 + step] = rng.standard_normal((n, min(step, p - j0)))
+    bt = np.zeros(p)
+    bt[rng.choice(p, m, replace=False)] = rng.uniform(size=m)
+    return a, a @ bt, bt
+
+
+def make_c3():
+    from oracle import entry
+    c = C3
+    t0 = time.time()
+    x, y = lasso_data(c["seed"], c["n"], c["p"], c["m"])
+    det = {"trace": []}
+    opts = dict(entry.LASSO_OPTS, maxit=c["maxit"])
+    # the picked lambdas of the automatic 100-grid (Lasso.cpp:78-89) need lambda_0 = max|X'y| of the standardised float data (ADMMLassoWide.h:197)
+    from oracle.datastd import DataStd
+    dx, dy = np.array(x, dtype=np.float32, order="F"), np.array(y, dtype=np.float32)
+    std = DataStd(c["n"], c["p"], True, True, np.float32)
+    std.standardize(dx, dy)
+    lambda0 = np.float32(np.abs((dx.T @ dy).astype(np.float32)).max())
+    lam = entry._lambda_grid(lambda0, c["n"], std.scaleY, 100, 0.01)[list(c["pick"])]
+    del dx, dy
+    ref = entry.admm_lasso(x, y, lam, 100, 0.01, True, True, opts, detail=det)
+    s = det["solver"]
+    path = os.path.join(HERE, "c3_fixed_maxit.npz")
+    np.savez_compressed(path, **{k: v for k, v in c.items() if k != "pick"}, pick=np.asarray(c["pick"]), lam=lam, beta=ref["beta"].astype(np.float32),
+                        niter=ref["niter"].astype(np.int64), sprad=np.float64(s.sprad), lambda0=np.float64(s.lambda0), trace=np.asarray(det["trace"], dtype=np.float64))
+    print("wrote", path, os.path.getsize(path), "bytes; niter", ref["niter"].tolist(), "sprad", float(s.sprad), "nnz", (ref["beta"][1:] != 0).sum(axis=0).tolist(),
+          f"{time.time() - t0:.0f} s", flush=True)
+
+
+def make_c4():
+    from oracle import entry
+    c = C4
+    t0 = time.time()
+    x, y = lasso_data(c["seed"], c["n"], c["p"], c["m"])
+    det = {"trace": []}
+    ref = entry.admm_parlasso(x, y, None, c["nlambda"], c["lmin_ratio"], True, True, c["K"], dict(entry.LASSO_OPTS, maxit=c["maxit"]), detail=det)
+    s = det["solver"]
+    path = os.path.join(HERE, "c4_fixed_maxit.npz")
+    np.savez_compressed(path, **c, lam=ref["lambda"], beta=ref["beta"].astype(np.float32), niter=ref["niter"].astype(np.int64), rho=np.float64(s.rho),
+                        trace=np.asarray(det["trace"], dtype=np.float64))
+    print("wrote", path, os.path.getsize(path), "bytes; niter", ref["niter"].tolist(), "rho", float(s.rho), "nnz", (ref["beta"][1:] != 0).sum(axis=0).tolist(),
+          f"{time.time() - t0:.0f} s", flush=True)
+
+
+def make_bp():
+    from oracle import entry
+    c = BP
+    t0 = time.time()
+    a, b, _ = bp_data(c["seed"], c["n"], c["p"], c["m"])
+    det = {"trace": []}
+    ref = entry.admm_bp(a, b, dict(entry.BP_OPTS, maxit=c["maxit"]), detail=det)
+    s = det["solver"]
+    path = os.path.join(HERE, "c5_bp_fixed_maxit.npz")
+    np.savez_compressed(path, **c, beta=ref["beta"], niter=np.int64(ref["niter"]), rho=np.float64(s.rho), trace=np.asarray(det["trace"], dtype=np.float64))
+    print("wrote", path, os.path.getsize(path), "bytes; niter", int(ref["niter"]), "final rho", float(s.rho), "nnz", int(np.count_nonzero(ref["beta"])),
+          f"{time.time() - t0:.0f} s", flush=True)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["c3", "c4", "bp"]
+    for w in which:
+        {"c3": make_c3, "c4": make_c4, "bp": make_bp}[w]()

@@ -254,3 +254,92 @@ def test_c2_width_short_path_vs_compiled_oracle_fixture():
     for j in range(len(lam)):                                  # same support up to entries at the float threshold
         a, b = np.abs(fit.beta_dense[1:, j]) > 1e-5 * floor * 100, np.abs(g["beta"][1:, j]) > 1e-5 * floor * 100
         assert (a != b).sum() <= 2, (j, int((a != b).sum()))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Round 5: fixed-maxit ORACLE fixtures at the BASELINE shapes of C3, C4 and C5-BP (tests/golden/make_fullsize.py), held like the C2
+# and C5-LAD ones: the GPU must take the oracle's decision at every iteration (compare_traces: same (lambda, iteration) sequence,
+# same outcomes, the scalars they were taken on within rounding) and return its coefficients to 1e-4 (BP, fp64: 1e-8).
+def _golden(name):
+    import os
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    return np.load(os.path.join(here, "golden", name))
+
+
+def _held_to_fixture_trace(trace, fx_trace, label, dev_tol):
+    from helpers import compare_traces
+    cmp_ = compare_traces(trace, fx_trace)
+    print(f"[{label}] {cmp_['summary']}")
+    assert cmp_["first_div"] is None, (label, cmp_["summary"])
+    assert cmp_["max_dev"] < dev_tol, (label, cmp_["summary"])
+    return cmp_
+
+
+def test_c3_full_size_wide_vs_oracle_fixture():
+    """BASELINE configs[2] at FULL size (n = 2000, p = 200 000): three lambdas of the automatic 100-grid x 40 iterations -- regular
+    steps at counters 0 / 3 / 15 and the active-set steps between them (ADMMLassoWide.h:86-155), rho adaptation from i > 3
+    (ADMMBase.h:85-109), all exits at maxit."""
+    from admm_amd import admm_lasso
+    from helpers import col_err, traced_fit
+    from make_fullsize import lasso_data
+    g = _golden("c3_fixed_maxit.npz")
+    x, y = lasso_data(int(g["seed"]), int(g["n"]), int(g["p"]), int(g["m"]))
+    lam, maxit = g["lam"], int(g["maxit"])
+    fit, trace = traced_fit(admm_lasso(x, y).penalty(lam).opts(maxit=maxit), capacity=len(lam) * (maxit + 2) + 8)
+    assert fit.stats["branch"] == 1
+    assert abs(fit.stats["eig_est"] - float(g["sprad"])) < 1e-4 * float(g["sprad"]), (fit.stats["eig_est"], float(g["sprad"]))     # Gram-free Lanczos vs the oracle's Gram-based one
+    _held_to_fixture_trace(trace, g["trace"], "C3 full size", 1e-3)
+    t = np.asarray(trace); t = t[1:] if t[0, 8] == -1 else t
+    assert np.allclose(t[:, 10], g["trace"][:, 10], rtol=1e-6), "rho after every decision (ADMMBase.h:85-109)"
+    assert list(map(int, fit.niter)) == list(map(int, g["niter"])), (fit.niter, g["niter"])
+    floor = 1e-2 * float(np.abs(g["beta"]).max())
+    errs = [col_err(fit.beta_dense[:, j], g["beta"][:, j], floor) for j in range(len(lam))]
+    nnz = [(int(np.count_nonzero(fit.beta_dense[1:, j])), int(np.count_nonzero(g["beta"][1:, j]))) for j in range(len(lam))]
+    print(f"[C3 full size] niter {list(map(int, fit.niter))}; non-zeros (GPU, oracle) {nnz}; max column error {max(errs):.2e}")
+    assert max(errs) < 1e-4, errs
+    for j, (a, b) in enumerate(nnz):
+        assert abs(a - b) <= max(2, b // 200), (j, a, b)           # same support up to coordinates at the float threshold
+
+
+def test_c4_full_size_consensus_vs_oracle_fixture():
+    """BASELINE configs[3] at FULL size: admm_lasso$parallel(8), n = 10 000, p = 100 000 -- eight 1250 x 10^5 Woodbury workers
+    (PADMMLasso.h:23-30; here in the one-pass form), automatic 3-lambda grid down to 0.3 lambda_max x 25 iterations."""
+    from admm_amd import admm_lasso
+    from helpers import col_err, traced_fit
+    from make_fullsize import lasso_data
+    g = _golden("c4_fixed_maxit.npz")
+    x, y = lasso_data(int(g["seed"]), int(g["n"]), int(g["p"]), int(g["m"]))
+    maxit, K = int(g["maxit"]), int(g["K"])
+    model = admm_lasso(x, y).penalty(nlambda=int(g["nlambda"]), lambda_min_ratio=float(g["lmin_ratio"])).parallel(K).opts(maxit=maxit)
+    fit, trace = traced_fit(model, capacity=int(g["nlambda"]) * (maxit + 2) + 8)
+    assert fit.stats["branch"] == 2
+    assert np.allclose(fit.lambda_, g["lam"], rtol=1e-6)
+    assert abs(fit.stats["rho"] - float(g["rho"])) < 1e-6 * float(g["rho"])
+    _held_to_fixture_trace(trace, g["trace"], "C4 full size", 1e-3)
+    assert list(map(int, fit.niter)) == list(map(int, g["niter"])), (fit.niter, g["niter"])
+    floor = 1e-2 * float(np.abs(g["beta"]).max())
+    errs = [col_err(fit.beta_dense[:, j], g["beta"][:, j], floor) for j in range(int(g["nlambda"]))]
+    print(f"[C4 full size] niter {list(map(int, fit.niter))}; max column error {max(errs):.2e}")
+    assert max(errs) < 1e-4, errs
+
+
+def test_c5_full_size_bp_vs_oracle_fixture():
+    """BASELINE configs[4], basis pursuit at FULL size (n = 5000, p = 50 000, fp64; here in the one-pass form): 25 iterations of
+    FADMMBase::solve + ADMMBP (acceleration / restart, rho adaptation from i > 5) against the oracle's."""
+    from admm_amd import admm_bp
+    from helpers import relerr
+    from make_fullsize import bp_data
+    g = _golden("c5_bp_fixed_maxit.npz")
+    a, b, _ = bp_data(int(g["seed"]), int(g["n"]), int(g["p"]), int(g["m"]))
+    maxit = int(g["maxit"])
+    fit = admm_bp(a, b).opts(maxit=maxit).fit(trace=True)
+    assert fit.niter == int(g["niter"]) == maxit + 1
+    cmp_ = _held_to_fixture_trace(fit.trace, g["trace"], "C5 BP full size", 1e-6)
+    t = np.asarray(fit.trace); t = t[1:] if t[0, 8] == -1 else t
+    assert np.allclose(t[:, 10], g["trace"][:, 10], rtol=1e-12), "rho after every decision (FADMMBase.h:109-133)"
+    beta = np.asarray(fit.beta.todense()).ravel()
+    err = relerr(beta, g["beta"])
+    print(f"[C5 BP full size] after {maxit} iterations: relative difference to the oracle fixture {err:.2e}, final rho {fit.stats['rho']}; {cmp_['summary']}")
+    assert err < 1e-8, err
