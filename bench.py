@@ -523,21 +523,26 @@ def _timed_oracle(make_runner, budget_s):
 
 
 def cpu_config_baseline(name, budget_s, seed):
-    """cpu_baseline of one of the other configs: the NumPy restatement of the reference's loop (oracle/solvers.py -- the checker
-    of the parity tests, here only TIMED) on the SAME shape, synthetic data of the same distribution, for as many iterations as
-    fit `budget_s`, twice: BLAS limited to ONE thread -- the reference's configuration (`Lasso.cpp:1` EIGEN_DONT_PARALLELIZE,
-    R's single-threaded reference BLAS for the dgemv of LAD / BP; only the consensus workers and the wide solver's active-set
-    loop use OpenMP there) -- and all host threads (`best_effort`).  Setup (Gram, factorisation) is not part of either rate."""
+    """cpu_baseline of one of the other configs (round 5: COMPILED): the C restatement of the reference's loop for that solver
+    (oracle/c/admm_loops_cpu.c through oracle/cloops.py -- the checker of tests/test_oracle_cloops.py, here only TIMED) on the SAME
+    shape, synthetic data of the same distribution, for as many iterations as fit `budget_s` (the loop cuts itself off), twice:
+    ONE thread -- the reference's configuration (`Lasso.cpp:1` EIGEN_DONT_PARALLELIZE; R's reference BLAS for the dgemv of LAD / BP;
+    only the consensus workers and the wide solver's active-set loop use OpenMP there) -- and all host threads, every product spread
+    over them, pinned (`best_effort`; OMP_PROC_BIND / OMP_PLACES are set by main() before the library is loaded).  The one-time
+    setup (Gram, factorisations: NumPy / LAPACK) is not part of either rate."""
     import numpy as np
     import torch
-    from threadpoolctl import threadpool_limits
-    from oracle.solvers import BP, LAD, LassoWide, PADMMLasso
+    os.environ.setdefault("OMP_PROC_BIND", "spread")       # (read when the OpenMP runtime starts: main() sets them first thing as well)
+    os.environ.setdefault("OMP_PLACES", "cores")
+    from oracle import cloops
     F = np.float32
     tg = torch.Generator(); tg.manual_seed(seed + 77)
+    threads = cloops.max_threads()
 
     def randn(shape, dtype, sd=1.0):
         return (torch.randn(shape, generator=tg, dtype=dtype) * sd).numpy()
 
+    scale = 1.0
     t_setup0 = time.time()
     if name == "c3":
         n, p = 2000, 200000
@@ -549,33 +554,23 @@ def cpu_config_baseline(name, budget_s, seed):
         Y = ((Y - Y.mean()) / Y.std()).astype(F)
         # (the constructor's n x n Gram -- 8e11 flop -- only serves the spectral-radius estimate: 30 power iterations of X (X'v) stand in,
         # setup is not timed)
-        s = LassoWide.__new__(LassoWide)
-        s.X, s.Y, s.n, s.p, s.eps_abs, s.eps_rel, s.alpha, s.info, s.trace_nnz = X, Y, n, p, 1e-5, 1e-5, None, {}, []
-        s.lambda0 = F(np.abs(X.T @ Y).max())
+        lambda0 = F(np.abs(X.T @ Y).max())
         v = np.ones(n, F) / np.sqrt(F(n))
         for _ in range(30):
             w = X @ (X.T @ v)
             nv = float(np.linalg.norm(w))
             v = (w / nv).astype(F)
-        s.sprad = F(0.95 * nv)                               # the reference's loose Lanczos value sits 3-8 % below lambda_max
-        lam = np.float64(s.lambda0) * 0.01 ** (np.arange(100) / 99.0)
-        what = f"ADMMLassoWide loop on n={n} p={p}, the first lambdas of the automatic 100-grid from a cold start"
+        sprad = F(0.95 * nv)                                 # the reference's loose Lanczos value sits 3-8 % below lambda_max
+        lam = np.float64(lambda0) * 0.01 ** (np.arange(100) / 99.0)
+        what = f"ADMMBase::solve + ADMMLassoWide on n={n} p={p}, the automatic 100-lambda grid from a cold start until the budget is used"
 
-        def make():
-            state = {"i": 0}
-
-            def step():
-                i = state["i"]
-                if i >= len(lam):
-                    return 0
-                s.lam_idx = i
-                (s.init(lam[i], -1.0) if i == 0 else s.init_warm(lam[i]))
-                state["i"] = i + 1
-                return min(int(s.solve(10000)), 10000)
-            return step
+        def run(nt, budget):
+            _, niter, secs, _ = cloops.wide_loop(X, Y, sprad, lambda0, lam, -1.0, 1e-5, 1e-5, 10000, nthreads=nt, want_beta=False, budget_s=budget)
+            return int(np.minimum(niter, 10000).sum()), secs
     elif name == "c4":
         # bounded sample: 2 of the 8 row blocks (2500 rows): the per-iteration cost is K workers x the same two products, so the
-        # measured rate is scaled by 2 / 8 (said in `sample`)
+        # measured rate is scaled by 2 / 8 (said in `sample`); the all-core leg gives every worker half of the threads
+        import scipy.linalg as sla
         n_full, K_full = 10000, 8
         n, p, K = 2500, 100000, 2
         X = randn((n, p), torch.float32, 2.0)
@@ -584,77 +579,108 @@ def cpu_config_baseline(name, budget_s, seed):
         X -= X.mean(axis=0, dtype=F)[None, :]
         X *= (1.0 / np.sqrt((X * X).sum(axis=0, dtype=F) / n)).astype(F)[None, :]
         Y = ((Y - Y.mean()) / Y.std()).astype(F)
-        s = PADMMLasso(X, Y, K, 1e-5, 1e-5)
+        lam0 = float(np.abs(X.T @ Y).max())
+        rho = 0.55 * lam0 / K_full                           # PADMMLasso.h:199-200 with the full problem's K
+        A = [np.asfortranarray(X[k * (n // K):(k + 1) * (n // K)]) for k in range(K)]
         del X
-        lam0 = float(s.lambda0)
+        Ab = [(a.T @ Y[k * (n // K):(k + 1) * (n // K)]).astype(F) for k, a in enumerate(A)]
+        Lf = []
+        for a in A:
+            G = (a @ a.T).astype(F)
+            G[np.arange(len(G)), np.arange(len(G))] += F(rho)
+            Lf.append(np.tril(sla.cho_factor(G, lower=True, check_finite=False)[0]))
         scale = float(K) / K_full
-        what = (f"PADMMBase_Master::solve with PADMMLasso workers (Woodbury branch, 1250 x {p} blocks), lambda = 0.55 lambda_max, workers one after the other "
-                f"(the reference runs them under OpenMP); SAMPLE: {K} of the {K_full} row blocks of n={n_full}, the measured rate scaled by {K}/{K_full}")
+        what = (f"PADMMBase_Master::solve with PADMMLasso workers (Woodbury branch, float LLT solve, 1250 x {p} blocks), lambda = 0.55 lambda_max; "
+                f"SAMPLE: {K} of the {K_full} row blocks of n={n_full}, the measured rate scaled by {K}/{K_full}")
 
-        def make():
-            s.init(0.55 * lam0, -1.0)
-            return lambda: min(int(s.solve(3)), 3)
+        def run(nt, budget):
+            _, niter, secs = cloops.consensus_loop(A, Ab, Lf, p, [0.55 * lam0], rho, 1e-5, 1e-5, 10000, nthreads=nt, budget_s=budget)
+            return int(np.minimum(niter, 10000).sum()), secs
     elif name == "c5lad":
+        import scipy.linalg as sla
         n, p = 50000, 5000
         X = np.asfortranarray(randn((p, n), torch.float64, 2.0).T)
         Y = X @ np.random.default_rng(seed).uniform(size=p) + randn((n,), torch.float64)
         X /= np.sqrt((X * X).sum(axis=0) / n - X.mean(axis=0) ** 2)[None, :]
         Y = Y / Y.std()
-        s = LAD(X, Y, 1.0, 1e-4, 1e-4)
-        what = f"FADMMBase::solve + ADMMLAD (general branch X (X'X)^-1 X') on n={n} p={p}"
+        Lf = np.tril(sla.cho_factor(X.T @ X, lower=True, check_finite=False)[0])
+        what = f"FADMMBase::solve + ADMMLAD (general branch X (X'X)^-1 X': two products with X and two triangular solves per iteration) on n={n} p={p}"
 
-        def make():
-            return lambda: min(int(s.solve(3)), 3)
+        def run(nt, budget):
+            r = cloops.dense_loop(0, X, Lf, Y, 1.0, 1e-4, 1e-4, 10000, nthreads=nt, budget_s=budget)
+            return min(int(r[4]), 10000), r[5]
     elif name == "c5bp":
+        from oracle.solvers import BP
         n, p = 5000, 50000
         A = randn((n, p), torch.float64)
         bt = np.zeros(p); bt[np.random.default_rng(seed).choice(p, 500, replace=False)] = np.random.default_rng(seed + 1).uniform(size=500)
         s = BP(A, A @ bt, 1.0, 1e-4, 1e-4)
+        B, c0 = np.asfortranarray(s.LinvA), s.cache_AAAb
+        del s, A
         what = f"FADMMBase::solve + ADMMBP (two products with L^-1 A per iteration) on n={n} p={p}"
 
-        def make():
-            return lambda: min(int(s.solve(3)), 3)
+        def run(nt, budget):
+            r = cloops.dense_loop(1, B, None, c0, 1.0, 1e-4, 1e-4, 10000, nthreads=nt, budget_s=budget)
+            return min(int(r[4]), 10000), r[5]
     elif name == "c5parbp":
-        from oracle.solvers import SharingBP
-        n, p, N = 5000, 50000, 8
-        A = randn((n, p), torch.float64)
-        bt = np.zeros(p); bt[np.random.default_rng(seed).choice(p, 500, replace=False)] = np.random.default_rng(seed + 1).uniform(size=500)
-        s = SharingBP.__new__(SharingBP)                     # the constructor's exact spectral norms (8 SVDs) replaced by 40 power iterations: setup only
-        s.n, s.p, s.N = n, p, N
-        chunk = p // N
-        s.off = [i * chunk for i in range(N)] + [p]
-        s.A = [A[:, s.off[i]:s.off[i + 1]] for i in range(N)]
-        s.b = A @ bt
-        s.eps_abs = s.eps_rel = 1e-4
-        s.trace = None
-        s.sprad = []
-        for Ai in s.A:
-            v = np.ones(Ai.shape[1]) / np.sqrt(Ai.shape[1])
-            for _ in range(40):
-                w = Ai.T @ (Ai @ v)
-                nv = float(np.linalg.norm(w))
-                v = w / nv
-            s.sprad.append(1.02 * nv)
-        what = f"the sharing-ADMM loop of TODO/PADMMBP.h restated (oracle/solvers.py SharingBP), {N} column blocks one after the other, on n={n} p={p}"
-
-        def make():
-            s.init(1.0)
-            return lambda: min(int(s.solve(10)), 10)
+        return _cpu_parbp_numpy(budget_s, seed)
     else:
         return None
     t_setup = time.time() - t_setup0
+    it1, s1 = run(1, budget_s)
+    itn, sn = run(threads, budget_s)
+    it1, itn = it1 * scale, itn * scale
+    return {"value": it1 / s1 if s1 > 0 else None, "unit": "iterations/s", "cores": 1, "kind": "port",
+            "sample": f"compiled C restatement (oracle/c/admm_loops_cpu.c, gcc -O3 -fopenmp) of {what}; ONE thread: {it1:g} (scaled) iterations in {s1:.1f} s; "
+                      f"data generation + setup (Gram / factorisation, NumPy) {t_setup:.1f} s not included",
+            "best_effort": {"value": itn / sn if sn > 0 else None, "unit": "iterations/s", "cores": int(threads),
+                            "sample": f"the same compiled loop with every product spread over {threads} OpenMP threads (OMP_PROC_BIND=spread, OMP_PLACES=cores): "
+                                      f"{itn:g} (scaled) iterations in {sn:.1f} s"}}
+
+
+def _cpu_parbp_numpy(budget_s, seed):
+    """admm_parbp has no compiled restatement (the reference never built it: src/TODO/PADMMBP.h): its cpu_baseline stays the NumPy
+    oracle (oracle/solvers.py SharingBP), BLAS on one thread and on all of them."""
+    import numpy as np
+    import torch
+    from threadpoolctl import threadpool_limits
+    from oracle.solvers import SharingBP
+    tg = torch.Generator(); tg.manual_seed(seed + 77)
+    t_setup0 = time.time()
+    n, p, N = 5000, 50000, 8
+    A = (torch.randn((n, p), generator=tg, dtype=torch.float64)).numpy()
+    bt = np.zeros(p); bt[np.random.default_rng(seed).choice(p, 500, replace=False)] = np.random.default_rng(seed + 1).uniform(size=500)
+    s = SharingBP.__new__(SharingBP)                     # the constructor's exact spectral norms (8 SVDs) replaced by 40 power iterations: setup only
+    s.n, s.p, s.N = n, p, N
+    chunk = p // N
+    s.off = [i * chunk for i in range(N)] + [p]
+    s.A = [A[:, s.off[i]:s.off[i + 1]] for i in range(N)]
+    s.b = A @ bt
+    s.eps_abs = s.eps_rel = 1e-4
+    s.trace = None
+    s.sprad = []
+    for Ai in s.A:
+        v = np.ones(Ai.shape[1]) / np.sqrt(Ai.shape[1])
+        for _ in range(40):
+            w = Ai.T @ (Ai @ v)
+            nv = float(np.linalg.norm(w))
+            v = w / nv
+        s.sprad.append(1.02 * nv)
+    what = f"the sharing-ADMM loop of TODO/PADMMBP.h restated (oracle/solvers.py SharingBP), {N} column blocks one after the other, on n={n} p={p}"
+
+    def make():
+        s.init(1.0)
+        return lambda: min(int(s.solve(10)), 10)
+    t_setup = time.time() - t_setup0
     threads = _blas_threads()
-    scale = scale if name == "c4" else 1.0
     with threadpool_limits(limits=1, user_api="blas"):
         it1, s1 = _timed_oracle(make, budget_s)
     itn, sn = _timed_oracle(make, budget_s)
-    it1, itn = it1 * scale, itn * scale
     return {"value": it1 / s1 if s1 > 0 else None, "unit": "iterations/s", "cores": 1, "kind": "port",
-            "sample": f"NumPy restatement (oracle/solvers.py) of {what}; BLAS limited to ONE thread: {it1:g} (scaled) iterations in {s1:.1f} s; data generation + setup "
-                      f"(Gram / factorisation, all threads) {t_setup:.1f} s not included",
+            "sample": f"NumPy restatement of {what}; BLAS limited to ONE thread: {it1:g} iterations in {s1:.1f} s; setup {t_setup:.1f} s not included",
             "best_effort": {"value": itn / sn if sn > 0 else None, "unit": "iterations/s", "cores": int(threads),
-                            "sample": f"the same loop with OpenBLAS on {threads} threads inside every product (its memory-bound gemv does not scale on this host: "
-                                      f"NUMA-blind, unpinned -- reported as measured, not a tuned CPU build): {itn:g} (scaled) iterations in {sn:.1f} s"}}
+                            "sample": f"the same loop with OpenBLAS on {threads} threads inside every product (reported as measured, not a tuned CPU build): "
+                                      f"{itn:g} iterations in {sn:.1f} s"}}
 
 
 def run_side_measurement(a, rank, world, kind, backend, seconds, port_offset):

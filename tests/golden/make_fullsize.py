@@ -3,7 +3,9 @@
     c3_fixed_maxit.npz     admm_lasso, wide: n = 2000, p = 200 000 (configs[2]); 3 lambdas of the automatic 100-grid x maxit 40
                            (regular steps at counters 0 / 3 / 15 and the active-set steps between them, ADMMLassoWide.h:121-155)
     c4_fixed_maxit.npz     admm_lasso$parallel(8): n = 10 000, p = 100 000 (configs[3]), 8 row blocks of 1250 x 10^5 -- the Woodbury
-                           branch of PADMMLasso.h:23-30; automatic 3-lambda grid down to 0.3 lambda_max x maxit 25
+                           branch of PADMMLasso.h:23-30; lambda = 0.3 and 0.25 lambda_max x maxit 600 (the consensus iteration with
+                           rho = lambda / K keeps z = 0 for its first ~500 iterations: a 25-iteration fixture would never see a
+                           non-zero consensus variable)
     c5_bp_fixed_maxit.npz  admm_bp: n = 5000, p = 50 000 fp64 (configs[4]), maxit 25
 
 each from oracle/entry.py (the NumPy restatement of the reference, pinned on the README vectors) on data the generators below
@@ -26,7 +28,7 @@ sys.path.insert(0, ROOT)
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 C3 = dict(n=2000, p=200000, m=100, seed=3003, maxit=40, pick=(5, 25, 50))
-C4 = dict(n=10000, p=100000, m=100, seed=4004, maxit=25, K=8, nlambda=3, lmin_ratio=0.3)
+C4 = dict(n=10000, p=100000, m=100, seed=4004, maxit=600, K=8, fractions=(0.3, 0.25))
 BP = dict(n=5000, p=50000, m=500, seed=5005, maxit=25)
 
 
@@ -82,10 +84,19 @@ def make_c4():
     t0 = time.time()
     x, y = lasso_data(c["seed"], c["n"], c["p"], c["m"])
     det = {"trace": []}
-    ref = entry.admm_parlasso(x, y, None, c["nlambda"], c["lmin_ratio"], True, True, c["K"], dict(entry.LASSO_OPTS, maxit=c["maxit"]), detail=det)
+    from oracle.datastd import DataStd
+    dx, dy = np.array(x, dtype=np.float32, order="F"), np.array(y, dtype=np.float32)
+    std = DataStd(c["n"], c["p"], True, True, np.float32)
+    std.standardize(dx, dy)
+    lambda0 = np.float64(np.float32(np.abs((dx.T @ dy).astype(np.float32)).max()))            # PADMMLasso.h:161
+    lmax = lambda0 / c["n"] * np.float64(std.scaleY)                                          # Lasso.cpp:82
+    del dx, dy
+    lam = np.asarray([f * lmax for f in c["fractions"]])
+    ref = entry.admm_parlasso(x, y, lam, 2, 0.5, True, True, c["K"], dict(entry.LASSO_OPTS, maxit=c["maxit"]), detail=det)
     s = det["solver"]
     path = os.path.join(HERE, "c4_fixed_maxit.npz")
-    np.savez_compressed(path, **c, lam=ref["lambda"], beta=ref["beta"].astype(np.float32), niter=ref["niter"].astype(np.int64), rho=np.float64(s.rho),
+    c = {k: v for k, v in c.items() if k != "fractions"}
+    np.savez_compressed(path, **c, fractions=np.asarray(C4["fractions"]), lam=ref["lambda"], beta=ref["beta"].astype(np.float32), niter=ref["niter"].astype(np.int64), rho=np.float64(s.rho),
                         trace=np.asarray(det["trace"], dtype=np.float64))
     print("wrote", path, os.path.getsize(path), "bytes; niter", ref["niter"].tolist(), "rho", float(s.rho), "nnz", (ref["beta"][1:] != 0).sum(axis=0).tolist(),
           f"{time.time() - t0:.0f} s", flush=True)
