@@ -427,12 +427,19 @@ def config_child(a, name, out_path):
         niter = fit.niter.astype(np.int64)
         reg = sum(int(sum(1 for c in range(k) if (c + 1) & c == 0 and ((c + 1) & 0x55555555))) for k in niter)
         tot = int(niter.sum())
-        # a regular iteration streams X once (4 n p); an active-set one reads the current non-zeros' columns once (4 n nS, the
-        # gather re-uses the column just dotted): nS per iteration is not recorded -- only the regular-step stream is counted
-        # (a lower bound of the algorithmic bytes, so `frac` is a lower bound too)
-        bytes_iter = 4.0 * n * p * reg / max(1, tot)
-        extra = {"regular_iterations": reg, "nnz_last_lambda": int(np.count_nonzero(fit.beta_dense[1:, -1])), "persist_iter": int(fit.stats["persist_iter"]),
-                 "kernel": "wide_x_kernel / wide_rows_persist_kernel (x-update of ADMMLassoWide)", "bytes_note": "regular-step stream of X only (lower bound)"}
+        # a regular iteration streams X once (4 n p); EVERY iteration reads the columns of the current support twice
+        # (X_S' t in the x-update, X_S x_S for A x: 2 * 4 n nS).  The kernels do not record nS per iteration; it is taken per lambda
+        # as the mean of the support sizes the lambda starts from (the previous lambda's final support: warm start) and ends with
+        # -- known exactly from the returned coefficients -- times that lambda's iteration count.
+        nnz = np.count_nonzero(fit.beta_dense[1:, :], axis=0).astype(np.float64)
+        nnz_start = np.concatenate([[0.0], nnz[:-1]])
+        supp_bytes = float((8.0 * n * 0.5 * (nnz_start + nnz) * niter).sum())
+        bytes_iter = (4.0 * n * p * reg + supp_bytes) / max(1, tot)
+        extra = {"regular_iterations": reg, "nnz_last_lambda": int(nnz[-1]), "persist_iter": int(fit.stats["persist_iter"]),
+                 "support_bytes_share": supp_bytes / (4.0 * n * p * reg + supp_bytes),
+                 "kernel": "wide_x_kernel / wide_rows_persist_kernel (x-update of ADMMLassoWide)",
+                 "bytes_note": "per ITERATION averaged over the path: 4np on the regular steps + 8 n nS on every step (nS per lambda = mean of its "
+                               "starting and final support sizes; SURVEY section 8(d))"}
     elif name == "c4":
         n, p, K = 10000, 100000, 8
         xt, y, _ = _gen_device(torch, dev, g, n, p, 2.0, 100)
@@ -493,6 +500,21 @@ def config_child(a, name, out_path):
                 "roofline": {"bound": "hbm", "kernel": extra.pop("kernel", None), "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                              "frac": achieved / HBM_PEAK, "traffic": None, "algorithmic_bytes_per_iteration": bytes_iter,
                              "avg_iteration_ms": t_iter * 1e3, "note": extra.pop("bytes_note", "per ITERATION (all launches of one ADMM iteration), HIP events around the loop")}})
+    try:          # PMC counters cannot be collected inside this run: quote the committed per-iteration measurement of this config
+        # (scripts/capture_pmc_configs.sh) while the source files of its loop kernels are unchanged -- else null: re-profile
+        import hashlib
+        ent = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("configs", {}).get(name)
+        if ent:
+            h = hashlib.sha256()
+            for f in ent["source_files"]:
+                h.update(open(os.path.join(ROOT, "admm_amd", "csrc", f), "rb").read())
+            if h.hexdigest()[:16] == ent["kernel_source_sha16"]:
+                res["roofline"]["traffic"] = ent["hbm_read_bytes_per_iteration"] + ent["hbm_write_bytes_per_iteration"]
+                res["roofline"]["traffic_source"] = ent["source"]
+            else:
+                res["roofline"]["traffic_source"] = "stale: the loop kernels' sources changed since %s was captured" % ent["source"]
+    except Exception:                                       # noqa: BLE001
+        pass
     if survey_bytes is not None:      # what SURVEY section 8(d) counts for the reference's arithmetic on the same iteration (may exceed the peak: bytes never read)
         res["roofline"]["survey_8d_bytes_per_iteration"] = survey_bytes
         res["roofline"]["survey_8d_equivalent_GBps"] = survey_bytes / t_iter / 1e9
