@@ -45,6 +45,18 @@ void upload_standardize_gram_f32(DeviceData<float>& d, const double* x, const do
 void clone_with_response_f32(DeviceData<float>& d, const DeviceData<float>& base, const float* gram, long long ldgram,
                              const double* y_dev, hipStream_t st);
 
+// The tall Gram on the bf16 matrix cores (gram_bf16x3.hip): Z = X' as three bf16 planes (x = h + m + l), six kept cross products.
+struct GramSplit3 {
+    DevBuf<unsigned short> planes;      // [3][nkg][ldz][8] bf16
+    long long ldz = 0;                  // entries (of 8 bf16) per k group: order rounded up to 128
+    int nkg = 0, M = 0;                 // k groups of 8 (K rounded up to 16); order
+    void alloc(int order, int kdepth, hipStream_t st);
+    void split_cols(const float* X, long long ldx, int rows, int c0, int nc, hipStream_t st);      // columns [c0, c0 + nc) of X (rows x nc at X)
+    void gram_lower(float* C, long long ldc, const int* tilemap, int ntiles, hipStream_t st) const;
+    void gram_rows(int r0, int nr, float* C, long long ldc, hipStream_t st) const;
+};
+bool gram_bf16x3_enabled();             // ADMM_HIP_GRAM_BF16=0: the exact-fp32 matrix-core kernel (syrk_mfma.hip) as before
+
 // Cross-validation folds formed as down-dates of the full-data Gram (cv.hip): what is formed once per call.
 struct CvBase {
     DeviceData<float> full;         // the full data standardised with ITS statistics: Z (n x p), its response, m, s

@@ -398,8 +398,13 @@ void upload_standardize_gram_f32(DeviceData<float>& d, const double* x, const do
     d.Y.zero(st);
     const long long ldz = round_up(p, 128);
     const int nk = (int)round_up(n, 16);
-    DevBuf<float> Z((size_t)ldz * nk);            // X' (output index contiguous), the operand of the matrix-core Gram
-    Z.zero(st);
+    // the operand of the matrix-core Gram: X' as three bf16 planes (gram_bf16x3.hip; p >= 4096 here, the same kernel the one-shot
+    // Gram takes at this size), or as floats with the output index contiguous (ADMM_HIP_GRAM_BF16=0)
+    const bool b3 = gram_bf16x3_enabled();
+    GramSplit3 z3;
+    DevBuf<float> Z;
+    if (b3) z3.alloc(p, n, st);
+    else { Z.alloc((size_t)ldz * nk); Z.zero(st); }
     d.ldgram = ldz;
     d.gram.alloc((size_t)ldz * ldz);
     d.gram.zero(st);
@@ -457,11 +462,13 @@ void upload_standardize_gram_f32(DeviceData<float>& d, const double* x, const do
         ADMM_HIP_CHECK(hipEventRecord(ev[b].e, s));               // the staging buffer is free once the conversion has read it
         used[b] = true;
         standardise_cols(c0, nc, false, s);
-        transpose<float>(d.X.get() + (size_t)c0 * d.ldx, d.ldx, n, nc, Z.get() + c0, ldz, s);
+        if (b3) z3.split_cols(d.X.get() + (size_t)c0 * d.ldx, d.ldx, n, c0, nc, s);
+        else transpose<float>(d.X.get() + (size_t)c0 * d.ldx, d.ldx, n, nc, Z.get() + c0, ldz, s);
         ADMM_HIP_CHECK(hipEventRecord(evT[b].e, s));
         // rows of Z of every earlier chunk: the even ones are ordered by this stream, the odd ones by the other's event
         if (c0 > 0) ADMM_HIP_CHECK(hipStreamWaitEvent(s, evT[b ^ 1].e, 0));
-        gram_rows_mfma_f32(Z.get(), ldz, c0, nc, nk, d.gram.get(), ldz, s);
+        if (b3) z3.gram_rows(c0, nc, d.gram.get(), ldz, s);
+        else gram_rows_mfma_f32(Z.get(), ldz, c0, nc, nk, d.gram.get(), ldz, s);
     }
     {
         Event done;

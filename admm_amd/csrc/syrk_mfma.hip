@@ -460,6 +460,18 @@ void gram_mfma_f32(const float* A, long long lda, int rows, int cols, bool atA, 
     const int ntiles = nb * (nb + 1) / 2;
     int ksplit = 1;
     if (ntiles < 512) ksplit = std::min(std::min(16, (1024 + ntiles - 1) / ntiles), std::max(1, Kd / 2048));
+    if (atA && ksplit == 1 && ntiles >= 512 && gram_bf16x3_enabled()) {
+        // deep-K lower-triangle Gram of a tall matrix (>= 512 tiles: order >= ~4000): bf16 matrix cores, three-way split
+        // (gram_bf16x3.hip); tiles in the same XCD-local square order
+        GramSplit3 z3;
+        z3.alloc(M, Kd, st);
+        z3.split_cols(A, lda, rows, 0, cols, st);
+        DevBuf<int> tmap = make_square_tilemap(nb, st);
+        z3.gram_lower(C, ldc, tmap.get(), ntiles, st);
+        ADMM_HIP_CHECK(hipGetLastError());
+        ADMM_HIP_CHECK(hipStreamSynchronize(st));
+        return;
+    }
     const int nk = (int)round_up(Kd, (long long)SK_BK * ksplit);
     DevBuf<float> Z((size_t)ldz * nk);
     Z.zero(st);
