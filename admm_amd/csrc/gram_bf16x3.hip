@@ -18,24 +18,37 @@
 // lane, consecutive lanes consecutive addresses.  A workgroup = 4 waves (2 x 2), 128 x 128 outputs, K tiles of 16 double buffered
 // (48 KB of LDS, 2 workgroups per CU), XCD-local square tile order as in syrk_mfma.hip; lower tiles + mirrored store.
 // The pipelined host-input setup (prep.hip) uses the rectangular mode on block rows: same K order per element, bit-identical.
+//
+// Second variant, the DEFAULT (ADMM_HIP_GRAM_SPLIT=f16x2): two fp16 planes, x = 2^e_j (h + l) with h = fp16(x 2^-e_j), l = fp16(rest),
+// 2^e_j <= max|x_j| < 2^(e_j+1) per column (exact scaling; fp16 has no range to spare, bf16 has fp32's), three products
+// h h' + h l' + l h' (dropped l l' <= 2^-22 |x y|; the operand is represented to 2^-23 of itself, i.e. the Gram is that of X with
+// every entry moved by less than one fp32 ulp -- random, averaging out over K -- while the fp32 accumulation over K, the error that
+// dominates either kernel's result, is unchanged).  Half the matrix instructions of the bf16 form: measured on C2 in
+// profiles/r05_gram_split.md.  The bf16 form needs no scaling and stays selectable (ADMM_HIP_GRAM_SPLIT=bf16x3).
 #include "prep.h"
+#include "device_utils.h"
+#include <string>
 
 namespace admm {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 constexpr int GB_BM = 128;
 constexpr int GB_BK = 16;
+constexpr int GB_KPAD = 6 * GB_BK;      // K is zero-padded to whole groups of six K tiles (the kernel's unrolled ring)
 constexpr int GB_THREADS = 256;
 
 struct GramB3 {
-    const uint4* Z[3];           // planes h, m, l: [k / 8][ldz] entries of 8 bf16 (16 bytes)
+    const uint4* Z[3];           // planes h, m, l (bf16x3) or h, l (f16x2): [k / 8][ldz] entries of 8 values (16 bytes)
     long long ldz;               // entries per k group (multiple of 128)
     const uint4* Zb[3];          // second operand (the same planes for the Gram; row offsets differ in the block-row mode)
+    const float* rs;             // f16x2: 2^e_i per output index (the planes hold x 2^-e_i), applied to the result; NULL: none
     int ioff, joff;              // first output row of operand A / B in units of entries
     float* C; long long ldc;
     int M, N, K;                 // K multiple of 16
+    int kt0, kt1;                // K tiles [kt0, kt1) of this launch; kt0 > 0: accumulate into C (the launches of one product run back to back)
     int lower, mirror;
     int nbi, nbj, ntiles;
     const int* tilemap;          // optional [ntiles]: bi << 16 | bj
@@ -53,10 +66,16 @@ __device__ __forceinline__ bf16x8 gb_frag(const uint4& u) {
     __builtin_memcpy(&f, &u, 16);
     return f;
 }
+__device__ __forceinline__ halfx8 gb_hfrag(const uint4& u) {
+    halfx8 f;
+    __builtin_memcpy(&f, &u, 16);
+    return f;
+}
 
+template <int NPL>      // 3: bf16 planes, six products; 2: fp16 planes, three products
 __global__ void __launch_bounds__(GB_THREADS, 2)
-gram_bf16x3_kernel(GramB3 g) {
-    __shared__ uint4 lds[2][2][3][2][GB_BM];             // [buffer][A/B][plane][k group][i]: 48 KB
+gram_split_kernel(GramB3 g) {
+    __shared__ uint4 lds[2][2][NPL][2][GB_BM];           // [buffer][A/B][plane][k group][i]: 48 KB (bf16x3) / 32 KB (f16x2)
     const int per = (g.ntiles + 7) / 8;
     const int w_idx = (blockIdx.x % 8) * per + blockIdx.x / 8;          // XCD b % 8 walks a contiguous range of the tile list
     if (w_idx >= g.ntiles) return;
@@ -68,9 +87,9 @@ gram_bf16x3_kernel(GramB3 g) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wi = (wid >> 1) * 64, wj = (wid & 1) * 64;
     const int s_kg = tid >> 7, s_i = tid & 127;          // staging: one 16-byte entry per thread, plane and operand
-    const size_t offA = (size_t)s_kg * g.ldz + g.ioff + I0 + s_i;
-    const size_t offB = (size_t)s_kg * g.ldz + g.joff + J0 + s_i;
     const size_t kstep = (size_t)2 * g.ldz;              // entries per K tile (two k groups)
+    const size_t offA = (size_t)s_kg * g.ldz + g.ioff + I0 + s_i + (size_t)g.kt0 * kstep;
+    const size_t offB = (size_t)s_kg * g.ldz + g.joff + J0 + s_i + (size_t)g.kt0 * kstep;
 
     floatx16 acc[2][2];
 #pragma unroll
@@ -80,54 +99,82 @@ gram_bf16x3_kernel(GramB3 g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    uint4 s0a0, s0a1, s0a2, s0b0, s0b1, s0b2, s1a0, s1a1, s1a2, s1b0, s1b1, s1b2;
+    // Global loads run THREE K tiles ahead of the matrix cores through a ring of three register sets (tile t travels through set
+    // t % 3 and LDS buffer t % 2).  One tile ahead -- the fp32 kernel's distance -- left this kernel at half of the matrix rate: a
+    // K tile takes 1.2 us here (2.7 x faster than there), 38 % of the operand requests miss the XCD's L2 (PMC: 183 GB fetched for
+    // 487 GB requested) and come back from the Infinity Cache / HBM later than that.
+    uint4 s0a0, s0a1, s0a2, s0b0, s0b1, s0b2, s1a0, s1a1, s1a2, s1b0, s1b1, s1b2, s2a0, s2a1, s2a2, s2b0, s2b1, s2b2;
 #define GB_GLOAD(S, t)                                          \
     {                                                           \
         const size_t k_ = (size_t)(t) * kstep;                  \
-        S##a0 = g.Z[0][offA + k_]; S##a1 = g.Z[1][offA + k_]; S##a2 = g.Z[2][offA + k_];        \
-        S##b0 = g.Zb[0][offB + k_]; S##b1 = g.Zb[1][offB + k_]; S##b2 = g.Zb[2][offB + k_];     \
+        S##a0 = g.Z[0][offA + k_]; S##a1 = g.Z[1][offA + k_];                                   \
+        S##b0 = g.Zb[0][offB + k_]; S##b1 = g.Zb[1][offB + k_];                                 \
+        if (NPL == 3) { S##a2 = g.Z[2][offA + k_]; S##b2 = g.Zb[2][offB + k_]; }                \
     }
 #define GB_LSTORE(S, buf)                                       \
     {                                                           \
-        lds[buf][0][0][s_kg][s_i] = S##a0; lds[buf][0][1][s_kg][s_i] = S##a1; lds[buf][0][2][s_kg][s_i] = S##a2;   \
-        lds[buf][1][0][s_kg][s_i] = S##b0; lds[buf][1][1][s_kg][s_i] = S##b1; lds[buf][1][2][s_kg][s_i] = S##b2;   \
+        lds[buf][0][0][s_kg][s_i] = S##a0; lds[buf][0][1][s_kg][s_i] = S##a1;                   \
+        lds[buf][1][0][s_kg][s_i] = S##b0; lds[buf][1][1][s_kg][s_i] = S##b1;                   \
+        if (NPL == 3) { lds[buf][0][NPL - 1][s_kg][s_i] = S##a2; lds[buf][1][NPL - 1][s_kg][s_i] = S##b2; }         \
     }
     const int fk = lane >> 5, fi = lane & 31;
     auto compute = [&](int buf) {
-        bf16x8 fa[2][3], fb[2][3];
+        uint4 ua[2][NPL], ub[2][NPL];
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
-                fa[a][pl] = gb_frag(lds[buf][0][pl][fk][wi + a * 32 + fi]);
-                fb[a][pl] = gb_frag(lds[buf][1][pl][fk][wj + a * 32 + fi]);
+            for (int pl = 0; pl < NPL; ++pl) {
+                ua[a][pl] = lds[buf][0][pl][fk][wi + a * 32 + fi];
+                ub[a][pl] = lds[buf][1][pl][fk][wj + a * 32 + fi];
             }
-        // the six kept products, smallest weights first; the four accumulators of the wave between two dependent instructions
-#define GB_TERM(PA, PB)                                                                                         \
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][PA], fb[0][PB], acc[0][0], 0, 0, 0);           \
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][PA], fb[1][PB], acc[0][1], 0, 0, 0);           \
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][PA], fb[0][PB], acc[1][0], 0, 0, 0);           \
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][PA], fb[1][PB], acc[1][1], 0, 0, 0);
-        GB_TERM(0, 2) GB_TERM(2, 0) GB_TERM(1, 1) GB_TERM(0, 1) GB_TERM(1, 0) GB_TERM(0, 0)
+        // the kept products, smallest weights first; the four accumulators of the wave between two dependent instructions
+        if constexpr (NPL == 3) {
+#define GB_TERM(PA, PB)                                                                                                               \
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gb_frag(ua[0][PA]), gb_frag(ub[0][PB]), acc[0][0], 0, 0, 0);           \
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gb_frag(ua[0][PA]), gb_frag(ub[1][PB]), acc[0][1], 0, 0, 0);           \
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gb_frag(ua[1][PA]), gb_frag(ub[0][PB]), acc[1][0], 0, 0, 0);           \
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gb_frag(ua[1][PA]), gb_frag(ub[1][PB]), acc[1][1], 0, 0, 0);
+            GB_TERM(0, 2) GB_TERM(2, 0) GB_TERM(1, 1) GB_TERM(0, 1) GB_TERM(1, 0) GB_TERM(0, 0)
 #undef GB_TERM
+        } else {
+#define GB_TERM(PA, PB)                                                                                                               \
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gb_hfrag(ua[0][PA]), gb_hfrag(ub[0][PB]), acc[0][0], 0, 0, 0);          \
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gb_hfrag(ua[0][PA]), gb_hfrag(ub[1][PB]), acc[0][1], 0, 0, 0);          \
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gb_hfrag(ua[1][PA]), gb_hfrag(ub[0][PB]), acc[1][0], 0, 0, 0);          \
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gb_hfrag(ua[1][PA]), gb_hfrag(ub[1][PB]), acc[1][1], 0, 0, 0);
+            GB_TERM(0, 1) GB_TERM(1, 0) GB_TERM(0, 0)
+#undef GB_TERM
+        }
     };
-    const int ntile_k = g.K / GB_BK;
+    const int ntile_k = g.kt1 - g.kt0;
+    // step T: request tile T + 3 (its register set held tile T, which is in LDS), run tile T from LDS[T % 2], then write tile T + 1 to the
+    // other buffer -- every wave left that buffer before the barrier that ended step T - 1 -- and close the step with ONE barrier.
+    // STRAIGHT-LINE: the launcher makes the K tiles of a launch a multiple of six (K is zero-padded to 96), requests past the end are
+    // clamped to the last tile and the final store goes to a buffer nobody reads -- with the requests and stores under `if`s the
+    // compiler's wait-counter pass gave up at the joins and put s_waitcnt vmcnt(0) in front of every request (no prefetch at all).
+#define GB_STEP(T, SLOAD, SSTORE, BUFC, BUFS)                   \
+    {                                                           \
+        GB_GLOAD(SLOAD, min((T) + 3, ntile_k - 1))              \
+        compute(BUFC);                                          \
+        GB_LSTORE(SSTORE, BUFS)                                 \
+        __syncthreads();                                        \
+    }
     if (ntile_k > 0) {
         GB_GLOAD(s0, 0)
+        GB_GLOAD(s1, min(1, ntile_k - 1))
+        GB_GLOAD(s2, min(2, ntile_k - 1))
         GB_LSTORE(s0, 0)
         __syncthreads();
-        for (int kt = 0; kt < ntile_k; kt += 2) {
-            if (kt + 1 < ntile_k) GB_GLOAD(s1, kt + 1)
-            compute(0);
-            if (kt + 1 < ntile_k) {
-                GB_LSTORE(s1, 1)
-                __syncthreads();
-                if (kt + 2 < ntile_k) GB_GLOAD(s0, kt + 2)
-                compute(1);
-                if (kt + 2 < ntile_k) { GB_LSTORE(s0, 0) __syncthreads(); }
-            }
+        for (int kt = 0; kt < ntile_k; kt += 6) {
+            GB_STEP(kt, s0, s1, 0, 1)
+            GB_STEP(kt + 1, s1, s2, 1, 0)
+            GB_STEP(kt + 2, s2, s0, 0, 1)
+            GB_STEP(kt + 3, s0, s1, 1, 0)
+            GB_STEP(kt + 4, s1, s2, 0, 1)
+            GB_STEP(kt + 5, s2, s0, 1, 0)
         }
     }
+#undef GB_STEP
 #undef GB_GLOAD
 #undef GB_LSTORE
     // C/D layout of the 32x32 instruction: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
@@ -145,7 +192,9 @@ gram_bf16x3_kernel(GramB3 g) {
                     // (h l', l h') / (h m', m h') enter the accumulator in an order that is not symmetric in (i, j), so (i, j) and (j, i)
                     // computed directly would differ in the last bit; the block-row mode is followed by symmetrize_from_lower (prep.hip)
                     if (g.lower && !offdiag && row < col) continue;
-                    const float v = acc[a][b][r];
+                    float v = acc[a][b][r];
+                    if (g.rs != nullptr) v *= g.rs[g.ioff + row] * g.rs[g.joff + col];          // powers of two: exact
+                    if (g.kt0 > 0) v += g.C[(size_t)col * g.ldc + row];          // the earlier K ranges of this product (fixed order: deterministic)
                     g.C[(size_t)col * g.ldc + row] = v;
                     if (g.lower && g.mirror && row != col) g.C[(size_t)row * g.ldc + col] = v;
                 }
@@ -153,16 +202,22 @@ gram_bf16x3_kernel(GramB3 g) {
         }
 }
 
-// Split columns [0, nc) of X (rows x nc, column-major, ld ldx, rows beyond `rows` zero up to a multiple of 8) into the three bf16
-// planes of Z = X': entry (k group kg, index i0 + j) of plane pl holds rows 8 kg .. 8 kg + 7 of column j.  A workgroup transposes a
+// Split columns [0, nc) of X (rows x nc, column-major, ld ldx, rows beyond `rows` zero up to a multiple of 8) into the planes of
+// Z = X': entry (k group kg, index i0 + j) of plane pl holds rows 8 kg .. 8 kg + 7 of column j.  A workgroup transposes a
 // 64-row x 64-column piece through LDS so that the reads run down the columns of X and the writes along i.
 __device__ __forceinline__ unsigned short gb_bf16_rn(float x) {      // round to nearest even (finite inputs)
     const unsigned u = __float_as_uint(x);
     return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
+__device__ __forceinline__ unsigned short gb_f16_bits(_Float16 h) {
+    unsigned short u;
+    __builtin_memcpy(&u, &h, 2);
+    return u;
+}
+template <int NPL>
 __global__ void __launch_bounds__(256)
-split3_kernel(const float* __restrict__ X, long long ldx, int rows, int nc, uint4* __restrict__ Zh, uint4* __restrict__ Zm, uint4* __restrict__ Zl,
-              long long ldz, int i0, int nkg) {
+split_kernel(const float* __restrict__ X, long long ldx, int rows, int nc, uint4* __restrict__ Z0, uint4* __restrict__ Z1, uint4* __restrict__ Z2,
+             long long ldz, int i0, int nkg, const float* __restrict__ rinv) {
     __shared__ float tile[64][65];
     const int R0 = blockIdx.x * 64, J0 = blockIdx.y * 64;
     const int tid = threadIdx.x;
@@ -181,49 +236,90 @@ split3_kernel(const float* __restrict__ X, long long ldx, int rows, int nc, uint
         const int kg = R0 / 8 + kgl;
         if (J0 + col >= nc || kg >= nkg) continue;
         unsigned short h[8], m[8], l[8];
+        const float sc = NPL == 2 ? rinv[i0 + J0 + col] : 1.f;           // 2^-e_j (exact)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int r = R0 + kgl * 8 + e;
-            const float x = r < rows ? tile[col][kgl * 8 + e] : 0.f;
-            h[e] = gb_bf16_rn(x);
-            const float r1 = x - __uint_as_float((unsigned)h[e] << 16);
-            m[e] = gb_bf16_rn(r1);
-            const float r2 = r1 - __uint_as_float((unsigned)m[e] << 16);
-            l[e] = gb_bf16_rn(r2);
+            const float x = r < rows ? tile[col][kgl * 8 + e] * sc : 0.f;
+            if constexpr (NPL == 3) {
+                h[e] = gb_bf16_rn(x);
+                const float r1 = x - __uint_as_float((unsigned)h[e] << 16);
+                m[e] = gb_bf16_rn(r1);
+                const float r2 = r1 - __uint_as_float((unsigned)m[e] << 16);
+                l[e] = gb_bf16_rn(r2);
+            } else {
+                const _Float16 hh = (_Float16)x;                          // round to nearest even; |x| < 2: no overflow
+                const _Float16 ll = (_Float16)(x - (float)hh);             // exact difference, then rounded (subnormals kept)
+                h[e] = gb_f16_bits(hh); m[e] = gb_f16_bits(ll);
+            }
         }
         auto pack = [](const unsigned short (&s)[8]) {
             return make_uint4((unsigned)s[0] | ((unsigned)s[1] << 16), (unsigned)s[2] | ((unsigned)s[3] << 16),
                               (unsigned)s[4] | ((unsigned)s[5] << 16), (unsigned)s[6] | ((unsigned)s[7] << 16));
         };
         const size_t o = (size_t)kg * ldz + i0 + J0 + col;
-        Zh[o] = pack(h); Zm[o] = pack(m); Zl[o] = pack(l);
+        Z0[o] = pack(h); Z1[o] = pack(m);
+        if (NPL == 3) Z2[o] = pack(l);
     }
 }
 
-bool gram_bf16x3_enabled() {
-    const char* e = std::getenv("ADMM_HIP_GRAM_BF16");       // read per call (the A/B test flips it inside one process)
-    return !(e && e[0] == '0');
+// f16x2: 2^e_j with 2^e_j <= max|x_j| < 2^(e_j + 1) (1 for a null column) and its reciprocal, per column -- exact scale factors
+__global__ void __launch_bounds__(256)
+colscale_kernel(const float* __restrict__ X, long long ldx, int rows, float* __restrict__ rs, float* __restrict__ rinv) {
+    __shared__ float red[4];
+    const float* c = X + (size_t)blockIdx.x * ldx;
+    float m = 0.f;
+    for (int i = threadIdx.x; i < rows; i += 256) m = fmaxf(m, fabsf(c[i]));
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        int e = 0;
+        if (m > 0.f && m < 3.0e38f) (void)frexpf(m, &e), e -= 1;       // m = f 2^(e+1), f in [0.5, 1)  ->  2^e <= m < 2^(e+1)
+        e = max(-100, min(100, e));
+        rs[blockIdx.x] = ldexpf(1.f, e);
+        rinv[blockIdx.x] = ldexpf(1.f, -e);
+    }
+}
+
+int gram_split_mode() {
+    const char* e = std::getenv("ADMM_HIP_GRAM_SPLIT");       // read per call (the A/B tests flip it inside one process)
+    if (e == nullptr) return 2;
+    const std::string v(e);
+    if (v == "0" || v == "fp32") return 0;
+    if (v == "bf16x3") return 3;
+    return 2;
 }
 
 void GramSplit3::alloc(int order, int kdepth, hipStream_t st) {
     M = order;
+    npl = gram_split_mode() == 3 ? 3 : 2;
     ldz = round_up(order, GB_BM);
-    nkg = (int)(round_up(kdepth, GB_BK) / 8);
-    planes.alloc((size_t)3 * nkg * ldz * 8);
+    nkg = (int)(round_up(kdepth, GB_KPAD) / 8);
+    planes.alloc((size_t)npl * nkg * ldz * 8);
     planes.zero(st);
+    if (npl == 2) { rs.alloc(2 * (size_t)ldz); rs.zero(st); }
 }
 
 void GramSplit3::split_cols(const float* X, long long ldx, int rows, int c0, int nc, hipStream_t st) {
     uint4* base = reinterpret_cast<uint4*>(planes.get());
     const size_t pl = (size_t)nkg * ldz;
-    hipLaunchKernelGGL(split3_kernel, dim3((rows + 63) / 64, (nc + 63) / 64), dim3(256), 0, st, X, ldx, rows, nc, base, base + pl, base + 2 * pl, ldz, c0, nkg);
+    const dim3 grid((rows + 63) / 64, (nc + 63) / 64);
+    if (npl == 3) {
+        hipLaunchKernelGGL((split_kernel<3>), grid, dim3(256), 0, st, X, ldx, rows, nc, base, base + pl, base + 2 * pl, ldz, c0, nkg, (const float*)nullptr);
+    } else {
+        hipLaunchKernelGGL(colscale_kernel, dim3(nc), dim3(256), 0, st, X, ldx, rows, rs.get() + c0, rs.get() + ldz + c0);
+        hipLaunchKernelGGL((split_kernel<2>), grid, dim3(256), 0, st, X, ldx, rows, nc, base, base + pl, (uint4*)nullptr, ldz, c0, nkg, (const float*)(rs.get() + ldz));
+    }
 }
 
 static void launch_gram_b3(const GramSplit3& z, int ioff, int joff, float* C, long long ldc, int M, int N, bool lower, const int* tilemap, int ntiles_listed, hipStream_t st) {
     GramB3 g;
     const uint4* base = reinterpret_cast<const uint4*>(z.planes.get());
     const size_t pl = (size_t)z.nkg * z.ldz;
-    for (int k = 0; k < 3; ++k) { g.Z[k] = base + k * pl; g.Zb[k] = base + k * pl; }
+    for (int k = 0; k < 3; ++k) { g.Z[k] = base + std::min(k, z.npl - 1) * pl; g.Zb[k] = g.Z[k]; }
+    g.rs = z.npl == 2 ? z.rs.get() : nullptr;
     g.ldz = z.ldz; g.ioff = ioff; g.joff = joff; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = z.nkg * 8;
     g.lower = lower ? 1 : 0; g.mirror = lower ? 1 : 0;
     g.nbi = (M + GB_BM - 1) / GB_BM; g.nbj = (N + GB_BM - 1) / GB_BM;
@@ -231,7 +327,19 @@ static void launch_gram_b3(const GramSplit3& z, int ioff, int joff, float* C, lo
     g.tilemap = tilemap;
     if (tilemap != nullptr && ntiles_listed >= 0) g.ntiles = ntiles_listed;
     if (g.ntiles <= 0) return;
-    hipLaunchKernelGGL(gram_bf16x3_kernel, dim3((g.ntiles + 7) / 8 * 8), dim3(GB_THREADS), 0, st, g);
+    // The K range goes out in several launches (C accumulated between them): the tiles that share operand panels in an XCD's L2 drift
+    // apart in K inside one long launch -- at 2.7 x the fp32 kernel's pace the operand over-fetch (57-fold there) is what the launch
+    // waits for -- and start together again with every launch.  ADMM_HIP_GRAM_B3_KTILES=<K tiles per launch> (A/B; 0 = one launch).
+    const int nkt = g.K / GB_BK;
+    int per_launch = 516;
+    if (const char* e = std::getenv("ADMM_HIP_GRAM_B3_KTILES")) per_launch = std::atoi(e);
+    if (per_launch <= 0) per_launch = nkt;
+    per_launch = (per_launch + 5) / 6 * 6;
+    for (int kt = 0; kt < nkt; kt += per_launch) {
+        g.kt0 = kt; g.kt1 = std::min(nkt, kt + per_launch);
+        if (z.npl == 3) hipLaunchKernelGGL((gram_split_kernel<3>), dim3((g.ntiles + 7) / 8 * 8), dim3(GB_THREADS), 0, st, g);
+        else hipLaunchKernelGGL((gram_split_kernel<2>), dim3((g.ntiles + 7) / 8 * 8), dim3(GB_THREADS), 0, st, g);
+    }
 }
 
 // C (both triangles, order x order) = Z Z' from the planes; tiles in the XCD-local square order of syrk_mfma.hip

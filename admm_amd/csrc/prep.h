@@ -45,9 +45,12 @@ void upload_standardize_gram_f32(DeviceData<float>& d, const double* x, const do
 void clone_with_response_f32(DeviceData<float>& d, const DeviceData<float>& base, const float* gram, long long ldgram,
                              const double* y_dev, hipStream_t st);
 
-// The tall Gram on the bf16 matrix cores (gram_bf16x3.hip): Z = X' as three bf16 planes (x = h + m + l), six kept cross products.
+// The tall Gram on the 16-bit matrix cores (gram_bf16x3.hip): Z = X' as two fp16 planes (x = 2^e (h + l), three kept cross products;
+// default) or three bf16 planes (x = h + m + l, six kept cross products).
 struct GramSplit3 {
-    DevBuf<unsigned short> planes;      // [3][nkg][ldz][8] bf16
+    int npl = 2;                        // planes: 2 = fp16 split, 3 = bf16 split
+    DevBuf<float> rs;                   // fp16 split: [2][ldz] 2^e_i and 2^-e_i per output index
+    DevBuf<unsigned short> planes;      // [npl][nkg][ldz][8] 16-bit values
     long long ldz = 0;                  // entries (of 8 bf16) per k group: order rounded up to 128
     int nkg = 0, M = 0;                 // k groups of 8 (K rounded up to 16); order
     void alloc(int order, int kdepth, hipStream_t st);
@@ -55,7 +58,7 @@ struct GramSplit3 {
     void gram_lower(float* C, long long ldc, const int* tilemap, int ntiles, hipStream_t st) const;
     void gram_rows(int r0, int nr, float* C, long long ldc, hipStream_t st) const;
 };
-bool gram_bf16x3_enabled();             // ADMM_HIP_GRAM_BF16=0: the exact-fp32 matrix-core kernel (syrk_mfma.hip) as before
+int gram_split_mode();                  // 2 (default) / 3 / 0 = the exact-fp32 matrix-core kernel (syrk_mfma.hip) as before: ADMM_HIP_GRAM_SPLIT=f16x2 | bf16x3 | 0
 
 // Cross-validation folds formed as down-dates of the full-data Gram (cv.hip): what is formed once per call.
 struct CvBase {

@@ -399,8 +399,8 @@ void upload_standardize_gram_f32(DeviceData<float>& d, const double* x, const do
     const long long ldz = round_up(p, 128);
     const int nk = (int)round_up(n, 16);
     // the operand of the matrix-core Gram: X' as three bf16 planes (gram_bf16x3.hip; p >= 4096 here, the same kernel the one-shot
-    // Gram takes at this size), or as floats with the output index contiguous (ADMM_HIP_GRAM_BF16=0)
-    const bool b3 = gram_bf16x3_enabled();
+    // Gram takes at this size), or as floats with the output index contiguous (ADMM_HIP_GRAM_SPLIT=0)
+    const bool b3 = gram_split_mode() != 0;
     GramSplit3 z3;
     DevBuf<float> Z;
     if (b3) z3.alloc(p, n, st);

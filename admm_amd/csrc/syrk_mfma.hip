@@ -460,7 +460,7 @@ void gram_mfma_f32(const float* A, long long lda, int rows, int cols, bool atA, 
     const int ntiles = nb * (nb + 1) / 2;
     int ksplit = 1;
     if (ntiles < 512) ksplit = std::min(std::min(16, (1024 + ntiles - 1) / ntiles), std::max(1, Kd / 2048));
-    if (atA && ksplit == 1 && ntiles >= 512 && gram_bf16x3_enabled()) {
+    if (atA && ksplit == 1 && ntiles >= 512 && gram_split_mode() != 0) {
         // deep-K lower-triangle Gram of a tall matrix (>= 512 tiles: order >= ~4000): bf16 matrix cores, three-way split
         // (gram_bf16x3.hip); tiles in the same XCD-local square order
         GramSplit3 z3;

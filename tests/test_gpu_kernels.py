@@ -54,7 +54,7 @@ def test_gram_tail_of_quarter_tiles_is_bit_identical(rows, cols, monkeypatch):
     the row-major tile order."""
     rng = np.random.default_rng(cols)
     A = (rng.standard_normal((rows, cols)) * 2 + 0.3).astype(np.float32)
-    monkeypatch.setenv("ADMM_HIP_GRAM_BF16", "0")                  # the exact-fp32 kernel: orders >= ~4000 take the bf16 split by default (below)
+    monkeypatch.setenv("ADMM_HIP_GRAM_SPLIT", "0")                 # the exact-fp32 kernel: orders >= ~4000 take the 16-bit split by default (below)
     G = _gram(A, True)
     monkeypatch.setenv("ADMM_HIP_GRAM_TAIL", "0")
     G0 = _gram(A, True)
@@ -67,31 +67,38 @@ def test_gram_tail_of_quarter_tiles_is_bit_identical(rows, cols, monkeypatch):
     assert np.abs(G - ref).max() / np.abs(ref).max() < 2e-5
 
 
-@pytest.mark.parametrize("rows,cols,kind", [(9000, 4136, "gauss"), (3000, 5700, "gauss"), (20000, 4200, "standardised"), (2500, 4100, "wild")])
-def test_gram_bf16_three_way_split_is_fp32_accurate(rows, cols, kind, monkeypatch):
-    """Tall Grams of order >= ~4000 run on the bf16 matrix cores with every fp32 entry split into three bf16 terms and the six
-    significant cross products kept (gram_bf16x3.hip).  Against float64: no worse than 2 x the error of the exact-fp32 matrix-core
-    kernel on the same input (both accumulate K products in fp32), mirrored exactly, and the dropped cross terms (<= 2^-25 of a
-    product) invisible -- also on columns of very different scales and entries spanning 12 orders of magnitude ("wild")."""
+@pytest.mark.parametrize("split", ["f16x2", "bf16x3"])
+@pytest.mark.parametrize("rows,cols,kind", [(9000, 4136, "gauss"), (3000, 5700, "gauss"), (20000, 4200, "standardised"), (2500, 4100, "wild"), (2100, 4000, "scales")])
+def test_gram_16bit_split_is_fp32_accurate(rows, cols, kind, split, monkeypatch):
+    """Tall Grams of order >= ~4000 run on the 16-bit matrix cores (gram_bf16x3.hip): every fp32 entry as two fp16 terms with an exact
+    per-column power-of-two scale and the three significant cross products (default), or as three bf16 terms and six products.
+    Against float64: no worse than 2 x the error of the exact-fp32 matrix-core kernel on the same input (all accumulate K products
+    in fp32), mirrored exactly -- also on entries spanning 12 orders of magnitude ("wild") and on columns whose scales span 1e-12 ..
+    1e12 ("scales": without the column scaling fp16 would overflow / flush)."""
+    monkeypatch.setenv("ADMM_HIP_GRAM_SPLIT", split)
     rng = np.random.default_rng(rows + cols)
     if kind == "gauss":
         A = rng.standard_normal((rows, cols)) * 2 + 0.3
     elif kind == "standardised":
         A = rng.standard_normal((rows, cols)) * rng.uniform(0.1, 30.0, size=cols)[None, :] + rng.uniform(-5, 5, size=cols)[None, :]
         A = (A - A.mean(0)) / A.std(0)
-    else:
+    elif kind == "wild":
         A = rng.standard_normal((rows, cols)) * 10.0 ** rng.uniform(-6, 6, size=(rows, cols))
+    else:
+        A = rng.standard_normal((rows, cols)) * 10.0 ** rng.uniform(-12, 12, size=cols)[None, :]
+        A[:, 7] = 0.0                                                  # a null column: scale 1
     A = A.astype(np.float32)
     G3 = _gram(A, True)
-    monkeypatch.setenv("ADMM_HIP_GRAM_BF16", "0")
+    monkeypatch.setenv("ADMM_HIP_GRAM_SPLIT", "0")
     G1 = _gram(A, True)
     A64 = A.astype(np.float64)
     ref = A64.T @ A64
     assert np.array_equal(G3, G3.T)
-    assert not np.array_equal(G3, G1), "the bf16 path was not taken"
-    scale = np.sqrt(np.outer(np.diag(ref), np.diag(ref)))             # entrywise: |g_ij| <= sqrt(g_ii g_jj)
+    assert not np.array_equal(G3, G1), "the 16-bit path was not taken"
+    d = np.where(np.diag(ref) > 0, np.diag(ref), 1.0)
+    scale = np.sqrt(np.outer(d, d))                                   # entrywise: |g_ij| <= sqrt(g_ii g_jj)
     e3, e1 = np.abs(G3 - ref) / scale, np.abs(G1 - ref) / scale
-    print(f"[gram bf16x3 {kind} {rows}x{cols}] max error / sqrt(g_ii g_jj): bf16x3 {e3.max():.2e} (rms {np.sqrt((e3 ** 2).mean()):.2e}), fp32 kernel {e1.max():.2e} (rms {np.sqrt((e1 ** 2).mean()):.2e})")
+    print(f"[gram {split} {kind} {rows}x{cols}] max error / sqrt(g_ii g_jj): split {e3.max():.2e} (rms {np.sqrt((e3 ** 2).mean()):.2e}), fp32 kernel {e1.max():.2e} (rms {np.sqrt((e1 ** 2).mean()):.2e})")
     assert e3.max() <= 2.0 * e1.max() + 1e-7
     assert np.sqrt((e3 ** 2).mean()) <= 2.0 * np.sqrt((e1 ** 2).mean()) + 1e-8
 
