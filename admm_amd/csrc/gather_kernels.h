@@ -35,6 +35,7 @@ struct GatherArgs {
     int ngroups;
     int cols_per_group;     // multiple of kGatherThreads
     const int* skip;        // optional device flag: non-zero -> no-op
+    const int* only_if;     // optional device flag: zero -> no-op (the consensus workers' per-iteration fall-back pass)
 };
 
 template <typename T>
@@ -109,6 +110,7 @@ __global__ void __launch_bounds__(kGatherThreads)
 gather_batch_kernel(const GatherArgs<T>* __restrict__ batch) {
     const GatherArgs<T> a = batch[blockIdx.z];
     if (a.skip != nullptr && load_flag_vector(a.skip) != 0) return;
+    if (a.only_if != nullptr && load_flag_vector(a.only_if) == 0) return;
     if ((int)blockIdx.y >= a.ngroups) return;
     constexpr int TILE = kGatherThreads * Vec16<T>::N;
     if ((long long)blockIdx.x * TILE >= a.rows) return;
@@ -146,7 +148,7 @@ template <typename T>
 inline GatherArgs<T> gather_args(const GatherPlan& g, const T* A, long long lda, int rows, int cols, const T* v, double* part, const int* skip) {
     GatherArgs<T> a;
     a.A = A; a.lda = lda; a.rows = rows; a.cols = cols; a.v = v; a.part = part; a.pstride = g.pstride;
-    a.ngroups = g.ngroups; a.cols_per_group = g.cols_per_group; a.skip = skip;
+    a.ngroups = g.ngroups; a.cols_per_group = g.cols_per_group; a.skip = skip; a.only_if = nullptr;
     return a;
 }
 

@@ -29,7 +29,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 C3 = dict(n=2000, p=200000, m=100, seed=3003, maxit=40, pick=(5, 25, 50))
 C4 = dict(n=10000, p=100000, m=100, seed=4004, maxit=600, K=8, fractions=(0.3, 0.25))
-BP = dict(n=5000, p=50000, m=500, seed=5005, maxit=25)
+BP = dict(n=5000, p=50000, m=500, seed=5005, maxit=25, scale=20.0)
 
 
 def lasso_data(seed, n, p, m):
@@ -43,14 +43,18 @@ def lasso_data(seed, n, p, m):
     return x, y
 
 
-def bp_data(seed, n, p, m):
+def bp_data(seed, n, p, m, scale=1.0):
+    """`scale` multiplies beta*: with the README's U(0,1) coefficients and rho = 1 the minimum-norm start A'(AA')^-1 b stays below the
+    soft threshold 1 / rho, z = 0 for the first iterations, the iterate REPEATS and the restart test c < 0.999 c_old (FADMMBase.h:243) is
+    an exact tie up to the order of a sum, several times in a row (oracle/stepcheck.py, rounding_ties) -- two executions of the
+    reference's own arithmetic then part ways at iteration 2 and no fixture can hold both.  U(0, 20) coefficients start with z != 0."""
     rng = np.random.default_rng(seed)
     a = np.empty((n, p), order="F")
     step = max(1, (1 << 24) // n)
     for j0 in range(0, p, step):
         a[:, j0:j0 + step] = rng.standard_normal((n, min(step, p - j0)))
     bt = np.zeros(p)
-    bt[rng.choice(p, m, replace=False)] = rng.uniform(size=m)
+    bt[rng.choice(p, m, replace=False)] = rng.uniform(size=m) * scale
     return a, a @ bt, bt
 
 
@@ -121,12 +125,15 @@ def make_bp():
     from oracle import entry
     c = BP
     t0 = time.time()
-    a, b, _ = bp_data(c["seed"], c["n"], c["p"], c["m"])
+    a, b, _ = bp_data(c["seed"], c["n"], c["p"], c["m"], c["scale"])
     det = {"trace": []}
     ref = entry.admm_bp(a, b, dict(entry.BP_OPTS, maxit=c["maxit"]), detail=det)
     s = det["solver"]
     path = os.path.join(HERE, "c5_bp_fixed_maxit.npz")
     np.savez_compressed(path, **c, beta=ref["beta"], niter=np.int64(ref["niter"]), rho=np.float64(s.rho), trace=np.asarray(det["trace"], dtype=np.float64))
+    t = np.asarray(det["trace"], dtype=np.float64)
+    nc = t[t[:, 8] > 0]
+    print("closest restart test |c / (0.999 c_old) - 1|:", float(np.abs(nc[:, 6] / (0.999 * nc[:, 7]) - 1).min()), flush=True)
     print("wrote", path, os.path.getsize(path), "bytes; niter", int(ref["niter"]), "final rho", float(s.rho), "nnz", int(np.count_nonzero(ref["beta"])),
           f"{time.time() - t0:.0f} s", flush=True)
 

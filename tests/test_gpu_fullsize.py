@@ -283,8 +283,8 @@ def test_c3_full_size_wide_vs_oracle_fixture():
     (ADMMBase.h:85-109), all exits at maxit."""
     from admm_amd import admm_lasso
     from helpers import col_err, traced_fit
-    from make_fullsize import lasso_data
     g = _golden("c3_fixed_maxit.npz")
+    from make_fullsize import lasso_data
     x, y = lasso_data(int(g["seed"]), int(g["n"]), int(g["p"]), int(g["m"]))
     lam, maxit = g["lam"], int(g["maxit"])
     fit, trace = traced_fit(admm_lasso(x, y).penalty(lam).opts(maxit=maxit), capacity=len(lam) * (maxit + 2) + 8)
@@ -309,8 +309,8 @@ def test_c4_full_size_consensus_vs_oracle_fixture():
     the fixture must run long enough to see the consensus variable move and the gather over its support do work)."""
     from admm_amd import admm_lasso
     from helpers import col_err, traced_fit
-    from make_fullsize import lasso_data
     g = _golden("c4_fixed_maxit.npz")
+    from make_fullsize import lasso_data
     x, y = lasso_data(int(g["seed"]), int(g["n"]), int(g["p"]), int(g["m"]))
     maxit, K = int(g["maxit"]), int(g["K"])
     nl = len(g["lam"])
@@ -341,9 +341,9 @@ def test_c5_full_size_bp_vs_oracle_fixture():
     FADMMBase::solve + ADMMBP (acceleration / restart, rho adaptation from i > 5) against the oracle's."""
     from admm_amd import admm_bp
     from helpers import relerr
-    from make_fullsize import bp_data
     g = _golden("c5_bp_fixed_maxit.npz")
-    a, b, _ = bp_data(int(g["seed"]), int(g["n"]), int(g["p"]), int(g["m"]))
+    from make_fullsize import bp_data
+    a, b, _ = bp_data(int(g["seed"]), int(g["n"]), int(g["p"]), int(g["m"]), float(g["scale"]))      # (why scaled: bp_data's docstring -- exact ties of the restart test)
     maxit = int(g["maxit"])
     fit = admm_bp(a, b).opts(maxit=maxit).fit(trace=True)
     assert fit.niter == int(g["niter"]) == maxit + 1
