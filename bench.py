@@ -201,6 +201,42 @@ def _max_over_ranks(v, torch, dist, multi):
     return float(t[0])
 
 
+def exchcheck_child(a, backend, out_path):
+    """First thing at N > 1: the exchange layer on its own, before any solver depends on it.  Every rank contributes a known vector
+    (floats and doubles, rank-dependent), the in-place sum all-reduce of `backend` runs three times (the slot parity of the PEER /
+    SHM protocols alternates), and every rank compares with the closed-form sum.  The first 8-GPU run of this tree is also the first
+    execution of every nccl* call of comm.hip with more than one rank in the communicator and the first PEER exchange across xGMI:
+    this child says WHICH of the two works there, the measurements that follow keep going either way (run_side_measurement)."""
+    rank, world, multi, torch, dist, dev, adist = _child_setup(backend)
+    import numpy as np
+    nf, nd = 100003, 5
+    ok, worst = True, 0.0
+    for rep in range(3):
+        f = ((np.arange(nf) % 977) * 1e-3 + rank + 0.25 * rep).astype(np.float32)
+        d = (np.arange(nd) * 1e-3 + 2.0 * rank + rep).astype(np.float64)
+        ef = sum(((np.arange(nf) % 977) * 1e-3 + r + 0.25 * rep).astype(np.float32).astype(np.float64) for r in range(world))
+        ed = sum((np.arange(nd) * 1e-3 + 2.0 * r + rep) for r in range(world))
+        adist.allreduce_host(f, d)
+        ferr = float(np.abs(f.astype(np.float64) - ef).max() / np.abs(ef).max())
+        derr = float(np.abs(d - ed).max() / np.abs(ed).max())
+        worst = max(worst, ferr, derr)
+        ok = ok and ferr < 1e-6 * world and derr < 1e-14 * world
+    allok = True
+    if multi:
+        t = torch.tensor([1 if ok else 0], dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        allok = bool(int(t[0]) == 1)
+    if rank == 0:
+        with open(out_path, "w") as f_:
+            json.dump({"exchange": backend, "ranks": world, "all_ranks_correct": allok, "worst_relative_error_rank0": worst,
+                       "payload": "%d floats + %d doubles, 3 exchanges" % (nf, nd)}, f_)
+    if multi:
+        dist.barrier()
+    adist.finalize_comm()
+    if multi:
+        dist.destroy_process_group()
+
+
 def consensus_child(a, backend, out_path):
     """Side measurement (own processes, own process group): BASELINE configs[3]-shaped consensus Lasso
     `admm_lasso(x, y)$parallel(K)`, n=10000, p=100000, K = number of ranks, one row block per GPU, rows
@@ -745,7 +781,7 @@ def main():
         if kind == "config":
             config_child(a, backend, out_path)
             return
-        {"consensus": consensus_child, "tallshard": tallshard_child, "widecols": widecols_child}[kind](a, backend, out_path)
+        {"consensus": consensus_child, "tallshard": tallshard_child, "widecols": widecols_child, "exchcheck": exchcheck_child}[kind](a, backend, out_path)
         return
     # The JSON line must be the only thing on stdout: libraries loaded below (RCCL prints a version banner to stdout when
     # its first communicator is created, flushed at exit) get stderr as their fd 1; the line goes to the saved descriptor.
@@ -836,6 +872,18 @@ def main():
 
     # ---- side measurements in child processes (own rendezvous, time-limited): the paths with a real exchange step
     consensus, shard = [], []
+    exch = []
+    if multi:
+        for k, backend in enumerate(("rccl", "peer")):
+            exch.append(run_side_measurement(a, rank, world, "exchcheck", backend, 120.0, 5 + 6 * k))
+            barrier()
+        if rank == 0:
+            good = [c["exchange"] for c in exch if c and c.get("all_ranks_correct")]
+            for c in exch:
+                if c and not c.get("all_ranks_correct"):
+                    sys.stderr.write("[bench] exchange self-check over %s FAILED at %d ranks: %s -- the measurements over it are kept apart as `rejected` / `error`; "
+                                     "continuing with %s\n" % (c["exchange"], world, c.get("error", "sums differ from the closed form (relative error %.2e)" % c.get("worst_relative_error_rank0", float("nan"))),
+                                                                 ", ".join(good) if good else "the replica figure only"))
     if a.consensus_seconds > 0:
         consensus.append(run_side_measurement(a, rank, world, "consensus", "rccl", a.consensus_seconds, 17))
         barrier()
@@ -912,6 +960,8 @@ def main():
         }
         consensus = [c for c in consensus if c]
         shard = [c for c in shard if c]
+        if exch:
+            out["exchange_self_check"] = [c for c in exch if c]
         if consensus:
             out["consensus"] = consensus[0] if len(consensus) == 1 else consensus
         widecols = [c for c in widecols if c]

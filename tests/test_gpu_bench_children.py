@@ -67,3 +67,12 @@ def test_bench_multi_rank_child_as_two_processes(kind):
     if kind == "consensus":
         assert res["peer"]["K"] == 8 and res["peer"]["scaling"] == "strong"
     print(f"[bench child {kind}] 2 ranks on one GPU: " + ", ".join(f"{b}: {it[b]} iterations, {res[b]['iters_per_s']:.0f} it/s" for b in res))
+
+
+def test_bench_exchange_self_check_as_two_processes():
+    """bench.py's first step at N > 1 (exchcheck_child): the all-reduce of each back-end against the closed-form sum, two ranks on one GPU
+    over PEER and SHM -- the child that tells the first multi-GPU run WHICH exchange works there."""
+    for b in ("peer", "shm"):
+        r = _run_child("exchcheck", b, timeout=180)
+        assert r["exchange"] == b and r["ranks"] == 2 and r["all_ranks_correct"] is True, r
+        assert r["worst_relative_error_rank0"] < 1e-6, r
