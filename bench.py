@@ -686,14 +686,23 @@ def cpu_config_baseline(name, budget_s, seed):
         return None
     t_setup = time.time() - t_setup0
     it1, s1 = run(1, budget_s)
-    itn, sn = run(threads, budget_s)
+    # all-core leg: the host may hand out fewer cores than it shows (cgroup quota on a shared box: 128 visible threads measured 4 x
+    # one core on the tall loop): the same loop at all visible threads, 32 and 8, the best one reported with its thread count
+    tried = []
+    for nt in sorted({threads, min(threads, 32), min(threads, 8)}, reverse=True):
+        if nt <= 1:
+            continue
+        itq, sq = run(nt, budget_s / 2)
+        tried.append((itq / sq if sq > 0 else 0.0, nt, itq, sq))
+    rate_n, threads, itn, sn = max(tried) if tried else (0.0, 1, 0, 0.0)
+    tried_note = ", ".join("%d threads: %.3g it/s" % (nt, r * scale) for r, nt, _, _ in tried)
     it1, itn = it1 * scale, itn * scale
     return {"value": it1 / s1 if s1 > 0 else None, "unit": "iterations/s", "cores": 1, "kind": "port",
             "sample": f"compiled C restatement (oracle/c/admm_loops_cpu.c, gcc -O3 -fopenmp) of {what}; ONE thread: {it1:g} (scaled) iterations in {s1:.1f} s; "
                       f"data generation + setup (Gram / factorisation, NumPy) {t_setup:.1f} s not included",
             "best_effort": {"value": itn / sn if sn > 0 else None, "unit": "iterations/s", "cores": int(threads),
                             "sample": f"the same compiled loop with every product spread over {threads} OpenMP threads (OMP_PROC_BIND=spread, OMP_PLACES=cores): "
-                                      f"{itn:g} (scaled) iterations in {sn:.1f} s"}}
+                                      f"{itn:g} (scaled) iterations in {sn:.1f} s; best of [{tried_note}]"}}
 
 
 def _cpu_parbp_numpy(budget_s, seed):
