@@ -138,9 +138,12 @@ par_head_kernel(ParParams q) {
 // relative accuracy down to zero and sees every rounding the stored y_k carries; q_k follows the un-rounded dual, so t_k misses
 // A_k (rounding of y_k) -- an absolute error of u |A_k||y_k| that the stepwise instrument (oracle/stepcheck.py) flags once
 // |t_k| << |q_k| (measured: 160 x the float-solve yardstick at |t| / |q| = 1 / 4000, fresh samples 811:42 / 812:42; below the
-// reference's own x-update error from |t| / |q| >= 1 / 64 on).  So: per worker and iteration, |t_k|_2 < tau |q_k|_2 (tau = 1 / 128)
-// -> t_k is formed the reference's way for this iteration, one dense pass A_k rhs_k through the same gather kernel (double
-// accumulation), and q_k is re-anchored on it.  Elsewhere the one-pass form is MORE accurate than the float product it replaces.
+// reference's own x-update error from |t| / |q| >= 1 / 64 on).  The missing term is the part of the dual's rounding noise that lies
+// in range(A_k'), sqrt(rows_k / p) of it, so its size against the yardstick goes like sqrt(rows_k / p) |q| / |t|.  So: per worker and
+// iteration, |t_k|_2 < tau_k |q_k|_2 with tau_k = sqrt(rows_k / p) / 16 (1/16 for a nearly square block: the soak's ill-conditioned
+// 947:142 is at the two-pass form's own 12 x there, 18 x at 1/128; 1/143 for C4's 1250 x 10^5 blocks) -> t_k is formed the
+// reference's way for this iteration, one dense pass A_k rhs_k through the same gather kernel (double accumulation), and q_k is
+// re-anchored on it.  Elsewhere the one-pass form is MORE accurate than the float product it replaces.
 __global__ void __launch_bounds__(256)
 par_wb_flag_kernel(ParParams q) {
     __shared__ double scratch[2 * 4];
@@ -154,7 +157,7 @@ par_wb_flag_kernel(ParParams q) {
     }
     block_sum<double, 2>(acc, scratch);
     if (threadIdx.x == 0) {
-        const int f = (rows > 0 && acc[0] < q.wb_tau2 * acc[1]) ? 1 : 0;
+        const int f = (rows > 0 && acc[0] < q.wb_tau2 * ((double)rows / (double)q.p) * acc[1]) ? 1 : 0;      // tau_k = tau0 sqrt(rows_k / p)
         q.wbflag[k] = f;
         if (f) atomicAdd(q.wbcount, 1ull);
     }
@@ -654,7 +657,7 @@ struct ParPlan final : LassoPlan {
             wbcount.alloc(1); wbcount.zero(st);
             q.azv = azv.get(); q.tv64 = tv64.get(); q.wbflag = wbflag.get(); q.dpart = dpart.get(); q.wbcount = wbcount.get();
             {
-                double tau = 1.0 / 128.0;
+                double tau = 1.0 / 16.0;                                                       // tau0: see par_wb_flag_kernel
                 if (const char* e = std::getenv("ADMM_HIP_PAR_ONEPASS_TAU")) tau = std::atof(e);       // 0: never fall back (the measurement of the failure); 1e30: always
                 q.wb_tau2 = tau * tau;
             }

@@ -106,6 +106,12 @@ SOAK_CASES = [
     (858, 11, "par", "stopping decision at iteration 225 needs 11.7 ulps (K=3, scale 0.01)"),
     (859, 15, "enet_tall", "stopping decision at iteration 1908 needs 8.4 ulps"),
     (868, 70, "enet_tall", "restart decision at iteration 501 needs 8.5 ulps"),
+    # round-5 soak on the round-4 seeds 901..948 with the ONE-PASS consensus workers (profiles/r05_soak_summary_seeds901.md: 6871 of
+    # 6882 pass; tall / wide / LAD populations identical to round 4's, decision for decision): the consensus failures -- stopping
+    # decisions 8.3 .. 9.3 ulps out on ill-conditioned nearly square Woodbury blocks, the kind listed above
+    (940, 147, "par", "stopping decision at iteration 436 needs 8.3 ulps (K=4, 21 x 54 blocks, unstandardised)"),
+    (945, 120, "par", "stopping decision at iteration 409 needs 9.1 ulps (K=3)"),
+    (947, 142, "par", "stopping decision needs 9.3 ulps (K=2, 28 x 31 blocks: round 4's two-pass form failed the same case at 17.9 ulps; x-update 12 x the reference's own in either form)"),
 ]
 # per-record ceiling of the x-update's error: x the first-order float-solve yardstick (tall family; measured <= 1.8), x the
 # reference's own float Cholesky / Woodbury solve on the same right-hand side (consensus; measured <= 10.4 -- the maximum
