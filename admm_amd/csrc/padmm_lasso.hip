@@ -46,6 +46,7 @@ struct ParWb {
     const float* spart;            // partial rows of s_k = Minv t_k (the worker's gM product), summed in row order like the next product's staging does
     long long sstride;
     int snseg, rows;               // rows = 0: a tall block (Cholesky branch), nothing to do
+    const float* G; long long ldg; // the float Gram A_k A_k' the cached inverse was formed from (par_wb_resid_kernel)
 };
 
 struct ParParams {
@@ -73,6 +74,7 @@ struct ParParams {
     const double* cv; double* qv; float* tvec; const double* azpart;
     double* azv; double* tv64; int* wbflag; const double* dpart; double wb_tau2;      // cancellation fall-back (par_wb_flag_kernel)
     unsigned long long* wbcount;                                                         // fall-back passes taken (diagnostic)
+    double* dlt;                                                                         // [Kl][wb_ld] residual of the small solve (par_wb_resid_kernel)
 #ifdef ADMM_HIP_PROBE
     long long* probe;
 #endif
@@ -124,7 +126,7 @@ par_head_kernel(ParParams q) {
             }
             float sv = 0.f;
             for (int r = 0; r < wb.snseg; ++r) sv += wb.spart[(size_t)r * wb.sstride + i];
-            const double qn = q.qv[gi] + rho_f * ((double)sv - az);
+            const double qn = q.qv[gi] + rho_f * ((double)sv - az) - q.dlt[gi];       // A_k x_k = s_k - delta_k / rho (par_wb_resid_kernel)
             const double tn = q.cv[gi] - qn + q.rho * az;
             q.qv[gi] = qn; q.azv[gi] = az; q.tv64[gi] = tn;
             q.tvec[gi] = (float)tn;
@@ -161,6 +163,66 @@ par_wb_flag_kernel(ParParams q) {
         q.wbflag[k] = f;
         if (f) atomicAdd(q.wbcount, 1ull);
     }
+}
+// The residual of the small solve, delta_k = (A_k A_k' + rho I) s_k - t_k, in double from the float Gram, the float s_k and the float t_k
+// the solve was given: with it A_k x_k = (t_k - A_k A_k's_k) / rho = s_k - delta_k / rho exactly, and the recurrence of q_k carries no
+// term of the cached inverse's own error (u cond(A_k A_k' + rho I) |t_k|; without it the x-update of ill-conditioned blocks was 1.2 .. 1.4
+// x the two-pass form's error in the rms over a run, emulation and soak 940:147 / 947:142; with it the two forms are level).
+// One wave per row of the symmetric Gram (its column, contiguous), all local workers in one launch.
+__device__ __forceinline__ void par_wb_resid_row(const ParParams& q, int wave) {
+    const int lane = threadIdx.x & 63;
+    const int k = wave / q.wb_ld, i = wave - k * q.wb_ld;
+    if (k >= q.Kl) return;
+    const ParWb wb = q.wb[k];
+    if (i >= wb.rows) return;
+    const float* g = wb.G + (size_t)i * wb.ldg;
+    double acc = 0.0;
+    // 16 bytes per lane and request (the Gram's columns start on 512-byte boundaries, the partial rows of s on 128-byte ones); rows
+    // beyond wb.rows of the Gram column are zero (the Gram buffer is zero padded), so whole float4 pieces are safe
+    const int r4 = (wb.rows + 3) / 4;
+    for (int j4 = lane; j4 < r4; j4 += 64) {
+        const float4 gv = reinterpret_cast<const float4*>(g)[j4];
+        float4 sv = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int r = 0; r < wb.snseg; ++r) {
+            const float4 pv = reinterpret_cast<const float4*>(wb.spart + (size_t)r * wb.sstride)[j4];
+            sv.x += pv.x; sv.y += pv.y; sv.z += pv.z; sv.w += pv.w;
+        }
+        const int j = 4 * j4;
+        acc = fma((double)gv.x, (double)sv.x, acc);
+        if (j + 1 < wb.rows) acc = fma((double)gv.y, (double)sv.y, acc);
+        if (j + 2 < wb.rows) acc = fma((double)gv.z, (double)sv.z, acc);
+        if (j + 3 < wb.rows) acc = fma((double)gv.w, (double)sv.w, acc);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) {
+        float si = 0.f;
+        for (int r = 0; r < wb.snseg; ++r) si += wb.spart[(size_t)r * wb.sstride + i];
+        q.dlt[(size_t)k * q.wb_ld + i] = acc + (double)(float)q.rho * (double)si - (double)q.tvec[(size_t)k * q.wb_ld + i];
+    }
+}
+__global__ void __launch_bounds__(256)
+par_wb_resid_kernel(ParParams q) {
+    if (load_flag_vector(q.done)) return;
+    par_wb_resid_row(q, blockIdx.x * 4 + (threadIdx.x >> 6));
+}
+// The workers' A_k's_k products (gemv_t_batch_kernel's body) with the residual rows as one more slice of the grid (blockIdx.y = 0,
+// dispatched first): delta_k only needs s_k, like the products, and is done in the first microseconds of their 0.6 ms instead of in a
+// launch of its own behind them (15 us per iteration at C4).
+template <bool NT>
+__global__ void __launch_bounds__(kGemvThreads)
+par_A_batch_resid_kernel(const GemvTArgs<float>* __restrict__ batch, ParParams q) {
+    if (blockIdx.y == 0) {
+        if (load_flag_vector(q.done)) return;
+        const int nw = q.Kl * q.wb_ld;
+        for (int w = blockIdx.x * 4 + (threadIdx.x >> 6); w < nw; w += gridDim.x * 4) par_wb_resid_row(q, w);
+        return;
+    }
+    const GemvTArgs<float> a = batch[blockIdx.y - 1];
+    if (a.skip != nullptr && *a.skip != 0) return;
+    const int ngroups = (a.k + 4 - 1) / 4;
+    const int grid = a.nseg * ((ngroups + a.groups_per_wg - 1) / a.groups_per_wg);
+    if ((int)blockIdx.x >= grid) return;
+    gemv_t_body<float, 1, 4, NT>(a, (int)blockIdx.x);
 }
 // after the fall-back pass: t_k = A_k rhs_k from its partial rows, q_k = c_k + rho A_k z - t_k (= A_k y_k as stored)
 __global__ void __launch_bounds__(256)
@@ -436,7 +498,7 @@ struct ParWorker {
     int rows = 0;
     bool wide = false;
     long long lda = 0, ldat = 0, ldm = 0;
-    DevBuf<float> A, At, Minv, tvec, svec;
+    DevBuf<float> A, At, Minv, tvec, svec, G;
     GemvT<float> gA, gAt, gM;       // gA: A' v (p outputs); gAt: A v via the stored transpose (rows outputs); gM: cached inverse
 };
 
@@ -485,7 +547,7 @@ struct ParPlan final : LassoPlan {
     GatherPlan gp;
     int wb_ld = 0, gather_tiles = 0;
     DevBuf<ParWb> wbd;
-    DevBuf<double> cv, qv, azpart, azv, tv64, dpart;
+    DevBuf<double> cv, qv, azpart, azv, tv64, dpart, dlt;
     DevBuf<float> tvec;
     DevBuf<int> wbflag;
     DevBuf<unsigned long long> wbcount;
@@ -575,6 +637,10 @@ struct ParPlan final : LassoPlan {
                 gram_full<float>(w.A.get(), w.lda, w.rows, p, false, w.Minv.get(), w.ldm, st);
                 ADMM_HIP_CHECK(hipStreamSynchronize(st));
                 t_gram += now_s() - t0; t0 = now_s();
+                if (onepass) {                               // the float Gram itself, for the residual of the small solve (par_wb_resid_kernel)
+                    w.G.alloc((size_t)w.ldm * w.ldm);
+                    ADMM_HIP_CHECK(hipMemcpyAsync(w.G.get(), w.Minv.get(), (size_t)w.ldm * w.ldm * sizeof(float), hipMemcpyDeviceToDevice, st));
+                }
                 par_inverse(w.Minv.get(), w.ldm, w.rows, rho, st);
                 if (!onepass) {
                     w.ldat = round_up(p, 32);
@@ -634,7 +700,7 @@ struct ParPlan final : LassoPlan {
             std::vector<ParWb> hwb(Kl);
             std::vector<GatherArgs<float>> hG(Kl), hG0(Kl), hGd(Kl);
             cv.alloc((size_t)Kl * wb_ld); qv.alloc((size_t)Kl * wb_ld); tvec.alloc((size_t)Kl * wb_ld);
-            azv.alloc((size_t)Kl * wb_ld); tv64.alloc((size_t)Kl * wb_ld); wbflag.alloc(Kl);
+            azv.alloc((size_t)Kl * wb_ld); tv64.alloc((size_t)Kl * wb_ld); wbflag.alloc(Kl); dlt.alloc((size_t)Kl * wb_ld); dlt.zero(st);
             azpart.alloc((size_t)Kl * gp.ngroups * wb_ld); dpart.alloc((size_t)Kl * gp.ngroups * wb_ld);
             cv.zero(st); qv.zero(st); tvec.zero(st); azpart.zero(st); azv.zero(st); tv64.zero(st); wbflag.zero(st); dpart.zero(st);
             GatherPlan gk = gp; gk.pstride = wb_ld;
@@ -642,6 +708,7 @@ struct ParPlan final : LassoPlan {
                 ParWorker& w = W[k];
                 hwb[k].spart = w.wide ? w.gM.part.get() : nullptr; hwb[k].sstride = w.gM.stride; hwb[k].snseg = w.gM.pl.nseg;
                 hwb[k].rows = w.wide ? w.rows : 0;
+                hwb[k].G = w.wide ? w.G.get() : nullptr; hwb[k].ldg = w.ldm;
                 double* part = azpart.get() + (size_t)k * gp.ngroups * wb_ld;
                 hG[k] = gather_args<float>(gk, w.A.get(), w.lda, hwb[k].rows, p, z.get(), part, done.get());
                 hG0[k] = gather_args<float>(gk, w.A.get(), w.lda, hwb[k].rows, p, Ab.get() + (size_t)k * ldv, part, nullptr);
@@ -655,7 +722,7 @@ struct ParPlan final : LassoPlan {
             q.wb = wbd.get(); q.wb_ld = wb_ld; q.az_ng = gp.ngroups;
             q.cv = cv.get(); q.qv = qv.get(); q.tvec = tvec.get(); q.azpart = azpart.get();
             wbcount.alloc(1); wbcount.zero(st);
-            q.azv = azv.get(); q.tv64 = tv64.get(); q.wbflag = wbflag.get(); q.dpart = dpart.get(); q.wbcount = wbcount.get();
+            q.azv = azv.get(); q.tv64 = tv64.get(); q.wbflag = wbflag.get(); q.dpart = dpart.get(); q.wbcount = wbcount.get(); q.dlt = dlt.get();
             {
                 double tau = 1.0 / 16.0;                                                       // tau0: see par_wb_flag_kernel
                 if (const char* e = std::getenv("ADMM_HIP_PAR_ONEPASS_TAU")) tau = std::atof(e);       // 0: never fall back (the measurement of the failure); 1e30: always
@@ -717,7 +784,7 @@ struct ParPlan final : LassoPlan {
         const int init_n = std::max(p, nwg * 8);
         hipLaunchKernelGGL(par_init_kernel, dim3((init_n + 255) / 256), dim3(256), 0, st, q, lam_int[0]);
         if (onepass) {               // y_k = 0, z = 0: q_k = A_k z = 0, and no s_k yet
-            qv.zero(st); azpart.zero(st);
+            qv.zero(st); azpart.zero(st); dlt.zero(st);
             for (int k = 0; k < Kl; ++k) if (W[k].wide) W[k].gM.part.zero(st);
         }
         if (q.state != nullptr)      // record 0 of the iterate dump: A_k'b_k as the workers hold them, in the x_k slots
@@ -739,6 +806,10 @@ struct ParPlan final : LassoPlan {
                 if (bt_wide) {
                     if (!onepass) launch_gemv_t_batch<float>(bAt.get(), Kl, gridAt, ldsAt, bt_nt, st);      // t_k = A_k rhs_k   (one-pass form: formed by the head)
                     launch_gemv_t_batch<float>(bM.get(), Kl, gridM, ldsM, bt_nt, st);         // s_k = (A_k A_k' + rho I)^-1 t_k
+                    if (onepass) {                                                            // A_k' s_k, and delta_k in the first slice of the same grid
+                        if (bt_nt) hipLaunchKernelGGL((par_A_batch_resid_kernel<true>), dim3(gridA, Kl + 1), dim3(kGemvThreads), (std::uint32_t)ldsA, st, bA.get(), q);
+                        else hipLaunchKernelGGL((par_A_batch_resid_kernel<false>), dim3(gridA, Kl + 1), dim3(kGemvThreads), (std::uint32_t)ldsA, st, bA.get(), q);
+                    } else
                     launch_gemv_t_batch<float>(bA.get(), Kl, gridA, ldsA, bt_nt, st);         // A_k' s_k
                 } else {
                     launch_gemv_t_batch<float>(bM.get(), Kl, gridM, ldsM, bt_nt, st);         // x_k = (A_k'A_k + rho I)^-1 rhs_k
@@ -760,6 +831,7 @@ struct ParPlan final : LassoPlan {
                     w.gA.run_partials_from(w.gM, skip, st);                // A' s
                 }
             }
+            if (onepass && !batched) hipLaunchKernelGGL(par_wb_resid_kernel, dim3((Kl * wb_ld + 3) / 4), dim3(256), 0, st, q);        // delta_k of every Woodbury worker
             if (peer_fused) {
                 // the only cross-worker exchange, produced by `pack` and consumed by `z` themselves (PEER slots)
                 const PeerExchange ex = comm_peer_begin(par_peer_norm_offset(p) + 3 * sizeof(double));
