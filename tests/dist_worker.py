@@ -39,6 +39,9 @@ def problem(case):
     if case == "wideblocks":          # 403 rows in 4 blocks over 2 ranks: Woodbury branch (:25-30), remainder block on the last rank
         x, y = synth_lasso(403, 300, 12, seed=62)
         return x, y, 4, dict(nlambda=4, maxit=300)
+    if case == "wideblocks_k2":       # ONE Woodbury block per rank (what K = N GPUs runs: the unbatched launches of the one-pass form)
+        x, y = synth_lasso(301, 420, 12, seed=63)
+        return x, y, 2, dict(nlambda=4, maxit=300)
     if case == "tallshard300":        # the serial tall solver with its x-update spread over the ranks (small p: one tile row)
         x, y = synth_lasso(2000, 300, 30, seed=7)
         return x, y, 0, dict(nlambda=12)

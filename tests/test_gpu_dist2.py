@@ -39,7 +39,7 @@ def _run_ranks(backend, case, nranks=2, timeout=300, extra_env=None):
 
 
 @pytest.mark.parametrize("backend", ["shm", "peer"])
-@pytest.mark.parametrize("case", ["tallblocks", "wideblocks"])
+@pytest.mark.parametrize("case", ["tallblocks", "wideblocks", "wideblocks_k2"])
 def test_two_process_consensus_matches_single_process(backend, case):
     from admm_amd import admm_lasso
     from admm_amd._lib import check
