@@ -41,29 +41,42 @@ inline double now_s() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// Cache of large device blocks (api.hip).  hipMalloc / hipFree of multi-GB buffers are synchronous page-table operations whose cost
+// varies by box and by what the process freed before (measured on C2, second plan creation of a process: 0.07 s of kernels inside
+// 0.07 .. 0.31 s of wall, the difference all in hipFree / hipMalloc of the 4 GB operands) -- a resident server or an R session that
+// calls $fit() repeatedly should not pay it per call.  Blocks of at least 32 MB that a DevBuf releases are kept (per device, at most
+// ADMM_HIP_POOL_MB megabytes in all, default 24576; 0 switches the cache off) and handed to the next allocation they fit (size <=
+// block <= 1.25 size).  A failed hipMalloc empties the cache and tries again; pool_cached_bytes() is what a caller adds to
+// hipMemGetInfo's free figure; admm_hip_trim_memory() returns everything to the driver.  Thread-safe (one mutex).
+void* pool_alloc(size_t bytes, size_t* granted);
+void pool_free(void* p, size_t granted);
+size_t pool_cached_bytes();
+void pool_trim();
+
 // Owning device allocation.
 template <typename T>
 struct DevBuf {
     T* p = nullptr;
     size_t n = 0;
+    size_t granted = 0;          // bytes of the block behind p (>= n * sizeof(T) when it came from the cache)
     DevBuf() = default;
     explicit DevBuf(size_t count) { alloc(count); }
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
-    DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n), granted(o.granted) { o.p = nullptr; o.n = 0; o.granted = 0; }
     DevBuf& operator=(DevBuf&& o) noexcept {
-        if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+        if (this != &o) { release(); p = o.p; n = o.n; granted = o.granted; o.p = nullptr; o.n = 0; o.granted = 0; }
         return *this;
     }
     ~DevBuf() { release(); }
     void alloc(size_t count) {
         release();
         n = count;
-        if (count) ADMM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)));
+        if (count) p = static_cast<T*>(pool_alloc(count * sizeof(T), &granted));
     }
     void release() {
-        if (p) (void)hipFree(p);
-        p = nullptr; n = 0;
+        if (p) pool_free(p, granted);
+        p = nullptr; n = 0; granted = 0;
     }
     void zero(hipStream_t s) { if (n) ADMM_HIP_CHECK(hipMemsetAsync(p, 0, n * sizeof(T), s)); }
     T* get() const { return p; }

@@ -1,6 +1,7 @@
 // extern "C" boundary of libadmm_hip.so (see include/admm_hip.h).
 #include "solvers.h"
 #include "comm.h"
+#include <mutex>
 
 namespace admm {
 const std::string& last_error_ref();
@@ -16,6 +17,103 @@ void comm_init_peer(int nranks, int rank, const void* handles);
 void comm_init_shm(int nranks, int rank, const char* name, unsigned long long token);
 void cv_gather(const double* x, long long ldx, const double* y, const int* d_idx, int m, int p, double* xo, double* yo, hipStream_t st);
 std::vector<double> cv_score(const double* xt, const double* yt, int m, int p, const float* beta_host, int nlam, hipStream_t st);
+
+// ---- cache of large device blocks (admm_internal.h, DevBuf)
+namespace {
+struct PoolBlock { void* p; size_t bytes; int dev; };
+struct Pool {
+    std::mutex mu;
+    std::vector<PoolBlock> blocks;
+    size_t cached = 0;
+};
+Pool& pool() { static Pool* p = new Pool(); return *p; }             // never destroyed: the runtime may be gone at process exit
+constexpr size_t kPoolMinBytes = size_t(32) << 20;
+size_t pool_cap_bytes() {
+    static const size_t cap = []() {
+        const char* e = std::getenv("ADMM_HIP_POOL_MB");
+        const long long mb = e ? std::atoll(e) : 24576;
+        return mb > 0 ? (size_t)mb << 20 : size_t(0);
+    }();
+    return cap;
+}
+void pool_drop_locked(Pool& P, int dev) {                               // dev < 0: every device
+    size_t w = 0;
+    for (size_t i = 0; i < P.blocks.size(); ++i) {
+        if (dev < 0 || P.blocks[i].dev == dev) { (void)hipFree(P.blocks[i].p); P.cached -= P.blocks[i].bytes; }
+        else P.blocks[w++] = P.blocks[i];
+    }
+    P.blocks.resize(w);
+}
+}  // namespace
+
+void* pool_alloc(size_t bytes, size_t* granted) {
+    *granted = bytes;
+    int dev = 0;
+    if (bytes >= kPoolMinBytes && pool_cap_bytes() > 0) {
+        ADMM_HIP_CHECK(hipGetDevice(&dev));
+        Pool& P = pool();
+        std::lock_guard<std::mutex> lk(P.mu);
+        int best = -1;
+        for (size_t i = 0; i < P.blocks.size(); ++i) {
+            const PoolBlock& b = P.blocks[i];
+            if (b.dev == dev && b.bytes >= bytes && b.bytes <= bytes + bytes / 4 && (best < 0 || b.bytes < P.blocks[best].bytes)) best = (int)i;
+        }
+        if (best >= 0) {
+            void* p = P.blocks[best].p;
+            *granted = P.blocks[best].bytes;
+            P.cached -= P.blocks[best].bytes;
+            P.blocks.erase(P.blocks.begin() + best);
+            return p;
+        }
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e == hipErrorOutOfMemory || e == hipErrorMemoryAllocation) {      // give the cached blocks back and try once more
+        (void)hipGetLastError();
+        { Pool& P = pool(); std::lock_guard<std::mutex> lk(P.mu); pool_drop_locked(P, -1); }
+        e = hipMalloc(&p, bytes);
+    }
+    if (e != hipSuccess)
+        throw Error(ADMM_ERR_HIP, std::string("hipMalloc(") + std::to_string(bytes) + " bytes): " + hipGetErrorString(e));
+    return p;
+}
+
+void pool_free(void* p, size_t granted) {
+    if (!p) return;
+    if (granted >= kPoolMinBytes && pool_cap_bytes() > 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            hipPointerAttribute_t at;
+            if (hipPointerGetAttributes(&at, p) == hipSuccess) dev = at.device;      // the device the block lives on (the caller may have switched)
+            Pool& P = pool();
+            std::lock_guard<std::mutex> lk(P.mu);
+            if (P.cached + granted <= pool_cap_bytes()) {
+                // a block may be handed to another stream's work next: everything enqueued on it must have finished (hipFree would have waited too)
+                (void)hipDeviceSynchronize();
+                P.blocks.push_back({p, granted, dev});
+                P.cached += granted;
+                return;
+            }
+        }
+    }
+    (void)hipFree(p);
+}
+
+size_t pool_cached_bytes() {
+    Pool& P = pool();
+    std::lock_guard<std::mutex> lk(P.mu);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    size_t s = 0;
+    for (const PoolBlock& b : P.blocks) if (b.dev == dev) s += b.bytes;
+    return s;
+}
+
+void pool_trim() {
+    Pool& P = pool();
+    std::lock_guard<std::mutex> lk(P.mu);
+    pool_drop_locked(P, -1);
+}
 
 std::vector<double> make_lambda_grid(const LassoProblem& pb, double lambda0, int n, double scaleY) {
     if (!pb.lambda_in.empty()) return pb.lambda_in;
@@ -874,6 +972,10 @@ int admm_hip_lasso_plan_system_read(admm_hip_plan* plan, float* out, long long l
 
 const char* admm_hip_last_error(void) { return last_error_ref().c_str(); }
 const char* admm_hip_version(void) { return "admm_hip 0.2 (gfx950)"; }
+int admm_hip_trim_memory(void) {
+    admm::pool_trim();
+    return ADMM_OK;
+}
 
 int admm_hip_device_count(void) {
     int cnt = 0;

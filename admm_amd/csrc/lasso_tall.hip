@@ -596,6 +596,7 @@ struct TallPlan final : LassoPlan {
         {
             size_t free_b = 0, total_b = 0;
             ADMM_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+            free_b += pool_cached_bytes();                        // blocks this library holds for re-use are free for it
             if (const char* e = std::getenv("ADMM_HIP_TEST_FREE_BYTES")) free_b = (size_t)std::atoll(e);
             const bool have_gram = d.gram.get() && d.ldgram == ldp;
             const bool inv64_wanted = p < 4096 || (std::getenv("ADMM_HIP_INVERSE") && std::string(std::getenv("ADMM_HIP_INVERSE")) == "f64");

@@ -374,6 +374,11 @@ ADMM_HIP_API int admm_hip_lasso_plan_create_dist_cols(const double* x_cols, cons
 
 ADMM_HIP_API const char* admm_hip_last_error(void);
 ADMM_HIP_API const char* admm_hip_version(void);
+/* The library keeps large device blocks (>= 32 MB) it has released for re-use by its next call -- at most ADMM_HIP_POOL_MB megabytes,
+ * default 24576, 0 = off -- because hipMalloc / hipFree of multi-GB buffers cost up to a quarter of a second per call on some hosts.
+ * No solver STATE survives a call (Lasso.cpp:74-76,126-129: neither does the reference's); only empty memory does.  This returns it
+ * all to the driver (an R session would call it from a finalizer or `gc()` hook; a failed allocation does it by itself). */
+ADMM_HIP_API int admm_hip_trim_memory(void);
 ADMM_HIP_API int admm_hip_device_count(void);
 ADMM_HIP_API int admm_hip_set_device(int device);
 /* hipDeviceSynchronize on the current device (bench.py brackets its timed region with it). */

@@ -110,3 +110,34 @@ def test_tall_memory_wall_is_reported_not_crashed_into():
     assert ei.value.code == 9 and "parallel" in str(ei.value)
     fit = admm_lasso(x, y).penalty(0.1).fit()                      # and the same call works once there is room
     assert np.all(np.isfinite(fit.beta_dense))
+
+
+def test_block_cache_is_bounded_reused_and_trimmed():
+    """Round 5: released device blocks >= 32 MB are kept for the library's next call (hipMalloc / hipFree of GB-sized buffers cost up to
+    0.25 s per call on some hosts) -- empty memory only, no solver state (`Lasso.cpp:74-76,126-129`).  After a fit some memory is still held;
+    a second identical fit is bit-identical and holds no more than the first; admm_hip_trim_memory() gives everything back."""
+    import torch
+    from admm_amd import admm_lasso, load
+    lib = load()
+
+    def used():
+        torch.cuda.synchronize()
+        free, total = torch.cuda.mem_get_info()
+        return total - free
+
+    rng = np.random.default_rng(5)
+    n, p = 30000, 1500                                    # X: 180 MB as floats, 360 MB as the staged doubles
+    x = rng.standard_normal((n, p)) * 2
+    y = x[:, :10] @ rng.uniform(size=10) + rng.standard_normal(n)
+    assert lib.admm_hip_trim_memory() == 0
+    u0 = used()
+    a = admm_lasso(x, y).penalty(nlambda=5).fit()
+    u1 = used()
+    b = admm_lasso(x, y).penalty(nlambda=5).fit()
+    u2 = used()
+    assert np.array_equal(a.beta_dense, b.beta_dense) and np.array_equal(a.niter, b.niter)
+    assert u1 - u0 >= (32 << 20), "nothing was kept for re-use"
+    assert u2 - u0 <= (u1 - u0) + (64 << 20), (u0, u1, u2)       # the second call re-used what the first left
+    assert lib.admm_hip_trim_memory() == 0
+    u3 = used()
+    assert u3 - u0 <= (16 << 20), (u0, u3)
