@@ -196,6 +196,56 @@ def test_medium_tall_problems_match_the_oracle():
     assert nloose <= 4, nloose
 
 
+def _medium_consensus(cs):
+    """One medium consensus case (p 200 .. 900, 2 .. 8 row blocks -- Cholesky or Woodbury branch by the block's shape --, random eps /
+    rho, maxit 7 or 300) by BOTH instruments: the stepwise rule on the iterate dump and the follow rule on the decision trace."""
+    from admm_amd import admm_lasso
+    from oracle import entry, stepcheck
+    x, y, icpt, stdz, K = cs["x"], cs["y"], cs["icpt"], cs["stdz"], cs["K"]
+    opts = dict(maxit=cs["maxit"], eps_abs=cs["eps"], eps_rel=cs["eps"], rho=cs["rho"])
+    lmr = 0.01 if cs["n"] < cs["p"] else 1e-4
+    lam = None
+    if cs["user_lam"]:
+        ref0 = entry.admm_lasso(x, y, None, 3, 0.1, stdz, icpt, dict(entry.LASSO_OPTS, maxit=1), {})
+        lam = np.sort(ref0["lambda"][0] * cs["ulam"])[::-1]
+    rho = None if cs["rho"] <= 0 else cs["rho"]
+    m = admm_lasso(x, y, icpt, stdz).penalty(lam, nlambda=cs["nl"], lambda_min_ratio=lmr).opts(cs["maxit"], cs["eps"], cs["eps"], rho)
+    m.nthread = K
+    fit, trace, st = traced_fit(m, capacity=cs["nl"] * (cs["maxit"] + 2) + 8, state=True)
+    rows = cs["n"] // K
+    label = f"medium {cs['c']} par n={cs['n']} p={cs['p']} K={K} ({rows} x {cs['p']} blocks: {'Woodbury' if rows < cs['p'] else 'Cholesky'}) maxit={cs['maxit']} eps={cs['eps']:g} rho={cs['rho']:g} scale={cs['scale']:g}"
+    problem = dict(x=x, y=y, lam=lam, nlambda=cs["nl"], lmin_ratio=lmr, standardize=stdz, intercept=icpt, opts=opts, alpha=None, nthread=K)
+    rep = stepcheck.check_consensus(problem, trace, st, label=label)
+    ratio = rep.get("x_vs_ref_max", rep["x_ratio_max"])
+    print(f"[stepwise {label}] {rep['records']} iterations, x-update <= {ratio:.2f} x the reference route's own error (rms {rep.get('x_rms_vs_ref', 0):.2f} x), bit mismatches {len(rep['bit_mismatch'])}")
+    stepcheck.assert_stepwise(dict(rep, x_ratio_max=ratio), label=label, x_factor=16.0, x_rms_factor=5.0)
+    return assert_followed_parity(fit.beta_dense, fit.niter, trace, problem, 1e-4, label=label), rows < cs["p"]
+
+
+def test_medium_consensus_problems_match_the_oracle():
+    """Consensus cases between the small sweep's nearly square blocks and C4's 1250 x 10^5 (round 5: the one-pass Woodbury workers --
+    recurrences in double, gather over the non-zeros of z, cancellation guard -- at block aspect ratios 0.05 .. 1): every iteration the
+    reference's by the stepwise rule, the answer by the follow rule, both branches present."""
+    nw = nc = 0
+    for seed in (3, 4, 5, 6):
+        for cs in medium_cases(12, seed):
+            if cs["kind"] != "par" or nw + nc >= 8:
+                continue
+            _, wide = _medium_consensus(cs)
+            nw += int(wide); nc += int(not wide)
+    assert nw >= 3 and nc >= 1, (nw, nc)
+    # the sweep's Woodbury blocks are 0.6 .. 0.76 as wide as long: two explicit cases at C4's end of the range (rows / p = 0.05, 0.0625)
+    rng = np.random.default_rng(55)
+    for c, (n, p, K, stdz, scale) in enumerate([(600, 3000, 4, True, 2.0), (1200, 2400, 8, False, 0.5)]):
+        x = rng.standard_normal((n, p)) * scale
+        b = np.zeros(p); b[:20] = rng.uniform(size=20)
+        y = x @ b + rng.standard_normal(n) * scale
+        cs = dict(c=100 + c, kind="par", icpt=True, stdz=stdz, scale=scale, n=n, p=p, x=x, y=y, user_lam=False, nl=4, alpha=None, ulam=None, K=K,
+                  maxit=300, eps=1e-5, rho=-1.0)
+        _, wide = _medium_consensus(cs)
+        assert wide
+
+
 def test_tiny_lambda_on_unstandardised_data_stops_like_the_reference():
     """rho * ulp(z) > eps_dual: the stopping rule only fires once the float right-hand side of the x-update stops
     changing (ADMMLassoTall.h:70-80 rounds it to float).  A formulation that bypasses that rounding ran these
