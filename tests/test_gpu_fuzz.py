@@ -229,14 +229,15 @@ def test_medium_consensus_problems_match_the_oracle():
     nw = nc = 0
     for seed in (3, 4, 5, 6):
         for cs in medium_cases(12, seed):
-            if cs["kind"] != "par" or nw + nc >= 8:
+            if cs["kind"] != "par" or nw + nc >= 7:
                 continue
             _, wide = _medium_consensus(cs)
             nw += int(wide); nc += int(not wide)
     assert nw >= 3 and nc >= 1, (nw, nc)
-    # the sweep's Woodbury blocks are 0.6 .. 0.76 as wide as long: two explicit cases at C4's end of the range (rows / p = 0.05, 0.0625)
+    # the sweep's Woodbury blocks are 0.6 .. 0.76 as wide as long: two explicit cases at C4's end of the range (rows / p = 0.0625; p = 3000 / 2400 with 150-row blocks measured when the test was written:
+    # 1139 / 747 iterations, x-update rms 0.54 / 0.46 x the reference route's own error -- 280 s of CPU checking, too long for the suite)
     rng = np.random.default_rng(55)
-    for c, (n, p, K, stdz, scale) in enumerate([(600, 3000, 4, True, 2.0), (1200, 2400, 8, False, 0.5)]):
+    for c, (n, p, K, stdz, scale) in enumerate([(400, 1600, 4, True, 2.0), (800, 1600, 8, False, 0.5)]):
         x = rng.standard_normal((n, p)) * scale
         b = np.zeros(p); b[:20] = rng.uniform(size=20)
         y = x @ b + rng.standard_normal(n) * scale
