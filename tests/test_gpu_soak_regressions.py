@@ -181,7 +181,7 @@ def test_soak_wide_case_intercept_row_is_the_column_statistics_rounding():
 @pytest.mark.parametrize("seed", [811, 812])
 def test_fresh_random_sample_every_iteration_is_the_reference_iteration(seed):
     from oracle import stepcheck
-    fallback = []
+    fallback, loose = [], []
     njudged = 0
     for cs in cases(60, seed):
         kind = cs["kind"]
@@ -199,13 +199,18 @@ def test_fresh_random_sample_every_iteration_is_the_reference_iteration(seed):
             ratio = rep.get("x_vs_ref_max", rep["x_ratio_max"]) if kind == "par" else rep["x_ratio_max"]
             stepcheck.assert_stepwise(dict(rep, x_ratio_max=ratio), label=label, x_factor=X_FACTOR[fam], x_rms_factor=X_RMS_FACTOR[fam])
         try:
-            T.judge_capture(cs, cap, budget=False)
+            rep = T.judge_capture(cs, cap, budget=False)
         except AssertionError as e:
             fallback.append((cs["c"], kind, str(e)[:160]))
-            T.judge_capture(cs, cap, band=1e9, budget=False)
+            rep = T.judge_capture(cs, cap, band=1e9, budget=False)
+        if rep and (rep.get("loose") or rep.get("max_err", 0.0) >= 1e-4):      # columns beyond 1e-4 that rule R3 / the threshold quantum let pass
+            loose.append((cs["c"], kind, list(rep.get("loose", [])), float(f"{rep.get('max_err', 0.0):.2e}")))
         njudged += 1
-    print(f"[fresh sample seed {seed}] {njudged} cases judged, {len(fallback)} needed the library's own trajectory: {fallback}")
+    print(f"[fresh sample seed {seed}] {njudged} cases judged, {len(fallback)} needed the library's own trajectory: {fallback}; "
+          f"cases with a column beyond 1e-4 inside the oracle's own rounding drift (R3): {loose}")
     assert len(fallback) <= 2, fallback
+    # the random paths must not let columns beyond 1e-4 pass unseen -- counted and bounded here (measured when written: 0 and 0)
+    assert len(loose) <= 1, loose
 
 
 def test_soak_wide_case_a_coordinate_on_the_soft_threshold_forks_the_active_set_path():
