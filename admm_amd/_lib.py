@@ -62,7 +62,7 @@ EXPORTS = ["admm_hip_lasso", "admm_hip_enet", "admm_hip_parlasso", "admm_hip_lad
            "admm_hip_lasso_dist_cols", "admm_hip_test_gemv_t", "admm_hip_lad_traced", "admm_hip_bp_traced",
            "admm_hip_lasso_plan_create_dist_cols", "admm_hip_lasso_cv", "admm_hip_lasso_multi",
            "admm_hip_parbp", "admm_hip_parbp_traced", "admm_hip_parbp_dist", "admm_hip_dantzig", "admm_hip_dantzig_traced",
-           "admm_hip_lad_state", "admm_hip_bp_state", "admm_hip_lasso_plan_data_read", "admm_hip_trim_memory"]
+           "admm_hip_lad_state", "admm_hip_bp_state", "admm_hip_lasso_plan_data_read", "admm_hip_trim_memory", "admm_hip_test_gather"]
 
 TRACE_FIELDS = 12
 TRACE_COLD, TRACE_CONVERGED, TRACE_ACCELERATE, TRACE_RESTART = -1, 0, 1, 2
@@ -199,6 +199,8 @@ def load():
     lib.admm_hip_test_cv_fold_system.restype = ctypes.c_int
     lib.admm_hip_host_lanczos.argtypes = [_c_float_p, ctypes.c_int, _c_float_p, _c_int_p]
     lib.admm_hip_host_lanczos.restype = ctypes.c_int
+    lib.admm_hip_test_gather.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, _c_double_p]
+    lib.admm_hip_test_gather.restype = ctypes.c_int
     lib.admm_hip_trim_memory.argtypes = []
     lib.admm_hip_trim_memory.restype = ctypes.c_int
     _lib = lib

@@ -9,6 +9,7 @@ void test_symv(const float* A, int p, const float* v0, const float* v1, float* y
 template <typename T> void test_gram(const T* A, int rows, int cols, bool atA, T* G);
 template <typename T> void test_spd_inverse(const T* A, int n, T* Ainv, bool via64);
 template <typename T> void test_gemv_t(const T* A, int rows, int cols, const T* v, T* y);
+template <typename T> void test_gather(const T* A, int rows, int cols, const T* v, double* y);
 int comm_unique_id(void* out);
 void comm_init(int nranks, int rank, const void* idbytes);
 void comm_finalize();
@@ -1026,6 +1027,14 @@ int admm_hip_test_gemv_t(const void* A, int rows, int cols, int is_double, const
         ADMM_REQUIRE(A && v && y && rows > 0 && cols > 0, "bad arguments");
         if (is_double) test_gemv_t<double>(static_cast<const double*>(A), rows, cols, static_cast<const double*>(v), static_cast<double*>(y));
         else test_gemv_t<float>(static_cast<const float*>(A), rows, cols, static_cast<const float*>(v), static_cast<float*>(y));
+    });
+}
+
+int admm_hip_test_gather(const void* A, int rows, int cols, int is_double, const void* v, double* y) {
+    return guarded([&] {
+        ADMM_REQUIRE(A && v && y && rows > 0 && cols > 0, "bad arguments");
+        if (is_double) test_gather<double>(static_cast<const double*>(A), rows, cols, static_cast<const double*>(v), y);
+        else test_gather<float>(static_cast<const float*>(A), rows, cols, static_cast<const float*>(v), y);
     });
 }
 

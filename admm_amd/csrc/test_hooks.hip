@@ -77,6 +77,36 @@ void test_gemv_t(const T* A, int rows, int cols, const T* v, T* y) {
 template void test_gemv_t<float>(const float*, int, int, const float*, float*);
 template void test_gemv_t<double>(const double*, int, int, const double*, double*);
 
+// y = A v over the non-zeros of v through the gather mat-vec of the one-pass forms (gather_kernels.h): A host, rows x cols
+// column-major (ld rows), v length cols, y length rows in DOUBLE (the kernel accumulates in double whatever T is); the column
+// groups' partial rows are summed in group order, as the consumers do.
+template <typename T>
+void test_gather(const T* A, int rows, int cols, const T* v, double* y) {
+    require_device();
+    Stream st;
+    const long long lda = round_up(rows, 32);
+    DevBuf<T> dA((size_t)lda * cols), dv(round_up(cols, 32));
+    dA.zero(st.s); dv.zero(st.s);
+    ADMM_HIP_CHECK(hipMemcpy2DAsync(dA.get(), lda * sizeof(T), A, (size_t)rows * sizeof(T), (size_t)rows * sizeof(T), cols, hipMemcpyHostToDevice, st.s));
+    ADMM_HIP_CHECK(hipMemcpyAsync(dv.get(), v, (size_t)cols * sizeof(T), hipMemcpyHostToDevice, st.s));
+    const GatherPlan gp = plan_gather<T>(rows, cols);
+    DevBuf<double> part((size_t)gp.ngroups * gp.pstride);
+    part.zero(st.s);
+    const GatherArgs<T> a = gather_args<T>(gp, dA.get(), lda, rows, cols, dv.get(), part.get(), nullptr);
+    hipLaunchKernelGGL((gather_kernel<T>), dim3(gp.tiles, gp.ngroups), dim3(kGatherThreads), 0, st.s, a);
+    std::vector<double> hp((size_t)gp.ngroups * gp.pstride);
+    ADMM_HIP_CHECK(hipMemcpyAsync(hp.data(), part.get(), hp.size() * sizeof(double), hipMemcpyDeviceToHost, st.s));
+    st.sync();
+    ADMM_HIP_CHECK(hipGetLastError());
+    for (int i = 0; i < rows; ++i) {
+        double s = 0.0;
+        for (int g = 0; g < gp.ngroups; ++g) s += hp[(size_t)g * gp.pstride + i];
+        y[i] = s;
+    }
+}
+template void test_gather<float>(const float*, int, int, const float*, double*);
+template void test_gather<double>(const double*, int, int, const double*, double*);
+
 // Symmetric inverse of an SPD host matrix (order n, ld n) through the solvers' own path: blocked Cholesky + inverse on
 // the matrix cores (chol_inverse.h) for n >= 256.  via64: the float matrix factorised / inverted in double and rounded once.
 template <typename T>

@@ -406,6 +406,10 @@ ADMM_HIP_API int admm_hip_test_gram(const void* A, int rows, int cols, int atA, 
 /* y = A' v with the streaming mat-vec every other product of the solvers uses (X'y, the wide regular step, the consensus /
  * LAD / BP products, the tall x-update below p = 2048): A HOST rows x cols column-major (leading dimension rows). */
 ADMM_HIP_API int admm_hip_test_gemv_t(const void* A, int rows, int cols, int is_double, const void* v, void* y);
+/* y = A v over the NON-ZERO entries of v with the gather mat-vec of the one-pass consensus workers and of basis pursuit (the product
+ * that replaces the reference's first streaming pass, PADMMLasso.h:25 / ADMMBP.h:65): A HOST rows x cols column-major (leading
+ * dimension rows), v length cols in A's type, y length rows in double (the kernel's accumulation type). */
+ADMM_HIP_API int admm_hip_test_gather(const void* A, int rows, int cols, int is_double, const void* v, double* y);
 ADMM_HIP_API int admm_hip_test_spd_inverse(const void* A, int n, int precision, void* Ainv);
 /* The system admm_hip_lasso_cv hands the tall solver for fold `fold` when it forms the folds as down-dates of the full-data
  * Gram (cv.hip): x, y HOST column-major doubles, fold_id as in admm_hip_lasso_cv (NULL: i mod nfolds).  Out (HOST): gram p x p

@@ -168,3 +168,29 @@ def test_gemv_t_vs_numpy(rows, cols, dtype):
     ref = A.astype(np.float64).T @ v.astype(np.float64)
     scale = (np.abs(A.astype(np.float64)).T @ np.abs(v.astype(np.float64))).max()
     assert np.abs(y - ref).max() / scale < (2e-6 if dtype == np.float32 else 1e-14)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("rows,cols,density", [(1250, 20000, 0.003), (5000, 6000, 0.02), (130, 777, 1.0), (2049, 300, 0.0), (37, 5000, 0.5), (1, 1, 1.0)])
+def test_gather_matvec_vs_numpy(rows, cols, density, dtype):
+    """The gather mat-vec of the one-pass forms (gather_kernels.h): y = A v over the non-zeros of v, double accumulation, fixed
+    summation order -- sparse, dense, empty and ragged right-hand sides (row tiles of 1024 / 512 rows, column chunks of 256, groups of
+    whole chunks), NaN in columns whose coefficient is zero (they must never be read), bit reproducibility."""
+    from admm_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(rows * 7 + cols)
+    A = np.asfortranarray(rng.standard_normal((rows, cols)).astype(dtype))
+    v = np.zeros(cols, dtype=dtype)
+    nz = rng.random(cols) < density
+    v[nz] = rng.standard_normal(int(nz.sum())).astype(dtype)
+    if 0.0 < density < 1.0 and (~nz).any():
+        A[:, np.nonzero(~nz)[0][:5]] = np.nan                          # unlisted columns are not touched
+    y = np.zeros(rows)
+    _lib.check(lib.admm_hip_test_gather(A.ctypes.data, rows, cols, int(dtype == np.float64), v.ctypes.data, y.ctypes.data_as(ctypes.POINTER(ctypes.c_double))))
+    ref = np.nan_to_num(A.astype(np.float64), nan=0.0) @ v.astype(np.float64)
+    scale = np.abs(np.nan_to_num(A.astype(np.float64), nan=0.0)) @ np.abs(v.astype(np.float64)) + 1e-300
+    assert np.all(np.isfinite(y))
+    assert (np.abs(y - ref) / scale).max() < 1e-14, float((np.abs(y - ref) / scale).max())     # products exact in double, sums in double
+    y2 = np.zeros(rows)
+    _lib.check(lib.admm_hip_test_gather(A.ctypes.data, rows, cols, int(dtype == np.float64), v.ctypes.data, y2.ctypes.data_as(ctypes.POINTER(ctypes.c_double))))
+    assert np.array_equal(y, y2)
