@@ -2,6 +2,8 @@
 // that the test-suite can compare them with the oracle / NumPy.  No solver entry point calls anything in this file.
 #include "symv_kernels.h"
 #include "prep.h"
+#include "gather_kernels.h"
+#include <vector>
 
 namespace admm {
 void require_device();
