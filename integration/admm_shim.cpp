@@ -174,3 +174,13 @@ BEGIN_RCPP
     return List::create(Named("beta") = sparse_column(b), Named("niter") = niter);
 END_RCPP
 }
+
+// Not in the reference (it keeps nothing between calls): libadmm_hip keeps EMPTY device blocks >= 32 MB for its next call
+// (include/admm_hip.h, admm_hip_trim_memory).  The package would call this from .onUnload(libpath) -- and may offer it to users
+// who share the GPU with other libraries:  .Call("admm_trim_memory", PACKAGE = "ADMM").
+RcppExport SEXP admm_trim_memory() {
+BEGIN_RCPP
+    check(admm_hip_trim_memory());
+    return R_NilValue;
+END_RCPP
+}
