@@ -32,7 +32,7 @@ struct PinnedFlag {
 // the wide path), and the batch grows from `batch` to 4 x `batch` as the solve gets long.
 template <typename F>
 inline LoopTimes run_until_done(hipStream_t st, const int* d_done, int batch, long long max_iters, F&& enqueue,
-                                const volatile int* h_flag = nullptr) {
+                                const volatile int* h_flag = nullptr, long long g_start = 0) {
     int* h_done = nullptr;
     ADMM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_done), 2 * sizeof(int), hipHostMallocDefault));
     struct HostFree { void* p; ~HostFree() { (void)hipHostFree(p); } } hf{h_done};
@@ -45,7 +45,7 @@ inline LoopTimes run_until_done(hipStream_t st, const int* d_done, int batch, lo
     ADMM_HIP_CHECK(hipStreamSynchronize(st));
     const double t0 = now_s();
     ADMM_HIP_CHECK(hipEventRecord(ev0.e, st));
-    long long g = 0;
+    long long g = g_start;                             // (a solver that resumes a halted loop continues its own count)
     auto enqueue_batch = [&](int slot) {
         for (int k = 0; k < batch; ++k, ++g) enqueue(g);
         if (h_flag == nullptr) ADMM_HIP_CHECK(hipMemcpyAsync(&h_done[slot], d_done, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -62,7 +62,7 @@ inline LoopTimes run_until_done(hipStream_t st, const int* d_done, int batch, lo
         done = h_flag ? (*h_flag != 0) : (h_done[slot] != 0);
         slot ^= 1;
         if (h_flag && (++npoll & 3) == 0 && batch < 4 * batch0) batch *= 2;      // stays even: the parity pattern of g is kept
-        if (!done && g > max_iters + 2 * batch)
+        if (!done && g - g_start > max_iters + 2 * batch)
             throw Error(ADMM_ERR_INTERNAL, "ADMM loop: iteration bound exceeded without completion");
     }
     ADMM_HIP_CHECK(hipEventRecord(ev1.e, st));
@@ -71,7 +71,7 @@ inline LoopTimes run_until_done(hipStream_t st, const int* d_done, int batch, lo
     float ms = 0.f;
     ADMM_HIP_CHECK(hipEventElapsedTime(&ms, ev0.e, ev1.e));
     t.events_ms = ms;
-    t.launched = g;
+    t.launched = g - g_start;
     return t;
 }
 

@@ -31,6 +31,7 @@
 #include "loop_driver.h"
 #include "comm.h"
 #include "device_utils.h"
+#include "gather_kernels.h"
 
 #include <cmath>
 
@@ -47,9 +48,30 @@ struct SbpBlk {                                   // 32 bytes: one vector round 
     long long pad;
 };
 
+// Gram-space state of the active-set iterations (see "Gram space" below).  U = the columns that have been non-zero since the
+// last reset, in the order they appeared; everything indexed by a < count is in that order.
+struct SbpGram {
+    int cap, ldg;                                 // most entries of U; leading dimension of G (= cap)
+    int* umap;                                    // [pl] index into U or -1
+    int* ucol; int* ubid;                         // [cap] local column, local block
+    int* ust;                                     // [8]: 0 count, 1 count before this stretch's additions, 2 this stretch runs in Gram space, 3 abort, 4 iteration of the abort, 5 resets, 6 stretches
+    double* G;                                    // [cap][ldg] A_U'A_U (symmetric, both halves stored)
+    double* gz;                                   // [cap] A_U'zbar
+    double* ugp;                                  // [cap][2] 1 / gamma and the threshold of the entry's block
+    double* xs; double* hr; double* gy;           // [2][cap] x_U, A_U'r, A_U'y (double-buffered by the iteration's parity)
+    double* sx;                                   // [cap] sum of the stretch's iterates
+    double* sxd;                                  // [pl] dense: sum_t (x_t - x_last) over the stretch, zero outside U
+    double* Ps;                                   // [cap / 8][8] workgroup partials of the seven sums a decision needs
+    double* sc;                                   // [2][4] ||r||^2, ||y||^2, y'zbar carried from decision to decision; [8] y'zbar of the stretch's start
+    double zz;                                    // zbar'zbar
+    double* partP; double* partT;                 // [NL][ngroups][pstride] partials of A_i x_i and of A_i sxd_i (gather_kernels.h)
+    int ngroups, pad; long long pstride;
+};
+
 struct SbpParams {
     int n, npad, N, NL, maxit, G, nT, min_share;
     double eps_abs, eps_rel, rho, sqrt_nN, sqrtN, dN;
+    double invN, inv_rho;                        // Gram space only (the direct launches divide, as the reference does)
     const double* A; long long lda;              // this rank's columns, n x pl column-major, rows padded with zeros to npad
     int Gb, pad1;                                // workgroups per local block (the same for every block: block = g / Gb, no table)
     const SbpBlk* blk;                           // [NL]
@@ -64,6 +86,7 @@ struct SbpParams {
     double* Q;                                   // [nT][8]
     SbpCtl* ctl; int* done; int* hflag;
     double* trace; long long trace_cap;
+    SbpGram gs;
 };
 
 constexpr int kSbpThreads = 256;
@@ -83,22 +106,10 @@ __host__ __device__ __forceinline__ int sbp_share(int total, int Gb, int min_sha
 // The decision every iteration starts with, evaluated identically by every workgroup of the iteration's first launch: the
 // residuals of the iteration just finished against the thresholds it ran with (PADMMBase.h:223-231), then the thresholds of the
 // coming one (:118-136).  Returns false when the loop is over (all threads agree).  red: 28 doubles of LDS.
-__device__ __forceinline__ bool sbp_decide(const SbpParams& q, int par, SbpCtl& out, double* red) {
-    const SbpCtl in = load_ctl_vector(q.ctl + par);
-    SbpCtl* outp = &q.ctl[par ^ 1];
-    out = in;
-    if (in.done) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) *outp = in;
-        return false;
-    }
-    double s[7] = {0, 0, 0, 0, 0, 0, 0};
-    for (int w = threadIdx.x; w < q.nT; w += kSbpThreads) {
-#pragma unroll
-        for (int k = 0; k < 5; ++k) s[k] += q.Q[w * 8 + k];
-        s[5] += q.Qa[w * 2]; s[6] += q.Qa[w * 2 + 1];
-    }
-    block_sum<double, 7>(s, red);
-    const double drdS = s[0], dr2 = s[1], r2 = s[2], y2 = s[3], abar_r = s[4], sax = s[5], qq = s[6];
+// `core`: from the seven sums to the new control block (all threads agree); `sbp_decide`: the sums from the norm partials the
+// tail left; `sbp_decide_gram` (below): the same seven from Gram-space quadratic forms.
+__device__ __forceinline__ bool sbp_decide_core(const SbpParams& q, const SbpCtl& in, SbpCtl* outp, SbpCtl& out,
+                                                double drdS, double dr2, double r2, double y2, double abar_r, double sax, double qq) {
     double code = ADMM_TRACE_COLD;
     if (in.iter > 0) {
         const double sd = qq - 2.0 * drdS + q.dN * dr2;
@@ -126,6 +137,24 @@ __device__ __forceinline__ bool sbp_decide(const SbpParams& q, int par, SbpCtl& 
         }
     }
     return !out.done;
+}
+
+__device__ __forceinline__ bool sbp_decide(const SbpParams& q, int par, SbpCtl& out, double* red) {
+    const SbpCtl in = load_ctl_vector(q.ctl + par);
+    SbpCtl* outp = &q.ctl[par ^ 1];
+    out = in;
+    if (in.done) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) *outp = in;
+        return false;
+    }
+    double s[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int w = threadIdx.x; w < q.nT; w += kSbpThreads) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) s[k] += q.Q[w * 8 + k];
+        s[5] += q.Qa[w * 2]; s[6] += q.Qa[w * 2 + 1];
+    }
+    block_sum<double, 7>(s, red);
+    return sbp_decide_core(q, in, outp, out, s[0], s[1], s[2], s[3], s[4], s[5], s[6]);
 }
 
 // Regular iterations (0, 10, 20, ...), first launch: x_j <- soft(x_j - A_j'v / gamma, pen) for EVERY column -- a streaming
@@ -454,6 +483,484 @@ sbp_tail_b_kernel(SbpParams q, int par) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ Gram space
+// Active-set iterations without the matrix (round 5).  Between two regular iterations only the columns U that have been
+// non-zero take part, a few hundred at the C5 shape, and an iteration needs of A only inner products of those columns:
+//   A_j'v = A_j'y / rho + A_j'r,        A_U'r = G x_U / N - gz,       G = A_U'A_U,  gz = A_U'zbar,
+//   A_U'y  by the recurrence  gy <- gy + rho A_U'r   from the exact product at the start of the stretch,
+// and every sum the decision needs is a quadratic form (dx = the iteration's change of x_U, block = same column block):
+//   ||A dx||^2 = dx'G dx = D          dr'dS = D / N      ||dr||^2 = D / N^2      sum_i ||A_i dx_i||^2 = dx'G_block dx
+//   ||r+||^2 = ||r||^2 + 2 (A_U'r)'dx / N + D / N^2                               sum_i ||A_i x_i||^2 = x'G_block x
+//   abar'r = x'(A_U'r) / N       y'r+ = gy'x+ / N - y'zbar       ||y+||^2 = ||y||^2 + 2 rho y'r+ + rho^2 ||r+||^2
+// (||r||^2 and ||y||^2 are carried from their exact values at the stretch's start by these recurrences -- never formed as the
+// difference of O(||b||^2) terms, which would cancel as r -> 0).  One launch per iteration: every workgroup repeats the decision
+// and the |U| soft-thresholds, then owns 8 rows of G for the two mat-vecs G x+ and G dx (the same loads) and writes 7 partial
+// sums.  After the ninth iteration the n-vectors are materialised for the regular iteration that follows:  A_i x_i  and
+// A sum_t (x_t - x_last)  by the gather mat-vec (gather_kernels.h) over the dense x, then
+//   y <- y + rho (9 r_last + A sum_t (x_t - x_last) / N)                           (r_t = r_last + A (x_t - x_last) / N)
+// and r, v, the exact norms.  G grows by the columns that enter U (a transposed mat-vec of U's columns against each new
+// one); entries whose x returned to zero stay in U and cost nothing (the lists the mat-vecs run over hold non-zeros only).
+// Every sum has a fixed order: U is appended to in (block, column) order by one workgroup, the lists are compacted in U order.
+// Differences to the direct launches are rounding only (measured: trace scalars agree to 1e-11 relative).
+constexpr int kGsCapMax = 1024;
+constexpr int kGsRows = 8;
+
+// After the regular iteration's list launch: append the listed columns that are not in U yet, in (block, column) order.  One
+// workgroup, the lists of all blocks flattened over its threads (at most kGsCapMax entries: four per thread): three dependent
+// round trips (list lengths, list entries, their slots in U).
+constexpr int kGsMaxBlocks = 256;
+__global__ void __launch_bounds__(kSbpThreads)
+sbp_gs_merge_kernel(SbpParams q, int par, int g) {
+    __shared__ int pre[kGsMaxBlocks + 1], c0s[kGsMaxBlocks];
+    __shared__ int wcnt[4][4];
+    const SbpGram& s = q.gs;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    int cb = 0;
+    if (tid < q.NL) { cb = q.cnt[tid]; c0s[tid] = q.blk[tid].c0; }
+    int uc = s.ust[0];
+    const SbpCtl c = load_ctl_vector(q.ctl + par);                  // written by this iteration's xreg launch
+    if (c.done) return;
+    if (tid < q.NL) pre[tid + 1] = cb;
+    __syncthreads();
+    if (tid == 0) { pre[0] = 0; for (int b = 0; b < q.NL; ++b) pre[b + 1] += pre[b]; }
+    __syncthreads();
+    const int T = pre[q.NL];
+    if (T > s.cap) {
+        // more non-zeros than G has room for: halt the enqueued launches (they all honour `done`); the host resumes from
+        // iteration g + 1 with the direct launches
+        if (tid == 0) {
+            s.ust[2] = 0; s.ust[3] = 1; s.ust[4] = g;
+            SbpCtl h = c;                                           // BOTH copies: the Gram-space launches that follow return on
+            h.done = 1;                                             // ust[2] == 0 without forwarding the control block
+            q.ctl[par] = h; q.ctl[par ^ 1] = h;
+            *q.done = 1; if (q.hflag) *q.hflag = 1;
+        }
+        return;
+    }
+    int col[4], blkv[4];
+    bool nw[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = tid + k * kSbpThreads;
+        col[k] = -1; blkv[k] = 0;
+        if (i < T) {
+            int lo = 0, hi = q.NL - 1;                              // the block of flattened entry i: pre[b] <= i < pre[b + 1]
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (pre[mid] <= i) lo = mid; else hi = mid - 1; }
+            blkv[k] = lo;
+            col[k] = c0s[lo] + q.list[c0s[lo] + i - pre[lo]];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) nw[k] = col[k] >= 0 && s.umap[col[k]] < 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        unsigned long long bal[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { bal[k] = __ballot(nw[k]); if (lane == 0) wcnt[k][wid] = __popcll(bal[k]); }
+        __syncthreads();
+        int newc = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            for (int w = 0; w < 4; ++w) newc += wcnt[k][w];
+        if (pass == 0 && uc + newc > s.cap) {                       // forget U and start from the current lists (T <= cap)
+            for (int a = tid; a < uc; a += kSbpThreads) { const int cc = s.ucol[a]; s.umap[cc] = -1; s.sxd[cc] = 0.0; }
+            if (tid == 0) s.ust[5] += 1;
+            uc = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) nw[k] = col[k] >= 0;
+            __syncthreads();
+            continue;
+        }
+        int base = uc;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int before = 0, tot = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { const int cw = wcnt[k][w]; before += w < wid ? cw : 0; tot += cw; }
+            if (nw[k]) {
+                const int a = base + before + __popcll(bal[k] & ((1ull << lane) - 1ull));
+                const SbpBlk bi = q.blk[blkv[k]];
+                s.umap[col[k]] = a; s.ucol[a] = col[k]; s.ubid[a] = blkv[k];
+                s.ugp[2 * a] = 1.0 / bi.gamma; s.ugp[2 * a + 1] = bi.pen;
+            }
+            base += tot;
+        }
+        if (tid == 0) { s.ust[1] = uc; s.ust[0] = base; s.ust[2] = 1; s.ust[6] += 1; }
+        break;
+    }
+}
+
+// One column against a vector in LDS (a wave; 16-byte loads, a chunk of the column in flight).
+__device__ __forceinline__ double sbp_wave_dot(const double* __restrict__ col, const double* vsh, int nk, int lane) {
+    const double2* a = reinterpret_cast<const double2*>(col) + lane;
+    const double2* vv = reinterpret_cast<const double2*>(vsh) + lane;
+    double d0 = 0.0, d1 = 0.0;
+    for (int k0 = 0; k0 < nk; k0 += kSbpChunk) {
+        double2 x[kSbpChunk];
+#pragma unroll
+        for (int u = 0; u < kSbpChunk; ++u) x[u] = k0 + u < nk ? a[(size_t)(k0 + u) * 64] : make_double2(0.0, 0.0);
+#pragma unroll
+        for (int u = 0; u < kSbpChunk; u += 2) {
+            if (k0 + u < nk) { const double2 w = vv[(k0 + u) * 64]; d0 = fma(x[u].x, w.x, d0); d0 = fma(x[u].y, w.y, d0); }
+            if (k0 + u + 1 < nk) { const double2 w = vv[(k0 + u + 1) * 64]; d1 = fma(x[u + 1].x, w.x, d1); d1 = fma(x[u + 1].y, w.y, d1); }
+        }
+    }
+    return wave_sum(d0 + d1);
+}
+
+// MODE 0 (grid x: shares of U, y: shares of the new entries): column c of G and gz for every entry c that joined U at this
+// regular iteration -- the new column staged in LDS, a wave per column of U.  Pairs of two new entries are computed from both
+// sides with the same products in the same order: the two stores carry the same bits.
+// MODE 1 (grid x: U four entries at a time): the start of a stretch -- gy = A_U'y, x_U gathered from x, the sum of iterates cleared,
+// y'zbar.
+template <int MODE>
+__global__ void __launch_bounds__(kSbpThreads)
+sbp_gs_dots_kernel(SbpParams q, int idx) {
+    extern __shared__ __attribute__((aligned(16))) double vsh[];    // npad doubles
+    const SbpGram& s = q.gs;
+    if (load_flag_vector(q.done) != 0) return;
+    if (load_flag_vector(s.ust + 2) == 0) return;
+    const int uc = load_flag_vector(s.ust), uold = load_flag_vector(s.ust + 1);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int nk = q.npad / 128;
+    if (MODE == 1) {
+        const bool last = blockIdx.x == gridDim.x - 1;              // (never one of U's: the grid has one workgroup more)
+        if ((int)blockIdx.x * 4 >= uc && !last) return;
+        for (int k = threadIdx.x; k < q.npad; k += kSbpThreads) vsh[k] = q.y[k];
+        __syncthreads();
+        const int a = blockIdx.x * 4 + wid;
+        if (a < uc) {
+            const int col = s.ucol[a];
+            const double xa = q.x[col];
+            const double d = sbp_wave_dot(q.A + (size_t)col * q.lda, vsh, nk, lane);
+            if (lane == 0) { s.gy[idx * s.cap + a] = d; s.xs[idx * s.cap + a] = xa; s.sx[a] = 0.0; }
+        }
+        if (last && wid == 0) {
+            const double d = sbp_wave_dot(q.zbar, vsh, nk, lane);
+            if (lane == 0) s.sc[8] = d;
+        }
+    } else {
+        if (uold >= uc) return;
+        for (int c = uold + blockIdx.y; c < uc; c += gridDim.y) {
+            __syncthreads();                                        // (the previous column's readers are done)
+            const double* ac = q.A + (size_t)s.ucol[c] * q.lda;
+            for (int k = threadIdx.x; k < q.npad; k += kSbpThreads) vsh[k] = ac[k];
+            __syncthreads();
+            for (int a = blockIdx.x * 4 + wid; a < uc; a += gridDim.x * 4) {
+                const double d = sbp_wave_dot(q.A + (size_t)s.ucol[a] * q.lda, vsh, nk, lane);
+                if (lane == 0) { s.G[(size_t)c * s.ldg + a] = d; s.G[(size_t)a * s.ldg + c] = d; }
+            }
+            if (blockIdx.x == 0 && wid == 0) {
+                const double d = sbp_wave_dot(q.zbar, vsh, nk, lane);
+                if (lane == 0) s.gz[c] = d;
+            }
+        }
+    }
+}
+
+// A workgroup barrier that orders LDS traffic only.  __syncthreads() is a fence: it also waits for every outstanding global
+// load (s_waitcnt vmcnt(0)) -- here that would be the 32 requests for G per thread that are in flight across the decision.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+template <int NV>
+__device__ __forceinline__ void block_sum_lds(double (&v)[NV], double* scratch) {      // block_sum (device_utils.h), 4 waves, LDS-only barriers
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = wave_sum(v[i]);
+    lds_barrier();
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) scratch[i * 4 + wid] = v[i];
+    }
+    lds_barrier();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = ((scratch[i * 4] + scratch[i * 4 + 1]) + scratch[i * 4 + 2]) + scratch[i * 4 + 3];
+}
+
+// The decision from the Gram-space partial sums of the previous launch (pp: this thread's row of them, already requested)
+// and the carried norms.
+__device__ __forceinline__ bool sbp_decide_gram(const SbpParams& q, const SbpCtl& in, int par, int idx, double (&p)[7],
+                                                double R, double Y, double yz, SbpCtl& out, double* red) {
+    const SbpGram& s = q.gs;
+    SbpCtl* outp = &q.ctl[par ^ 1];
+    out = in;
+    if (in.done) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) *outp = in;
+        return false;
+    }
+    block_sum_lds<7>(p, red);
+    const double D = p[0], hdx = p[1], xh = p[2], sax = p[3], qq = p[4], gyx = p[5], gzx = p[6];
+    const double iN = q.invN;                                       // (a double division is ~0.2 us of a wave's time: none in this launch)
+    const double Rn = fmax(R + 2.0 * hdx * iN + D * (iN * iN), 0.0);
+    const double yr = gyx * iN - yz, rz = gzx * iN - s.zz;
+    const double Yn = fmax(Y + 2.0 * q.rho * yr + q.rho * q.rho * Rn, 0.0);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double* o = s.sc + (idx ^ 1) * 4;
+        o[0] = Rn; o[1] = Yn; o[2] = yz + q.rho * rz;
+    }
+    return sbp_decide_core(q, in, outp, out, D * iN, D * (iN * iN), Rn, Yn, xh * iN, sax, qq);
+}
+
+// One active-set iteration in Gram space (INIT: the start of a stretch -- A_U'r for the x the regular iteration left, the
+// carried norms from the tail's exact partials).  grid: cap / 8 workgroups; workgroup g owns rows [8 g, 8 g + 8) of G.
+// par: the control block's parity, idx: the buffer this launch reads (it writes idx ^ 1), first: the decision reads the
+// regular iteration's norm partials, nth: the iterates summed after this launch.
+// Latency is what the launch costs: everything that does not depend on the decision -- U's state, the previous launch's
+// partials, the rows' own entries -- is requested before the first wait (the buffers are `cap` long, so the requests need not
+// know U's length), and the G requests of the mat-vecs are all in flight together.
+constexpr int kGsFlight = kGsCapMax / 32;                           // G requests per thread: the whole list in one round trip
+// "This value is needed HERE": keeps a prefetch where it was written (the compiler otherwise sinks a load into the branch
+// that uses it, i.e. behind the decision -- one more dependent round trip; measured 3.2 -> 0.7 us for the decision).
+__device__ __forceinline__ void pin(double v) { asm volatile("" :: "v"(v)); }
+__device__ __forceinline__ void pin(int v) { asm volatile("" :: "v"(v)); }
+template <bool INIT>
+__global__ void __launch_bounds__(kSbpThreads)
+sbp_gs_kernel(SbpParams q, int par, int idx, int first, int nth) {
+    __shared__ double red[8 * 4];
+    __shared__ double xsh[kGsCapMax];
+    __shared__ double lx[kGsCapMax], ld[kGsCapMax];
+    __shared__ int lc[kGsCapMax], lb[kGsCapMax];
+    __shared__ int wcnt[4][4];
+    __shared__ double shr[4][32][kGsRows];
+    const SbpGram& s = q.gs;
+    const int cap = s.cap;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    // ---- requests that depend on nothing
+    double xt[4], gyv[4], hrv[4], gam[4], pen[4];
+    int bidv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int a = tid + k * kSbpThreads;
+        xt[k] = 0.0; gyv[k] = 0.0; hrv[k] = 0.0; gam[k] = 1.0; pen[k] = 0.0; bidv[k] = 0;
+        if (a < cap) {
+            xt[k] = s.xs[idx * cap + a];
+            bidv[k] = s.ubid[a];
+            if (!INIT) {
+                gyv[k] = s.gy[idx * cap + a]; hrv[k] = s.hr[idx * cap + a];
+                const double2 gp = reinterpret_cast<const double2*>(s.ugp)[a];
+                gam[k] = gp.x; pen[k] = gp.y;
+            }
+        }
+    }
+    const int a0 = blockIdx.x * kGsRows;
+    const int r = tid & (kGsRows - 1), cs = tid >> 3;
+    const int arow = a0 + r;                                        // < cap: the grid is cap / 8
+    const int mybid0 = s.ubid[arow];
+    double e_gz = 0.0, e_xo = 0.0, e_hro = 0.0, e_gyo = 0.0, e_sx = 0.0;
+    int e_col = 0;
+    if (tid < kGsRows) {
+        e_gz = s.gz[arow];
+        if (!INIT) { e_xo = s.xs[idx * cap + arow]; e_hro = s.hr[idx * cap + arow]; e_gyo = s.gy[idx * cap + arow]; e_sx = s.sx[arow]; e_col = s.ucol[arow]; }
+    }
+    double pp[7] = {0, 0, 0, 0, 0, 0, 0};
+    double cR = 0.0, cY = 0.0, cyz = 0.0;
+    if (!INIT && !first) {
+        if (tid < cap / kGsRows) {
+            const double2* pr = reinterpret_cast<const double2*>(s.Ps + (size_t)tid * 8);
+            const double2 p0 = pr[0], p1 = pr[1], p2 = pr[2], p3 = pr[3];
+            pp[0] = p0.x; pp[1] = p0.y; pp[2] = p1.x; pp[3] = p1.y; pp[4] = p2.x; pp[5] = p2.y; pp[6] = p3.x;
+        }
+        cR = s.sc[idx * 4]; cY = s.sc[idx * 4 + 1]; cyz = s.sc[idx * 4 + 2];
+    }
+    SbpCtl in{};
+    if (INIT || !first) in = load_ctl_vector(q.ctl + par);
+    const int smode = load_flag_vector(s.ust + 2);
+    const int uc = load_flag_vector(s.ust);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { pin(xt[k]); pin(gyv[k]); pin(hrv[k]); pin(gam[k]); pin(pen[k]); pin(bidv[k]); }
+#pragma unroll
+    for (int k = 0; k < 7; ++k) pin(pp[k]);
+    pin(cR); pin(cY); pin(cyz); pin(mybid0); pin(e_gz); pin(e_xo); pin(e_hro); pin(e_gyo); pin(e_sx); pin(e_col);
+    if (smode == 0) return;
+    if (INIT || !first) { if (in.done) { if (!INIT && blockIdx.x == 0 && tid == 0) q.ctl[par ^ 1] = in; return; } }
+    // ---- the entries the mat-vecs run over (ascending): the pattern of x, known before the decision
+    bool nz[4];
+    unsigned long long bal[4];
+    int slot[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int a = tid + k * kSbpThreads;
+        if (a >= uc) xt[k] = 0.0;
+        nz[k] = xt[k] != 0.0;                                       // an entry the active set has already pruned stays zero (PADMMBP.h:43)
+        bal[k] = __ballot(nz[k]);
+        if (lane == 0) wcnt[k][wid] = __popcll(bal[k]);
+    }
+    __syncthreads();
+    int nnz = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int before = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { const int cw = wcnt[k][w]; before += w < wid ? cw : 0; tot += cw; }
+        slot[k] = nnz + before + __popcll(bal[k] & ((1ull << lane) - 1ull));
+        if (nz[k]) { lc[slot[k]] = tid + k * kSbpThreads; lb[slot[k]] = bidv[k]; }
+        nnz += tot;
+    }
+    __syncthreads();
+    const bool valid = arow < uc;
+    const int mybid = valid ? mybid0 : -1;
+    // ---- rows a0 .. a0 + 7 of G, the listed columns: requested now, used after the decision (32 slices of the list, 8 rows each)
+    double gv[kGsFlight];
+    {
+        const double* Gr = s.G + (valid ? arow : 0);
+#pragma unroll
+        for (int j = 0; j < kGsFlight; ++j) { const int e = cs + 32 * j; gv[j] = (valid && e < nnz && a0 < uc) ? Gr[(size_t)lc[e] * s.ldg] : 0.0; }
+    }
+    SbpCtl out;
+    if (INIT) {
+        out = in;                                                   // written by this (regular) iteration's xreg launch
+        if (blockIdx.x == 0) {                                      // the carried norms: exact, from the tail's partials
+            double p[2] = {0.0, 0.0};
+            for (int w = tid; w < q.nT; w += kSbpThreads) { p[0] += q.Q[w * 8 + 2]; p[1] += q.Q[w * 8 + 3]; }
+            block_sum<double, 2>(p, red);
+            if (tid == 0) { s.sc[idx * 4] = p[0]; s.sc[idx * 4 + 1] = p[1]; s.sc[idx * 4 + 2] = s.sc[8]; }
+        }
+    } else if (first) {
+        if (!sbp_decide(q, par, out, red)) return;
+        if (blockIdx.x == 0 && tid == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) s.sc[(idx ^ 1) * 4 + k] = s.sc[idx * 4 + k];
+        }
+    } else {
+        if (tid >= (uc + kGsRows - 1) / kGsRows) {                  // partial rows of workgroups beyond U are stale
+#pragma unroll
+            for (int k = 0; k < 7; ++k) pp[k] = 0.0;
+        }
+        if (!sbp_decide_gram(q, in, par, idx, pp, cR, cY, cyz, out, red)) return;
+    }
+    if (a0 >= uc) return;                                           // no rows (the decision's stores, workgroup 0's, are done)
+    // ---- the new x for every entry of U
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int a = tid + k * kSbpThreads;
+        double xn = xt[k];
+        if (!INIT && xt[k] != 0.0) {
+#pragma clang fp contract(off)
+            const double d = gyv[k] * q.inv_rho + hrv[k];
+            xn = sbp_soft(xt[k] - d * gam[k], pen[k]);                // gam: 1 / gamma
+        }
+        if (a < uc) xsh[a] = xn;
+        if (nz[k]) { lx[slot[k]] = xn; ld[slot[k]] = xn - xt[k]; }
+    }
+    __syncthreads();
+    double au = 0.0, ab = 0.0, aw = 0.0, awb = 0.0;
+#pragma unroll
+    for (int j = 0; j < kGsFlight; ++j) {
+        const int e = cs + 32 * j;
+        if (e < nnz) {
+            const double xe = lx[e], de = ld[e];
+            const bool same = lb[e] == mybid;
+            au = fma(gv[j], xe, au); aw = fma(gv[j], de, aw);
+            if (same) { ab = fma(gv[j], xe, ab); awb = fma(gv[j], de, awb); }
+        }
+    }
+    shr[0][cs][r] = au; shr[1][cs][r] = ab; shr[2][cs][r] = aw; shr[3][cs][r] = awb;
+    __syncthreads();
+    // ---- the 32 slices' sums: thread (quantity, row, quarter) adds eight slices in order, the quarters are added in order
+    double part = 0.0;
+    if (tid < 128) {
+        const int qn = tid >> 5, rr = (tid >> 2) & 7, h = tid & 3;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) part += shr[qn][h * 8 + c][rr];
+    }
+    part = (part + __shfl_down(part, 1)) ;
+    const double part2 = __shfl_down(part, 2);
+    part = part + part2;                                            // lanes with (tid & 3) == 0: ((h0 + h1) + (h2 + h3))
+    __syncthreads();
+    if (tid < 128 && (tid & 3) == 0) shr[tid >> 5][0][(tid >> 2) & 7] = part;
+    __syncthreads();
+    if (tid >= kGsRows) return;
+    const double u = shr[0][0][r], ub = shr[1][0][r], w = shr[2][0][r], wb = shr[3][0][r];
+    double p[7] = {0, 0, 0, 0, 0, 0, 0};
+    if (valid) {
+        const double hrn = u * q.invN - e_gz;
+        if (INIT) {
+            s.hr[idx * cap + arow] = hrn;
+        } else {
+            const double xv = xsh[arow], dx = xv - e_xo;
+            p[0] = dx * w; p[1] = e_hro * dx; p[2] = xv * hrn; p[3] = xv * ub; p[4] = dx * wb; p[5] = e_gyo * xv; p[6] = e_gz * xv;
+            const int o = (idx ^ 1) * cap + arow;
+            s.xs[o] = xv; s.hr[o] = hrn; s.gy[o] = e_gyo + q.rho * hrn;
+            const double sxn = e_sx + xv;
+            s.sx[arow] = sxn;
+            q.x[e_col] = xv;
+            s.sxd[e_col] = sxn - (double)nth * xv;
+        }
+    }
+    if (INIT) return;
+    // the eight rows' partials, in row order (lanes 0..7 of wave 0)
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < kGsRows; ++i) t += readlane_f64(p[k], i);
+        p[k] = t;
+    }
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) s.Ps[blockIdx.x * 8 + k] = p[k];
+    }
+}
+
+// End of a stretch: the n-vectors from the gather partials (see the section header).  grid: npad / 64 tiles, eight waves.
+__global__ void __launch_bounds__(64 * kSbpTailWaves)
+sbp_gs_tail_kernel(SbpParams q, int par, int nth) {
+    __shared__ double shA[kSbpTailBlocks][64], shT[kSbpTailBlocks][64];
+    __shared__ double red[2 * kSbpTailWaves];
+    const SbpGram& s = q.gs;
+    if (load_flag_vector(s.ust + 2) == 0) return;
+    const int uc = load_flag_vector(s.ust);
+    const SbpCtl c = load_ctl_vector(q.ctl + par);                  // written by the stretch's last iteration
+    if (c.done) return;
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int row = blockIdx.x * 64 + lane;
+    double D = 0.0, qq = 0.0;
+    if (blockIdx.x == 0) {                                          // the two sums that only exist in Gram space
+        double p[2] = {0.0, 0.0};
+        const int nR = (uc + kGsRows - 1) / kGsRows;
+        for (int w = threadIdx.x; w < nR; w += 64 * kSbpTailWaves) { p[0] += s.Ps[w * 8]; p[1] += s.Ps[w * 8 + 4]; }
+        block_sum<double, 2>(p, red);
+        D = p[0]; qq = p[1];
+    }
+    double S = 0.0, Tq = 0.0, sax = 0.0;                            // wave 0 only
+    for (int b0 = 0; b0 < q.NL; b0 += kSbpTailBlocks) {
+        const int b = b0 + grp;
+        double av = 0.0, tv = 0.0;
+        if (b < q.NL) {
+            const double* pp = s.partP + (size_t)b * s.ngroups * s.pstride + row;
+            const double* pt = s.partT + (size_t)b * s.ngroups * s.pstride + row;
+            for (int gq = 0; gq < s.ngroups; ++gq) { av += pp[(size_t)gq * s.pstride]; tv += pt[(size_t)gq * s.pstride]; }
+            q.Axo[(size_t)b * q.npad + row] = av;
+        }
+        __syncthreads();
+        shA[grp][lane] = av; shT[grp][lane] = tv;
+        __syncthreads();
+        if (grp == 0) {
+            const int nb = min(kSbpTailBlocks, q.NL - b0);
+            for (int t = 0; t < nb; ++t) { const double a = shA[t][lane]; S += a; sax += a * a; Tq += shT[t][lane]; }
+        }
+    }
+    if (grp != 0) return;
+    sax = wave_sum(sax);
+    const bool t0 = blockIdx.x == 0;
+    if (lane == 0) { q.Qa[blockIdx.x * 2] = sax; q.Qa[blockIdx.x * 2 + 1] = t0 ? qq : 0.0; }
+    double r2, y2, abar_r;
+    {
+#pragma clang fp contract(off)
+        q.Sold[row] = S;
+        const double abar = S / q.dN;
+        const double rn = abar - q.zbar[row];
+        q.r[row] = rn;
+        const double yn = q.y[row] + q.rho * ((double)nth * rn + Tq / q.dN);
+        q.y[row] = yn;
+        q.v[row] = yn / q.rho + rn;
+        r2 = rn * rn; y2 = yn * yn; abar_r = abar * rn;
+    }
+    r2 = wave_sum(r2); y2 = wave_sum(y2); abar_r = wave_sum(abar_r);
+    if (lane == 0) {
+        double* Q = q.Q + (size_t)blockIdx.x * 8;
+        Q[0] = t0 ? D / q.dN : 0.0; Q[1] = t0 ? D / (q.dN * q.dN) : 0.0; Q[2] = r2; Q[3] = y2; Q[4] = abar_r;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ setup
 // Largest eigenvalue of a symmetric tridiagonal matrix (diagonal a[0..m), off-diagonal e[0..m-1)) and the LAST component of
 // its unit eigenvector: implicit QL with the rotations applied to one row only.
@@ -697,11 +1204,12 @@ void solve_parbp(const DeviceData<double>& d, const admm_opts& opts, int nblocks
     h2d(d_blk.get(), hblk.data(), (size_t)NL * sizeof(SbpBlk));
     x.zero(st); xl.zero(st); Axo.zero(st); ex.zero(st); Sold.zero(st); y.zero(st); r.zero(st); v.zero(st); zbar.zero(st); Q.zero(st);
     d_list.zero(st); d_cnt.zero(st); d_wcount.zero(st); d_done.zero(st);
+    double zz = 0.0;                                                // zbar'zbar (Gram space)
     {
         std::vector<double> hz(n), hy(n);
         ADMM_HIP_CHECK(hipMemcpyAsync(hy.data(), d.Y.get(), (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
         ADMM_HIP_CHECK(hipStreamSynchronize(st));
-        for (int i = 0; i < n; ++i) hz[i] = hy[i] / (double)N;
+        for (int i = 0; i < n; ++i) { hz[i] = hy[i] / (double)N; zz += hz[i] * hz[i]; }
         h2d(zbar.get(), hz.data(), (size_t)n * sizeof(double));
         ADMM_HIP_CHECK(hipStreamSynchronize(st));
     }
@@ -716,6 +1224,7 @@ void solve_parbp(const DeviceData<double>& d, const admm_opts& opts, int nblocks
     q.n = n; q.npad = npad; q.N = N; q.NL = NL; q.maxit = opts.maxit; q.G = G; q.nT = nT;
     q.eps_abs = opts.eps_abs; q.eps_rel = opts.eps_rel; q.rho = rho;
     q.sqrt_nN = std::sqrt((double)n * (double)N); q.sqrtN = std::sqrt((double)N); q.dN = (double)N;
+    q.invN = 1.0 / (double)N; q.inv_rho = 1.0 / rho;
     q.A = A; q.lda = lda;
     q.Gb = Gb; q.blk = d_blk.get();
     q.x = x.get(); q.list = d_list.get(); q.cnt = d_cnt.get(); q.wcount = d_wcount.get();
@@ -723,6 +1232,48 @@ void solve_parbp(const DeviceData<double>& d, const admm_opts& opts, int nblocks
     q.Sold = Sold.get(); q.y = y.get(); q.r = r.get(); q.v = v.get(); q.zbar = zbar.get(); q.Q = Q.get();
     q.ctl = ctl.get(); q.done = d_done.get(); q.hflag = dist ? nullptr : hflag.p;
     q.trace = res.trace_cap > 0 ? trace.get() : nullptr; q.trace_cap = res.trace_cap;
+
+    // ---- Gram space (single process): state, the gather launches that materialise the n-vectors
+    bool gram = !dist && NL <= kGsMaxBlocks;
+    if (const char* e = std::getenv("ADMM_HIP_SBP_GRAM")) gram = gram && std::atoi(e) != 0;      // 0: the direct launches on every iteration (A/B)
+    const int gcap = std::min(kGsCapMax, std::max(kGsRows, env_int("ADMM_HIP_SBP_GRAM_CAP", kGsCapMax)) / kGsRows * kGsRows);
+    DevBuf<int> g_umap, g_ucol, g_ubid, g_ust;
+    DevBuf<double> g_G, g_gz, g_ugp, g_xs, g_hr, g_gy, g_sx, g_sxd, g_Ps, g_sc, g_partP, g_partT;
+    DevBuf<GatherArgs<double>> g_args;
+    GatherPlan gp;
+    if (gram) {
+        int maxpb = 0;
+        for (int b = 0; b < NL; ++b) maxpb = std::max(maxpb, c0[b + 1] - c0[b]);
+        gp = plan_gather<double>(n, maxpb, 2 * NL);
+        g_umap.alloc(pl); g_ucol.alloc(gcap); g_ubid.alloc(gcap); g_ust.alloc(8);
+        g_G.alloc((size_t)gcap * gcap); g_gz.alloc(gcap); g_ugp.alloc(2 * (size_t)gcap);
+        g_xs.alloc(2 * (size_t)gcap); g_hr.alloc(2 * (size_t)gcap); g_gy.alloc(2 * (size_t)gcap); g_sx.alloc(gcap); g_sxd.alloc(pl);
+        g_Ps.alloc((size_t)(gcap / kGsRows) * 8); g_sc.alloc(16);
+        g_partP.alloc((size_t)NL * gp.ngroups * npad); g_partT.alloc((size_t)NL * gp.ngroups * npad);
+        g_args.alloc(2 * (size_t)NL);
+        ADMM_HIP_CHECK(hipMemsetAsync(g_umap.get(), 0xff, (size_t)pl * sizeof(int), st));
+        g_ucol.zero(st); g_ubid.zero(st); g_ust.zero(st); g_G.zero(st); g_gz.zero(st); g_ugp.zero(st); g_xs.zero(st); g_hr.zero(st); g_gy.zero(st);
+        g_sx.zero(st); g_sxd.zero(st); g_Ps.zero(st); g_sc.zero(st); g_partP.zero(st); g_partT.zero(st);
+        SbpGram& gs = q.gs;
+        gs.cap = gcap; gs.ldg = gcap;
+        gs.umap = g_umap.get(); gs.ucol = g_ucol.get(); gs.ubid = g_ubid.get(); gs.ust = g_ust.get();
+        gs.G = g_G.get(); gs.gz = g_gz.get(); gs.ugp = g_ugp.get(); gs.xs = g_xs.get(); gs.hr = g_hr.get(); gs.gy = g_gy.get();
+        gs.sx = g_sx.get(); gs.sxd = g_sxd.get(); gs.Ps = g_Ps.get(); gs.sc = g_sc.get();
+        gs.partP = g_partP.get(); gs.partT = g_partT.get(); gs.ngroups = gp.ngroups; gs.pstride = npad;
+        gs.zz = zz;
+        std::vector<GatherArgs<double>> ha(2 * (size_t)NL);
+        for (int k = 0; k < 2 * NL; ++k) {
+            const int b = k % NL;
+            GatherArgs<double>& a = ha[k];
+            a.A = A + (size_t)c0[b] * lda; a.lda = lda; a.rows = n; a.cols = c0[b + 1] - c0[b];
+            a.v = (k < NL ? x.get() : g_sxd.get()) + c0[b];
+            a.part = (k < NL ? g_partP.get() : g_partT.get()) + (size_t)b * gp.ngroups * npad;
+            a.pstride = npad; a.ngroups = gp.ngroups; a.cols_per_group = gp.cols_per_group;
+            a.skip = d_done.get(); a.only_if = g_ust.get() + 2;
+        }
+        h2d(g_args.get(), ha.data(), ha.size() * sizeof(GatherArgs<double>));
+        ADMM_HIP_CHECK(hipStreamSynchronize(st));                   // (ha leaves scope)
+    }
 
     const bool big = npad > 8192;                                  // the x-update's row slice per thread: 16 rows up to npad = 8192, 32 beyond
     {
@@ -732,7 +1283,8 @@ void solve_parbp(const DeviceData<double>& d, const admm_opts& opts, int nblocks
         // kernel whenever static + dynamic exceeds the default, and fail loudly when even the opt-in limit is too small.
         const size_t lds = (size_t)npad * sizeof(double);
         const void* fns[] = {reinterpret_cast<const void*>(&sbp_xreg_kernel<true>), reinterpret_cast<const void*>(&sbp_xreg_kernel<false>),
-                             big ? reinterpret_cast<const void*>(&sbp_xact_kernel<false, 32>) : reinterpret_cast<const void*>(&sbp_xact_kernel<false, 16>)};
+                             big ? reinterpret_cast<const void*>(&sbp_xact_kernel<false, 32>) : reinterpret_cast<const void*>(&sbp_xact_kernel<false, 16>),
+                             reinterpret_cast<const void*>(&sbp_gs_dots_kernel<0>), reinterpret_cast<const void*>(&sbp_gs_dots_kernel<1>)};
         for (const void* fn : fns) {
             hipFuncAttributes fa{};
             ADMM_HIP_CHECK(hipFuncGetAttributes(&fa, fn));
@@ -745,27 +1297,68 @@ void solve_parbp(const DeviceData<double>& d, const admm_opts& opts, int nblocks
     }
     const bool nt = (double)lda * (double)pl * 8.0 > 220e6;       // as gemv_plan.h: beyond what the 256 MB Infinity Cache keeps
     ADMM_HIP_CHECK(hipStreamSynchronize(st));
-    LoopTimes lt = run_until_done(st, d_done.get(), sbp_batch(), (long long)opts.maxit + 2,
-        [&](long long g) {
-            const int par = (int)(g & 1);
-            if (g % 10 == 0) {                                       // regular iteration (the counter IS the enqueue index until `done`)
-                if (nt) hipLaunchKernelGGL((sbp_xreg_kernel<true>), dim3(G), dim3(kSbpThreads), (size_t)npad * sizeof(double), st, q, par);
-                else hipLaunchKernelGGL((sbp_xreg_kernel<false>), dim3(G), dim3(kSbpThreads), (size_t)npad * sizeof(double), st, q, par);
-                hipLaunchKernelGGL(sbp_list_kernel, dim3(G), dim3(kSbpThreads), 0, st, q, par ^ 1);
-                if (big) hipLaunchKernelGGL((sbp_xact_kernel<true, 32>), dim3(G), dim3(kSbpThreads), 0, st, q, par ^ 1);
-                else hipLaunchKernelGGL((sbp_xact_kernel<true, 16>), dim3(G), dim3(kSbpThreads), 0, st, q, par ^ 1);
-            } else {
-                if (big) hipLaunchKernelGGL((sbp_xact_kernel<false, 32>), dim3(G), dim3(kSbpThreads), (size_t)npad * sizeof(double), st, q, par);
-                else hipLaunchKernelGGL((sbp_xact_kernel<false, 16>), dim3(G), dim3(kSbpThreads), (size_t)npad * sizeof(double), st, q, par);
+    const size_t ldsv = (size_t)npad * sizeof(double);
+    const bool gram_on = gram;
+    long long gram_from = 0;                                       // the first regular iteration whose stretch may run in Gram space
+    auto enqueue = [&](long long g) {
+        const int par = (int)(g & 1);
+        const int t = (int)(g % 10);
+        const bool gram = gram_on && g - t >= gram_from;            // a stretch runs one way from its regular iteration on
+        if (t == 0) {                                                // regular iteration (the counter IS the enqueue index until `done`)
+            if (nt) hipLaunchKernelGGL((sbp_xreg_kernel<true>), dim3(G), dim3(kSbpThreads), ldsv, st, q, par);
+            else hipLaunchKernelGGL((sbp_xreg_kernel<false>), dim3(G), dim3(kSbpThreads), ldsv, st, q, par);
+            hipLaunchKernelGGL(sbp_list_kernel, dim3(G), dim3(kSbpThreads), 0, st, q, par ^ 1);
+            if (big) hipLaunchKernelGGL((sbp_xact_kernel<true, 32>), dim3(G), dim3(kSbpThreads), 0, st, q, par ^ 1);
+            else hipLaunchKernelGGL((sbp_xact_kernel<true, 16>), dim3(G), dim3(kSbpThreads), 0, st, q, par ^ 1);
+        } else if (gram) {
+            hipLaunchKernelGGL((sbp_gs_kernel<false>), dim3(gcap / kGsRows), dim3(kSbpThreads), 0, st, q, par, par, t == 1 ? 1 : 0, t);
+            if (t == 9) {                                            // the n-vectors for the regular iteration that follows
+                hipLaunchKernelGGL((gather_batch_kernel<double>), dim3(gp.tiles, gp.ngroups, 2 * NL), dim3(kGatherThreads), 0, st, g_args.get());
+                hipLaunchKernelGGL(sbp_gs_tail_kernel, dim3(nT), dim3(64 * kSbpTailWaves), 0, st, q, par ^ 1, 9);
             }
-            if (dist) {
-                hipLaunchKernelGGL((sbp_tail_kernel<false>), dim3(nT), dim3(64 * kSbpTailWaves), 0, st, q, par ^ 1);
-                allreduce_sum_f64(ex.get(), (size_t)npad + 2 * nT, st);
-                hipLaunchKernelGGL(sbp_tail_b_kernel, dim3(nT), dim3(64), 0, st, q, par ^ 1);
-            } else {
-                hipLaunchKernelGGL((sbp_tail_kernel<true>), dim3(nT), dim3(64 * kSbpTailWaves), 0, st, q, par ^ 1);
-            }
-        }, dist ? nullptr : hflag.p);
+            return;
+        } else {
+            if (big) hipLaunchKernelGGL((sbp_xact_kernel<false, 32>), dim3(G), dim3(kSbpThreads), ldsv, st, q, par);
+            else hipLaunchKernelGGL((sbp_xact_kernel<false, 16>), dim3(G), dim3(kSbpThreads), ldsv, st, q, par);
+        }
+        if (dist) {
+            hipLaunchKernelGGL((sbp_tail_kernel<false>), dim3(nT), dim3(64 * kSbpTailWaves), 0, st, q, par ^ 1);
+            allreduce_sum_f64(ex.get(), (size_t)npad + 2 * nT, st);
+            hipLaunchKernelGGL(sbp_tail_b_kernel, dim3(nT), dim3(64), 0, st, q, par ^ 1);
+        } else {
+            hipLaunchKernelGGL((sbp_tail_kernel<true>), dim3(nT), dim3(64 * kSbpTailWaves), 0, st, q, par ^ 1);
+        }
+        if (t == 0 && gram) {                                        // U, G and the start of the stretch in Gram space
+            hipLaunchKernelGGL(sbp_gs_merge_kernel, dim3(1), dim3(kSbpThreads), 0, st, q, par ^ 1, (int)g);
+            hipLaunchKernelGGL((sbp_gs_dots_kernel<0>), dim3(32, 8), dim3(kSbpThreads), ldsv, st, q, 0);
+            hipLaunchKernelGGL((sbp_gs_dots_kernel<1>), dim3(gcap / 4 + 1), dim3(kSbpThreads), ldsv, st, q, par ^ 1);
+            hipLaunchKernelGGL((sbp_gs_kernel<true>), dim3(gcap / kGsRows), dim3(kSbpThreads), 0, st, q, par ^ 1, par ^ 1, 0, 0);
+        }
+    };
+    LoopTimes lt;
+    int gstat[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int halts = 0;
+    for (long long g_start = 0;;) {
+        const LoopTimes l1 = run_until_done(st, d_done.get(), sbp_batch(), (long long)opts.maxit + 2, enqueue, dist ? nullptr : hflag.p, g_start);
+        lt.wall_s += l1.wall_s; lt.events_ms += l1.events_ms; lt.launched += l1.launched;
+        if (!gram_on) break;
+        ADMM_HIP_CHECK(hipGetLastError());
+        ADMM_HIP_CHECK(hipMemcpy(gstat, g_ust.get(), sizeof(gstat), hipMemcpyDeviceToHost));
+        if (gstat[3] == 0) break;
+        // More non-zeros than the Gram matrix has room for: the merge launch of (regular) iteration gstat[4] halted the stream
+        // right after that iteration.  Lift the halt and go on from the next iteration with the direct launches; Gram space
+        // is tried again 100, 200, 400, ... iterations later (supports usually shrink as the solve goes on).
+        SbpCtl hc[2];
+        ADMM_HIP_CHECK(hipMemcpy(hc, ctl.get(), sizeof(hc), hipMemcpyDeviceToHost));
+        hc[0].done = hc[1].done = 0;
+        ADMM_HIP_CHECK(hipMemcpy(ctl.get(), hc, sizeof(hc), hipMemcpyHostToDevice));
+        ADMM_HIP_CHECK(hipMemset(d_done.get(), 0, sizeof(int)));
+        ADMM_HIP_CHECK(hipMemset(g_ust.get() + 2, 0, 2 * sizeof(int)));
+        *hflag.p = 0;
+        g_start = (long long)gstat[4] + 1;
+        gram_from = (long long)gstat[4] + 100LL * (1LL << std::min(halts, 20));
+        ++halts;
+    }
     ADMM_HIP_CHECK(hipGetLastError());                             // a refused launch (LDS request, grid) is an error, not a silent no-op
     SbpCtl hc[2];
     ADMM_HIP_CHECK(hipMemcpy(hc, ctl.get(), sizeof(hc), hipMemcpyDeviceToHost));
@@ -784,6 +1377,9 @@ void solve_parbp(const DeviceData<double>& d, const admm_opts& opts, int nblocks
     S.loop_ms_events = lt.events_ms;
     S.exchange_variant = dist ? 1 : 0;
     S.xupdate_samples = lsteps;                                     // Lanczos steps of the longest spectral-radius run
+    S.xupdate_variant = gstat[6] == 0 ? 0 : (halts > 0 ? 2 : 1);      // how the active-set iterations ran (include/admm_hip.h)
+    S.xupdate_launches = gstat[6];                                  // stretches that ran in Gram space
+    S.persist_iter = gstat[5];                                      // times U was rebuilt from the current lists
 }
 
 }  // namespace admm

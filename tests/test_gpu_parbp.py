@@ -125,3 +125,36 @@ def test_more_than_8192_rows_takes_the_large_lds_variant():
     import admm_amd
     with pytest.raises(RuntimeError):
         admm_amd.admm_bp(np.zeros((16390, 16400), order="F"), np.zeros(16390)).parallel(2).fit()      # beyond the row limit: a clear error
+
+
+def test_gram_space_and_its_ways_out(monkeypatch):
+    """Round 5: the active-set iterations run in Gram space (one |U| x |U| mat-vec per iteration instead of two passes over the
+    non-zero columns; sharing_bp.hip "Gram space").  Every way through that code is held to the oracle like the direct launches:
+    the default, the direct launches alone (ADMM_HIP_SBP_GRAM=0), a Gram matrix too small for the support (the merge launch halts
+    the stream, the host resumes with the direct launches and returns to Gram space 100, 200, ... iterations later), and one that
+    overflows with columns that have come and gone first (U is rebuilt from the current lists)."""
+    from oracle import readme
+    x, y, _ = readme.bp_data(1000, 2000, 100)                    # README.md:369-393: ~100 non-zeros at the end, more on the way
+    seen = {}
+    for label, env in (("default", {}), ("direct", {"ADMM_HIP_SBP_GRAM": "0"}), ("cap 64: halt + resume", {"ADMM_HIP_SBP_GRAM_CAP": "64"}),
+                       ("cap 96: a rebuild, then halt + resume", {"ADMM_HIP_SBP_GRAM_CAP": "96"})):
+        with monkeypatch.context() as m:
+            for k, v in env.items():
+                m.setenv(k, v)
+            fit, o = _compare(x, y, 4, f"README n=1000 p=2000, {label}")
+        st = fit.stats
+        seen[label] = (st["xupdate_variant"], st["xupdate_launches"], st["persist_iter"])
+        print(f"[parbp gram] {label}: variant {st['xupdate_variant']}, {st['xupdate_launches']} stretches in Gram space, {st['persist_iter']} rebuilds of U")
+    assert seen["default"][0] == 1 and seen["default"][1] >= fit.niter // 10 - 1
+    assert seen["direct"] == (0, 0, 0)
+    assert seen["cap 64: halt + resume"][0] == 2 and seen["cap 64: halt + resume"][1] >= 1
+    assert seen["cap 96: a rebuild, then halt + resume"][0] == 2 and seen["cap 96: a rebuild, then halt + resume"][2] >= 1
+    # a small problem whose support comes and goes: different block counts, ragged
+    rng = np.random.default_rng(21)
+    n, p = 120, 700
+    xs = np.asfortranarray(rng.standard_normal((n, p)))
+    b0 = np.zeros(p); b0[rng.choice(p, 12, replace=False)] = rng.standard_normal(12) * 4
+    for N, cap in ((3, "1024"), (6, "16"), (6, "24")):
+        with monkeypatch.context() as m:
+            m.setenv("ADMM_HIP_SBP_GRAM_CAP", cap)
+            _compare(xs, xs @ b0, N, f"n=120 p=700 cap {cap}")
