@@ -510,7 +510,7 @@ constexpr int kGsRows = 8;
 // round trips (list lengths, list entries, their slots in U).
 constexpr int kGsMaxBlocks = 256;
 __global__ void __launch_bounds__(kSbpThreads)
-sbp_gs_merge_kernel(SbpParams q, int par, int g) {
+sbp_gs_merge_kernel(SbpParams q, int par, int g, int may_reset) {
     __shared__ int pre[kGsMaxBlocks + 1], c0s[kGsMaxBlocks];
     __shared__ int wcnt[4][4];
     const SbpGram& s = q.gs;
@@ -525,7 +525,22 @@ sbp_gs_merge_kernel(SbpParams q, int par, int g) {
     if (tid == 0) { pre[0] = 0; for (int b = 0; b < q.NL; ++b) pre[b + 1] += pre[b]; }
     __syncthreads();
     const int T = pre[q.NL];
-    if (T > s.cap) {
+    bool halt = T > s.cap;
+    if (!halt && !may_reset) {
+        // a stretch that carries its state over from the previous one cannot have U re-numbered under it: count first
+        int newc = 0;
+        for (int i = tid; i < T; i += kSbpThreads) {
+            int lo = 0, hi = q.NL - 1;
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (pre[mid] <= i) lo = mid; else hi = mid - 1; }
+            newc += s.umap[c0s[lo] + q.list[c0s[lo] + i - pre[lo]]] < 0 ? 1 : 0;
+        }
+        newc = wave_sum(newc);
+        if (lane == 0) wcnt[0][wid] = newc;
+        __syncthreads();
+        halt = uc + wcnt[0][0] + wcnt[0][1] + wcnt[0][2] + wcnt[0][3] > s.cap;
+        __syncthreads();
+    }
+    if (halt) {
         // more non-zeros than G has room for: halt the enqueued launches (they all honour `done`); the host resumes from
         // iteration g + 1 with the direct launches
         if (tid == 0) {
@@ -649,9 +664,16 @@ sbp_gs_dots_kernel(SbpParams q, int idx) {
                 const double d = sbp_wave_dot(q.A + (size_t)s.ucol[a] * q.lda, vsh, nk, lane);
                 if (lane == 0) { s.G[(size_t)c * s.ldg + a] = d; s.G[(size_t)a * s.ldg + c] = d; }
             }
-            if (blockIdx.x == 0 && wid == 0) {
-                const double d = sbp_wave_dot(q.zbar, vsh, nk, lane);
-                if (lane == 0) s.gz[c] = d;
+            if (blockIdx.x == 0) {
+                // the entry's place in the vectors a stretch that follows a Gram-space stretch starts from (buffer idx): it was
+                // zero there, A_c'y and A_c'r of the n-vectors the previous stretch's tail left are exact products
+                const double* vec = wid == 0 ? q.zbar : (wid == 1 ? q.y : q.r);
+                if (wid < 3) {
+                    const double d = sbp_wave_dot(vec, vsh, nk, lane);
+                    if (lane == 0) { if (wid == 0) s.gz[c] = d; else if (wid == 1) s.gy[idx * s.cap + c] = d; else s.hr[idx * s.cap + c] = d; }
+                } else if (lane == 0) {
+                    s.xs[idx * s.cap + c] = 0.0;
+                }
             }
         }
     }
@@ -706,34 +728,42 @@ __device__ __forceinline__ bool sbp_decide_gram(const SbpParams& q, const SbpCtl
 // Latency is what the launch costs: everything that does not depend on the decision -- U's state, the previous launch's
 // partials, the rows' own entries -- is requested before the first wait (the buffers are `cap` long, so the requests need not
 // know U's length), and the G requests of the mat-vecs are all in flight together.
-constexpr int kGsFlight = kGsCapMax / 32;                           // G requests per thread: the whole list in one round trip
+constexpr int kGsSlices = 64;                                       // slices of the list: a thread owns one slice and two of the workgroup's eight rows
+constexpr int kGsFlight = kGsCapMax / kGsSlices;                    // 16-byte G requests per thread: the whole list in one round trip
 // "This value is needed HERE": keeps a prefetch where it was written (the compiler otherwise sinks a load into the branch
 // that uses it, i.e. behind the decision -- one more dependent round trip; measured 3.2 -> 0.7 us for the decision).
 __device__ __forceinline__ void pin(double v) { asm volatile("" :: "v"(v)); }
 __device__ __forceinline__ void pin(int v) { asm volatile("" :: "v"(v)); }
-template <bool INIT>
+// MODE 0: an active-set iteration.  MODE 1 (INIT): the start of a stretch after an iteration that ran with the direct launches.
+// MODE 2 (REG): the start of a stretch that follows a Gram-space stretch -- the regular iteration's x (gathered from the dense
+// vector xreg wrote) takes the place of the soft-thresholds: its partials make the NEXT launch's decision the regular
+// iteration's, A_U'y follows its recurrence across the regular iteration, and the carried norms are the exact ones the
+// previous stretch's tail left.  No n-vector is touched at the regular iteration then (xact / tail / dots<1> are not launched).
+template <int MODE>
 __global__ void __launch_bounds__(kSbpThreads)
 sbp_gs_kernel(SbpParams q, int par, int idx, int first, int nth) {
+    constexpr bool INIT = MODE == 1, REG = MODE == 2;
     __shared__ double red[8 * 4];
     __shared__ double xsh[kGsCapMax];
     __shared__ double lx[kGsCapMax], ld[kGsCapMax];
     __shared__ int lc[kGsCapMax], lb[kGsCapMax];
     __shared__ int wcnt[4][4];
-    __shared__ double shr[4][32][kGsRows];
+    __shared__ double shr[4][kGsSlices][kGsRows];
     const SbpGram& s = q.gs;
     const int cap = s.cap;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     // ---- requests that depend on nothing
     double xt[4], gyv[4], hrv[4], gam[4], pen[4];
-    int bidv[4];
+    int bidv[4], ucv[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int a = tid + k * kSbpThreads;
-        xt[k] = 0.0; gyv[k] = 0.0; hrv[k] = 0.0; gam[k] = 1.0; pen[k] = 0.0; bidv[k] = 0;
+        xt[k] = 0.0; gyv[k] = 0.0; hrv[k] = 0.0; gam[k] = 1.0; pen[k] = 0.0; bidv[k] = 0; ucv[k] = 0;
         if (a < cap) {
             xt[k] = s.xs[idx * cap + a];
             bidv[k] = s.ubid[a];
-            if (!INIT) {
+            if (REG) ucv[k] = s.ucol[a];
+            if (MODE == 0) {
                 gyv[k] = s.gy[idx * cap + a]; hrv[k] = s.hr[idx * cap + a];
                 const double2 gp = reinterpret_cast<const double2*>(s.ugp)[a];
                 gam[k] = gp.x; pen[k] = gp.y;
@@ -741,9 +771,10 @@ sbp_gs_kernel(SbpParams q, int par, int idx, int first, int nth) {
         }
     }
     const int a0 = blockIdx.x * kGsRows;
-    const int r = tid & (kGsRows - 1), cs = tid >> 3;
+    const int r = tid & (kGsRows - 1);                              // the row this thread finishes (threads 0..7)
+    const int rp = tid & 3, cs = tid >> 2;                          // mat-vec: row pair and list slice
     const int arow = a0 + r;                                        // < cap: the grid is cap / 8
-    const int mybid0 = s.ubid[arow];
+    const int2 pbid0 = *reinterpret_cast<const int2*>(s.ubid + a0 + 2 * rp);
     double e_gz = 0.0, e_xo = 0.0, e_hro = 0.0, e_gyo = 0.0, e_sx = 0.0;
     int e_col = 0;
     if (tid < kGsRows) {
@@ -752,7 +783,7 @@ sbp_gs_kernel(SbpParams q, int par, int idx, int first, int nth) {
     }
     double pp[7] = {0, 0, 0, 0, 0, 0, 0};
     double cR = 0.0, cY = 0.0, cyz = 0.0;
-    if (!INIT && !first) {
+    if (MODE == 0 && !first) {
         if (tid < cap / kGsRows) {
             const double2* pr = reinterpret_cast<const double2*>(s.Ps + (size_t)tid * 8);
             const double2 p0 = pr[0], p1 = pr[1], p2 = pr[2], p3 = pr[3];
@@ -765,12 +796,17 @@ sbp_gs_kernel(SbpParams q, int par, int idx, int first, int nth) {
     const int smode = load_flag_vector(s.ust + 2);
     const int uc = load_flag_vector(s.ust);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { pin(xt[k]); pin(gyv[k]); pin(hrv[k]); pin(gam[k]); pin(pen[k]); pin(bidv[k]); }
+    for (int k = 0; k < 4; ++k) { pin(xt[k]); pin(gyv[k]); pin(hrv[k]); pin(gam[k]); pin(pen[k]); pin(bidv[k]); pin(ucv[k]); }
 #pragma unroll
     for (int k = 0; k < 7; ++k) pin(pp[k]);
-    pin(cR); pin(cY); pin(cyz); pin(mybid0); pin(e_gz); pin(e_xo); pin(e_hro); pin(e_gyo); pin(e_sx); pin(e_col);
+    pin(cR); pin(cY); pin(cyz); pin(pbid0.x); pin(pbid0.y); pin(e_gz); pin(e_xo); pin(e_hro); pin(e_gyo); pin(e_sx); pin(e_col);
     if (smode == 0) return;
-    if (INIT || !first) { if (in.done) { if (!INIT && blockIdx.x == 0 && tid == 0) q.ctl[par ^ 1] = in; return; } }
+    if (INIT || !first) { if (in.done) { if (MODE == 0 && blockIdx.x == 0 && tid == 0) q.ctl[par ^ 1] = in; return; } }
+    double xg[4] = {0.0, 0.0, 0.0, 0.0};                            // REG: the x the regular iteration left
+    if (REG) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (tid + k * kSbpThreads < uc) xg[k] = q.x[ucv[k]];
+    }
     // ---- the entries the mat-vecs run over (ascending): the pattern of x, known before the decision
     bool nz[4];
     unsigned long long bal[4];
@@ -779,7 +815,7 @@ sbp_gs_kernel(SbpParams q, int par, int idx, int first, int nth) {
     for (int k = 0; k < 4; ++k) {
         const int a = tid + k * kSbpThreads;
         if (a >= uc) xt[k] = 0.0;
-        nz[k] = xt[k] != 0.0;                                       // an entry the active set has already pruned stays zero (PADMMBP.h:43)
+        nz[k] = xt[k] != 0.0 || (REG && xg[k] != 0.0);              // an entry the active set has already pruned stays zero (PADMMBP.h:43)
         bal[k] = __ballot(nz[k]);
         if (lane == 0) wcnt[k][wid] = __popcll(bal[k]);
     }
@@ -796,22 +832,28 @@ sbp_gs_kernel(SbpParams q, int par, int idx, int first, int nth) {
     }
     __syncthreads();
     const bool valid = arow < uc;
-    const int mybid = valid ? mybid0 : -1;
-    // ---- rows a0 .. a0 + 7 of G, the listed columns: requested now, used after the decision (32 slices of the list, 8 rows each)
-    double gv[kGsFlight];
+    // ---- rows a0 .. a0 + 7 of G, the listed columns: requested now, used after the decision (64 slices of the list; a thread
+    // takes two rows with one 16-byte request -- rows beyond U hold zeros or stale numbers and are never stored)
+    double2 gv[kGsFlight];
     {
-        const double* Gr = s.G + (valid ? arow : 0);
+        const double* Gr = s.G + a0 + 2 * rp;
 #pragma unroll
-        for (int j = 0; j < kGsFlight; ++j) { const int e = cs + 32 * j; gv[j] = (valid && e < nnz && a0 < uc) ? Gr[(size_t)lc[e] * s.ldg] : 0.0; }
+        for (int j = 0; j < kGsFlight; ++j) {
+            const int e = cs + kGsSlices * j;
+            gv[j] = (e < nnz && a0 < uc) ? *reinterpret_cast<const double2*>(Gr + (size_t)lc[e] * s.ldg) : make_double2(0.0, 0.0);
+        }
     }
     SbpCtl out;
-    if (INIT) {
+    if (INIT || REG) {
         out = in;                                                   // written by this (regular) iteration's xreg launch
         if (blockIdx.x == 0) {                                      // the carried norms: exact, from the tail's partials
-            double p[2] = {0.0, 0.0};
-            for (int w = tid; w < q.nT; w += kSbpThreads) { p[0] += q.Q[w * 8 + 2]; p[1] += q.Q[w * 8 + 3]; }
-            block_sum<double, 2>(p, red);
-            if (tid == 0) { s.sc[idx * 4] = p[0]; s.sc[idx * 4 + 1] = p[1]; s.sc[idx * 4 + 2] = s.sc[8]; }
+            double p[3] = {0.0, 0.0, 0.0};
+            for (int w = tid; w < q.nT; w += kSbpThreads) { p[0] += q.Q[w * 8 + 2]; p[1] += q.Q[w * 8 + 3]; p[2] += q.Q[w * 8 + 5]; }
+            block_sum<double, 3>(p, red);
+            // INIT: for the launch that reads this buffer next (the first iteration decides from the direct tail's partials and
+            // forwards them); REG: for the next launch, whose decision is this iteration's
+            double* o = s.sc + (REG ? idx ^ 1 : idx) * 4;
+            if (tid == 0) { o[0] = p[0]; o[1] = p[1]; o[2] = REG ? p[2] : s.sc[8]; }
         }
     } else if (first) {
         if (!sbp_decide(q, par, out, red)) return;
@@ -831,8 +873,8 @@ sbp_gs_kernel(SbpParams q, int par, int idx, int first, int nth) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int a = tid + k * kSbpThreads;
-        double xn = xt[k];
-        if (!INIT && xt[k] != 0.0) {
+        double xn = REG ? xg[k] : xt[k];
+        if (MODE == 0 && xt[k] != 0.0) {
 #pragma clang fp contract(off)
             const double d = gyv[k] * q.inv_rho + hrv[k];
             xn = sbp_soft(xt[k] - d * gam[k], pen[k]);                // gam: 1 / gamma
@@ -841,27 +883,30 @@ sbp_gs_kernel(SbpParams q, int par, int idx, int first, int nth) {
         if (nz[k]) { lx[slot[k]] = xn; ld[slot[k]] = xn - xt[k]; }
     }
     __syncthreads();
-    double au = 0.0, ab = 0.0, aw = 0.0, awb = 0.0;
+    double au[2] = {0.0, 0.0}, ab[2] = {0.0, 0.0}, aw[2] = {0.0, 0.0}, awb[2] = {0.0, 0.0};
 #pragma unroll
     for (int j = 0; j < kGsFlight; ++j) {
-        const int e = cs + 32 * j;
+        const int e = cs + kGsSlices * j;
         if (e < nnz) {
             const double xe = lx[e], de = ld[e];
-            const bool same = lb[e] == mybid;
-            au = fma(gv[j], xe, au); aw = fma(gv[j], de, aw);
-            if (same) { ab = fma(gv[j], xe, ab); awb = fma(gv[j], de, awb); }
+            const int be = lb[e];
+            au[0] = fma(gv[j].x, xe, au[0]); aw[0] = fma(gv[j].x, de, aw[0]);
+            au[1] = fma(gv[j].y, xe, au[1]); aw[1] = fma(gv[j].y, de, aw[1]);
+            if (be == pbid0.x) { ab[0] = fma(gv[j].x, xe, ab[0]); awb[0] = fma(gv[j].x, de, awb[0]); }
+            if (be == pbid0.y) { ab[1] = fma(gv[j].y, xe, ab[1]); awb[1] = fma(gv[j].y, de, awb[1]); }
         }
     }
-    shr[0][cs][r] = au; shr[1][cs][r] = ab; shr[2][cs][r] = aw; shr[3][cs][r] = awb;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) { shr[0][cs][2 * rp + h] = au[h]; shr[1][cs][2 * rp + h] = ab[h]; shr[2][cs][2 * rp + h] = aw[h]; shr[3][cs][2 * rp + h] = awb[h]; }
     __syncthreads();
-    // ---- the 32 slices' sums: thread (quantity, row, quarter) adds eight slices in order, the quarters are added in order
+    // ---- the 64 slices' sums: thread (quantity, row, quarter) adds sixteen slices in order, the quarters are added in order
     double part = 0.0;
     if (tid < 128) {
         const int qn = tid >> 5, rr = (tid >> 2) & 7, h = tid & 3;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) part += shr[qn][h * 8 + c][rr];
+        for (int c = 0; c < kGsSlices / 4; ++c) part += shr[qn][h * (kGsSlices / 4) + c][rr];
     }
-    part = (part + __shfl_down(part, 1)) ;
+    part = part + __shfl_down(part, 1);
     const double part2 = __shfl_down(part, 2);
     part = part + part2;                                            // lanes with (tid & 3) == 0: ((h0 + h1) + (h2 + h3))
     __syncthreads();
@@ -879,7 +924,7 @@ sbp_gs_kernel(SbpParams q, int par, int idx, int first, int nth) {
             p[0] = dx * w; p[1] = e_hro * dx; p[2] = xv * hrn; p[3] = xv * ub; p[4] = dx * wb; p[5] = e_gyo * xv; p[6] = e_gz * xv;
             const int o = (idx ^ 1) * cap + arow;
             s.xs[o] = xv; s.hr[o] = hrn; s.gy[o] = e_gyo + q.rho * hrn;
-            const double sxn = e_sx + xv;
+            const double sxn = (REG ? 0.0 : e_sx) + xv;                // REG: the stretch's sum starts with the regular iteration's x
             s.sx[arow] = sxn;
             q.x[e_col] = xv;
             s.sxd[e_col] = sxn - (double)nth * xv;
@@ -942,7 +987,7 @@ sbp_gs_tail_kernel(SbpParams q, int par, int nth) {
     sax = wave_sum(sax);
     const bool t0 = blockIdx.x == 0;
     if (lane == 0) { q.Qa[blockIdx.x * 2] = sax; q.Qa[blockIdx.x * 2 + 1] = t0 ? qq : 0.0; }
-    double r2, y2, abar_r;
+    double r2, y2, abar_r, yzp;
     {
 #pragma clang fp contract(off)
         q.Sold[row] = S;
@@ -952,12 +997,13 @@ sbp_gs_tail_kernel(SbpParams q, int par, int nth) {
         const double yn = q.y[row] + q.rho * ((double)nth * rn + Tq / q.dN);
         q.y[row] = yn;
         q.v[row] = yn / q.rho + rn;
-        r2 = rn * rn; y2 = yn * yn; abar_r = abar * rn;
+        r2 = rn * rn; y2 = yn * yn; abar_r = abar * rn; yzp = yn * q.zbar[row];
     }
-    r2 = wave_sum(r2); y2 = wave_sum(y2); abar_r = wave_sum(abar_r);
+    r2 = wave_sum(r2); y2 = wave_sum(y2); abar_r = wave_sum(abar_r); yzp = wave_sum(yzp);
     if (lane == 0) {
         double* Q = q.Q + (size_t)blockIdx.x * 8;
         Q[0] = t0 ? D / q.dN : 0.0; Q[1] = t0 ? D / (q.dN * q.dN) : 0.0; Q[2] = r2; Q[3] = y2; Q[4] = abar_r;
+        Q[5] = yzp;                                                 // y'zbar, exact: the next stretch carries it on (MODE 2 above)
     }
 }
 
@@ -1299,7 +1345,17 @@ void solve_parbp(const DeviceData<double>& d, const admm_opts& opts, int nblocks
     ADMM_HIP_CHECK(hipStreamSynchronize(st));
     const size_t ldsv = (size_t)npad * sizeof(double);
     const bool gram_on = gram;
+    bool carry_on = true;                                          // 0: every Gram-space stretch starts from the direct launches' n-vectors (A/B)
+    if (const char* e = std::getenv("ADMM_HIP_SBP_GRAM_CARRY")) carry_on = std::atoi(e) != 0;
     long long gram_from = 0;                                       // the first regular iteration whose stretch may run in Gram space
+    long long last_gram = -100;                                    // the regular iteration of the last stretch enqueued in Gram space
+    std::vector<char> carried;                                     // per stretch: it started from the previous stretch's Gram-space state
+    bool cur_carried = false;
+    auto launch_xact_tail = [&](int par) {                         // a regular iteration's n-vectors (direct launches)
+        if (big) hipLaunchKernelGGL((sbp_xact_kernel<true, 32>), dim3(G), dim3(kSbpThreads), 0, st, q, par ^ 1);
+        else hipLaunchKernelGGL((sbp_xact_kernel<true, 16>), dim3(G), dim3(kSbpThreads), 0, st, q, par ^ 1);
+        hipLaunchKernelGGL((sbp_tail_kernel<true>), dim3(nT), dim3(64 * kSbpTailWaves), 0, st, q, par ^ 1);
+    };
     auto enqueue = [&](long long g) {
         const int par = (int)(g & 1);
         const int t = (int)(g % 10);
@@ -1308,13 +1364,32 @@ void solve_parbp(const DeviceData<double>& d, const admm_opts& opts, int nblocks
             if (nt) hipLaunchKernelGGL((sbp_xreg_kernel<true>), dim3(G), dim3(kSbpThreads), ldsv, st, q, par);
             else hipLaunchKernelGGL((sbp_xreg_kernel<false>), dim3(G), dim3(kSbpThreads), ldsv, st, q, par);
             hipLaunchKernelGGL(sbp_list_kernel, dim3(G), dim3(kSbpThreads), 0, st, q, par ^ 1);
+            if (gram) {
+                // U, G and the start of the stretch in Gram space.  After a Gram-space stretch everything carries over (MODE 2:
+                // no n-vector is touched at this iteration); otherwise the direct launches make the n-vectors first.
+                cur_carried = carry_on && last_gram == g - 10;
+                if ((size_t)(g / 10) >= carried.size()) carried.resize((size_t)(g / 10) + 1, 0);
+                carried[(size_t)(g / 10)] = cur_carried ? 1 : 0;
+                last_gram = g;
+                if (!cur_carried) launch_xact_tail(par);
+                hipLaunchKernelGGL(sbp_gs_merge_kernel, dim3(1), dim3(kSbpThreads), 0, st, q, par ^ 1, (int)g, cur_carried ? 0 : 1);
+                hipLaunchKernelGGL((sbp_gs_dots_kernel<0>), dim3(32, 8), dim3(kSbpThreads), ldsv, st, q, par);
+                if (cur_carried) {
+                    hipLaunchKernelGGL((sbp_gs_kernel<2>), dim3(gcap / kGsRows), dim3(kSbpThreads), 0, st, q, par ^ 1, par, 0, 1);
+                } else {
+                    hipLaunchKernelGGL((sbp_gs_dots_kernel<1>), dim3(gcap / 4 + 1), dim3(kSbpThreads), ldsv, st, q, par ^ 1);
+                    hipLaunchKernelGGL((sbp_gs_kernel<1>), dim3(gcap / kGsRows), dim3(kSbpThreads), 0, st, q, par ^ 1, par ^ 1, 0, 0);
+                }
+                return;
+            }
             if (big) hipLaunchKernelGGL((sbp_xact_kernel<true, 32>), dim3(G), dim3(kSbpThreads), 0, st, q, par ^ 1);
             else hipLaunchKernelGGL((sbp_xact_kernel<true, 16>), dim3(G), dim3(kSbpThreads), 0, st, q, par ^ 1);
         } else if (gram) {
-            hipLaunchKernelGGL((sbp_gs_kernel<false>), dim3(gcap / kGsRows), dim3(kSbpThreads), 0, st, q, par, par, t == 1 ? 1 : 0, t);
+            // (a carried stretch's sum of iterates starts with the regular iteration's x: one more term)
+            hipLaunchKernelGGL((sbp_gs_kernel<0>), dim3(gcap / kGsRows), dim3(kSbpThreads), 0, st, q, par, par, (!cur_carried && t == 1) ? 1 : 0, cur_carried ? t + 1 : t);
             if (t == 9) {                                            // the n-vectors for the regular iteration that follows
                 hipLaunchKernelGGL((gather_batch_kernel<double>), dim3(gp.tiles, gp.ngroups, 2 * NL), dim3(kGatherThreads), 0, st, g_args.get());
-                hipLaunchKernelGGL(sbp_gs_tail_kernel, dim3(nT), dim3(64 * kSbpTailWaves), 0, st, q, par ^ 1, 9);
+                hipLaunchKernelGGL(sbp_gs_tail_kernel, dim3(nT), dim3(64 * kSbpTailWaves), 0, st, q, par ^ 1, cur_carried ? 10 : 9);
             }
             return;
         } else {
@@ -1327,12 +1402,6 @@ void solve_parbp(const DeviceData<double>& d, const admm_opts& opts, int nblocks
             hipLaunchKernelGGL(sbp_tail_b_kernel, dim3(nT), dim3(64), 0, st, q, par ^ 1);
         } else {
             hipLaunchKernelGGL((sbp_tail_kernel<true>), dim3(nT), dim3(64 * kSbpTailWaves), 0, st, q, par ^ 1);
-        }
-        if (t == 0 && gram) {                                        // U, G and the start of the stretch in Gram space
-            hipLaunchKernelGGL(sbp_gs_merge_kernel, dim3(1), dim3(kSbpThreads), 0, st, q, par ^ 1, (int)g);
-            hipLaunchKernelGGL((sbp_gs_dots_kernel<0>), dim3(32, 8), dim3(kSbpThreads), ldsv, st, q, 0);
-            hipLaunchKernelGGL((sbp_gs_dots_kernel<1>), dim3(gcap / 4 + 1), dim3(kSbpThreads), ldsv, st, q, par ^ 1);
-            hipLaunchKernelGGL((sbp_gs_kernel<true>), dim3(gcap / kGsRows), dim3(kSbpThreads), 0, st, q, par ^ 1, par ^ 1, 0, 0);
         }
     };
     LoopTimes lt;
@@ -1355,6 +1424,8 @@ void solve_parbp(const DeviceData<double>& d, const admm_opts& opts, int nblocks
         ADMM_HIP_CHECK(hipMemset(d_done.get(), 0, sizeof(int)));
         ADMM_HIP_CHECK(hipMemset(g_ust.get() + 2, 0, 2 * sizeof(int)));
         *hflag.p = 0;
+        if ((size_t)(gstat[4] / 10) < carried.size() && carried[(size_t)(gstat[4] / 10)]) launch_xact_tail(gstat[4] & 1);   // (not made at a carried start)
+        last_gram = -100;
         g_start = (long long)gstat[4] + 1;
         gram_from = (long long)gstat[4] + 100LL * (1LL << std::min(halts, 20));
         ++halts;

@@ -130,13 +130,15 @@ def test_more_than_8192_rows_takes_the_large_lds_variant():
 def test_gram_space_and_its_ways_out(monkeypatch):
     """Round 5: the active-set iterations run in Gram space (one |U| x |U| mat-vec per iteration instead of two passes over the
     non-zero columns; sharing_bp.hip "Gram space").  Every way through that code is held to the oracle like the direct launches:
-    the default, the direct launches alone (ADMM_HIP_SBP_GRAM=0), a Gram matrix too small for the support (the merge launch halts
+    the default (a stretch after a Gram-space stretch carries everything over: no n-vector is touched at the regular iteration), every
+    stretch started from the direct launches' n-vectors (ADMM_HIP_SBP_GRAM_CARRY=0), the direct launches alone (ADMM_HIP_SBP_GRAM=0), a Gram matrix too small for the support (the merge launch halts
     the stream, the host resumes with the direct launches and returns to Gram space 100, 200, ... iterations later), and one that
     overflows with columns that have come and gone first (U is rebuilt from the current lists)."""
     from oracle import readme
     x, y, _ = readme.bp_data(1000, 2000, 100)                    # README.md:369-393: ~100 non-zeros at the end, more on the way
     seen = {}
-    for label, env in (("default", {}), ("direct", {"ADMM_HIP_SBP_GRAM": "0"}), ("cap 64: halt + resume", {"ADMM_HIP_SBP_GRAM_CAP": "64"}),
+    for label, env in (("default", {}), ("direct", {"ADMM_HIP_SBP_GRAM": "0"}), ("no carry-over", {"ADMM_HIP_SBP_GRAM_CARRY": "0"}),
+                       ("cap 64: halt + resume", {"ADMM_HIP_SBP_GRAM_CAP": "64"}),
                        ("cap 96: a rebuild, then halt + resume", {"ADMM_HIP_SBP_GRAM_CAP": "96"})):
         with monkeypatch.context() as m:
             for k, v in env.items():
@@ -146,7 +148,7 @@ def test_gram_space_and_its_ways_out(monkeypatch):
         seen[label] = (st["xupdate_variant"], st["xupdate_launches"], st["persist_iter"])
         print(f"[parbp gram] {label}: variant {st['xupdate_variant']}, {st['xupdate_launches']} stretches in Gram space, {st['persist_iter']} rebuilds of U")
     assert seen["default"][0] == 1 and seen["default"][1] >= fit.niter // 10 - 1
-    assert seen["direct"] == (0, 0, 0)
+    assert seen["direct"] == (0, 0, 0) and seen["no carry-over"][0] == 1
     assert seen["cap 64: halt + resume"][0] == 2 and seen["cap 64: halt + resume"][1] >= 1
     assert seen["cap 96: a rebuild, then halt + resume"][0] == 2 and seen["cap 96: a rebuild, then halt + resume"][2] >= 1
     # a small problem whose support comes and goes: different block counts, ragged
