@@ -1059,26 +1059,49 @@ static void tridiag_top(std::vector<double> d, std::vector<double> e, double* th
 // |beta_m s_m| is below 1e-14 of the value (the reference asks an R function that does not exist: PADMMBP.h:64-71).
 // Round 4: the Krylov basis stays on the DEVICE and so does the full re-orthogonalisation (two passes of c = V'w, w -= V c): round 3
 // kept the basis on the host and orthogonalised there in scalar loops -- ~150 steps per block at the C5 shape, 4.7e8 host flops per
-// block, 0.71 s of the solver's 1.09 s.  Per step the host now receives two numbers (alpha_j = v_j'A v_j, ||w||^2).
-__global__ void __launch_bounds__(256) sbp_lz_dots_kernel(const double* __restrict__ V, long long ldv, int n, const double* __restrict__ w, double* __restrict__ c) {
-    __shared__ double red[4];                                       // c[k] = V[:, k]'w, one workgroup per column k (k = gridDim.x - 1: w'w when V == nullptr there)
+// block, 0.71 s of the solver's 1.09 s.  Per step the host now receives two numbers (alpha_j = v_j'A v_j, ||w||^2), eight steps at a time.
+__global__ void __launch_bounds__(256) sbp_lz_dots_kernel(const double* __restrict__ V, long long ldv, int n, const double* __restrict__ w, double* __restrict__ c,
+                                                          double* __restrict__ keep) {
+    __shared__ double red[4];                                       // c[k] = V[:, k]'w, one workgroup per column k; keep: a second home for the LAST one
     const double* col = V + (size_t)blockIdx.x * ldv;
     double s = 0.0;
     for (int i = threadIdx.x; i < n; i += 256) s += col[i] * w[i];
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) c[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (threadIdx.x == 0) {
+        const double v = (red[0] + red[1]) + (red[2] + red[3]);
+        c[blockIdx.x] = v;
+        if (keep != nullptr && blockIdx.x == gridDim.x - 1) *keep = v;
+    }
 }
+// w[i] -= sum_k V[i, k] c[k]: a workgroup = 32 rows x 8 slices of k (k = slice, slice + 8, ... ascending; the slices added in order)
 __global__ void __launch_bounds__(256) sbp_lz_update_kernel(const double* __restrict__ V, long long ldv, int n, int m, const double* __restrict__ c, double* __restrict__ w) {
-    const int i = blockIdx.x * 256 + threadIdx.x;                   // w[i] -= sum_k V[i, k] c[k], k ascending
-    if (i >= n) return;
+    __shared__ double sh[8][32];
+    const int r = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + r;
     double acc = 0.0;
-    for (int k = 0; k < m; ++k) acc += V[(size_t)k * ldv + i] * c[k];
-    w[i] -= acc;
+    if (i < n) {
+        int k = sl;
+        for (; k + 24 < m; k += 32) {
+            const double v0 = V[(size_t)k * ldv + i], v1 = V[(size_t)(k + 8) * ldv + i], v2 = V[(size_t)(k + 16) * ldv + i], v3 = V[(size_t)(k + 24) * ldv + i];
+            acc += v0 * c[k]; acc += v1 * c[k + 8]; acc += v2 * c[k + 16]; acc += v3 * c[k + 24];
+        }
+        for (; k < m; k += 8) acc += V[(size_t)k * ldv + i] * c[k];
+    }
+    sh[sl][r] = acc;
+    __syncthreads();
+    if (sl == 0 && i < n) {
+        double t = sh[0][r];
+#pragma unroll
+        for (int q8 = 1; q8 < 8; ++q8) t += sh[q8][r];
+        w[i] -= t;
+    }
 }
-__global__ void __launch_bounds__(256) sbp_lz_scale_kernel(const double* __restrict__ w, double inv, int n, double* __restrict__ vnext) {
+// v_next = w / ||w||, the norm's square read from the device (the host sees it a few steps later)
+__global__ void __launch_bounds__(256) sbp_lz_scale_kernel(const double* __restrict__ w, const double* __restrict__ b2, int n, double* __restrict__ vnext) {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    const double inv = 1.0 / sqrt(*b2);
     if (i < n) vnext[i] = w[i] * inv;
 }
 
@@ -1098,50 +1121,60 @@ static double sbp_sprad(const double* Ab, long long lda, int n, int pb, hipStrea
     nrm = std::sqrt(nrm);
     for (int i = 0; i < n; ++i) v0[i] /= nrm;
     ADMM_HIP_CHECK(hipMemcpyAsync(V.get(), v0.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
-    const dim3 rows((n + 255) / 256);
+    const dim3 rows((n + 255) / 256), rows32((n + 31) / 32);
+    // The host needs two numbers per step (alpha_j, ||w||^2) but only to DECIDE, every fourth step: they are kept on the device and
+    // fetched eight steps at a time (a fetch is a stream synchronisation: ~60 us of idle device per step when done every step,
+    // a third of this function at the C5 shape); the steps are then judged one by one in order, so the value returned is the
+    // one a step-by-step loop returns -- up to seven steps run for nothing.
+    DevBuf<double> d_al(mmax), d_b2(mmax);
+    std::vector<double> hal(mmax), hb2(mmax);
     double theta = 0;
+    int seen = 0;
     for (int j = 0; j < mmax; ++j) {
         const double* vj = V.get() + (size_t)j * ldv;
         launch_gemv_t<double, 1, 4>(op.pl, Gm.get(), ldg, n, n, vj, nullptr, op.part.get(), nullptr, op.stride, nullptr, st);
         hipLaunchKernelGGL((reduce_partials_kernel<double>), rows, dim3(256), 0, st, op.part.get(), op.stride, op.pl.nseg, n, w.get(), (const int*)nullptr);
         // full re-orthogonalisation, twice; the first pass's coefficient of v_j is alpha_j = v_j'A v_j
-        hipLaunchKernelGGL(sbp_lz_dots_kernel, dim3(j + 1), dim3(256), 0, st, V.get(), ldv, n, w.get(), c.get());
-        double hc[2] = {0, 0};
-        ADMM_HIP_CHECK(hipMemcpyAsync(&hc[0], c.get() + j, sizeof(double), hipMemcpyDeviceToHost, st));
-        hipLaunchKernelGGL(sbp_lz_update_kernel, rows, dim3(256), 0, st, V.get(), ldv, n, j + 1, c.get(), w.get());
-        hipLaunchKernelGGL(sbp_lz_dots_kernel, dim3(j + 1), dim3(256), 0, st, V.get(), ldv, n, w.get(), c.get());
-        hipLaunchKernelGGL(sbp_lz_update_kernel, rows, dim3(256), 0, st, V.get(), ldv, n, j + 1, c.get(), w.get());
-        hipLaunchKernelGGL(sbp_lz_dots_kernel, dim3(1), dim3(256), 0, st, w.get(), ldv, n, w.get(), c.get() + mmax + 1);      // ||w||^2
-        ADMM_HIP_CHECK(hipMemcpyAsync(&hc[1], c.get() + mmax + 1, sizeof(double), hipMemcpyDeviceToHost, st));
+        hipLaunchKernelGGL(sbp_lz_dots_kernel, dim3(j + 1), dim3(256), 0, st, V.get(), ldv, n, w.get(), c.get(), d_al.get() + j);
+        hipLaunchKernelGGL(sbp_lz_update_kernel, rows32, dim3(256), 0, st, V.get(), ldv, n, j + 1, c.get(), w.get());
+        hipLaunchKernelGGL(sbp_lz_dots_kernel, dim3(j + 1), dim3(256), 0, st, V.get(), ldv, n, w.get(), c.get(), (double*)nullptr);
+        hipLaunchKernelGGL(sbp_lz_update_kernel, rows32, dim3(256), 0, st, V.get(), ldv, n, j + 1, c.get(), w.get());
+        hipLaunchKernelGGL(sbp_lz_dots_kernel, dim3(1), dim3(256), 0, st, w.get(), ldv, n, w.get(), d_b2.get() + j, (double*)nullptr);      // ||w||^2
+        if (j + 1 < mmax) hipLaunchKernelGGL(sbp_lz_scale_kernel, rows, dim3(256), 0, st, w.get(), d_b2.get() + j, n, V.get() + (size_t)(j + 1) * ldv);
+        if (!(j == 0 || (j + 1) % 8 == 0 || j + 1 == mmax)) continue;
+        ADMM_HIP_CHECK(hipMemcpyAsync(hal.data() + seen, d_al.get() + seen, (size_t)(j + 1 - seen) * sizeof(double), hipMemcpyDeviceToHost, st));
+        ADMM_HIP_CHECK(hipMemcpyAsync(hb2.data() + seen, d_b2.get() + seen, (size_t)(j + 1 - seen) * sizeof(double), hipMemcpyDeviceToHost, st));
         ADMM_HIP_CHECK(hipStreamSynchronize(st));
-        const double a = hc[0], b = std::sqrt(hc[1]);
-        al.push_back(a);
-        *nsteps = j + 1;
-        if (j + 1 >= 2 && ((j + 1) % 4 == 0 || j + 1 == mmax || b <= 1e-300)) {
-            double last = 0;
-            tridiag_top(al, be, &theta, &last);
-            if (std::fabs(b * last) <= 1e-14 * std::fabs(theta) || b <= 1e-300) return theta;
-        } else if (j == 0) {
-            theta = a;
-            if (b <= 1e-300 || n == 1) return theta;
-        }
-        if (j + 1 == mmax) {
-            // n steps span the whole space (exact up to rounding).  Fewer, without the 1e-14 residual bound met (clustered top
-            // eigenvalues; that bound is close to the rounding floor of the device Gram): rho and gamma_i = 2 rho + sprad_i hang on the
-            // value and an UNDER-estimate breaks the majorisation of the linearised x-update, so the safe side is returned -- an
-            // eigenvalue lies within |b last| of theta, theta + |b last| bounds it from above -- and only a value that is
-            // not even accurate to 1e-8 is an error.
-            if (mmax < n) {
+        for (int jj = seen; jj <= j; ++jj) {
+            const double a = hal[jj], b = std::sqrt(hb2[jj]);
+            al.push_back(a);
+            *nsteps = jj + 1;
+            if (jj + 1 >= 2 && ((jj + 1) % 4 == 0 || jj + 1 == mmax || b <= 1e-300)) {
                 double last = 0;
                 tridiag_top(al, be, &theta, &last);
-                const double r = std::fabs(b * last);
-                if (r <= 1e-8 * std::fabs(theta)) return theta + r;
-                throw Error(ADMM_ERR_EIGS, "admm_parbp: the spectral radius of a column block did not converge in 600 Lanczos steps");
+                if (std::fabs(b * last) <= 1e-14 * std::fabs(theta) || b <= 1e-300) return theta;
+            } else if (jj == 0) {
+                theta = a;
+                if (b <= 1e-300 || n == 1) return theta;
             }
-            break;
+            if (jj + 1 == mmax) {
+                // n steps span the whole space (exact up to rounding).  Fewer, without the 1e-14 residual bound met (clustered top
+                // eigenvalues; that bound is close to the rounding floor of the device Gram): rho and gamma_i = 2 rho + sprad_i hang on the
+                // value and an UNDER-estimate breaks the majorisation of the linearised x-update, so the safe side is returned -- an
+                // eigenvalue lies within |b last| of theta, theta + |b last| bounds it from above -- and only a value that is
+                // not even accurate to 1e-8 is an error.
+                if (mmax < n) {
+                    double last = 0;
+                    tridiag_top(al, be, &theta, &last);
+                    const double r = std::fabs(b * last);
+                    if (r <= 1e-8 * std::fabs(theta)) return theta + r;
+                    throw Error(ADMM_ERR_EIGS, "admm_parbp: the spectral radius of a column block did not converge in 600 Lanczos steps");
+                }
+                break;
+            }
+            be.push_back(b);
         }
-        be.push_back(b);
-        hipLaunchKernelGGL(sbp_lz_scale_kernel, rows, dim3(256), 0, st, w.get(), 1.0 / b, n, V.get() + (size_t)(j + 1) * ldv);
+        seen = j + 1;
     }
     ADMM_HIP_CHECK(hipGetLastError());
     return theta;                                                   // n steps: exact up to rounding

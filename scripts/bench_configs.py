@@ -98,7 +98,8 @@ if "c5parbp" in which:  # the same problem by the column-block sharing solver (a
         reg = (it + 9) // 10
         report(f"C5 admm_bp$parallel({nb}) n=5000 p=50000 fp64 (sharing ADMM)", fit, 8.0 * n * p * reg / max(it, 1),
                {"recovery_error_range": [float(err.min()), float(err.max())], "regular_iterations": reg, "nnz": int(np.count_nonzero(beta)),
-                "lanczos_steps": int(fit.stats["xupdate_samples"]), "rho": fit.stats["rho"]})
+                "lanczos_steps": int(fit.stats["xupdate_samples"]), "rho": fit.stats["rho"],
+                "active_set_variant": int(fit.stats["xupdate_variant"]), "gram_space_stretches": int(fit.stats["xupdate_launches"]), "rebuilds_of_U": int(fit.stats["persist_iter"])})
 if "dantzig" in which:  # Dantzig selector (admm_hip_dantzig, the reference's unbuilt TODO/ADMMDantzig.h), operator form: n = 50 000, p = 2000 fp64
     n, p = 50000, 2000
     xt, y, _ = gen(n, p, 2.0, 100)

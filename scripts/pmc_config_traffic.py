@@ -21,7 +21,7 @@ LOOP = {
     "c4": (["gemv_t_batch_kernel", "par_A_batch_resid_kernel", "gather_batch_kernel", "par_head_kernel", "par_pack_kernel", "par_z_kernel", "par_wb_"], ["padmm_lasso.hip", "gemv_kernels.h", "gather_kernels.h"]),
     "c5lad": (["gemv_t_kernel<double", "reduce_partials_kernel<double", "dense_head_kernel", "dense_tail_kernel"], ["fadmm_dense.hip", "gemv_kernels.h"]),
     "c5bp": (["gemv_t_kernel<double", "bp_gather_kernel", "dense_head_kernel", "dense_tail_kernel"], ["fadmm_dense.hip", "gemv_kernels.h", "gather_kernels.h"]),
-    "c5parbp": (["sbp_xreg_kernel", "sbp_list_kernel", "sbp_xact_kernel", "sbp_tail_kernel"], ["sharing_bp.hip"]),
+    "c5parbp": (["sbp_xreg_kernel", "sbp_list_kernel", "sbp_xact_kernel", "sbp_tail_kernel", "sbp_gs_", "gather_batch_kernel"], ["sharing_bp.hip", "gather_kernels.h"]),
     "dantzig": (["dz_head_kernel", "dz_mid_kernel", "dz_tail_kernel", "gemv_t_kernel<double", "reduce_partials_kernel<double"], ["dantzig.hip", "gemv_kernels.h"]),
 }
 
