@@ -34,6 +34,8 @@
 #include "gather_kernels.h"
 
 #include <cmath>
+#include <exception>
+#include <thread>
 
 namespace admm {
 
@@ -1008,6 +1010,13 @@ sbp_gs_tail_kernel(SbpParams q, int par, int nth) {
 }
 
 // ------------------------------------------------------------------------------------------------ setup
+static int env_int(const char* name, int dflt) {
+    const char* e = std::getenv(name);
+    const int v = e ? std::atoi(e) : 0;
+    return v > 0 ? v : dflt;
+}
+
+
 // Largest eigenvalue of a symmetric tridiagonal matrix (diagonal a[0..m), off-diagonal e[0..m-1)) and the LAST component of
 // its unit eigenvector: implicit QL with the rotations applied to one row only.
 static void tridiag_top(std::vector<double> d, std::vector<double> e, double* theta, double* last) {
@@ -1060,28 +1069,52 @@ static void tridiag_top(std::vector<double> d, std::vector<double> e, double* th
 // Round 4: the Krylov basis stays on the DEVICE and so does the full re-orthogonalisation (two passes of c = V'w, w -= V c): round 3
 // kept the basis on the host and orthogonalised there in scalar loops -- ~150 steps per block at the C5 shape, 4.7e8 host flops per
 // block, 0.71 s of the solver's 1.09 s.  Per step the host now receives two numbers (alpha_j = v_j'A v_j, ||w||^2), eight steps at a time.
-__global__ void __launch_bounds__(256) sbp_lz_dots_kernel(const double* __restrict__ V, long long ldv, int n, const double* __restrict__ w, double* __restrict__ c,
-                                                          double* __restrict__ keep) {
-    __shared__ double red[4];                                       // c[k] = V[:, k]'w, one workgroup per column k; keep: a second home for the LAST one
-    const double* col = V + (size_t)blockIdx.x * ldv;
+// All kernels below take the column block from blockIdx.y: the Lanczos runs of several blocks advance in lockstep (same n, same
+// step), one launch per operation for all of them -- at the C5 shape 8 blocks x ~155 steps x 8 small launches were 0.12 s of
+// launches that each kept the device busy for 7 us.
+struct LzBatch {
+    double* V; long long ldv, vblk;                                 // basis of block b: V + b * vblk, columns ldv apart
+    double* w; double* vcur; long long wblk;                        // w and the current basis vector (the mat-vec's fixed input) of block b: + b * wblk
+    double* c; long long cblk;                                      // coefficients of block b: c + b * cblk
+    double* al; double* b2; long long sblk;                         // per-step alpha and ||w||^2 of block b: + b * sblk
+    const double* part; long long pstride, pblk; int nseg;          // the mat-vec's partial rows of block b: part + b * pblk
+    int n;
+};
+__global__ void __launch_bounds__(256) sbp_lz_reduce_kernel(LzBatch q) {
+    const int i = blockIdx.x * 256 + threadIdx.x;                   // w = the mat-vec's partial rows summed in order
+    if (i >= q.n) return;
+    const double* p = q.part + (size_t)blockIdx.y * q.pblk + i;
+    double t = 0.0;
+    for (int k = 0; k < q.nseg; ++k) t += p[(size_t)k * q.pstride];
+    q.w[(size_t)blockIdx.y * q.wblk + i] = t;
+}
+// c[k] = V[:, k]'w, one workgroup per column k (`self`: w'w into b2[step] instead); the LAST coefficient of the first pass is alpha
+__global__ void __launch_bounds__(256) sbp_lz_dots_kernel(LzBatch q, int step, int self, int keep) {
+    __shared__ double red[4];
+    const double* w = q.w + (size_t)blockIdx.y * q.wblk;
+    const double* col = self ? w : q.V + (size_t)blockIdx.y * q.vblk + (size_t)blockIdx.x * q.ldv;
     double s = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) s += col[i] * w[i];
+    for (int i = threadIdx.x; i < q.n; i += 256) s += col[i] * w[i];
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
         const double v = (red[0] + red[1]) + (red[2] + red[3]);
-        c[blockIdx.x] = v;
-        if (keep != nullptr && blockIdx.x == gridDim.x - 1) *keep = v;
+        if (self) { q.b2[(size_t)blockIdx.y * q.sblk + step] = v; return; }
+        q.c[(size_t)blockIdx.y * q.cblk + blockIdx.x] = v;
+        if (keep && blockIdx.x == gridDim.x - 1) q.al[(size_t)blockIdx.y * q.sblk + step] = v;
     }
 }
 // w[i] -= sum_k V[i, k] c[k]: a workgroup = 32 rows x 8 slices of k (k = slice, slice + 8, ... ascending; the slices added in order)
-__global__ void __launch_bounds__(256) sbp_lz_update_kernel(const double* __restrict__ V, long long ldv, int n, int m, const double* __restrict__ c, double* __restrict__ w) {
+__global__ void __launch_bounds__(256) sbp_lz_update_kernel(LzBatch q, int m) {
     __shared__ double sh[8][32];
     const int r = threadIdx.x & 31, sl = threadIdx.x >> 5;
     const int i = blockIdx.x * 32 + r;
+    const double* V = q.V + (size_t)blockIdx.y * q.vblk;
+    const double* c = q.c + (size_t)blockIdx.y * q.cblk;
+    const long long ldv = q.ldv;
     double acc = 0.0;
-    if (i < n) {
+    if (i < q.n) {
         int k = sl;
         for (; k + 24 < m; k += 32) {
             const double v0 = V[(size_t)k * ldv + i], v1 = V[(size_t)(k + 8) * ldv + i], v2 = V[(size_t)(k + 16) * ldv + i], v3 = V[(size_t)(k + 24) * ldv + i];
@@ -1091,71 +1124,96 @@ __global__ void __launch_bounds__(256) sbp_lz_update_kernel(const double* __rest
     }
     sh[sl][r] = acc;
     __syncthreads();
-    if (sl == 0 && i < n) {
+    if (sl == 0 && i < q.n) {
         double t = sh[0][r];
 #pragma unroll
         for (int q8 = 1; q8 < 8; ++q8) t += sh[q8][r];
-        w[i] -= t;
+        q.w[(size_t)blockIdx.y * q.wblk + i] -= t;
     }
 }
-// v_next = w / ||w||, the norm's square read from the device (the host sees it a few steps later)
-__global__ void __launch_bounds__(256) sbp_lz_scale_kernel(const double* __restrict__ w, const double* __restrict__ b2, int n, double* __restrict__ vnext) {
+// v_next = w / ||w||, the norm's square read from the device (the host sees it a few steps later); also the mat-vec's input
+__global__ void __launch_bounds__(256) sbp_lz_scale_kernel(LzBatch q, int step) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    const double inv = 1.0 / sqrt(*b2);
-    if (i < n) vnext[i] = w[i] * inv;
+    const double inv = 1.0 / sqrt(q.b2[(size_t)blockIdx.y * q.sblk + step]);
+    if (i >= q.n) return;
+    const double v = q.w[(size_t)blockIdx.y * q.wblk + i] * inv;
+    q.V[(size_t)blockIdx.y * q.vblk + (size_t)(step + 1) * q.ldv + i] = v;
+    q.vcur[(size_t)blockIdx.y * q.wblk + i] = v;
 }
 
-static double sbp_sprad(const double* Ab, long long lda, int n, int pb, hipStream_t st, int* nsteps) {
+// The spectral radii of the column blocks [b0, b0 + B) (local indices): their Gram matrices, then B Lanczos runs in lockstep.
+static void sbp_sprad_batch(const double* A, long long lda, int n, const std::vector<int>& c0, int b0, int B, hipStream_t st, double* out, int* nsteps) {
     const long long ldg = round_up(n, 32);
-    DevBuf<double> Gm((size_t)ldg * ldg);
+    DevBuf<double> Gm((size_t)ldg * ldg * B);
     Gm.zero(st);
-    gram_full<double>(Ab, lda, n, pb, false, Gm.get(), ldg, st);
-    SymMatVec<double> op(Gm.get(), ldg, n, st);                     // (its plan and partial buffer; the products below stay on the device)
+    for (int b = 0; b < B; ++b)
+        gram_full<double>(A + (size_t)c0[b0 + b] * lda, lda, n, c0[b0 + b + 1] - c0[b0 + b], false, Gm.get() + (size_t)b * ldg * ldg, ldg, st);
+    GemvTPlan pl = plan_gemv_t<double>(n, n, 1, 4);
+    pl.nt = (size_t)B * (size_t)ldg * (size_t)ldg * sizeof(double) > kGemvNtBytes;      // what the launch streams, not one block of it
+    const long long pstride = ldg;
     const int mmax = std::min(n, 600);
     const long long ldv = ldg;
-    DevBuf<double> V((size_t)ldv * (mmax + 1)), w(ldg), c(mmax + 2);
-    V.zero(st); w.zero(st);
-    std::vector<double> al, be, v0(n);
+    DevBuf<double> V((size_t)ldv * (mmax + 1) * B), w((size_t)ldg * B), vcur((size_t)ldg * B), c((size_t)(mmax + 2) * B), part((size_t)pl.nseg * pstride * B);
+    DevBuf<double> d_al((size_t)mmax * B), d_b2((size_t)mmax * B);
+    DevBuf<GemvTArgs<double>> d_args(B);
+    V.zero(st); w.zero(st); vcur.zero(st); part.zero(st);
+    std::vector<double> v0(n);
     double nrm = 0;
     for (int i = 0; i < n; ++i) { v0[i] = 1.0 + 0.5 * std::sin(0.7 * (i + 1)); nrm += v0[i] * v0[i]; }
     nrm = std::sqrt(nrm);
     for (int i = 0; i < n; ++i) v0[i] /= nrm;
-    ADMM_HIP_CHECK(hipMemcpyAsync(V.get(), v0.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
-    const dim3 rows((n + 255) / 256), rows32((n + 31) / 32);
-    // The host needs two numbers per step (alpha_j, ||w||^2) but only to DECIDE, every fourth step: they are kept on the device and
-    // fetched eight steps at a time (a fetch is a stream synchronisation: ~60 us of idle device per step when done every step,
-    // a third of this function at the C5 shape); the steps are then judged one by one in order, so the value returned is the
-    // one a step-by-step loop returns -- up to seven steps run for nothing.
-    DevBuf<double> d_al(mmax), d_b2(mmax);
-    std::vector<double> hal(mmax), hb2(mmax);
-    double theta = 0;
-    int seen = 0;
-    for (int j = 0; j < mmax; ++j) {
-        const double* vj = V.get() + (size_t)j * ldv;
-        launch_gemv_t<double, 1, 4>(op.pl, Gm.get(), ldg, n, n, vj, nullptr, op.part.get(), nullptr, op.stride, nullptr, st);
-        hipLaunchKernelGGL((reduce_partials_kernel<double>), rows, dim3(256), 0, st, op.part.get(), op.stride, op.pl.nseg, n, w.get(), (const int*)nullptr);
-        // full re-orthogonalisation, twice; the first pass's coefficient of v_j is alpha_j = v_j'A v_j
-        hipLaunchKernelGGL(sbp_lz_dots_kernel, dim3(j + 1), dim3(256), 0, st, V.get(), ldv, n, w.get(), c.get(), d_al.get() + j);
-        hipLaunchKernelGGL(sbp_lz_update_kernel, rows32, dim3(256), 0, st, V.get(), ldv, n, j + 1, c.get(), w.get());
-        hipLaunchKernelGGL(sbp_lz_dots_kernel, dim3(j + 1), dim3(256), 0, st, V.get(), ldv, n, w.get(), c.get(), (double*)nullptr);
-        hipLaunchKernelGGL(sbp_lz_update_kernel, rows32, dim3(256), 0, st, V.get(), ldv, n, j + 1, c.get(), w.get());
-        hipLaunchKernelGGL(sbp_lz_dots_kernel, dim3(1), dim3(256), 0, st, w.get(), ldv, n, w.get(), d_b2.get() + j, (double*)nullptr);      // ||w||^2
-        if (j + 1 < mmax) hipLaunchKernelGGL(sbp_lz_scale_kernel, rows, dim3(256), 0, st, w.get(), d_b2.get() + j, n, V.get() + (size_t)(j + 1) * ldv);
-        if (!(j == 0 || (j + 1) % 8 == 0 || j + 1 == mmax)) continue;
-        ADMM_HIP_CHECK(hipMemcpyAsync(hal.data() + seen, d_al.get() + seen, (size_t)(j + 1 - seen) * sizeof(double), hipMemcpyDeviceToHost, st));
-        ADMM_HIP_CHECK(hipMemcpyAsync(hb2.data() + seen, d_b2.get() + seen, (size_t)(j + 1 - seen) * sizeof(double), hipMemcpyDeviceToHost, st));
-        ADMM_HIP_CHECK(hipStreamSynchronize(st));
-        for (int jj = seen; jj <= j; ++jj) {
-            const double a = hal[jj], b = std::sqrt(hb2[jj]);
-            al.push_back(a);
-            *nsteps = jj + 1;
-            if (jj + 1 >= 2 && ((jj + 1) % 4 == 0 || jj + 1 == mmax || b <= 1e-300)) {
+    std::vector<GemvTArgs<double>> ha(B);
+    for (int b = 0; b < B; ++b) {
+        ADMM_HIP_CHECK(hipMemcpyAsync(V.get() + (size_t)b * ldv * (mmax + 1), v0.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+        ADMM_HIP_CHECK(hipMemcpyAsync(vcur.get() + (size_t)b * ldg, v0.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+        GemvTArgs<double>& a = ha[b];
+        a.A = Gm.get() + (size_t)b * ldg * ldg; a.lda = ldg; a.m = n; a.k = n;
+        a.v[0] = vcur.get() + (size_t)b * ldg; a.v[1] = nullptr; a.vparts = 1; a.vstride = 0;
+        a.out[0] = part.get() + (size_t)b * pl.nseg * pstride; a.out[1] = nullptr; a.out_stride = pstride;
+        a.seg_len = pl.seg_len; a.seg_alloc = pl.seg_alloc; a.nseg = pl.nseg; a.groups_per_wg = pl.groups_per_wg; a.skip = nullptr;
+    }
+    ADMM_HIP_CHECK(hipMemcpyAsync(d_args.get(), ha.data(), (size_t)B * sizeof(GemvTArgs<double>), hipMemcpyHostToDevice, st));
+    LzBatch q{};
+    q.V = V.get(); q.ldv = ldv; q.vblk = ldv * (mmax + 1);
+    q.w = w.get(); q.vcur = vcur.get(); q.wblk = ldg;
+    q.c = c.get(); q.cblk = mmax + 2;
+    q.al = d_al.get(); q.b2 = d_b2.get(); q.sblk = mmax;
+    q.part = part.get(); q.pstride = pstride; q.pblk = (long long)pl.nseg * pstride; q.nseg = pl.nseg;
+    q.n = n;
+    const int rows = (n + 255) / 256, rows32 = (n + 31) / 32;
+    // The host needs two numbers per step and block (alpha_j, ||w||^2) but only to DECIDE, every fourth step: they are kept on the
+    // device and fetched eight steps at a time (a fetch is a stream synchronisation); the steps are then judged one by one in
+    // order, so the value returned is the one a step-by-step loop returns -- up to seven steps run for nothing, and a block that
+    // is finished keeps stepping (its numbers are not looked at again) until the last one is.
+    // The host needs two numbers per step and block (alpha_j, ||w||^2) but only to DECIDE, every fourth step: they are kept on the
+    // device and fetched a group of eight steps at a time into pinned memory; the steps are then judged one by one in order, so
+    // the value returned is the one a step-by-step loop returns.  Judging is host work (an implicit-QL sweep of the tridiagonal
+    // matrix per block, 55 ms in all at the C5 shape -- as long as the device needs for the steps): the NEXT group is enqueued
+    // before a group is judged, and the blocks are judged by a thread each.  Up to two groups run for nothing, and a block that is
+    // finished keeps stepping (its numbers are not looked at again) until the last one is.
+    struct Pinned {
+        double* p = nullptr;
+        explicit Pinned(size_t n_) { ADMM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&p), n_ * sizeof(double), hipHostMallocDefault)); }
+        ~Pinned() { if (p) (void)hipHostFree(p); }
+        Pinned(const Pinned&) = delete;
+        Pinned& operator=(const Pinned&) = delete;
+    } hal((size_t)mmax * B), hb2((size_t)mmax * B);
+    std::vector<std::vector<double>> al(B), be(B);
+    std::vector<char> fin(B, 0);
+    std::vector<double> theta(B, 0.0);
+    // judge steps [s0, s1) of block b; returns true when the block is finished (out[b] set).  Throws like the serial loop.
+    auto judge = [&](int b, int s0, int s1) -> bool {
+        for (int jj = s0; jj < s1; ++jj) {
+            const double a = hal.p[(size_t)b * mmax + jj], bb = std::sqrt(hb2.p[(size_t)b * mmax + jj]);
+            al[b].push_back(a);
+            nsteps[b] = jj + 1;
+            if (jj + 1 >= 2 && ((jj + 1) % 4 == 0 || jj + 1 == mmax || bb <= 1e-300)) {
                 double last = 0;
-                tridiag_top(al, be, &theta, &last);
-                if (std::fabs(b * last) <= 1e-14 * std::fabs(theta) || b <= 1e-300) return theta;
+                tridiag_top(al[b], be[b], &theta[b], &last);
+                if (std::fabs(bb * last) <= 1e-14 * std::fabs(theta[b]) || bb <= 1e-300) { out[b] = theta[b]; return true; }
             } else if (jj == 0) {
-                theta = a;
-                if (b <= 1e-300 || n == 1) return theta;
+                theta[b] = a;
+                if (bb <= 1e-300 || n == 1) { out[b] = theta[b]; return true; }
             }
             if (jj + 1 == mmax) {
                 // n steps span the whole space (exact up to rounding).  Fewer, without the 1e-14 residual bound met (clustered top
@@ -1165,25 +1223,65 @@ static double sbp_sprad(const double* Ab, long long lda, int n, int pb, hipStrea
                 // not even accurate to 1e-8 is an error.
                 if (mmax < n) {
                     double last = 0;
-                    tridiag_top(al, be, &theta, &last);
-                    const double r = std::fabs(b * last);
-                    if (r <= 1e-8 * std::fabs(theta)) return theta + r;
+                    tridiag_top(al[b], be[b], &theta[b], &last);
+                    const double r = std::fabs(bb * last);
+                    if (r <= 1e-8 * std::fabs(theta[b])) { out[b] = theta[b] + r; return true; }
                     throw Error(ADMM_ERR_EIGS, "admm_parbp: the spectral radius of a column block did not converge in 600 Lanczos steps");
                 }
-                break;
+                out[b] = theta[b];                                  // n steps: exact up to rounding
+                return true;
             }
-            be.push_back(b);
+            be[b].push_back(bb);
         }
-        seen = j + 1;
+        return false;
+    };
+    // groups of steps between two fetches: [0, 1), [1, 8), [8, 16), ...
+    std::vector<int> gend;
+    for (int j = 0; j < mmax; ++j) if (j == 0 || (j + 1) % 8 == 0 || j + 1 == mmax) gend.push_back(j + 1);
+    std::vector<Event> ev(gend.size());
+    auto enqueue_group = [&](size_t g) {
+        const int s0 = g == 0 ? 0 : gend[g - 1], s1 = gend[g];
+        for (int j = s0; j < s1; ++j) {
+            launch_gemv_t_batch<double>(d_args.get(), B, pl.grid, pl.lds_bytes, pl.nt, st);
+            hipLaunchKernelGGL(sbp_lz_reduce_kernel, dim3(rows, B), dim3(256), 0, st, q);
+            // full re-orthogonalisation, twice; the first pass's coefficient of v_j is alpha_j = v_j'A v_j
+            hipLaunchKernelGGL(sbp_lz_dots_kernel, dim3(j + 1, B), dim3(256), 0, st, q, j, 0, 1);
+            hipLaunchKernelGGL(sbp_lz_update_kernel, dim3(rows32, B), dim3(256), 0, st, q, j + 1);
+            hipLaunchKernelGGL(sbp_lz_dots_kernel, dim3(j + 1, B), dim3(256), 0, st, q, j, 0, 0);
+            hipLaunchKernelGGL(sbp_lz_update_kernel, dim3(rows32, B), dim3(256), 0, st, q, j + 1);
+            hipLaunchKernelGGL(sbp_lz_dots_kernel, dim3(1, B), dim3(256), 0, st, q, j, 1, 0);                                   // ||w||^2
+            if (j + 1 < mmax) hipLaunchKernelGGL(sbp_lz_scale_kernel, dim3(rows, B), dim3(256), 0, st, q, j);
+        }
+        const size_t wbytes = (size_t)(s1 - s0) * sizeof(double), pitch = (size_t)mmax * sizeof(double);
+        ADMM_HIP_CHECK(hipMemcpy2DAsync(hal.p + s0, pitch, d_al.get() + s0, pitch, wbytes, B, hipMemcpyDeviceToHost, st));
+        ADMM_HIP_CHECK(hipMemcpy2DAsync(hb2.p + s0, pitch, d_b2.get() + s0, pitch, wbytes, B, hipMemcpyDeviceToHost, st));
+        ADMM_HIP_CHECK(hipEventRecord(ev[g].e, st));
+    };
+    int left = B;
+    enqueue_group(0);
+    for (size_t g = 0; g < gend.size() && left > 0; ++g) {
+        if (g + 1 < gend.size()) enqueue_group(g + 1);
+        ADMM_HIP_CHECK(hipEventSynchronize(ev[g].e));
+        const int s0 = g == 0 ? 0 : gend[g - 1], s1 = gend[g];
+        std::vector<std::exception_ptr> err(B);
+        std::vector<char> now(B, 0);
+        auto run = [&](int b) { try { now[b] = judge(b, s0, s1) ? 1 : 0; } catch (...) { err[b] = std::current_exception(); } };
+        std::vector<std::thread> th;
+        int first = -1;
+        for (int b = 0; b < B; ++b) {
+            if (fin[b]) continue;
+            if (first < 0) { first = b; continue; }                 // (one block on this thread)
+            th.emplace_back(run, b);
+        }
+        if (first >= 0) run(first);
+        for (auto& t : th) t.join();
+        for (int b = 0; b < B; ++b) {
+            if (err[b]) { (void)hipStreamSynchronize(st); std::rethrow_exception(err[b]); }
+            if (now[b]) { fin[b] = 1; --left; }
+        }
     }
+    ADMM_HIP_CHECK(hipStreamSynchronize(st));                        // (a group may still be running: its buffers go out of scope here)
     ADMM_HIP_CHECK(hipGetLastError());
-    return theta;                                                   // n steps: exact up to rounding
-}
-
-static int env_int(const char* name, int dflt) {
-    const char* e = std::getenv(name);
-    const int v = e ? std::atoi(e) : 0;
-    return v > 0 ? v : dflt;
 }
 
 static int sbp_batch() {
@@ -1226,10 +1324,17 @@ void solve_parbp(const DeviceData<double>& d, const admm_opts& opts, int nblocks
     double t0 = now_s();
     std::vector<double> sprad(N, 0.0);
     int lsteps = 0;
-    for (int b = 0; b < NL; ++b) {
-        int ns = 0;
-        sprad[b_first + b] = sbp_sprad(d.X.get() + (size_t)c0[b] * d.ldx, d.ldx, n, c0[b + 1] - c0[b], st, &ns);
-        lsteps = std::max(lsteps, ns);
+    {
+        // as many blocks in lockstep as ~3 GB of Gram matrices and Lanczos bases allow (A/B: ADMM_HIP_SBP_LZ_BATCH)
+        const double per = (double)round_up(n, 32) * ((double)round_up(n, 32) + (double)std::min(n, 600) + 8.0) * 8.0;
+        int Bmax = std::max(1, std::min(NL, (int)(3.0e9 / per)));
+        Bmax = std::min(Bmax, env_int("ADMM_HIP_SBP_LZ_BATCH", Bmax));
+        for (int b = 0; b < NL; b += Bmax) {
+            const int B = std::min(Bmax, NL - b);
+            std::vector<int> ns(B, 0);
+            sbp_sprad_batch(d.X.get(), d.ldx, n, c0, b, B, st, sprad.data() + b_first + b, ns.data());
+            for (int k = 0; k < B; ++k) lsteps = std::max(lsteps, ns[k]);
+        }
     }
     if (dist) {
         DevBuf<double> t(N);
