@@ -229,7 +229,7 @@ def test_medium_consensus_problems_match_the_oracle():
     nw = nc = 0
     for seed in (3, 4, 5, 6):
         for cs in medium_cases(12, seed):
-            if cs["kind"] != "par" or nw + nc >= 7 or (cs["n"] // cs["K"] >= cs["p"] and nc >= 2):      # two Cholesky-branch cases suffice here (tests/test_gpu_parlasso.py has more)
+            if cs["kind"] != "par" or nw + nc >= 6 or (cs["n"] // cs["K"] >= cs["p"] and nc >= 2):      # two Cholesky-branch cases suffice here (tests/test_gpu_parlasso.py has more)
                 continue
             _, wide = _medium_consensus(cs)
             nw += int(wide); nc += int(not wide)
