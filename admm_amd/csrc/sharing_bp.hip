@@ -942,7 +942,7 @@ sbp_gs_kernel(SbpParams q, int par, int idx, int first, int nth) {
             s.xs[o] = xv; s.hr[o] = hrn; s.gy[o] = e_gyo + q.rho * hrn;
             const double sxn = (REG ? 0.0 : e_sx) + xv;                // REG: the stretch's sum starts with the regular iteration's x
             s.sx[arow] = sxn;
-            q.x[e_col] = xv;
+            if (!REG) q.x[e_col] = xv;                              // (REG: that is where xv was read from, by every workgroup)
             s.sxd[e_col] = sxn - (double)nth * xv;
         }
     }

@@ -4,7 +4,9 @@ decision, on randomised problems -- the drawing of tests/test_gpu_fuzz_new.py wi
 random capacity of the Gram matrix (ADMM_HIP_SBP_GRAM_CAP) so that halts (support larger than the matrix), re-entries and
 rebuilds of the column set are exercised as well as the plain path.  Prints one line per seed and a summary (markdown).
 
-    python tests/tools/parbp_gram_soak.py [first_seed [n_seeds [cases_per_seed]]]
+    python tests/tools/parbp_gram_soak.py [first_seed [n_seeds [cases_per_seed [shape_factor]]]]
+
+shape_factor f > 1 draws n from 8f .. 400f (supports of several hundred columns: U near the default capacity of 1024).
 """
 import os
 import sys
@@ -24,13 +26,14 @@ def main():
     s0 = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     ns = int(sys.argv[2]) if len(sys.argv) > 2 else 12
     nc = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+    sf = int(sys.argv[4]) if len(sys.argv) > 4 else 1
     tot = dict(cases=0, fail=0, trace=0.0, beta=0.0, v0=0, v1=0, v2=0, stretches=0, rebuilds=0, iters=0)
     fails = []
     for seed in range(s0, s0 + ns):
         rng = np.random.default_rng(seed)
         worst = 0.0
         for c in range(nc):
-            n = int(rng.integers(8, 400))
+            n = int(rng.integers(8 * sf, 400 * sf))
             p = int(rng.integers(n + 3, 5 * n + 8))
             N = int(rng.integers(2, 9))
             scale = float(rng.choice([0.05, 1.0, 1.0, 30.0]))
@@ -41,7 +44,7 @@ def main():
             eps = float(rng.choice([1e-3, 1e-4, 1e-6]))
             maxit = int(rng.choice([60, 400, 3000]))
             ratio = float(rng.choice([0.5, 1.0, 1.0, 3.0]))
-            cap = int(rng.choice([8, 16, 32, 64, 128, 1024, 1024]))
+            cap = int(rng.choice([8, 16, 32, 64, 128, 1024, 1024])) if sf == 1 else int(rng.choice([256, 512, 1024, 1024]))
             os.environ["ADMM_HIP_SBP_GRAM_CAP"] = str(cap)
             fit = admm_amd.admm_bp(A, b).parallel(N).opts(maxit=maxit, eps_abs=eps, eps_rel=eps, rho=ratio).fit(trace=True)
             d = {"trace": []}
