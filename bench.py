@@ -559,27 +559,6 @@ def config_child(a, name, out_path):
         json.dump(res, f)
 
 
-def _blas_threads():
-    try:
-        from threadpoolctl import threadpool_info
-        return max([int(i.get("num_threads", 1)) for i in threadpool_info() if i.get("user_api") == "blas"] or [1])
-    except Exception:                                       # noqa: BLE001
-        return 1
-
-
-def _timed_oracle(make_runner, budget_s):
-    """make_runner() -> step() that runs a further chunk of the oracle's loop and returns the iterations it made (0: finished).
-    Runs chunks until the budget is used; returns (iterations, seconds)."""
-    step = make_runner()
-    it, t0 = 0, time.time()
-    while True:
-        k = step()
-        it += k
-        if k == 0 or time.time() - t0 >= budget_s:
-            break
-    return it, time.time() - t0
-
-
 def cpu_config_baseline(name, budget_s, seed):
     """cpu_baseline of one of the other configs (round 5: COMPILED): the C restatement of the reference's loop for that solver
     (oracle/c/admm_loops_cpu.c through oracle/cloops.py -- the checker of tests/test_oracle_cloops.py, here only TIMED) on the SAME
@@ -681,7 +660,28 @@ def cpu_config_baseline(name, budget_s, seed):
             r = cloops.dense_loop(1, B, None, c0, 1.0, 1e-4, 1e-4, 10000, nthreads=nt, budget_s=budget)
             return min(int(r[4]), 10000), r[5]
     elif name == "c5parbp":
-        return _cpu_parbp_numpy(budget_s, seed)
+        n, p, N = 5000, 50000, 8
+        A = randn((p, n), torch.float64).T                         # column-major n x p without a 2 GB copy
+        bt = np.zeros(p); bt[np.random.default_rng(seed).choice(p, 500, replace=False)] = np.random.default_rng(seed + 1).uniform(size=500)
+        bvec = A @ bt
+        chunk = p // N
+        sprad = []                                                  # the class's exact spectral norms (8 SVDs) replaced by 40 power iterations: setup only
+        for i in range(N):
+            Ai = A[:, i * chunk:(p if i == N - 1 else (i + 1) * chunk)]
+            v = np.ones(Ai.shape[1]) / np.sqrt(Ai.shape[1])
+            nv = 1.0
+            for _ in range(40):
+                w = Ai.T @ (Ai @ v)
+                nv = float(np.linalg.norm(w))
+                v = w / nv
+            sprad.append(1.02 * nv)
+        rho = 1.0 / float(np.mean(sprad))
+        what = (f"the sharing-ADMM loop of TODO/PADMMBP.h as oracle/solvers.py SharingBP restates it (every column on every 10th iteration, the current "
+                f"non-zeros otherwise), {N} column blocks, on n={n} p={p}")
+
+        def run(nt, budget):
+            _, niter, secs = cloops.sharing_loop(A, bvec, N, sprad, rho, 1e-4, 1e-4, 10000, nthreads=nt, budget_s=budget)
+            return min(int(niter), 10000), secs
     else:
         return None
     t_setup = time.time() - t_setup0
@@ -703,51 +703,6 @@ def cpu_config_baseline(name, budget_s, seed):
             "best_effort": {"value": itn / sn if sn > 0 else None, "unit": "iterations/s", "cores": int(threads),
                             "sample": f"the same compiled loop with every product spread over {threads} OpenMP threads (OMP_PROC_BIND=spread, OMP_PLACES=cores): "
                                       f"{itn:g} (scaled) iterations in {sn:.1f} s; best of [{tried_note}]"}}
-
-
-def _cpu_parbp_numpy(budget_s, seed):
-    """admm_parbp has no compiled restatement (the reference never built it: src/TODO/PADMMBP.h): its cpu_baseline stays the NumPy
-    oracle (oracle/solvers.py SharingBP), BLAS on one thread and on all of them."""
-    import numpy as np
-    import torch
-    from threadpoolctl import threadpool_limits
-    from oracle.solvers import SharingBP
-    tg = torch.Generator(); tg.manual_seed(seed + 77)
-    t_setup0 = time.time()
-    n, p, N = 5000, 50000, 8
-    A = (torch.randn((n, p), generator=tg, dtype=torch.float64)).numpy()
-    bt = np.zeros(p); bt[np.random.default_rng(seed).choice(p, 500, replace=False)] = np.random.default_rng(seed + 1).uniform(size=500)
-    s = SharingBP.__new__(SharingBP)                     # the constructor's exact spectral norms (8 SVDs) replaced by 40 power iterations: setup only
-    s.n, s.p, s.N = n, p, N
-    chunk = p // N
-    s.off = [i * chunk for i in range(N)] + [p]
-    s.A = [A[:, s.off[i]:s.off[i + 1]] for i in range(N)]
-    s.b = A @ bt
-    s.eps_abs = s.eps_rel = 1e-4
-    s.trace = None
-    s.sprad = []
-    for Ai in s.A:
-        v = np.ones(Ai.shape[1]) / np.sqrt(Ai.shape[1])
-        for _ in range(40):
-            w = Ai.T @ (Ai @ v)
-            nv = float(np.linalg.norm(w))
-            v = w / nv
-        s.sprad.append(1.02 * nv)
-    what = f"the sharing-ADMM loop of TODO/PADMMBP.h restated (oracle/solvers.py SharingBP), {N} column blocks one after the other, on n={n} p={p}"
-
-    def make():
-        s.init(1.0)
-        return lambda: min(int(s.solve(10)), 10)
-    t_setup = time.time() - t_setup0
-    threads = _blas_threads()
-    with threadpool_limits(limits=1, user_api="blas"):
-        it1, s1 = _timed_oracle(make, budget_s)
-    itn, sn = _timed_oracle(make, budget_s)
-    return {"value": it1 / s1 if s1 > 0 else None, "unit": "iterations/s", "cores": 1, "kind": "port",
-            "sample": f"NumPy restatement of {what}; BLAS limited to ONE thread: {it1:g} iterations in {s1:.1f} s; setup {t_setup:.1f} s not included",
-            "best_effort": {"value": itn / sn if sn > 0 else None, "unit": "iterations/s", "cores": int(threads),
-                            "sample": f"the same loop with OpenBLAS on {threads} threads inside every product (reported as measured, not a tuned CPU build): "
-                                      f"{itn:g} iterations in {sn:.1f} s"}}
 
 
 def run_side_measurement(a, rank, world, kind, backend, seconds, port_offset):

@@ -11,6 +11,8 @@
  *   FADMMBase::solve / update_rho         src/FADMMBase.h:100-133,185-265
  *   ADMMLAD                               src/ADMMLAD.h:62-107,152-169      (general branch X (X'X)^-1 X')
  *   ADMMBP                                src/ADMMBP.h:48-93,138-153
+ *   column-block ("sharing") basis pursuit src/TODO/PADMMBP.h:19-61,137-140 (worker x-update, z-bar) on the loop shape of
+ *                                         src/PADMMBase.h:118-142,174-237 -- as restated in oracle/solvers.py SharingBP, line by line
  * One-time quantities (standardised data, spectral radius, Cholesky factors, L^-1 A, ...) are INPUTS: the Python side builds them
  * with NumPy / LAPACK exactly as the NumPy oracle does (oracle/cloops.py); this file is the per-iteration hot loop in the two CPU
  * configurations bench.py reports -- nthreads = 1 (the reference's effective configuration: Eigen products are serial under
@@ -529,6 +531,107 @@ int oracle_dense_loop(int prob, const double* M, int n, int p, const double* L, 
     if (adjy_out) memcpy(adjy_out, ay, (size_t)dim * sizeof(double));
     if (ntrace) *ntrace = ntr;
     free(x); free(z); free(y); free(az); free(ay); free(oz); free(oy); free(vec); free(small); free(g); free(Mown);
+    return 0;
+}
+
+/* Column-block ("sharing") basis pursuit: the loop of oracle/solvers.py SharingBP.solve (that class states what is the unbuilt
+ * reference source's, src/TODO/PADMMBP.h, and what had to be modelled on the current PADMMBase_Master).  A: n x p column-major,
+ * N blocks of p div N columns (the last takes the remainder, PADMMBP.h:150-167); sprad[i] = lambda_max(A_i'A_i) and rho are inputs.
+ * trace: 7 doubles per iteration (iteration, eps_primal, eps_dual, resid_primal, resid_dual, regular, converged) as the NumPy class
+ * records them.  nthreads > 1: the columns' dot products of a block spread over the threads; the blocks' A_i x_i one thread each. */
+int oracle_sharing_loop(const double* A, long lda, int n, int p, int N, const double* b, const double* sprad, double rho, double eps_abs,
+                        double eps_rel, int maxit, int nthreads, double* x_out, int* niter_out, double* loop_seconds, double* trace,
+                        int trace_cap, int* ntrace, double budget_s) {
+    if (nthreads < 1) nthreads = 1;
+    double* Aown = lda == n ? own_copy(A, (size_t)n * sizeof(double), p, nthreads) : NULL;
+    if (Aown) A = Aown;
+    const int chunk = p / N;
+    double* x = calloc((size_t)p, sizeof(double));
+    double* Ax = calloc((size_t)N * n, sizeof(double));
+    double* nAx = calloc((size_t)N * n, sizeof(double));
+    double* y = calloc((size_t)n, sizeof(double));
+    double* r = calloc((size_t)n, sizeof(double));
+    double* S = calloc((size_t)n, sizeof(double));
+    double* v = calloc((size_t)n, sizeof(double));
+    double* Sn = calloc((size_t)n, sizeof(double));
+    double* zbar = calloc((size_t)n, sizeof(double));
+    if (!x || !Ax || !nAx || !y || !r || !S || !v || !Sn || !zbar) return 1;
+    for (int k = 0; k < n; ++k) zbar[k] = b[k] / (double)N;
+    const double dN = (double)N, sq = sqrt((double)n * (double)N);
+    int it = maxit + 1, ntr = 0, counter = 0;
+    const double t0 = now_s();
+    for (int i = 0; i < maxit; ++i) {
+        /* thresholds (SharingBP._eps) */
+        double sax = 0.0, abar_r = 0.0, r2 = 0.0;
+        for (int q = 0; q < N; ++q) sax += dot_d(Ax + (size_t)q * n, Ax + (size_t)q * n, n);
+        for (int k = 0; k < n; ++k) {
+            double a = 0.0;
+            for (int q = 0; q < N; ++q) a += Ax[(size_t)q * n + k];
+            abar_r += (a / dN) * r[k];
+            r2 += r[k] * r[k];
+        }
+        const double sz = sax - 2.0 * dN * abar_r + dN * r2;
+        double m = sax > sz ? sax : sz;
+        if (m < 0.0) m = 0.0;
+        const double eps_primal = eps_rel * sqrt(m) + sq * eps_abs;
+        const double eps_dual = eps_rel * sqrt(dN) * norm_d(y, n) + sq * eps_abs;
+        for (int k = 0; k < n; ++k) v[k] = y[k] / rho + r[k];
+        const int regular = counter % 10 == 0;
+        /* workers: x-update (every column on regular iterations, the current non-zeros otherwise) */
+        for (int q = 0; q < N; ++q) {
+            const int c0 = q * chunk, c1 = q == N - 1 ? p : c0 + chunk;
+            const double gamma = 2.0 * rho + sprad[q], pen = 1.0 / (rho * gamma);
+#pragma omp parallel for schedule(static) num_threads(nthreads) if (nthreads > 1)
+            for (int j = c0; j < c1; ++j) {
+                if (!regular && x[j] == 0.0) continue;
+                const double val = x[j] - dot_d(A + (size_t)j * lda, v, n) / gamma;
+                x[j] = val > pen ? val - pen : (val < -pen ? val + pen : 0.0);
+            }
+        }
+#pragma omp parallel for schedule(static) num_threads(nthreads < N ? nthreads : N) if (nthreads > 1)
+        for (int q = 0; q < N; ++q) {                                   /* A_i x_i over the non-zeros, column order */
+            const int c0 = q * chunk, c1 = q == N - 1 ? p : c0 + chunk;
+            double* o = nAx + (size_t)q * n;
+            for (int k = 0; k < n; ++k) o[k] = 0.0;
+            for (int j = c0; j < c1; ++j) {
+                const double xj = x[j];
+                if (xj == 0.0) continue;
+                const double* c = A + (size_t)j * lda;
+                for (int k = 0; k < n; ++k) o[k] += xj * c[k];
+            }
+        }
+        ++counter;
+        double qd = 0.0, drdS = 0.0, dr2 = 0.0, rn2 = 0.0;
+        for (int k = 0; k < n; ++k) {
+            double sn = 0.0;
+            for (int q = 0; q < N; ++q) sn += nAx[(size_t)q * n + k];
+            Sn[k] = sn;
+        }
+        for (int q = 0; q < N; ++q)
+            for (int k = 0; k < n; ++k) { const double d = nAx[(size_t)q * n + k] - Ax[(size_t)q * n + k]; qd += d * d; }
+        for (int k = 0; k < n; ++k) {
+            const double rn = Sn[k] / dN - zbar[k];
+            const double dr = rn - r[k], dS = Sn[k] - S[k];
+            drdS += dr * dS; dr2 += dr * dr; rn2 += rn * rn;
+            r[k] = rn; S[k] = Sn[k];
+            y[k] = y[k] + rho * rn;
+        }
+        memcpy(Ax, nAx, (size_t)N * n * sizeof(double));
+        const double sd = qd - 2.0 * drdS + dN * dr2;
+        const double resid_dual = rho * sqrt(sd > 0.0 ? sd : 0.0), resid_primal = sqrt(dN * rn2);
+        const int conv = resid_primal < eps_primal && resid_dual < eps_dual;
+        if (trace && ntr < trace_cap) {
+            double* tr = trace + 7 * (size_t)ntr++;
+            tr[0] = i; tr[1] = eps_primal; tr[2] = eps_dual; tr[3] = resid_primal; tr[4] = resid_dual; tr[5] = regular; tr[6] = conv;
+        }
+        if (conv) { it = i + 1; break; }
+        if (budget_s > 0 && now_s() - t0 > budget_s) { it = i + 1; break; }
+    }
+    *loop_seconds = now_s() - t0;
+    *niter_out = it;
+    if (x_out) memcpy(x_out, x, (size_t)p * sizeof(double));
+    if (ntrace) *ntrace = ntr;
+    free(x); free(Ax); free(nAx); free(y); free(r); free(S); free(v); free(Sn); free(zbar); free(Aown);
     return 0;
 }
 

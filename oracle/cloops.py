@@ -13,7 +13,7 @@ import scipy.linalg as sla
 
 from .datastd import DataStd
 from .entry import _lambda_grid
-from .solvers import BP, LAD, LassoWide, PADMMLasso
+from .solvers import BP, LAD, LassoWide, PADMMLasso, SharingBP
 
 F = np.float32
 _DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "c")
@@ -47,6 +47,8 @@ def load():
         lib.oracle_consensus_path.restype = c_int
         lib.oracle_dense_loop.argtypes = [c_int, _dp, c_int, c_int, _dp, _dp, c_dbl, c_dbl, c_dbl, c_int, c_int, _dp, _dp, _dp, _dp, _ip, _dp, _dp, c_int, _ip, c_dbl]
         lib.oracle_dense_loop.restype = c_int
+        lib.oracle_sharing_loop.argtypes = [_dp, c_long, c_int, c_int, c_int, _dp, _dp, c_dbl, c_dbl, c_dbl, c_int, c_int, _dp, _ip, _dp, _dp, c_int, _ip, c_dbl]
+        lib.oracle_sharing_loop.restype = c_int
         lib.oracle_loops_max_threads.restype = c_int
         _lib = lib
     return _lib
@@ -203,3 +205,32 @@ def admm_bp_c(x, y, opts, nthreads=1, trace=None):
     s = BP(x, y, float(opts["rho"]), float(opts["eps_abs"]), float(opts["eps_rel"]))
     z, _, _, rho, niter, secs = dense_loop(1, s.LinvA, None, s.cache_AAAb, float(opts["rho"]), opts["eps_abs"], opts["eps_rel"], opts["maxit"], nthreads, trace)
     return {"beta": z, "niter": niter, "loop_seconds": secs, "rho": rho}
+
+
+def sharing_loop(A, b, N, sprad, rho, eps_abs, eps_rel, maxit, nthreads=1, trace=None, budget_s=0.0):
+    """The loop of oracle/solvers.py SharingBP.solve in C.  trace: list that receives the class's own 7-field records."""
+    lib = load()
+    A = np.asfortranarray(A, dtype=np.float64)
+    n, p = A.shape
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    sprad = np.ascontiguousarray(sprad, dtype=np.float64)
+    x = np.zeros(p)
+    secs, niter = ctypes.c_double(), ctypes.c_int()
+    cap = int(maxit) if trace is not None else 0
+    tr, ntr = np.zeros((max(cap, 1), 7)), ctypes.c_int(0)
+    rc = lib.oracle_sharing_loop(A.ctypes.data_as(_dp), n, n, p, int(N), b.ctypes.data_as(_dp), sprad.ctypes.data_as(_dp), float(rho), float(eps_abs),
+                                 float(eps_rel), int(maxit), int(nthreads), x.ctypes.data_as(_dp), ctypes.byref(niter), ctypes.byref(secs),
+                                 tr.ctypes.data_as(_dp) if cap else None, cap, ctypes.byref(ntr), float(budget_s))
+    if rc != 0:
+        raise MemoryError("oracle_sharing_loop failed")
+    if trace is not None:
+        trace.extend(tuple(row) for row in tr[:ntr.value].tolist())
+    return x, niter.value, secs.value
+
+
+def admm_parbp_c(x, y, nthread, opts, nthreads=1, trace=None):
+    """Mirror of oracle.entry.admm_parbp: the constructor (partition, exact spectral radii, rho) is the NumPy class's, the loop is C."""
+    s = SharingBP(x, y, int(nthread), float(opts["eps_abs"]), float(opts["eps_rel"]))
+    rho = 1.0 / (float(opts["rho_ratio"]) * float(np.mean(s.sprad)))
+    beta, niter, secs = sharing_loop(x, y, int(nthread), s.sprad, rho, opts["eps_abs"], opts["eps_rel"], opts["maxit"], nthreads, trace)
+    return {"beta": beta, "niter": niter, "loop_seconds": secs, "rho": rho}

@@ -102,3 +102,29 @@ def test_readme_lad_and_bp_through_the_c_loops(readme_lasso_xy):
     r = cloops.admm_bp_c(xb, yb, entry.BP_OPTS)
     e = bt - r["beta"]
     assert abs(e.min() - readme.BP_RANGE[0]) < 1e-6 and abs(e.max() - readme.BP_RANGE[1]) < 1e-6
+
+
+def test_sharing_bp_loop_c_vs_numpy():
+    """The compiled restatement of the column-block sharing basis pursuit (bench.py's cpu_baseline of the parbp config) against the
+    NumPy class it follows (oracle/solvers.py SharingBP): the README basis-pursuit data (README.md:217-246) and a ragged random
+    problem, 2 .. 7 blocks, one and three threads -- same iteration counts, the same regular / active-set schedule and decisions,
+    every recorded threshold and residual to 1e-9 of its column's largest value, coefficients to 1e-10, the same support."""
+    from oracle import cloops, entry, readme
+    xb, yb, bt = readme.bp_data()
+    rng = np.random.default_rng(8)
+    A = rng.standard_normal((61, 233))
+    b0 = np.zeros(233); b0[rng.choice(233, 9, replace=False)] = rng.standard_normal(9) * 3
+    opts = dict(maxit=10000, eps_abs=1e-4, eps_rel=1e-4, rho_ratio=1.0)
+    for x, y, N, nt in ((xb, yb, 2, 1), (xb, yb, 7, 3), (A, A @ b0, 3, 1), (A, A @ b0, 5, 3)):
+        d, trc = {"trace": []}, []
+        ref = entry.admm_parbp(x, y, N, opts, d)
+        got = cloops.admm_parbp_c(x, y, N, opts, nthreads=nt, trace=trc)
+        assert got["niter"] == ref["niter"], (N, got["niter"], ref["niter"])
+        a, r = np.asarray(trc), np.asarray(d["trace"], dtype=np.float64)
+        assert a.shape == r.shape
+        assert np.array_equal(a[:, [0, 5, 6]], r[:, [0, 5, 6]])
+        for col in range(1, 5):                                   # (the dual residual is a difference of sums: measured against the column's scale, as tests/test_gpu_parbp.py does)
+            assert np.abs(a[:, col] - r[:, col]).max() < 1e-9 * np.abs(r[:, col]).max(), (N, col)
+        assert relerr(got["beta"], ref["beta"]) < 1e-10 and np.array_equal(got["beta"] != 0, ref["beta"] != 0)
+        assert abs(got["rho"] / d["solver"].rho - 1) < 1e-14
+    assert np.abs(got["beta"] - b0).max() < 5e-3                  # (and it is basis pursuit: the sparse truth comes back)
