@@ -1,4 +1,7 @@
 #!/bin/bash
+# Kernel trace + PMC bytes + plain bench line of the sharing-BP config alone (run from the repo root through gpurun; outputs in
+# gpurun_out/r05q/: copy c5parbp_kernel_stats.md / c5parbp_pmc_hbm_bytes.md to profiles/r05_* and merge pmc_traffic.json's
+# configs.c5parbp into profiles/pmc_traffic.json).  The other configs: scripts/capture_profiles.sh, scripts/capture_pmc_configs.sh.
 set -u
 export TMPDIR=/tmp
 OUT=gpurun_out/r05q
