@@ -67,7 +67,9 @@ struct SbpGram {
     double* xs; double* hr; double* gy;           // [2][cap] x_U, A_U'r, A_U'y (double-buffered by the iteration's parity)
     double* sx;                                   // [cap] sum of the stretch's iterates
     double* sxd;                                  // [pl] dense: sum_t (x_t - x_last) over the stretch, zero outside U
-    double* Ps;                                   // [cap / 8][8] workgroup partials of the seven sums a decision needs
+    double* Ps;                                   // [2][cap / 8][8] workgroup partials of the seven sums a decision needs: a launch reads the
+                                                  // buffer of its parity and writes the other (a workgroup that finishes early must not overwrite
+                                                  // what a workgroup of the SAME launch that started late has yet to read)
     double* sc;                                   // [2][4] ||r||^2, ||y||^2, y'zbar carried from decision to decision; [8] y'zbar of the stretch's start
     double zz;                                    // zbar'zbar
     double* partP; double* partT;                 // [NL][ngroups][pstride] partials of A_i x_i and of A_i sxd_i (gather_kernels.h)
@@ -801,7 +803,7 @@ sbp_gs_kernel(SbpParams q, int par, int idx, int first, int nth) {
     double cR = 0.0, cY = 0.0, cyz = 0.0;
     if (MODE == 0 && !first) {
         if (tid < cap / kGsRows) {
-            const double2* pr = reinterpret_cast<const double2*>(s.Ps + (size_t)tid * 8);
+            const double2* pr = reinterpret_cast<const double2*>(s.Ps + ((size_t)idx * (cap / kGsRows) + tid) * 8);
             const double2 p0 = pr[0], p1 = pr[1], p2 = pr[2], p3 = pr[3];
             pp[0] = p0.x; pp[1] = p0.y; pp[2] = p1.x; pp[3] = p1.y; pp[4] = p2.x; pp[5] = p2.y; pp[6] = p3.x;
         }
@@ -957,7 +959,7 @@ sbp_gs_kernel(SbpParams q, int par, int idx, int first, int nth) {
     }
     if (tid == 0) {
 #pragma unroll
-        for (int k = 0; k < 7; ++k) s.Ps[blockIdx.x * 8 + k] = p[k];
+        for (int k = 0; k < 7; ++k) s.Ps[((size_t)(idx ^ 1) * (cap / kGsRows) + blockIdx.x) * 8 + k] = p[k];
     }
 }
 
@@ -977,7 +979,8 @@ sbp_gs_tail_kernel(SbpParams q, int par, int nth) {
     if (blockIdx.x == 0) {                                          // the two sums that only exist in Gram space
         double p[2] = {0.0, 0.0};
         const int nR = (uc + kGsRows - 1) / kGsRows;
-        for (int w = threadIdx.x; w < nR; w += 64 * kSbpTailWaves) { p[0] += s.Ps[w * 8]; p[1] += s.Ps[w * 8 + 4]; }
+        const double* Pl = s.Ps + (size_t)par * (s.cap / kGsRows) * 8;       // the buffer the stretch's last iteration wrote: it read parity par ^ 1
+        for (int w = threadIdx.x; w < nR; w += 64 * kSbpTailWaves) { p[0] += Pl[w * 8]; p[1] += Pl[w * 8 + 4]; }
         block_sum<double, 2>(p, red);
         D = p[0]; qq = p[1];
     }
@@ -1446,7 +1449,7 @@ void solve_parbp(const DeviceData<double>& d, const admm_opts& opts, int nblocks
         g_umap.alloc(pl); g_ucol.alloc(gcap); g_ubid.alloc(gcap); g_ust.alloc(8);
         g_G.alloc((size_t)gcap * gcap); g_gz.alloc(gcap); g_ugp.alloc(2 * (size_t)gcap);
         g_xs.alloc(2 * (size_t)gcap); g_hr.alloc(2 * (size_t)gcap); g_gy.alloc(2 * (size_t)gcap); g_sx.alloc(gcap); g_sxd.alloc(pl);
-        g_Ps.alloc((size_t)(gcap / kGsRows) * 8); g_sc.alloc(16);
+        g_Ps.alloc(2 * (size_t)(gcap / kGsRows) * 8); g_sc.alloc(16);
         g_partP.alloc((size_t)NL * gp.ngroups * npad); g_partT.alloc((size_t)NL * gp.ngroups * npad);
         g_args.alloc(2 * (size_t)NL);
         ADMM_HIP_CHECK(hipMemsetAsync(g_umap.get(), 0xff, (size_t)pl * sizeof(int), st));
