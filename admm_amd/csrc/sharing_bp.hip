@@ -74,6 +74,7 @@ struct SbpGram {
     double zz;                                    // zbar'zbar
     double* partP; double* partT;                 // [NL][ngroups][pstride] partials of A_i x_i and of A_i sxd_i (gather_kernels.h)
     int ngroups, pad; long long pstride;
+    int test_delay, pad2;                         // test hook: ticks (10 ns) by which every even workgroup of a Gram-space launch starts late
 };
 
 struct SbpParams {
@@ -770,6 +771,12 @@ sbp_gs_kernel(SbpParams q, int par, int idx, int first, int nth) {
     const SbpGram& s = q.gs;
     const int cap = s.cap;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (s.test_delay > 0 && (blockIdx.x & 1) == 0) {               // (workgroup 0 among them: its decision is the one that is recorded)
+        // Test hook (ADMM_HIP_SBP_TEST_DELAY_US, tests/test_gpu_parbp.py): the workgroups of a launch do not start together -- make
+        // that visible.  Whatever one workgroup writes at the end of a launch must not be what another reads at its start.
+        const long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < s.test_delay) __builtin_amdgcn_s_sleep(8);
+    }
     // ---- requests that depend on nothing
     double xt[4], gyv[4], hrv[4], gam[4], pen[4];
     int bidv[4], ucv[4];
@@ -1462,6 +1469,7 @@ void solve_parbp(const DeviceData<double>& d, const admm_opts& opts, int nblocks
         gs.sx = g_sx.get(); gs.sxd = g_sxd.get(); gs.Ps = g_Ps.get(); gs.sc = g_sc.get();
         gs.partP = g_partP.get(); gs.partT = g_partT.get(); gs.ngroups = gp.ngroups; gs.pstride = npad;
         gs.zz = zz;
+        gs.test_delay = 100 * env_int("ADMM_HIP_SBP_TEST_DELAY_US", 0); gs.pad2 = 0;
         std::vector<GatherArgs<double>> ha(2 * (size_t)NL);
         for (int k = 0; k < 2 * NL; ++k) {
             const int b = k % NL;

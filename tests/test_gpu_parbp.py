@@ -160,3 +160,23 @@ def test_gram_space_and_its_ways_out(monkeypatch):
         with monkeypatch.context() as m:
             m.setenv("ADMM_HIP_SBP_GRAM_CAP", cap)
             _compare(xs, xs @ b0, N, f"n=120 p=700 cap {cap}")
+
+
+def test_gram_space_launches_do_not_depend_on_their_workgroups_starting_together(monkeypatch):
+    """Regression (round 5, found by tests/tools/parbp_gram_soak.py: 4 of 1200 cases with one wrong recorded residual, never the same
+    ones): a Gram-space launch reads, in every workgroup, the partial sums that ALL workgroups of the previous launch left, and
+    every workgroup leaves its own for the next launch -- in the same array at the time, so a workgroup that started a few
+    microseconds late read numbers of the launch it belonged to.  ADMM_HIP_SBP_TEST_DELAY_US holds every even workgroup back at the
+    start of each such launch (30 us, three launches' worth; workgroup 0, whose decision is the recorded one, among them), which
+    turns a dependence of that kind into a certain failure (checked against the single-buffered build when the test was written)."""
+    from oracle import readme
+    monkeypatch.setenv("ADMM_HIP_SBP_TEST_DELAY_US", "30")
+    x, y, _ = readme.bp_data()
+    _compare(x, y, 3, "README n=50 p=100, even workgroups 30 us late")
+    rng = np.random.default_rng(21)
+    n, p = 120, 700
+    xs = np.asfortranarray(rng.standard_normal((n, p)))
+    b0 = np.zeros(p); b0[rng.choice(p, 12, replace=False)] = rng.standard_normal(12) * 4
+    _compare(xs, xs @ b0, 4, "n=120 p=700, even workgroups 30 us late")
+    monkeypatch.setenv("ADMM_HIP_SBP_GRAM_CARRY", "0")
+    _compare(xs, xs @ b0, 4, "n=120 p=700, no carry-over, even workgroups 30 us late")
