@@ -52,7 +52,7 @@ _c_int_p = ctypes.POINTER(ctypes.c_int)
 EXPORTS = ["admm_hip_lasso", "admm_hip_enet", "admm_hip_parlasso", "admm_hip_lad", "admm_hip_bp",
            "admm_hip_last_error", "admm_hip_version", "admm_hip_device_count", "admm_hip_set_device",
            "admm_hip_device_synchronize", "admm_hip_lasso_plan_create", "admm_hip_lasso_plan_run",
-           "admm_hip_lasso_plan_destroy", "admm_hip_comm_unique_id", "admm_hip_comm_init", "admm_hip_comm_finalize",
+           "admm_hip_lasso_plan_destroy", "admm_hip_comm_unique_id", "admm_hip_comm_init", "admm_hip_comm_finalize", "admm_hip_comm_info",
            "admm_hip_parlasso_dist", "admm_hip_lasso_plan_create_dist",
            "admm_hip_lasso_plan_trace_enable", "admm_hip_lasso_plan_trace_read",
            "admm_hip_lasso_plan_state_enable", "admm_hip_lasso_plan_state_read", "admm_hip_lasso_plan_system_read",
@@ -163,6 +163,8 @@ def load():
     lib.admm_hip_comm_init.restype = ctypes.c_int
     lib.admm_hip_comm_finalize.argtypes = []
     lib.admm_hip_comm_finalize.restype = ctypes.c_int
+    lib.admm_hip_comm_info.argtypes = [ctypes.POINTER(ctypes.c_int)] * 3
+    lib.admm_hip_comm_info.restype = ctypes.c_int
     lib.admm_hip_comm_peer_prepare.argtypes = [ctypes.c_int, ctypes.c_void_p]
     lib.admm_hip_comm_peer_prepare.restype = ctypes.c_int
     lib.admm_hip_comm_init_peer.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]

@@ -316,7 +316,7 @@ static void lasso_cv(const double* x, const double* y, int n, int p, int mem, co
         xd_own.alloc((size_t)n * p); yd_own.alloc(n);
         write_device(xd_own.get(), x, (size_t)n * p * sizeof(double));
         write_device(yd_own.get(), y, (size_t)n * sizeof(double));
-        ADMM_HIP_CHECK(hipStreamSynchronize(st.s));
+        comm_stream_sync(st.s);
         xd = xd_own.get(); yd = yd_own.get();
     }
     // Folds as down-dates of the full-data Gram (cv.hip): when every fit of the call is the tall solver's and the Gram is
@@ -383,7 +383,7 @@ static void lasso_cv(const double* x, const double* y, int n, int p, int mem, co
         } else {
             xtr.alloc((size_t)ntr * p); ytr.alloc(ntr);
             cv_gather(xd, n, yd, didx.get(), ntr, p, xtr.get(), ytr.get(), st.s);
-            ADMM_HIP_CHECK(hipStreamSynchronize(st.s));
+            comm_stream_sync(st.s);
             std::unique_ptr<PlanHandle> h(create_plan(xtr.get(), ytr.get(), ntr, p, ADMM_MEM_DEVICE, lam.data(), nlam, 0, lmin_ratio,
                                                       standardize, intercept, enet, enet ? alpha : 1.0, 0, opts));
             h->plan->run(res);
@@ -399,7 +399,7 @@ static void lasso_cv(const double* x, const double* y, int n, int p, int mem, co
         allreduce_sum_f64(t.get(), (size_t)2 * nfolds * nlam, st.s);
         ADMM_HIP_CHECK(hipMemcpyAsync(mse.data(), t.get(), mse.size() * sizeof(double), hipMemcpyDeviceToHost, st.s));
         ADMM_HIP_CHECK(hipMemcpyAsync(nit.data(), t.get() + mse.size(), nit.size() * sizeof(double), hipMemcpyDeviceToHost, st.s));
-        ADMM_HIP_CHECK(hipStreamSynchronize(st.s));
+        comm_stream_sync(st.s);
         comm_check();
         if (fold_beta) {
             const size_t nfb = (size_t)(p + 1) * nlam * nfolds;
@@ -407,7 +407,7 @@ static void lasso_cv(const double* x, const double* y, int n, int p, int mem, co
             ADMM_HIP_CHECK(hipMemcpyAsync(fb.get(), fold_beta, nfb * sizeof(float), hipMemcpyHostToDevice, st.s));
             allreduce_sum_f32(fb.get(), nfb, st.s);
             read_back(fold_beta, fb.get(), nfb * sizeof(float), st.s);
-            ADMM_HIP_CHECK(hipStreamSynchronize(st.s));
+            comm_stream_sync(st.s);
             comm_check();
         }
     }
@@ -458,7 +458,7 @@ static void lasso_multi(const double* x, const double* Y, int n, int p, int m, i
         xd_own.alloc((size_t)n * p); yd_own.alloc((size_t)n * m);
         write_device(xd_own.get(), x, (size_t)n * p * sizeof(double));
         write_device(yd_own.get(), Y, (size_t)n * m * sizeof(double));
-        ADMM_HIP_CHECK(hipStreamSynchronize(st.s));
+        comm_stream_sync(st.s);
         xd = xd_own.get(); yd = yd_own.get();
     }
     const CommInfo ci = comm_info();
@@ -493,7 +493,7 @@ static void lasso_multi(const double* x, const double* Y, int n, int p, int m, i
             ldg = round_up(p, 128);
             G.alloc((size_t)ldg * ldg); G.zero(st.s);
             gram_full<float>(base.X.get(), base.ldx, n, p, true, G.get(), ldg, st.s);
-            ADMM_HIP_CHECK(hipStreamSynchronize(st.s));
+            comm_stream_sync(st.s);
         }
         t_shared = now_s() - t0;
     }
@@ -521,7 +521,7 @@ static void lasso_multi(const double* x, const double* Y, int n, int p, int m, i
         ADMM_HIP_CHECK(hipMemcpyAsync(fb.get(), beta_out, bsz * m * sizeof(float), hipMemcpyHostToDevice, st.s));
         allreduce_sum_f32(fb.get(), bsz * m, st.s);
         read_back(beta_out, fb.get(), bsz * m * sizeof(float), st.s);
-        ADMM_HIP_CHECK(hipStreamSynchronize(st.s));
+        comm_stream_sync(st.s);
         comm_check();
     }
     for (size_t k = 0; k < lam.size(); ++k) { lambda_out[k] = lam[k]; niter_out[k] = (int)std::llround(nit[k]); }
@@ -859,6 +859,14 @@ int admm_hip_comm_init(int nranks, int rank, const void* id) {
 }
 int admm_hip_comm_finalize(void) {
     return guarded([&] { comm_finalize(); });
+}
+int admm_hip_comm_info(int* nranks_out, int* rank_out, int* backend_out) {
+    return guarded([&] {
+        const CommInfo ci = comm_info_live();
+        if (nranks_out) *nranks_out = ci.active ? ci.nranks : 1;
+        if (rank_out) *rank_out = ci.active ? ci.rank : 0;
+        if (backend_out) *backend_out = ci.active ? ci.backend : 0;
+    });
 }
 int admm_hip_comm_peer_prepare(int nranks, void* handle_out) {
     return guarded([&] { ADMM_REQUIRE(handle_out != nullptr, "handle_out must not be NULL"); require_device(); comm_peer_prepare(nranks, handle_out); });

@@ -41,6 +41,16 @@ struct CommLockstep { CommLockstep(); ~CommLockstep(); CommLockstep(const CommLo
 // Throws ADMM_ERR_COMM if an exchange of the SHM / PEER backends timed out or a peer reported failure (checked by the
 // loop drivers at every poll; the kernels of a failed exchange return immediately instead of spinning).
 void comm_check();
+// Host waits of the solvers.  SHM / PEER: plain synchronisation (their device / host-function waits are bounded themselves).
+// RCCL: an RCCL kernel waiting for a rank that died never returns, so the host polls instead -- hipStreamQuery / hipEventQuery,
+// ncclCommGetAsyncError every few milliseconds, and the bound in force (lock-step 20 s inside a solve's loop, patient otherwise):
+// on an asynchronous error or a timed-out wait the communicator is aborted (ncclCommAbort ends its kernels) and the call returns
+// ADMM_ERR_COMM instead of hanging ("return an error code if a rank fails").
+void comm_stream_sync(hipStream_t st);
+void comm_event_sync(hipEvent_t ev);
+// The ranks the attached communicator REALLY holds (RCCL: ncclCommCount / ncclCommUserRank of the live communicator, not what the
+// caller asked for).
+CommInfo comm_info_live();
 // PEER backend only: start the next exchange for a solver whose own kernels write the slots / wait and read them
 // (peer_device.h): no launches of the exchange layer itself.
 struct PeerExchange;

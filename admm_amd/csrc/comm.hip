@@ -392,6 +392,65 @@ void comm_check() {
     if (g_err && *g_err) throw Error(ADMM_ERR_COMM, "exchange failed: a rank did not arrive within the time limit (or a peer reported failure)");
 }
 
+namespace {
+// RCCL only: give up on the communicator (its in-flight kernels end) and report.
+[[noreturn]] void rccl_fail(const std::string& why) {
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (g_comm) { (void)ncclCommAbort(g_comm); g_comm = nullptr; }
+        g_info = CommInfo();
+        g_seq = 0;
+    }
+    throw Error(ADMM_ERR_COMM, "RCCL exchange failed: " + why + " (communicator aborted; call admm_hip_comm_finalize and re-attach)");
+}
+template <typename Q>
+void rccl_watched_wait(Q&& query) {
+    const double t0 = now_s(), bound = wait_seconds_now();
+    double next = t0 + 2e-3;
+    for (;;) {
+        const hipError_t q = query();
+        if (q == hipSuccess) return;
+        if (q != hipErrorNotReady) ADMM_HIP_CHECK(q);
+        const double t = now_s();
+        if (t >= next) {
+            next = t + 5e-3;
+            ncclResult_t ar = ncclSuccess;
+            const ncclResult_t rc = ncclCommGetAsyncError(g_comm, &ar);
+            if (rc != ncclSuccess) rccl_fail(std::string("ncclCommGetAsyncError: ") + ncclGetErrorString(rc));
+            if (ar != ncclSuccess && ar != ncclInProgress) rccl_fail(std::string("asynchronous error: ") + ncclGetErrorString(ar));
+            if (t - t0 > bound) rccl_fail("a rank did not arrive within " + std::to_string((int)bound) + " s");
+        }
+        if (t - t0 > 100e-6) sched_yield();              // the first 100 us spin: a batch of iterations is that short
+    }
+}
+}  // namespace
+
+void comm_stream_sync(hipStream_t st) {
+    if (g_info.backend != COMM_RCCL || !g_comm) { ADMM_HIP_CHECK(hipStreamSynchronize(st)); return; }
+    rccl_watched_wait([&] { return hipStreamQuery(st); });
+}
+void comm_event_sync(hipEvent_t ev) {
+    if (g_info.backend != COMM_RCCL || !g_comm) { ADMM_HIP_CHECK(hipEventSynchronize(ev)); return; }
+    rccl_watched_wait([&] { return hipEventQuery(ev); });
+}
+CommInfo comm_info_live() {
+    std::lock_guard<std::mutex> lk(g_mu);
+    CommInfo ci = g_info;
+    if (ci.backend == COMM_RCCL && g_comm) {
+        int n = 0, r = -1;
+        ADMM_NCCL_CHECK(ncclCommCount(g_comm, &n));
+        ADMM_NCCL_CHECK(ncclCommUserRank(g_comm, &r));
+        ci.nranks = n; ci.rank = r;
+    } else if (ci.backend == COMM_SHM && g_shm.hdr) {
+        ci.nranks = (int)g_shm.hdr->attached.load(std::memory_order_acquire);
+    } else if (ci.backend == COMM_PEER) {
+        int n = 0;
+        for (int r = 0; r < kMaxRanks; ++r) n += (g_peer.remote[r] != nullptr);
+        ci.nranks = n;
+    }
+    return ci;
+}
+
 void allreduce_sum_f32(float* buf, size_t n, hipStream_t st) {
     if (!g_info.active || n == 0) return;
     if (g_info.backend == COMM_RCCL) { exchange(buf, n, nullptr, 0, st); return; }

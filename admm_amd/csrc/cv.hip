@@ -88,7 +88,7 @@ std::vector<double> cv_score(const double* xt, const double* yt, int m, int p, c
     ADMM_HIP_CHECK(hipGetLastError());
     std::vector<double> hp((size_t)nb * nlam);
     ADMM_HIP_CHECK(hipMemcpyAsync(hp.data(), part.get(), hp.size() * sizeof(double), hipMemcpyDeviceToHost, st));
-    ADMM_HIP_CHECK(hipStreamSynchronize(st));
+    comm_stream_sync(st);
     for (int l = 0; l < nlam; ++l) {
         double s = 0;
         for (int b = 0; b < nb; ++b) s += hp[(size_t)b * nlam + l];
@@ -172,7 +172,7 @@ void cv_downdate_prepare(CvBase& b, const double* xd, const double* yd, int n, i
     b.s1.resize(p); b.s2.resize(p);
     ADMM_HIP_CHECK(hipMemcpyAsync(b.s1.data(), s.get(), (size_t)p * sizeof(double), hipMemcpyDeviceToHost, st));
     ADMM_HIP_CHECK(hipMemcpyAsync(b.s2.data(), s.get() + p, (size_t)p * sizeof(double), hipMemcpyDeviceToHost, st));
-    ADMM_HIP_CHECK(hipStreamSynchronize(st));
+    comm_stream_sync(st);
     b.t_prepare = now_s() - t0;
 }
 
@@ -188,7 +188,7 @@ void cv_downdate_full(DeviceData<float>& d, const CvBase& b, hipStream_t st) {
     d.t_gram_tail = b.t_prepare;
     d.xy.alloc(b.ldp); d.xy.zero(st);
     gemv_t_simple<float>(f.X.get(), f.ldx, f.n, f.p, f.Y.get(), d.xy.get(), st);
-    ADMM_HIP_CHECK(hipStreamSynchronize(st));
+    comm_stream_sync(st);
 }
 
 // Fold data in Gram form.  d_train / d_test: device row indices (ntr / nte of them); yd: the response as handed over.
@@ -227,7 +227,7 @@ void cv_downdate_fold(DeviceData<float>& d, const CvBase& b, const double* yd, c
     DevBuf<float> raw(ldp);
     raw.zero(st);
     gemv_t_simple<float>(f.X.get(), f.ldx, n, p, w.get(), raw.get(), st);
-    ADMM_HIP_CHECK(hipStreamSynchronize(st));
+    comm_stream_sync(st);
     double sw = 0;
     for (int i = 0; i < ntr; ++i) sw += (double)hY[i];
     // ---- the training rows' column statistics in the coordinates of Z
@@ -254,7 +254,7 @@ void cv_downdate_fold(DeviceData<float>& d, const CvBase& b, const double* yd, c
     d.xy.alloc(ldp); d.xy.zero(st);
     hipLaunchKernelGGL(cv_xy_fix_kernel, dim3((p + 255) / 256), dim3(256), 0, st, raw.get(), p, centre ? sw : 0.0, dd.get(), dd.get() + p, d.xy.get());
     ADMM_HIP_CHECK(hipGetLastError());
-    ADMM_HIP_CHECK(hipStreamSynchronize(st));
+    comm_stream_sync(st);
     d.t_gram_tail = now_s() - t0;
 }
 

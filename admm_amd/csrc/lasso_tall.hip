@@ -619,7 +619,7 @@ struct TallPlan final : LassoPlan {
         } else {
             M.alloc((size_t)ldp * ldp); M.zero(st);
             gram_full<float>(d.X.get(), d.ldx, n, p, true, M.get(), ldp, st);      // sharded: this rank's term of the split-K sum (reduced below)
-            ADMM_HIP_CHECK(hipStreamSynchronize(st));
+            comm_stream_sync(st);
             S.t_gram = now_s() - t0;
         }
         // Row-sharded solver: decided here because it chooses how the split-K Gram is reduced (below)
@@ -645,7 +645,7 @@ struct TallPlan final : LassoPlan {
                     ADMM_HIP_CHECK(hipMemcpyAsync(wsum.get(), w_, (size_t)p * sizeof(float), hipMemcpyHostToDevice, st));
                     allreduce_sum_f32(wsum.get(), (size_t)p, st);
                     ADMM_HIP_CHECK(hipMemcpyAsync(w_, wsum.get(), (size_t)p * sizeof(float), hipMemcpyDeviceToHost, st));
-                    ADMM_HIP_CHECK(hipStreamSynchronize(st));
+                    comm_stream_sync(st);
                     comm_check();
                 }
             }, p, &nmatop);
@@ -681,7 +681,7 @@ struct TallPlan final : LassoPlan {
             } else {
                 allreduce_sum_f32(M.get(), (size_t)ldp * ldp, st);
             }
-            ADMM_HIP_CHECK(hipStreamSynchronize(st));
+            comm_stream_sync(st);
             comm_check();
             S.t_gram += now_s() - tr0;
         }
@@ -729,7 +729,7 @@ struct TallPlan final : LassoPlan {
             add_diag<float>(M.get(), ldp, p, (float)rho, st);
             spd_inverse_f32(M.get(), ldp, p, st);
         }
-        ADMM_HIP_CHECK(hipStreamSynchronize(st));
+        comm_stream_sync(st);
         S.t_factor = now_s() - t0;
         // X itself is no longer needed by the loop (only X'y and Minv are): release 4np bytes.
         d.X.release();
@@ -805,7 +805,7 @@ struct TallPlan final : LassoPlan {
         // Pinned mirror of the control block for asynchronous polling.
         ADMM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&hctl), 2 * sizeof(TallCtl), hipHostMallocDefault));
         ADMM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&hbeta), (size_t)nlam * p * sizeof(float), hipHostMallocDefault));
-        ADMM_HIP_CHECK(hipStreamSynchronize(st));
+        comm_stream_sync(st);
     }
 
     void enable_trace(long long cap) override {
@@ -878,7 +878,7 @@ struct TallPlan final : LassoPlan {
         size_t nev = 0;                                                // events of ev_pool used by this run
         Event ev_loop0, ev_loop1, ev_poll[2];
 
-        ADMM_HIP_CHECK(hipStreamSynchronize(st));
+        comm_stream_sync(st);
         const CommLockstep lockstep;                                   // per-iteration exchanges: the short wait bound (comm.h)
         const double tl0 = now_s();
         ADMM_HIP_CHECK(hipEventRecord(ev_loop0.e, st));
@@ -993,14 +993,14 @@ struct TallPlan final : LassoPlan {
         bool done = false;
         while (!done) {
             if (use_graph) enqueue_batch_graph(slot ^ 1); else enqueue_batch(slot ^ 1);      // keep one batch in flight while polling the previous one
-            ADMM_HIP_CHECK(hipEventSynchronize(ev_poll[slot].e));
+            comm_event_sync(ev_poll[slot].e);
             comm_check();
             done = shard ? hctl[slot].done != 0 : *static_cast<volatile int*>(hflag.p) != 0;
             slot ^= 1;
             if (!done && g > max_total) throw Error(ADMM_ERR_INTERNAL, "tall path: iteration bound exceeded without completion");
         }
         ADMM_HIP_CHECK(hipEventRecord(ev_loop1.e, st));
-        ADMM_HIP_CHECK(hipStreamSynchronize(st));
+        comm_stream_sync(st);
         S.t_loop = now_s() - tl0;
         ADMM_HIP_CHECK(hipMemcpy(hctl, ctl.get(), 2 * sizeof(TallCtl), hipMemcpyDeviceToHost));      // both slots: decisions taken
 #ifdef ADMM_HIP_PROBE
@@ -1040,7 +1040,7 @@ struct TallPlan final : LassoPlan {
         res.niter.assign(nlam, 0);
         ADMM_HIP_CHECK(hipMemcpy(res.niter.data(), niter.get(), nlam * sizeof(int), hipMemcpyDeviceToHost));
         ADMM_HIP_CHECK(hipMemcpyAsync(hbeta, beta.get(), (size_t)nlam * p * sizeof(float), hipMemcpyDeviceToHost, st));
-        ADMM_HIP_CHECK(hipStreamSynchronize(st));
+        comm_stream_sync(st);
         res.beta.assign((size_t)(p + 1) * nlam, 0.f);
         long long tot_it = 0;
         for (int l = 0; l < nlam; ++l) {

@@ -1552,7 +1552,7 @@ struct WidePlan final : LassoPlan {
     }
     // the standardised data as this solver holds them (test hook admm_hip_lasso_plan_data_read)
     void read_data(float* x_out, long long ld, float* y_out) override {
-        ADMM_HIP_CHECK(hipStreamSynchronize(st));
+        comm_stream_sync(st);
         if (x_out) ADMM_HIP_CHECK(hipMemcpy2D(x_out, (size_t)ld * sizeof(float), d.X.get(), (size_t)d.ldx * sizeof(float), (size_t)n * sizeof(float), (size_t)p, hipMemcpyDeviceToHost));
         if (y_out) ADMM_HIP_CHECK(hipMemcpy(y_out, d.Y.get(), (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
     }
@@ -1587,7 +1587,7 @@ struct WidePlan final : LassoPlan {
                 ADMM_HIP_CHECK(hipMemcpyAsync(dm.get(), h.data(), ci.nranks * sizeof(float), hipMemcpyHostToDevice, st));
                 allreduce_sum_f32(dm.get(), (size_t)ci.nranks, st);
                 ADMM_HIP_CHECK(hipMemcpyAsync(h.data(), dm.get(), ci.nranks * sizeof(float), hipMemcpyDeviceToHost, st));
-                ADMM_HIP_CHECK(hipStreamSynchronize(st));
+                comm_stream_sync(st);
                 comm_check();
                 for (float v : h) lambda0 = std::max(lambda0, v);
             }
@@ -1601,7 +1601,7 @@ struct WidePlan final : LassoPlan {
         if (const char* e = std::getenv("ADMM_HIP_WIDE_SPRAD")) gram_free = !cshard && std::string(e) != "gram";
         if (gram_free) {
             GramFreeWideOp op(d.X.get(), d.ldx, n, p, st);
-            ADMM_HIP_CHECK(hipStreamSynchronize(st));
+            comm_stream_sync(st);
             S.t_gram = 0.0;
             int nmatop = 0;
             sprad = lanczos_largest_f32([&](const float* v, float* w) { op(v, w); }, n, &nmatop);
@@ -1611,7 +1611,7 @@ struct WidePlan final : LassoPlan {
             DevBuf<float> G((size_t)ldg * n); G.zero(st);
             gram_full<float>(d.X.get(), d.ldx, n, p, false, G.get(), ldg, st);
             if (cshard) allreduce_sum_f32(G.get(), (size_t)ldg * n, st);       // X X' = sum over the ranks' column blocks
-            ADMM_HIP_CHECK(hipStreamSynchronize(st));
+            comm_stream_sync(st);
             comm_check();
             S.t_gram = now_s() - t0; t0 = now_s();
             SymMatVec<float> op(G.get(), ldg, n, st);
@@ -1694,7 +1694,7 @@ struct WidePlan final : LassoPlan {
         q.probe = probe.get();
 #endif
         setup_persist_rows();
-        ADMM_HIP_CHECK(hipStreamSynchronize(st));
+        comm_stream_sync(st);
     }
 
     // persistent active-set stretch (wide_rows_persist_kernel)
@@ -1791,7 +1791,7 @@ struct WidePlan final : LassoPlan {
             if (herr) {
                 persist_rows = false;
                 rstat.zero(st);
-                ADMM_HIP_CHECK(hipStreamSynchronize(st));
+                comm_stream_sync(st);
                 run(res);
                 res.stats.persist_iter = -1;
                 return;
@@ -1828,7 +1828,7 @@ struct WidePlan final : LassoPlan {
             hipLaunchKernelGGL(wide_beta_count_kernel, dim3(nlam), dim3(256), 0, st, beta.get(), p, dcnt.get());
             std::vector<int> hcnt(nlam);
             ADMM_HIP_CHECK(hipMemcpyAsync(hcnt.data(), dcnt.get(), (size_t)nlam * sizeof(int), hipMemcpyDeviceToHost, st));
-            ADMM_HIP_CHECK(hipStreamSynchronize(st));
+            comm_stream_sync(st);
             std::vector<long long> hoff(nlam + 1, 0);
             for (int l = 0; l < nlam; ++l) hoff[l + 1] = hoff[l] + hcnt[l];
             const size_t tot_nz = (size_t)hoff[nlam];
@@ -1844,7 +1844,7 @@ struct WidePlan final : LassoPlan {
                 read_back(hval.data(), dval.get(), tot_nz * sizeof(float), st);
             }
             std::memset(res.beta_dst, 0, pt1 * nlam * sizeof(float));
-            ADMM_HIP_CHECK(hipStreamSynchronize(st));
+            comm_stream_sync(st);
             for (int l = 0; l < nlam; ++l) {
                 float b0 = 0.f;
                 recover_coef_sparse<float>(d, hidx.data() + hoff[l], hval.data() + hoff[l], hcnt[l], &b0, res.beta_dst + (size_t)l * pt1 + 1);
@@ -1877,7 +1877,7 @@ struct WidePlan final : LassoPlan {
             allreduce_sum_f64(di.get(), (size_t)nlam, st);
             read_back(res.beta.data(), db.get(), res.beta.size() * sizeof(float), st);
             ADMM_HIP_CHECK(hipMemcpyAsync(icpt.data(), di.get(), nlam * sizeof(double), hipMemcpyDeviceToHost, st));
-            ADMM_HIP_CHECK(hipStreamSynchronize(st));
+            comm_stream_sync(st);
             comm_check();
             for (int l = 0; l < nlam; ++l) res.beta[(size_t)l * pt1] = has_icpt ? (float)((double)d.meanY - icpt[l]) : 0.f;
         }

@@ -57,7 +57,7 @@ inline LoopTimes run_until_done(hipStream_t st, const int* d_done, int batch, lo
     bool done = false;
     while (!done) {
         enqueue_batch(slot ^ 1);
-        ADMM_HIP_CHECK(hipEventSynchronize(poll[slot].e));
+        comm_event_sync(poll[slot].e);
         comm_check();                                  // a timed-out exchange ends the solve with ADMM_ERR_COMM
         done = h_flag ? (*h_flag != 0) : (h_done[slot] != 0);
         slot ^= 1;
@@ -66,7 +66,7 @@ inline LoopTimes run_until_done(hipStream_t st, const int* d_done, int batch, lo
             throw Error(ADMM_ERR_INTERNAL, "ADMM loop: iteration bound exceeded without completion");
     }
     ADMM_HIP_CHECK(hipEventRecord(ev1.e, st));
-    ADMM_HIP_CHECK(hipStreamSynchronize(st));
+    comm_stream_sync(st);
     t.wall_s = now_s() - t0;
     float ms = 0.f;
     ADMM_HIP_CHECK(hipEventElapsedTime(&ms, ev0.e, ev1.e));

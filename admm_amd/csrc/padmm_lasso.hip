@@ -594,7 +594,7 @@ struct ParPlan final : LassoPlan {
         // lambda_0 from the full data (PADMMLasso.h:161)
         DevBuf<float> XY(ldv); XY.zero(st);
         gemv_t_simple<float>(d.X.get(), d.ldx, n, p, d.Y.get(), XY.get(), st);
-        if (pb.dist) { allreduce_sum_f32(XY.get(), p, st); ADMM_HIP_CHECK(hipStreamSynchronize(st)); }
+        if (pb.dist) { allreduce_sum_f32(XY.get(), p, st); comm_stream_sync(st); }
         const float lambda0 = device_absmax<float>(XY.get(), p, st);
         lam_user = make_lambda_grid(pb, lambda0, (int)nt, (double)d.scaleY);
         nlam = (int)lam_user.size();
@@ -626,7 +626,7 @@ struct ParPlan final : LassoPlan {
                 w.ldm = round_up(p, 128);                      // whole 128-blocks for the matrix-core inverse
                 w.Minv.alloc((size_t)w.ldm * w.ldm); w.Minv.zero(st);
                 gram_full<float>(w.A.get(), w.lda, w.rows, p, true, w.Minv.get(), w.ldm, st);
-                ADMM_HIP_CHECK(hipStreamSynchronize(st));
+                comm_stream_sync(st);
                 t_gram += now_s() - t0; t0 = now_s();
                 par_inverse(w.Minv.get(), w.ldm, p, rho, st);
                 w.gM.init(w.Minv.get(), w.ldm, p, p);
@@ -635,7 +635,7 @@ struct ParPlan final : LassoPlan {
                 w.ldm = round_up(w.rows, 128);
                 w.Minv.alloc((size_t)w.ldm * w.ldm); w.Minv.zero(st);
                 gram_full<float>(w.A.get(), w.lda, w.rows, p, false, w.Minv.get(), w.ldm, st);
-                ADMM_HIP_CHECK(hipStreamSynchronize(st));
+                comm_stream_sync(st);
                 t_gram += now_s() - t0; t0 = now_s();
                 if (onepass) {                               // the float Gram itself, for the residual of the small solve (par_wb_resid_kernel)
                     w.G.alloc((size_t)w.ldm * w.ldm);
@@ -652,7 +652,7 @@ struct ParPlan final : LassoPlan {
                 w.gA.init(w.A.get(), w.lda, w.rows, p);
                 w.tvec.alloc(w.ldm); w.svec.alloc(w.ldm); w.tvec.zero(st); w.svec.zero(st);
             }
-            ADMM_HIP_CHECK(hipStreamSynchronize(st));
+            comm_stream_sync(st);
             t_fac += now_s() - t0;
         }
         S.t_gram = t_gram; S.t_factor = t_fac;
@@ -732,9 +732,9 @@ struct ParPlan final : LassoPlan {
             ADMM_HIP_CHECK(hipMemcpyAsync(bG.get(), hG0.data(), Kl * sizeof(GatherArgs<float>), hipMemcpyHostToDevice, st));
             hipLaunchKernelGGL((gather_batch_kernel<float>), dim3(gather_tiles, gp.ngroups, Kl), dim3(kGatherThreads), 0, st, bG.get());
             hipLaunchKernelGGL(par_wb_c_kernel, dim3((Kl * wb_ld + 255) / 256), dim3(256), 0, st, q, cv.get());
-            ADMM_HIP_CHECK(hipStreamSynchronize(st));              // hG0 is a host temporary; the per-iteration blocks replace it
+            comm_stream_sync(st);              // hG0 is a host temporary; the per-iteration blocks replace it
             ADMM_HIP_CHECK(hipMemcpyAsync(bG.get(), hG.data(), Kl * sizeof(GatherArgs<float>), hipMemcpyHostToDevice, st));
-            ADMM_HIP_CHECK(hipStreamSynchronize(st));
+            comm_stream_sync(st);
         }
         // ---- batched launches of the workers' products (ADMM_HIP_PAR_BATCH=0: one launch per worker and product, as before)
         {
@@ -772,7 +772,7 @@ struct ParPlan final : LassoPlan {
                 batched = true;
             }
         }
-        ADMM_HIP_CHECK(hipStreamSynchronize(st));
+        comm_stream_sync(st);
     }
 
     static void A_release_if_tall(ParWorker& w) { w.A.release(); }   // a tall block only needs A'b and the inverse

@@ -302,7 +302,7 @@ void upload_standardize(DeviceData<T>& d, const double* x, const double* y, int 
         write_device(ystage.get(), y, (size_t)n * sizeof(double));
         th += now_s() - t1;
         hipLaunchKernelGGL((convert_cols_kernel<T>), dim3(1, ny), dim3(256), 0, st, ystage.get(), (long long)n, n, d.Y.get(), d.ldx);
-        ADMM_HIP_CHECK(hipStreamSynchronize(st));
+        comm_stream_sync(st);
     }
     d.meanX.assign(p, T(0));
     d.scaleX.assign(p, T(1));
@@ -322,12 +322,12 @@ void upload_standardize(DeviceData<T>& d, const double* x, const double* y, int 
         std::vector<T> hm(cnt), hs(cnt);
         ADMM_HIP_CHECK(hipMemcpyAsync(hm.data(), mean.get(), cnt * sizeof(T), hipMemcpyDeviceToHost, st));
         ADMM_HIP_CHECK(hipMemcpyAsync(hs.data(), scale.get(), cnt * sizeof(T), hipMemcpyDeviceToHost, st));
-        ADMM_HIP_CHECK(hipStreamSynchronize(st));
+        comm_stream_sync(st);
         if (d.flag & 2) { for (int j = 0; j < p; ++j) d.meanX[j] = hm[j]; d.meanY = hm[p]; }
         if (d.flag & 1) for (int j = 0; j < p; ++j) d.scaleX[j] = hs[j];
         d.scaleY = hs[p];
     }
-    ADMM_HIP_CHECK(hipStreamSynchronize(st));
+    comm_stream_sync(st);
     d.t_h2d = th;
     d.t_std = now_s() - t0 - th;
 }
@@ -355,7 +355,7 @@ void standardize_response_f32(const double* y_dev, int n, int flag, long long n_
         T hm = 0, hs = 1;
         ADMM_HIP_CHECK(hipMemcpyAsync(&hm, mean.get(), sizeof(T), hipMemcpyDeviceToHost, st));
         ADMM_HIP_CHECK(hipMemcpyAsync(&hs, scale.get(), sizeof(T), hipMemcpyDeviceToHost, st));
-        ADMM_HIP_CHECK(hipStreamSynchronize(st));
+        comm_stream_sync(st);
         if (flag & 2) *meanY = hm;
         *scaleY = hs;
     }
@@ -379,7 +379,7 @@ void clone_with_response_f32(DeviceData<float>& d, const DeviceData<float>& base
         d.t_gram_tail = 0;
     }
     ADMM_HIP_CHECK(hipGetLastError());
-    ADMM_HIP_CHECK(hipStreamSynchronize(st));
+    comm_stream_sync(st);
 }
 
 template void upload_standardize<double>(DeviceData<double>&, const double*, const double*, int, int, int, bool, bool, hipStream_t, long long);
@@ -433,7 +433,7 @@ void upload_standardize_gram_f32(DeviceData<float>& d, const double* x, const do
         th += now_s() - t1;
         hipLaunchKernelGGL((convert_cols_kernel<T>), dim3(1, ny), dim3(256), 0, st, ystage.get(), (long long)n, n, d.Y.get(), d.ldx);
         standardise_cols(0, 0, true, st);
-        ADMM_HIP_CHECK(hipStreamSynchronize(st));
+        comm_stream_sync(st);
     }
     // x: chunks of whole 128-column blocks (about 400 MB) through two staging buffers.  Chunks alternate between two
     // streams so that the block rows of consecutive chunks (each too few tiles to fill the chip) overlap when the GPU
@@ -484,12 +484,12 @@ void upload_standardize_gram_f32(DeviceData<float>& d, const double* x, const do
         std::vector<T> hm(cnt), hs(cnt);
         ADMM_HIP_CHECK(hipMemcpyAsync(hm.data(), mean.get(), cnt * sizeof(T), hipMemcpyDeviceToHost, st));
         ADMM_HIP_CHECK(hipMemcpyAsync(hs.data(), scale.get(), cnt * sizeof(T), hipMemcpyDeviceToHost, st));
-        ADMM_HIP_CHECK(hipStreamSynchronize(st));
+        comm_stream_sync(st);
         if (d.flag & 2) { for (int j = 0; j < p; ++j) d.meanX[j] = hm[j]; d.meanY = hm[p]; }
         if (d.flag & 1) for (int j = 0; j < p; ++j) d.scaleX[j] = hs[j];
         d.scaleY = hs[p];
     }
-    ADMM_HIP_CHECK(hipStreamSynchronize(st));
+    comm_stream_sync(st);
     d.t_gram_tail = now_s() - t_last;
     d.t_h2d = th;
     d.t_std = t_last - t0 - th;                    // host time between copies (launch overhead; the kernels overlap the copies)
@@ -642,7 +642,7 @@ template void gram_full<double>(const double*, long long, int, int, bool, double
 static void check_info(const DevBuf<rocblas_int>& info, hipStream_t st, const char* what) {
     rocblas_int h = 0;
     ADMM_HIP_CHECK(hipMemcpyAsync(&h, info.get(), sizeof(h), hipMemcpyDeviceToHost, st));
-    ADMM_HIP_CHECK(hipStreamSynchronize(st));
+    comm_stream_sync(st);
     if (h != 0) throw Error(ADMM_ERR_NOT_SPD, std::string(what) + ": matrix is not positive definite (info=" + std::to_string(h) + ")");
 }
 
@@ -702,7 +702,7 @@ void spd_inverse_full(T* A, long long lda, int n, hipStream_t st) {
     }
     hipLaunchKernelGGL((mirror_lower_kernel<T>), dim3((n + 255) / 256, n), dim3(256), 0, st, X.get(), (long long)n, A, lda, n);
     ADMM_HIP_CHECK(hipGetLastError());
-    ADMM_HIP_CHECK(hipStreamSynchronize(st));        // X is released on return
+    comm_stream_sync(st);        // X is released on return
 }
 template void spd_inverse_full<float>(float*, long long, int, hipStream_t);
 
@@ -735,7 +735,7 @@ void spd_inverse_f32_via_f64(float* A, long long lda, int n, double diag, hipStr
     spd_inverse_f64(D.get(), lda, n, st);
     hipLaunchKernelGGL(narrow_kernel, dim3((unsigned)((lda + 255) / 256), pp), dim3(256), 0, st, D.get(), A, lda, n);
     ADMM_HIP_CHECK(hipGetLastError());
-    ADMM_HIP_CHECK(hipStreamSynchronize(st));
+    comm_stream_sync(st);
 }
 
 void spd_inverse_f32(float* A, long long lda, int n, hipStream_t st) {
@@ -803,7 +803,7 @@ T device_absmax(const T* v, int n, hipStream_t st) {
     hipLaunchKernelGGL((absmax_kernel<T>), dim3(1), dim3(1024), 0, st, v, n, out.get());
     T h;
     ADMM_HIP_CHECK(hipMemcpyAsync(&h, out.get(), sizeof(T), hipMemcpyDeviceToHost, st));
-    ADMM_HIP_CHECK(hipStreamSynchronize(st));
+    comm_stream_sync(st);
     return h;
 }
 template float device_absmax<float>(const float*, int, hipStream_t);
@@ -816,7 +816,7 @@ void gemv_t_simple(const T* A, long long lda, int m, int k, const T* v, T* y, hi
     DevBuf<T> part((size_t)pl.nseg * stride);
     launch_gemv_t<T, 1, 4>(pl, A, lda, m, k, v, nullptr, part.get(), nullptr, stride, nullptr, st);
     hipLaunchKernelGGL((reduce_partials_kernel<T>), dim3((k + 255) / 256), dim3(256), 0, st, part.get(), stride, pl.nseg, k, y);
-    ADMM_HIP_CHECK(hipStreamSynchronize(st));   // part is freed on return
+    comm_stream_sync(st);   // part is freed on return
 }
 template void gemv_t_simple<float>(const float*, long long, int, int, const float*, float*, hipStream_t);
 template void gemv_t_simple<double>(const double*, long long, int, int, const double*, double*, hipStream_t);

@@ -1285,7 +1285,7 @@ static void sbp_sprad_batch(const double* A, long long lda, int n, const std::ve
     enqueue_group(0);
     for (size_t g = 0; g < gend.size() && left > 0; ++g) {
         if (g + 1 < gend.size()) enqueue_group(g + 1);
-        ADMM_HIP_CHECK(hipEventSynchronize(ev[g].e));
+        comm_event_sync(ev[g].e);
         const int s0 = g == 0 ? 0 : gend[g - 1], s1 = gend[g];
         std::vector<std::exception_ptr> err(B);
         std::vector<char> now(B, 0);
@@ -1304,7 +1304,7 @@ static void sbp_sprad_batch(const double* A, long long lda, int n, const std::ve
             if (now[b]) { fin[b] = 1; --left; }
         }
     }
-    ADMM_HIP_CHECK(hipStreamSynchronize(st));                        // (a group may still be running: its buffers go out of scope here)
+    comm_stream_sync(st);                        // (a group may still be running: its buffers go out of scope here)
     ADMM_HIP_CHECK(hipGetLastError());
 }
 
@@ -1365,7 +1365,7 @@ void solve_parbp(const DeviceData<double>& d, const admm_opts& opts, int nblocks
         ADMM_HIP_CHECK(hipMemcpyAsync(t.get(), sprad.data(), (size_t)N * sizeof(double), hipMemcpyHostToDevice, st));
         allreduce_sum_f64(t.get(), (size_t)N, st);
         ADMM_HIP_CHECK(hipMemcpyAsync(sprad.data(), t.get(), (size_t)N * sizeof(double), hipMemcpyDeviceToHost, st));
-        ADMM_HIP_CHECK(hipStreamSynchronize(st));
+        comm_stream_sync(st);
         comm_check();
     }
     double avg = 0;
@@ -1416,10 +1416,10 @@ void solve_parbp(const DeviceData<double>& d, const admm_opts& opts, int nblocks
     {
         std::vector<double> hz(n), hy(n);
         ADMM_HIP_CHECK(hipMemcpyAsync(hy.data(), d.Y.get(), (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
-        ADMM_HIP_CHECK(hipStreamSynchronize(st));
+        comm_stream_sync(st);
         for (int i = 0; i < n; ++i) { hz[i] = hy[i] / (double)N; zz += hz[i] * hz[i]; }
         h2d(zbar.get(), hz.data(), (size_t)n * sizeof(double));
-        ADMM_HIP_CHECK(hipStreamSynchronize(st));
+        comm_stream_sync(st);
     }
     SbpCtl c0ctl{};
     c0ctl.rp = c0ctl.rd = 9999.0;
@@ -1481,7 +1481,7 @@ void solve_parbp(const DeviceData<double>& d, const admm_opts& opts, int nblocks
             a.skip = d_done.get(); a.only_if = g_ust.get() + 2;
         }
         h2d(g_args.get(), ha.data(), ha.size() * sizeof(GatherArgs<double>));
-        ADMM_HIP_CHECK(hipStreamSynchronize(st));                   // (ha leaves scope)
+        comm_stream_sync(st);                   // (ha leaves scope)
     }
 
     const bool big = npad > 8192;                                  // the x-update's row slice per thread: 16 rows up to npad = 8192, 32 beyond
@@ -1505,7 +1505,7 @@ void solve_parbp(const DeviceData<double>& d, const admm_opts& opts, int nblocks
         }
     }
     const bool nt = (double)lda * (double)pl * 8.0 > 220e6;       // as gemv_plan.h: beyond what the 256 MB Infinity Cache keeps
-    ADMM_HIP_CHECK(hipStreamSynchronize(st));
+    comm_stream_sync(st);
     const size_t ldsv = (size_t)npad * sizeof(double);
     const bool gram_on = gram;
     bool carry_on = true;                                          // 0: every Gram-space stretch starts from the direct launches' n-vectors (A/B)

@@ -351,7 +351,7 @@ static std::vector<std::vector<int>> square_tile_lists(int nb) {
 static DevBuf<int> upload_ints(const std::vector<int>& v, hipStream_t st) {
     DevBuf<int> d(std::max<size_t>(v.size(), 1));
     if (!v.empty()) ADMM_HIP_CHECK(hipMemcpyAsync(d.get(), v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice, st));
-    ADMM_HIP_CHECK(hipStreamSynchronize(st));
+    comm_stream_sync(st);
     return d;
 }
 
@@ -469,7 +469,7 @@ void gram_mfma_f32(const float* A, long long lda, int rows, int cols, bool atA, 
         DevBuf<int> tmap = make_square_tilemap(nb, st);
         z3.gram_lower(C, ldc, tmap.get(), ntiles, st);
         ADMM_HIP_CHECK(hipGetLastError());
-        ADMM_HIP_CHECK(hipStreamSynchronize(st));
+        comm_stream_sync(st);
         return;
     }
     const int nk = (int)round_up(Kd, (long long)SK_BK * ksplit);
@@ -486,7 +486,7 @@ void gram_mfma_f32(const float* A, long long lda, int rows, int cols, bool atA, 
         } else if (et && std::string(et) == "0") {
             DevBuf<int> tmap = make_square_tilemap(nb, st);
             launch_gemm_nt(true, Z.get(), ldz, Z.get(), ldz, C, ldc, M, M, nk, 1.f, 0.f, true, false, st, 1, 0, tmap.get());
-            ADMM_HIP_CHECK(hipStreamSynchronize(st));
+            comm_stream_sync(st);
         } else {
             std::vector<int> full, quarters;
             int wg_per_cu = 2;                               // resident workgroups per CU (registers / LDS: 4 as compiled today)
@@ -496,10 +496,10 @@ void gram_mfma_f32(const float* A, long long lda, int rows, int cols, bool atA, 
             DevBuf<int> tmap = upload_ints(full, st), qmap = upload_ints(quarters, st);
             launch_gemm_nt(true, Z.get(), ldz, Z.get(), ldz, C, ldc, M, M, nk, 1.f, 0.f, true, false, st, 1, 0, tmap.get(), (int)full.size(),
                            qmap.get(), (int)quarters.size());
-            ADMM_HIP_CHECK(hipStreamSynchronize(st));
+            comm_stream_sync(st);
         }
         ADMM_HIP_CHECK(hipGetLastError());
-        ADMM_HIP_CHECK(hipStreamSynchronize(st));      // Z and the tile map are freed on return
+        comm_stream_sync(st);      // Z and the tile map are freed on return
         return;
     }
     const long long stride = ldz * ldz;
@@ -507,7 +507,7 @@ void gram_mfma_f32(const float* A, long long lda, int rows, int cols, bool atA, 
     launch_gemm_nt(true, Z.get(), ldz, Z.get(), ldz, part.get(), ldz, M, M, nk, 1.f, 0.f, false, false, st, ksplit, stride);
     hipLaunchKernelGGL(sum_splits_mirror_kernel, dim3((M + 255) / 256, M), dim3(256), 0, st, part.get(), ldz, stride, ksplit, C, ldc, M);
     ADMM_HIP_CHECK(hipGetLastError());
-    ADMM_HIP_CHECK(hipStreamSynchronize(st));
+    comm_stream_sync(st);
 }
 
 // Block row of a Gram matrix, for the pipelined host-input setup: C[r0 : r0 + nr, 0 : r0 + nr] = Z[r0 : r0 + nr, :] Z[0 : r0 + nr, :]'
@@ -538,7 +538,7 @@ void spd_inverse_mfma_f32_dist(float* A, long long lda, int p, const std::vector
     launch_gemm_nt(true, U.get(), lda, U.get(), lda, A, lda, p, p, pp, 1.f, 0.f, false, true, st, 1, 0, tmap.get(), (int)need.size());
     for (int m : need) { const int bi = m >> 16; fl += 2.0 * 128 * 128 * (double)(pp - bi * 128); }
     ADMM_HIP_CHECK(hipGetLastError());
-    ADMM_HIP_CHECK(hipStreamSynchronize(st));
+    comm_stream_sync(st);
     if (flops) *flops = fl;
 }
 

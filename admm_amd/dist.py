@@ -53,6 +53,16 @@ def init_comm(nranks=1, rank=0, broadcast=None):
     check(lib.admm_hip_comm_init(int(nranks), int(rank), buf.ctypes.data))
 
 
+def comm_info():
+    """(nranks, rank, backend name) of the communicator the library REALLY holds (admm_hip_comm_info): RCCL's own count of the live
+    communicator, the ranks attached to the SHM segment, the PEER buffers mapped -- (1, 0, "none") when nothing is attached."""
+    import ctypes
+    lib = _lib.load()
+    n, r, b = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    check(lib.admm_hip_comm_info(ctypes.byref(n), ctypes.byref(r), ctypes.byref(b)))
+    return n.value, r.value, {0: "none", 1: "rccl", 2: "shm", 3: "peer"}[b.value]
+
+
 def init_comm_from_torch(device=None):
     """Bootstrap over an initialised torch.distributed process group (gloo or nccl)."""
     import torch

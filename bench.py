@@ -15,13 +15,20 @@ runs once before the timed region and is reported separately as `setup_s`; `sec_
 setup + one path.  value = sum of ADMM iterations of the K timed steps (over all ranks) divided
 by the max-over-ranks wall time of the timed region.
 
-N > 1: the serial tall solver does not shard in the reference ("replicas only", SURVEY.md 8e);
-each rank runs an independent replica (its own synthetic problem) -> "scaling": "weak", no
-data-path collective.  One process per GPU (torch.distributed / RCCL for the barriers only).
-The path that DOES have an exchange step -- the row-block consensus solver -- is measured beside
-it in a side run (`consensus` object: BASELINE configs[3] shape, K = N row blocks, rows sharded
-over the N GPUs, one grouped RCCL all-reduce per iteration), executed in child processes with a
-time limit so that it can never invalidate the primary line.
+N > 1 (one process per GPU; `python bench.py --gpus N` started WITHOUT a launcher re-executes itself under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`, and a WORLD_SIZE that
+disagrees with --gpus is refused -- a line saying n_gpus: 1 can not come out of a --gpus 8 call):
+  * primary line = the headline workload itself with its x-update spread over the N GPUs (1/N of the
+    inverse's lower-triangle tiles per rank, ONE all-reduce of 2p floats per ADMM iteration, RCCL or the
+    hand-written peer-mapped exchange -- the better of the two valid runs) -> "scaling": "strong".  A sharded run
+    only counts when its communicator really held N ranks, the ranks agreed on every iteration count and every
+    lambda converged; otherwise the line falls back to the replica figure and says so (`parallelism`).
+  * `replicas_weak`: N independent replicas of the single-GPU solver (what the reference's serial solver offers,
+    SURVEY.md 8e "replicas only"), no data-path collective.
+  * side objects, each from time-limited child processes with their own rendezvous so that a failing exchange can
+    never take the primary line down: `exchange_self_check` (both back-ends against a closed-form sum, first),
+    `consensus` (BASELINE configs[3]: 8 row blocks spread over the ranks, one grouped all-reduce of p floats per
+    iteration), `wide_column_sharded` (configs[2] with its columns spread over the ranks, all-reduce of n floats).
 
 Extra objects on the JSON line: `roofline` for the dominant kernel (the x-update mat-vec: 2*p^2
 algorithmic bytes per launch for the symmetric lower-triangle kernel, 4*p^2 for the full-matrix
@@ -42,6 +49,32 @@ sys.path.insert(0, ROOT)
 HBM_PEAK = 8.0e12   # B/s, MI355X spec (MI355X_MICROARCH.md)
 # test hook: take every multi-rank branch (process groups, all-reduces, consensus children) with WORLD_SIZE=1
 FORCE_DIST = os.environ.get("ADMM_BENCH_FORCE_DIST") == "1"
+# test hook: ranks share devices (local_rank modulo the device count) and the control plane runs over gloo -- the self-spawned
+# N > 1 launch executed on a one-GPU box (tests/test_gpu_bench_children.py)
+OVERSUBSCRIBE = os.environ.get("ADMM_BENCH_OVERSUBSCRIBE") == "1"
+
+
+def self_spawn(a):
+    """`python bench.py --gpus N` (N > 1) without a launcher: become `torch.distributed.run` with N ranks on this node (what the
+    driver's own command line does), after checking that N devices exist.  Never returns."""
+    import socket
+    import subprocess
+    r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True)
+    try:
+        ndev = int(r.stdout.strip().splitlines()[-1])
+    except Exception:                                        # noqa: BLE001
+        raise SystemExit("bench.py: could not count the visible GPUs: " + (r.stderr or r.stdout)[-300:])
+    if ndev < a.gpus and not OVERSUBSCRIBE:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but only {ndev} device(s) visible: refusing to run (no n_gpus: {ndev} line for a --gpus {a.gpus} call)")
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    argv = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write("[bench] --gpus %d without a launcher: re-executing as %s\n" % (a.gpus, " ".join(argv[1:9])))
+    sys.stderr.flush()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.execv(sys.executable, argv)
 
 
 def parse():
@@ -64,6 +97,7 @@ def parse():
                     help="time limit of each child run of the other BASELINE configs at N = 1 (C3 wide, C4 consensus, C5 LAD / BP, parbp; 0 disables them)")
     ap.add_argument("--cpu-config-seconds", type=float, default=6.0,
                     help="budget of EACH timed CPU leg (1 thread, all threads) of the other configs (0 disables their cpu_baseline)")
+    ap.add_argument("--exchanges", default="rccl,peer", help="exchange back-ends of the sharded / consensus child runs at N > 1 (comma-separated: rccl, peer)")
     ap.add_argument("--side-shapes", default="", help=argparse.SUPPRESS)      # test hook: "n,p" of the consensus child and "n,p,nl" of the wide child, ";"-separated (tests/test_gpu_bench_children.py)
     ap.add_argument("--child", default="", help=argparse.SUPPRESS)
     return ap.parse_args()
@@ -156,6 +190,8 @@ def _child_setup(backend):
     multi = world > 1 or FORCE_DIST
     import torch
     import torch.distributed as dist
+    if OVERSUBSCRIBE:
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if multi:
@@ -277,7 +313,7 @@ def consensus_child(a, backend, out_path):
         res = {"workload": "admm_lasso$parallel(8) n=10000 p=100000 (BASELINE configs[3]), 8 row blocks spread over the GPUs, 3 lambdas down to 0.3 lambda_max, run to convergence (maxit 4000)",
                "scaling": "strong",
                "converged": bool(all(int(v) <= 4000 for v in fit.niter)), "ranks_agree_on_niter": agree,
-               "exchange": backend, "n_gpus": world, "ranks_in_communicator": world, "K": K, "iterations": iters, "loop_s": loop_s,
+               "exchange": backend, "n_gpus": world, "ranks_in_communicator": adist.comm_info()[0], "K": K, "iterations": iters, "loop_s": loop_s,
                "iters_per_s": iters / loop_s, "ms_per_iter": loop_s / iters * 1e3, "setup_s": setup_s,
                "alg_bytes_per_gpu_per_iter": bytes_per_gpu, "achieved_GBps_per_gpu": bytes_per_gpu * iters / loop_s / 1e9,
                "allreduce_payload_bytes": 4 * p + 24, "niter": [int(v) for v in fit.niter]}
@@ -334,7 +370,7 @@ def tallshard_child(a, backend, out_path):
         x_ms = xms / max(1, xsamp)
         res = {"workload": "admm_lasso tall path (BASELINE configs[1]), x-update sharded over the ranks", "exchange": backend,
                "ranks_agree_on_niter": agree, "all_lambdas_converged": bool(int(max(fit.niter)) <= 10000),
-               "n_gpus": world, "ranks_in_communicator": world, "scaling": "strong", "steps": a.steps,
+               "n_gpus": world, "ranks_in_communicator": adist.comm_info()[0], "scaling": "strong", "steps": a.steps,
                "iterations_per_step": iters / a.steps, "elapsed_s": elapsed, "iters_per_s": iters / elapsed,
                "us_per_iter": elapsed / iters * 1e6, "loop_ms_events_per_step": loop_ms / a.steps, "setup_s": setup_s,
                "xupdate_share_avg_launch_ms": x_ms, "xupdate_share_alg_bytes": 2.0 * p * p / world,
@@ -394,7 +430,7 @@ def widecols_child(a, backend, out_path):
     agree = _ranks_agree(niter, torch, dist, multi, dev)
     if rank == 0:
         res = {"workload": "admm_lasso wide n=%d p=%d (BASELINE configs[2]), columns sharded over the ranks, %d-lambda path" % (n, p, nl),
-               "exchange": backend, "ranks_agree_on_niter": agree, "all_lambdas_converged": bool(int(niter.max()) <= 10000), "n_gpus": world, "ranks_in_communicator": world, "scaling": "strong", "iterations": iters,
+               "exchange": backend, "ranks_agree_on_niter": agree, "all_lambdas_converged": bool(int(niter.max()) <= 10000), "n_gpus": world, "ranks_in_communicator": adist.comm_info()[0], "scaling": "strong", "iterations": iters,
                "loop_s": loop_s, "iters_per_s": iters / loop_s, "us_per_iter": loop_s / iters * 1e6,
                "setup_s": st["t_total"] - st["t_loop"], "allreduce_payload_bytes": 4 * n, "niter_first": [int(v) for v in niter[:8]]}
         with open(out_path, "w") as f:
@@ -747,6 +783,8 @@ def main():
             return
         {"consensus": consensus_child, "tallshard": tallshard_child, "widecols": widecols_child, "exchcheck": exchcheck_child}[kind](a, backend, out_path)
         return
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_spawn(a)
     # The JSON line must be the only thing on stdout: libraries loaded below (RCCL prints a version banner to stdout when
     # its first communicator is created, flushed at exit) get stderr as their fd 1; the line goes to the saved descriptor.
     sys.stdout.flush()
@@ -755,15 +793,26 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: refusing to run (the line would misreport n_gpus)")
     multi = world > 1 or FORCE_DIST
     import torch                      # before libadmm_hip: one HIP runtime per process
     import torch.distributed as dist
+    ndev = torch.cuda.device_count()
+    if OVERSUBSCRIBE:                 # test hook: several ranks per device, control plane over gloo (RCCL refuses two ranks on one device)
+        local_rank = local_rank % max(1, ndev)
+    elif local_rank >= ndev:
+        raise SystemExit(f"bench.py: rank {rank} needs device {local_rank} but only {ndev} are visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if multi:
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if OVERSUBSCRIBE:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
+        if dist.get_world_size() != a.gpus:
+            raise SystemExit(f"bench.py: the process group holds {dist.get_world_size()} ranks, --gpus {a.gpus}")
+    rdev = torch.device("cpu") if OVERSUBSCRIBE else dev      # where the control-plane reductions of this function live
     os.environ["ADMM_HIP_PROFILE_STRIDE"] = str(a.profile_stride)
     import numpy as np
     from admm_amd import admm_lasso, DevicePtr, LassoPlan, load
@@ -825,7 +874,7 @@ def main():
     barrier()
     elapsed = time.time() - t0
     if multi:
-        t = torch.tensor([elapsed, float(iters)], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, float(iters)], dtype=torch.float64, device=rdev)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
@@ -837,8 +886,9 @@ def main():
     # ---- side measurements in child processes (own rendezvous, time-limited): the paths with a real exchange step
     consensus, shard = [], []
     exch = []
+    backends = tuple(b for b in a.exchanges.split(",") if b in ("rccl", "peer"))
     if multi:
-        for k, backend in enumerate(("rccl", "peer")):
+        for k, backend in enumerate(backends):
             exch.append(run_side_measurement(a, rank, world, "exchcheck", backend, 120.0, 5 + 6 * k))
             barrier()
         if rank == 0:
@@ -849,17 +899,15 @@ def main():
                                      "continuing with %s\n" % (c["exchange"], world, c.get("error", "sums differ from the closed form (relative error %.2e)" % c.get("worst_relative_error_rank0", float("nan"))),
                                                                  ", ".join(good) if good else "the replica figure only"))
     if a.consensus_seconds > 0:
-        consensus.append(run_side_measurement(a, rank, world, "consensus", "rccl", a.consensus_seconds, 17))
-        barrier()
-        if multi:
-            consensus.append(run_side_measurement(a, rank, world, "consensus", "peer", a.consensus_seconds, 29))
+        for k, backend in enumerate(backends if multi else ("rccl",)):
+            consensus.append(run_side_measurement(a, rank, world, "consensus", backend, a.consensus_seconds, 17 + 12 * k))
             barrier()
     widecols = []
     if multi and a.shard_seconds > 0:
-        for k, backend in enumerate(("rccl", "peer")):
+        for k, backend in enumerate(backends):
             shard.append(run_side_measurement(a, rank, world, "tallshard", backend, a.shard_seconds, 41 + 12 * k))
             barrier()
-        for k, backend in enumerate(("rccl", "peer")):
+        for k, backend in enumerate(backends):
             widecols.append(run_side_measurement(a, rank, world, "widecols", backend, a.shard_seconds, 71 + 12 * k))
             barrier()
     cfg_results = {}
@@ -941,7 +989,9 @@ def main():
             valid = []
             for c in ok:
                 why = None
-                if not c.get("ranks_agree_on_niter", True):
+                if int(c.get("ranks_in_communicator", 0)) != world or int(c.get("n_gpus", 0)) != world:
+                    why = "the communicator held %s ranks, not %d" % (c.get("ranks_in_communicator"), world)
+                elif not c.get("ranks_agree_on_niter", True):
                     why = "ranks disagree on the iteration counts"
                 elif not c.get("all_lambdas_converged", True):
                     why = "a lambda ran into maxit"
@@ -952,6 +1002,8 @@ def main():
                 else:
                     valid.append(c)
             ok = valid
+            if not ok:
+                out["config"]["parallelism"] = "replicas x%d (no sharded run was valid: see `sharded`)" % world
             if ok:
                 # N > 1: the primary line is the headline workload itself with its x-update spread over the N GPUs (total
                 # work fixed: strong scaling), over the better of the two exchanges; the independent-replica figure
@@ -964,6 +1016,7 @@ def main():
                 out["scaling"] = "strong"
                 out["config"]["parallelism"] = "x-update sharded over %d GPUs, one all-reduce of 2p floats per iteration (%s)" % (world, best["exchange"])
                 out["config"]["iters_per_step"] = best["iterations_per_step"]
+                out["config"]["ranks_in_communicator"] = best["ranks_in_communicator"]
                 out["setup_s"] = best["setup_s"]
                 out["sec_to_eps"] = best["setup_s"] + best["elapsed_s"] / best["steps"]
                 out["roofline"]["note"] = "single-GPU replica kernel; the sharded run's share is in `sharded`"

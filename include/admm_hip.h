@@ -307,6 +307,10 @@ ADMM_HIP_API int admm_hip_lasso_plan_state_read(admm_hip_plan* plan, float* out,
 ADMM_HIP_API int admm_hip_comm_unique_id(void* id_out);
 ADMM_HIP_API int admm_hip_comm_init(int nranks, int rank, const void* id);
 ADMM_HIP_API int admm_hip_comm_finalize(void);
+/* What the attached communicator REALLY holds (RCCL: ncclCommCount / ncclCommUserRank of the live communicator; SHM: ranks attached to
+ * the segment; PEER: exchange buffers mapped): *nranks_out = 1, *rank_out = 0, *backend_out = 0 when none is attached;
+ * backend 1 RCCL, 2 SHM, 3 PEER.  A launcher (bench.py) checks this against the number of GPUs it was asked to use. */
+ADMM_HIP_API int admm_hip_comm_info(int* nranks_out, int* rank_out, int* backend_out);
 /* Two more exchange backends behind the same entry points (one of the three is attached at a time; comm.h):
  *  - PEER: one-shot all-reduce over peer-mapped device memory.  Every rank calls admm_hip_comm_peer_prepare on its own
  *    device (allocates its exchange buffer, returns its ADMM_HIP_PEER_HANDLE_BYTES-byte hipIpc handle), the caller
@@ -319,6 +323,8 @@ ADMM_HIP_API int admm_hip_comm_finalize(void);
  * Every wait is bounded: the per-iteration exchanges of a solve by ADMM_HIP_COMM_TIMEOUT_S (20 s), setup reductions and
  * the one join of the replica modes (cross-validation folds, several responses -- ranks are unbalanced there by design) by
  * ADMM_HIP_COMM_PATIENT_TIMEOUT_S (one hour); a missing rank yields ADMM_ERR_COMM from the running call, never a hang.
+ * RCCL: the host waits of the solvers poll (stream / event queries + ncclCommGetAsyncError) under the same two bounds; on an
+ * asynchronous error or a timed-out wait the communicator is aborted (ncclCommAbort) and the call returns ADMM_ERR_COMM.
  * Ranks should synchronise (barrier) before admm_hip_comm_finalize. */
 #define ADMM_HIP_PEER_HANDLE_BYTES 64
 ADMM_HIP_API int admm_hip_comm_peer_prepare(int nranks, void* handle_out);

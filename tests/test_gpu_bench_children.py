@@ -76,3 +76,35 @@ def test_bench_exchange_self_check_as_two_processes():
         r = _run_child("exchcheck", b, timeout=180)
         assert r["exchange"] == b and r["ranks"] == 2 and r["all_ranks_correct"] is True, r
         assert r["worst_relative_error_rank0"] < 1e-6, r
+
+
+def test_bench_gpus2_without_a_launcher_spawns_its_ranks():
+    """`python bench.py --gpus 2` started WITHOUT torchrun and without WORLD_SIZE (round-5 review: it ran one GPU and printed n_gpus: 1):
+    it must re-execute itself under torch.distributed.run with two ranks and print a line that says n_gpus: 2, whose primary figure
+    comes from a sharded run whose communicator really held two ranks (admm_hip_comm_info).  One-GPU box: the two ranks share the
+    device (ADMM_BENCH_OVERSUBSCRIBE=1: local_rank modulo the device count, control plane over gloo) and only the PEER exchange runs
+    (RCCL refuses two ranks on one device)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(ADMM_BENCH_OVERSUBSCRIBE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--n", "24000", "--p", "2304", "--m", "100", "--nlambda", "12", "--steps", "1",
+           "--warmup", "1", "--exchanges", "peer", "--consensus-seconds", "0", "--shard-seconds", "240", "--cpu-seconds", "0",
+           "--side-shapes", "2000,20000;600,30000,8"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2, out
+    assert out["scaling"] == "strong" and out["config"]["ranks_in_communicator"] == 2, out["config"]
+    sh = [c for c in out["sharded"] if "error" not in c]
+    assert sh and all(c["ranks_in_communicator"] == 2 and c["n_gpus"] == 2 and "rejected" not in c for c in sh), out["sharded"]
+    assert out["replicas_weak"]["value"] > 0
+    assert [c for c in out["exchange_self_check"] if c["exchange"] == "peer"][0]["all_ranks_correct"] is True
+    print(f"[bench --gpus 2, self-spawned] {out['value']:.0f} it/s sharded over 2 ranks ({out['config']['parallelism']}); replicas {out['replicas_weak']['value']:.0f} it/s")
+
+
+def test_bench_refuses_a_world_size_that_disagrees_with_gpus():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout), (r.returncode, r.stderr[-500:])
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
