@@ -55,5 +55,8 @@ CommInfo comm_info_live();
 // (peer_device.h): no launches of the exchange layer itself.
 struct PeerExchange;
 PeerExchange comm_peer_begin(size_t payload_bytes);
+// PEER backend only: the AUX region (peer_device.h) for a kernel that exchanges many times inside ONE launch.
+struct PeerAux;
+PeerAux comm_peer_aux();
 
 }  // namespace admm

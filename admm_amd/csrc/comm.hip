@@ -177,6 +177,8 @@ struct PeerState {
     unsigned char* remote[kMaxRanks] = {};               // every rank's buffer as mapped here (remote[rank] == local)
     bool opened[kMaxRanks] = {};
     size_t bytes = 0, flags_off = 0;
+    size_t aux_data_off = 0, aux_flags_off = 0;          // the AUX region (peer_device.h): exchanges numbered on the device
+    unsigned long long* aux_seq = nullptr;               // device word
     unsigned int* count = nullptr;                       // [nranks] workgroup arrival counters of the push (device)
     unsigned char** d_remote = nullptr;                  // device copy of remote[]
 } g_peer;
@@ -319,6 +321,7 @@ void peer_close() {
         if (g_peer.opened[r] && g_peer.remote[r]) (void)hipIpcCloseMemHandle(g_peer.remote[r]);
     if (g_peer.local) (void)hipFree(g_peer.local);
     if (g_peer.count) (void)hipFree(g_peer.count);
+    if (g_peer.aux_seq) (void)hipFree(g_peer.aux_seq);
     if (g_peer.d_remote) (void)hipFree(g_peer.d_remote);
     g_peer = PeerState();
 }
@@ -326,7 +329,9 @@ void peer_close() {
 void peer_alloc_local(int nranks) {
     g_slot = slot_bytes_from_env();
     g_peer.flags_off = (size_t)2 * nranks * g_slot;
-    g_peer.bytes = g_peer.flags_off + (size_t)2 * nranks * 64;
+    g_peer.aux_data_off = g_peer.flags_off + (size_t)2 * nranks * 64;
+    g_peer.aux_flags_off = g_peer.aux_data_off + (size_t)2 * nranks * kAuxSlotBytes;
+    g_peer.bytes = g_peer.aux_flags_off + (size_t)2 * nranks * (kAuxGroups + 1) * 64;
     void* ptr = nullptr;
     // Fine-grained device memory: the HIP memory model makes system-scope release / acquire pairs (the flag protocol
     // below) order and publish plain accesses to it across agents, so stores arriving from a peer are never shadowed by
@@ -374,6 +379,15 @@ PeerExchange comm_peer_begin(size_t payload_bytes) {
     PeerExchange e;
     peer_fill(e);
     return e;
+}
+
+PeerAux comm_peer_aux() {
+    if (g_info.backend != COMM_PEER) throw Error(ADMM_ERR_COMM, "the PEER exchange is not attached");
+    PeerAux a;
+    a.remote = g_peer.d_remote; a.local = g_peer.local; a.data_off = g_peer.aux_data_off; a.flags_off = g_peer.aux_flags_off;
+    a.nranks = g_info.nranks; a.rank = g_info.rank; a.seq = g_peer.aux_seq; a.err = g_derr;
+    a.timeout_ticks = (long long)(wait_seconds_now() * 100e6);
+    return a;
 }
 
 CommInfo comm_info() {
@@ -624,6 +638,8 @@ void comm_init_peer(int nranks, int rank, const void* handles) {
     ADMM_HIP_CHECK(hipMemset(g_derr, 0, sizeof(int)));
     ADMM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g_peer.count), (nranks + 1) * sizeof(unsigned int)));
     ADMM_HIP_CHECK(hipMemset(g_peer.count, 0, (nranks + 1) * sizeof(unsigned int)));
+    ADMM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g_peer.aux_seq), sizeof(unsigned long long)));
+    ADMM_HIP_CHECK(hipMemset(g_peer.aux_seq, 0, sizeof(unsigned long long)));
     ADMM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g_peer.d_remote), nranks * sizeof(unsigned char*)));
     ADMM_HIP_CHECK(hipMemcpy(g_peer.d_remote, g_peer.remote, nranks * sizeof(unsigned char*), hipMemcpyHostToDevice));
     ADMM_HIP_CHECK(hipDeviceSynchronize());

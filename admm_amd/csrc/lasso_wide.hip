@@ -972,8 +972,17 @@ __device__ __forceinline__ float wr_load_f32(const float* p) {
 constexpr int kRRS = 256;                 // rows per row group
 constexpr int kRKRES = 24;                // register-resident columns per wave (float4 each: 96 registers)
 
+// CS (column-sharded solver, PEER exchange): the same stretch on this rank's column block.  Two things cross the ranks, both through
+// the AUX region of the exchange buffers (peer_device.h), numbered on the device:
+//   * once per launch, the AGREEMENT: every rank's count of active columns.  A stretch runs only if every rank can carry its list
+//     (and somebody has one); the hint that skips hopeless launches is formed from the largest count, so it is replicated too;
+//   * once per iteration, A x = sum over the ranks of the row group's 256 local sums: workgroup (r, 0) writes them into every rank's
+//     slot and raises the row group's flag there; every workgroup (r, c) of every rank waits for the nranks flags of ITS row group
+//     and adds the nranks shares in rank order -- identical sums on every rank and in every column group, so z, y, the norm shares
+//     and the decisions stay replicated bit for bit.  (The re-formed t after a rho change needs no exchange: A x, z, y are replicated.)
+template <bool CS>
 __global__ void __launch_bounds__(kRNW * 64)
-wide_rows_persist_kernel(WideParams q, int cpar, WideRows ps) {
+wide_rows_persist_kernel(WideParams q, int cpar, WideRows ps, PeerAux ax_) {
     if ((blockIdx.x & 7) != 0) return;
     const int g = blockIdx.x >> 3, G = ps.G, R = ps.R, C = ps.C;
     if (g >= G) return;
@@ -1005,6 +1014,9 @@ wide_rows_persist_kernel(WideParams q, int cpar, WideRows ps) {
     WideCtl out = wide_ctl_uniform(dec.out);
     if (out.done || out.type != W_ACT || __builtin_amdgcn_readfirstlane(dec.lam_finished) >= 0) { if (leader) { hout[0] = h_nnz; hout[1] = h_wait; } return; }
     const long long tick0 = wall_clock64();
+    // CS: the exchanges of this launch are numbered ebase + 1 (agreement), ebase + 2 (iteration 0), ...; the word is rewritten by the
+    // leader after every workgroup of the launch has read it (they all pass the hand-overs below first)
+    const unsigned long long ebase = CS ? __hip_atomic_load(ax_.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
 
     // ---- the active columns.  Workgroup g lists the non-zeros of ITS slice of x (two-pass ballot compaction: counts per (pass,
     // wave), exclusive prefix, ordered write), publishes count + list, and after the first hand-over of the launch every
@@ -1108,7 +1120,31 @@ wide_rows_persist_kernel(WideParams q, int cpar, WideRows ps) {
     }
     __syncthreads();
     const int nS = s_ns;
-    if (nS > kRCMAX || nS == 0) { if (leader) { hout[0] = (double)nS; hout[1] = 64.0; } return; }
+    int nS_all = nS;                                        // what the go / no-go and the hint are formed from (CS: the largest count of any rank)
+    if (CS) {
+        const unsigned long long e = ebase + 1;
+        if (g == 0 && wid == 0) {
+            for (int dst = lane; dst < ax_.nranks; dst += 64)
+                peer_store_u64(reinterpret_cast<unsigned long long*>(aux_slot(ax_.remote[dst], ax_, e, ax_.rank) + kAuxRows), (unsigned long long)(unsigned)nS);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (int dst = lane; dst < ax_.nranks; dst += 64)
+                peer_store_u64(aux_flag(ax_.remote[dst], ax_, e, ax_.rank, kAuxEntry), e);
+        }
+        if (!aux_wait(ax_, e, kAuxEntry)) { if (lane == 0) __hip_atomic_store(ps.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+        int mx = 0, any = 0;
+        for (int r0 = 0; r0 < ax_.nranks; r0 += 64) {
+            const int rr = r0 + lane;
+            const int v = rr < ax_.nranks ? (int)peer_load_u64(reinterpret_cast<const unsigned long long*>(aux_slot(ax_.local, ax_, e, rr) + kAuxRows)) : 0;
+            mx = max(mx, v); any |= v;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { mx = max(mx, __shfl_xor(mx, d, 64)); any |= __shfl_xor(any, d, 64); }
+        nS_all = any == 0 ? 0 : mx;
+    }
+    if (nS_all > kRCMAX || nS_all == 0) {
+        if (leader) { hout[0] = (double)nS_all; hout[1] = 64.0; if (CS) __hip_atomic_store(ax_.seq, ebase + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        return;
+    }
     for (int j = tid; j < nS; j += T) {
         int lo = 0, hi = G;                                 // the list j falls into: loff[lo] <= j < loff[lo + 1]
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (loff[mid] <= j) lo = mid; else hi = mid; }
@@ -1313,9 +1349,9 @@ wide_rows_persist_kernel(WideParams q, int cpar, WideRows ps) {
         if (!wait_for(hs, 1)) { failed = true; break; }
         WR_PHASE(3)
         double nacc[5] = {0, 0, 0, 0, 0};
+        float ax = 0.f;
         if (tid < RS) {
             const float* src = ps.pa + ((size_t)(k_done & 1) * G + (size_t)r * C) * RS + tid;      // workgroups (r, 0), (r, 1), ...
-            float ax = 0.f;
             for (int u0 = 0; u0 < C; u0 += 8) {             // the C partials in column-group order, eight requests in flight
                 float v[8];
 #pragma unroll
@@ -1323,6 +1359,33 @@ wide_rows_persist_kernel(WideParams q, int cpar, WideRows ps) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) ax = (u0 + u == 0) ? v[0] : (u0 + u < C ? ax + v[u] : ax);
             }
+        }
+        if (CS) {                                           // A x of these rows summed over the ranks                 [exchange over the links]
+            const unsigned long long e = ebase + 2 + k_done;
+            if (c == 0) {
+                if (tid < RS) {
+                    const float mine = own ? ax : 0.f;
+                    for (int dst = 0; dst < ax_.nranks; ++dst) peer_store_f32(aux_slot(ax_.remote[dst], ax_, e, ax_.rank) + r * RS + tid, mine);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (wid == 0)
+                    for (int dst = lane; dst < ax_.nranks; dst += 64) peer_store_u64(aux_flag(ax_.remote[dst], ax_, e, ax_.rank, r), e);
+            }
+            if (!aux_wait(ax_, e, r)) { if (lane == 0) __hip_atomic_store(ps.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); failed = true; break; }
+            if (tid < RS) {
+                float a = 0.f;
+                for (int u0 = 0; u0 < ax_.nranks; u0 += 8) {   // the ranks' shares in rank order, eight requests in flight
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = peer_load_f32(aux_slot(ax_.local, ax_, e, min(u0 + u, ax_.nranks - 1)) + r * RS + tid);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) a = (u0 + u == 0) ? v[0] : (u0 + u < ax_.nranks ? a + v[u] : a);
+                }
+                ax = a;
+            }
+        }
+        if (tid < RS) {
             if (own) {
 #pragma clang fp contract(off)
                 const float rho_f = (float)out.rho;
@@ -1416,7 +1479,8 @@ wide_rows_persist_kernel(WideParams q, int cpar, WideRows ps) {
     }
     if (failed) return;
     if (leader) {
-        hout[0] = (double)nS; hout[1] = 64.0;
+        if (CS) __hip_atomic_store(ax_.seq, ebase + 1 + k_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // agreement + one exchange per iteration made
+        hout[0] = (double)nS_all; hout[1] = 64.0;
         ps.stat[0] += k_done; ps.stat[1] += 1; ps.stat[2] += (unsigned long long)(wall_clock64() - tick0); ps.stat[3] += wt ? 1 : 0; ps.stat[4] += redo;
         ps.stat[5] += (unsigned long long)(tick1 - tick0);
         for (int i = 0; i < 8; ++i) ps.stat[6 + i] += (unsigned long long)ph[i];
@@ -1707,7 +1771,11 @@ struct WidePlan final : LassoPlan {
     unsigned long long rseq = 0;
     void setup_persist_rows() {
         // ADMM_HIP_WIDE_PERSIST=0: two launches per iteration only
-        persist_rows = !cshard && n <= kRRS * kRG && (long long)p <= 262144;
+        // column-sharded: only where the ranks exchange through peer-mapped memory (the stretch exchanges INSIDE its launch, which RCCL
+        // and the host shared-memory back-end cannot do); ADMM_HIP_WIDE_PERSIST_COLS=0 switches it off there alone
+        persist_rows = (!cshard || (peer_fused && ci.nranks <= 64)) && n <= kRRS * kRG && (long long)p <= 262144;
+        static_assert(kRRS * kRG <= kAuxRows && kRG <= kAuxGroups, "the AUX region carries one float per row, one flag per row group");
+        if (cshard) if (const char* e = std::getenv("ADMM_HIP_WIDE_PERSIST_COLS")) if (std::string(e) == "0") persist_rows = false;
         if (const char* e = std::getenv("ADMM_HIP_WIDE_PERSIST")) if (std::string(e) == "0") persist_rows = false;
         if (!persist_rows) return;
         rows_R = (n + kRRS - 1) / kRRS;                                     // row groups of 256 rows
@@ -1729,7 +1797,8 @@ struct WidePlan final : LassoPlan {
         ps.pd = rpd.get(); ps.np = rnp.get(); ps.err = rerr.get(); ps.seq = ++rseq; ps.stat = rstat.get(); ps.hint = rhint.get();
         ps.G = rows_G; ps.R = rows_R; ps.C = rows_C; ps.pa = rpa.get(); ps.diag = std::getenv("ADMM_HIP_WIDE_PERSIST_STATS") ? 1 : 0;
         ps.lst_idx = rli.get(); ps.lst_x = rlx.get(); ps.lcount = rlc.get();
-        hipLaunchKernelGGL(wide_rows_persist_kernel, dim3(8 * rows_G), dim3(kRNW * 64), 0, st, q, cpar, ps);
+        if (cshard) hipLaunchKernelGGL(wide_rows_persist_kernel<true>, dim3(8 * rows_G), dim3(kRNW * 64), 0, st, q, cpar, ps, comm_peer_aux());
+        else hipLaunchKernelGGL(wide_rows_persist_kernel<false>, dim3(8 * rows_G), dim3(kRNW * 64), 0, st, q, cpar, ps, PeerAux{});
     }
 
     void run(LassoResult& res) override {
@@ -1765,10 +1834,11 @@ struct WidePlan final : LassoPlan {
                 const PeerExchange ex = comm_peer_begin((size_t)ldn * sizeof(float));
                 if (peer_one) {
                     hipLaunchKernelGGL(wide_tail_kernel<2>, dim3(nwg_tail), dim3(kWideThreads), 0, st, q, par, ex);
-                    return;
+                } else {
+                    hipLaunchKernelGGL(wide_ax_push_kernel, dim3((unsigned)((ldn + kWtElems - 1) / kWtElems)), dim3(kWideThreads), 0, st, q, par, ex);
+                    hipLaunchKernelGGL(wide_tail_kernel<1>, dim3(nwg_tail), dim3(kWideThreads), 0, st, q, par, ex);
                 }
-                hipLaunchKernelGGL(wide_ax_push_kernel, dim3((unsigned)((ldn + kWtElems - 1) / kWtElems)), dim3(kWideThreads), 0, st, q, par, ex);
-                hipLaunchKernelGGL(wide_tail_kernel<1>, dim3(nwg_tail), dim3(kWideThreads), 0, st, q, par, ex);
+                if (persist_rows) launch_persist_rows(par ^ 1);          // the stretch on this rank's column block, its A x summed over the ranks inside the launch
                 return;
             }
             if (cshard) {                                              // the only exchange: A x summed over the ranks' column blocks
@@ -1788,6 +1858,8 @@ struct WidePlan final : LassoPlan {
             // workgroup, so one workgroup may have left without its write-back while the others completed theirs: the state behind
             // such a launch cannot be trusted.  The whole path is discarded and run again with the stretch switched off
             // for the rest of this plan's life; persist_iter = -1 in the stats of that run says so.
+            if (herr && cshard)                                         // (the ranks cannot agree on a re-run after the fact)
+                throw Error(ADMM_ERR_COMM, "column-sharded wide solver: a hand-over of the persistent stretch timed out (a rank missing, or the stretch's workgroups not co-resident); ADMM_HIP_WIDE_PERSIST_COLS=0 runs without it");
             if (herr) {
                 persist_rows = false;
                 rstat.zero(st);

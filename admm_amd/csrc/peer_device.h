@@ -87,6 +87,53 @@ __device__ __forceinline__ void peer_store_f32x2(float* p, float x, float y) {
     peer_store_u64(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__float_as_uint(x) | ((unsigned long long)__float_as_uint(y) << 32));
 }
 
+// ---- AUX region: exchanges INSIDE one launch (the persistent active-set stretch of the column-sharded wide solver).
+// The slots above are numbered by the host when it enqueues an exchange; a kernel that exchanges once per ADMM iteration for as many
+// iterations as the decisions allow cannot be numbered that way.  A second, small region of every rank's exchange buffer therefore
+// carries its own sequence: a DEVICE word (PeerAux::seq, replicated -- every rank performs the same exchanges because every rank
+// takes the same decisions) read by the launch when it starts and advanced by its leader when it ends.  Exchange e uses parity e & 1:
+//     data [2][nranks][kAuxRows floats | one 64-byte line for the agreement word]     flags [2][nranks][kAuxGroups + 1] lines
+// The payload is flagged per GROUP of 256 floats (a row group of the stretch proceeds as soon as ITS rows have arrived from every
+// rank).  Reuse of a parity is safe for the same reason as above, per group: rank A writes group r of e + 2 only after it consumed
+// group r of e + 1, which rank B published only after all of ITS readers of group r of e had moved on (lasso_wide.hip).
+constexpr int kAuxRows = 8192;
+constexpr int kAuxGroups = 32;
+constexpr int kAuxEntry = kAuxGroups;      // flag index of the once-per-launch agreement word
+constexpr size_t kAuxSlotBytes = (size_t)kAuxRows * sizeof(float) + 64;
+struct PeerAux {
+    unsigned char* const* remote; unsigned char* local;
+    size_t data_off, flags_off;
+    int nranks, rank;
+    unsigned long long* seq;            // device word: exchanges made through the region so far
+    int* err; long long timeout_ticks;
+};
+__device__ __forceinline__ float* aux_slot(unsigned char* buf, const PeerAux& a, unsigned long long e, int src) {
+    return reinterpret_cast<float*>(buf + a.data_off + ((size_t)(e & 1) * a.nranks + src) * kAuxSlotBytes);
+}
+__device__ __forceinline__ unsigned long long* aux_flag(unsigned char* buf, const PeerAux& a, unsigned long long e, int src, int idx) {
+    return reinterpret_cast<unsigned long long*>(buf + a.flags_off + (((size_t)(e & 1) * a.nranks + src) * (kAuxGroups + 1) + idx) * 64);
+}
+// every wave that needs group `idx` of exchange e calls this: lanes < nranks poll one rank's flag each (bounded)
+__device__ __forceinline__ bool aux_wait(const PeerAux& a, unsigned long long e, int idx) {
+    const int lane = threadIdx.x & 63;
+    bool ok = true;
+    for (int r = lane; r < a.nranks; r += 64) {
+        unsigned long long* f = aux_flag(a.local, a, e, r, idx);
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < e) {
+            __builtin_amdgcn_s_sleep(1);
+            if (wall_clock64() - t0 > a.timeout_ticks) { __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = false; break; }
+        }
+    }
+    return __all(ok) != 0;
+}
+__device__ __forceinline__ float peer_load_f32(const float* p) {
+    return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned int*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+}
+__device__ __forceinline__ unsigned long long peer_load_u64(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // Consumer prologue, called by every thread of the consuming launch before it reads the slots: lanes < nranks of every
 // wave spin (bounded) until the flag of their rank reads seq.  Returns false when the exchange failed (time limit).
 __device__ __forceinline__ bool peer_wait(const PeerExchange& e) {

@@ -69,8 +69,11 @@ def self_spawn(a):
     with socket.socket() as s_:
         s_.bind(("127.0.0.1", 0))
         port = s_.getsockname()[1]
+    # the launcher's own option parser looks at the script's arguments too (and rejects e.g. `--n` as an ambiguous abbreviation of its
+    # own options): only the three flags of the driver's contract travel on the command line, the full argument list in the environment
+    os.environ["ADMM_BENCH_ARGV"] = json.dumps(sys.argv[1:])
     argv = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
-            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+            "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(a.gpus), "--steps", str(a.steps), "--warmup", str(a.warmup)]
     sys.stderr.write("[bench] --gpus %d without a launcher: re-executing as %s\n" % (a.gpus, " ".join(argv[1:9])))
     sys.stderr.flush()
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -100,6 +103,8 @@ def parse():
     ap.add_argument("--exchanges", default="rccl,peer", help="exchange back-ends of the sharded / consensus child runs at N > 1 (comma-separated: rccl, peer)")
     ap.add_argument("--side-shapes", default="", help=argparse.SUPPRESS)      # test hook: "n,p" of the consensus child and "n,p,nl" of the wide child, ";"-separated (tests/test_gpu_bench_children.py)
     ap.add_argument("--child", default="", help=argparse.SUPPRESS)
+    if os.environ.get("ADMM_BENCH_ARGV") and "--child" not in sys.argv:      # a self-spawned rank (self_spawn): the original argument list
+        return ap.parse_args(json.loads(os.environ["ADMM_BENCH_ARGV"]))
     return ap.parse_args()
 
 
@@ -432,7 +437,8 @@ def widecols_child(a, backend, out_path):
         res = {"workload": "admm_lasso wide n=%d p=%d (BASELINE configs[2]), columns sharded over the ranks, %d-lambda path" % (n, p, nl),
                "exchange": backend, "ranks_agree_on_niter": agree, "all_lambdas_converged": bool(int(niter.max()) <= 10000), "n_gpus": world, "ranks_in_communicator": adist.comm_info()[0], "scaling": "strong", "iterations": iters,
                "loop_s": loop_s, "iters_per_s": iters / loop_s, "us_per_iter": loop_s / iters * 1e6,
-               "setup_s": st["t_total"] - st["t_loop"], "allreduce_payload_bytes": 4 * n, "niter_first": [int(v) for v in niter[:8]]}
+               "setup_s": st["t_total"] - st["t_loop"], "allreduce_payload_bytes": 4 * n, "niter_first": [int(v) for v in niter[:8]],
+               "persist_iter": int(st.get("persist_iter", 0)), "exchange_variant": int(st.get("exchange_variant", 0))}
         with open(out_path, "w") as f:
             json.dump(res, f)
     if multi:
