@@ -74,6 +74,9 @@ struct ParParams {
     const double* cv; double* qv; float* tvec; const double* azpart;
     double* azv; double* tv64; int* wbflag; const double* dpart; double wb_tau2;      // cancellation fall-back (par_wb_flag_kernel)
     unsigned long long* wbcount;                                                         // fall-back passes taken (diagnostic)
+    int wb_nb;                                                                           // workgroups per worker of the head's one-pass part (ceil(wb_ld / 256))
+    double* wbnorm;                                                                      // [Kl][wb_nb][2] their shares of |t_k|^2, |q_k|^2
+    unsigned int* wbarrive;                                                              // [2 Kl] arrival counters: head's workgroups per worker, fall-back pass's workgroups per worker
     double* dlt;                                                                         // [Kl][wb_ld] residual of the small solve (par_wb_resid_kernel)
 #ifdef ADMM_HIP_PROBE
     long long* probe;
@@ -81,14 +84,84 @@ struct ParParams {
 };
 
 // head: rhs_k = A_k'b_k - y_k + rho z (PADMMLasso.h:19-21) for the local workers.
+// Grid (round 6: three launches fewer per iteration): the first Kl * wb_nb workgroups form the one-pass workers' t_k / q_k -- 256 rows of one
+// worker each -- and the cancellation guard's flag with them (the last of a worker's workgroups to arrive adds up their shares of
+// |t_k|^2, |q_k|^2 in workgroup order: the same decision whoever arrives last); the next workgroup folds the previous iteration's norm
+// partials into nsum (was: workgroup 0 of `pack`); the others form rhs.
 __global__ void __launch_bounds__(kParThreads)
 par_head_kernel(ParParams q) {
     // no fused multiply-adds in the elementwise arithmetic: the reference is built without them (see lasso_tall.hip, tall_update_elem)
 #pragma clang fp contract(off)
+    __shared__ double scratch[5 * (kParThreads / 64)];
     if (load_flag_vector(q.done)) return;
+    const int nwb = q.wb != nullptr ? q.Kl * q.wb_nb : 0;
+    if ((int)blockIdx.x < nwb) {
+        // one-pass Woodbury workers: A_k z from the gather launch's partial rows (group order), q_k = A_k y_k advanced by the dual
+        // update the z kernel just made (its rho is the float one, PADMMBase.h:70-78), t_k = A_k rhs_k for the product with the inverse
+        const double rho_f = (double)(float)q.rho;
+        const int k = blockIdx.x / q.wb_nb, jb = blockIdx.x - k * q.wb_nb;
+        const int i = jb * kParThreads + threadIdx.x;
+        const ParWb wb = q.wb[k];
+        double nacc[2] = {0.0, 0.0};
+        if (i < wb.rows) {
+            const int gi = k * q.wb_ld + i;
+            const double* ap = q.azpart + (size_t)k * q.az_ng * q.wb_ld + i;
+            double az = 0.0;
+            for (int c0 = 0; c0 < q.az_ng; c0 += 8) {
+                double tv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) tv[u] = ap[(size_t)min(c0 + u, q.az_ng - 1) * q.wb_ld];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) az += c0 + u < q.az_ng ? tv[u] : 0.0;
+            }
+            float sv = 0.f;
+            for (int r = 0; r < wb.snseg; ++r) sv += wb.spart[(size_t)r * wb.sstride + i];
+            const double qn = q.qv[gi] + rho_f * ((double)sv - az) - q.dlt[gi];       // A_k x_k = s_k - delta_k / rho (par_wb_resid_kernel)
+            const double tn = q.cv[gi] - qn + q.rho * az;
+            q.qv[gi] = qn; q.azv[gi] = az; q.tv64[gi] = tn;
+            q.tvec[gi] = (float)tn;
+            nacc[0] = tn * tn; nacc[1] = qn * qn;
+        }
+        // the cancellation guard's flag (see below): this workgroup's share, then -- last arrival of the worker -- the flag
+        block_sum<double, 2>(nacc, scratch);
+        if (threadIdx.x == 0) {
+            double* sh = q.wbnorm + ((size_t)k * q.wb_nb + jb) * 2;
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(sh), (unsigned long long)__double_as_longlong(nacc[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(sh + 1), (unsigned long long)__double_as_longlong(nacc[1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned prev = __hip_atomic_fetch_add(q.wbarrive + k, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (prev == (unsigned)q.wb_nb - 1) {
+                __hip_atomic_store(q.wbarrive + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                double t2 = 0.0, q2 = 0.0;
+                for (int j = 0; j < q.wb_nb; ++j) {
+                    const unsigned long long* o = reinterpret_cast<const unsigned long long*>(q.wbnorm + ((size_t)k * q.wb_nb + j) * 2);
+                    t2 += __longlong_as_double((long long)__hip_atomic_load(o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    q2 += __longlong_as_double((long long)__hip_atomic_load(o + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                }
+                const int f = (wb.rows > 0 && t2 < q.wb_tau2 * ((double)wb.rows / (double)q.p) * q2) ? 1 : 0;      // tau_k = tau0 sqrt(rows_k / p)
+                q.wbflag[k] = f;
+                if (f) atomicAdd(q.wbcount, 1ull);
+            }
+        }
+        return;
+    }
+    const int b = (int)blockIdx.x - nwb;
+    if (b == 0) {                                       // the norm partials of the previous iteration's z launch -> nsum[0..4]
+        double acc[5] = {0, 0, 0, 0, 0};
+        for (int w = threadIdx.x; w < q.nwg; w += kParThreads) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) acc[k] += q.P[(size_t)w * 8 + k];
+        }
+        block_sum<double, 5>(acc, scratch);
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) q.nsum[k] = acc[k];
+        }
+    }
+    const int nb = (int)gridDim.x - nwb;
     // workers in groups of 8: the 16 loads of a group are requested together (one worker at a time was a chain of dependent
     // round trips: kernel arguments -> addresses -> values, per worker)
-    for (int i = blockIdx.x * kParThreads + threadIdx.x; i < q.p; i += gridDim.x * kParThreads) {
+    for (int i = b * kParThreads + threadIdx.x; i < q.p; i += nb * kParThreads) {
         const double rz = q.rho * (double)q.z[i];
         for (int k0 = 0; k0 < q.Kl; k0 += 8) {
             float ab[8], yv[8];
@@ -106,32 +179,6 @@ par_head_kernel(ParParams q) {
             }
         }
     }
-    if (q.wb != nullptr) {
-        // one-pass Woodbury workers: A_k z from the gather launch's partial rows (group order), q_k = A_k y_k advanced by the dual
-        // update the z kernel just made (its rho is the float one, PADMMBase.h:70-78), t_k = A_k rhs_k for the product with the inverse
-        const double rho_f = (double)(float)q.rho;
-        const int tot = q.Kl * q.wb_ld;
-        for (int gi = blockIdx.x * kParThreads + threadIdx.x; gi < tot; gi += gridDim.x * kParThreads) {
-            const int k = gi / q.wb_ld, i = gi - k * q.wb_ld;
-            const ParWb wb = q.wb[k];
-            if (i >= wb.rows) continue;
-            const double* ap = q.azpart + (size_t)k * q.az_ng * q.wb_ld + i;
-            double az = 0.0;
-            for (int c0 = 0; c0 < q.az_ng; c0 += 8) {
-                double tv[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) tv[u] = ap[(size_t)min(c0 + u, q.az_ng - 1) * q.wb_ld];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) az += c0 + u < q.az_ng ? tv[u] : 0.0;
-            }
-            float sv = 0.f;
-            for (int r = 0; r < wb.snseg; ++r) sv += wb.spart[(size_t)r * wb.sstride + i];
-            const double qn = q.qv[gi] + rho_f * ((double)sv - az) - q.dlt[gi];       // A_k x_k = s_k - delta_k / rho (par_wb_resid_kernel)
-            const double tn = q.cv[gi] - qn + q.rho * az;
-            q.qv[gi] = qn; q.azv[gi] = az; q.tv64[gi] = tn;
-            q.tvec[gi] = (float)tn;
-        }
-    }
 }
 
 // One-pass Woodbury workers, the guard against CANCELLATION.  t_k = c_k - q_k + rho A_k z is a difference; where the iteration
@@ -146,24 +193,7 @@ par_head_kernel(ParParams q) {
 // 947:142 is at the two-pass form's own 12 x there, 18 x at 1/128; 1/143 for C4's 1250 x 10^5 blocks) -> t_k is formed the
 // reference's way for this iteration, one dense pass A_k rhs_k through the same gather kernel (double accumulation), and q_k is
 // re-anchored on it.  Elsewhere the one-pass form is MORE accurate than the float product it replaces.
-__global__ void __launch_bounds__(256)
-par_wb_flag_kernel(ParParams q) {
-    __shared__ double scratch[2 * 4];
-    if (load_flag_vector(q.done)) return;
-    const int k = blockIdx.x;
-    const int rows = q.wb[k].rows;
-    double acc[2] = {0.0, 0.0};
-    for (int i = threadIdx.x; i < rows; i += 256) {
-        const double t = q.tv64[(size_t)k * q.wb_ld + i], qq = q.qv[(size_t)k * q.wb_ld + i];
-        acc[0] += t * t; acc[1] += qq * qq;
-    }
-    block_sum<double, 2>(acc, scratch);
-    if (threadIdx.x == 0) {
-        const int f = (rows > 0 && acc[0] < q.wb_tau2 * ((double)rows / (double)q.p) * acc[1]) ? 1 : 0;      // tau_k = tau0 sqrt(rows_k / p)
-        q.wbflag[k] = f;
-        if (f) atomicAdd(q.wbcount, 1ull);
-    }
-}
+// (the flag itself: par_head_kernel, last arrival of the worker's workgroups)
 // The residual of the small solve, delta_k = (A_k A_k' + rho I) s_k - t_k, in double from the float Gram, the float s_k and the float t_k
 // the solve was given: with it A_k x_k = (t_k - A_k A_k's_k) / rho = s_k - delta_k / rho exactly, and the recurrence of q_k carries no
 // term of the cached inverse's own error (u cond(A_k A_k' + rho I) |t_k|; without it the x-update of ill-conditioned blocks was 1.2 .. 1.4
@@ -224,18 +254,42 @@ par_A_batch_resid_kernel(const GemvTArgs<float>* __restrict__ batch, ParParams q
     if ((int)blockIdx.x >= grid) return;
     gemv_t_body<float, 1, 4, NT>(a, (int)blockIdx.x);
 }
-// after the fall-back pass: t_k = A_k rhs_k from its partial rows, q_k = c_k + rho A_k z - t_k (= A_k y_k as stored)
-__global__ void __launch_bounds__(256)
-par_wb_fix_kernel(ParParams q) {
-    if (load_flag_vector(q.done)) return;
-    const int gi = blockIdx.x * 256 + threadIdx.x;
-    if (gi >= q.Kl * q.wb_ld) return;
-    const int k = gi / q.wb_ld, i = gi - k * q.wb_ld;
-    if (q.wbflag[k] == 0 || i >= q.wb[k].rows) return;
-    double t = 0.0;
-    for (int g = 0; g < q.az_ng; ++g) t += q.dpart[((size_t)k * q.az_ng + g) * q.wb_ld + i];
-    q.tvec[gi] = (float)t;
-    q.qv[gi] = q.cv[gi] + q.rho * q.azv[gi] - t;
+// The fall-back pass of the cancellation guard and what follows it, in ONE launch (round 6; was gather_batch_kernel + par_wb_fix_kernel):
+// the workgroups of a flagged worker run the dense gather A_k rhs_k (gather_kernels.h), and the last of them to finish forms
+// t_k = A_k rhs_k from the partial rows (group order) and re-anchors q_k = c_k + rho A_k z - t_k (= A_k y_k as stored).  A worker whose
+// flag is down costs its workgroups one flag load.
+__global__ void __launch_bounds__(kGatherThreads)
+par_gather_fix_kernel(const GatherArgs<float>* __restrict__ batch, ParParams q) {
+    __shared__ int s_last;
+    const GatherArgs<float> a = batch[blockIdx.z];
+    if (a.skip != nullptr && load_flag_vector(a.skip) != 0) return;
+    if (a.only_if != nullptr && load_flag_vector(a.only_if) == 0) return;
+    constexpr int TILE = kGatherThreads * Vec16<float>::N;
+    const int k = blockIdx.z;
+    const int tiles = (a.rows + TILE - 1) / TILE;
+    if ((int)blockIdx.y >= a.ngroups || (int)blockIdx.x >= tiles) return;
+    gather_body<float>(a, (int)blockIdx.x, (int)blockIdx.y);
+    __threadfence();                                     // the partial rows are visible device-wide before this workgroup counts itself in
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned total = (unsigned)(tiles * a.ngroups);
+        const unsigned prev = __hip_atomic_fetch_add(q.wbarrive + q.Kl + k, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = prev == total - 1 ? 1 : 0;
+        if (s_last) __hip_atomic_store(q.wbarrive + q.Kl + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    const int rows = q.wb[k].rows;
+    for (int i = threadIdx.x; i < rows; i += kGatherThreads) {
+        const int gi = k * q.wb_ld + i;
+        double t = 0.0;
+        for (int g = 0; g < q.az_ng; ++g)
+            t += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(q.dpart + ((size_t)k * q.az_ng + g) * q.wb_ld + i),
+                                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        q.tvec[gi] = (float)t;
+        q.qv[gi] = q.cv[gi] + q.rho * q.azv[gi] - t;
+    }
 }
 
 // c_k = A_k (A_k'b_k) from the setup gather's partial rows (dense right-hand side), in double
@@ -257,59 +311,51 @@ __global__ void par_wb_c_kernel(ParParams q, double* cv) {
 // last workgroup to finish raises the flags (peer_device.h); par_z_kernel<1> is the consumer.  No launches of the exchange
 // layer, like the sharded tall and wide solvers (replaces the shared-memory reads of PADMMLasso.h:99-108, PADMMBase.h:200-214).
 constexpr size_t par_peer_norm_offset(int p) { return ((size_t)p * sizeof(float) + 15) / 16 * 16; }
+// x_k of element i from the mat-vec results, returns this process's share of the consensus sum  sum_k (x_k + y_k / rho)  (PADMMLasso.h:23-30,65-68)
+__device__ __forceinline__ float par_pack_elem(const ParParams& q, int i, float rho_f) {
+#pragma clang fp contract(off)
+    float w = 0.f;
+    for (int k0 = 0; k0 < q.Kl; k0 += 8) {                                      // 8 workers' operands requested together, consumed in order
+        float g0[8], rh[8], yv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = min(k0 + u, q.Kl - 1);
+            const size_t o = (size_t)k * q.ldv + i;
+            g0[u] = q.gout[k][i]; rh[u] = q.rhs[o]; yv[u] = q.y[o];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = k0 + u;
+            if (k < q.Kl) {
+                float g = 0.f;
+                g += g0[u];
+                for (int s = 1; s < q.gnseg[k]; ++s) g += q.gout[k][(size_t)s * q.gstride[k] + i];
+                const float x = q.wide[k] ? (rh[u] - g) / rho_f : g;            // PADMMLasso.h:23-30
+                q.x[(size_t)k * q.ldv + i] = x;
+                w += x + yv[u] / rho_f;
+            }
+        }
+    }
+    return w;
+}
+
 template <int PEER>
 __global__ void __launch_bounds__(kParThreads)
 par_pack_kernel(ParParams q, PeerExchange ex) {
     // no fused multiply-adds in the elementwise arithmetic: the reference is built without them (see lasso_tall.hip, tall_update_elem)
 #pragma clang fp contract(off)
-    __shared__ double scratch[5 * (kParThreads / 64)];
     if (load_flag_vector(q.done)) return;
-    if (blockIdx.x == 0) {
-        double acc[5] = {0, 0, 0, 0, 0};
-        for (int w = threadIdx.x; w < q.nwg; w += kParThreads) {
+    if (PEER && blockIdx.x == 0 && threadIdx.x == 0) {               // the three worker-summed norms behind the payload (nsum: folded by the head launch)
+        for (int dst = 0; dst < ex.nranks; ++dst) {
+            unsigned long long* nd = reinterpret_cast<unsigned long long*>(peer_dst_slot(ex, dst) + par_peer_norm_offset(q.p));
 #pragma unroll
-            for (int k = 0; k < 5; ++k) acc[k] += q.P[(size_t)w * 8 + k];
-        }
-        block_sum<double, 5>(acc, scratch);
-        if (threadIdx.x == 0) {
-#pragma unroll
-            for (int k = 0; k < 5; ++k) q.nsum[k] = acc[k];
-            if (PEER) {
-                for (int dst = 0; dst < ex.nranks; ++dst) {
-                    unsigned long long* nd = reinterpret_cast<unsigned long long*>(peer_dst_slot(ex, dst) + par_peer_norm_offset(q.p));
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) peer_store_u64(nd + k, (unsigned long long)__double_as_longlong(acc[k]));
-                }
-            }
+            for (int k = 0; k < 3; ++k) peer_store_u64(nd + k, (unsigned long long)__double_as_longlong(q.nsum[k]));
         }
     }
     const float rho_f = (float)q.rho;
     const int pe = PEER ? (q.p + 1) / 2 * 2 : q.p;        // PEER: whole pairs (the partner lane of the last odd element stores a zero)
     for (int i = blockIdx.x * kParThreads + threadIdx.x; i < pe; i += gridDim.x * kParThreads) {
-        float w = 0.f;
-        if (i < q.p) {
-        for (int k0 = 0; k0 < q.Kl; k0 += 8) {                                      // 8 workers' operands requested together, consumed in order
-            float g0[8], rh[8], yv[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int k = min(k0 + u, q.Kl - 1);
-                const size_t o = (size_t)k * q.ldv + i;
-                g0[u] = q.gout[k][i]; rh[u] = q.rhs[o]; yv[u] = q.y[o];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int k = k0 + u;
-                if (k < q.Kl) {
-                    float g = 0.f;
-                    g += g0[u];
-                    for (int s = 1; s < q.gnseg[k]; ++s) g += q.gout[k][(size_t)s * q.gstride[k] + i];
-                    const float x = q.wide[k] ? (rh[u] - g) / rho_f : g;            // PADMMLasso.h:23-30
-                    q.x[(size_t)k * q.ldv + i] = x;
-                    w += x + yv[u] / rho_f;
-                }
-            }
-        }
-        }
+        const float w = i < q.p ? par_pack_elem(q, i, rho_f) : 0.f;
         if (PEER) {
             const float wn = __shfl_down(w, 1, 64);        // i is even in even lanes (grid stride and block size are even)
             if ((i & 1) == 0) {
@@ -323,10 +369,90 @@ par_pack_kernel(ParParams q, PeerExchange ex) {
     if (PEER) peer_publish(ex, gridDim.x);
 }
 
+// The decision for the iteration that has just been summed up (PADMMBase.h:216-221,230-231; eps :117-139) and the lambda schedule.
+struct ParDecision { ParCtl out; int lam_finished, niter_val; double rp, rd, code; };
+__device__ __forceinline__ ParDecision par_decide(const ParParams& q, const ParCtl& in, double x2, double y2, double r2, double z2, double dz2) {
+    ParDecision d;
+    d.out = in;
+    d.out.first = 0;
+    d.lam_finished = -1; d.niter_val = 0; d.rp = 0; d.rd = 0; d.code = ADMM_TRACE_COLD;
+    if (!in.first) {
+        const double rp = sqrt(r2);                                  // sqrt(sum_k |x_k - z|^2)        PADMMBase.h:213
+        const double rd = q.rho * sqrt((double)q.K * dz2);           // rho sqrt(K |z_new - z|^2)      PADMMLasso.h:149-152
+        d.rp = rp; d.rd = rd; d.code = (rp < in.eps_primal && rd < in.eps_dual) ? ADMM_TRACE_CONVERGED : ADMM_TRACE_CONTINUE;
+        if (rp < in.eps_primal && rd < in.eps_dual) { d.lam_finished = in.lam_idx; d.niter_val = in.iter + 1; }
+        else {
+            d.out.iter = in.iter + 1;
+            if (in.iter + 1 >= q.maxit) { d.lam_finished = in.lam_idx; d.niter_val = q.maxit + 1; }
+        }
+        if (d.lam_finished >= 0) {
+            d.out.lam_idx = in.lam_idx + 1; d.out.iter = 0;
+            if (d.out.lam_idx >= q.nlam) d.out.done = 1;
+            else d.out.lam = q.lambdas[d.out.lam_idx];
+        }
+    }
+    const double sK = sqrt((double)q.K), spK = sqrt((double)q.p * (double)q.K);
+    d.out.eps_primal = fmax(sqrt(x2), sqrt(z2) * sK) * q.eps_rel + spK * q.eps_abs;   // PADMMBase.h:117-128
+    d.out.eps_dual = sqrt(y2) * q.eps_rel + spK * q.eps_abs;                           // PADMMBase.h:129-139
+    d.out.total = in.total + 1;
+    return d;
+}
+__device__ __forceinline__ void par_record(const ParParams& q, const ParCtl& in, const ParDecision& d, ParCtl* outp) {
+    if (d.lam_finished >= 0) q.niter[d.lam_finished] = d.niter_val;
+    *outp = d.out;
+    if (d.out.done) *q.done = 1;
+    if (q.trace != nullptr && in.total < q.trace_cap) {
+        double* t = q.trace + (size_t)in.total * ADMM_TRACE_FIELDS;
+        t[0] = in.lam_idx; t[1] = in.iter; t[2] = in.eps_primal; t[3] = in.eps_dual; t[4] = d.rp; t[5] = d.rd;
+        t[6] = q.rho; t[7] = 0.0; t[8] = d.code; t[9] = q.rho; t[10] = q.rho; t[11] = in.lam;
+    }
+}
+// z_new = soft(w / K, lambda / (rho K)); y_k += rho (x_k - z_new); norm shares   (PADMMLasso.h:99-108, PADMMBase.h:70-78) of element i
+__device__ __forceinline__ void par_z_elem(const ParParams& q, int i, float wtot, const ParDecision& d, double pen, float rho_f, double (&acc)[5]) {
+#pragma clang fp contract(off)
+    const float zo = q.z[i];
+    if (d.lam_finished >= 0) q.beta[(size_t)d.lam_finished * q.p + i] = zo;           // get_z()  ParLasso.cpp:98
+    if (d.out.done) return;
+    const float v = wtot / (float)q.K;
+    const double vd = (double)v;
+    const float zn = vd > pen ? (float)(vd - pen) : (vd < -pen ? (float)(vd + pen) : 0.f);
+    for (int k0 = 0; k0 < q.Kl; k0 += 8) {                                      // 8 workers' operands requested together
+        float xv[8], yv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const size_t o = (size_t)min(k0 + u, q.Kl - 1) * q.ldv + i;
+            xv[u] = q.x[o]; yv[u] = q.y[o];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (k0 + u < q.Kl) {
+                const float x = xv[u];
+                const float r = x - zn;
+                const float yn = yv[u] + rho_f * r;
+                q.y[(size_t)(k0 + u) * q.ldv + i] = yn;
+                if (q.state != nullptr && d.out.total < q.state_cap) {     // record out.total = the trace record that will judge this iteration
+                    float* s = q.state + (size_t)d.out.total * (1 + 2 * (size_t)q.Kl) * q.p;
+                    s[(size_t)(1 + k0 + u) * q.p + i] = x; s[(size_t)(1 + q.Kl + k0 + u) * q.p + i] = yn;
+                }
+                acc[0] += (double)x * x; acc[1] += (double)yn * yn; acc[2] += (double)r * r;
+            }
+        }
+    }
+    const float dz = zn - zo;
+    acc[3] += (double)zn * zn; acc[4] += (double)dz * dz;
+    q.z[i] = zn;
+    if (q.state != nullptr && d.out.total < q.state_cap) q.state[(size_t)d.out.total * (1 + 2 * (size_t)q.Kl) * q.p + i] = zn;
+}
+
 // z(g): decision for iteration g-1 from nsum (after the all-reduce every rank holds identical numbers and
 // takes identical decisions: PADMMBase.h:216-221,230-231; eps :117-139), lambda schedule, then
 // z_new = soft(w / K, lambda / (rho K)); y_k += rho (x_k - z_new); norms   (PADMMLasso.h:99-108, PADMMBase.h:70-78)
-template <int PEER>      // 1: the consensus sum and the worker-summed norms arrive in the K exchange slots (par_pack_kernel<1> of every rank)
+// PEER 0: the consensus sum is in q.wsum (single process, or all-reduced by the exchange layer between `pack` and this launch).
+// PEER 1: the consensus sum and the worker-summed norms arrive in the K exchange slots (par_pack_kernel<1> of every rank).
+// FUSED (round 6): `pack` and `z` in ONE launch -- every thread forms x_k and the consensus share of ITS elements first.  PEER 0
+// (single process): the share IS the sum, nothing travels.  PEER 1: the launch is producer and consumer of the exchange (the host
+// chooses it only when the grid is resident with room to spare: its workgroups wait for one another, and for the other ranks).
+template <int PEER, bool FUSED>
 __global__ void __launch_bounds__(kParThreads)
 par_z_kernel(ParParams q, int par, PeerExchange ex) {
     // no fused multiply-adds in the elementwise arithmetic: the reference is built without them (see lasso_tall.hip, tall_update_elem)
@@ -341,8 +467,29 @@ par_z_kernel(ParParams q, int par, PeerExchange ex) {
         return;
     }
     WIDE_PROBE(4);
+    const float rho_f = (float)q.rho;
     double x2 = q.nsum[0], y2 = q.nsum[1], r2 = q.nsum[2];
     const double z2 = q.nsum[3], dz2 = q.nsum[4];
+    if (FUSED && PEER) {                                                  // producer half: this workgroup's elements into every rank's slot
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            for (int dst = 0; dst < ex.nranks; ++dst) {
+                unsigned long long* nd = reinterpret_cast<unsigned long long*>(peer_dst_slot(ex, dst) + par_peer_norm_offset(q.p));
+                peer_store_u64(nd + 0, (unsigned long long)__double_as_longlong(x2));
+                peer_store_u64(nd + 1, (unsigned long long)__double_as_longlong(y2));
+                peer_store_u64(nd + 2, (unsigned long long)__double_as_longlong(r2));
+            }
+        }
+        const int pe = (q.p + 1) / 2 * 2;
+        for (int i = blockIdx.x * kParThreads + threadIdx.x; i < pe; i += gridDim.x * kParThreads) {
+            const float w = i < q.p ? par_pack_elem(q, i, rho_f) : 0.f;
+            const float wn = __shfl_down(w, 1, 64);
+            if ((i & 1) == 0) {
+                for (int dst = 0; dst < ex.nranks; ++dst)
+                    peer_store_f32x2(reinterpret_cast<float*>(peer_dst_slot(ex, dst)) + i, w, wn);
+            }
+        }
+        peer_publish(ex, gridDim.x);
+    }
     if (PEER) {
         if (!peer_wait_relaxed(ex)) return;                               // a rank did not arrive in time: ADMM_ERR_COMM at the next poll
         x2 = 0.0; y2 = 0.0; r2 = 0.0;
@@ -357,51 +504,16 @@ par_z_kernel(ParParams q, int par, PeerExchange ex) {
     asm volatile("" :: "v"(x2), "v"(y2), "v"(r2), "v"(z2), "v"(dz2));
 #endif
     WIDE_PROBE(5);
-    ParCtl out = in;
-    out.first = 0;
-    int lam_finished = -1, niter_val = 0;
-    double tr_rp = 0, tr_rd = 0, tr_code = ADMM_TRACE_COLD;
-    if (!in.first) {
-        const double rp = sqrt(r2);                                  // sqrt(sum_k |x_k - z|^2)        PADMMBase.h:213
-        const double rd = q.rho * sqrt((double)q.K * dz2);           // rho sqrt(K |z_new - z|^2)      PADMMLasso.h:149-152
-        tr_rp = rp; tr_rd = rd; tr_code = (rp < in.eps_primal && rd < in.eps_dual) ? ADMM_TRACE_CONVERGED : ADMM_TRACE_CONTINUE;
-        if (rp < in.eps_primal && rd < in.eps_dual) { lam_finished = in.lam_idx; niter_val = in.iter + 1; }
-        else {
-            out.iter = in.iter + 1;
-            if (in.iter + 1 >= q.maxit) { lam_finished = in.lam_idx; niter_val = q.maxit + 1; }
-        }
-        if (lam_finished >= 0) {
-            out.lam_idx = in.lam_idx + 1; out.iter = 0;
-            if (out.lam_idx >= q.nlam) out.done = 1;
-            else out.lam = q.lambdas[out.lam_idx];
-        }
-    }
-    const double sK = sqrt((double)q.K), spK = sqrt((double)q.p * (double)q.K);
-    out.eps_primal = fmax(sqrt(x2), sqrt(z2) * sK) * q.eps_rel + spK * q.eps_abs;   // PADMMBase.h:117-128
-    out.eps_dual = sqrt(y2) * q.eps_rel + spK * q.eps_abs;                           // PADMMBase.h:129-139
-    out.total = in.total + 1;
+    const ParDecision d = par_decide(q, in, x2, y2, r2, z2, dz2);
 #ifdef ADMM_HIP_PROBE
-    asm volatile("" :: "v"(out.eps_primal), "v"(out.eps_dual));
+    asm volatile("" :: "v"(d.out.eps_primal), "v"(d.out.eps_dual));
 #endif
     WIDE_PROBE(6);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (lam_finished >= 0) q.niter[lam_finished] = niter_val;
-        *outp = out;
-        if (out.done) *q.done = 1;
-        if (q.trace != nullptr && in.total < q.trace_cap) {
-            double* t = q.trace + (size_t)in.total * ADMM_TRACE_FIELDS;
-            t[0] = in.lam_idx; t[1] = in.iter; t[2] = in.eps_primal; t[3] = in.eps_dual; t[4] = tr_rp; t[5] = tr_rd;
-            t[6] = q.rho; t[7] = 0.0; t[8] = tr_code; t[9] = q.rho; t[10] = q.rho; t[11] = in.lam;
-        }
-    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) par_record(q, in, d, outp);
     WIDE_PROBE(1);
-    const float rho_f = (float)q.rho;
-    const double pen = out.lam / (q.rho * (double)q.K);
+    const double pen = d.out.lam / (q.rho * (double)q.K);
     double acc[5] = {0, 0, 0, 0, 0};
     for (int i = blockIdx.x * kParThreads + threadIdx.x; i < q.p; i += gridDim.x * kParThreads) {
-        const float zo = q.z[i];
-        if (lam_finished >= 0) q.beta[(size_t)lam_finished * q.p + i] = zo;           // get_z()  ParLasso.cpp:98
-        if (out.done) continue;
         float wtot;
         if (PEER) {
             wtot = 0.f;
@@ -409,40 +521,14 @@ par_z_kernel(ParParams q, int par, PeerExchange ex) {
                 const float2 pr = peer_load_f32x2(reinterpret_cast<const float*>(peer_src_slot(ex, r)) + (i & ~1));
                 wtot += (i & 1) ? pr.y : pr.x;
             }
+        } else if (FUSED) {
+            wtot = par_pack_elem(q, i, rho_f);
         } else {
             wtot = q.wsum[i];
         }
-        const float v = wtot / (float)q.K;
-        const double vd = (double)v;
-        const float zn = vd > pen ? (float)(vd - pen) : (vd < -pen ? (float)(vd + pen) : 0.f);
-        for (int k0 = 0; k0 < q.Kl; k0 += 8) {                                      // 8 workers' operands requested together
-            float xv[8], yv[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const size_t o = (size_t)min(k0 + u, q.Kl - 1) * q.ldv + i;
-                xv[u] = q.x[o]; yv[u] = q.y[o];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (k0 + u < q.Kl) {
-                    const float x = xv[u];
-                    const float r = x - zn;
-                    const float yn = yv[u] + rho_f * r;
-                    q.y[(size_t)(k0 + u) * q.ldv + i] = yn;
-                    if (q.state != nullptr && out.total < q.state_cap) {     // record out.total = the trace record that will judge this iteration
-                        float* s = q.state + (size_t)out.total * (1 + 2 * (size_t)q.Kl) * q.p;
-                        s[(size_t)(1 + k0 + u) * q.p + i] = x; s[(size_t)(1 + q.Kl + k0 + u) * q.p + i] = yn;
-                    }
-                    acc[0] += (double)x * x; acc[1] += (double)yn * yn; acc[2] += (double)r * r;
-                }
-            }
-        }
-        const float dz = zn - zo;
-        acc[3] += (double)zn * zn; acc[4] += (double)dz * dz;
-        q.z[i] = zn;
-        if (q.state != nullptr && out.total < q.state_cap) q.state[(size_t)out.total * (1 + 2 * (size_t)q.Kl) * q.p + i] = zn;
+        par_z_elem(q, i, wtot, d, pen, rho_f, acc);
     }
-    if (out.done) return;
+    if (d.out.done) return;
     WIDE_PROBE(2);
     block_sum<double, 5>(acc, scratch);
     if (threadIdx.x == 0) {
@@ -551,6 +637,10 @@ struct ParPlan final : LassoPlan {
     DevBuf<float> tvec;
     DevBuf<int> wbflag;
     DevBuf<unsigned long long> wbcount;
+    DevBuf<double> wbnorm;
+    DevBuf<unsigned int> wbarrive;
+    int wb_nb = 0;
+    bool fuse_pz = false;             // pack + z in one launch (single process; PEER: when the grid is resident with room to spare)
     DevBuf<GatherArgs<float>> bG, bGd;
     long long fallback_passes = 0;
     DevBuf<float> state;
@@ -672,6 +762,14 @@ struct ParPlan final : LassoPlan {
         peer_fused = pb.dist && ci.active && ci.backend == COMM_PEER;
         if (const char* e = std::getenv("ADMM_HIP_PEER_FUSED")) { if (std::string(e) == "0") peer_fused = false; }
         nwg = std::max(1, std::min(1024, (p + kParThreads - 1) / kParThreads));     // one element per thread up to p = 262144 (was <= 64 workgroups: 31 us for p = 10^5)
+        // ADMM_HIP_PAR_FUSE_PZ=0: `pack` and `z` as two launches everywhere
+        fuse_pz = !pb.dist;
+        if (peer_fused) {
+            int occ = 0;
+            ADMM_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(par_z_kernel<1, true>), kParThreads, 0));
+            fuse_pz = (long long)nwg * 2 <= resident_workgroups(occ);       // its workgroups wait for one another: resident with room to spare
+        }
+        if (const char* e = std::getenv("ADMM_HIP_PAR_FUSE_PZ")) { if (std::string(e) == "0") fuse_pz = false; }
         rhs.alloc((size_t)Kl * ldv); x.alloc((size_t)Kl * ldv); y.alloc((size_t)Kl * ldv); nsum.alloc(8);
         z.alloc(ldv); wsum.alloc(ldv);
         rhs.zero(st); x.zero(st); y.zero(st);
@@ -722,6 +820,10 @@ struct ParPlan final : LassoPlan {
             q.wb = wbd.get(); q.wb_ld = wb_ld; q.az_ng = gp.ngroups;
             q.cv = cv.get(); q.qv = qv.get(); q.tvec = tvec.get(); q.azpart = azpart.get();
             wbcount.alloc(1); wbcount.zero(st);
+            wb_nb = (wb_ld + kParThreads - 1) / kParThreads;
+            wbnorm.alloc((size_t)Kl * wb_nb * 2); wbnorm.zero(st);
+            wbarrive.alloc((size_t)2 * Kl); wbarrive.zero(st);
+            q.wb_nb = wb_nb; q.wbnorm = wbnorm.get(); q.wbarrive = wbarrive.get();
             q.azv = azv.get(); q.tv64 = tv64.get(); q.wbflag = wbflag.get(); q.dpart = dpart.get(); q.wbcount = wbcount.get(); q.dlt = dlt.get();
             {
                 double tau = 1.0 / 16.0;                                                       // tau0: see par_wb_flag_kernel
@@ -795,12 +897,9 @@ struct ParPlan final : LassoPlan {
         const int batch = pb.batch_iters > 0 ? (pb.batch_iters + 1) / 2 * 2 : 16;
         LoopTimes lt = run_until_done(st, skip, batch, (long long)nlam * ((long long)pb.opts.maxit + 2) + 4, [&](long long g) {
             const int par = (int)(g & 1);
-            hipLaunchKernelGGL(par_head_kernel, dim3(nwg_e), dim3(kParThreads), 0, st, q);
-            if (onepass) {      // cancellation guard: flag per worker, the fall-back pass where it is up (no-op launches otherwise), t_k / q_k from it
-                hipLaunchKernelGGL(par_wb_flag_kernel, dim3(Kl), dim3(256), 0, st, q);
-                hipLaunchKernelGGL((gather_batch_kernel<float>), dim3(gather_tiles, gp.ngroups, Kl), dim3(kGatherThreads), 0, st, bGd.get());
-                hipLaunchKernelGGL(par_wb_fix_kernel, dim3((Kl * wb_ld + 255) / 256), dim3(256), 0, st, q);
-            }
+            hipLaunchKernelGGL(par_head_kernel, dim3(nwg_e + (onepass ? Kl * wb_nb : 0)), dim3(kParThreads), 0, st, q);      // rhs_k; one-pass: t_k, q_k and the guard's flag
+            if (onepass)        // cancellation guard: the fall-back pass where a worker's flag is up (its workgroups leave at once otherwise), t_k / q_k from it
+                hipLaunchKernelGGL(par_gather_fix_kernel, dim3(gather_tiles, gp.ngroups, Kl), dim3(kGatherThreads), 0, st, bGd.get(), q);
             if (batched) {
                 // all workers' products of one kind in ONE launch (bit-identical to the per-worker launches below)
                 if (bt_wide) {
@@ -835,20 +934,28 @@ struct ParPlan final : LassoPlan {
             if (peer_fused) {
                 // the only cross-worker exchange, produced by `pack` and consumed by `z` themselves (PEER slots)
                 const PeerExchange ex = comm_peer_begin(par_peer_norm_offset(p) + 3 * sizeof(double));
-                hipLaunchKernelGGL(par_pack_kernel<1>, dim3(nwg_e), dim3(kParThreads), 0, st, q, ex);
-                hipLaunchKernelGGL(par_z_kernel<1>, dim3(nwg), dim3(kParThreads), 0, st, q, par, ex);
+                if (fuse_pz) {
+                    hipLaunchKernelGGL((par_z_kernel<1, true>), dim3(nwg), dim3(kParThreads), 0, st, q, par, ex);
+                } else {
+                    hipLaunchKernelGGL(par_pack_kernel<1>, dim3(nwg_e), dim3(kParThreads), 0, st, q, ex);
+                    hipLaunchKernelGGL((par_z_kernel<1, false>), dim3(nwg), dim3(kParThreads), 0, st, q, par, ex);
+                }
                 if (onepass) hipLaunchKernelGGL((gather_batch_kernel<float>), dim3(gather_tiles, gp.ngroups, Kl), dim3(kGatherThreads), 0, st, bG.get());
                 return;
             }
-            hipLaunchKernelGGL(par_pack_kernel<0>, dim3(nwg_e), dim3(kParThreads), 0, st, q, PeerExchange{});
-            // the only cross-worker exchange: consensus sum (p floats) + the three worker-summed norms, one grouped
-            // RCCL all-reduce over xGMI (no-op in a single process)
-            if (pb.dist) allreduce_sum_f32_f64(wsum.get(), (size_t)p, nsum.get(), 3, st);
-            hipLaunchKernelGGL(par_z_kernel<0>, dim3(nwg), dim3(kParThreads), 0, st, q, par, PeerExchange{});
+            if (fuse_pz) {       // single process: nothing travels between `pack` and `z`
+                hipLaunchKernelGGL((par_z_kernel<0, true>), dim3(nwg), dim3(kParThreads), 0, st, q, par, PeerExchange{});
+            } else {
+                hipLaunchKernelGGL(par_pack_kernel<0>, dim3(nwg_e), dim3(kParThreads), 0, st, q, PeerExchange{});
+                // the only cross-worker exchange: consensus sum (p floats) + the three worker-summed norms, one grouped
+                // RCCL all-reduce over xGMI (no-op in a single process)
+                if (pb.dist) allreduce_sum_f32_f64(wsum.get(), (size_t)p, nsum.get(), 3, st);
+                hipLaunchKernelGGL((par_z_kernel<0, false>), dim3(nwg), dim3(kParThreads), 0, st, q, par, PeerExchange{});
+            }
             if (onepass) hipLaunchKernelGGL((gather_batch_kernel<float>), dim3(gather_tiles, gp.ngroups, Kl), dim3(kGatherThreads), 0, st, bG.get());      // A_k z_new over the non-zeros of z
         });
         S.t_loop = lt.wall_s; S.loop_ms_events = lt.events_ms; S.xupdate_launches = lt.launched;
-        S.exchange_variant = !pb.dist ? 0 : (peer_fused ? 2 : 1);
+        S.exchange_variant = !pb.dist ? 0 : (peer_fused ? (fuse_pz ? 3 : 2) : 1);      // 3: `pack` and `z` as ONE launch, producer and consumer of the exchange
         if (onepass) {
             unsigned long long hc = 0;
             ADMM_HIP_CHECK(hipMemcpy(&hc, wbcount.get(), sizeof(hc), hipMemcpyDeviceToHost));

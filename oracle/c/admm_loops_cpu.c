@@ -301,14 +301,49 @@ static void llt_solve_f(const float* L, int m, float* x) {
     }
 }
 
+/* the same in double on a double factor: the rounding VARIANT "exact" of oracle/solvers.py PADMMLasso (the float system the reference
+ * builds, solved without the float LLT's rounding; the right-hand side and the result stay the float vectors they are) */
+static void llt_solve_fd(const double* L, int m, float* xf, double* x) {
+    for (int i = 0; i < m; ++i) x[i] = (double)xf[i];
+    for (int j = 0; j < m; ++j) {
+        const double* c = L + (size_t)j * m;
+        const double xj = x[j] / c[j];
+        x[j] = xj;
+        for (int i = j + 1; i < m; ++i) x[i] -= xj * c[i];
+    }
+    for (int j = m - 1; j >= 0; --j) {
+        const double* c = L + (size_t)j * m;
+        double s = 0.0;
+        for (int i = j + 1; i < m; ++i) s += c[i] * x[i];
+        x[j] = (x[j] - s) / c[j];
+    }
+    for (int i = 0; i < m; ++i) xf[i] = (float)x[i];
+}
+
 /* PADMMBase_Master::solve with PADMMLasso workers, one warm-started lambda path.
  *   A[k]: rows[k] x p float column-major (ld rows[k]);  Ab[k] = A_k'b_k (p);  L[k]: Cholesky factor of A_k'A_k + rho I (p x p, tall block)
  *   or of A_k A_k' + rho I (rows x rows, wide block: Woodbury, PADMMLasso.h:23-30), lower, column-major, dense.
  *   nthreads: OpenMP threads over the workers (the reference's loop, PADMMBase.h:180) -- and, when nthreads > K, inside the products. */
+static int consensus_path_impl(const float* const* A, const int* rows, const float* const* Ab, const float* const* L, const double* const* Ld, int K, int p,
+                          const double* lam, int nlam, double rho, double eps_abs, double eps_rel, int maxit, int nthreads,
+                          float* beta_out, int* niter_out, double* loop_seconds, double* trace, int trace_cap, int* ntrace, double budget_s);
 int oracle_consensus_path(const float* const* A, const int* rows, const float* const* Ab, const float* const* L, int K, int p,
                           const double* lam, int nlam, double rho, double eps_abs, double eps_rel, int maxit, int nthreads,
                           float* beta_out, int* niter_out, double* loop_seconds, double* trace, int trace_cap, int* ntrace, double budget_s) {
+    return consensus_path_impl(A, rows, Ab, L, NULL, K, p, lam, nlam, rho, eps_abs, eps_rel, maxit, nthreads, beta_out, niter_out, loop_seconds, trace, trace_cap, ntrace, budget_s);
+}
+/* Ld[k]: the Cholesky factor of the SAME float system in double -- the workers' small solves then run in double (rounding variant) */
+int oracle_consensus_path_exact(const float* const* A, const int* rows, const float* const* Ab, const double* const* Ld, int K, int p,
+                          const double* lam, int nlam, double rho, double eps_abs, double eps_rel, int maxit, int nthreads,
+                          float* beta_out, int* niter_out, double* loop_seconds, double* trace, int trace_cap, int* ntrace, double budget_s) {
+    return consensus_path_impl(A, rows, Ab, NULL, Ld, K, p, lam, nlam, rho, eps_abs, eps_rel, maxit, nthreads, beta_out, niter_out, loop_seconds, trace, trace_cap, ntrace, budget_s);
+}
+static int consensus_path_impl(const float* const* A, const int* rows, const float* const* Ab, const float* const* L, const double* const* Ld, int K, int p,
+                          const double* lam, int nlam, double rho, double eps_abs, double eps_rel, int maxit, int nthreads,
+                          float* beta_out, int* niter_out, double* loop_seconds, double* trace, int trace_cap, int* ntrace, double budget_s) {
     if (nthreads < 1) nthreads = 1;
+    double** dwork = malloc((size_t)K * sizeof(double*));
+    for (int k = 0; k < K; ++k) dwork[k] = Ld ? malloc((size_t)(rows[k] > p ? rows[k] : p) * sizeof(double)) : NULL;
     int cut = 0;
     float** x = malloc((size_t)K * sizeof(float*));
     float** y = malloc((size_t)K * sizeof(float*));
@@ -361,10 +396,10 @@ int oracle_consensus_path(const float* const* A, const int* rows, const float* c
                 }
                 if (m >= p) {
                     memcpy(x[k], rhs[k], (size_t)p * sizeof(float));
-                    llt_solve_f(L[k], p, x[k]);
+                    if (Ld) llt_solve_fd(Ld[k], p, x[k], dwork[k]); else llt_solve_f(L[k], p, x[k]);
                 } else {
                     axpy_cols_f(Ak, m, m, NULL, rhs[k], p, tv[k], inner);               /* t = A rhs */
-                    llt_solve_f(L[k], m, tv[k]);                                        /* s = (AA' + rho I)^-1 t */
+                    if (Ld) llt_solve_fd(Ld[k], m, tv[k], dwork[k]); else llt_solve_f(L[k], m, tv[k]);   /* s = (AA' + rho I)^-1 t */
 #pragma omp parallel for schedule(static) num_threads(inner) if (inner > 1)
                     for (int j = 0; j < p; ++j) g[k][j] = dot_f(Ak + (size_t)j * m, tv[k], m);   /* A's */
                     for (int j = 0; j < p; ++j) x[k][j] = (rhs[k][j] - g[k][j]) / rho_f;
@@ -412,8 +447,8 @@ int oracle_consensus_path(const float* const* A, const int* rows, const float* c
     }
     *loop_seconds = now_s() - t0;
     if (ntrace) *ntrace = ntr;
-    for (int k = 0; k < K; ++k) { free(x[k]); free(y[k]); free(rhs[k]); free(g[k]); free(tv[k]); free(Aown[k]); }
-    free(Ause); free(Aown);
+    for (int k = 0; k < K; ++k) { free(x[k]); free(y[k]); free(rhs[k]); free(g[k]); free(tv[k]); free(Aown[k]); free(dwork[k]); }
+    free(Ause); free(Aown); free(dwork);
     free(x); free(y); free(rhs); free(g); free(tv); free(sqr); free(z); free(nz);
     return 0;
 }

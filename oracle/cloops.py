@@ -45,6 +45,9 @@ def load():
         pp = ctypes.POINTER(_fp)
         lib.oracle_consensus_path.argtypes = [pp, _ip, pp, pp, c_int, c_int, _dp, c_int, c_dbl, c_dbl, c_dbl, c_int, c_int, _fp, _ip, _dp, _dp, c_int, _ip, c_dbl]
         lib.oracle_consensus_path.restype = c_int
+        ppd = ctypes.POINTER(_dp)
+        lib.oracle_consensus_path_exact.argtypes = [pp, _ip, pp, ppd, c_int, c_int, _dp, c_int, c_dbl, c_dbl, c_dbl, c_int, c_int, _fp, _ip, _dp, _dp, c_int, _ip, c_dbl]
+        lib.oracle_consensus_path_exact.restype = c_int
         lib.oracle_dense_loop.argtypes = [c_int, _dp, c_int, c_int, _dp, _dp, c_dbl, c_dbl, c_dbl, c_int, c_int, _dp, _dp, _dp, _dp, _ip, _dp, _dp, c_int, _ip, c_dbl]
         lib.oracle_dense_loop.restype = c_int
         lib.oracle_sharing_loop.argtypes = [_dp, c_long, c_int, c_int, c_int, _dp, _dp, c_dbl, c_dbl, c_dbl, c_int, c_int, _dp, _ip, _dp, _dp, c_int, _ip, c_dbl]
@@ -111,14 +114,16 @@ def admm_lasso_wide_c(x, y, lam, nlambda, lmin_ratio, standardize, intercept, op
 
 
 # ------------------------------------------------------------------------------------------------------------------- consensus
-def consensus_loop(A, Ab, Lf, p, lam_int, rho, eps_abs, eps_rel, maxit, nthreads=1, trace=None, budget_s=0.0):
+def consensus_loop(A, Ab, Lf, p, lam_int, rho, eps_abs, eps_rel, maxit, nthreads=1, trace=None, budget_s=0.0, exact=False):
     """A: list of row blocks (rows_k x p float32, column-major), Ab: their A_k'b_k, Lf: Cholesky factors (lower, float32,
-    column-major) of A_k'A_k + rho I (tall block) or A_k A_k' + rho I (wide block).  Returns (z per lambda, niter, seconds)."""
+    column-major) of A_k'A_k + rho I (tall block) or A_k A_k' + rho I (wide block).  Returns (z per lambda, niter, seconds).
+    exact=True: Lf are the factors of the same float systems in DOUBLE and the workers' small solves run in double (the rounding
+    variant "exact" of oracle/solvers.py PADMMLasso)."""
     lib = load()
     K = len(A)
     A = [np.asfortranarray(a, dtype=F) for a in A]
     Ab = [np.ascontiguousarray(v, dtype=F) for v in Ab]
-    Lf = [np.asfortranarray(np.tril(l), dtype=F) for l in Lf]
+    Lf = [np.asfortranarray(np.tril(l), dtype=np.float64 if exact else F) for l in Lf]
     rows = np.asarray([a.shape[0] for a in A], dtype=np.int32)
     arr = lambda xs: (_fp * K)(*[v.ctypes.data_as(_fp) for v in xs])
     lam_int = np.ascontiguousarray(lam_int, dtype=np.float64)
@@ -128,7 +133,8 @@ def consensus_loop(A, Ab, Lf, p, lam_int, rho, eps_abs, eps_rel, maxit, nthreads
     secs = ctypes.c_double()
     cap = nl * int(maxit) if trace is not None else 0
     tr, ntr = _trace_buf(cap)
-    rc = lib.oracle_consensus_path(arr(A), rows.ctypes.data_as(_ip), arr(Ab), arr(Lf), K, int(p), lam_int.ctypes.data_as(_dp), nl, float(rho),
+    fn, larr = (lib.oracle_consensus_path_exact, (_dp * K)(*[v.ctypes.data_as(_dp) for v in Lf])) if exact else (lib.oracle_consensus_path, arr(Lf))
+    rc = fn(arr(A), rows.ctypes.data_as(_ip), arr(Ab), larr, K, int(p), lam_int.ctypes.data_as(_dp), nl, float(rho),
                                    float(eps_abs), float(eps_rel), int(maxit), int(nthreads), beta.ctypes.data_as(_fp), niter.ctypes.data_as(_ip),
                                    ctypes.byref(secs), tr.ctypes.data_as(_dp) if cap else None, cap, ctypes.byref(ntr), float(budget_s))
     if rc != 0:
@@ -138,7 +144,7 @@ def consensus_loop(A, Ab, Lf, p, lam_int, rho, eps_abs, eps_rel, maxit, nthreads
     return beta, niter, secs.value
 
 
-def admm_parlasso_c(x, y, lam, nlambda, lmin_ratio, standardize, intercept, nthread, opts, nthreads=1, trace=None):
+def admm_parlasso_c(x, y, lam, nlambda, lmin_ratio, standardize, intercept, nthread, opts, nthreads=1, trace=None, exact=False):
     x = np.asarray(x, dtype=np.float64)
     y = np.asarray(y, dtype=np.float64)
     n, p = x.shape
@@ -151,9 +157,11 @@ def admm_parlasso_c(x, y, lam, nlambda, lmin_ratio, standardize, intercept, nthr
     if lam.size < 1:
         lam = _lambda_grid(s.lambda0, n, std.scaleY, nlambda, lmin_ratio)
     lam_int = np.array([l * n / np.float64(std.scaleY) for l in lam])
+    if exact:
+        s.xmode = "exact"                                    # instance attribute: double factors of the same float systems
     s.init(lam_int[0], float(opts["rho"]))                   # rho = lambda / K, the workers' float LLT factors (PADMMLasso.h:48-63)
     Lf = [np.tril(c[0]) for c in s.chol]
-    b, niter, secs = consensus_loop(s.A, s.Ab, Lf, p, lam_int, s.rho, opts["eps_abs"], opts["eps_rel"], opts["maxit"], nthreads, trace)
+    b, niter, secs = consensus_loop(s.A, s.Ab, Lf, p, lam_int, s.rho, opts["eps_abs"], opts["eps_rel"], opts["maxit"], nthreads, trace, exact=exact)
     beta = np.zeros((p + 1, lam.size), dtype=F)
     for i in range(lam.size):
         b0, coef = std.recover(b[i])

@@ -39,9 +39,9 @@ def _sparse(beta):
     return dict(beta_rows=r.astype(np.int32), beta_cols=c.astype(np.int32), beta_vals=beta[r, c].astype(np.float32), beta_shape=np.asarray(beta.shape))
 
 
-def dense_beta(g):
-    b = np.zeros(tuple(int(v) for v in g["beta_shape"]), dtype=np.float32)
-    b[g["beta_rows"], g["beta_cols"]] = g["beta_vals"]
+def dense_beta(g, prefix="beta"):
+    b = np.zeros(tuple(int(v) for v in g[prefix + "_shape"]), dtype=np.float32)
+    b[g[prefix + "_rows"], g[prefix + "_cols"]] = g[prefix + "_vals"]
     return b
 
 
@@ -128,9 +128,20 @@ def make_c4():
                                  nthreads=cloops.max_threads(), trace=trace)
     tr = np.asarray(trace)
     m = stop_margins(tr, accelerated=False)
+    # The reference's OWN rounding sensitivity at convergence: the same run with the workers' small solves (A_k A_k' + rho I) s = t carried
+    # out in double on the same float systems (rounding variant "exact" of oracle/solvers.py PADMMLasso; everything else -- the two float
+    # products with A_k, rhs, z, y -- unchanged).  Stored beside the reference-arithmetic run: `beta_exact_*`, `niter_exact`.
+    alt = cloops.admm_parlasso_c(x, y, None, c["nl"], c["lmin_ratio"], True, True, c["K"], dict(entry.LASSO_OPTS, maxit=c["maxit"]),
+                                 nthreads=cloops.max_threads(), exact=True)
+    ex = {"beta_exact_" + k[5:]: v for k, v in _sparse(alt["beta"]).items()}
+    sys.path.insert(0, os.path.dirname(HERE))
+    from helpers import col_err
+    floor = 1e-2 * float(np.abs(ref["beta"]).max())
+    drift = [float(col_err(alt["beta"][:, j], ref["beta"][:, j], floor)) for j in range(c["nl"])]
+    print(f"[c4] exact-solve variant: niter {alt['niter'].tolist()}; distance from the reference-arithmetic run per column {drift}", flush=True)
     path = os.path.join(HERE, "c4_converged.npz")
     np.savez_compressed(path, **{k: v for k, v in c.items()}, lam=ref["lambda"], niter=ref["niter"].astype(np.int64), rho=np.float64(ref["rho"]),
-                        trace=tr, margins=m, **_sparse(ref["beta"]))
+                        trace=tr, margins=m, niter_exact=alt["niter"].astype(np.int64), drift_exact=np.asarray(drift), **ex, **_sparse(ref["beta"]))
     print(f"[c4] wrote {path} {os.path.getsize(path)} bytes; niter {ref['niter'].tolist()} rho {ref['rho']} nnz {(ref['beta'][1:] != 0).sum(axis=0).tolist()}; "
           f"closest stopping test {m.min():.2e}; loop {ref['loop_seconds']:.0f} s, total {time.time() - t0:.0f} s", flush=True)
 

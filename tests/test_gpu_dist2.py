@@ -219,7 +219,7 @@ def test_shm_bootstrap_ignores_a_stale_segment_of_the_same_name():
             os.unlink(path)
 
 
-@pytest.mark.parametrize("case", ["tallshard2300", "widecols"])
+@pytest.mark.parametrize("case", ["tallshard2300", "widecols", "wideblocks"])
 def test_single_launch_exchange_falls_back_when_its_grid_would_not_be_resident(case):
     """The PEER exchange of the two sharded solvers normally runs producer and consumer in ONE launch (tall_tail_kernel
     <TAIL_PEER1>, wide_tail_kernel<2>): every workgroup publishes its share, counts itself in and then WAITS for the flags,
@@ -229,7 +229,8 @@ def test_single_launch_exchange_falls_back_when_its_grid_would_not_be_resident(c
     workgroups): the solvers must take the two-launch form (exchange_variant 2, not 3) -- no hang -- and return the very
     same bits."""
     one = _run_ranks("peer", case)
-    two = _run_ranks("peer", case, extra_env=dict(ADMM_HIP_TEST_RESIDENT_WGS="4"))
+    # (wideblocks, round 6: the consensus solver's `pack` + `z` as one launch, par_z_kernel<1, true>; p = 300 is two workgroups: a device that holds one)
+    two = _run_ranks("peer", case, extra_env=dict(ADMM_HIP_TEST_RESIDENT_WGS="1" if case == "wideblocks" else "4"))
     assert int(one[0]["exchange_variant"]) == 3 and int(two[0]["exchange_variant"]) == 2, (one[0]["exchange_variant"], two[0]["exchange_variant"])
     for r in range(2):
         assert np.array_equal(one[r]["beta"], two[r]["beta"]) and np.array_equal(one[r]["niter"], two[r]["niter"])

@@ -103,6 +103,43 @@ def test_gram_16bit_split_is_fp32_accurate(rows, cols, kind, split, monkeypatch)
     assert np.sqrt((e3 ** 2).mean()) <= 2.0 * np.sqrt((e1 ** 2).mean()) + 1e-8
 
 
+def test_gram_16bit_split_at_the_headline_row_count(monkeypatch):
+    """The DEFAULT Gram of BASELINE configs[1] at its real K range: 100 000 rows x 10 000 standardised columns through the fp16 x 2 split
+    (13 launches of 8192-row slabs accumulated in fp32), against float64 X'X formed on the device by torch.  Same normalised metric and
+    same bound as test_gram_16bit_split_is_fp32_accurate (which stops at 20 000 rows): no worse than 2 x the exact-fp32 matrix-core
+    kernel on the same input.  (BlasWrapper.h:89-112: the reference forms this matrix in float with Eigen.)"""
+    import torch
+    rows, cols = 100000, 10000
+    rng = np.random.default_rng(100000 + 10000)
+    A = np.empty((rows, cols), dtype=np.float32, order="F")
+    for j0 in range(0, cols, 500):
+        blk = rng.standard_normal((rows, 500), dtype=np.float32) * rng.uniform(0.1, 30.0, size=500).astype(np.float32)[None, :] \
+            + rng.uniform(-5, 5, size=500).astype(np.float32)[None, :]
+        blk64 = blk.astype(np.float64)
+        A[:, j0:j0 + 500] = ((blk64 - blk64.mean(0)) / blk64.std(0)).astype(np.float32)
+    monkeypatch.setenv("ADMM_HIP_GRAM_SPLIT", "f16x2")
+    G3 = _gram(A, True)
+    monkeypatch.setenv("ADMM_HIP_GRAM_SPLIT", "0")
+    G1 = _gram(A, True)
+    assert np.array_equal(G3, G3.T) and not np.array_equal(G3, G1), "the 16-bit path was not taken"
+    dev = torch.device("cuda", 0)
+    ref = torch.zeros((cols, cols), dtype=torch.float64, device=dev)
+    for r0 in range(0, rows, 10000):                                   # float64 X'X on the device, 10 000 rows at a time
+        blk = torch.from_numpy(np.ascontiguousarray(A[r0:r0 + 10000])).to(dev).double()
+        ref += blk.T @ blk
+    del blk
+    d = torch.diagonal(ref).clamp_min(1e-300).sqrt()
+    out = {}
+    for name, G in (("split", G3), ("fp32", G1)):
+        e = (torch.from_numpy(G).to(dev).double() - ref).abs() / (d[:, None] * d[None, :])
+        out[name] = (float(e.max()), float((e * e).mean().sqrt()))
+        del e
+    print(f"[gram f16x2 at n = 10^5, p = 10^4] max error / sqrt(g_ii g_jj): split {out['split'][0]:.2e} (rms {out['split'][1]:.2e}), "
+          f"fp32 kernel {out['fp32'][0]:.2e} (rms {out['fp32'][1]:.2e})")
+    assert out["split"][0] <= 2.0 * out["fp32"][0] + 1e-7
+    assert out["split"][1] <= 2.0 * out["fp32"][1] + 1e-8
+
+
 @pytest.mark.parametrize("n", [256, 301, 1100, 2300])
 @pytest.mark.parametrize("precision", [0, 1])
 def test_output_tiles_through_lds_are_bit_identical(n, precision, monkeypatch):
