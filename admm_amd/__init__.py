@@ -5,7 +5,7 @@ lib/libadmm_hip.so by `python -m admm_amd.build`) and `api.py`, the host-side mi
 reference's `admm_lasso()/admm_enet()/admm_lad()/admm_bp()` builder chain.
 """
 from .api import (LassoPlan, ADMM_BP, ADMM_Dantzig, ADMM_Enet, ADMM_LAD, ADMM_Lasso, admm_bp, admm_dantzig, admm_enet, admm_lad, admm_lasso)
-from ._lib import AdmmHipError, DevicePtr, load
+from ._lib import AdmmHipError, DevicePtr, load, options
 
 __all__ = ["admm_lasso", "admm_enet", "admm_lad", "admm_bp", "admm_dantzig", "ADMM_Dantzig", "ADMM_Lasso", "ADMM_Enet", "ADMM_LAD", "ADMM_BP",
-           "LassoPlan", "DevicePtr", "AdmmHipError", "load"]
+           "LassoPlan", "DevicePtr", "AdmmHipError", "load", "options"]

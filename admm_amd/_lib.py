@@ -20,6 +20,14 @@ class AdmmOpts(ctypes.Structure):
                 ("eps_rel", ctypes.c_double), ("rho", ctypes.c_double)]
 
 
+class AdmmHipOptions(ctypes.Structure):
+    """include/admm_hip.h: admm_hip_options (variant selectors of the calling thread; every field 0 = library default)."""
+    _fields_ = [(k, ctypes.c_int) for k in (
+        "struct_size", "gram_backend", "gram_split", "factor_backend", "inverse_precision", "tall_xupdate", "tall_refine",
+        "consensus_two_pass", "consensus_unfused", "bp_two_pass", "lad_no_hat", "wide_no_persist", "wide_unfused", "wide_gram_sprad",
+        "sharing_bp_direct", "cv_downdate", "peer_exchange", "batch_iters", "profile_stride", "pool_mb")] + [("reserved", ctypes.c_int * 12)]
+
+
 class AdmmStats(ctypes.Structure):
     _fields_ = [("t_h2d", ctypes.c_double), ("t_standardize", ctypes.c_double), ("t_gram", ctypes.c_double),
                 ("t_eigs", ctypes.c_double), ("t_factor", ctypes.c_double), ("t_loop", ctypes.c_double),
@@ -62,7 +70,8 @@ EXPORTS = ["admm_hip_lasso", "admm_hip_enet", "admm_hip_parlasso", "admm_hip_lad
            "admm_hip_lasso_dist_cols", "admm_hip_test_gemv_t", "admm_hip_lad_traced", "admm_hip_bp_traced",
            "admm_hip_lasso_plan_create_dist_cols", "admm_hip_lasso_cv", "admm_hip_lasso_multi",
            "admm_hip_parbp", "admm_hip_parbp_traced", "admm_hip_parbp_dist", "admm_hip_dantzig", "admm_hip_dantzig_traced",
-           "admm_hip_lad_state", "admm_hip_bp_state", "admm_hip_lasso_plan_data_read", "admm_hip_trim_memory", "admm_hip_test_gather"]
+           "admm_hip_lad_state", "admm_hip_bp_state", "admm_hip_lasso_plan_data_read", "admm_hip_trim_memory", "admm_hip_test_gather",
+           "admm_hip_options_default", "admm_hip_options_set", "admm_hip_option_set", "admm_hip_options_reset", "admm_hip_option_get"]
 
 TRACE_FIELDS = 12
 TRACE_COLD, TRACE_CONVERGED, TRACE_ACCELERATE, TRACE_RESTART = -1, 0, 1, 2
@@ -163,6 +172,16 @@ def load():
     lib.admm_hip_comm_init.restype = ctypes.c_int
     lib.admm_hip_comm_finalize.argtypes = []
     lib.admm_hip_comm_finalize.restype = ctypes.c_int
+    lib.admm_hip_options_default.argtypes = [ctypes.POINTER(AdmmHipOptions)]
+    lib.admm_hip_options_default.restype = ctypes.c_int
+    lib.admm_hip_options_set.argtypes = [ctypes.POINTER(AdmmHipOptions)]
+    lib.admm_hip_options_set.restype = ctypes.c_int
+    lib.admm_hip_option_set.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+    lib.admm_hip_option_set.restype = ctypes.c_int
+    lib.admm_hip_options_reset.argtypes = []
+    lib.admm_hip_options_reset.restype = ctypes.c_int
+    lib.admm_hip_option_get.argtypes = [ctypes.c_char_p]
+    lib.admm_hip_option_get.restype = ctypes.c_char_p
     lib.admm_hip_comm_info.argtypes = [ctypes.POINTER(ctypes.c_int)] * 3
     lib.admm_hip_comm_info.restype = ctypes.c_int
     lib.admm_hip_comm_peer_prepare.argtypes = [ctypes.c_int, ctypes.c_void_p]
@@ -227,3 +246,52 @@ def as_input(a, n=None, p=None):
         return ctypes.c_void_p(a.ptr), ADMM_MEM_DEVICE, a
     arr = np.asfortranarray(np.asarray(a, dtype=np.float64))
     return ctypes.c_void_p(arr.ctypes.data), ADMM_MEM_HOST, arr
+
+
+class options:
+    """Variant selectors / tuning values of the CALLING THREAD for the duration of a `with` block (admm_hip_option_set; names as in
+    INTEGRATION.md, case-insensitive, with or without the ADMM_HIP_ prefix; value None = library default):
+
+        with admm_amd.options(GRAM_SPLIT="f16x2", INVERSE="f64"):
+            fit = admm_amd.admm_lasso(x, y).penalty(nlambda=20).fit()
+
+    A prepared problem (LassoPlan) reads them when it is created.  On exit the previous values of exactly these names are restored.
+    Fields of the typed struct go through `options.struct(gram_split=2, ...)` (admm_hip_options_set: replaces ALL of the thread's settings)."""
+
+    def __init__(self, **kw):
+        self.kw = {k.upper(): (None if v is None else str(v)) for k, v in kw.items()}
+        self.old = {}
+
+    def __enter__(self):
+        lib = load()
+        for k, v in self.kw.items():
+            cur = lib.admm_hip_option_get(k.encode())
+            self.old[k] = cur.decode() if cur is not None else None
+            check(lib.admm_hip_option_set(k.encode(), None if v is None else v.encode()))
+        return self
+
+    def __exit__(self, *exc):
+        lib = load()
+        for k, v in self.old.items():
+            check(lib.admm_hip_option_set(k.encode(), None if v is None else v.encode()))
+        return False
+
+    @staticmethod
+    def set(**kw):
+        lib = load()
+        for k, v in kw.items():
+            check(lib.admm_hip_option_set(k.upper().encode(), None if v is None else str(v).encode()))
+
+    @staticmethod
+    def reset():
+        check(load().admm_hip_options_reset())
+
+    @staticmethod
+    def struct(**fields):
+        lib = load()
+        o = AdmmHipOptions()
+        check(lib.admm_hip_options_default(ctypes.byref(o)))
+        for k, v in fields.items():
+            setattr(o, k, int(v))
+        check(lib.admm_hip_options_set(ctypes.byref(o)))
+        return o

@@ -41,6 +41,16 @@ inline double now_s() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// Variant selectors / tuning values of the library (api.hip).  option("GRAM_SPLIT") returns the value in force for the CALLING THREAD, or
+// nullptr for "library default": first what the thread set through the C ABI (admm_hip_options_set / admm_hip_option_set -- what
+// admm_amd/api.py's options() and an R caller use), then the process-wide overlay of ADMM_HIP_<NAME> environment variables, which is
+// captured ONCE when the library is first used (a debugging aid: nothing reads the environment per call, and two threads can run two
+// different variants at the same time).  The pointer stays valid until the thread changes its options.
+const char* option(const char* name);
+int option_int(const char* name, int dflt);
+void option_set_thread(const char* name, const char* value);      // value nullptr: back to the default / overlay
+void options_reset_thread();
+
 // Cache of large device blocks (api.hip).  hipMalloc / hipFree of multi-GB buffers are synchronous page-table operations whose cost
 // varies by box and by what the process freed before (measured on C2, second plan creation of a process: 0.07 s of kernels inside
 // 0.07 .. 0.31 s of wall, the difference all in hipFree / hipMalloc of the 4 GB operands) -- a resident server or an R session that

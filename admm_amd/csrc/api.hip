@@ -1,4 +1,6 @@
 // extern "C" boundary of libadmm_hip.so (see include/admm_hip.h).
+#include <cstring>
+#include <unordered_map>
 #include "solvers.h"
 #include "comm.h"
 #include <mutex>
@@ -19,6 +21,43 @@ void comm_init_shm(int nranks, int rank, const char* name, unsigned long long to
 void cv_gather(const double* x, long long ldx, const double* y, const int* d_idx, int m, int p, double* xo, double* yo, hipStream_t st);
 std::vector<double> cv_score(const double* xt, const double* yt, int m, int p, const float* beta_host, int nlam, hipStream_t st);
 
+// ---- variant selectors / tuning values (admm_internal.h: option)
+}  // namespace admm
+extern char** environ;
+namespace admm {
+namespace {
+using OptMap = std::unordered_map<std::string, std::string>;
+// the ADMM_HIP_* variables of the environment the library was first used in -- read once, never again
+const OptMap& option_overlay() {
+    static const OptMap* m = []() {
+        OptMap* o = new OptMap();
+        for (char** e = environ; e && *e; ++e) {
+            if (std::strncmp(*e, "ADMM_HIP_", 9) != 0) continue;
+            const char* eq = std::strchr(*e, '=');
+            if (eq && eq > *e + 9) (*o)[std::string(*e + 9, (size_t)(eq - (*e + 9)))] = std::string(eq + 1);
+        }
+        return o;
+    }();
+    return *m;
+}
+OptMap& option_thread() { static thread_local OptMap m; return m; }
+}  // namespace
+const char* option(const char* name) {
+    const OptMap& t = option_thread();
+    if (!t.empty()) { auto it = t.find(name); if (it != t.end()) return it->second.c_str(); }
+    const OptMap& o = option_overlay();
+    auto it = o.find(name);
+    return it != o.end() ? it->second.c_str() : nullptr;
+}
+int option_int(const char* name, int dflt) {
+    const char* v = option(name);
+    return v ? std::atoi(v) : dflt;
+}
+void option_set_thread(const char* name, const char* value) {
+    if (value) option_thread()[name] = value; else option_thread().erase(name);
+}
+void options_reset_thread() { option_thread().clear(); }
+
 // ---- cache of large device blocks (admm_internal.h, DevBuf)
 namespace {
 struct PoolBlock { void* p; size_t bytes; int dev; };
@@ -29,13 +68,18 @@ struct Pool {
 };
 Pool& pool() { static Pool* p = new Pool(); return *p; }             // never destroyed: the runtime may be gone at process exit
 constexpr size_t kPoolMinBytes = size_t(32) << 20;
+// Cap of the cache: ADMM_HIP_POOL_MB, default the smaller of 16 GB and an eighth of the device's memory (24 GB held back from
+// every other allocator of the process -- library workspaces, RCCL, torch, an R session -- was too much to keep silently; what a warm
+// C2 setup re-uses is ~10 GB).  Allocators of this library that bypass DevBuf (the PEER exchange buffer) trim the cache and retry on
+// out-of-memory themselves; admm_hip_trim_memory() hands everything back on request.
 size_t pool_cap_bytes() {
-    static const size_t cap = []() {
-        const char* e = std::getenv("ADMM_HIP_POOL_MB");
-        const long long mb = e ? std::atoll(e) : 24576;
-        return mb > 0 ? (size_t)mb << 20 : size_t(0);
+    if (const char* e = option("POOL_MB")) { const long long mb = std::atoll(e); return mb > 0 ? (size_t)mb << 20 : size_t(0); }
+    static const size_t dflt = []() {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); total_b = size_t(128) << 30; }
+        return std::min(size_t(16) << 30, total_b / 8);
     }();
-    return cap;
+    return dflt;
 }
 void pool_drop_locked(Pool& P, int dev) {                               // dev < 0: every device
     size_t w = 0;
@@ -87,12 +131,21 @@ void pool_free(void* p, size_t granted) {
             hipPointerAttribute_t at;
             if (hipPointerGetAttributes(&at, p) == hipSuccess) dev = at.device;      // the device the block lives on (the caller may have switched)
             Pool& P = pool();
-            std::lock_guard<std::mutex> lk(P.mu);
-            if (P.cached + granted <= pool_cap_bytes()) {
-                // a block may be handed to another stream's work next: everything enqueued on it must have finished (hipFree would have waited too)
+            bool keep = false;
+            {   // reserve the room first, synchronise OUTSIDE the lock (other threads' allocations must not queue behind this device's streams)
+                std::lock_guard<std::mutex> lk(P.mu);
+                if (P.cached + granted <= pool_cap_bytes()) { P.cached += granted; keep = true; }
+            }
+            if (keep) {
+                // a block may be handed to another stream's work next: everything enqueued on ITS device must have finished (hipFree would
+                // have waited too) -- under a device guard: the caller may have switched devices since the block was allocated
+                int cur = dev;
+                (void)hipGetDevice(&cur);
+                if (cur != dev) (void)hipSetDevice(dev);
                 (void)hipDeviceSynchronize();
-                P.blocks.push_back({p, granted, dev});
-                P.cached += granted;
+                if (cur != dev) (void)hipSetDevice(cur);
+                std::lock_guard<std::mutex> lk(P.mu);
+                P.blocks.push_back({p, granted, dev});          // (its bytes are already counted)
                 return;
             }
         }
@@ -131,10 +184,6 @@ std::vector<double> make_lambda_grid(const LassoProblem& pb, double lambda0, int
     return lam;
 }
 
-static int env_int(const char* name, int dflt) {
-    const char* v = std::getenv(name);
-    return v ? std::atoi(v) : dflt;
-}
 
 template <typename F>
 static int guarded(F&& f) {
@@ -180,8 +229,8 @@ static LassoProblem make_problem(const double* lambda_in, int nlambda_in, int nl
     pb.alpha = alpha;
     pb.nworkers = nworkers;
     pb.dist = dist;
-    pb.batch_iters = env_int("ADMM_HIP_BATCH_ITERS", 0);
-    pb.profile_stride = env_int("ADMM_HIP_PROFILE_STRIDE", 0);
+    pb.batch_iters = option_int("BATCH_ITERS", 0);
+    pb.profile_stride = option_int("PROFILE_STRIDE", 0);
     return pb;
 }
 
@@ -207,7 +256,7 @@ static PlanHandle* create_plan(const double* x, const double* y, int n, int p, i
     const LassoProblem pb = make_problem(lambda_in, nlambda_in, nlambda_auto, lmin_ratio, enet, alpha, nworkers, dist, opts);
     DeviceData<float> d;
     // Host input of a large tall problem: standardisation and X'X run under the PCIe transfer (bit-identical result).
-    const char* eg = std::getenv("ADMM_HIP_GRAM");
+    const char* eg = option("GRAM");
     const bool pipelined = mem == ADMM_MEM_HOST && !dist && nworkers <= 0 && n > p && p >= 4096 &&
                            !(eg && (std::string(eg) == "rocblas" || std::string(eg) == "oneshot"));
     if (pipelined) upload_standardize_gram_f32(d, x, y, n, p, standardize != 0, intercept != 0, h->st.s);
@@ -246,7 +295,7 @@ static PlanHandle* create_plan_cols(const double* x_cols, const double* y, int n
     pb.alpha = alpha;
     pb.p_total = p_total;
     pb.col_offset = col_offset;
-    pb.batch_iters = env_int("ADMM_HIP_BATCH_ITERS", 0);
+    pb.batch_iters = option_int("BATCH_ITERS", 0);
     DeviceData<float> d;
     upload_standardize<float>(d, x_cols, y, n, p_local, mem, standardize != 0, intercept != 0, h->st.s, 0);   // column moments are local, y is replicated
     h->plan = make_wide_plan(std::move(d), pb, h->st.s);
@@ -324,7 +373,7 @@ static void lasso_cv(const double* x, const double* y, int n, int p, int mem, co
     int min_tr = n;
     for (int f = 0; f < nfolds; ++f) min_tr = std::min(min_tr, n - cnt[f]);
     bool downdate = min_tr > p && p >= 1024;
-    if (const char* e = std::getenv("ADMM_HIP_CV_DOWNDATE")) downdate = min_tr > p && std::string(e) == "1";
+    if (const char* e = option("CV_DOWNDATE")) downdate = min_tr > p && std::string(e) == "1";
     CvBase base;
     if (downdate) {
         ADMM_REQUIRE(nlambda_in >= 0, "nlambda_in must be >= 0");
@@ -474,7 +523,7 @@ static void lasso_multi(const double* x, const double* Y, int n, int p, int m, i
     pb.lmin_ratio = lmin_ratio;
     pb.enet = enet;
     pb.alpha = enet ? alpha : 1.0;
-    pb.batch_iters = env_int("ADMM_HIP_BATCH_ITERS", 0);
+    pb.batch_iters = option_int("BATCH_ITERS", 0);
     pb.profile_stride = 0;
     if (nlambda_in == 0) ADMM_REQUIRE(lmin_ratio > 0 && lmin_ratio < 1, "lambda_min_ratio must be within (0, 1)");
     for (int i = 0; i < nlambda_in; ++i) ADMM_REQUIRE(lambda_in[i] > 0, "lambda must be positive");
@@ -851,6 +900,63 @@ int admm_hip_lasso_plan_create_dist_cols(const double* x_cols, const double* y, 
     });
 }
 
+int admm_hip_options_default(admm_hip_options* o) {
+    return guarded([&] {
+        ADMM_REQUIRE(o != nullptr, "options must not be NULL");
+        std::memset(o, 0, sizeof(*o));
+        o->struct_size = (int)sizeof(*o);
+    });
+}
+int admm_hip_options_reset(void) { return guarded([&] { options_reset_thread(); }); }
+int admm_hip_option_set(const char* name, const char* value) {
+    return guarded([&] {
+        ADMM_REQUIRE(name != nullptr && name[0] != 0, "option name must not be empty");
+        std::string n(name);
+        if (n.rfind("ADMM_HIP_", 0) == 0) n = n.substr(9);
+        for (char& c : n) c = (char)std::toupper((unsigned char)c);
+        option_set_thread(n.c_str(), value);
+    });
+}
+const char* admm_hip_option_get(const char* name) {
+    if (!name) return nullptr;
+    std::string n(name);
+    if (n.rfind("ADMM_HIP_", 0) == 0) n = n.substr(9);
+    for (char& c : n) c = (char)std::toupper((unsigned char)c);
+    return option(n.c_str());
+}
+int admm_hip_options_set(const admm_hip_options* o) {
+    return guarded([&] {
+        options_reset_thread();
+        if (o == nullptr) return;
+        ADMM_REQUIRE(o->struct_size >= (int)(2 * sizeof(int)) && o->struct_size <= (int)sizeof(admm_hip_options), "options: bad struct_size");
+        admm_hip_options v;
+        std::memset(&v, 0, sizeof(v));
+        std::memcpy(&v, o, (size_t)o->struct_size);
+        auto set = [](const char* k, const char* val) { option_set_thread(k, val); };
+        auto num = [](const char* k, int val) { option_set_thread(k, std::to_string(val).c_str()); };
+        if (v.gram_backend == 1) set("GRAM", "rocblas");
+        if (v.gram_split) { ADMM_REQUIRE(v.gram_split >= 1 && v.gram_split <= 3, "options: gram_split"); set("GRAM_SPLIT", v.gram_split == 1 ? "0" : (v.gram_split == 2 ? "f16x2" : "bf16x3")); }
+        if (v.factor_backend == 1) set("FACTOR", "rocsolver");
+        if (v.inverse_precision) { ADMM_REQUIRE(v.inverse_precision == 1 || v.inverse_precision == 2, "options: inverse_precision"); set("INVERSE", v.inverse_precision == 1 ? "f32" : "f64"); }
+        if (v.tall_xupdate) { ADMM_REQUIRE(v.tall_xupdate == 1 || v.tall_xupdate == 2, "options: tall_xupdate"); set("XUPDATE", v.tall_xupdate == 1 ? "gemv" : "sym"); }
+        if (v.tall_refine) set("REFINE", "1");
+        if (v.consensus_two_pass) set("PAR_ONEPASS", "0");
+        if (v.consensus_unfused >= 1) set("PAR_FUSE_PZ", "0");
+        if (v.consensus_unfused >= 2) set("PAR_BATCH", "0");
+        if (v.bp_two_pass) set("BP_ONEPASS", "0");
+        if (v.lad_no_hat) set("LAD_HAT", "0");
+        if (v.wide_no_persist == 1) set("WIDE_PERSIST", "0");
+        if (v.wide_no_persist == 2) set("WIDE_PERSIST_COLS", "0");
+        if (v.wide_unfused) set("WIDE_FUSE", "0");
+        if (v.wide_gram_sprad) set("WIDE_SPRAD", "gram");
+        if (v.sharing_bp_direct) set("SBP_GRAM", "0");
+        if (v.cv_downdate) set("CV_DOWNDATE", v.cv_downdate == 1 ? "1" : "0");
+        if (v.peer_exchange) set("PEER_FUSED", v.peer_exchange == 1 ? "2" : "0");
+        if (v.batch_iters > 0) num("BATCH_ITERS", v.batch_iters);
+        if (v.profile_stride > 0) num("PROFILE_STRIDE", v.profile_stride);
+        if (v.pool_mb) num("POOL_MB", v.pool_mb < 0 ? 0 : v.pool_mb);
+    });
+}
 int admm_hip_comm_unique_id(void* id_out) {
     return guarded([&] { ADMM_REQUIRE(id_out != nullptr, "id_out must not be NULL"); comm_unique_id(id_out); });
 }

@@ -34,11 +34,11 @@ constexpr size_t kDefaultSlotBytes = 4u << 20;        // payload capacity of one
 //              ADMM_HIP_COMM_PATIENT_TIMEOUT_S (default one hour).
 // An exchange takes the bound in force when it is ENQUEUED (CommLockstep, comm.h).
 double env_seconds(const char* name, double dflt) {
-    if (const char* e = std::getenv(name)) { const double v = std::atof(e); if (v > 0.0) return v; }
+    if (const char* e = option(name)) { const double v = std::atof(e); if (v > 0.0) return v; }
     return dflt;
 }
-double wait_seconds_lockstep() { static const double v = env_seconds("ADMM_HIP_COMM_TIMEOUT_S", 20.0); return v; }
-double wait_seconds_patient() { static const double v = env_seconds("ADMM_HIP_COMM_PATIENT_TIMEOUT_S", 3600.0); return v; }
+double wait_seconds_lockstep() { return env_seconds("COMM_TIMEOUT_S", 20.0); }
+double wait_seconds_patient() { return env_seconds("COMM_PATIENT_TIMEOUT_S", 3600.0); }
 std::atomic<int> g_lockstep{0};
 double wait_seconds_now() { return g_lockstep.load(std::memory_order_relaxed) > 0 ? wait_seconds_lockstep() : wait_seconds_patient(); }
 
@@ -59,7 +59,7 @@ int* g_derr = nullptr;                                // device word: set by a t
     } while (0)
 
 size_t slot_bytes_from_env() {
-    if (const char* e = std::getenv("ADMM_HIP_COMM_SLOT_BYTES")) {
+    if (const char* e = option("COMM_SLOT_BYTES")) {
         const long long v = std::atoll(e);
         if (v >= 4096) return (size_t)v / 16 * 16;
     }
@@ -337,10 +337,11 @@ void peer_alloc_local(int nranks) {
     // below) order and publish plain accesses to it across agents, so stores arriving from a peer are never shadowed by
     // a stale line of this device's L2.  ADMM_HIP_PEER_MEM=uncached selects MTYPE UC instead (every access a memory
     // transaction of its own: measured 3-10x slower for the 80 KB payload; kept as the conservative fallback).
-    const char* pm = std::getenv("ADMM_HIP_PEER_MEM");
+    const char* pm = option("PEER_MEM");
     const bool uncached = pm && std::string(pm) == "uncached";
     if (hipExtMallocWithFlags(&ptr, g_peer.bytes, uncached ? hipDeviceMallocUncached : hipDeviceMallocFinegrained) != hipSuccess) {
         (void)hipGetLastError();
+        pool_trim();                                          // the cache of released device blocks must never starve this allocation
         ADMM_HIP_CHECK(hipExtMallocWithFlags(&ptr, g_peer.bytes, uncached ? hipDeviceMallocFinegrained : hipDeviceMallocUncached));
     }
     g_peer.local = static_cast<unsigned char*>(ptr);

@@ -162,7 +162,7 @@ dz_tail_kernel(DzParams q, int par) {
 }
 
 static int dz_batch() {
-    const char* e = std::getenv("ADMM_HIP_BATCH_ITERS");
+    const char* e = option("BATCH_ITERS");
     const int v = e ? std::atoi(e) : 0;
     return v > 0 ? (v + 1) / 2 * 2 : 16;
 }

@@ -295,7 +295,7 @@ struct DenseLoop {
 };
 
 int env_batch(int dflt) {
-    const char* v = std::getenv("ADMM_HIP_BATCH_ITERS");
+    const char* v = option("BATCH_ITERS");
     int b = v ? std::atoi(v) : dflt;
     if (b <= 0) b = dflt;
     return (b + 1) / 2 * 2;
@@ -321,7 +321,7 @@ static void dense_collect_trace(DenseLoop& L, const DenseCtl& fc, DenseResult& r
         res.state_dim = L.q.dim;
         res.state.resize((size_t)ns * 5 * L.q.dim);
         if (ns > 0) read_back(res.state.data(), L.state.get(), res.state.size() * sizeof(double), st);
-        if (ns > 0 && std::getenv("ADMM_HIP_DEBUG_REREAD")) {
+        if (ns > 0 && option("DEBUG_REREAD")) {
             // diagnosis of profiles/r04_transient_stale_lines.md: the dump above came through read_back()'s pinned bounce buffer.  Read the
             // same device memory again through the pinned path and through the runtime's pageable hipMemcpy, and report which differs.
             std::vector<double> pinned2(res.state.size()), pageable(res.state.size());
@@ -353,7 +353,7 @@ void solve_lad(const DeviceData<double>& d, const admm_opts& opts, DenseResult& 
     t0 = now_s();
     // n <= 2000: the hat-matrix branch below also needs the Cholesky factor of the same Gram matrix: keep a copy
     bool hat = n <= 2000;
-    if (const char* e = std::getenv("ADMM_HIP_LAD_HAT")) hat = hat && std::string(e) != "0";
+    if (const char* e = option("LAD_HAT")) hat = hat && std::string(e) != "0";
     DevBuf<double> G2;
     if (hat) {
         G2.alloc((size_t)ldp * ldp);
@@ -460,7 +460,7 @@ void solve_bp(const DeviceData<double>& d, const admm_opts& opts, DenseResult& r
     DevBuf<double> w0(d.ldx); w0.zero(st);
     const long long ldbt = round_up(p, 32);
     DevBuf<double> Bt((size_t)ldbt * n); Bt.zero(st);
-    const char* efac = std::getenv("ADMM_HIP_FACTOR");
+    const char* efac = option("FACTOR");
     if (efac && std::string(efac) == "rocsolver") {
         cholesky_lower<double>(G.get(), ldn, n, st);
         ADMM_HIP_CHECK(hipMemcpyAsync(B.get(), d.X.get(), (size_t)d.ldx * p * sizeof(double), hipMemcpyDeviceToDevice, st));
@@ -493,7 +493,7 @@ void solve_bp(const DeviceData<double>& d, const admm_opts& opts, DenseResult& r
     // iteration, B vec comes from n-sized recurrences + a gather over the non-zeros of z (DenseParams), and the second stored
     // layout of B (its transpose, another 8np bytes) is a setup temporary.
     bool onepass = true;
-    if (const char* e = std::getenv("ADMM_HIP_BP_ONEPASS")) onepass = std::string(e) != "0";
+    if (const char* e = option("BP_ONEPASS")) onepass = std::string(e) != "0";
     GemvT<double> gB, gBt;                       // t = B' w (p outputs) ; w = B vec (n outputs, via the stored transpose)
     gB.init(B.get(), d.ldx, n, p);
     if (!onepass) gBt.init(Bt.get(), ldbt, p, n);

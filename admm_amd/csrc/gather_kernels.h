@@ -136,7 +136,7 @@ inline GatherPlan plan_gather(int rows, int cols, int products = 1) {
     g.tiles = (rows + TILE - 1) / TILE;
     // about four workgroups per CU over all products of the launch, 8 ... 64 groups (the consumer sums `ngroups` partial rows)
     int want = (4 * device_info().num_cu + g.tiles * products - 1) / (g.tiles * products);
-    if (const char* e = std::getenv("ADMM_HIP_GATHER_GROUPS")) { if (std::atoi(e) > 0) want = std::atoi(e); }      // A/B knob
+    if (const char* e = option("GATHER_GROUPS")) { if (std::atoi(e) > 0) want = std::atoi(e); }      // A/B knob
     want = std::max(8, std::min(64, want));
     g.cols_per_group = round_up((cols + want - 1) / want, kGatherThreads);
     g.ngroups = (cols + g.cols_per_group - 1) / g.cols_per_group;

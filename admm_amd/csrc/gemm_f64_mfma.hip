@@ -44,7 +44,7 @@ __device__ __forceinline__ void tri_decode_d(int t, int& bi, int& bj) {
 // C = alpha A B' + beta C on 128 x 128 tiles (LOWER: only tiles on or below the diagonal of a square C)
 // EPI = 1 (every launch without the mirrored store): the output tile leaves through LDS, as in the float kernel
 // (syrk_mfma.hip: C read and written in whole column pieces instead of 32-byte pieces of 16 columns per instruction); same
-// arithmetic per element, bit-identical; ADMM_HIP_GEMM_EPI=0 keeps the direct stores.
+// arithmetic per element, bit-identical (measured against the direct stores in round 5).
 template <int LOWER, int EPI = 0>
 __global__ void __launch_bounds__(DK_THREADS, 2)
 gemm_nt_mfma_f64_kernel(GemmNTd g) {
@@ -207,9 +207,7 @@ static void launch_gemm_nt_f64(bool lower, const double* A, long long lda, const
     g.nbi = (M + DK_BM - 1) / DK_BM; g.nbj = (N + DK_BM - 1) / DK_BM;
     g.ntiles = lower ? g.nbi * (g.nbi + 1) / 2 : g.nbi * g.nbj;
     const int grid = (g.ntiles + 7) / 8 * 8;
-    const char* epi_env = std::getenv("ADMM_HIP_GEMM_EPI");             // read per call: the A/B test flips it inside one process
-    const bool epi_lds = !(epi_env && epi_env[0] == '0');
-    if (epi_lds && !mirror) {
+    if (!mirror) {                                          // output tile handed over through LDS (whole column pieces); the mirrored store keeps the direct stores
         if (lower) hipLaunchKernelGGL((gemm_nt_mfma_f64_kernel<1, 1>), dim3(grid), dim3(DK_THREADS), 0, st, g);
         else hipLaunchKernelGGL((gemm_nt_mfma_f64_kernel<0, 1>), dim3(grid), dim3(DK_THREADS), 0, st, g);
     } else if (lower) hipLaunchKernelGGL((gemm_nt_mfma_f64_kernel<1, 0>), dim3(grid), dim3(DK_THREADS), 0, st, g);

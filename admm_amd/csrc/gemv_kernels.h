@@ -267,7 +267,7 @@ struct GemvT {
         // (fp32, the consensus solver's 500 MB blocks: segments of 4096 rows take a single 100000 x 1250 product from 83.3 to 77.6 us, but the
         // batched launch of the eight workers' products does not gain: C4 782-790 against 801 it/s -- not applied)
         int seg = big64 ? 2048 : 0;
-        if (const char* e = std::getenv("ADMM_HIP_GEMV_SEG64")) { if (sizeof(T) == 8) seg = std::atoi(e); }      // A/B knob: 0 = the LDS-budget segments
+        if (const char* e = option("GEMV_SEG64")) { if (sizeof(T) == 8) seg = std::atoi(e); }      // A/B knob: 0 = the LDS-budget segments
         pl = plan_gemv_t<T>(m, k, 1, 4, seg, wg_per_cu);
         stride = round_up(k, 32);
         part.alloc((size_t)pl.nseg * stride);
@@ -279,7 +279,7 @@ struct GemvT {
     // the same with the right-hand vector taken from the un-reduced partials of `prev` (prev.k == m): a chain of
     // products needs no reduction launches in between
     void run_partials_from(const GemvT<T>& prev, const int* skip, hipStream_t st) {
-        static const int chain_rows = []() { const char* e = std::getenv("ADMM_HIP_GEMV_CHAIN"); return e ? std::atoi(e) : kChainRows; }();      // A/B knob
+        const int chain_rows = option_int("GEMV_CHAIN", kChainRows);      // A/B knob
         if (prev.pl.nseg > chain_rows) {
             // many partial rows (the 2048-row segments of a tall fp64 operand leave 25): EVERY workgroup of this product would sum
             // them all for its right-hand segment -- more L2 traffic than the matrix is HBM traffic.  One small launch sums them once,

@@ -284,7 +284,7 @@ colscale_kernel(const float* __restrict__ X, long long ldx, int rows, float* __r
 }
 
 int gram_split_mode() {
-    const char* e = std::getenv("ADMM_HIP_GRAM_SPLIT");       // read per call (the A/B tests flip it inside one process)
+    const char* e = option("GRAM_SPLIT");       // read per call (the A/B tests flip it inside one process)
     if (e == nullptr) return 2;
     const std::string v(e);
     if (v == "0" || v == "fp32") return 0;
@@ -332,7 +332,7 @@ static void launch_gram_b3(const GramSplit3& z, int ioff, int joff, float* C, lo
     // waits for -- and start together again with every launch.  ADMM_HIP_GRAM_B3_KTILES=<K tiles per launch> (A/B; 0 = one launch).
     const int nkt = g.K / GB_BK;
     int per_launch = 516;
-    if (const char* e = std::getenv("ADMM_HIP_GRAM_B3_KTILES")) per_launch = std::atoi(e);
+    if (const char* e = option("GRAM_B3_KTILES")) per_launch = std::atoi(e);
     if (per_launch <= 0) per_launch = nkt;
     per_launch = (per_launch + 5) / 6 * 6;
     for (int kt = 0; kt < nkt; kt += per_launch) {

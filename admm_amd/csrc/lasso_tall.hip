@@ -350,98 +350,6 @@ tall_tail_kernel(TallParams q, int par, PeerExchange ex) {
     WIDE_PROBE_FLUSH(blockIdx.x == 0 ? 0 : (blockIdx.x == gridDim.x - 1 ? 1 : -1), c.total - 1);
 }
 
-// ---------------------------------------------------------------------------------------------- single-launch iteration
-// ONE launch per ADMM iteration (p >= 2048, single GPU).  Launch g holds
-//   workgroups [0, nwg)      : the element-wise tail of iteration g-1 (it needs the mat-vec partials of launch g-1, which
-//                              crossed a kernel boundary), then -- by whichever of them finishes last -- the decision g;
-//   workgroups [nwg, nwg + T): the T lower-triangle tiles of the mat-vec of iteration g, which need the right-hand
-//                              sides u, w that the tail workgroups of THIS launch produce.
-// The tiles request their first matrix columns at once (those do not depend on u, w), then wait for a generation flag; the
-// tail workgroups publish u, w and their norm partials with write-through (agent-scope relaxed atomic) stores, wait for
-// the acknowledgements (workgroup-scope release = s_waitcnt, no cache write-back), and count themselves in; the last one
-// raises the flag (64 replicas, one cache line each, so that 1600 polling workgroups do not share a line) and evaluates
-// the decision from the partials (bypass loads).  The tiles then read u, w with bypass loads.  No fence writes back or
-// invalidates a cache, nothing spins on a line another agent hammers.  Against two launches per iteration this removes
-// one kernel boundary and hides the tail's latency under the start of the matrix stream.  The arithmetic, its order and
-// therefore every bit of the result are those of the two-launch path (tests/test_gpu_tall.py compares them).
-// The tail workgroups have the lowest block indices, so they are dispatched before any tile: a tile never waits for a
-// workgroup that cannot start.  Every wait is bounded all the same.
-struct TallFused {
-    SymvArgs sy;
-    int* flag;                   // [64][16] generation flags (one per 64-byte line)
-    unsigned int* arrive;        // tail workgroups that finished in this launch
-    int gen;                     // g + 1
-    int ntail;
-};
-
-struct TallFusedWait {
-    const int* flag; int gen;
-    __device__ __forceinline__ void operator()() const {
-        if (threadIdx.x == 0) {
-            const int* f = flag + (blockIdx.x & 63) * 16;
-            const long long t0 = wall_clock64();
-            while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gen) {
-                __builtin_amdgcn_s_sleep(1);
-                if (wall_clock64() - t0 > 200000000ll) break;           // 2 s: never hang (the result is then wrong and the solve fails its checks)
-            }
-        }
-        __syncthreads();
-    }
-};
-
-template <bool PRE>      // PRE: the tiles request their first matrix columns before they wait (symv2_tile)
-__global__ void __launch_bounds__(kTailThreads, 4)
-tall_fused_kernel(TallParams q, int par, TallFused f) {
-    __shared__ float4 red[2][kSyThreads];
-    __shared__ __attribute__((aligned(16))) float sdot[2][kSyCBMax];
-    __shared__ double scratch[6 * (kTailThreads / 64)];
-    __shared__ int s_last;
-    if ((int)blockIdx.x >= f.ntail) {                       // ---- a tile of the mat-vec of iteration g
-        if (*f.sy.skip != 0) return;                        // finished in an earlier launch
-        if (!PRE) TallFusedWait{f.flag, f.gen}();
-        symv2_tile<PRE>(f.sy, f.sy.tiles[blockIdx.x - f.ntail], TallFusedWait{f.flag, f.gen}, SymvBypassVec(), red, sdot);
-        return;
-    }
-    // ---- tail of iteration g - 1: parity of that iteration's launch pair in the two-launch scheme
-    const int tp = par ^ 1;
-    const TallCtl c = q.ctl[tp ^ 1];                        // == ctl[par]: published by the decision of launch g - 1
-    if (c.done && c.fin_idx < 0) {                          // finished earlier: the tiles of this launch do not wait either
-        if (blockIdx.x == 0 && threadIdx.x == 0) q.ctl[par ^ 1] = c;     // keep `done` sticky in both slots
-        return;
-    }
-    const int sub = threadIdx.x & (kTailLanes - 1);
-    const int i = blockIdx.x * kTailElems + threadIdx.x / kTailLanes;
-    const bool valid = i < q.p;
-    const bool owner = valid && sub == 0;
-    double acc[6] = {0, 0, 0, 0, 0, 0};
-    if (!c.first) {                                         // launch 0 has no previous iteration: u, w come from the init kernel
-        TallElem e = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (owner) e = tall_load_elem(q, tp, i);
-        float a, b;
-        symv_sum_partials<kTailLanes>(q.dot0, q.dot1, q.axp0, q.axp1, q.ldo, q.nrb, q.sched, q.p32, i, sub, valid, a, b);
-        if (owner) tall_update_elem<true>(q, c, tp, i, e, a, b, acc);
-    }
-    if (!c.done) {
-        block_sum<double, 6>(acc, scratch);
-        if (threadIdx.x == 0) {
-            double* Pout = q.P + ((size_t)(tp ^ 1) * q.nwg + blockIdx.x) * 8;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) tall_store_wt(Pout + k, acc[k]);
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's write-through stores are acknowledged
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned int prev = __hip_atomic_fetch_add(f.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = prev == (unsigned int)f.ntail - 1;
-        if (s_last) __hip_atomic_store(f.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (!s_last) return;
-    if (threadIdx.x < 64) __hip_atomic_store(f.flag + threadIdx.x * 16, f.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // u, w are complete
-    tall_decide<true>(q, par);                              // decision g from the partials of iteration g - 1 -> ctl[par ^ 1]
-}
-
 // Round 4 also built the whole path as ONE persistent launch with a third of the inverse's triangle resident in registers (two
 // grid barriers per iteration, decision off the critical path; bit-identical): 66.7 us per iteration against 39.25 at C2 -- the
 // barriers + an in-launch tail cost 16.6 us where the kernel boundaries cost 5.6, residency saves at most 10.8 us of the stream, and
@@ -525,9 +433,6 @@ struct TallPlan final : LassoPlan {
     CommInfo ci;
     DevBuf<float> ab;                                   // [2][ldp] this rank's share of (a, b), all-reduced in place
     double dist_flops = 0;                              // distributed factorisation: flops this rank performed (0: replicated)
-    bool fused = false, fused_pre = false;              // one launch per iteration (tall_fused_kernel); tiles prefetch before they wait
-    DevBuf<int> fflag;                                  // [64][16] generation flags of the single-launch iteration
-    DevBuf<unsigned int> farrive;
     long long ldv = 0;
     DevBuf<float> XY, M, a_part, b_part, x, z0, z1, y0, y1, adj_z, adj_y, u, w, beta;
     DevBuf<int> niter;
@@ -597,11 +502,11 @@ struct TallPlan final : LassoPlan {
             size_t free_b = 0, total_b = 0;
             ADMM_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
             free_b += pool_cached_bytes();                        // blocks this library holds for re-use are free for it
-            if (const char* e = std::getenv("ADMM_HIP_TEST_FREE_BYTES")) free_b = (size_t)std::atoll(e);
+            if (const char* e = option("TEST_FREE_BYTES")) free_b = (size_t)std::atoll(e);
             const bool have_gram = d.gram.get() && d.ldgram == ldp;
-            const bool inv64_wanted = p < 4096 || (std::getenv("ADMM_HIP_INVERSE") && std::string(std::getenv("ADMM_HIP_INVERSE")) == "f64");
+            const bool inv64_wanted = p < 4096 || (option("INVERSE") && std::string(option("INVERSE")) == "f64");
             const double mat = (double)ldp * (double)ldp * 4.0;
-            const double need = (have_gram ? 0.0 : mat) + (inv64_wanted ? 2.0 * mat : 0.5 * mat) + (std::getenv("ADMM_HIP_REFINE") ? mat : 0.0) +
+            const double need = (have_gram ? 0.0 : mat) + (inv64_wanted ? 2.0 * mat : 0.5 * mat) + (option("REFINE") ? mat : 0.0) +
                                 (shard && ci.nranks > 1 ? mat + mat / ci.nranks : 0.0);      // packed send / receive buffers of the Gram's reduce-scatter
             if (need > 0.97 * (double)free_b) {
                 char msg[320];
@@ -624,9 +529,9 @@ struct TallPlan final : LassoPlan {
         }
         // Row-sharded solver: decided here because it chooses how the split-K Gram is reduced (below)
         bool inv64 = p < 4096;
-        if (const char* e = std::getenv("ADMM_HIP_INVERSE")) inv64 = std::string(e) == "f64";
+        if (const char* e = option("INVERSE")) inv64 = std::string(e) == "f64";
         bool dist_factor = shard && ci.nranks > 1 && !inv64 && (p + 127) / 128 >= 2 * ci.nranks && p >= 256;
-        if (const char* e = std::getenv("ADMM_HIP_DIST_FACTOR")) dist_factor = dist_factor && std::string(e) != "0";
+        if (const char* e = option("DIST_FACTOR")) dist_factor = dist_factor && std::string(e) != "0";
 
         // rho (ADMMLassoTall.h:194-202)
         rho = pb.opts.rho;
@@ -696,7 +601,7 @@ struct TallPlan final : LassoPlan {
         // from the float system M = X'X + rho I (the reference's: XX.diagonal() += rho in float, ADMMLassoTall.h:204) -- the
         // x-update's error against the exact solve of that system drops from cond(M) ulps to about one ulp, i.e. onto what
         // oracle/variants.py calls the `exact` variant, at three passes over the triangle per iteration instead of one.
-        if (const char* e = std::getenv("ADMM_HIP_REFINE")) refine = std::string(e) == "1" && !shard;
+        if (const char* e = option("REFINE")) refine = std::string(e) == "1" && !shard;
         if (refine) {
             Mg.alloc((size_t)ldp * ldp);
             ADMM_HIP_CHECK(hipMemcpyAsync(Mg.get(), M.get(), (size_t)ldp * ldp * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -738,7 +643,7 @@ struct TallPlan final : LassoPlan {
         // x-update variant: lower-triangle symmetric mat-vec (2p^2 bytes) for large p, full-matrix
         // gemv_t (4p^2 bytes, fewer and larger workgroups) for small p.  ADMM_HIP_XUPDATE=full|sym overrides.
         use_sym = p >= 2048;
-        if (const char* e = std::getenv("ADMM_HIP_XUPDATE")) use_sym = std::string(e) == "sym";
+        if (const char* e = option("XUPDATE")) use_sym = std::string(e) == "sym";
         if (refine) use_sym = true;                      // the refinement is built on the symmetric kernel's partial layout
         if (shard) use_sym = true;                       // the sharded x-update is the tile list of the symmetric kernel dealt out to the ranks
         pl = plan_gemv_t<float>(p, p, 2, 4);
@@ -756,27 +661,18 @@ struct TallPlan final : LassoPlan {
         else if (!use_sym) { a_part.alloc((size_t)pl.nseg * ldp); b_part.alloc((size_t)pl.nseg * ldp); a_part.zero(st); b_part.zero(st); }
         // ADMM_HIP_PEER_FUSED=0: go through the generic all-reduce of the exchange layer also on the PEER backend
         peer_fused = shard && ci.backend == COMM_PEER;
-        if (const char* e = std::getenv("ADMM_HIP_PEER_FUSED")) { if (std::string(e) == "0") peer_fused = false; }
+        if (const char* e = option("PEER_FUSED")) { if (std::string(e) == "0") peer_fused = false; }
         if (peer_fused) {
             // one launch only when the whole grid is resident with room to spare (its workgroups wait for one another)
             int occ = 0;
             ADMM_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(tall_tail_kernel<TAIL_PEER1>), kTailThreads, 0));
             const int nwg_tail = (p + kTailElems - 1) / kTailElems;
             peer_one = (long long)nwg_tail * 2 <= resident_workgroups(occ);
-            if (const char* e = std::getenv("ADMM_HIP_PEER_FUSED")) { if (std::string(e) == "2") peer_one = false; }
+            if (const char* e = option("PEER_FUSED")) { if (std::string(e) == "2") peer_one = false; }
         }
-        // single-launch iteration (single GPU, symmetric x-update): opt-in with ADMM_HIP_TALL_FUSED=1 (=2: the tiles also
-        // request their first matrix columns before they wait).  Measured on C2 (scripts/fused_check.py, same box, all
-        // bit-identical): two launches 42.1 us per iteration, one launch 44.5 us, with the prefetch 47.1 us -- the kernel
-        // boundary it removes (1.8 us) and the tail latency it hides are paid back by the in-launch dependency chain
-        // (write-through acknowledgements, arrival counter, flag, poll, bypass loads of u, w: ~2 us per hop through the
-        // memory side), and carrying a prefetched chunk into the column loop costs the stream 4 us.  Two launches stay.
-        fused = false;
-        if (const char* e = std::getenv("ADMM_HIP_TALL_FUSED")) {
-            fused = use_sym && !shard && (std::string(e) == "1" || std::string(e) == "2");
-            fused_pre = std::string(e) == "2";
-        }
-        if (fused) { fflag.alloc(64 * 16); farrive.alloc(1); }
+        // (A single-launch iteration -- tail, decision and tiles in one launch -- and a hipGraph replay of the batch were built, measured
+        // bit-identical and SLOWER on C2 in rounds 4 / 5 (44.5 and 46.9 us per iteration against 42.1 / 46.6): removed in round 6,
+        // profiles/HISTORY.md.)
         x.alloc(ldv); z0.alloc(ldv); z1.alloc(ldv); y0.alloc(ldv); y1.alloc(ldv);
         adj_z.alloc(ldv); adj_y.alloc(ldv); u.alloc(ldv); w.alloc(ldv);
         beta.alloc((size_t)nlam * p); niter.alloc(nlam);
@@ -851,12 +747,12 @@ struct TallPlan final : LassoPlan {
 
     // One warm-started lambda path from a cold start (init at the first lambda, init_warm after).
     void run(LassoResult& res) override {
-        if (std::getenv("ADMM_HIP_DEBUG_DUMP")) {
+        if (option("DEBUG_DUMP")) {
             if (M.get()) debug_dump("M", M.get(), (size_t)ldp * ldp);
             debug_dump("XY", XY.get(), ldp);
         }
         admm_stats S = setup_stats;
-        S.xupdate_variant = shard ? 2 : (fused ? 3 : (use_sym ? 1 : 0));
+        S.xupdate_variant = shard ? 2 : (use_sym ? 1 : 0);
         S.exchange_variant = !shard ? 0 : (!peer_fused ? 1 : (peer_one ? 3 : 2));
         S.refine = refine ? 1 : 0;
         S.factor_flops = dist_flops;
@@ -866,7 +762,6 @@ struct TallPlan final : LassoPlan {
         hipLaunchKernelGGL(tall_init_kernel, dim3((init_n + 255) / 256), dim3(256), 0, st, q, rho, lam_int[0]);
         if (q.state != nullptr)      // record 0 of the iterate dump (the cold start has no iterates): X'y as this solver holds it, in the x slot
             ADMM_HIP_CHECK(hipMemcpyAsync(q.state, XY.get(), (size_t)p * sizeof(float), hipMemcpyDeviceToDevice, st));
-        if (fused) { fflag.zero(st); farrive.zero(st); }
         hctl[0].done = hctl[1].done = 0;
         *hflag.p = 0;
 #ifdef ADMM_HIP_PROBE
@@ -900,13 +795,7 @@ struct TallPlan final : LassoPlan {
                 // sampled launches carry start/stop events that time exactly the x-update kernel on this stream
                 // the decision of this iteration rides along as one extra workgroup of the x-update launch
                 const TallDecideExtra dec{q, par};
-                if (fused) {
-                    TallFused f;
-                    f.sy = sy.args(M.get(), ldp, u.get(), w.get(), &ctl.get()[par].done);
-                    f.flag = fflag.get(); f.arrive = farrive.get(); f.gen = (int)(g + 1); f.ntail = nwg;
-                    if (fused_pre) hipExtLaunchKernelGGL(tall_fused_kernel<true>, dim3(nwg + sy.ntiles), dim3(kTailThreads), 0, st, e0, e1, 0, q, par, f);
-                    else hipExtLaunchKernelGGL(tall_fused_kernel<false>, dim3(nwg + sy.ntiles), dim3(kTailThreads), 0, st, e0, e1, 0, q, par, f);
-                } else if (shard && peer_fused) {
+                if (shard && peer_fused) {
                     // this rank's tiles -> its share of (a, b) written into every rank's exchange slot by the reduction
                     // launch itself -> the (replicated) tail waits for the K flags and sums the K slots: three launches,
                     // none of them the exchange layer's
@@ -954,45 +843,12 @@ struct TallPlan final : LassoPlan {
             if (shard) ADMM_HIP_CHECK(hipMemcpyAsync(&hctl[slot], &ctl.get()[(int)(g & 1)], sizeof(TallCtl), hipMemcpyDeviceToHost, st));
             ADMM_HIP_CHECK(hipEventRecord(ev_poll[slot].e, st));
         };
-        // ADMM_HIP_TALL_GRAPH=1 (A/B knob): capture one batch (an even number of iterations, so the parity pattern repeats)
-        // into a hipGraph and replay it instead of enqueueing 2 x batch launches per poll.  Measured on C2
-        // (scripts/graph_check.py): bit-identical, 46.86 us per iteration against 46.56 us with plain launches on the
-        // same box -- the host already runs a whole batch ahead of the device, so there is no launch latency left to
-        // remove and the graph's kernel nodes dispatch no faster than back-to-back launches.  Plain launches stay.
-        hipGraphExec_t gexec = nullptr;
-        const bool use_graph = std::getenv("ADMM_HIP_TALL_GRAPH") && std::string(std::getenv("ADMM_HIP_TALL_GRAPH")) == "1" && stride <= 0 && !shard && !fused;
-        if (use_graph) {
-            hipGraph_t graph = nullptr;
-            ADMM_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-            const long long g_save = g;
-            for (int k = 0; k < batch; ++k, ++g) {
-                const int par = (int)(g & 1);
-                const TallDecideExtra dec{q, par};
-                if (use_sym) {
-                    sy.launch(M.get(), ldp, u.get(), w.get(), &ctl.get()[par].done, st, dec, nullptr, nullptr);
-                    hipLaunchKernelGGL(tall_tail_kernel<TAIL_SYMV>, dim3(nwg), dim3(kTailThreads), 0, st, q, par, PeerExchange{});
-                } else {
-                    launch_gemv_t<float, 2, 4, TallDecideExtra>(pl, M.get(), ldp, p, p, u.get(), w.get(), a_part.get(), b_part.get(), ldp,
-                                                                &ctl.get()[par].done, st, dec, nullptr, nullptr);
-                    hipLaunchKernelGGL(tall_tail_kernel<TAIL_GEMV>, dim3(nwg), dim3(kTailThreads), 0, st, q, par, PeerExchange{});
-                }
-            }
-            g = g_save;
-            ADMM_HIP_CHECK(hipStreamEndCapture(st, &graph));
-            ADMM_HIP_CHECK(hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
-            (void)hipGraphDestroy(graph);
-        }
-        auto enqueue_batch_graph = [&](int slot) {
-            ADMM_HIP_CHECK(hipGraphLaunch(gexec, st));
-            g += batch; launches += batch;
-            ADMM_HIP_CHECK(hipEventRecord(ev_poll[slot].e, st));
-        };
         int slot = 0;
-        if (use_graph) enqueue_batch_graph(slot); else enqueue_batch(slot);
+        enqueue_batch(slot);
         ADMM_HIP_CHECK(hipGetLastError());                 // launch failures surface here
         bool done = false;
         while (!done) {
-            if (use_graph) enqueue_batch_graph(slot ^ 1); else enqueue_batch(slot ^ 1);      // keep one batch in flight while polling the previous one
+            enqueue_batch(slot ^ 1);      // keep one batch in flight while polling the previous one
             comm_event_sync(ev_poll[slot].e);
             comm_check();
             done = shard ? hctl[slot].done != 0 : *static_cast<volatile int*>(hflag.p) != 0;
@@ -1004,13 +860,12 @@ struct TallPlan final : LassoPlan {
         S.t_loop = now_s() - tl0;
         ADMM_HIP_CHECK(hipMemcpy(hctl, ctl.get(), 2 * sizeof(TallCtl), hipMemcpyDeviceToHost));      // both slots: decisions taken
 #ifdef ADMM_HIP_PROBE
-        if (const char* f = std::getenv("ADMM_HIP_PROBE_OUT")) {
+        if (const char* f = option("PROBE_OUT")) {
             std::vector<long long> hp((size_t)4096 * 4 * 8);
             ADMM_HIP_CHECK(hipMemcpy(hp.data(), probe.get(), hp.size() * sizeof(long long), hipMemcpyDeviceToHost));
             if (FILE* fp = std::fopen(f, "wb")) { std::fwrite(hp.data(), sizeof(long long), hp.size(), fp); std::fclose(fp); }
         }
 #endif
-        if (gexec) (void)hipGraphExecDestroy(gexec);
         float ms = 0.f;
         ADMM_HIP_CHECK(hipEventElapsedTime(&ms, ev_loop0.e, ev_loop1.e));
         S.loop_ms_events = ms;
@@ -1026,7 +881,7 @@ struct TallPlan final : LassoPlan {
             S.xupdate_ms_avg = tot / (double)(nev / 2);
         }
 
-        if (std::getenv("ADMM_HIP_DEBUG_DUMP")) {
+        if (option("DEBUG_DUMP")) {
             debug_dump("x", x.get(), ldv); debug_dump("u", u.get(), ldv); debug_dump("w", w.get(), ldv);
             debug_dump("z0", z0.get(), ldv); debug_dump("y0", y0.get(), ldv);
             if (!use_sym) { debug_dump("a_part", a_part.get(), (size_t)pl.nseg * ldp); debug_dump("b_part", b_part.get(), (size_t)pl.nseg * ldp); }

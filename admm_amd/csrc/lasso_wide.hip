@@ -1632,7 +1632,7 @@ struct WidePlan final : LassoPlan {
         cshard = pb.p_total > 0;
         ci = cshard ? comm_info() : CommInfo();
         peer_fused = cshard && ci.backend == COMM_PEER;
-        if (const char* e = std::getenv("ADMM_HIP_PEER_FUSED")) { if (std::string(e) == "0") peer_fused = false; }
+        if (const char* e = option("PEER_FUSED")) { if (std::string(e) == "0") peer_fused = false; }
         p_total = cshard ? pb.p_total : p; col_offset = cshard ? pb.col_offset : 0;
         admm_stats& S = setup_stats;
         S.branch = 1; S.t_h2d = d.t_h2d; S.t_standardize = d.t_std;
@@ -1662,7 +1662,7 @@ struct WidePlan final : LassoPlan {
         // n x n matrix once instead of exchanging a p-vector per product).
         double t0 = now_s();
         bool gram_free = !cshard;
-        if (const char* e = std::getenv("ADMM_HIP_WIDE_SPRAD")) gram_free = !cshard && std::string(e) != "gram";
+        if (const char* e = option("WIDE_SPRAD")) gram_free = !cshard && std::string(e) != "gram";
         if (gram_free) {
             GramFreeWideOp op(d.X.get(), d.ldx, n, p, st);
             comm_stream_sync(st);
@@ -1698,13 +1698,13 @@ struct WidePlan final : LassoPlan {
             int occ = 0;
             ADMM_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(wide_tail_kernel<2>), kWideThreads, 0));
             peer_one = (long long)nwg_tail * 2 <= resident_workgroups(occ);
-            if (const char* e = std::getenv("ADMM_HIP_PEER_FUSED")) { if (std::string(e) == "2") peer_one = false; }
+            if (const char* e = option("PEER_FUSED")) { if (std::string(e) == "2") peer_one = false; }
         }
         x.alloc(ldp); x.zero(st);
         for (DevBuf<float>* b : {&Ax, &z, &y}) { b->alloc(std::max<long long>(ldn, 8192)); b->zero(st); }   // the fused x-update reads up to 32 x 256 entries unconditionally
         // ADMM_HIP_WIDE_FUSE=0: always three launches per iteration
         fuse_rt = n <= 1024 ? 4 : (n <= 2048 ? 8 : (n <= 4096 ? 16 : (n <= 6144 ? 24 : (n <= 8192 ? 32 : 0))));
-        if (const char* e = std::getenv("ADMM_HIP_WIDE_FUSE")) if (std::string(e) == "0") fuse_rt = 0;
+        if (const char* e = option("WIDE_FUSE")) if (std::string(e) == "0") fuse_rt = 0;
         lds_x = std::max((size_t)((n + 255) / 256 * 256) * 2 * sizeof(float), (size_t)std::min(std::max(fuse_rt, 4), 8) * kWideThreads * sizeof(float4));
         // The x-update stages t and t / gamma (2 n floats) in dynamic LDS: up to 64 KB by default, up to the device's
         // opt-in limit (160 KB on gfx950) after raising the kernel's attribute; beyond that (n > ~20 000) t goes through
@@ -1717,7 +1717,7 @@ struct WidePlan final : LassoPlan {
                 t_global = true;
             }
         }
-        if (const char* e = std::getenv("ADMM_HIP_WIDE_TGLOBAL")) if (std::string(e) == "1") t_global = true;
+        if (const char* e = option("WIDE_TGLOBAL")) if (std::string(e) == "1") t_global = true;
         if (t_global) { fuse_rt = 0; lds_x = 0; tbuf.alloc(ldn); tbuf.zero(st); }
         // grid of the x-update launch: exactly ONE resident round of workgroups (a regular step streams all of X; a
         // partial second round runs at a fraction of the occupancy: 342 us instead of 280 us at C3 with 4 per CU
@@ -1734,7 +1734,7 @@ struct WidePlan final : LassoPlan {
             ADMM_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&wgx, fn, kWideThreads, lds_x));
             wgx = std::max(1, std::min(wgx, 4));
         }
-        if (const char* e = std::getenv("ADMM_HIP_WIDE_WGX")) wgx = std::max(1, std::atoi(e));
+        if (const char* e = option("WIDE_WGX")) wgx = std::max(1, std::atoi(e));
         nwg_x = std::max(wgx * device_info().num_cu, kActWG);
         axpart.alloc((size_t)(fuse_rt ? nwg_x : kAxWG) * ldn); axpart.zero(st);
         beta.alloc((size_t)nlam * p); niter.alloc(nlam); done.alloc(1); dlam.alloc(nlam);
@@ -1775,12 +1775,12 @@ struct WidePlan final : LassoPlan {
         // and the host shared-memory back-end cannot do); ADMM_HIP_WIDE_PERSIST_COLS=0 switches it off there alone
         persist_rows = (!cshard || (peer_fused && ci.nranks <= 64)) && n <= kRRS * kRG && (long long)p <= 262144;
         static_assert(kRRS * kRG <= kAuxRows && kRG <= kAuxGroups, "the AUX region carries one float per row, one flag per row group");
-        if (cshard) if (const char* e = std::getenv("ADMM_HIP_WIDE_PERSIST_COLS")) if (std::string(e) == "0") persist_rows = false;
-        if (const char* e = std::getenv("ADMM_HIP_WIDE_PERSIST")) if (std::string(e) == "0") persist_rows = false;
+        if (cshard) if (const char* e = option("WIDE_PERSIST_COLS")) if (std::string(e) == "0") persist_rows = false;
+        if (const char* e = option("WIDE_PERSIST")) if (std::string(e) == "0") persist_rows = false;
         if (!persist_rows) return;
         rows_R = (n + kRRS - 1) / kRRS;                                     // row groups of 256 rows
         rows_C = std::max(1, kRG / rows_R);                                 // column groups: R C <= 32 workgroups (one XCD)
-        if (const char* e = std::getenv("ADMM_HIP_WIDE_ROWS_C")) { const int c = std::atoi(e); if (c >= 1 && c * rows_R <= kRG) rows_C = c; }
+        if (const char* e = option("WIDE_ROWS_C")) { const int c = std::atoi(e); if (c >= 1 && c * rows_R <= kRG) rows_C = c; }
         rows_G = rows_R * rows_C;
         rflags.alloc((size_t)3 * kRG * 8); rflags.zero(st);
         rpd.alloc((size_t)2 * rows_G * kRCMAX); rpd.zero(st);
@@ -1795,7 +1795,7 @@ struct WidePlan final : LassoPlan {
         WideRows ps;
         ps.flag = rflags.get(); ps.flagX = rflags.get() + (size_t)kRG * 8; ps.flagS = rflags.get() + (size_t)2 * kRG * 8;
         ps.pd = rpd.get(); ps.np = rnp.get(); ps.err = rerr.get(); ps.seq = ++rseq; ps.stat = rstat.get(); ps.hint = rhint.get();
-        ps.G = rows_G; ps.R = rows_R; ps.C = rows_C; ps.pa = rpa.get(); ps.diag = std::getenv("ADMM_HIP_WIDE_PERSIST_STATS") ? 1 : 0;
+        ps.G = rows_G; ps.R = rows_R; ps.C = rows_C; ps.pa = rpa.get(); ps.diag = option("WIDE_PERSIST_STATS") ? 1 : 0;
         ps.lst_idx = rli.get(); ps.lst_x = rlx.get(); ps.lcount = rlc.get();
         if (cshard) hipLaunchKernelGGL(wide_rows_persist_kernel<true>, dim3(8 * rows_G), dim3(kRNW * 64), 0, st, q, cpar, ps, comm_peer_aux());
         else hipLaunchKernelGGL(wide_rows_persist_kernel<false>, dim3(8 * rows_G), dim3(kRNW * 64), 0, st, q, cpar, ps, PeerAux{});
@@ -1872,7 +1872,7 @@ struct WidePlan final : LassoPlan {
             ADMM_HIP_CHECK(hipMemcpy(hs, rstat.get(), sizeof(hs), hipMemcpyDeviceToHost));
             S.persist_iter = (long long)hs[0];
             rstat.zero(st);
-            if (std::getenv("ADMM_HIP_WIDE_PERSIST_STATS"))
+            if (option("WIDE_PERSIST_STATS"))
             {
                 const double it = hs[0] ? (double)hs[0] : 1.0;
                 std::fprintf(stderr, "[wide rows persist] %llu iterations in %llu stretches (%llu not on one XCD, %llu extra hand-overs after a rho change), %.2f us per iteration inside; %d row groups x %d column groups\n"
@@ -1882,7 +1882,7 @@ struct WidePlan final : LassoPlan {
             }
         }
 #ifdef ADMM_HIP_PROBE
-        if (const char* f = std::getenv("ADMM_HIP_PROBE_OUT")) {
+        if (const char* f = option("PROBE_OUT")) {
             std::vector<long long> hp((size_t)4096 * 4 * 8);
             ADMM_HIP_CHECK(hipMemcpy(hp.data(), probe.get(), hp.size() * sizeof(long long), hipMemcpyDeviceToHost));
             if (FILE* fp = std::fopen(f, "wb")) { std::fwrite(hp.data(), sizeof(long long), hp.size(), fp); std::fclose(fp); }

@@ -571,7 +571,7 @@ __global__ void copy_rows_kernel(const float* X, long long ldx, int row0, int nr
 // reference's own on ill-conditioned blocks with the float-built inverse.
 static void par_inverse(float* M, long long ldm, int order, double rho, hipStream_t st) {
     bool inv64 = order < 4096;
-    if (const char* e = std::getenv("ADMM_HIP_INVERSE")) inv64 = std::string(e) == "f64";
+    if (const char* e = option("INVERSE")) inv64 = std::string(e) == "f64";
     if (inv64) {
         spd_inverse_f32_via_f64(M, ldm, order, (double)(float)rho, st);
     } else {
@@ -698,7 +698,7 @@ struct ParPlan final : LassoPlan {
         Ab.alloc((size_t)Kl * ldv); Ab.zero(st);
         W.resize(Kl);
         onepass = true;
-        if (const char* e = std::getenv("ADMM_HIP_PAR_ONEPASS")) onepass = std::string(e) != "0";
+        if (const char* e = option("PAR_ONEPASS")) onepass = std::string(e) != "0";
         double t_gram = 0, t_fac = 0;
         for (int k = 0; k < Kl; ++k) {
             ParWorker& w = W[k];
@@ -760,7 +760,7 @@ struct ParPlan final : LassoPlan {
         }
 
         peer_fused = pb.dist && ci.active && ci.backend == COMM_PEER;
-        if (const char* e = std::getenv("ADMM_HIP_PEER_FUSED")) { if (std::string(e) == "0") peer_fused = false; }
+        if (const char* e = option("PEER_FUSED")) { if (std::string(e) == "0") peer_fused = false; }
         nwg = std::max(1, std::min(1024, (p + kParThreads - 1) / kParThreads));     // one element per thread up to p = 262144 (was <= 64 workgroups: 31 us for p = 10^5)
         // ADMM_HIP_PAR_FUSE_PZ=0: `pack` and `z` as two launches everywhere
         fuse_pz = !pb.dist;
@@ -769,7 +769,7 @@ struct ParPlan final : LassoPlan {
             ADMM_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(par_z_kernel<1, true>), kParThreads, 0));
             fuse_pz = (long long)nwg * 2 <= resident_workgroups(occ);       // its workgroups wait for one another: resident with room to spare
         }
-        if (const char* e = std::getenv("ADMM_HIP_PAR_FUSE_PZ")) { if (std::string(e) == "0") fuse_pz = false; }
+        if (const char* e = option("PAR_FUSE_PZ")) { if (std::string(e) == "0") fuse_pz = false; }
         rhs.alloc((size_t)Kl * ldv); x.alloc((size_t)Kl * ldv); y.alloc((size_t)Kl * ldv); nsum.alloc(8);
         z.alloc(ldv); wsum.alloc(ldv);
         rhs.zero(st); x.zero(st); y.zero(st);
@@ -827,7 +827,7 @@ struct ParPlan final : LassoPlan {
             q.azv = azv.get(); q.tv64 = tv64.get(); q.wbflag = wbflag.get(); q.dpart = dpart.get(); q.wbcount = wbcount.get(); q.dlt = dlt.get();
             {
                 double tau = 1.0 / 16.0;                                                       // tau0: see par_wb_flag_kernel
-                if (const char* e = std::getenv("ADMM_HIP_PAR_ONEPASS_TAU")) tau = std::atof(e);       // 0: never fall back (the measurement of the failure); 1e30: always
+                if (const char* e = option("PAR_ONEPASS_TAU")) tau = std::atof(e);       // 0: never fall back (the measurement of the failure); 1e30: always
                 q.wb_tau2 = tau * tau;
             }
             // c_k = A_k (A_k'b_k): the same gather with the dense A_k'b_k as right-hand side, once
@@ -840,7 +840,7 @@ struct ParPlan final : LassoPlan {
         }
         // ---- batched launches of the workers' products (ADMM_HIP_PAR_BATCH=0: one launch per worker and product, as before)
         {
-            const char* e = std::getenv("ADMM_HIP_PAR_BATCH");
+            const char* e = option("PAR_BATCH");
             bool same = Kl > 1 && !(e && std::string(e) == "0");
             for (int k = 1; k < Kl && same; ++k) same = W[k].wide == W[0].wide && W[k].gM.pl.nt == W[0].gM.pl.nt;
             if (same) {
@@ -961,11 +961,11 @@ struct ParPlan final : LassoPlan {
             ADMM_HIP_CHECK(hipMemcpy(&hc, wbcount.get(), sizeof(hc), hipMemcpyDeviceToHost));
             fallback_passes = (long long)hc;
             wbcount.zero(st);
-            if (std::getenv("ADMM_HIP_PAR_ONEPASS_STATS"))
+            if (option("PAR_ONEPASS_STATS"))
                 std::fprintf(stderr, "[consensus one-pass] %lld worker-iterations took the dense fall-back pass (cancellation guard) of %lld x %d\n", fallback_passes, (long long)lt.launched, Kl);
         }
 #ifdef ADMM_HIP_PROBE
-        if (const char* f = std::getenv("ADMM_HIP_PROBE_OUT")) {
+        if (const char* f = option("PROBE_OUT")) {
             std::vector<long long> hp((size_t)4096 * 4 * 8);
             ADMM_HIP_CHECK(hipMemcpy(hp.data(), probe.get(), hp.size() * sizeof(long long), hipMemcpyDeviceToHost));
             if (FILE* fp = std::fopen(f, "wb")) { std::fwrite(hp.data(), sizeof(long long), hp.size(), fp); std::fclose(fp); }

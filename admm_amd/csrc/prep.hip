@@ -26,7 +26,7 @@ void require_device() {
 }
 
 long long resident_workgroups(int occupancy_per_cu) {
-    if (const char* e = std::getenv("ADMM_HIP_TEST_RESIDENT_WGS")) { const long long v = std::atoll(e); if (v >= 0) return v; }
+    if (const char* e = option("TEST_RESIDENT_WGS")) { const long long v = std::atoll(e); if (v >= 0) return v; }
     return (long long)occupancy_per_cu * device_info().num_cu;
 }
 
@@ -203,21 +203,36 @@ struct H2DRing {
         ADMM_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     }
 };
-// one ring per host thread and device, never freed (like the stream pool and the read-back bounce buffer): the C ABI is
-// re-entrant per thread, and a ring is 96 MB of pinned memory only in threads that pass large host inputs
+// One ring per host thread and device, owned by the thread: the holder's destructor releases the pinned slots, the events and the
+// stream when the thread exits (a bare thread_local vector of pointers leaked 96 MB of pinned memory per short-lived
+// thread that passed a host input).  A ring exists only in threads that pass LARGE host inputs (write_device: small transfers are
+// plain copies).
+struct H2DRingHolder {
+    std::vector<H2DRing*> rings;
+    ~H2DRingHolder() {
+        for (H2DRing* r : rings) {
+            if (r->st) { (void)hipStreamSynchronize(r->st); (void)hipStreamDestroy(r->st); }
+            for (int i = 0; i < H2DRing::kSlots; ++i) {
+                if (r->ev[i]) (void)hipEventDestroy(r->ev[i]);
+                if (r->slot[i]) (void)hipHostFree(r->slot[i]);
+            }
+            delete r;
+        }
+    }
+};
 H2DRing& h2d_ring() {
-    static thread_local std::vector<H2DRing*> rings;
+    static thread_local H2DRingHolder holder;
     int dev = 0;
     ADMM_HIP_CHECK(hipGetDevice(&dev));
-    for (H2DRing* r : rings) if (r->dev == dev) return *r;
+    for (H2DRing* r : holder.rings) if (r->dev == dev) return *r;
     H2DRing* r = new H2DRing();
+    holder.rings.push_back(r);                           // owned from here on: a failed init() is cleaned up by the holder
     r->init();
-    rings.push_back(r);
     return *r;
 }
 int h2d_threads() {
+    if (const char* e = option("H2D_THREADS")) { const int v = std::atoi(e); if (v >= 1) return std::min(v, 32); }
     static const int n = []() {
-        if (const char* e = std::getenv("ADMM_HIP_H2D_THREADS")) { const int v = std::atoi(e); if (v >= 1) return std::min(v, 32); }
         const unsigned hw = std::thread::hardware_concurrency();
         return (int)std::max(1u, std::min(16u, hw ? hw / 2 : 4u));      // C2 host input on the 128-thread box: 8 threads 50 GB/s, 16 threads 56 GB/s = the pageable hipMemcpy's rate
     }();
@@ -239,21 +254,28 @@ void parallel_memcpy(char* dst, const char* src, size_t bytes, int nthreads) {
 
 void write_device(void* dst, const void* src, size_t bytes) {
     if (!bytes) return;
-    static const bool pageable = []() { const char* e = std::getenv("ADMM_HIP_H2D"); return e && std::string(e) == "pageable"; }();
+    const char* h2d = option("H2D");
+    const bool pageable = h2d && std::string(h2d) == "pageable";
     if (pageable) { ADMM_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return; }
+    if (bytes < (size_t(4) << 20)) { ADMM_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return; }      // (a y vector, a lambda grid: no ring for those)
     H2DRing& r = h2d_ring();
     const int nt = h2d_threads();
     int i = 0;
     bool used[H2DRing::kSlots] = {false, false, false};
-    for (size_t off = 0; off < bytes; off += H2DRing::kSlot, i = (i + 1) % H2DRing::kSlots) {
-        const size_t n = std::min(H2DRing::kSlot, bytes - off);
-        if (used[i]) ADMM_HIP_CHECK(hipEventSynchronize(r.ev[i]));          // the DMA that read this slot has finished
-        parallel_memcpy(static_cast<char*>(r.slot[i]), static_cast<const char*>(src) + off, n, nt);
-        ADMM_HIP_CHECK(hipMemcpyAsync(static_cast<char*>(dst) + off, r.slot[i], n, hipMemcpyHostToDevice, r.st));
-        ADMM_HIP_CHECK(hipEventRecord(r.ev[i], r.st));
-        used[i] = true;
+    try {
+        for (size_t off = 0; off < bytes; off += H2DRing::kSlot, i = (i + 1) % H2DRing::kSlots) {
+            const size_t n = std::min(H2DRing::kSlot, bytes - off);
+            if (used[i]) ADMM_HIP_CHECK(hipEventSynchronize(r.ev[i]));          // the DMA that read this slot has finished
+            parallel_memcpy(static_cast<char*>(r.slot[i]), static_cast<const char*>(src) + off, n, nt);
+            ADMM_HIP_CHECK(hipMemcpyAsync(static_cast<char*>(dst) + off, r.slot[i], n, hipMemcpyHostToDevice, r.st));
+            ADMM_HIP_CHECK(hipEventRecord(r.ev[i], r.st));
+            used[i] = true;
+        }
+        ADMM_HIP_CHECK(hipStreamSynchronize(r.st));
+    } catch (...) {
+        (void)hipStreamSynchronize(r.st);                   // no DMA may still be reading a slot when the next call starts with used[] = false
+        throw;
     }
-    ADMM_HIP_CHECK(hipStreamSynchronize(r.st));
 }
 
 template <typename T>
@@ -616,7 +638,7 @@ void gram_full(const T* A, long long lda, int rows, int cols, bool atA, T* C, lo
     // BLAS handle is ever created in a default run (rocBLAS handle creation alone costs 0.1-0.2 s per process);
     // ADMM_HIP_GRAM=rocblas forces the library path (A/B tests)
     {
-        const char* e = std::getenv("ADMM_HIP_GRAM");
+        const char* e = option("GRAM");
         const bool force_lib = e && std::string(e) == "rocblas";
         if (!force_lib) {
             if constexpr (std::is_same<T, float>::value) gram_mfma_f32(A, lda, rows, cols, atA, C, ldc, st);
@@ -739,13 +761,13 @@ void spd_inverse_f32_via_f64(float* A, long long lda, int n, double diag, hipStr
 }
 
 void spd_inverse_f32(float* A, long long lda, int n, hipStream_t st) {
-    const char* e = std::getenv("ADMM_HIP_FACTOR");
+    const char* e = option("FACTOR");
     if ((e && std::string(e) == "rocsolver") || lda < round_up(n, 128)) spd_inverse_full<float>(A, lda, n, st);
     else spd_inverse_mfma_f32(A, lda, n, st);
 }
 
 void spd_inverse_f64(double* A, long long lda, int n, hipStream_t st) {
-    const char* e = std::getenv("ADMM_HIP_FACTOR");
+    const char* e = option("FACTOR");
     if ((e && std::string(e) == "rocsolver") || lda < round_up(n, 128)) spd_inverse_full<double>(A, lda, n, st);
     else spd_inverse_mfma_f64(A, lda, n, st);
 }

@@ -29,6 +29,7 @@
 // that never touches A (section "Gram space" below: sbp_gs_*), and the regular iteration itself then needs only `xreg`, `list`
 // and three Gram-space launches; the `xact` / `tail` launches above remain for the sharded solver, for supports too large for
 // the Gram matrix and as the A/B (ADMM_HIP_SBP_GRAM=0).  Same shape: 9.3 us per active-set iteration, loop 0.257 s.
+#include <system_error>
 #include "prep.h"
 #include "gemv_kernels.h"
 #include "solvers.h"
@@ -1034,9 +1035,8 @@ sbp_gs_tail_kernel(SbpParams q, int par, int nth) {
 }
 
 // ------------------------------------------------------------------------------------------------ setup
-static int env_int(const char* name, int dflt) {
-    const char* e = std::getenv(name);
-    const int v = e ? std::atoi(e) : 0;
+static int env_int(const char* name, int dflt) {          // a positive option value, or the default
+    const int v = option_int(name, 0);
     return v > 0 ? v : dflt;
 }
 
@@ -1291,11 +1291,12 @@ static void sbp_sprad_batch(const double* A, long long lda, int n, const std::ve
         std::vector<char> now(B, 0);
         auto run = [&](int b) { try { now[b] = judge(b, s0, s1) ? 1 : 0; } catch (...) { err[b] = std::current_exception(); } };
         std::vector<std::thread> th;
+        struct Joiner { std::vector<std::thread>& t; ~Joiner() { for (auto& x : t) if (x.joinable()) x.join(); } } joiner{th};      // joined on every path out
         int first = -1;
         for (int b = 0; b < B; ++b) {
             if (fin[b]) continue;
             if (first < 0) { first = b; continue; }                 // (one block on this thread)
-            th.emplace_back(run, b);
+            try { th.emplace_back(run, b); } catch (const std::system_error&) { run(b); }      // no thread to be had: judged here
         }
         if (first >= 0) run(first);
         for (auto& t : th) t.join();
@@ -1309,7 +1310,7 @@ static void sbp_sprad_batch(const double* A, long long lda, int n, const std::ve
 }
 
 static int sbp_batch() {
-    const char* e = std::getenv("ADMM_HIP_BATCH_ITERS");
+    const char* e = option("BATCH_ITERS");
     const int v = e ? std::atoi(e) : 0;
     return v > 0 ? (v + 1) / 2 * 2 : 20;                            // even: the parity pattern of the control block
 }
@@ -1352,7 +1353,7 @@ void solve_parbp(const DeviceData<double>& d, const admm_opts& opts, int nblocks
         // as many blocks in lockstep as ~3 GB of Gram matrices and Lanczos bases allow (A/B: ADMM_HIP_SBP_LZ_BATCH)
         const double per = (double)round_up(n, 32) * ((double)round_up(n, 32) + (double)std::min(n, 600) + 8.0) * 8.0;
         int Bmax = std::max(1, std::min(NL, (int)(3.0e9 / per)));
-        Bmax = std::min(Bmax, env_int("ADMM_HIP_SBP_LZ_BATCH", Bmax));
+        Bmax = std::min(Bmax, env_int("SBP_LZ_BATCH", Bmax));
         for (int b = 0; b < NL; b += Bmax) {
             const int B = std::min(Bmax, NL - b);
             std::vector<int> ns(B, 0);
@@ -1391,7 +1392,7 @@ void solve_parbp(const DeviceData<double>& d, const admm_opts& opts, int nblocks
     int ncu = 256;
     { hipDeviceProp_t prop; int dev = 0; ADMM_HIP_CHECK(hipGetDevice(&dev)); ADMM_HIP_CHECK(hipGetDeviceProperties(&prop, dev)); ncu = prop.multiProcessorCount; }
     // workgroups per block: the same for every local block (block = g / Gb), about two per CU in all, never more than a block has columns
-    int Gb = std::max(1, env_int("ADMM_HIP_SBP_WGS", 2 * ncu) / NL);
+    int Gb = std::max(1, env_int("SBP_WGS", 2 * ncu) / NL);
     for (int b = 0; b < NL; ++b) Gb = std::min(Gb, c0[b + 1] - c0[b]);
     const int G = Gb * NL;
     const int nT = npad / 64;
@@ -1428,7 +1429,7 @@ void solve_parbp(const DeviceData<double>& d, const admm_opts& opts, int nblocks
     PinnedFlag hflag;
 
     SbpParams q{};
-    q.min_share = std::max(1, env_int("ADMM_HIP_SBP_SHARE", 4));
+    q.min_share = std::max(1, env_int("SBP_SHARE", 4));
     q.n = n; q.npad = npad; q.N = N; q.NL = NL; q.maxit = opts.maxit; q.G = G; q.nT = nT;
     q.eps_abs = opts.eps_abs; q.eps_rel = opts.eps_rel; q.rho = rho;
     q.sqrt_nN = std::sqrt((double)n * (double)N); q.sqrtN = std::sqrt((double)N); q.dN = (double)N;
@@ -1443,8 +1444,8 @@ void solve_parbp(const DeviceData<double>& d, const admm_opts& opts, int nblocks
 
     // ---- Gram space (single process): state, the gather launches that materialise the n-vectors
     bool gram = !dist && NL <= kGsMaxBlocks;
-    if (const char* e = std::getenv("ADMM_HIP_SBP_GRAM")) gram = gram && std::atoi(e) != 0;      // 0: the direct launches on every iteration (A/B)
-    const int gcap = std::min(kGsCapMax, std::max(kGsRows, env_int("ADMM_HIP_SBP_GRAM_CAP", kGsCapMax)) / kGsRows * kGsRows);
+    if (const char* e = option("SBP_GRAM")) gram = gram && std::atoi(e) != 0;      // 0: the direct launches on every iteration (A/B)
+    const int gcap = std::min(kGsCapMax, std::max(kGsRows, env_int("SBP_GRAM_CAP", kGsCapMax)) / kGsRows * kGsRows);
     DevBuf<int> g_umap, g_ucol, g_ubid, g_ust;
     DevBuf<double> g_G, g_gz, g_ugp, g_xs, g_hr, g_gy, g_sx, g_sxd, g_Ps, g_sc, g_partP, g_partT;
     DevBuf<GatherArgs<double>> g_args;
@@ -1469,7 +1470,7 @@ void solve_parbp(const DeviceData<double>& d, const admm_opts& opts, int nblocks
         gs.sx = g_sx.get(); gs.sxd = g_sxd.get(); gs.Ps = g_Ps.get(); gs.sc = g_sc.get();
         gs.partP = g_partP.get(); gs.partT = g_partT.get(); gs.ngroups = gp.ngroups; gs.pstride = npad;
         gs.zz = zz;
-        gs.test_delay = 100 * env_int("ADMM_HIP_SBP_TEST_DELAY_US", 0); gs.pad2 = 0;
+        gs.test_delay = 100 * env_int("SBP_TEST_DELAY_US", 0); gs.pad2 = 0;
         std::vector<GatherArgs<double>> ha(2 * (size_t)NL);
         for (int k = 0; k < 2 * NL; ++k) {
             const int b = k % NL;
@@ -1509,7 +1510,7 @@ void solve_parbp(const DeviceData<double>& d, const admm_opts& opts, int nblocks
     const size_t ldsv = (size_t)npad * sizeof(double);
     const bool gram_on = gram;
     bool carry_on = true;                                          // 0: every Gram-space stretch starts from the direct launches' n-vectors (A/B)
-    if (const char* e = std::getenv("ADMM_HIP_SBP_GRAM_CARRY")) carry_on = std::atoi(e) != 0;
+    if (const char* e = option("SBP_GRAM_CARRY")) carry_on = std::atoi(e) != 0;
     long long gram_from = 0;                                       // the first regular iteration whose stretch may run in Gram space
     long long last_gram = -100;                                    // the regular iteration of the last stretch enqueued in Gram space
     std::vector<char> carried;                                     // per stretch: it started from the previous stretch's Gram-space state

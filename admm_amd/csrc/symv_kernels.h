@@ -381,7 +381,7 @@ struct SymvPlan {
         else if (count(uniform(64)) <= slots) sched = uniform(64);
         else if (10 * count(two(128, 64)) <= 14 * slots) sched = two(128, 64);
         else sched = two(192, 64);
-        if (const char* e = std::getenv("ADMM_HIP_SYMV_SCHED")) {
+        if (const char* e = option("SYMV_SCHED")) {
             int wb = 0, ws = 0, pm = 0;
             if (std::sscanf(e, "%d,%d,%d", &wb, &ws, &pm) == 3 && wb >= 32 && wb <= kSyCBMax && wb % 32 == 0 && ws >= 32 && ws <= kSyCBMax && ws % 32 == 0 &&
                 pm >= 0 && pm <= 1000) {
@@ -424,7 +424,7 @@ struct SymvPlan {
         // p = 10000 5.7 vs 5.3 | 11000 5.90 vs 5.24 | 12000 6.08 vs 5.41 | 13000 4.31 vs 5.50 | 16000 4.1-4.4 vs 5.3-5.4.
         // (a rank of the row-sharded solver re-reads only its 1 / nparts share)
         nt = (size_t)2 * (size_t)p * (size_t)p / (size_t)std::max(1, nparts) > (size_t)310000000;
-        if (const char* e = std::getenv("ADMM_HIP_SYMV_NT")) nt = std::string(e) == "1";
+        if (const char* e = option("SYMV_NT")) nt = std::string(e) == "1";
         tiles.alloc(std::max<size_t>(h.size(), 1));
         if (!h.empty()) ADMM_HIP_CHECK(hipMemcpyAsync(tiles.get(), h.data(), h.size() * sizeof(int4), hipMemcpyHostToDevice, st));
         dot0.alloc((size_t)nrb * ldo); dot1.alloc((size_t)nrb * ldo);

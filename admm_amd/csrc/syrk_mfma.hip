@@ -136,7 +136,7 @@ __device__ __forceinline__ void gemm_nt_quarter(const GemmNT& g, float (*lds)[2]
 // from the registers, a wave's load or store touches 32 columns with 16 bytes each -- measured (scripts/gemm_shortk.hip) 10 us
 // per 128 x 128 tile for the stores and 10 more for the loads of beta C, against 4 us for the K = 128 product itself: the
 // rank-128 updates of the blocked factorisation were 5/6 epilogue.  Same arithmetic per element, bit-identical
-// (tests/test_gpu_kernels.py; ADMM_HIP_GEMM_EPI=0 keeps the direct stores for the A/B).
+// (held bit-identical to the direct stores in round 5).
 template <int LOWER, int EPI = 0>
 __global__ void __launch_bounds__(SK_THREADS, 2)
 gemm_nt_mfma_kernel(GemmNT g) {
@@ -412,9 +412,7 @@ static void launch_gemm_nt(bool lower, const float* A, long long lda, const floa
     if (g.ntiles <= 0 && g.nq <= 0) return;
     g.grid_full = (g.ntiles * ksplit + 7) / 8 * 8;
     const int grid = g.grid_full + (g.nq + 7) / 8 * 8;
-    const char* epi_env = std::getenv("ADMM_HIP_GEMM_EPI");             // read per call: the A/B test flips it inside one process
-    const bool epi_lds = !(epi_env && epi_env[0] == '0');
-    if (epi_lds && !mirror && g.nq == 0) {                              // (the quarter items of the Gram's tail come with the mirrored store)
+    if (!mirror && g.nq == 0) {                              // (the quarter items of the Gram's tail come with the mirrored store)
         if (lower) hipLaunchKernelGGL((gemm_nt_mfma_kernel<1, 1>), dim3(grid), dim3(SK_THREADS), 0, st, g);
         else hipLaunchKernelGGL((gemm_nt_mfma_kernel<0, 1>), dim3(grid), dim3(SK_THREADS), 0, st, g);
     } else if (lower) hipLaunchKernelGGL((gemm_nt_mfma_kernel<1, 0>), dim3(grid), dim3(SK_THREADS), 0, st, g);
@@ -478,21 +476,12 @@ void gram_mfma_f32(const float* A, long long lda, int rows, int cols, bool atA, 
     if (atA) transpose<float>(A, lda, rows, cols, Z.get(), ldz, st);
     else hipLaunchKernelGGL(pad_copy_f32_kernel, dim3((rows + 255) / 256, cols), dim3(256), 0, st, A, lda, rows, cols, Z.get(), ldz);
     if (ksplit == 1) {
-        // ADMM_HIP_GRAM_ORDER=row: the plain row-major triangle order; ADMM_HIP_GRAM_TAIL=0: no quarter items (A/B measurements)
-        const char* eo = std::getenv("ADMM_HIP_GRAM_ORDER");
-        const char* et = std::getenv("ADMM_HIP_GRAM_TAIL");
-        if (eo && std::string(eo) == "row") {
-            launch_gemm_nt(true, Z.get(), ldz, Z.get(), ldz, C, ldc, M, M, nk, 1.f, 0.f, true, false, st);
-        } else if (et && std::string(et) == "0") {
-            DevBuf<int> tmap = make_square_tilemap(nb, st);
-            launch_gemm_nt(true, Z.get(), ldz, Z.get(), ldz, C, ldc, M, M, nk, 1.f, 0.f, true, false, st, 1, 0, tmap.get());
-            comm_stream_sync(st);
-        } else {
+        // square-ish tile order with quarter items for the tail (the row-major order and the no-quarter form lost their A/B in round 4)
+        {
             std::vector<int> full, quarters;
             int wg_per_cu = 2;                               // resident workgroups per CU (registers / LDS: 4 as compiled today)
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu, gemm_nt_mfma_kernel<1, 0>, SK_THREADS, 0) != hipSuccess || wg_per_cu < 1) wg_per_cu = 2;
-            gram_work_lists(M, wg_per_cu * device_info().num_cu, et ? std::atof(et) : 0.55, full, quarters);
-            if (std::getenv("ADMM_HIP_GRAM_DEBUG")) std::fprintf(stderr, "[gram] M %d wg/cu %d full %zu quarters %zu\n", M, wg_per_cu, full.size(), quarters.size());
+            gram_work_lists(M, wg_per_cu * device_info().num_cu, 0.55, full, quarters);
             DevBuf<int> tmap = upload_ints(full, st), qmap = upload_ints(quarters, st);
             launch_gemm_nt(true, Z.get(), ldz, Z.get(), ldz, C, ldc, M, M, nk, 1.f, 0.f, true, false, st, 1, 0, tmap.get(), (int)full.size(),
                            qmap.get(), (int)quarters.size());

@@ -349,7 +349,8 @@ def tallshard_child(a, backend, out_path):
         xt[c0:c1] = torch.randn((c1 - c0, nl), generator=g, device=dev, dtype=torch.float64) * 2.0
     y = beta_true @ xt + torch.randn(nl, generator=g, device=dev, dtype=torch.float64)
     torch.cuda.synchronize()
-    os.environ["ADMM_HIP_PROFILE_STRIDE"] = str(a.profile_stride)
+    from admm_amd import options as _options
+    _options.set(PROFILE_STRIDE=a.profile_stride)           # (the child's _child_setup has loaded the library: the environment is not read any more)
     t0 = time.time()
     plan = adist.DistLassoPlan(DevicePtr(xt.data_ptr()), DevicePtr(y.data_ptr()), n, p, 0, nlambda=a.nlambda, lambda_min_ratio=1e-4,
                                n_local=nl)
@@ -819,10 +820,10 @@ def main():
         if dist.get_world_size() != a.gpus:
             raise SystemExit(f"bench.py: the process group holds {dist.get_world_size()} ranks, --gpus {a.gpus}")
     rdev = torch.device("cpu") if OVERSUBSCRIBE else dev      # where the control-plane reductions of this function live
-    os.environ["ADMM_HIP_PROFILE_STRIDE"] = str(a.profile_stride)
     import numpy as np
-    from admm_amd import admm_lasso, DevicePtr, LassoPlan, load
+    from admm_amd import admm_lasso, DevicePtr, LassoPlan, load, options
     lib = load()
+    options.set(PROFILE_STRIDE=a.profile_stride)            # time every k-th x-update launch with HIP events (admm_hip_options.profile_stride)
     rc = lib.admm_hip_set_device(local_rank)
     assert rc == 0
 

@@ -293,6 +293,42 @@ ADMM_HIP_API int admm_hip_lasso_plan_state_enable(admm_hip_plan* plan, long long
 ADMM_HIP_API int admm_hip_lasso_plan_state_read(admm_hip_plan* plan, float* out, long long cap_records, long long* nrecords_out,
                                                 long long* record_floats_out);
 
+/* ---- variant selectors and tuning values (round 6: replaces the ADMM_HIP_* environment variables of earlier rounds).
+ * Options belong to the CALLING THREAD and are read by the entry points when they run (a prepared problem reads them when it is
+ * created): two threads can run two different variants at the same time, and nothing reads the environment per call.  The typed
+ * struct carries the selectors that choose between numerically different (all parity-tested) paths; admm_hip_option_set reaches the
+ * long tail of tuning / diagnostic values by name (INTEGRATION.md lists them).  Every field 0 = the library's default.
+ * Debugging aid: ADMM_HIP_<NAME> environment variables present when the library is FIRST used form a process-wide overlay under
+ * the thread's own settings (read once; changing the environment afterwards has no effect). */
+typedef struct admm_hip_options {
+    int struct_size;          /* sizeof(admm_hip_options): lets the library accept older, shorter structs */
+    int gram_backend;         /* 0 hand-written matrix-core kernels, 1 rocBLAS (dlopen) */
+    int gram_split;           /* tall Gram of order >= ~4000: 0 default (fp16 x 2 planes), 1 exact fp32 kernel, 2 fp16 x 2, 3 bf16 x 3 */
+    int factor_backend;       /* 0 hand-written blocked Cholesky + inverse, 1 rocSOLVER (dlopen) */
+    int inverse_precision;    /* cached inverse: 0 default (built in double below order 4096), 1 always float, 2 always double */
+    int tall_xupdate;         /* tall x-update: 0 default (symmetric lower-triangle kernel for p >= 2048), 1 full-matrix mat-vec, 2 symmetric */
+    int tall_refine;          /* 1: mixed-precision refinement of the tall x-update */
+    int consensus_two_pass;   /* 1: the reference's two products per Woodbury worker (default: one-pass form) */
+    int consensus_unfused;    /* 1: `pack` and `z` as two launches; 2: also one launch per worker and product */
+    int bp_two_pass;          /* 1: basis pursuit with the reference's two products (default: one-pass form) */
+    int lad_no_hat;           /* 1: LAD never forms the n x n hat matrix (the reference does for n <= 2000) */
+    int wide_no_persist;      /* 1: wide solver without the persistent active-set stretch; 2: only the column-sharded solver without it */
+    int wide_unfused;         /* 1: wide solver with three launches per iteration */
+    int wide_gram_sprad;      /* 1: spectral radius from the explicit n x n Gram (default single process: Gram-free) */
+    int sharing_bp_direct;    /* 1: column-block basis pursuit without Gram-space stretches */
+    int cv_downdate;          /* cross-validation folds as down-dates of the full-data Gram: 0 default (when the Gram is what setup costs), 1 always, 2 never */
+    int peer_exchange;        /* PEER back-end: 0 default (producer + consumer in one launch when resident), 1 two launches, 2 through the exchange layer */
+    int batch_iters;          /* iterations enqueued between two host polls (0: default 16) */
+    int profile_stride;       /* time every k-th x-update launch with HIP events (0: off) */
+    int pool_mb;              /* cache of released device blocks: -1 off, 0 default (min(16 GB, memory / 8)), > 0 megabytes */
+    int reserved[12];
+} admm_hip_options;
+ADMM_HIP_API int admm_hip_options_default(admm_hip_options* o);               /* zero-fills and sets struct_size */
+ADMM_HIP_API int admm_hip_options_set(const admm_hip_options* o);             /* NULL: back to the defaults (keeps nothing of the thread's earlier settings) */
+ADMM_HIP_API int admm_hip_option_set(const char* name, const char* value);    /* one value by name ("GRAM_SPLIT", "f16x2"); value NULL: back to the default */
+ADMM_HIP_API int admm_hip_options_reset(void);
+ADMM_HIP_API const char* admm_hip_option_get(const char* name);               /* value in force for this thread, or NULL (library default) */
+
 /* ---- one process per GPU: consensus Lasso with its row blocks spread over ranks (RCCL over xGMI).
  * Bootstrap: rank 0 calls admm_hip_comm_unique_id and ships the ADMM_HIP_UNIQUE_ID_BYTES bytes to the
  * other ranks over any channel (bench.py uses torch.distributed); every rank then calls

@@ -39,3 +39,15 @@ def pytest_collection_modifyitems(config, items):
 def readme_lasso_xy():
     from oracle import readme
     return readme.lasso_data()
+
+
+@pytest.fixture(autouse=True)
+def _reset_library_options():
+    """Variant selectors set through admm_amd.options.set(...) belong to the thread: back to the defaults after every test."""
+    yield
+    try:
+        from admm_amd import _lib
+        if _lib._lib is not None:
+            _lib.options.reset()
+    except Exception:      # noqa: BLE001  (library not built / no device: nothing to reset)
+        pass

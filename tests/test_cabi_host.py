@@ -161,15 +161,49 @@ def test_fit_objects_mirror_show_and_plot_data():
         dz.fit_responses(np.zeros((30, 2)))
 
 
-def test_every_environment_knob_the_library_reads_is_in_the_integration_guide():
-    """INTEGRATION.md's knob table is the only place a maintainer learns what ADMM_HIP_* variables do: every name the sources
-    pass to getenv must appear there."""
+def test_every_option_the_library_reads_is_in_the_integration_guide_and_nothing_reads_the_environment():
+    """INTEGRATION.md's option table is the only place a maintainer learns what the named options do: every name the sources pass
+    to option() / option_int() must appear there.  And the sources must not call getenv at all (round 6: variant selectors belong to
+    the calling thread, admm_hip_options / admm_hip_option_set; ADMM_HIP_* variables are an overlay captured once from `environ`)."""
     import glob, os, re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    names = set()
+    names, getenvs = set(), 0
     for f in glob.glob(os.path.join(root, "admm_amd", "csrc", "*")):
         if f.endswith((".hip", ".h")):
-            names |= set(re.findall(r'getenv\("(ADMM_HIP_[A-Z0-9_]+)"', open(f).read()))
+            src = open(f).read()
+            names |= set(re.findall(r'\b(?:option|option_int|env_int|env_seconds)\("([A-Z0-9_]+)"', src))
+            getenvs += len(re.findall(r'\bgetenv\s*\(', src))
+    assert getenvs == 0, f"{getenvs} getenv calls in admm_amd/csrc"
     guide = open(os.path.join(root, "INTEGRATION.md")).read()
     missing = sorted(n for n in names if n not in guide)
     assert len(names) > 20 and not missing, missing
+
+
+
+def test_options_are_per_thread_and_the_typed_struct_maps_onto_the_named_ones():
+    """The options ABI without a GPU: admm_hip_options_default / _set / admm_hip_option_set / _get / _reset (include/admm_hip.h)."""
+    import ctypes
+    import threading
+    from admm_amd import _lib
+    lib = _lib.load()
+    _lib.options.reset()
+    assert lib.admm_hip_option_get(b"GRAM_SPLIT") is None
+    o = _lib.AdmmHipOptions()
+    _lib.check(lib.admm_hip_options_default(ctypes.byref(o)))
+    assert o.struct_size == ctypes.sizeof(_lib.AdmmHipOptions) and o.gram_split == 0
+    o.gram_split, o.inverse_precision, o.consensus_two_pass, o.batch_iters = 3, 2, 1, 32
+    _lib.check(lib.admm_hip_options_set(ctypes.byref(o)))
+    assert lib.admm_hip_option_get(b"GRAM_SPLIT") == b"bf16x3" and lib.admm_hip_option_get(b"INVERSE") == b"f64"
+    assert lib.admm_hip_option_get(b"ADMM_HIP_PAR_ONEPASS") == b"0" and lib.admm_hip_option_get(b"batch_iters") == b"32"
+    seen = {}
+    t = threading.Thread(target=lambda: seen.update(other=lib.admm_hip_option_get(b"GRAM_SPLIT")))
+    t.start(); t.join()
+    assert seen["other"] is None                                   # another thread sees the defaults
+    with _lib.options(GRAM_SPLIT="f16x2", WIDE_PERSIST=0):
+        assert lib.admm_hip_option_get(b"GRAM_SPLIT") == b"f16x2" and lib.admm_hip_option_get(b"WIDE_PERSIST") == b"0"
+    assert lib.admm_hip_option_get(b"GRAM_SPLIT") == b"bf16x3" and lib.admm_hip_option_get(b"WIDE_PERSIST") is None
+    o.gram_split = 7
+    assert lib.admm_hip_options_set(ctypes.byref(o)) != 0          # rejected, with a message
+    assert b"gram_split" in lib.admm_hip_last_error()
+    _lib.check(lib.admm_hip_options_set(None))
+    assert lib.admm_hip_option_get(b"INVERSE") is None

@@ -200,9 +200,9 @@ def test_cv_with_downdated_folds_against_direct_calls(monkeypatch):
     x += np.linspace(-3, 3, 60)[None, :]                                     # column means that the folds' centring has to follow
     nfolds = 5
     fid = (np.arange(1500) * 7 % nfolds).astype(np.int32)
-    monkeypatch.setenv("ADMM_HIP_CV_DOWNDATE", "1")
+    admm_amd.options.set(CV_DOWNDATE="1")
     cv = admm_amd.admm_lasso(x, y).penalty(nlambda=15).cv(nfolds=nfolds, fold_id=fid, keep_fold_beta=True)
-    monkeypatch.setenv("ADMM_HIP_CV_DOWNDATE", "0")
+    admm_amd.options.set(CV_DOWNDATE="0")
     ref = admm_amd.admm_lasso(x, y).penalty(nlambda=15).cv(nfolds=nfolds, fold_id=fid, keep_fold_beta=True)
     full = admm_amd.admm_lasso(x, y).penalty(nlambda=15).fit()
     assert np.array_equal(full.beta_dense, cv.fit.beta_dense) and np.array_equal(full.niter, cv.fit.niter) and np.array_equal(full.lambda_, cv.lambda_)
@@ -236,11 +236,11 @@ def test_cv_downdate_is_automatic_where_the_gram_is_the_setup_cost(monkeypatch):
     full fit say so through t_gram covering the one-time base), and the table agrees with the direct mode to 1e-4."""
     import admm_amd
     x, y = _data(3300, 1030, 12, 33)
-    monkeypatch.delenv("ADMM_HIP_CV_DOWNDATE", raising=False)
+    admm_amd.options.set(CV_DOWNDATE=None)
     auto = admm_amd.admm_lasso(x, y).penalty(nlambda=6, lambda_min_ratio=0.05).cv(nfolds=3)
-    monkeypatch.setenv("ADMM_HIP_CV_DOWNDATE", "1")
+    admm_amd.options.set(CV_DOWNDATE="1")
     forced = admm_amd.admm_lasso(x, y).penalty(nlambda=6, lambda_min_ratio=0.05).cv(nfolds=3)
-    monkeypatch.setenv("ADMM_HIP_CV_DOWNDATE", "0")
+    admm_amd.options.set(CV_DOWNDATE="0")
     direct = admm_amd.admm_lasso(x, y).penalty(nlambda=6, lambda_min_ratio=0.05).cv(nfolds=3)
     assert np.array_equal(auto.fold_mse, forced.fold_mse) and np.array_equal(auto.fold_niter, forced.fold_niter)      # automatic == forced on
     assert not np.array_equal(auto.fold_mse, direct.fold_mse)                                                           # and it is not the direct mode

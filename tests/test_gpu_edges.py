@@ -79,16 +79,14 @@ def test_lad_and_bp_minimal_shapes():
 
 def test_wide_gram_free_spectral_radius_matches_the_gram_based_value():
     """the wide solver's Lanczos products are X (X' v) on the stored X, no n x n Gram; same loose Ritz value as
-    the Gram-based call (ADMM_HIP_WIDE_SPRAD=gram) to float rounding, hence the same rho and the same path."""
+    the Gram-based call (option WIDE_SPRAD=gram) to float rounding, hence the same rho and the same path."""
     import os
     from admm_amd import admm_lasso
     x, y = synth_lasso(300, 3000, 20, seed=51)
     free = admm_lasso(x, y).penalty(nlambda=6, lambda_min_ratio=0.05).fit()
-    os.environ["ADMM_HIP_WIDE_SPRAD"] = "gram"
-    try:
+    from admm_amd import options
+    with options(WIDE_SPRAD="gram"):
         gram = admm_lasso(x, y).penalty(nlambda=6, lambda_min_ratio=0.05).fit()
-    finally:
-        del os.environ["ADMM_HIP_WIDE_SPRAD"]
     assert free.stats["branch"] == 1 and free.stats["t_gram"] == 0.0 and gram.stats["t_gram"] > 0.0
     assert abs(free.stats["eig_est"] - gram.stats["eig_est"]) < 2e-5 * gram.stats["eig_est"], (free.stats["eig_est"], gram.stats["eig_est"])
     for j in range(6):
@@ -97,16 +95,14 @@ def test_wide_gram_free_spectral_radius_matches_the_gram_based_value():
 
 def test_tall_memory_wall_is_reported_not_crashed_into():
     """The tall solver caches a p x p inverse: when that does not fit, ADMM_ERR_MEMORY with a pointer to $parallel(), instead
-    of a failed allocation somewhere inside the setup (ADMM_HIP_TEST_FREE_BYTES pretends the device is nearly full)."""
+    of a failed allocation somewhere inside the setup (the test option TEST_FREE_BYTES pretends the device is nearly full)."""
     import os
     from admm_amd import AdmmHipError, admm_lasso
     x, y = synth_lasso(900, 300, 10, seed=52)
-    os.environ["ADMM_HIP_TEST_FREE_BYTES"] = "200000"
-    try:
+    from admm_amd import options
+    with options(TEST_FREE_BYTES="200000"):
         with pytest.raises(AdmmHipError) as ei:
             admm_lasso(x, y).penalty(0.1).fit()
-    finally:
-        del os.environ["ADMM_HIP_TEST_FREE_BYTES"]
     assert ei.value.code == 9 and "parallel" in str(ei.value)
     fit = admm_lasso(x, y).penalty(0.1).fit()                      # and the same call works once there is room
     assert np.all(np.isfinite(fit.beta_dense))

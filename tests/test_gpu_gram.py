@@ -13,20 +13,12 @@ def _traced_with_env(env, x, y, lam, label):
     """A tall fit with kernel-variant knobs set (read at plan creation), judged by the trace rule (helpers R1-R4): every
     variant is its own execution with its own near-ties, so each is held to the oracle -- identical iteration counts,
     columns within 1e-4 -- instead of to the other variant with a slack on the counts."""
-    from admm_amd import admm_lasso
+    from admm_amd import admm_lasso, options
     from helpers import traced_parity
     from oracle import entry
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
+    with options(**{k.replace("ADMM_HIP_", ""): v for k, v in env.items()}):
         prob = dict(x=x, y=y, lam=lam, nlambda=100, lmin_ratio=1e-4, standardize=True, intercept=True, opts=entry.LASSO_OPTS, alpha=None)
         return traced_parity(admm_lasso(x, y).penalty(lam), prob, 1e-4, label=label)[0]
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
 
 
 def test_mfma_gram_matches_library_gram_end_to_end():
@@ -75,12 +67,9 @@ def test_fp64_mfma_gram_matches_library_gram_in_lad_and_bp():
     a = rng.standard_normal((2100, 4803)); b0 = np.zeros(4803); b0[:40] = rng.standard_normal(40); b = a @ b0
     out = {}
     for mode in ("rocblas", None):
-        if mode:
-            os.environ["ADMM_HIP_GRAM"] = mode
-        try:
+        from admm_amd import options
+        with options(GRAM=mode):
             out[mode] = (admm_lad(x, y).opts(maxit=25).fit(), admm_bp(a, b).opts(maxit=25).fit())
-        finally:
-            os.environ.pop("ADMM_HIP_GRAM", None)
     lad_ref, bp_ref = out["rocblas"]
     lad, bp = out[None]
     assert lad.niter == lad_ref.niter == 26 and bp.niter == bp_ref.niter == 26
@@ -91,7 +80,7 @@ def test_fp64_mfma_gram_matches_library_gram_in_lad_and_bp():
 @pytest.mark.parametrize("flags", [(True, True), (True, False), (False, True), (False, False)])
 def test_pipelined_host_input_setup_is_bit_identical(flags):
     """Host input with p >= 4096: conversion, standardisation and the Gram block rows run chunk by chunk under the
-    host-to-device transfer.  ADMM_HIP_GRAM=oneshot takes the sequential path; both must agree bit for bit
+    host-to-device transfer.  The option GRAM=oneshot takes the sequential path; both must agree bit for bit
     (p = 4200: ragged last 128-block and, with the 128-column minimum chunk, 33 chunks)."""
     from admm_amd import admm_lasso
     standardize, intercept = flags
@@ -100,11 +89,9 @@ def test_pipelined_host_input_setup_is_bit_identical(flags):
     x = rng.standard_normal((n, p)) * 1.5 + 0.3
     y = x[:, :20] @ rng.uniform(size=20) + rng.standard_normal(n)
     lam = [0.2, 0.05]
-    os.environ["ADMM_HIP_GRAM"] = "oneshot"
-    try:
+    from admm_amd import options
+    with options(GRAM="oneshot"):
         ref = admm_lasso(x, y, intercept, standardize).penalty(lam).opts(maxit=200).fit()
-    finally:
-        del os.environ["ADMM_HIP_GRAM"]
     fit = admm_lasso(x, y, intercept, standardize).penalty(lam).opts(maxit=200).fit()
     assert fit.stats["rho"] == ref.stats["rho"]
     assert np.array_equal(fit.niter, ref.niter)

@@ -45,23 +45,18 @@ def test_gram_vs_numpy(rows, cols, atA, dtype):
 
 
 @pytest.mark.parametrize("rows,cols", [(300, 4136), (200, 5700), (200, 5800)])
-def test_gram_tail_of_quarter_tiles_is_bit_identical(rows, cols, monkeypatch):
+def test_gram_tail_of_quarter_tiles(rows, cols):
     """Deep-K Gram launches end with QUARTER work items instead of a straggling round of full tiles (syrk_mfma.hip,
     gram_work_lists / gemm_nt_quarter): the ragged last block row when at most 64 of its rows are real (4136 = 32 x 128 + 40;
     5800 = 45 x 128 + 40) and the tiles of a last round that would be mostly empty (5700: 45 block rows = 1035 tiles on 1024
-    resident workgroups -> 11 tiles as 41 quarters).  A quarter item accumulates every element in the same K order with the same
-    instruction as the full tile, so the matrix must be bit-identical to the launch without them (ADMM_HIP_GRAM_TAIL=0) and to
-    the row-major tile order."""
+    resident workgroups -> 11 tiles as 41 quarters).  (Round 4 held them bit-identical to the launch without them and to the
+    row-major tile order; those two forms lost their A/B and are gone.)  Against float64, mirrored exactly."""
+    import admm_amd
     rng = np.random.default_rng(cols)
     A = (rng.standard_normal((rows, cols)) * 2 + 0.3).astype(np.float32)
-    monkeypatch.setenv("ADMM_HIP_GRAM_SPLIT", "0")                 # the exact-fp32 kernel: orders >= ~4000 take the 16-bit split by default (below)
-    G = _gram(A, True)
-    monkeypatch.setenv("ADMM_HIP_GRAM_TAIL", "0")
-    G0 = _gram(A, True)
-    monkeypatch.delenv("ADMM_HIP_GRAM_TAIL")
-    monkeypatch.setenv("ADMM_HIP_GRAM_ORDER", "row")
-    G1 = _gram(A, True)
-    assert np.array_equal(G, G0) and np.array_equal(G, G1) and np.array_equal(G, G.T)
+    with admm_amd.options(GRAM_SPLIT="0"):                         # the exact-fp32 kernel: orders >= ~4000 take the 16-bit split by default (below)
+        G = _gram(A, True)
+    assert np.array_equal(G, G.T)
     A64 = A.astype(np.float64)
     ref = A64.T @ A64
     assert np.abs(G - ref).max() / np.abs(ref).max() < 2e-5
@@ -69,13 +64,13 @@ def test_gram_tail_of_quarter_tiles_is_bit_identical(rows, cols, monkeypatch):
 
 @pytest.mark.parametrize("split", ["f16x2", "bf16x3"])
 @pytest.mark.parametrize("rows,cols,kind", [(9000, 4136, "gauss"), (3000, 5700, "gauss"), (20000, 4200, "standardised"), (2500, 4100, "wild"), (2100, 4000, "scales")])
-def test_gram_16bit_split_is_fp32_accurate(rows, cols, kind, split, monkeypatch):
+def test_gram_16bit_split_is_fp32_accurate(rows, cols, kind, split):
     """Tall Grams of order >= ~4000 run on the 16-bit matrix cores (gram_bf16x3.hip): every fp32 entry as two fp16 terms with an exact
     per-column power-of-two scale and the three significant cross products (default), or as three bf16 terms and six products.
     Against float64: no worse than 2 x the error of the exact-fp32 matrix-core kernel on the same input (all accumulate K products
     in fp32), mirrored exactly -- also on entries spanning 12 orders of magnitude ("wild") and on columns whose scales span 1e-12 ..
     1e12 ("scales": without the column scaling fp16 would overflow / flush)."""
-    monkeypatch.setenv("ADMM_HIP_GRAM_SPLIT", split)
+    import admm_amd
     rng = np.random.default_rng(rows + cols)
     if kind == "gauss":
         A = rng.standard_normal((rows, cols)) * 2 + 0.3
@@ -88,9 +83,10 @@ def test_gram_16bit_split_is_fp32_accurate(rows, cols, kind, split, monkeypatch)
         A = rng.standard_normal((rows, cols)) * 10.0 ** rng.uniform(-12, 12, size=cols)[None, :]
         A[:, 7] = 0.0                                                  # a null column: scale 1
     A = A.astype(np.float32)
-    G3 = _gram(A, True)
-    monkeypatch.setenv("ADMM_HIP_GRAM_SPLIT", "0")
-    G1 = _gram(A, True)
+    with admm_amd.options(GRAM_SPLIT=split):
+        G3 = _gram(A, True)
+    with admm_amd.options(GRAM_SPLIT="0"):
+        G1 = _gram(A, True)
     A64 = A.astype(np.float64)
     ref = A64.T @ A64
     assert np.array_equal(G3, G3.T)
@@ -103,7 +99,7 @@ def test_gram_16bit_split_is_fp32_accurate(rows, cols, kind, split, monkeypatch)
     assert np.sqrt((e3 ** 2).mean()) <= 2.0 * np.sqrt((e1 ** 2).mean()) + 1e-8
 
 
-def test_gram_16bit_split_at_the_headline_row_count(monkeypatch):
+def test_gram_16bit_split_at_the_headline_row_count():
     """The DEFAULT Gram of BASELINE configs[1] at its real K range: 100 000 rows x 10 000 standardised columns through the fp16 x 2 split
     (13 launches of 8192-row slabs accumulated in fp32), against float64 X'X formed on the device by torch.  Same normalised metric and
     same bound as test_gram_16bit_split_is_fp32_accurate (which stops at 20 000 rows): no worse than 2 x the exact-fp32 matrix-core
@@ -117,10 +113,11 @@ def test_gram_16bit_split_at_the_headline_row_count(monkeypatch):
             + rng.uniform(-5, 5, size=500).astype(np.float32)[None, :]
         blk64 = blk.astype(np.float64)
         A[:, j0:j0 + 500] = ((blk64 - blk64.mean(0)) / blk64.std(0)).astype(np.float32)
-    monkeypatch.setenv("ADMM_HIP_GRAM_SPLIT", "f16x2")
-    G3 = _gram(A, True)
-    monkeypatch.setenv("ADMM_HIP_GRAM_SPLIT", "0")
-    G1 = _gram(A, True)
+    import admm_amd
+    with admm_amd.options(GRAM_SPLIT="f16x2"):
+        G3 = _gram(A, True)
+    with admm_amd.options(GRAM_SPLIT="0"):
+        G1 = _gram(A, True)
     assert np.array_equal(G3, G3.T) and not np.array_equal(G3, G1), "the 16-bit path was not taken"
     dev = torch.device("cuda", 0)
     ref = torch.zeros((cols, cols), dtype=torch.float64, device=dev)
@@ -138,26 +135,6 @@ def test_gram_16bit_split_at_the_headline_row_count(monkeypatch):
           f"fp32 kernel {out['fp32'][0]:.2e} (rms {out['fp32'][1]:.2e})")
     assert out["split"][0] <= 2.0 * out["fp32"][0] + 1e-7
     assert out["split"][1] <= 2.0 * out["fp32"][1] + 1e-8
-
-
-@pytest.mark.parametrize("n", [256, 301, 1100, 2300])
-@pytest.mark.parametrize("precision", [0, 1])
-def test_output_tiles_through_lds_are_bit_identical(n, precision, monkeypatch):
-    """The NT-GEMMs (float: syrk_mfma.hip, double: gemm_f64_mfma.hip) hand their output tile over through LDS so that C is read
-    and written in whole column pieces (EPI = 1: every launch without the mirrored store -- all rank-128 updates of the blocked
-    factorisation, the split-K partial Grams).  Same arithmetic per element as the direct stores from the matrix-core layout
-    (ADMM_HIP_GEMM_EPI=0): the inverse (beta = 1 updates, orders that are not multiples of 4 or 128 -> the scalar edge path) and
-    a split-K Gram (beta = 0, partial tiles) must not change in a single bit."""
-    rng = np.random.default_rng(n)
-    dtype = np.float64 if precision == 1 else np.float32
-    X = rng.standard_normal((2 * n, n))
-    A = (X.T @ X + 0.05 * n * np.eye(n)).astype(dtype)
-    W = (rng.standard_normal((3 * n, n // 2)) * 2 + 0.3).astype(dtype)           # few tiles, deep K: split-K launch (float)
-    inv1, g1 = _inverse(A, precision), _gram(W, True)
-    monkeypatch.setenv("ADMM_HIP_GEMM_EPI", "0")
-    inv0, g0 = _inverse(A, precision), _gram(W, True)
-    assert np.array_equal(inv1, inv0) and np.array_equal(g1, g0)
-    assert np.abs(inv1 @ A.astype(np.float64) - np.eye(n)).max() < (1e-9 if precision == 1 else 5e-3)
 
 
 @pytest.mark.parametrize("n", [256, 300, 1100, 2048, 2300])

@@ -131,18 +131,17 @@ def test_gram_space_and_its_ways_out(monkeypatch):
     """Round 5: the active-set iterations run in Gram space (one |U| x |U| mat-vec per iteration instead of two passes over the
     non-zero columns; sharing_bp.hip "Gram space").  Every way through that code is held to the oracle like the direct launches:
     the default (a stretch after a Gram-space stretch carries everything over: no n-vector is touched at the regular iteration), every
-    stretch started from the direct launches' n-vectors (ADMM_HIP_SBP_GRAM_CARRY=0), the direct launches alone (ADMM_HIP_SBP_GRAM=0), a Gram matrix too small for the support (the merge launch halts
+    stretch started from the direct launches' n-vectors (option SBP_GRAM_CARRY=0), the direct launches alone (option SBP_GRAM=0), a Gram matrix too small for the support (the merge launch halts
     the stream, the host resumes with the direct launches and returns to Gram space 100, 200, ... iterations later), and one that
     overflows with columns that have come and gone first (U is rebuilt from the current lists)."""
+    import admm_amd
     from oracle import readme
     x, y, _ = readme.bp_data(1000, 2000, 100)                    # README.md:369-393: ~100 non-zeros at the end, more on the way
     seen = {}
     for label, env in (("default", {}), ("direct", {"ADMM_HIP_SBP_GRAM": "0"}), ("no carry-over", {"ADMM_HIP_SBP_GRAM_CARRY": "0"}),
                        ("cap 64: halt + resume", {"ADMM_HIP_SBP_GRAM_CAP": "64"}),
                        ("cap 96: a rebuild, then halt + resume", {"ADMM_HIP_SBP_GRAM_CAP": "96"})):
-        with monkeypatch.context() as m:
-            for k, v in env.items():
-                m.setenv(k, v)
+        with admm_amd.options(**{k.replace("ADMM_HIP_", ""): v for k, v in env.items()}):
             fit, o = _compare(x, y, 4, f"README n=1000 p=2000, {label}")
         st = fit.stats
         seen[label] = (st["xupdate_variant"], st["xupdate_launches"], st["persist_iter"])
@@ -157,8 +156,7 @@ def test_gram_space_and_its_ways_out(monkeypatch):
     xs = np.asfortranarray(rng.standard_normal((n, p)))
     b0 = np.zeros(p); b0[rng.choice(p, 12, replace=False)] = rng.standard_normal(12) * 4
     for N, cap in ((3, "1024"), (6, "16"), (6, "24")):
-        with monkeypatch.context() as m:
-            m.setenv("ADMM_HIP_SBP_GRAM_CAP", cap)
+        with admm_amd.options(SBP_GRAM_CAP=cap):
             _compare(xs, xs @ b0, N, f"n=120 p=700 cap {cap}")
 
 
@@ -166,11 +164,12 @@ def test_gram_space_launches_do_not_depend_on_their_workgroups_starting_together
     """Regression (round 5, found by tests/tools/parbp_gram_soak.py: 4 of 1200 cases with one wrong recorded residual, never the same
     ones): a Gram-space launch reads, in every workgroup, the partial sums that ALL workgroups of the previous launch left, and
     every workgroup leaves its own for the next launch -- in the same array at the time, so a workgroup that started a few
-    microseconds late read numbers of the launch it belonged to.  ADMM_HIP_SBP_TEST_DELAY_US holds every even workgroup back at the
+    microseconds late read numbers of the launch it belonged to.  The test option SBP_TEST_DELAY_US holds every even workgroup back at the
     start of each such launch (30 us, three launches' worth; workgroup 0, whose decision is the recorded one, among them), which
     turns a dependence of that kind into a certain failure (checked against the single-buffered build when the test was written)."""
+    import admm_amd
     from oracle import readme
-    monkeypatch.setenv("ADMM_HIP_SBP_TEST_DELAY_US", "30")
+    admm_amd.options.set(SBP_TEST_DELAY_US="30")
     x, y, _ = readme.bp_data()
     _compare(x, y, 3, "README n=50 p=100, even workgroups 30 us late")
     rng = np.random.default_rng(21)
@@ -178,5 +177,5 @@ def test_gram_space_launches_do_not_depend_on_their_workgroups_starting_together
     xs = np.asfortranarray(rng.standard_normal((n, p)))
     b0 = np.zeros(p); b0[rng.choice(p, 12, replace=False)] = rng.standard_normal(12) * 4
     _compare(xs, xs @ b0, 4, "n=120 p=700, even workgroups 30 us late")
-    monkeypatch.setenv("ADMM_HIP_SBP_GRAM_CARRY", "0")
+    admm_amd.options.set(SBP_GRAM_CARRY="0")
     _compare(xs, xs @ b0, 4, "n=120 p=700, no carry-over, even workgroups 30 us late")

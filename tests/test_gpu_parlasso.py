@@ -71,7 +71,7 @@ def test_batched_worker_products_are_bit_identical_to_per_worker_launches(monkey
         x, y = synth_lasso(n, p, 10, seed=n + p)
         out = []
         for flag in ("1", "0"):
-            monkeypatch.setenv("ADMM_HIP_PAR_BATCH", flag)
+            admm_amd.options.set(PAR_BATCH=flag)
             m = admm_amd.admm_lasso(x, y).penalty(nlambda=nl).opts(maxit=maxit)
             m.nthread = K
             out.append(m.fit())

@@ -1,4 +1,4 @@
-"""GPU: mixed-precision refinement of the tall x-update (ADMM_HIP_REFINE=1).
+"""GPU: mixed-precision refinement of the tall x-update (option REFINE=1 / admm_hip_options.tall_refine).
 
 x1 = Minv rhs with the cached float inverse, r = rhs - M x1 in DOUBLE from the float system M = X'X + rho I (the system the
 reference factorises, ADMMLassoTall.h:191-205), x = x1 + Minv r: one refinement step per x-update, three passes over the
@@ -25,9 +25,8 @@ def _fit(x, y, nl, refine):
     """(fit, trace, state, system): system = X'X + rho I as the library formed it (kept by the refined plan only)."""
     from admm_amd import admm_lasso
     from admm_amd.api import LassoPlan
-    old = os.environ.get("ADMM_HIP_REFINE")
-    if refine:
-        os.environ["ADMM_HIP_REFINE"] = "1"
+    from admm_amd import options
+    options.set(REFINE="1" if refine else None)
     try:
         plan = LassoPlan(admm_lasso(x, y).penalty(nlambda=nl))
         plan.enable_trace(1 << 14)
@@ -37,10 +36,7 @@ def _fit(x, y, nl, refine):
         plan.close()
         return out
     finally:
-        if old is None:
-            os.environ.pop("ADMM_HIP_REFINE", None)
-        else:
-            os.environ["ADMM_HIP_REFINE"] = old
+        options.set(REFINE=None)
 
 
 def test_refined_xupdate_is_the_exact_solve_to_one_rounding():

@@ -241,7 +241,7 @@ def test_soak_853_39_the_one_case_beyond_r3_is_named():
     29 x 28 standardised Gaussian matrix has condition ~1e4 .. 1e5, the path runs 5257 iterations at its rounding floor, and the
     stepwise instrument finds every one of them the reference's iteration (x-update within 0.61 x the float-solve yardstick, 0 bit
     mismatches): the 1.3e-4 is the accumulated difference of two correct float executions, 0.3e-4 past the bar.  Not refinable
-    (ADMM_HIP_REFINE covers p >= 2048).  Held here: stepwise clean; the column within 8 x the variants' drift and below 2e-4 --
+    (the refinement option covers p >= 2048).  Held here: stepwise clean; the column within 8 x the variants' drift and below 2e-4 --
     so that it can neither get worse unnoticed nor stay a footnote."""
     import re
     from oracle import stepcheck

@@ -107,20 +107,3 @@ def test_device_resident_input_matches_host_input():
     fit_d = admm_lasso(DevicePtr(xd.data_ptr()), DevicePtr(yd.data_ptr()), n=1200, p=150).penalty(nlambda=8).fit()
     assert np.array_equal(fit_h.beta_dense, fit_d.beta_dense)
     assert list(fit_h.niter) == list(fit_d.niter)
-
-
-def test_single_launch_iteration_is_bit_identical():
-    """ADMM_HIP_TALL_FUSED=1: tail of iteration g-1, decision g and the mat-vec tiles of iteration g in ONE launch
-    (in-launch hand-over of u, w through write-through stores, generation flags and bypass loads).  Same arithmetic in
-    the same order as the default two-launch path: every bit of the result must agree."""
-    import os
-    from admm_amd import admm_lasso
-    x, y = synth_lasso(4700, 2300, 40, seed=2300)
-    a = admm_lasso(x, y).penalty(nlambda=8).fit()
-    os.environ["ADMM_HIP_TALL_FUSED"] = "1"
-    try:
-        b = admm_lasso(x, y).penalty(nlambda=8).fit()
-    finally:
-        os.environ.pop("ADMM_HIP_TALL_FUSED")
-    assert a.stats["xupdate_variant"] == 1 and b.stats["xupdate_variant"] == 3
-    assert np.array_equal(a.beta_dense, b.beta_dense) and list(a.niter) == list(b.niter)

@@ -70,3 +70,46 @@ def test_concurrent_calls_are_bit_equal_to_sequential_ones():
     assert len(results) == nthreads * rounds * len(names)
     bad = [k for k, v in results.items() if v != alone[k[2]]]
     assert not bad, ("results of concurrent calls differ from the same calls made alone", bad[:8])
+
+
+def test_two_threads_run_two_different_variants_at_the_same_time():
+    """Variant selectors belong to the calling thread (admm_hip_options_set / admm_hip_option_set, round 6; they were process-wide
+    environment variables): thread A fits the consensus problem in the one-pass form, thread B the SAME problem in the reference's
+    two-pass form, and a tall problem with / without the refinement, concurrently and repeatedly.  Every result must be bit-equal to
+    the same variant run alone, the two variants must really have been different executions, and the options of one thread must
+    never show in the other."""
+    import admm_amd
+    from admm_amd import admm_lasso
+    rng = np.random.default_rng(12)
+    x = rng.standard_normal((403, 900)) * 2
+    y = x[:, :15] @ rng.uniform(size=15) + rng.standard_normal(403)
+    job = lambda: admm_lasso(x, y).penalty(nlambda=4, lambda_min_ratio=0.2).parallel(4).opts(maxit=300).fit()      # noqa: E731  (Woodbury workers)
+    variants = {"one-pass": {}, "two-pass": dict(consensus_two_pass=1)}
+    alone = {}
+    for name, fields in variants.items():
+        admm_amd.options.struct(**fields)
+        alone[name] = _key(job())
+        admm_amd.options.reset()
+    assert alone["one-pass"] != alone["two-pass"], "the two variants are different float executions of one algorithm"
+    errors, results = [], {}
+    start = threading.Barrier(2)
+
+    def worker(name):
+        try:
+            admm_amd.options.struct(**variants[name])                  # this thread's options only
+            assert (admm_amd.load().admm_hip_option_get(b"PAR_ONEPASS") is not None) == (name == "two-pass")
+            start.wait()
+            for r in range(6):
+                results[(name, r)] = _key(job())
+        except Exception as e:                                        # noqa: BLE001
+            errors.append((name, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(n,)) for n in variants]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    bad = [k for k, v in results.items() if v != alone[k[0]]]
+    assert len(results) == 12 and not bad, bad
+    assert admm_amd.load().admm_hip_option_get(b"PAR_ONEPASS") is None      # nothing leaked into the main thread

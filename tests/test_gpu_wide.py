@@ -68,38 +68,20 @@ def test_wide_user_lambda_and_maxit():
 
 
 def _fit_env(x, y, nl, maxit, **env):
-    """Fit with kernel-variant environment knobs (read at plan creation)."""
-    import os
-    from admm_amd import admm_lasso
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
+    """Fit with kernel-variant options of the calling thread (admm_amd.options; read at plan creation)."""
+    from admm_amd import admm_lasso, options
+    with options(**env):
         return admm_lasso(x, y).penalty(nlambda=nl).opts(maxit=maxit).fit()
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
 
 
 def _traced_env(x, y, nl, maxit, label, **env):
     """Traced fit under kernel-variant knobs, judged by the trace rule against the oracle (counts identical, columns 1e-4)."""
-    import os
-    from admm_amd import admm_lasso
+    from admm_amd import admm_lasso, options
     from helpers import traced_parity
     from oracle import entry
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
+    with options(**env):
         prob = dict(x=x, y=y, lam=None, nlambda=nl, lmin_ratio=0.01, standardize=True, intercept=True, opts=dict(entry.LASSO_OPTS, maxit=maxit), alpha=None)
         return traced_parity(admm_lasso(x, y).penalty(nlambda=nl, lambda_min_ratio=0.01).opts(maxit=maxit), prob, TOL, label=label)[0]
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
 
 
 def test_wide_large_n_lds_modes():
@@ -109,12 +91,12 @@ def test_wide_large_n_lds_modes():
     the LDS mode where both exist, and the large sizes reproduce the oracle."""
     from oracle import entry
     x, y = synth_lasso(3000, 3600, 15, seed=41)
-    a = _fit_env(x, y, 4, 40, ADMM_HIP_WIDE_FUSE="0")
-    b = _fit_env(x, y, 4, 40, ADMM_HIP_WIDE_TGLOBAL="1")
+    a = _fit_env(x, y, 4, 40, WIDE_FUSE="0")
+    b = _fit_env(x, y, 4, 40, WIDE_TGLOBAL="1")
     assert np.array_equal(a.beta_dense, b.beta_dense) and list(a.niter) == list(b.niter)
     x, y = synth_lasso(9000, 9500, 20, seed=43)
     a = _traced_env(x, y, 3, 25, "wide n=9000 (LDS opt-in)")                      # trace rule: counts identical to the oracle's, columns 1e-4
-    b = _fit_env(x, y, 3, 25, ADMM_HIP_WIDE_TGLOBAL="1")
+    b = _fit_env(x, y, 3, 25, WIDE_TGLOBAL="1")
     assert np.array_equal(a.beta_dense, b.beta_dense) and list(a.niter) == list(b.niter)
     x, y = synth_lasso(21000, 21500, 20, seed=47)
     _traced_env(x, y, 2, 12, "wide n=21000 (t through global memory)")
@@ -128,7 +110,7 @@ def test_wide_fused_x_update_up_to_8192_rows(n, p):
     from oracle import entry
     x, y = synth_lasso(n, p, 20, seed=n)
     a = _traced_env(x, y, 3, 30, f"wide fused n={n}")                              # each variant is its own execution: both held to the oracle
-    b = _traced_env(x, y, 3, 30, f"wide three launches n={n}", ADMM_HIP_WIDE_FUSE="0")
+    b = _traced_env(x, y, 3, 30, f"wide three launches n={n}", WIDE_FUSE="0")
     assert a.stats["xupdate_launches"] > 0
     for j in range(3):
         assert relerr(a.beta_dense[:, j], b.beta_dense[:, j]) < 1e-4, j
@@ -144,11 +126,11 @@ def test_persistent_active_set_stretch(n, p, cgroups):
     path.  n = 600: 3 x 10 workgroups; n = 1500: 6 x 5; n = 3000 / 5000: 12 x 2 / 20 x 1 (beyond the 2048 rows the round-3 stretch
     stops at); n = 257: a second row group that owns ONE row, 2 x 16; C forced to 1 / 2: no / fewer column groups."""
     x, y = synth_lasso(n, p, 15, seed=n + p)
-    env = {}                                                 # the stretch is the default (ADMM_HIP_WIDE_PERSIST=0 switches it off)
+    env = {}                                                 # the stretch is the default (WIDE_PERSIST=0 switches it off)
     if cgroups:
-        env["ADMM_HIP_WIDE_ROWS_C"] = cgroups
+        env["WIDE_ROWS_C"] = cgroups
     a = _traced_env(x, y, 10, 10000, f"wide 2-D stretch n={n} C={cgroups or 'auto'}", **env)
-    b = _fit_env(x, y, 10, 10000, ADMM_HIP_WIDE_PERSIST="0")
+    b = _fit_env(x, y, 10, 10000, WIDE_PERSIST="0")
     assert int(a.stats["persist_iter"]) > 0.5 * int(a.stats["total_iter"]), (a.stats["persist_iter"], a.stats["total_iter"])
     for j in range(10):
         assert relerr(a.beta_dense[:, j], b.beta_dense[:, j]) < 1e-4, j
