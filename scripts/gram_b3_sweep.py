@@ -4,6 +4,7 @@ import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
+import admm_amd
 from admm_amd import DevicePtr, admm_lasso
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev); g.manual_seed(123)
@@ -16,8 +17,8 @@ y = b @ xt + torch.randn(n, generator=g, device=dev, dtype=torch.float64)
 torch.cuda.synchronize()
 variants = [("fp32", {"ADMM_HIP_GRAM_SPLIT": "0"})] + [(f"{m} ktiles={k}", {"ADMM_HIP_GRAM_SPLIT": m, "ADMM_HIP_GRAM_B3_KTILES": str(k)}) for m in ("bf16x3", "f16x2") for k in sys.argv[1:] or ["0", "516"]]
 for name, env in variants:
-    os.environ.pop("ADMM_HIP_GRAM_SPLIT", None); os.environ.pop("ADMM_HIP_GRAM_B3_KTILES", None)
-    os.environ.update(env)
+    admm_amd.options.reset()
+    admm_amd.options.set(**{k.replace("ADMM_HIP_", ""): v for k, v in env.items()})
     ts = []
     for rep in range(3):
         fit = admm_lasso(DevicePtr(xt.data_ptr()), DevicePtr(y.data_ptr()), n=n, p=p).penalty(nlambda=2).opts(maxit=3).fit()

@@ -36,10 +36,10 @@ for rep in range(3):
         admm_amd.admm_lasso(xt, yt).penalty(nlambda=4).fit_responses(np.stack([yt, yt[::-1]], axis=1))
         admm_amd.admm_bp(xb, yb).parallel(4).fit()                                   # sharing basis pursuit (round 3)
         admm_amd.admm_dantzig(xt[:, :40], yt).penalty(nlambda=3, lambda_min_ratio=0.1).opts(maxit=300).fit()
-        os.environ["ADMM_HIP_CV_DOWNDATE"] = "1"
+        admm_amd.options.set(CV_DOWNDATE="1")
         admm_amd.admm_lasso(xt, yt).penalty(nlambda=4).cv(nfolds=3)                  # folds as down-dates
-        os.environ.pop("ADMM_HIP_CV_DOWNDATE")
-        os.environ["ADMM_HIP_REFINE"] = "1"
+        admm_amd.options.set(CV_DOWNDATE=None)
+        admm_amd.options.set(REFINE="1")
         admm_amd.admm_lasso(xt, yt).penalty(nlambda=3).fit()                         # refined x-update keeps a second p x p matrix
-        os.environ.pop("ADMM_HIP_REFINE")
+        admm_amd.options.set(REFINE=None)
     print("round", rep, "device MiB in use before/after", round(u0, 1), round(used(), 1), flush=True)

@@ -20,6 +20,7 @@ p = int(args.pop(0)) if args and args[0].isdigit() else 10000
 n = int(args.pop(0)) if args and args[0].isdigit() else 100000
 scheds = args or ["128,128,0", "192,64,550"]
 os.environ["ADMM_HIP_PROFILE_STRIDE"] = "32"
+import admm_amd  # noqa: E402
 from admm_amd import admm_lasso, DevicePtr, LassoPlan, load  # noqa: E402
 lib = load()
 dev = torch.device("cuda", 0)
@@ -37,7 +38,7 @@ torch.cuda.synchronize()
 model = admm_lasso(DevicePtr(xt.data_ptr()), DevicePtr(y.data_ptr()), n=n, p=p).penalty(nlambda=100)
 ref = None
 for sc in scheds:
-    os.environ["ADMM_HIP_SYMV_SCHED"] = sc
+    admm_amd.options.set(SYMV_SCHED=sc)
     plan = LassoPlan(model)
     fit = plan.run()
     best = None
