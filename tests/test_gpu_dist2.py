@@ -159,7 +159,7 @@ def test_two_process_cross_validation_folds_as_replicas(backend, downdate, monke
         pytest.skip("covered over shm (the modes differ in the setup only, not in the exchange)")
     res = _run_ranks(backend, "cv", extra_env={"ADMM_HIP_CV_DOWNDATE": downdate})
     x, y, _, kw = problem("cv")
-    monkeypatch.setenv("ADMM_HIP_CV_DOWNDATE", downdate)
+    admm_amd.options.set(CV_DOWNDATE=downdate)       # this process: through the options of the calling thread (the ranks: the overlay of their environment)
     one = admm_amd.admm_lasso(np.asfortranarray(x), y).penalty(nlambda=kw["nlambda"]).cv(nfolds=5, keep_fold_beta=True)
     for r in res:
         assert np.array_equal(r["fold_mse"], one.fold_mse) and np.array_equal(r["fold_niter"], one.fold_niter)
