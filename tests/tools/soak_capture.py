@@ -47,7 +47,13 @@ def worker(seed, ncases, out):
     path = os.path.join(out, f"seed_{seed}.jsonl")
     with open(path, "w") as fh:
         for cs in cases(ncases, seed):
-            rec = dict(seed=seed, case=cs["c"], kind=cs["kind"], n=cs["n"], p=cs["p"], K=cs.get("K", 0), icpt=int(cs["icpt"]),
+            orig = cs["kind"]
+            if os.environ.get("SOAK_SWAP") == "1":              # round 6: the SAME data with the prox labels swapped (is a failure the label's or the data's?)
+                if orig == "tall":
+                    cs["kind"], cs["alpha"] = "enet_tall", [0.1, 0.5, 0.9, 1.0][(7 * seed + cs["c"]) % 4]
+                elif orig == "enet_tall":
+                    cs["kind"], cs["alpha"] = "tall", None
+            rec = dict(seed=seed, case=cs["c"], kind=cs["kind"], orig_kind=orig, alpha=cs.get("alpha"), n=cs["n"], p=cs["p"], K=cs.get("K", 0), icpt=int(cs["icpt"]),
                        stdz=int(cs["stdz"]), scale=cs["scale"])
             t0 = time.time()
             try:
@@ -55,6 +61,7 @@ def worker(seed, ncases, out):
                 always_sw = cs["kind"] in ("lad", "bp") or (cs["n"] <= cs["p"] and not (cs["kind"] == "par" and cs.get("K", 0) > 1))
                 cap = T.gpu_capture(cs, state=always_sw)
                 rec["decisions"] = int(len(cap["trace"]))
+                rec["longest_lambda"] = int(np.asarray(cap["trace"])[:, 1].max()) + 1 if len(cap["trace"]) else 0
                 rec["t_gpu"] = round(time.time() - t0, 3)
                 buf = io.StringIO()
                 try:
