@@ -51,6 +51,17 @@ int option_int(const char* name, int dflt);
 void option_set_thread(const char* name, const char* value);      // value nullptr: back to the default / overlay
 void options_reset_thread();
 
+// roctx range around a phase of a call (setup: convert + standardise, Gram, Lanczos, factorisation + inverse; the ADMM loop; the
+// read-back): shows as a named span in rocprofv3 --marker-trace / omnitrace next to the kernels.  libroctx64 is
+// dlopen'ed on first use; without it the ranges cost one branch.
+struct TraceRange {
+    explicit TraceRange(const char* name);
+    ~TraceRange();
+    TraceRange(const TraceRange&) = delete;
+    TraceRange& operator=(const TraceRange&) = delete;
+    bool on;
+};
+
 // Cache of large device blocks (api.hip).  hipMalloc / hipFree of multi-GB buffers are synchronous page-table operations whose cost
 // varies by box and by what the process freed before (measured on C2, second plan creation of a process: 0.07 s of kernels inside
 // 0.07 .. 0.31 s of wall, the difference all in hipFree / hipMalloc of the 4 GB operands) -- a resident server or an R session that

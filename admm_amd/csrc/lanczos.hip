@@ -283,6 +283,7 @@ static T lanczos_largest_impl(const std::function<void(const T*, T*)>& op, int n
 
 
 float lanczos_largest_f32(const std::function<void(const float*, float*)>& op, int n, int* nmatop_out) {
+    const TraceRange trace_range("admm:lanczos");
     return lanczos_largest_impl<float>(op, n, nmatop_out);
 }
 // the same call with Scalar = double (src/TODO/ADMMDantzig.h:226-233)

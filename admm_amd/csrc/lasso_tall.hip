@@ -775,6 +775,7 @@ struct TallPlan final : LassoPlan {
 
         comm_stream_sync(st);
         const CommLockstep lockstep;                                   // per-iteration exchanges: the short wait bound (comm.h)
+        const TraceRange trace_range("admm:loop");
         const double tl0 = now_s();
         ADMM_HIP_CHECK(hipEventRecord(ev_loop0.e, st));
         long long g = 0, launches = 0;

@@ -1595,11 +1595,10 @@ struct WidePlan final : LassoPlan {
         return nrec;
     }
 
-    // iterate dump (test facility): record s = x | A x | z | y (p + 3 n floats) the decision of trace record s judged
+    // iterate dump (test facility): record s = x | A x | z | y (p + 3 n floats; column-sharded: x of this rank's p columns) the decision of trace record s judged
     DevBuf<float> state;
     long long state_cap = 0;
     void enable_state(long long cap) override {
-        if (cshard) throw Error(ADMM_ERR_INVALID_ARG, "the column-sharded wide solver records no iterate dump");
         const size_t rec = (size_t)p + 3 * (size_t)n;
         state.alloc((size_t)cap * rec);
         ADMM_HIP_CHECK(hipMemsetAsync(state.get(), 0, (size_t)cap * rec * sizeof(float), st));
@@ -1838,6 +1837,7 @@ struct WidePlan final : LassoPlan {
                     hipLaunchKernelGGL(wide_ax_push_kernel, dim3((unsigned)((ldn + kWtElems - 1) / kWtElems)), dim3(kWideThreads), 0, st, q, par, ex);
                     hipLaunchKernelGGL(wide_tail_kernel<1>, dim3(nwg_tail), dim3(kWideThreads), 0, st, q, par, ex);
                 }
+                if (q.state != nullptr) hipLaunchKernelGGL(wide_state_kernel, dim3(std::min(1024, (std::max(n, p) + kWideThreads - 1) / kWideThreads)), dim3(kWideThreads), 0, st, q, par);
                 if (persist_rows) launch_persist_rows(par ^ 1);          // the stretch on this rank's column block, its A x summed over the ranks inside the launch
                 return;
             }

@@ -33,6 +33,7 @@ struct PinnedFlag {
 template <typename F>
 inline LoopTimes run_until_done(hipStream_t st, const int* d_done, int batch, long long max_iters, F&& enqueue,
                                 const volatile int* h_flag = nullptr, long long g_start = 0) {
+    const TraceRange trace_range("admm:loop");
     int* h_done = nullptr;
     ADMM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_done), 2 * sizeof(int), hipHostMallocDefault));
     struct HostFree { void* p; ~HostFree() { (void)hipHostFree(p); } } hf{h_done};

@@ -25,6 +25,26 @@ void require_device() {
         throw Error(ADMM_ERR_NO_DEVICE, "no usable HIP device (libadmm_hip has no CPU fallback)");
 }
 
+namespace {
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        for (const char* n : {"libroctx64.so.4", "libroctx64.so", "/opt/rocm/lib/libroctx64.so"}) {
+            if (void* h = dlopen(n, RTLD_NOW | RTLD_GLOBAL)) {
+                push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+                pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+                if (push && pop) return;
+                push = nullptr; pop = nullptr;
+            }
+        }
+    }
+};
+const Roctx& roctx() { static const Roctx* r = new Roctx(); return *r; }
+}  // namespace
+TraceRange::TraceRange(const char* name) : on(roctx().push != nullptr) { if (on) (void)roctx().push(name); }
+TraceRange::~TraceRange() { if (on) (void)roctx().pop(); }
+
 long long resident_workgroups(int occupancy_per_cu) {
     if (const char* e = option("TEST_RESIDENT_WGS")) { const long long v = std::atoll(e); if (v >= 0) return v; }
     return (long long)occupancy_per_cu * device_info().num_cu;
@@ -281,6 +301,7 @@ void write_device(void* dst, const void* src, size_t bytes) {
 template <typename T>
 void upload_standardize(DeviceData<T>& d, const double* x, const double* y, int n, int p, int mem,
                         bool standardize, bool intercept, hipStream_t st, long long n_total) {
+    const TraceRange trace_range("admm:convert+standardize");
     const bool dist = n_total > 0;          // only the multi-process entry points pass n_total: all ranks are in this call
     if (n_total <= 0) n_total = n;
     d.n = n; d.p = p; d.n_total = n_total;
@@ -410,6 +431,7 @@ void gram_rows_mfma_f32(const float* Z, long long ldz, int r0, int nr, int K, fl
 
 void upload_standardize_gram_f32(DeviceData<float>& d, const double* x, const double* y, int n, int p,
                                  bool standardize, bool intercept, hipStream_t st) {
+    const TraceRange trace_range("admm:upload+standardize+gram (pipelined)");
     using T = float;
     d.n = n; d.p = p; d.n_total = n;
     d.flag = int(standardize) + 2 * int(intercept);
@@ -634,6 +656,7 @@ void gram_mfma_f64(const double* A, long long lda, int rows, int cols, bool atA,
 
 template <typename T>
 void gram_full(const T* A, long long lda, int rows, int cols, bool atA, T* C, long long ldc, hipStream_t st) {
+    const TraceRange trace_range("admm:gram");
     // hand-written matrix-core kernels (fp32: split-K when the triangle has few tiles; fp64) for every size, so that no
     // BLAS handle is ever created in a default run (rocBLAS handle creation alone costs 0.1-0.2 s per process);
     // ADMM_HIP_GRAM=rocblas forces the library path (A/B tests)
@@ -750,6 +773,7 @@ __global__ void __launch_bounds__(256) narrow_kernel(const double* __restrict__ 
 // float ONCE, so that each entry of the cached inverse carries half an ulp of error instead of the accumulated
 // rounding of an fp32 factorisation (lasso_tall.hip: fewer stopping-rule / restart flips against a Cholesky solve).
 void spd_inverse_f32_via_f64(float* A, long long lda, int n, double diag, hipStream_t st) {
+    const TraceRange trace_range("admm:factor+inverse (f64)");
     const int pp = round_up(n, 128);
     ADMM_REQUIRE(lda >= pp, "spd_inverse_f32_via_f64: leading dimension must cover whole 128-row blocks");
     DevBuf<double> D((size_t)lda * pp);
@@ -761,12 +785,14 @@ void spd_inverse_f32_via_f64(float* A, long long lda, int n, double diag, hipStr
 }
 
 void spd_inverse_f32(float* A, long long lda, int n, hipStream_t st) {
+    const TraceRange trace_range("admm:factor+inverse (f32)");
     const char* e = option("FACTOR");
     if ((e && std::string(e) == "rocsolver") || lda < round_up(n, 128)) spd_inverse_full<float>(A, lda, n, st);
     else spd_inverse_mfma_f32(A, lda, n, st);
 }
 
 void spd_inverse_f64(double* A, long long lda, int n, hipStream_t st) {
+    const TraceRange trace_range("admm:factor+inverse (f64)");
     const char* e = option("FACTOR");
     if ((e && std::string(e) == "rocsolver") || lda < round_up(n, 128)) spd_inverse_full<double>(A, lda, n, st);
     else spd_inverse_mfma_f64(A, lda, n, st);

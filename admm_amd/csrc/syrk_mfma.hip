@@ -516,6 +516,7 @@ void spd_inverse_mfma_f32(float* A, long long lda, int p, hipStream_t st) {
 // cholesky_linvt_blocked_dist) and, of the inverse U U', only the lower 128 x 128 tiles listed in `need` (bi << 16 | bj): the tiles
 // this rank's share of the sharded x-update reads.  Everything a rank computes is bit-identical to the single-process result.
 void spd_inverse_mfma_f32_dist(float* A, long long lda, int p, const std::vector<int>& need, double* flops, hipStream_t st) {
+    const TraceRange trace_range("admm:factor+inverse (distributed)");
     const CommInfo ci = comm_info();
     double fl = 0;
     DevBuf<float> U = cholesky_linvt_blocked_dist<float>(A, lda, p, st, launch_gemm_nt_f32, ci.nranks, ci.rank,

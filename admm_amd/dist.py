@@ -336,11 +336,31 @@ class DistLassoPlan:
                                                        self._trace_cap, ctypes.byref(n)))
         return buf[:n.value].copy()
 
+    def enable_state(self, capacity):
+        """Iterate dump of every iteration of the following run() calls (admm_hip_lasso_plan_state_*): record s = the iterates trace
+        record s judged.  Column-sharded wide solver: x of THIS rank's columns | A x | z | y (p_local + 3 n floats)."""
+        check(self._lib.admm_hip_lasso_plan_state_enable(self._h, int(capacity)))
+
+    def read_state(self):
+        n, rf = ctypes.c_longlong(), ctypes.c_longlong()
+        check(self._lib.admm_hip_lasso_plan_state_read(self._h, None, 0, ctypes.byref(n), ctypes.byref(rf)))     # size query
+        nrec = max(int(n.value), 1)
+        buf = np.zeros((nrec, rf.value), dtype=np.float32)
+        check(self._lib.admm_hip_lasso_plan_state_read(self._h, buf.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), nrec, ctypes.byref(n), ctypes.byref(rf)))
+        return buf[:n.value]
+
+    def read_data(self, n, p_local):
+        """(X_local, Y): the standardised float32 data as the solver holds them (admm_hip_lasso_plan_data_read)."""
+        X = np.zeros((n, p_local), dtype=np.float32, order="F")
+        Y = np.zeros(n, dtype=np.float32)
+        check(self._lib.admm_hip_lasso_plan_data_read(self._h, X.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), n, Y.ctypes.data_as(ctypes.POINTER(ctypes.c_float))))
+        return X, Y
+
     def close(self):
         if self._h:
             check(self._lib.admm_hip_lasso_plan_destroy(self._h))
             self._h = None
 
 
-for _name in ("run", "enable_trace", "read_trace", "close"):
+for _name in ("run", "enable_trace", "read_trace", "close", "enable_state", "read_state", "read_data"):
     setattr(DistColsPlan, _name, getattr(DistLassoPlan, _name))

@@ -147,8 +147,16 @@ def main():
         lo, hi = adist.col_partition(p, nranks, rank)
         plan = adist.DistColsPlan(np.asfortranarray(x[:, lo:hi]), y, p, lo, lambda_min_ratio=0.01, **kw)
         plan.enable_trace(1 << 16)
+        dump = os.environ.get("ADMM_TEST_WIDECOLS_STATE") == "1"       # the iterate dump of this rank (x of its columns | A x | z | y) + its standardised data
+        if dump:
+            plan.enable_state(1 << 13)
         fit = plan.run()
         trace = plan.read_trace()
+        if dump:
+            st = plan.read_state()
+            Xl, Yl = plan.read_data(n, hi - lo)
+            np.savez(os.path.join(workdir, f"state.{rank}.npz"), state=st, X=Xl, Y=Yl, lo=lo, hi=hi, persist_iter=int(fit.stats.get("persist_iter", 0)),
+                     eig_est=float(fit.stats["eig_est"]))
         plan.close()
         assert fit.stats["branch"] == 1
         one = adist.lasso_dist_cols(np.asfortranarray(x[:, lo:hi]), y, p, lo, lambda_min_ratio=0.01, **kw)       # the one-shot entry point

@@ -35,7 +35,12 @@ def _run_ranks(backend, case, nranks=2, timeout=300, extra_env=None):
                     pr.kill()
         for r, pr in enumerate(procs):
             assert pr.returncode == 0, f"rank {r} failed:\n{outs[r][-3000:]}"
-        return [dict(np.load(os.path.join(wd, f"result.{r}.npz"))) for r in range(nranks)]
+        res = [dict(np.load(os.path.join(wd, f"result.{r}.npz"))) for r in range(nranks)]
+        for r in range(nranks):                                      # the ranks' iterate dumps, where a case wrote them
+            sp = os.path.join(wd, f"state.{r}.npz")
+            if os.path.exists(sp):
+                res[r]["dump"] = dict(np.load(sp))
+        return res
 
 
 @pytest.mark.parametrize("backend", ["shm", "peer"])
@@ -143,6 +148,39 @@ def test_two_process_column_sharded_wide_solver(backend, case):
     h = nl // 2
     for j in range(h):
         assert relerr(res[0]["beta"][:, j], one.beta_dense[:, j]) < 1e-4, j
+
+
+@pytest.mark.parametrize("case", ["widecols", "widecols_enet"])
+def test_two_process_column_sharded_stretch_is_stepwise_clean(case):
+    """Round 6: the column-sharded wide solver runs its active-set iterations inside the persistent stretch, A x summed over the ranks
+    INSIDE the launch (wide_rows_persist_kernel<true>, AUX region of the PEER exchange).  Held by the stepwise instrument as the
+    single-process stretch is: both ranks dump their iterates (x of their own columns | A x | z | y) and their standardised column
+    blocks; put together they are one dump of the whole problem, and every iteration in it must be the reference's iteration applied to
+    the library's own previous iterates -- zero pattern, z, y bit for bit, the two mat-vecs within the float dot-product yardstick,
+    thresholds / residuals / decisions / rho adaptation exact (oracle/stepcheck.py check_wide).  And the replicated vectors must be
+    bit-identical on the two ranks in every record."""
+    from oracle import entry, stepcheck
+    sys.path.insert(0, HERE)
+    from dist_worker import problem
+    res = _run_ranks("peer", case, extra_env=dict(ADMM_TEST_WIDECOLS_STATE="1"))
+    x, y, _, kw = problem(case)
+    n, p = x.shape
+    d0, d1 = res[0]["dump"], res[1]["dump"]
+    assert int(d0["persist_iter"]) > 0 and int(d0["persist_iter"]) == int(d1["persist_iter"]), "the stretch ran, on both ranks alike"
+    p0 = int(d0["hi"]) - int(d0["lo"])
+    s0, s1 = d0["state"], d1["state"]
+    assert s0.shape[0] == s1.shape[0] and s0.shape[1] == p0 + 3 * n
+    assert np.array_equal(s0[:, p0:], s1[:, s1.shape[1] - 3 * n:]), "A x, z, y replicated bit for bit in every record"
+    state = np.concatenate([s0[:, :p0], s1[:, :s1.shape[1] - 3 * n], s0[:, p0:]], axis=1)
+    X = np.asfortranarray(np.concatenate([d0["X"], d1["X"]], axis=1))
+    assert np.array_equal(d0["Y"], d1["Y"])
+    assert np.array_equal(res[0]["trace"], res[1]["trace"])
+    prob = dict(x=x, y=y, lam=None, nlambda=kw["nlambda"], lmin_ratio=0.01, standardize=True, intercept=True, opts=entry.LASSO_OPTS, alpha=kw.get("alpha"))
+    rep = stepcheck.check_wide(prob, res[0]["trace"], state, float(d0["eig_est"]), X=X, Y=d0["Y"], label=f"2-process {case}")
+    stepcheck.assert_stepwise_wide(rep, label=f"2-process {case}")
+    print(f"[stepwise 2-process {case}] {rep['decisions_checked']} iterations replayed ({int(d0['persist_iter'])} of them inside the stretch; zero / regular / active-set "
+          f"{rep['kinds'][0]} / {rep['kinds'][1]} / {rep['kinds'][2]}): z, y, zero pattern bit-exact; X't within {rep['xt_ratio_max']:.2f}, A x within {rep['ax_ratio_max']:.2f} "
+          f"float-dot yardsticks")
 
 
 @pytest.mark.parametrize("backend", ["shm", "peer"])
