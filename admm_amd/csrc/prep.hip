@@ -30,7 +30,8 @@ struct Roctx {
     int (*push)(const char*) = nullptr;
     int (*pop)() = nullptr;
     Roctx() {
-        for (const char* n : {"libroctx64.so.4", "libroctx64.so", "/opt/rocm/lib/libroctx64.so"}) {
+        // rocprofv3 --marker-trace listens to the rocprofiler-sdk's roctx library; the roctracer one is the fall-back for older tools
+        for (const char* n : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "/opt/rocm/lib/librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
             if (void* h = dlopen(n, RTLD_NOW | RTLD_GLOBAL)) {
                 push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
                 pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
