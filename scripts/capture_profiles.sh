@@ -23,3 +23,25 @@ for c in c3 c4 c5lad c5bp c5parbp dantzig; do
 done
 rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/trace_c3 $OUT/trace_c4 $OUT/trace_c5lad $OUT/trace_c5bp $OUT/trace_c5parbp $OUT/trace_dantzig      # the databases are large; the summaries are what is kept
 ls -la $OUT
+# round 6: the column-sharded wide solver as one rank over PEER (persistent stretch with the exchange inside the launch), and the roctx ranges
+rocprofv3 --kernel-trace --stats -d $OUT/trace_wc -o k -- python bench.py --child widecols:peer:$OUT/widecols_one_rank.json --seed 123 > $OUT/trace_wc.log 2>&1
+python scripts/rocpd_summary.py $OUT/trace_wc/k_results.db $OUT/widecols_one_rank_kernel_stats.md 10
+rocprofv3 --marker-trace --kernel-trace --output-format csv -d $OUT/markers -o m -- python __graft_entry__.py smoke > $OUT/markers.log 2>&1
+f=$(find $OUT/markers -name '*marker*trace*.csv' | head -1)
+if [ -n "$f" ]; then python - "$f" > $OUT/roctx_ranges.md <<'PY'
+import csv, sys, collections
+rows = list(csv.DictReader(open(sys.argv[1])))
+agg = collections.OrderedDict()
+for r in rows:
+    name = r.get("Function") or r.get("Name") or r.get("Message") or str(r)
+    try:
+        d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    except Exception:
+        d = 0.0
+    a = agg.setdefault(name, [0, 0.0]); a[0] += 1; a[1] += d
+print("| roctx range | count | total us |\n|---|---|---|")
+for k, (c, t) in agg.items():
+    print(f"| `{k}` | {c} | {t:.1f} |")
+PY
+fi
+rm -rf $OUT/trace_wc $OUT/markers
