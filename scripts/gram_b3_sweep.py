@@ -16,8 +16,6 @@ b = torch.zeros(p, dtype=torch.float64, device=dev); b[:1000] = torch.rand(1000,
 y = b @ xt + torch.randn(n, generator=g, device=dev, dtype=torch.float64)
 torch.cuda.synchronize()
 variants = [("fp32", {"ADMM_HIP_GRAM_SPLIT": "0"})] + [(f"{m} ktiles={k}", {"ADMM_HIP_GRAM_SPLIT": m, "ADMM_HIP_GRAM_B3_KTILES": str(k)}) for m in ("bf16x3", "f16x2") for k in sys.argv[1:] or ["0", "516"]]
-# round 6: the fp16 form with one (BK = 16) or two (BK = 32, default) matrix-core K steps per barrier, K tiles per launch
-variants += [(f"f16x2 BK={bk} ktiles={k}", {"ADMM_HIP_GRAM_SPLIT": "f16x2", "ADMM_HIP_GRAM_B3_BK": bk, "ADMM_HIP_GRAM_B3_KTILES": str(k)}) for bk in ("16", "32") for k in ("516", "1032", "264")]
 for name, env in variants:
     admm_amd.options.reset()
     admm_amd.options.set(**{k.replace("ADMM_HIP_", ""): v for k, v in env.items()})
