@@ -9,8 +9,8 @@ share the device there) and fail across xGMI.  Rules checked on the sources:
   2. every __global__ kernel that takes a PeerExchange / PeerArgs (the producers and consumers the `_dist` entry points launch over PEER)
      contains no agent- or workgroup-scope ATOMIC in its body and calls no device helper that contains one -- except the three
      exchange-layer helpers whose agent-scope objects rule 1 has vetted;
-  3. the persistent single-device protocols (wide_rows_persist_kernel, tall_fused_kernel), which DO use agent scope by design, take no
-     PeerExchange and are never enqueued by a column- / row-sharded plan (their launch sites are guarded by `!cshard` / single-process flags)."""
+  3. the persistent stretch (wide_rows_persist_kernel), which DOES use agent scope by design for its hand-overs inside one device, touches
+     exchange memory (round 6: the AUX region, in its column-sharded instantiation) through the system-scope helpers only."""
 import os
 import re
 
@@ -80,11 +80,31 @@ def test_kernels_of_the_sharded_solvers_use_no_agent_scope_atomics():
     assert {"par_pack_kernel", "par_z_kernel", "wide_tail_kernel", "wide_ax_push_kernel", "tall_tail_kernel", "peer_push_kernel", "peer_sum_kernel"} <= names, names
 
 
-def test_single_device_spin_protocols_are_never_reached_by_a_sharded_plan():
+def test_the_persistent_stretch_touches_exchange_memory_at_system_scope_only():
+    """wide_rows_persist_kernel hands its results from workgroup to workgroup of ONE device through agent-scope atomics by design (ps.*:
+    flags, partial dots, norm shares -- all device-local allocations of the plan).  Round 6: its column-sharded instantiation also writes
+    and reads the AUX region of the PEER exchange buffers (other devices' memory).  Checked on the source: every statement of the kernel
+    that names AUX memory (aux_slot / aux_flag / ax_.remote / ax_.local) goes through the system-scope helpers of peer_device.h
+    (peer_store_*, peer_load_*, aux_wait) and carries no agent- or workgroup-scope atomic; the agent-scope atomics that mention the
+    exchange descriptor at all are on its two device-local words (the sequence number `ax_.seq`, the error word); those helpers are
+    system scope themselves; and the host enqueues the sharded instantiation only over the PEER back-end."""
     wide = _read("lasso_wide.hip")
     _, params, body = next(f for f in _functions(wide, "__global__") if f[0] == "wide_rows_persist_kernel")
-    assert "PeerExchange" not in params and "__HIP_MEMORY_SCOPE_AGENT" in body        # single-device by design ...
-    assert re.search(r"persist_rows\s*=\s*!cshard\s*&&", wide)                          # ... and switched off for the column-sharded plan
-    tall = _read("lasso_tall.hip")
-    _, params, _ = next(f for f in _functions(tall, "__global__") if f[0] == "tall_fused_kernel")
-    assert "PeerExchange" not in params
+    assert "PeerAux" in params and "PeerExchange" not in params and "__HIP_MEMORY_SCOPE_AGENT" in body
+    stmts = [st for st in body.split(";") if re.search(r"aux_slot|aux_flag|ax_\.remote|ax_\.local", st)]
+    assert len(stmts) >= 5, len(stmts)
+    for st in stmts:
+        assert not re.search(r"__HIP_MEMORY_SCOPE_(AGENT|WORKGROUP)", st), st.strip()[:200]
+        assert re.search(r"peer_store_f32|peer_store_u64|peer_load_f32|peer_load_u64", st), st.strip()[:200]
+    for st in body.split(";"):
+        if "ax_." in st and re.search(r"__hip_atomic[^;]*__HIP_MEMORY_SCOPE_(AGENT|WORKGROUP)", st, flags=re.S):
+            assert "ax_.seq" in st, st.strip()[:200]
+    pd = _read("peer_device.h")
+    for helper in ("peer_load_f32", "peer_load_u64"):
+        b = next(b for n, _, b in _functions(pd, "__device__") if n == helper)
+        assert "__HIP_MEMORY_SCOPE_SYSTEM" in b and "SCOPE_AGENT" not in b, helper
+    b = next(b for n, _, b in _functions(pd, "__device__") if n == "aux_wait")
+    loads = re.findall(r"__hip_atomic_load\([^;]*\)", b)
+    assert loads and all("__HIP_MEMORY_SCOPE_SYSTEM" in ld for ld in loads)
+    assert re.search(r"persist_rows\s*=\s*\(!cshard\s*\|\|\s*\(peer_fused", wide)          # sharded: PEER only (RCCL / SHM cannot exchange inside a launch)
+    assert "wide_rows_persist_kernel<true>" in wide and "comm_peer_aux()" in wide
