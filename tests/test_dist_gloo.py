@@ -619,3 +619,92 @@ def test_two_rank_gram_reduce_scatter_hands_every_rank_its_block_columns(tmp_pat
     v = np.random.default_rng(5).standard_normal(p)
     assert np.array_equal(r[0]["w"], r[1]["w"])
     assert np.abs(r[0]["w"] - G @ v.astype(F)).max() < 1e-4 * np.abs(G @ v).max()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The exchange INSIDE a launch (round 6: the column-sharded wide solver's persistent stretch; peer_device.h "AUX region",
+# lasso_wide.hip wide_rows_persist_kernel<true>): world_size-2 model of the PROTOCOL -- a sequence number kept by every rank and
+# advanced identically, two parities of slots, one flag per (source rank, row group), a once-per-launch agreement word, row groups
+# that run concurrently and are only coupled by the rank's own hand-overs.  What the model checks is the claim the kernel's comment
+# makes: a rank that runs ahead can never overwrite a slot a slower rank (or a slower row group's reader) has yet to read, whatever
+# the timing -- every sum a reader forms is the sum of the values that belong to ITS exchange number.
+def _aux_model_rank(rank, world, port, data, flags, nlaunch, seed, out):
+    import threading
+    import time
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    G, W = 3, 4                                             # row groups, floats per group
+    rng = np.random.default_rng(seed + 17 * rank)          # the TIMING differs per rank; the values are functions of (exchange, group, rank)
+    seq = 0                                                 # the device word: exchanges made so far (replicated)
+    errors = []
+
+    def value(e, r, src):
+        return float(1000 * e + 10 * r + src)
+
+    def push(e, r, payload):                                # this rank's slot of EVERY rank's buffer, then the flag there
+        for dst in range(world):
+            data[dst, e & 1, rank, r] = payload
+        for dst in range(world):
+            flags[dst, e & 1, rank, r] = e
+
+    def wait_and_sum(e, r):
+        t0 = time.time()
+        while any(int(flags[rank, e & 1, src, r]) < e for src in range(world)):
+            if time.time() - t0 > 20:
+                raise RuntimeError(f"rank {rank}: exchange {e} group {r} never arrived")
+            time.sleep(0)
+        return sum(data[rank, e & 1, src, r].clone() for src in range(world))          # rank order
+
+    for launch in range(nlaunch):
+        # ---- agreement: every rank's count (group index G of the flag array is the agreement word's flag)
+        e = seq + 1
+        count = int((launch * 7 + rank * 3) % 5)             # rank-dependent; the verdict is a function of ALL counts
+        push(e, G, torch.full((W,), float(count)))
+        s = wait_and_sum(e, G)
+        total = int(round(float(s[0])))
+        if total == 0:                                       # nobody has anything: all ranks leave, one exchange made
+            seq += 1
+            continue
+        niter = 1 + total % 4                                # replicated: the "decisions" end the stretch after the same iteration everywhere
+        bar = threading.Barrier(G)                           # the rank's own hand-over couples its row groups once per iteration
+
+        def group(r):
+            try:
+                g_rng = np.random.default_rng(seed + 1000 * launch + 31 * rank + r)
+                for k in range(niter):
+                    ek = seq + 2 + k
+                    time.sleep(float(g_rng.uniform(0, 2e-3)) if g_rng.random() < 0.5 else 0)
+                    push(ek, r, torch.full((W,), value(ek, r, rank)))
+                    got = wait_and_sum(ek, r)
+                    want = sum(value(ek, r, src) for src in range(world))
+                    if not torch.all(got == want):
+                        errors.append((launch, k, r, got.tolist(), want))
+                    time.sleep(float(g_rng.uniform(0, 2e-3)) if g_rng.random() < 0.3 else 0)
+                    bar.wait()                               # (hand-over B: every row group of the rank has read before any starts the next iteration)
+            except Exception as ex:                         # noqa: BLE001
+                errors.append(("exception", repr(ex)))
+                bar.abort()
+
+        th = [threading.Thread(target=group, args=(r,)) for r in range(G)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        seq += 1 + niter
+        if rng.random() < 0.5:
+            time.sleep(float(rng.uniform(0, 3e-3)))          # the ranks' hosts enqueue at different paces
+    torch.save({"errors": errors, "seq": seq}, out + f".{rank}.pt")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_in_launch_exchange_protocol_never_reads_another_exchanges_slot(tmp_path):
+    world, G, W = 2, 3, 4
+    data = torch.zeros((world, 2, world, G + 1, W), dtype=torch.float64).share_memory_()          # [owner][parity][source rank][group | agreement][floats]
+    flags = torch.zeros((world, 2, world, G + 1), dtype=torch.int64).share_memory_()
+    out = str(tmp_path / "aux")
+    mp.spawn(_aux_model_rank, args=(world, _free_port(), data, flags, 60, 5, out), nprocs=world, join=True)
+    r = [torch.load(out + f".{k}.pt") for k in range(world)]
+    assert r[0]["errors"] == [] and r[1]["errors"] == [], (r[0]["errors"][:3], r[1]["errors"][:3])
+    assert r[0]["seq"] == r[1]["seq"] > 60                    # both ranks advanced the sequence identically
