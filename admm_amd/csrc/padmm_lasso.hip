@@ -841,7 +841,9 @@ struct ParPlan final : LassoPlan {
         // ---- batched launches of the workers' products (ADMM_HIP_PAR_BATCH=0: one launch per worker and product, as before)
         {
             const char* e = option("PAR_BATCH");
-            bool same = Kl > 1 && !(e && std::string(e) == "0");
+            // (one-pass workers: also for ONE block per process -- what K = N GPUs runs -- so that the residual of the small solve rides in the
+            // first slice of the streaming launch there too instead of in a launch of its own)
+            bool same = (Kl > 1 || onepass) && !(e && std::string(e) == "0");
             for (int k = 1; k < Kl && same; ++k) same = W[k].wide == W[0].wide && W[k].gM.pl.nt == W[0].gM.pl.nt;
             if (same) {
                 const int* skip = done.get();
