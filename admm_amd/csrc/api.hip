@@ -1086,7 +1086,7 @@ int admm_hip_lasso_plan_system_read(admm_hip_plan* plan, float* out, long long l
 }
 
 const char* admm_hip_last_error(void) { return last_error_ref().c_str(); }
-const char* admm_hip_version(void) { return "admm_hip 0.2 (gfx950)"; }
+const char* admm_hip_version(void) { return "admm_hip 0.3 (gfx950)"; }
 int admm_hip_trim_memory(void) {
     admm::pool_trim();
     return ADMM_OK;
