@@ -72,6 +72,89 @@ __device__ __forceinline__ halfx8 gb_hfrag(const uint4& u) {
     return f;
 }
 
+// Epilogue (round 6): the output tile leaves through LDS in whole column pieces.  In the matrix-core register layout a lane holds 16
+// values of ONE column at rows 8 apart and the 32 lanes of a half-wave hold 32 different columns: stored directly, every instruction
+// touched 64 different cache lines with 4 bytes each, and the accumulation over the K ranges read them back the same way -- 0.38 of a
+// launch's 2.56 ms at C2 (scripts/gram_probe.hip runs the same loop without an epilogue).  Now: two passes of 64 columns; the two waves
+// that own them write their accumulators (scaled by the exact powers of two of the fp16 form) into a 64 x 128 float tile (float4
+// index XOR column: the 32 columns of an instruction spread over 8 banks), all 256 threads then add the earlier K ranges and store
+// float4 pieces down the columns (512 contiguous bytes per column), and -- last launch of a lower-triangle product only -- the final
+// values go back into the tile and are read across for the mirrored store (contiguous along the other index).  Same value per
+// element, bit for bit (scale, then add the earlier ranges, as before).
+__device__ __forceinline__ void gb_store_tile(const GramB3& g, const floatx16 (&acc)[2][2], float* T, int I0, int J0, int wi, int wj, int tid) {
+    const int lane = tid & 63;
+    const bool diag = g.lower && I0 == J0;
+    for (int h = 0; h < 2; ++h) {
+        __syncthreads();                                     // the tile is free: K loop finished / previous half consumed
+        if (wj == 64 * h) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int c = b * 32 + (lane & 31);
+                    const int col = J0 + 64 * h + c;
+                    const float cs = (g.rs != nullptr && col < g.N) ? g.rs[g.joff + col] : 1.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rl = wi + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        const int row = I0 + rl;
+                        float v = acc[a][b][r];
+                        if (g.rs != nullptr && row < g.M && col < g.N) v *= g.rs[g.ioff + row] * cs;          // powers of two: exact
+                        T[c * 128 + ((((rl >> 2) ^ (c & 31)) << 2) | (rl & 3))] = v;
+                    }
+                }
+        }
+        __syncthreads();
+        const bool fin = g.lower && g.mirror;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int piece = it * GB_THREADS + tid;
+            const int c = piece >> 5, q = piece & 31;
+            const int col = J0 + 64 * h + c, row0 = I0 + 4 * q;
+            if (col >= g.N || row0 >= g.M) continue;
+            float* tp = T + c * 128 + ((q ^ (c & 31)) << 2);
+            float4 v = *reinterpret_cast<const float4*>(tp);
+            float* cp = g.C + (size_t)col * g.ldc + row0;
+            if (row0 + 3 < g.M && (!diag || row0 >= col)) {       // a whole piece on / below the diagonal (or no diagonal in this tile)
+                if (g.kt0 > 0) { const float4 o = *reinterpret_cast<const float4*>(cp); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                *reinterpret_cast<float4*>(cp) = v;
+            } else {
+                float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int row = row0 + k;
+                    if (row >= g.M || (diag && row < col)) continue;        // lower mode: the upper triangle is ALWAYS the mirror of the lower one
+                    if (g.kt0 > 0) e[k] += cp[k];
+                    cp[k] = e[k];
+                }
+                v = make_float4(e[0], e[1], e[2], e[3]);
+            }
+            if (fin) *reinterpret_cast<float4*>(tp) = v;          // the final values, for the mirrored store below
+        }
+        if (fin) {
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int piece = it * GB_THREADS + tid;
+                const int rl = piece >> 4, c4 = piece & 15;           // row of the tile, group of four columns of this half
+                const int row = I0 + rl, col0 = J0 + 64 * h + 4 * c4;
+                if (row >= g.M || col0 >= g.N) continue;
+                float e[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const int c = 4 * c4 + k; e[k] = T[c * 128 + ((((rl >> 2) ^ (c & 31)) << 2) | (rl & 3))]; }
+                float* mp = g.C + (size_t)row * g.ldc + col0;
+                if (col0 + 3 < g.N && (!diag || row > col0 + 3)) {
+                    *reinterpret_cast<float4*>(mp) = make_float4(e[0], e[1], e[2], e[3]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (col0 + k < g.N && (!diag || row > col0 + k)) mp[k] = e[k];
+                }
+            }
+        }
+    }
+}
+
 template <int NPL>      // 3: bf16 planes, six products; 2: fp16 planes, three products
 __global__ void __launch_bounds__(GB_THREADS, 2)
 gram_split_kernel(GramB3 g) {
@@ -178,28 +261,177 @@ gram_split_kernel(GramB3 g) {
 #undef GB_GLOAD
 #undef GB_LSTORE
     // C/D layout of the 32x32 instruction: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-    const bool offdiag = I0 != J0;
+    gb_store_tile(g, acc, reinterpret_cast<float*>(&lds[0][0][0][0][0]), I0, J0, wi, wj, tid);
+}
+
+// Round 6: 256 x 256 macro-tiles for the lower-triangle product of the fp16 form.  scripts/gram_probe.hip takes the 128 x 128 loop apart:
+// matrix instructions alone 1.11 ms per C2 launch (0.92 of the fp16 peak), + fragment reads 1.14, + LDS stores and the barrier 1.37,
+// + the operand requests 1.83 even when every one of them hits the L2, 2.19 with the real traffic -- a 128 x 128 tile pulls 16 KB
+// through the L2 -> L1 path per 1.6 Mflop (96 flop per byte): at the matrix rate that is ~27 TB/s out of the L2s, which they do not
+// deliver.  A 256 x 256 tile stages 512 operand rows for four times the products (192 flop per byte): the same loop runs at 0.71 of
+// the peak in whole rounds.  8 waves as 4 x 2, a wave owns 64 rows x 128 columns (2 x 4 matrix-core tiles, 24 instructions per K
+// step, 128 accumulator registers), one workgroup per CU, 64 KB of LDS; same ring of three register sets, same products in the same
+// K order per output element as gram_split_kernel<2> -- bit-identical, so the block-row mode of the pipelined host-input setup keeps
+// the 128 x 128 kernel (tests/test_gpu_gram.py holds the two setups bit for bit).  820 tiles on 256 workgroups are 3.2 rounds run
+// as 4: 1.82 ms per launch against 2.19 (the tail is what is left on the table).
+constexpr int GB2_BM = 256;
+constexpr int GB2_THREADS = 512;
+
+__device__ __forceinline__ void gb_store_tile256(const GramB3& g, const floatx16 (&acc)[2][4], float* T, int I0, int J0, int wi, int wj, int tid) {
+    const int lane = tid & 63;
+    const bool diag = g.lower && I0 == J0;
+    const bool fin = g.lower && g.mirror;
+    for (int h = 0; h < 4; ++h) {                               // four passes of 64 columns through a 64 x 256 float tile (64 KB)
+        __syncthreads();
+        if (wj == 128 * (h >> 1)) {
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int col = J0 + wj + b * 32 + (lane & 31);
+                for (int bb = 0; bb < 2; ++bb) {
+                    const int b = 2 * (h & 1) + bb;
+                    const int c = bb * 32 + (lane & 31);
+                    const int col = J0 + 64 * h + c;
+                    const float cs = (g.rs != nullptr && col < g.N) ? g.rs[g.joff + col] : 1.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = I0 + wi + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row < g.M && col < g.N) {
-                    // lower mode: the upper triangle is ALWAYS the mirror of the lower one, inside the diagonal tiles too -- the pairs
-                    // (h l', l h') / (h m', m h') enter the accumulator in an order that is not symmetric in (i, j), so (i, j) and (j, i)
-                    // computed directly would differ in the last bit; the block-row mode is followed by symmetrize_from_lower (prep.hip)
-                    if (g.lower && !offdiag && row < col) continue;
-                    float v = acc[a][b][r];
-                    if (g.rs != nullptr) v *= g.rs[g.ioff + row] * g.rs[g.joff + col];          // powers of two: exact
-                    if (g.kt0 > 0) v += g.C[(size_t)col * g.ldc + row];          // the earlier K ranges of this product (fixed order: deterministic)
-                    g.C[(size_t)col * g.ldc + row] = v;
-                    if (g.lower && g.mirror && row != col) g.C[(size_t)row * g.ldc + col] = v;
+                    for (int r = 0; r < 16; ++r) {
+                        const int rl = wi + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        const int row = I0 + rl;
+                        // (b is a compile-time index after unrolling: the accumulators stay in registers)
+                        float v = (h & 1) ? acc[a][2 + bb][r] : acc[a][bb][r];
+                        (void)b;
+                        if (g.rs != nullptr && row < g.M && col < g.N) v *= g.rs[g.ioff + row] * cs;
+                        T[c * 256 + ((((rl >> 2) ^ (c & 31)) << 2) | (rl & 3))] = v;
+                    }
+                }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int piece = it * GB2_THREADS + tid;
+            const int c = piece >> 6, q = piece & 63;
+            const int col = J0 + 64 * h + c, row0 = I0 + 4 * q;
+            if (col >= g.N || row0 >= g.M) continue;
+            float* tp = T + c * 256 + ((q ^ (c & 31)) << 2);
+            float4 v = *reinterpret_cast<const float4*>(tp);
+            float* cp = g.C + (size_t)col * g.ldc + row0;
+            if (row0 + 3 < g.M && (!diag || row0 >= col)) {
+                if (g.kt0 > 0) { const float4 o = *reinterpret_cast<const float4*>(cp); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                *reinterpret_cast<float4*>(cp) = v;
+            } else {
+                float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int row = row0 + k;
+                    if (row >= g.M || (diag && row < col)) continue;
+                    if (g.kt0 > 0) e[k] += cp[k];
+                    cp[k] = e[k];
+                }
+                v = make_float4(e[0], e[1], e[2], e[3]);
+            }
+            if (fin) *reinterpret_cast<float4*>(tp) = v;
+        }
+        if (fin) {
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int piece = it * GB2_THREADS + tid;
+                const int rl = piece >> 4, c4 = piece & 15;
+                const int row = I0 + rl, col0 = J0 + 64 * h + 4 * c4;
+                if (row >= g.M || col0 >= g.N) continue;
+                float e[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const int c = 4 * c4 + k; e[k] = T[c * 256 + ((((rl >> 2) ^ (c & 31)) << 2) | (rl & 3))]; }
+                float* mp = g.C + (size_t)row * g.ldc + col0;
+                if (col0 + 3 < g.N && (!diag || row > col0 + 3)) {
+                    *reinterpret_cast<float4*>(mp) = make_float4(e[0], e[1], e[2], e[3]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (col0 + k < g.N && (!diag || row > col0 + k)) mp[k] = e[k];
                 }
             }
         }
+    }
+}
+
+__global__ void __launch_bounds__(GB2_THREADS, 1)
+gram_split256_kernel(GramB3 g) {
+    __shared__ uint4 lds[2][2][2][2][GB2_BM];             // [buffer][A/B][plane][k group][i]: 64 KB
+    const int per = (g.ntiles + 7) / 8;
+    const int w_idx = (blockIdx.x % 8) * per + blockIdx.x / 8;
+    if (w_idx >= g.ntiles) return;
+    int bi, bj;
+    if (g.tilemap != nullptr) { const int m = g.tilemap[w_idx]; bi = m >> 16; bj = m & 0xffff; }
+    else gb_tri_decode(w_idx, bi, bj);
+    const int I0 = bi * GB2_BM, J0 = bj * GB2_BM;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wi = (wid >> 1) * 64, wj = (wid & 1) * 128;
+    const int s_kg = tid >> 8, s_i = tid & 255;
+    const size_t kstep = (size_t)2 * g.ldz;
+    const size_t offA = (size_t)s_kg * g.ldz + g.ioff + I0 + s_i + (size_t)g.kt0 * kstep;
+    const size_t offB = (size_t)s_kg * g.ldz + g.joff + J0 + s_i + (size_t)g.kt0 * kstep;
+
+    floatx16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    uint4 s0a0, s0a1, s0b0, s0b1, s1a0, s1a1, s1b0, s1b1;      // a ring of TWO register sets (three spill: 128 accumulator registers per lane)
+#define G2_GLOAD(S, t)                                          \
+    {                                                           \
+        const size_t k_ = (size_t)(t) * kstep;                  \
+        S##a0 = g.Z[0][offA + k_]; S##a1 = g.Z[1][offA + k_];                                   \
+        S##b0 = g.Zb[0][offB + k_]; S##b1 = g.Zb[1][offB + k_];                                 \
+    }
+#define G2_LSTORE(S, buf)                                       \
+    {                                                           \
+        lds[buf][0][0][s_kg][s_i] = S##a0; lds[buf][0][1][s_kg][s_i] = S##a1;                   \
+        lds[buf][1][0][s_kg][s_i] = S##b0; lds[buf][1][1][s_kg][s_i] = S##b1;                   \
+    }
+    const int fk = lane >> 5, fi = lane & 31;
+    auto compute = [&](int buf) {
+        uint4 ua[2][2], ub[4][2];
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a) ua[a][pl] = lds[buf][0][pl][fk][wi + a * 32 + fi];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) ub[b][pl] = lds[buf][1][pl][fk][wj + b * 32 + fi];
+        }
+        // the kept products in the order of gram_split_kernel<2> (per output element: h l', l h', h h' of every K step)
+#define G2_TERM(PA, PB)                                                                                                                  \
+        _Pragma("unroll") for (int a = 0; a < 2; ++a) _Pragma("unroll") for (int b = 0; b < 4; ++b)                                        \
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gb_hfrag(ua[a][PA]), gb_hfrag(ub[b][PB]), acc[a][b], 0, 0, 0);
+        G2_TERM(0, 1) G2_TERM(1, 0) G2_TERM(0, 0)
+#undef G2_TERM
+    };
+    const int ntile_k = g.kt1 - g.kt0;
+#define G2_STEP(T, SLOAD, SSTORE, BUFC, BUFS)                   \
+    {                                                           \
+        G2_GLOAD(SLOAD, min((T) + 2, ntile_k - 1))              \
+        compute(BUFC);                                          \
+        G2_LSTORE(SSTORE, BUFS)                                 \
+        __syncthreads();                                        \
+    }
+    if (ntile_k > 0) {
+        // step T: request tile T + 2 into the set that held tile T (in LDS since the end of step T - 1), run tile T from LDS[T % 2], write
+        // tile T + 1 to the other buffer, one barrier (the launcher makes the K tiles of a launch a multiple of six, hence even)
+        G2_GLOAD(s0, 0)
+        G2_GLOAD(s1, min(1, ntile_k - 1))
+        G2_LSTORE(s0, 0)
+        __syncthreads();
+        for (int kt = 0; kt < ntile_k; kt += 2) {
+            G2_STEP(kt, s0, s1, 0, 1)
+            G2_STEP(kt + 1, s1, s0, 1, 0)
+        }
+    }
+#undef G2_STEP
+#undef G2_GLOAD
+#undef G2_LSTORE
+    gb_store_tile256(g, acc, reinterpret_cast<float*>(&lds[0][0][0][0][0]), I0, J0, wi, wj, tid);
 }
 
 // Split columns [0, nc) of X (rows x nc, column-major, ld ldx, rows beyond `rows` zero up to a multiple of 8) into the planes of
@@ -295,7 +527,7 @@ int gram_split_mode() {
 void GramSplit3::alloc(int order, int kdepth, hipStream_t st) {
     M = order;
     npl = gram_split_mode() == 3 ? 3 : 2;
-    ldz = round_up(order, GB_BM);
+    ldz = round_up(order, GB2_BM);                        // whole 256-row macro-tiles (the 128 x 128 kernel needs whole 128s)
     nkg = (int)(round_up(kdepth, GB_KPAD) / 8);
     planes.alloc((size_t)npl * nkg * ldz * 8);
     planes.zero(st);
@@ -314,7 +546,8 @@ void GramSplit3::split_cols(const float* X, long long ldx, int rows, int c0, int
     }
 }
 
-static void launch_gram_b3(const GramSplit3& z, int ioff, int joff, float* C, long long ldc, int M, int N, bool lower, const int* tilemap, int ntiles_listed, hipStream_t st) {
+static void launch_gram_b3(const GramSplit3& z, int ioff, int joff, float* C, long long ldc, int M, int N, bool lower, const int* tilemap, int ntiles_listed, hipStream_t st,
+                           bool big = false) {
     GramB3 g;
     const uint4* base = reinterpret_cast<const uint4*>(z.planes.get());
     const size_t pl = (size_t)z.nkg * z.ldz;
@@ -322,7 +555,8 @@ static void launch_gram_b3(const GramSplit3& z, int ioff, int joff, float* C, lo
     g.rs = z.npl == 2 ? z.rs.get() : nullptr;
     g.ldz = z.ldz; g.ioff = ioff; g.joff = joff; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = z.nkg * 8;
     g.lower = lower ? 1 : 0; g.mirror = lower ? 1 : 0;
-    g.nbi = (M + GB_BM - 1) / GB_BM; g.nbj = (N + GB_BM - 1) / GB_BM;
+    const int bm = big ? GB2_BM : GB_BM;
+    g.nbi = (M + bm - 1) / bm; g.nbj = (N + bm - 1) / bm;
     g.ntiles = lower ? g.nbi * (g.nbi + 1) / 2 : g.nbi * g.nbj;
     g.tilemap = tilemap;
     if (tilemap != nullptr && ntiles_listed >= 0) g.ntiles = ntiles_listed;
@@ -337,7 +571,9 @@ static void launch_gram_b3(const GramSplit3& z, int ioff, int joff, float* C, lo
     per_launch = (per_launch + 5) / 6 * 6;
     for (int kt = 0; kt < nkt; kt += per_launch) {
         g.kt0 = kt; g.kt1 = std::min(nkt, kt + per_launch);
-        if (z.npl == 3) hipLaunchKernelGGL((gram_split_kernel<3>), dim3((g.ntiles + 7) / 8 * 8), dim3(GB_THREADS), 0, st, g);
+        g.mirror = (lower && g.kt1 == nkt) ? 1 : 0;           // the mirrored store once, with the final values (it was written by every launch: 12 x 400 MB at C2)
+        if (big) hipLaunchKernelGGL(gram_split256_kernel, dim3((g.ntiles + 7) / 8 * 8), dim3(GB2_THREADS), 0, st, g);
+        else if (z.npl == 3) hipLaunchKernelGGL((gram_split_kernel<3>), dim3((g.ntiles + 7) / 8 * 8), dim3(GB_THREADS), 0, st, g);
         else hipLaunchKernelGGL((gram_split_kernel<2>), dim3((g.ntiles + 7) / 8 * 8), dim3(GB_THREADS), 0, st, g);
     }
 }
@@ -345,6 +581,10 @@ static void launch_gram_b3(const GramSplit3& z, int ioff, int joff, float* C, lo
 // C (both triangles, order x order) = Z Z' from the planes; tiles in the XCD-local square order of syrk_mfma.hip
 void GramSplit3::gram_lower(float* C, long long ldc, const int* tilemap, int ntiles, hipStream_t st) const {
     launch_gram_b3(*this, 0, 0, C, ldc, M, M, true, tilemap, ntiles, st);
+}
+// the same with 256 x 256 macro-tiles (fp16 form only; `tilemap` lists 256-blocks): bit-identical to gram_lower
+void GramSplit3::gram_lower256(float* C, long long ldc, const int* tilemap, int ntiles, hipStream_t st) const {
+    launch_gram_b3(*this, 0, 0, C, ldc, M, M, true, tilemap, ntiles, st, true);
 }
 // block row: C[r0 : r0 + nr, 0 : r0 + nr] = Z[r0 : r0 + nr, :] Z[0 : r0 + nr, :]'  (r0 a multiple of 128)
 void GramSplit3::gram_rows(int r0, int nr, float* C, long long ldc, hipStream_t st) const {

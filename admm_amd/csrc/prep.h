@@ -51,11 +51,12 @@ struct GramSplit3 {
     int npl = 2;                        // planes: 2 = fp16 split, 3 = bf16 split
     DevBuf<float> rs;                   // fp16 split: [2][ldz] 2^e_i and 2^-e_i per output index
     DevBuf<unsigned short> planes;      // [npl][nkg][ldz][8] 16-bit values
-    long long ldz = 0;                  // entries (of 8 bf16) per k group: order rounded up to 128
+    long long ldz = 0;                  // entries (of 8 bf16) per k group: order rounded up to 256
     int nkg = 0, M = 0;                 // k groups of 8 (K rounded up to 16); order
     void alloc(int order, int kdepth, hipStream_t st);
     void split_cols(const float* X, long long ldx, int rows, int c0, int nc, hipStream_t st);      // columns [c0, c0 + nc) of X (rows x nc at X)
     void gram_lower(float* C, long long ldc, const int* tilemap, int ntiles, hipStream_t st) const;
+    void gram_lower256(float* C, long long ldc, const int* tilemap, int ntiles, hipStream_t st) const;      // 256 x 256 macro-tiles (npl == 2), bit-identical
     void gram_rows(int r0, int nr, float* C, long long ldc, hipStream_t st) const;
 };
 int gram_split_mode();                  // 2 (default) / 3 / 0 = the exact-fp32 matrix-core kernel (syrk_mfma.hip) as before: ADMM_HIP_GRAM_SPLIT=f16x2 | bf16x3 | 0

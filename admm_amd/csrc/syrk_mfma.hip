@@ -464,8 +464,17 @@ void gram_mfma_f32(const float* A, long long lda, int rows, int cols, bool atA, 
         GramSplit3 z3;
         z3.alloc(M, Kd, st);
         z3.split_cols(A, lda, rows, 0, cols, st);
-        DevBuf<int> tmap = make_square_tilemap(nb, st);
-        z3.gram_lower(C, ldc, tmap.get(), ntiles, st);
+        // fp16 form: 256 x 256 macro-tiles (round 6; option GRAM_B3_TILE=128 keeps the 128 x 128 tiles: the A/B, bit-identical)
+        bool big = z3.npl == 2;
+        if (const char* e = option("GRAM_B3_TILE")) big = big && std::atoi(e) != 128;
+        if (big) {
+            const int nb2 = (M + 255) / 256;
+            DevBuf<int> tmap = make_square_tilemap(nb2, st);
+            z3.gram_lower256(C, ldc, tmap.get(), nb2 * (nb2 + 1) / 2, st);
+        } else {
+            DevBuf<int> tmap = make_square_tilemap(nb, st);
+            z3.gram_lower(C, ldc, tmap.get(), ntiles, st);      // (round 6 A/B: the plain row-major triangle order 35.8 against 34.7 ms)
+        }
         ADMM_HIP_CHECK(hipGetLastError());
         comm_stream_sync(st);
         return;
