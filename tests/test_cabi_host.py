@@ -207,3 +207,14 @@ def test_options_are_per_thread_and_the_typed_struct_maps_onto_the_named_ones():
     assert b"gram_split" in lib.admm_hip_last_error()
     _lib.check(lib.admm_hip_options_set(None))
     assert lib.admm_hip_option_get(b"INVERSE") is None
+
+
+def test_bench_refuses_a_world_size_that_disagrees_with_gpus_without_a_gpu():
+    """`python bench.py --gpus 8` under WORLD_SIZE=1 must refuse before it touches a device (round-5 review: it ran one GPU and printed
+    n_gpus: 1); the check sits in front of every import that needs one, so it is testable here."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout), (r.returncode, r.stderr[-300:])
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
