@@ -529,6 +529,8 @@ constexpr int kGsRows = 8;
 // workgroup, the lists of all blocks flattened over its threads (at most kGsCapMax entries: four per thread): three dependent
 // round trips (list lengths, list entries, their slots in U).
 constexpr int kGsMaxBlocks = 256;
+static_assert(kGsCapMax == 4 * kSbpThreads, "the merge launch flattens the blocks' lists over its threads, four entries per thread (ADVICE r5)");
+static_assert(kGsMaxBlocks <= kSbpThreads, "one thread per block in the merge launch's prefix scan");
 __global__ void __launch_bounds__(kSbpThreads)
 sbp_gs_merge_kernel(SbpParams q, int par, int g, int may_reset) {
     __shared__ int pre[kGsMaxBlocks + 1], c0s[kGsMaxBlocks];
