@@ -23,9 +23,8 @@ int main() {
     const long long ld = P;
     DevBuf<float> A((size_t)ld * 1024), C((size_t)ld * P);
     A.zero(st); C.zero(st);
-    for (int epi = 1; epi >= 0; --epi)
+    const int epi = 1;      // (round 6: the direct-store epilogue's A/B knob is gone; profiles/r04_gemm_shortk.md holds that comparison)
     for (int M : {1280, 2560, 5120, 7680, 9984}) {
-        setenv("ADMM_HIP_GEMM_EPI", epi ? "1" : "0", 1);
         for (int lower = 1; lower >= 0; --lower) {
             const long long tiles = lower ? (long long)(M / 128) * (M / 128 + 1) / 2 : (long long)(M / 128) * (M / 128);
             for (int K : {16, 128, 256, 1024}) {
