@@ -87,7 +87,7 @@ typedef struct admm_stats {
     int branch;            /* 0 tall (Cholesky), 1 wide (linearised), 2 consensus; 6 admm_parbp (column-block sharing); 7 admm_dantzig */
     int xupdate_variant;   /* tall path: 0 = full-matrix mat-vec (4p^2 B), 1 = lower-triangle symmetric mat-vec (2p^2 B),
                               2 = the same with the tiles dealt out to the ranks + one all-reduce of 2p floats (admm_hip_lasso_dist),
-                              3 = 1 with the element-wise tail of the previous iteration inside the same launch (one launch per iteration);
+                              (3, a single-launch iteration, existed in rounds 3 - 5: measured slower, removed in round 6);
                               admm_hip_parbp: 0 = every active-set iteration streams the non-zero columns twice, 1 = active-set iterations
                               in Gram space (one |U| x |U| mat-vec each; xupdate_launches = stretches of nine that ran so, persist_iter =
                               times the column set U was rebuilt), 2 = 1 except for stretches of 100, 200, 400, ... iterations after the non-zeros
