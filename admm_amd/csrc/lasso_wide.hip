@@ -107,6 +107,10 @@ struct WideParams {
     int* done_host;                       // pinned host word, set together with *done (loop_driver.h: PinnedFlag)
     double* trace; long long trace_cap;   // optional decision records (admm_hip_lasso_plan_trace_*), or NULL
     float* state; long long state_cap;    // optional [state_cap][p + 3 n] iterates x | Ax | z | y of every iteration (admm_hip_lasso_plan_state_*), or NULL
+    // safe screening of the regular steps (wide_x_kernel, "screen"): a 2-byte copy of X and a per-column error bound, or NULL
+    const unsigned short* Xh; long long ldh;      // [p][ldh] X rounded to fp16 (non-finite roundings stored as 0), ldh a multiple of 8, rows [n, ldh) zero
+    const float* scr_s; int scr_S;                // s_j in the x-update launch's own order: column (k, w) = k * NW + w at scr_s[w * scr_S + k]
+    unsigned long long* scr_stat;                 // optional [2]: columns screened, columns that took the exact path (WIDE_SCREEN_STATS)
 #ifdef ADMM_HIP_PROBE
     long long* probe;                     // dev build only: in-kernel timestamps [4096 iterations][4 observers][8]
 #endif
@@ -446,6 +450,128 @@ wide_x_kernel(WideParams q, int par) {
         return finish(wave_sum(d0 + d1), xv);
     };
 
+    // ---- safe screening of a regular step (fused mode).  A regular step applies the prox to EVERY column, and for all but a per cent
+    // of them the outcome is "stays zero": x_j = 0 and |fl(X_j't)| / gamma below the threshold.  Which ones cannot be known without a
+    // product with every column -- but a product with a ROUNDED column is enough to prove it: with Xh = fp16(X),
+    //     |fl32(X_j't)| <= |fl32(Xh_j't)| + s_j ||t||_2 ,     s_j = ||X_j - Xh_j||_2 + gamma_n (||X_j||_2 + ||Xh_j||_2)
+    // (Cauchy-Schwarz on the rounding of the column, the standard bound gamma_n = n u / (1 - n u) on an n-term float inner product in
+    // ANY order for each of the two computed sums; s_j is formed once at setup in double and rounded UP, wide_screen_prep_kernel).  A
+    // column with x_j = 0 whose bound stays below gamma * threshold * (1 - 2^-21) is left alone -- the exact step would have stored the
+    // zero it already holds (the float division by gamma rounds by at most 2^-24, the comparison is monotone) -- and every other
+    // column (x_j != 0, bound not met, anything non-finite) takes the exact path below on the float column: the iterates are
+    // BIT-IDENTICAL to the unscreened step's, and a regular step streams 2 n p bytes instead of 4 n p.
+    constexpr int NH = (RT + 1) / 2;                                   // 16-byte pieces of a 2-byte column per lane (512 rows per wave load)
+    constexpr bool kScrPipe = NH <= 4;                                 // two rounds in flight (n <= 2048: registers to spare at two waves per SIMD)
+    constexpr int CR = 2;                                              // columns per round
+    const bool screen = RT > 0 && reg && q.Xh != nullptr;
+    double scrT = 0.0, scrG = 0.0;
+    if (RT > 0 && screen) {
+        double tsq = 0.0;
+        for (int i = lane; i < npad; i += 64) { const double v = (double)tl[i]; tsq = fma(v, v, tsq); }
+        scrT = sqrt(wave_sum(tsq)) * (1.0 + 1e-12);                    // >= ||t||_2 (every wave forms it itself: 32 LDS reads)
+        scrG = (double)q.gamma * (q.enet ? (double)thresh_r : pen_d) * (1.0 - 4.8e-7);
+    }
+    unsigned long long scr_seen = 0, scr_exact = 0;
+
+    if constexpr (RT > 0) {
+        if (screen) {
+            // a round = CR rounded columns of the wave; two rounds' requests are in flight at any time (the next round is requested
+            // before the current one is reduced), and the next group's x / bounds are requested a group ahead
+            auto scr_request = [&](unsigned long long& mask, int sc, int (&lc)[CR], long long (&jc)[CR], uint4 (&h)[CR][NH]) {
+#pragma unroll
+                for (int c = 0; c < CR; ++c) {
+                    lc[c] = -1; jc[c] = 0;
+                    if (mask) { lc[c] = __ffsll((long long)mask) - 1; mask &= mask - 1; jc[c] = (long long)(sc + lc[c]) * NW + w; }
+                    const unsigned short* hcol = q.Xh + (size_t)jc[c] * q.ldh;
+#pragma unroll
+                    for (int k = 0; k < NH; ++k) {
+                        const int r = k * 512 + lane * 8;
+                        h[c][k] = make_uint4(0u, 0u, 0u, 0u);
+                        if (lc[c] >= 0 && r < q.ldh) h[c][k] = load16_nt<uint4>(hcol + r);
+                    }
+                }
+            };
+            auto scr_consume = [&](const int (&lc)[CR], const long long (&jc)[CR], const uint4 (&h)[CR][NH], float xj, float sj) {
+                float dd[CR];
+#pragma unroll
+                for (int c = 0; c < CR; ++c) dd[c] = 0.f;
+#pragma unroll
+                for (int k = 0; k < NH; ++k) {
+                    const int r = k * 512 + lane * 8;
+                    if (r < q.ldh) {
+                        typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+                        const float4 b0 = *reinterpret_cast<const float4*>(tl + r), b1 = *reinterpret_cast<const float4*>(tl + r + 4);
+#pragma unroll
+                        for (int c = 0; c < CR; ++c) {
+                            const half8_t hv = __builtin_bit_cast(half8_t, h[c][k]);
+                            float d0 = dd[c], d1 = 0.f;
+                            d0 = fmaf((float)hv[0], b0.x, d0); d0 = fmaf((float)hv[1], b0.y, d0); d0 = fmaf((float)hv[2], b0.z, d0); d0 = fmaf((float)hv[3], b0.w, d0);
+                            d1 = fmaf((float)hv[4], b1.x, d1); d1 = fmaf((float)hv[5], b1.y, d1); d1 = fmaf((float)hv[6], b1.z, d1); d1 = fmaf((float)hv[7], b1.w, d1);
+                            dd[c] = d0 + d1;
+                        }
+                    }
+                }
+                float v8[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v8[c] = c < CR ? dd[c < CR ? c : 0] : 0.f;
+                const float tot = halving_sum8(v8, lane);              // lanes 8 c .. 8 c + 7: the wave total of column c
+#pragma unroll
+                for (int c = 0; c < CR; ++c) {
+                    if (lc[c] < 0) break;                              // uniform
+                    const float dc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tot), 8 * c));
+                    const float sc_j = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sj), lc[c]));
+                    const float xc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xj), lc[c]));
+                    const bool stays_zero = xc == 0.f && (double)fabsf(dc) + (double)sc_j * scrT <= scrG;          // (a NaN anywhere: false)
+                    if (!stays_zero) {                                 // the exact step on the float column
+                        float4 cv[NRT];
+                        col_request(jc[c], cv, false);
+                        const float xn = col_finish(xc, cv);
+                        if (lane == lc[c]) q.x[jc[c]] = xn;
+                        ++scr_exact;
+                    }
+                }
+            };
+            auto group_load = [&](int sc, float& xj, float& sj) {
+                const long long jl = (long long)(sc + lane) * NW + w;
+                xj = 0.f; sj = 0.f;
+                if ((long long)sc * NW < q.p) {
+                    xj = jl < q.p ? q.x[jl] : 0.f;
+                    sj = q.scr_s[(size_t)w * q.scr_S + sc + lane];     // the bounds of the group's 64 columns: one 256-byte line
+                }
+            };
+            float xj_n, sj_n;
+            group_load(0, xj_n, sj_n);
+            for (int sc = 0; (long long)sc * NW < q.p; sc += 64) {
+                const long long jl = (long long)(sc + lane) * NW + w;
+                const float xj = xj_n, sj = sj_n;
+                group_load(sc + 64, xj_n, sj_n);
+                if (snap && jl < q.p) bsnap[jl] = xj;
+                unsigned long long mask = __ballot(jl < q.p);
+                scr_seen += __popcll(mask);
+                int lA[CR], lB[CR];
+                long long jA[CR], jB[CR];
+                uint4 hA[CR][NH], hB[CR][NH];
+                if constexpr (kScrPipe) {
+                    scr_request(mask, sc, lA, jA, hA);
+                    for (;;) {
+                        scr_request(mask, sc, lB, jB, hB);
+                        scr_consume(lA, jA, hA, xj, sj);
+                        if (lB[0] < 0) break;
+                        scr_request(mask, sc, lA, jA, hA);
+                        scr_consume(lB, jB, hB, xj, sj);
+                        if (lA[0] < 0) break;
+                    }
+                } else {
+                    (void)lB; (void)jB; (void)hB;
+                    while (mask) {
+                        scr_request(mask, sc, lA, jA, hA);
+                        scr_consume(lA, jA, hA, xj, sj);
+                    }
+                }
+            }
+        }
+    }
+    if (!screen)
     for (int sc = 0; (long long)sc * NW < q.p; sc += 64 * 8) {
         float xs[8];
 #pragma unroll
@@ -505,6 +631,7 @@ wide_x_kernel(WideParams q, int par) {
         }
     }
     WIDE_PROBE(4);
+    if (RT > 0 && screen && q.scr_stat != nullptr && lane == 0) { atomicAdd(q.scr_stat, scr_seen); atomicAdd(q.scr_stat + 1, scr_exact); }
     if (RT > 0) {
         // combine the 4 waves of the workgroup through the (now free) t buffers, up to 8 row slices per round (one round
         // for n <= 2048), then write this workgroup's partial row
@@ -1553,6 +1680,46 @@ __global__ void wide_init_kernel(WideParams q, double rho, float lam0) {
     }
 }
 
+// Setup of the regular steps' screen (wide_x_kernel): column j of X rounded to fp16 (one wave per column) and its bound
+//   s_j >= ||X_j - Xh_j||_2 + 2 gamma_n max(||X_j||_2, ||Xh_j||_2),   gamma_n = n u / (1 - n u) <= 1.001 n 2^-24  (n <= 8192),
+// sums in double, the result rounded up to float.  A rounding that is not finite (|X_ij| > 65504) is stored as zero -- the whole
+// entry then counts as rounding error -- and a column holding a NaN / Inf gets s_j = +Inf: it always takes the exact path.
+__global__ void __launch_bounds__(256)
+wide_screen_prep_kernel(const float* __restrict__ X, long long ldx, int n, int p, unsigned short* __restrict__ Xh, long long ldh,
+                        float* __restrict__ s, int NW, int S) {
+    const int lane = threadIdx.x & 63;
+    const long long j = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= p) return;
+    const float* col = X + (size_t)j * ldx;
+    unsigned short* hc = Xh + (size_t)j * ldh;
+    double e2 = 0.0, x2 = 0.0, h2 = 0.0;
+    for (long long r = (long long)lane * 8; r < ldh; r += 512) {       // ldh <= ldx, both multiples of 8: whole 32-byte pieces
+        const float4 a0 = *reinterpret_cast<const float4*>(col + r), a1 = *reinterpret_cast<const float4*>(col + r + 4);
+        const float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+        half8_t hv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = r + e < n ? v[e] : 0.f;                    // rows [n, ldx) may hold anything
+            _Float16 hh = (_Float16)x;
+            float back = (float)hh;
+            if (!(fabsf(back) <= 65504.f)) { hh = (_Float16)0.f; back = 0.f; }
+            hv[e] = hh;
+            const double dx = (double)x, db = (double)back;
+            e2 = fma(dx - db, dx - db, e2); x2 = fma(dx, dx, x2); h2 = fma(db, db, h2);
+        }
+        *reinterpret_cast<uint4*>(hc + r) = __builtin_bit_cast(uint4, hv);
+    }
+    e2 = wave_sum(e2); x2 = wave_sum(x2); h2 = wave_sum(h2);
+    if (lane == 0) {
+        const double gn = 1.001 * (double)n * 5.9604644775390625e-8;   // gamma_n
+        const double sd = (sqrt(e2) + 2.0 * gn * sqrt(fmax(x2, h2))) * (1.0 + 1e-6);
+        float sv = __double2float_ru(sd);
+        if (!(sv < __builtin_huge_valf())) sv = __builtin_huge_valf();
+        s[(size_t)(j % NW) * S + (size_t)(j / NW)] = sv;
+    }
+}
+
 struct WidePlan final : LassoPlan {
     DeviceData<float> d;
     LassoProblem pb;
@@ -1573,6 +1740,10 @@ struct WidePlan final : LassoPlan {
     std::vector<double> lam_user;
     std::vector<float> lam_int;
     DevBuf<float> x, Ax, z, y, axpart, tbuf, beta, dlam;
+    DevBuf<unsigned short> Xh;           // the regular steps' screen: X rounded to fp16 ...
+    DevBuf<float> scr_s;                 // ... and the per-column bounds (wide_screen_prep_kernel)
+    DevBuf<unsigned long long> scr_stat;
+    bool screened = false;
     DevBuf<int> niter, done;
     DevBuf<double> P;
     DevBuf<WideCtl> ctl;
@@ -1756,8 +1927,34 @@ struct WidePlan final : LassoPlan {
         probe.alloc((size_t)4096 * 4 * 8); probe.zero(st);
         q.probe = probe.get();
 #endif
+        setup_screen();
         setup_persist_rows();
         comm_stream_sync(st);
+    }
+
+    // Safe screening of the regular steps (wide_x_kernel): worth its 2 n p bytes when X is a stream from HBM at all (beyond the
+    // Infinity Cache the regular step is bandwidth, below it launch latency).  WIDE_SCREEN = 0 never, 1 always (tests); when the
+    // copy does not fit the device the solver simply runs unscreened.
+    void setup_screen() {
+        const size_t xbytes = (size_t)d.ldx * (size_t)p * sizeof(float);
+        bool want = fuse_rt > 0 && xbytes >= ((size_t)256 << 20);
+        if (const char* e = option("WIDE_SCREEN")) want = fuse_rt > 0 && std::string(e) != "0";
+        const long long ldh = round_up(n, 8);
+        if (!want || d.ldx % 8 != 0 || ldh > d.ldx) return;
+        const int NW = nwg_x * (kWideThreads / 64);
+        const int S = (int)round_up((p + NW - 1) / NW, 64);
+        try {
+            Xh.alloc((size_t)p * (size_t)ldh);
+            scr_s.alloc((size_t)NW * (size_t)S);
+        } catch (const Error&) {
+            Xh.release(); scr_s.release();
+            return;
+        }
+        scr_s.zero(st);
+        hipLaunchKernelGGL(wide_screen_prep_kernel, dim3((unsigned)((p + 3) / 4)), dim3(256), 0, st, d.X.get(), d.ldx, n, p, Xh.get(), ldh, scr_s.get(), NW, S);
+        q.Xh = Xh.get(); q.ldh = ldh; q.scr_s = scr_s.get(); q.scr_S = S;
+        if (option("WIDE_SCREEN_STATS")) { scr_stat.alloc(2); scr_stat.zero(st); q.scr_stat = scr_stat.get(); }
+        screened = true;
     }
 
     // persistent active-set stretch (wide_rows_persist_kernel)
@@ -1851,6 +2048,13 @@ struct WidePlan final : LassoPlan {
         }, cshard ? nullptr : hflag.p);       // column-sharded: every rank must enqueue the same number of exchanges -> stream-ordered sampling of `done`
         S.t_loop = lt.wall_s; S.loop_ms_events = lt.events_ms; S.xupdate_launches = lt.launched;
         S.exchange_variant = !cshard ? 0 : (!peer_fused ? 1 : (peer_one ? 3 : 2));
+        S.xupdate_variant = screened ? 1 : 0;
+        if (q.scr_stat != nullptr) {
+            unsigned long long hs[2] = {0, 0};
+            ADMM_HIP_CHECK(hipMemcpy(hs, scr_stat.get(), sizeof(hs), hipMemcpyDeviceToHost));
+            std::fprintf(stderr, "[wide screen] %llu columns screened on regular steps, %llu took the exact path (%.3f %%)\n", hs[0], hs[1], hs[0] ? 100.0 * (double)hs[1] / (double)hs[0] : 0.0);
+            scr_stat.zero(st);
+        }
         if (persist_rows) {
             int herr = 0;
             ADMM_HIP_CHECK(hipMemcpy(&herr, rerr.get(), sizeof(int), hipMemcpyDeviceToHost));

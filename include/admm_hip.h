@@ -85,7 +85,9 @@ typedef struct admm_stats {
     double rho;            /* rho actually used (first lambda) */
     double eig_est;        /* the loose Lanczos value (lambda_max or spectral-radius estimate) */
     int branch;            /* 0 tall (Cholesky), 1 wide (linearised), 2 consensus; 6 admm_parbp (column-block sharing); 7 admm_dantzig */
-    int xupdate_variant;   /* tall path: 0 = full-matrix mat-vec (4p^2 B), 1 = lower-triangle symmetric mat-vec (2p^2 B),
+    int xupdate_variant;   /* wide path: 1 = the regular steps ran screened (2-byte copy of X + exact step on the few columns the bound does not
+                              settle: bit-identical iterates, 2np instead of 4np bytes), 0 = unscreened;
+                              tall path: 0 = full-matrix mat-vec (4p^2 B), 1 = lower-triangle symmetric mat-vec (2p^2 B),
                               2 = the same with the tiles dealt out to the ranks + one all-reduce of 2p floats (admm_hip_lasso_dist),
                               (3, a single-launch iteration, existed in rounds 3 - 5: measured slower, removed in round 6);
                               admm_hip_parbp: 0 = every active-set iteration streams the non-zero columns twice, 1 = active-set iterations
@@ -321,7 +323,9 @@ typedef struct admm_hip_options {
     int batch_iters;          /* iterations enqueued between two host polls (0: default 16) */
     int profile_stride;       /* time every k-th x-update launch with HIP events (0: off) */
     int pool_mb;              /* cache of released device blocks: -1 off, 0 default (min(16 GB, memory / 8)), > 0 megabytes */
-    int reserved[12];
+    int wide_screen;          /* wide solver, regular steps screened through a 2-byte copy of X (bit-identical iterates, half the bytes):
+                                 0 default (when X is larger than 256 MB), 1 always, 2 never */
+    int reserved[11];
 } admm_hip_options;
 ADMM_HIP_API int admm_hip_options_default(admm_hip_options* o);               /* zero-fills and sets struct_size */
 ADMM_HIP_API int admm_hip_options_set(const admm_hip_options* o);             /* NULL: back to the defaults (keeps nothing of the thread's earlier settings) */

@@ -134,3 +134,59 @@ def test_persistent_active_set_stretch(n, p, cgroups):
     assert int(a.stats["persist_iter"]) > 0.5 * int(a.stats["total_iter"]), (a.stats["persist_iter"], a.stats["total_iter"])
     for j in range(10):
         assert relerr(a.beta_dense[:, j], b.beta_dense[:, j]) < 1e-4, j
+
+
+def _wide_fit(x, y, enet, **opt):
+    from admm_amd import admm_enet, admm_lasso, options
+    with options(**opt):
+        m = admm_enet(x, y) if enet else admm_lasso(x, y)
+        m = m.penalty(nlambda=10, lambda_min_ratio=0.02, alpha=0.6) if enet else m.penalty(nlambda=10, lambda_min_ratio=0.02)
+        return traced_fit(m)
+
+
+@pytest.mark.parametrize("n,p,enet", [(300, 3000, False), (900, 5000, True), (1500, 6000, False), (2000, 9000, True), (3000, 5000, False), (5000, 5600, False), (7600, 8000, True)])
+def test_screened_regular_steps_are_bit_identical(n, p, enet):
+    """The regular steps' safe screen (wide_x_kernel: a product with the fp16-rounded column proves "stays zero" for all but a few
+    columns; every other column takes the exact float step) must not change a single bit: the same path with WIDE_SCREEN=1 and =0
+    -- coefficients, iteration counts and every record of the decision trace (residuals, thresholds, rho) identical.  All five
+    register layouts of the fused x-update (n <= 1024 / 2048 / 4096 / 6144 / 8192), lasso (double compare) and elastic net (float
+    compare).  The screened run is then also held to the oracle by the trace rule like every other variant."""
+    x, y = synth_lasso(n, p, 15, seed=211 + n)
+    on, tr_on = _wide_fit(x, y, enet, WIDE_SCREEN="1")
+    off, tr_off = _wide_fit(x, y, enet, WIDE_SCREEN="0")
+    assert on.stats["xupdate_variant"] == 1 and off.stats["xupdate_variant"] == 0 and on.stats["branch"] == 1
+    assert list(on.niter) == list(off.niter)
+    assert np.array_equal(on.beta_dense, off.beta_dense)
+    assert tr_on.shape == tr_off.shape and np.array_equal(tr_on, tr_off)
+    assert sum(on.niter) > 100
+
+
+@pytest.mark.parametrize("case", ["huge", "tiny", "mixed", "nan_free_inf_round"])
+def test_screen_with_values_fp16_cannot_hold(case):
+    """Columns whose entries overflow fp16 (|x| > 65504: stored as zero in the copy, the whole entry counted as rounding error), fall
+    into its subnormal range or underflow to zero, without standardisation: still bit-identical to the unscreened run."""
+    rng = np.random.default_rng(5)
+    n, p = 400, 3000
+    x = rng.standard_normal((n, p))
+    scale = np.ones(p)
+    if case == "huge":
+        scale[::3] = 3e5
+    elif case == "tiny":
+        scale[::2] = 1e-6
+        scale[1::4] = 3e-9
+    elif case == "mixed":
+        scale = 10.0 ** rng.uniform(-8, 6, p)
+    else:
+        x[rng.random((n, p)) < 0.01] *= 7e4                       # isolated entries beyond 65504 inside ordinary columns
+    x = x * scale
+    beta = np.zeros(p)
+    beta[rng.choice(p, 12, replace=False)] = rng.standard_normal(12) / scale[:12].mean()
+    y = x @ beta + 0.1 * rng.standard_normal(n) * np.abs(x @ beta).mean()
+    from admm_amd import admm_lasso, options
+    fits = {}
+    for scr in ("1", "0"):
+        with options(WIDE_SCREEN=scr):
+            fits[scr] = traced_fit(admm_lasso(x, y, standardize=False).penalty(nlambda=8, lambda_min_ratio=0.05).opts(maxit=400))
+    (on, tr_on), (off, tr_off) = fits["1"], fits["0"]
+    assert on.stats["xupdate_variant"] == 1
+    assert list(on.niter) == list(off.niter) and np.array_equal(on.beta_dense, off.beta_dense) and np.array_equal(tr_on, tr_off)
