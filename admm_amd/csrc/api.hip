@@ -955,7 +955,7 @@ int admm_hip_options_set(const admm_hip_options* o) {
         if (v.batch_iters > 0) num("BATCH_ITERS", v.batch_iters);
         if (v.profile_stride > 0) num("PROFILE_STRIDE", v.profile_stride);
         if (v.pool_mb) num("POOL_MB", v.pool_mb < 0 ? 0 : v.pool_mb);
-        if (v.wide_screen) { ADMM_REQUIRE(v.wide_screen == 1 || v.wide_screen == 2, "options: wide_screen"); set("WIDE_SCREEN", v.wide_screen == 1 ? "1" : "0"); }
+        if (v.screen) { ADMM_REQUIRE(v.screen == 1 || v.screen == 2, "options: screen"); set("WIDE_SCREEN", v.screen == 1 ? "1" : "0"); set("SBP_SCREEN", v.screen == 1 ? "1" : "0"); }
     });
 }
 int admm_hip_comm_unique_id(void* id_out) {

@@ -83,6 +83,9 @@ struct SbpParams {
     double eps_abs, eps_rel, rho, sqrt_nN, sqrtN, dN;
     double invN, inv_rho;                        // Gram space only (the direct launches divide, as the reference does)
     const double* A; long long lda;              // this rank's columns, n x pl column-major, rows padded with zeros to npad
+    const unsigned short* Ah; long long ldh;     // the regular iterations' screen: A rounded to fp16 ([pl][ldh], ldh a multiple of 8, rows [n, ldh) zero), or NULL
+    const float* scr_s;                          // [pl] per-column bound (sbp_screen_prep_kernel)
+    unsigned long long* scr_stat;                // optional [2]: columns screened, columns that took the exact path (SBP_SCREEN_STATS)
     int Gb, pad1;                                // workgroups per local block (the same for every block: block = g / Gb, no table)
     const SbpBlk* blk;                           // [NL]
     double* x;                                   // [pl]
@@ -227,6 +230,147 @@ sbp_xreg_kernel(SbpParams q, int par) {
     if (lane == 0) wnz[wid] = nzc;
     __syncthreads();
     if (threadIdx.x == 0) q.wcount[g] = wnz[0] + wnz[1] + wnz[2] + wnz[3];
+}
+
+// Regular iterations, first launch, SCREENED (round 6; the argument is wide_x_kernel's, lasso_wide.hip): the prox leaves all but a per
+// cent of the columns at zero, and a product with the column ROUNDED to fp16 proves it for nearly all of them --
+//     |fl64(A_j'v)| <= |fl32(Ah_j'vf)| + s_j ||v||_2,   s_j >= ||A_j - Ah_j||_2 + ((n + 2) 2^-24 + n 2^-53) max(||A_j||_2, ||Ah_j||_2)
+// (rounding of the column by Cauchy-Schwarz; the float inner product's gamma_n; v rounded to float, 2^-24 per entry; the double inner
+// product's own gamma_n).  A column with x_j = 0 whose bound stays below gamma * pen * (1 - 1e-9) keeps the zero it holds (the
+// exact step divides by gamma -- one rounding of 2^-53 -- and compares); every other column takes the exact step on the double
+// column, IN THE ARITHMETIC OF sbp_xreg_kernel (one accumulator per lane, rows ascending, then the wave sum): x and the
+// per-workgroup counts are bit-identical to the unscreened launch's, and the launch streams 2 n p bytes instead of 8 n p.
+__device__ __forceinline__ double sbp_col_dot_seq(const double* __restrict__ col, const double* vsh, int nk, int lane) {
+    const double2* a = reinterpret_cast<const double2*>(col) + lane;
+    const double2* vv = reinterpret_cast<const double2*>(vsh) + lane;
+    double d = 0.0;
+    for (int k0 = 0; k0 < nk; k0 += 16) {
+        double2 x[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) x[u] = k0 + u < nk ? a[(size_t)(k0 + u) * 64] : make_double2(0.0, 0.0);
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (k0 + u < nk) { const double2 w = vv[(k0 + u) * 64]; d = fma(x[u].x, w.x, d); d = fma(x[u].y, w.y, d); }
+    }
+    return wave_sum(d);
+}
+
+__global__ void __launch_bounds__(kSbpThreads)
+sbp_xreg_screen_kernel(SbpParams q, int par) {
+    extern __shared__ __attribute__((aligned(16))) double vsh[];    // npad doubles
+    __shared__ double red[8 * 4];
+    __shared__ int wnz[4];
+    SbpCtl c;
+    if (!sbp_decide(q, par, c, red)) return;
+    for (int k = threadIdx.x; k < q.npad; k += kSbpThreads) vsh[k] = q.v[k];
+    __syncthreads();
+    const int g = blockIdx.x;
+    const int Gb = q.Gb, b = g / Gb, sub = g - b * Gb;
+    const SbpBlk bi = load_ctl_vector(q.blk + b);
+    const int c0 = bi.c0, pb = bi.pb;
+    const double gamma = bi.gamma, pen = bi.pen;
+    const int per = sbp_share(pb, Gb, 0);
+    const int lo = sub * per, hi = min(pb, lo + per);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int nk = q.npad / 128;
+    double vs = 0.0;
+    for (int i = lane; i < q.npad; i += 64) vs = fma(vsh[i], vsh[i], vs);
+    const double V = sqrt(wave_sum(vs)) * (1.0 + 1e-12);             // >= ||v||_2
+    const double Gthr = gamma * pen * (1.0 - 1e-9);
+    const int nkh = (int)((q.ldh + 511) / 512);                      // 16-byte pieces per lane of a rounded column
+    typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+    constexpr int kScrUn = 8;                                        // pieces of each of the two columns requested together (16 KB per wave in flight)
+    int nzc = 0;
+    unsigned long long seen = 0, exact = 0;
+    for (int e = lo + 2 * wid; e < hi; e += 8) {
+        const bool two = e + 1 < hi;
+        const int j0 = c0 + e, j1 = c0 + e + (two ? 1 : 0);
+        const double xo0 = q.x[j0], xo1 = q.x[j1];
+        const float s0 = q.scr_s[j0], s1 = q.scr_s[j1];
+        const unsigned short* h0 = q.Ah + (size_t)j0 * q.ldh + lane * 8;
+        const unsigned short* h1 = q.Ah + (size_t)j1 * q.ldh + lane * 8;
+        float d0 = 0.f, d1 = 0.f;
+        for (int k0 = 0; k0 < nkh; k0 += kScrUn) {
+            uint4 a0[kScrUn], a1[kScrUn];
+#pragma unroll
+            for (int u = 0; u < kScrUn; ++u) {
+                const long long r = (long long)(k0 + u) * 512 + lane * 8;
+                a0[u] = make_uint4(0u, 0u, 0u, 0u); a1[u] = make_uint4(0u, 0u, 0u, 0u);
+                if (k0 + u < nkh && r < q.ldh) { a0[u] = load16_nt<uint4>(h0 + (size_t)(k0 + u) * 512); a1[u] = load16_nt<uint4>(h1 + (size_t)(k0 + u) * 512); }
+            }
+#pragma unroll
+            for (int u = 0; u < kScrUn; ++u) {
+                const long long r = (long long)(k0 + u) * 512 + lane * 8;
+                if (k0 + u < nkh && r < q.ldh) {                     // ldh <= npad: the eight rows are inside vsh
+                    const double2* vp = reinterpret_cast<const double2*>(vsh + r);
+                    const double2 w0 = vp[0], w1 = vp[1], w2 = vp[2], w3 = vp[3];
+                    const float vf[8] = {(float)w0.x, (float)w0.y, (float)w1.x, (float)w1.y, (float)w2.x, (float)w2.y, (float)w3.x, (float)w3.y};
+                    const half8_t x0 = __builtin_bit_cast(half8_t, a0[u]), x1 = __builtin_bit_cast(half8_t, a1[u]);
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) { d0 = fmaf((float)x0[t], vf[t], d0); d1 = fmaf((float)x1[t], vf[t], d1); }
+                }
+            }
+        }
+        d0 = wave_sum(d0); d1 = wave_sum(d1);
+        seen += two ? 2 : 1;
+        double xn0 = 0.0, xn1 = 0.0;
+        if (!(xo0 == 0.0 && (double)fabsf(d0) + (double)s0 * V <= Gthr)) {              // (a NaN anywhere: the exact step)
+            const double d = sbp_col_dot_seq(q.A + (size_t)j0 * q.lda, vsh, nk, lane);
+            {
+#pragma clang fp contract(off)
+                xn0 = sbp_soft(xo0 - d / gamma, pen);
+            }
+            if (lane == 0) q.x[j0] = xn0;
+            ++exact;
+        }
+        if (two && !(xo1 == 0.0 && (double)fabsf(d1) + (double)s1 * V <= Gthr)) {
+            const double d = sbp_col_dot_seq(q.A + (size_t)j1 * q.lda, vsh, nk, lane);
+            {
+#pragma clang fp contract(off)
+                xn1 = sbp_soft(xo1 - d / gamma, pen);
+            }
+            if (lane == 0) q.x[j1] = xn1;
+            ++exact;
+        }
+        nzc += (xn0 != 0.0) + (xn1 != 0.0);
+    }
+    if (lane == 0) wnz[wid] = nzc;
+    __syncthreads();
+    if (threadIdx.x == 0) q.wcount[g] = wnz[0] + wnz[1] + wnz[2] + wnz[3];
+    if (q.scr_stat != nullptr && lane == 0) { atomicAdd(q.scr_stat, seen); atomicAdd(q.scr_stat + 1, exact); }
+}
+
+// Setup of the screen: column j of A rounded to fp16 (a wave per column; a rounding that is not finite is stored as zero and counts
+// as rounding error in full) and its bound s_j, sums in double, rounded up to float; a column holding a NaN / Inf gets +Inf.
+__global__ void __launch_bounds__(256)
+sbp_screen_prep_kernel(const double* __restrict__ A, long long lda, int n, int pl, unsigned short* __restrict__ Ah, long long ldh, float* __restrict__ s) {
+    const int lane = threadIdx.x & 63;
+    const long long j = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= pl) return;
+    const double* col = A + (size_t)j * lda;
+    unsigned short* hc = Ah + (size_t)j * ldh;
+    typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+    double e2 = 0.0, x2 = 0.0, h2 = 0.0;
+    for (long long r = (long long)lane * 8; r < ldh; r += 512) {
+        half8_t hv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const double x = r + e < n ? col[r + e] : 0.0;
+            _Float16 hh = (_Float16)(float)x;
+            double back = (double)(float)hh;
+            if (!(fabs(back) <= 65504.0)) { hh = (_Float16)0.f; back = 0.0; }
+            hv[e] = hh;
+            e2 = fma(x - back, x - back, e2); x2 = fma(x, x, x2); h2 = fma(back, back, h2);
+        }
+        *reinterpret_cast<uint4*>(hc + r) = __builtin_bit_cast(uint4, hv);
+    }
+    e2 = wave_sum(e2); x2 = wave_sum(x2); h2 = wave_sum(h2);
+    if (lane == 0) {
+        const double sd = (sqrt(e2) + 1.01 * ((double)n + 4.0) * 5.9604644775390625e-8 * sqrt(fmax(x2, h2))) * (1.0 + 1e-6);
+        float sv = __double2float_ru(sd);
+        if (!(sv < __builtin_huge_valf())) sv = __builtin_huge_valf();
+        s[j] = sv;
+    }
 }
 
 // Active-set iterations, first launch (AXONLY = false): the decision, then x_j <- soft(x_j - A_j'v / gamma, pen) for the blocks'
@@ -1495,6 +1639,7 @@ void solve_parbp(const DeviceData<double>& d, const admm_opts& opts, int nblocks
         // kernel whenever static + dynamic exceeds the default, and fail loudly when even the opt-in limit is too small.
         const size_t lds = (size_t)npad * sizeof(double);
         const void* fns[] = {reinterpret_cast<const void*>(&sbp_xreg_kernel<true>), reinterpret_cast<const void*>(&sbp_xreg_kernel<false>),
+                             reinterpret_cast<const void*>(&sbp_xreg_screen_kernel),
                              big ? reinterpret_cast<const void*>(&sbp_xact_kernel<false, 32>) : reinterpret_cast<const void*>(&sbp_xact_kernel<false, 16>),
                              reinterpret_cast<const void*>(&sbp_gs_dots_kernel<0>), reinterpret_cast<const void*>(&sbp_gs_dots_kernel<1>)};
         for (const void* fn : fns) {
@@ -1508,6 +1653,25 @@ void solve_parbp(const DeviceData<double>& d, const admm_opts& opts, int nblocks
         }
     }
     const bool nt = (double)lda * (double)pl * 8.0 > 220e6;       // as gemv_plan.h: beyond what the 256 MB Infinity Cache keeps
+    // the regular iterations' screen (sbp_xreg_screen_kernel): worth its 2 n p bytes when A streams from HBM; SBP_SCREEN = 0 never, 1 always
+    bool screen = nt;
+    if (const char* e = option("SBP_SCREEN")) screen = std::atoi(e) != 0;
+    DevBuf<unsigned short> Ah;
+    DevBuf<float> scr_s;
+    DevBuf<unsigned long long> scr_stat;
+    if (screen) {
+        const long long ldh = round_up(n, 8);
+        try {
+            Ah.alloc((size_t)pl * (size_t)ldh); scr_s.alloc(pl);
+        } catch (const Error&) {
+            Ah.release(); scr_s.release(); screen = false;          // the copy does not fit: unscreened
+        }
+        if (screen) {
+            hipLaunchKernelGGL(sbp_screen_prep_kernel, dim3((unsigned)((pl + 3) / 4)), dim3(256), 0, st, A, lda, n, pl, Ah.get(), ldh, scr_s.get());
+            q.Ah = Ah.get(); q.ldh = ldh; q.scr_s = scr_s.get();
+            if (option("SBP_SCREEN_STATS")) { scr_stat.alloc(2); scr_stat.zero(st); q.scr_stat = scr_stat.get(); }
+        }
+    }
     comm_stream_sync(st);
     const size_t ldsv = (size_t)npad * sizeof(double);
     const bool gram_on = gram;
@@ -1527,7 +1691,8 @@ void solve_parbp(const DeviceData<double>& d, const admm_opts& opts, int nblocks
         const int t = (int)(g % 10);
         const bool gram = gram_on && g - t >= gram_from;            // a stretch runs one way from its regular iteration on
         if (t == 0) {                                                // regular iteration (the counter IS the enqueue index until `done`)
-            if (nt) hipLaunchKernelGGL((sbp_xreg_kernel<true>), dim3(G), dim3(kSbpThreads), ldsv, st, q, par);
+            if (screen) hipLaunchKernelGGL(sbp_xreg_screen_kernel, dim3(G), dim3(kSbpThreads), ldsv, st, q, par);
+            else if (nt) hipLaunchKernelGGL((sbp_xreg_kernel<true>), dim3(G), dim3(kSbpThreads), ldsv, st, q, par);
             else hipLaunchKernelGGL((sbp_xreg_kernel<false>), dim3(G), dim3(kSbpThreads), ldsv, st, q, par);
             hipLaunchKernelGGL(sbp_list_kernel, dim3(G), dim3(kSbpThreads), 0, st, q, par ^ 1);
             if (gram) {
@@ -1614,7 +1779,12 @@ void solve_parbp(const DeviceData<double>& d, const admm_opts& opts, int nblocks
     S.loop_ms_events = lt.events_ms;
     S.exchange_variant = dist ? 1 : 0;
     S.xupdate_samples = lsteps;                                     // Lanczos steps of the longest spectral-radius run
-    S.xupdate_variant = gstat[6] == 0 ? 0 : (halts > 0 ? 2 : 1);      // how the active-set iterations ran (include/admm_hip.h)
+    S.xupdate_variant = (gstat[6] == 0 ? 0 : (halts > 0 ? 2 : 1)) + (screen ? 4 : 0);      // how the active-set iterations ran, + 4: regular iterations screened (include/admm_hip.h)
+    if (q.scr_stat != nullptr) {
+        unsigned long long hs[2] = {0, 0};
+        ADMM_HIP_CHECK(hipMemcpy(hs, scr_stat.get(), sizeof(hs), hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "[parbp screen] %llu columns screened on regular iterations, %llu took the exact step (%.3f %%)\n", hs[0], hs[1], hs[0] ? 100.0 * (double)hs[1] / (double)hs[0] : 0.0);
+    }
     S.xupdate_launches = gstat[6];                                  // stretches that ran in Gram space
     S.persist_iter = gstat[5];                                      // times U was rebuilt from the current lists
 }

@@ -90,7 +90,8 @@ typedef struct admm_stats {
                               tall path: 0 = full-matrix mat-vec (4p^2 B), 1 = lower-triangle symmetric mat-vec (2p^2 B),
                               2 = the same with the tiles dealt out to the ranks + one all-reduce of 2p floats (admm_hip_lasso_dist),
                               (3, a single-launch iteration, existed in rounds 3 - 5: measured slower, removed in round 6);
-                              admm_hip_parbp: 0 = every active-set iteration streams the non-zero columns twice, 1 = active-set iterations
+                              admm_hip_parbp: + 4 = the regular iterations ran screened (as the wide path's);
+                              0 = every active-set iteration streams the non-zero columns twice, 1 = active-set iterations
                               in Gram space (one |U| x |U| mat-vec each; xupdate_launches = stretches of nine that ran so, persist_iter =
                               times the column set U was rebuilt), 2 = 1 except for stretches of 100, 200, 400, ... iterations after the non-zeros
                               outgrew the Gram matrix, which ran as 0 */
@@ -323,8 +324,8 @@ typedef struct admm_hip_options {
     int batch_iters;          /* iterations enqueued between two host polls (0: default 16) */
     int profile_stride;       /* time every k-th x-update launch with HIP events (0: off) */
     int pool_mb;              /* cache of released device blocks: -1 off, 0 default (min(16 GB, memory / 8)), > 0 megabytes */
-    int wide_screen;          /* wide solver, regular steps screened through a 2-byte copy of X (bit-identical iterates, half the bytes):
-                                 0 default (when X is larger than 256 MB), 1 always, 2 never */
+    int screen;               /* wide solver and admm_hip_parbp: regular steps screened through a 2-byte copy of the matrix (bit-identical
+                                 iterates, half / a quarter of the bytes): 0 default (when the matrix streams from HBM), 1 always, 2 never */
     int reserved[11];
 } admm_hip_options;
 ADMM_HIP_API int admm_hip_options_default(admm_hip_options* o);               /* zero-fills and sets struct_size */

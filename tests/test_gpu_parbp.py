@@ -179,3 +179,36 @@ def test_gram_space_launches_do_not_depend_on_their_workgroups_starting_together
     _compare(xs, xs @ b0, 4, "n=120 p=700, even workgroups 30 us late")
     admm_amd.options.set(SBP_GRAM_CARRY="0")
     _compare(xs, xs @ b0, 4, "n=120 p=700, no carry-over, even workgroups 30 us late")
+
+
+@pytest.mark.parametrize("n,p,N,scale", [(50, 100, 3, "plain"), (300, 2400, 4, "plain"), (700, 3000, 8, "mixed"), (1030, 4100, 2, "huge"), (8400, 8600, 2, "plain")])
+def test_screened_regular_iterations_are_bit_identical(n, p, N, scale):
+    """The regular iterations' screen (sbp_xreg_screen_kernel: a product with the fp16-rounded column proves "stays zero" for nearly
+    every column; the others take the exact double step in the arithmetic of the unscreened launch): the same solve with
+    SBP_SCREEN=1 and =0 -- coefficients, iteration count and every record of the decision trace identical, also with columns whose
+    entries overflow or underflow fp16.  The screened run is then held to the oracle like every other variant."""
+    import admm_amd
+    rng = np.random.default_rng(17 + n)
+    x = rng.standard_normal((n, p))
+    if scale == "mixed":
+        x = x * 10.0 ** rng.uniform(-7, 5, p)
+    elif scale == "huge":
+        x[:, ::3] *= 2e5
+        x[rng.random((n, p)) < 0.005] *= 9e4
+    x = np.asfortranarray(x)
+    b0 = np.zeros(p)
+    idx = rng.choice(p, max(3, n // 25), replace=False)
+    b0[idx] = rng.standard_normal(len(idx)) * 2 / np.abs(x[:, idx]).mean(axis=0)
+    y = x @ b0
+    maxit = 10000 if n <= 1100 else 24
+    fits = {}
+    for scr in ("1", "0"):
+        with admm_amd.options(SBP_SCREEN=scr):
+            fits[scr] = _fit(x, y, N, maxit=maxit)
+    on, off = fits["1"], fits["0"]
+    assert on.stats["xupdate_variant"] >= 4 and off.stats["xupdate_variant"] < 4
+    assert on.niter == off.niter and np.array_equal(on.trace, off.trace)
+    assert np.array_equal(on.beta.toarray(), off.beta.toarray())
+    if scale == "plain":
+        with admm_amd.options(SBP_SCREEN="1"):
+            _compare(x, y, N, f"screened n={n} p={p}", maxit=maxit)
