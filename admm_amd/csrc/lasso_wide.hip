@@ -1686,7 +1686,7 @@ __global__ void wide_init_kernel(WideParams q, double rho, float lam0) {
 // entry then counts as rounding error -- and a column holding a NaN / Inf gets s_j = +Inf: it always takes the exact path.
 __global__ void __launch_bounds__(256)
 wide_screen_prep_kernel(const float* __restrict__ X, long long ldx, int n, int p, unsigned short* __restrict__ Xh, long long ldh,
-                        float* __restrict__ s, int NW, int S) {
+                        float* __restrict__ s, int NW, int S, double loosen) {
     const int lane = threadIdx.x & 63;
     const long long j = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= p) return;
@@ -1713,7 +1713,7 @@ wide_screen_prep_kernel(const float* __restrict__ X, long long ldx, int n, int p
     e2 = wave_sum(e2); x2 = wave_sum(x2); h2 = wave_sum(h2);
     if (lane == 0) {
         const double gn = 1.001 * (double)n * 5.9604644775390625e-8;   // gamma_n
-        const double sd = (sqrt(e2) + 2.0 * gn * sqrt(fmax(x2, h2))) * (1.0 + 1e-6);
+        const double sd = (sqrt(e2) + 2.0 * gn * sqrt(fmax(x2, h2))) * (1.0 + 1e-6) * loosen;
         float sv = __double2float_ru(sd);
         if (!(sv < __builtin_huge_valf())) sv = __builtin_huge_valf();
         s[(size_t)(j % NW) * S + (size_t)(j / NW)] = sv;
@@ -1951,7 +1951,9 @@ struct WidePlan final : LassoPlan {
             return;
         }
         scr_s.zero(st);
-        hipLaunchKernelGGL(wide_screen_prep_kernel, dim3((unsigned)((p + 3) / 4)), dim3(256), 0, st, d.X.get(), d.ldx, n, p, Xh.get(), ldh, scr_s.get(), NW, S);
+        double loosen = 1.0;                                          // WIDE_SCREEN_SLACK >= 1: bounds that much looser (what a coarser copy would cost in exact steps; diagnosis)
+        if (const char* e = option("WIDE_SCREEN_SLACK")) loosen = std::max(1.0, std::atof(e));
+        hipLaunchKernelGGL(wide_screen_prep_kernel, dim3((unsigned)((p + 3) / 4)), dim3(256), 0, st, d.X.get(), d.ldx, n, p, Xh.get(), ldh, scr_s.get(), NW, S, loosen);
         q.Xh = Xh.get(); q.ldh = ldh; q.scr_s = scr_s.get(); q.scr_S = S;
         if (option("WIDE_SCREEN_STATS")) { scr_stat.alloc(2); scr_stat.zero(st); q.scr_stat = scr_stat.get(); }
         screened = true;

@@ -150,19 +150,21 @@ def test_two_process_column_sharded_wide_solver(backend, case):
         assert relerr(res[0]["beta"][:, j], one.beta_dense[:, j]) < 1e-4, j
 
 
-@pytest.mark.parametrize("case", ["widecols", "widecols_enet"])
-def test_two_process_column_sharded_stretch_is_stepwise_clean(case):
+@pytest.mark.parametrize("case,screen", [("widecols", ""), ("widecols_enet", ""), ("widecols", "1"), ("widecols_enet", "1")])
+def test_two_process_column_sharded_stretch_is_stepwise_clean(case, screen):
     """Round 6: the column-sharded wide solver runs its active-set iterations inside the persistent stretch, A x summed over the ranks
     INSIDE the launch (wide_rows_persist_kernel<true>, AUX region of the PEER exchange).  Held by the stepwise instrument as the
     single-process stretch is: both ranks dump their iterates (x of their own columns | A x | z | y) and their standardised column
     blocks; put together they are one dump of the whole problem, and every iteration in it must be the reference's iteration applied to
     the library's own previous iterates -- zero pattern, z, y bit for bit, the two mat-vecs within the float dot-product yardstick,
     thresholds / residuals / decisions / rho adaptation exact (oracle/stepcheck.py check_wide).  And the replicated vectors must be
-    bit-identical on the two ranks in every record."""
+    bit-identical on the two ranks in every record.  screen = "1": with the regular steps screened on every rank's column block
+    (wide_x_kernel's fp16 bound, forced on at this size): the regular steps in the dump are still the reference's, bit for bit in
+    their zero pattern."""
     from oracle import entry, stepcheck
     sys.path.insert(0, HERE)
     from dist_worker import problem
-    res = _run_ranks("peer", case, extra_env=dict(ADMM_TEST_WIDECOLS_STATE="1"))
+    res = _run_ranks("peer", case, extra_env=dict(ADMM_TEST_WIDECOLS_STATE="1", **({"ADMM_HIP_WIDE_SCREEN": "1"} if screen else {})))
     x, y, _, kw = problem(case)
     n, p = x.shape
     d0, d1 = res[0]["dump"], res[1]["dump"]

@@ -17,17 +17,20 @@ def _problem(x, y, nl, lmr, alpha=None):
     return dict(x=x, y=y, lam=None, nlambda=nl, lmin_ratio=lmr, standardize=True, intercept=True, opts=entry.LASSO_OPTS, alpha=alpha)
 
 
-@pytest.mark.parametrize("n,p,m", [(300, 2000, 20), (257, 1031, 10), (500, 500, 15)])
-def test_wide_lasso_path_vs_oracle(n, p, m):
+@pytest.mark.parametrize("n,p,m,screen", [(300, 2000, 20, ""), (257, 1031, 10, ""), (500, 500, 15, ""), (300, 2000, 20, "1"), (1500, 4000, 25, "1")])
+def test_wide_lasso_path_vs_oracle(n, p, m, screen):
     """12-lambda path judged on the decision trace: the oracle follows the GPU through rounding-level near-ties of the
-    stopping test and of the rho adaptation only (helpers.assert_followed_parity); counts identical, every column 1e-4."""
-    from admm_amd import admm_lasso
+    stopping test and of the rho adaptation only (helpers.assert_followed_parity); counts identical, every column 1e-4.
+    screen = "1": with the regular steps screened (forced on at this size): follow + stepwise hold it like the default."""
+    from admm_amd import admm_lasso, options
     from helpers import traced_parity
     x, y = synth_lasso(n, p, m, seed=29)
     lmr = 0.01 if n < p else 1e-4                                # R default (R/30_admm_lasso.R:43)
+    if screen:
+        options.set(WIDE_SCREEN=screen)                          # (reset after every test: conftest.py)
     # the follow rule AND the stepwise rule on the iterate dump (helpers.traced_parity -> wide_stepwise)
     fit, rep = traced_parity(admm_lasso(x, y).penalty(nlambda=12, lambda_min_ratio=lmr), _problem(x, y, 12, lmr), TOL, label=f"wide n={n} p={p}")
-    assert fit.stats["branch"] == 1
+    assert fit.stats["branch"] == 1 and fit.stats["xupdate_variant"] == (1 if screen else 0)
     ref = rep["ref"]
     assert np.allclose(fit.lambda_, ref["lambda"], rtol=1e-5)
     # support agreement
@@ -47,10 +50,13 @@ def test_wide_spectral_radius_estimate():
     assert abs(fit.stats["eig_est"] - float(d["solver"].sprad)) < 1e-4 * float(d["solver"].sprad)
 
 
-def test_wide_enet_path_vs_oracle():
-    from admm_amd import admm_enet
+@pytest.mark.parametrize("screen", ["", "1"])
+def test_wide_enet_path_vs_oracle(screen):
+    from admm_amd import admm_enet, options
     x, y = synth_lasso(250, 900, 12, seed=31)
     from helpers import traced_parity
+    if screen:
+        options.set(WIDE_SCREEN=screen)
     traced_parity(admm_enet(x, y).penalty(nlambda=10, lambda_min_ratio=0.01, alpha=0.5), _problem(x, y, 10, 0.01, alpha=0.5), TOL, label="wide enet")
 
 
