@@ -108,8 +108,11 @@ struct WideParams {
     double* trace; long long trace_cap;   // optional decision records (admm_hip_lasso_plan_trace_*), or NULL
     float* state; long long state_cap;    // optional [state_cap][p + 3 n] iterates x | Ax | z | y of every iteration (admm_hip_lasso_plan_state_*), or NULL
     // safe screening of the regular steps (wide_x_kernel, "screen"): a 2-byte copy of X and a per-column error bound, or NULL
-    const unsigned short* Xh; long long ldh;      // [p][ldh] X rounded to fp16 (non-finite roundings stored as 0), ldh a multiple of 8, rows [n, ldh) zero
+    const void* Xh; long long ldh;                // [p][ldh] the copy: fp16 roundings (scr_fmt 16; non-finite ones stored as 0) or signed bytes q with
+                                                  // X ~ scale_j q (scr_fmt 8); ldh a multiple of the 8 / 16 elements of a 16-byte piece, rows [n, ldh) zero
+    int scr_fmt;
     const float* scr_s; int scr_S;                // s_j in the x-update launch's own order: column (k, w) = k * NW + w at scr_s[w * scr_S + k]
+    const float* scr_scale;                       // scr_fmt 8: scale_j, same order
     unsigned long long* scr_stat;                 // optional [2]: columns screened, columns that took the exact path (WIDE_SCREEN_STATS)
 #ifdef ADMM_HIP_PROBE
     long long* probe;                     // dev build only: in-kernel timestamps [4096 iterations][4 observers][8]
@@ -460,9 +463,6 @@ wide_x_kernel(WideParams q, int par) {
     // zero it already holds (the float division by gamma rounds by at most 2^-24, the comparison is monotone) -- and every other
     // column (x_j != 0, bound not met, anything non-finite) takes the exact path below on the float column: the iterates are
     // BIT-IDENTICAL to the unscreened step's, and a regular step streams 2 n p bytes instead of 4 n p.
-    constexpr int NH = (RT + 1) / 2;                                   // 16-byte pieces of a 2-byte column per lane (512 rows per wave load)
-    constexpr bool kScrPipe = NH <= 4;                                 // two rounds in flight (n <= 2048: registers to spare at two waves per SIMD)
-    constexpr int CR = 2;                                              // columns per round
     const bool screen = RT > 0 && reg && q.Xh != nullptr;
     double scrT = 0.0, scrG = 0.0;
     if (RT > 0 && screen) {
@@ -475,100 +475,132 @@ wide_x_kernel(WideParams q, int par) {
 
     if constexpr (RT > 0) {
         if (screen) {
-            // a round = CR rounded columns of the wave; two rounds' requests are in flight at any time (the next round is requested
-            // before the current one is reduced), and the next group's x / bounds are requested a group ahead
-            auto scr_request = [&](unsigned long long& mask, int sc, int (&lc)[CR], long long (&jc)[CR], uint4 (&h)[CR][NH]) {
+            // The copy is fp16 (8 elements per 16-byte piece) or, where a linear 8-bit code of the column is fine enough (setup decides),
+            // signed bytes with a per-column scale (16 per piece: n p bytes per regular step); the bound has the same form for both.
+            // A round = CR columns of the wave; while NP * CR * 2 <= 16 pieces two rounds' requests are in flight at any time (the next
+            // round is requested before the current one is reduced); the next group's x / bounds are requested a group ahead.
+            auto screened_step = [&](auto fmt_tag) {
+                constexpr int FMT = decltype(fmt_tag)::value;
+                constexpr int EPL = FMT == 16 ? 8 : 16;                               // elements of a piece
+                constexpr int NP = (RT * 4 + EPL - 1) / EPL;                          // pieces of a column per lane (64 EPL rows per wave load)
+                constexpr int CR = (FMT == 8 && NP <= 2) ? 4 : 2;                     // columns per round
+                constexpr bool kPipe = NP * CR * 2 <= 16;
+                const unsigned char* base = reinterpret_cast<const unsigned char*>(q.Xh);
+                const size_t colbytes = (size_t)q.ldh * (FMT / 8);
+                auto scr_request = [&](unsigned long long& mask, int sc, int (&lc)[CR], long long (&jc)[CR], uint4 (&h)[CR][NP]) {
 #pragma unroll
-                for (int c = 0; c < CR; ++c) {
-                    lc[c] = -1; jc[c] = 0;
-                    if (mask) { lc[c] = __ffsll((long long)mask) - 1; mask &= mask - 1; jc[c] = (long long)(sc + lc[c]) * NW + w; }
-                    const unsigned short* hcol = q.Xh + (size_t)jc[c] * q.ldh;
+                    for (int c = 0; c < CR; ++c) {
+                        lc[c] = -1; jc[c] = 0;
+                        if (mask) { lc[c] = __ffsll((long long)mask) - 1; mask &= mask - 1; jc[c] = (long long)(sc + lc[c]) * NW + w; }
+                        const unsigned char* hcol = base + (size_t)jc[c] * colbytes;
 #pragma unroll
-                    for (int k = 0; k < NH; ++k) {
-                        const int r = k * 512 + lane * 8;
-                        h[c][k] = make_uint4(0u, 0u, 0u, 0u);
-                        if (lc[c] >= 0 && r < q.ldh) h[c][k] = load16_nt<uint4>(hcol + r);
+                        for (int k = 0; k < NP; ++k) {
+                            const int r = (k * 64 + lane) * EPL;
+                            h[c][k] = make_uint4(0u, 0u, 0u, 0u);
+                            if (lc[c] >= 0 && r < q.ldh) h[c][k] = load16_nt<uint4>(hcol + (size_t)(k * 64 + lane) * 16);
+                        }
                     }
-                }
-            };
-            auto scr_consume = [&](const int (&lc)[CR], const long long (&jc)[CR], const uint4 (&h)[CR][NH], float xj, float sj) {
-                float dd[CR];
+                };
+                auto scr_consume = [&](const int (&lc)[CR], const long long (&jc)[CR], const uint4 (&h)[CR][NP], float xj, float sj, float scj) {
+                    float dd[CR];
 #pragma unroll
-                for (int c = 0; c < CR; ++c) dd[c] = 0.f;
+                    for (int c = 0; c < CR; ++c) dd[c] = 0.f;
 #pragma unroll
-                for (int k = 0; k < NH; ++k) {
-                    const int r = k * 512 + lane * 8;
-                    if (r < q.ldh) {
-                        typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
-                        const float4 b0 = *reinterpret_cast<const float4*>(tl + r), b1 = *reinterpret_cast<const float4*>(tl + r + 4);
+                    for (int k = 0; k < NP; ++k) {
+                        const int r = (k * 64 + lane) * EPL;
+                        if (r < q.ldh) {
+                            float tv8[EPL];
 #pragma unroll
-                        for (int c = 0; c < CR; ++c) {
-                            const half8_t hv = __builtin_bit_cast(half8_t, h[c][k]);
-                            float d0 = dd[c], d1 = 0.f;
-                            d0 = fmaf((float)hv[0], b0.x, d0); d0 = fmaf((float)hv[1], b0.y, d0); d0 = fmaf((float)hv[2], b0.z, d0); d0 = fmaf((float)hv[3], b0.w, d0);
-                            d1 = fmaf((float)hv[4], b1.x, d1); d1 = fmaf((float)hv[5], b1.y, d1); d1 = fmaf((float)hv[6], b1.z, d1); d1 = fmaf((float)hv[7], b1.w, d1);
-                            dd[c] = d0 + d1;
+                            for (int e4 = 0; e4 < EPL / 4; ++e4) {
+                                const float4 b = *reinterpret_cast<const float4*>(tl + r + 4 * e4);
+                                tv8[4 * e4] = b.x; tv8[4 * e4 + 1] = b.y; tv8[4 * e4 + 2] = b.z; tv8[4 * e4 + 3] = b.w;
+                            }
+#pragma unroll
+                            for (int c = 0; c < CR; ++c) {
+                                float d0 = dd[c], d1 = 0.f;
+                                if constexpr (FMT == 16) {
+                                    typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+                                    const half8_t hv = __builtin_bit_cast(half8_t, h[c][k]);
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) { d0 = fmaf((float)hv[e], tv8[e], d0); d1 = fmaf((float)hv[4 + e], tv8[4 + e], d1); }
+                                } else {
+                                    const unsigned wq[4] = {h[c][k].x, h[c][k].y, h[c][k].z, h[c][k].w};
+#pragma unroll
+                                    for (int e = 0; e < 16; ++e) {
+                                        const float qv = (float)(int)(signed char)(unsigned char)(wq[e >> 2] >> (8 * (e & 3)));
+                                        if (e & 1) d1 = fmaf(qv, tv8[e], d1); else d0 = fmaf(qv, tv8[e], d0);
+                                    }
+                                }
+                                dd[c] = d0 + d1;
+                            }
+                        }
+                    }
+                    float v8[8];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) v8[c] = c < CR ? dd[c < CR ? c : 0] : 0.f;
+                    const float tot = halving_sum8(v8, lane);          // lanes 8 c .. 8 c + 7: the wave total of column c
+#pragma unroll
+                    for (int c = 0; c < CR; ++c) {
+                        if (lc[c] < 0) break;                          // uniform
+                        const float dc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tot), 8 * c));
+                        const float sc_j = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sj), lc[c]));
+                        const float xc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xj), lc[c]));
+                        double dabs = (double)fabsf(dc);
+                        if constexpr (FMT == 8) dabs *= (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(scj), lc[c]));
+                        const bool stays_zero = xc == 0.f && dabs + (double)sc_j * scrT <= scrG;          // (a NaN anywhere: false)
+                        if (!stays_zero) {                             // the exact step on the float column
+                            float4 cv[NRT];
+                            col_request(jc[c], cv, false);
+                            const float xn = col_finish(xc, cv);
+                            if (lane == lc[c]) q.x[jc[c]] = xn;
+                            ++scr_exact;
+                        }
+                    }
+                };
+                auto group_load = [&](int sc, float& xj, float& sj, float& scj) {
+                    const long long jl = (long long)(sc + lane) * NW + w;
+                    xj = 0.f; sj = 0.f; scj = 0.f;
+                    if ((long long)sc * NW < q.p) {
+                        xj = jl < q.p ? q.x[jl] : 0.f;
+                        sj = q.scr_s[(size_t)w * q.scr_S + sc + lane];                 // the bounds of the group's 64 columns: one 256-byte line
+                        if constexpr (FMT == 8) scj = q.scr_scale[(size_t)w * q.scr_S + sc + lane];
+                    }
+                };
+                float xj_n, sj_n, scj_n;
+                group_load(0, xj_n, sj_n, scj_n);
+                for (int sc = 0; (long long)sc * NW < q.p; sc += 64) {
+                    const long long jl = (long long)(sc + lane) * NW + w;
+                    const float xj = xj_n, sj = sj_n, scj = scj_n;
+                    group_load(sc + 64, xj_n, sj_n, scj_n);
+                    if (snap && jl < q.p) bsnap[jl] = xj;
+                    unsigned long long mask = __ballot(jl < q.p);
+                    scr_seen += __popcll(mask);
+                    int lA[CR];
+                    long long jA[CR];
+                    uint4 hA[CR][NP];
+                    if constexpr (kPipe) {
+                        int lB[CR];
+                        long long jB[CR];
+                        uint4 hB[CR][NP];
+                        scr_request(mask, sc, lA, jA, hA);
+                        for (;;) {
+                            scr_request(mask, sc, lB, jB, hB);
+                            scr_consume(lA, jA, hA, xj, sj, scj);
+                            if (lB[0] < 0) break;
+                            scr_request(mask, sc, lA, jA, hA);
+                            scr_consume(lB, jB, hB, xj, sj, scj);
+                            if (lA[0] < 0) break;
+                        }
+                    } else {
+                        while (mask) {
+                            scr_request(mask, sc, lA, jA, hA);
+                            scr_consume(lA, jA, hA, xj, sj, scj);
                         }
                     }
                 }
-                float v8[8];
-#pragma unroll
-                for (int c = 0; c < 8; ++c) v8[c] = c < CR ? dd[c < CR ? c : 0] : 0.f;
-                const float tot = halving_sum8(v8, lane);              // lanes 8 c .. 8 c + 7: the wave total of column c
-#pragma unroll
-                for (int c = 0; c < CR; ++c) {
-                    if (lc[c] < 0) break;                              // uniform
-                    const float dc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tot), 8 * c));
-                    const float sc_j = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sj), lc[c]));
-                    const float xc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xj), lc[c]));
-                    const bool stays_zero = xc == 0.f && (double)fabsf(dc) + (double)sc_j * scrT <= scrG;          // (a NaN anywhere: false)
-                    if (!stays_zero) {                                 // the exact step on the float column
-                        float4 cv[NRT];
-                        col_request(jc[c], cv, false);
-                        const float xn = col_finish(xc, cv);
-                        if (lane == lc[c]) q.x[jc[c]] = xn;
-                        ++scr_exact;
-                    }
-                }
             };
-            auto group_load = [&](int sc, float& xj, float& sj) {
-                const long long jl = (long long)(sc + lane) * NW + w;
-                xj = 0.f; sj = 0.f;
-                if ((long long)sc * NW < q.p) {
-                    xj = jl < q.p ? q.x[jl] : 0.f;
-                    sj = q.scr_s[(size_t)w * q.scr_S + sc + lane];     // the bounds of the group's 64 columns: one 256-byte line
-                }
-            };
-            float xj_n, sj_n;
-            group_load(0, xj_n, sj_n);
-            for (int sc = 0; (long long)sc * NW < q.p; sc += 64) {
-                const long long jl = (long long)(sc + lane) * NW + w;
-                const float xj = xj_n, sj = sj_n;
-                group_load(sc + 64, xj_n, sj_n);
-                if (snap && jl < q.p) bsnap[jl] = xj;
-                unsigned long long mask = __ballot(jl < q.p);
-                scr_seen += __popcll(mask);
-                int lA[CR], lB[CR];
-                long long jA[CR], jB[CR];
-                uint4 hA[CR][NH], hB[CR][NH];
-                if constexpr (kScrPipe) {
-                    scr_request(mask, sc, lA, jA, hA);
-                    for (;;) {
-                        scr_request(mask, sc, lB, jB, hB);
-                        scr_consume(lA, jA, hA, xj, sj);
-                        if (lB[0] < 0) break;
-                        scr_request(mask, sc, lA, jA, hA);
-                        scr_consume(lB, jB, hB, xj, sj);
-                        if (lA[0] < 0) break;
-                    }
-                } else {
-                    (void)lB; (void)jB; (void)hB;
-                    while (mask) {
-                        scr_request(mask, sc, lA, jA, hA);
-                        scr_consume(lA, jA, hA, xj, sj);
-                    }
-                }
-            }
+            if (q.scr_fmt == 8) screened_step(std::integral_constant<int, 8>{});
+            else screened_step(std::integral_constant<int, 16>{});
         }
     }
     if (!screen)
@@ -1720,6 +1752,83 @@ wide_screen_prep_kernel(const float* __restrict__ X, long long ldx, int n, int p
     }
 }
 
+// The same for a linear 8-bit code: q_ij = round(X_ij / scale_j) in [-127, 127], scale_j = max_i |X_ij| / 127; the copy stands for
+// scale_j q_j in the bound (||X_j - scale_j q_j||_2 measured here, in double).  The screen's product is fl32(q_j't) times scale_j in double.
+__global__ void __launch_bounds__(256)
+wide_screen_prep8_kernel(const float* __restrict__ X, long long ldx, int n, int p, signed char* __restrict__ Xq, long long ldq,
+                         float* __restrict__ s, float* __restrict__ scale, int NW, int S, double loosen) {
+    const int lane = threadIdx.x & 63;
+    const long long j = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= p) return;
+    const float* col = X + (size_t)j * ldx;
+    signed char* qc = Xq + (size_t)j * ldq;
+    float mx = 0.f;
+    bool bad = false;
+    for (long long r = (long long)lane * 4; r < n; r += 256) {
+        const float4 a = *reinterpret_cast<const float4*>(col + r);
+        const float v[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (r + e < n) { const float av = fabsf(v[e]); if (!(av <= 3.0e38f)) bad = true; mx = fmaxf(mx, av); }
+    }
+    mx = wave_max(mx);
+    bad = __any(bad) != 0;
+    const float sc = bad ? 0.f : mx / 127.f;
+    double e2 = 0.0, x2 = 0.0, h2 = 0.0;
+    for (long long r = (long long)lane * 16; r < ldq; r += 1024) {                       // the column again (from the cache)
+        unsigned wq[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float x = r + e < n ? col[r + e] : 0.f;
+            int qi = 0;
+            if (sc > 0.f) { const float t = rintf(x / sc); qi = (int)fminf(fmaxf(t, -127.f), 127.f); }
+            wq[e >> 2] |= ((unsigned)qi & 0xffu) << (8 * (e & 3));
+            const double dx = (double)x, db = (double)sc * (double)qi;
+            e2 = fma(dx - db, dx - db, e2); x2 = fma(dx, dx, x2); h2 = fma(db, db, h2);
+        }
+        *reinterpret_cast<uint4*>(qc + r) = make_uint4(wq[0], wq[1], wq[2], wq[3]);
+    }
+    e2 = wave_sum(e2); x2 = wave_sum(x2); h2 = wave_sum(h2);
+    if (lane == 0) {
+        const double gn = 1.001 * (double)n * 5.9604644775390625e-8;
+        const double sd = (sqrt(e2) + 2.0 * gn * sqrt(fmax(x2, h2))) * (1.0 + 1e-6) * loosen;
+        float sv = __double2float_ru(sd);
+        if (bad || !(sv < __builtin_huge_valf())) sv = __builtin_huge_valf();
+        const size_t pos = (size_t)(j % NW) * S + (size_t)(j / NW);
+        s[pos] = sv; scale[pos] = sc;
+    }
+}
+
+// Which copy, if any: the bound of column j costs exact steps in proportion to its size in units of the spread of X_j't over random t,
+// r_j = s_j sqrt(n) / ||X_j||_2 (Gaussian-looking columns: 0.02 for fp16, 0.0082 sqrt(n) for the 8-bit code; a column with outliers
+// wastes the 8-bit code's range).  Per workgroup (four columns): the sum of min(r_j, 4) for the 8-bit code; the host adds them up in order.
+__global__ void __launch_bounds__(256)
+wide_screen_rate8_kernel(const float* __restrict__ X, long long ldx, int n, int p, double* __restrict__ part) {
+    __shared__ double sh[4];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const long long j = (long long)blockIdx.x * 4 + wid;
+    double rj = 0.0;
+    if (j < p) {
+        const float* col = X + (size_t)j * ldx;
+        float mx = 0.f;
+        for (long long r = lane; r < n; r += 64) mx = fmaxf(mx, fabsf(col[r]));
+        mx = wave_max(mx);
+        const float sc = mx / 127.f;
+        double e2 = 0.0, x2 = 0.0;
+        for (long long r = lane; r < n; r += 64) {
+            const float x = col[r];
+            const double db = sc > 0.f ? (double)sc * (double)fminf(fmaxf(rintf(x / sc), -127.f), 127.f) : 0.0;
+            e2 = fma((double)x - db, (double)x - db, e2); x2 = fma((double)x, (double)x, x2);
+        }
+        e2 = wave_sum(e2); x2 = wave_sum(x2);
+        const double gn = 1.001 * (double)n * 5.9604644775390625e-8;
+        rj = x2 > 0.0 ? (sqrt(e2) + 4.0 * gn * sqrt(x2)) * sqrt((double)n) / sqrt(x2) : 0.0;
+        if (!(rj <= 4.0)) rj = 4.0;
+    }
+    if (lane == 0) sh[wid] = rj;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
 struct WidePlan final : LassoPlan {
     DeviceData<float> d;
     LassoProblem pb;
@@ -1740,8 +1849,9 @@ struct WidePlan final : LassoPlan {
     std::vector<double> lam_user;
     std::vector<float> lam_int;
     DevBuf<float> x, Ax, z, y, axpart, tbuf, beta, dlam;
-    DevBuf<unsigned short> Xh;           // the regular steps' screen: X rounded to fp16 ...
-    DevBuf<float> scr_s;                 // ... and the per-column bounds (wide_screen_prep_kernel)
+    DevBuf<unsigned char> Xh;            // the regular steps' screen: X rounded to fp16 or coded in 8 bits ...
+    DevBuf<float> scr_s, scr_scale;      // ... the per-column bounds, the 8-bit code's scales (wide_screen_prep_kernel / wide_screen_prep8_kernel)
+    int screen_fmt = 0;
     DevBuf<unsigned long long> scr_stat;
     bool screened = false;
     DevBuf<int> niter, done;
@@ -1932,31 +2042,53 @@ struct WidePlan final : LassoPlan {
         comm_stream_sync(st);
     }
 
-    // Safe screening of the regular steps (wide_x_kernel): worth its 2 n p bytes when X is a stream from HBM at all (beyond the
-    // Infinity Cache the regular step is bandwidth, below it launch latency).  WIDE_SCREEN = 0 never, 1 always (tests); when the
-    // copy does not fit the device the solver simply runs unscreened.
+    // Safe screening of the regular steps (wide_x_kernel): worth its copy when X is a stream from HBM at all (beyond the Infinity Cache
+    // the regular step is bandwidth, below it launch latency).  WIDE_SCREEN = 0 never, 1 / 16 the fp16 copy, 8 the 8-bit code (tests);
+    // default: the 8-bit code when its bounds are tight enough on these columns (wide_screen_rate8_kernel: mean r_j <= 0.6), else
+    // fp16.  When the copy does not fit the device the solver simply runs unscreened.
     void setup_screen() {
         const size_t xbytes = (size_t)d.ldx * (size_t)p * sizeof(float);
-        bool want = fuse_rt > 0 && xbytes >= ((size_t)256 << 20);
-        if (const char* e = option("WIDE_SCREEN")) want = fuse_rt > 0 && std::string(e) != "0";
-        const long long ldh = round_up(n, 8);
-        if (!want || d.ldx % 8 != 0 || ldh > d.ldx) return;
+        if (fuse_rt == 0) return;
+        int fmt = xbytes >= ((size_t)256 << 20) ? -1 : 0;                // -1: choose
+        if (const char* e = option("WIDE_SCREEN")) { const int v = std::atoi(e); fmt = v == 0 ? 0 : (v == 8 ? 8 : 16); }
+        if (fmt == 0 || d.ldx % 16 != 0) return;
+        if (fmt < 0) {
+            const int nb = (p + 3) / 4;
+            DevBuf<double> part(nb);
+            hipLaunchKernelGGL(wide_screen_rate8_kernel, dim3((unsigned)nb), dim3(256), 0, st, d.X.get(), d.ldx, n, p, part.get());
+            std::vector<double> hp(nb);
+            read_back(hp.data(), part.get(), (size_t)nb * sizeof(double), st);
+            double sum = 0.0;
+            for (double v : hp) sum += v;
+            fmt = sum / (double)p <= 0.6 ? 8 : 16;
+        }
+        const int epl = fmt == 8 ? 16 : 8;
+        const long long ldh = round_up(n, epl);
+        if (ldh > d.ldx) return;
         const int NW = nwg_x * (kWideThreads / 64);
         const int S = (int)round_up((p + NW - 1) / NW, 64);
         try {
-            Xh.alloc((size_t)p * (size_t)ldh);
+            Xh.alloc((size_t)p * (size_t)ldh * (size_t)(fmt / 8));
             scr_s.alloc((size_t)NW * (size_t)S);
+            if (fmt == 8) scr_scale.alloc((size_t)NW * (size_t)S);
         } catch (const Error&) {
-            Xh.release(); scr_s.release();
+            Xh.release(); scr_s.release(); scr_scale.release();
             return;
         }
         scr_s.zero(st);
         double loosen = 1.0;                                          // WIDE_SCREEN_SLACK >= 1: bounds that much looser (what a coarser copy would cost in exact steps; diagnosis)
         if (const char* e = option("WIDE_SCREEN_SLACK")) loosen = std::max(1.0, std::atof(e));
-        hipLaunchKernelGGL(wide_screen_prep_kernel, dim3((unsigned)((p + 3) / 4)), dim3(256), 0, st, d.X.get(), d.ldx, n, p, Xh.get(), ldh, scr_s.get(), NW, S, loosen);
-        q.Xh = Xh.get(); q.ldh = ldh; q.scr_s = scr_s.get(); q.scr_S = S;
+        if (fmt == 8) {
+            scr_scale.zero(st);
+            hipLaunchKernelGGL(wide_screen_prep8_kernel, dim3((unsigned)((p + 3) / 4)), dim3(256), 0, st, d.X.get(), d.ldx, n, p,
+                               reinterpret_cast<signed char*>(Xh.get()), ldh, scr_s.get(), scr_scale.get(), NW, S, loosen);
+        } else {
+            hipLaunchKernelGGL(wide_screen_prep_kernel, dim3((unsigned)((p + 3) / 4)), dim3(256), 0, st, d.X.get(), d.ldx, n, p,
+                               reinterpret_cast<unsigned short*>(Xh.get()), ldh, scr_s.get(), NW, S, loosen);
+        }
+        q.Xh = Xh.get(); q.ldh = ldh; q.scr_fmt = fmt; q.scr_s = scr_s.get(); q.scr_S = S; q.scr_scale = scr_scale.get();
         if (option("WIDE_SCREEN_STATS")) { scr_stat.alloc(2); scr_stat.zero(st); q.scr_stat = scr_stat.get(); }
-        screened = true;
+        screened = true; screen_fmt = fmt;
     }
 
     // persistent active-set stretch (wide_rows_persist_kernel)
@@ -2050,11 +2182,11 @@ struct WidePlan final : LassoPlan {
         }, cshard ? nullptr : hflag.p);       // column-sharded: every rank must enqueue the same number of exchanges -> stream-ordered sampling of `done`
         S.t_loop = lt.wall_s; S.loop_ms_events = lt.events_ms; S.xupdate_launches = lt.launched;
         S.exchange_variant = !cshard ? 0 : (!peer_fused ? 1 : (peer_one ? 3 : 2));
-        S.xupdate_variant = screened ? 1 : 0;
+        S.xupdate_variant = !screened ? 0 : (screen_fmt == 8 ? 2 : 1);
         if (q.scr_stat != nullptr) {
             unsigned long long hs[2] = {0, 0};
             ADMM_HIP_CHECK(hipMemcpy(hs, scr_stat.get(), sizeof(hs), hipMemcpyDeviceToHost));
-            std::fprintf(stderr, "[wide screen] %llu columns screened on regular steps, %llu took the exact path (%.3f %%)\n", hs[0], hs[1], hs[0] ? 100.0 * (double)hs[1] / (double)hs[0] : 0.0);
+            std::fprintf(stderr, "[wide screen] %d-bit copy: %llu columns screened on regular steps, %llu took the exact path (%.3f %%)\n", screen_fmt, hs[0], hs[1], hs[0] ? 100.0 * (double)hs[1] / (double)hs[0] : 0.0);
             scr_stat.zero(st);
         }
         if (persist_rows) {

@@ -514,15 +514,15 @@ def config_child(a, name, out_path):
         nnz_start = np.concatenate([[0.0], nnz[:-1]])
         supp_bytes = float((8.0 * n * 0.5 * (nnz_start + nnz) * niter).sum())
         bytes_iter = (4.0 * n * p * reg + supp_bytes) / max(1, tot)
-        screened = int(fit.stats["xupdate_variant"]) == 1
+        screened = int(fit.stats["xupdate_variant"])            # 0 no, 1 fp16 copy, 2 8-bit code
         extra = {"regular_iterations": reg, "nnz_last_lambda": int(nnz[-1]), "persist_iter": int(fit.stats["persist_iter"]),
                  "support_bytes_share": supp_bytes / (4.0 * n * p * reg + supp_bytes),
-                 "regular_steps_screened": screened,
-                 "moved_bytes_per_iteration": ((2.0 if screened else 4.0) * n * p * reg + supp_bytes) / max(1, tot),
+                 "regular_steps_screened": {0: False, 1: "fp16 copy", 2: "8-bit code"}[screened],
+                 "moved_bytes_per_iteration": ({0: 4.0, 1: 2.0, 2: 1.0}[screened] * n * p * reg + supp_bytes) / max(1, tot),
                  "kernel": "wide_x_kernel / wide_rows_persist_kernel (x-update of ADMMLassoWide)",
                  "bytes_note": "per ITERATION averaged over the path: 4np on the regular steps + 8 n nS on every step (nS per lambda = mean of its "
                                "starting and final support sizes; SURVEY section 8(d)).  Screened regular steps (DESIGN.md section 3) prove 'stays zero' "
-                               "from a 2-byte copy of X and move 2np bytes, not 4np: `achieved` prices the ALGORITHMIC bytes, `moved_bytes_per_iteration` "
+                               "from a 1- or 2-byte copy of X and move np / 2np bytes, not 4np: `achieved` prices the ALGORITHMIC bytes, `moved_bytes_per_iteration` "
                                "what the kernels stream"}
     elif name == "c4":
         n, p, K = 10000, 100000, 8

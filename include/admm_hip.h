@@ -85,8 +85,8 @@ typedef struct admm_stats {
     double rho;            /* rho actually used (first lambda) */
     double eig_est;        /* the loose Lanczos value (lambda_max or spectral-radius estimate) */
     int branch;            /* 0 tall (Cholesky), 1 wide (linearised), 2 consensus; 6 admm_parbp (column-block sharing); 7 admm_dantzig */
-    int xupdate_variant;   /* wide path: 1 = the regular steps ran screened (2-byte copy of X + exact step on the few columns the bound does not
-                              settle: bit-identical iterates, 2np instead of 4np bytes), 0 = unscreened;
+    int xupdate_variant;   /* wide path: 1 / 2 = the regular steps ran screened through the fp16 copy / the 8-bit code of X (+ the exact step on the
+                              few columns the bound does not settle: bit-identical iterates, 2np / np instead of 4np bytes), 0 = unscreened;
                               tall path: 0 = full-matrix mat-vec (4p^2 B), 1 = lower-triangle symmetric mat-vec (2p^2 B),
                               2 = the same with the tiles dealt out to the ranks + one all-reduce of 2p floats (admm_hip_lasso_dist),
                               (3, a single-launch iteration, existed in rounds 3 - 5: measured slower, removed in round 6);
@@ -324,8 +324,10 @@ typedef struct admm_hip_options {
     int batch_iters;          /* iterations enqueued between two host polls (0: default 16) */
     int profile_stride;       /* time every k-th x-update launch with HIP events (0: off) */
     int pool_mb;              /* cache of released device blocks: -1 off, 0 default (min(16 GB, memory / 8)), > 0 megabytes */
-    int screen;               /* wide solver and admm_hip_parbp: regular steps screened through a 2-byte copy of the matrix (bit-identical
-                                 iterates, half / a quarter of the bytes): 0 default (when the matrix streams from HBM), 1 always, 2 never */
+    int screen;               /* wide solver and admm_hip_parbp: regular steps screened through a 1- or 2-byte copy of the matrix (bit-identical
+                                 iterates, a quarter to a half of the bytes): 0 default (when the matrix streams from HBM; the wide solver
+                                 picks the 8-bit code where its bounds are tight enough, else fp16), 1 always (fp16), 2 never, 3 always, wide
+                                 solver with the 8-bit code */
     int reserved[11];
 } admm_hip_options;
 ADMM_HIP_API int admm_hip_options_default(admm_hip_options* o);               /* zero-fills and sets struct_size */

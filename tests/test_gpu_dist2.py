@@ -150,7 +150,7 @@ def test_two_process_column_sharded_wide_solver(backend, case):
         assert relerr(res[0]["beta"][:, j], one.beta_dense[:, j]) < 1e-4, j
 
 
-@pytest.mark.parametrize("case,screen", [("widecols", ""), ("widecols_enet", ""), ("widecols", "1"), ("widecols_enet", "1")])
+@pytest.mark.parametrize("case,screen", [("widecols", ""), ("widecols_enet", ""), ("widecols", "16"), ("widecols_enet", "8")])
 def test_two_process_column_sharded_stretch_is_stepwise_clean(case, screen):
     """Round 6: the column-sharded wide solver runs its active-set iterations inside the persistent stretch, A x summed over the ranks
     INSIDE the launch (wide_rows_persist_kernel<true>, AUX region of the PEER exchange).  Held by the stepwise instrument as the
@@ -164,7 +164,7 @@ def test_two_process_column_sharded_stretch_is_stepwise_clean(case, screen):
     from oracle import entry, stepcheck
     sys.path.insert(0, HERE)
     from dist_worker import problem
-    res = _run_ranks("peer", case, extra_env=dict(ADMM_TEST_WIDECOLS_STATE="1", **({"ADMM_HIP_WIDE_SCREEN": "1"} if screen else {})))
+    res = _run_ranks("peer", case, extra_env=dict(ADMM_TEST_WIDECOLS_STATE="1", **({"ADMM_HIP_WIDE_SCREEN": screen} if screen else {})))
     x, y, _, kw = problem(case)
     n, p = x.shape
     d0, d1 = res[0]["dump"], res[1]["dump"]

@@ -17,7 +17,7 @@ def _problem(x, y, nl, lmr, alpha=None):
     return dict(x=x, y=y, lam=None, nlambda=nl, lmin_ratio=lmr, standardize=True, intercept=True, opts=entry.LASSO_OPTS, alpha=alpha)
 
 
-@pytest.mark.parametrize("n,p,m,screen", [(300, 2000, 20, ""), (257, 1031, 10, ""), (500, 500, 15, ""), (300, 2000, 20, "1"), (1500, 4000, 25, "1")])
+@pytest.mark.parametrize("n,p,m,screen", [(300, 2000, 20, ""), (257, 1031, 10, ""), (500, 500, 15, ""), (300, 2000, 20, "16"), (1500, 4000, 25, "16"), (1500, 4000, 25, "8")])
 def test_wide_lasso_path_vs_oracle(n, p, m, screen):
     """12-lambda path judged on the decision trace: the oracle follows the GPU through rounding-level near-ties of the
     stopping test and of the rho adaptation only (helpers.assert_followed_parity); counts identical, every column 1e-4.
@@ -30,7 +30,7 @@ def test_wide_lasso_path_vs_oracle(n, p, m, screen):
         options.set(WIDE_SCREEN=screen)                          # (reset after every test: conftest.py)
     # the follow rule AND the stepwise rule on the iterate dump (helpers.traced_parity -> wide_stepwise)
     fit, rep = traced_parity(admm_lasso(x, y).penalty(nlambda=12, lambda_min_ratio=lmr), _problem(x, y, 12, lmr), TOL, label=f"wide n={n} p={p}")
-    assert fit.stats["branch"] == 1 and fit.stats["xupdate_variant"] == (1 if screen else 0)
+    assert fit.stats["branch"] == 1 and fit.stats["xupdate_variant"] == {"": 0, "16": 1, "8": 2}[screen]
     ref = rep["ref"]
     assert np.allclose(fit.lambda_, ref["lambda"], rtol=1e-5)
     # support agreement
@@ -50,7 +50,7 @@ def test_wide_spectral_radius_estimate():
     assert abs(fit.stats["eig_est"] - float(d["solver"].sprad)) < 1e-4 * float(d["solver"].sprad)
 
 
-@pytest.mark.parametrize("screen", ["", "1"])
+@pytest.mark.parametrize("screen", ["", "16", "8"])
 def test_wide_enet_path_vs_oracle(screen):
     from admm_amd import admm_enet, options
     x, y = synth_lasso(250, 900, 12, seed=31)
@@ -150,25 +150,27 @@ def _wide_fit(x, y, enet, **opt):
         return traced_fit(m)
 
 
+@pytest.mark.parametrize("fmt", ["16", "8"])
 @pytest.mark.parametrize("n,p,enet", [(300, 3000, False), (900, 5000, True), (1500, 6000, False), (2000, 9000, True), (3000, 5000, False), (5000, 5600, False), (7600, 8000, True)])
-def test_screened_regular_steps_are_bit_identical(n, p, enet):
+def test_screened_regular_steps_are_bit_identical(n, p, enet, fmt):
     """The regular steps' safe screen (wide_x_kernel: a product with the fp16-rounded column proves "stays zero" for all but a few
-    columns; every other column takes the exact float step) must not change a single bit: the same path with WIDE_SCREEN=1 and =0
+    columns -- or, fmt 8, with its linear 8-bit code; every other column takes the exact float step) must not change a single bit: the same path with WIDE_SCREEN=16 / 8 and =0
     -- coefficients, iteration counts and every record of the decision trace (residuals, thresholds, rho) identical.  All five
     register layouts of the fused x-update (n <= 1024 / 2048 / 4096 / 6144 / 8192), lasso (double compare) and elastic net (float
     compare).  The screened run is then also held to the oracle by the trace rule like every other variant."""
     x, y = synth_lasso(n, p, 15, seed=211 + n)
-    on, tr_on = _wide_fit(x, y, enet, WIDE_SCREEN="1")
+    on, tr_on = _wide_fit(x, y, enet, WIDE_SCREEN=fmt)
     off, tr_off = _wide_fit(x, y, enet, WIDE_SCREEN="0")
-    assert on.stats["xupdate_variant"] == 1 and off.stats["xupdate_variant"] == 0 and on.stats["branch"] == 1
+    assert on.stats["xupdate_variant"] == (2 if fmt == "8" else 1) and off.stats["xupdate_variant"] == 0 and on.stats["branch"] == 1
     assert list(on.niter) == list(off.niter)
     assert np.array_equal(on.beta_dense, off.beta_dense)
     assert tr_on.shape == tr_off.shape and np.array_equal(tr_on, tr_off)
     assert sum(on.niter) > 100
 
 
+@pytest.mark.parametrize("fmt", ["16", "8"])
 @pytest.mark.parametrize("case", ["huge", "tiny", "mixed", "nan_free_inf_round"])
-def test_screen_with_values_fp16_cannot_hold(case):
+def test_screen_with_values_fp16_cannot_hold(case, fmt):
     """Columns whose entries overflow fp16 (|x| > 65504: stored as zero in the copy, the whole entry counted as rounding error), fall
     into its subnormal range or underflow to zero, without standardisation: still bit-identical to the unscreened run."""
     rng = np.random.default_rng(5)
@@ -190,9 +192,9 @@ def test_screen_with_values_fp16_cannot_hold(case):
     y = x @ beta + 0.1 * rng.standard_normal(n) * np.abs(x @ beta).mean()
     from admm_amd import admm_lasso, options
     fits = {}
-    for scr in ("1", "0"):
+    for scr in (fmt, "0"):
         with options(WIDE_SCREEN=scr):
             fits[scr] = traced_fit(admm_lasso(x, y, standardize=False).penalty(nlambda=8, lambda_min_ratio=0.05).opts(maxit=400))
-    (on, tr_on), (off, tr_off) = fits["1"], fits["0"]
-    assert on.stats["xupdate_variant"] == 1
+    (on, tr_on), (off, tr_off) = fits[fmt], fits["0"]
+    assert on.stats["xupdate_variant"] == (2 if fmt == "8" else 1)
     assert list(on.niter) == list(off.niter) and np.array_equal(on.beta_dense, off.beta_dense) and np.array_equal(tr_on, tr_off)
