@@ -2043,14 +2043,14 @@ struct WidePlan final : LassoPlan {
     }
 
     // Safe screening of the regular steps (wide_x_kernel): worth its copy when X is a stream from HBM at all (beyond the Infinity Cache
-    // the regular step is bandwidth, below it launch latency).  WIDE_SCREEN = 0 never, 1 / 16 the fp16 copy, 8 the 8-bit code (tests);
+    // the regular step is bandwidth, below it launch latency).  WIDE_SCREEN = 0 never, 1 / 16 the fp16 copy, 8 the 8-bit code, auto = the default's choice at any size (tests);
     // default: the 8-bit code when its bounds are tight enough on these columns (wide_screen_rate8_kernel: mean r_j <= 0.6), else
     // fp16.  When the copy does not fit the device the solver simply runs unscreened.
     void setup_screen() {
         const size_t xbytes = (size_t)d.ldx * (size_t)p * sizeof(float);
         if (fuse_rt == 0) return;
         int fmt = xbytes >= ((size_t)256 << 20) ? -1 : 0;                // -1: choose
-        if (const char* e = option("WIDE_SCREEN")) { const int v = std::atoi(e); fmt = v == 0 ? 0 : (v == 8 ? 8 : 16); }
+        if (const char* e = option("WIDE_SCREEN")) { const int v = std::atoi(e); fmt = std::string(e) == "auto" ? -1 : (v == 0 ? 0 : (v == 8 ? 8 : 16)); }
         if (fmt == 0 || d.ldx % 16 != 0) return;
         if (fmt < 0) {
             const int nb = (p + 3) / 4;

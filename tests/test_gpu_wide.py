@@ -198,3 +198,22 @@ def test_screen_with_values_fp16_cannot_hold(case, fmt):
     (on, tr_on), (off, tr_off) = fits[fmt], fits["0"]
     assert on.stats["xupdate_variant"] == (2 if fmt == "8" else 1)
     assert list(on.niter) == list(off.niter) and np.array_equal(on.beta_dense, off.beta_dense) and np.array_equal(tr_on, tr_off)
+
+
+def test_screen_picks_the_copy_by_the_columns_at_hand():
+    """The default's choice (WIDE_SCREEN=auto: the same rule at any size): Gaussian-looking columns take the 8-bit code, columns with
+    outliers -- which waste a linear code's range: its bounds would send a large share of the columns down the exact path -- the fp16
+    copy.  Either way the result is the unscreened one."""
+    from admm_amd import admm_lasso, options
+    rng = np.random.default_rng(3)
+    n, p = 600, 4000
+    x, y = synth_lasso(n, p, 15, seed=77)
+    xo = x.copy()
+    xo[rng.integers(0, n, p), np.arange(p)] *= 400.0              # one outlier per column
+    for data, want in ((x, 2), (xo, 1)):
+        with options(WIDE_SCREEN="auto"):
+            a = admm_lasso(data, y).penalty(nlambda=6, lambda_min_ratio=0.05).fit()
+        with options(WIDE_SCREEN="0"):
+            b = admm_lasso(data, y).penalty(nlambda=6, lambda_min_ratio=0.05).fit()
+        assert a.stats["xupdate_variant"] == want and b.stats["xupdate_variant"] == 0
+        assert np.array_equal(a.beta_dense, b.beta_dense) and list(a.niter) == list(b.niter)
