@@ -59,8 +59,10 @@ if "c3" in which:       # wide Lasso n=2000 p=200000, 100-lambda path (lambda_mi
     # iteration, so only the regular-step stream is counted here (lower bound of the traffic)
     niter = fit.niter.astype(np.int64)
     reg = sum(int(sum(1 for c in range(k) if (c + 1) & c == 0 and ((c + 1) & 0x55555555))) for k in niter)
-    report("C3 admm_lasso wide n=2000 p=200000 nlambda=100", fit, 4.0 * n * p * reg / max(1, int(niter.sum())),
-           {"regular_iterations": reg, "nnz_last_lambda": nnz, "niter_minmax": [int(niter.min()), int(niter.max())]})
+    scr = int(fit.stats["xupdate_variant"])                     # regular steps screened: 0 no (4np), 1 fp16 copy (2np), 2 8-bit code (np)
+    report("C3 admm_lasso wide n=2000 p=200000 nlambda=100", fit, {0: 4.0, 1: 2.0, 2: 1.0}[scr] * n * p * reg / max(1, int(niter.sum())),
+           {"regular_iterations": reg, "nnz_last_lambda": nnz, "niter_minmax": [int(niter.min()), int(niter.max())],
+            "regular_steps_screened": {0: False, 1: "fp16 copy", 2: "8-bit code"}[scr]})
     del xt
     torch.cuda.empty_cache()
 if "c4" in which:       # consensus Lasso n=10000 p=100000, 8 row blocks on ONE GPU (Woodbury branch), short path
@@ -96,10 +98,11 @@ if "c5parbp" in which:  # the same problem by the column-block sharing solver (a
         it = int(fit.stats["total_iter"])
         # algorithmic bytes: a regular iteration (every 10th) reads the whole matrix once, 8np; an active-set iteration the non-zero columns twice
         reg = (it + 9) // 10
-        report(f"C5 admm_bp$parallel({nb}) n=5000 p=50000 fp64 (sharing ADMM)", fit, 8.0 * n * p * reg / max(it, 1),
+        scr = int(fit.stats["xupdate_variant"]) >= 4            # regular iterations screened through the fp16 copy (2np instead of 8np)
+        report(f"C5 admm_bp$parallel({nb}) n=5000 p=50000 fp64 (sharing ADMM)", fit, (2.0 if scr else 8.0) * n * p * reg / max(it, 1),
                {"recovery_error_range": [float(err.min()), float(err.max())], "regular_iterations": reg, "nnz": int(np.count_nonzero(beta)),
                 "lanczos_steps": int(fit.stats["xupdate_samples"]), "rho": fit.stats["rho"],
-                "active_set_variant": int(fit.stats["xupdate_variant"]), "gram_space_stretches": int(fit.stats["xupdate_launches"]), "rebuilds_of_U": int(fit.stats["persist_iter"])})
+                "active_set_variant": int(fit.stats["xupdate_variant"]) & 3, "regular_iterations_screened": scr, "gram_space_stretches": int(fit.stats["xupdate_launches"]), "rebuilds_of_U": int(fit.stats["persist_iter"])})
 if "dantzig" in which:  # Dantzig selector (admm_hip_dantzig, the reference's unbuilt TODO/ADMMDantzig.h), operator form: n = 50 000, p = 2000 fp64
     n, p = 50000, 2000
     xt, y, _ = gen(n, p, 2.0, 100)
