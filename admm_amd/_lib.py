@@ -25,7 +25,7 @@ class AdmmHipOptions(ctypes.Structure):
     _fields_ = [(k, ctypes.c_int) for k in (
         "struct_size", "gram_backend", "gram_split", "factor_backend", "inverse_precision", "tall_xupdate", "tall_refine",
         "consensus_two_pass", "consensus_unfused", "bp_two_pass", "lad_no_hat", "wide_no_persist", "wide_unfused", "wide_gram_sprad",
-        "sharing_bp_direct", "cv_downdate", "peer_exchange", "batch_iters", "profile_stride", "pool_mb", "screen")] + [("reserved", ctypes.c_int * 11)]
+        "sharing_bp_direct", "cv_downdate", "peer_exchange", "batch_iters", "profile_stride", "pool_mb", "screen", "lad_two_pass")] + [("reserved", ctypes.c_int * 10)]
 
 
 class AdmmStats(ctypes.Structure):

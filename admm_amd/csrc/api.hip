@@ -955,6 +955,7 @@ int admm_hip_options_set(const admm_hip_options* o) {
         if (v.batch_iters > 0) num("BATCH_ITERS", v.batch_iters);
         if (v.profile_stride > 0) num("PROFILE_STRIDE", v.profile_stride);
         if (v.pool_mb) num("POOL_MB", v.pool_mb < 0 ? 0 : v.pool_mb);
+        if (v.lad_two_pass) set("LAD_ONEPASS", "0");
         if (v.screen) {
             ADMM_REQUIRE(v.screen >= 1 && v.screen <= 3, "options: screen");
             set("WIDE_SCREEN", v.screen == 1 ? "16" : (v.screen == 3 ? "8" : "0"));

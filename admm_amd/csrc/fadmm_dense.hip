@@ -48,6 +48,17 @@ struct DenseParams {
     const double* w0;
     double *Bz0, *Bz1, *By0, *By1, *Badjy, *w;
     const double* gpart; int gngroups; long long gpstride;
+    // LAD, one-pass form (round 6; lp = 0: the two-pass form).  The projection needs X'vec with vec = d - adj_y / rho + adj_z, and adj_z /
+    // adj_y are the accelerate / restart combinations of the two latest z / y: X'vec is the same combination of the p-vectors X'd
+    // (fixed), X'z and X'y of the two latest iterates -- and X'z_new, X'y_new can be formed by the launch that produces z_new, y_new:
+    // lad_rows_kernel streams the ROWS of X once, forms x_i = row_i . s, the prox and the dual for that row, and adds row_i z_i,
+    // row_i y_i to its partials of X'z, X'y.  One pass over X per iteration instead of two (X'vec, then X s); the p-vectors are direct
+    // products of the current iterates, not recurrences: nothing accumulates.
+    int lp;
+    const double* Xd;                         // X'd [lp]
+    double *Xz0, *Xz1, *Xy0, *Xy1;            // X'z, X'y in the slots of z0 / z1, y0 / y1
+    double* u;                                // X'vec of this iteration
+    const double* cpart; int cnwg; long long cstride;      // the rows launch's partials: [cnwg][2][cstride] (X'z_new | X'y_new)
 };
 
 constexpr int kDenseThreads = 256;
@@ -165,6 +176,155 @@ dense_head_kernel(DenseParams q, int par) {
             q.w[i] = badjz - badjy / rho;
         }
     }
+    if (q.lp > 0) {
+        // X'z, X'y of the iterate the rows launch has just produced (its partials summed in workgroup order) into the `cur` slots, then
+        // u = X'vec as the combination the adj vectors above are of z / y
+        double* Xzc = cur ? q.Xz1 : q.Xz0; double* Xyc = cur ? q.Xy1 : q.Xy0;
+        const double* Xzo = cur ? q.Xz0 : q.Xz1; const double* Xyo = cur ? q.Xy0 : q.Xy1;
+        for (int i = blockIdx.x * kDenseThreads + threadIdx.x; i < q.lp; i += gridDim.x * kDenseThreads) {
+#pragma clang fp contract(off)
+            double xz = 0.0, xy = 0.0;
+            for (int w0 = 0; w0 < q.cnwg; w0 += 8) {
+                double tz[8], ty[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const size_t w = (size_t)min(w0 + k, q.cnwg - 1);
+                    tz[k] = q.cpart[(w * 2) * q.cstride + i]; ty[k] = q.cpart[(w * 2 + 1) * q.cstride + i];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { xz += w0 + k < q.cnwg ? tz[k] : 0.0; xy += w0 + k < q.cnwg ? ty[k] : 0.0; }
+            }
+            if (in.first) { xz = 0.0; xy = 0.0; }
+            const double xzo = Xzo[i], xyo = Xyo[i];
+            Xzc[i] = xz; Xyc[i] = xy;
+            double xadjz, xadjy;
+            if (out.restart) { xadjz = xzo; xadjy = xyo; }
+            else { xadjz = t1 * xz - t * xzo; xadjy = t1 * xy - t * xyo; }
+            q.u[i] = q.Xd[i] - xadjy / rho + xadjz;
+        }
+    }
+}
+
+// LAD one-pass form: the rows of X (the stored transpose: row i is ld contiguous doubles) streamed ONCE.  A workgroup of eight waves
+// owns a run of rows and takes them R at a time: every thread holds its 2 NPT columns of the R rows, the lanes' partial dots go through
+// one halving butterfly per wave and the eight waves' sums through LDS (waves in order: a fixed order), every thread then knows
+// x_i = row_i . s and forms z_i, y_i as the tail kernel does (same expressions, no contraction: the stepwise instrument replays them bit
+// for bit), thread 0 stores them and adds up the six norms, and every thread adds row_i z_i, row_i y_i to its columns of X'z, X'y.
+// The next R rows are requested before the current ones are reduced.
+constexpr int kLadThreads = 512;
+constexpr int kLadRows = 4;
+template <int NPT>
+__global__ void __launch_bounds__(kLadThreads)
+lad_rows_kernel(DenseParams q, int par, const double* __restrict__ Xt, long long ld, const double* __restrict__ spart, int snseg, long long sstride,
+                double* __restrict__ cpart, int rows_per_wg) {
+    constexpr int R = NPT <= 4 ? kLadRows : 2, NWV = kLadThreads / 64;      // (beyond 4096 columns two rows at a time: the registers hold two groups of rows)
+    __shared__ double wsum[2][NWV][R];
+    const DenseCtl c = load_ctl_vector(q.ctl + (par ^ 1));           // written by this iteration's head
+    if (c.done) return;
+    const int cur = (c.total - 1) & 1;
+    const double* zc_ = cur ? q.z1 : q.z0;
+    double* zn_ = cur ? q.z0 : q.z1; double* yn_ = cur ? q.y0 : q.y1;
+    const double rho = c.rho, pen = 1.0 / rho;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int row_lo = blockIdx.x * rows_per_wg, row_hi = min(q.dim, row_lo + rows_per_wg);
+    double2 sv[NPT], az[NPT], ay[NPT];
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+        const long long col = ((long long)k * kLadThreads + tid) * 2;
+        double2 a = make_double2(0.0, 0.0);
+        if (col < ld) for (int g = 0; g < snseg; ++g) { const double2 v = *reinterpret_cast<const double2*>(spart + (size_t)g * sstride + col); a.x += v.x; a.y += v.y; }
+        if (col >= q.lp) a.x = 0.0;
+        if (col + 1 >= q.lp) a.y = 0.0;
+        sv[k] = a; az[k] = make_double2(0.0, 0.0); ay[k] = make_double2(0.0, 0.0);
+    }
+    auto load_rows = [&](int i0, double2 (&rv)[R][NPT]) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const double* row = Xt + (size_t)min(i0 + r, q.dim - 1) * ld;       // clamped: rows beyond the run are weighted with zero below
+#pragma unroll
+            for (int k = 0; k < NPT; ++k) {
+                const long long col = ((long long)k * kLadThreads + tid) * 2;
+                rv[r][k] = col < ld ? load16_nt<double2>(row + col) : make_double2(0.0, 0.0);
+            }
+        }
+    };
+    double nacc[6] = {0, 0, 0, 0, 0, 0};
+    double2 ra[R][NPT], rb[R][NPT];
+    int buf = 0;
+    auto group = [&](int i0, const double2 (&rv)[R][NPT]) {
+        // the four vectors' entries of the R rows (the same addresses in every lane), requested before the reduction
+        double dv[R], ajy[R], ajz[R], zc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = min(i0 + r, q.dim - 1);
+            dv[r] = q.data_vec[i]; ajy[r] = q.adj_y[i]; ajz[r] = q.adj_z[i]; zc[r] = zc_[i];
+        }
+        double v8[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v8[r] = 0.0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            double d = 0.0;
+#pragma unroll
+            for (int k = 0; k < NPT; ++k) { d = fma(rv[r][k].x, sv[k].x, d); d = fma(rv[r][k].y, sv[k].y, d); }
+            v8[r] = d;
+        }
+        const double tot = halving_sum8(v8, lane);                   // lane 8 r: the wave's sum of row r
+        if ((lane & 7) == 0 && (lane >> 3) < R) wsum[buf][wid][lane >> 3] = tot;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = i0 + r;
+            if (i >= row_hi) break;                                  // uniform
+            double x = wsum[buf][0][r];
+#pragma unroll
+            for (int w = 1; w < NWV; ++w) x += wsum[buf][w][r];
+            double zn, yn;
+            {
+#pragma clang fp contract(off)
+                zn = soft1(x - dv[r] + ajy[r] / rho, pen);           // dense_tail_kernel, prob 0 (ADMMLAD.h:94-107)
+                const double rr = x - dv[r] - zn;
+                yn = ajy[r] + rho * rr;
+                if (tid == 0) {
+                    const double dz = zn - zc[r], daz = zn - ajz[r];
+                    nacc[0] += rr * rr; nacc[1] += dz * dz; nacc[2] += daz * daz; nacc[3] += x * x; nacc[4] += zn * zn; nacc[5] += yn * yn;
+                    q.x[i] = x; zn_[i] = zn; yn_[i] = yn;
+                    if (q.state != nullptr && c.total < q.state_cap) {
+                        double* s = q.state + (size_t)c.total * 5 * q.dim;
+                        s[i] = x; s[(size_t)q.dim + i] = zn; s[2 * (size_t)q.dim + i] = yn; s[3 * (size_t)q.dim + i] = ajz[r]; s[4 * (size_t)q.dim + i] = ajy[r];
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NPT; ++k) {
+                az[k].x = fma(rv[r][k].x, zn, az[k].x); az[k].y = fma(rv[r][k].y, zn, az[k].y);
+                ay[k].x = fma(rv[r][k].x, yn, ay[k].x); ay[k].y = fma(rv[r][k].y, yn, ay[k].y);
+            }
+        }
+        buf ^= 1;                                                    // (the next group writes the other half of wsum: one barrier per group)
+    };
+    if (row_lo < row_hi) {
+        load_rows(row_lo, ra);
+        for (int i0 = row_lo; i0 < row_hi; i0 += 2 * R) {
+            if (i0 + R < row_hi) load_rows(i0 + R, rb);
+            group(i0, ra);
+            if (i0 + R >= row_hi) break;
+            if (i0 + 2 * R < row_hi) load_rows(i0 + 2 * R, ra);
+            group(i0 + R, rb);
+        }
+    }
+    double* cz = cpart + ((size_t)blockIdx.x * 2) * q.cstride;
+    double* cy = cz + q.cstride;
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+        const long long col = ((long long)k * kLadThreads + tid) * 2;
+        if (col < q.cstride) { *reinterpret_cast<double2*>(cz + col) = az[k]; *reinterpret_cast<double2*>(cy + col) = ay[k]; }
+    }
+    if (tid == 0) {
+        double* Pout = q.P + (size_t)blockIdx.x * 8;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) Pout[k] = nacc[k];
+    }
 }
 
 // BP one-pass form: B z_new for the z the tail of this iteration just wrote (gather over its non-zeros)
@@ -258,10 +418,11 @@ struct DenseLoop {
     int nwg_head = 0;
     DevBuf<double> trace, state;
 
-    void init(int dim, int prob, const admm_opts& o, const double* data_vec, double extra_norm, hipStream_t st, long long trace_cap = 0, long long state_cap = 0) {
+    void init(int dim, int prob, const admm_opts& o, const double* data_vec, double extra_norm, hipStream_t st, long long trace_cap = 0, long long state_cap = 0,
+              int norm_rows = 0) {      // norm_rows > 0: that many rows of norm partials (the launch that forms them is not dense_tail_kernel)
         const long long ld = round_up(dim, 32);
         for (DevBuf<double>* b : {&x, &z0, &z1, &y0, &y1, &adj_z, &adj_y, &vec}) { b->alloc(ld); b->zero(st); }
-        const int nwg_tail = std::max(1, std::min(64, (dim + kDenseThreads - 1) / kDenseThreads));
+        const int nwg_tail = norm_rows > 0 ? norm_rows : std::max(1, std::min(64, (dim + kDenseThreads - 1) / kDenseThreads));
         nwg_head = std::max(1, std::min(device_info().num_cu, (dim + kDenseThreads - 1) / kDenseThreads));
         P.alloc((size_t)nwg_tail * 8); ctl.alloc(2); done.alloc(1);
         q.dim = dim; q.prob = prob; q.maxit = o.maxit; q.nwg_tail = nwg_tail;
@@ -372,8 +533,15 @@ void solve_lad(const DeviceData<double>& d, const admm_opts& opts, DenseResult& 
     ADMM_HIP_CHECK(hipMemcpyAsync(&ynorm, ynorm_d.get(), sizeof(double), hipMemcpyDeviceToHost, st));
     ADMM_HIP_CHECK(hipStreamSynchronize(st));
 
+    // general branch, one-pass form (DenseParams::lp): X streamed once per iteration by rows.  LAD_ONEPASS=0: the reference's two products.
+    constexpr int kLadMaxCols = 2 * kLadThreads * 6;             // 6144 columns: six double2 per thread and row (more would spill)
+    bool onepass = !hat && p <= kLadMaxCols;
+    if (const char* e = option("LAD_ONEPASS")) onepass = onepass && std::string(e) != "0";
+    const int lad_nwg = std::max(1, std::min(device_info().num_cu, (n + 2 * kLadRows - 1) / (2 * kLadRows)));
+    const int lad_rows = (int)round_up((n + lad_nwg - 1) / lad_nwg, kLadRows);
+
     DenseLoop L;
-    L.init(n, 0, opts, d.Y.get(), ynorm, st, res.trace_cap, res.state_cap);
+    L.init(n, 0, opts, d.Y.get(), ynorm, st, res.trace_cap, res.state_cap, onepass ? lad_nwg : 0);
     GemvT<double> g1, g2, g3, gH;                // t = X' vec ; s = (X'X)^-1 t ; xs = X s ;  or xs = H vec
     g1.init(d.X.get(), d.ldx, n, p);
     g2.init(M.get(), ldp, p, p);
@@ -403,18 +571,45 @@ void solve_lad(const DeviceData<double>& d, const admm_opts& opts, DenseResult& 
         gH.init(H.get(), ldh, n, n);
         gH.set_nt(gemv_stream_nt(gH.bytes()));
         L.q.gout = gH.part.get(); L.q.gout_nseg = gH.pl.nseg; L.q.gout_stride = gH.stride;
-    } else {
+    } else if (!onepass) {
         g3.init(Xt.get(), ldxt, p, n);
         const bool nt = gemv_stream_nt(g1.bytes() + g2.bytes() + g3.bytes());        // per iteration: X', the inverse, X
         g1.set_nt(nt); g2.set_nt(nt); g3.set_nt(nt);
         L.q.gout = g3.part.get(); L.q.gout_nseg = g3.pl.nseg; L.q.gout_stride = g3.stride;
     }
+    DevBuf<double> Xd, Xz0, Xz1, Xy0, Xy1, uvec, cpart;
+    if (onepass) {
+        g2.set_nt(gemv_stream_nt(g1.bytes() + g2.bytes()));
+        for (DevBuf<double>* b : {&Xd, &Xz0, &Xz1, &Xy0, &Xy1, &uvec}) { b->alloc(ldp); b->zero(st); }
+        cpart.alloc((size_t)lad_nwg * 2 * ldp); cpart.zero(st);
+        g1.run(d.Y.get(), Xd.get(), nullptr, st);                // X'd, once
+        L.q.lp = p; L.q.Xd = Xd.get(); L.q.Xz0 = Xz0.get(); L.q.Xz1 = Xz1.get(); L.q.Xy0 = Xy0.get(); L.q.Xy1 = Xy1.get(); L.q.u = uvec.get();
+        L.q.cpart = cpart.get(); L.q.cnwg = lad_nwg; L.q.cstride = ldp;
+    }
+    auto launch_rows = [&](long long g) {
+        const int par = (int)(g & 1);
+        const int npt = (int)((ldxt / 2 + kLadThreads - 1) / kLadThreads);
+#define ADMM_LAD_ROWS(N) hipLaunchKernelGGL((lad_rows_kernel<N>), dim3(lad_nwg), dim3(kLadThreads), 0, st, L.q, par, Xt.get(), ldxt, g2.part.get(), g2.pl.nseg, g2.stride, cpart.get(), lad_rows)
+        switch (npt) {
+            case 1: ADMM_LAD_ROWS(1); break;
+            case 2: ADMM_LAD_ROWS(2); break;
+            case 3: ADMM_LAD_ROWS(3); break;
+            case 4: ADMM_LAD_ROWS(4); break;
+            case 5: ADMM_LAD_ROWS(5); break;
+            default: ADMM_LAD_ROWS(6); break;
+        }
+#undef ADMM_LAD_ROWS
+    };
 
     const int* skip = L.done.get();
     LoopTimes lt = run_until_done(st, skip, env_batch(8), (long long)opts.maxit + 2, [&](long long g) {
         L.head(g, st);
         if (hat) {
             gH.run_partials(L.vec.get(), skip, st);          // dsymv(H, vec)
+        } else if (onepass) {
+            g2.run_partials(uvec.get(), skip, st);           // s = (X'X)^-1 u, u = X'vec formed by the head from X'd, X'z, X'y
+            launch_rows(g);                                   // x = X s, z, y, norms, X'z_new, X'y_new: one pass over the rows of X
+            return;
         } else {
             g1.run_partials(L.vec.get(), skip, st);          // chained: the next product sums these partial rows while staging
             g2.run_partials_from(g1, skip, st);
@@ -427,6 +622,7 @@ void solve_lad(const DeviceData<double>& d, const admm_opts& opts, DenseResult& 
     const DenseCtl fc = L.final_ctl(st);
     res.niter = fc.niter;
     S.total_iter = fc.niter; S.rho = fc.rho;
+    S.xupdate_variant = onepass ? 1 : 0;
     dense_collect_trace(L, fc, res, st);
     // get_x(): beta = (X'X)^-1 X' (y - adj_y/rho + adj_z) with the final adj and rho (ADMMLAD.h:220-225)
     hipLaunchKernelGGL(lad_final_vec_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d.Y.get(), L.adj_y.get(), L.adj_z.get(), fc.rho, n, L.vec.get());

@@ -546,8 +546,16 @@ def config_child(a, name, out_path):
         model = admm_lad(DevicePtr(xt.data_ptr()), DevicePtr(y.data_ptr()), intercept=False, n=n, p=p)
         model.fit()
         fit = model.fit()
-        bytes_iter = 16.0 * n * p + 8.0 * p * p
-        extra = {"kernel": "gemv_t_kernel<double> (X' v, (X'X)^-1 t, X s: ADMMLAD.h:75-76)"}
+        # round 6, one-pass form: the rows of X stream ONCE per iteration (x = X s, prox, dual, X'z_new, X'y_new from the same rows;
+        # X'vec from p-vectors); SURVEY section 8(d) prices the reference's two products with X
+        onepass = int(fit.stats["xupdate_variant"]) == 1
+        bytes_iter = (8.0 if onepass else 16.0) * n * p + 8.0 * p * p
+        survey_bytes = 16.0 * n * p + 8.0 * p * p
+        extra = {"kernel": "lad_rows_kernel (x = X s, z, y, norms, X'z, X'y in one pass over the rows of X) + gemv_t_kernel<double> ((X'X)^-1 u)" if onepass
+                           else "gemv_t_kernel<double> (X' v, (X'X)^-1 t, X s: ADMMLAD.h:75-76)",
+                 "one_pass": onepass,
+                 "bytes_note": "per ITERATION (all launches of one ADMM iteration), HIP events around the loop: X once (8np) + the inverse (8p^2) in the one-pass form"
+                               if onepass else "per ITERATION (all launches of one ADMM iteration), HIP events around the loop"}
     elif name in ("c5bp", "c5parbp"):
         n, p = 5000, 50000
         xt, y, b = _gen_device(torch, dev, g, n, p, 1.0, 500, noise=False)

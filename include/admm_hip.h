@@ -85,7 +85,8 @@ typedef struct admm_stats {
     double rho;            /* rho actually used (first lambda) */
     double eig_est;        /* the loose Lanczos value (lambda_max or spectral-radius estimate) */
     int branch;            /* 0 tall (Cholesky), 1 wide (linearised), 2 consensus; 6 admm_parbp (column-block sharing); 7 admm_dantzig */
-    int xupdate_variant;   /* wide path: 1 / 2 = the regular steps ran screened through the fp16 copy / the 8-bit code of X (+ the exact step on the
+    int xupdate_variant;   /* admm_hip_lad: 1 = one pass over the rows of X per iteration (general branch, p <= 6144), 0 = two products / hat matrix;
+                              wide path: 1 / 2 = the regular steps ran screened through the fp16 copy / the 8-bit code of X (+ the exact step on the
                               few columns the bound does not settle: bit-identical iterates, 2np / np instead of 4np bytes), 0 = unscreened;
                               tall path: 0 = full-matrix mat-vec (4p^2 B), 1 = lower-triangle symmetric mat-vec (2p^2 B),
                               2 = the same with the tiles dealt out to the ranks + one all-reduce of 2p floats (admm_hip_lasso_dist),
@@ -328,7 +329,8 @@ typedef struct admm_hip_options {
                                  iterates, a quarter to a half of the bytes): 0 default (when the matrix streams from HBM; the wide solver
                                  picks the 8-bit code where its bounds are tight enough, else fp16), 1 always (fp16), 2 never, 3 always, wide
                                  solver with the 8-bit code */
-    int reserved[11];
+    int lad_two_pass;         /* 1: LAD with the reference's two products per iteration (default: one pass over the rows of X, p <= 6144) */
+    int reserved[10];
 } admm_hip_options;
 ADMM_HIP_API int admm_hip_options_default(admm_hip_options* o);               /* zero-fills and sets struct_size */
 ADMM_HIP_API int admm_hip_options_set(const admm_hip_options* o);             /* NULL: back to the defaults (keeps nothing of the thread's earlier settings) */

@@ -34,6 +34,30 @@ def test_lad_general_branch_vs_oracle(intercept):
     dense_stepwise("lad", fit, x, y, entry.LAD_OPTS, intercept=intercept, label=f"LAD n=3000 icpt={int(intercept)}")
 
 
+
+@pytest.mark.parametrize("n,p,maxit", [(3001, 60, 10000), (2600, 1100, 60), (4100, 2300, 30), (4300, 3300, 25), (5203, 4200, 25), (6200, 5300, 20), (12000, 6200, 12)])
+@pytest.mark.parametrize("onepass", ["1", "0"])
+def test_lad_one_pass_and_two_pass_forms_vs_oracle(n, p, maxit, onepass):
+    """The general branch in both forms: round 6's one pass over the ROWS of X per iteration (lad_rows_kernel: x = X s, the prox, the dual
+    and X'z_new, X'y_new from the same rows; X'vec from the p-vectors X'd, X'z, X'y) and the reference's two products (LAD_ONEPASS=0).
+    Every register layout of the rows kernel (1 ... 6 double2 per thread and row; 6200 columns are beyond it: two-pass either way), ragged
+    row runs; each form held to the oracle by the follow rule at 1e-8 and by the stepwise instrument (adj, z, y bit for bit; the projection
+    against Householder QR)."""
+    from admm_amd import admm_lad, options
+    from oracle import entry
+    rng = np.random.default_rng(100 + p)
+    x = rng.standard_normal((n, p)) * 2 + 0.3
+    b = rng.uniform(size=p) / np.sqrt(p)
+    y = x @ b + rng.standard_t(3, size=n) + 1.5
+    opts = dict(entry.LAD_OPTS, maxit=maxit)
+    with options(LAD_ONEPASS=onepass):
+        fit = admm_lad(x, y, intercept=True).opts(maxit=maxit).fit(trace=True, state=dense_state_records(n, maxit))
+    assert fit.stats["xupdate_variant"] == (1 if onepass == "1" and p <= 6144 else 0)
+    label = f"LAD n={n} p={p} onepass={onepass}"
+    assert_dense_followed("lad", fit.beta, fit.niter, fit.trace, x, y, opts, intercept=True, tol=1e-8, label=label)
+    dense_stepwise("lad", fit, x, y, opts, intercept=True, label=label)
+
+
 def test_readme_bp_fixture():
     from admm_amd import admm_bp
     from oracle import entry, readme
