@@ -181,19 +181,27 @@ dense_head_kernel(DenseParams q, int par) {
         // u = X'vec as the combination the adj vectors above are of z / y
         double* Xzc = cur ? q.Xz1 : q.Xz0; double* Xyc = cur ? q.Xy1 : q.Xy0;
         const double* Xzo = cur ? q.Xz0 : q.Xz1; const double* Xyo = cur ? q.Xy0 : q.Xy1;
-        for (int i = blockIdx.x * kDenseThreads + threadIdx.x; i < q.lp; i += gridDim.x * kDenseThreads) {
+        // eight lanes share an element: lane `sub` adds the partial rows sub, sub + 8, ... (eight requests of each vector in flight), the eight
+        // sums are added in a fixed order -- one memory round trip per 64 partial rows instead of one per 8
+        const int sub = threadIdx.x & 7;
+        const int epb = kDenseThreads / 8;                                // elements per block and pass
+        for (int i0 = blockIdx.x * epb; i0 < q.lp; i0 += gridDim.x * epb) {
 #pragma clang fp contract(off)
+            const int i = min(i0 + (int)(threadIdx.x >> 3), q.lp - 1);    // (clamped: whole groups of eight lanes take part in the exchange)
             double xz = 0.0, xy = 0.0;
-            for (int w0 = 0; w0 < q.cnwg; w0 += 8) {
+            for (int w0 = sub; w0 < q.cnwg; w0 += 64) {
                 double tz[8], ty[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    const size_t w = (size_t)min(w0 + k, q.cnwg - 1);
+                    const size_t w = (size_t)min(w0 + 8 * k, q.cnwg - 1);
                     tz[k] = q.cpart[(w * 2) * q.cstride + i]; ty[k] = q.cpart[(w * 2 + 1) * q.cstride + i];
                 }
 #pragma unroll
-                for (int k = 0; k < 8; ++k) { xz += w0 + k < q.cnwg ? tz[k] : 0.0; xy += w0 + k < q.cnwg ? ty[k] : 0.0; }
+                for (int k = 0; k < 8; ++k) { xz += w0 + 8 * k < q.cnwg ? tz[k] : 0.0; xy += w0 + 8 * k < q.cnwg ? ty[k] : 0.0; }
             }
+#pragma unroll
+            for (int m = 1; m < 8; m <<= 1) { xz += __shfl_xor(xz, m, 64); xy += __shfl_xor(xy, m, 64); }
+            if (sub != 0 || i0 + (int)(threadIdx.x >> 3) >= q.lp) continue;
             if (in.first) { xz = 0.0; xy = 0.0; }
             const double xzo = Xzo[i], xyo = Xyo[i];
             Xzc[i] = xz; Xyc[i] = xy;
