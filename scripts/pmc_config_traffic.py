@@ -18,10 +18,10 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LOOP = {
     "c3": (["wide_x_kernel", "wide_tail_kernel", "wide_rows_persist_kernel", "wide_ax_kernel", "wide_t_kernel", "wide_state_kernel"], ["lasso_wide.hip"]),
-    "c4": (["gemv_t_batch_kernel", "par_A_batch_resid_kernel", "gather_batch_kernel", "par_head_kernel", "par_pack_kernel", "par_z_kernel", "par_wb_"], ["padmm_lasso.hip", "gemv_kernels.h", "gather_kernels.h"]),
-    "c5lad": (["gemv_t_kernel<double", "reduce_partials_kernel<double", "dense_head_kernel", "dense_tail_kernel"], ["fadmm_dense.hip", "gemv_kernels.h"]),
+    "c4": (["gemv_t_batch_kernel", "par_A_batch_resid_kernel", "gather_batch_kernel", "par_head_kernel", "par_pack_kernel", "par_z_kernel", "par_wb_", "par_gather_fix_kernel"], ["padmm_lasso.hip", "gemv_kernels.h", "gather_kernels.h"]),
+    "c5lad": (["lad_rows_kernel", "gemv_t_kernel<double", "reduce_partials_kernel<double", "dense_head_kernel", "dense_tail_kernel"], ["fadmm_dense.hip", "gemv_kernels.h"]),
     "c5bp": (["gemv_t_kernel<double", "bp_gather_kernel", "dense_head_kernel", "dense_tail_kernel"], ["fadmm_dense.hip", "gemv_kernels.h", "gather_kernels.h"]),
-    "c5parbp": (["sbp_xreg_kernel", "sbp_list_kernel", "sbp_xact_kernel", "sbp_tail_kernel", "sbp_gs_", "gather_batch_kernel"], ["sharing_bp.hip", "gather_kernels.h"]),
+    "c5parbp": (["sbp_xreg_kernel", "sbp_xreg_screen_kernel", "sbp_list_kernel", "sbp_xact_kernel", "sbp_tail_kernel", "sbp_gs_", "gather_batch_kernel"], ["sharing_bp.hip", "gather_kernels.h"]),
     "dantzig": (["dz_head_kernel", "dz_mid_kernel", "dz_tail_kernel", "gemv_t_kernel<double", "reduce_partials_kernel<double"], ["dantzig.hip", "gemv_kernels.h"]),
 }
 
