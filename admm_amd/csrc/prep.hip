@@ -205,6 +205,74 @@ apply_std_kernel(T* __restrict__ X, long long ldx, T* __restrict__ Y, int n, int
     }
 }
 
+// The four steps above for one column in ONE launch (round 6; single process): the block narrows its column, keeps the sum, forms the
+// mean, the centred sum of squares, the scale, and applies them -- every thread re-reads only what it wrote itself (same indices in
+// every sweep), from the cache.  The statistics are the separate kernels' to the bit (same elements per thread in the same order, the
+// same block sum), so the data are bit-identical to the unfused path's (PREP_FUSED=0); HBM sees the input once and the output once
+// instead of seven sweeps.  Column p is y.  Rows [n, ldx) are zeroed here (no memset of the whole matrix).
+template <typename T>
+__global__ void __launch_bounds__(256)
+convert_standardize_kernel(const double* __restrict__ x, const double* __restrict__ y, long long ldin, int n, int p, int j0,
+                           T* __restrict__ X, T* __restrict__ Y, long long ldx, int flag, double n_total,
+                           T* __restrict__ mean_out, T* __restrict__ scale_out) {
+    __shared__ double scratch[4];
+    const int jl = blockIdx.x;                      // column of this launch's input block; j0 + jl: its number
+    const bool isy = y != nullptr;
+    const double* src = isy ? y : x + (size_t)jl * ldin;
+    T* dst = isy ? Y : X + (size_t)(j0 + jl) * ldx;
+    const int j = isy ? p : j0 + jl;
+    double s[1] = {0.0};
+    {   // eight requests in flight per thread; the additions keep their order
+        int i = threadIdx.x;
+        for (; i + 7 * 256 < n; i += 8 * 256) {
+            double v8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v8[u] = __builtin_nontemporal_load(src + i + u * 256);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const T v = (T)v8[u]; dst[i + u * 256] = v; s[0] += (double)v; }
+        }
+        for (; i < n; i += 256) { const T v = (T)src[i]; dst[i] = v; s[0] += (double)v; }
+    }
+    for (long long i = n + threadIdx.x; i < ldx; i += 256) dst[i] = T(0);
+    if (flag == 0) return;
+    block_sum<double, 1>(s, scratch);
+    const T m = (T)(s[0] / n_total);
+    double ss[1] = {0.0};
+    {
+        int i = threadIdx.x;
+        for (; i + 7 * 256 < n; i += 8 * 256) {
+            T v8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v8[u] = dst[i + u * 256];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const T c = v8[u] - m; ss[0] += (double)c * (double)c; }
+        }
+        for (; i < n; i += 256) { const T c = dst[i] - m; ss[0] += (double)c * (double)c; }
+    }
+    __syncthreads();                                // (scratch is reused)
+    block_sum<double, 1>(ss, scratch);
+    const T n_invsqrt = (T)(1.0 / sqrt((double)(T)n_total));
+    const T sc = (T)((T)sqrt(ss[0]) * n_invsqrt);
+    const T iv = (T)(1.0 / (double)sc);
+    const bool center = (flag & 2) != 0;
+    if (!isy) {
+        const T ivv = (flag & 1) ? iv : T(1);
+        for (int i = threadIdx.x; i < n; i += 256) {
+            T v = dst[i];
+            if (center) v = v - m;
+            if (flag & 1) v = v * ivv;
+            dst[i] = v;
+        }
+    } else {
+        for (int i = threadIdx.x; i < n; i += 256) {
+            T v = dst[i];
+            if (center) v = v - m;
+            dst[i] = v / sc;
+        }
+    }
+    if (threadIdx.x == 0) { mean_out[j] = m; scale_out[j] = sc; }
+}
+
 // ---- write_device (admm_internal.h): pinned staging ring + worker threads for the host-side copy
 namespace {
 struct H2DRing {
@@ -310,15 +378,29 @@ void upload_standardize(DeviceData<T>& d, const double* x, const double* y, int 
     d.ldx = round_up(n, 32);
     d.X.alloc((size_t)d.ldx * p);
     d.Y.alloc((size_t)d.ldx);
-    d.X.zero(st);
-    d.Y.zero(st);
+    // one launch per block of columns does everything (convert_standardize_kernel) unless the moments are global (several processes)
+    bool fused = !dist;
+    if (const char* e = option("PREP_FUSED")) fused = fused && std::string(e) != "0";
+    DevBuf<T> fmean, fscale;
+    if (fused) { fmean.alloc(p + 1); fscale.alloc(p + 1); }
+    if (!fused) { d.X.zero(st); d.Y.zero(st); }
     const int ny = std::max(1, std::min(64, (n + 255) / 256));
     double t0 = now_s();
     double th = 0;
+    auto convert_block = [&](const double* src, int c0, int nc) {       // columns [c0, c0 + nc) from a device block of nc columns
+        if (fused) hipLaunchKernelGGL((convert_standardize_kernel<T>), dim3(nc), dim3(256), 0, st, src, (const double*)nullptr, (long long)n, n, p, c0,
+                                      d.X.get(), d.Y.get(), d.ldx, d.flag, (double)n_total, fmean.get(), fscale.get());
+        else hipLaunchKernelGGL((convert_cols_kernel<T>), dim3(nc, ny), dim3(256), 0, st, src, (long long)n, n, d.X.get() + (size_t)c0 * d.ldx, d.ldx);
+    };
+    auto convert_y = [&](const double* src) {
+        if (fused) hipLaunchKernelGGL((convert_standardize_kernel<T>), dim3(1), dim3(256), 0, st, (const double*)nullptr, src, (long long)n, n, p, 0,
+                                      d.X.get(), d.Y.get(), d.ldx, d.flag, (double)n_total, fmean.get(), fscale.get());
+        else hipLaunchKernelGGL((convert_cols_kernel<T>), dim3(1, ny), dim3(256), 0, st, src, (long long)n, n, d.Y.get(), d.ldx);
+    };
     // ---- pass 0: narrow to T on the device
     if (mem == ADMM_MEM_DEVICE) {
-        hipLaunchKernelGGL((convert_cols_kernel<T>), dim3(p, ny), dim3(256), 0, st, x, (long long)n, n, d.X.get(), d.ldx);
-        hipLaunchKernelGGL((convert_cols_kernel<T>), dim3(1, ny), dim3(256), 0, st, y, (long long)n, n, d.Y.get(), d.ldx);
+        convert_block(x, 0, p);
+        convert_y(y);
     } else {
         // Host input (what R hands over): stream column chunks through two device staging buffers.
         const size_t chunk_bytes = (size_t)256 << 20;
@@ -336,8 +418,7 @@ void upload_standardize(DeviceData<T>& d, const double* x, const double* y, int 
             double t1 = now_s();
             write_device(stage[b].get(), x + (size_t)c0 * n, (size_t)nc * n * sizeof(double));
             th += now_s() - t1;
-            hipLaunchKernelGGL((convert_cols_kernel<T>), dim3(nc, ny), dim3(256), 0, st, stage[b].get(), (long long)n, n,
-                               d.X.get() + (size_t)c0 * d.ldx, d.ldx);
+            convert_block(stage[b].get(), c0, nc);
             ADMM_HIP_CHECK(hipEventRecord(ev[b].e, st));
             used[b] = true;
         }
@@ -345,13 +426,22 @@ void upload_standardize(DeviceData<T>& d, const double* x, const double* y, int 
         double t1 = now_s();
         write_device(ystage.get(), y, (size_t)n * sizeof(double));
         th += now_s() - t1;
-        hipLaunchKernelGGL((convert_cols_kernel<T>), dim3(1, ny), dim3(256), 0, st, ystage.get(), (long long)n, n, d.Y.get(), d.ldx);
+        convert_y(ystage.get());
         comm_stream_sync(st);
     }
     d.meanX.assign(p, T(0));
     d.scaleX.assign(p, T(1));
     d.meanY = T(0); d.scaleY = T(1);
-    if (d.flag != 0) {
+    if (d.flag != 0 && fused) {
+        const int cnt = p + 1;
+        std::vector<T> hm(cnt), hs(cnt);
+        ADMM_HIP_CHECK(hipMemcpyAsync(hm.data(), fmean.get(), cnt * sizeof(T), hipMemcpyDeviceToHost, st));
+        ADMM_HIP_CHECK(hipMemcpyAsync(hs.data(), fscale.get(), cnt * sizeof(T), hipMemcpyDeviceToHost, st));
+        comm_stream_sync(st);
+        if (d.flag & 2) { for (int j = 0; j < p; ++j) d.meanX[j] = hm[j]; d.meanY = hm[p]; }
+        if (d.flag & 1) for (int j = 0; j < p; ++j) d.scaleX[j] = hs[j];
+        d.scaleY = hs[p];
+    } else if (d.flag != 0) {
         const int cnt = p + 1;
         DevBuf<double> stat(cnt);
         DevBuf<T> mean(cnt), scale(cnt), inv(cnt);

@@ -208,3 +208,33 @@ def test_gather_matvec_vs_numpy(rows, cols, density, dtype):
     y2 = np.zeros(rows)
     _lib.check(lib.admm_hip_test_gather(A.ctypes.data, rows, cols, int(dtype == np.float64), v.ctypes.data, y2.ctypes.data_as(ctypes.POINTER(ctypes.c_double))))
     assert np.array_equal(y, y2)
+
+
+@pytest.mark.parametrize("kind,n,p", [("tall", 3000, 700), ("wide", 300, 2100), ("lad", 2600, 300), ("bp", 200, 900)])
+@pytest.mark.parametrize("flags", [(True, True), (True, False), (False, True), (False, False)])
+def test_fused_convert_and_standardise_is_bit_identical(kind, n, p, flags):
+    """Round 6: convert + column sums + means + centred sums of squares + scales + apply as ONE launch per block of columns
+    (prep.hip convert_standardize_kernel: every thread re-reads only what it wrote) against the separate sweeps (PREP_FUSED=0): the
+    statistics are formed from the same elements in the same order, so coefficients, iteration counts and the recovered intercepts are
+    identical to the bit -- float (tall / wide) and double (LAD / BP) data, every standardize / intercept combination, ragged n."""
+    from admm_amd import admm_bp, admm_lad, admm_lasso, options
+    standardize, intercept = flags
+    rng = np.random.default_rng(7 + n)
+    x = rng.standard_normal((n + 3, p)) * rng.uniform(0.1, 30.0, p) + rng.uniform(-5.0, 5.0, p)
+    b = np.zeros(p); b[:8] = rng.standard_normal(8)
+    y = x @ b + rng.standard_normal(n + 3) + 2.0
+    yb = x @ np.concatenate([rng.standard_normal(5), np.zeros(p - 5)])
+    out = {}
+    for fused in ("1", "0"):
+        with options(PREP_FUSED=fused):
+            if kind in ("tall", "wide"):
+                f = admm_lasso(x, y, intercept=intercept, standardize=standardize).penalty(nlambda=5, lambda_min_ratio=0.05).opts(maxit=300).fit()
+                out[fused] = (f.beta_dense, list(f.niter))
+            elif kind == "lad":
+                f = admm_lad(x, y, intercept=intercept).opts(maxit=60).fit()
+                out[fused] = (np.asarray(f.beta), [f.niter])
+            else:
+                f = admm_bp(x, yb).opts(maxit=60).fit()
+                out[fused] = (f.beta.toarray(), [f.niter])
+    assert out["1"][1] == out["0"][1]
+    assert np.array_equal(out["1"][0], out["0"][0])
