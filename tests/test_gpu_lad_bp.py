@@ -35,8 +35,8 @@ def test_lad_general_branch_vs_oracle(intercept):
 
 
 
-@pytest.mark.parametrize("n,p,maxit", [(3001, 60, 10000), (2600, 1100, 60), (4100, 2300, 30), (4300, 3300, 25), (5203, 4200, 25), (6200, 5300, 20), (12000, 6200, 12)])
-@pytest.mark.parametrize("onepass", ["1", "0"])
+@pytest.mark.parametrize("n,p,maxit,onepass", [(3001, 60, 10000, "1"), (2600, 1100, 60, "1"), (4100, 2300, 30, "1"), (4300, 3300, 25, "1"), (5203, 4200, 25, "1"),
+                                                 (6200, 5300, 20, "1"), (12000, 6200, 12, "1"), (3001, 60, 10000, "0"), (2600, 1100, 60, "0"), (4100, 2300, 30, "0")])
 def test_lad_one_pass_and_two_pass_forms_vs_oracle(n, p, maxit, onepass):
     """The general branch in both forms: round 6's one pass over the ROWS of X per iteration (lad_rows_kernel: x = X s, the prox, the dual
     and X'z_new, X'y_new from the same rows; X'vec from the p-vectors X'd, X'z, X'y) and the reference's two products (LAD_ONEPASS=0).
