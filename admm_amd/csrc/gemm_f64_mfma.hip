@@ -30,6 +30,7 @@ struct GemmNTd {
     int nbi, nbj, ntiles;
     int mirror;                          // LOWER mode: also store the transposed tile (both triangles)
     int kstart_row;                      // start the K loop at the tile's first row (A, B upper triangular)
+    int ksplit; long long cstride;       // > 1: blockIdx.y takes the y-th share of the K range and writes its own copy of C (C + y cstride): summed afterwards
     int kend_col;                        // B is LOWER triangular (B[j, k] = 0 for k > j): end the K loop after the tile's last column --
                                          //   the skipped products are exact zeros, the result is bit-identical, half the flops
 };
@@ -90,8 +91,14 @@ gemm_nt_mfma_f64_kernel(GemmNTd g) {
         *reinterpret_cast<double2*>(&lds[buf][1][s_row0 + 4][s_col]) = rb1;
     };
 
-    const int kbeg = g.kstart_row ? (max(I0, J0) / DK_BK) * DK_BK : 0;
-    const int kend = g.kend_col ? min(g.K, (J0 + DK_BM + DK_BK - 1) / DK_BK * DK_BK) : g.K;
+    int k_lo = 0, k_hi = g.K;
+    if (g.ksplit > 1) {                                     // (Gram only: neither triangular shortcut)
+        const int per_k = (g.K / DK_BK + g.ksplit - 1) / g.ksplit * DK_BK;
+        k_lo = min(g.K, (int)blockIdx.y * per_k); k_hi = min(g.K, k_lo + per_k);
+        g.C += (size_t)blockIdx.y * g.cstride;
+    }
+    const int kbeg = g.kstart_row ? (max(I0, J0) / DK_BK) * DK_BK : k_lo;
+    const int kend = g.kend_col ? min(g.K, (J0 + DK_BM + DK_BK - 1) / DK_BK * DK_BK) : k_hi;
     const int ntile_k = (kend - kbeg) / DK_BK;
     const int fk = lane >> 4, fi = lane & 15;            // A / B fragment: one f64 per lane, [i = lane & 15][k = lane >> 4]
     if (ntile_k > 0) {
@@ -198,9 +205,11 @@ gemm_nt_mfma_f64_kernel(GemmNTd g) {
 }
 
 static void launch_gemm_nt_f64(bool lower, const double* A, long long lda, const double* B, long long ldb, double* C, long long ldc,
-                               int M, int N, int K, double alpha, double beta, bool mirror, bool kstart_row, hipStream_t st, bool kend_col) {
+                               int M, int N, int K, double alpha, double beta, bool mirror, bool kstart_row, hipStream_t st, bool kend_col,
+                               int ksplit = 1, long long cstride = 0) {
     if (M <= 0 || N <= 0) return;
     GemmNTd g;
+    g.ksplit = ksplit; g.cstride = cstride;
     g.kend_col = kend_col && !lower ? 1 : 0;
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
     g.alpha = alpha; g.beta = beta; g.mirror = mirror ? 1 : 0; g.kstart_row = kstart_row ? 1 : 0;
@@ -208,7 +217,7 @@ static void launch_gemm_nt_f64(bool lower, const double* A, long long lda, const
     g.ntiles = lower ? g.nbi * (g.nbi + 1) / 2 : g.nbi * g.nbj;
     const int grid = (g.ntiles + 7) / 8 * 8;
     if (!mirror) {                                          // output tile handed over through LDS (whole column pieces); the mirrored store keeps the direct stores
-        if (lower) hipLaunchKernelGGL((gemm_nt_mfma_f64_kernel<1, 1>), dim3(grid), dim3(DK_THREADS), 0, st, g);
+        if (lower) hipLaunchKernelGGL((gemm_nt_mfma_f64_kernel<1, 1>), dim3(grid, ksplit), dim3(DK_THREADS), 0, st, g);
         else hipLaunchKernelGGL((gemm_nt_mfma_f64_kernel<0, 1>), dim3(grid), dim3(DK_THREADS), 0, st, g);
     } else if (lower) hipLaunchKernelGGL((gemm_nt_mfma_f64_kernel<1, 0>), dim3(grid), dim3(DK_THREADS), 0, st, g);
     else hipLaunchKernelGGL((gemm_nt_mfma_f64_kernel<0, 0>), dim3(grid), dim3(DK_THREADS), 0, st, g);
@@ -245,6 +254,19 @@ pad_copy_f64_kernel(const double* __restrict__ in, long long ldi, int rows, int 
 }
 
 // C (both triangles) = A'A (atA, C is cols x cols) or A A' (C is rows x rows), A rows x cols column-major.
+// out(i, j) = sum_s part[s](i, j) for i >= j, mirrored (both triangles)
+__global__ void __launch_bounds__(256) sum_splits_mirror_f64_kernel(const double* __restrict__ part, long long ldp, long long stride, int nsplit,
+                                                                    double* __restrict__ C, long long ldc, int m) {
+    const int j = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < m && i >= j) {
+        double v = 0.0;
+        for (int s = 0; s < nsplit; ++s) v += part[(size_t)s * stride + (size_t)j * ldp + i];
+        C[(size_t)j * ldc + i] = v;
+        C[(size_t)i * ldc + j] = v;
+    }
+}
+
 void gram_mfma_f64(const double* A, long long lda, int rows, int cols, bool atA, double* C, long long ldc, hipStream_t st) {
     const int M = atA ? cols : rows;          // order of C
     const int Kd = atA ? rows : cols;         // summation length
@@ -254,7 +276,29 @@ void gram_mfma_f64(const double* A, long long lda, int rows, int cols, bool atA,
     Z.zero(st);
     if (atA) hipLaunchKernelGGL((pad_copy_f64_kernel<true>), dim3((rows + 31) / 32, (cols + 31) / 32), dim3(256), 0, st, A, lda, rows, cols, Z.get(), ldz);
     else hipLaunchKernelGGL((pad_copy_f64_kernel<false>), dim3((rows + 31) / 32, (cols + 31) / 32), dim3(256), 0, st, A, lda, rows, cols, Z.get(), ldz);
-    launch_gemm_nt_f64(true, Z.get(), ldz, Z.get(), ldz, C, ldc, M, M, K, 1.0, 0.0, true, false, st, false);
+    // The lower triangle's 128 x 128 tiles rarely fill whole rounds of the chip's 2 x 256 resident workgroups (order 5000: 820 tiles = 1.6
+    // rounds, the second 60 % idle): the K range is cut into S shares inside ONE launch (tiles x S work items: S = 3 -> 4.8 rounds of a
+    // third each), every share into its own copy of C, summed in share order afterwards (deterministic).  S = 1 keeps the single sweep.
+    const int nb = (M + DK_BM - 1) / DK_BM;
+    const long long tiles = (long long)nb * (nb + 1) / 2, slots = 2LL * device_info().num_cu;
+    int S = 1;
+    double best = (double)((tiles + slots - 1) / slots);
+    for (int c = 2; c <= 4; ++c) {
+        if (K / c < 4096) break;
+        const double cost = (double)((tiles * c + slots - 1) / slots) / c;
+        if (cost < best * 0.93) { best = cost; S = c; }
+    }
+    if (const char* e = option("GRAM64_KSPLIT")) { const int v = std::atoi(e); if (v >= 1 && v <= 8) S = v; }
+    if (S == 1) {
+        launch_gemm_nt_f64(true, Z.get(), ldz, Z.get(), ldz, C, ldc, M, M, K, 1.0, 0.0, true, false, st, false);
+    } else {
+        const long long stride = ldz * ldz;
+        DevBuf<double> part((size_t)stride * S);
+        launch_gemm_nt_f64(true, Z.get(), ldz, Z.get(), ldz, part.get(), ldz, M, M, K, 1.0, 0.0, false, false, st, false, S, stride);
+        hipLaunchKernelGGL(sum_splits_mirror_f64_kernel, dim3((M + 255) / 256, M), dim3(256), 0, st, part.get(), ldz, stride, S, C, ldc, M);
+        ADMM_HIP_CHECK(hipGetLastError());
+        ADMM_HIP_CHECK(hipStreamSynchronize(st));
+    }
     ADMM_HIP_CHECK(hipGetLastError());
     ADMM_HIP_CHECK(hipStreamSynchronize(st));     // Z is freed on return
 }
