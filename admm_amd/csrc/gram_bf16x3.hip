@@ -547,7 +547,7 @@ void GramSplit3::split_cols(const float* X, long long ldx, int rows, int c0, int
 }
 
 static void launch_gram_b3(const GramSplit3& z, int ioff, int joff, float* C, long long ldc, int M, int N, bool lower, const int* tilemap, int ntiles_listed, hipStream_t st,
-                           bool big = false) {
+                           bool big = false, const int* tail = nullptr, int ntail = 0) {
     GramB3 g;
     const uint4* base = reinterpret_cast<const uint4*>(z.planes.get());
     const size_t pl = (size_t)z.nkg * z.ldz;
@@ -572,8 +572,15 @@ static void launch_gram_b3(const GramSplit3& z, int ioff, int joff, float* C, lo
     for (int kt = 0; kt < nkt; kt += per_launch) {
         g.kt0 = kt; g.kt1 = std::min(nkt, kt + per_launch);
         g.mirror = (lower && g.kt1 == nkt) ? 1 : 0;           // the mirrored store once, with the final values (it was written by every launch: 12 x 400 MB at C2)
-        if (big) hipLaunchKernelGGL(gram_split256_kernel, dim3((g.ntiles + 7) / 8 * 8), dim3(GB2_THREADS), 0, st, g);
-        else if (z.npl == 3) hipLaunchKernelGGL((gram_split_kernel<3>), dim3((g.ntiles + 7) / 8 * 8), dim3(GB_THREADS), 0, st, g);
+        if (big) {
+            hipLaunchKernelGGL(gram_split256_kernel, dim3((g.ntiles + 7) / 8 * 8), dim3(GB2_THREADS), 0, st, g);
+            if (ntail > 0) {                                   // the macro-tiles that would make a straggling round, as 128 x 128 tiles (same values)
+                GramB3 t = g;
+                t.nbi = (M + GB_BM - 1) / GB_BM; t.nbj = (N + GB_BM - 1) / GB_BM;
+                t.tilemap = tail; t.ntiles = ntail;
+                hipLaunchKernelGGL((gram_split_kernel<2>), dim3((ntail + 7) / 8 * 8), dim3(GB_THREADS), 0, st, t);
+            }
+        } else if (z.npl == 3) hipLaunchKernelGGL((gram_split_kernel<3>), dim3((g.ntiles + 7) / 8 * 8), dim3(GB_THREADS), 0, st, g);
         else hipLaunchKernelGGL((gram_split_kernel<2>), dim3((g.ntiles + 7) / 8 * 8), dim3(GB_THREADS), 0, st, g);
     }
 }
@@ -583,8 +590,8 @@ void GramSplit3::gram_lower(float* C, long long ldc, const int* tilemap, int nti
     launch_gram_b3(*this, 0, 0, C, ldc, M, M, true, tilemap, ntiles, st);
 }
 // the same with 256 x 256 macro-tiles (fp16 form only; `tilemap` lists 256-blocks): bit-identical to gram_lower
-void GramSplit3::gram_lower256(float* C, long long ldc, const int* tilemap, int ntiles, hipStream_t st) const {
-    launch_gram_b3(*this, 0, 0, C, ldc, M, M, true, tilemap, ntiles, st, true);
+void GramSplit3::gram_lower256(float* C, long long ldc, const int* tilemap, int ntiles, hipStream_t st, const int* tail, int ntail) const {
+    launch_gram_b3(*this, 0, 0, C, ldc, M, M, true, tilemap, ntiles, st, true, tail, ntail);
 }
 // block row: C[r0 : r0 + nr, 0 : r0 + nr] = Z[r0 : r0 + nr, :] Z[0 : r0 + nr, :]'  (r0 a multiple of 128)
 void GramSplit3::gram_rows(int r0, int nr, float* C, long long ldc, hipStream_t st) const {

@@ -56,7 +56,8 @@ struct GramSplit3 {
     void alloc(int order, int kdepth, hipStream_t st);
     void split_cols(const float* X, long long ldx, int rows, int c0, int nc, hipStream_t st);      // columns [c0, c0 + nc) of X (rows x nc at X)
     void gram_lower(float* C, long long ldc, const int* tilemap, int ntiles, hipStream_t st) const;
-    void gram_lower256(float* C, long long ldc, const int* tilemap, int ntiles, hipStream_t st) const;      // 256 x 256 macro-tiles (npl == 2), bit-identical
+    // 256 x 256 macro-tiles (npl == 2), bit-identical; tail / ntail: 128 x 128 tiles (bi << 16 | bj) dispatched after the macro-tiles of every launch (the round that would straggle)
+    void gram_lower256(float* C, long long ldc, const int* tilemap, int ntiles, hipStream_t st, const int* tail = nullptr, int ntail = 0) const;
     void gram_rows(int r0, int nr, float* C, long long ldc, hipStream_t st) const;
 };
 int gram_split_mode();                  // 2 (default) / 3 / 0 = the exact-fp32 matrix-core kernel (syrk_mfma.hip) as before: ADMM_HIP_GRAM_SPLIT=f16x2 | bf16x3 | 0

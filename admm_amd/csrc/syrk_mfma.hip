@@ -468,9 +468,30 @@ void gram_mfma_f32(const float* A, long long lda, int rows, int cols, bool atA, 
         bool big = z3.npl == 2;
         if (const char* e = option("GRAM_B3_TILE")) big = big && std::atoi(e) != 128;
         if (big) {
+            // One macro-tile workgroup is resident per CU: T macro-tiles take ceil(T / CUs) rounds (p = 10^4: 820 on 256 CUs, the fourth round
+            // a fifth full).  Whole rounds of macro-tiles; the rest -- taken evenly from the back of the 8 XCD lists -- as 128 x 128 tiles after
+            // them (four per CU are resident: one short round).  GRAM_B3_TAIL=0: every tile a macro-tile.
             const int nb2 = (M + 255) / 256;
-            DevBuf<int> tmap = make_square_tilemap(nb2, st);
-            z3.gram_lower256(C, ldc, tmap.get(), nb2 * (nb2 + 1) / 2, st);
+            std::vector<std::vector<int>> q = square_tile_lists(nb2);
+            size_t total = 0;
+            for (const auto& l : q) total += l.size();
+            const size_t slots = (size_t)device_info().num_cu;
+            size_t cut = total > slots ? total % slots : 0;
+            if (const char* e = option("GRAM_B3_TAIL")) { if (std::atoi(e) == 0) cut = 0; }
+            if (cut * 4 > slots * 3) cut = 0;                     // a last round three quarters full is left alone
+            std::vector<int> tail;
+            auto longest = [&]() { int x = 0; for (int k = 1; k < 8; ++k) if (q[k].size() > q[x].size()) x = k; return x; };
+            for (; cut > 0; --cut) {
+                const int x = longest();
+                const int m = q[x].back(); q[x].pop_back();
+                const int bi = m >> 16, bj = m & 0xffff;
+                for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b)
+                    if (2 * bi + a >= 2 * bj + b && 2 * bi + a < nb) tail.push_back((2 * bi + a) << 16 | (2 * bj + b));
+            }
+            std::vector<int> order;
+            for (int x = 0; x < 8; ++x) for (int v : q[x]) order.push_back(v);
+            DevBuf<int> tmap = upload_ints(order, st), ttail = upload_ints(tail, st);
+            z3.gram_lower256(C, ldc, tmap.get(), (int)order.size(), st, ttail.get(), (int)tail.size());
         } else {
             DevBuf<int> tmap = make_square_tilemap(nb, st);
             z3.gram_lower(C, ldc, tmap.get(), ntiles, st);      // (round 6 A/B: the plain row-major triangle order 35.8 against 34.7 ms)
